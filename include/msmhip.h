@@ -1,0 +1,218 @@
+/*
+ * msmhip.h -- C ABI of libmsmhip: the MI355X (gfx950) implementation of newMSM's data-parallel hot
+ * path (octree nearest-triangle search + barycentric / adaptive-barycentric resampling, and the
+ * discrete unary / pairwise / triplet label-cost evaluation).
+ *
+ * Every entry point names the reference interface it replaces (paths under
+ * /root/reference/libraries/: R/ = msm-newresampler/src, M/ = msm-newmeshreg/src,
+ * I/ = msm-newmeshreg/include).  INTEGRATION.md shows the binding a newMSM maintainer would add.
+ *
+ * Conventions
+ *  - plain C types only; all arrays are caller-owned HOST memory unless a name ends in _dev;
+ *  - point sets are SoA: xyz = x[0..N) y[0..N) z[0..N) (3 x N doubles); triangle lists are
+ *    3 x T int32 (first, second, third vertex rows); feature matrices are D x V row-major doubles
+ *    (the reference's pvalues[dim][vertex], R/mesh.h:45);
+ *  - every function returning int returns MSM_OK (0) or a negative MSM_ERR_* code; the message is
+ *    available from msm_last_error() (thread-local).  No exception crosses this boundary;
+ *  - handles are opaque; a handle belongs to one context (one GPU, one HIP stream); calls on one
+ *    context must be serialised by the caller (the reference's OpenMP loops become one launch);
+ *  - functions marked [host] need no GPU and may be called on a machine without one.  Everything
+ *    else fails with MSM_ERR_NOGPU when no device is present: there is no CPU fallback.
+ */
+#ifndef MSMHIP_H
+#define MSMHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MSM_ABI_VERSION 1
+
+#define MSM_OK 0
+#define MSM_ERR_INVALID (-1)  /* bad argument / inconsistent sizes */
+#define MSM_ERR_HIP (-2)      /* HIP runtime failure */
+#define MSM_ERR_OUTSIDE (-3)  /* "Point is not in the bounding box of the mesh", R/octree.cpp:158 */
+#define MSM_ERR_NOTFOUND (-4) /* "Error in octree. ... too distorted mesh face", R/octree.cpp:210 */
+#define MSM_ERR_NOGPU (-5)    /* no gfx950 device / extension unusable */
+#define MSM_ERR_STATE (-6)    /* call order violated (e.g. cost evaluated before get_source_data) */
+#define MSM_ERR_CAPACITY (-7) /* caller buffer too small */
+#define MSM_ERR_ROTATION (-8) /* "rotation angle is greater than 90 degrees", R/point.cpp:112 */
+
+#define MSM_RAD 100.0    /* R/point.h:32 */
+#define MSM_FOLDING 1e7  /* M/reg_tools.h:30 */
+
+typedef struct msm_ctx msm_ctx;
+typedef struct msm_mesh msm_mesh;
+typedef struct msm_cost msm_cost;
+
+/* ------------------------------------------------------------------------------------------------
+ * library
+ * ---------------------------------------------------------------------------------------------- */
+int         msm_abi_version(void);                 /* [host] */
+const char *msm_last_error(void);                  /* [host] message of the last failing call on this thread */
+int         msm_device_count(void);                /* [host] number of visible HIP devices (0 when none) */
+
+/* ------------------------------------------------------------------------------------------------
+ * [host] mesh utilities the reference keeps in R/mesh.cpp and M/DiscreteModel.cpp.  They produce
+ * the inputs of the device path (numbering is observable in outputs, so they reproduce the
+ * reference's vertex / triangle / neighbour order exactly).
+ * ---------------------------------------------------------------------------------------------- */
+/* vertex and triangle count of make_mesh_from_icosa(order); Mesh::get_resolution R/mesh.cpp:810-830 */
+int msm_icosphere_counts(int order, int32_t *V, int32_t *T);
+/* make_mesh_from_icosa(order) R/mesh.cpp:1111-1196 followed by true_rescale(radius) :1210-1219
+ * (radius <= 0: keep the unit sphere).  Same vertex and triangle numbering as the reference. */
+int msm_icosphere(int order, double radius, double *xyz, int32_t *tri);
+/* Mpoint::nID / trID lists in Mesh::push_triangle order, R/mesh.cpp:115-134, as CSR.
+ * nbr / tid may be NULL to size: nbr_ptr[V] / tid_ptr[V] give the lengths. */
+int msm_mesh_adjacency(const int32_t *tri, int32_t V, int32_t T, int32_t *nbr_ptr, int32_t *nbr, int32_t *tid_ptr, int32_t *tid);
+/* per-vertex mean adjacent triangle area: compute_vertex_area R/mesh.cpp:1275-1283 with the
+ * triangle areas taken from the given coordinates (Triangle::calc_area R/triangle.cpp:52-55) */
+int msm_vertex_areas(const double *xyz, const int32_t *tri, int32_t V, int32_t T, double *area);
+/* NonLinearSRegDiscreteModel::Initialize M/DiscreteModel.cpp:72-89: per control point the largest
+ * geodesic distance to a neighbour, and Mesh::calculate_MaxVD R/mesh.cpp:263-277 */
+int msm_cp_spacings(const double *xyz, const int32_t *tri, int32_t V, int32_t T, double *maxsep, double *mvdmax);
+/* Initialize_sampling_grid + label_sampling_grid M/DiscreteModel.cpp:110-190 on the icosphere of
+ * order sg_order (radius 100).  samples / barycentres: 3 x cap SoA, entry 0 is the centre.
+ * abs_is_int != 0 selects the int abs() overload the reference may bind at :170 (SURVEY hard parts). */
+int msm_label_sampling_grid(int sg_order, double max_dist, int abs_is_int, int32_t cap,
+                            double *samples, int32_t *nsamples, double *barycentres, int32_t *nbarycentres);
+/* rescale_sampling_grid M/DiscreteModel.cpp:192-214; *scale is read and updated (x0.8) */
+int msm_rescale_sampling_grid(const double *samples, int32_t n, double *scale, double *labels);
+/* estimate_rotation_matrix R/point.cpp:97-152, row-major 3x3 */
+int msm_rotation_matrix(const double ci[3], const double index[3], double R[9]);
+/* get_rotations M/DiscreteModel.cpp:310-319: rot[9*k..] = R(centre -> cp[k]) row-major */
+int msm_cp_rotations(const double centre[3], const double *cp_xyz, int32_t N, double *rot);
+/* estimate_triplets M/DiscreteModel.cpp:291-308 (triplets: 3 per triangle, ascending, AoS T x 3 as
+ * the optimisers expect) and estimate_pairs :271-289 (pairs may be NULL to count; returns count) */
+int msm_estimate_triplets(const int32_t *tri, int32_t T, int32_t *triplets);
+int msm_estimate_pairs(const int32_t *tri, int32_t V, int32_t T, int32_t *pairs);
+
+/* ------------------------------------------------------------------------------------------------
+ * context: one per GPU
+ * ---------------------------------------------------------------------------------------------- */
+msm_ctx *msm_ctx_create(int device);                         /* owns a new non-blocking HIP stream */
+msm_ctx *msm_ctx_create_on_stream(int device, void *hip_stream); /* launches on the caller's stream */
+void     msm_ctx_destroy(msm_ctx *ctx);
+int      msm_ctx_synchronize(msm_ctx *ctx);
+void    *msm_ctx_stream(msm_ctx *ctx);                        /* hipStream_t, for event timing */
+
+/* ------------------------------------------------------------------------------------------------
+ * mesh + search structure.  Replaces newresampler::Mesh (coords/triangles/pvalues) as seen by the
+ * hot path and newresampler::Octree(const Mesh&) R/octree.h:48-52, R/octree.cpp:31-141.  The
+ * octree is built on first use and rebuilt after msm_mesh_update_coords (the reference constructs a
+ * new Octree per call site).
+ * ---------------------------------------------------------------------------------------------- */
+msm_mesh *msm_mesh_create(msm_ctx *ctx, const double *xyz, int32_t V, const int32_t *tri, int32_t T);
+void      msm_mesh_destroy(msm_mesh *m);
+int       msm_mesh_update_coords(msm_mesh *m, const double *xyz);   /* Mesh::set_coord for all vertices */
+int       msm_mesh_get_coords(msm_mesh *m, double *xyz);
+int       msm_mesh_set_features(msm_mesh *m, const double *feat, int32_t D); /* Mesh::set_pvalues */
+int       msm_mesh_sizes(const msm_mesh *m, int32_t *V, int32_t *T, int32_t *D);
+/* [host part] stats[0]=nodes [1]=leaves [2]=max depth (root 0) [3]=triangle references [4]=largest leaf */
+int       msm_mesh_octree_stats(msm_mesh *m, int64_t stats[5]);
+
+/* ------------------------------------------------------------------------------------------------
+ * resampler (R/resampler.h:38-53)
+ * ---------------------------------------------------------------------------------------------- */
+#define MSM_WEIGHTS_PROJECTED 0 /* calc_barycentric_weights R/triangle.cpp:124-143 (query ray-projected) */
+#define MSM_WEIGHTS_RAW 1       /* the area ratios inside barycentric_interpolation :145-157 (query as given) */
+/* Octree::get_closest_triangle R/octree.cpp:156-214 for N points + Resampler::get_barycentric_weights
+ * R/resampler.cpp:142-167.  tri_id[N]; v_id 3 x N (triangle vertex order); w 3 x N.  Any output may be NULL.
+ * A failing query yields tri_id < 0 (MSM_ERR_OUTSIDE / MSM_ERR_NOTFOUND) and the call returns the first such code. */
+int msm_query_triangles(msm_mesh *target, const double *q_xyz, int32_t N, int32_t *tri_id, int32_t *v_id, double *w, int weight_mode);
+/* Octree::get_closest_vertex_ID R/octree.cpp:216-233 */
+int msm_closest_vertex(msm_mesh *target, const double *q_xyz, int32_t N, int32_t *v_id);
+/* Resampler::get_adaptive_barycentric_weights R/resampler.cpp:72-140 as CSR (rows = vertices of new_mesh,
+ * columns ascending = std::map order).  excl (length V of in_mesh) may be NULL.  Vertex areas are taken
+ * from the meshes' current coordinates.  Call with col == NULL to obtain *nnz only. */
+int msm_adaptive_barycentric_weights(msm_mesh *in_mesh, msm_mesh *new_mesh, const double *excl,
+                                     int32_t *row_ptr, int32_t *col, double *val, int64_t cap, int64_t *nnz);
+/* metric_resample R/resampler.cpp:304-309 (= barycentric_data_interpolation :30-70, no exclusion mask):
+ * data D x V(in_mesh) -> out D x V(new_mesh) */
+int msm_metric_resample(msm_mesh *in_mesh, const double *data, int32_t D, msm_mesh *new_mesh, double *out);
+/* sphere_project_warp R/resampler.cpp:311-328: sphere (3 x N, in/out) is carried through from -> to_xyz (3 x V(from)) */
+int msm_sphere_project_warp(msm_mesh *from, const double *to_xyz, double *sphere_xyz, int32_t N);
+/* surface_resample :284-302 / project_anatomical_mesh :260-282 core: out = sum_j w_j * coords[v_j] for the
+ * barycentric weights of q against `from` (no renormalisation); coords 3 x V(from), out 3 x N */
+int msm_barycentric_coords_resample(msm_mesh *from, const double *coords_xyz, const double *q_xyz, int32_t N, double *out_xyz);
+/* nearest_neighbour_interpolation R/resampler.cpp:232-258 without exclusion: data D x V(orig) -> out D x N */
+int msm_nearest_neighbour(msm_mesh *orig, const double *data, int32_t D, const double *q_xyz, int32_t N, double *out);
+
+/* ------------------------------------------------------------------------------------------------
+ * discrete cost function.  Replaces NonLinearSRegDiscreteCostFunction and its five subclasses
+ * (M/DiscreteCostFunction.h:83-283) behind the DiscreteCostFunction evaluator interface
+ * (M/DiscreteCostFunction.h:41-59) the optimisers call.
+ * ---------------------------------------------------------------------------------------------- */
+#define MSM_COST_UNIVARIATE 0      /* UnivariateNonLinearSRegDiscreteCostFunction */
+#define MSM_COST_MULTIVARIATE 1    /* MultivariateNonLinearSRegDiscreteCostFunction */
+#define MSM_COST_PATCHWISE 2       /* PatchwiseMultivariateNonLinearSRegDiscreteCostFunction */
+#define MSM_COST_HO_UNIVARIATE 3   /* HOUnivariateNonLinearSRegDiscreteCostFunction (--triclique) */
+#define MSM_COST_HO_MULTIVARIATE 4 /* HOMultivariateNonLinearSRegDiscreteCostFunction */
+
+typedef struct msm_cost_params { /* set_parameters M/DiscreteCostFunction.cpp:119-133 */
+    int32_t kind;        /* MSM_COST_* (chosen in initialize_cost_function M/DiscreteModel.cpp:43-61) */
+    int32_t simmeasure;  /* "simmeasure": 1 SSD, 2 correlation (4/5 DICE are not offloaded) */
+    int32_t rmode;       /* "regularisermode": 1 pairwise angle, 2/3 triangle strain */
+    int32_t reserved;
+    double  lambda;      /* "lambda" */
+    double  mu;          /* "shearmodulus" */
+    double  kappa;       /* "bulkmodulus" */
+    double  k_exp;       /* "kexponent" */
+    double  rexp;        /* "exponent" */
+    double  range;       /* "range" (_controlptrange) */
+} msm_cost_params;
+
+msm_cost *msm_cost_create(msm_ctx *ctx, const msm_cost_params *params);
+void      msm_cost_destroy(msm_cost *c);
+/* set_meshes M/DiscreteCostFunction.h:196-198: captures _ORIG (source coords) and _oCPgrid */
+int msm_cost_set_meshes(msm_cost *c, msm_mesh *target, msm_mesh *source, msm_mesh *cpgrid);
+/* reset_source :208 / reset_CPgrid :209: pick up the meshes' current coordinates */
+int msm_cost_reset_source(msm_cost *c, msm_mesh *source);
+int msm_cost_reset_cpgrid(msm_cost *c, msm_mesh *cpgrid);
+/* set_featurespace :203-205: input (moving) features D x V(source); reference features are the
+ * target mesh's features (msm_mesh_set_features) */
+int msm_cost_set_source_features(msm_cost *c, const double *feat, int32_t D);
+/* set_dataaffintyweighting :165: rows x V(source), rows == 1 or D; NULL = all ones (M/mesh_registration.cpp:234-238) */
+int msm_cost_set_cfweight(msm_cost *c, const double *w, int32_t rows);
+/* set_spacings :207 */
+int msm_cost_set_spacings(msm_cost *c, const double *maxsep, double mvdmax);
+/* set_labels :199-202: labels 3 x L SoA, rot 9 per control point (row-major) */
+int msm_cost_set_labels(msm_cost *c, const double *labels, int32_t L, const double *rot);
+/* setTriplets / setPairs M/DiscreteCostFunction.h:44-45 (AoS, node ids ascending within a clique) */
+int msm_cost_set_triplets(msm_cost *c, const int32_t *triplets, int32_t T);
+int msm_cost_set_pairs(msm_cost *c, const int32_t *pairs, int32_t P);
+/* initialize() + get_source_data(): Univariate M/DiscreteCostFunction.cpp:334-351, Multivariate :393-416,
+ * Patchwise :629-650 (range test per control point), HO :468-485 / :541-563 (bin by closest CP triangle),
+ * then resample_weights :303-323 */
+int msm_cost_get_source_data(msm_cost *c);
+/* _sourceinrange as CSR: ptr[groups+1], idx[ptr[groups]]; idx may be NULL to size */
+int msm_cost_patches(msm_cost *c, int32_t *ngroups, int32_t *ptr, int32_t *idx, int64_t cap);
+int msm_cost_absolute_weights(msm_cost *c, double *absw /* N */);
+/* computeUnaryCosts M/DiscreteCostFunction.cpp:236-243: U[label * N + node] (the layout FastPD and MCMC read,
+ * I/FastPD/FastPD.h:126, M/mcmc_opt.h:59).  _async only enqueues on the context's stream; _fetch copies back. */
+int msm_cost_unary_table(msm_cost *c, double *U);
+int msm_cost_unary_table_async(msm_cost *c);
+int msm_cost_unary_table_fetch(msm_cost *c, double *U);
+/* computeUnaryCost(node,label) :378 for a list of (node,label) queries (Fusion's per-label sweep, I/Fusion/Fusion.h:148-155) */
+int msm_cost_unary_batch(msm_cost *c, const int32_t *nodes, const int32_t *labels, int32_t n, double *out);
+/* computeTripletCost M/DiscreteCostFunction.cpp:135-188 for n (triplet, labelA, labelB, labelC) queries */
+int msm_cost_triplet_batch(msm_cost *c, const int32_t *triplet, const int32_t *la, const int32_t *lb, const int32_t *lc, int32_t n, double *out);
+/* the 8 costs per triplet of one fusion move, I/Fusion/Fusion.h:181-196: E[8*t + k], k = 000..111 with bit
+ * order (A,B,C) and 0 = current labeling, 1 = `label` */
+int msm_cost_triplet_octets(msm_cost *c, const int32_t *labeling, int32_t label, double *E);
+/* computePairwiseCost :190-226 for n (pair, labelA, labelB) queries, and the full table of
+ * computePairwiseCosts :228-234: paircosts[(pair*L + labelB)*L + labelA] */
+int msm_cost_pairwise_batch(msm_cost *c, const int32_t *pair, const int32_t *la, const int32_t *lb, int32_t n, double *out);
+int msm_cost_pairwise_table(msm_cost *c, double *paircosts);
+/* evaluateTotalCostSum :55-77: parts = {unary, pairwise, triplet} sums in the reference's serial order */
+int msm_cost_total(msm_cost *c, const int32_t *labeling, double *total, double parts[3]);
+/* counters since creation: [0] point samples (rotate + nearest triangle + interpolate), [1] unary evals,
+ * [2] triplet evals, [3] pairwise evals */
+int msm_cost_counters(msm_cost *c, int64_t counters[4]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MSMHIP_H */

@@ -1,0 +1,119 @@
+"""Loader for libmsmhip.so (the C ABI declared in include/msmhip.h).
+
+There is no Python or CPU fallback: if the shared library is missing the import fails loudly, and
+every device entry point fails with MSM_ERR_NOGPU on a machine without a GPU.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmsmhip.so")
+
+c_dp = C.POINTER(C.c_double)
+c_ip = C.POINTER(C.c_int32)
+c_lp = C.POINTER(C.c_int64)
+
+MSM_OK = 0
+ERR_NAMES = {-1: "MSM_ERR_INVALID", -2: "MSM_ERR_HIP", -3: "MSM_ERR_OUTSIDE", -4: "MSM_ERR_NOTFOUND", -5: "MSM_ERR_NOGPU",
+             -6: "MSM_ERR_STATE", -7: "MSM_ERR_CAPACITY", -8: "MSM_ERR_ROTATION"}
+
+
+class MsmError(RuntimeError):
+    """Raised for any non-zero status of the C ABI (the reference throws MeshException / MeshregException)."""
+
+    def __init__(self, code, message):
+        super().__init__("%s (%d): %s" % (ERR_NAMES.get(code, "MSM_ERR"), code, message))
+        self.code = code
+
+
+class CostParams(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("simmeasure", C.c_int32), ("rmode", C.c_int32), ("reserved", C.c_int32),
+                ("lambda_", C.c_double), ("mu", C.c_double), ("kappa", C.c_double), ("k_exp", C.c_double),
+                ("rexp", C.c_double), ("range", C.c_double)]
+
+
+# name -> (restype, argtypes); mirrors include/msmhip.h one to one
+_VP = C.c_void_p
+SIGNATURES = {
+    "msm_abi_version": (C.c_int, []),
+    "msm_last_error": (C.c_char_p, []),
+    "msm_device_count": (C.c_int, []),
+    "msm_icosphere_counts": (C.c_int, [C.c_int, c_ip, c_ip]),
+    "msm_icosphere": (C.c_int, [C.c_int, C.c_double, c_dp, c_ip]),
+    "msm_mesh_adjacency": (C.c_int, [c_ip, C.c_int32, C.c_int32, c_ip, c_ip, c_ip, c_ip]),
+    "msm_vertex_areas": (C.c_int, [c_dp, c_ip, C.c_int32, C.c_int32, c_dp]),
+    "msm_cp_spacings": (C.c_int, [c_dp, c_ip, C.c_int32, C.c_int32, c_dp, c_dp]),
+    "msm_label_sampling_grid": (C.c_int, [C.c_int, C.c_double, C.c_int, C.c_int32, c_dp, c_ip, c_dp, c_ip]),
+    "msm_rescale_sampling_grid": (C.c_int, [c_dp, C.c_int32, c_dp, c_dp]),
+    "msm_rotation_matrix": (C.c_int, [c_dp, c_dp, c_dp]),
+    "msm_cp_rotations": (C.c_int, [c_dp, c_dp, C.c_int32, c_dp]),
+    "msm_estimate_triplets": (C.c_int, [c_ip, C.c_int32, c_ip]),
+    "msm_estimate_pairs": (C.c_int, [c_ip, C.c_int32, C.c_int32, c_ip]),
+    "msm_ctx_create": (_VP, [C.c_int]),
+    "msm_ctx_create_on_stream": (_VP, [C.c_int, _VP]),
+    "msm_ctx_destroy": (None, [_VP]),
+    "msm_ctx_synchronize": (C.c_int, [_VP]),
+    "msm_ctx_stream": (_VP, [_VP]),
+    "msm_mesh_create": (_VP, [_VP, c_dp, C.c_int32, c_ip, C.c_int32]),
+    "msm_mesh_destroy": (None, [_VP]),
+    "msm_mesh_update_coords": (C.c_int, [_VP, c_dp]),
+    "msm_mesh_get_coords": (C.c_int, [_VP, c_dp]),
+    "msm_mesh_set_features": (C.c_int, [_VP, c_dp, C.c_int32]),
+    "msm_mesh_sizes": (C.c_int, [_VP, c_ip, c_ip, c_ip]),
+    "msm_mesh_octree_stats": (C.c_int, [_VP, c_lp]),
+    "msm_query_triangles": (C.c_int, [_VP, c_dp, C.c_int32, c_ip, c_ip, c_dp, C.c_int]),
+    "msm_closest_vertex": (C.c_int, [_VP, c_dp, C.c_int32, c_ip]),
+    "msm_adaptive_barycentric_weights": (C.c_int, [_VP, _VP, c_dp, c_ip, c_ip, c_dp, C.c_int64, c_lp]),
+    "msm_metric_resample": (C.c_int, [_VP, c_dp, C.c_int32, _VP, c_dp]),
+    "msm_sphere_project_warp": (C.c_int, [_VP, c_dp, c_dp, C.c_int32]),
+    "msm_barycentric_coords_resample": (C.c_int, [_VP, c_dp, c_dp, C.c_int32, c_dp]),
+    "msm_nearest_neighbour": (C.c_int, [_VP, c_dp, C.c_int32, c_dp, C.c_int32, c_dp]),
+    "msm_cost_create": (_VP, [_VP, C.POINTER(CostParams)]),
+    "msm_cost_destroy": (None, [_VP]),
+    "msm_cost_set_meshes": (C.c_int, [_VP, _VP, _VP, _VP]),
+    "msm_cost_reset_source": (C.c_int, [_VP, _VP]),
+    "msm_cost_reset_cpgrid": (C.c_int, [_VP, _VP]),
+    "msm_cost_set_source_features": (C.c_int, [_VP, c_dp, C.c_int32]),
+    "msm_cost_set_cfweight": (C.c_int, [_VP, c_dp, C.c_int32]),
+    "msm_cost_set_spacings": (C.c_int, [_VP, c_dp, C.c_double]),
+    "msm_cost_set_labels": (C.c_int, [_VP, c_dp, C.c_int32, c_dp]),
+    "msm_cost_set_triplets": (C.c_int, [_VP, c_ip, C.c_int32]),
+    "msm_cost_set_pairs": (C.c_int, [_VP, c_ip, C.c_int32]),
+    "msm_cost_get_source_data": (C.c_int, [_VP]),
+    "msm_cost_patches": (C.c_int, [_VP, c_ip, c_ip, c_ip, C.c_int64]),
+    "msm_cost_absolute_weights": (C.c_int, [_VP, c_dp]),
+    "msm_cost_unary_table": (C.c_int, [_VP, c_dp]),
+    "msm_cost_unary_table_async": (C.c_int, [_VP]),
+    "msm_cost_unary_table_fetch": (C.c_int, [_VP, c_dp]),
+    "msm_cost_unary_batch": (C.c_int, [_VP, c_ip, c_ip, C.c_int32, c_dp]),
+    "msm_cost_triplet_batch": (C.c_int, [_VP, c_ip, c_ip, c_ip, c_ip, C.c_int32, c_dp]),
+    "msm_cost_triplet_octets": (C.c_int, [_VP, c_ip, C.c_int32, c_dp]),
+    "msm_cost_pairwise_batch": (C.c_int, [_VP, c_ip, c_ip, c_ip, C.c_int32, c_dp]),
+    "msm_cost_pairwise_table": (C.c_int, [_VP, c_dp]),
+    "msm_cost_total": (C.c_int, [_VP, c_ip, c_dp, c_dp]),
+    "msm_cost_counters": (C.c_int, [_VP, c_lp]),
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded library.  Raises ImportError when libmsmhip.so has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("newmsm_amd: %s is missing -- run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(hipcc --offload-arch=gfx950). There is no fallback path." % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError = header / library mismatch: fail loudly
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(status):
+    if status != MSM_OK:
+        raise MsmError(status, lib().msm_last_error().decode("utf-8", "replace"))
+    return status

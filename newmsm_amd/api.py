@@ -1,0 +1,410 @@
+"""Thin Python mirror of the reference's C++ interfaces on top of the libmsmhip C ABI.
+
+Names follow newMSM: Mesh / Octree queries and the free functions of resampler.h
+(/root/reference/libraries/msm-newresampler/src/resampler.h:38-53), and the evaluator interface of
+DiscreteCostFunction (/root/reference/libraries/msm-newmeshreg/src/DiscreteCostFunction.h:41-59,
+:161-209).  Points are (N,3) numpy arrays here; the ABI's 3 x N SoA layout is produced at the boundary.
+This module is plumbing for tests and bench.py -- all computation happens in libmsmhip.so.
+"""
+import ctypes as C
+
+import numpy as np
+
+from ._lib import CostParams, MsmError, c_dp, c_ip, c_lp, check, lib
+
+WEIGHTS_PROJECTED = 0
+WEIGHTS_RAW = 1
+KINDS = dict(univariate=0, multivariate=1, patchwise=2, ho_univariate=3, ho_multivariate=4)
+
+
+def _soa(points):
+    """(N,3) -> contiguous 3 x N"""
+    a = np.ascontiguousarray(np.asarray(points, dtype=np.float64).reshape(-1, 3).T)
+    return a, a.ctypes.data_as(c_dp)
+
+
+def _aos(soa, n):
+    return np.ascontiguousarray(np.asarray(soa).reshape(3, n).T)
+
+
+def _tri_soa(tri):
+    a = np.ascontiguousarray(np.asarray(tri, dtype=np.int32).reshape(-1, 3).T)
+    return a, a.ctypes.data_as(c_ip)
+
+
+def _d(a):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return a, a.ctypes.data_as(c_dp)
+
+
+def _i(a):
+    a = np.ascontiguousarray(a, dtype=np.int32)
+    return a, a.ctypes.data_as(c_ip)
+
+
+# ------------------------------------------------------------------ host helpers
+def device_count():
+    return lib().msm_device_count()
+
+
+def icosphere_counts(order):
+    v, t = C.c_int32(), C.c_int32()
+    check(lib().msm_icosphere_counts(order, C.byref(v), C.byref(t)))
+    return v.value, t.value
+
+
+def make_mesh_from_icosa(order, radius=100.0):
+    """make_mesh_from_icosa(order) + true_rescale(radius). Returns (xyz[V,3], tri[T,3])."""
+    V, T = icosphere_counts(order)
+    xyz = np.zeros((3, V))
+    tri = np.zeros((3, T), dtype=np.int32)
+    check(lib().msm_icosphere(order, float(radius if radius else 0.0), xyz.ctypes.data_as(c_dp), tri.ctypes.data_as(c_ip)))
+    return np.ascontiguousarray(xyz.T), np.ascontiguousarray(tri.T)
+
+
+def mesh_adjacency(tri, V):
+    t, pt = _tri_soa(tri)
+    T = t.shape[1]
+    nbr_ptr = np.zeros(V + 1, dtype=np.int32)
+    tid_ptr = np.zeros(V + 1, dtype=np.int32)
+    check(lib().msm_mesh_adjacency(pt, V, T, nbr_ptr.ctypes.data_as(c_ip), None, tid_ptr.ctypes.data_as(c_ip), None))
+    nbr = np.zeros(nbr_ptr[-1], dtype=np.int32)
+    tid = np.zeros(tid_ptr[-1], dtype=np.int32)
+    check(lib().msm_mesh_adjacency(pt, V, T, nbr_ptr.ctypes.data_as(c_ip), nbr.ctypes.data_as(c_ip), tid_ptr.ctypes.data_as(c_ip),
+                                   tid.ctypes.data_as(c_ip)))
+    return nbr_ptr, nbr, tid_ptr, tid
+
+
+def vertex_areas(xyz, tri):
+    x, px = _soa(xyz)
+    t, pt = _tri_soa(tri)
+    out = np.zeros(x.shape[1])
+    check(lib().msm_vertex_areas(px, pt, x.shape[1], t.shape[1], out.ctypes.data_as(c_dp)))
+    return out
+
+
+def cp_spacings(xyz, tri):
+    x, px = _soa(xyz)
+    t, pt = _tri_soa(tri)
+    ms = np.zeros(x.shape[1])
+    mvd = C.c_double()
+    check(lib().msm_cp_spacings(px, pt, x.shape[1], t.shape[1], ms.ctypes.data_as(c_dp), C.byref(mvd)))
+    return ms, mvd.value
+
+
+def label_sampling_grid(sg_order, max_dist, abs_is_int=False, cap=4096):
+    s = np.zeros((3, cap))
+    b = np.zeros((3, cap))
+    ns, nb = C.c_int32(), C.c_int32()
+    check(lib().msm_label_sampling_grid(sg_order, float(max_dist), int(abs_is_int), cap, s.ctypes.data_as(c_dp), C.byref(ns),
+                                        b.ctypes.data_as(c_dp), C.byref(nb)))
+    return np.ascontiguousarray(s[:, : ns.value].T), np.ascontiguousarray(b[:, : nb.value].T)
+
+
+def rescale_sampling_grid(samples, scale):
+    s, ps = _soa(samples)
+    n = s.shape[1]
+    out = np.zeros((3, n))
+    sc = C.c_double(scale)
+    check(lib().msm_rescale_sampling_grid(ps, n, C.byref(sc), out.ctypes.data_as(c_dp)))
+    return np.ascontiguousarray(out.T), sc.value
+
+
+def estimate_rotation_matrix(ci, index):
+    R = np.zeros(9)
+    check(lib().msm_rotation_matrix(_d(ci)[1], _d(index)[1], R.ctypes.data_as(c_dp)))
+    return R.reshape(3, 3)
+
+
+def cp_rotations(centre, cp_xyz):
+    x, px = _soa(cp_xyz)
+    rot = np.zeros((x.shape[1], 9))
+    check(lib().msm_cp_rotations(_d(centre)[1], px, x.shape[1], rot.ctypes.data_as(c_dp)))
+    return rot
+
+
+def estimate_triplets(tri):
+    t, pt = _tri_soa(tri)
+    out = np.zeros((t.shape[1], 3), dtype=np.int32)
+    check(lib().msm_estimate_triplets(pt, t.shape[1], out.ctypes.data_as(c_ip)))
+    return out
+
+
+def estimate_pairs(tri, V):
+    t, pt = _tri_soa(tri)
+    n = lib().msm_estimate_pairs(pt, V, t.shape[1], None)
+    if n < 0:
+        check(n)
+    out = np.zeros((n, 2), dtype=np.int32)
+    lib().msm_estimate_pairs(pt, V, t.shape[1], out.ctypes.data_as(c_ip))
+    return out
+
+
+# ------------------------------------------------------------------ context / mesh
+class Context:
+    """One per GPU (msm_ctx)."""
+
+    def __init__(self, device=0, stream=None):
+        L = lib()
+        self.h = L.msm_ctx_create(device) if stream is None else L.msm_ctx_create_on_stream(device, C.c_void_p(stream))
+        if not self.h:
+            raise MsmError(-5, L.msm_last_error().decode())
+        self.device = device
+
+    def synchronize(self):
+        check(lib().msm_ctx_synchronize(self.h))
+
+    @property
+    def stream(self):
+        return lib().msm_ctx_stream(self.h)
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().msm_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+
+class Mesh:
+    """newresampler::Mesh as the hot path sees it + its Octree (built lazily on the device side)."""
+
+    def __init__(self, ctx, xyz, tri):
+        self.ctx = ctx
+        x, px = _soa(xyz)
+        t, pt = _tri_soa(tri)
+        self.V, self.T = x.shape[1], t.shape[1]
+        self.tri = np.ascontiguousarray(t.T)
+        self.h = lib().msm_mesh_create(ctx.h, px, self.V, pt, self.T)
+        if not self.h:
+            raise MsmError(-1, lib().msm_last_error().decode())
+
+    def close(self):
+        if getattr(self, "h", None) and getattr(self.ctx, "h", None):
+            lib().msm_mesh_destroy(self.h)
+        self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def set_coords(self, xyz):
+        check(lib().msm_mesh_update_coords(self.h, _soa(xyz)[1]))
+
+    def get_coords(self):
+        out = np.zeros((3, self.V))
+        check(lib().msm_mesh_get_coords(self.h, out.ctypes.data_as(c_dp)))
+        return np.ascontiguousarray(out.T)
+
+    def set_pvalues(self, feat):
+        f, pf = _d(np.atleast_2d(feat))
+        assert f.shape[1] == self.V
+        check(lib().msm_mesh_set_features(self.h, pf, f.shape[0]))
+
+    def octree_stats(self):
+        s = (C.c_int64 * 5)()
+        check(lib().msm_mesh_octree_stats(self.h, s))
+        return dict(nodes=s[0], leaves=s[1], depth=s[2], refs=s[3], max_leaf=s[4])
+
+    # Octree::get_closest_triangle + get_barycentric_weights
+    def query_triangles(self, q, mode=WEIGHTS_PROJECTED, check_status=True):
+        x, px = _soa(q)
+        N = x.shape[1]
+        tri = np.zeros(N, dtype=np.int32)
+        vid = np.zeros((3, N), dtype=np.int32)
+        w = np.zeros((3, N))
+        st = lib().msm_query_triangles(self.h, px, N, tri.ctypes.data_as(c_ip), vid.ctypes.data_as(c_ip), w.ctypes.data_as(c_dp), mode)
+        if check_status:
+            check(st)
+        return st, tri, np.ascontiguousarray(vid.T), np.ascontiguousarray(w.T)
+
+    def get_closest_vertex_ID(self, q):
+        x, px = _soa(q)
+        out = np.zeros(x.shape[1], dtype=np.int32)
+        check(lib().msm_closest_vertex(self.h, px, x.shape[1], out.ctypes.data_as(c_ip)))
+        return out
+
+
+# ------------------------------------------------------------------ resampler free functions
+def get_adaptive_barycentric_weights(in_mesh, new_mesh, excl=None):
+    nnz = C.c_int64()
+    pe = _d(excl)[1] if excl is not None else None
+    check(lib().msm_adaptive_barycentric_weights(in_mesh.h, new_mesh.h, pe, None, None, None, 0, C.byref(nnz)))
+    rp = np.zeros(new_mesh.V + 1, dtype=np.int32)
+    col = np.zeros(nnz.value, dtype=np.int32)
+    val = np.zeros(nnz.value)
+    check(lib().msm_adaptive_barycentric_weights(in_mesh.h, new_mesh.h, pe, rp.ctypes.data_as(c_ip), col.ctypes.data_as(c_ip),
+                                                 val.ctypes.data_as(c_dp), nnz.value, C.byref(nnz)))
+    return rp, col, val
+
+
+def metric_resample(in_mesh, data, new_mesh):
+    d, pd = _d(np.atleast_2d(data))
+    out = np.zeros((d.shape[0], new_mesh.V))
+    check(lib().msm_metric_resample(in_mesh.h, pd, d.shape[0], new_mesh.h, out.ctypes.data_as(c_dp)))
+    return out
+
+
+def sphere_project_warp(sphere, from_mesh, to_xyz):
+    s, ps = _soa(sphere)
+    s = s.copy()
+    check(lib().msm_sphere_project_warp(from_mesh.h, _soa(to_xyz)[1], s.ctypes.data_as(c_dp), s.shape[1]))
+    return np.ascontiguousarray(s.T)
+
+
+def barycentric_coords_resample(from_mesh, coords, q):
+    x, px = _soa(q)
+    out = np.zeros((3, x.shape[1]))
+    check(lib().msm_barycentric_coords_resample(from_mesh.h, _soa(coords)[1], px, x.shape[1], out.ctypes.data_as(c_dp)))
+    return np.ascontiguousarray(out.T)
+
+
+def nearest_neighbour_interpolation(orig_mesh, data, q):
+    d, pd = _d(np.atleast_2d(data))
+    x, px = _soa(q)
+    out = np.zeros((d.shape[0], x.shape[1]))
+    check(lib().msm_nearest_neighbour(orig_mesh.h, pd, d.shape[0], px, x.shape[1], out.ctypes.data_as(c_dp)))
+    return out
+
+
+# ------------------------------------------------------------------ cost function
+class DiscreteCostFunction:
+    """NonLinearSRegDiscreteCostFunction family behind the DiscreteCostFunction evaluator interface."""
+
+    def __init__(self, ctx, kind="univariate", simmeasure=2, rmode=3, lambda_=0.1, mu=0.1, kappa=10.0, k_exp=2.0, rexp=2.0, range_=1.0):
+        self.ctx = ctx
+        self.params = CostParams(KINDS[kind], simmeasure, rmode, 0, lambda_, mu, kappa, k_exp, rexp, range_)
+        self.h = lib().msm_cost_create(ctx.h, C.byref(self.params))
+        if not self.h:
+            raise MsmError(-1, lib().msm_last_error().decode())
+        self._keep = {}
+
+    def close(self):
+        if getattr(self, "h", None) and getattr(self.ctx, "h", None):
+            lib().msm_cost_destroy(self.h)
+        self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def set_meshes(self, target, source, cpgrid):
+        self._keep.update(target=target, source=source, cpgrid=cpgrid)
+        self.N = cpgrid.V
+        check(lib().msm_cost_set_meshes(self.h, target.h, source.h, cpgrid.h))
+
+    def reset_source(self, source):
+        self._keep["source"] = source
+        check(lib().msm_cost_reset_source(self.h, source.h))
+
+    def reset_CPgrid(self, cpgrid):
+        self._keep["cpgrid"] = cpgrid
+        check(lib().msm_cost_reset_cpgrid(self.h, cpgrid.h))
+
+    def set_featurespace(self, src_feat, ref_feat=None):
+        f, pf = _d(np.atleast_2d(src_feat))
+        if ref_feat is not None:
+            self._keep["target"].set_pvalues(ref_feat)
+        check(lib().msm_cost_set_source_features(self.h, pf, f.shape[0]))
+
+    def set_dataaffintyweighting(self, w):
+        if w is None:
+            check(lib().msm_cost_set_cfweight(self.h, None, 0))
+        else:
+            w, pw = _d(np.atleast_2d(w))
+            check(lib().msm_cost_set_cfweight(self.h, pw, w.shape[0]))
+
+    def set_spacings(self, maxsep, mvdmax):
+        check(lib().msm_cost_set_spacings(self.h, _d(maxsep)[1], float(mvdmax)))
+
+    def set_labels(self, labels, rot):
+        l, pl = _soa(labels)
+        self.L = l.shape[1]
+        check(lib().msm_cost_set_labels(self.h, pl, self.L, _d(rot)[1]))
+
+    def setTriplets(self, triplets):
+        t, pt = _i(triplets)
+        self.T = len(t)
+        check(lib().msm_cost_set_triplets(self.h, pt, self.T))
+
+    def setPairs(self, pairs):
+        p, pp = _i(pairs)
+        self.P = len(p)
+        check(lib().msm_cost_set_pairs(self.h, pp, self.P))
+
+    def get_source_data(self):
+        check(lib().msm_cost_get_source_data(self.h))
+
+    def patches(self):
+        ng = C.c_int32()
+        check(lib().msm_cost_patches(self.h, C.byref(ng), None, None, 0))
+        ptr = np.zeros(ng.value + 1, dtype=np.int32)
+        check(lib().msm_cost_patches(self.h, C.byref(ng), ptr.ctypes.data_as(c_ip), None, 0))
+        idx = np.zeros(max(int(ptr[-1]), 1), dtype=np.int32)
+        check(lib().msm_cost_patches(self.h, C.byref(ng), ptr.ctypes.data_as(c_ip), idx.ctypes.data_as(c_ip), len(idx)))
+        return ptr, idx[: int(ptr[-1])]
+
+    def absolute_weights(self):
+        out = np.zeros(self.N)
+        check(lib().msm_cost_absolute_weights(self.h, out.ctypes.data_as(c_dp)))
+        return out
+
+    # computeUnaryCosts() + getUnaryCosts(): table[label, node]
+    def computeUnaryCosts(self):
+        U = np.zeros((self.L, self.N))
+        check(lib().msm_cost_unary_table(self.h, U.ctypes.data_as(c_dp)))
+        return U
+
+    def computeUnaryCosts_async(self):
+        check(lib().msm_cost_unary_table_async(self.h))
+
+    def getUnaryCosts(self):
+        U = np.zeros((self.L, self.N))
+        check(lib().msm_cost_unary_table_fetch(self.h, U.ctypes.data_as(c_dp)))
+        return U
+
+    def computeUnaryCost(self, nodes, labels):
+        n, pn = _i(np.atleast_1d(nodes))
+        l, pl = _i(np.atleast_1d(labels))
+        out = np.zeros(len(n))
+        check(lib().msm_cost_unary_batch(self.h, pn, pl, len(n), out.ctypes.data_as(c_dp)))
+        return out
+
+    def computeTripletCost(self, triplet, la, lb, lc):
+        t, pt = _i(np.atleast_1d(triplet))
+        a, pa = _i(np.atleast_1d(la))
+        b, pb = _i(np.atleast_1d(lb))
+        c_, pc = _i(np.atleast_1d(lc))
+        out = np.zeros(len(t))
+        check(lib().msm_cost_triplet_batch(self.h, pt, pa, pb, pc, len(t), out.ctypes.data_as(c_dp)))
+        return out
+
+    def tripletOctets(self, labeling, label):
+        lab, pl = _i(labeling)
+        out = np.zeros((self.T, 8))
+        check(lib().msm_cost_triplet_octets(self.h, pl, int(label), out.ctypes.data_as(c_dp)))
+        return out
+
+    def computePairwiseCost(self, pair, la, lb):
+        p, pp = _i(np.atleast_1d(pair))
+        a, pa = _i(np.atleast_1d(la))
+        b, pb = _i(np.atleast_1d(lb))
+        out = np.zeros(len(p))
+        check(lib().msm_cost_pairwise_batch(self.h, pp, pa, pb, len(p), out.ctypes.data_as(c_dp)))
+        return out
+
+    def computePairwiseCosts(self):
+        out = np.zeros(self.P * self.L * self.L)
+        check(lib().msm_cost_pairwise_table(self.h, out.ctypes.data_as(c_dp)))
+        return out
+
+    def evaluateTotalCostSum(self, labeling):
+        lab, pl = _i(labeling)
+        tot = C.c_double()
+        parts = np.zeros(3)
+        check(lib().msm_cost_total(self.h, pl, C.byref(tot), parts.ctypes.data_as(c_dp)))
+        return tot.value, parts
+
+    def counters(self):
+        c = (C.c_int64 * 4)()
+        check(lib().msm_cost_counters(self.h, c))
+        return dict(samples=c[0], unary=c[1], triplet=c[2], pairwise=c[3])

@@ -1,0 +1,484 @@
+// api.cpp -- C ABI of libmsmhip (include/msmhip.h): contexts, meshes and the resampler entry points.
+// The cost-function entry points live in cost.cpp.
+#include <algorithm>
+#include <cstring>
+
+#include "devbuf.hpp"
+#include "kernels.hpp"
+
+using namespace msm;
+
+namespace msm {
+
+int check_status(msm_ctx *ctx, const char *what) {
+    MSM_HIP(hipMemcpyAsync(ctx->h_status, ctx->d_status, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    MSM_HIP(hipStreamSynchronize(ctx->stream));
+    const int st = *ctx->h_status;
+    if (st != 0) {
+        MSM_HIP(hipMemsetAsync(ctx->d_status, 0, sizeof(int), ctx->stream));
+        switch (st) {
+            case MSM_ERR_OUTSIDE: return fail(st, "%s: Point is not in the bounding box of the mesh", what);
+            case MSM_ERR_NOTFOUND:
+                return fail(st, "%s: Error in octree. This may caused by a too distorted mesh face. Try increasing regularisation lambda.", what);
+            case MSM_ERR_ROTATION: return fail(st, "%s: rotation angle is greater than 90 degrees", what);
+            default: return fail(st, "%s: kernel reported status %d", what, st);
+        }
+    }
+    return MSM_OK;
+}
+
+int ensure_tree(msm_mesh *m) {
+    if (m->tree_valid) return MSM_OK;
+    std::vector<TriRec> recs;
+    build_octree(m->xyz.data(), m->tri.data(), m->V, m->T, m->tree, recs);
+    msm_ctx *ctx = m->ctx;
+    MSM_HIP(hipSetDevice(ctx->device));
+    auto grow = [&](void **p, size_t &cap, size_t need, size_t elem) -> hipError_t {
+        if (need <= cap && *p) return hipSuccess;
+        if (*p) (void)hipFree(*p);
+        *p = nullptr;
+        cap = need + need / 4 + 16;
+        return hipMalloc(p, cap * elem);
+    };
+    size_t cap_parent = m->cap_node, cap_cone = m->cap_leaf;
+    MSM_HIP(grow((void **)&m->d_node, m->cap_node, m->tree.node.size(), sizeof(int2)));
+    MSM_HIP(grow((void **)&m->d_parent, cap_parent, m->tree.node.size(), sizeof(int32_t)));
+    MSM_HIP(grow((void **)&m->d_leaf_tri, m->cap_leaf, m->tree.leaf_tri.size(), sizeof(int32_t)));
+    MSM_HIP(grow((void **)&m->d_cone, cap_cone, m->tree.leaf_tri.size(), sizeof(float4)));
+    MSM_HIP(grow((void **)&m->d_rec, m->cap_rec, recs.size(), sizeof(TriRec)));
+    // the staging vectors die at scope exit, so these copies must complete here
+    MSM_HIP(hipMemcpyAsync(m->d_node, m->tree.node.data(), m->tree.node.size() * sizeof(int2), hipMemcpyHostToDevice, ctx->stream));
+    MSM_HIP(hipMemcpyAsync(m->d_parent, m->tree.parent.data(), m->tree.parent.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    MSM_HIP(hipMemcpyAsync(m->d_leaf_tri, m->tree.leaf_tri.data(), m->tree.leaf_tri.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    MSM_HIP(hipMemcpyAsync(m->d_cone, m->tree.cone.data(), m->tree.cone.size() * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
+    MSM_HIP(hipMemcpyAsync(m->d_rec, recs.data(), recs.size() * sizeof(TriRec), hipMemcpyHostToDevice, ctx->stream));
+    MSM_HIP(hipStreamSynchronize(ctx->stream));
+    m->tree_valid = true;
+    return MSM_OK;
+}
+
+DevTree dev_tree(const msm_mesh *m) {
+    DevTree t;
+    t.node = m->d_node;
+    t.parent = m->d_parent;
+    t.leaf_tri = m->d_leaf_tri;
+    t.cone = m->d_cone;
+    t.rec = m->d_rec;
+    t.nnodes = (int)m->tree.node.size();
+    return t;
+}
+
+const Adjacency &mesh_adjacency(msm_mesh *m) {
+    if (!m->adj_valid) {
+        build_adjacency(m->tri.data(), m->V, m->T, m->adj);
+        m->adj_valid = true;
+    }
+    return m->adj;
+}
+
+// get_barycentric_weights on the device for host-resident query points
+int query_host(msm_mesh *target, const double *q, int N, int *tri_id, int *vid, double *w, int mode, const char *what) {
+    msm_ctx *ctx = target->ctx;
+    int st = ensure_tree(target);
+    if (st) return st;
+    DevBuf<double> dq, dw;
+    DevBuf<int> dt, dv;
+    MSM_HIP(dq.upload(q, 3 * (size_t)N, ctx->stream));
+    if (tri_id) MSM_HIP(dt.ensure(N));
+    if (vid) MSM_HIP(dv.ensure(3 * (size_t)N));
+    if (w) MSM_HIP(dw.ensure(3 * (size_t)N));
+    st = launch_query(ctx, dev_tree(target), dq.p, N, tri_id ? dt.p : nullptr, vid ? dv.p : nullptr, w ? dw.p : nullptr, mode);
+    if (st) return st;
+    if (tri_id) MSM_HIP(dt.download(tri_id, N, ctx->stream));
+    if (vid) MSM_HIP(dv.download(vid, 3 * (size_t)N, ctx->stream));
+    if (w) MSM_HIP(dw.download(w, 3 * (size_t)N, ctx->stream));
+    return check_status(ctx, what);
+}
+
+int vertex_areas(msm_mesh *m, std::vector<double> &area) {
+    const Adjacency &a = mesh_adjacency(m);
+    const int V = m->V, T = m->T;
+    std::vector<double> ta(T);
+    auto pt = [&](int i) { return mk(m->xyz[i], m->xyz[V + i], m->xyz[2 * V + i]); };
+    for (int t = 0; t < T; ++t) ta[t] = tri_area(pt(m->tri[t]), pt(m->tri[T + t]), pt(m->tri[2 * T + t]));
+    area.resize(V);
+    for (int v = 0; v < V; ++v) {
+        double sum = 0;
+        for (int j = a.tid_ptr[v]; j < a.tid_ptr[v + 1]; ++j) sum += ta[a.tid[j]];
+        area[v] = sum / (a.tid_ptr[v + 1] - a.tid_ptr[v]);
+    }
+    return MSM_OK;
+}
+
+// Resampler::get_adaptive_barycentric_weights, R/resampler.cpp:72-140.  The 2 x N nearest-triangle
+// queries run on the GPU; the list surgery (transpose, pick, area correction) is done on the host in
+// the reference's serial order so that every sum has the same operand order.
+int adaptive_weights(msm_mesh *in_mesh, msm_mesh *new_mesh, const double *excl, std::vector<int32_t> &row_ptr,
+                     std::vector<int32_t> &col, std::vector<double> &val) {
+    const int nOld = in_mesh->V, nNew = new_mesh->V;
+    std::vector<int> fvid(3 * (size_t)nNew), rvid(3 * (size_t)nOld);
+    std::vector<double> fw(3 * (size_t)nNew), rw(3 * (size_t)nOld);
+    int st = query_host(in_mesh, new_mesh->xyz.data(), nNew, nullptr, fvid.data(), fw.data(), MSM_WEIGHTS_PROJECTED, "adaptive weights (forward)");
+    if (st) return st;
+    st = query_host(new_mesh, in_mesh->xyz.data(), nOld, nullptr, rvid.data(), rw.data(), MSM_WEIGHTS_PROJECTED, "adaptive weights (reverse)");
+    if (st) return st;
+    std::vector<int> closest;
+    if (excl) {
+        closest.resize(nNew);
+        msm_ctx *ctx = in_mesh->ctx;
+        DevBuf<double> dq;
+        DevBuf<int> dout;
+        MSM_HIP(dq.upload(new_mesh->xyz.data(), 3 * (size_t)nNew, ctx->stream));
+        MSM_HIP(dout.ensure(nNew));
+        st = launch_closest_vertex(ctx, dev_tree(in_mesh), dq.p, nNew, dout.p);
+        if (st) return st;
+        MSM_HIP(dout.download(closest.data(), nNew, ctx->stream));
+        st = check_status(ctx, "adaptive weights (exclusion)");
+        if (st) return st;
+    }
+    std::vector<double> oldA, newA;
+    vertex_areas(in_mesh, oldA);
+    vertex_areas(new_mesh, newA);
+
+    struct Entry {
+        int32_t key;
+        double w;
+    };
+    // a std::map<int,double> holding the three weights of one query: ascending key, later writes win
+    auto small_map = [](const int *vid, const double *w, int stride, int k, Entry out[3]) {
+        int n = 0;
+        for (int j = 0; j < 3; ++j) {
+            const int32_t key = vid[j * stride + k];
+            const double wt = w[j * stride + k];
+            int pos = 0;
+            while (pos < n && out[pos].key < key) ++pos;
+            if (pos < n && out[pos].key == key) {
+                out[pos].w = wt;
+                continue;
+            }
+            for (int q = n; q > pos; --q) out[q] = out[q - 1];
+            out[pos] = Entry{key, wt};
+            ++n;
+        }
+        return n;
+    };
+    // reverse lists transposed: for each new vertex the old vertices whose triangle contains it (:91-97);
+    // old vertices are visited in ascending order, so each list is already sorted by key
+    std::vector<int32_t> rcount(nNew + 1, 0);
+    for (int o = 0; o < nOld; ++o) {
+        Entry e[3];
+        const int n = small_map(rvid.data(), rw.data(), nOld, o, e);
+        for (int j = 0; j < n; ++j) rcount[e[j].key + 1]++;
+    }
+    for (int k = 0; k < nNew; ++k) rcount[k + 1] += rcount[k];
+    std::vector<Entry> rlist(rcount[nNew]);
+    {
+        std::vector<int32_t> fill(rcount.begin(), rcount.end() - 1);
+        for (int o = 0; o < nOld; ++o) {
+            Entry e[3];
+            const int n = small_map(rvid.data(), rw.data(), nOld, o, e);
+            for (int j = 0; j < n; ++j) rlist[fill[e[j].key]++] = Entry{o, e[j].w};
+        }
+    }
+    row_ptr.assign(nNew + 1, 0);
+    col.clear();
+    val.clear();
+    std::vector<double> correction(nOld, 0.0);
+    std::vector<char> active(nNew, 0);
+    for (int k = 0; k < nNew; ++k) {  // :99-118
+        row_ptr[k] = (int32_t)col.size();
+        if (excl && !(closest[k] >= 0 && excl[closest[k]] != 0)) continue;
+        active[k] = 1;
+        Entry f[3];
+        const int nf = small_map(fvid.data(), fw.data(), nNew, k, f);
+        const int nr = rcount[k + 1] - rcount[k];
+        const Entry *src = (nr <= nf) ? f : &rlist[rcount[k]];
+        const int n = (nr <= nf) ? nf : nr;
+        for (int j = 0; j < n; ++j) {
+            const double wgt = src[j].w * newA[k];
+            col.push_back(src[j].key);
+            val.push_back(wgt);
+            correction[src[j].key] += wgt;
+        }
+    }
+    row_ptr[nNew] = (int32_t)col.size();
+    for (int k = 0; k < nNew; ++k) {  // :120-137
+        if (!active[k]) continue;
+        double wsum = 0.0;
+        for (int e = row_ptr[k]; e < row_ptr[k + 1]; ++e) {
+            val[e] *= oldA[col[e]] / correction[col[e]];
+            wsum += val[e];
+        }
+        if (wsum != 0.0)
+            for (int e = row_ptr[k]; e < row_ptr[k + 1]; ++e) val[e] /= wsum;
+    }
+    return MSM_OK;
+}
+
+}  // namespace msm
+
+extern "C" {
+
+// ------------------------------------------------------------------ context
+static msm_ctx *ctx_make(int device, hipStream_t stream, bool own) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        fail(MSM_ERR_NOGPU, "no HIP device available: libmsmhip has no CPU fallback");
+        return nullptr;
+    }
+    if (device < 0 || device >= n) {
+        fail(MSM_ERR_INVALID, "device %d out of range (%d visible)", device, n);
+        return nullptr;
+    }
+    if (hipSetDevice(device) != hipSuccess) {
+        fail(MSM_ERR_HIP, "hipSetDevice(%d) failed", device);
+        return nullptr;
+    }
+    msm_ctx *ctx = new msm_ctx();
+    ctx->device = device;
+    ctx->own_stream = own;
+    ctx->stream = stream;
+    if (own && hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx;
+        fail(MSM_ERR_HIP, "hipStreamCreate failed");
+        return nullptr;
+    }
+    if (hipMalloc((void **)&ctx->d_status, sizeof(int)) != hipSuccess || hipHostMalloc((void **)&ctx->h_status, sizeof(int)) != hipSuccess ||
+        hipMemsetAsync(ctx->d_status, 0, sizeof(int), ctx->stream) != hipSuccess) {
+        fail(MSM_ERR_HIP, "context allocation failed");
+        msm_ctx_destroy(ctx);
+        return nullptr;
+    }
+    return ctx;
+}
+
+msm_ctx *msm_ctx_create(int device) { return ctx_make(device, nullptr, true); }
+msm_ctx *msm_ctx_create_on_stream(int device, void *hip_stream) { return ctx_make(device, (hipStream_t)hip_stream, false); }
+
+void msm_ctx_destroy(msm_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->d_status) (void)hipFree(ctx->d_status);
+    if (ctx->h_status) (void)hipHostFree(ctx->h_status);
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int msm_ctx_synchronize(msm_ctx *ctx) {
+    if (!ctx) return fail(MSM_ERR_INVALID, "null context");
+    MSM_HIP(hipStreamSynchronize(ctx->stream));
+    return MSM_OK;
+}
+
+void *msm_ctx_stream(msm_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+// ------------------------------------------------------------------ mesh
+msm_mesh *msm_mesh_create(msm_ctx *ctx, const double *xyz, int32_t V, const int32_t *tri, int32_t T) {
+    if (!ctx || !xyz || !tri || V <= 0 || T <= 0) {
+        fail(MSM_ERR_INVALID, "msm_mesh_create: bad arguments");
+        return nullptr;
+    }
+    for (int64_t i = 0; i < 3 * (int64_t)T; ++i)
+        if (tri[i] < 0 || tri[i] >= V) {
+            fail(MSM_ERR_INVALID, "msm_mesh_create: triangle vertex id %d out of range [0,%d)", tri[i], V);
+            return nullptr;
+        }
+    msm_mesh *m = new msm_mesh();
+    m->ctx = ctx;
+    m->V = V;
+    m->T = T;
+    m->xyz.assign(xyz, xyz + 3 * (size_t)V);
+    m->tri.assign(tri, tri + 3 * (size_t)T);
+    (void)hipSetDevice(ctx->device);
+    if (hipMalloc((void **)&m->d_xyz, sizeof(double) * 3 * (size_t)V) != hipSuccess ||
+        hipMemcpyAsync(m->d_xyz, m->xyz.data(), sizeof(double) * 3 * (size_t)V, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
+        fail(MSM_ERR_HIP, "msm_mesh_create: device allocation failed");
+        msm_mesh_destroy(m);
+        return nullptr;
+    }
+    return m;
+}
+
+void msm_mesh_destroy(msm_mesh *m) {
+    if (!m) return;
+    (void)hipSetDevice(m->ctx->device);
+    (void)hipStreamSynchronize(m->ctx->stream);
+    for (void *p : {(void *)m->d_xyz, (void *)m->d_feat, (void *)m->d_node, (void *)m->d_parent, (void *)m->d_leaf_tri, (void *)m->d_cone, (void *)m->d_rec})
+        if (p) (void)hipFree(p);
+    delete m;
+}
+
+int msm_mesh_update_coords(msm_mesh *m, const double *xyz) {
+    if (!m || !xyz) return fail(MSM_ERR_INVALID, "msm_mesh_update_coords: null argument");
+    MSM_HIP(hipStreamSynchronize(m->ctx->stream));  // the host copy may still be the source of an async upload
+    m->xyz.assign(xyz, xyz + 3 * (size_t)m->V);
+    m->tree_valid = false;
+    MSM_HIP(hipMemcpyAsync(m->d_xyz, m->xyz.data(), sizeof(double) * 3 * (size_t)m->V, hipMemcpyHostToDevice, m->ctx->stream));
+    return MSM_OK;
+}
+
+int msm_mesh_get_coords(msm_mesh *m, double *xyz) {
+    if (!m || !xyz) return fail(MSM_ERR_INVALID, "msm_mesh_get_coords: null argument");
+    std::copy(m->xyz.begin(), m->xyz.end(), xyz);
+    return MSM_OK;
+}
+
+int msm_mesh_set_features(msm_mesh *m, const double *feat, int32_t D) {
+    if (!m || !feat || D <= 0) return fail(MSM_ERR_INVALID, "msm_mesh_set_features: bad arguments");
+    const int V = m->V;
+    MSM_HIP(hipStreamSynchronize(m->ctx->stream));
+    m->feat.assign(feat, feat + (size_t)D * V);
+    std::vector<double> vm((size_t)D * V);  // vertex-major rows so that a gather by vertex id reads D contiguous values
+    for (int d = 0; d < D; ++d)
+        for (int v = 0; v < V; ++v) vm[(size_t)v * D + d] = feat[(size_t)d * V + v];
+    if (m->d_feat && m->D != D) {
+        (void)hipFree(m->d_feat);
+        m->d_feat = nullptr;
+    }
+    if (!m->d_feat) MSM_HIP(hipMalloc((void **)&m->d_feat, sizeof(double) * (size_t)D * V));
+    m->D = D;
+    MSM_HIP(hipMemcpyAsync(m->d_feat, vm.data(), sizeof(double) * (size_t)D * V, hipMemcpyHostToDevice, m->ctx->stream));
+    MSM_HIP(hipStreamSynchronize(m->ctx->stream));
+    return MSM_OK;
+}
+
+int msm_mesh_sizes(const msm_mesh *m, int32_t *V, int32_t *T, int32_t *D) {
+    if (!m) return fail(MSM_ERR_INVALID, "null mesh");
+    if (V) *V = m->V;
+    if (T) *T = m->T;
+    if (D) *D = m->D;
+    return MSM_OK;
+}
+
+int msm_mesh_octree_stats(msm_mesh *m, int64_t stats[5]) {
+    if (!m || !stats) return fail(MSM_ERR_INVALID, "msm_mesh_octree_stats: null argument");
+    int st = ensure_tree(m);
+    if (st) return st;
+    std::copy(m->tree.stats, m->tree.stats + 5, stats);
+    return MSM_OK;
+}
+
+// ------------------------------------------------------------------ resampler
+int msm_query_triangles(msm_mesh *target, const double *q, int32_t N, int32_t *tri_id, int32_t *v_id, double *w, int mode) {
+    if (!target || !q || N < 0) return fail(MSM_ERR_INVALID, "msm_query_triangles: bad arguments");
+    if (mode != MSM_WEIGHTS_PROJECTED && mode != MSM_WEIGHTS_RAW) return fail(MSM_ERR_INVALID, "unknown weight mode %d", mode);
+    if (N == 0) return MSM_OK;
+    return query_host(target, q, N, tri_id, v_id, w, mode, "msm_query_triangles");
+}
+
+int msm_closest_vertex(msm_mesh *target, const double *q, int32_t N, int32_t *v_id) {
+    if (!target || !q || !v_id || N < 0) return fail(MSM_ERR_INVALID, "msm_closest_vertex: bad arguments");
+    if (N == 0) return MSM_OK;
+    msm_ctx *ctx = target->ctx;
+    int st = ensure_tree(target);
+    if (st) return st;
+    DevBuf<double> dq;
+    DevBuf<int> dout;
+    MSM_HIP(dq.upload(q, 3 * (size_t)N, ctx->stream));
+    MSM_HIP(dout.ensure(N));
+    st = launch_closest_vertex(ctx, dev_tree(target), dq.p, N, dout.p);
+    if (st) return st;
+    MSM_HIP(dout.download(v_id, N, ctx->stream));
+    return check_status(ctx, "msm_closest_vertex");
+}
+
+int msm_adaptive_barycentric_weights(msm_mesh *in_mesh, msm_mesh *new_mesh, const double *excl, int32_t *row_ptr, int32_t *col, double *val,
+                                     int64_t cap, int64_t *nnz) {
+    if (!in_mesh || !new_mesh) return fail(MSM_ERR_INVALID, "msm_adaptive_barycentric_weights: null mesh");
+    std::vector<int32_t> rp, c;
+    std::vector<double> v;
+    int st = adaptive_weights(in_mesh, new_mesh, excl, rp, c, v);
+    if (st) return st;
+    if (nnz) *nnz = (int64_t)c.size();
+    if (!col) return MSM_OK;
+    if ((int64_t)c.size() > cap) return fail(MSM_ERR_CAPACITY, "weights need %zu entries, buffer holds %lld", c.size(), (long long)cap);
+    if (row_ptr) std::copy(rp.begin(), rp.end(), row_ptr);
+    std::copy(c.begin(), c.end(), col);
+    if (val) std::copy(v.begin(), v.end(), val);
+    return MSM_OK;
+}
+
+int msm_metric_resample(msm_mesh *in_mesh, const double *data, int32_t D, msm_mesh *new_mesh, double *out) {
+    if (!in_mesh || !new_mesh || !data || !out || D <= 0) return fail(MSM_ERR_INVALID, "msm_metric_resample: bad arguments");
+    std::vector<int32_t> rp, c;
+    std::vector<double> v;
+    int st = adaptive_weights(in_mesh, new_mesh, nullptr, rp, c, v);
+    if (st) return st;
+    const int Vin = in_mesh->V, Vn = new_mesh->V;
+    for (int d = 0; d < D; ++d)  // barycentric_data_interpolation, R/resampler.cpp:40-52
+        for (int k = 0; k < Vn; ++k) {
+            double acc = 0.0;
+            for (int e = rp[k]; e < rp[k + 1]; ++e) acc += data[(size_t)d * Vin + c[e]] * v[e];
+            out[(size_t)d * Vn + k] = acc;
+        }
+    return MSM_OK;
+}
+
+// shared by the coordinate-resampling entry points: out = sum_j w_j * coords[v_j], ids in ascending order
+// (the reference iterates a std::map<int,double>)
+static int bary_coords(msm_mesh *from, const double *coords, const double *q, int N, double *out, bool to_sphere, const char *what) {
+    std::vector<int> vid(3 * (size_t)N);
+    std::vector<double> w(3 * (size_t)N);
+    int st = query_host(from, q, N, nullptr, vid.data(), w.data(), MSM_WEIGHTS_PROJECTED, what);
+    if (st) return st;
+    const int V = from->V;
+    for (int i = 0; i < N; ++i) {
+        int id[3] = {vid[i], vid[N + i], vid[2 * N + i]};
+        double wt[3] = {w[i], w[N + i], w[2 * N + i]};
+        // std::map semantics: later duplicate keys overwrite, iteration ascending
+        int n = 0, kid[3];
+        double kw[3];
+        for (int j = 0; j < 3; ++j) {
+            int pos = 0;
+            while (pos < n && kid[pos] < id[j]) ++pos;
+            if (pos < n && kid[pos] == id[j]) {
+                kw[pos] = wt[j];
+                continue;
+            }
+            for (int s = n; s > pos; --s) {
+                kid[s] = kid[s - 1];
+                kw[s] = kw[s - 1];
+            }
+            kid[pos] = id[j];
+            kw[pos] = wt[j];
+            ++n;
+        }
+        V3 p = mk(0, 0, 0);
+        for (int j = 0; j < n; ++j) {
+            p.x += coords[kid[j]] * kw[j];
+            p.y += coords[V + kid[j]] * kw[j];
+            p.z += coords[2 * V + kid[j]] * kw[j];
+        }
+        if (to_sphere) p = scale(normalized(p), 100);  // R/resampler.cpp:324-325
+        out[i] = p.x;
+        out[N + i] = p.y;
+        out[2 * N + i] = p.z;
+    }
+    return MSM_OK;
+}
+
+int msm_sphere_project_warp(msm_mesh *from, const double *to_xyz, double *sphere, int32_t N) {
+    if (!from || !to_xyz || !sphere || N < 0) return fail(MSM_ERR_INVALID, "msm_sphere_project_warp: bad arguments");
+    if (N == 0) return MSM_OK;
+    std::vector<double> q(sphere, sphere + 3 * (size_t)N);
+    return bary_coords(from, to_xyz, q.data(), N, sphere, true, "msm_sphere_project_warp");
+}
+
+int msm_barycentric_coords_resample(msm_mesh *from, const double *coords, const double *q, int32_t N, double *out) {
+    if (!from || !coords || !q || !out || N < 0) return fail(MSM_ERR_INVALID, "msm_barycentric_coords_resample: bad arguments");
+    if (N == 0) return MSM_OK;
+    return bary_coords(from, coords, q, N, out, false, "msm_barycentric_coords_resample");
+}
+
+int msm_nearest_neighbour(msm_mesh *orig, const double *data, int32_t D, const double *q, int32_t N, double *out) {
+    if (!orig || !data || !q || !out || D <= 0 || N < 0) return fail(MSM_ERR_INVALID, "msm_nearest_neighbour: bad arguments");
+    std::vector<int32_t> cv(N);
+    int st = msm_closest_vertex(orig, q, N, cv.data());
+    if (st) return st;
+    for (int d = 0; d < D; ++d)
+        for (int i = 0; i < N; ++i) out[(size_t)d * N + i] = data[(size_t)d * orig->V + cv[i]];
+    return MSM_OK;
+}
+
+}  // extern "C"

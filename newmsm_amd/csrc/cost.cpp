@@ -1,0 +1,467 @@
+// cost.cpp -- C ABI of the discrete cost function (include/msmhip.h, "discrete cost function").
+//
+// msm_cost mirrors NonLinearSRegDiscreteCostFunction (M/DiscreteCostFunction.h:83-224): the setters
+// take what DiscreteModel hands the cost function each iteration, get_source_data() builds the
+// per-control-point patches, and the table / batch evaluators replace the OpenMP loops of
+// computeUnaryCosts, computeTripletCosts and Fusion's per-label sweeps with kernel launches.
+#include <algorithm>
+#include <cmath>
+
+#include "devbuf.hpp"
+#include "kernels.hpp"
+
+using namespace msm;
+
+namespace msm {
+int adaptive_weights(msm_mesh *in_mesh, msm_mesh *new_mesh, const double *excl, std::vector<int32_t> &row_ptr, std::vector<int32_t> &col,
+                     std::vector<double> &val);
+int query_host(msm_mesh *target, const double *q, int N, int *tri_id, int *vid, double *w, int mode, const char *what);
+}  // namespace msm
+
+struct msm_cost {
+    msm_ctx *ctx = nullptr;
+    msm_cost_params p{};
+    msm_mesh *target = nullptr, *source = nullptr, *cpgrid = nullptr;
+    std::vector<double> orig_xyz;  // _ORIG: source coordinates at set_meshes (3 x Nsrc)
+    std::vector<double> ocp_xyz;   // _oCPgrid
+    int D = 0;
+    std::vector<double> sfeat;
+    DevBuf<double> d_sfeat;
+    std::vector<double> cfw;
+    int cfw_rows = 0;
+    DevBuf<double> d_cfw;
+    std::vector<double> maxsep;
+    double mvdmax = 0;
+    DevBuf<double> d_maxsep;
+    int L = 0;
+    std::vector<double> labels, rot;
+    DevBuf<double> d_labels, d_rot;
+    std::vector<int32_t> triplets, pairs;
+    DevBuf<int32_t> d_triplets, d_pairs;
+    DevBuf<double> d_orig, d_ocp;
+    // get_source_data products
+    bool have_source = false;
+    int ngroups = 0, pmax = 0;
+    std::vector<int32_t> pptr, pidx;
+    DevBuf<int32_t> d_pptr, d_pidx;
+    std::vector<double> absw;
+    DevBuf<double> d_absw;
+    // unary table
+    DevBuf<double> d_U;
+    bool table_valid = false;
+    std::vector<double> h_U;
+    DevBuf<unsigned long long> d_counters;
+    int64_t counters[4] = {0, 0, 0, 0};
+    // scratch for the range kernel
+    DevBuf<uint32_t> d_slots;
+    DevBuf<int> d_counts;
+};
+
+namespace {
+
+void invalidate_table(msm_cost *c) {
+    c->table_valid = false;
+    c->h_U.clear();
+}
+
+bool is_ho(const msm_cost *c) { return c->p.kind == MSM_COST_HO_UNIVARIATE || c->p.kind == MSM_COST_HO_MULTIVARIATE; }
+
+int need(const msm_cost *c, bool cond, const char *what) {
+    if (!cond) return fail(MSM_ERR_STATE, "msm_cost: %s must be set first", what);
+    return MSM_OK;
+}
+
+// cfweight(row, vertex); all ones when none was given (M/mesh_registration.cpp:234-238)
+inline double cfw_at(const msm_cost *c, int row, int i) { return c->cfw.empty() ? 1.0 : c->cfw[(size_t)row * c->source->V + i]; }
+inline int cfw_nrows(const msm_cost *c) { return c->cfw.empty() ? 1 : c->cfw_rows; }
+
+// Patches by range test (Univariate :338-349, Multivariate :399-404, Patchwise :636-648).
+int patches_by_range(msm_cost *c) {
+    msm_ctx *ctx = c->ctx;
+    const int N = c->cpgrid->V, Ns = c->source->V;
+    MSM_HIP(c->d_maxsep.upload(c->maxsep.data(), N, ctx->stream));
+    MSM_HIP(c->d_counts.ensure(N));
+    int cap = 128;
+    std::vector<int> counts(N);
+    std::vector<uint32_t> slots;
+    for (int attempt = 0; attempt < 3; ++attempt) {
+        MSM_HIP(c->d_slots.ensure((size_t)N * cap));
+        int st = launch_range(ctx, c->cpgrid->d_xyz, N, c->source->d_xyz, Ns, c->d_maxsep.p, c->p.range, cap, c->d_slots.p, c->d_counts.p);
+        if (st) return st;
+        MSM_HIP(c->d_counts.download(counts.data(), N, ctx->stream));
+        MSM_HIP(hipStreamSynchronize(ctx->stream));
+        const int mx = *std::max_element(counts.begin(), counts.end());
+        if (mx <= cap) break;
+        if (attempt == 2) return fail(MSM_ERR_CAPACITY, "patch capacity");
+        cap = mx + 16;
+    }
+    slots.resize((size_t)N * cap);
+    MSM_HIP(c->d_slots.download(slots.data(), slots.size(), ctx->stream));
+    MSM_HIP(hipStreamSynchronize(ctx->stream));
+    const double *cp = c->cpgrid->xyz.data(), *src = c->source->xyz.data();
+    c->pptr.assign(N + 1, 0);
+    c->pidx.clear();
+    for (int k = 0; k < N; ++k) {
+        c->pptr[k] = (int32_t)c->pidx.size();
+        const V3 ck = mk(cp[k], cp[N + k], cp[2 * N + k]);
+        for (int j = 0; j < counts[k]; ++j) {
+            const uint32_t e = slots[(size_t)k * cap + j];
+            const int i = (int)(e & 0x7fffffffu);
+            if (e & 0x80000000u) {  // within 1e-11 of the threshold: decide with the host libm, as the reference does
+                const double arc = chord_to_arc(norm(sub(ck, mk(src[i], src[Ns + i], src[2 * Ns + i]))));
+                if (!(arc < c->p.range * c->maxsep[k])) continue;
+            }
+            c->pidx.push_back(i);
+        }
+    }
+    c->pptr[N] = (int32_t)c->pidx.size();
+    c->ngroups = N;
+    return MSM_OK;
+}
+
+// Bins by closest control-grid triangle (HOUnivariate :472-483, HOMultivariate :545-561).
+int patches_by_triangle(msm_cost *c) {
+    const int Ns = c->source->V, Tc = c->cpgrid->T;
+    std::vector<int> tri(Ns);
+    int st = query_host(c->cpgrid, c->source->xyz.data(), Ns, tri.data(), nullptr, nullptr, MSM_WEIGHTS_RAW, "get_source_data (HO)");
+    if (st) return st;
+    c->pptr.assign(Tc + 1, 0);
+    for (int i = 0; i < Ns; ++i) c->pptr[tri[i] + 1]++;
+    for (int t = 0; t < Tc; ++t) c->pptr[t + 1] += c->pptr[t];
+    c->pidx.resize(Ns);
+    std::vector<int32_t> fill(c->pptr.begin(), c->pptr.end() - 1);
+    for (int i = 0; i < Ns; ++i) c->pidx[fill[tri[i]]++] = i;
+    c->ngroups = Tc;
+    return MSM_OK;
+}
+
+// resample_weights, M/DiscreteCostFunction.cpp:303-323
+int resample_weights(msm_cost *c) {
+    const int Ns = c->source->V, N = c->cpgrid->V;
+    std::vector<double> mw(Ns);
+    for (int k = 0; k < Ns; ++k) {
+        double best = -DBL_MAX;
+        for (int j = 0; j < cfw_nrows(c); ++j)
+            if (cfw_at(c, j, k) > best) best = cfw_at(c, j, k);
+        mw[k] = best;
+    }
+    std::vector<int32_t> rp, col;
+    std::vector<double> val;
+    int st = adaptive_weights(c->source, c->cpgrid, nullptr, rp, col, val);
+    if (st) return st;
+    c->absw.resize(N);
+    for (int k = 0; k < N; ++k) {
+        double acc = 0.0;
+        for (int e = rp[k]; e < rp[k + 1]; ++e) acc += mw[col[e]] * val[e];
+        c->absw[k] = acc;
+    }
+    return MSM_OK;
+}
+
+int ensure_unary_table(msm_cost *c) {
+    if (c->table_valid) return MSM_OK;
+    int st = need(c, c->have_source, "get_source_data()");
+    if (st) return st;
+    st = need(c, c->L > 0, "labels");
+    if (st) return st;
+    st = need(c, c->target->d_feat != nullptr && c->target->D == c->D, "target features matching the source features");
+    if (st) return st;
+    msm_ctx *ctx = c->ctx;
+    const int N = c->cpgrid->V;
+    MSM_HIP(c->d_U.ensure((size_t)c->L * N));
+    if (is_ho(c)) {  // the HO classes' computeUnaryCost returns 0, M/DiscreteCostFunction.h:249,258
+        MSM_HIP(hipMemsetAsync(c->d_U.p, 0, sizeof(double) * (size_t)c->L * N, ctx->stream));
+        c->table_valid = true;
+        return MSM_OK;
+    }
+    st = ensure_tree(c->target);
+    if (st) return st;
+    UnaryLaunch u;
+    u.tree = dev_tree(c->target);
+    u.tfeat = c->target->d_feat;
+    u.D = c->D;
+    u.N = N;
+    u.L = c->L;
+    u.cp = c->cpgrid->d_xyz;
+    u.rot = c->d_rot.p;
+    u.labels = c->d_labels.p;
+    u.src = c->source->d_xyz;
+    u.Nsrc = c->source->V;
+    u.sfeat = c->d_sfeat.p;
+    u.cfw = c->cfw.empty() ? nullptr : c->d_cfw.p;
+    u.cfw_rows = c->cfw_rows;
+    u.pptr = c->d_pptr.p;
+    u.pidx = c->d_pidx.p;
+    u.absw = c->d_absw.p;
+    u.pmax = c->pmax;
+    u.simmeasure = c->p.simmeasure;
+    u.U = c->d_U.p;
+    u.nsamples = c->d_counters.p;
+    switch (c->p.kind) {
+        case MSM_COST_UNIVARIATE: st = launch_unary_univariate(ctx, u); break;
+        default: return fail(MSM_ERR_INVALID, "cost kind %d is not implemented on the device yet", c->p.kind);
+    }
+    if (st) return st;
+    c->counters[1] += (int64_t)c->L * N;
+    c->table_valid = true;
+    return MSM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+msm_cost *msm_cost_create(msm_ctx *ctx, const msm_cost_params *params) {
+    if (!ctx || !params) {
+        fail(MSM_ERR_INVALID, "msm_cost_create: null argument");
+        return nullptr;
+    }
+    if (params->kind < MSM_COST_UNIVARIATE || params->kind > MSM_COST_HO_MULTIVARIATE) {
+        fail(MSM_ERR_INVALID, "msm_cost_create: unknown cost kind %d", params->kind);
+        return nullptr;
+    }
+    if (params->simmeasure != 1 && params->simmeasure != 2) {
+        fail(MSM_ERR_INVALID, "msm_cost_create: similarity measure %d is not offloaded (1 = SSD, 2 = correlation)", params->simmeasure);
+        return nullptr;
+    }
+    msm_cost *c = new msm_cost();
+    c->ctx = ctx;
+    c->p = *params;
+    (void)hipSetDevice(ctx->device);
+    if (c->d_counters.zero(4, ctx->stream) != hipSuccess) {
+        fail(MSM_ERR_HIP, "msm_cost_create: allocation failed");
+        delete c;
+        return nullptr;
+    }
+    return c;
+}
+
+void msm_cost_destroy(msm_cost *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->ctx->device);
+    (void)hipStreamSynchronize(c->ctx->stream);
+    delete c;
+}
+
+int msm_cost_set_meshes(msm_cost *c, msm_mesh *target, msm_mesh *source, msm_mesh *cpgrid) {
+    if (!c || !target || !source || !cpgrid) return fail(MSM_ERR_INVALID, "msm_cost_set_meshes: null argument");
+    if (target->ctx != c->ctx || source->ctx != c->ctx || cpgrid->ctx != c->ctx) return fail(MSM_ERR_INVALID, "meshes belong to another context");
+    if (source->V < cpgrid->V) return fail(MSM_ERR_INVALID, "source mesh has fewer vertices than the control grid");
+    c->target = target;
+    c->source = source;
+    c->cpgrid = cpgrid;
+    c->orig_xyz = source->xyz;
+    c->ocp_xyz = cpgrid->xyz;
+    MSM_HIP(c->d_orig.upload(c->orig_xyz.data(), c->orig_xyz.size(), c->ctx->stream));
+    MSM_HIP(c->d_ocp.upload(c->ocp_xyz.data(), c->ocp_xyz.size(), c->ctx->stream));
+    MSM_HIP(hipStreamSynchronize(c->ctx->stream));
+    c->have_source = false;
+    invalidate_table(c);
+    return MSM_OK;
+}
+
+int msm_cost_reset_source(msm_cost *c, msm_mesh *source) {
+    if (!c || !source) return fail(MSM_ERR_INVALID, "msm_cost_reset_source: null argument");
+    if (c->source && source->V != c->source->V) return fail(MSM_ERR_INVALID, "source mesh size changed");
+    c->source = source;
+    c->have_source = false;
+    invalidate_table(c);
+    return MSM_OK;
+}
+
+int msm_cost_reset_cpgrid(msm_cost *c, msm_mesh *cpgrid) {
+    if (!c || !cpgrid) return fail(MSM_ERR_INVALID, "msm_cost_reset_cpgrid: null argument");
+    if (c->cpgrid && cpgrid->V != c->cpgrid->V) return fail(MSM_ERR_INVALID, "control grid size changed");
+    c->cpgrid = cpgrid;
+    c->have_source = false;
+    invalidate_table(c);
+    return MSM_OK;
+}
+
+int msm_cost_set_source_features(msm_cost *c, const double *feat, int32_t D) {
+    if (!c || !feat || D <= 0) return fail(MSM_ERR_INVALID, "msm_cost_set_source_features: bad arguments");
+    int st = need(c, c->source != nullptr, "meshes");
+    if (st) return st;
+    if ((c->p.kind == MSM_COST_UNIVARIATE || c->p.kind == MSM_COST_HO_UNIVARIATE) && D != 1) {
+        // the univariate classes read feature row 1 only (M/DiscreteCostFunction.cpp:343, :477)
+    }
+    c->D = D;
+    MSM_HIP(hipStreamSynchronize(c->ctx->stream));
+    c->sfeat.assign(feat, feat + (size_t)D * c->source->V);
+    MSM_HIP(c->d_sfeat.upload(c->sfeat.data(), c->sfeat.size(), c->ctx->stream));
+    invalidate_table(c);
+    return MSM_OK;
+}
+
+int msm_cost_set_cfweight(msm_cost *c, const double *w, int32_t rows) {
+    if (!c) return fail(MSM_ERR_INVALID, "null cost");
+    int st = need(c, c->source != nullptr, "meshes");
+    if (st) return st;
+    MSM_HIP(hipStreamSynchronize(c->ctx->stream));
+    if (!w) {
+        c->cfw.clear();
+        c->cfw_rows = 0;
+    } else {
+        if (rows <= 0) return fail(MSM_ERR_INVALID, "msm_cost_set_cfweight: rows must be positive");
+        // initialize(), M/DiscreteCostFunction.cpp:114-115
+        if (rows != 1 && c->D > 0 && rows != c->D)
+            return fail(MSM_ERR_INVALID, "DiscreteModel ERROR:: costfunction weighting has dimensions incompatible with data");
+        c->cfw.assign(w, w + (size_t)rows * c->source->V);
+        c->cfw_rows = rows;
+        MSM_HIP(c->d_cfw.upload(c->cfw.data(), c->cfw.size(), c->ctx->stream));
+    }
+    c->have_source = false;
+    invalidate_table(c);
+    return MSM_OK;
+}
+
+int msm_cost_set_spacings(msm_cost *c, const double *maxsep, double mvdmax) {
+    if (!c || !maxsep) return fail(MSM_ERR_INVALID, "msm_cost_set_spacings: null argument");
+    int st = need(c, c->cpgrid != nullptr, "meshes");
+    if (st) return st;
+    c->maxsep.assign(maxsep, maxsep + c->cpgrid->V);
+    c->mvdmax = mvdmax;
+    c->have_source = false;
+    invalidate_table(c);
+    return MSM_OK;
+}
+
+int msm_cost_set_labels(msm_cost *c, const double *labels, int32_t L, const double *rot) {
+    if (!c || !labels || !rot || L <= 0) return fail(MSM_ERR_INVALID, "msm_cost_set_labels: bad arguments");
+    int st = need(c, c->cpgrid != nullptr, "meshes");
+    if (st) return st;
+    MSM_HIP(hipStreamSynchronize(c->ctx->stream));
+    c->L = L;
+    c->labels.assign(labels, labels + 3 * (size_t)L);
+    c->rot.assign(rot, rot + 9 * (size_t)c->cpgrid->V);
+    MSM_HIP(c->d_labels.upload(c->labels.data(), c->labels.size(), c->ctx->stream));
+    MSM_HIP(c->d_rot.upload(c->rot.data(), c->rot.size(), c->ctx->stream));
+    invalidate_table(c);
+    return MSM_OK;
+}
+
+int msm_cost_set_triplets(msm_cost *c, const int32_t *triplets, int32_t T) {
+    if (!c || (!triplets && T > 0) || T < 0) return fail(MSM_ERR_INVALID, "msm_cost_set_triplets: bad arguments");
+    int st = need(c, c->cpgrid != nullptr, "meshes");
+    if (st) return st;
+    for (int64_t i = 0; i < 3 * (int64_t)T; ++i)
+        if (triplets[i] < 0 || triplets[i] >= c->cpgrid->V) return fail(MSM_ERR_INVALID, "triplet node id out of range");
+    MSM_HIP(hipStreamSynchronize(c->ctx->stream));
+    c->triplets.assign(triplets, triplets + 3 * (size_t)T);
+    if (T > 0) MSM_HIP(c->d_triplets.upload(c->triplets.data(), c->triplets.size(), c->ctx->stream));
+    return MSM_OK;
+}
+
+int msm_cost_set_pairs(msm_cost *c, const int32_t *pairs, int32_t P) {
+    if (!c || (!pairs && P > 0) || P < 0) return fail(MSM_ERR_INVALID, "msm_cost_set_pairs: bad arguments");
+    int st = need(c, c->cpgrid != nullptr, "meshes");
+    if (st) return st;
+    for (int64_t i = 0; i < 2 * (int64_t)P; ++i)
+        if (pairs[i] < 0 || pairs[i] >= c->cpgrid->V) return fail(MSM_ERR_INVALID, "pair node id out of range");
+    MSM_HIP(hipStreamSynchronize(c->ctx->stream));
+    c->pairs.assign(pairs, pairs + 2 * (size_t)P);
+    if (P > 0) MSM_HIP(c->d_pairs.upload(c->pairs.data(), c->pairs.size(), c->ctx->stream));
+    return MSM_OK;
+}
+
+int msm_cost_get_source_data(msm_cost *c) {
+    if (!c) return fail(MSM_ERR_INVALID, "null cost");
+    int st = need(c, c->target && c->source && c->cpgrid, "meshes");
+    if (st) return st;
+    st = need(c, c->D > 0, "source features");
+    if (st) return st;
+    st = need(c, (int)c->maxsep.size() == c->cpgrid->V, "spacings");
+    if (st) return st;
+    // NonLinearSRegDiscreteCostFunction::initialize, M/DiscreteCostFunction.cpp:109-117
+    if (c->target->V == 0 || c->source->V == 0) return fail(MSM_ERR_STATE, "CostFunction::You must supply source and target meshes.");
+    st = is_ho(c) ? patches_by_triangle(c) : patches_by_range(c);
+    if (st) return st;
+    c->pmax = 1;
+    for (int g = 0; g < c->ngroups; ++g) c->pmax = std::max(c->pmax, c->pptr[g + 1] - c->pptr[g]);
+    st = resample_weights(c);
+    if (st) return st;
+    msm_ctx *ctx = c->ctx;
+    MSM_HIP(c->d_pptr.upload(c->pptr.data(), c->pptr.size(), ctx->stream));
+    MSM_HIP(c->d_pidx.upload(c->pidx.data(), std::max<size_t>(c->pidx.size(), 1), ctx->stream));
+    MSM_HIP(c->d_absw.upload(c->absw.data(), c->absw.size(), ctx->stream));
+    MSM_HIP(hipStreamSynchronize(ctx->stream));
+    c->have_source = true;
+    invalidate_table(c);
+    return MSM_OK;
+}
+
+int msm_cost_patches(msm_cost *c, int32_t *ngroups, int32_t *ptr, int32_t *idx, int64_t cap) {
+    if (!c) return fail(MSM_ERR_INVALID, "null cost");
+    int st = need(c, c->have_source, "get_source_data()");
+    if (st) return st;
+    if (ngroups) *ngroups = c->ngroups;
+    if (ptr) std::copy(c->pptr.begin(), c->pptr.end(), ptr);
+    if (idx) {
+        if ((int64_t)c->pidx.size() > cap) return fail(MSM_ERR_CAPACITY, "patch index buffer too small");
+        std::copy(c->pidx.begin(), c->pidx.end(), idx);
+    }
+    return MSM_OK;
+}
+
+int msm_cost_absolute_weights(msm_cost *c, double *absw) {
+    if (!c || !absw) return fail(MSM_ERR_INVALID, "msm_cost_absolute_weights: null argument");
+    int st = need(c, c->have_source, "get_source_data()");
+    if (st) return st;
+    std::copy(c->absw.begin(), c->absw.end(), absw);
+    return MSM_OK;
+}
+
+int msm_cost_unary_table_async(msm_cost *c) {
+    if (!c) return fail(MSM_ERR_INVALID, "null cost");
+    invalidate_table(c);  // every call is a fresh computeUnaryCosts()
+    return ensure_unary_table(c);
+}
+
+int msm_cost_unary_table_fetch(msm_cost *c, double *U) {
+    if (!c || !U) return fail(MSM_ERR_INVALID, "msm_cost_unary_table_fetch: null argument");
+    int st = need(c, c->table_valid, "msm_cost_unary_table_async()");
+    if (st) return st;
+    MSM_HIP(c->d_U.download(U, (size_t)c->L * c->cpgrid->V, c->ctx->stream));
+    return check_status(c->ctx, "computeUnaryCosts");
+}
+
+int msm_cost_unary_table(msm_cost *c, double *U) {
+    int st = msm_cost_unary_table_async(c);
+    if (st) return st;
+    return msm_cost_unary_table_fetch(c, U);
+}
+
+int msm_cost_unary_batch(msm_cost *c, const int32_t *nodes, const int32_t *labels, int32_t n, double *out) {
+    if (!c || !nodes || !labels || !out || n < 0) return fail(MSM_ERR_INVALID, "msm_cost_unary_batch: bad arguments");
+    // computeUnaryCost(node,label) is a pure function between two get_source_data()/set_labels() calls,
+    // so the batch is served from the table (computed once)
+    if (!c->table_valid || c->h_U.size() != (size_t)c->L * c->cpgrid->V) {
+        int st = ensure_unary_table(c);
+        if (st) return st;
+        c->h_U.resize((size_t)c->L * c->cpgrid->V);
+        st = msm_cost_unary_table_fetch(c, c->h_U.data());
+        if (st) return st;
+    }
+    const int N = c->cpgrid->V;
+    for (int i = 0; i < n; ++i) {
+        if (nodes[i] < 0 || nodes[i] >= N || labels[i] < 0 || labels[i] >= c->L) return fail(MSM_ERR_INVALID, "unary query %d out of range", i);
+        out[i] = c->h_U[(size_t)labels[i] * N + nodes[i]];
+    }
+    return MSM_OK;
+}
+
+int msm_cost_counters(msm_cost *c, int64_t counters[4]) {
+    if (!c || !counters) return fail(MSM_ERR_INVALID, "msm_cost_counters: null argument");
+    unsigned long long dev[4];
+    MSM_HIP(c->d_counters.download(dev, 4, c->ctx->stream));
+    MSM_HIP(hipStreamSynchronize(c->ctx->stream));
+    counters[0] = (int64_t)dev[0];
+    counters[1] = c->counters[1];
+    counters[2] = c->counters[2];
+    counters[3] = c->counters[3];
+    return MSM_OK;
+}
+
+// ---- clique costs: implemented in cost_cliques.cpp ----
+
+}  // extern "C"

@@ -1,0 +1,49 @@
+// devbuf.hpp -- minimal growable device buffer (HBM allocations are kept and reused across calls).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+
+namespace msm {
+
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t cap = 0;
+
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { release(); }
+
+    void release() {
+        if (p) (void)hipFree(p);  // hipFree waits for work that may still use the buffer
+        p = nullptr;
+        cap = 0;
+    }
+    hipError_t ensure(size_t n) {
+        if (n <= cap && p) return hipSuccess;
+        release();
+        cap = n + n / 4 + 16;
+        hipError_t e = hipMalloc((void **)&p, cap * sizeof(T));
+        if (e != hipSuccess) {
+            p = nullptr;
+            cap = 0;
+        }
+        return e;
+    }
+    hipError_t upload(const T *host, size_t n, hipStream_t s) {
+        hipError_t e = ensure(n);
+        if (e != hipSuccess) return e;
+        return hipMemcpyAsync(p, host, n * sizeof(T), hipMemcpyHostToDevice, s);
+    }
+    hipError_t download(T *host, size_t n, hipStream_t s) const { return hipMemcpyAsync(host, p, n * sizeof(T), hipMemcpyDeviceToHost, s); }
+    hipError_t zero(size_t n, hipStream_t s) {
+        hipError_t e = ensure(n);
+        if (e != hipSuccess) return e;
+        return hipMemsetAsync(p, 0, n * sizeof(T), s);
+    }
+};
+
+}  // namespace msm

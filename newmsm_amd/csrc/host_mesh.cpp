@@ -1,0 +1,349 @@
+// host_mesh.cpp -- [host] entry points of msmhip.h: icosphere generation, mesh adjacency and the small
+// pieces of NonLinearSRegDiscreteModel that prepare inputs for the device path.  No GPU needed.
+//
+// Vertex / triangle / neighbour numbering is observable in newMSM's outputs, so these routines
+// reproduce the reference's order exactly (file:line cited per function, paths under
+// /root/reference/libraries/).
+#include <algorithm>
+#include <map>
+#include <unordered_map>
+
+#include "internal.hpp"
+
+namespace msm {
+
+thread_local std::string g_error;
+
+void set_error(const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_error = buf;
+}
+
+int fail(int code, const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_error = buf;
+    return code;
+}
+
+// One 1->4 subdivision, R/mesh.cpp:910-1005.  The reference finds already-created edge midpoints by
+// an O(V^2) tolerance search over the points added in this pass; midpoints of one edge are computed
+// from the same two operands either way round, so they are bit-identical and an edge-keyed hash map
+// finds the same point (distinct edges of an icosphere have midpoints far more than 1e-8 apart).
+// New points are numbered in the order (v1,v2) (v0,v2) (v0,v1) per triangle, and every vertex is
+// re-normalised at the end of the pass, as in the reference.
+static void subdivide(std::vector<double> &xyz, std::vector<int32_t> &tri) {
+    const size_t oldT = tri.size() / 3;
+    std::vector<int32_t> next;
+    next.reserve(oldT * 12);
+    std::unordered_map<uint64_t, int32_t> midpoint;
+    midpoint.reserve(oldT * 2);
+    auto key = [](int32_t a, int32_t b) { return (uint64_t)std::min(a, b) << 32 | (uint32_t)std::max(a, b); };
+    for (size_t t = 0; t < oldT; ++t) {
+        const int32_t v0 = tri[3 * t], v1 = tri[3 * t + 1], v2 = tri[3 * t + 2];
+        const int32_t ea[3] = {v1, v0, v0}, eb[3] = {v2, v2, v1};
+        int32_t p[3];
+        bool fresh[3];
+        for (int m = 0; m < 3; ++m) {
+            auto it = midpoint.find(key(ea[m], eb[m]));
+            fresh[m] = it == midpoint.end();
+            p[m] = fresh[m] ? -1 : it->second;
+        }
+        for (int m = 0; m < 3; ++m)
+            if (fresh[m]) {
+                p[m] = (int32_t)(xyz.size() / 3);
+                for (int k = 0; k < 3; ++k) xyz.push_back((xyz[3 * ea[m] + k] + xyz[3 * eb[m] + k]) / 2);
+                midpoint.emplace(key(ea[m], eb[m]), p[m]);
+            }
+        const int32_t kids[12] = {p[2], p[0], p[1], p[1], v0, p[2], p[0], v2, p[1], p[2], v1, p[0]};
+        next.insert(next.end(), kids, kids + 12);
+    }
+    tri.swap(next);
+    for (size_t i = 0; i < xyz.size() / 3; ++i) {
+        V3 n = normalized(mk(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]));
+        xyz[3 * i] = n.x;
+        xyz[3 * i + 1] = n.y;
+        xyz[3 * i + 2] = n.z;
+    }
+}
+
+// make_mesh_from_icosa, R/mesh.cpp:1111-1196 (AoS output, unit sphere)
+void icosphere_unit(int order, std::vector<double> &xyz, std::vector<int32_t> &tri) {
+    const double t = 0.8506508084, o = 0.5257311121;
+    // ZA ZB ZC ZD YA YB YC YD XA XB XC XD
+    const double base[36] = {t, o, 0, -t, o, 0, -t, -o, 0, t, -o, 0, o, 0, t, o, 0, -t, -o, 0, -t, -o, 0, t, 0, t, o, 0, -t, o, 0, -t, -o, 0, t, -o};
+    enum { ZA, ZB, ZC, ZD, YA, YB, YC, YD, XA, XB, XC, XD };
+    const int32_t faces[60] = {YD, XA, YA, XB, YD, YA, XD, YC, YB, YC, XC, YB, ZD, YA, ZA, YB, ZD, ZA, ZB, YD, ZC, YC, ZB, ZC, XD, ZA, XA, ZB, XD, XA,
+                               ZD, XC, XB, XC, ZC, XB, ZA, YA, XA, YB, ZA, XD, ZD, XB, YA, XC, ZD, YB, ZB, XA, YD, XD, ZB, YC, XB, ZC, YD, ZC, XC, YC};
+    xyz.assign(base, base + 36);
+    tri.resize(60);
+    for (int f = 0; f < 20; ++f) {  // swap_orientation(): second and third vertex exchanged
+        tri[3 * f] = faces[3 * f];
+        tri[3 * f + 1] = faces[3 * f + 2];
+        tri[3 * f + 2] = faces[3 * f + 1];
+    }
+    for (int i = 0; i < order; ++i) subdivide(xyz, tri);
+}
+
+// Mesh::push_triangle applied to every triangle in order, R/mesh.cpp:115-134
+void build_adjacency(const int32_t *tri, int V, int T, Adjacency &adj) {
+    std::vector<std::vector<int32_t>> nb(V), tr(V);
+    for (int t = 0; t < T; ++t) {
+        const int32_t n[3] = {tri[t], tri[T + t], tri[2 * T + t]};
+        for (int k = 0; k < 3; ++k) tr[n[k]].push_back(t);
+        static const int ord[6][2] = {{0, 1}, {0, 2}, {1, 0}, {1, 2}, {2, 0}, {2, 1}};
+        for (auto &q : ord) {
+            auto &list = nb[n[q[0]]];
+            if (std::find(list.begin(), list.end(), n[q[1]]) == list.end()) list.push_back(n[q[1]]);
+        }
+    }
+    adj.nbr_ptr.assign(V + 1, 0);
+    adj.tid_ptr.assign(V + 1, 0);
+    for (int v = 0; v < V; ++v) {
+        adj.nbr_ptr[v + 1] = adj.nbr_ptr[v] + (int32_t)nb[v].size();
+        adj.tid_ptr[v + 1] = adj.tid_ptr[v] + (int32_t)tr[v].size();
+    }
+    adj.nbr.clear();
+    adj.tid.clear();
+    adj.nbr.reserve(adj.nbr_ptr[V]);
+    adj.tid.reserve(adj.tid_ptr[V]);
+    for (int v = 0; v < V; ++v) {
+        adj.nbr.insert(adj.nbr.end(), nb[v].begin(), nb[v].end());
+        adj.tid.insert(adj.tid.end(), tr[v].begin(), tr[v].end());
+    }
+}
+
+static inline V3 pt(const double *xyz, int V, int i) { return mk(xyz[i], xyz[V + i], xyz[2 * V + i]); }
+
+}  // namespace msm
+
+using namespace msm;
+
+extern "C" {
+
+int msm_abi_version(void) { return MSM_ABI_VERSION; }
+const char *msm_last_error(void) { return g_error.c_str(); }
+
+int msm_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int msm_icosphere_counts(int order, int32_t *V, int32_t *T) {
+    if (order < 0 || order > 9) return fail(MSM_ERR_INVALID, "icosphere order %d out of range [0,9]", order);
+    int64_t v = 12, t = 20;
+    for (int i = 0; i < order; ++i) {
+        v += 3 * t / 2;
+        t *= 4;
+    }
+    if (V) *V = (int32_t)v;
+    if (T) *T = (int32_t)t;
+    return MSM_OK;
+}
+
+int msm_icosphere(int order, double radius, double *xyz, int32_t *tri) {
+    int32_t V, T;
+    int st = msm_icosphere_counts(order, &V, &T);
+    if (st) return st;
+    if (!xyz || !tri) return fail(MSM_ERR_INVALID, "msm_icosphere: null output");
+    std::vector<double> p;
+    std::vector<int32_t> f;
+    icosphere_unit(order, p, f);
+    for (int i = 0; i < V; ++i) {
+        V3 c = mk(p[3 * i], p[3 * i + 1], p[3 * i + 2]);
+        if (radius > 0) c = scale(normalized(c), radius);  // true_rescale, R/mesh.cpp:1210-1219
+        xyz[i] = c.x;
+        xyz[V + i] = c.y;
+        xyz[2 * V + i] = c.z;
+    }
+    for (int t = 0; t < T; ++t)
+        for (int k = 0; k < 3; ++k) tri[k * T + t] = f[3 * t + k];
+    return MSM_OK;
+}
+
+int msm_mesh_adjacency(const int32_t *tri, int32_t V, int32_t T, int32_t *nbr_ptr, int32_t *nbr, int32_t *tid_ptr, int32_t *tid) {
+    if (!tri || V <= 0 || T <= 0) return fail(MSM_ERR_INVALID, "msm_mesh_adjacency: bad mesh");
+    for (int i = 0; i < 3 * T; ++i)
+        if (tri[i] < 0 || tri[i] >= V) return fail(MSM_ERR_INVALID, "triangle vertex id %d out of range", tri[i]);
+    Adjacency a;
+    build_adjacency(tri, V, T, a);
+    if (nbr_ptr) std::copy(a.nbr_ptr.begin(), a.nbr_ptr.end(), nbr_ptr);
+    if (tid_ptr) std::copy(a.tid_ptr.begin(), a.tid_ptr.end(), tid_ptr);
+    if (nbr) std::copy(a.nbr.begin(), a.nbr.end(), nbr);
+    if (tid) std::copy(a.tid.begin(), a.tid.end(), tid);
+    return MSM_OK;
+}
+
+int msm_vertex_areas(const double *xyz, const int32_t *tri, int32_t V, int32_t T, double *area) {
+    if (!xyz || !tri || !area || V <= 0 || T <= 0) return fail(MSM_ERR_INVALID, "msm_vertex_areas: bad arguments");
+    Adjacency a;
+    build_adjacency(tri, V, T, a);
+    std::vector<double> ta(T);
+    for (int t = 0; t < T; ++t) ta[t] = tri_area(pt(xyz, V, tri[t]), pt(xyz, V, tri[T + t]), pt(xyz, V, tri[2 * T + t]));
+    for (int v = 0; v < V; ++v) {
+        double sum = 0;
+        for (int j = a.tid_ptr[v]; j < a.tid_ptr[v + 1]; ++j) sum += ta[a.tid[j]];
+        area[v] = sum / (a.tid_ptr[v + 1] - a.tid_ptr[v]);
+    }
+    return MSM_OK;
+}
+
+int msm_cp_spacings(const double *xyz, const int32_t *tri, int32_t V, int32_t T, double *maxsep, double *mvdmax) {
+    if (!xyz || !tri || !maxsep || !mvdmax) return fail(MSM_ERR_INVALID, "msm_cp_spacings: null argument");
+    Adjacency a;
+    build_adjacency(tri, V, T, a);
+    double best = -DBL_MAX;  // calculate_MaxVD starts from lowest()
+    for (int k = 0; k < V; ++k) {
+        maxsep[k] = 0;
+        V3 cp = pt(xyz, V, k);
+        for (int j = a.nbr_ptr[k]; j < a.nbr_ptr[k + 1]; ++j) {
+            double dist = chord_to_arc(norm(sub(cp, pt(xyz, V, a.nbr[j]))));
+            if (dist > maxsep[k]) maxsep[k] = dist;
+            if (dist > best) best = dist;
+        }
+    }
+    *mvdmax = best;
+    return MSM_OK;
+}
+
+int msm_label_sampling_grid(int sg_order, double max_dist, int abs_is_int, int32_t cap, double *samples, int32_t *nsamples,
+                            double *barycentres, int32_t *nbarycentres) {
+    int32_t V, T;
+    int st = msm_icosphere_counts(sg_order, &V, &T);
+    if (st) return st;
+    std::vector<double> g(3 * (size_t)V);
+    std::vector<int32_t> f(3 * (size_t)T);
+    msm_icosphere(sg_order, kRad, g.data(), f.data());
+    Adjacency a;
+    build_adjacency(f.data(), V, T, a);
+    int centroid = 0;  // first vertex with six neighbours, M/DiscreteModel.cpp:115-120
+    for (int i = 0; i < V; ++i)
+        if (a.nbr_ptr[i + 1] - a.nbr_ptr[i] == 6) {
+            centroid = i;
+            break;
+        }
+    const V3 centre = pt(g.data(), V, centroid);
+    // std::map<double,Point>: ascending distance, equal keys overwrite
+    std::map<double, V3> smp, bar;
+    std::vector<char> found(V, 0), found_tr(T, 0);
+    std::vector<int> ring{centroid}, next;
+    while (!ring.empty()) {
+        for (int gn : ring) {
+            for (int j = a.nbr_ptr[gn]; j < a.nbr_ptr[gn + 1]; ++j) {
+                int v = a.nbr[j];
+                V3 s = pt(g.data(), V, v);
+                double distance = norm(sub(s, centre));
+                if (distance <= max_dist && !found[v] && v != centroid) {
+                    smp[distance] = s;
+                    next.push_back(v);
+                    found[v] = 1;
+                }
+            }
+            for (int j = a.tid_ptr[gn]; j < a.tid_ptr[gn + 1]; ++j) {
+                int t = a.tid[j];
+                V3 v1 = pt(g.data(), V, f[t]), v2 = pt(g.data(), V, f[T + t]), v3 = pt(g.data(), V, f[2 * T + t]);
+                V3 b = normalized(mk((v1.x + v2.x + v3.x) / 3, (v1.y + v2.y + v3.y) / 3, (v1.z + v2.z + v3.z) / 3));
+                b = scale(b, kRad);
+                V3 bc = sub(b, centre);
+                double distance = norm(bc);
+                if (distance <= max_dist && norm(bc) > 0 && !found_tr[t]) {
+                    for (auto &e : bar) {
+                        V3 oc = sub(e.second, centre);
+                        double q = 1 - (dot(bc, oc) / (norm(bc) * norm(oc)));
+                        double aq = abs_is_int ? (double)std::abs((int)q) : std::fabs(q);
+                        if (aq < 1e-2) found_tr[t] = 1;
+                    }
+                    if (!found_tr[t]) bar[distance] = b;
+                    found_tr[t] = 1;
+                }
+            }
+        }
+        ring.swap(next);
+        next.clear();
+    }
+    const int ns = 1 + (int)smp.size(), nb = 1 + (int)bar.size();
+    if (nsamples) *nsamples = ns;
+    if (nbarycentres) *nbarycentres = nb;
+    if (ns > cap || nb > cap) return fail(MSM_ERR_CAPACITY, "label buffers hold %d entries, need %d / %d", cap, ns, nb);
+    auto emit = [&](double *out, const std::map<double, V3> &m) {
+        if (!out) return;
+        int i = 0;
+        out[0] = centre.x, out[cap] = centre.y, out[2 * cap] = centre.z;
+        for (auto &e : m) {
+            ++i;
+            out[i] = e.second.x, out[cap + i] = e.second.y, out[2 * cap + i] = e.second.z;
+        }
+    };
+    emit(samples, smp);
+    emit(barycentres, bar);
+    return MSM_OK;
+}
+
+int msm_rescale_sampling_grid(const double *samples, int32_t n, double *sc, double *labels) {
+    if (!samples || !sc || !labels || n <= 0) return fail(MSM_ERR_INVALID, "msm_rescale_sampling_grid: bad arguments");
+    const V3 centre = pt(samples, n, 0);
+    if (*sc >= 0.25) {
+        for (int i = 0; i < n; ++i) {
+            V3 s = pt(samples, n, i);
+            V3 p = mk(centre.x + (centre.x - s.x) * (*sc), centre.y + (centre.y - s.y) * (*sc), centre.z + (centre.z - s.z) * (*sc));
+            p = scale(normalized(p), 100);
+            labels[i] = p.x, labels[n + i] = p.y, labels[2 * n + i] = p.z;
+        }
+    } else {
+        *sc = 1;
+        std::copy(samples, samples + 3 * (size_t)n, labels);
+    }
+    *sc *= 0.8;
+    return MSM_OK;
+}
+
+int msm_rotation_matrix(const double ci[3], const double index[3], double R[9]) {
+    if (!rotation_matrix(mk(ci[0], ci[1], ci[2]), mk(index[0], index[1], index[2]), R))
+        return fail(MSM_ERR_ROTATION, "rotation angle is greater than 90 degrees");
+    return MSM_OK;
+}
+
+int msm_cp_rotations(const double centre[3], const double *cp, int32_t N, double *rot) {
+    if (!centre || !cp || !rot) return fail(MSM_ERR_INVALID, "msm_cp_rotations: null argument");
+    for (int k = 0; k < N; ++k)
+        if (!rotation_matrix(mk(centre[0], centre[1], centre[2]), pt(cp, N, k), rot + 9 * (size_t)k))
+            return fail(MSM_ERR_ROTATION, "rotation angle is greater than 90 degrees");
+    return MSM_OK;
+}
+
+int msm_estimate_triplets(const int32_t *tri, int32_t T, int32_t *triplets) {
+    if (!tri || !triplets) return fail(MSM_ERR_INVALID, "msm_estimate_triplets: null argument");
+    for (int t = 0; t < T; ++t) {
+        int32_t v[3] = {tri[t], tri[T + t], tri[2 * T + t]};
+        std::sort(v, v + 3);
+        std::copy(v, v + 3, triplets + 3 * (size_t)t);
+    }
+    return MSM_OK;
+}
+
+int msm_estimate_pairs(const int32_t *tri, int32_t V, int32_t T, int32_t *pairs) {
+    if (!tri) return fail(MSM_ERR_INVALID, "msm_estimate_pairs: null argument");
+    Adjacency a;
+    build_adjacency(tri, V, T, a);
+    int n = 0;
+    for (int i = 0; i < V; ++i)
+        for (int j = a.nbr_ptr[i]; j < a.nbr_ptr[i + 1]; ++j)
+            if (a.nbr[j] > i) {
+                if (pairs) {
+                    pairs[2 * n] = i;
+                    pairs[2 * n + 1] = a.nbr[j];
+                }
+                ++n;
+            }
+    return n;
+}
+
+}  // extern "C"

@@ -1,0 +1,104 @@
+// internal.hpp -- shared declarations of libmsmhip (not part of the C ABI).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/msmhip.h"
+#include "geom.hpp"
+
+namespace msm {
+
+// ---------------------------------------------------------------- errors
+void set_error(const char *fmt, ...);
+int fail(int code, const char *fmt, ...);
+
+#define MSM_HIP(call)                                                                                 \
+    do {                                                                                              \
+        hipError_t e_ = (call);                                                                       \
+        if (e_ != hipSuccess) return msm::fail(MSM_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+// ---------------------------------------------------------------- host mesh helpers (host_mesh.cpp)
+struct Adjacency {
+    std::vector<int32_t> nbr_ptr, nbr, tid_ptr, tid;
+};
+void build_adjacency(const int32_t *tri /*3 x T SoA*/, int V, int T, Adjacency &adj);
+void icosphere_unit(int order, std::vector<double> &xyz_aos, std::vector<int32_t> &tri_aos);
+
+// ---------------------------------------------------------------- octree (octree.cpp)
+// Per-triangle record used by the exact test: vertices, the triangle-only half of project_point, ids.
+struct alignas(128) TriRec {
+    double v0[3], v1[3], v2[3];
+    double s3[3];
+    double d;
+    int32_t id[3];
+    int32_t tri;
+};
+static_assert(sizeof(TriRec) == 128, "TriRec must be 128 bytes");
+
+struct FlatOctree {
+    // node[n].x >= 0: internal node, children are node[n].x .. +7 in (i,j,k) order.
+    // node[n].x <  0: leaf with (-x - 1) entries starting at node[n].y in leaf_tri / cone.
+    std::vector<int2> node;
+    std::vector<int32_t> parent;
+    std::vector<int32_t> leaf_tri;
+    std::vector<float4> cone;  // per leaf entry: unit axis (xyz) and |cos| threshold (w) of the conservative bounding cone
+    int64_t stats[5] = {0, 0, 0, 0, 0};
+};
+// builds the tree exactly as Octree::initialize_tree / add_triangle do (R/octree.cpp:42-141)
+void build_octree(const double *xyz /*3 x V SoA*/, const int32_t *tri /*3 x T SoA*/, int V, int T, FlatOctree &out,
+                  std::vector<TriRec> &recs);
+
+// device view of a mesh's search structure
+struct DevTree {
+    const int2 *node;
+    const int32_t *parent;
+    const int32_t *leaf_tri;
+    const float4 *cone;
+    const TriRec *rec;
+    int nnodes;
+};
+
+}  // namespace msm
+
+// ---------------------------------------------------------------- handles
+struct msm_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int *d_status = nullptr;  // first error code raised by a kernel (atomicMin), 0 when clean
+    int *h_status = nullptr;  // pinned
+};
+
+struct msm_mesh {
+    msm_ctx *ctx = nullptr;
+    int V = 0, T = 0, D = 0;
+    std::vector<double> xyz;   // 3 x V SoA (host copy)
+    std::vector<int32_t> tri;  // 3 x T SoA
+    std::vector<double> feat;  // D x V host copy
+    bool tree_valid = false;
+    msm::FlatOctree tree;
+    // device
+    double *d_xyz = nullptr;   // 3 x V SoA
+    double *d_feat = nullptr;  // V x D (vertex-major: one row per vertex for gathers)
+    int2 *d_node = nullptr;
+    int32_t *d_parent = nullptr;
+    int32_t *d_leaf_tri = nullptr;
+    float4 *d_cone = nullptr;
+    msm::TriRec *d_rec = nullptr;
+    size_t cap_node = 0, cap_leaf = 0, cap_rec = 0;
+    msm::Adjacency adj;
+    bool adj_valid = false;
+};
+
+namespace msm {
+int ensure_tree(msm_mesh *m);  // build + upload the search structure if stale
+DevTree dev_tree(const msm_mesh *m);
+int check_status(msm_ctx *ctx, const char *what);  // sync + read kernel status
+}  // namespace msm

@@ -1,0 +1,35 @@
+// kernels.hpp -- launch wrappers implemented in kernels.hip (device pointers only).
+#pragma once
+
+#include "internal.hpp"
+
+namespace msm {
+
+int launch_query(msm_ctx *ctx, const DevTree &T, const double *d_q, int N, int *d_tri, int *d_vid, double *d_w, int mode);
+int launch_closest_vertex(msm_ctx *ctx, const DevTree &T, const double *d_q, int N, int *d_out);
+int launch_range(msm_ctx *ctx, const double *d_cp, int Ncp, const double *d_src, int Nsrc, const double *d_maxsep, double range, int cap,
+                 uint32_t *d_slots, int *d_counts);
+
+struct UnaryLaunch {
+    DevTree tree;
+    const double *tfeat;   // target features, V x D vertex-major
+    int D;
+    int N, L;
+    const double *cp;      // 3 x N
+    const double *rot;     // N x 9
+    const double *labels;  // 3 x L
+    const double *src;     // 3 x Nsrc
+    int Nsrc;
+    const double *sfeat;   // D x Nsrc
+    const double *cfw;     // rows x Nsrc or nullptr
+    int cfw_rows;
+    const int *pptr, *pidx;
+    const double *absw;
+    int pmax;
+    int simmeasure;
+    double *U;             // L x N
+    unsigned long long *nsamples;
+};
+int launch_unary_univariate(msm_ctx *ctx, const UnaryLaunch &u);
+
+}  // namespace msm

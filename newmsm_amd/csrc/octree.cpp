@@ -1,0 +1,208 @@
+// octree.cpp -- host construction of the triangle search structure.
+//
+// newresampler::Octree (R/octree.cpp:31-141, R/node.cpp) grows a pointer tree by inserting triangles
+// one at a time: a leaf that reaches MAX_TRIANGLES entries is split when the split heuristic holds,
+// and its triangles are handed down to every child whose closed box overlaps their AABB.  Which leaf
+// a query lands in -- and so which triangles are candidates -- depends on that insertion history, so
+// the same incremental procedure is run here, on index-based nodes, and then laid out as flat arrays
+// for the GPU:
+//   node[]      int2 per node (first child, or leaf entry range)   -> descent is arithmetic + 1 load/level
+//   leaf_tri[]  triangle ids of all leaves, contiguous per leaf, in insertion (= ascending id) order
+//   cone[]      float4 per leaf entry: conservative bounding cone of the triangle (cheap reject test)
+//   recs[]      128-byte record per triangle for the exact test
+#include <cmath>
+#include <deque>
+
+#include "internal.hpp"
+
+namespace msm {
+
+namespace {
+
+struct BNode {
+    int first_child = -1;  // index of child (0,0,0); children are consecutive in (i,j,k) order
+    int parent = -1;
+    double b[3][3];  // per axis: lower, middle, upper (Node::bounds, R/node.h:42)
+    std::vector<int32_t> tris;
+};
+
+struct Builder {
+    const double *xyz;
+    const int32_t *tri;
+    int V, T;
+    std::deque<BNode> nodes;
+
+    void aabb(int t, double lo[3], double hi[3]) const {
+        for (int a = 0; a < 3; ++a) lo[a] = hi[a] = xyz[a * V + tri[t]];
+        for (int k = 1; k < 3; ++k)
+            for (int a = 0; a < 3; ++a) {
+                double c = xyz[a * V + tri[k * T + t]];
+                if (c < lo[a]) lo[a] = c;
+                if (c > hi[a]) hi[a] = c;
+            }
+    }
+    // Node::can_contain, R/node.cpp:108-116
+    bool overlaps(int n, const double lo[3], const double hi[3]) const {
+        const BNode &nd = nodes[n];
+        for (int a = 0; a < 3; ++a)
+            if (hi[a] < nd.b[a][0] || lo[a] > nd.b[a][2]) return false;
+        return true;
+    }
+    // Node::make_children, R/node.cpp:84-106
+    void split(int n) {
+        int base = (int)nodes.size();
+        for (int c = 0; c < 8; ++c) {
+            BNode ch;
+            const int oct[3] = {(c >> 2) & 1, (c >> 1) & 1, c & 1};
+            for (int a = 0; a < 3; ++a) {
+                ch.b[a][0] = nodes[n].b[a][oct[a]];
+                ch.b[a][2] = nodes[n].b[a][oct[a] + 1];
+                ch.b[a][1] = (ch.b[a][0] + ch.b[a][2]) / 2.0;
+            }
+            ch.parent = n;
+            ch.tris.reserve(kMaxTriangles);
+            nodes.push_back(std::move(ch));
+        }
+        nodes[n].first_child = base;
+    }
+    // Octree::add_triangle, R/octree.cpp:65-141
+    void add(int n, int t, const double lo[3], const double hi[3]) {
+        if (nodes[n].first_child < 0) {
+            nodes[n].tris.push_back(t);
+            const int num = (int)nodes[n].tris.size();
+            if (num < kMaxTriangles) return;
+            int total_size = 0, num_split = 0;
+            for (int i = 0; i < num; ++i) {
+                double tlo[3], thi[3];
+                aabb(nodes[n].tris[i], tlo, thi);
+                int split_size = 8;
+                for (int d = 0; d < 3; ++d)  // containing_oct: coordinate < middle, R/node.cpp:70-82
+                    if ((tlo[d] < nodes[n].b[d][1]) == (thi[d] < nodes[n].b[d][1])) split_size >>= 1;
+                total_size += split_size;
+                if (split_size != 8) ++num_split;
+            }
+            if (!(num_split > 0 && total_size < 3 * num)) return;
+            split(n);
+            std::vector<int32_t> held;
+            held.swap(nodes[n].tris);  // clear_triangles() after redistribution
+            for (int tt : held) {
+                double tlo[3], thi[3];
+                aabb(tt, tlo, thi);
+                for (int c = 0; c < 8; ++c)
+                    if (overlaps(nodes[n].first_child + c, tlo, thi)) add(nodes[n].first_child + c, tt, tlo, thi);
+            }
+        } else {
+            for (int c = 0; c < 8; ++c)
+                if (overlaps(nodes[n].first_child + c, lo, hi)) add(nodes[n].first_child + c, t, lo, hi);
+        }
+    }
+};
+
+inline V3 vtx(const double *xyz, int V, int i) { return mk(xyz[i], xyz[V + i], xyz[2 * V + i]); }
+
+// Conservative bounding cone of the set of directions for which the reference's inside test
+// (project_point + point_in_triangle with its -1e-8 slack, R/point.cpp:36-60) can succeed.
+// A point passes same_side for edge e iff its in-plane signed distance from the edge line exceeds
+// -1e-8 / (2 * area * |e|); the accepted region is the triangle grown by that band.
+float4 bounding_cone(const V3 &a, const V3 &b, const V3 &c, const TriRec &r) {
+    const float4 always = make_float4(0.f, 0.f, 1.f, -2.f);
+    V3 axis = mk(a.x + b.x + c.x, a.y + b.y + c.y, a.z + b.z + c.z);
+    double an = norm(axis);
+    if (!(an > 1e-12) || !std::isfinite(an)) return always;
+    axis = scale(axis, 1.0 / an);
+    double rho = 0.0;
+    for (const V3 *v : {&a, &b, &c}) {
+        double n = norm(*v);
+        if (!(n > 1e-12)) return always;
+        double cs = dot(axis, *v) / n;
+        cs = cs > 1 ? 1 : (cs < -1 ? -1 : cs);
+        rho = std::fmax(rho, std::acos(cs));
+    }
+    const double la = norm(sub(b, c)), lb = norm(sub(a, c)), lc = norm(sub(a, b));
+    const double area = 0.5 * norm(cross(sub(b, a), sub(c, a)));
+    const double lmin = std::fmin(la, std::fmin(lb, lc)), lmax = std::fmax(la, std::fmax(lb, lc));
+    if (!(area > 0) || !(lmin > 0)) return always;
+    // widest band over the three edges, plus rounding noise of the reference's own cross/dot products
+    const double band = 1e-8 / (2 * area * lmin) + 1e-9 * (1 + lmax);
+    // an offset polygon's corner moves by band / sin(angle/2); smallest interior angle from the altitude
+    // sin(smallest interior angle) = 2*area / (product of its two sides) >= 2*area / lmax^2
+    const double half = 0.5 * std::asin(std::fmin(1.0, 2 * area / (lmax * lmax)));
+    const double reach = band / std::fmax(std::sin(half), 1e-300);
+    const double h = std::fabs(r.d);  // distance of the triangle's plane from the origin
+    if (!(h > 0) || !(reach / h < 0.25) || !std::isfinite(reach)) return always;
+    const double rho2 = rho + 1.0001 * std::asin(reach / h) + 1e-7;
+    if (!(rho2 < 1.5)) return always;
+    // 2e-6 absorbs float rounding of the query direction and of the dot product
+    return make_float4((float)axis.x, (float)axis.y, (float)axis.z, (float)(std::cos(rho2) - 2e-6));
+}
+
+}  // namespace
+
+void build_octree(const double *xyz, const int32_t *tri, int V, int T, FlatOctree &out, std::vector<TriRec> &recs) {
+    Builder b{xyz, tri, V, T, {}};
+    BNode root;
+    for (int a = 0; a < 3; ++a) {
+        root.b[a][0] = -kBounds;
+        root.b[a][2] = kBounds;
+        root.b[a][1] = (root.b[a][0] + root.b[a][2]) / 2.0;
+    }
+    root.tris.reserve(kMaxTriangles);
+    b.nodes.push_back(std::move(root));
+    for (int t = 0; t < T; ++t) {  // initialize_tree, R/octree.cpp:42-63
+        double lo[3], hi[3];
+        b.aabb(t, lo, hi);
+        b.add(0, t, lo, hi);
+    }
+
+    recs.resize(T);
+    std::vector<float4> tcone(T);
+    for (int t = 0; t < T; ++t) {
+        const V3 v0 = vtx(xyz, V, tri[t]), v1 = vtx(xyz, V, tri[T + t]), v2 = vtx(xyz, V, tri[2 * T + t]);
+        TriRec &r = recs[t];
+        r.v0[0] = v0.x, r.v0[1] = v0.y, r.v0[2] = v0.z;
+        r.v1[0] = v1.x, r.v1[1] = v1.y, r.v1[2] = v1.z;
+        r.v2[0] = v2.x, r.v2[1] = v2.y, r.v2[2] = v2.z;
+        V3 s3;
+        plane_of(v0, v1, v2, s3, r.d);  // distance_to_triangle calls project_point(pt, v0, v1, v2), R/octree.cpp:149
+        r.s3[0] = s3.x, r.s3[1] = s3.y, r.s3[2] = s3.z;
+        r.id[0] = tri[t], r.id[1] = tri[T + t], r.id[2] = tri[2 * T + t];
+        r.tri = t;
+        tcone[t] = bounding_cone(v0, v1, v2, r);
+    }
+
+    const int n = (int)b.nodes.size();
+    out.node.resize(n);
+    out.parent.resize(n);
+    out.leaf_tri.clear();
+    out.cone.clear();
+    int64_t leaves = 0, maxleaf = 0;
+    for (int i = 0; i < n; ++i) {
+        const BNode &nd = b.nodes[i];
+        out.parent[i] = nd.parent;
+        if (nd.first_child >= 0) {
+            out.node[i] = make_int2(nd.first_child, 0);
+        } else {
+            out.node[i] = make_int2(-(int)nd.tris.size() - 1, (int)out.leaf_tri.size());
+            for (int32_t t : nd.tris) {
+                out.leaf_tri.push_back(t);
+                out.cone.push_back(tcone[t]);
+            }
+            ++leaves;
+            maxleaf = std::max<int64_t>(maxleaf, (int64_t)nd.tris.size());
+        }
+    }
+    // depth: children always follow their parent in the node array
+    std::vector<int> depth(n, 0);
+    int maxdepth = 0;
+    for (int i = 1; i < n; ++i) {
+        depth[i] = depth[out.parent[i]] + 1;
+        maxdepth = std::max(maxdepth, depth[i]);
+    }
+    out.stats[0] = n;
+    out.stats[1] = leaves;
+    out.stats[2] = maxdepth;
+    out.stats[3] = (int64_t)out.leaf_tri.size();
+    out.stats[4] = maxleaf;
+}
+
+}  // namespace msm

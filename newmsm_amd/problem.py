@@ -1,0 +1,58 @@
+"""Assembles one discrete-optimisation iteration of a pairwise registration (what
+NonLinearSRegDiscreteModel::Initialize + setupCostFunction prepare, M/DiscreteModel.cpp:63-108, :216-262)
+from synthetic inputs, using only libmsmhip's [host] entry points.  Returns plain numpy arrays so that
+tests can feed the very same numbers to the oracle.
+"""
+import numpy as np
+
+from . import api, synthetic
+
+
+def pairwise_inputs(data_order=6, cp_order=4, sg_order=None, D=1, seed=1234, warp_amp=0.6, warp_rot=2.0, rescale=True,
+                    labeldist=0.5):
+    """Inputs of one iteration: target / source / control grids, features, labels, rotations, cliques."""
+    if sg_order is None:
+        sg_order = cp_order + 2
+    txyz, ttri = api.make_mesh_from_icosa(data_order)  # reference sphere (regular)
+    cxyz, ctri = api.make_mesh_from_icosa(cp_order)    # control grid
+    # source: the data sphere part-way through a registration (smoothly warped), features of the moving image
+    sxyz = synthetic.known_warp(txyz, seed=seed + 1, rot_deg=warp_rot, amp=warp_amp)
+    ref_feat = synthetic.features(txyz, D, seed)
+    src_feat = synthetic.features(synthetic.known_warp(txyz, seed=seed + 2, rot_deg=1.5 * warp_rot, amp=2 * warp_amp), D, seed)
+    # the control grid rides along with the source (warp_CPgrid): move it through the same warp
+    cxyz_cur = synthetic.known_warp(cxyz, seed=seed + 1, rot_deg=warp_rot, amp=warp_amp)
+    maxsep, mvdmax = api.cp_spacings(cxyz_cur, ctri)
+    samples, barycentres = api.label_sampling_grid(sg_order, labeldist * mvdmax)
+    if rescale:
+        labels, _ = api.rescale_sampling_grid(samples, 1.0)
+    else:
+        labels = samples
+    rot = api.cp_rotations(samples[0], cxyz_cur)
+    return dict(data_order=data_order, cp_order=cp_order, sg_order=sg_order, D=D,
+                target_xyz=txyz, target_tri=ttri, source_xyz=sxyz, source_tri=ttri, source_orig_xyz=txyz,
+                cp_xyz=cxyz_cur, cp_orig_xyz=cxyz, cp_tri=ctri, ref_feat=ref_feat, src_feat=src_feat,
+                maxsep=maxsep, mvdmax=mvdmax, samples=samples, barycentres=barycentres, labels=labels, rot=rot,
+                triplets=api.estimate_triplets(ctri), pairs=api.estimate_pairs(ctri, len(cxyz)))
+
+
+def build_cost(ctx, inp, kind="univariate", simmeasure=2, rmode=3, **params):
+    """Product-side objects for `inp` (set_meshes happens with the ORIGINAL source / control grid, as in
+    Initialize(); the current coordinates arrive through reset_source / reset_CPgrid)."""
+    target = api.Mesh(ctx, inp["target_xyz"], inp["target_tri"])
+    target.set_pvalues(inp["ref_feat"])
+    source = api.Mesh(ctx, inp["source_orig_xyz"], inp["source_tri"])
+    cpgrid = api.Mesh(ctx, inp["cp_orig_xyz"], inp["cp_tri"])
+    cf = api.DiscreteCostFunction(ctx, kind=kind, simmeasure=simmeasure, rmode=rmode, **params)
+    cf.set_meshes(target, source, cpgrid)
+    source.set_coords(inp["source_xyz"])
+    cpgrid.set_coords(inp["cp_xyz"])
+    cf.reset_source(source)
+    cf.reset_CPgrid(cpgrid)
+    cf.set_featurespace(inp["src_feat"])
+    cf.set_spacings(inp["maxsep"], inp["mvdmax"])
+    cf.set_labels(inp["labels"], inp["rot"])
+    if rmode == 1:
+        cf.setPairs(inp["pairs"])
+    else:
+        cf.setTriplets(inp["triplets"])
+    return cf, dict(target=target, source=source, cpgrid=cpgrid)

@@ -1,0 +1,170 @@
+"""Nearest-triangle search and resampling on the GPU against the oracle.  Index results (triangle,
+vertex ids, patch membership, CSR structure) must be bit-exact; barycentric weights too, because the
+kernels use the reference's FP64 operation order (no FMA contraction, no transcendental on this path)."""
+import numpy as np
+import pytest
+
+import newmsm_amd as M
+from newmsm_amd import synthetic
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def queries(xyz, n, seed):
+    """mix of: rotated mesh vertices (land on/near vertices and edges), random points, exact vertices, edge midpoints"""
+    rng = np.random.default_rng(seed)
+    R = synthetic.rotation(rng.normal(size=3), 2.5)
+    a = (xyz @ R.T)[rng.permutation(len(xyz))[: n // 2]]
+    b = synthetic.random_sphere_points(n // 4, seed + 1)
+    c = xyz[rng.permutation(len(xyz))[: n // 8]]
+    i, j = rng.integers(0, len(xyz), n // 8), rng.integers(0, len(xyz), n // 8)
+    d = xyz[i] + xyz[j]
+    nrm = np.linalg.norm(d, axis=1, keepdims=True)
+    d = np.where(nrm > 1e-6, d / np.maximum(nrm, 1e-6) * 100.0, xyz[i])
+    return np.concatenate([a, b, c, d])
+
+
+@pytest.mark.parametrize("order", [2, 4, 5])
+def test_octree_layout_matches_oracle(ctx, order):
+    xyz, tri = M.make_mesh_from_icosa(order)
+    m = M.Mesh(ctx, xyz, tri)
+    assert m.octree_stats() == O.Octree(O.Mesh(xyz, tri)).stats()
+
+
+def test_octree_stats_ico6_pin(ctx):
+    m = M.Mesh(ctx, *M.make_mesh_from_icosa(6))
+    assert m.octree_stats() == dict(nodes=14281, leaves=12496, depth=6, refs=176096, max_leaf=49)
+
+
+@pytest.mark.parametrize("order,n", [(1, 500), (3, 4000), (5, 20000)])
+@pytest.mark.parametrize("mode", [M.WEIGHTS_PROJECTED, M.WEIGHTS_RAW])
+def test_query_bit_exact_regular_sphere(ctx, order, n, mode):
+    xyz, tri = M.make_mesh_from_icosa(order)
+    q = queries(xyz, n, seed=order)
+    st, t, vid, w = M.Mesh(ctx, xyz, tri).query_triangles(q, mode=mode)
+    ost, ot, ovid, ow = O.Octree(O.Mesh(xyz, tri)).barycentric_weights(q, raw=(mode == M.WEIGHTS_RAW))
+    assert st == 0 and ost == 0
+    assert np.array_equal(t, ot)
+    assert np.array_equal(vid, ovid)
+    assert np.array_equal(w, ow)  # bit-exact
+
+
+def test_query_bit_exact_warped_sphere(ctx):
+    xyz, tri = M.make_mesh_from_icosa(5)
+    wxyz = synthetic.known_warp(xyz, seed=11, rot_deg=4.0, amp=1.5)
+    q = queries(xyz, 20000, seed=9)
+    st, t, vid, w = M.Mesh(ctx, wxyz, tri).query_triangles(q)
+    ost, ot, ovid, ow = O.Octree(O.Mesh(wxyz, tri)).barycentric_weights(q)
+    assert st == 0 and ost == 0
+    assert np.array_equal(t, ot) and np.array_equal(vid, ovid) and np.array_equal(w, ow)
+
+
+def test_query_folded_mesh_uses_reference_tie_breaks(ctx):
+    # strong high-frequency warp: folds and slivers -> several triangles pass the inside test, fallbacks fire
+    xyz, tri = M.make_mesh_from_icosa(4)
+    rng = np.random.default_rng(5)
+    wxyz = xyz + rng.normal(scale=1.5, size=xyz.shape)
+    wxyz = wxyz / np.linalg.norm(wxyz, axis=1, keepdims=True) * 100.0
+    q = queries(xyz, 8000, seed=2)
+    st, t, vid, w = M.Mesh(ctx, wxyz, tri).query_triangles(q, check_status=False)
+    ost, ot, ovid, ow = O.Octree(O.Mesh(wxyz, tri)).barycentric_weights(q)
+    assert np.array_equal(t, ot)
+    ok = ot >= 0
+    assert np.array_equal(vid[ok], ovid[ok]) and np.array_equal(w[ok], ow[ok])
+    assert (st == 0) == (ost == 0)
+
+
+def test_query_outside_root_box_reports_reference_error(ctx):
+    xyz, tri = M.make_mesh_from_icosa(2)
+    m = M.Mesh(ctx, xyz, tri)
+    q = np.array([[0.0, 0.0, 100.0], [0.0, 150.0, 0.0]])
+    with pytest.raises(M.MsmError) as e:
+        m.query_triangles(q)
+    assert e.value.code == -3 and "bounding box" in str(e.value)
+    st, t, _, _ = m.query_triangles(q, check_status=False)
+    assert t[0] >= 0 and t[1] == -3
+    # the context stays usable
+    st, t, _, _ = m.query_triangles(q[:1])
+    assert st == 0
+
+
+def test_empty_and_ragged_inputs(ctx):
+    xyz, tri = M.make_mesh_from_icosa(2)
+    m = M.Mesh(ctx, xyz, tri)
+    st, t, vid, w = m.query_triangles(np.zeros((0, 3)))
+    assert st == 0 and len(t) == 0
+    for n in (1, 63, 64, 65, 257):
+        q = synthetic.random_sphere_points(n, seed=n)
+        _, t, _, _ = m.query_triangles(q)
+        assert np.array_equal(t, O.Octree(O.Mesh(xyz, tri)).closest_triangle(q))
+
+
+def test_closest_vertex(ctx):
+    xyz, tri = M.make_mesh_from_icosa(4)
+    q = queries(xyz, 6000, seed=4)
+    got = M.Mesh(ctx, xyz, tri).get_closest_vertex_ID(q)
+    assert np.array_equal(got, O.Octree(O.Mesh(xyz, tri)).closest_vertex(q))
+
+
+def test_update_coords_rebuilds_search_structure(ctx):
+    xyz, tri = M.make_mesh_from_icosa(4)
+    m = M.Mesh(ctx, xyz, tri)
+    q = queries(xyz, 3000, seed=8)
+    m.query_triangles(q)
+    wxyz = synthetic.known_warp(xyz, seed=3, rot_deg=10.0, amp=2.0)
+    m.set_coords(wxyz)
+    _, t, vid, w = m.query_triangles(q)
+    _, ot, ovid, ow = O.Octree(O.Mesh(wxyz, tri)).barycentric_weights(q)
+    assert np.array_equal(t, ot) and np.array_equal(w, ow)
+
+
+@pytest.mark.parametrize("oin,onew", [(4, 3), (3, 4), (5, 4)])
+def test_adaptive_barycentric_weights_bit_exact(ctx, oin, onew):
+    xin, tin = M.make_mesh_from_icosa(oin)
+    xnew, tnew = M.make_mesh_from_icosa(onew)
+    xin = synthetic.known_warp(xin, seed=21, rot_deg=5.0, amp=1.0)
+    rp, col, val = M.get_adaptive_barycentric_weights(M.Mesh(ctx, xin, tin), M.Mesh(ctx, xnew, tnew))
+    orp, ocol, oval = O.adaptive_barycentric_weights(O.Mesh(xin, tin), O.Mesh(xnew, tnew))
+    assert np.array_equal(rp, orp) and np.array_equal(col, ocol) and np.array_equal(val, oval)
+    # rows are convex combinations
+    sums = np.add.reduceat(val, rp[:-1])
+    assert np.allclose(sums, 1.0, atol=1e-14)
+
+
+def test_adaptive_weights_with_exclusion(ctx):
+    xin, tin = M.make_mesh_from_icosa(4)
+    xnew, tnew = M.make_mesh_from_icosa(3)
+    excl = (xin[:, 2] > -20).astype(float)
+    rp, col, val = M.get_adaptive_barycentric_weights(M.Mesh(ctx, xin, tin), M.Mesh(ctx, xnew, tnew), excl)
+    orp, ocol, oval = O.adaptive_barycentric_weights(O.Mesh(xin, tin), O.Mesh(xnew, tnew), excl)
+    assert np.array_equal(rp, orp) and np.array_equal(col, ocol) and np.array_equal(val, oval)
+    assert (np.diff(rp) == 0).any()  # excluded rows are empty
+
+
+def test_metric_resample_warp_and_nn(ctx):
+    xin, tin = M.make_mesh_from_icosa(5)
+    xnew, tnew = M.make_mesh_from_icosa(4)
+    data = synthetic.features(xin, 3)
+    min_, mnew = M.Mesh(ctx, xin, tin), M.Mesh(ctx, xnew, tnew)
+    oin, onew = O.Mesh(xin, tin), O.Mesh(xnew, tnew)
+    assert np.array_equal(M.metric_resample(min_, data, mnew), O.metric_resample(oin, data, onew))
+    # sphere_project_warp: carry a fine sphere through a coarse deformation
+    to = synthetic.known_warp(xnew, seed=5, rot_deg=6.0, amp=2.0)
+    assert np.array_equal(M.sphere_project_warp(xin, mnew, to), O.sphere_project_warp(xin, onew, to))
+    q = queries(xin, 3000, seed=6)
+    assert np.array_equal(M.nearest_neighbour_interpolation(min_, data, q), O.nearest_neighbour(oin, data, q))
+
+
+def test_warp_roundtrip_property(ctx):
+    # size-independent property at full size: warping through the identity deformation leaves an ico6 sphere
+    # where it is (to rounding), and through a rigid rotation rotates it
+    x6, t6 = M.make_mesh_from_icosa(6)
+    x4, t4 = M.make_mesh_from_icosa(4)
+    m4 = M.Mesh(ctx, x4, t4)
+    same = M.sphere_project_warp(x6, m4, x4)
+    assert np.max(np.abs(same - x6)) < 1e-10
+    R = synthetic.rotation([0.3, -1.0, 0.5], 7.0)
+    rot = M.sphere_project_warp(x6, m4, x4 @ R.T)
+    assert np.max(np.abs(rot - x6 @ R.T)) < 0.05  # piecewise-linear interpolation of a rotation, then re-projection
+    assert np.allclose(np.linalg.norm(rot, axis=1), 100.0, atol=1e-10)

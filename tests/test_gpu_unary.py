@@ -1,0 +1,91 @@
+"""Unary label-cost evaluation on the GPU against the oracle.
+
+Tolerance: patch membership, AbsoluteWeights and triangle choices are exact; the cost values go through
+acos/sincos (device libm vs glibc, <= 1-2 ulp) and a wavefront-parallel summation instead of the
+reference's serial one, so costs are compared to rtol 1e-10 / atol 1e-12 (north_star's bar is 1e-4 rad
+on final coordinates)."""
+import numpy as np
+import pytest
+
+import newmsm_amd as M
+from newmsm_amd import problem
+from tests.helpers import oracle_cost
+
+pytestmark = pytest.mark.gpu
+RTOL, ATOL = 1e-10, 1e-12
+
+
+def run_pair(ctx, inp, kind, **kw):
+    cf, keep = problem.build_cost(ctx, inp, kind=kind, **kw)
+    cf.get_source_data()
+    oc = oracle_cost(inp, kind, **kw)
+    oc.get_source_data()
+    return cf, oc, keep
+
+
+@pytest.mark.parametrize("data_order,cp_order", [(4, 2), (5, 3)])
+def test_source_data_exact(ctx, data_order, cp_order):
+    inp = problem.pairwise_inputs(data_order, cp_order, D=1)
+    cf, oc, _ = run_pair(ctx, inp, "univariate")
+    ptr, idx = cf.patches()
+    optr, oidx = oc.patches()
+    assert np.array_equal(ptr, optr) and np.array_equal(idx, oidx)
+    assert np.array_equal(cf.absolute_weights(), oc.absolute_weights())
+
+
+def test_source_data_exact_ties_regular_grids(ctx):
+    # un-warped grids: every control point's farthest neighbour sits exactly on the range threshold
+    inp = problem.pairwise_inputs(5, 3, D=1, warp_amp=0.0, warp_rot=0.0)
+    cf, oc, _ = run_pair(ctx, inp, "univariate")
+    ptr, idx = cf.patches()
+    optr, oidx = oc.patches()
+    assert np.array_equal(ptr, optr) and np.array_equal(idx, oidx)
+
+
+@pytest.mark.parametrize("data_order,cp_order,sim", [(4, 2, 2), (5, 3, 2), (5, 3, 1)])
+def test_unary_table_univariate(ctx, data_order, cp_order, sim):
+    inp = problem.pairwise_inputs(data_order, cp_order, D=1)
+    cf, oc, _ = run_pair(ctx, inp, "univariate", simmeasure=sim)
+    U = cf.computeUnaryCosts()
+    Uo = oc.unary_table()
+    assert U.shape == Uo.shape == (len(inp["labels"]), len(inp["cp_xyz"]))
+    assert np.isfinite(U).all()
+    assert np.allclose(U, Uo, rtol=RTOL, atol=ATOL), np.max(np.abs(U - Uo))
+    # on-demand evaluation (Fusion's per-label sweep) returns the same numbers
+    nodes = np.arange(0, cf.N, 7, dtype=np.int32)
+    labels = (nodes * 5) % cf.L
+    assert np.array_equal(cf.computeUnaryCost(nodes, labels), U[labels, nodes])
+
+
+def test_unary_table_with_cfweight_and_samples_set(ctx):
+    inp = problem.pairwise_inputs(5, 3, D=1, rescale=False)
+    rng = np.random.default_rng(0)
+    w = rng.uniform(0.2, 1.0, size=(1, len(inp["source_xyz"])))
+    cf, keep = problem.build_cost(ctx, inp, kind="univariate")
+    cf.set_dataaffintyweighting(w)
+    cf.get_source_data()
+    oc = oracle_cost(inp, "univariate")
+    oc.set_cfweight(w)
+    oc.get_source_data()
+    assert np.array_equal(cf.absolute_weights(), oc.absolute_weights())
+    assert np.allclose(cf.computeUnaryCosts(), oc.unary_table(), rtol=RTOL, atol=ATOL)
+
+
+def test_full_size_properties_ico6(ctx):
+    # BASELINE config 2 size (ico6 data / ico4 control grid): checked through size-independent properties
+    inp = problem.pairwise_inputs(6, 4, D=1)
+    cf, keep = problem.build_cost(ctx, inp, kind="univariate")
+    cf.get_source_data()
+    ptr, idx = cf.patches()
+    assert len(ptr) == 2563 and 40 <= np.diff(ptr).min() and np.diff(ptr).max() <= 90
+    U = cf.computeUnaryCosts()
+    assert U.shape == (19, 2562) and np.isfinite(U).all()
+    assert (U >= -1e-12).all() and (U <= 1.0 + 1e-9).all()  # AbsW * (1 - (1 + r)/2), r in [-1, 1]
+    assert np.array_equal(U, cf.computeUnaryCosts())          # deterministic
+    # spot-check 40 (node,label) evaluations against the oracle at full size
+    oc = oracle_cost(inp, "univariate")
+    oc.get_source_data()
+    rng = np.random.default_rng(1)
+    for n, l in zip(rng.integers(0, 2562, 40), rng.integers(0, 19, 40)):
+        assert abs(U[l, n] - oc.unary(n, l)) <= ATOL + RTOL * abs(U[l, n])
+    assert cf.counters()["samples"] == 2 * 19 * int(ptr[-1])
