@@ -138,7 +138,8 @@ def test_adaptive_weights_with_exclusion(ctx):
     excl = (xin[:, 2] > -20).astype(float)
     rp, col, val = M.get_adaptive_barycentric_weights(M.Mesh(ctx, xin, tin), M.Mesh(ctx, xnew, tnew), excl)
     orp, ocol, oval = O.adaptive_barycentric_weights(O.Mesh(xin, tin), O.Mesh(xnew, tnew), excl)
-    assert np.array_equal(rp, orp) and np.array_equal(col, ocol) and np.array_equal(val, oval)
+    # rows next to the mask edge divide 0 by a zero scatter-sum in the reference too (NaN): compare NaN-aware
+    assert np.array_equal(rp, orp) and np.array_equal(col, ocol) and np.array_equal(val, oval, equal_nan=True)
     assert (np.diff(rp) == 0).any()  # excluded rows are empty
 
 
