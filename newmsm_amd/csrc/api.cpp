@@ -46,12 +46,14 @@ int ensure_tree(msm_mesh *m) {
     MSM_HIP(grow((void **)&m->d_leaf_tri, m->cap_leaf, m->tree.leaf_tri.size(), sizeof(int32_t)));
     MSM_HIP(grow((void **)&m->d_cone, cap_cone, m->tree.leaf_tri.size(), sizeof(float4)));
     MSM_HIP(grow((void **)&m->d_rec, m->cap_rec, recs.size(), sizeof(TriRec)));
+    MSM_HIP(grow((void **)&m->d_grid, m->cap_grid, m->tree.grid.size(), sizeof(int32_t)));
     // the staging vectors die at scope exit, so these copies must complete here
     MSM_HIP(hipMemcpyAsync(m->d_node, m->tree.node.data(), m->tree.node.size() * sizeof(int2), hipMemcpyHostToDevice, ctx->stream));
     MSM_HIP(hipMemcpyAsync(m->d_parent, m->tree.parent.data(), m->tree.parent.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
     MSM_HIP(hipMemcpyAsync(m->d_leaf_tri, m->tree.leaf_tri.data(), m->tree.leaf_tri.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
     MSM_HIP(hipMemcpyAsync(m->d_cone, m->tree.cone.data(), m->tree.cone.size() * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
     MSM_HIP(hipMemcpyAsync(m->d_rec, recs.data(), recs.size() * sizeof(TriRec), hipMemcpyHostToDevice, ctx->stream));
+    MSM_HIP(hipMemcpyAsync(m->d_grid, m->tree.grid.data(), m->tree.grid.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
     MSM_HIP(hipStreamSynchronize(ctx->stream));
     m->tree_valid = true;
     return MSM_OK;
@@ -64,6 +66,8 @@ DevTree dev_tree(const msm_mesh *m) {
     t.leaf_tri = m->d_leaf_tri;
     t.cone = m->d_cone;
     t.rec = m->d_rec;
+    t.grid = m->d_grid;
+    t.grid_depth = m->tree.grid_depth;
     t.nnodes = (int)m->tree.node.size();
     return t;
 }
@@ -304,7 +308,7 @@ void msm_mesh_destroy(msm_mesh *m) {
     if (!m) return;
     (void)hipSetDevice(m->ctx->device);
     (void)hipStreamSynchronize(m->ctx->stream);
-    for (void *p : {(void *)m->d_xyz, (void *)m->d_feat, (void *)m->d_node, (void *)m->d_parent, (void *)m->d_leaf_tri, (void *)m->d_cone, (void *)m->d_rec})
+    for (void *p : {(void *)m->d_xyz, (void *)m->d_feat, (void *)m->d_node, (void *)m->d_parent, (void *)m->d_leaf_tri, (void *)m->d_cone, (void *)m->d_rec, (void *)m->d_grid})
         if (p) (void)hipFree(p);
     delete m;
 }

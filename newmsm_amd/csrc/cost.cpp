@@ -36,6 +36,7 @@ struct msm_cost {
     int L = 0;
     std::vector<double> labels, rot;
     DevBuf<double> d_labels, d_rot;
+    DevBuf<double> d_rnl, d_moved;  // per (node,label): rotation matrix and moved control point
     std::vector<int32_t> triplets, pairs;
     DevBuf<int32_t> d_triplets, d_pairs;
     DevBuf<double> d_orig, d_ocp;
@@ -183,7 +184,11 @@ int ensure_unary_table(msm_cost *c) {
     u.N = N;
     u.L = c->L;
     u.cp = c->cpgrid->d_xyz;
-    u.rot = c->d_rot.p;
+    MSM_HIP(c->d_rnl.ensure((size_t)N * c->L * 9));
+    MSM_HIP(c->d_moved.ensure((size_t)N * c->L * 3));
+    st = launch_label_rotations(ctx, c->cpgrid->d_xyz, N, c->d_rot.p, c->d_labels.p, c->L, c->d_rnl.p, c->d_moved.p);
+    if (st) return st;
+    u.rnl = c->d_rnl.p;
     u.labels = c->d_labels.p;
     u.src = c->source->d_xyz;
     u.Nsrc = c->source->V;

@@ -49,6 +49,11 @@ struct FlatOctree {
     std::vector<int32_t> parent;
     std::vector<int32_t> leaf_tri;
     std::vector<float4> cone;  // per leaf entry: unit axis (xyz) and |cos| threshold (w) of the conservative bounding cone
+    // Dense top of the tree: the node reached after grid_depth levels of descent (or the leaf met earlier),
+    // indexed [ix][iy][iz] with G = 2^grid_depth cells per axis over (-101, 101).  Child boxes are exact
+    // halvings, so the cell of a point is found arithmetically and the descent starts there.
+    std::vector<int32_t> grid;
+    int grid_depth = 0;
     int64_t stats[5] = {0, 0, 0, 0, 0};
 };
 // builds the tree exactly as Octree::initialize_tree / add_triangle do (R/octree.cpp:42-141)
@@ -62,6 +67,8 @@ struct DevTree {
     const int32_t *leaf_tri;
     const float4 *cone;
     const TriRec *rec;
+    const int32_t *grid;
+    int grid_depth;  // G = 1 << grid_depth cells per axis
     int nnodes;
 };
 
@@ -92,7 +99,8 @@ struct msm_mesh {
     int32_t *d_leaf_tri = nullptr;
     float4 *d_cone = nullptr;
     msm::TriRec *d_rec = nullptr;
-    size_t cap_node = 0, cap_leaf = 0, cap_rec = 0;
+    int32_t *d_grid = nullptr;
+    size_t cap_node = 0, cap_leaf = 0, cap_rec = 0, cap_grid = 0;
     msm::Adjacency adj;
     bool adj_valid = false;
 };

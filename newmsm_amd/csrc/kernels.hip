@@ -23,8 +23,7 @@ __global__ __launch_bounds__(256) void k_query(DevTree T, const double *__restri
                                                 int *__restrict__ vid, double *__restrict__ w, int mode, int *status) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
         const V3 p = mk(q[i], q[N + i], q[2 * N + i]);
-        Hit h;
-        const int t = find_closest_triangle(T, p, h);
+        const int t = find_closest_triangle(T, p);
         if (t < 0) {
             raise_status(status, t);
             if (tri_id) tri_id[i] = t;
@@ -32,17 +31,19 @@ __global__ __launch_bounds__(256) void k_query(DevTree T, const double *__restri
             if (w) w[i] = w[N + i] = w[2 * N + i] = 0.0;
             continue;
         }
+        const TriRec &r = T.rec[t];
         if (tri_id) tri_id[i] = t;
         if (vid) {
-            vid[i] = h.id0;
-            vid[N + i] = h.id1;
-            vid[2 * N + i] = h.id2;
+            vid[i] = r.id[0];
+            vid[N + i] = r.id[1];
+            vid[2 * N + i] = r.id[2];
         }
         if (w) {
             // calc_barycentric_weights projects the query first (R/triangle.cpp:130); barycentric_interpolation does not
-            const V3 pp = (mode == MSM_WEIGHTS_PROJECTED) ? project_point(p, h.v0, h.v1, h.v2) : p;
+            const V3 v0 = rec_v0(r), v1 = rec_v1(r), v2 = rec_v2(r);
+            const V3 pp = (mode == MSM_WEIGHTS_PROJECTED) ? project_point(p, v0, v1, v2) : p;
             double wa, wb, wc;
-            area_weights(h.v0, h.v1, h.v2, pp, wa, wb, wc);
+            area_weights(v0, v1, v2, pp, wa, wb, wc);
             w[i] = wa;
             w[N + i] = wb;
             w[2 * N + i] = wc;
@@ -54,17 +55,17 @@ __global__ __launch_bounds__(256) void k_query(DevTree T, const double *__restri
 __global__ __launch_bounds__(256) void k_closest_vertex(DevTree T, const double *__restrict__ q, int N, int *__restrict__ out, int *status) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
         const V3 p = mk(q[i], q[N + i], q[2 * N + i]);
-        Hit h;
-        const int t = find_closest_triangle(T, p, h);
+        const int t = find_closest_triangle(T, p);
         if (t < 0) {
             raise_status(status, t);
             out[i] = t;
             continue;
         }
+        const TriRec &r = T.rec[t];
         double dist = DBL_MAX;
         int best = 0;
-        const V3 vv[3] = {h.v0, h.v1, h.v2};
-        const int ids[3] = {h.id0, h.id1, h.id2};
+        const V3 vv[3] = {rec_v0(r), rec_v1(r), rec_v2(r)};
+        const int ids[3] = {r.id[0], r.id[1], r.id[2]};
 #pragma unroll
         for (int v = 0; v < 3; ++v) {
             const double d = norm(sub(p, vv[v]));
@@ -145,7 +146,7 @@ struct UnaryArgs {
     int N;                // control points
     int L;                // labels
     const double *cp;     // 3 x N SoA
-    const double *rot;    // N x 9
+    const double *rnl;    // N x L x 9: estimate_rotation_matrix(CP[node], ROT[node]*label[l]) from k_label_rotations
     const double *labels; // 3 x L SoA
     const double *src;    // 3 x Nsrc SoA
     int Nsrc;
@@ -186,36 +187,27 @@ __global__ __launch_bounds__(256) void k_unary_univariate(UnaryArgs a) {
         sA[i] = a.sfeat[s];
         sW[i] = (a.cfw && a.cfw_rows >= 1) ? a.cfw[s] : 1.0;
     }
-    const V3 cpt = mk(a.cp[node], a.cp[a.N + node], a.cp[2 * a.N + node]);
     const double absw = a.absw[node];
 
     for (int l0 = 0; l0 < a.L; l0 += a.lchunk) {
         const int nl = min(a.lchunk, a.L - l0);
         __syncthreads();  // patch ready / previous chunk consumed
-        if (tid < nl) {
-            const int l = l0 + tid;
-            const V3 lab = mk(a.labels[l], a.labels[a.L + l], a.labels[2 * a.L + l]);
-            const V3 moved = rotate(a.rot + 9 * (size_t)node, lab);
-            double R[9];
-            if (!rotation_matrix(cpt, moved, R)) raise_status(a.status, MSM_ERR_ROTATION);
-#pragma unroll
-            for (int k = 0; k < 9; ++k) sR[9 * tid + k] = R[k];
-        }
+        for (int k = tid; k < 9 * nl; k += 256) sR[k] = a.rnl[((size_t)node * a.L + l0) * 9 + k];
         __syncthreads();
         const int total = nl * P;
         for (int s = tid; s < total; s += 256) {
             const int ll = s / P, i = s - ll * P;
             const V3 p = rotate(sR + 9 * ll, mk(sx[i], sy[i], sz[i]));
-            Hit h;
-            const int t = find_closest_triangle(a.tree, p, h);
+            const int t = find_closest_triangle(a.tree, p);
             double val;
             if (t < 0) {
                 raise_status(a.status, t);
                 val = __longlong_as_double(0x7ff8000000000000ll);
             } else {
+                const TriRec &r = a.tree.rec[t];
                 double wa, wb, wc;
-                area_weights(h.v0, h.v1, h.v2, p, wa, wb, wc);  // barycentric_interpolation: raw point
-                val = wa * a.tfeat[h.id0] + wb * a.tfeat[h.id1] + wc * a.tfeat[h.id2];
+                area_weights(rec_v0(r), rec_v1(r), rec_v2(r), p, wa, wb, wc);  // barycentric_interpolation: raw point
+                val = wa * a.tfeat[r.id[0]] + wb * a.tfeat[r.id[1]] + wc * a.tfeat[r.id[2]];
             }
             sT[ll * a.pmax + i] = val;
         }
@@ -272,6 +264,38 @@ __global__ __launch_bounds__(256) void k_unary_univariate(UnaryArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// The rotation every (control point, label) evaluation starts with:
+// estimate_rotation_matrix(_CPgrid[node], ROTATIONS[node] * labels[label]), M/DiscreteCostFunction.cpp:380.
+// Kept out of the table kernels: acos/sincos would otherwise set their register budget.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_label_rotations(const double *__restrict__ cp, int N, const double *__restrict__ rot,
+                                                          const double *__restrict__ labels, int L, double *__restrict__ rnl,
+                                                          double *__restrict__ moved_out, int *status) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * L) return;
+    const int node = i / L, l = i - node * L;
+    const V3 lab = mk(labels[l], labels[L + l], labels[2 * L + l]);
+    const V3 moved = rotate(rot + 9 * (size_t)node, lab);
+    if (moved_out) {
+        moved_out[3 * (size_t)i] = moved.x;
+        moved_out[3 * (size_t)i + 1] = moved.y;
+        moved_out[3 * (size_t)i + 2] = moved.z;
+    }
+    double R[9];
+    if (!rotation_matrix(mk(cp[node], cp[N + node], cp[2 * N + node]), moved, R)) raise_status(status, MSM_ERR_ROTATION);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) rnl[9 * (size_t)i + k] = R[k];
+}
+
+int launch_label_rotations(msm_ctx *ctx, const double *d_cp, int N, const double *d_rot, const double *d_labels, int L, double *d_rnl,
+                           double *d_moved) {
+    hipLaunchKernelGGL(k_label_rotations, dim3((N * L + 255) / 256), dim3(256), 0, ctx->stream, d_cp, N, d_rot, d_labels, L, d_rnl, d_moved,
+                       ctx->d_status);
+    MSM_HIP(hipGetLastError());
+    return MSM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // launch wrappers
 // ------------------------------------------------------------------------------------------------
 static inline int grid_for(int n, int block, int cap) {
@@ -309,7 +333,7 @@ int launch_unary_univariate(msm_ctx *ctx, const UnaryLaunch &u) {
     a.N = u.N;
     a.L = u.L;
     a.cp = u.cp;
-    a.rot = u.rot;
+    a.rnl = u.rnl;
     a.labels = u.labels;
     a.src = u.src;
     a.Nsrc = u.Nsrc;

@@ -10,13 +10,17 @@ int launch_closest_vertex(msm_ctx *ctx, const DevTree &T, const double *d_q, int
 int launch_range(msm_ctx *ctx, const double *d_cp, int Ncp, const double *d_src, int Nsrc, const double *d_maxsep, double range, int cap,
                  uint32_t *d_slots, int *d_counts);
 
+// rnl[(node*L + l)*9..] = estimate_rotation_matrix(cp[node], rot[node]*labels[l]); moved (optional, N x L x 3 AoS) = rot[node]*labels[l]
+int launch_label_rotations(msm_ctx *ctx, const double *d_cp, int N, const double *d_rot, const double *d_labels, int L, double *d_rnl,
+                           double *d_moved);
+
 struct UnaryLaunch {
     DevTree tree;
     const double *tfeat;   // target features, V x D vertex-major
     int D;
     int N, L;
     const double *cp;      // 3 x N
-    const double *rot;     // N x 9
+    const double *rnl;     // N x L x 9 from launch_label_rotations
     const double *labels;  // 3 x L
     const double *src;     // 3 x Nsrc
     int Nsrc;

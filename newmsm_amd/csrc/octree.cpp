@@ -198,6 +198,29 @@ void build_octree(const double *xyz, const int32_t *tri, int V, int T, FlatOctre
         depth[i] = depth[out.parent[i]] + 1;
         maxdepth = std::max(maxdepth, depth[i]);
     }
+    // dense top grid: every node at depth <= grid_depth that is a leaf, or sits at grid_depth, owns a cube of cells
+    out.grid_depth = std::min(maxdepth, 6);
+    const int G = 1 << out.grid_depth;
+    out.grid.assign((size_t)G * G * G, 0);
+    {
+        struct Item { int node, depth, ix, iy, iz; };
+        std::vector<Item> stack{{0, 0, 0, 0, 0}};
+        while (!stack.empty()) {
+            const Item it = stack.back();
+            stack.pop_back();
+            const BNode &nd = b.nodes[it.node];
+            if (nd.first_child < 0 || it.depth == out.grid_depth) {
+                const int span = 1 << (out.grid_depth - it.depth);
+                for (int x = 0; x < span; ++x)
+                    for (int y = 0; y < span; ++y)
+                        for (int z = 0; z < span; ++z)
+                            out.grid[((size_t)(it.ix * span + x) * G + (it.iy * span + y)) * G + (it.iz * span + z)] = it.node;
+            } else {
+                for (int c = 0; c < 8; ++c)
+                    stack.push_back({nd.first_child + c, it.depth + 1, 2 * it.ix + ((c >> 2) & 1), 2 * it.iy + ((c >> 1) & 1), 2 * it.iz + (c & 1)});
+            }
+        }
+    }
     out.stats[0] = n;
     out.stats[1] = leaves;
     out.stats[2] = maxdepth;

@@ -8,102 +8,154 @@
 //   3. if none: the same test over the 8 children of the leaf's parent;
 //   4. if none: the triangle owning the vertex with the smallest geodesic distance among those.
 // The device code makes the same decisions with the same FP64 arithmetic.  What it changes is cost:
-//   - the descent needs no node bounds: child boxes are halvings of (-101,101), recomputed on the fly
-//     with the reference's own (lo+hi)/2.0, so a level costs three compares and one 8-byte load;
+//   - child boxes are exact halvings of (-101,101), so the first grid_depth levels of the descent are
+//     one arithmetic cell lookup in a dense grid (1 load instead of a chain of dependent loads);
 //   - a float bounding-cone test (conservative, see octree.cpp) discards most leaf entries before the
 //     exact FP64 test, and hits are first collected in a bit mask so that the expensive exact tests of
 //     the 64 lanes of a wavefront run together instead of at 34 different loop iterations;
 //   - dist_to_point is only evaluated when a second triangle also passes the inside test (its value
-//     cannot change the result otherwise).
+//     cannot change the result otherwise);
+//   - only the winning triangle id is carried (few live registers -> more wavefronts per SIMD); callers
+//     re-read its 128-byte record, which is L1/L2 resident by then.
 #pragma once
 
 #include "internal.hpp"
 
 namespace msm {
 
-struct Hit {
-    int tri;
-    int id0, id1, id2;
-    V3 v0, v1, v2;
-};
-
 struct ScanState {
-    int best;
-    bool have_d;
+    int best;      // winning triangle so far, -1 = EMPTY_TRIANGLE
+    int have_d;    // bestd holds dist_to_point of `best`
     double bestd;
-    V3 best_mp;
-    Hit hit;
 };
 
-__device__ __forceinline__ void take(ScanState &s, const TriRec &r, int t) {
-    s.best = t;
-    s.hit.tri = t;
-    s.hit.id0 = r.id[0];
-    s.hit.id1 = r.id[1];
-    s.hit.id2 = r.id[2];
-    s.hit.v0 = mk(r.v0[0], r.v0[1], r.v0[2]);
-    s.hit.v1 = mk(r.v1[0], r.v1[1], r.v1[2]);
-    s.hit.v2 = mk(r.v2[0], r.v2[1], r.v2[2]);
+__device__ __forceinline__ V3 rec_v0(const TriRec &r) { return mk(r.v0[0], r.v0[1], r.v0[2]); }
+__device__ __forceinline__ V3 rec_v1(const TriRec &r) { return mk(r.v1[0], r.v1[1], r.v1[2]); }
+__device__ __forceinline__ V3 rec_v2(const TriRec &r) { return mk(r.v2[0], r.v2[1], r.v2[2]); }
+
+// distance_to_triangle (R/octree.cpp:143-154): the projected point and whether it is inside
+__device__ __forceinline__ bool inside_test(const TriRec &r, const V3 &p, V3 &mp) {
+    mp = project_with_plane(p, mk(r.s3[0], r.s3[1], r.s3[2]), r.d);
+    return point_in_triangle(mp, rec_v0(r), rec_v1(r), rec_v2(r));
 }
 
-// distance_to_triangle (R/octree.cpp:143-154) + the running-minimum update (:172-178) for one entry
-__device__ __forceinline__ void exact_candidate(const DevTree &T, int t, const V3 &p, ScanState &s) {
+__device__ __forceinline__ double candidate_distance(const DevTree &T, int t, const V3 &p) {
     const TriRec &r = T.rec[t];
-    const V3 v0 = mk(r.v0[0], r.v0[1], r.v0[2]), v1 = mk(r.v1[0], r.v1[1], r.v1[2]), v2 = mk(r.v2[0], r.v2[1], r.v2[2]);
-    const V3 mp = project_with_plane(p, mk(r.s3[0], r.s3[1], r.s3[2]), r.d);
-    if (!point_in_triangle(mp, v0, v1, v2)) return;
-    if (s.best < 0) {
-        take(s, r, t);
-        s.best_mp = mp;
-        s.have_d = false;
+    V3 mp;
+    inside_test(r, p, mp);
+    return dist_to_point(mp, rec_v0(r), rec_v1(r), rec_v2(r));
+}
+
+// the running-minimum update of R/octree.cpp:172-178 for one entry that passed the cone test
+__device__ __forceinline__ void exact_candidate(const DevTree &T, int t, const V3 &p, ScanState &s) {
+    V3 mp;
+    if (!inside_test(T.rec[t], p, mp)) return;
+    if (s.best < 0) {  // first triangle that contains the projection: accepted whatever its distance
+        s.best = t;
+        s.have_d = 0;
         return;
     }
     if (!s.have_d) {
-        s.bestd = dist_to_point(s.best_mp, s.hit.v0, s.hit.v1, s.hit.v2);
-        s.have_d = true;
+        s.bestd = candidate_distance(T, s.best, p);
+        s.have_d = 1;
     }
-    const double d = dist_to_point(mp, v0, v1, v2);
+    const double d = candidate_distance(T, t, p);
     if (d > -1.0 && d < s.bestd) {
-        take(s, r, t);
+        s.best = t;
         s.bestd = d;
     }
 }
 
-// one leaf: cone pre-filter into a bit mask, then exact tests in entry order
+// one leaf: cone pre-filter into bit masks (32 entries at a time), then exact tests in entry order
 __device__ __forceinline__ void scan_leaf(const DevTree &T, int beg, int cnt, const V3 &p, float fx, float fy, float fz, ScanState &s) {
-    for (int base = 0; base < cnt; base += 64) {
-        const int m = min(64, cnt - base);
-        unsigned long long mask = 0ull;
+    for (int base = 0; base < cnt; base += 32) {
+        const int m = min(32, cnt - base);
+        unsigned mask = 0u;
         const float4 *cone = T.cone + beg + base;
         for (int e = 0; e < m; ++e) {
             const float4 c = cone[e];
-            const float dt = c.x * fx + c.y * fy + c.z * fz;
-            if (fabsf(dt) >= c.w) mask |= 1ull << e;
+            // a filter with its own safety margin: fused multiply-adds are fine here
+            const float dt = __builtin_fmaf(c.z, fz, __builtin_fmaf(c.y, fy, c.x * fx));
+            mask |= (fabsf(dt) >= c.w ? 1u : 0u) << e;
         }
         while (mask) {
-            const int e = __ffsll((long long)mask) - 1;
+            const int e = __ffs((int)mask) - 1;
             mask &= mask - 1;
             exact_candidate(T, T.leaf_tri[beg + base + e], p, s);
         }
     }
 }
 
-// Returns the triangle id (>= 0) and fills `hit`, or MSM_ERR_OUTSIDE / MSM_ERR_NOTFOUND.
-__device__ __forceinline__ int find_closest_triangle(const DevTree &T, const V3 &p, Hit &hit) {
+// Steps 3 and 4 of get_closest_triangle (R/octree.cpp:180-208); rare, kept out of line so that the hot
+// path does not pay registers for it
+__device__ __forceinline__ int fallback_search(const DevTree &T, int n, const V3 &p, float fx, float fy, float fz) {
+    ScanState s;
+    s.best = -1;
+    s.have_d = 0;
+    s.bestd = DBL_MAX;
+    const int par = T.parent[n];
+    if (par < 0) return MSM_ERR_NOTFOUND;  // the reference dereferences a null parent here
+    const int first = T.node[par].x;
+    for (int c = 0; c < 8; ++c) {
+        const int2 sib = T.node[first + c];
+        if (sib.x < 0) scan_leaf(T, sib.y, -sib.x - 1, p, fx, fy, fz, s);
+    }
+    if (s.best >= 0) return s.best;
+    // closest vertex by geodesic distance, R/octree.cpp:195-208
+    double bestd = DBL_MAX;
+    for (int c = 0; c < 8; ++c) {
+        const int2 sib = T.node[first + c];
+        if (sib.x >= 0) continue;
+        for (int e = 0; e < -sib.x - 1; ++e) {
+            const int t = T.leaf_tri[sib.y + e];
+            const TriRec &r = T.rec[t];
+            for (int v = 0; v < 3; ++v) {
+                const double *vv = v == 0 ? r.v0 : (v == 1 ? r.v1 : r.v2);
+                const double d = chord_to_arc(norm(sub(mk(vv[0], vv[1], vv[2]), p)));
+                if (d < bestd) {
+                    s.best = t;
+                    bestd = d;
+                }
+            }
+        }
+    }
+    return s.best >= 0 ? s.best : MSM_ERR_NOTFOUND;
+}
+
+// index of the grid cell along one axis: the number of cell boundaries b_j = -101 + j*h that are <= p,
+// i.e. exactly the upper/lower choices the reference's descent makes with its (lo+hi)/2.0 midpoints
+// (h = 202/G and all b_j are exact in FP64)
+__device__ __forceinline__ int grid_axis(double p, int G, double h) {
+    int i = (int)((p + kBounds) / h);
+    i = max(0, min(G - 1, i));
+    if (i + 1 < G && !(p < -kBounds + (i + 1) * h)) ++i;
+    else if (i > 0 && p < -kBounds + i * h) --i;
+    return (p == p) ? i : G - 1;  // NaN: every child "contains" it, the last one wins
+}
+
+// Returns the triangle id (>= 0), or MSM_ERR_OUTSIDE / MSM_ERR_NOTFOUND.
+__device__ __forceinline__ int find_closest_triangle(const DevTree &T, const V3 &p) {
     // Node::contains_point of the root, R/node.cpp:58-68 (written so that NaN behaves as in the reference)
     if (p.x < -kBounds || p.x > kBounds || p.y < -kBounds || p.y > kBounds || p.z < -kBounds || p.z > kBounds) return MSM_ERR_OUTSIDE;
-    double lx = -kBounds, hx = kBounds, ly = -kBounds, hy = kBounds, lz = -kBounds, hz = kBounds;
-    int n = 0;
-    int2 nd = T.node[0];
-    while (nd.x >= 0) {
-        const double mx = (lx + hx) / 2.0, my = (ly + hy) / 2.0, mz = (lz + hz) / 2.0;
-        // the upper child's closed box [mid, hi] contains p unless p < mid; the last containing child wins
-        const int cx = !(p.x < mx), cy = !(p.y < my), cz = !(p.z < mz);
-        if (cx) lx = mx; else hx = mx;
-        if (cy) ly = my; else hy = my;
-        if (cz) lz = mz; else hz = mz;
-        n = nd.x + 4 * cx + 2 * cy + cz;
-        nd = T.node[n];
+    const int G = 1 << T.grid_depth;
+    const double h = 2 * kBounds / G;
+    const int ix = grid_axis(p.x, G, h), iy = grid_axis(p.y, G, h), iz = grid_axis(p.z, G, h);
+    int n = T.grid[((size_t)ix * G + iy) * G + iz];
+    int2 nd = T.node[n];
+    if (nd.x >= 0) {  // deeper than the grid: continue the reference's descent from this cell's box
+        double lx = -kBounds + ix * h, hx = -kBounds + (ix + 1) * h;
+        double ly = -kBounds + iy * h, hy = -kBounds + (iy + 1) * h;
+        double lz = -kBounds + iz * h, hz = -kBounds + (iz + 1) * h;
+        while (nd.x >= 0) {
+            const double mx = (lx + hx) / 2.0, my = (ly + hy) / 2.0, mz = (lz + hz) / 2.0;
+            // the upper child's closed box [mid, hi] contains p unless p < mid; the last containing child wins
+            const int cx = !(p.x < mx), cy = !(p.y < my), cz = !(p.z < mz);
+            if (cx) lx = mx; else hx = mx;
+            if (cy) ly = my; else hy = my;
+            if (cz) lz = mz; else hz = mz;
+            n = nd.x + 4 * cx + 2 * cy + cz;
+            nd = T.node[n];
+        }
     }
     // direction of p in float for the cone pre-filter
     const float qx = (float)p.x, qy = (float)p.y, qz = (float)p.z;
@@ -112,41 +164,13 @@ __device__ __forceinline__ int find_closest_triangle(const DevTree &T, const V3 
 
     ScanState s;
     s.best = -1;
-    s.have_d = false;
+    s.have_d = 0;
     s.bestd = DBL_MAX;
     scan_leaf(T, nd.y, -nd.x - 1, p, fx, fy, fz, s);
-    if (s.best < 0) {
-        const int par = T.parent[n];
-        if (par < 0) return MSM_ERR_NOTFOUND;  // the reference dereferences a null parent here
-        const int first = T.node[par].x;
-        for (int c = 0; c < 8; ++c) {
-            const int2 sib = T.node[first + c];
-            if (sib.x < 0) scan_leaf(T, sib.y, -sib.x - 1, p, fx, fy, fz, s);
-        }
-        if (s.best < 0) {
-            // closest vertex by geodesic distance, R/octree.cpp:195-208
-            double bestd = DBL_MAX;
-            for (int c = 0; c < 8; ++c) {
-                const int2 sib = T.node[first + c];
-                if (sib.x >= 0) continue;
-                for (int e = 0; e < -sib.x - 1; ++e) {
-                    const int t = T.leaf_tri[sib.y + e];
-                    const TriRec &r = T.rec[t];
-                    const double *vv[3] = {r.v0, r.v1, r.v2};
-                    for (int v = 0; v < 3; ++v) {
-                        const double d = chord_to_arc(norm(sub(mk(vv[v][0], vv[v][1], vv[v][2]), p)));
-                        if (d < bestd) {
-                            take(s, r, t);
-                            bestd = d;
-                        }
-                    }
-                }
-            }
-        }
-        if (s.best < 0) return MSM_ERR_NOTFOUND;
-    }
-    hit = s.hit;
-    return s.best;
+    if (s.best >= 0) return s.best;
+
+    // rare: nothing in the leaf contains the projection
+    return fallback_search(T, n, p, fx, fy, fz);
 }
 
 }  // namespace msm
