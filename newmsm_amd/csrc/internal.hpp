@@ -44,11 +44,12 @@ static_assert(sizeof(TriRec) == 128, "TriRec must be 128 bytes");
 
 struct FlatOctree {
     // node[n].x >= 0: internal node, children are node[n].x .. +7 in (i,j,k) order.
-    // node[n].x <  0: leaf with (-x - 1) entries starting at node[n].y in leaf_tri / cone.
+    // node[n].x <  0: leaf with (-x - 1) entries starting at node[n].y (a multiple of 8) in leaf_tri / cone;
+    //                 each leaf's entries are padded to a multiple of 8 (leaf_tri -1).
     std::vector<int2> node;
     std::vector<int32_t> parent;
     std::vector<int32_t> leaf_tri;
-    std::vector<float4> cone;  // per leaf entry: unit axis (xyz) and |cos| threshold (w) of the conservative bounding cone
+    std::vector<float4> cone;  // per 8 entries: 8 float4 = x[8] y[8] z[8] thr[8] (unit cone axis, |cos| threshold)
     // Dense top of the tree: the node reached after grid_depth levels of descent (or the leaf met earlier),
     // indexed [ix][iy][iz] with G = 2^grid_depth cells per axis over (-101, 101).  Child boxes are exact
     // halvings, so the cell of a point is found arithmetically and the descent starts there.

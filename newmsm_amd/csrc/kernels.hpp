@@ -33,6 +33,13 @@ struct UnaryLaunch {
     int simmeasure;
     double *U;             // L x N
     unsigned long long *nsamples;
+    // scratch owned by the cost object
+    int ntri;                      // triangles in the target mesh
+    double *tval;                  // one double per point sample (L * total patch points)
+    unsigned long long *fix_list;  // capacity fix_cap
+    unsigned int *fix_count;       // 2 words: [0] fix-up entries, [1] nodes to re-reduce
+    unsigned int fix_cap;
+    int *redo_list;                // N ints
 };
 int launch_unary_univariate(msm_ctx *ctx, const UnaryLaunch &u);
 

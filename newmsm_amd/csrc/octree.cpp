@@ -7,8 +7,8 @@
 // the same incremental procedure is run here, on index-based nodes, and then laid out as flat arrays
 // for the GPU:
 //   node[]      int2 per node (first child, or leaf entry range)   -> descent is arithmetic + 1 load/level
-//   leaf_tri[]  triangle ids of all leaves, contiguous per leaf, in insertion (= ascending id) order
-//   cone[]      float4 per leaf entry: conservative bounding cone of the triangle (cheap reject test)
+//   leaf_tri[]  triangle ids of all leaves, contiguous per leaf, in insertion (= ascending id) order, padded to x8
+//   cone[]      per batch of 8 leaf entries: conservative bounding cones (cheap reject test), transposed
 //   recs[]      128-byte record per triangle for the exact test
 #include <cmath>
 #include <deque>
@@ -170,25 +170,48 @@ void build_octree(const double *xyz, const int32_t *tri, int V, int T, FlatOctre
         tcone[t] = bounding_cone(v0, v1, v2, r);
     }
 
+    // Leaf entries are padded to multiples of 8 (id -1, a cone nothing passes) so that the filter reads whole
+    // batches (one 128-byte line each); the cones of a batch are stored transposed -- x[8] y[8] z[8] thr[8] --
+    // which is the register layout packed FP32 math (v_pk_fma_f32) wants.
     const int n = (int)b.nodes.size();
     out.node.resize(n);
     out.parent.resize(n);
     out.leaf_tri.clear();
     out.cone.clear();
-    int64_t leaves = 0, maxleaf = 0;
+    int64_t leaves = 0, maxleaf = 0, refs = 0;
     for (int i = 0; i < n; ++i) {
         const BNode &nd = b.nodes[i];
         out.parent[i] = nd.parent;
         if (nd.first_child >= 0) {
             out.node[i] = make_int2(nd.first_child, 0);
         } else {
-            out.node[i] = make_int2(-(int)nd.tris.size() - 1, (int)out.leaf_tri.size());
-            for (int32_t t : nd.tris) {
-                out.leaf_tri.push_back(t);
-                out.cone.push_back(tcone[t]);
+            const int cnt = (int)nd.tris.size();
+            out.node[i] = make_int2(-cnt - 1, (int)out.leaf_tri.size());
+            for (int eb = 0; eb < cnt; eb += 8) {
+                float bx[8], by[8], bz[8], bw[8];
+                for (int j = 0; j < 8; ++j) {
+                    if (eb + j < cnt) {
+                        const int32_t t = nd.tris[eb + j];
+                        out.leaf_tri.push_back(t);
+                        bx[j] = tcone[t].x, by[j] = tcone[t].y, bz[j] = tcone[t].z, bw[j] = tcone[t].w;
+                    } else {
+                        out.leaf_tri.push_back(-1);
+                        bx[j] = by[j] = bz[j] = 0.f;
+                        bw[j] = 2.f;  // |dot| <= 1 < 2: never passes
+                    }
+                }
+                out.cone.push_back(make_float4(bx[0], bx[1], bx[2], bx[3]));
+                out.cone.push_back(make_float4(bx[4], bx[5], bx[6], bx[7]));
+                out.cone.push_back(make_float4(by[0], by[1], by[2], by[3]));
+                out.cone.push_back(make_float4(by[4], by[5], by[6], by[7]));
+                out.cone.push_back(make_float4(bz[0], bz[1], bz[2], bz[3]));
+                out.cone.push_back(make_float4(bz[4], bz[5], bz[6], bz[7]));
+                out.cone.push_back(make_float4(bw[0], bw[1], bw[2], bw[3]));
+                out.cone.push_back(make_float4(bw[4], bw[5], bw[6], bw[7]));
             }
             ++leaves;
-            maxleaf = std::max<int64_t>(maxleaf, (int64_t)nd.tris.size());
+            refs += cnt;
+            maxleaf = std::max<int64_t>(maxleaf, (int64_t)cnt);
         }
     }
     // depth: children always follow their parent in the node array
@@ -224,7 +247,7 @@ void build_octree(const double *xyz, const int32_t *tri, int V, int T, FlatOctre
     out.stats[0] = n;
     out.stats[1] = leaves;
     out.stats[2] = maxdepth;
-    out.stats[3] = (int64_t)out.leaf_tri.size();
+    out.stats[3] = refs;
     out.stats[4] = maxleaf;
 }
 

@@ -66,22 +66,36 @@ __device__ __forceinline__ void exact_candidate(const DevTree &T, int t, const V
     }
 }
 
-// one leaf: cone pre-filter into bit masks (32 entries at a time), then exact tests in entry order
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+// cone filter for one batch of 8 leaf entries (layout: octree.cpp); bit j set = entry j may contain p.
+// A filter with its own safety margin: packed fused multiply-adds are fine here.
+__device__ __forceinline__ unsigned cone_batch(const float4 *__restrict__ cb, float fx, float fy, float fz) {
+    const float4 X0 = cb[0], X1 = cb[1], Y0 = cb[2], Y1 = cb[3], Z0 = cb[4], Z1 = cb[5], W0 = cb[6], W1 = cb[7];
+    const f2 vx = {fx, fx}, vy = {fy, fy}, vz = {fz, fz};
+    unsigned bits = 0u;
+#define MSM_CONE_PAIR(X, Y, Z, W, a, b, sh)                                                                                              \
+    {                                                                                                                                    \
+        const f2 d = __builtin_elementwise_fma((f2){Z.a, Z.b}, vz, __builtin_elementwise_fma((f2){Y.a, Y.b}, vy, (f2){X.a, X.b} * vx)); \
+        bits |= (__builtin_fabsf(d.x) >= W.a ? 1u : 0u) << (sh);                                                                         \
+        bits |= (__builtin_fabsf(d.y) >= W.b ? 1u : 0u) << ((sh) + 1);                                                                   \
+    }
+    MSM_CONE_PAIR(X0, Y0, Z0, W0, x, y, 0)
+    MSM_CONE_PAIR(X0, Y0, Z0, W0, z, w, 2)
+    MSM_CONE_PAIR(X1, Y1, Z1, W1, x, y, 4)
+    MSM_CONE_PAIR(X1, Y1, Z1, W1, z, w, 6)
+#undef MSM_CONE_PAIR
+    return bits;
+}
+
+// one leaf: cone pre-filter (8 entries per step), then exact tests in entry order
 __device__ __forceinline__ void scan_leaf(const DevTree &T, int beg, int cnt, const V3 &p, float fx, float fy, float fz, ScanState &s) {
-    for (int base = 0; base < cnt; base += 32) {
-        const int m = min(32, cnt - base);
-        unsigned mask = 0u;
-        const float4 *cone = T.cone + beg + base;
-        for (int e = 0; e < m; ++e) {
-            const float4 c = cone[e];
-            // a filter with its own safety margin: fused multiply-adds are fine here
-            const float dt = __builtin_fmaf(c.z, fz, __builtin_fmaf(c.y, fy, c.x * fx));
-            mask |= (fabsf(dt) >= c.w ? 1u : 0u) << e;
-        }
-        while (mask) {
-            const int e = __ffs((int)mask) - 1;
-            mask &= mask - 1;
-            exact_candidate(T, T.leaf_tri[beg + base + e], p, s);
+    for (int eb = 0; eb < cnt; eb += 8) {
+        unsigned bits = cone_batch(T.cone + beg + eb, fx, fy, fz);
+        while (bits) {
+            const int e = __ffs((int)bits) - 1;
+            bits &= bits - 1;
+            exact_candidate(T, T.leaf_tri[beg + eb + e], p, s);
         }
     }
 }
@@ -107,7 +121,7 @@ __device__ __forceinline__ int fallback_search(const DevTree &T, int n, const V3
         const int2 sib = T.node[first + c];
         if (sib.x >= 0) continue;
         for (int e = 0; e < -sib.x - 1; ++e) {
-            const int t = T.leaf_tri[sib.y + e];
+            const int t = T.leaf_tri[sib.y + e];  // e < count: never a padding entry
             const TriRec &r = T.rec[t];
             for (int v = 0; v < 3; ++v) {
                 const double *vv = v == 0 ? r.v0 : (v == 1 ? r.v1 : r.v2);
@@ -126,7 +140,7 @@ __device__ __forceinline__ int fallback_search(const DevTree &T, int n, const V3
 // i.e. exactly the upper/lower choices the reference's descent makes with its (lo+hi)/2.0 midpoints
 // (h = 202/G and all b_j are exact in FP64)
 __device__ __forceinline__ int grid_axis(double p, int G, double h) {
-    int i = (int)((p + kBounds) / h);
+    int i = (int)((p + kBounds) * (1.0 / h));  // estimate; the two comparisons below make it exact
     i = max(0, min(G - 1, i));
     if (i + 1 < G && !(p < -kBounds + (i + 1) * h)) ++i;
     else if (i > 0 && p < -kBounds + i * h) --i;
