@@ -41,21 +41,42 @@ int ensure_tree(msm_mesh *m) {
         return hipMalloc(p, cap * elem);
     };
     size_t cap_parent = m->cap_node, cap_cone = m->cap_leaf;
-    MSM_HIP(grow((void **)&m->d_node, m->cap_node, m->tree.node.size(), sizeof(int2)));
+    MSM_HIP(grow((void **)&m->d_node, m->cap_node, m->tree.node.size(), sizeof(int4)));
     MSM_HIP(grow((void **)&m->d_parent, cap_parent, m->tree.node.size(), sizeof(int32_t)));
     MSM_HIP(grow((void **)&m->d_leaf_tri, m->cap_leaf, m->tree.leaf_tri.size(), sizeof(int32_t)));
     MSM_HIP(grow((void **)&m->d_cone, cap_cone, m->tree.leaf_tri.size(), sizeof(float4)));
     MSM_HIP(grow((void **)&m->d_rec, m->cap_rec, recs.size(), sizeof(TriRec)));
     MSM_HIP(grow((void **)&m->d_grid, m->cap_grid, m->tree.grid.size(), sizeof(int32_t)));
+    size_t cap_box = cap_parent;
+    MSM_HIP(grow((void **)&m->d_nodebox, cap_box, m->tree.node.size(), sizeof(double4)));
     // the staging vectors die at scope exit, so these copies must complete here
-    MSM_HIP(hipMemcpyAsync(m->d_node, m->tree.node.data(), m->tree.node.size() * sizeof(int2), hipMemcpyHostToDevice, ctx->stream));
+    MSM_HIP(hipMemcpyAsync(m->d_node, m->tree.node.data(), m->tree.node.size() * sizeof(int4), hipMemcpyHostToDevice, ctx->stream));
     MSM_HIP(hipMemcpyAsync(m->d_parent, m->tree.parent.data(), m->tree.parent.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
     MSM_HIP(hipMemcpyAsync(m->d_leaf_tri, m->tree.leaf_tri.data(), m->tree.leaf_tri.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
     MSM_HIP(hipMemcpyAsync(m->d_cone, m->tree.cone.data(), m->tree.cone.size() * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
     MSM_HIP(hipMemcpyAsync(m->d_rec, recs.data(), recs.size() * sizeof(TriRec), hipMemcpyHostToDevice, ctx->stream));
     MSM_HIP(hipMemcpyAsync(m->d_grid, m->tree.grid.data(), m->tree.grid.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    MSM_HIP(hipMemcpyAsync(m->d_nodebox, m->tree.nodebox.data(), m->tree.nodebox.size() * sizeof(double4), hipMemcpyHostToDevice, ctx->stream));
+    m->masks_valid = false;
     MSM_HIP(hipStreamSynchronize(ctx->stream));
     m->tree_valid = true;
+    return MSM_OK;
+}
+
+int ensure_masks(msm_mesh *m) {
+    int st = ensure_tree(m);
+    if (st) return st;
+    if (m->masks_valid) return MSM_OK;
+    const size_t need = (size_t)std::max(m->tree.nmask_blocks, 1) * 64;
+    if (need > m->cap_mask || !m->d_mask) {
+        if (m->d_mask) (void)hipFree(m->d_mask);
+        m->d_mask = nullptr;
+        m->cap_mask = need + need / 4;
+        MSM_HIP(hipMalloc((void **)&m->d_mask, m->cap_mask * sizeof(unsigned long long)));
+    }
+    st = launch_build_masks(m->ctx, dev_tree(m), m->d_nodebox, m->d_mask);
+    if (st) return st;
+    m->masks_valid = true;
     return MSM_OK;
 }
 
@@ -68,6 +89,7 @@ DevTree dev_tree(const msm_mesh *m) {
     t.rec = m->d_rec;
     t.grid = m->d_grid;
     t.grid_depth = m->tree.grid_depth;
+    t.mask = m->masks_valid ? m->d_mask : nullptr;
     t.nnodes = (int)m->tree.node.size();
     return t;
 }
@@ -308,7 +330,7 @@ void msm_mesh_destroy(msm_mesh *m) {
     if (!m) return;
     (void)hipSetDevice(m->ctx->device);
     (void)hipStreamSynchronize(m->ctx->stream);
-    for (void *p : {(void *)m->d_xyz, (void *)m->d_feat, (void *)m->d_node, (void *)m->d_parent, (void *)m->d_leaf_tri, (void *)m->d_cone, (void *)m->d_rec, (void *)m->d_grid})
+    for (void *p : {(void *)m->d_xyz, (void *)m->d_feat, (void *)m->d_node, (void *)m->d_parent, (void *)m->d_leaf_tri, (void *)m->d_cone, (void *)m->d_rec, (void *)m->d_grid, (void *)m->d_nodebox, (void *)m->d_mask})
         if (p) (void)hipFree(p);
     delete m;
 }

@@ -182,7 +182,7 @@ int ensure_unary_table(msm_cost *c) {
         c->table_valid = true;
         return MSM_OK;
     }
-    st = ensure_tree(c->target);
+    st = ensure_masks(c->target);
     if (st) return st;
     UnaryLaunch u;
     u.tree = dev_tree(c->target);

@@ -46,10 +46,14 @@ struct FlatOctree {
     // node[n].x >= 0: internal node, children are node[n].x .. +7 in (i,j,k) order.
     // node[n].x <  0: leaf with (-x - 1) entries starting at node[n].y (a multiple of 8) in leaf_tri / cone;
     //                 each leaf's entries are padded to a multiple of 8 (leaf_tri -1).
-    std::vector<int2> node;
+    // node[n].z: leaves with 1..64 entries own 64 sub-cell masks at mask[64 * z ..]; -1 otherwise.
+    // node[n].w: depth of the node (root 0); its box has edge 202 / 2^w.
+    std::vector<int4> node;
+    std::vector<double4> nodebox;  // per node: lower corner (x,y,z) and edge length (w), all exact dyadics
+    int nmask_blocks = 0;
     std::vector<int32_t> parent;
     std::vector<int32_t> leaf_tri;
-    std::vector<float4> cone;  // per 8 entries: 8 float4 = x[8] y[8] z[8] thr[8] (unit cone axis, |cos| threshold)
+    std::vector<float4> cone;  // per padded leaf entry: unit cone axis (xyz) and |cos| threshold (w)
     // Dense top of the tree: the node reached after grid_depth levels of descent (or the leaf met earlier),
     // indexed [ix][iy][iz] with G = 2^grid_depth cells per axis over (-101, 101).  Child boxes are exact
     // halvings, so the cell of a point is found arithmetically and the descent starts there.
@@ -63,13 +67,14 @@ void build_octree(const double *xyz /*3 x V SoA*/, const int32_t *tri /*3 x T So
 
 // device view of a mesh's search structure
 struct DevTree {
-    const int2 *node;
+    const int4 *node;
     const int32_t *parent;
     const int32_t *leaf_tri;
     const float4 *cone;
     const TriRec *rec;
     const int32_t *grid;
     int grid_depth;  // G = 1 << grid_depth cells per axis
+    const unsigned long long *mask;  // 64 per mask block (see FlatOctree::node), or nullptr before the masks are built
     int nnodes;
 };
 
@@ -95,19 +100,23 @@ struct msm_mesh {
     // device
     double *d_xyz = nullptr;   // 3 x V SoA
     double *d_feat = nullptr;  // V x D (vertex-major: one row per vertex for gathers)
-    int2 *d_node = nullptr;
+    int4 *d_node = nullptr;
+    double4 *d_nodebox = nullptr;
+    unsigned long long *d_mask = nullptr;
+    bool masks_valid = false;
     int32_t *d_parent = nullptr;
     int32_t *d_leaf_tri = nullptr;
     float4 *d_cone = nullptr;
     msm::TriRec *d_rec = nullptr;
     int32_t *d_grid = nullptr;
-    size_t cap_node = 0, cap_leaf = 0, cap_rec = 0, cap_grid = 0;
+    size_t cap_node = 0, cap_leaf = 0, cap_rec = 0, cap_grid = 0, cap_mask = 0;
     msm::Adjacency adj;
     bool adj_valid = false;
 };
 
 namespace msm {
 int ensure_tree(msm_mesh *m);  // build + upload the search structure if stale
+int ensure_masks(msm_mesh *m);  // + the per-leaf sub-cell masks the cost kernels use (built on the GPU)
 DevTree dev_tree(const msm_mesh *m);
 int check_status(msm_ctx *ctx, const char *what);  // sync + read kernel status
 }  // namespace msm

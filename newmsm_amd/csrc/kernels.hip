@@ -17,6 +17,57 @@ __device__ __forceinline__ double wave_sum(double v) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Sub-cell masks.  A leaf's box is cut into 4x4x4 sub-cells; bit e of mask[sub-cell] is set unless no point of
+// that (closed) sub-cell can pass entry e's cone filter -- and with it the reference's inside test, which the
+// cone contains.  One 64-lane workgroup per node, one lane per sub-cell.  All directions of points in a box lie
+// within beta of the direction of its centre c, sin(beta) = half-diagonal / |c|; with theta the angle between c
+// and the cone axis, the largest |cos| a point of the box can reach is cos(max(theta-beta,0)) on the axis side
+// and -cos(min(theta+beta,pi)) on the antipodal side.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_build_masks(DevTree T, const double4 *__restrict__ nodebox, unsigned long long *__restrict__ mask) {
+    const int n = blockIdx.x;
+    const int4 nd = T.node[n];
+    if (nd.x >= 0 || nd.z < 0) return;
+    const int cnt = -nd.x - 1;
+    const double4 box = nodebox[n];
+    const double q = box.w / 4;
+    const int s = threadIdx.x, sx = s >> 4, sy = (s >> 2) & 3, sz = s & 3;
+    const double cx = box.x + (sx + 0.5) * q, cy = box.y + (sy + 0.5) * q, cz = box.z + (sz + 0.5) * q;
+    const double cn = sqrt(cx * cx + cy * cy + cz * cz);
+    const double rb = 0.5 * q * 1.7320508075688774 * (1 + 1e-9) + 1e-9;
+    unsigned long long m = 0ull;
+    if (!(cn > rb)) {
+        m = cnt >= 64 ? ~0ull : ((1ull << cnt) - 1ull);  // the box reaches the origin: any direction
+    } else {
+        const double sb = rb / cn, cb = sqrt(1 - sb * sb);
+        const double ux = cx / cn, uy = cy / cn, uz = cz / cn;
+        for (int e = 0; e < cnt; ++e) {
+            const float4 c = T.cone[nd.y + e];
+            const double thr = (double)c.w - 1e-6;  // the device evaluates the cone test in float
+            bool hit = thr <= 0.0;
+            if (!hit) {
+                const double an = sqrt((double)c.x * c.x + (double)c.y * c.y + (double)c.z * c.z);
+                double ct = (ux * c.x + uy * c.y + uz * c.z) / an;
+                ct = ct > 1 ? 1 : (ct < -1 ? -1 : ct);
+                const double stt = sqrt(1 - ct * ct);
+                // cos(theta - beta) and -cos(theta + beta), saturated at 1 when the axis (or its antipode) is inside the cap
+                const double near = (ct >= cb) ? 1.0 : ct * cb + stt * sb;
+                const double far = (-ct >= cb) ? 1.0 : -(ct * cb - stt * sb);
+                hit = near >= thr || far >= thr;
+            }
+            if (hit) m |= 1ull << e;
+        }
+    }
+    mask[(size_t)nd.z * 64 + s] = m;
+}
+
+int launch_build_masks(msm_ctx *ctx, const DevTree &T, const double4 *d_nodebox, unsigned long long *d_mask) {
+    hipLaunchKernelGGL(k_build_masks, dim3(T.nnodes), dim3(64), 0, ctx->stream, T, d_nodebox, d_mask);
+    MSM_HIP(hipGetLastError());
+    return MSM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // msm_query_triangles: one lane per query point (Resampler::get_barycentric_weights, R/resampler.cpp:142-167)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_query(DevTree T, const double *__restrict__ q, int N, int *__restrict__ tri_id,

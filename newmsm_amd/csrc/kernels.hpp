@@ -5,6 +5,8 @@
 
 namespace msm {
 
+// per-leaf sub-cell masks (see FlatOctree::node); writes 64 words per mask block
+int launch_build_masks(msm_ctx *ctx, const DevTree &T, const double4 *d_nodebox, unsigned long long *d_mask);
 int launch_query(msm_ctx *ctx, const DevTree &T, const double *d_q, int N, int *d_tri, int *d_vid, double *d_w, int mode);
 int launch_closest_vertex(msm_ctx *ctx, const DevTree &T, const double *d_q, int N, int *d_out);
 int launch_range(msm_ctx *ctx, const double *d_cp, int Ncp, const double *d_src, int Nsrc, const double *d_maxsep, double range, int cap,

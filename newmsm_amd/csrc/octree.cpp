@@ -6,9 +6,11 @@
 // a query lands in -- and so which triangles are candidates -- depends on that insertion history, so
 // the same incremental procedure is run here, on index-based nodes, and then laid out as flat arrays
 // for the GPU:
-//   node[]      int2 per node (first child, or leaf entry range)   -> descent is arithmetic + 1 load/level
+//   node[]      int4 per node (first child, or leaf entry range + mask block + depth) -> descent is arithmetic + 1 load/level
 //   leaf_tri[]  triangle ids of all leaves, contiguous per leaf, in insertion (= ascending id) order, padded to x8
-//   cone[]      per batch of 8 leaf entries: conservative bounding cones (cheap reject test), transposed
+//   cone[]      float4 per (padded) leaf entry: conservative bounding cone of the triangle (cheap reject test)
+//   mask[]      per leaf 64 x 64-bit: which entries a query inside each of the leaf's 4x4x4 sub-cells can hit
+//               (filled on the GPU, kernels.hip k_build_masks)
 //   recs[]      128-byte record per triangle for the exact test
 #include <cmath>
 #include <deque>
@@ -170,56 +172,42 @@ void build_octree(const double *xyz, const int32_t *tri, int V, int T, FlatOctre
         tcone[t] = bounding_cone(v0, v1, v2, r);
     }
 
-    // Leaf entries are padded to multiples of 8 (id -1, a cone nothing passes) so that the filter reads whole
-    // batches (one 128-byte line each); the cones of a batch are stored transposed -- x[8] y[8] z[8] thr[8] --
-    // which is the register layout packed FP32 math (v_pk_fma_f32) wants.
+    // Leaf entries are padded to multiples of 8 (id -1, a cone nothing passes): 8 cones = one 128-byte line.
     const int n = (int)b.nodes.size();
     out.node.resize(n);
+    out.nodebox.resize(n);
     out.parent.resize(n);
     out.leaf_tri.clear();
     out.cone.clear();
+    out.nmask_blocks = 0;
     int64_t leaves = 0, maxleaf = 0, refs = 0;
+    std::vector<int> depth(n, 0);
+    int maxdepth = 0;
     for (int i = 0; i < n; ++i) {
         const BNode &nd = b.nodes[i];
         out.parent[i] = nd.parent;
+        if (i > 0) depth[i] = depth[nd.parent] + 1;  // children always follow their parent in the node array
+        maxdepth = std::max(maxdepth, depth[i]);
+        out.nodebox[i] = make_double4(nd.b[0][0], nd.b[1][0], nd.b[2][0], nd.b[0][2] - nd.b[0][0]);
         if (nd.first_child >= 0) {
-            out.node[i] = make_int2(nd.first_child, 0);
+            out.node[i] = make_int4(nd.first_child, 0, -1, depth[i]);
         } else {
             const int cnt = (int)nd.tris.size();
-            out.node[i] = make_int2(-cnt - 1, (int)out.leaf_tri.size());
-            for (int eb = 0; eb < cnt; eb += 8) {
-                float bx[8], by[8], bz[8], bw[8];
-                for (int j = 0; j < 8; ++j) {
-                    if (eb + j < cnt) {
-                        const int32_t t = nd.tris[eb + j];
-                        out.leaf_tri.push_back(t);
-                        bx[j] = tcone[t].x, by[j] = tcone[t].y, bz[j] = tcone[t].z, bw[j] = tcone[t].w;
-                    } else {
-                        out.leaf_tri.push_back(-1);
-                        bx[j] = by[j] = bz[j] = 0.f;
-                        bw[j] = 2.f;  // |dot| <= 1 < 2: never passes
-                    }
+            const int mblock = (cnt >= 1 && cnt <= 64) ? out.nmask_blocks++ : -1;
+            out.node[i] = make_int4(-cnt - 1, (int)out.leaf_tri.size(), mblock, depth[i]);
+            for (int e = 0; e < ((cnt + 7) & ~7); ++e) {
+                if (e < cnt) {
+                    out.leaf_tri.push_back(nd.tris[e]);
+                    out.cone.push_back(tcone[nd.tris[e]]);
+                } else {
+                    out.leaf_tri.push_back(-1);
+                    out.cone.push_back(make_float4(0.f, 0.f, 0.f, 2.f));  // |dot| <= 1 < 2: never passes
                 }
-                out.cone.push_back(make_float4(bx[0], bx[1], bx[2], bx[3]));
-                out.cone.push_back(make_float4(bx[4], bx[5], bx[6], bx[7]));
-                out.cone.push_back(make_float4(by[0], by[1], by[2], by[3]));
-                out.cone.push_back(make_float4(by[4], by[5], by[6], by[7]));
-                out.cone.push_back(make_float4(bz[0], bz[1], bz[2], bz[3]));
-                out.cone.push_back(make_float4(bz[4], bz[5], bz[6], bz[7]));
-                out.cone.push_back(make_float4(bw[0], bw[1], bw[2], bw[3]));
-                out.cone.push_back(make_float4(bw[4], bw[5], bw[6], bw[7]));
             }
             ++leaves;
             refs += cnt;
             maxleaf = std::max<int64_t>(maxleaf, (int64_t)cnt);
         }
-    }
-    // depth: children always follow their parent in the node array
-    std::vector<int> depth(n, 0);
-    int maxdepth = 0;
-    for (int i = 1; i < n; ++i) {
-        depth[i] = depth[out.parent[i]] + 1;
-        maxdepth = std::max(maxdepth, depth[i]);
     }
     // dense top grid: every node at depth <= grid_depth that is a leaf, or sits at grid_depth, owns a cube of cells
     out.grid_depth = std::min(maxdepth, 6);

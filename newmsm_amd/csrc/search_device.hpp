@@ -66,25 +66,20 @@ __device__ __forceinline__ void exact_candidate(const DevTree &T, int t, const V
     }
 }
 
-typedef float f2 __attribute__((ext_vector_type(2)));
+// the float cone test of one leaf entry; a filter with its own safety margin: fused multiply-adds are fine here
+__device__ __forceinline__ bool cone_pass(const float4 &c, float fx, float fy, float fz) {
+    const float dt = __builtin_fmaf(c.z, fz, __builtin_fmaf(c.y, fy, c.x * fx));
+    return fabsf(dt) >= c.w;
+}
 
-// cone filter for one batch of 8 leaf entries (layout: octree.cpp); bit j set = entry j may contain p.
-// A filter with its own safety margin: packed fused multiply-adds are fine here.
+// cone filter for 8 consecutive leaf entries (one 128-byte line); bit j set = entry j may contain p
 __device__ __forceinline__ unsigned cone_batch(const float4 *__restrict__ cb, float fx, float fy, float fz) {
-    const float4 X0 = cb[0], X1 = cb[1], Y0 = cb[2], Y1 = cb[3], Z0 = cb[4], Z1 = cb[5], W0 = cb[6], W1 = cb[7];
-    const f2 vx = {fx, fx}, vy = {fy, fy}, vz = {fz, fz};
+    float4 c[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) c[j] = cb[j];
     unsigned bits = 0u;
-#define MSM_CONE_PAIR(X, Y, Z, W, a, b, sh)                                                                                              \
-    {                                                                                                                                    \
-        const f2 d = __builtin_elementwise_fma((f2){Z.a, Z.b}, vz, __builtin_elementwise_fma((f2){Y.a, Y.b}, vy, (f2){X.a, X.b} * vx)); \
-        bits |= (__builtin_fabsf(d.x) >= W.a ? 1u : 0u) << (sh);                                                                         \
-        bits |= (__builtin_fabsf(d.y) >= W.b ? 1u : 0u) << ((sh) + 1);                                                                   \
-    }
-    MSM_CONE_PAIR(X0, Y0, Z0, W0, x, y, 0)
-    MSM_CONE_PAIR(X0, Y0, Z0, W0, z, w, 2)
-    MSM_CONE_PAIR(X1, Y1, Z1, W1, x, y, 4)
-    MSM_CONE_PAIR(X1, Y1, Z1, W1, z, w, 6)
-#undef MSM_CONE_PAIR
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bits |= (cone_pass(c[j], fx, fy, fz) ? 1u : 0u) << j;
     return bits;
 }
 
@@ -111,14 +106,14 @@ __device__ __forceinline__ int fallback_search(const DevTree &T, int n, const V3
     if (par < 0) return MSM_ERR_NOTFOUND;  // the reference dereferences a null parent here
     const int first = T.node[par].x;
     for (int c = 0; c < 8; ++c) {
-        const int2 sib = T.node[first + c];
+        const int4 sib = T.node[first + c];
         if (sib.x < 0) scan_leaf(T, sib.y, -sib.x - 1, p, fx, fy, fz, s);
     }
     if (s.best >= 0) return s.best;
     // closest vertex by geodesic distance, R/octree.cpp:195-208
     double bestd = DBL_MAX;
     for (int c = 0; c < 8; ++c) {
-        const int2 sib = T.node[first + c];
+        const int4 sib = T.node[first + c];
         if (sib.x >= 0) continue;
         for (int e = 0; e < -sib.x - 1; ++e) {
             const int t = T.leaf_tri[sib.y + e];  // e < count: never a padding entry
@@ -155,7 +150,7 @@ __device__ __forceinline__ int find_closest_triangle(const DevTree &T, const V3 
     const double h = 2 * kBounds / G;
     const int ix = grid_axis(p.x, G, h), iy = grid_axis(p.y, G, h), iz = grid_axis(p.z, G, h);
     int n = T.grid[((size_t)ix * G + iy) * G + iz];
-    int2 nd = T.node[n];
+    int4 nd = T.node[n];
     if (nd.x >= 0) {  // deeper than the grid: continue the reference's descent from this cell's box
         double lx = -kBounds + ix * h, hx = -kBounds + (ix + 1) * h;
         double ly = -kBounds + iy * h, hy = -kBounds + (iy + 1) * h;

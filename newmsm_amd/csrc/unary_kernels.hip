@@ -75,17 +75,26 @@ struct SamplesArgs {
     unsigned long long *nsamples;
 };
 
-// locate the octree leaf of p: (first entry, count).  Same decisions as find_closest_triangle.
-__device__ __forceinline__ int2 locate_leaf(const DevTree &T, const V3 &p) {
+// locate the octree leaf of p (same decisions as find_closest_triangle) and the sub-cell of p inside the leaf's
+// box: the box is cut 4x4x4 and the three cut positions per axis are exact dyadics, so plain comparisons place p
+// in the same (closed) sub-cell the mask builder reasoned about.
+__device__ __forceinline__ int4 locate_leaf(const DevTree &T, const V3 &p, int &subcell) {
     const int G = 1 << T.grid_depth;
     const double h = 2 * kBounds / G;
     const int ix = grid_axis(p.x, G, h), iy = grid_axis(p.y, G, h), iz = grid_axis(p.z, G, h);
-    int n = T.grid[((size_t)ix * G + iy) * G + iz];
-    int2 nd = T.node[n];
-    if (nd.x >= 0) {
-        double lx = -kBounds + ix * h, hx = -kBounds + (ix + 1) * h;
-        double ly = -kBounds + iy * h, hy = -kBounds + (iy + 1) * h;
-        double lz = -kBounds + iz * h, hz = -kBounds + (iz + 1) * h;
+    int4 nd = T.node[T.grid[((size_t)ix * G + iy) * G + iz]];
+    double lx, ly, lz, size;
+    if (nd.x < 0) {  // a leaf at depth w <= grid_depth: its box is the depth-w cell above this grid cell
+        const int up = T.grid_depth - nd.w;
+        size = 2 * kBounds / (double)(1 << nd.w);
+        lx = -kBounds + (ix >> up) * size;
+        ly = -kBounds + (iy >> up) * size;
+        lz = -kBounds + (iz >> up) * size;
+    } else {
+        lx = -kBounds + ix * h;
+        ly = -kBounds + iy * h;
+        lz = -kBounds + iz * h;
+        double hx = lx + h, hy = ly + h, hz = lz + h;
         while (nd.x >= 0) {
             const double mx = (lx + hx) / 2.0, my = (ly + hy) / 2.0, mz = (lz + hz) / 2.0;
             const int cx = !(p.x < mx), cy = !(p.y < my), cz = !(p.z < mz);
@@ -94,8 +103,14 @@ __device__ __forceinline__ int2 locate_leaf(const DevTree &T, const V3 &p) {
             if (cz) lz = mz; else hz = mz;
             nd = T.node[nd.x + 4 * cx + 2 * cy + cz];
         }
+        size = hx - lx;
     }
-    return make_int2(nd.y, -nd.x - 1);
+    const double q = size / 4;
+    const int sx = (p.x >= lx + q) + (p.x >= lx + 2 * q) + (p.x >= lx + 3 * q);
+    const int sy = (p.y >= ly + q) + (p.y >= ly + 2 * q) + (p.y >= ly + 3 * q);
+    const int sz = (p.z >= lz + q) + (p.z >= lz + 2 * q) + (p.z >= lz + 3 * q);
+    subcell = 16 * sx + 4 * sy + sz;
+    return nd;
 }
 
 // s / P for 0 <= s < 2^22, P > 0, with a float reciprocal and an exact correction step
@@ -233,7 +248,7 @@ __global__ __launch_bounds__(256) void k_unary_samples(SamplesArgs a) {
             // Every lane runs the same number of rounds so that the queue reservation can use wavefront shuffles.
             for (int r0 = 0; r0 < nchunk; r0 += 256) {
                 const int sl = r0 + tid;
-                unsigned m0 = 0u, m1 = 0u;
+                unsigned long long pm = 0ull;  // entries that passed the cone filter
                 int lbeg = 0;
                 bool defer = false;
                 if (sl < nchunk) {
@@ -243,26 +258,41 @@ __global__ __launch_bounds__(256) void k_unary_samples(SamplesArgs a) {
                     if (outside_root(p)) {
                         nin[sl] = -1;
                     } else {
-                        const int2 leaf = locate_leaf(a.tree, p);
-                        const int cnt = leaf.y;
-                        lbeg = leaf.x;
-                        if (cnt > 64) {
-                            defer = true;  // oversized leaf (the split heuristic refused to split it): complete search
+                        int sub;
+                        const int4 leaf = locate_leaf(a.tree, p, sub);
+                        lbeg = leaf.y;
+                        if (leaf.z < 0) {
+                            // no masks: an oversized leaf (the split heuristic refused to split it) needs the complete
+                            // search; an empty one yields no pair and reaches the fix-up list through nin == 0
+                            defer = (-leaf.x - 1) > 64;
                         } else {
                             const float qx = (float)p.x, qy = (float)p.y, qz = (float)p.z;
                             const float inv = rsqrtf(qx * qx + qy * qy + qz * qz);
                             const float fx = qx * inv, fy = qy * inv, fz = qz * inv;
-                            const float4 *cone = a.tree.cone + leaf.x;
-                            for (int eb = 0; eb < cnt; eb += 8) {
-                                const unsigned bits = cone_batch(cone + eb, fx, fy, fz);
-                                if (eb < 32) m0 |= bits << eb;
-                                else m1 |= bits << (eb - 32);
+                            const float4 *cone = a.tree.cone + leaf.y;
+                            // entries a point of this sub-cell can hit at all; cone-test those, four loads in flight
+                            unsigned long long mm = a.tree.mask[(size_t)leaf.z * 64 + sub];
+                            while (mm) {
+                                int e[4];
+                                bool v[4];
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) {
+                                    v[k] = mm != 0ull;
+                                    e[k] = v[k] ? __ffsll((long long)mm) - 1 : 0;
+                                    mm &= mm - 1ull;  // 0 stays 0
+                                }
+                                float4 c[4];
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) c[k] = cone[e[k]];
+#pragma unroll
+                                for (int k = 0; k < 4; ++k)
+                                    if (v[k] && cone_pass(c[k], fx, fy, fz)) pm |= 1ull << e[k];
                             }
                         }
                     }
                 }
                 // reserve queue space: wavefront prefix sum of the per-lane pair counts, one LDS atomic per wave
-                const int cntp = __popc(m0) + __popc(m1);
+                const int cntp = __popcll(pm);
                 int incl = cntp;
 #pragma unroll
                 for (int off = 1; off < 64; off <<= 1) {
@@ -279,15 +309,10 @@ __global__ __launch_bounds__(256) void k_unary_samples(SamplesArgs a) {
                     } else {
                         const int *lt = a.tree.leaf_tri + lbeg;
                         const unsigned tag = (unsigned)sl << kTriBits;
-                        while (m0) {
-                            const int e = __ffs((int)m0) - 1;
-                            m0 &= m0 - 1;
+                        while (pm) {
+                            const int e = __ffsll((long long)pm) - 1;
+                            pm &= pm - 1ull;
                             queue[pos++] = tag | (unsigned)lt[e];
-                        }
-                        while (m1) {
-                            const int e = __ffs((int)m1) - 1;
-                            m1 &= m1 - 1;
-                            queue[pos++] = tag | (unsigned)lt[32 + e];
                         }
                     }
                 }
