@@ -7,62 +7,23 @@
 #include <algorithm>
 #include <cmath>
 
-#include "devbuf.hpp"
-#include "kernels.hpp"
+#include "cost_internal.hpp"
 
 using namespace msm;
 
 namespace msm {
-int adaptive_weights(msm_mesh *in_mesh, msm_mesh *new_mesh, const double *excl, std::vector<int32_t> &row_ptr, std::vector<int32_t> &col,
-                     std::vector<double> &val);
-int query_host(msm_mesh *target, const double *q, int N, int *tri_id, int *vid, double *w, int mode, const char *what);
+int ensure_label_rotations(msm_cost *c) {
+    if (c->rotations_valid) return MSM_OK;  // a pure function of the control grid, ROT and the label set
+    if (c->L <= 0 || !c->cpgrid) return fail(MSM_ERR_STATE, "msm_cost: labels must be set first");
+    const int N = c->cpgrid->V;
+    MSM_HIP(c->d_rnl.ensure((size_t)N * c->L * 9));
+    MSM_HIP(c->d_moved.ensure((size_t)N * c->L * 3));
+    int st = launch_label_rotations(c->ctx, c->cpgrid->d_xyz, N, c->d_rot.p, c->d_labels.p, c->L, c->d_rnl.p, c->d_moved.p);
+    if (st) return st;
+    c->rotations_valid = true;
+    return MSM_OK;
+}
 }  // namespace msm
-
-struct msm_cost {
-    msm_ctx *ctx = nullptr;
-    msm_cost_params p{};
-    msm_mesh *target = nullptr, *source = nullptr, *cpgrid = nullptr;
-    std::vector<double> orig_xyz;  // _ORIG: source coordinates at set_meshes (3 x Nsrc)
-    std::vector<double> ocp_xyz;   // _oCPgrid
-    int D = 0;
-    std::vector<double> sfeat;
-    DevBuf<double> d_sfeat;
-    std::vector<double> cfw;
-    int cfw_rows = 0;
-    DevBuf<double> d_cfw;
-    std::vector<double> maxsep;
-    double mvdmax = 0;
-    DevBuf<double> d_maxsep;
-    int L = 0;
-    std::vector<double> labels, rot;
-    DevBuf<double> d_labels, d_rot;
-    DevBuf<double> d_rnl, d_moved;  // per (node,label): rotation matrix and moved control point
-    std::vector<int32_t> triplets, pairs;
-    DevBuf<int32_t> d_triplets, d_pairs;
-    DevBuf<double> d_orig, d_ocp;
-    // get_source_data products
-    bool have_source = false;
-    int ngroups = 0, pmax = 0;
-    std::vector<int32_t> pptr, pidx;
-    DevBuf<int32_t> d_pptr, d_pidx;
-    std::vector<double> absw;
-    DevBuf<double> d_absw;
-    // unary table
-    DevBuf<double> d_U;
-    bool table_valid = false;
-    bool rotations_valid = false;
-    std::vector<double> h_U;
-    DevBuf<unsigned long long> d_counters;
-    int64_t counters[4] = {0, 0, 0, 0};
-    // scratch for the range kernel
-    DevBuf<uint32_t> d_slots;
-    // scratch of the unary kernels
-    DevBuf<double> d_tval;
-    DevBuf<unsigned long long> d_fix_list;
-    DevBuf<unsigned int> d_fix_count;
-    DevBuf<int> d_queues;  // nodes whose reduction waits for the fix-up kernel
-    DevBuf<int> d_counts;
-};
 
 namespace {
 
@@ -72,7 +33,7 @@ void invalidate_table(msm_cost *c) {
     c->h_U.clear();
 }
 
-bool is_ho(const msm_cost *c) { return c->p.kind == MSM_COST_HO_UNIVARIATE || c->p.kind == MSM_COST_HO_MULTIVARIATE; }
+bool is_ho(const msm_cost *c) { return cost_is_ho(c); }
 
 int need(const msm_cost *c, bool cond, const char *what) {
     if (!cond) return fail(MSM_ERR_STATE, "msm_cost: %s must be set first", what);
@@ -191,13 +152,8 @@ int ensure_unary_table(msm_cost *c) {
     u.N = N;
     u.L = c->L;
     u.cp = c->cpgrid->d_xyz;
-    if (!c->rotations_valid) {  // a pure function of the control grid, ROT and the label set
-        MSM_HIP(c->d_rnl.ensure((size_t)N * c->L * 9));
-        MSM_HIP(c->d_moved.ensure((size_t)N * c->L * 3));
-        st = launch_label_rotations(ctx, c->cpgrid->d_xyz, N, c->d_rot.p, c->d_labels.p, c->L, c->d_rnl.p, c->d_moved.p);
-        if (st) return st;
-        c->rotations_valid = true;
-    }
+    st = ensure_label_rotations(c);
+    if (st) return st;
     u.rnl = c->d_rnl.p;
     u.labels = c->d_labels.p;
     u.src = c->source->d_xyz;
@@ -225,7 +181,15 @@ int ensure_unary_table(msm_cost *c) {
     u.redo_list = c->d_queues.p;
     switch (c->p.kind) {
         case MSM_COST_UNIVARIATE: st = launch_unary_univariate(ctx, u); break;
-        default: return fail(MSM_ERR_INVALID, "cost kind %d is not implemented on the device yet", c->p.kind);
+        case MSM_COST_MULTIVARIATE:
+        case MSM_COST_PATCHWISE: {
+            MSM_HIP(c->d_stri.ensure(nsamp));
+            MSM_HIP(c->d_sw3.ensure(3 * nsamp));
+            UnaryWeightsScratch w{c->d_stri.p, c->d_sw3.p};
+            st = launch_unary_multivariate(ctx, u, w, c->p.kind == MSM_COST_PATCHWISE);
+            break;
+        }
+        default: return fail(MSM_ERR_INVALID, "unknown cost kind %d", c->p.kind);
     }
     if (st) return st;
     c->counters[1] += (int64_t)c->L * N;
@@ -276,6 +240,7 @@ int msm_cost_set_meshes(msm_cost *c, msm_mesh *target, msm_mesh *source, msm_mes
     c->target = target;
     c->source = source;
     c->cpgrid = cpgrid;
+    c->cp_conn_valid = false;
     c->orig_xyz = source->xyz;
     c->ocp_xyz = cpgrid->xyz;
     MSM_HIP(c->d_orig.upload(c->orig_xyz.data(), c->orig_xyz.size(), c->ctx->stream));
@@ -299,6 +264,7 @@ int msm_cost_reset_cpgrid(msm_cost *c, msm_mesh *cpgrid) {
     if (!c || !cpgrid) return fail(MSM_ERR_INVALID, "msm_cost_reset_cpgrid: null argument");
     if (c->cpgrid && cpgrid->V != c->cpgrid->V) return fail(MSM_ERR_INVALID, "control grid size changed");
     c->cpgrid = cpgrid;
+    c->cp_conn_valid = false;
     c->have_source = false;
     invalidate_table(c);
     return MSM_OK;

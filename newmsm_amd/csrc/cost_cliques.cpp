@@ -1,18 +1,211 @@
-// cost_cliques.cpp -- triplet / pairwise clique costs of the discrete cost function (placeholder until
-// the clique kernels land; every symbol of msmhip.h must exist).
-#include "internal.hpp"
+// cost_cliques.cpp -- C ABI of the pairwise / triplet clique costs and of evaluateTotalCostSum
+// (include/msmhip.h).  Kernels: clique_kernels.hip.
+#include <algorithm>
+
+#include "cost_internal.hpp"
 
 using namespace msm;
 
+namespace {
+
+// everything the clique kernels read; uploads the control grid's connectivity on first use
+int clique_args(msm_cost *c, bool need_triplets, bool need_pairs, CliqueArgs &a) {
+    if (!c->cpgrid || !c->source || !c->target) return fail(MSM_ERR_STATE, "msm_cost: meshes must be set first");
+    if (need_triplets && c->triplets.empty()) return fail(MSM_ERR_STATE, "msm_cost: triplets must be set first");
+    if (need_pairs && c->pairs.empty()) return fail(MSM_ERR_STATE, "msm_cost: pairs must be set first");
+    int st = ensure_label_rotations(c);
+    if (st) return st;
+    msm_ctx *ctx = c->ctx;
+    msm_mesh *g = c->cpgrid;
+    if (!c->cp_conn_valid) {
+        const Adjacency &adj = mesh_adjacency(g);
+        MSM_HIP(c->d_cp_tri.upload(g->tri.data(), g->tri.size(), ctx->stream));
+        MSM_HIP(c->d_cp_tid_ptr.upload(adj.tid_ptr.data(), adj.tid_ptr.size(), ctx->stream));
+        MSM_HIP(c->d_cp_tid.upload(adj.tid.data(), adj.tid.size(), ctx->stream));
+        MSM_HIP(hipStreamSynchronize(ctx->stream));
+        c->cp_conn_valid = true;
+    }
+    a.kind = c->p.kind;
+    a.simmeasure = c->p.simmeasure;
+    a.N = g->V;
+    a.L = c->L;
+    a.T = (int)(c->triplets.size() / 3);
+    a.P = (int)(c->pairs.size() / 2);
+    a.triplets = c->d_triplets.p;
+    a.pairs = c->d_pairs.p;
+    a.cp = g->d_xyz;
+    a.ocp = c->d_ocp.p;
+    a.orig = c->d_orig.p;
+    a.Norig = (int)(c->orig_xyz.size() / 3);
+    a.moved = c->d_moved.p;
+    a.rnl = c->d_rnl.p;
+    a.cp_tri = c->d_cp_tri.p;
+    a.Tc = g->T;
+    a.cp_tid_ptr = c->d_cp_tid_ptr.p;
+    a.cp_tid = c->d_cp_tid.p;
+    a.lambda = c->p.lambda;
+    a.mu = c->p.mu;
+    a.kappa = c->p.kappa;
+    a.k_exp = c->p.k_exp;
+    a.rexp = c->p.rexp;
+    a.mvdmax = c->mvdmax;
+    a.tfeat = c->target->d_feat;
+    a.D = c->D;
+    a.src = c->source->d_xyz;
+    a.Nsrc = c->source->V;
+    a.sfeat = c->d_sfeat.p;
+    a.cfw = c->cfw.empty() ? nullptr : c->d_cfw.p;
+    a.cfw_rows = c->cfw_rows;
+    a.bin_ptr = c->d_pptr.p;
+    a.bin_idx = c->d_pidx.p;
+    a.absw = c->d_absw.p;
+    a.status = ctx->d_status;
+    if (need_triplets && cost_is_ho(c)) {
+        if (!c->have_source) return fail(MSM_ERR_STATE, "msm_cost: get_source_data() must be called first");
+        if (!c->target->d_feat || c->target->D != c->D) return fail(MSM_ERR_STATE, "msm_cost: target features must match the source features");
+        st = ensure_tree(c->target);
+        if (st) return st;
+    }
+    a.tree = dev_tree(c->target);
+    if (need_triplets && c->p.rmode != 2 && c->p.rmode != 3)
+        return fail(MSM_ERR_INVALID, "DiscreteModel computeTripletCost regoption does not exist (regularisermode %d; the anatomical modes are not offloaded)",
+                    c->p.rmode);
+    return MSM_OK;
+}
+
+int upload_ints(msm_ctx *ctx, DevBuf<int> &buf, const int32_t *host, size_t n) {
+    MSM_HIP(buf.upload(host, n, ctx->stream));
+    return MSM_OK;
+}
+
+}  // namespace
+
 extern "C" {
 
-int msm_cost_triplet_batch(msm_cost *, const int32_t *, const int32_t *, const int32_t *, const int32_t *, int32_t, double *) {
-    return fail(MSM_ERR_STATE, "msm_cost_triplet_batch: not implemented yet");
+int msm_cost_triplet_batch(msm_cost *c, const int32_t *triplet, const int32_t *la, const int32_t *lb, const int32_t *lc, int32_t n, double *out) {
+    if (!c || !triplet || !la || !lb || !lc || !out || n < 0) return fail(MSM_ERR_INVALID, "msm_cost_triplet_batch: bad arguments");
+    if (n == 0) return MSM_OK;
+    CliqueArgs a;
+    int st = clique_args(c, true, false, a);
+    if (st) return st;
+    for (int i = 0; i < n; ++i)
+        if (triplet[i] < 0 || triplet[i] >= a.T || la[i] < 0 || la[i] >= a.L || lb[i] < 0 || lb[i] >= a.L || lc[i] < 0 || lc[i] >= a.L)
+            return fail(MSM_ERR_INVALID, "triplet query %d out of range", i);
+    msm_ctx *ctx = c->ctx;
+    DevBuf<int> qt, qa, qb, qc;
+    DevBuf<double> dout;
+    if ((st = upload_ints(ctx, qt, triplet, n)) || (st = upload_ints(ctx, qa, la, n)) || (st = upload_ints(ctx, qb, lb, n)) ||
+        (st = upload_ints(ctx, qc, lc, n)))
+        return st;
+    MSM_HIP(dout.ensure(n));
+    st = launch_triplet_batch(ctx, a, qt.p, qa.p, qb.p, qc.p, n, dout.p);
+    if (st) return st;
+    MSM_HIP(dout.download(out, n, ctx->stream));
+    c->counters[2] += n;
+    return check_status(ctx, "computeTripletCost");
 }
-int msm_cost_triplet_octets(msm_cost *, const int32_t *, int32_t, double *) { return fail(MSM_ERR_STATE, "msm_cost_triplet_octets: not implemented yet"); }
-int msm_cost_pairwise_batch(msm_cost *, const int32_t *, const int32_t *, const int32_t *, int32_t, double *) {
-    return fail(MSM_ERR_STATE, "msm_cost_pairwise_batch: not implemented yet");
+
+int msm_cost_triplet_octets(msm_cost *c, const int32_t *labeling, int32_t label, double *E) {
+    if (!c || !labeling || !E) return fail(MSM_ERR_INVALID, "msm_cost_triplet_octets: null argument");
+    CliqueArgs a;
+    int st = clique_args(c, true, false, a);
+    if (st) return st;
+    if (label < 0 || label >= a.L) return fail(MSM_ERR_INVALID, "label %d out of range", label);
+    for (int i = 0; i < a.N; ++i)
+        if (labeling[i] < 0 || labeling[i] >= a.L) return fail(MSM_ERR_INVALID, "labeling[%d] out of range", i);
+    msm_ctx *ctx = c->ctx;
+    MSM_HIP(c->d_labeling.upload(labeling, a.N, ctx->stream));
+    MSM_HIP(c->d_clique_out.ensure((size_t)8 * a.T));
+    st = launch_triplet_octets(ctx, a, c->d_labeling.p, label, c->d_clique_out.p);
+    if (st) return st;
+    MSM_HIP(c->d_clique_out.download(E, (size_t)8 * a.T, ctx->stream));
+    c->counters[2] += (int64_t)8 * a.T;
+    return check_status(ctx, "computeTripletCost");
 }
-int msm_cost_pairwise_table(msm_cost *, double *) { return fail(MSM_ERR_STATE, "msm_cost_pairwise_table: not implemented yet"); }
-int msm_cost_total(msm_cost *, const int32_t *, double *, double *) { return fail(MSM_ERR_STATE, "msm_cost_total: not implemented yet"); }
+
+int msm_cost_pairwise_batch(msm_cost *c, const int32_t *pair, const int32_t *la, const int32_t *lb, int32_t n, double *out) {
+    if (!c || !pair || !la || !lb || !out || n < 0) return fail(MSM_ERR_INVALID, "msm_cost_pairwise_batch: bad arguments");
+    if (n == 0) return MSM_OK;
+    CliqueArgs a;
+    int st = clique_args(c, false, true, a);
+    if (st) return st;
+    for (int i = 0; i < n; ++i)
+        if (pair[i] < 0 || pair[i] >= a.P || la[i] < 0 || la[i] >= a.L || lb[i] < 0 || lb[i] >= a.L) return fail(MSM_ERR_INVALID, "pairwise query %d out of range", i);
+    msm_ctx *ctx = c->ctx;
+    DevBuf<int> qp, qa, qb;
+    DevBuf<double> dout;
+    if ((st = upload_ints(ctx, qp, pair, n)) || (st = upload_ints(ctx, qa, la, n)) || (st = upload_ints(ctx, qb, lb, n))) return st;
+    MSM_HIP(dout.ensure(n));
+    st = launch_pairwise_batch(ctx, a, qp.p, qa.p, qb.p, n, dout.p);
+    if (st) return st;
+    MSM_HIP(dout.download(out, n, ctx->stream));
+    c->counters[3] += n;
+    return check_status(ctx, "computePairwiseCost");
 }
+
+int msm_cost_pairwise_table(msm_cost *c, double *paircosts) {
+    if (!c || !paircosts) return fail(MSM_ERR_INVALID, "msm_cost_pairwise_table: null argument");
+    CliqueArgs a;
+    int st = clique_args(c, false, true, a);
+    if (st) return st;
+    msm_ctx *ctx = c->ctx;
+    const size_t total = (size_t)a.P * a.L * a.L;
+    MSM_HIP(c->d_clique_out.ensure(total));
+    st = launch_pairwise_table(ctx, a, c->d_clique_out.p);
+    if (st) return st;
+    MSM_HIP(c->d_clique_out.download(paircosts, total, ctx->stream));
+    c->counters[3] += (int64_t)total;
+    return check_status(ctx, "computePairwiseCosts");
+}
+
+// evaluateTotalCostSum, M/DiscreteCostFunction.cpp:55-77: the three sums run in the reference's serial order on
+// the host over device-evaluated terms (N + P + T values), because the order defines the reported energy
+int msm_cost_total(msm_cost *c, const int32_t *labeling, double *total, double parts[3]) {
+    if (!c || !labeling || !total) return fail(MSM_ERR_INVALID, "msm_cost_total: null argument");
+    if (!c->cpgrid) return fail(MSM_ERR_STATE, "msm_cost: meshes must be set first");
+    const int N = c->cpgrid->V;
+    double u = 0.0, pw = 0.0, tc = 0.0;
+    {
+        std::vector<int32_t> nodes(N);
+        std::vector<double> vals(N);
+        for (int i = 0; i < N; ++i) nodes[i] = i;
+        int st = msm_cost_unary_batch(c, nodes.data(), labeling, N, vals.data());
+        if (st) return st;
+        for (int i = 0; i < N; ++i) u += vals[i];
+    }
+    const int P = (int)(c->pairs.size() / 2), T = (int)(c->triplets.size() / 3);
+    if (P > 0) {
+        std::vector<int32_t> id(P), la(P), lb(P);
+        std::vector<double> vals(P);
+        for (int p = 0; p < P; ++p) {
+            id[p] = p;
+            la[p] = labeling[c->pairs[2 * p]];
+            lb[p] = labeling[c->pairs[2 * p + 1]];
+        }
+        int st = msm_cost_pairwise_batch(c, id.data(), la.data(), lb.data(), P, vals.data());
+        if (st) return st;
+        for (int p = 0; p < P; ++p) pw += vals[p];
+    }
+    if (T > 0) {
+        std::vector<int32_t> id(T), la(T), lb(T), lc(T);
+        std::vector<double> vals(T);
+        for (int t = 0; t < T; ++t) {
+            id[t] = t;
+            la[t] = labeling[c->triplets[3 * t]];
+            lb[t] = labeling[c->triplets[3 * t + 1]];
+            lc[t] = labeling[c->triplets[3 * t + 2]];
+        }
+        int st = msm_cost_triplet_batch(c, id.data(), la.data(), lb.data(), lc.data(), T, vals.data());
+        if (st) return st;
+        for (int t = 0; t < T; ++t) tc += vals[t];
+    }
+    if (parts) {
+        parts[0] = u;
+        parts[1] = pw;
+        parts[2] = tc;
+    }
+    *total = u + pw + tc;
+    return MSM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,73 @@
+// cost_internal.hpp -- the msm_cost handle shared by cost.cpp (unary) and cost_cliques.cpp (pairwise / triplet).
+#pragma once
+
+#include <vector>
+
+#include "devbuf.hpp"
+#include "kernels.hpp"
+
+using msm::DevBuf;
+
+struct msm_cost {
+    msm_ctx *ctx = nullptr;
+    msm_cost_params p{};
+    msm_mesh *target = nullptr, *source = nullptr, *cpgrid = nullptr;
+    std::vector<double> orig_xyz;  // _ORIG: source coordinates at set_meshes (3 x Nsrc)
+    std::vector<double> ocp_xyz;   // _oCPgrid
+    int D = 0;
+    std::vector<double> sfeat;
+    DevBuf<double> d_sfeat;
+    std::vector<double> cfw;
+    int cfw_rows = 0;
+    DevBuf<double> d_cfw;
+    std::vector<double> maxsep;
+    double mvdmax = 0;
+    DevBuf<double> d_maxsep;
+    int L = 0;
+    std::vector<double> labels, rot;
+    DevBuf<double> d_labels, d_rot;
+    DevBuf<double> d_rnl, d_moved;  // per (node,label): rotation matrix and moved control point
+    std::vector<int32_t> triplets, pairs;
+    DevBuf<int32_t> d_triplets, d_pairs;
+    DevBuf<double> d_orig, d_ocp;
+    // control grid connectivity for the pairwise fold test
+    DevBuf<int32_t> d_cp_tri, d_cp_tid_ptr, d_cp_tid;
+    bool cp_conn_valid = false;
+    DevBuf<int32_t> d_labeling;
+    DevBuf<double> d_clique_out;
+    // get_source_data products
+    bool have_source = false;
+    int ngroups = 0, pmax = 0;
+    std::vector<int32_t> pptr, pidx;
+    DevBuf<int32_t> d_pptr, d_pidx;
+    std::vector<double> absw;
+    DevBuf<double> d_absw;
+    // unary table
+    DevBuf<double> d_U;
+    bool table_valid = false;
+    bool rotations_valid = false;
+    std::vector<double> h_U;
+    DevBuf<unsigned long long> d_counters;
+    int64_t counters[4] = {0, 0, 0, 0};
+    // scratch for the range kernel
+    DevBuf<uint32_t> d_slots;
+    // scratch of the unary kernels
+    DevBuf<double> d_tval;
+    DevBuf<int> d_stri;
+    DevBuf<double> d_sw3;
+    DevBuf<unsigned long long> d_fix_list;
+    DevBuf<unsigned int> d_fix_count;
+    DevBuf<int> d_queues;  // nodes whose reduction waits for the fix-up kernel
+    DevBuf<int> d_counts;
+};
+
+
+namespace msm {
+int adaptive_weights(msm_mesh *in_mesh, msm_mesh *new_mesh, const double *excl, std::vector<int32_t> &row_ptr, std::vector<int32_t> &col,
+                     std::vector<double> &val);
+int query_host(msm_mesh *target, const double *q, int N, int *tri_id, int *vid, double *w, int mode, const char *what);
+const Adjacency &mesh_adjacency(msm_mesh *m);
+// (re)computes the per (control point, label) rotation matrices and moved control points if stale
+int ensure_label_rotations(msm_cost *c);
+inline bool cost_is_ho(const msm_cost *c) { return c->p.kind == MSM_COST_HO_UNIVARIATE || c->p.kind == MSM_COST_HO_MULTIVARIATE; }
+}  // namespace msm

@@ -44,5 +44,45 @@ struct UnaryLaunch {
     int *redo_list;                // N ints
 };
 int launch_unary_univariate(msm_ctx *ctx, const UnaryLaunch &u);
+// multivariate / patchwise: the samples kernel stores (triangle, raw weights) per sample, a second kernel reduces
+struct UnaryWeightsScratch {
+    int *stri;      // one int per sample
+    double *sw3;    // three doubles per sample
+};
+int launch_unary_multivariate(msm_ctx *ctx, const UnaryLaunch &u, const UnaryWeightsScratch &w, bool patchwise);
+
+// pairwise / triplet clique costs
+struct CliqueArgs {
+    int kind, simmeasure;
+    int N, L, T, P;
+    const int *triplets;      // T x 3
+    const int *pairs;         // P x 2
+    const double *cp;         // 3 x N current control grid
+    const double *ocp;        // 3 x N control grid at set_meshes (_oCPgrid)
+    const double *orig;       // 3 x Norig source coordinates at set_meshes (_ORIG), indexed by control-point id
+    int Norig;
+    const double *moved;      // N x L x 3: ROT[node] * label
+    const double *rnl;        // N x L x 9
+    const int *cp_tri;        // 3 x Tc control grid triangles
+    int Tc;
+    const int *cp_tid_ptr, *cp_tid;  // triangles adjacent to each control point
+    double lambda, mu, kappa, k_exp, rexp, mvdmax;
+    // HO likelihood
+    DevTree tree;
+    const double *tfeat;      // V x D
+    int D;
+    const double *src;        // 3 x Nsrc
+    int Nsrc;
+    const double *sfeat;      // D x Nsrc
+    const double *cfw;
+    int cfw_rows;
+    const int *bin_ptr, *bin_idx;  // source vertices per control-grid triangle
+    const double *absw;
+    int *status;
+};
+int launch_triplet_batch(msm_ctx *ctx, const CliqueArgs &a, const int *qt, const int *qa, const int *qb, const int *qc, int n, double *out);
+int launch_triplet_octets(msm_ctx *ctx, const CliqueArgs &a, const int *labeling, int label, double *out);
+int launch_pairwise_batch(msm_ctx *ctx, const CliqueArgs &a, const int *qp, const int *qa, const int *qb, int n, double *out);
+int launch_pairwise_table(msm_ctx *ctx, const CliqueArgs &a, double *out);
 
 }  // namespace msm

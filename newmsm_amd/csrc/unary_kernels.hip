@@ -25,6 +25,7 @@
 
 #include "kernels.hpp"
 #include "search_device.hpp"
+#include "similarity_device.hpp"
 
 #ifndef MSM_VARIANT
 #define MSM_VARIANT 0  // profiling only: 1 = stop after phase A, 2 = stop after phase B, 4 = skip the cone filter
@@ -439,15 +440,131 @@ __global__ __launch_bounds__(256) void k_unary_reduce_univariate(ReduceArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Multivariate / patchwise reductions from the stored (triangle, raw weights) of every sample.
+//   multivariate (M/DiscreteCostFunction.cpp:444-458): mean over the patch points of a D-long feature-vector
+//                similarity; one lane per patch point, the D loop runs inside the lane;
+//   patchwise    (:680-692): per feature channel a patch similarity (lanes over points, shuffle reduction),
+//                averaged over the channels.
+// One workgroup per control point, one wavefront per label.
+// ------------------------------------------------------------------------------------------------
+struct ReduceMvArgs {
+    int N, L, Nsrc, D;
+    const double *tfeat;  // V x D vertex-major
+    const TriRec *rec;
+    const double *sfeat;  // D x Nsrc
+    const double *cfw;
+    int cfw_rows;
+    const int *pptr, *pidx;
+    const double *absw;
+    const int *stri;
+    const double *sw3;
+    int simmeasure;
+    int patchwise;
+    double *U;
+};
+
+__global__ __launch_bounds__(256) void k_unary_reduce_features(ReduceMvArgs a) {
+    const int node = blockIdx.x;
+    const int beg = a.pptr[node], P = a.pptr[node + 1] - beg;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const double absw = a.absw[node];
+    const double nan = __longlong_as_double(0x7ff8000000000000ll);
+    for (int l = wave; l < a.L; l += 4) {
+        const size_t g0 = (size_t)a.L * beg + (size_t)l * P;
+        double cost;
+        if (!a.patchwise) {
+            double acc = 0.0;
+            bool bad = false;
+            for (int i = lane; i < P; i += 64) {
+                const int t = a.stri[g0 + i];
+                if (t < 0) {
+                    bad = true;
+                    continue;
+                }
+                const TriRec &r = a.rec[t];
+                const double *f0 = a.tfeat + (size_t)r.id[0] * a.D, *f1 = a.tfeat + (size_t)r.id[1] * a.D, *f2 = a.tfeat + (size_t)r.id[2] * a.D;
+                acc += feature_vector_similarity(a.simmeasure, a.sfeat, a.cfw, a.cfw_rows, a.Nsrc, a.pidx[beg + i], a.D, f0, f1, f2,
+                                                 a.sw3[3 * (g0 + i)], a.sw3[3 * (g0 + i) + 1], a.sw3[3 * (g0 + i) + 2]);
+            }
+            acc = wave_sum(acc);
+            cost = P > 0 ? acc / P : acc;
+            if (__ballot(bad)) cost = nan;
+        } else {
+            double total = 0.0;
+            bool bad = false;
+            for (int d = 0; d < a.D; ++d) {
+                const double *A = a.sfeat + (size_t)d * a.Nsrc;
+                auto Bv = [&](int i) {
+                    const int t = a.stri[g0 + i];
+                    if (t < 0) {
+                        bad = true;
+                        return nan;
+                    }
+                    const TriRec &r = a.rec[t];
+                    return a.sw3[3 * (g0 + i)] * a.tfeat[(size_t)r.id[0] * a.D + d] + a.sw3[3 * (g0 + i) + 1] * a.tfeat[(size_t)r.id[1] * a.D + d] +
+                           a.sw3[3 * (g0 + i) + 2] * a.tfeat[(size_t)r.id[2] * a.D + d];
+                };
+                auto Wv = [&](int i) { return (a.cfw && a.cfw_rows >= 1) ? a.cfw[a.pidx[beg + i]] : 1.0; };
+                double c;
+                if (a.simmeasure == 2) {
+                    double sw = 0, ma = 0, mb = 0;
+                    for (int i = lane; i < P; i += 64) {
+                        const double w = Wv(i);
+                        sw += w;
+                        ma += w * A[a.pidx[beg + i]];
+                        mb += w * Bv(i);
+                    }
+                    sw = wave_sum(sw);
+                    ma = wave_sum(ma);
+                    mb = wave_sum(mb);
+                    if (sw > 0.0) {
+                        ma /= sw;
+                        mb /= sw;
+                    }
+                    double pr = 0, va = 0, vb = 0;
+                    for (int i = lane; i < P; i += 64) {
+                        const double w = Wv(i), da = A[a.pidx[beg + i]] - ma, db = Bv(i) - mb;
+                        pr += w * da * db;
+                        va += w * da * da;
+                        vb += w * db * db;
+                    }
+                    pr = wave_sum(pr);
+                    va = wave_sum(va);
+                    vb = wave_sum(vb);
+                    if (sw > 0.0) {
+                        pr /= sw;
+                        va /= sw;
+                        vb /= sw;
+                    }
+                    const double r = (va == 0.0 || vb == 0.0) ? 0.0 : pr / (sqrt(va) * sqrt(vb));
+                    c = 1 - (1 + r) * 0.5;
+                } else {
+                    double pr = 0;
+                    for (int i = lane; i < P; i += 64) {
+                        const double df = A[a.pidx[beg + i]] - Bv(i);
+                        pr += Wv(i) * df * df;
+                    }
+                    pr = wave_sum(pr);
+                    c = sqrt(pr) / P;
+                }
+                total += c;
+            }
+            cost = total / a.D;
+            if (__ballot(bad)) cost = nan;
+        }
+        if (lane == 0) a.U[(size_t)l * a.N + node] = absw * cost;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // launch
 // ------------------------------------------------------------------------------------------------
 static size_t samples_lds(int pmax, int L) {
     return sizeof(double) * (5 * (size_t)pmax + 9 * (size_t)L + (size_t)L * pmax) + sizeof(unsigned) * kQueueCap + sizeof(int) * 2 * kChunk;
 }
 
-int launch_unary_univariate(msm_ctx *ctx, const UnaryLaunch &u) {
-    if (u.tree.nnodes <= 0) return fail(MSM_ERR_STATE, "target search structure missing");
-    SamplesArgs a;
+static int launch_samples(msm_ctx *ctx, const UnaryLaunch &u, const UnaryWeightsScratch *w, SamplesArgs &a) {
+    if (u.tree.nnodes <= 0 || !u.tree.mask) return fail(MSM_ERR_STATE, "target search structure missing");
     a.tree = u.tree;
     a.tfeat = u.tfeat;
     a.N = u.N;
@@ -458,9 +575,9 @@ int launch_unary_univariate(msm_ctx *ctx, const UnaryLaunch &u) {
     a.pptr = u.pptr;
     a.pidx = u.pidx;
     a.pmax = u.pmax;
-    a.tval = u.tval;
-    a.stri = nullptr;
-    a.sw3 = nullptr;
+    a.tval = w ? nullptr : u.tval;
+    a.stri = w ? w->stri : nullptr;
+    a.sw3 = w ? w->sw3 : nullptr;
     a.fix_list = u.fix_list;
     a.fix_count = u.fix_count;
     a.fix_cap = u.fix_cap;
@@ -468,7 +585,7 @@ int launch_unary_univariate(msm_ctx *ctx, const UnaryLaunch &u) {
     a.cfw = (u.cfw && u.cfw_rows >= 1) ? u.cfw : nullptr;
     a.absw = u.absw;
     a.simmeasure = u.simmeasure;
-    a.U = u.U;
+    a.U = w ? nullptr : u.U;  // the fused reduction is the univariate one
     a.redo_list = u.redo_list;
     a.redo_count = u.fix_count + 1;
     a.status = ctx->d_status;
@@ -485,6 +602,14 @@ int launch_unary_univariate(msm_ctx *ctx, const UnaryLaunch &u) {
     MSM_HIP(hipGetLastError());
     hipLaunchKernelGGL(k_unary_fixup, dim3(64), dim3(256), 0, ctx->stream, a);
     MSM_HIP(hipGetLastError());
+    return MSM_OK;
+}
+
+int launch_unary_univariate(msm_ctx *ctx, const UnaryLaunch &u) {
+    SamplesArgs a;
+    int st = launch_samples(ctx, u, nullptr, a);
+    if (st) return st;
+    // control points that had deferred samples are reduced now that the fix-up kernel has filled them in
     ReduceArgs r;
     r.N = u.N;
     r.L = u.L;
@@ -502,6 +627,33 @@ int launch_unary_univariate(msm_ctx *ctx, const UnaryLaunch &u) {
     r.redo_list = u.redo_list;
     r.redo_count = u.fix_count + 1;
     hipLaunchKernelGGL(k_unary_reduce_univariate, dim3(64), dim3(256), sizeof(double) * 2 * (size_t)u.pmax, ctx->stream, r);
+    MSM_HIP(hipGetLastError());
+    return MSM_OK;
+}
+
+int launch_unary_multivariate(msm_ctx *ctx, const UnaryLaunch &u, const UnaryWeightsScratch &w, bool patchwise) {
+    SamplesArgs a;
+    int st = launch_samples(ctx, u, &w, a);
+    if (st) return st;
+    ReduceMvArgs r;
+    r.N = u.N;
+    r.L = u.L;
+    r.Nsrc = u.Nsrc;
+    r.D = u.D;
+    r.tfeat = u.tfeat;
+    r.rec = u.tree.rec;
+    r.sfeat = u.sfeat;
+    r.cfw = u.cfw;
+    r.cfw_rows = u.cfw_rows;
+    r.pptr = u.pptr;
+    r.pidx = u.pidx;
+    r.absw = u.absw;
+    r.stri = w.stri;
+    r.sw3 = w.sw3;
+    r.simmeasure = u.simmeasure;
+    r.patchwise = patchwise ? 1 : 0;
+    r.U = u.U;
+    hipLaunchKernelGGL(k_unary_reduce_features, dim3(u.N), dim3(256), 0, ctx->stream, r);
     MSM_HIP(hipGetLastError());
     return MSM_OK;
 }

@@ -1,0 +1,151 @@
+"""The other cost-function classes and the clique costs on the GPU against the oracle.
+
+Tolerances: these costs go through acos/asin/sincos/pow (device libm vs glibc) and, for the strain energy, a
+2x2 inverse and 3x3 determinant that the oracle writes out with cofactors; rtol 1e-9 / atol 1e-11."""
+import numpy as np
+import pytest
+
+import newmsm_amd as M
+from newmsm_amd import problem
+from tests.helpers import oracle_cost
+
+pytestmark = pytest.mark.gpu
+RTOL, ATOL = 1e-9, 1e-11
+
+
+def pair(ctx, inp, kind, **kw):
+    cf, keep = problem.build_cost(ctx, inp, kind=kind, **kw)
+    cf.get_source_data()
+    oc = oracle_cost(inp, kind, **kw)
+    oc.get_source_data()
+    return cf, oc, keep
+
+
+@pytest.mark.parametrize("kind", ["multivariate", "patchwise"])
+@pytest.mark.parametrize("sim", [2, 1])
+def test_unary_table_feature_kinds(ctx, kind, sim):
+    inp = problem.pairwise_inputs(5, 3, D=4)
+    cf, oc, _ = pair(ctx, inp, kind, simmeasure=sim)
+    U, Uo = cf.computeUnaryCosts(), oc.unary_table()
+    assert np.isfinite(U).all()
+    assert np.allclose(U, Uo, rtol=RTOL, atol=ATOL), np.max(np.abs(U - Uo))
+
+
+def test_multivariate_with_per_dimension_weights(ctx):
+    inp = problem.pairwise_inputs(4, 2, D=3)
+    rng = np.random.default_rng(4)
+    w = rng.uniform(0.1, 1.0, size=(3, len(inp["source_xyz"])))
+    cf, _ = problem.build_cost(ctx, inp, kind="multivariate")
+    cf.set_dataaffintyweighting(w)
+    cf.get_source_data()
+    oc = oracle_cost(inp, "multivariate")
+    oc.set_cfweight(w)
+    oc.get_source_data()
+    assert np.array_equal(cf.absolute_weights(), oc.absolute_weights())
+    assert np.allclose(cf.computeUnaryCosts(), oc.unary_table(), rtol=RTOL, atol=ATOL)
+
+
+def test_multivariate_d32_full_size_spot_check(ctx):
+    # BASELINE config 3 shape (MSMAll-like, 32 feature dimensions) at ico6 / ico4, checked on a sample of evaluations
+    inp = problem.pairwise_inputs(6, 4, D=32)
+    cf, oc, _ = pair(ctx, inp, "multivariate")
+    U = cf.computeUnaryCosts()
+    assert U.shape == (19, 2562) and np.isfinite(U).all()
+    rng = np.random.default_rng(2)
+    for n, l in zip(rng.integers(0, 2562, 12), rng.integers(0, 19, 12)):
+        assert abs(U[l, n] - oc.unary(n, l)) <= ATOL + RTOL * abs(U[l, n])
+
+
+def random_queries(rng, n, count, L, k):
+    return [rng.integers(0, count, n).astype(np.int32)] + [rng.integers(0, L, n).astype(np.int32) for _ in range(k)]
+
+
+def test_triplet_strain_costs(ctx):
+    inp = problem.pairwise_inputs(5, 3, D=1)
+    cf, oc, _ = pair(ctx, inp, "univariate", rmode=3, lambda_=0.2, mu=0.1, kappa=10.0, k_exp=2.0, rexp=2.0)
+    rng = np.random.default_rng(0)
+    t, la, lb, lc = random_queries(rng, 3000, cf.T, cf.L, 3)
+    got = cf.computeTripletCost(t, la, lb, lc)
+    want = np.array([oc.triplet(*q) for q in zip(t, la, lb, lc)])
+    assert np.allclose(got, want, rtol=RTOL, atol=ATOL), np.max(np.abs(got - want))
+    assert (want >= 1e6).sum() > 0, "the sample should include folded moves"
+    assert np.array_equal(got >= 1e6, want >= 1e6)
+    # the zero labelling costs exactly the strain of the current grid; label 0 is the centre
+    lab0 = np.zeros(cf.N, dtype=np.int32)
+    E = cf.tripletOctets(lab0, 0)
+    assert np.allclose(E, E[:, :1], rtol=0, atol=0)  # all eight combinations coincide when label == current
+
+
+def test_triplet_octets_match_fusion_order(ctx):
+    inp = problem.pairwise_inputs(4, 2, D=1)
+    cf, oc, _ = pair(ctx, inp, "univariate", rmode=3, rexp=1.0, k_exp=1.5)
+    rng = np.random.default_rng(1)
+    labeling = rng.integers(0, cf.L, cf.N).astype(np.int32)
+    label = 5
+    E = cf.tripletOctets(labeling, label)
+    trip = inp["triplets"]
+    for t in rng.integers(0, cf.T, 60):
+        a, b, c = labeling[trip[t]]
+        combos = [(a, b, c), (a, b, label), (a, label, c), (a, label, label), (label, b, c), (label, b, label), (label, label, c), (label, label, label)]
+        want = [oc.triplet(t, *q) for q in combos]  # order 000..111 of I/Fusion/Fusion.h:188-195
+        assert np.allclose(E[t], want, rtol=RTOL, atol=ATOL)
+
+
+@pytest.mark.parametrize("kind,D", [("ho_univariate", 1), ("ho_multivariate", 3)])
+def test_triclique_likelihood(ctx, kind, D):
+    inp = problem.pairwise_inputs(5, 3, D=D)
+    cf, oc, _ = pair(ctx, inp, kind, rmode=3, lambda_=0.1)
+    ptr, idx = cf.patches()
+    optr, oidx = oc.patches()
+    assert np.array_equal(ptr, optr) and np.array_equal(idx, oidx)  # bins per control-grid triangle
+    assert np.array_equal(cf.absolute_weights(), oc.absolute_weights())
+    assert np.all(cf.computeUnaryCosts() == 0.0)  # the HO classes' computeUnaryCost returns 0
+    rng = np.random.default_rng(3)
+    t, la, lb, lc = random_queries(rng, 1500, cf.T, cf.L, 3)
+    got = cf.computeTripletCost(t, la, lb, lc)
+    want = np.array([oc.triplet(*q) for q in zip(t, la, lb, lc)])
+    assert np.isfinite(got).all()
+    assert np.allclose(got, want, rtol=RTOL, atol=ATOL), np.max(np.abs(got - want))
+
+
+def test_pairwise_costs(ctx):
+    inp = problem.pairwise_inputs(5, 3, D=1)
+    cf, oc, _ = pair(ctx, inp, "univariate", rmode=1, lambda_=0.3, rexp=2.0)
+    rng = np.random.default_rng(5)
+    p, la, lb = random_queries(rng, 4000, cf.P, cf.L, 2)
+    got = cf.computePairwiseCost(p, la, lb)
+    want = np.array([oc.pairwise(*q) for q in zip(p, la, lb)])
+    assert np.allclose(got, want, rtol=RTOL, atol=ATOL), np.max(np.abs(got - want))
+    same = la == lb  # identical labels on both ends: equal rotations are not guaranteed, but label 0 (no move) is free
+    zero = cf.computePairwiseCost(p[:50], np.zeros(50, np.int32), np.zeros(50, np.int32))
+    assert np.all(zero == np.array([oc.pairwise(q, 0, 0) for q in p[:50]]))
+    # full table layout: paircosts[(pair*L + labelB)*L + labelA]
+    tab = cf.computePairwiseCosts().reshape(cf.P, cf.L, cf.L)
+    assert np.allclose(tab[p, lb, la], got, rtol=0, atol=0)
+
+
+def test_pairwise_rexp_one_and_folding(ctx):
+    inp = problem.pairwise_inputs(4, 2, D=1, labeldist=1.5)  # long moves: some fold the neighbouring triangles
+    cf, oc, _ = pair(ctx, inp, "univariate", rmode=1, lambda_=1.0, rexp=1.0)
+    rng = np.random.default_rng(6)
+    p, la, lb = random_queries(rng, 3000, cf.P, cf.L, 2)
+    got = cf.computePairwiseCost(p, la, lb)
+    want = np.array([oc.pairwise(*q) for q in zip(p, la, lb)])
+    assert np.allclose(got, want, rtol=RTOL, atol=ATOL)
+    assert (want == 1e7).any()
+
+
+@pytest.mark.parametrize("rmode", [1, 3])
+def test_total_cost_sum(ctx, rmode):
+    inp = problem.pairwise_inputs(4, 2, D=1)
+    cf, oc, _ = pair(ctx, inp, "univariate", rmode=rmode)
+    if rmode == 1:
+        cf.setPairs(inp["pairs"])
+        oc.set_triplets(np.zeros((0, 3), dtype=np.int32))
+    else:
+        oc.set_pairs(np.zeros((0, 2), dtype=np.int32))
+    rng = np.random.default_rng(7)
+    labeling = rng.integers(0, cf.L, cf.N).astype(np.int32)
+    tot, parts = cf.evaluateTotalCostSum(labeling)
+    otot, oparts = oc.total(labeling)
+    assert np.allclose(parts, oparts, rtol=RTOL, atol=ATOL) and abs(tot - otot) <= ATOL + RTOL * abs(otot)
