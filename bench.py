@@ -152,7 +152,9 @@ def main():
             },
         }
         if world == 1 and not args.no_cpu_baseline:
-            threads = os.cpu_count() or 1
+            from newmsm_amd.dist import host_cores
+
+            threads = host_cores()  # cgroup / affinity aware: the GPU box gives one GPU's share of the host
             Uo, rate, dt = cpu_baseline(inp, kind, threads)
             out["cpu_baseline"] = {
                 "value": rate, "unit": "evals/s", "cores": threads, "kind": "port",

@@ -1,0 +1,68 @@
+"""The N > 1 path on CPU: two gloo ranks (world_size 2) exercise sharding, the max-over-ranks timing reduction
+and the group template all-reduce that the GPU box runs over RCCL."""
+import os
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+
+from newmsm_amd import dist as D
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_partitions_every_subject_once():
+    for n in (0, 1, 7, 8, 64, 65):
+        for world in (1, 2, 3, 8):
+            got = [i for r in range(world) for i in D.shard(n, r, world)]
+            assert got == list(range(n))
+            sizes = [len(D.shard(n, r, world)) for r in range(world)]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_single_process_template_update_matches_numpy():
+    rng = np.random.default_rng(0)
+    spheres = rng.normal(size=(5, 42, 3))
+    feats = rng.normal(size=(5, 2, 42))
+    out = D.group_template_update(spheres, feats)
+    m = spheres.mean(axis=0)
+    assert np.allclose(out["template"], m / np.linalg.norm(m, axis=1, keepdims=True) * 100.0)
+    assert np.allclose(out["mean"], feats.mean(axis=0)) and np.allclose(out["stdev"], feats.std(axis=0))
+    assert out["n_subjects"] == 5
+
+
+WORKER = textwrap.dedent("""
+    import os, sys, json
+    import numpy as np
+    sys.path.insert(0, %r)
+    from newmsm_amd import dist as D
+    rank, local_rank, world = D.env()
+    dist = D.init("gloo")
+    rng = np.random.default_rng(123)
+    spheres = rng.normal(size=(7, 162, 3)); feats = rng.normal(size=(7, 3, 162))
+    mine = list(D.shard(7, rank, world))
+    out = D.group_template_update(spheres[mine], feats[mine], dist)
+    tmax = D.max_over_ranks(1.0 + rank, dist)
+    ref = D.group_template_update(spheres, feats)
+    ok = all(np.allclose(out[k], ref[k], rtol=1e-12, atol=1e-12) for k in ("template", "mean", "stdev"))
+    dist.barrier()
+    print(json.dumps({"rank": rank, "ok": bool(ok), "n": out["n_subjects"], "tmax": tmax, "mine": mine}))
+    dist.destroy_process_group()
+""")
+
+
+def test_two_gloo_ranks(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % ROOT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True) for r in range(2)]
+    outs = []
+    for p in procs:
+        so, se = p.communicate(timeout=240)
+        assert p.returncode == 0, se[-2000:]
+        outs.append(eval(so.strip().splitlines()[-1].replace("true", "True").replace("false", "False")))
+    assert all(o["ok"] for o in outs)
+    assert all(o["n"] == 7 and o["tmax"] == 2.0 for o in outs)
+    assert sorted(outs[0]["mine"] + outs[1]["mine"]) == list(range(7))
