@@ -212,6 +212,43 @@ int msm_cost_total(msm_cost *c, const int32_t *labeling, double *total, double p
  * [2] triplet evals, [3] pairwise evals */
 int msm_cost_counters(msm_cost *c, int64_t counters[4]);
 
+/* ------------------------------------------------------------------------------------------------
+ * groupwise registration (gMSM).  Replaces DiscreteGroupModel::setupCostFunction and its helpers
+ * (M/DiscreteGroupModel.cpp:37-196) and DiscreteGroupCostFunction's evaluators
+ * (M/DiscreteGroupCostFunction.cpp:26-98).  Node ids are subject * N + control point, as in the reference.
+ * Subjects are independent until the pairwise costs, so a multi-GPU run shards them.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct msm_group msm_group;
+typedef struct msm_group_params { /* set_parameters M/DiscreteCostFunction.cpp:119-133 */
+    int32_t simmeasure;  /* 1 SSD, 2 correlation */
+    int32_t fixnan;      /* "fixnan": NaN cost -> FIX_NAN = 1e7 (M/reg_tools.h:31) */
+    double  lambda, mu, kappa, k_exp, rexp, range;
+} msm_group_params;
+msm_group *msm_group_create(msm_ctx *ctx, const msm_group_params *params, int32_t num_subjects);
+void       msm_group_destroy(msm_group *g);
+/* DiscreteGroupModel::set_meshspace target_space M/DiscreteGroupModel.h:56-61, set_masks :54 (mask: V(template) or NULL) */
+int msm_group_set_template(msm_group *g, msm_mesh *template_mesh, const double *mask);
+/* Initialize(controlgrid) M/DiscreteGroupModel.cpp:141-161: every subject starts from this grid; builds the triplets */
+int msm_group_set_controlgrid(msm_group *g, const double *xyz, const int32_t *tri, int32_t N, int32_t Tc);
+/* m_datameshes[s] (reset_meshspace M/DiscreteGroupModel.h:63-65) and FEAT->get_data_matrix(s) (D x V).  The first call
+ * for a subject also captures _ORIG_MESHES[s] (set_meshes M/DiscreteGroupCostFunction.h:40-46). */
+int msm_group_set_subject(msm_group *g, int32_t subject, msm_mesh *data_mesh, const double *feat, int32_t D);
+/* reset_CPgrid M/DiscreteGroupModel.h:67-70 */
+int msm_group_reset_cpgrid(msm_group *g, int32_t subject, const double *xyz);
+/* m_labels = m_samples (M/DiscreteGroupModel.cpp:177); labels[0] is the sampling-grid centre */
+int msm_group_set_labels(msm_group *g, const double *labels, int32_t L);
+/* setupCostFunction M/DiscreteGroupModel.cpp:163-196: estimate_pairs :37-55, get_spacings :123-139, get_rotations :77-86,
+ * get_patch_data :88-121 */
+int msm_group_setup(msm_group *g);
+int msm_group_sizes(msm_group *g, int32_t *nodes, int32_t *pairs, int32_t *triplets);
+int msm_group_get_pairs(msm_group *g, int32_t *pairs /* P x 2 */);
+int msm_group_get_triplets(msm_group *g, int32_t *triplets /* T x 3 */);
+/* one patch (subject, control point, label): ascending template vertex ids and their D values (cap entries); *n = size */
+int msm_group_patch(msm_group *g, int32_t subject, int32_t cp, int32_t label, int32_t *ids, double *data, int32_t cap, int32_t *n);
+/* computePairwiseCost M/DiscreteGroupCostFunction.cpp:54-98 / computeTripletCost :26-52 for n queries */
+int msm_group_pairwise_batch(msm_group *g, const int32_t *pair, const int32_t *la, const int32_t *lb, int32_t n, double *out);
+int msm_group_triplet_batch(msm_group *g, const int32_t *triplet, const int32_t *la, const int32_t *lb, const int32_t *lc, int32_t n, double *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -26,6 +26,11 @@ class MsmError(RuntimeError):
         self.code = code
 
 
+class GroupParams(C.Structure):
+    _fields_ = [("simmeasure", C.c_int32), ("fixnan", C.c_int32), ("lambda_", C.c_double), ("mu", C.c_double),
+                ("kappa", C.c_double), ("k_exp", C.c_double), ("rexp", C.c_double), ("range", C.c_double)]
+
+
 class CostParams(C.Structure):
     _fields_ = [("kind", C.c_int32), ("simmeasure", C.c_int32), ("rmode", C.c_int32), ("reserved", C.c_int32),
                 ("lambda_", C.c_double), ("mu", C.c_double), ("kappa", C.c_double), ("k_exp", C.c_double),
@@ -92,6 +97,20 @@ SIGNATURES = {
     "msm_cost_pairwise_table": (C.c_int, [_VP, c_dp]),
     "msm_cost_total": (C.c_int, [_VP, c_ip, c_dp, c_dp]),
     "msm_cost_counters": (C.c_int, [_VP, c_lp]),
+    "msm_group_create": (_VP, [_VP, C.POINTER(GroupParams), C.c_int32]),
+    "msm_group_destroy": (None, [_VP]),
+    "msm_group_set_template": (C.c_int, [_VP, _VP, c_dp]),
+    "msm_group_set_controlgrid": (C.c_int, [_VP, c_dp, c_ip, C.c_int32, C.c_int32]),
+    "msm_group_set_subject": (C.c_int, [_VP, C.c_int32, _VP, c_dp, C.c_int32]),
+    "msm_group_reset_cpgrid": (C.c_int, [_VP, C.c_int32, c_dp]),
+    "msm_group_set_labels": (C.c_int, [_VP, c_dp, C.c_int32]),
+    "msm_group_setup": (C.c_int, [_VP]),
+    "msm_group_sizes": (C.c_int, [_VP, c_ip, c_ip, c_ip]),
+    "msm_group_get_pairs": (C.c_int, [_VP, c_ip]),
+    "msm_group_get_triplets": (C.c_int, [_VP, c_ip]),
+    "msm_group_patch": (C.c_int, [_VP, C.c_int32, C.c_int32, C.c_int32, c_ip, c_dp, C.c_int32, c_ip]),
+    "msm_group_pairwise_batch": (C.c_int, [_VP, c_ip, c_ip, c_ip, C.c_int32, c_dp]),
+    "msm_group_triplet_batch": (C.c_int, [_VP, c_ip, c_ip, c_ip, c_ip, C.c_int32, c_dp]),
 }
 
 _lib = None

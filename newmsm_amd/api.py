@@ -408,3 +408,94 @@ class DiscreteCostFunction:
         c = (C.c_int64 * 4)()
         check(lib().msm_cost_counters(self.h, c))
         return dict(samples=c[0], unary=c[1], triplet=c[2], pairwise=c[3])
+
+
+# ------------------------------------------------------------------ groupwise (gMSM)
+class DiscreteGroupCostFunction:
+    """DiscreteGroupModel::setupCostFunction + DiscreteGroupCostFunction's evaluators
+    (/root/reference/libraries/msm-newmeshreg/src/DiscreteGroupModel.cpp:163-196, DiscreteGroupCostFunction.cpp:26-98)."""
+
+    def __init__(self, ctx, num_subjects, simmeasure=2, fixnan=False, lambda_=0.1, mu=0.1, kappa=10.0, k_exp=2.0, rexp=2.0, range_=1.0):
+        from ._lib import GroupParams
+
+        self.ctx = ctx
+        self.S = num_subjects
+        self.params = GroupParams(simmeasure, int(fixnan), lambda_, mu, kappa, k_exp, rexp, range_)
+        self.h = lib().msm_group_create(ctx.h, C.byref(self.params), num_subjects)
+        if not self.h:
+            raise MsmError(-1, lib().msm_last_error().decode())
+        self._keep = {}
+
+    def close(self):
+        if getattr(self, "h", None) and getattr(self.ctx, "h", None):
+            lib().msm_group_destroy(self.h)
+        self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def set_template(self, mesh, mask=None):
+        self._keep["template"] = mesh
+        check(lib().msm_group_set_template(self.h, mesh.h, _d(mask)[1] if mask is not None else None))
+
+    def Initialize(self, cp_xyz, cp_tri):
+        x, px = _soa(cp_xyz)
+        t, pt = _tri_soa(cp_tri)
+        self.N, self.Tc = x.shape[1], t.shape[1]
+        check(lib().msm_group_set_controlgrid(self.h, px, pt, self.N, self.Tc))
+
+    def reset_meshspace(self, subject, data_mesh, feat):
+        f, pf = _d(np.atleast_2d(feat))
+        self._keep[("data", subject)] = data_mesh
+        self.D = f.shape[0]
+        check(lib().msm_group_set_subject(self.h, subject, data_mesh.h, pf, f.shape[0]))
+
+    def reset_CPgrid(self, subject, cp_xyz):
+        check(lib().msm_group_reset_cpgrid(self.h, subject, _soa(cp_xyz)[1]))
+
+    def set_labels(self, labels):
+        l, pl = _soa(labels)
+        self.L = l.shape[1]
+        check(lib().msm_group_set_labels(self.h, pl, self.L))
+
+    def setupCostFunction(self):
+        check(lib().msm_group_setup(self.h))
+        n, p, t = C.c_int32(), C.c_int32(), C.c_int32()
+        check(lib().msm_group_sizes(self.h, C.byref(n), C.byref(p), C.byref(t)))
+        self.num_nodes, self.P, self.T = n.value, p.value, t.value
+
+    def getPairs(self):
+        out = np.zeros((self.P, 2), dtype=np.int32)
+        check(lib().msm_group_get_pairs(self.h, out.ctypes.data_as(c_ip)))
+        return out
+
+    def getTriplets(self):
+        out = np.zeros((self.T, 3), dtype=np.int32)
+        check(lib().msm_group_get_triplets(self.h, out.ctypes.data_as(c_ip)))
+        return out
+
+    def patch(self, subject, cp, label):
+        subject, cp, label = int(subject), int(cp), int(label)
+        n = C.c_int32()
+        check(lib().msm_group_patch(self.h, subject, cp, label, None, None, 0, C.byref(n)))
+        ids = np.zeros(n.value, dtype=np.int32)
+        data = np.zeros((n.value, self.D))
+        check(lib().msm_group_patch(self.h, subject, cp, label, ids.ctypes.data_as(c_ip), data.ctypes.data_as(c_dp), n.value, C.byref(n)))
+        return ids, data
+
+    def computePairwiseCost(self, pair, la, lb):
+        p, pp = _i(np.atleast_1d(pair))
+        a, pa = _i(np.atleast_1d(la))
+        b, pb = _i(np.atleast_1d(lb))
+        out = np.zeros(len(p))
+        check(lib().msm_group_pairwise_batch(self.h, pp, pa, pb, len(p), out.ctypes.data_as(c_dp)))
+        return out
+
+    def computeTripletCost(self, t, la, lb, lc):
+        t_, pt = _i(np.atleast_1d(t))
+        a, pa = _i(np.atleast_1d(la))
+        b, pb = _i(np.atleast_1d(lb))
+        c_, pc = _i(np.atleast_1d(lc))
+        out = np.zeros(len(t_))
+        check(lib().msm_group_triplet_batch(self.h, pt, pa, pb, pc, len(t_), out.ctypes.data_as(c_dp)))
+        return out

@@ -1,0 +1,470 @@
+// group.cpp -- C ABI of the groupwise (gMSM) path (include/msmhip.h, "groupwise registration").
+//
+// DiscreteGroupModel::setupCostFunction (M/DiscreteGroupModel.cpp:163-196) is per-iteration set-up: closest
+// control points between subjects, and for every (subject, label) a rigid rotation of the data mesh followed by
+// an adaptive-barycentric resample of its features to the template.  All nearest-triangle queries run on the
+// GPU; the resampled feature maps F[subject][label] (D x V_template) and the patch lists stay in HBM, where the
+// pairwise kernel reads them (group_kernels.hip).
+#include <algorithm>
+#include <cmath>
+#include <memory>
+
+#include "devbuf.hpp"
+#include "kernels.hpp"
+
+using namespace msm;
+
+namespace msm {
+int adaptive_weights(msm_mesh *in_mesh, msm_mesh *new_mesh, const double *excl, std::vector<int32_t> &row_ptr, std::vector<int32_t> &col,
+                     std::vector<double> &val);
+const Adjacency &mesh_adjacency(msm_mesh *m);
+}  // namespace msm
+
+struct msm_group {
+    msm_ctx *ctx = nullptr;
+    msm_group_params p{};
+    int S = 0;
+    msm_mesh *tmpl = nullptr;
+    std::vector<double> mask;
+    DevBuf<double> d_mask;
+    int N = 0, Tc = 0;
+    std::vector<int32_t> cp_tri;                 // 3 x Tc SoA
+    std::vector<msm_mesh *> cpmesh;              // per subject (owned)
+    std::vector<msm_mesh *> data;                // per subject (borrowed)
+    std::vector<msm_mesh *> scratch;             // per subject: the rotated data mesh (owned)
+    std::vector<std::vector<double>> feat;       // per subject D x V
+    std::vector<std::vector<double>> orig;       // per subject 3 x N: _ORIG_MESHES coords of the control-point ids
+    std::vector<char> have_orig;
+    int D = 0, L = 0;
+    std::vector<double> labels;                  // 3 x L SoA
+    // setup products
+    bool ready = false;
+    std::vector<int32_t> pairs, triplets;
+    DevBuf<int32_t> d_pairs, d_triplets;
+    std::vector<double> rot, moved;              // (S*N) x 9, (S*N) x L x 3
+    DevBuf<double> d_moved, d_cp, d_orig;
+    std::vector<std::vector<double>> spacing;
+    std::vector<std::unique_ptr<DevBuf<double>>> F;  // S * L
+    std::vector<std::unique_ptr<DevBuf<int32_t>>> pptr, pidx;  // per subject
+    std::vector<std::vector<int32_t>> h_pptr, h_pidx;
+    DevBuf<const double *> d_Fp;
+    DevBuf<const int *> d_pptrp, d_pidxp;
+};
+
+namespace {
+
+inline V3 pt(const double *xyz, int V, int i) { return mk(xyz[i], xyz[V + i], xyz[2 * V + i]); }
+
+// patch lists of one subject: template vertices within range*spacing of each rotated control point
+// (get_patch_data, M/DiscreteGroupModel.cpp:109-117), via the range kernel + host tie resolution (see k_range)
+int subject_patches(msm_group *g, int s) {
+    msm_ctx *ctx = g->ctx;
+    const int N = g->N, L = g->L, M = N * L, Vt = g->tmpl->V;
+    std::vector<double> centres(3 * (size_t)M), sep(M);
+    for (int v = 0; v < N; ++v)
+        for (int l = 0; l < L; ++l) {
+            const double *m = &g->moved[(((size_t)s * N + v) * L + l) * 3];
+            const int k = v * L + l;
+            centres[k] = m[0];
+            centres[M + k] = m[1];
+            centres[2 * (size_t)M + k] = m[2];
+            sep[k] = g->spacing[s][v];
+        }
+    DevBuf<double> d_c, d_sep;
+    DevBuf<uint32_t> d_slots;
+    DevBuf<int> d_counts;
+    MSM_HIP(d_c.upload(centres.data(), centres.size(), ctx->stream));
+    MSM_HIP(d_sep.upload(sep.data(), sep.size(), ctx->stream));
+    MSM_HIP(d_counts.ensure(M));
+    int cap = 256;
+    std::vector<int> counts(M);
+    for (int attempt = 0; attempt < 3; ++attempt) {
+        MSM_HIP(d_slots.ensure((size_t)M * cap));
+        int st = launch_range(ctx, d_c.p, M, g->tmpl->d_xyz, Vt, d_sep.p, g->p.range, cap, d_slots.p, d_counts.p);
+        if (st) return st;
+        MSM_HIP(d_counts.download(counts.data(), M, ctx->stream));
+        MSM_HIP(hipStreamSynchronize(ctx->stream));
+        const int mx = *std::max_element(counts.begin(), counts.end());
+        if (mx <= cap) break;
+        if (attempt == 2) return fail(MSM_ERR_CAPACITY, "group patch capacity");
+        cap = mx + 16;
+    }
+    std::vector<uint32_t> slots((size_t)M * cap);
+    MSM_HIP(d_slots.download(slots.data(), slots.size(), ctx->stream));
+    MSM_HIP(hipStreamSynchronize(ctx->stream));
+    auto &pp = g->h_pptr[s];
+    auto &pi = g->h_pidx[s];
+    pp.assign(M + 1, 0);
+    pi.clear();
+    const double *tx = g->tmpl->xyz.data();
+    for (int k = 0; k < M; ++k) {
+        pp[k] = (int32_t)pi.size();
+        const V3 c = mk(centres[k], centres[M + k], centres[2 * (size_t)M + k]);
+        for (int j = 0; j < counts[k]; ++j) {
+            const uint32_t e = slots[(size_t)k * cap + j];
+            const int i = (int)(e & 0x7fffffffu);
+            if (e & 0x80000000u) {
+                const double arc = chord_to_arc(norm(sub(c, pt(tx, Vt, i))));
+                if (!(arc < g->p.range * sep[k])) continue;
+            }
+            pi.push_back(i);
+        }
+    }
+    pp[M] = (int32_t)pi.size();
+    MSM_HIP(g->pptr[s]->upload(pp.data(), pp.size(), ctx->stream));
+    MSM_HIP(g->pidx[s]->upload(pi.data(), std::max<size_t>(pi.size(), 1), ctx->stream));
+    MSM_HIP(hipStreamSynchronize(ctx->stream));
+    return MSM_OK;
+}
+
+int group_args(msm_group *g, GroupArgs &a) {
+    if (!g->ready) return fail(MSM_ERR_STATE, "msm_group: msm_group_setup() must be called first");
+    a.S = g->S;
+    a.N = g->N;
+    a.L = g->L;
+    a.D = g->D;
+    a.Tc = g->Tc;
+    a.Vt = g->tmpl->V;
+    a.simmeasure = g->p.simmeasure;
+    a.fixnan = g->p.fixnan;
+    a.pairs = g->d_pairs.p;
+    a.triplets = g->d_triplets.p;
+    a.pptr = g->d_pptrp.p;
+    a.pidx = g->d_pidxp.p;
+    a.F = g->d_Fp.p;
+    a.mask = g->mask.empty() ? nullptr : g->d_mask.p;
+    a.moved = g->d_moved.p;
+    a.cp = g->d_cp.p;
+    a.orig = g->d_orig.p;
+    a.lambda = g->p.lambda;
+    a.mu = g->p.mu;
+    a.kappa = g->p.kappa;
+    a.k_exp = g->p.k_exp;
+    a.rexp = g->p.rexp;
+    a.subcorr = 0.1 * g->S;  // set_meshes, M/DiscreteGroupCostFunction.h:45
+    a.status = g->ctx->d_status;
+    return MSM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+msm_group *msm_group_create(msm_ctx *ctx, const msm_group_params *params, int32_t S) {
+    if (!ctx || !params || S < 1) {
+        fail(MSM_ERR_INVALID, "msm_group_create: bad arguments");
+        return nullptr;
+    }
+    if (params->simmeasure != 1 && params->simmeasure != 2) {
+        fail(MSM_ERR_INVALID, "msm_group_create: similarity measure %d is not offloaded", params->simmeasure);
+        return nullptr;
+    }
+    msm_group *g = new msm_group();
+    g->ctx = ctx;
+    g->p = *params;
+    g->S = S;
+    g->cpmesh.assign(S, nullptr);
+    g->data.assign(S, nullptr);
+    g->scratch.assign(S, nullptr);
+    g->feat.resize(S);
+    g->orig.resize(S);
+    g->have_orig.assign(S, 0);
+    g->spacing.resize(S);
+    g->h_pptr.resize(S);
+    g->h_pidx.resize(S);
+    for (int s = 0; s < S; ++s) {
+        g->pptr.emplace_back(new DevBuf<int32_t>());
+        g->pidx.emplace_back(new DevBuf<int32_t>());
+    }
+    return g;
+}
+
+void msm_group_destroy(msm_group *g) {
+    if (!g) return;
+    (void)hipStreamSynchronize(g->ctx->stream);
+    for (msm_mesh *m : g->cpmesh) msm_mesh_destroy(m);
+    for (msm_mesh *m : g->scratch) msm_mesh_destroy(m);
+    delete g;
+}
+
+int msm_group_set_template(msm_group *g, msm_mesh *t, const double *mask) {
+    if (!g || !t) return fail(MSM_ERR_INVALID, "msm_group_set_template: null argument");
+    g->tmpl = t;
+    g->mask.clear();
+    if (mask) {
+        g->mask.assign(mask, mask + t->V);
+        MSM_HIP(g->d_mask.upload(g->mask.data(), g->mask.size(), g->ctx->stream));
+        MSM_HIP(hipStreamSynchronize(g->ctx->stream));
+    }
+    g->ready = false;
+    return MSM_OK;
+}
+
+int msm_group_set_controlgrid(msm_group *g, const double *xyz, const int32_t *tri, int32_t N, int32_t Tc) {
+    if (!g || !xyz || !tri || N <= 0 || Tc <= 0) return fail(MSM_ERR_INVALID, "msm_group_set_controlgrid: bad arguments");
+    g->N = N;
+    g->Tc = Tc;
+    g->cp_tri.assign(tri, tri + 3 * (size_t)Tc);
+    for (int s = 0; s < g->S; ++s) {
+        msm_mesh_destroy(g->cpmesh[s]);
+        g->cpmesh[s] = msm_mesh_create(g->ctx, xyz, N, tri, Tc);
+        if (!g->cpmesh[s]) return MSM_ERR_HIP;
+    }
+    // estimate_triplets, M/DiscreteGroupModel.cpp:57-75
+    g->triplets.resize(3 * (size_t)g->S * Tc);
+    for (int s = 0; s < g->S; ++s)
+        for (int t = 0; t < Tc; ++t) {
+            int32_t v[3] = {tri[t] + s * N, tri[Tc + t] + s * N, tri[2 * Tc + t] + s * N};
+            std::sort(v, v + 3);
+            std::copy(v, v + 3, &g->triplets[3 * ((size_t)s * Tc + t)]);
+        }
+    MSM_HIP(g->d_triplets.upload(g->triplets.data(), g->triplets.size(), g->ctx->stream));
+    MSM_HIP(hipStreamSynchronize(g->ctx->stream));
+    g->ready = false;
+    return MSM_OK;
+}
+
+int msm_group_set_subject(msm_group *g, int32_t s, msm_mesh *data, const double *feat, int32_t D) {
+    if (!g || !data || !feat || s < 0 || s >= g->S || D <= 0) return fail(MSM_ERR_INVALID, "msm_group_set_subject: bad arguments");
+    if (g->N <= 0) return fail(MSM_ERR_STATE, "msm_group: the control grid must be set first");
+    if (data->V < g->N) return fail(MSM_ERR_INVALID, "data mesh has fewer vertices than the control grid");
+    if (g->D != 0 && g->D != D && std::any_of(g->data.begin(), g->data.end(), [](msm_mesh *m) { return m != nullptr; }) && g->data[s] == nullptr)
+        return fail(MSM_ERR_INVALID, "all subjects must have the same number of feature dimensions");
+    g->D = D;
+    g->data[s] = data;
+    g->feat[s].assign(feat, feat + (size_t)D * data->V);
+    if (!g->have_orig[s]) {
+        g->orig[s].resize(3 * (size_t)g->N);
+        for (int v = 0; v < g->N; ++v) {
+            g->orig[s][v] = data->xyz[v];
+            g->orig[s][g->N + v] = data->xyz[data->V + v];
+            g->orig[s][2 * (size_t)g->N + v] = data->xyz[2 * (size_t)data->V + v];
+        }
+        g->have_orig[s] = 1;
+    }
+    if (!g->scratch[s] || g->scratch[s]->V != data->V || g->scratch[s]->T != data->T) {
+        msm_mesh_destroy(g->scratch[s]);
+        g->scratch[s] = msm_mesh_create(g->ctx, data->xyz.data(), data->V, data->tri.data(), data->T);
+        if (!g->scratch[s]) return MSM_ERR_HIP;
+    }
+    g->ready = false;
+    return MSM_OK;
+}
+
+int msm_group_reset_cpgrid(msm_group *g, int32_t s, const double *xyz) {
+    if (!g || !xyz || s < 0 || s >= g->S || !g->cpmesh[s]) return fail(MSM_ERR_INVALID, "msm_group_reset_cpgrid: bad arguments");
+    g->ready = false;
+    return msm_mesh_update_coords(g->cpmesh[s], xyz);
+}
+
+int msm_group_set_labels(msm_group *g, const double *labels, int32_t L) {
+    if (!g || !labels || L <= 0) return fail(MSM_ERR_INVALID, "msm_group_set_labels: bad arguments");
+    g->L = L;
+    g->labels.assign(labels, labels + 3 * (size_t)L);
+    g->ready = false;
+    return MSM_OK;
+}
+
+int msm_group_setup(msm_group *g) {
+    if (!g) return fail(MSM_ERR_INVALID, "null group");
+    if (!g->tmpl || g->N <= 0 || g->L <= 0) return fail(MSM_ERR_STATE, "msm_group: template, control grid and labels must be set first");
+    for (int s = 0; s < g->S; ++s)
+        if (!g->data[s]) return fail(MSM_ERR_STATE, "msm_group: subject %d has no data", s);
+    msm_ctx *ctx = g->ctx;
+    const int S = g->S, N = g->N, L = g->L, D = g->D, Vt = g->tmpl->V;
+    const double centre[3] = {g->labels[0], g->labels[L], g->labels[2 * (size_t)L]};
+
+    // estimate_pairs, M/DiscreteGroupModel.cpp:37-55: closest control point of subject B for every control point of A
+    g->pairs.resize((size_t)N * S * (S - 1));
+    {
+        std::vector<std::vector<int32_t>> closest((size_t)S * S);
+        for (int a = 0; a < S; ++a)
+            for (int b = a + 1; b < S; ++b) {
+                closest[(size_t)a * S + b].resize(N);
+                int st = msm_closest_vertex(g->cpmesh[b], g->cpmesh[a]->xyz.data(), N, closest[(size_t)a * S + b].data());
+                if (st) return st;
+            }
+        size_t pair = 0;
+        for (int a = 0; a < S; ++a)
+            for (int v = 0; v < N; ++v)
+                for (int b = a + 1; b < S; ++b) {
+                    g->pairs[2 * pair] = a * N + v;
+                    g->pairs[2 * pair + 1] = b * N + closest[(size_t)a * S + b][v];
+                    ++pair;
+                }
+    }
+    MSM_HIP(g->d_pairs.upload(g->pairs.data(), std::max<size_t>(g->pairs.size(), 1), ctx->stream));
+
+    // get_spacings :123-139, get_rotations :77-86, and ROT * label for every (node, label)
+    g->rot.resize(9 * (size_t)S * N);
+    g->moved.resize(3 * (size_t)S * N * L);
+    std::vector<double> cp_all(3 * (size_t)S * N), orig_all(3 * (size_t)S * N);
+    for (int s = 0; s < S; ++s) {
+        msm_mesh *cm = g->cpmesh[s];
+        g->spacing[s].resize(N);
+        double mvd;
+        int st = msm_cp_spacings(cm->xyz.data(), cm->tri.data(), N, g->Tc, g->spacing[s].data(), &mvd);
+        if (st) return st;
+        st = msm_cp_rotations(centre, cm->xyz.data(), N, &g->rot[9 * (size_t)s * N]);
+        if (st) return st;
+        for (int v = 0; v < N; ++v)
+            for (int l = 0; l < L; ++l) {
+                const V3 m = rotate(&g->rot[9 * ((size_t)s * N + v)], mk(g->labels[l], g->labels[L + l], g->labels[2 * (size_t)L + l]));
+                double *o = &g->moved[(((size_t)s * N + v) * L + l) * 3];
+                o[0] = m.x, o[1] = m.y, o[2] = m.z;
+            }
+        std::copy(cm->xyz.begin(), cm->xyz.end(), cp_all.begin() + 3 * (size_t)s * N);
+        std::copy(g->orig[s].begin(), g->orig[s].end(), orig_all.begin() + 3 * (size_t)s * N);
+    }
+    MSM_HIP(g->d_moved.upload(g->moved.data(), g->moved.size(), ctx->stream));
+    MSM_HIP(g->d_cp.upload(cp_all.data(), cp_all.size(), ctx->stream));
+    MSM_HIP(g->d_orig.upload(orig_all.data(), orig_all.size(), ctx->stream));
+    MSM_HIP(hipStreamSynchronize(ctx->stream));
+
+    // get_patch_data :88-121
+    g->F.resize((size_t)S * L);
+    std::vector<double> rotated, resampled((size_t)D * Vt);
+    std::vector<int32_t> rp, col;
+    std::vector<double> val;
+    for (int s = 0; s < S; ++s) {
+        msm_mesh *dm = g->data[s], *sm = g->scratch[s];
+        const int V = dm->V;
+        rotated.resize(3 * (size_t)V);
+        DevBuf<double> d_rot;
+        MSM_HIP(d_rot.ensure(3 * (size_t)V));
+        for (int l = 0; l < L; ++l) {
+            if (l > 0) {
+                const double lab[3] = {g->labels[l], g->labels[L + l], g->labels[2 * (size_t)L + l]};
+                int st = launch_rotate_to_label(ctx, dm->d_xyz, V, centre, lab, d_rot.p);
+                if (st) return st;
+                MSM_HIP(d_rot.download(rotated.data(), rotated.size(), ctx->stream));
+                st = check_status(ctx, "get_patch_data (rotation)");
+                if (st) return st;
+            } else {
+                rotated = dm->xyz;
+            }
+            int st = msm_mesh_update_coords(sm, rotated.data());
+            if (st) return st;
+            st = adaptive_weights(sm, g->tmpl, nullptr, rp, col, val);  // metric_resample(rotated_mesh, target_space)
+            if (st) return st;
+            for (int d = 0; d < D; ++d)
+                for (int k = 0; k < Vt; ++k) {
+                    double acc = 0.0;
+                    for (int e = rp[k]; e < rp[k + 1]; ++e) acc += g->feat[s][(size_t)d * V + col[e]] * val[e];
+                    resampled[(size_t)d * Vt + k] = acc;
+                }
+            auto &buf = g->F[(size_t)s * L + l];
+            if (!buf) buf.reset(new DevBuf<double>());
+            MSM_HIP(buf->upload(resampled.data(), resampled.size(), ctx->stream));
+            MSM_HIP(hipStreamSynchronize(ctx->stream));
+        }
+        int st = subject_patches(g, s);
+        if (st) return st;
+    }
+    // pointer tables for the kernels
+    std::vector<const double *> Fp((size_t)S * L);
+    for (size_t k = 0; k < Fp.size(); ++k) Fp[k] = g->F[k]->p;
+    std::vector<const int *> pp(S), pi(S);
+    for (int s = 0; s < S; ++s) {
+        pp[s] = g->pptr[s]->p;
+        pi[s] = g->pidx[s]->p;
+    }
+    MSM_HIP(g->d_Fp.upload(Fp.data(), Fp.size(), ctx->stream));
+    MSM_HIP(g->d_pptrp.upload(pp.data(), pp.size(), ctx->stream));
+    MSM_HIP(g->d_pidxp.upload(pi.data(), pi.size(), ctx->stream));
+    MSM_HIP(hipStreamSynchronize(ctx->stream));
+    g->ready = true;
+    return MSM_OK;
+}
+
+int msm_group_sizes(msm_group *g, int32_t *nodes, int32_t *pairs, int32_t *triplets) {
+    if (!g) return fail(MSM_ERR_INVALID, "null group");
+    if (nodes) *nodes = g->S * g->N;
+    if (pairs) *pairs = g->N * g->S * (g->S - 1) / 2;
+    if (triplets) *triplets = g->S * g->Tc;
+    return MSM_OK;
+}
+
+int msm_group_get_pairs(msm_group *g, int32_t *pairs) {
+    if (!g || !pairs) return fail(MSM_ERR_INVALID, "msm_group_get_pairs: null argument");
+    if (!g->ready) return fail(MSM_ERR_STATE, "msm_group: msm_group_setup() must be called first");
+    std::copy(g->pairs.begin(), g->pairs.end(), pairs);
+    return MSM_OK;
+}
+
+int msm_group_get_triplets(msm_group *g, int32_t *triplets) {
+    if (!g || !triplets) return fail(MSM_ERR_INVALID, "msm_group_get_triplets: null argument");
+    std::copy(g->triplets.begin(), g->triplets.end(), triplets);
+    return MSM_OK;
+}
+
+int msm_group_patch(msm_group *g, int32_t s, int32_t v, int32_t l, int32_t *ids, double *data, int32_t cap, int32_t *n) {
+    if (!g || !n) return fail(MSM_ERR_INVALID, "msm_group_patch: null argument");
+    if (!g->ready) return fail(MSM_ERR_STATE, "msm_group: msm_group_setup() must be called first");
+    if (s < 0 || s >= g->S || v < 0 || v >= g->N || l < 0 || l >= g->L) return fail(MSM_ERR_INVALID, "msm_group_patch: index out of range");
+    const int beg = g->h_pptr[s][v * g->L + l], cnt = g->h_pptr[s][v * g->L + l + 1] - beg;
+    *n = cnt;
+    if (!ids && !data) return MSM_OK;
+    const int Vt = g->tmpl->V;
+    std::vector<double> F;
+    if (data) {
+        F.resize((size_t)g->D * Vt);
+        MSM_HIP(g->F[(size_t)s * g->L + l]->download(F.data(), F.size(), g->ctx->stream));
+        MSM_HIP(hipStreamSynchronize(g->ctx->stream));
+    }
+    for (int i = 0; i < cnt && i < cap; ++i) {
+        const int id = g->h_pidx[s][beg + i];
+        if (ids) ids[i] = id;
+        if (data)
+            for (int d = 0; d < g->D; ++d) data[(size_t)i * g->D + d] = F[(size_t)d * Vt + id];
+    }
+    return MSM_OK;
+}
+
+int msm_group_pairwise_batch(msm_group *g, const int32_t *pair, const int32_t *la, const int32_t *lb, int32_t n, double *out) {
+    if (!g || !pair || !la || !lb || !out || n < 0) return fail(MSM_ERR_INVALID, "msm_group_pairwise_batch: bad arguments");
+    if (n == 0) return MSM_OK;
+    GroupArgs a;
+    int st = group_args(g, a);
+    if (st) return st;
+    const int P = (int)(g->pairs.size() / 2);
+    for (int i = 0; i < n; ++i)
+        if (pair[i] < 0 || pair[i] >= P || la[i] < 0 || la[i] >= g->L || lb[i] < 0 || lb[i] >= g->L) return fail(MSM_ERR_INVALID, "group pairwise query %d out of range", i);
+    msm_ctx *ctx = g->ctx;
+    DevBuf<int> qp, qa, qb;
+    DevBuf<double> dout;
+    MSM_HIP(qp.upload(pair, n, ctx->stream));
+    MSM_HIP(qa.upload(la, n, ctx->stream));
+    MSM_HIP(qb.upload(lb, n, ctx->stream));
+    MSM_HIP(dout.ensure(n));
+    st = launch_group_pairwise(ctx, a, qp.p, qa.p, qb.p, n, dout.p);
+    if (st) return st;
+    MSM_HIP(dout.download(out, n, ctx->stream));
+    return check_status(ctx, "DiscreteGroupCostFunction::computePairwiseCost");
+}
+
+int msm_group_triplet_batch(msm_group *g, const int32_t *t, const int32_t *la, const int32_t *lb, const int32_t *lc, int32_t n, double *out) {
+    if (!g || !t || !la || !lb || !lc || !out || n < 0) return fail(MSM_ERR_INVALID, "msm_group_triplet_batch: bad arguments");
+    if (n == 0) return MSM_OK;
+    GroupArgs a;
+    int st = group_args(g, a);
+    if (st) return st;
+    const int T = g->S * g->Tc;
+    for (int i = 0; i < n; ++i)
+        if (t[i] < 0 || t[i] >= T || la[i] < 0 || la[i] >= g->L || lb[i] < 0 || lb[i] >= g->L || lc[i] < 0 || lc[i] >= g->L)
+            return fail(MSM_ERR_INVALID, "group triplet query %d out of range", i);
+    msm_ctx *ctx = g->ctx;
+    DevBuf<int> qt, qa, qb, qc;
+    DevBuf<double> dout;
+    MSM_HIP(qt.upload(t, n, ctx->stream));
+    MSM_HIP(qa.upload(la, n, ctx->stream));
+    MSM_HIP(qb.upload(lb, n, ctx->stream));
+    MSM_HIP(qc.upload(lc, n, ctx->stream));
+    MSM_HIP(dout.ensure(n));
+    st = launch_group_triplet(ctx, a, qt.p, qa.p, qb.p, qc.p, n, dout.p);
+    if (st) return st;
+    MSM_HIP(dout.download(out, n, ctx->stream));
+    return check_status(ctx, "DiscreteGroupCostFunction::computeTripletCost");
+}
+
+}  // extern "C"

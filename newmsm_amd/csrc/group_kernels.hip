@@ -1,0 +1,178 @@
+// group_kernels.hip -- groupwise (gMSM) kernels: the per-label rigid rotation of a subject's data mesh
+// (DiscreteGroupModel::get_patch_data, M/DiscreteGroupModel.cpp:99-103), the inter-subject patch similarity
+// (DiscreteGroupCostFunction::computePairwiseCost, M/DiscreteGroupCostFunction.cpp:54-98) and the per-subject strain
+// triplet (:26-52).
+#include "kernels.hpp"
+#include "strain_device.hpp"
+
+namespace msm {
+
+namespace {
+
+__device__ __forceinline__ void raise_status(int *status, int code) { atomicMin(status, code); }
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+}  // namespace
+
+// every data vertex v is moved to estimate_rotation_matrix(centre, v) * label: "rigid rotation" of the mesh by the label
+__global__ __launch_bounds__(256) void k_rotate_to_label(const double *__restrict__ xyz, int V, V3 centre, V3 label, double *__restrict__ out,
+                                                          int *status) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= V) return;
+    double R[9];
+    if (!rotation_matrix(centre, mk(xyz[i], xyz[V + i], xyz[2 * V + i]), R)) raise_status(status, MSM_ERR_ROTATION);
+    const V3 p = rotate(R, label);
+    out[i] = p.x;
+    out[V + i] = p.y;
+    out[2 * V + i] = p.z;
+}
+
+int launch_rotate_to_label(msm_ctx *ctx, const double *d_xyz, int V, const double centre[3], const double label[3], double *d_out) {
+    hipLaunchKernelGGL(k_rotate_to_label, dim3((V + 255) / 256), dim3(256), 0, ctx->stream, d_xyz, V, mk(centre[0], centre[1], centre[2]),
+                       mk(label[0], label[1], label[2]), d_out, ctx->d_status);
+    MSM_HIP(hipGetLastError());
+    return MSM_OK;
+}
+
+// One wavefront per query.  Patch A = template vertices in range of (subject A, control point, label A), ascending;
+// the lanes take A's entries, look each up in B's list by binary search (std::map::find), and the similarity of
+// the two subjects' resampled features over the intersection is reduced per feature dimension with shuffles.
+__global__ __launch_bounds__(256) void k_group_pairwise(GroupArgs a, const int *__restrict__ qp, const int *__restrict__ qa,
+                                                         const int *__restrict__ qb, int n, double *__restrict__ out) {
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (q >= n) return;
+    const int pair = qp[q], la = qa[q], lb = qb[q];
+    const int ga = a.pairs[2 * pair], gb = a.pairs[2 * pair + 1];
+    const int sa = ga / a.N, sb = gb / a.N, na = ga - sa * a.N, nb = gb - sb * a.N;
+    const int *pa = a.pptr[sa], *pb = a.pptr[sb];
+    const int ba = pa[na * a.L + la], ea = pa[na * a.L + la + 1], bb = pb[nb * a.L + lb], eb = pb[nb * a.L + lb + 1];
+    const int *ia = a.pidx[sa] + ba, *ib = a.pidx[sb] + bb;
+    const int cntA = ea - ba, cntB = eb - bb;
+    const double *FA = a.F[(size_t)sa * a.L + la], *FB = a.F[(size_t)sb * a.L + lb];
+    const double nan = __longlong_as_double(0x7ff8000000000000ll);
+    // membership of A's entries in B, kept as a bit per (lane, round): patches hold at most 64 * 32 entries
+    unsigned member = 0u;
+    int common = 0;
+    for (int r = 0, i = lane; i < cntA; i += 64, ++r) {
+        const int id = ia[i];
+        int lo = 0, hi = cntB;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (ib[mid] < id) lo = mid + 1;
+            else hi = mid;
+        }
+        if (lo < cntB && ib[lo] == id) {
+            member |= 1u << r;
+            ++common;
+        }
+    }
+    if (cntA > 64 * 32) raise_status(a.status, MSM_ERR_CAPACITY);
+    const int ncommon = (int)wave_sum((double)common);
+    double cost = 0.0;
+    if (ncommon == 0) {
+        cost = nan;  // the reference indexes an empty vector here (undefined behaviour)
+    } else {
+        for (int d = 0; d < a.D; ++d) {
+            const double *A = FA + (size_t)d * a.Vt, *B = FB + (size_t)d * a.Vt;
+            double c;
+            if (a.simmeasure == 2) {  // sparsesimkernel::corr, M/similarities.cpp:129-158
+                double sw = 0, ma = 0, mb = 0;
+                for (int r = 0, i = lane; i < cntA; i += 64, ++r)
+                    if (member >> r & 1u) {
+                        const int id = ia[i];
+                        const double w = a.mask ? fabs(a.mask[id]) : 1.0;
+                        sw += w;
+                        ma += w * A[id];
+                        mb += w * B[id];
+                    }
+                sw = wave_sum(sw);
+                ma = wave_sum(ma);
+                mb = wave_sum(mb);
+                if (sw > 0.0) {
+                    ma /= sw;
+                    mb /= sw;
+                }
+                double pr = 0, va = 0, vb = 0;
+                for (int r = 0, i = lane; i < cntA; i += 64, ++r)
+                    if (member >> r & 1u) {
+                        const int id = ia[i];
+                        const double w = a.mask ? fabs(a.mask[id]) : 1.0, da = A[id] - ma, db = B[id] - mb;
+                        pr += w * da * db;
+                        va += w * da * da;
+                        vb += w * db * db;
+                    }
+                pr = wave_sum(pr);
+                va = wave_sum(va);
+                vb = wave_sum(vb);
+                if (sw > 0.0) {
+                    pr /= sw;
+                    va /= sw;
+                    vb /= sw;
+                }
+                const double rr = (va == 0.0 || vb == 0.0) ? 0.0 : pr / (sqrt(va) * sqrt(vb));
+                c = 1 - (1 + rr) * 0.5;
+            } else {  // sparsesimkernel::SSD, :179-188
+                double pr = 0;
+                for (int r = 0, i = lane; i < cntA; i += 64, ++r)
+                    if (member >> r & 1u) {
+                        const int id = ia[i];
+                        const double w = a.mask ? fabs(a.mask[id]) : 1.0, df = A[id] - B[id];
+                        pr += w * df * df;
+                    }
+                pr = wave_sum(pr);
+                c = sqrt(pr) / ncommon;
+            }
+            cost += c;
+        }
+        cost /= a.D;
+    }
+    if (a.fixnan && cost != cost) cost = 1e7;  // FIX_NAN, M/reg_tools.h:31
+    if (lane == 0) out[q] = cost;
+}
+
+__global__ __launch_bounds__(128) void k_group_triplet(GroupArgs a, const int *__restrict__ qt, const int *__restrict__ qa,
+                                                        const int *__restrict__ qb, const int *__restrict__ qc, int n, double *__restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int t = qt[i];
+    const int s = t / a.Tc;
+    const int lab[3] = {qa[i], qb[i], qc[i]};
+    V3 r[3], cur[3], org[3];
+    for (int k = 0; k < 3; ++k) {
+        const int gid = a.triplets[3 * t + k], v = gid - s * a.N;
+        const double *m = a.moved + ((size_t)gid * a.L + lab[k]) * 3;
+        r[k] = mk(m[0], m[1], m[2]);
+        const double *c = a.cp + (size_t)s * 3 * a.N, *o = a.orig + (size_t)s * 3 * a.N;
+        cur[k] = mk(c[v], c[a.N + v], c[2 * a.N + v]);
+        org[k] = mk(o[v], o[a.N + v], o[2 * a.N + v]);
+    }
+    double cost;
+    if (dot(tri_normal(r[0], r[1], r[2]), tri_normal(cur[0], cur[1], cur[2])) < 0.0) {
+        cost = MSM_FOLDING;
+    } else {
+        const double e = triangular_strain(org, r, a.mu, a.kappa, a.k_exp);
+        cost = (a.fixnan && e != e) ? 1e7 : a.subcorr * a.lambda * pow(e, a.rexp);
+    }
+    out[i] = cost;
+}
+
+int launch_group_pairwise(msm_ctx *ctx, const GroupArgs &a, const int *qp, const int *qa, const int *qb, int n, double *out) {
+    if (n <= 0) return MSM_OK;
+    hipLaunchKernelGGL(k_group_pairwise, dim3((n + 3) / 4), dim3(256), 0, ctx->stream, a, qp, qa, qb, n, out);
+    MSM_HIP(hipGetLastError());
+    return MSM_OK;
+}
+
+int launch_group_triplet(msm_ctx *ctx, const GroupArgs &a, const int *qt, const int *qa, const int *qb, const int *qc, int n, double *out) {
+    if (n <= 0) return MSM_OK;
+    hipLaunchKernelGGL(k_group_triplet, dim3((n + 127) / 128), dim3(128), 0, ctx->stream, a, qt, qa, qb, qc, n, out);
+    MSM_HIP(hipGetLastError());
+    return MSM_OK;
+}
+
+}  // namespace msm

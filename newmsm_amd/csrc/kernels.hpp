@@ -85,4 +85,25 @@ int launch_triplet_octets(msm_ctx *ctx, const CliqueArgs &a, const int *labeling
 int launch_pairwise_batch(msm_ctx *ctx, const CliqueArgs &a, const int *qp, const int *qa, const int *qb, int n, double *out);
 int launch_pairwise_table(msm_ctx *ctx, const CliqueArgs &a, double *out);
 
+
+// groupwise (gMSM)
+struct GroupArgs {
+    int S, N, L, D, Tc, Vt;
+    int simmeasure, fixnan;
+    const int *pairs;            // P x 2 global node ids
+    const int *triplets;         // T x 3 global node ids
+    const int *const *pptr;      // per subject: CSR over (control point * L + label)
+    const int *const *pidx;      // per subject: template vertex ids, ascending per patch
+    const double *const *F;      // per (subject * L + label): D x Vt resampled features
+    const double *mask;          // Vt or nullptr
+    const double *moved;         // (S * N) x L x 3: ROT * label
+    const double *cp;            // S x (3 x N) current control grids
+    const double *orig;          // S x (3 x N) _ORIG_MESHES coordinates of the control-point ids
+    double lambda, mu, kappa, k_exp, rexp, subcorr;
+    int *status;
+};
+int launch_rotate_to_label(msm_ctx *ctx, const double *d_xyz, int V, const double centre[3], const double label[3], double *d_out);
+int launch_group_pairwise(msm_ctx *ctx, const GroupArgs &a, const int *qp, const int *qa, const int *qb, int n, double *out);
+int launch_group_triplet(msm_ctx *ctx, const GroupArgs &a, const int *qt, const int *qa, const int *qb, const int *qc, int n, double *out);
+
 }  // namespace msm

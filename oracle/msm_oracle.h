@@ -178,6 +178,33 @@ double orc_cost_total(orc_cost *c, const int *labeling, double parts[3]);
 /* number of patch point samples evaluated so far (for throughput accounting) */
 long   orc_cost_samples(const orc_cost *c);
 
+/* ------------------------------------------------------------------ groupwise (gMSM): M/DiscreteGroupModel.cpp, M/DiscreteGroupCostFunction.cpp */
+typedef struct orc_group orc_group;
+typedef struct {
+    int    simmeasure, fixnan;
+    double lambda, mu, kappa, k_exp, rexp, range;
+} orc_group_params;
+orc_group *orc_group_create(const orc_group_params *p, int num_subjects);
+void       orc_group_destroy(orc_group *g);
+/* set_meshspace(target_space, ...) :  the template mesh every subject is resampled to */
+void orc_group_set_template(orc_group *g, const orc_mesh *tmpl, const double *mask /* V_tmpl or NULL */);
+/* Initialize(controlgrid) :141-161: every subject starts from this control grid */
+void orc_group_set_controlgrid(orc_group *g, const orc_mesh *cp);
+/* data mesh of one subject (m_datameshes[s], reset_meshspace) with its features D x V; the first call per subject also
+ * captures _ORIG_MESHES[s] (set_meshes) */
+void orc_group_set_subject(orc_group *g, int s, const orc_mesh *data, const double *feat, int D);
+void orc_group_reset_cpgrid(orc_group *g, int s, const double *xyz);
+void orc_group_set_labels(orc_group *g, const double *labels, int L);
+/* setupCostFunction :163-196: estimate_pairs, get_spacings, get_rotations, get_patch_data */
+int  orc_group_setup(orc_group *g);
+void orc_group_sizes(const orc_group *g, int *nodes, int *pairs, int *triplets);
+const int *orc_group_pairs(const orc_group *g);
+const int *orc_group_triplets(const orc_group *g);
+/* patch (subject, control point, label): template vertex ids (ascending) and their D values; returns the count */
+int  orc_group_patch(const orc_group *g, int s, int v, int l, int *ids, double *data, int cap);
+double orc_group_pairwise(orc_group *g, int pair, int la, int lb);   /* DiscreteGroupCostFunction.cpp:54-98 */
+double orc_group_triplet(orc_group *g, int t, int la, int lb, int lc); /* :26-52 */
+
 #ifdef __cplusplus
 }
 #endif

@@ -395,3 +395,83 @@ class Cost:
 
     def samples(self):
         return lib().orc_cost_samples(self.h)
+
+
+# ---------------------------------------------------------------- groupwise (gMSM)
+class GroupParams(C.Structure):
+    _fields_ = [("simmeasure", C.c_int), ("fixnan", C.c_int), ("lambda_", C.c_double), ("mu", C.c_double), ("kappa", C.c_double),
+                ("k_exp", C.c_double), ("rexp", C.c_double), ("range", C.c_double)]
+
+
+class Group:
+    """Oracle mirror of DiscreteGroupModel + DiscreteGroupCostFunction."""
+
+    def __init__(self, num_subjects, simmeasure=2, fixnan=False, lambda_=0.1, mu=0.1, kappa=10.0, k_exp=2.0, rexp=2.0, range_=1.0):
+        L = lib()
+        L.orc_group_create.restype = C.c_void_p
+        L.orc_group_pairwise.restype = C.c_double
+        L.orc_group_triplet.restype = C.c_double
+        L.orc_group_pairs.restype = c_ip
+        L.orc_group_triplets.restype = c_ip
+        self.params = GroupParams(simmeasure, int(fixnan), lambda_, mu, kappa, k_exp, rexp, range_)
+        self.S = num_subjects
+        self.h = C.c_void_p(L.orc_group_create(C.byref(self.params), num_subjects))
+        self._keep = {}
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_group_destroy(self.h)
+            self.h = None
+
+    def set_template(self, mesh, mask=None):
+        self._keep["template"] = mesh
+        self.Vt = mesh.V
+        pm = None
+        if mask is not None:
+            self._keep["mask"], pm = _d(mask)
+        lib().orc_group_set_template(self.h, mesh.h, pm)
+
+    def set_controlgrid(self, cp_mesh):
+        self._keep["cp"] = cp_mesh
+        self.N, self.Tc = cp_mesh.V, cp_mesh.T
+        lib().orc_group_set_controlgrid(self.h, cp_mesh.h)
+
+    def set_subject(self, s, data_mesh, feat):
+        f, pf = _d(np.atleast_2d(feat))
+        self._keep[("data", s)] = data_mesh
+        self.D = f.shape[0]
+        lib().orc_group_set_subject(self.h, s, data_mesh.h, pf, f.shape[0])
+
+    def reset_cpgrid(self, s, xyz):
+        lib().orc_group_reset_cpgrid(self.h, s, _d(xyz)[1])
+
+    def set_labels(self, labels):
+        l, pl = _d(labels)
+        self.L = len(l)
+        lib().orc_group_set_labels(self.h, pl, self.L)
+
+    def setup(self):
+        st = lib().orc_group_setup(self.h)
+        if st:
+            raise RuntimeError("group setup failed (%d)" % st)
+        n, p, t = C.c_int(), C.c_int(), C.c_int()
+        lib().orc_group_sizes(self.h, C.byref(n), C.byref(p), C.byref(t))
+        self.num_nodes, self.P, self.T = n.value, p.value, t.value
+
+    def pairs(self):
+        return np.ctypeslib.as_array(lib().orc_group_pairs(self.h), (self.P, 2)).copy()
+
+    def triplets(self):
+        return np.ctypeslib.as_array(lib().orc_group_triplets(self.h), (self.T, 3)).copy()
+
+    def patch(self, s, v, l, cap=4096):
+        ids = np.zeros(cap, dtype=np.int32)
+        data = np.zeros((cap, self.D))
+        n = lib().orc_group_patch(self.h, int(s), int(v), int(l), ids.ctypes.data_as(c_ip), data.ctypes.data_as(c_dp), cap)
+        return ids[:n].copy(), data[:n].copy()
+
+    def pairwise(self, pair, la, lb):
+        return lib().orc_group_pairwise(self.h, int(pair), int(la), int(lb))
+
+    def triplet(self, t, la, lb, lc):
+        return lib().orc_group_triplet(self.h, int(t), int(la), int(lb), int(lc))

@@ -1,0 +1,89 @@
+"""Groupwise (gMSM) path on the GPU against the oracle: pairs, patches, inter-subject pairwise costs and
+per-subject strain triplets for a small synthetic group (3 subjects, ico4 data / ico2 control grid / ico4 template).
+
+The per-label rigid rotation of the data mesh goes through acos/sincos on the device, so the resampled feature
+maps agree to ~1e-12 rather than bit for bit; patch index sets and pair lists are exact."""
+import numpy as np
+import pytest
+
+import newmsm_amd as M
+from newmsm_amd import synthetic
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+RTOL, ATOL = 1e-9, 1e-11
+
+
+def build(ctx, S=3, data_order=4, cp_order=2, D=2, mask=False, sim=2):
+    dxyz, dtri = M.make_mesh_from_icosa(data_order)
+    cxyz, ctri = M.make_mesh_from_icosa(cp_order)
+    txyz, ttri = dxyz, dtri  # template space = a regular sphere at data resolution
+    _, mvd = M.cp_spacings(cxyz, ctri)
+    samples, _ = M.label_sampling_grid(cp_order + 2, 0.5 * mvd)
+    mk = (np.cos(txyz[:, 0] / 30.0) if mask else None)
+    g = M.DiscreteGroupCostFunction(ctx, S, simmeasure=sim, lambda_=0.2)
+    og = O.Group(S, simmeasure=sim, lambda_=0.2)
+    tm = M.Mesh(ctx, txyz, ttri)
+    g.set_template(tm, mk)
+    otm = O.Mesh(txyz, ttri)
+    og.set_template(otm, mk)
+    g.Initialize(cxyz, ctri)
+    og.set_controlgrid(O.Mesh(cxyz, ctri))
+    keep = [tm, otm]
+    for s in range(S):
+        sph = synthetic.known_warp(dxyz, seed=40 + s, rot_deg=1.0 + s, amp=0.5)   # this subject's registered sphere so far
+        feat = synthetic.features(synthetic.known_warp(dxyz, seed=90 + s, rot_deg=2.0, amp=1.0), D, seed=5)
+        regular = M.Mesh(ctx, dxyz, dtri)
+        g.reset_meshspace(s, regular, feat)        # first call: _ORIG_MESHES = the regular sphere
+        regular.set_coords(sph)
+        g.reset_meshspace(s, regular, feat)
+        om = O.Mesh(dxyz, dtri)
+        og.set_subject(s, om, feat)
+        om.set_coords(sph)
+        og.set_subject(s, om, feat)
+        cp_s = synthetic.known_warp(cxyz, seed=40 + s, rot_deg=1.0 + s, amp=0.5)
+        g.reset_CPgrid(s, cp_s)
+        og.reset_cpgrid(s, cp_s)
+        keep += [regular, om]
+    g.set_labels(samples)
+    og.set_labels(samples)
+    g.setupCostFunction()
+    og.setup()
+    return g, og, keep
+
+
+def test_group_structure_and_patches(ctx):
+    g, og, _ = build(ctx)
+    assert (g.num_nodes, g.P, g.T) == (og.num_nodes, og.P, og.T) == (3 * 162, 162 * 3, 3 * 320)
+    assert np.array_equal(g.getPairs(), og.pairs())
+    assert np.array_equal(g.getTriplets(), og.triplets())
+    rng = np.random.default_rng(0)
+    for s, v, l in zip(rng.integers(0, 3, 25), rng.integers(0, 162, 25), rng.integers(0, g.L, 25)):
+        ids, data = g.patch(s, v, l)
+        oids, odata = og.patch(s, v, l)
+        assert np.array_equal(ids, oids)
+        assert np.allclose(data, odata, rtol=1e-10, atol=1e-11)
+
+
+@pytest.mark.parametrize("mask,sim", [(False, 2), (True, 2), (False, 1)])
+def test_group_pairwise_costs(ctx, mask, sim):
+    g, og, _ = build(ctx, mask=mask, sim=sim)
+    rng = np.random.default_rng(1)
+    p = rng.integers(0, g.P, 400).astype(np.int32)
+    la = rng.integers(0, g.L, 400).astype(np.int32)
+    lb = rng.integers(0, g.L, 400).astype(np.int32)
+    got = g.computePairwiseCost(p, la, lb)
+    want = np.array([og.pairwise(*q) for q in zip(p, la, lb)])
+    assert np.allclose(got, want, rtol=RTOL, atol=ATOL, equal_nan=True), np.nanmax(np.abs(got - want))
+    assert np.isfinite(want).sum() > 300
+
+
+def test_group_triplet_costs(ctx):
+    g, og, _ = build(ctx, D=1)
+    rng = np.random.default_rng(2)
+    t = rng.integers(0, g.T, 800).astype(np.int32)
+    la, lb, lc = (rng.integers(0, g.L, 800).astype(np.int32) for _ in range(3))
+    got = g.computeTripletCost(t, la, lb, lc)
+    want = np.array([og.triplet(*q) for q in zip(t, la, lb, lc)])
+    assert np.allclose(got, want, rtol=RTOL, atol=ATOL)
+    assert (want == 1e7).any()
