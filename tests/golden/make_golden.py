@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Regenerates tests/golden/oracle_small.npz.
+
+The reference ships no golden vectors and cannot be built here, so these vectors are
+ORACLE outputs (oracle/, the C restatement) on small seeded inputs, frozen so that (a) an accidental change of
+the oracle is caught on CPU and (b) the GPU path can be checked against committed numbers.  They are not
+reference outputs and do not pin the oracle to the reference.
+
+    python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+from newmsm_amd import problem, synthetic  # noqa: E402  (host-only helpers, no GPU)
+from oracle import oracle as O  # noqa: E402
+from tests.helpers import oracle_cost  # noqa: E402
+
+
+def main():
+    out = {}
+    # G1: octree queries on ico3, both weight modes
+    xyz, tri = O.icosphere(3)
+    q = np.concatenate([synthetic.random_sphere_points(300, seed=1), xyz[::7] @ synthetic.rotation([1, 2, 3], 3.0).T])
+    t = O.Octree(O.Mesh(xyz, tri))
+    st, tid, vid, w = t.barycentric_weights(q)
+    _, _, _, wr = t.barycentric_weights(q, raw=True)
+    out.update(g1_q=q, g1_tri=tid, g1_vid=vid, g1_w=w, g1_wraw=wr)
+    # G2: adaptive barycentric CSR ico3 -> ico2 (warped input)
+    xin = synthetic.known_warp(xyz, seed=21, rot_deg=5.0, amp=1.0)
+    x2, t2 = O.icosphere(2)
+    rp, col, val = O.adaptive_barycentric_weights(O.Mesh(xin, tri), O.Mesh(x2, t2))
+    out.update(g2_xin=xin, g2_rp=rp, g2_col=col, g2_val=val)
+    # G3/G4: unary tables (univariate, multivariate D=3) and clique costs on ico4 data / ico2 control grid
+    inp = problem.pairwise_inputs(4, 2, D=3)
+    inp1 = dict(inp, src_feat=inp["src_feat"][:1], ref_feat=inp["ref_feat"][:1], D=1)
+    oc = oracle_cost(inp1, "univariate", rmode=3)
+    oc.get_source_data()
+    ptr, idx = oc.patches()
+    out.update(g3_ptr=ptr, g3_idx=idx, g3_absw=oc.absolute_weights(), g3_unary=oc.unary_table())
+    om = oracle_cost(inp, "multivariate")
+    om.get_source_data()
+    out.update(g3_unary_mv=om.unary_table())
+    rng = np.random.default_rng(0)
+    tq = np.stack([rng.integers(0, oc.T, 200), rng.integers(0, oc.L, 200), rng.integers(0, oc.L, 200), rng.integers(0, oc.L, 200)], 1)
+    out.update(g4_tq=tq, g4_triplet=np.array([oc.triplet(*r) for r in tq]))
+    op = oracle_cost(inp1, "univariate", rmode=1)
+    pq = np.stack([rng.integers(0, op.P, 200), rng.integers(0, op.L, 200), rng.integers(0, op.L, 200)], 1)
+    out.update(g4_pq=pq, g4_pairwise=np.array([op.pairwise(*r) for r in pq]))
+    # G5: strain energy of random triangle pairs
+    tris = rng.normal(size=(100, 2, 3, 3)) + np.array([100.0, 0, 0])
+    out.update(g5_tris=tris, g5_strain=np.array([O.triangular_strain(a, b, 0.1, 10.0, 2.0) for a, b in tris]))
+    np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "oracle_small.npz"), **out)
+    print("wrote oracle_small.npz:", {k: v.shape for k, v in out.items()})
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,59 @@
+"""Committed vectors (tests/golden/oracle_small.npz, made by tests/golden/make_golden.py from the ORACLE -- the
+reference ships none).  CPU: the oracle still reproduces them.  GPU: the product reproduces them."""
+import os
+
+import numpy as np
+import pytest
+
+import newmsm_amd as M
+from newmsm_amd import problem
+from oracle import oracle as O
+from tests.helpers import oracle_cost
+
+G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_small.npz"))
+
+
+def inputs():
+    inp = problem.pairwise_inputs(4, 2, D=3)
+    inp1 = dict(inp, src_feat=inp["src_feat"][:1], ref_feat=inp["ref_feat"][:1], D=1)
+    return inp, inp1
+
+
+def test_oracle_reproduces_golden(built):
+    xyz, tri = O.icosphere(3)
+    t = O.Octree(O.Mesh(xyz, tri))
+    _, tid, vid, w = t.barycentric_weights(G["g1_q"])
+    assert np.array_equal(tid, G["g1_tri"]) and np.array_equal(vid, G["g1_vid"]) and np.array_equal(w, G["g1_w"])
+    rp, col, val = O.adaptive_barycentric_weights(O.Mesh(G["g2_xin"], tri), O.Mesh(*O.icosphere(2)))
+    assert np.array_equal(rp, G["g2_rp"]) and np.array_equal(col, G["g2_col"]) and np.array_equal(val, G["g2_val"])
+    inp, inp1 = inputs()
+    oc = oracle_cost(inp1, "univariate", rmode=3)
+    oc.get_source_data()
+    assert np.array_equal(oc.patches()[1], G["g3_idx"]) and np.array_equal(oc.unary_table(), G["g3_unary"])
+    assert np.array_equal(np.array([oc.triplet(*r) for r in G["g4_tq"]]), G["g4_triplet"])
+    assert np.array_equal(np.array([O.triangular_strain(a, b, 0.1, 10.0, 2.0) for a, b in G["g5_tris"]]), G["g5_strain"])
+
+
+@pytest.mark.gpu
+def test_gpu_reproduces_golden(ctx):
+    xyz, tri = M.make_mesh_from_icosa(3)
+    _, tid, vid, w = M.Mesh(ctx, xyz, tri).query_triangles(G["g1_q"])
+    assert np.array_equal(tid, G["g1_tri"]) and np.array_equal(vid, G["g1_vid"]) and np.array_equal(w, G["g1_w"])
+    _, _, _, wr = M.Mesh(ctx, xyz, tri).query_triangles(G["g1_q"], mode=M.WEIGHTS_RAW)
+    assert np.array_equal(wr, G["g1_wraw"])
+    rp, col, val = M.get_adaptive_barycentric_weights(M.Mesh(ctx, G["g2_xin"], tri), M.Mesh(ctx, *M.make_mesh_from_icosa(2)))
+    assert np.array_equal(rp, G["g2_rp"]) and np.array_equal(col, G["g2_col"]) and np.array_equal(val, G["g2_val"])
+    inp, inp1 = inputs()
+    cf, _ = problem.build_cost(ctx, inp1, kind="univariate", rmode=3)
+    cf.get_source_data()
+    ptr, idx = cf.patches()
+    assert np.array_equal(ptr, G["g3_ptr"]) and np.array_equal(idx, G["g3_idx"]) and np.array_equal(cf.absolute_weights(), G["g3_absw"])
+    assert np.allclose(cf.computeUnaryCosts(), G["g3_unary"], rtol=1e-10, atol=1e-12)
+    tq = G["g4_tq"].astype(np.int32)
+    assert np.allclose(cf.computeTripletCost(tq[:, 0], tq[:, 1], tq[:, 2], tq[:, 3]), G["g4_triplet"], rtol=1e-9, atol=1e-11)
+    cm, _ = problem.build_cost(ctx, inp, kind="multivariate")
+    cm.get_source_data()
+    assert np.allclose(cm.computeUnaryCosts(), G["g3_unary_mv"], rtol=1e-9, atol=1e-11)
+    cp, _ = problem.build_cost(ctx, inp1, kind="univariate", rmode=1)
+    pq = G["g4_pq"].astype(np.int32)
+    assert np.allclose(cp.computePairwiseCost(pq[:, 0], pq[:, 1], pq[:, 2]), G["g4_pairwise"], rtol=1e-9, atol=1e-11)
