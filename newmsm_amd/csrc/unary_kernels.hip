@@ -57,6 +57,7 @@ struct SamplesArgs {
     int Nsrc;
     const int *pptr, *pidx;
     int pmax;
+    int nsplit;            // workgroups per control point (label ranges)
     // outputs, indexed by global sample id g = L*pptr[node] + l*P + i
     double *tval;          // D == 1: interpolated reference feature
     int *stri;             // otherwise: triangle id and the three raw barycentric weights
@@ -215,13 +216,20 @@ __global__ __launch_bounds__(256) void k_unary_samples(SamplesArgs a) {
     __shared__ int s_qn, s_ndefer;
     const int tid = threadIdx.x, lane = tid & 63;
     const int per = (a.N + 7) >> 3;
+    const int slots = 8 * per;
 
     // blockIdx -> control point: the blocks of one XCD (blockIdx % 8, round-robin dispatch) get a contiguous id
     // range, i.e. spatial neighbours on the icosphere, so each XCD's L2 keeps its own part of the target.
     // (A device-side work queue was measured 2.4x slower here: the returning atomics serialise the blocks.)
+    // The labels of a control point are split over a.nsplit workgroups (same XCD) so that one workgroup's samples
+    // fit a single LDS pass and the grid has enough workgroups to balance over the 256 CUs.
     {
-        const int node = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+        const int part = blockIdx.x / slots, slot = blockIdx.x - part * slots;
+        const int node = (slot & 7) * per + (slot >> 3);
         if (node >= a.N) return;
+        const int lper = (a.L + a.nsplit - 1) / a.nsplit;
+        const int l_beg = part * lper, l_end = min(a.L, l_beg + lper);
+        if (l_beg >= l_end) return;
         const int beg = a.pptr[node], P = a.pptr[node + 1] - beg;
         const size_t gbase = (size_t)a.L * beg;
         for (int i = tid; i < P; i += 256) {
@@ -236,11 +244,11 @@ __global__ __launch_bounds__(256) void k_unary_samples(SamplesArgs a) {
         }
         for (int k = tid; k < 9 * a.L; k += 256) sR[k] = a.rnl[(size_t)node * a.L * 9 + k];
         if (tid == 0) s_ndefer = 0;
-        const int total = a.L * P;
+        const int sbeg = l_beg * P, send = l_end * P;  // this workgroup's samples: s = label * P + patch point
         const float invP = 1.0f / (float)max(P, 1);
 
-        for (int base = 0; base < total; base += kChunk) {
-            const int nchunk = min(kChunk, total - base);
+        for (int base = sbeg; base < send; base += kChunk) {
+            const int nchunk = min(kChunk, send - base);
             for (int k = tid; k < kChunk; k += 256) nin[k] = 0;
             if (tid == 0) s_qn = 0;
             __syncthreads();
@@ -249,7 +257,7 @@ __global__ __launch_bounds__(256) void k_unary_samples(SamplesArgs a) {
             // Every lane runs the same number of rounds so that the queue reservation can use wavefront shuffles.
             for (int r0 = 0; r0 < nchunk; r0 += 256) {
                 const int sl = r0 + tid;
-                unsigned long long pm = 0ull;  // entries that passed the cone filter
+                unsigned pm_lo = 0u, pm_hi = 0u;  // entries that passed the cone filter
                 int lbeg = 0;
                 bool defer = false;
                 if (sl < nchunk) {
@@ -271,29 +279,38 @@ __global__ __launch_bounds__(256) void k_unary_samples(SamplesArgs a) {
                             const float inv = rsqrtf(qx * qx + qy * qy + qz * qz);
                             const float fx = qx * inv, fy = qy * inv, fz = qz * inv;
                             const float4 *cone = a.tree.cone + leaf.y;
-                            // entries a point of this sub-cell can hit at all; cone-test those, four loads in flight
-                            unsigned long long mm = a.tree.mask[(size_t)leaf.z * 64 + sub];
-                            while (mm) {
-                                int e[4];
-                                bool v[4];
+                            // entries a point of this sub-cell can hit at all; cone-test those, four loads in flight.
+                            // The two 32-bit halves of the mask are walked with 32-bit bit operations.
+                            const unsigned long long mm = a.tree.mask[(size_t)leaf.z * 64 + sub];
 #pragma unroll
-                                for (int k = 0; k < 4; ++k) {
-                                    v[k] = mm != 0ull;
-                                    e[k] = v[k] ? __ffsll((long long)mm) - 1 : 0;
-                                    mm &= mm - 1ull;  // 0 stays 0
+                            for (int half = 0; half < 2; ++half) {
+                                unsigned m = half ? (unsigned)(mm >> 32) : (unsigned)mm;
+                                const float4 *ch = cone + 32 * half;
+                                unsigned hits = 0u;
+                                while (m) {
+                                    int e[4];
+                                    bool v[4];
+#pragma unroll
+                                    for (int k = 0; k < 4; ++k) {
+                                        v[k] = m != 0u;
+                                        e[k] = v[k] ? __ffs((int)m) - 1 : 0;
+                                        m &= m - 1u;  // 0 stays 0
+                                    }
+                                    float4 c[4];
+#pragma unroll
+                                    for (int k = 0; k < 4; ++k) c[k] = ch[e[k]];
+#pragma unroll
+                                    for (int k = 0; k < 4; ++k)
+                                        if (v[k] && cone_pass(c[k], fx, fy, fz)) hits |= 1u << e[k];
                                 }
-                                float4 c[4];
-#pragma unroll
-                                for (int k = 0; k < 4; ++k) c[k] = cone[e[k]];
-#pragma unroll
-                                for (int k = 0; k < 4; ++k)
-                                    if (v[k] && cone_pass(c[k], fx, fy, fz)) pm |= 1ull << e[k];
+                                if (half) pm_hi = hits;
+                                else pm_lo = hits;
                             }
                         }
                     }
                 }
                 // reserve queue space: wavefront prefix sum of the per-lane pair counts, one LDS atomic per wave
-                const int cntp = __popcll(pm);
+                const int cntp = __popc(pm_lo) + __popc(pm_hi);
                 int incl = cntp;
 #pragma unroll
                 for (int off = 1; off < 64; off <<= 1) {
@@ -310,10 +327,15 @@ __global__ __launch_bounds__(256) void k_unary_samples(SamplesArgs a) {
                     } else {
                         const int *lt = a.tree.leaf_tri + lbeg;
                         const unsigned tag = (unsigned)sl << kTriBits;
-                        while (pm) {
-                            const int e = __ffsll((long long)pm) - 1;
-                            pm &= pm - 1ull;
+                        while (pm_lo) {
+                            const int e = __ffs((int)pm_lo) - 1;
+                            pm_lo &= pm_lo - 1u;
                             queue[pos++] = tag | (unsigned)lt[e];
+                        }
+                        while (pm_hi) {
+                            const int e = __ffs((int)pm_hi) - 1;
+                            pm_hi &= pm_hi - 1u;
+                            queue[pos++] = tag | (unsigned)lt[32 + e];
                         }
                     }
                 }
@@ -362,13 +384,13 @@ __global__ __launch_bounds__(256) void k_unary_samples(SamplesArgs a) {
             __syncthreads();
 #endif
         }
-        if (tid == 0 && a.nsamples) atomicAdd(a.nsamples, (unsigned long long)total);
+        if (tid == 0 && a.nsamples) atomicAdd(a.nsamples, (unsigned long long)(send - sbeg));
         // ---- reduction: every sample of this control point is in LDS unless some were deferred
         if (a.U) {
             __syncthreads();  // s_ndefer and sT are final (also when the patch is empty and the loop never ran)
             if (s_ndefer == 0) {
                 const double absw = a.absw[node];
-                for (int l = tid >> 6; l < a.L; l += 4) {
+                for (int l = l_beg + (tid >> 6); l < l_end; l += 4) {
                     const double cost = patch_similarity(sA, sW, sT + l * a.pmax, P, lane, a.simmeasure);
                     if (lane == 0) a.U[(size_t)l * a.N + node] = absw * cost;
                 }
@@ -597,7 +619,8 @@ static int launch_samples(msm_ctx *ctx, const UnaryLaunch &u, const UnaryWeights
         MSM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_unary_samples), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
     MSM_HIP(hipMemsetAsync(u.fix_count, 0, 2 * sizeof(unsigned), ctx->stream));  // fix-up and redo counters
-    const int blocks = 8 * ((u.N + 7) / 8);
+    a.nsplit = std::max(1, std::min(4, (int)(((size_t)u.L * u.pmax + kChunk - 1) / kChunk)));
+    const int blocks = a.nsplit * 8 * ((u.N + 7) / 8);
     hipLaunchKernelGGL(k_unary_samples, dim3(blocks), dim3(256), lds, ctx->stream, a);
     MSM_HIP(hipGetLastError());
     hipLaunchKernelGGL(k_unary_fixup, dim3(64), dim3(256), 0, ctx->stream, a);
