@@ -257,7 +257,7 @@ __global__ __launch_bounds__(256) void k_unary_samples(SamplesArgs a) {
             // Every lane runs the same number of rounds so that the queue reservation can use wavefront shuffles.
             for (int r0 = 0; r0 < nchunk; r0 += 256) {
                 const int sl = r0 + tid;
-                unsigned pm_lo = 0u, pm_hi = 0u;  // entries that passed the cone filter
+                unsigned long long pm = 0ull;  // entries that passed the cone filter
                 int lbeg = 0;
                 bool defer = false;
                 if (sl < nchunk) {
@@ -279,38 +279,29 @@ __global__ __launch_bounds__(256) void k_unary_samples(SamplesArgs a) {
                             const float inv = rsqrtf(qx * qx + qy * qy + qz * qz);
                             const float fx = qx * inv, fy = qy * inv, fz = qz * inv;
                             const float4 *cone = a.tree.cone + leaf.y;
-                            // entries a point of this sub-cell can hit at all; cone-test those, four loads in flight.
-                            // The two 32-bit halves of the mask are walked with 32-bit bit operations.
-                            const unsigned long long mm = a.tree.mask[(size_t)leaf.z * 64 + sub];
+                            // entries a point of this sub-cell can hit at all; cone-test those, four loads in flight
+                            unsigned long long mm = a.tree.mask[(size_t)leaf.z * 64 + sub];
+                            while (mm) {
+                                int e[4];
+                                bool v[4];
 #pragma unroll
-                            for (int half = 0; half < 2; ++half) {
-                                unsigned m = half ? (unsigned)(mm >> 32) : (unsigned)mm;
-                                const float4 *ch = cone + 32 * half;
-                                unsigned hits = 0u;
-                                while (m) {
-                                    int e[4];
-                                    bool v[4];
-#pragma unroll
-                                    for (int k = 0; k < 4; ++k) {
-                                        v[k] = m != 0u;
-                                        e[k] = v[k] ? __ffs((int)m) - 1 : 0;
-                                        m &= m - 1u;  // 0 stays 0
-                                    }
-                                    float4 c[4];
-#pragma unroll
-                                    for (int k = 0; k < 4; ++k) c[k] = ch[e[k]];
-#pragma unroll
-                                    for (int k = 0; k < 4; ++k)
-                                        if (v[k] && cone_pass(c[k], fx, fy, fz)) hits |= 1u << e[k];
+                                for (int k = 0; k < 4; ++k) {
+                                    v[k] = mm != 0ull;
+                                    e[k] = v[k] ? __ffsll((long long)mm) - 1 : 0;
+                                    mm &= mm - 1ull;  // 0 stays 0
                                 }
-                                if (half) pm_hi = hits;
-                                else pm_lo = hits;
+                                float4 c[4];
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) c[k] = cone[e[k]];
+#pragma unroll
+                                for (int k = 0; k < 4; ++k)
+                                    if (v[k] && cone_pass(c[k], fx, fy, fz)) pm |= 1ull << e[k];
                             }
                         }
                     }
                 }
                 // reserve queue space: wavefront prefix sum of the per-lane pair counts, one LDS atomic per wave
-                const int cntp = __popc(pm_lo) + __popc(pm_hi);
+                const int cntp = __popcll(pm);
                 int incl = cntp;
 #pragma unroll
                 for (int off = 1; off < 64; off <<= 1) {
@@ -327,15 +318,10 @@ __global__ __launch_bounds__(256) void k_unary_samples(SamplesArgs a) {
                     } else {
                         const int *lt = a.tree.leaf_tri + lbeg;
                         const unsigned tag = (unsigned)sl << kTriBits;
-                        while (pm_lo) {
-                            const int e = __ffs((int)pm_lo) - 1;
-                            pm_lo &= pm_lo - 1u;
+                        while (pm) {
+                            const int e = __ffsll((long long)pm) - 1;
+                            pm &= pm - 1ull;
                             queue[pos++] = tag | (unsigned)lt[e];
-                        }
-                        while (pm_hi) {
-                            const int e = __ffs((int)pm_hi) - 1;
-                            pm_hi &= pm_hi - 1u;
-                            queue[pos++] = tag | (unsigned)lt[32 + e];
                         }
                     }
                 }
