@@ -240,6 +240,15 @@ int msm_group_set_labels(msm_group *g, const double *labels, int32_t L);
 /* setupCostFunction M/DiscreteGroupModel.cpp:163-196: estimate_pairs :37-55, get_spacings :123-139, get_rotations :77-86,
  * get_patch_data :88-121 */
 int msm_group_setup(msm_group *g);
+/* Sharded set-up (one process per GPU, subjects split over ranks): every rank runs msm_group_setup_subjects on ITS
+ * subjects (the pair list, spacings and rotations are computed for all subjects -- they only need the control grids),
+ * exports them, imports the other ranks' subjects (the exchange itself is the caller's all-gather / broadcast over
+ * RCCL, see newmsm_amd/dist.py), then msm_group_finalize.  msm_group_setup = all subjects + finalize.
+ * F: L x D x V(template) doubles; pptr: N*L + 1; pidx: pptr[N*L] entries (query *npidx with pidx == NULL). */
+int msm_group_setup_subjects(msm_group *g, const int32_t *subjects, int32_t n);
+int msm_group_export_subject(msm_group *g, int32_t subject, double *F, int32_t *pptr, int32_t *pidx, int64_t cap, int64_t *npidx);
+int msm_group_import_subject(msm_group *g, int32_t subject, const double *F, const int32_t *pptr, const int32_t *pidx, int64_t npidx);
+int msm_group_finalize(msm_group *g);
 int msm_group_sizes(msm_group *g, int32_t *nodes, int32_t *pairs, int32_t *triplets);
 int msm_group_get_pairs(msm_group *g, int32_t *pairs /* P x 2 */);
 int msm_group_get_triplets(msm_group *g, int32_t *triplets /* T x 3 */);

@@ -464,6 +464,34 @@ class DiscreteGroupCostFunction:
         check(lib().msm_group_sizes(self.h, C.byref(n), C.byref(p), C.byref(t)))
         self.num_nodes, self.P, self.T = n.value, p.value, t.value
 
+    # ---- sharded set-up (one process per GPU; see newmsm_amd.dist.sharded_group_setup) ----
+    def setup_subjects(self, subjects):
+        s, ps = _i(np.asarray(list(subjects), dtype=np.int32))
+        check(lib().msm_group_setup_subjects(self.h, ps, len(s)))
+
+    def export_subject(self, subject):
+        n = C.c_int64()
+        check(lib().msm_group_export_subject(self.h, int(subject), None, None, None, 0, C.byref(n)))
+        Vt = self._keep["template"].V
+        F = np.zeros((self.L, self.D, Vt))
+        pptr = np.zeros(self.N * self.L + 1, dtype=np.int32)
+        pidx = np.zeros(max(n.value, 1), dtype=np.int32)
+        check(lib().msm_group_export_subject(self.h, int(subject), F.ctypes.data_as(c_dp), pptr.ctypes.data_as(c_ip), pidx.ctypes.data_as(c_ip),
+                                             len(pidx), C.byref(n)))
+        return F, pptr, pidx[: n.value]
+
+    def import_subject(self, subject, F, pptr, pidx):
+        F, pF = _d(F)
+        pp, ppp = _i(pptr)
+        pi, ppi = _i(pidx)
+        check(lib().msm_group_import_subject(self.h, int(subject), pF, ppp, ppi if len(pi) else None, len(pi)))
+
+    def finalize(self):
+        check(lib().msm_group_finalize(self.h))
+        n, p, t = C.c_int32(), C.c_int32(), C.c_int32()
+        check(lib().msm_group_sizes(self.h, C.byref(n), C.byref(p), C.byref(t)))
+        self.num_nodes, self.P, self.T = n.value, p.value, t.value
+
     def getPairs(self):
         out = np.zeros((self.P, 2), dtype=np.int32)
         check(lib().msm_group_get_pairs(self.h, out.ctypes.data_as(c_ip)))

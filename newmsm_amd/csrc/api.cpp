@@ -40,15 +40,13 @@ int ensure_tree(msm_mesh *m) {
         cap = need + need / 4 + 16;
         return hipMalloc(p, cap * elem);
     };
-    size_t cap_parent = m->cap_node, cap_cone = m->cap_leaf;
     MSM_HIP(grow((void **)&m->d_node, m->cap_node, m->tree.node.size(), sizeof(int4)));
-    MSM_HIP(grow((void **)&m->d_parent, cap_parent, m->tree.node.size(), sizeof(int32_t)));
+    MSM_HIP(grow((void **)&m->d_parent, m->cap_parent, m->tree.node.size(), sizeof(int32_t)));
     MSM_HIP(grow((void **)&m->d_leaf_tri, m->cap_leaf, m->tree.leaf_tri.size(), sizeof(int32_t)));
-    MSM_HIP(grow((void **)&m->d_cone, cap_cone, m->tree.leaf_tri.size(), sizeof(float4)));
+    MSM_HIP(grow((void **)&m->d_cone, m->cap_cone, m->tree.leaf_tri.size(), sizeof(float4)));
     MSM_HIP(grow((void **)&m->d_rec, m->cap_rec, recs.size(), sizeof(TriRec)));
     MSM_HIP(grow((void **)&m->d_grid, m->cap_grid, m->tree.grid.size(), sizeof(int32_t)));
-    size_t cap_box = cap_parent;
-    MSM_HIP(grow((void **)&m->d_nodebox, cap_box, m->tree.node.size(), sizeof(double4)));
+    MSM_HIP(grow((void **)&m->d_nodebox, m->cap_box, m->tree.node.size(), sizeof(double4)));
     // the staging vectors die at scope exit, so these copies must complete here
     MSM_HIP(hipMemcpyAsync(m->d_node, m->tree.node.data(), m->tree.node.size() * sizeof(int4), hipMemcpyHostToDevice, ctx->stream));
     MSM_HIP(hipMemcpyAsync(m->d_parent, m->tree.parent.data(), m->tree.parent.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));

@@ -38,7 +38,8 @@ struct msm_group {
     int D = 0, L = 0;
     std::vector<double> labels;                  // 3 x L SoA
     // setup products
-    bool ready = false;
+    bool ready = false, common_ready = false;
+    std::vector<char> have_subject;
     std::vector<int32_t> pairs, triplets;
     DevBuf<int32_t> d_pairs, d_triplets;
     std::vector<double> rot, moved;              // (S*N) x 9, (S*N) x L x 3
@@ -197,6 +198,7 @@ int msm_group_set_template(msm_group *g, msm_mesh *t, const double *mask) {
         MSM_HIP(hipStreamSynchronize(g->ctx->stream));
     }
     g->ready = false;
+    g->common_ready = false;
     return MSM_OK;
 }
 
@@ -221,6 +223,7 @@ int msm_group_set_controlgrid(msm_group *g, const double *xyz, const int32_t *tr
     MSM_HIP(g->d_triplets.upload(g->triplets.data(), g->triplets.size(), g->ctx->stream));
     MSM_HIP(hipStreamSynchronize(g->ctx->stream));
     g->ready = false;
+    g->common_ready = false;
     return MSM_OK;
 }
 
@@ -228,8 +231,8 @@ int msm_group_set_subject(msm_group *g, int32_t s, msm_mesh *data, const double 
     if (!g || !data || !feat || s < 0 || s >= g->S || D <= 0) return fail(MSM_ERR_INVALID, "msm_group_set_subject: bad arguments");
     if (g->N <= 0) return fail(MSM_ERR_STATE, "msm_group: the control grid must be set first");
     if (data->V < g->N) return fail(MSM_ERR_INVALID, "data mesh has fewer vertices than the control grid");
-    if (g->D != 0 && g->D != D && std::any_of(g->data.begin(), g->data.end(), [](msm_mesh *m) { return m != nullptr; }) && g->data[s] == nullptr)
-        return fail(MSM_ERR_INVALID, "all subjects must have the same number of feature dimensions");
+    for (int o = 0; o < g->S; ++o)
+        if (o != s && g->data[o] && g->D != D) return fail(MSM_ERR_INVALID, "all subjects must have the same number of feature dimensions");
     g->D = D;
     g->data[s] = data;
     g->feat[s].assign(feat, feat + (size_t)D * data->V);
@@ -248,12 +251,14 @@ int msm_group_set_subject(msm_group *g, int32_t s, msm_mesh *data, const double 
         if (!g->scratch[s]) return MSM_ERR_HIP;
     }
     g->ready = false;
+    g->common_ready = false;
     return MSM_OK;
 }
 
 int msm_group_reset_cpgrid(msm_group *g, int32_t s, const double *xyz) {
     if (!g || !xyz || s < 0 || s >= g->S || !g->cpmesh[s]) return fail(MSM_ERR_INVALID, "msm_group_reset_cpgrid: bad arguments");
     g->ready = false;
+    g->common_ready = false;
     return msm_mesh_update_coords(g->cpmesh[s], xyz);
 }
 
@@ -262,18 +267,20 @@ int msm_group_set_labels(msm_group *g, const double *labels, int32_t L) {
     g->L = L;
     g->labels.assign(labels, labels + 3 * (size_t)L);
     g->ready = false;
+    g->common_ready = false;
     return MSM_OK;
 }
 
-int msm_group_setup(msm_group *g) {
-    if (!g) return fail(MSM_ERR_INVALID, "null group");
-    if (!g->tmpl || g->N <= 0 || g->L <= 0) return fail(MSM_ERR_STATE, "msm_group: template, control grid and labels must be set first");
-    for (int s = 0; s < g->S; ++s)
-        if (!g->data[s]) return fail(MSM_ERR_STATE, "msm_group: subject %d has no data", s);
-    msm_ctx *ctx = g->ctx;
-    const int S = g->S, N = g->N, L = g->L, D = g->D, Vt = g->tmpl->V;
-    const double centre[3] = {g->labels[0], g->labels[L], g->labels[2 * (size_t)L]};
+}  // extern "C" (re-opened below)
 
+namespace {
+
+// estimate_pairs, spacings, rotations: cheap, needs every subject's control grid, identical on every rank
+int group_common_setup(msm_group *g) {
+    if (!g->tmpl || g->N <= 0 || g->L <= 0) return fail(MSM_ERR_STATE, "msm_group: template, control grid and labels must be set first");
+    msm_ctx *ctx = g->ctx;
+    const int S = g->S, N = g->N, L = g->L;
+    const double centre[3] = {g->labels[0], g->labels[L], g->labels[2 * (size_t)L]};
     // estimate_pairs, M/DiscreteGroupModel.cpp:37-55: closest control point of subject B for every control point of A
     g->pairs.resize((size_t)N * S * (S - 1));
     {
@@ -294,11 +301,10 @@ int msm_group_setup(msm_group *g) {
                 }
     }
     MSM_HIP(g->d_pairs.upload(g->pairs.data(), std::max<size_t>(g->pairs.size(), 1), ctx->stream));
-
     // get_spacings :123-139, get_rotations :77-86, and ROT * label for every (node, label)
     g->rot.resize(9 * (size_t)S * N);
     g->moved.resize(3 * (size_t)S * N * L);
-    std::vector<double> cp_all(3 * (size_t)S * N), orig_all(3 * (size_t)S * N);
+    std::vector<double> cp_all(3 * (size_t)S * N), orig_all(3 * (size_t)S * N, 0.0);
     for (int s = 0; s < S; ++s) {
         msm_mesh *cm = g->cpmesh[s];
         g->spacing[s].resize(N);
@@ -314,54 +320,126 @@ int msm_group_setup(msm_group *g) {
                 o[0] = m.x, o[1] = m.y, o[2] = m.z;
             }
         std::copy(cm->xyz.begin(), cm->xyz.end(), cp_all.begin() + 3 * (size_t)s * N);
-        std::copy(g->orig[s].begin(), g->orig[s].end(), orig_all.begin() + 3 * (size_t)s * N);
+        if (g->have_orig[s]) std::copy(g->orig[s].begin(), g->orig[s].end(), orig_all.begin() + 3 * (size_t)s * N);
     }
     MSM_HIP(g->d_moved.upload(g->moved.data(), g->moved.size(), ctx->stream));
     MSM_HIP(g->d_cp.upload(cp_all.data(), cp_all.size(), ctx->stream));
     MSM_HIP(g->d_orig.upload(orig_all.data(), orig_all.size(), ctx->stream));
     MSM_HIP(hipStreamSynchronize(ctx->stream));
-
-    // get_patch_data :88-121
     g->F.resize((size_t)S * L);
-    std::vector<double> rotated, resampled((size_t)D * Vt);
+    g->have_subject.assign(S, 0);
+    g->common_ready = true;
+    return MSM_OK;
+}
+
+// get_patch_data for one subject, M/DiscreteGroupModel.cpp:88-121
+int group_subject_setup(msm_group *g, int s) {
+    if (!g->data[s]) return fail(MSM_ERR_STATE, "msm_group: subject %d has no data", s);
+    msm_ctx *ctx = g->ctx;
+    const int L = g->L, D = g->D, Vt = g->tmpl->V;
+    const double centre[3] = {g->labels[0], g->labels[L], g->labels[2 * (size_t)L]};
+    msm_mesh *dm = g->data[s], *sm = g->scratch[s];
+    const int V = dm->V;
+    std::vector<double> rotated(3 * (size_t)V), resampled((size_t)D * Vt);
     std::vector<int32_t> rp, col;
     std::vector<double> val;
-    for (int s = 0; s < S; ++s) {
-        msm_mesh *dm = g->data[s], *sm = g->scratch[s];
-        const int V = dm->V;
-        rotated.resize(3 * (size_t)V);
-        DevBuf<double> d_rot;
-        MSM_HIP(d_rot.ensure(3 * (size_t)V));
-        for (int l = 0; l < L; ++l) {
-            if (l > 0) {
-                const double lab[3] = {g->labels[l], g->labels[L + l], g->labels[2 * (size_t)L + l]};
-                int st = launch_rotate_to_label(ctx, dm->d_xyz, V, centre, lab, d_rot.p);
-                if (st) return st;
-                MSM_HIP(d_rot.download(rotated.data(), rotated.size(), ctx->stream));
-                st = check_status(ctx, "get_patch_data (rotation)");
-                if (st) return st;
-            } else {
-                rotated = dm->xyz;
-            }
-            int st = msm_mesh_update_coords(sm, rotated.data());
+    DevBuf<double> d_rot;
+    MSM_HIP(d_rot.ensure(3 * (size_t)V));
+    for (int l = 0; l < L; ++l) {
+        if (l > 0) {
+            const double lab[3] = {g->labels[l], g->labels[L + l], g->labels[2 * (size_t)L + l]};
+            int st = launch_rotate_to_label(ctx, dm->d_xyz, V, centre, lab, d_rot.p);
             if (st) return st;
-            st = adaptive_weights(sm, g->tmpl, nullptr, rp, col, val);  // metric_resample(rotated_mesh, target_space)
+            MSM_HIP(d_rot.download(rotated.data(), rotated.size(), ctx->stream));
+            st = check_status(ctx, "get_patch_data (rotation)");
             if (st) return st;
-            for (int d = 0; d < D; ++d)
-                for (int k = 0; k < Vt; ++k) {
-                    double acc = 0.0;
-                    for (int e = rp[k]; e < rp[k + 1]; ++e) acc += g->feat[s][(size_t)d * V + col[e]] * val[e];
-                    resampled[(size_t)d * Vt + k] = acc;
-                }
-            auto &buf = g->F[(size_t)s * L + l];
-            if (!buf) buf.reset(new DevBuf<double>());
-            MSM_HIP(buf->upload(resampled.data(), resampled.size(), ctx->stream));
-            MSM_HIP(hipStreamSynchronize(ctx->stream));
+        } else {
+            rotated = dm->xyz;
         }
-        int st = subject_patches(g, s);
+        int st = msm_mesh_update_coords(sm, rotated.data());
+        if (st) return st;
+        st = adaptive_weights(sm, g->tmpl, nullptr, rp, col, val);  // metric_resample(rotated_mesh, target_space)
+        if (st) return st;
+        for (int d = 0; d < D; ++d)
+            for (int k = 0; k < Vt; ++k) {
+                double acc = 0.0;
+                for (int e = rp[k]; e < rp[k + 1]; ++e) acc += g->feat[s][(size_t)d * V + col[e]] * val[e];
+                resampled[(size_t)d * Vt + k] = acc;
+            }
+        auto &buf = g->F[(size_t)s * L + l];
+        if (!buf) buf.reset(new DevBuf<double>());
+        MSM_HIP(buf->upload(resampled.data(), resampled.size(), ctx->stream));
+        MSM_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    int st = subject_patches(g, s);
+    if (st) return st;
+    g->have_subject[s] = 1;
+    return MSM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int msm_group_setup_subjects(msm_group *g, const int32_t *subjects, int32_t n) {
+    if (!g || (n > 0 && !subjects) || n < 0) return fail(MSM_ERR_INVALID, "msm_group_setup_subjects: bad arguments");
+    g->ready = false;
+    g->common_ready = false;
+    int st = group_common_setup(g);
+    if (st) return st;
+    for (int i = 0; i < n; ++i) {
+        if (subjects[i] < 0 || subjects[i] >= g->S) return fail(MSM_ERR_INVALID, "subject %d out of range", subjects[i]);
+        st = group_subject_setup(g, subjects[i]);
         if (st) return st;
     }
-    // pointer tables for the kernels
+    return MSM_OK;
+}
+
+int msm_group_export_subject(msm_group *g, int32_t s, double *F, int32_t *pptr, int32_t *pidx, int64_t cap, int64_t *npidx) {
+    if (!g || s < 0 || s >= g->S) return fail(MSM_ERR_INVALID, "msm_group_export_subject: bad arguments");
+    if (!g->common_ready || !g->have_subject[s]) return fail(MSM_ERR_STATE, "msm_group: subject %d has not been set up on this rank", s);
+    const size_t per = (size_t)g->D * g->tmpl->V;
+    if (npidx) *npidx = (int64_t)g->h_pidx[s].size();
+    if (F) {
+        for (int l = 0; l < g->L; ++l) MSM_HIP(g->F[(size_t)s * g->L + l]->download(F + per * l, per, g->ctx->stream));
+        MSM_HIP(hipStreamSynchronize(g->ctx->stream));
+    }
+    if (pptr) std::copy(g->h_pptr[s].begin(), g->h_pptr[s].end(), pptr);
+    if (pidx) {
+        if ((int64_t)g->h_pidx[s].size() > cap) return fail(MSM_ERR_CAPACITY, "patch index buffer too small");
+        std::copy(g->h_pidx[s].begin(), g->h_pidx[s].end(), pidx);
+    }
+    return MSM_OK;
+}
+
+int msm_group_import_subject(msm_group *g, int32_t s, const double *F, const int32_t *pptr, const int32_t *pidx, int64_t npidx) {
+    if (!g || !F || !pptr || (!pidx && npidx > 0) || s < 0 || s >= g->S || npidx < 0) return fail(MSM_ERR_INVALID, "msm_group_import_subject: bad arguments");
+    if (!g->common_ready) return fail(MSM_ERR_STATE, "msm_group: msm_group_setup_subjects() must be called first (an empty list is fine)");
+    msm_ctx *ctx = g->ctx;
+    const size_t per = (size_t)g->D * g->tmpl->V;
+    const size_t M = (size_t)g->N * g->L;
+    if (pptr[M] != npidx) return fail(MSM_ERR_INVALID, "patch CSR of subject %d is inconsistent", s);
+    for (int l = 0; l < g->L; ++l) {
+        auto &buf = g->F[(size_t)s * g->L + l];
+        if (!buf) buf.reset(new DevBuf<double>());
+        MSM_HIP(buf->upload(F + per * l, per, ctx->stream));
+    }
+    g->h_pptr[s].assign(pptr, pptr + M + 1);
+    g->h_pidx[s].assign(pidx, pidx + npidx);
+    MSM_HIP(g->pptr[s]->upload(g->h_pptr[s].data(), M + 1, ctx->stream));
+    MSM_HIP(g->pidx[s]->upload(g->h_pidx[s].data(), std::max<size_t>(g->h_pidx[s].size(), 1), ctx->stream));
+    MSM_HIP(hipStreamSynchronize(ctx->stream));
+    g->have_subject[s] = 1;
+    return MSM_OK;
+}
+
+int msm_group_finalize(msm_group *g) {
+    if (!g) return fail(MSM_ERR_INVALID, "null group");
+    if (!g->common_ready) return fail(MSM_ERR_STATE, "msm_group: nothing has been set up");
+    for (int s = 0; s < g->S; ++s)
+        if (!g->have_subject[s]) return fail(MSM_ERR_STATE, "msm_group: subject %d is neither set up nor imported", s);
+    msm_ctx *ctx = g->ctx;
+    const int S = g->S, L = g->L;
     std::vector<const double *> Fp((size_t)S * L);
     for (size_t k = 0; k < Fp.size(); ++k) Fp[k] = g->F[k]->p;
     std::vector<const int *> pp(S), pi(S);
@@ -375,6 +453,15 @@ int msm_group_setup(msm_group *g) {
     MSM_HIP(hipStreamSynchronize(ctx->stream));
     g->ready = true;
     return MSM_OK;
+}
+
+int msm_group_setup(msm_group *g) {
+    if (!g) return fail(MSM_ERR_INVALID, "null group");
+    std::vector<int32_t> all(g->S);
+    for (int s = 0; s < g->S; ++s) all[s] = s;
+    int st = msm_group_setup_subjects(g, all.data(), g->S);
+    if (st) return st;
+    return msm_group_finalize(g);
 }
 
 int msm_group_sizes(msm_group *g, int32_t *nodes, int32_t *pairs, int32_t *triplets) {

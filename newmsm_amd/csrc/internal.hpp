@@ -109,7 +109,7 @@ struct msm_mesh {
     float4 *d_cone = nullptr;
     msm::TriRec *d_rec = nullptr;
     int32_t *d_grid = nullptr;
-    size_t cap_node = 0, cap_leaf = 0, cap_rec = 0, cap_grid = 0, cap_mask = 0;
+    size_t cap_node = 0, cap_parent = 0, cap_box = 0, cap_leaf = 0, cap_cone = 0, cap_rec = 0, cap_grid = 0, cap_mask = 0;  // one per buffer
     msm::Adjacency adj;
     bool adj_valid = false;
 };

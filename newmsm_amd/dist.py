@@ -103,3 +103,38 @@ def group_template_update(local_spheres, local_features=None, dist=None, device=
         out["mean"] = mean
         out["stdev"] = np.sqrt(np.maximum(s2 / n - mean ** 2, 0.0))
     return out
+
+
+def sharded_group_setup(group, n_subjects, dist=None, device="cpu"):
+    """Groupwise set-up with the subjects sharded over the ranks.
+
+    `group` offers setup_subjects(list), export_subject(s) -> (F, pptr, pidx), import_subject(s, F, pptr, pidx) and
+    finalize() (newmsm_amd.DiscreteGroupCostFunction).  Every rank runs the expensive per-subject work -- one rigid
+    rotation + adaptive-barycentric resample per label -- for ITS subjects only; the resampled feature maps and
+    patch lists are then broadcast from their owner (RCCL over xGMI with the nccl backend; F is L x D x V doubles,
+    12.5 MB per subject at ico6 / 19 labels / D = 2) so that every rank can evaluate any inter-subject pair."""
+    rank, _, world = env() if dist is not None else (0, 0, 1)
+    mine = list(shard(n_subjects, rank, world))
+    group.setup_subjects(mine)
+    if dist is not None and world > 1:
+        import torch
+
+        for s in range(n_subjects):
+            owner = next(r for r in range(world) if s in shard(n_subjects, r, world))
+            if owner == rank:
+                F, pptr, pidx = group.export_subject(s)
+                meta = torch.tensor([F.size, len(pptr), len(pidx)] + list(F.shape), dtype=torch.int64, device=device)
+            else:
+                meta = torch.zeros(6, dtype=torch.int64, device=device)
+            dist.broadcast(meta, src=owner)
+            nF, npp, npi, L, D, V = (int(x) for x in meta.cpu().tolist())
+            tF = _tensor(F.ravel(), device) if owner == rank else torch.zeros(nF, dtype=torch.float64, device=device)
+            tI = (torch.as_tensor(np.concatenate([pptr, pidx]).astype(np.int32), device=device) if owner == rank
+                  else torch.zeros(npp + npi, dtype=torch.int32, device=device))
+            dist.broadcast(tF, src=owner)
+            dist.broadcast(tI, src=owner)
+            if owner != rank:
+                ints = tI.cpu().numpy()
+                group.import_subject(s, tF.cpu().numpy().reshape(L, D, V), ints[:npp], ints[npp:])
+    group.finalize()
+    return mine

@@ -66,3 +66,53 @@ def test_two_gloo_ranks(tmp_path):
     assert all(o["ok"] for o in outs)
     assert all(o["n"] == 7 and o["tmax"] == 2.0 for o in outs)
     assert sorted(outs[0]["mine"] + outs[1]["mine"]) == list(range(7))
+
+
+GROUP_WORKER = textwrap.dedent("""
+    import os, sys, json
+    import numpy as np
+    sys.path.insert(0, %r)
+    from newmsm_amd import dist as D
+
+    class FakeGroup:
+        \"\"\"stands in for DiscreteGroupCostFunction: per-subject products are deterministic functions of the subject id\"\"\"
+        def __init__(self): self.have = {}; self.final = False
+        @staticmethod
+        def make(s):
+            rng = np.random.default_rng(100 + s)
+            n = int(rng.integers(5, 40))
+            pptr = np.sort(rng.integers(0, n, 12)).astype(np.int32); pptr[0] = 0; pptr = np.append(pptr, n).astype(np.int32)
+            return rng.normal(size=(3, 2, 42)), pptr, rng.integers(0, 42, n).astype(np.int32)
+        def setup_subjects(self, subjects):
+            for s in subjects: self.have[s] = self.make(s)
+        def export_subject(self, s): return self.have[s]
+        def import_subject(self, s, F, pptr, pidx): self.have[s] = (np.array(F), np.array(pptr), np.array(pidx))
+        def finalize(self): self.final = True
+
+    rank, _, world = D.env()
+    dist = D.init("gloo")
+    g = FakeGroup()
+    mine = D.sharded_group_setup(g, 5, dist)
+    ok = g.final and sorted(g.have) == list(range(5))
+    for s in range(5):
+        F, pp, pi = FakeGroup.make(s)
+        ok = ok and np.array_equal(g.have[s][0], F) and np.array_equal(g.have[s][1], pp) and np.array_equal(g.have[s][2], pi)
+    dist.barrier()
+    print(json.dumps({"rank": rank, "ok": bool(ok), "mine": mine}))
+    dist.destroy_process_group()
+""")
+
+
+def test_sharded_group_exchange_two_gloo_ranks(tmp_path):
+    script = tmp_path / "gworker.py"
+    script.write_text(GROUP_WORKER % ROOT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True) for r in range(2)]
+    outs = []
+    for p in procs:
+        so, se = p.communicate(timeout=240)
+        assert p.returncode == 0, se[-2000:]
+        outs.append(eval(so.strip().splitlines()[-1].replace("true", "True").replace("false", "False")))
+    assert all(o["ok"] for o in outs)
+    assert sorted(outs[0]["mine"] + outs[1]["mine"]) == list(range(5))

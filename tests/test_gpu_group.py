@@ -87,3 +87,64 @@ def test_group_triplet_costs(ctx):
     want = np.array([og.triplet(*q) for q in zip(t, la, lb, lc)])
     assert np.allclose(got, want, rtol=RTOL, atol=ATOL)
     assert (want == 1e7).any()
+
+
+SHARDED_WORKER = '''
+import os, sys, json
+import numpy as np
+sys.path.insert(0, %r)
+import newmsm_amd as M
+from newmsm_amd import dist as D, synthetic
+
+rank, _, world = D.env()
+dist = D.init("gloo")          # two processes share the single GPU of the test box; on the 8-GPU node this is "nccl"
+ctx = M.Context(0)
+S, Dm = 4, 2
+dxyz, dtri = M.make_mesh_from_icosa(3)
+cxyz, ctri = M.make_mesh_from_icosa(1)
+_, mvd = M.cp_spacings(cxyz, ctri)
+samples, _ = M.label_sampling_grid(3, 0.5 * mvd)
+def make():
+    g = M.DiscreteGroupCostFunction(ctx, S, lambda_=0.2)
+    tm = M.Mesh(ctx, dxyz, dtri); g.set_template(tm); g.Initialize(cxyz, ctri); keep = [tm]
+    for s in range(S):   # every rank registers every subject (small); only the per-label resampling is sharded
+        m = M.Mesh(ctx, dxyz, dtri)
+        feat = synthetic.features(synthetic.known_warp(dxyz, seed=90 + s, rot_deg=2.0, amp=1.0), Dm, seed=5)
+        g.reset_meshspace(s, m, feat)
+        m.set_coords(synthetic.known_warp(dxyz, seed=40 + s, rot_deg=1.0 + s, amp=0.5)); g.reset_meshspace(s, m, feat)
+        g.reset_CPgrid(s, synthetic.known_warp(cxyz, seed=40 + s, rot_deg=1.0 + s, amp=0.5)); keep.append(m)
+    g.set_labels(samples)
+    return g, keep
+g, keep = make()
+mine = D.sharded_group_setup(g, S, dist)
+rng = np.random.default_rng(3)
+p = rng.integers(0, g.P, 300).astype(np.int32); la = rng.integers(0, g.L, 300).astype(np.int32); lb = rng.integers(0, g.L, 300).astype(np.int32)
+sharded = g.computePairwiseCost(p, la, lb)
+g1, keep1 = make(); g1.setupCostFunction()
+single = g1.computePairwiseCost(p, la, lb)
+tmpl = D.group_template_update(np.stack([keep[1 + s].get_coords() for s in mine]), None, dist)
+dist.barrier()
+print(json.dumps({"rank": rank, "mine": mine, "equal": bool(np.array_equal(sharded, single, equal_nan=True)), "finite": int(np.isfinite(single).sum()),
+                  "template_radius_ok": bool(np.allclose(np.linalg.norm(tmpl["template"], axis=1), 100.0)), "n": tmpl["n_subjects"]}))
+dist.destroy_process_group()
+'''
+
+
+def test_sharded_group_two_ranks_match_single_rank(tmp_path):
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "sharded.py"
+    script.write_text(SHARDED_WORKER % root)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29561", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True) for r in range(2)]
+    outs = []
+    for pr in procs:
+        so, se = pr.communicate(timeout=500)
+        assert pr.returncode == 0, se[-3000:]
+        outs.append(eval(so.strip().splitlines()[-1].replace("true", "True").replace("false", "False")))
+    assert all(o["equal"] and o["template_radius_ok"] and o["n"] == 4 and o["finite"] > 200 for o in outs), outs
+    assert sorted(outs[0]["mine"] + outs[1]["mine"]) == [0, 1, 2, 3]

@@ -169,3 +169,23 @@ def test_warp_roundtrip_property(ctx):
     rot = M.sphere_project_warp(x6, m4, x4 @ R.T)
     assert np.max(np.abs(rot - x6 @ R.T)) < 0.05  # piecewise-linear interpolation of a rotation, then re-projection
     assert np.allclose(np.linalg.norm(rot, axis=1), 100.0, atol=1e-10)
+
+
+def test_repeated_coordinate_updates_grow_and_shrink_the_tree(ctx):
+    # the octree's node / leaf-entry counts change with the geometry; every device buffer must follow
+    xyz, tri = M.make_mesh_from_icosa(3)
+    m = M.Mesh(ctx, xyz, tri)
+    q = queries(xyz, 2000, seed=12)
+    rng = np.random.default_rng(9)
+    sizes = set()
+    for k, scale in enumerate([0.0, 3.0, 0.2, 6.0, 0.0]):
+        w = xyz + rng.normal(scale=scale, size=xyz.shape)
+        w = w / np.linalg.norm(w, axis=1, keepdims=True) * 100.0
+        m.set_coords(w)
+        sizes.add(m.octree_stats()["nodes"])
+        _, t, vid, wt = m.query_triangles(q, check_status=False)
+        _, ot, ovid, ow = O.Octree(O.Mesh(w, tri)).barycentric_weights(q)
+        assert np.array_equal(t, ot)
+        ok = ot >= 0
+        assert np.array_equal(wt[ok], ow[ok])
+    assert len(sizes) > 1
