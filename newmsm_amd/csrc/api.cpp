@@ -88,6 +88,7 @@ DevTree dev_tree(const msm_mesh *m) {
     t.grid = m->d_grid;
     t.grid_depth = m->tree.grid_depth;
     t.mask = m->masks_valid ? m->d_mask : nullptr;
+    t.simple = m->tree.simple ? 1 : 0;
     t.nnodes = (int)m->tree.node.size();
     return t;
 }

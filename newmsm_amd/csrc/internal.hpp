@@ -39,6 +39,9 @@ struct alignas(128) TriRec {
     double d;
     int32_t id[3];
     int32_t tri;
+    // On a simple surface (FlatOctree::simple) a projection whose three same_side products all exceed `safe` lies so
+    // far inside this triangle that no other triangle can pass the reference's inside test; +inf disables the shortcut.
+    double safe;
 };
 static_assert(sizeof(TriRec) == 128, "TriRec must be 128 bytes");
 
@@ -59,6 +62,9 @@ struct FlatOctree {
     // halvings, so the cell of a point is found arithmetically and the descent starts there.
     std::vector<int32_t> grid;
     int grid_depth = 0;
+    // closed, consistently oriented, star-shaped about the origin, covering the sphere exactly once: every ray from
+    // the origin meets exactly one triangle (true for the icosphere targets; false for folded meshes)
+    bool simple = false;
     int64_t stats[5] = {0, 0, 0, 0, 0};
 };
 // builds the tree exactly as Octree::initialize_tree / add_triangle do (R/octree.cpp:42-141)
@@ -74,6 +80,7 @@ struct DevTree {
     const TriRec *rec;
     const int32_t *grid;
     int grid_depth;  // G = 1 << grid_depth cells per axis
+    int simple;  // see FlatOctree::simple
     const unsigned long long *mask;  // 64 per mask block (see FlatOctree::node), or nullptr before the masks are built
     int nnodes;
 };

@@ -14,6 +14,7 @@
 //   recs[]      128-byte record per triangle for the exact test
 #include <cmath>
 #include <deque>
+#include <unordered_map>
 
 #include "internal.hpp"
 
@@ -138,6 +139,73 @@ float4 bounding_cone(const V3 &a, const V3 &b, const V3 &c, const TriRec &r) {
     return make_float4((float)axis.x, (float)axis.y, (float)axis.z, (float)(std::cos(rho2) - 2e-6));
 }
 
+
+// True when every ray from the origin meets exactly one triangle: the mesh is a closed, consistently oriented
+// 2-manifold, every face is strictly front- (or every face strictly back-) facing seen from the origin, and the faces'
+// solid angles add up to one full sphere (degree of the radial projection = 1).
+bool simple_star_surface(const double *xyz, const int32_t *tri, int V, int T) {
+    if (T < 4) return false;
+    std::unordered_map<uint64_t, int> edge;  // directed edge -> count
+    edge.reserve((size_t)T * 3);
+    double solid = 0.0;
+    int sign = 0;
+    for (int t = 0; t < T; ++t) {
+        const int id[3] = {tri[t], tri[T + t], tri[2 * T + t]};
+        if (id[0] == id[1] || id[1] == id[2] || id[0] == id[2]) return false;
+        for (int k = 0; k < 3; ++k) {
+            const uint64_t key = ((uint64_t)(uint32_t)id[k] << 32) | (uint32_t)id[(k + 1) % 3];
+            if (++edge[key] > 1) return false;  // same directed edge twice: not consistently oriented / not manifold
+        }
+        const V3 a = vtx(xyz, V, id[0]), b = vtx(xyz, V, id[1]), c = vtx(xyz, V, id[2]);
+        const double la = norm(a), lb = norm(b), lc = norm(c);
+        const double triple = dot(a, cross(b, c));
+        if (!(la > 0 && lb > 0 && lc > 0) || !std::isfinite(triple)) return false;
+        const int s = triple > 1e-12 * la * lb * lc ? 1 : (triple < -1e-12 * la * lb * lc ? -1 : 0);
+        if (s == 0 || (sign != 0 && s != sign)) return false;  // a face seen edge-on or from behind
+        sign = s;
+        // Van Oosterom-Strackee solid angle of the face
+        const double den = la * lb * lc + dot(a, b) * lc + dot(a, c) * lb + dot(b, c) * la;
+        solid += 2.0 * std::atan2(std::fabs(triple), den);
+    }
+    for (const auto &e : edge) {  // every directed edge needs its opposite: closed surface
+        const uint64_t rev = (e.first << 32) | (e.first >> 32);
+        if (edge.find(rev) == edge.end()) return false;
+    }
+    const long E = (long)edge.size() / 2;
+    if ((long)V - E + (long)T != 2) return false;  // sphere topology (all vertices referenced is implied when this holds for a closed manifold)
+    return std::fabs(solid - 4.0 * M_PI) < 1e-6;
+}
+
+// TriRec::safe: a same_side product equals 2*area*|edge|*(in-plane distance to that edge).  Demanding a distance of
+// max(1e-5 * longest edge, 1000 * the widest -1e-8 acceptance band of this triangle and its neighbours) from every
+// edge puts the point out of reach of any neighbour's inside test by a wide margin.
+void safe_margins(const double *xyz, const int32_t *tri, int V, int T, std::vector<TriRec> &recs) {
+    std::vector<double> band(T), area(T), lmax(T);
+    std::unordered_map<uint64_t, int> owner;  // directed edge -> triangle
+    owner.reserve((size_t)T * 3);
+    for (int t = 0; t < T; ++t) {
+        const int id[3] = {tri[t], tri[T + t], tri[2 * T + t]};
+        const V3 a = vtx(xyz, V, id[0]), b = vtx(xyz, V, id[1]), c = vtx(xyz, V, id[2]);
+        const double la = norm(sub(b, c)), lb = norm(sub(a, c)), lc = norm(sub(a, b));
+        area[t] = 0.5 * norm(cross(sub(b, a), sub(c, a)));
+        lmax[t] = std::fmax(la, std::fmax(lb, lc));
+        const double lmin = std::fmin(la, std::fmin(lb, lc));
+        band[t] = (area[t] > 0 && lmin > 0) ? 1e-8 / (2 * area[t] * lmin) : HUGE_VAL;
+        for (int k = 0; k < 3; ++k) owner[((uint64_t)(uint32_t)id[k] << 32) | (uint32_t)id[(k + 1) % 3]] = t;
+    }
+    for (int t = 0; t < T; ++t) {
+        const int id[3] = {tri[t], tri[T + t], tri[2 * T + t]};
+        double widest = band[t];
+        for (int k = 0; k < 3; ++k) {
+            auto it = owner.find(((uint64_t)(uint32_t)id[(k + 1) % 3] << 32) | (uint32_t)id[k]);
+            widest = std::fmax(widest, it == owner.end() ? HUGE_VAL : band[it->second]);
+        }
+        const double dist = std::fmax(1e-5 * lmax[t], 1e3 * widest);
+        const double safe = 2 * area[t] * lmax[t] * dist;
+        recs[t].safe = (std::isfinite(safe) && dist < 0.05 * lmax[t]) ? safe : HUGE_VAL;
+    }
+}
+
 }  // namespace
 
 void build_octree(const double *xyz, const int32_t *tri, int V, int T, FlatOctree &out, std::vector<TriRec> &recs) {
@@ -169,8 +237,11 @@ void build_octree(const double *xyz, const int32_t *tri, int V, int T, FlatOctre
         r.s3[0] = s3.x, r.s3[1] = s3.y, r.s3[2] = s3.z;
         r.id[0] = tri[t], r.id[1] = tri[T + t], r.id[2] = tri[2 * T + t];
         r.tri = t;
+        r.safe = HUGE_VAL;
         tcone[t] = bounding_cone(v0, v1, v2, r);
     }
+    out.simple = simple_star_surface(xyz, tri, V, T);
+    if (out.simple) safe_margins(xyz, tri, V, T, recs);
 
     // Leaf entries are padded to multiples of 8 (id -1, a cone nothing passes): 8 cones = one 128-byte line.
     const int n = (int)b.nodes.size();

@@ -39,6 +39,19 @@ __device__ __forceinline__ bool inside_test(const TriRec &r, const V3 &p, V3 &mp
     return point_in_triangle(mp, rec_v0(r), rec_v1(r), rec_v2(r));
 }
 
+// Shortcut for simple surfaces: true when the projection of p lies inside the triangle with all three same_side
+// products above the triangle's `safe` threshold (octree.cpp: safe_margins), i.e. no other triangle of the mesh can
+// contain it.  A NaN anywhere makes the comparisons fail, which sends the sample to the complete path.
+__device__ __forceinline__ bool safely_inside(const TriRec &r, const V3 &p) {
+    const V3 v0 = rec_v0(r), v1 = rec_v1(r), v2 = rec_v2(r);
+    const V3 mp = project_with_plane(p, mk(r.s3[0], r.s3[1], r.s3[2]), r.d);
+    const V3 e0 = sub(v2, v1), e1 = sub(v0, v2), e2 = sub(v1, v0);
+    const double d0 = dot(cross(e0, sub(mp, v1)), cross(e0, sub(v0, v1)));
+    const double d1 = dot(cross(e1, sub(mp, v2)), cross(e1, sub(v1, v2)));
+    const double d2 = dot(cross(e2, sub(mp, v0)), cross(e2, sub(v2, v0)));
+    return d0 > r.safe && d1 > r.safe && d2 > r.safe;
+}
+
 __device__ __forceinline__ double candidate_distance(const DevTree &T, int t, const V3 &p) {
     const TriRec &r = T.rec[t];
     V3 mp;

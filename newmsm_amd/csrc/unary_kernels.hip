@@ -38,6 +38,8 @@ namespace {
 constexpr int kChunk = 768;       // samples per LDS pass (3 rounds of 256 lanes)
 constexpr int kQueueCap = 3072;   // (sample, triangle) pairs per pass
 constexpr int kDeferred = 1 << 20; // nin marker: leave this sample to the fix-up kernel
+constexpr int kDone = -2;          // nin marker: already emitted by the fast path
+constexpr unsigned kInvalidPair = 0xffffffffu;  // queue slot reserved by a sample that was deferred (sample ids stay below 1023)
 constexpr int kTriBits = 22;      // queue entry = sample << 22 | triangle
 
 __device__ __forceinline__ void raise_status(int *status, int code) { atomicMin(status, code); }
@@ -281,6 +283,8 @@ __global__ __launch_bounds__(256) void k_unary_samples(SamplesArgs a) {
                             const float4 *cone = a.tree.cone + leaf.y;
                             // entries a point of this sub-cell can hit at all; cone-test those, four loads in flight
                             unsigned long long mm = a.tree.mask[(size_t)leaf.z * 64 + sub];
+                            float bestdot = -1.f;
+                            int best = -1;
                             while (mm) {
                                 int e[4];
                                 bool v[4];
@@ -294,8 +298,27 @@ __global__ __launch_bounds__(256) void k_unary_samples(SamplesArgs a) {
 #pragma unroll
                                 for (int k = 0; k < 4; ++k) c[k] = cone[e[k]];
 #pragma unroll
-                                for (int k = 0; k < 4; ++k)
-                                    if (v[k] && cone_pass(c[k], fx, fy, fz)) pm |= 1ull << e[k];
+                                for (int k = 0; k < 4; ++k) {
+                                    const float dt = fabsf(__builtin_fmaf(c[k].z, fz, __builtin_fmaf(c[k].y, fy, c[k].x * fx)));
+                                    if (v[k] && dt >= c[k].w) {
+                                        pm |= 1ull << e[k];
+                                        if (dt > bestdot) {  // the cone axis is the triangle's centroid direction: nearest centroid
+                                            bestdot = dt;
+                                            best = e[k];
+                                        }
+                                    }
+                                }
+                            }
+                            // Fast path on simple surfaces: on a near-regular mesh the nearest centroid's triangle is the
+                            // containing one; if the projection is safely inside it, it is the reference's answer.
+                            if (a.tree.simple && best >= 0) {
+                                const int t = a.tree.leaf_tri[leaf.y + best];
+                                if (safely_inside(a.tree.rec[t], p)) {
+                                    const double val = emit_sample(a, gbase + s, p, t);
+                                    if (a.U) sT[l * a.pmax + i] = val;
+                                    nin[sl] = kDone;
+                                    pm = 0ull;
+                                }
                             }
                         }
                     }
@@ -314,7 +337,8 @@ __global__ __launch_bounds__(256) void k_unary_samples(SamplesArgs a) {
                 int pos = wbase + incl - cntp;
                 if (cntp > 0) {
                     if (pos + cntp > kQueueCap) {
-                        defer = true;
+                        defer = true;  // queue full: the fix-up kernel takes this sample; its reserved slots must not stay stale
+                        for (int j = pos; j < kQueueCap; ++j) queue[j] = kInvalidPair;
                     } else {
                         const int *lt = a.tree.leaf_tri + lbeg;
                         const unsigned tag = (unsigned)sl << kTriBits;
@@ -334,6 +358,7 @@ __global__ __launch_bounds__(256) void k_unary_samples(SamplesArgs a) {
             const int qn = min(s_qn, kQueueCap);
             for (int j = tid; j < qn; j += 256) {
                 const unsigned e = queue[j];
+                if (e == kInvalidPair) continue;
                 const int sl = (int)(e >> kTriBits), t = (int)(e & ((1u << kTriBits) - 1));
                 const int s = base + sl;
                 const int l = fast_div(s, P, invP), i = s - l * P;
@@ -357,6 +382,8 @@ __global__ __launch_bounds__(256) void k_unary_samples(SamplesArgs a) {
                     const V3 p = rotate(sR + 9 * l, mk(sx[i], sy[i], sz[i]));
                     const double v = emit_sample(a, gbase + s, p, win[sl]);
                     if (a.U) sT[l * a.pmax + i] = v;
+                } else if (n == kDone) {
+                    // emitted in phase A
                 } else if (n < 0) {
                     emit_failure(a, gbase + s, MSM_ERR_OUTSIDE);
                     atomicAdd(&s_ndefer, 1);

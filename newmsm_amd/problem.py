@@ -9,16 +9,23 @@ from . import api, synthetic
 
 
 def pairwise_inputs(data_order=6, cp_order=4, sg_order=None, D=1, seed=1234, warp_amp=0.6, warp_rot=2.0, rescale=True,
-                    labeldist=0.5):
+                    labeldist=0.5, target_noise=0.0, target_warp=0.0):
     """Inputs of one iteration: target / source / control grids, features, labels, rotations, cliques."""
     if sg_order is None:
         sg_order = cp_order + 2
-    txyz, ttri = api.make_mesh_from_icosa(data_order)  # reference sphere (regular)
+    txyz0, ttri = api.make_mesh_from_icosa(data_order)  # reference sphere (regular unless asked otherwise)
+    txyz = txyz0
+    if target_warp > 0:  # smooth deformation: irregular triangles, still a simple (fold-free) surface
+        txyz = synthetic.known_warp(txyz, seed=seed + 5, rot_deg=0.0, amp=target_warp)
+    if target_noise > 0:  # vertex jitter: slivers and folds -> several triangles can contain a projection
+        rng = np.random.default_rng(seed + 6)
+        txyz = txyz + rng.normal(scale=target_noise, size=txyz.shape)
+        txyz = txyz / np.linalg.norm(txyz, axis=1, keepdims=True) * synthetic.RAD
     cxyz, ctri = api.make_mesh_from_icosa(cp_order)    # control grid
     # source: the data sphere part-way through a registration (smoothly warped), features of the moving image
-    sxyz = synthetic.known_warp(txyz, seed=seed + 1, rot_deg=warp_rot, amp=warp_amp)
+    sxyz = synthetic.known_warp(txyz0, seed=seed + 1, rot_deg=warp_rot, amp=warp_amp)
     ref_feat = synthetic.features(txyz, D, seed)
-    src_feat = synthetic.features(synthetic.known_warp(txyz, seed=seed + 2, rot_deg=1.5 * warp_rot, amp=2 * warp_amp), D, seed)
+    src_feat = synthetic.features(synthetic.known_warp(txyz0, seed=seed + 2, rot_deg=1.5 * warp_rot, amp=2 * warp_amp), D, seed)
     # the control grid rides along with the source (warp_CPgrid): move it through the same warp
     cxyz_cur = synthetic.known_warp(cxyz, seed=seed + 1, rot_deg=warp_rot, amp=warp_amp)
     maxsep, mvdmax = api.cp_spacings(cxyz_cur, ctri)
@@ -29,7 +36,7 @@ def pairwise_inputs(data_order=6, cp_order=4, sg_order=None, D=1, seed=1234, war
         labels = samples
     rot = api.cp_rotations(samples[0], cxyz_cur)
     return dict(data_order=data_order, cp_order=cp_order, sg_order=sg_order, D=D,
-                target_xyz=txyz, target_tri=ttri, source_xyz=sxyz, source_tri=ttri, source_orig_xyz=txyz,
+                target_xyz=txyz, target_tri=ttri, source_xyz=sxyz, source_tri=ttri, source_orig_xyz=txyz0,
                 cp_xyz=cxyz_cur, cp_orig_xyz=cxyz, cp_tri=ctri, ref_feat=ref_feat, src_feat=src_feat,
                 maxsep=maxsep, mvdmax=mvdmax, samples=samples, barycentres=barycentres, labels=labels, rot=rot,
                 triplets=api.estimate_triplets(ctri), pairs=api.estimate_pairs(ctri, len(cxyz)))

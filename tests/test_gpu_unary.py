@@ -89,3 +89,15 @@ def test_full_size_properties_ico6(ctx):
     for n, l in zip(rng.integers(0, 2562, 40), rng.integers(0, 19, 40)):
         assert abs(U[l, n] - oc.unary(n, l)) <= ATOL + RTOL * abs(U[l, n])
     assert cf.counters()["samples"] == 2 * 19 * int(ptr[-1])
+
+
+@pytest.mark.parametrize("noise,warp", [(0.0, 2.0), (0.6, 0.0), (1.5, 0.0)])
+def test_unary_table_irregular_and_folded_targets(ctx, noise, warp):
+    # warp: smooth, fold-free but irregular target -> the nearest-centroid shortcut is legal but often misses;
+    # noise: jittered target with slivers / folds -> the shortcut must be disabled and the reference's tie-breaks decide
+    inp = problem.pairwise_inputs(5, 3, D=1, target_noise=noise, target_warp=warp)
+    cf, oc, _ = run_pair(ctx, inp, "univariate")
+    U = cf.computeUnaryCosts()
+    Uo = oc.unary_table()
+    assert np.isfinite(Uo).all()
+    assert np.allclose(U, Uo, rtol=RTOL, atol=ATOL), np.max(np.abs(U - Uo))
