@@ -29,6 +29,18 @@ def algorithmic_bytes(samples, evals, D):
     return samples * (116 + 32 * D) + evals * 80
 
 
+def pmc_traffic(args):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (separate --pmc runs,
+    (2 * FETCH_SIZE + WRITE_SIZE) * 1024 as MI355X_MICROARCH.md prescribes for gfx950).  Only valid for the default workload."""
+    if (args.data_order, args.cp_order, args.dims) != (6, 4, 1):
+        return None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r1_j_unary_samples_pmc.json")) as f:
+            return json.load(f)["hbm_traffic_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def cpu_baseline(inp, kind, threads):
     """The oracle (CPU restatement of the reference algorithm, OpenMP over control points like
     M/DiscreteCostFunction.cpp:238-242) on the same workload.  Checker / baseline only."""
@@ -36,11 +48,15 @@ def cpu_baseline(inp, kind, threads):
 
     oc = oracle_cost(inp, kind)
     oc.get_source_data()
-    oc.unary_table(threads=threads)  # warm caches
     t0 = time.perf_counter()
-    U = oc.unary_table(threads=threads)
+    U = oc.unary_table(threads=threads)  # also warms the caches
+    first = time.perf_counter() - t0
+    reps = max(1, min(200, int(12.0 / max(first, 1e-3))))  # about 12 s of CPU work
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        U = oc.unary_table(threads=threads)
     dt = time.perf_counter() - t0
-    return U, U.size / dt, dt
+    return U, reps * U.size / dt, dt, reps
 
 
 def main():
@@ -96,6 +112,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    cf.enable_timing(True)  # HIP events around the dominant kernel of every launch, on the launch stream
     with torch.cuda.stream(stream):
         for _ in range(args.warmup):
             cf.computeUnaryCosts_async()
@@ -110,7 +127,9 @@ def main():
         ctx.synchronize()
         sync_all()
         wall = time.perf_counter() - t0
-    kernel_ms = e0.elapsed_time(e1) / args.steps  # HIP events on the launch stream
+    step_ms = e0.elapsed_time(e1) / args.steps  # HIP events on the launch stream: whole step (all kernels of one table)
+    kt = cf.kernel_times()[-min(args.steps, 64):]
+    kernel_ms = float(np.mean(kt))  # k_unary_samples alone (the dominant kernel), last <= 64 launches of the timed region
     U = cf.getUnaryCosts()
     if not np.isfinite(U).all() and not os.environ.get("MSM_BENCH_NOCHECK"):
         raise SystemExit("non-finite unary costs")
@@ -147,18 +166,18 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None, "kernel": "k_unary_univariate" if args.dims == 1 else "k_unary_multivariate",
-                "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": abytes,
+                "traffic": pmc_traffic(args), "kernel": "msm::k_unary_samples",
+                "kernel_ms": kernel_ms, "step_ms_events": step_ms, "algorithmic_bytes_per_launch": abytes,
             },
         }
         if world == 1 and not args.no_cpu_baseline:
             from newmsm_amd.dist import host_cores
 
             threads = host_cores()  # cgroup / affinity aware: the GPU box gives one GPU's share of the host
-            Uo, rate, dt = cpu_baseline(inp, kind, threads)
+            Uo, rate, dt, reps = cpu_baseline(inp, kind, threads)
             out["cpu_baseline"] = {
                 "value": rate, "unit": "evals/s", "cores": threads, "kind": "port",
-                "sample": "1 full unary table (%d evals, %.2f s) of the same workload, OpenMP over control points" % (Uo.size, dt),
+                "sample": "%d full unary tables (%d evals each, %.1f s in total) of the same workload, OpenMP over control points" % (reps, Uo.size, dt),
                 "max_abs_diff_vs_gpu": float(np.max(np.abs(Uo - U))),
             }
         print(json.dumps(out))

@@ -208,6 +208,11 @@ int msm_cost_pairwise_batch(msm_cost *c, const int32_t *pair, const int32_t *la,
 int msm_cost_pairwise_table(msm_cost *c, double *paircosts);
 /* evaluateTotalCostSum :55-77: parts = {unary, pairwise, triplet} sums in the reference's serial order */
 int msm_cost_total(msm_cost *c, const int32_t *labeling, double *total, double parts[3]);
+/* Optional HIP-event timing of the dominant kernel (k_unary_samples) of each unary-table launch, recorded on the
+ * context's stream.  msm_cost_kernel_times returns the durations (ms) of the last launches (most recent last; at most
+ * 64 are kept) after synchronising the stream. */
+int msm_cost_enable_timing(msm_cost *c, int enable);
+int msm_cost_kernel_times(msm_cost *c, double *ms, int32_t cap, int32_t *n);
 /* counters since creation: [0] point samples (rotate + nearest triangle + interpolate), [1] unary evals,
  * [2] triplet evals, [3] pairwise evals */
 int msm_cost_counters(msm_cost *c, int64_t counters[4]);

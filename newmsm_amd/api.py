@@ -404,6 +404,15 @@ class DiscreteCostFunction:
         check(lib().msm_cost_total(self.h, pl, C.byref(tot), parts.ctypes.data_as(c_dp)))
         return tot.value, parts
 
+    def enable_timing(self, on=True):
+        check(lib().msm_cost_enable_timing(self.h, int(on)))
+
+    def kernel_times(self):
+        ms = np.zeros(64)
+        n = C.c_int32()
+        check(lib().msm_cost_kernel_times(self.h, ms.ctypes.data_as(c_dp), 64, C.byref(n)))
+        return ms[: n.value].copy()
+
     def counters(self):
         c = (C.c_int64 * 4)()
         check(lib().msm_cost_counters(self.h, c))

@@ -179,6 +179,12 @@ int ensure_unary_table(msm_cost *c) {
     u.fix_count = c->d_fix_count.p;
     u.fix_cap = (unsigned)std::min<size_t>(nsamp, 0xffffffffu);
     u.redo_list = c->d_queues.p;
+    if (c->timing) {
+        u.ev_start = c->ev0[c->ev_next];
+        u.ev_stop = c->ev1[c->ev_next];
+        c->ev_next = (c->ev_next + 1) % (int)c->ev0.size();
+        c->ev_count = std::min(c->ev_count + 1, (int)c->ev0.size());
+    }
     switch (c->p.kind) {
         case MSM_COST_UNIVARIATE: st = launch_unary_univariate(ctx, u); break;
         case MSM_COST_MULTIVARIATE:
@@ -230,6 +236,8 @@ void msm_cost_destroy(msm_cost *c) {
     if (!c) return;
     (void)hipSetDevice(c->ctx->device);
     (void)hipStreamSynchronize(c->ctx->stream);
+    for (hipEvent_t e : c->ev0) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->ev1) (void)hipEventDestroy(e);
     delete c;
 }
 
@@ -440,6 +448,36 @@ int msm_cost_unary_batch(msm_cost *c, const int32_t *nodes, const int32_t *label
         if (nodes[i] < 0 || nodes[i] >= N || labels[i] < 0 || labels[i] >= c->L) return fail(MSM_ERR_INVALID, "unary query %d out of range", i);
         out[i] = c->h_U[(size_t)labels[i] * N + nodes[i]];
     }
+    return MSM_OK;
+}
+
+int msm_cost_enable_timing(msm_cost *c, int enable) {
+    if (!c) return fail(MSM_ERR_INVALID, "null cost");
+    if (enable && c->ev0.empty()) {
+        c->ev0.resize(64);
+        c->ev1.resize(64);
+        for (size_t i = 0; i < c->ev0.size(); ++i) {
+            MSM_HIP(hipEventCreate(&c->ev0[i]));
+            MSM_HIP(hipEventCreate(&c->ev1[i]));
+        }
+    }
+    c->timing = enable != 0;
+    c->ev_next = 0;
+    c->ev_count = 0;
+    return MSM_OK;
+}
+
+int msm_cost_kernel_times(msm_cost *c, double *ms, int32_t cap, int32_t *n) {
+    if (!c || !ms || !n) return fail(MSM_ERR_INVALID, "msm_cost_kernel_times: null argument");
+    MSM_HIP(hipStreamSynchronize(c->ctx->stream));
+    const int total = (int)c->ev0.size(), cnt = std::min(c->ev_count, (int)cap);
+    for (int k = 0; k < cnt; ++k) {
+        const int slot = ((c->ev_next - cnt + k) % total + total) % total;
+        float f = 0.f;
+        MSM_HIP(hipEventElapsedTime(&f, c->ev0[slot], c->ev1[slot]));
+        ms[k] = f;
+    }
+    *n = cnt;
     return MSM_OK;
 }
 

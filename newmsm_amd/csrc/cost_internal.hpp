@@ -57,6 +57,10 @@ struct msm_cost {
     DevBuf<double> d_sw3;
     DevBuf<unsigned long long> d_fix_list;
     DevBuf<unsigned int> d_fix_count;
+    // optional event timing of the samples kernel
+    bool timing = false;
+    std::vector<hipEvent_t> ev0, ev1;
+    int ev_next = 0, ev_count = 0;
     DevBuf<int> d_queues;  // nodes whose reduction waits for the fix-up kernel
     DevBuf<int> d_counts;
 };

@@ -42,6 +42,7 @@ struct UnaryLaunch {
     unsigned int *fix_count;       // 2 words: [0] fix-up entries, [1] nodes to re-reduce
     unsigned int fix_cap;
     int *redo_list;                // N ints
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;  // optional: recorded around the samples kernel
 };
 int launch_unary_univariate(msm_ctx *ctx, const UnaryLaunch &u);
 // multivariate / patchwise: the samples kernel stores (triangle, raw weights) per sample, a second kernel reduces

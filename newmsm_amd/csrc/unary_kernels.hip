@@ -90,7 +90,7 @@ __device__ __forceinline__ int4 locate_leaf(const DevTree &T, const V3 &p, int &
     double lx, ly, lz, size;
     if (nd.x < 0) {  // a leaf at depth w <= grid_depth: its box is the depth-w cell above this grid cell
         const int up = T.grid_depth - nd.w;
-        size = 2 * kBounds / (double)(1 << nd.w);
+        size = ldexp(2 * kBounds, -nd.w);  // 202 / 2^w, exact
         lx = -kBounds + (ix >> up) * size;
         ly = -kBounds + (iy >> up) * size;
         lz = -kBounds + (iz >> up) * size;
@@ -634,8 +634,10 @@ static int launch_samples(msm_ctx *ctx, const UnaryLaunch &u, const UnaryWeights
     MSM_HIP(hipMemsetAsync(u.fix_count, 0, 2 * sizeof(unsigned), ctx->stream));  // fix-up and redo counters
     a.nsplit = std::max(1, std::min(4, (int)(((size_t)u.L * u.pmax + kChunk - 1) / kChunk)));
     const int blocks = a.nsplit * 8 * ((u.N + 7) / 8);
+    if (u.ev_start) MSM_HIP(hipEventRecord(u.ev_start, ctx->stream));
     hipLaunchKernelGGL(k_unary_samples, dim3(blocks), dim3(256), lds, ctx->stream, a);
     MSM_HIP(hipGetLastError());
+    if (u.ev_stop) MSM_HIP(hipEventRecord(u.ev_stop, ctx->stream));
     hipLaunchKernelGGL(k_unary_fixup, dim3(64), dim3(256), 0, ctx->stream, a);
     MSM_HIP(hipGetLastError());
     return MSM_OK;
