@@ -76,16 +76,22 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    # rehearsal of the N > 1 path on a one-GPU box: all ranks share cuda:0 and talk over gloo
+    rehearse = os.environ.get("MSM_BENCH_REHEARSAL") == "1"
+    device_index = 0 if rehearse else local_rank
+    torch.cuda.set_device(device_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))  # nccl = RCCL over xGMI
+    reduce_device = "cpu" if rehearse else "cuda"
 
     import __graft_entry__ as g
 
@@ -98,7 +104,7 @@ def main():
 
     kind = "univariate" if args.dims == 1 else "multivariate"
     stream = torch.cuda.Stream()
-    ctx = M.Context(local_rank, stream=stream.cuda_stream)
+    ctx = M.Context(device_index, stream=stream.cuda_stream)
     # one synthetic subject per rank (different warp / feature phase)
     inp = problem.pairwise_inputs(args.data_order, args.cp_order, D=args.dims, seed=1234 + 17 * rank)
     cf, keep = problem.build_cost(ctx, inp, kind=kind)
@@ -135,10 +141,10 @@ def main():
         raise SystemExit("non-finite unary costs")
 
     if dist is not None:
-        t = torch.tensor([wall], device="cuda", dtype=torch.float64)
+        t = torch.tensor([wall], device=reduce_device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
-        k = torch.tensor([kernel_ms], device="cuda", dtype=torch.float64)
+        k = torch.tensor([kernel_ms], device=reduce_device, dtype=torch.float64)
         dist.all_reduce(k, op=dist.ReduceOp.MAX)
         kernel_ms = float(k.item())
 
