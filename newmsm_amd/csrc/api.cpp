@@ -56,6 +56,7 @@ int ensure_tree(msm_mesh *m) {
     MSM_HIP(hipMemcpyAsync(m->d_grid, m->tree.grid.data(), m->tree.grid.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
     MSM_HIP(hipMemcpyAsync(m->d_nodebox, m->tree.nodebox.data(), m->tree.nodebox.size() * sizeof(double4), hipMemcpyHostToDevice, ctx->stream));
     m->masks_valid = false;
+    m->rays_valid = false;
     MSM_HIP(hipStreamSynchronize(ctx->stream));
     m->tree_valid = true;
     return MSM_OK;
@@ -78,6 +79,30 @@ int ensure_masks(msm_mesh *m) {
     return MSM_OK;
 }
 
+int ensure_rays(msm_mesh *m) {
+    int st = ensure_masks(m);  // what the ray table cannot settle goes through the masked search
+    if (st) return st;
+    if (m->rays_valid) return MSM_OK;
+    msm_ctx *ctx = m->ctx;
+    build_ray_table(m->xyz.data(), m->tri.data(), m->V, m->T, m->tree);
+    if (m->tree.ray_G > 0) {
+        auto grow = [&](void **p, size_t &cap, size_t need, size_t elem) -> hipError_t {
+            if (need <= cap && *p) return hipSuccess;
+            if (*p) (void)hipFree(*p);
+            *p = nullptr;
+            cap = need + need / 4 + 16;
+            return hipMalloc(p, cap * elem);
+        };
+        MSM_HIP(grow((void **)&m->d_ray_cell, m->cap_ray_cell, m->tree.ray_cell.size(), sizeof(int4)));
+        MSM_HIP(grow((void **)&m->d_ray_edge, m->cap_ray_edge, m->tree.ray_edge.size(), sizeof(float4)));
+        MSM_HIP(hipMemcpyAsync(m->d_ray_cell, m->tree.ray_cell.data(), m->tree.ray_cell.size() * sizeof(int4), hipMemcpyHostToDevice, ctx->stream));
+        MSM_HIP(hipMemcpyAsync(m->d_ray_edge, m->tree.ray_edge.data(), m->tree.ray_edge.size() * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
+        MSM_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    m->rays_valid = true;
+    return MSM_OK;
+}
+
 DevTree dev_tree(const msm_mesh *m) {
     DevTree t;
     t.node = m->d_node;
@@ -90,6 +115,11 @@ DevTree dev_tree(const msm_mesh *m) {
     t.mask = m->masks_valid ? m->d_mask : nullptr;
     t.simple = m->tree.simple ? 1 : 0;
     t.nnodes = (int)m->tree.node.size();
+    t.ray_G = m->rays_valid ? m->tree.ray_G : 0;
+    t.ray_cell = m->d_ray_cell;
+    t.ray_edge = m->d_ray_edge;
+    t.ray_r2lo = m->tree.ray_r2lo;
+    t.ray_r2hi = m->tree.ray_r2hi;
     return t;
 }
 
@@ -329,7 +359,7 @@ void msm_mesh_destroy(msm_mesh *m) {
     if (!m) return;
     (void)hipSetDevice(m->ctx->device);
     (void)hipStreamSynchronize(m->ctx->stream);
-    for (void *p : {(void *)m->d_xyz, (void *)m->d_feat, (void *)m->d_node, (void *)m->d_parent, (void *)m->d_leaf_tri, (void *)m->d_cone, (void *)m->d_rec, (void *)m->d_grid, (void *)m->d_nodebox, (void *)m->d_mask})
+    for (void *p : {(void *)m->d_xyz, (void *)m->d_feat, (void *)m->d_node, (void *)m->d_parent, (void *)m->d_leaf_tri, (void *)m->d_cone, (void *)m->d_rec, (void *)m->d_grid, (void *)m->d_nodebox, (void *)m->d_mask, (void *)m->d_ray_cell, (void *)m->d_ray_edge})
         if (p) (void)hipFree(p);
     delete m;
 }

@@ -143,7 +143,7 @@ int ensure_unary_table(msm_cost *c) {
         c->table_valid = true;
         return MSM_OK;
     }
-    st = ensure_masks(c->target);
+    st = ensure_rays(c->target);
     if (st) return st;
     UnaryLaunch u;
     u.tree = dev_tree(c->target);
@@ -163,21 +163,28 @@ int ensure_unary_table(msm_cost *c) {
     u.cfw_rows = c->cfw_rows;
     u.pptr = c->d_pptr.p;
     u.pidx = c->d_pidx.p;
+    u.order = c->d_order.p;
     u.absw = c->d_absw.p;
     u.pmax = c->pmax;
     u.simmeasure = c->p.simmeasure;
     u.U = c->d_U.p;
-    u.nsamples = c->d_counters.p;
     const size_t nsamp = (size_t)c->L * c->pidx.size();
     MSM_HIP(c->d_tval.ensure(nsamp));
     MSM_HIP(c->d_fix_list.ensure(nsamp));
-    MSM_HIP(c->d_fix_count.ensure(2));
+    MSM_HIP(c->d_fix_count.ensure(unary_fix_counter_words()));
+    if (!c->fix_off_valid) {
+        std::vector<uint32_t> off;
+        unary_fix_offsets(N, c->L, c->pmax, c->pptr.data(), c->order.data(), off);
+        MSM_HIP(c->d_fix_off.upload(off.data(), off.size(), ctx->stream));
+        MSM_HIP(hipStreamSynchronize(ctx->stream));
+        c->fix_off_valid = true;
+    }
     MSM_HIP(c->d_queues.ensure(N));
     u.ntri = c->target->T;
     u.tval = c->d_tval.p;
     u.fix_list = c->d_fix_list.p;
-    u.fix_count = c->d_fix_count.p;
-    u.fix_cap = (unsigned)std::min<size_t>(nsamp, 0xffffffffu);
+    u.fix_cnt = c->d_fix_count.p;
+    u.fix_off = c->d_fix_off.p;
     u.redo_list = c->d_queues.p;
     if (c->timing) {
         u.ev_start = c->ev0[c->ev_next];
@@ -198,6 +205,7 @@ int ensure_unary_table(msm_cost *c) {
         default: return fail(MSM_ERR_INVALID, "unknown cost kind %d", c->p.kind);
     }
     if (st) return st;
+    c->counters[0] += (int64_t)nsamp;
     c->counters[1] += (int64_t)c->L * N;
     c->table_valid = true;
     return MSM_OK;
@@ -332,6 +340,7 @@ int msm_cost_set_labels(msm_cost *c, const double *labels, int32_t L, const doub
     if (st) return st;
     MSM_HIP(hipStreamSynchronize(c->ctx->stream));
     c->L = L;
+    c->fix_off_valid = false;
     c->labels.assign(labels, labels + 3 * (size_t)L);
     c->rot.assign(rot, rot + 9 * (size_t)c->cpgrid->V);
     MSM_HIP(c->d_labels.upload(c->labels.data(), c->labels.size(), c->ctx->stream));
@@ -384,6 +393,35 @@ int msm_cost_get_source_data(msm_cost *c) {
     MSM_HIP(c->d_pptr.upload(c->pptr.data(), c->pptr.size(), ctx->stream));
     MSM_HIP(c->d_pidx.upload(c->pidx.data(), std::max<size_t>(c->pidx.size(), 1), ctx->stream));
     MSM_HIP(c->d_absw.upload(c->absw.data(), c->absw.size(), ctx->stream));
+    {
+        // Launch order of the control points in the unary kernels: Morton order of their positions, so that the
+        // contiguous share of each XCD (kernels map blockIdx % 8 to a range of this list) is one region of the sphere
+        // and that XCD's L2 only has to hold the matching part of the target.
+        const int N = c->cpgrid->V;
+        const double *cp = c->cpgrid->xyz.data();
+        auto spread = [](uint32_t v) {  // 10 bits -> every third bit
+            v &= 0x3ff;
+            v = (v | (v << 16)) & 0x030000ff;
+            v = (v | (v << 8)) & 0x0300f00f;
+            v = (v | (v << 4)) & 0x030c30c3;
+            v = (v | (v << 2)) & 0x09249249;
+            return v;
+        };
+        std::vector<std::pair<uint32_t, int32_t>> key(N);
+        for (int i = 0; i < N; ++i) {
+            uint32_t q[3];
+            for (int a = 0; a < 3; ++a) {
+                const double u = (cp[(size_t)a * N + i] + kBounds) / (2 * kBounds);
+                q[a] = (uint32_t)std::max(0.0, std::min(1023.0, u == u ? u * 1024.0 : 0.0));
+            }
+            key[i] = {spread(q[0]) << 2 | spread(q[1]) << 1 | spread(q[2]), i};
+        }
+        std::sort(key.begin(), key.end());
+        c->order.resize(N);
+        for (int i = 0; i < N; ++i) c->order[i] = key[i].second;
+        MSM_HIP(c->d_order.upload(c->order.data(), c->order.size(), ctx->stream));
+        c->fix_off_valid = false;
+    }
     MSM_HIP(hipStreamSynchronize(ctx->stream));
     c->have_source = true;
     invalidate_table(c);
@@ -483,10 +521,7 @@ int msm_cost_kernel_times(msm_cost *c, double *ms, int32_t cap, int32_t *n) {
 
 int msm_cost_counters(msm_cost *c, int64_t counters[4]) {
     if (!c || !counters) return fail(MSM_ERR_INVALID, "msm_cost_counters: null argument");
-    unsigned long long dev[4];
-    MSM_HIP(c->d_counters.download(dev, 4, c->ctx->stream));
-    MSM_HIP(hipStreamSynchronize(c->ctx->stream));
-    counters[0] = (int64_t)dev[0];
+    counters[0] = c->counters[0];  // point samples (counted on the host: L x patch points per table)
     counters[1] = c->counters[1];
     counters[2] = c->counters[2];
     counters[3] = c->counters[3];

@@ -40,6 +40,10 @@ struct msm_cost {
     int ngroups = 0, pmax = 0;
     std::vector<int32_t> pptr, pidx;
     DevBuf<int32_t> d_pptr, d_pidx;
+    std::vector<int32_t> order;
+    DevBuf<int32_t> d_order;  // launch order of the groups (see msm_cost_get_source_data)
+    DevBuf<uint32_t> d_fix_off;  // segment offsets of the fix-up list for (patches, L)
+    bool fix_off_valid = false;
     std::vector<double> absw;
     DevBuf<double> d_absw;
     // unary table

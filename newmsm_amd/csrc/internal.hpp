@@ -39,9 +39,7 @@ struct alignas(128) TriRec {
     double d;
     int32_t id[3];
     int32_t tri;
-    // On a simple surface (FlatOctree::simple) a projection whose three same_side products all exceed `safe` lies so
-    // far inside this triangle that no other triangle can pass the reference's inside test; +inf disables the shortcut.
-    double safe;
+    double reserved;
 };
 static_assert(sizeof(TriRec) == 128, "TriRec must be 128 bytes");
 
@@ -65,11 +63,18 @@ struct FlatOctree {
     // closed, consistently oriented, star-shaped about the origin, covering the sphere exactly once: every ray from
     // the origin meets exactly one triangle (true for the icosphere targets; false for folded meshes)
     bool simple = false;
+    // Ray table of a simple surface (octree.cpp: build_ray_table); ray_G == 0 when absent.
+    int ray_G = 0;                   // cube-map cells per face axis
+    std::vector<int4> ray_cell;      // 6 x G x G: up to four candidate triangles per direction cell, -1 padded
+    std::vector<float4> ray_edge;    // 3 per triangle: inward unit normal of the plane (origin, edge k), acceptance threshold
+    double ray_r2lo = 0, ray_r2hi = 0;  // squared radius range of the query points the table is valid for
     int64_t stats[5] = {0, 0, 0, 0, 0};
 };
 // builds the tree exactly as Octree::initialize_tree / add_triangle do (R/octree.cpp:42-141)
 void build_octree(const double *xyz /*3 x V SoA*/, const int32_t *tri /*3 x T SoA*/, int V, int T, FlatOctree &out,
                   std::vector<TriRec> &recs);
+// decides FlatOctree::simple and, for a simple surface, fills the ray table of an already built tree
+void build_ray_table(const double *xyz, const int32_t *tri, int V, int T, FlatOctree &tree);
 
 // device view of a mesh's search structure
 struct DevTree {
@@ -83,6 +88,11 @@ struct DevTree {
     int simple;  // see FlatOctree::simple
     const unsigned long long *mask;  // 64 per mask block (see FlatOctree::node), or nullptr before the masks are built
     int nnodes;
+    // ray table (FlatOctree::ray_*); ray_G == 0: none
+    int ray_G;
+    const int4 *ray_cell;
+    const float4 *ray_edge;
+    double ray_r2lo, ray_r2hi;
 };
 
 }  // namespace msm
@@ -111,11 +121,15 @@ struct msm_mesh {
     double4 *d_nodebox = nullptr;
     unsigned long long *d_mask = nullptr;
     bool masks_valid = false;
+    bool rays_valid = false;
     int32_t *d_parent = nullptr;
     int32_t *d_leaf_tri = nullptr;
     float4 *d_cone = nullptr;
     msm::TriRec *d_rec = nullptr;
     int32_t *d_grid = nullptr;
+    int4 *d_ray_cell = nullptr;
+    float4 *d_ray_edge = nullptr;
+    size_t cap_ray_cell = 0, cap_ray_edge = 0;
     size_t cap_node = 0, cap_parent = 0, cap_box = 0, cap_leaf = 0, cap_cone = 0, cap_rec = 0, cap_grid = 0, cap_mask = 0;  // one per buffer
     msm::Adjacency adj;
     bool adj_valid = false;
@@ -124,6 +138,7 @@ struct msm_mesh {
 namespace msm {
 int ensure_tree(msm_mesh *m);  // build + upload the search structure if stale
 int ensure_masks(msm_mesh *m);  // + the per-leaf sub-cell masks the cost kernels use (built on the GPU)
+int ensure_rays(msm_mesh *m);   // + the ray table of a simple surface (unary table kernels)
 DevTree dev_tree(const msm_mesh *m);
 int check_status(msm_ctx *ctx, const char *what);  // sync + read kernel status
 }  // namespace msm

@@ -30,20 +30,24 @@ struct UnaryLaunch {
     const double *cfw;     // rows x Nsrc or nullptr
     int cfw_rows;
     const int *pptr, *pidx;
+    const int *order;      // launch order of the control points (a permutation of 0..N-1)
     const double *absw;
     int pmax;
     int simmeasure;
     double *U;             // L x N
-    unsigned long long *nsamples;
     // scratch owned by the cost object
     int ntri;                      // triangles in the target mesh
     double *tval;                  // one double per point sample (L * total patch points)
-    unsigned long long *fix_list;  // capacity fix_cap
-    unsigned int *fix_count;       // 2 words: [0] fix-up entries, [1] nodes to re-reduce
-    unsigned int fix_cap;
+    unsigned long long *fix_list;  // one slot per point sample
+    unsigned int *fix_cnt;         // unary_fix_counter_words() words (zeroed by the launch)
+    const unsigned int *fix_off;   // unary_fix_segments() + 1 offsets from unary_fix_offsets()
     int *redo_list;                // N ints
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;  // optional: recorded around the samples kernel
 };
+int unary_nsplit(int L, int pmax);
+int unary_fix_segments();
+size_t unary_fix_counter_words();
+void unary_fix_offsets(int N, int L, int pmax, const int32_t *pptr, const int32_t *order, std::vector<uint32_t> &off);
 int launch_unary_univariate(msm_ctx *ctx, const UnaryLaunch &u);
 // multivariate / patchwise: the samples kernel stores (triangle, raw weights) per sample, a second kernel reduces
 struct UnaryWeightsScratch {

@@ -12,7 +12,13 @@
 //   mask[]      per leaf 64 x 64-bit: which entries a query inside each of the leaf's 4x4x4 sub-cells can hit
 //               (filled on the GPU, kernels.hip k_build_masks)
 //   recs[]      128-byte record per triangle for the exact test
+//   ray table   (simple surfaces only) cube-map of directions -> candidate triangles, plus three float edge planes
+//               per triangle: decides most queries without touching the tree, with the reference's result
+#include <algorithm>
 #include <cmath>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <deque>
 #include <unordered_map>
 
@@ -145,17 +151,14 @@ float4 bounding_cone(const V3 &a, const V3 &b, const V3 &c, const TriRec &r) {
 // solid angles add up to one full sphere (degree of the radial projection = 1).
 bool simple_star_surface(const double *xyz, const int32_t *tri, int V, int T) {
     if (T < 4) return false;
-    std::unordered_map<uint64_t, int> edge;  // directed edge -> count
+    std::vector<uint64_t> edge;  // directed edges
     edge.reserve((size_t)T * 3);
     double solid = 0.0;
     int sign = 0;
     for (int t = 0; t < T; ++t) {
         const int id[3] = {tri[t], tri[T + t], tri[2 * T + t]};
         if (id[0] == id[1] || id[1] == id[2] || id[0] == id[2]) return false;
-        for (int k = 0; k < 3; ++k) {
-            const uint64_t key = ((uint64_t)(uint32_t)id[k] << 32) | (uint32_t)id[(k + 1) % 3];
-            if (++edge[key] > 1) return false;  // same directed edge twice: not consistently oriented / not manifold
-        }
+        for (int k = 0; k < 3; ++k) edge.push_back(((uint64_t)(uint32_t)id[k] << 32) | (uint32_t)id[(k + 1) % 3]);
         const V3 a = vtx(xyz, V, id[0]), b = vtx(xyz, V, id[1]), c = vtx(xyz, V, id[2]);
         const double la = norm(a), lb = norm(b), lc = norm(c);
         const double triple = dot(a, cross(b, c));
@@ -167,46 +170,229 @@ bool simple_star_surface(const double *xyz, const int32_t *tri, int V, int T) {
         const double den = la * lb * lc + dot(a, b) * lc + dot(a, c) * lb + dot(b, c) * la;
         solid += 2.0 * std::atan2(std::fabs(triple), den);
     }
-    for (const auto &e : edge) {  // every directed edge needs its opposite: closed surface
-        const uint64_t rev = (e.first << 32) | (e.first >> 32);
-        if (edge.find(rev) == edge.end()) return false;
-    }
+    std::sort(edge.begin(), edge.end());
+    for (size_t i = 1; i < edge.size(); ++i)
+        if (edge[i] == edge[i - 1]) return false;  // same directed edge twice: not consistently oriented / not manifold
+    for (const uint64_t e : edge)  // every directed edge needs its opposite: closed surface
+        if (!std::binary_search(edge.begin(), edge.end(), (e << 32) | (e >> 32))) return false;
     const long E = (long)edge.size() / 2;
     if ((long)V - E + (long)T != 2) return false;  // sphere topology (all vertices referenced is implied when this holds for a closed manifold)
     return std::fabs(solid - 4.0 * M_PI) < 1e-6;
 }
 
-// TriRec::safe: a same_side product equals 2*area*|edge|*(in-plane distance to that edge).  Demanding a distance of
-// max(1e-5 * longest edge, 1000 * the widest -1e-8 acceptance band of this triangle and its neighbours) from every
-// edge puts the point out of reach of any neighbour's inside test by a wide margin.
-void safe_margins(const double *xyz, const int32_t *tri, int V, int T, std::vector<TriRec> &recs) {
-    std::vector<double> band(T), area(T), lmax(T);
-    std::unordered_map<uint64_t, int> owner;  // directed edge -> triangle
-    owner.reserve((size_t)T * 3);
+// Per triangle: the in-plane distance from every edge of the triangle beyond which no OTHER triangle of a simple
+// surface can pass the reference's inside test.  A same_side product equals 2*area*|edge|*(in-plane distance to that
+// edge), so a triangle accepts points up to band = 1e-8 / (2*area*shortest edge) outside its edges; the margin is
+// max(1e-5 * longest edge, 1000 * the widest band among all triangles sharing a vertex with this one).
+std::vector<double> safe_margins(const double *xyz, const int32_t *tri, int V, int T) {
+    std::vector<double> band(T), lmax(T), vband(V, 0.0), margin(T);
     for (int t = 0; t < T; ++t) {
         const int id[3] = {tri[t], tri[T + t], tri[2 * T + t]};
         const V3 a = vtx(xyz, V, id[0]), b = vtx(xyz, V, id[1]), c = vtx(xyz, V, id[2]);
         const double la = norm(sub(b, c)), lb = norm(sub(a, c)), lc = norm(sub(a, b));
-        area[t] = 0.5 * norm(cross(sub(b, a), sub(c, a)));
+        const double area = 0.5 * norm(cross(sub(b, a), sub(c, a)));
         lmax[t] = std::fmax(la, std::fmax(lb, lc));
         const double lmin = std::fmin(la, std::fmin(lb, lc));
-        band[t] = (area[t] > 0 && lmin > 0) ? 1e-8 / (2 * area[t] * lmin) : HUGE_VAL;
-        for (int k = 0; k < 3; ++k) owner[((uint64_t)(uint32_t)id[k] << 32) | (uint32_t)id[(k + 1) % 3]] = t;
+        band[t] = (area > 0 && lmin > 0) ? 1e-8 / (2 * area * lmin) : HUGE_VAL;
+        if (!(band[t] == band[t])) band[t] = HUGE_VAL;
+        for (int k = 0; k < 3; ++k) vband[id[k]] = std::fmax(vband[id[k]], band[t]);
     }
     for (int t = 0; t < T; ++t) {
-        const int id[3] = {tri[t], tri[T + t], tri[2 * T + t]};
-        double widest = band[t];
-        for (int k = 0; k < 3; ++k) {
-            auto it = owner.find(((uint64_t)(uint32_t)id[(k + 1) % 3] << 32) | (uint32_t)id[k]);
-            widest = std::fmax(widest, it == owner.end() ? HUGE_VAL : band[it->second]);
-        }
+        const double widest = std::fmax(vband[tri[t]], std::fmax(vband[tri[T + t]], vband[tri[2 * T + t]]));
         const double dist = std::fmax(1e-5 * lmax[t], 1e3 * widest);
-        const double safe = 2 * area[t] * lmax[t] * dist;
-        recs[t].safe = (std::isfinite(safe) && dist < 0.05 * lmax[t]) ? safe : HUGE_VAL;
+        margin[t] = (std::isfinite(dist) && dist < 0.05 * lmax[t]) ? dist : HUGE_VAL;
     }
+    return margin;
 }
 
+// Is triangle t listed in every leaf whose closed box meets [lo, hi]?
+bool region_covered(const FlatOctree &o, int n, const double lo[3], const double hi[3], int t) {
+    const double4 box = o.nodebox[n];
+    const double blo[3] = {box.x, box.y, box.z};
+    for (int a = 0; a < 3; ++a)
+        if (hi[a] < blo[a] || lo[a] > blo[a] + box.w) return true;
+    const int4 nd = o.node[n];
+    if (nd.x < 0) {
+        const int32_t *first = o.leaf_tri.data() + nd.y, *last = first + (-nd.x - 1);
+        return std::find(first, last, t) != last;
+    }
+    for (int c = 0; c < 8; ++c)
+        if (!region_covered(o, nd.x + c, lo, hi, t)) return false;
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Ray table (simple surfaces).  On such a surface exactly one triangle t meets the ray through a query p, and
+// Octree::get_closest_triangle (R/octree.cpp:156-214) returns t provided that
+//   (1) t is listed in the leaf p descends to, and
+//   (2) no other listed triangle passes the -1e-8 inside test,
+// because a single passing triangle wins whatever its dist_to_point.  Both are settled per triangle here:
+//   edge planes  the inward unit normals n_k of the planes through the origin and edge k.  The in-plane distance of
+//                the projected point from edge k is at least |projection| * (p^ . n_k) >= rho * (p^ . n_k), rho = distance
+//                of the triangle's plane from the origin, so  p^ . n_k >= margin / rho  for k = 0,1,2  implies (2);
+//                the stored threshold adds 3e-6 for the float evaluation (direction 2e-7, normals 6e-8, dot 2e-7);
+//   robustness   every point of the shell kRayShell around radius 100 whose direction lies in t's spherical triangle
+//                is within `sag` of the flat triangle scaled to that radius; if every leaf meeting the AABB of that
+//                region lists t, (1) holds for every such p.  Triangles that fail get a threshold nothing passes.
+// The cube-map cells only propose candidates (up to four, likeliest first); a miss just means the complete search.
+// ------------------------------------------------------------------------------------------------
+constexpr double kRayShell = 1e-4;
+
+#define TICK(name) do { if (std::getenv("MSMHIP_TIMING")) { auto now_ = std::chrono::steady_clock::now(); fprintf(stderr, "  %s %.1f ms\n", name, std::chrono::duration<double, std::milli>(now_ - tick_).count()); tick_ = now_; } } while (0)
 }  // namespace
+
+void build_ray_table(const double *xyz, const int32_t *tri, int V, int T, FlatOctree &out) {
+    auto tick_ = std::chrono::steady_clock::now();
+    out.ray_G = 0;
+    out.ray_cell.clear();
+    out.ray_edge.clear();
+    out.simple = simple_star_surface(xyz, tri, V, T);
+    const char *no_table = std::getenv("MSMHIP_DISABLE_RAYTABLE");  // testing: force the complete search everywhere
+    if (!out.simple || (no_table && no_table[0] == '1')) return;
+    TICK("simple");
+    const std::vector<double> margin = safe_margins(xyz, tri, V, T);
+    TICK("margins");
+    out.ray_edge.assign((size_t)3 * T, make_float4(0.f, 0.f, 0.f, 2.f));
+    out.ray_r2lo = (kRad - kRayShell) * (kRad - kRayShell);
+    out.ray_r2hi = (kRad + kRayShell) * (kRad + kRayShell);
+    std::vector<char> usable(T, 0);
+    for (int t = 0; t < T; ++t) {
+        const V3 v[3] = {vtx(xyz, V, tri[t]), vtx(xyz, V, tri[T + t]), vtx(xyz, V, tri[2 * T + t])};
+        V3 s3;
+        double pd;
+        plane_of(v[0], v[1], v[2], s3, pd);
+        const double rho = std::fabs(pd);  // distance of the triangle's plane from the origin
+        if (!(margin[t] < HUGE_VAL) || !(rho > 0)) continue;
+        const double thr = margin[t] / rho * (1 + 1e-6) + 3e-6;
+        if (!(thr < 0.1)) continue;
+        // (1): the shell region above the triangle
+        V3 u[3];
+        double cosmax = 1.0;
+        bool ok = true;
+        for (int k = 0; k < 3; ++k) {
+            const double n = norm(v[k]);
+            ok = ok && n > 0;
+            u[k] = scale(v[k], 1.0 / n);
+        }
+        if (!ok) continue;
+        for (int k = 0; k < 3; ++k) cosmax = std::fmin(cosmax, dot(u[k], u[(k + 1) % 3]));
+        if (!(cosmax > 0.5)) continue;
+        const double rlo = kRad - kRayShell, rhi = kRad + kRayShell;
+        const double sag = rhi * (1 - std::sqrt(cosmax)) * (1 + 1e-9) + 1e-9;
+        double lo[3] = {HUGE_VAL, HUGE_VAL, HUGE_VAL}, hi[3] = {-HUGE_VAL, -HUGE_VAL, -HUGE_VAL};
+        for (int k = 0; k < 3; ++k) {
+            const double c[3] = {u[k].x, u[k].y, u[k].z};
+            for (int a = 0; a < 3; ++a) {
+                lo[a] = std::fmin(lo[a], std::fmin(rlo * c[a], rhi * c[a]));
+                hi[a] = std::fmax(hi[a], std::fmax(rlo * c[a], rhi * c[a]));
+            }
+        }
+        for (int a = 0; a < 3; ++a) {
+            lo[a] -= sag;
+            hi[a] += sag;
+        }
+        if (!region_covered(out, 0, lo, hi, t)) continue;
+        // (2): edge planes; edge k is opposite vertex k (same_side(p, v_k, v_k+1, v_k+2), R/point.cpp:41-44)
+        float4 e[3];
+        for (int k = 0; k < 3 && ok; ++k) {
+            V3 n = cross(v[(k + 1) % 3], v[(k + 2) % 3]);
+            const double nn = norm(n);
+            if (!(nn > 0) || !std::isfinite(nn)) {
+                ok = false;
+                break;
+            }
+            n = scale(n, 1.0 / nn);
+            if (dot(n, v[k]) < 0) n = scale(n, -1.0);
+            e[k] = make_float4((float)n.x, (float)n.y, (float)n.z, (float)thr);
+            if (!((double)e[k].w >= thr)) e[k].w = std::nextafterf(e[k].w, 1.f);  // round the threshold up
+        }
+        if (!ok) continue;
+        for (int k = 0; k < 3; ++k) out.ray_edge[(size_t)3 * t + k] = e[k];
+        usable[t] = 1;
+    }
+
+    TICK("edges+robust");
+    // cube map: face f = 2*axis + (negative side); (u, v) = the two other components over |major component|
+    int G = 8;
+    while (G < 512 && (double)G * G * 6 < 4.0 * T) G *= 2;
+    out.ray_G = G;
+    const size_t ncell = (size_t)6 * G * G;
+    struct Cand {
+        uint32_t cell;
+        float score;
+        int32_t tri;
+    };
+    std::vector<Cand> found;
+    found.reserve((size_t)T * 8);
+    std::vector<int32_t> count(ncell + 1, 0);
+    const double m = 1e-5;  // cells are grown by this much (uv units) before the overlap test
+    for (int t = 0; t < T; ++t) {
+        if (!usable[t]) continue;
+        const V3 v[3] = {vtx(xyz, V, tri[t]), vtx(xyz, V, tri[T + t]), vtx(xyz, V, tri[2 * T + t])};
+        const double ln[3] = {norm(v[0]), norm(v[1]), norm(v[2])};
+        for (int f = 0; f < 6; ++f) {
+            const int a = f >> 1, bb = (a + 1) % 3, cc = (a + 2) % 3;
+            const double sgn = (f & 1) ? -1.0 : 1.0;
+            double pu[3], pv[3];
+            bool front = true;
+            for (int k = 0; k < 3; ++k) {
+                const double c[3] = {v[k].x, v[k].y, v[k].z};
+                const double w = sgn * c[a];
+                if (!(w > 0.05 * ln[k])) {
+                    front = false;
+                    break;
+                }
+                pu[k] = c[bb] / w;
+                pv[k] = c[cc] / w;
+            }
+            if (!front) continue;
+            const double umin = std::fmin(pu[0], std::fmin(pu[1], pu[2])) - m, umax = std::fmax(pu[0], std::fmax(pu[1], pu[2])) + m;
+            const double vmin = std::fmin(pv[0], std::fmin(pv[1], pv[2])) - m, vmax = std::fmax(pv[0], std::fmax(pv[1], pv[2])) + m;
+            if (umax < -1 || umin > 1 || vmax < -1 || vmin > 1) continue;
+            auto cellof = [&](double x) { return std::max(0, std::min(G - 1, (int)std::floor((x + 1) * 0.5 * G))); };
+            const int iu0 = cellof(umin), iu1 = cellof(umax), iv0 = cellof(vmin), iv1 = cellof(vmax);
+            const double gu = (pu[0] + pu[1] + pu[2]) / 3, gv = (pv[0] + pv[1] + pv[2]) / 3;
+            // edge functions, oriented so that the third vertex is on the positive side
+            double ex[3], ey[3], ox[3], oy[3], sg[3];
+            for (int k = 0; k < 3; ++k) {
+                const int p = (k + 1) % 3, q = (k + 2) % 3;
+                ex[k] = pu[q] - pu[p], ey[k] = pv[q] - pv[p], ox[k] = pu[p], oy[k] = pv[p];
+                sg[k] = (ex[k] * (pv[k] - oy[k]) - ey[k] * (pu[k] - ox[k])) >= 0 ? 1.0 : -1.0;
+            }
+            for (int iu = iu0; iu <= iu1; ++iu)
+                for (int iv = iv0; iv <= iv1; ++iv) {
+                    const double x0 = -1 + 2.0 * iu / G - m, x1 = -1 + 2.0 * (iu + 1) / G + m;
+                    const double y0 = -1 + 2.0 * iv / G - m, y1 = -1 + 2.0 * (iv + 1) / G + m;
+                    bool sep = false;  // a triangle edge with the whole (grown) cell strictly outside
+                    for (int k = 0; k < 3 && !sep; ++k) {
+                        auto E = [&](double x, double y) { return sg[k] * (ex[k] * (y - oy[k]) - ey[k] * (x - ox[k])); };
+                        sep = E(x0, y0) < 0 && E(x1, y0) < 0 && E(x0, y1) < 0 && E(x1, y1) < 0;
+                    }
+                    if (sep) continue;
+                    const double cu = 0.5 * (x0 + x1) - gu, cv = 0.5 * (y0 + y1) - gv;
+                    const size_t cell = ((size_t)f * G + iu) * G + iv;
+                    found.push_back(Cand{(uint32_t)cell, (float)(cu * cu + cv * cv), t});
+                    ++count[cell + 1];
+                }
+        }
+    }
+    TICK("raster");
+    for (size_t c = 0; c < ncell; ++c) count[c + 1] += count[c];
+    std::vector<Cand> cand(found.size());
+    {
+        std::vector<int32_t> fill(count.begin(), count.end() - 1);
+        for (const Cand &c : found) cand[(size_t)fill[c.cell]++] = c;
+    }
+    TICK("bucket");
+    out.ray_cell.assign(ncell, make_int4(-1, -1, -1, -1));
+    for (size_t c = 0; c < ncell; ++c) {
+        Cand *first = cand.data() + count[c], *last = cand.data() + count[c + 1];
+        std::sort(first, last, [](const Cand &x, const Cand &y) { return x.score < y.score || (x.score == y.score && x.tri < y.tri); });
+        int32_t *slot = &out.ray_cell[c].x;
+        for (int k = 0; k < 4 && first + k < last; ++k) slot[k] = first[k].tri;
+    }
+    TICK("cells");
+}
 
 void build_octree(const double *xyz, const int32_t *tri, int V, int T, FlatOctree &out, std::vector<TriRec> &recs) {
     Builder b{xyz, tri, V, T, {}};
@@ -237,11 +423,13 @@ void build_octree(const double *xyz, const int32_t *tri, int V, int T, FlatOctre
         r.s3[0] = s3.x, r.s3[1] = s3.y, r.s3[2] = s3.z;
         r.id[0] = tri[t], r.id[1] = tri[T + t], r.id[2] = tri[2 * T + t];
         r.tri = t;
-        r.safe = HUGE_VAL;
+        r.reserved = 0.0;
         tcone[t] = bounding_cone(v0, v1, v2, r);
     }
-    out.simple = simple_star_surface(xyz, tri, V, T);
-    if (out.simple) safe_margins(xyz, tri, V, T, recs);
+    out.simple = false;  // decided together with the ray table (build_ray_table), which only the cost kernels need
+    out.ray_G = 0;
+    out.ray_cell.clear();
+    out.ray_edge.clear();
 
     // Leaf entries are padded to multiples of 8 (id -1, a cone nothing passes): 8 cones = one 128-byte line.
     const int n = (int)b.nodes.size();

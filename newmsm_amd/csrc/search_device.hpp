@@ -39,17 +39,48 @@ __device__ __forceinline__ bool inside_test(const TriRec &r, const V3 &p, V3 &mp
     return point_in_triangle(mp, rec_v0(r), rec_v1(r), rec_v2(r));
 }
 
-// Shortcut for simple surfaces: true when the projection of p lies inside the triangle with all three same_side
-// products above the triangle's `safe` threshold (octree.cpp: safe_margins), i.e. no other triangle of the mesh can
-// contain it.  A NaN anywhere makes the comparisons fail, which sends the sample to the complete path.
-__device__ __forceinline__ bool safely_inside(const TriRec &r, const V3 &p) {
-    const V3 v0 = rec_v0(r), v1 = rec_v1(r), v2 = rec_v2(r);
-    const V3 mp = project_with_plane(p, mk(r.s3[0], r.s3[1], r.s3[2]), r.d);
-    const V3 e0 = sub(v2, v1), e1 = sub(v0, v2), e2 = sub(v1, v0);
-    const double d0 = dot(cross(e0, sub(mp, v1)), cross(e0, sub(v0, v1)));
-    const double d1 = dot(cross(e1, sub(mp, v2)), cross(e1, sub(v1, v2)));
-    const double d2 = dot(cross(e2, sub(mp, v0)), cross(e2, sub(v2, v0)));
-    return d0 > r.safe && d1 > r.safe && d2 > r.safe;
+// Ray-table lookup (octree.cpp: build_ray_table): the triangle the reference's search returns for p, or -1 when the
+// table cannot tell (p off the radius shell, near an edge, a triangle the table does not vouch for, NaN): the caller
+// then runs the complete search.  Float arithmetic only proposes and accepts with the margins built into the
+// thresholds; it never decides between two candidates.
+__device__ __forceinline__ bool ray_accepts(const float4 *__restrict__ e, float fx, float fy, float fz) {
+    const float4 e0 = e[0], e1 = e[1], e2 = e[2];
+    const float d0 = __builtin_fmaf(e0.z, fz, __builtin_fmaf(e0.y, fy, e0.x * fx));
+    const float d1 = __builtin_fmaf(e1.z, fz, __builtin_fmaf(e1.y, fy, e1.x * fx));
+    const float d2 = __builtin_fmaf(e2.z, fz, __builtin_fmaf(e2.y, fy, e2.x * fx));
+    return d0 >= e0.w && d1 >= e1.w && d2 >= e2.w;
+}
+
+__device__ __forceinline__ int ray_lookup(const DevTree &T, const V3 &p) {
+    const double r2 = p.x * p.x + p.y * p.y + p.z * p.z;
+    if (!(r2 >= T.ray_r2lo && r2 <= T.ray_r2hi)) return -1;
+    const float qx = (float)p.x, qy = (float)p.y, qz = (float)p.z;
+    const float inv = rsqrtf(qx * qx + qy * qy + qz * qz);
+    const float fx = qx * inv, fy = qy * inv, fz = qz * inv;
+    const float ax = fabsf(fx), ay = fabsf(fy), az = fabsf(fz);
+    int face;
+    float w, u, v;
+    if (ax >= ay && ax >= az) {
+        face = fx < 0.f ? 1 : 0, w = ax, u = fy, v = fz;
+    } else if (ay >= az) {
+        face = fy < 0.f ? 3 : 2, w = ay, u = fz, v = fx;
+    } else {
+        face = fz < 0.f ? 5 : 4, w = az, u = fx, v = fy;
+    }
+    const float iw = 1.0f / w, half = 0.5f * (float)T.ray_G;
+    const int G = T.ray_G;
+    const int iu = max(0, min(G - 1, (int)((u * iw + 1.0f) * half)));
+    const int iv = max(0, min(G - 1, (int)((v * iw + 1.0f) * half)));
+    const int4 c = T.ray_cell[((size_t)face * G + iu) * G + iv];
+    if (c.x < 0) return -1;
+    if (ray_accepts(T.ray_edge + 3 * (size_t)c.x, fx, fy, fz)) return c.x;
+    if (c.y < 0) return -1;
+    if (ray_accepts(T.ray_edge + 3 * (size_t)c.y, fx, fy, fz)) return c.y;
+    if (c.z < 0) return -1;
+    if (ray_accepts(T.ray_edge + 3 * (size_t)c.z, fx, fy, fz)) return c.z;
+    if (c.w < 0) return -1;
+    if (ray_accepts(T.ray_edge + 3 * (size_t)c.w, fx, fy, fz)) return c.w;
+    return -1;
 }
 
 __device__ __forceinline__ double candidate_distance(const DevTree &T, int t, const V3 &p) {

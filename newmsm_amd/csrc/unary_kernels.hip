@@ -35,10 +35,11 @@ namespace msm {
 
 namespace {
 
+constexpr int kFixSegs = 64;       // segments of the fix-up list (see SamplesArgs)
+constexpr int kCntStride = 32;     // counters sit 128 bytes apart
 constexpr int kChunk = 768;       // samples per LDS pass (3 rounds of 256 lanes)
 constexpr int kQueueCap = 3072;   // (sample, triangle) pairs per pass
 constexpr int kDeferred = 1 << 20; // nin marker: leave this sample to the fix-up kernel
-constexpr int kDone = -2;          // nin marker: already emitted by the fast path
 constexpr unsigned kInvalidPair = 0xffffffffu;  // queue slot reserved by a sample that was deferred (sample ids stay below 1023)
 constexpr int kTriBits = 22;      // queue entry = sample << 22 | triangle
 
@@ -58,15 +59,19 @@ struct SamplesArgs {
     const double *src;     // 3 x Nsrc SoA
     int Nsrc;
     const int *pptr, *pidx;
+    const int *order;      // launch order of the control points
     int pmax;
     int nsplit;            // workgroups per control point (label ranges)
     // outputs, indexed by global sample id g = L*pptr[node] + l*P + i
     double *tval;          // D == 1: interpolated reference feature
     int *stri;             // otherwise: triangle id and the three raw barycentric weights
     double *sw3;           // 3 doubles per sample
+    // Fix-up list: kFixSegs segments (a workgroup appends to segment blockIdx % kFixSegs, which is sized for all
+    // samples of its workgroups: it cannot overflow).  One list with one counter would funnel every append of
+    // the chip through a single address; measured: 10 ns per append, i.e. most of the kernel's time.
     unsigned long long *fix_list;  // node << 32 | local sample
-    unsigned int *fix_count;
-    unsigned int fix_cap;
+    unsigned int *fix_cnt;         // counter of segment s at fix_cnt[kCntStride * (1 + s)]; [0] is the redo counter
+    const unsigned int *fix_off;   // kFixSegs + 1 segment offsets into fix_list
     // fused reduction (univariate): moving feature, weights, AbsoluteWeights, output table
     const double *sfeat;   // Nsrc (feature row 1)
     const double *cfw;     // Nsrc (weight row 1) or nullptr
@@ -76,7 +81,6 @@ struct SamplesArgs {
     int *redo_list;        // nodes whose reduction must wait for the fix-up kernel
     unsigned int *redo_count;
     int *status;
-    unsigned long long *nsamples;
 };
 
 // locate the octree leaf of p (same decisions as find_closest_triangle) and the sub-cell of p inside the leaf's
@@ -227,8 +231,9 @@ __global__ __launch_bounds__(256) void k_unary_samples(SamplesArgs a) {
     // fit a single LDS pass and the grid has enough workgroups to balance over the 256 CUs.
     {
         const int part = blockIdx.x / slots, slot = blockIdx.x - part * slots;
-        const int node = (slot & 7) * per + (slot >> 3);
-        if (node >= a.N) return;
+        const int at = (slot & 7) * per + (slot >> 3);
+        if (at >= a.N) return;
+        const int node = a.order[at];
         const int lper = (a.L + a.nsplit - 1) / a.nsplit;
         const int l_beg = part * lper, l_end = min(a.L, l_beg + lper);
         if (l_beg >= l_end) return;
@@ -283,8 +288,6 @@ __global__ __launch_bounds__(256) void k_unary_samples(SamplesArgs a) {
                             const float4 *cone = a.tree.cone + leaf.y;
                             // entries a point of this sub-cell can hit at all; cone-test those, four loads in flight
                             unsigned long long mm = a.tree.mask[(size_t)leaf.z * 64 + sub];
-                            float bestdot = -1.f;
-                            int best = -1;
                             while (mm) {
                                 int e[4];
                                 bool v[4];
@@ -300,24 +303,7 @@ __global__ __launch_bounds__(256) void k_unary_samples(SamplesArgs a) {
 #pragma unroll
                                 for (int k = 0; k < 4; ++k) {
                                     const float dt = fabsf(__builtin_fmaf(c[k].z, fz, __builtin_fmaf(c[k].y, fy, c[k].x * fx)));
-                                    if (v[k] && dt >= c[k].w) {
-                                        pm |= 1ull << e[k];
-                                        if (dt > bestdot) {  // the cone axis is the triangle's centroid direction: nearest centroid
-                                            bestdot = dt;
-                                            best = e[k];
-                                        }
-                                    }
-                                }
-                            }
-                            // Fast path on simple surfaces: on a near-regular mesh the nearest centroid's triangle is the
-                            // containing one; if the projection is safely inside it, it is the reference's answer.
-                            if (a.tree.simple && best >= 0) {
-                                const int t = a.tree.leaf_tri[leaf.y + best];
-                                if (safely_inside(a.tree.rec[t], p)) {
-                                    const double val = emit_sample(a, gbase + s, p, t);
-                                    if (a.U) sT[l * a.pmax + i] = val;
-                                    nin[sl] = kDone;
-                                    pm = 0ull;
+                                    if (v[k] && dt >= c[k].w) pm |= 1ull << e[k];
                                 }
                             }
                         }
@@ -382,22 +368,20 @@ __global__ __launch_bounds__(256) void k_unary_samples(SamplesArgs a) {
                     const V3 p = rotate(sR + 9 * l, mk(sx[i], sy[i], sz[i]));
                     const double v = emit_sample(a, gbase + s, p, win[sl]);
                     if (a.U) sT[l * a.pmax + i] = v;
-                } else if (n == kDone) {
-                    // emitted in phase A
                 } else if (n < 0) {
                     emit_failure(a, gbase + s, MSM_ERR_OUTSIDE);
                     atomicAdd(&s_ndefer, 1);
                 } else {
                     atomicAdd(&s_ndefer, 1);
-                    const unsigned slot = atomicAdd(a.fix_count, 1u);
-                    if (slot < a.fix_cap) a.fix_list[slot] = ((unsigned long long)node << 32) | (unsigned)s;
+                    const int seg = blockIdx.x % kFixSegs;
+                    const unsigned slot = a.fix_off[seg] + atomicAdd(&a.fix_cnt[kCntStride * (1 + seg)], 1u);
+                    if (slot < a.fix_off[seg + 1]) a.fix_list[slot] = ((unsigned long long)node << 32) | (unsigned)s;
                     else raise_status(a.status, MSM_ERR_CAPACITY);
                 }
             }
             __syncthreads();
 #endif
         }
-        if (tid == 0 && a.nsamples) atomicAdd(a.nsamples, (unsigned long long)(send - sbeg));
         // ---- reduction: every sample of this control point is in LDS unless some were deferred
         if (a.U) {
             __syncthreads();  // s_ndefer and sT are final (also when the patch is empty and the loop never ran)
@@ -414,12 +398,102 @@ __global__ __launch_bounds__(256) void k_unary_samples(SamplesArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Simple-surface targets: the ray table (search_device.hpp: ray_lookup) settles a sample with one cell load and
+// ~1.3 edge-plane tests; what it cannot settle (about 1 % on an icosphere target) goes to the fix-up list, where
+// k_unary_fixup runs the complete search.  Same workgroup -> control point mapping as k_unary_samples; no phases,
+// no queue: after staging, every wavefront strides over the samples on its own.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_unary_rays(SamplesArgs a) {
+    extern __shared__ double lds[];
+    double *sx = lds, *sy = sx + a.pmax, *sz = sy + a.pmax, *sR = sz + a.pmax;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int per = (a.N + 7) >> 3;
+    const int slots = 8 * per;
+    const int part = blockIdx.x / slots, slot = blockIdx.x - part * slots;
+    const int at = (slot & 7) * per + (slot >> 3);
+    if (at >= a.N) return;
+    const int node = a.order[at];
+    const int lper = (a.L + a.nsplit - 1) / a.nsplit;
+    const int l_beg = part * lper, l_end = min(a.L, l_beg + lper);
+    if (l_beg >= l_end) return;
+    const int beg = a.pptr[node], P = a.pptr[node + 1] - beg;
+    const size_t gbase = (size_t)a.L * beg;
+    for (int i = tid; i < P; i += 256) {
+        const int s = a.pidx[beg + i];
+        sx[i] = a.src[s];
+        sy[i] = a.src[a.Nsrc + s];
+        sz[i] = a.src[2 * a.Nsrc + s];
+    }
+    for (int k = 9 * l_beg + tid; k < 9 * l_end; k += 256) sR[k] = a.rnl[(size_t)node * a.L * 9 + k];
+    __syncthreads();
+    const int sbeg = l_beg * P, send = l_end * P;
+    const float invP = 1.0f / (float)max(P, 1);
+    // unsettled samples are collected in LDS and appended to the global list with ONE atomic per workgroup
+    // (a returning atomic per wavefront on one address was measured to triple the kernel's time)
+    int *sleft = reinterpret_cast<int *>(sR + 9 * a.L);
+    __shared__ int s_nleft;
+    __shared__ unsigned s_base;
+    if (tid == 0) s_nleft = 0;
+    __syncthreads();
+    for (int s0 = sbeg; s0 < send; s0 += 256) {
+        const int s = s0 + tid;
+        bool left = false;
+        if (s < send) {
+            const int l = fast_div(s, P, invP), i = s - l * P;
+            const V3 p = rotate(sR + 9 * l, mk(sx[i], sy[i], sz[i]));
+            const int t = ray_lookup(a.tree, p);
+            if (t >= 0) emit_sample(a, gbase + s, p, t);
+            else left = true;
+        }
+        const unsigned long long bal = __ballot(left);
+        if (bal) {
+            const int leader = __ffsll((long long)bal) - 1;
+            int base = 0;
+            if (lane == leader) base = atomicAdd(&s_nleft, __popcll(bal));
+            base = __shfl(base, leader, 64);
+            if (left) sleft[base + __popcll(bal & ((1ull << lane) - 1ull))] = s;
+        }
+    }
+    __syncthreads();
+    const int nleft = s_nleft;
+    if (nleft > 0) {
+        const int seg = blockIdx.x % kFixSegs;
+        if (tid == 0) s_base = a.fix_off[seg] + atomicAdd(&a.fix_cnt[kCntStride * (1 + seg)], (unsigned)nleft);
+        __syncthreads();
+        const unsigned base = s_base, end = a.fix_off[seg + 1];
+        for (int j = tid; j < nleft; j += 256) {
+            if (base + j < end) a.fix_list[base + j] = ((unsigned long long)node << 32) | (unsigned)sleft[j];
+            else raise_status(a.status, MSM_ERR_CAPACITY);
+        }
+    }
+}
+
 // the rare samples: complete reference search (several containing triangles -> dist_to_point tie-break; none ->
 // sibling leaves, then nearest vertex)
 __global__ __launch_bounds__(256) void k_unary_fixup(SamplesArgs a) {
-    const unsigned n = min(*a.fix_count, a.fix_cap);
+    // dense index over the segments: prefix sums of the segment counts (one wavefront, kFixSegs == 64)
+    __shared__ unsigned s_pre[kFixSegs + 1];
+    if (threadIdx.x < kFixSegs) {
+        const int seg = threadIdx.x;
+        const unsigned cnt = min(a.fix_cnt[kCntStride * (1 + seg)], a.fix_off[seg + 1] - a.fix_off[seg]);
+        unsigned incl = cnt;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned up = __shfl_up(incl, off, 64);
+            if (seg >= off) incl += up;
+        }
+        s_pre[seg + 1] = incl;
+        if (seg == 0) s_pre[0] = 0;
+    }
+    __syncthreads();
+    const unsigned n = s_pre[kFixSegs];
     for (unsigned j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
-        const unsigned long long e = a.fix_list[j];
+        int seg = 0;
+#pragma unroll
+        for (int step = kFixSegs / 2; step > 0; step >>= 1)
+            if (s_pre[seg + step] <= j) seg += step;
+        const unsigned long long e = a.fix_list[a.fix_off[seg] + (j - s_pre[seg])];
         const int node = (int)(e >> 32), s = (int)(e & 0xffffffffu);
         const int beg = a.pptr[node], P = a.pptr[node + 1] - beg;
         const int l = s / P, i = s - l * P;
@@ -472,6 +546,70 @@ __global__ __launch_bounds__(256) void k_unary_reduce_univariate(ReduceArgs a) {
             if (lane == 0) a.U[(size_t)l * a.N + node] = absw * cost;
         }
     }
+}
+
+// The same reduction for a whole table whose samples all sit in tval (ray-table path): one 16-lane group per
+// (control point, label), four evaluations per wavefront; the 16-lane sums are DPP row operations.
+__device__ __forceinline__ double group16_sum(double v) {
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) v += __shfl_xor(v, off, 16);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void k_unary_reduce_flat(ReduceArgs a) {
+    const int e = blockIdx.x * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15;
+    if (e >= a.N * a.L) return;
+    const int node = e / a.L, l = e - node * a.L;
+    const int beg = a.pptr[node], P = a.pptr[node + 1] - beg;
+    const double *B = a.tval + (size_t)a.L * beg + (size_t)l * P;
+    const bool has_w = a.cfw && a.cfw_rows >= 1;
+    double cost;
+    if (a.simmeasure == 2) {  // sparsesimkernel::corr, M/similarities.cpp:129-158
+        double sw = 0, ma = 0, mb = 0;
+        for (int i = sub; i < P; i += 16) {
+            const int s = a.pidx[beg + i];
+            const double w = has_w ? a.cfw[s] : 1.0;
+            sw += w;
+            ma += w * a.sfeat[s];
+            mb += w * B[i];
+        }
+        sw = group16_sum(sw);
+        ma = group16_sum(ma);
+        mb = group16_sum(mb);
+        if (sw > 0.0) {
+            ma /= sw;
+            mb /= sw;
+        }
+        double pr = 0, va = 0, vb = 0;
+        for (int i = sub; i < P; i += 16) {
+            const int s = a.pidx[beg + i];
+            const double w = has_w ? a.cfw[s] : 1.0;
+            const double da = a.sfeat[s] - ma, db = B[i] - mb;
+            pr += w * da * db;
+            va += w * da * da;
+            vb += w * db * db;
+        }
+        pr = group16_sum(pr);
+        va = group16_sum(va);
+        vb = group16_sum(vb);
+        if (sw > 0.0) {
+            pr /= sw;
+            va /= sw;
+            vb /= sw;
+        }
+        const double r = (va == 0.0 || vb == 0.0) ? 0.0 : pr / (sqrt(va) * sqrt(vb));
+        cost = 1 - (1 + r) * 0.5;
+    } else {  // sparsesimkernel::SSD, M/similarities.cpp:179-188
+        double pr = 0;
+        for (int i = sub; i < P; i += 16) {
+            const int s = a.pidx[beg + i];
+            const double df = a.sfeat[s] - B[i];
+            pr += (has_w ? a.cfw[s] : 1.0) * df * df;
+        }
+        pr = group16_sum(pr);
+        cost = sqrt(pr) / P;
+    }
+    if (sub == 0) a.U[(size_t)l * a.N + node] = a.absw[node] * cost;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -598,6 +736,29 @@ static size_t samples_lds(int pmax, int L) {
     return sizeof(double) * (5 * (size_t)pmax + 9 * (size_t)L + (size_t)L * pmax) + sizeof(unsigned) * kQueueCap + sizeof(int) * 2 * kChunk;
 }
 
+int unary_nsplit(int L, int pmax) { return std::max(1, std::min(4, (int)(((size_t)L * pmax + kChunk - 1) / kChunk))); }
+int unary_fix_segments() { return kFixSegs; }
+size_t unary_fix_counter_words() { return (size_t)kCntStride * (1 + kFixSegs); }
+// samples of workgroup `block` of the unary sample kernels (the mapping at the top of k_unary_samples / k_unary_rays)
+void unary_fix_offsets(int N, int L, int pmax, const int32_t *pptr, const int32_t *order, std::vector<uint32_t> &off) {
+    const int nsplit = unary_nsplit(L, pmax), per = (N + 7) >> 3, slots = 8 * per;
+    const int lper = (L + nsplit - 1) / nsplit;
+    std::vector<uint64_t> size(kFixSegs, 0);
+    for (int b = 0; b < nsplit * slots; ++b) {
+        const int part = b / slots, slot = b - part * slots;
+        const int at = (slot & 7) * per + (slot >> 3);
+        if (at >= N) continue;
+        const int node = order[at];
+        const int l_beg = part * lper, l_end = std::min(L, l_beg + lper);
+        if (l_beg >= l_end) continue;
+        size[b % kFixSegs] += (uint64_t)(l_end - l_beg) * (pptr[node + 1] - pptr[node]);
+    }
+    off.assign(kFixSegs + 1, 0);
+    for (int s = 0; s < kFixSegs; ++s) off[s + 1] = (uint32_t)std::min<uint64_t>(0xffffffffull, off[s] + size[s]);
+}
+
+static bool uses_ray_table(const DevTree &t) { return t.simple && t.ray_G > 0 && t.ray_cell && t.ray_edge; }
+
 static int launch_samples(msm_ctx *ctx, const UnaryLaunch &u, const UnaryWeightsScratch *w, SamplesArgs &a) {
     if (u.tree.nnodes <= 0 || !u.tree.mask) return fail(MSM_ERR_STATE, "target search structure missing");
     a.tree = u.tree;
@@ -609,36 +770,44 @@ static int launch_samples(msm_ctx *ctx, const UnaryLaunch &u, const UnaryWeights
     a.Nsrc = u.Nsrc;
     a.pptr = u.pptr;
     a.pidx = u.pidx;
+    a.order = u.order;
     a.pmax = u.pmax;
     a.tval = w ? nullptr : u.tval;
     a.stri = w ? w->stri : nullptr;
     a.sw3 = w ? w->sw3 : nullptr;
     a.fix_list = u.fix_list;
-    a.fix_count = u.fix_count;
-    a.fix_cap = u.fix_cap;
+    a.fix_cnt = u.fix_cnt;
+    a.fix_off = u.fix_off;
     a.sfeat = u.sfeat;
     a.cfw = (u.cfw && u.cfw_rows >= 1) ? u.cfw : nullptr;
     a.absw = u.absw;
     a.simmeasure = u.simmeasure;
     a.U = w ? nullptr : u.U;  // the fused reduction is the univariate one
     a.redo_list = u.redo_list;
-    a.redo_count = u.fix_count + 1;
+    a.redo_count = u.fix_cnt;
     a.status = ctx->d_status;
-    a.nsamples = u.nsamples;
     if (u.ntri >= (1 << kTriBits)) return fail(MSM_ERR_CAPACITY, "target mesh has %d triangles; the sample queue packs ids in %d bits", u.ntri, kTriBits);
     const size_t lds = samples_lds(u.pmax, u.L);
     if (lds > 64 * 1024) {
         if (lds > 160 * 1024) return fail(MSM_ERR_CAPACITY, "patch of %d points x %d labels does not fit in LDS", u.pmax, u.L);
         MSM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_unary_samples), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
-    MSM_HIP(hipMemsetAsync(u.fix_count, 0, 2 * sizeof(unsigned), ctx->stream));  // fix-up and redo counters
-    a.nsplit = std::max(1, std::min(4, (int)(((size_t)u.L * u.pmax + kChunk - 1) / kChunk)));
+    MSM_HIP(hipMemsetAsync(u.fix_cnt, 0, unary_fix_counter_words() * sizeof(unsigned), ctx->stream));  // fix-up and redo counters
+    a.nsplit = unary_nsplit(u.L, u.pmax);
     const int blocks = a.nsplit * 8 * ((u.N + 7) / 8);
     if (u.ev_start) MSM_HIP(hipEventRecord(u.ev_start, ctx->stream));
-    hipLaunchKernelGGL(k_unary_samples, dim3(blocks), dim3(256), lds, ctx->stream, a);
+    if (uses_ray_table(u.tree)) {
+        a.U = nullptr;  // the reduction is a kernel of its own on this path
+        const int lper = (u.L + a.nsplit - 1) / a.nsplit;
+        const size_t rays_lds = sizeof(double) * (3 * (size_t)u.pmax + 9 * (size_t)u.L) + sizeof(int) * (size_t)lper * u.pmax;
+        if (rays_lds > 64 * 1024) MSM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_unary_rays), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rays_lds));
+        hipLaunchKernelGGL(k_unary_rays, dim3(blocks), dim3(256), rays_lds, ctx->stream, a);
+    } else {
+        hipLaunchKernelGGL(k_unary_samples, dim3(blocks), dim3(256), lds, ctx->stream, a);
+    }
     MSM_HIP(hipGetLastError());
     if (u.ev_stop) MSM_HIP(hipEventRecord(u.ev_stop, ctx->stream));
-    hipLaunchKernelGGL(k_unary_fixup, dim3(64), dim3(256), 0, ctx->stream, a);
+    hipLaunchKernelGGL(k_unary_fixup, dim3(512), dim3(256), 0, ctx->stream, a);
     MSM_HIP(hipGetLastError());
     return MSM_OK;
 }
@@ -663,8 +832,13 @@ int launch_unary_univariate(msm_ctx *ctx, const UnaryLaunch &u) {
     r.simmeasure = u.simmeasure;
     r.U = u.U;
     r.redo_list = u.redo_list;
-    r.redo_count = u.fix_count + 1;
-    hipLaunchKernelGGL(k_unary_reduce_univariate, dim3(64), dim3(256), sizeof(double) * 2 * (size_t)u.pmax, ctx->stream, r);
+    r.redo_count = u.fix_cnt;
+    if (uses_ray_table(u.tree)) {
+        const int evals = u.N * u.L;
+        hipLaunchKernelGGL(k_unary_reduce_flat, dim3((evals + 15) / 16), dim3(256), 0, ctx->stream, r);
+    } else {
+        hipLaunchKernelGGL(k_unary_reduce_univariate, dim3(64), dim3(256), sizeof(double) * 2 * (size_t)u.pmax, ctx->stream, r);
+    }
     MSM_HIP(hipGetLastError());
     return MSM_OK;
 }
