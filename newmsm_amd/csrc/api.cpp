@@ -79,10 +79,12 @@ int ensure_masks(msm_mesh *m) {
     return MSM_OK;
 }
 
+static int ensure_rayrec(msm_mesh *m);
+
 int ensure_rays(msm_mesh *m) {
     int st = ensure_masks(m);  // what the ray table cannot settle goes through the masked search
     if (st) return st;
-    if (m->rays_valid) return MSM_OK;
+    if (m->rays_valid) return ensure_rayrec(m);
     msm_ctx *ctx = m->ctx;
     build_ray_table(m->xyz.data(), m->tri.data(), m->V, m->T, m->tree);
     if (m->tree.ray_G > 0) {
@@ -98,8 +100,24 @@ int ensure_rays(msm_mesh *m) {
         MSM_HIP(hipMemcpyAsync(m->d_ray_cell, m->tree.ray_cell.data(), m->tree.ray_cell.size() * sizeof(int4), hipMemcpyHostToDevice, ctx->stream));
         MSM_HIP(hipMemcpyAsync(m->d_ray_edge, m->tree.ray_edge.data(), m->tree.ray_edge.size() * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
         MSM_HIP(hipStreamSynchronize(ctx->stream));
+        m->rayrec_valid = false;
     }
     m->rays_valid = true;
+    return ensure_rayrec(m);
+}
+
+// (re)fills the per-triangle records of the ray-table path after the tree or the features changed
+static int ensure_rayrec(msm_mesh *m) {
+    if (m->tree.ray_G <= 0 || m->rayrec_valid) return MSM_OK;
+    if ((size_t)m->T > m->cap_ray_rec || !m->d_ray_tri) {
+        if (m->d_ray_tri) (void)hipFree(m->d_ray_tri);
+        m->d_ray_tri = nullptr;
+        m->cap_ray_rec = (size_t)m->T + m->T / 4 + 16;
+        MSM_HIP(hipMalloc((void **)&m->d_ray_tri, m->cap_ray_rec * kRayPieces * sizeof(float4)));
+    }
+    int st = launch_build_raytri(m->ctx, m->d_rec, m->d_ray_edge, m->T, m->D == 1 ? m->d_feat : nullptr, m->d_ray_tri);
+    if (st) return st;
+    m->rayrec_valid = true;
     return MSM_OK;
 }
 
@@ -117,7 +135,7 @@ DevTree dev_tree(const msm_mesh *m) {
     t.nnodes = (int)m->tree.node.size();
     t.ray_G = m->rays_valid ? m->tree.ray_G : 0;
     t.ray_cell = m->d_ray_cell;
-    t.ray_edge = m->d_ray_edge;
+    t.ray_tri = m->d_ray_tri;
     t.ray_r2lo = m->tree.ray_r2lo;
     t.ray_r2hi = m->tree.ray_r2hi;
     return t;
@@ -359,7 +377,7 @@ void msm_mesh_destroy(msm_mesh *m) {
     if (!m) return;
     (void)hipSetDevice(m->ctx->device);
     (void)hipStreamSynchronize(m->ctx->stream);
-    for (void *p : {(void *)m->d_xyz, (void *)m->d_feat, (void *)m->d_node, (void *)m->d_parent, (void *)m->d_leaf_tri, (void *)m->d_cone, (void *)m->d_rec, (void *)m->d_grid, (void *)m->d_nodebox, (void *)m->d_mask, (void *)m->d_ray_cell, (void *)m->d_ray_edge})
+    for (void *p : {(void *)m->d_xyz, (void *)m->d_feat, (void *)m->d_node, (void *)m->d_parent, (void *)m->d_leaf_tri, (void *)m->d_cone, (void *)m->d_rec, (void *)m->d_grid, (void *)m->d_nodebox, (void *)m->d_mask, (void *)m->d_ray_cell, (void *)m->d_ray_edge, (void *)m->d_ray_tri})
         if (p) (void)hipFree(p);
     delete m;
 }
@@ -393,6 +411,7 @@ int msm_mesh_set_features(msm_mesh *m, const double *feat, int32_t D) {
     }
     if (!m->d_feat) MSM_HIP(hipMalloc((void **)&m->d_feat, sizeof(double) * (size_t)D * V));
     m->D = D;
+    m->rayrec_valid = false;
     MSM_HIP(hipMemcpyAsync(m->d_feat, vm.data(), sizeof(double) * (size_t)D * V, hipMemcpyHostToDevice, m->ctx->stream));
     MSM_HIP(hipStreamSynchronize(m->ctx->stream));
     return MSM_OK;

@@ -171,7 +171,7 @@ int ensure_unary_table(msm_cost *c) {
     const size_t nsamp = (size_t)c->L * c->pidx.size();
     MSM_HIP(c->d_tval.ensure(nsamp));
     MSM_HIP(c->d_fix_list.ensure(nsamp));
-    MSM_HIP(c->d_fix_count.ensure(unary_fix_counter_words()));
+    if (!c->d_fix_count.p) MSM_HIP(c->d_fix_count.zero(unary_fix_counter_words(), ctx->stream));  // every launch leaves them zero again
     if (!c->fix_off_valid) {
         std::vector<uint32_t> off;
         unary_fix_offsets(N, c->L, c->pmax, c->pptr.data(), c->order.data(), off);

@@ -43,6 +43,14 @@ struct alignas(128) TriRec {
 };
 static_assert(sizeof(TriRec) == 128, "TriRec must be 128 bytes");
 
+// Per-triangle record of the ray-table path, nine 16-byte pieces (144 bytes, two cache lines):
+//   pieces 0-2  the three edge planes (float4: inward unit normal, acceptance threshold)      -- octree.cpp
+//   pieces 3-8  the vertices v0,v1,v2 (9 doubles) and, on single-feature meshes, the feature at them (3 doubles)
+// so that a wavefront can fetch the records of its 64 samples with 9 load instructions that touch ~2 lines per
+// record (lanes of one instruction read neighbouring pieces) instead of 9 x 64 lines.  Built on the GPU
+// (kernels.hip: k_build_raytri).
+constexpr int kRayPieces = 9;
+
 struct FlatOctree {
     // node[n].x >= 0: internal node, children are node[n].x .. +7 in (i,j,k) order.
     // node[n].x <  0: leaf with (-x - 1) entries starting at node[n].y (a multiple of 8) in leaf_tri / cone;
@@ -91,7 +99,7 @@ struct DevTree {
     // ray table (FlatOctree::ray_*); ray_G == 0: none
     int ray_G;
     const int4 *ray_cell;
-    const float4 *ray_edge;
+    const float4 *ray_tri;   // kRayPieces float4 per triangle
     double ray_r2lo, ray_r2hi;
 };
 
@@ -129,7 +137,9 @@ struct msm_mesh {
     int32_t *d_grid = nullptr;
     int4 *d_ray_cell = nullptr;
     float4 *d_ray_edge = nullptr;
-    size_t cap_ray_cell = 0, cap_ray_edge = 0;
+    float4 *d_ray_tri = nullptr;
+    bool rayrec_valid = false;  // d_ray_tri matches the current coordinates and features
+    size_t cap_ray_cell = 0, cap_ray_edge = 0, cap_ray_rec = 0;
     size_t cap_node = 0, cap_parent = 0, cap_box = 0, cap_leaf = 0, cap_cone = 0, cap_rec = 0, cap_grid = 0, cap_mask = 0;  // one per buffer
     msm::Adjacency adj;
     bool adj_valid = false;

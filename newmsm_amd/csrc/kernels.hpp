@@ -7,6 +7,8 @@ namespace msm {
 
 // per-leaf sub-cell masks (see FlatOctree::node); writes 64 words per mask block
 int launch_build_masks(msm_ctx *ctx, const DevTree &T, const double4 *d_nodebox, unsigned long long *d_mask);
+// ray-table records (internal.hpp: kRayPieces) from the triangle records, the edge planes and, when given, a single feature row (V doubles)
+int launch_build_raytri(msm_ctx *ctx, const TriRec *d_rec, const float4 *d_edge, int T, const double *d_feat1, float4 *d_out);
 int launch_query(msm_ctx *ctx, const DevTree &T, const double *d_q, int N, int *d_tri, int *d_vid, double *d_w, int mode);
 int launch_closest_vertex(msm_ctx *ctx, const DevTree &T, const double *d_q, int N, int *d_out);
 int launch_range(msm_ctx *ctx, const double *d_cp, int Ncp, const double *d_src, int Nsrc, const double *d_maxsep, double range, int cap,

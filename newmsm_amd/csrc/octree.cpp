@@ -315,6 +315,7 @@ void build_ray_table(const double *xyz, const int32_t *tri, int V, int T, FlatOc
     // cube map: face f = 2*axis + (negative side); (u, v) = the two other components over |major component|
     int G = 8;
     while (G < 512 && (double)G * G * 6 < 4.0 * T) G *= 2;
+    if (const char *e = std::getenv("MSMHIP_RAY_G")) G = std::max(8, std::min(1024, atoi(e)));  // experiments only
     out.ray_G = G;
     const size_t ncell = (size_t)6 * G * G;
     struct Cand {

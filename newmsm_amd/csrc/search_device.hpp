@@ -39,24 +39,16 @@ __device__ __forceinline__ bool inside_test(const TriRec &r, const V3 &p, V3 &mp
     return point_in_triangle(mp, rec_v0(r), rec_v1(r), rec_v2(r));
 }
 
-// Ray-table lookup (octree.cpp: build_ray_table): the triangle the reference's search returns for p, or -1 when the
-// table cannot tell (p off the radius shell, near an edge, a triangle the table does not vouch for, NaN): the caller
-// then runs the complete search.  Float arithmetic only proposes and accepts with the margins built into the
-// thresholds; it never decides between two candidates.
-__device__ __forceinline__ bool ray_accepts(const float4 *__restrict__ e, float fx, float fy, float fz) {
-    const float4 e0 = e[0], e1 = e[1], e2 = e[2];
-    const float d0 = __builtin_fmaf(e0.z, fz, __builtin_fmaf(e0.y, fy, e0.x * fx));
-    const float d1 = __builtin_fmaf(e1.z, fz, __builtin_fmaf(e1.y, fy, e1.x * fx));
-    const float d2 = __builtin_fmaf(e2.z, fz, __builtin_fmaf(e2.y, fy, e2.x * fx));
-    return d0 >= e0.w && d1 >= e1.w && d2 >= e2.w;
-}
-
-__device__ __forceinline__ int ray_lookup(const DevTree &T, const V3 &p) {
+// Ray table (octree.cpp: build_ray_table): the direction cell of p, i.e. up to four candidate triangles, likeliest
+// first; all -1 when p is off the radius shell the table vouches for (or NaN).  Float arithmetic only proposes
+// candidates and accepts them with the margins built into the thresholds; it never decides between two candidates.
+__device__ __forceinline__ int4 ray_cell_of(const DevTree &T, const V3 &p, float &fx, float &fy, float &fz) {
     const double r2 = p.x * p.x + p.y * p.y + p.z * p.z;
-    if (!(r2 >= T.ray_r2lo && r2 <= T.ray_r2hi)) return -1;
+    fx = fy = fz = 0.f;
+    if (!(r2 >= T.ray_r2lo && r2 <= T.ray_r2hi)) return make_int4(-1, -1, -1, -1);
     const float qx = (float)p.x, qy = (float)p.y, qz = (float)p.z;
     const float inv = rsqrtf(qx * qx + qy * qy + qz * qz);
-    const float fx = qx * inv, fy = qy * inv, fz = qz * inv;
+    fx = qx * inv, fy = qy * inv, fz = qz * inv;
     const float ax = fabsf(fx), ay = fabsf(fy), az = fabsf(fz);
     int face;
     float w, u, v;
@@ -71,16 +63,15 @@ __device__ __forceinline__ int ray_lookup(const DevTree &T, const V3 &p) {
     const int G = T.ray_G;
     const int iu = max(0, min(G - 1, (int)((u * iw + 1.0f) * half)));
     const int iv = max(0, min(G - 1, (int)((v * iw + 1.0f) * half)));
-    const int4 c = T.ray_cell[((size_t)face * G + iu) * G + iv];
-    if (c.x < 0) return -1;
-    if (ray_accepts(T.ray_edge + 3 * (size_t)c.x, fx, fy, fz)) return c.x;
-    if (c.y < 0) return -1;
-    if (ray_accepts(T.ray_edge + 3 * (size_t)c.y, fx, fy, fz)) return c.y;
-    if (c.z < 0) return -1;
-    if (ray_accepts(T.ray_edge + 3 * (size_t)c.z, fx, fy, fz)) return c.z;
-    if (c.w < 0) return -1;
-    if (ray_accepts(T.ray_edge + 3 * (size_t)c.w, fx, fy, fz)) return c.w;
-    return -1;
+    return T.ray_cell[((size_t)face * G + iu) * G + iv];
+}
+
+// the acceptance test of one candidate: all three edge-plane products at or above their thresholds
+__device__ __forceinline__ bool ray_accepts(const float4 &e0, const float4 &e1, const float4 &e2, float fx, float fy, float fz) {
+    const float d0 = __builtin_fmaf(e0.z, fz, __builtin_fmaf(e0.y, fy, e0.x * fx));
+    const float d1 = __builtin_fmaf(e1.z, fz, __builtin_fmaf(e1.y, fy, e1.x * fx));
+    const float d2 = __builtin_fmaf(e2.z, fz, __builtin_fmaf(e2.y, fy, e2.x * fx));
+    return (int)(d0 >= e0.w) & (int)(d1 >= e1.w) & (int)(d2 >= e2.w);
 }
 
 __device__ __forceinline__ double candidate_distance(const DevTree &T, int t, const V3 &p) {

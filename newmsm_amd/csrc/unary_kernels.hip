@@ -22,6 +22,7 @@
 //
 // Decisions (which triangle) use the reference's FP64 arithmetic; see search_device.hpp.
 #include <algorithm>
+#include <cstdlib>
 
 #include "kernels.hpp"
 #include "search_device.hpp"
@@ -211,7 +212,7 @@ __device__ __forceinline__ double patch_similarity(const double *A, const double
 }  // namespace
 
 __global__ __launch_bounds__(256) void k_unary_samples(SamplesArgs a) {
-    extern __shared__ double lds[];
+    extern __shared__ __align__(16) double lds[];
     double *sx = lds, *sy = sx + a.pmax, *sz = sy + a.pmax;
     double *sA = sz + a.pmax, *sW = sA + a.pmax;                 // moving feature and weights of the patch
     double *sR = sW + a.pmax;                                    // L x 9
@@ -399,13 +400,21 @@ __global__ __launch_bounds__(256) void k_unary_samples(SamplesArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Simple-surface targets: the ray table (search_device.hpp: ray_lookup) settles a sample with one cell load and
-// ~1.3 edge-plane tests; what it cannot settle (about 1 % on an icosphere target) goes to the fix-up list, where
-// k_unary_fixup runs the complete search.  Same workgroup -> control point mapping as k_unary_samples; no phases,
-// no queue: after staging, every wavefront strides over the samples on its own.
+// Simple-surface targets: the ray table (search_device.hpp, octree.cpp: build_ray_table) settles a sample with one
+// direction-cell load and ~1.3 candidate records; what it cannot settle (about 2 % on an icosphere target) goes to
+// the fix-up list, where k_unary_fixup runs the complete search.  Same workgroup -> control point mapping as
+// k_unary_samples; after staging every wavefront strides over the samples on its own.
+//
+// The kernel is bound by the vector L1's line-lookup rate (one 128-byte line per cycle per CU: a load whose 64
+// lanes hit 64 different lines costs 64 cycles, whatever its width), not by HBM or the ALUs: about 13 line
+// lookups per sample (cell 1, edge planes 3, vertices + features 6, retries) = 4.1e7 per table, 161 k cycles per CU.
+// A variant in which the wavefront fetches the 64 records as a team (lane j of load k reads piece (64k+j) % 9 of the
+// record of lane (64k+j) / 9, straight into LDS with global_load_lds_dwordx4) halved the lookups but doubled the
+// VALU work (four candidate rounds per wavefront) and, at 9 KB of LDS per wavefront, cut the occupancy: 123 us
+// against 86 us for the plain per-lane loads below.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_unary_rays(SamplesArgs a) {
-    extern __shared__ double lds[];
+    extern __shared__ __align__(16) double lds[];
     double *sx = lds, *sy = sx + a.pmax, *sz = sy + a.pmax, *sR = sz + a.pmax;
     const int tid = threadIdx.x, lane = tid & 63;
     const int per = (a.N + 7) >> 3;
@@ -426,7 +435,6 @@ __global__ __launch_bounds__(256) void k_unary_rays(SamplesArgs a) {
         sz[i] = a.src[2 * a.Nsrc + s];
     }
     for (int k = 9 * l_beg + tid; k < 9 * l_end; k += 256) sR[k] = a.rnl[(size_t)node * a.L * 9 + k];
-    __syncthreads();
     const int sbeg = l_beg * P, send = l_end * P;
     const float invP = 1.0f / (float)max(P, 1);
     // unsettled samples are collected in LDS and appended to the global list with ONE atomic per workgroup
@@ -438,14 +446,53 @@ __global__ __launch_bounds__(256) void k_unary_rays(SamplesArgs a) {
     __syncthreads();
     for (int s0 = sbeg; s0 < send; s0 += 256) {
         const int s = s0 + tid;
-        bool left = false;
-        if (s < send) {
+        const bool act = s < send;
+        bool done = false;
+        if (act) {
             const int l = fast_div(s, P, invP), i = s - l * P;
             const V3 p = rotate(sR + 9 * l, mk(sx[i], sy[i], sz[i]));
-            const int t = ray_lookup(a.tree, p);
-            if (t >= 0) emit_sample(a, gbase + s, p, t);
-            else left = true;
+            float fx, fy, fz;
+            const int4 c = ray_cell_of(a.tree, p, fx, fy, fz);
+            if (c.x >= 0) {
+                // the first candidate is the answer three times out of four: its vertices are requested together with
+                // its edge planes, so a settled sample costs two dependent loads after the cell
+                const float4 *rec = a.tree.ray_tri + (size_t)kRayPieces * c.x;
+                const float4 e0 = rec[0], e1 = rec[1], e2 = rec[2];
+                const double2 *dv = reinterpret_cast<const double2 *>(rec + 3);
+                double2 d0 = dv[0], d1 = dv[1], d2 = dv[2], d3 = dv[3], d4 = dv[4], d5 = dv[5];
+                int t = c.x;
+                if (!ray_accepts(e0, e1, e2, fx, fy, fz)) {
+                    t = -1;
+                    const int more[3] = {c.y, c.z, c.w};
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        if (t >= 0 || more[k] < 0) continue;
+                        const float4 *r2 = a.tree.ray_tri + (size_t)kRayPieces * more[k];
+                        const float4 g0 = r2[0], g1 = r2[1], g2 = r2[2];
+                        if (ray_accepts(g0, g1, g2, fx, fy, fz)) t = more[k];
+                    }
+                    if (t >= 0) {
+                        dv = reinterpret_cast<const double2 *>(a.tree.ray_tri + (size_t)kRayPieces * t + 3);
+                        d0 = dv[0], d1 = dv[1], d2 = dv[2], d3 = dv[3], d4 = dv[4], d5 = dv[5];
+                    }
+                }
+                if (t >= 0) {
+                    double wa, wb, wc;
+                    area_weights(mk(d0.x, d0.y, d1.x), mk(d1.y, d2.x, d2.y), mk(d3.x, d3.y, d4.x), p, wa, wb, wc);
+                    const size_t g = gbase + s;
+                    if (a.tval) {
+                        a.tval[g] = wa * d4.y + wb * d5.x + wc * d5.y;
+                    } else {
+                        a.stri[g] = t;
+                        a.sw3[3 * g] = wa;
+                        a.sw3[3 * g + 1] = wb;
+                        a.sw3[3 * g + 2] = wc;
+                    }
+                    done = true;
+                }
+            }
         }
+        const bool left = act && !done;
         const unsigned long long bal = __ballot(left);
         if (bal) {
             const int leader = __ffsll((long long)bal) - 1;
@@ -526,7 +573,7 @@ struct ReduceArgs {
 };
 
 __global__ __launch_bounds__(256) void k_unary_reduce_univariate(ReduceArgs a) {
-    extern __shared__ double lds[];
+    extern __shared__ __align__(16) double lds[];
     double *sA = lds, *sW = sA + a.pmax;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const unsigned n = a.redo_count ? *a.redo_count : (unsigned)a.N;
@@ -548,68 +595,90 @@ __global__ __launch_bounds__(256) void k_unary_reduce_univariate(ReduceArgs a) {
     }
 }
 
-// The same reduction for a whole table whose samples all sit in tval (ray-table path): one 16-lane group per
-// (control point, label), four evaluations per wavefront; the 16-lane sums are DPP row operations.
+// The same reduction for a whole table whose samples all sit in tval (ray-table path): one workgroup per control
+// point stages the moving patch (feature, weight) in LDS once; a 16-lane group per label then reads that label's
+// sampled target patch (contiguous in tval) -- 16 labels per pass, the 16-lane sums are DPP row operations.
+// The weighted mean and variance of the moving patch do not depend on the label and are computed once.
+// The last kernel of a ray-table launch also clears the fix-up counters for the next one.
 __device__ __forceinline__ double group16_sum(double v) {
 #pragma unroll
     for (int off = 8; off > 0; off >>= 1) v += __shfl_xor(v, off, 16);
     return v;
 }
 
-__global__ __launch_bounds__(256) void k_unary_reduce_flat(ReduceArgs a) {
-    const int e = blockIdx.x * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15;
-    if (e >= a.N * a.L) return;
-    const int node = e / a.L, l = e - node * a.L;
+__global__ __launch_bounds__(256) void k_unary_reduce_flat(ReduceArgs a, unsigned int *clear, int clear_words) {
+    extern __shared__ __align__(16) double lds[];
+    double *sA = lds, *sW = sA + a.pmax;
+    __shared__ double s_stat[3];  // sum of weights, weighted mean of A, weighted variance sum of A
+    const int tid = threadIdx.x, sub = tid & 15, grp = tid >> 4;
+    if (blockIdx.x == 0 && clear)
+        for (int k = tid; k < clear_words; k += 256) clear[k] = 0u;
+    const int node = a.redo_list ? a.redo_list[blockIdx.x] : (int)blockIdx.x;  // launch order = Morton order
     const int beg = a.pptr[node], P = a.pptr[node + 1] - beg;
-    const double *B = a.tval + (size_t)a.L * beg + (size_t)l * P;
     const bool has_w = a.cfw && a.cfw_rows >= 1;
-    double cost;
-    if (a.simmeasure == 2) {  // sparsesimkernel::corr, M/similarities.cpp:129-158
-        double sw = 0, ma = 0, mb = 0;
-        for (int i = sub; i < P; i += 16) {
-            const int s = a.pidx[beg + i];
-            const double w = has_w ? a.cfw[s] : 1.0;
-            sw += w;
-            ma += w * a.sfeat[s];
-            mb += w * B[i];
-        }
-        sw = group16_sum(sw);
-        ma = group16_sum(ma);
-        mb = group16_sum(mb);
-        if (sw > 0.0) {
-            ma /= sw;
-            mb /= sw;
-        }
-        double pr = 0, va = 0, vb = 0;
-        for (int i = sub; i < P; i += 16) {
-            const int s = a.pidx[beg + i];
-            const double w = has_w ? a.cfw[s] : 1.0;
-            const double da = a.sfeat[s] - ma, db = B[i] - mb;
-            pr += w * da * db;
-            va += w * da * da;
-            vb += w * db * db;
-        }
-        pr = group16_sum(pr);
-        va = group16_sum(va);
-        vb = group16_sum(vb);
-        if (sw > 0.0) {
-            pr /= sw;
-            va /= sw;
-            vb /= sw;
-        }
-        const double r = (va == 0.0 || vb == 0.0) ? 0.0 : pr / (sqrt(va) * sqrt(vb));
-        cost = 1 - (1 + r) * 0.5;
-    } else {  // sparsesimkernel::SSD, M/similarities.cpp:179-188
-        double pr = 0;
-        for (int i = sub; i < P; i += 16) {
-            const int s = a.pidx[beg + i];
-            const double df = a.sfeat[s] - B[i];
-            pr += (has_w ? a.cfw[s] : 1.0) * df * df;
-        }
-        pr = group16_sum(pr);
-        cost = sqrt(pr) / P;
+    for (int i = tid; i < P; i += 256) {
+        const int s = a.pidx[beg + i];
+        sA[i] = a.sfeat[s];
+        sW[i] = has_w ? a.cfw[s] : 1.0;
     }
-    if (sub == 0) a.U[(size_t)l * a.N + node] = a.absw[node] * cost;
+    __syncthreads();
+    if (a.simmeasure == 2) {
+        if (tid < 64) {  // one wavefront: moving-patch statistics
+            double sw = 0, ma = 0;
+            for (int i = tid; i < P; i += 64) {
+                sw += sW[i];
+                ma += sW[i] * sA[i];
+            }
+            sw = wave_sum(sw);
+            ma = wave_sum(ma);
+            if (sw > 0.0) ma /= sw;
+            double va = 0;
+            for (int i = tid; i < P; i += 64) {
+                const double da = sA[i] - ma;
+                va += sW[i] * da * da;
+            }
+            va = wave_sum(va);
+            if (tid == 0) s_stat[0] = sw, s_stat[1] = ma, s_stat[2] = va;
+        }
+        __syncthreads();
+    }
+    const double absw = a.absw[node];
+    for (int l = grp; l < a.L; l += 16) {
+        const double *B = a.tval + (size_t)a.L * beg + (size_t)l * P;
+        double cost;
+        if (a.simmeasure == 2) {  // sparsesimkernel::corr, M/similarities.cpp:129-158
+            const double sw = s_stat[0], ma = s_stat[1];
+            double mb = 0;
+            for (int i = sub; i < P; i += 16) mb += sW[i] * B[i];
+            mb = group16_sum(mb);
+            if (sw > 0.0) mb /= sw;
+            double pr = 0, vb = 0;
+            for (int i = sub; i < P; i += 16) {
+                const double da = sA[i] - ma, db = B[i] - mb;
+                pr += sW[i] * da * db;
+                vb += sW[i] * db * db;
+            }
+            pr = group16_sum(pr);
+            vb = group16_sum(vb);
+            double va = s_stat[2];
+            if (sw > 0.0) {
+                pr /= sw;
+                va /= sw;
+                vb /= sw;
+            }
+            const double r = (va == 0.0 || vb == 0.0) ? 0.0 : pr / (sqrt(va) * sqrt(vb));
+            cost = 1 - (1 + r) * 0.5;
+        } else {  // sparsesimkernel::SSD, M/similarities.cpp:179-188
+            double pr = 0;
+            for (int i = sub; i < P; i += 16) {
+                const double df = sA[i] - B[i];
+                pr += sW[i] * df * df;
+            }
+            pr = group16_sum(pr);
+            cost = sqrt(pr) / P;
+        }
+        if (sub == 0) a.U[(size_t)l * a.N + node] = absw * cost;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -736,7 +805,10 @@ static size_t samples_lds(int pmax, int L) {
     return sizeof(double) * (5 * (size_t)pmax + 9 * (size_t)L + (size_t)L * pmax) + sizeof(unsigned) * kQueueCap + sizeof(int) * 2 * kChunk;
 }
 
-int unary_nsplit(int L, int pmax) { return std::max(1, std::min(4, (int)(((size_t)L * pmax + kChunk - 1) / kChunk))); }
+int unary_nsplit(int L, int pmax) {
+    if (const char *e = std::getenv("MSMHIP_NSPLIT")) return std::max(1, std::min(L, atoi(e)));  // experiments only
+    return std::max(1, std::min(4, (int)(((size_t)L * pmax + kChunk - 1) / kChunk)));
+}
 int unary_fix_segments() { return kFixSegs; }
 size_t unary_fix_counter_words() { return (size_t)kCntStride * (1 + kFixSegs); }
 // samples of workgroup `block` of the unary sample kernels (the mapping at the top of k_unary_samples / k_unary_rays)
@@ -757,7 +829,7 @@ void unary_fix_offsets(int N, int L, int pmax, const int32_t *pptr, const int32_
     for (int s = 0; s < kFixSegs; ++s) off[s + 1] = (uint32_t)std::min<uint64_t>(0xffffffffull, off[s] + size[s]);
 }
 
-static bool uses_ray_table(const DevTree &t) { return t.simple && t.ray_G > 0 && t.ray_cell && t.ray_edge; }
+static bool uses_ray_table(const DevTree &t) { return t.simple && t.ray_G > 0 && t.ray_cell && t.ray_tri; }
 
 static int launch_samples(msm_ctx *ctx, const UnaryLaunch &u, const UnaryWeightsScratch *w, SamplesArgs &a) {
     if (u.tree.nnodes <= 0 || !u.tree.mask) return fail(MSM_ERR_STATE, "target search structure missing");
@@ -792,7 +864,6 @@ static int launch_samples(msm_ctx *ctx, const UnaryLaunch &u, const UnaryWeights
         if (lds > 160 * 1024) return fail(MSM_ERR_CAPACITY, "patch of %d points x %d labels does not fit in LDS", u.pmax, u.L);
         MSM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_unary_samples), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
-    MSM_HIP(hipMemsetAsync(u.fix_cnt, 0, unary_fix_counter_words() * sizeof(unsigned), ctx->stream));  // fix-up and redo counters
     a.nsplit = unary_nsplit(u.L, u.pmax);
     const int blocks = a.nsplit * 8 * ((u.N + 7) / 8);
     if (u.ev_start) MSM_HIP(hipEventRecord(u.ev_start, ctx->stream));
@@ -834,10 +905,12 @@ int launch_unary_univariate(msm_ctx *ctx, const UnaryLaunch &u) {
     r.redo_list = u.redo_list;
     r.redo_count = u.fix_cnt;
     if (uses_ray_table(u.tree)) {
-        const int evals = u.N * u.L;
-        hipLaunchKernelGGL(k_unary_reduce_flat, dim3((evals + 15) / 16), dim3(256), 0, ctx->stream, r);
+        r.redo_list = u.order;  // all control points, in launch order
+        hipLaunchKernelGGL(k_unary_reduce_flat, dim3(u.N), dim3(256), sizeof(double) * 2 * (size_t)u.pmax, ctx->stream, r, u.fix_cnt,
+                           (int)unary_fix_counter_words());
     } else {
         hipLaunchKernelGGL(k_unary_reduce_univariate, dim3(64), dim3(256), sizeof(double) * 2 * (size_t)u.pmax, ctx->stream, r);
+        MSM_HIP(hipMemsetAsync(u.fix_cnt, 0, unary_fix_counter_words() * sizeof(unsigned), ctx->stream));  // counters are zero between launches
     }
     MSM_HIP(hipGetLastError());
     return MSM_OK;
@@ -867,6 +940,7 @@ int launch_unary_multivariate(msm_ctx *ctx, const UnaryLaunch &u, const UnaryWei
     r.U = u.U;
     hipLaunchKernelGGL(k_unary_reduce_features, dim3(u.N), dim3(256), 0, ctx->stream, r);
     MSM_HIP(hipGetLastError());
+    MSM_HIP(hipMemsetAsync(u.fix_cnt, 0, unary_fix_counter_words() * sizeof(unsigned), ctx->stream));  // counters are zero between launches
     return MSM_OK;
 }
 
