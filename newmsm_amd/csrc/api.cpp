@@ -99,6 +99,12 @@ int ensure_rays(msm_mesh *m) {
         MSM_HIP(grow((void **)&m->d_ray_edge, m->cap_ray_edge, m->tree.ray_edge.size(), sizeof(float4)));
         MSM_HIP(hipMemcpyAsync(m->d_ray_cell, m->tree.ray_cell.data(), m->tree.ray_cell.size() * sizeof(int4), hipMemcpyHostToDevice, ctx->stream));
         MSM_HIP(hipMemcpyAsync(m->d_ray_edge, m->tree.ray_edge.data(), m->tree.ray_edge.size() * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
+        MSM_HIP(grow((void **)&m->d_ray_more, m->cap_ray_more, m->tree.ray_more.size() + 1, sizeof(int4)));
+        MSM_HIP(grow((void **)&m->d_ray_excl, m->cap_ray_excl, m->tree.ray_excl.size() + 1, sizeof(int4)));
+        if (!m->tree.ray_more.empty())
+            MSM_HIP(hipMemcpyAsync(m->d_ray_more, m->tree.ray_more.data(), m->tree.ray_more.size() * sizeof(int4), hipMemcpyHostToDevice, ctx->stream));
+        if (!m->tree.ray_excl.empty())
+            MSM_HIP(hipMemcpyAsync(m->d_ray_excl, m->tree.ray_excl.data(), m->tree.ray_excl.size() * sizeof(int4), hipMemcpyHostToDevice, ctx->stream));
         MSM_HIP(hipStreamSynchronize(ctx->stream));
         m->rayrec_valid = false;
     }
@@ -136,6 +142,8 @@ DevTree dev_tree(const msm_mesh *m) {
     t.ray_G = m->rays_valid ? m->tree.ray_G : 0;
     t.ray_cell = m->d_ray_cell;
     t.ray_tri = m->d_ray_tri;
+    t.ray_more = m->d_ray_more;
+    t.ray_excl = m->d_ray_excl;
     t.ray_r2lo = m->tree.ray_r2lo;
     t.ray_r2hi = m->tree.ray_r2hi;
     return t;
@@ -377,7 +385,7 @@ void msm_mesh_destroy(msm_mesh *m) {
     if (!m) return;
     (void)hipSetDevice(m->ctx->device);
     (void)hipStreamSynchronize(m->ctx->stream);
-    for (void *p : {(void *)m->d_xyz, (void *)m->d_feat, (void *)m->d_node, (void *)m->d_parent, (void *)m->d_leaf_tri, (void *)m->d_cone, (void *)m->d_rec, (void *)m->d_grid, (void *)m->d_nodebox, (void *)m->d_mask, (void *)m->d_ray_cell, (void *)m->d_ray_edge, (void *)m->d_ray_tri})
+    for (void *p : {(void *)m->d_xyz, (void *)m->d_feat, (void *)m->d_node, (void *)m->d_parent, (void *)m->d_leaf_tri, (void *)m->d_cone, (void *)m->d_rec, (void *)m->d_grid, (void *)m->d_nodebox, (void *)m->d_mask, (void *)m->d_ray_cell, (void *)m->d_ray_edge, (void *)m->d_ray_tri, (void *)m->d_ray_more, (void *)m->d_ray_excl})
         if (p) (void)hipFree(p);
     delete m;
 }

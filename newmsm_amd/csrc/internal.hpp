@@ -74,7 +74,9 @@ struct FlatOctree {
     // Ray table of a simple surface (octree.cpp: build_ray_table); ray_G == 0 when absent.
     int ray_G = 0;                   // cube-map cells per face axis
     std::vector<int4> ray_cell;      // 6 x G x G: up to four candidate triangles per direction cell, -1 padded
-    std::vector<float4> ray_edge;    // 3 per triangle: inward unit normal of the plane (origin, edge k), acceptance threshold
+    std::vector<float4> ray_edge;    // 3 per triangle: inward unit normal of the plane (origin, edge k); .w: see octree.cpp
+    std::vector<int4> ray_more;      // candidates 4..7 of the cells that have more than four
+    std::vector<int4> ray_excl;      // up to three leaf boxes a query must not lie in for its triangle to be vouched for (.w = count)
     double ray_r2lo = 0, ray_r2hi = 0;  // squared radius range of the query points the table is valid for
     int64_t stats[5] = {0, 0, 0, 0, 0};
 };
@@ -100,6 +102,7 @@ struct DevTree {
     int ray_G;
     const int4 *ray_cell;
     const float4 *ray_tri;   // kRayPieces float4 per triangle
+    const int4 *ray_more, *ray_excl;
     double ray_r2lo, ray_r2hi;
 };
 
@@ -138,6 +141,8 @@ struct msm_mesh {
     int4 *d_ray_cell = nullptr;
     float4 *d_ray_edge = nullptr;
     float4 *d_ray_tri = nullptr;
+    int4 *d_ray_more = nullptr, *d_ray_excl = nullptr;
+    size_t cap_ray_more = 0, cap_ray_excl = 0;
     bool rayrec_valid = false;  // d_ray_tri matches the current coordinates and features
     size_t cap_ray_cell = 0, cap_ray_edge = 0, cap_ray_rec = 0;
     size_t cap_node = 0, cap_parent = 0, cap_box = 0, cap_leaf = 0, cap_cone = 0, cap_rec = 0, cap_grid = 0, cap_mask = 0;  // one per buffer

@@ -205,8 +205,9 @@ std::vector<double> safe_margins(const double *xyz, const int32_t *tri, int V, i
     return margin;
 }
 
-// Is triangle t listed in every leaf whose closed box meets [lo, hi]?
-bool region_covered(const FlatOctree &o, int n, const double lo[3], const double hi[3], int t) {
+// The leaves whose closed box meets [lo, hi] but which do not list triangle t (at most `cap` are collected; returns
+// false when there are more)
+bool lacking_leaves(const FlatOctree &o, int n, const double lo[3], const double hi[3], int t, int cap, std::vector<int> &lack) {
     const double4 box = o.nodebox[n];
     const double blo[3] = {box.x, box.y, box.z};
     for (int a = 0; a < 3; ++a)
@@ -214,10 +215,13 @@ bool region_covered(const FlatOctree &o, int n, const double lo[3], const double
     const int4 nd = o.node[n];
     if (nd.x < 0) {
         const int32_t *first = o.leaf_tri.data() + nd.y, *last = first + (-nd.x - 1);
-        return std::find(first, last, t) != last;
+        if (std::find(first, last, t) != last) return true;
+        if ((int)lack.size() >= cap) return false;
+        lack.push_back(n);
+        return true;
     }
     for (int c = 0; c < 8; ++c)
-        if (!region_covered(o, nd.x + c, lo, hi, t)) return false;
+        if (!lacking_leaves(o, nd.x + c, lo, hi, t, cap, lack)) return false;
     return true;
 }
 
@@ -233,8 +237,12 @@ bool region_covered(const FlatOctree &o, int n, const double lo[3], const double
 //                the stored threshold adds 3e-6 for the float evaluation (direction 2e-7, normals 6e-8, dot 2e-7);
 //   robustness   every point of the shell kRayShell around radius 100 whose direction lies in t's spherical triangle
 //                is within `sag` of the flat triangle scaled to that radius; if every leaf meeting the AABB of that
-//                region lists t, (1) holds for every such p.  Triangles that fail get a threshold nothing passes.
-// The cube-map cells only propose candidates (up to four, likeliest first); a miss just means the complete search.
+//                region lists t, (1) holds for every such p.  Up to three leaves that do not list t are recorded as
+//                exclusion boxes (ray_excl): (1) then holds for every p outside those leaves, and p's leaf at depth d
+//                is found arithmetically (child boxes are exact halvings).  More than three: a threshold nothing passes.
+// Record layout (three float4 per triangle): {n0, thr} {n1, bits of the ray_excl index or -1} {n2, 0}.
+// The cube-map cells only propose candidates, likeliest first: {c0,c1,c2,c3}, or {c0,c1,c2,-2-k} with c3..c6 in
+// ray_more[k]; a miss just means the complete search.
 // ------------------------------------------------------------------------------------------------
 constexpr double kRayShell = 1e-4;
 
@@ -253,6 +261,9 @@ void build_ray_table(const double *xyz, const int32_t *tri, int V, int T, FlatOc
     const std::vector<double> margin = safe_margins(xyz, tri, V, T);
     TICK("margins");
     out.ray_edge.assign((size_t)3 * T, make_float4(0.f, 0.f, 0.f, 2.f));
+    out.ray_excl.clear();
+    out.ray_more.clear();
+    std::vector<int> lack;
     out.ray_r2lo = (kRad - kRayShell) * (kRad - kRayShell);
     out.ray_r2hi = (kRad + kRayShell) * (kRad + kRayShell);
     std::vector<char> usable(T, 0);
@@ -291,7 +302,8 @@ void build_ray_table(const double *xyz, const int32_t *tri, int V, int T, FlatOc
             lo[a] -= sag;
             hi[a] += sag;
         }
-        if (!region_covered(out, 0, lo, hi, t)) continue;
+        lack.clear();
+        if (!lacking_leaves(out, 0, lo, hi, t, 3, lack)) continue;
         // (2): edge planes; edge k is opposite vertex k (same_side(p, v_k, v_k+1, v_k+2), R/point.cpp:41-44)
         float4 e[3];
         for (int k = 0; k < 3 && ok; ++k) {
@@ -307,6 +319,27 @@ void build_ray_table(const double *xyz, const int32_t *tri, int V, int T, FlatOc
             if (!((double)e[k].w >= thr)) e[k].w = std::nextafterf(e[k].w, 1.f);  // round the threshold up
         }
         if (!ok) continue;
+        int excl = -1;
+        if (!lack.empty()) {  // leaf boxes as depth << 24 | ix << 16 | iy << 8 | iz (depth <= 8: coordinates fit 8 bits)
+            int4 boxes = make_int4(-1, -1, -1, (int)lack.size());
+            int32_t *bx = &boxes.x;
+            for (size_t j = 0; j < lack.size() && ok; ++j) {
+                const double4 nb = out.nodebox[lack[j]];
+                const int d = out.node[lack[j]].w;
+                if (d > 8) {
+                    ok = false;
+                    break;
+                }
+                const double size = 2 * kBounds / (double)(1 << d);
+                const int ix = (int)std::lround((nb.x + kBounds) / size), iy = (int)std::lround((nb.y + kBounds) / size), iz = (int)std::lround((nb.z + kBounds) / size);
+                bx[j] = (d << 24) | (ix << 16) | (iy << 8) | iz;
+            }
+            if (!ok) continue;
+            excl = (int)out.ray_excl.size();
+            out.ray_excl.push_back(boxes);
+        }
+        e[1].w = __builtin_bit_cast(float, (int32_t)excl);
+        e[2].w = 0.f;
         for (int k = 0; k < 3; ++k) out.ray_edge[(size_t)3 * t + k] = e[k];
         usable[t] = 1;
     }
@@ -390,7 +423,17 @@ void build_ray_table(const double *xyz, const int32_t *tri, int V, int T, FlatOc
         Cand *first = cand.data() + count[c], *last = cand.data() + count[c + 1];
         std::sort(first, last, [](const Cand &x, const Cand &y) { return x.score < y.score || (x.score == y.score && x.tri < y.tri); });
         int32_t *slot = &out.ray_cell[c].x;
-        for (int k = 0; k < 4 && first + k < last; ++k) slot[k] = first[k].tri;
+        const int ncand = (int)(last - first);
+        if (ncand <= 4) {
+            for (int k = 0; k < ncand; ++k) slot[k] = first[k].tri;
+        } else {
+            for (int k = 0; k < 3; ++k) slot[k] = first[k].tri;
+            slot[3] = -2 - (int)out.ray_more.size();
+            int4 more = make_int4(-1, -1, -1, -1);
+            int32_t *ms = &more.x;
+            for (int k = 0; k < 4 && 3 + k < ncand; ++k) ms[k] = first[3 + k].tri;
+            out.ray_more.push_back(more);
+        }
     }
     TICK("cells");
 }

@@ -66,13 +66,17 @@ __device__ __forceinline__ int4 ray_cell_of(const DevTree &T, const V3 &p, float
     return T.ray_cell[((size_t)face * G + iu) * G + iv];
 }
 
-// the acceptance test of one candidate: all three edge-plane products at or above their thresholds
+// the acceptance test of one candidate: all three edge-plane products at or above the triangle's threshold (e0.w)
 __device__ __forceinline__ bool ray_accepts(const float4 &e0, const float4 &e1, const float4 &e2, float fx, float fy, float fz) {
     const float d0 = __builtin_fmaf(e0.z, fz, __builtin_fmaf(e0.y, fy, e0.x * fx));
     const float d1 = __builtin_fmaf(e1.z, fz, __builtin_fmaf(e1.y, fy, e1.x * fx));
     const float d2 = __builtin_fmaf(e2.z, fz, __builtin_fmaf(e2.y, fy, e2.x * fx));
-    return (int)(d0 >= e0.w) & (int)(d1 >= e1.w) & (int)(d2 >= e2.w);
+    return (int)(d0 >= e0.w) & (int)(d1 >= e0.w) & (int)(d2 >= e0.w);
 }
+
+// Is the accepted triangle listed in the octree leaf p descends to?  Yes unless p lies in one of the (at most three)
+// leaf boxes recorded for the triangle (octree.cpp: build_ray_table); e1.w carries the index of that record, or -1.
+__device__ __forceinline__ bool ray_vouches(const DevTree &T, const float4 &e1, const V3 &p);
 
 __device__ __forceinline__ double candidate_distance(const DevTree &T, int t, const V3 &p) {
     const TriRec &r = T.rec[t];
@@ -177,8 +181,26 @@ __device__ __forceinline__ int grid_axis(double p, int G, double h) {
     return (p == p) ? i : G - 1;  // NaN: every child "contains" it, the last one wins
 }
 
+__device__ __forceinline__ bool ray_vouches(const DevTree &T, const float4 &e1, const V3 &p) {
+    const int k = __float_as_int(e1.w);
+    if (k < 0) return true;
+    const int4 b = T.ray_excl[k];
+    const int box[3] = {b.x, b.y, b.z};
+    bool clear = true;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        if (j >= b.w) continue;
+        const int d = box[j] >> 24, G = 1 << d;
+        const double h = 2 * kBounds / G;
+        const bool inside = grid_axis(p.x, G, h) == ((box[j] >> 16) & 0xff) && grid_axis(p.y, G, h) == ((box[j] >> 8) & 0xff) &&
+                            grid_axis(p.z, G, h) == (box[j] & 0xff);
+        clear = clear && !inside;
+    }
+    return clear;
+}
+
 // Returns the triangle id (>= 0), or MSM_ERR_OUTSIDE / MSM_ERR_NOTFOUND.
-__device__ __forceinline__ int find_closest_triangle(const DevTree &T, const V3 &p) {
+__device__ __forceinline__ int find_closest_triangle(const DevTree &T, const V3 &p, bool allow_fallback = true) {
     // Node::contains_point of the root, R/node.cpp:58-68 (written so that NaN behaves as in the reference)
     if (p.x < -kBounds || p.x > kBounds || p.y < -kBounds || p.y > kBounds || p.z < -kBounds || p.z > kBounds) return MSM_ERR_OUTSIDE;
     const int G = 1 << T.grid_depth;
@@ -214,6 +236,7 @@ __device__ __forceinline__ int find_closest_triangle(const DevTree &T, const V3 
     if (s.best >= 0) return s.best;
 
     // rare: nothing in the leaf contains the projection
+    if (!allow_fallback) return MSM_ERR_NOTFOUND;  // profiling variants only
     return fallback_search(T, n, p, fx, fy, fz);
 }
 

@@ -461,21 +461,32 @@ __global__ __launch_bounds__(256) void k_unary_rays(SamplesArgs a) {
                 const double2 *dv = reinterpret_cast<const double2 *>(rec + 3);
                 double2 d0 = dv[0], d1 = dv[1], d2 = dv[2], d3 = dv[3], d4 = dv[4], d5 = dv[5];
                 int t = c.x;
+                bool vouch_needed = __float_as_int(e1.w) >= 0;
+                float4 ev = e1;
                 if (!ray_accepts(e0, e1, e2, fx, fy, fz)) {
                     t = -1;
-                    const int more[3] = {c.y, c.z, c.w};
+                    int more[7] = {c.y, c.z, c.w, -1, -1, -1, -1};
+                    if (c.w < -1) {  // a cell with more than four candidates
+                        const int4 mo = a.tree.ray_more[-2 - c.w];
+                        more[2] = mo.x, more[3] = mo.y, more[4] = mo.z, more[5] = mo.w;
+                    }
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) {
+                    for (int k = 0; k < 6; ++k) {
                         if (t >= 0 || more[k] < 0) continue;
                         const float4 *r2 = a.tree.ray_tri + (size_t)kRayPieces * more[k];
                         const float4 g0 = r2[0], g1 = r2[1], g2 = r2[2];
-                        if (ray_accepts(g0, g1, g2, fx, fy, fz)) t = more[k];
+                        if (ray_accepts(g0, g1, g2, fx, fy, fz)) {
+                            t = more[k];
+                            ev = g1;
+                            vouch_needed = __float_as_int(g1.w) >= 0;
+                        }
                     }
                     if (t >= 0) {
                         dv = reinterpret_cast<const double2 *>(a.tree.ray_tri + (size_t)kRayPieces * t + 3);
                         d0 = dv[0], d1 = dv[1], d2 = dv[2], d3 = dv[3], d4 = dv[4], d5 = dv[5];
                     }
                 }
+                if (t >= 0 && vouch_needed && !ray_vouches(a.tree, ev, p)) t = -1;  // its leaf may not list the triangle
                 if (t >= 0) {
                     double wa, wb, wc;
                     area_weights(mk(d0.x, d0.y, d1.x), mk(d1.y, d2.x, d2.y), mk(d3.x, d3.y, d4.x), p, wa, wb, wc);
@@ -516,8 +527,15 @@ __global__ __launch_bounds__(256) void k_unary_rays(SamplesArgs a) {
     }
 }
 
-// the rare samples: complete reference search (several containing triangles -> dist_to_point tie-break; none ->
-// sibling leaves, then nearest vertex)
+// The listed samples, eight lanes each.  The list is short (a few per cent of the samples at most), so what
+// counts is the length of one wavefront's dependent chain, not throughput: with a lane per sample the exact
+// tests of 64 lanes end up at 64 different loop positions and run one after the other (32 us for 2 % of an ico6
+// table).  Here the eight lanes of a group share the point and split the leaf's entries (entry e goes to lane
+// e % 8): sub-cell mask bit, cone test, exact inside test -- every lane at most 8 times, and the tests of one round
+// run together.  Exactly one containing triangle = the reference's answer (R/octree.cpp:166-178: a single passing
+// triangle wins whatever its distance); anything else (tie-break by dist_to_point, sibling leaves, nearest vertex,
+// oversized leaves) is redone by the group's first lane with the complete search of search_device.hpp (with the
+// exclusion boxes and overflow candidates of the ray table these are a handful per table).
 __global__ __launch_bounds__(256) void k_unary_fixup(SamplesArgs a) {
     // dense index over the segments: prefix sums of the segment counts (one wavefront, kFixSegs == 64)
     __shared__ unsigned s_pre[kFixSegs + 1];
@@ -535,21 +553,100 @@ __global__ __launch_bounds__(256) void k_unary_fixup(SamplesArgs a) {
     }
     __syncthreads();
     const unsigned n = s_pre[kFixSegs];
-    for (unsigned j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
-        int seg = 0;
+    const int lane = threadIdx.x & 63, sub = lane & 7, grp = lane >> 3;
+    const unsigned per_block = 256 / 8, stride = gridDim.x * per_block;
+    // wavefront-uniform loop: the ballots below need all 64 lanes
+    for (unsigned j0 = blockIdx.x * per_block + (threadIdx.x >> 6) * 8; j0 < n; j0 += stride) {
+        const unsigned j = j0 + grp;
+        const bool valid = j < n;
+        V3 p = mk(0.0, 0.0, 0.0);
+        size_t g = 0;
+        int4 leaf = make_int4(-1, 0, -1, 0);
+        unsigned long long mm = 0ull;
+        float fx = 0.f, fy = 0.f, fz = 0.f;
+        bool serial = false;  // this sample needs the complete search
+        if (valid) {
+            int seg = 0;
 #pragma unroll
-        for (int step = kFixSegs / 2; step > 0; step >>= 1)
-            if (s_pre[seg + step] <= j) seg += step;
-        const unsigned long long e = a.fix_list[a.fix_off[seg] + (j - s_pre[seg])];
-        const int node = (int)(e >> 32), s = (int)(e & 0xffffffffu);
-        const int beg = a.pptr[node], P = a.pptr[node + 1] - beg;
-        const int l = s / P, i = s - l * P;
-        const int sv = a.pidx[beg + i];
-        const V3 p = rotate(a.rnl + ((size_t)node * a.L + l) * 9, mk(a.src[sv], a.src[a.Nsrc + sv], a.src[2 * a.Nsrc + sv]));
-        const size_t g = (size_t)a.L * beg + s;
-        const int t = find_closest_triangle(a.tree, p);
-        if (t < 0) emit_failure(a, g, t);
-        else emit_sample(a, g, p, t);
+            for (int step = kFixSegs / 2; step > 0; step >>= 1)
+                if (s_pre[seg + step] <= j) seg += step;
+            const unsigned long long e = a.fix_list[a.fix_off[seg] + (j - s_pre[seg])];
+            const int node = (int)(e >> 32), s = (int)(e & 0xffffffffu);
+            const int beg = a.pptr[node], P = a.pptr[node + 1] - beg;
+            const int l = s / P, i = s - l * P;
+            const int sv = a.pidx[beg + i];
+            p = rotate(a.rnl + ((size_t)node * a.L + l) * 9, mk(a.src[sv], a.src[a.Nsrc + sv], a.src[2 * a.Nsrc + sv]));
+            g = (size_t)a.L * beg + s;
+            if (outside_root(p) || !(p.x == p.x && p.y == p.y && p.z == p.z)) {
+                serial = true;  // the complete search reports it
+            } else {
+                int subcell;
+                leaf = locate_leaf(a.tree, p, subcell);
+                if (leaf.z < 0) {
+                    serial = true;  // empty or oversized leaf: no masks
+                } else {
+                    mm = a.tree.mask[(size_t)leaf.z * 64 + subcell];
+                    const float qx = (float)p.x, qy = (float)p.y, qz = (float)p.z;
+                    const float inv = rsqrtf(qx * qx + qy * qy + qz * qz);
+                    fx = qx * inv, fy = qy * inv, fz = qz * inv;
+                }
+            }
+        }
+        unsigned long long hits = 0ull;  // entries whose triangle contains the projection (same in all lanes of a group)
+        // lane `sub` of the group takes the sub-th, (sub+8)-th, ... set bit of the mask: ceil(popcount / 8) rounds
+        unsigned long long mine = (valid && !serial) ? mm : 0ull;
+        for (int k = 0; k < sub; ++k) mine &= mine - 1ull;
+        while (__any(mine != 0ull)) {
+            bool hit = false;
+            int e = 0;
+            if (mine) {
+                e = __ffsll((long long)mine) - 1;
+                const float4 c = a.tree.cone[leaf.y + e];
+                const float dt = fabsf(__builtin_fmaf(c.z, fz, __builtin_fmaf(c.y, fy, c.x * fx)));
+                if (dt >= c.w) {
+                    V3 mp;
+                    hit = inside_test(a.tree.rec[a.tree.leaf_tri[leaf.y + e]], p, mp);
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) mine &= mine - 1ull;  // my next bit is eight set bits further
+            }
+            // gather the group's hits: each lane contributes one entry index
+            const unsigned long long bal = __ballot(hit);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int ek = __shfl(e, (lane & ~7) | k, 64);
+                if ((bal >> ((lane & ~7) | k)) & 1ull) hits |= 1ull << ek;
+            }
+        }
+        // Several containing triangles (the point sits in the -1e-8 band of an edge): the reference keeps the first and
+        // replaces it by a later one only if that one's dist_to_point is strictly smaller (R/octree.cpp:172-178).
+        // The owner lane of each hit evaluates its distance, the group follows the hits in entry order.
+        int win = -1;
+        {
+            double bestd = 0.0;
+            unsigned long long rest = (valid && !serial && __popcll(hits) >= 2) ? hits : 0ull;
+            while (__any(rest != 0ull)) {
+                const int e = rest ? __ffsll((long long)rest) - 1 : 0;
+                double d = 0.0;
+                if (rest && (e & 7) == sub) d = candidate_distance(a.tree, a.tree.leaf_tri[leaf.y + e], p);
+                d = __shfl(d, (lane & ~7) | (e & 7), 64);
+                if (rest) {
+                    if (win < 0 || (d > -1.0 && d < bestd)) {
+                        win = e;
+                        bestd = d;
+                    }
+                    rest &= rest - 1ull;
+                }
+            }
+        }
+        if (valid && sub == 0) {
+            int t;
+            if (!serial && __popcll(hits) == 1) t = a.tree.leaf_tri[leaf.y + __ffsll((long long)hits) - 1];
+            else if (win >= 0) t = a.tree.leaf_tri[leaf.y + win];
+            else t = find_closest_triangle(a.tree, p);  // nothing in the leaf, no masks, outside the root: the complete search
+            if (t < 0) emit_failure(a, g, t);
+            else emit_sample(a, g, p, t);
+        }
     }
 }
 
@@ -596,13 +693,17 @@ __global__ __launch_bounds__(256) void k_unary_reduce_univariate(ReduceArgs a) {
 }
 
 // The same reduction for a whole table whose samples all sit in tval (ray-table path): one workgroup per control
-// point stages the moving patch (feature, weight) in LDS once; a 16-lane group per label then reads that label's
-// sampled target patch (contiguous in tval) -- 16 labels per pass, the 16-lane sums are DPP row operations.
-// The weighted mean and variance of the moving patch do not depend on the label and are computed once.
-// The last kernel of a ray-table launch also clears the fix-up counters for the next one.
-__device__ __forceinline__ double group16_sum(double v) {
+// point stages the moving patch (feature, weight) in LDS once; an 8-lane group per label (32 labels per pass) reads
+// that label's sampled target patch, contiguous in tval, into registers while the staging loads are still in
+// flight -- the kernel is a chain of dependent loads, so they are issued as early as they can be.  The 8-lane sums
+// are DPP row operations.  The weighted mean and variance of the moving patch do not depend on the label and are
+// computed once.  The last kernel of a ray-table launch also clears the fix-up counters for the next one.
+constexpr int kRedLanes = 8;      // lanes per label
+constexpr int kRedKeep = 12;      // target values per lane kept in registers (patches up to 96 points)
+
+__device__ __forceinline__ double group_sum(double v) {
 #pragma unroll
-    for (int off = 8; off > 0; off >>= 1) v += __shfl_xor(v, off, 16);
+    for (int off = kRedLanes / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, kRedLanes);
     return v;
 }
 
@@ -610,12 +711,21 @@ __global__ __launch_bounds__(256) void k_unary_reduce_flat(ReduceArgs a, unsigne
     extern __shared__ __align__(16) double lds[];
     double *sA = lds, *sW = sA + a.pmax;
     __shared__ double s_stat[3];  // sum of weights, weighted mean of A, weighted variance sum of A
-    const int tid = threadIdx.x, sub = tid & 15, grp = tid >> 4;
+    const int tid = threadIdx.x, sub = tid & (kRedLanes - 1), grp = tid / kRedLanes;
     if (blockIdx.x == 0 && clear)
         for (int k = tid; k < clear_words; k += 256) clear[k] = 0u;
     const int node = a.redo_list ? a.redo_list[blockIdx.x] : (int)blockIdx.x;  // launch order = Morton order
     const int beg = a.pptr[node], P = a.pptr[node + 1] - beg;
     const bool has_w = a.cfw && a.cfw_rows >= 1;
+    const bool in_regs = true;  // the first kRedKeep values per lane always travel through registers
+    double breg[kRedKeep];
+#pragma unroll
+    for (int k = 0; k < kRedKeep; ++k) breg[k] = 0.0;
+    if (grp < a.L) {
+        const double *B = a.tval + (size_t)a.L * beg + (size_t)grp * P;
+#pragma unroll
+        for (int k = 0; k < kRedKeep; ++k) breg[k] = (sub + kRedLanes * k < P) ? B[sub + kRedLanes * k] : 0.0;
+    }
     for (int i = tid; i < P; i += 256) {
         const int s = a.pidx[beg + i];
         sA[i] = a.sfeat[s];
@@ -643,23 +753,41 @@ __global__ __launch_bounds__(256) void k_unary_reduce_flat(ReduceArgs a, unsigne
         __syncthreads();
     }
     const double absw = a.absw[node];
-    for (int l = grp; l < a.L; l += 16) {
+    for (int l = grp; l < a.L; l += 256 / kRedLanes) {
         const double *B = a.tval + (size_t)a.L * beg + (size_t)l * P;
+        if (!(in_regs && l == grp)) {  // not prefetched: more than 32 labels, or a patch too big for the registers
+#pragma unroll
+            for (int k = 0; k < kRedKeep; ++k) breg[k] = (sub + kRedLanes * k < P) ? B[sub + kRedLanes * k] : 0.0;
+        }
         double cost;
         if (a.simmeasure == 2) {  // sparsesimkernel::corr, M/similarities.cpp:129-158
             const double sw = s_stat[0], ma = s_stat[1];
             double mb = 0;
-            for (int i = sub; i < P; i += 16) mb += sW[i] * B[i];
-            mb = group16_sum(mb);
+#pragma unroll
+            for (int k = 0; k < kRedKeep; ++k) {
+                const int i = sub + kRedLanes * k;
+                if (i < P) mb += sW[i] * breg[k];
+            }
+            for (int i = sub + kRedLanes * kRedKeep; i < P; i += kRedLanes) mb += sW[i] * B[i];
+            mb = group_sum(mb);
             if (sw > 0.0) mb /= sw;
             double pr = 0, vb = 0;
-            for (int i = sub; i < P; i += 16) {
+#pragma unroll
+            for (int k = 0; k < kRedKeep; ++k) {
+                const int i = sub + kRedLanes * k;
+                if (i < P) {
+                    const double da = sA[i] - ma, db = breg[k] - mb;
+                    pr += sW[i] * da * db;
+                    vb += sW[i] * db * db;
+                }
+            }
+            for (int i = sub + kRedLanes * kRedKeep; i < P; i += kRedLanes) {
                 const double da = sA[i] - ma, db = B[i] - mb;
                 pr += sW[i] * da * db;
                 vb += sW[i] * db * db;
             }
-            pr = group16_sum(pr);
-            vb = group16_sum(vb);
+            pr = group_sum(pr);
+            vb = group_sum(vb);
             double va = s_stat[2];
             if (sw > 0.0) {
                 pr /= sw;
@@ -670,11 +798,19 @@ __global__ __launch_bounds__(256) void k_unary_reduce_flat(ReduceArgs a, unsigne
             cost = 1 - (1 + r) * 0.5;
         } else {  // sparsesimkernel::SSD, M/similarities.cpp:179-188
             double pr = 0;
-            for (int i = sub; i < P; i += 16) {
+#pragma unroll
+            for (int k = 0; k < kRedKeep; ++k) {
+                const int i = sub + kRedLanes * k;
+                if (i < P) {
+                    const double df = sA[i] - breg[k];
+                    pr += sW[i] * df * df;
+                }
+            }
+            for (int i = sub + kRedLanes * kRedKeep; i < P; i += kRedLanes) {
                 const double df = sA[i] - B[i];
                 pr += sW[i] * df * df;
             }
-            pr = group16_sum(pr);
+            pr = group_sum(pr);
             cost = sqrt(pr) / P;
         }
         if (sub == 0) a.U[(size_t)l * a.N + node] = absw * cost;
@@ -878,7 +1014,7 @@ static int launch_samples(msm_ctx *ctx, const UnaryLaunch &u, const UnaryWeights
     }
     MSM_HIP(hipGetLastError());
     if (u.ev_stop) MSM_HIP(hipEventRecord(u.ev_stop, ctx->stream));
-    hipLaunchKernelGGL(k_unary_fixup, dim3(512), dim3(256), 0, ctx->stream, a);
+    hipLaunchKernelGGL(k_unary_fixup, dim3(4096), dim3(256), 0, ctx->stream, a);
     MSM_HIP(hipGetLastError());
     return MSM_OK;
 }
