@@ -408,10 +408,11 @@ __global__ __launch_bounds__(256) void k_unary_samples(SamplesArgs a) {
 // The kernel is bound by the vector L1's line-lookup rate (one 128-byte line per cycle per CU: a load whose 64
 // lanes hit 64 different lines costs 64 cycles, whatever its width), not by HBM or the ALUs: about 13 line
 // lookups per sample (cell 1, edge planes 3, vertices + features 6, retries) = 4.1e7 per table, 161 k cycles per CU.
-// A variant in which the wavefront fetches the 64 records as a team (lane j of load k reads piece (64k+j) % 9 of the
-// record of lane (64k+j) / 9, straight into LDS with global_load_lds_dwordx4) halved the lookups but doubled the
-// VALU work (four candidate rounds per wavefront) and, at 9 KB of LDS per wavefront, cut the occupancy: 123 us
-// against 86 us for the plain per-lane loads below.
+// Two variants in which the wavefront fetches the 64 records as a team (lane j of load k reads piece (64k+j) % 9 of
+// the record of lane (64k+j) / 9, straight into LDS with global_load_lds_dwordx4) halved the lookups, but at 9 KB of
+// LDS per wavefront they cut the occupancy to 3 waves per SIMD and lengthen the dependent chain (shuffle -> load ->
+// LDS -> test): 123 us (all four candidate rounds as a team) and 107 us (first candidate only) against 85 us for
+// the plain per-lane loads below.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_unary_rays(SamplesArgs a) {
     extern __shared__ __align__(16) double lds[];
@@ -448,11 +449,15 @@ __global__ __launch_bounds__(256) void k_unary_rays(SamplesArgs a) {
         const int s = s0 + tid;
         const bool act = s < send;
         bool done = false;
+        V3 p = mk(0.0, 0.0, 0.0);
+        float fx = 0.f, fy = 0.f, fz = 0.f;
+        int4 c = make_int4(-1, -1, -1, -1);
         if (act) {
             const int l = fast_div(s, P, invP), i = s - l * P;
-            const V3 p = rotate(sR + 9 * l, mk(sx[i], sy[i], sz[i]));
-            float fx, fy, fz;
-            const int4 c = ray_cell_of(a.tree, p, fx, fy, fz);
+            p = rotate(sR + 9 * l, mk(sx[i], sy[i], sz[i]));
+            c = ray_cell_of(a.tree, p, fx, fy, fz);
+        }
+        if (act) {
             if (c.x >= 0) {
                 // the first candidate is the answer three times out of four: its vertices are requested together with
                 // its edge planes, so a settled sample costs two dependent loads after the cell
@@ -465,18 +470,17 @@ __global__ __launch_bounds__(256) void k_unary_rays(SamplesArgs a) {
                 float4 ev = e1;
                 if (!ray_accepts(e0, e1, e2, fx, fy, fz)) {
                     t = -1;
-                    int more[7] = {c.y, c.z, c.w, -1, -1, -1, -1};
-                    if (c.w < -1) {  // a cell with more than four candidates
-                        const int4 mo = a.tree.ray_more[-2 - c.w];
-                        more[2] = mo.x, more[3] = mo.y, more[4] = mo.z, more[5] = mo.w;
-                    }
-#pragma unroll
-                    for (int k = 0; k < 6; ++k) {
-                        if (t >= 0 || more[k] < 0) continue;
-                        const float4 *r2 = a.tree.ray_tri + (size_t)kRayPieces * more[k];
+                    int4 mo = make_int4(c.w, -1, -1, -1);
+                    if (c.w < -1) mo = a.tree.ray_more[-2 - c.w];  // a cell with more than four candidates
+                    // a real loop, not unrolled: this path is taken by one lane in four and must not cost registers
+#pragma unroll 1
+                    for (int k = 0; k < 6 && t < 0; ++k) {
+                        const int ck = k == 0 ? c.y : (k == 1 ? c.z : (k == 2 ? mo.x : (k == 3 ? mo.y : (k == 4 ? mo.z : mo.w))));
+                        if (ck < 0) break;
+                        const float4 *r2 = a.tree.ray_tri + (size_t)kRayPieces * ck;
                         const float4 g0 = r2[0], g1 = r2[1], g2 = r2[2];
                         if (ray_accepts(g0, g1, g2, fx, fy, fz)) {
-                            t = more[k];
+                            t = ck;
                             ev = g1;
                             vouch_needed = __float_as_int(g1.w) >= 0;
                         }
@@ -1006,7 +1010,7 @@ static int launch_samples(msm_ctx *ctx, const UnaryLaunch &u, const UnaryWeights
     if (uses_ray_table(u.tree)) {
         a.U = nullptr;  // the reduction is a kernel of its own on this path
         const int lper = (u.L + a.nsplit - 1) / a.nsplit;
-        const size_t rays_lds = sizeof(double) * (3 * (size_t)u.pmax + 9 * (size_t)u.L) + sizeof(int) * (size_t)lper * u.pmax;
+        const size_t rays_lds = sizeof(double) * (3 * (size_t)u.pmax + 9 * (size_t)u.L) + sizeof(int) * ((size_t)lper * u.pmax + 4) + 16;
         if (rays_lds > 64 * 1024) MSM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_unary_rays), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rays_lds));
         hipLaunchKernelGGL(k_unary_rays, dim3(blocks), dim3(256), rays_lds, ctx->stream, a);
     } else {

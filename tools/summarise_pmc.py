@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""tools/summarise_pmc.py TAG -- averages the rocprofv3 counter_collection.csv files of tools/collect_profile.sh per
+kernel and writes gpurun_out/TAG_pmc.json (per-launch means, HBM traffic per launch, kernel time from the stats pass)."""
+import collections
+import csv
+import glob
+import json
+import sys
+
+tag = sys.argv[1]
+per = collections.defaultdict(dict)
+for d in sorted(glob.glob("gpurun_out/pmc_%s_*" % tag)):
+    for f in glob.glob(d + "/*/*counter_collection.csv"):
+        acc = collections.defaultdict(list)
+        for r in csv.DictReader(open(f)):
+            acc[(r["Kernel_Name"].split("(")[0], r["Counter_Name"])].append(float(r["Counter_Value"]))
+        for (k, c), v in acc.items():
+            per[k][c] = sum(v) / len(v)
+avg_ns = {}
+for r in csv.DictReader(open("gpurun_out/%s_kernel_stats.csv" % tag)):
+    avg_ns[r["Name"].split("(")[0]] = float(r["AverageNs"])
+out = {
+    "command": "rocprofv3 --kernel-trace --pmc <one counter set per pass> -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline",
+    "traffic_formula": "(2 * FETCH_SIZE + WRITE_SIZE) * 1024: FETCH_SIZE/WRITE_SIZE are reported in KiB; gfx950 FETCH_SIZE counts "
+                       "half of the bytes of wide reads (MI355X_MICROARCH.md, HBM section)",
+    "kernels": {},
+}
+for k, v in per.items():
+    if not k.startswith("msm::k_unary"):
+        continue
+    e = {"per_launch_mean": v, "kernel_avg_ns_from_kernel_stats": avg_ns.get(k)}
+    if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+        e["hbm_traffic_bytes_per_launch"] = (2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024
+    out["kernels"][k] = e
+json.dump(out, open("gpurun_out/%s_pmc.json" % tag, "w"), indent=1)
+for k, e in out["kernels"].items():
+    print(k, "avg_ns", e["kernel_avg_ns_from_kernel_stats"], "hbm_bytes", e.get("hbm_traffic_bytes_per_launch"))
