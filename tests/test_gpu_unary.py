@@ -101,3 +101,47 @@ def test_unary_table_irregular_and_folded_targets(ctx, noise, warp):
     Uo = oc.unary_table()
     assert np.isfinite(Uo).all()
     assert np.allclose(U, Uo, rtol=RTOL, atol=ATOL), np.max(np.abs(U - Uo))
+
+
+def test_ray_table_and_general_kernel_agree(ctx, monkeypatch):
+    # the same simple-surface target through both sampling kernels: identical triangles and weights, so the tables
+    # agree to the rounding of the two reduction orders (fused wavefront sums vs 8-lane groups)
+    inp = problem.pairwise_inputs(5, 3, D=1)
+    cf, oc, keep = run_pair(ctx, inp, "univariate")
+    U_ray = cf.computeUnaryCosts()
+    monkeypatch.setenv("MSMHIP_DISABLE_RAYTABLE", "1")  # read when the target's search structures are built
+    cf2, keep2 = problem.build_cost(ctx, inp, kind="univariate")
+    cf2.get_source_data()
+    U_gen = cf2.computeUnaryCosts()
+    monkeypatch.delenv("MSMHIP_DISABLE_RAYTABLE")
+    Uo = oc.unary_table()
+    assert np.allclose(U_ray, U_gen, rtol=1e-12, atol=1e-14), np.max(np.abs(U_ray - U_gen))
+    assert np.allclose(U_ray, Uo, rtol=RTOL, atol=ATOL) and np.allclose(U_gen, Uo, rtol=RTOL, atol=ATOL)
+
+
+def test_ray_table_multivariate_weights_are_bit_exact_with_general_kernel(ctx, monkeypatch):
+    # D > 1: the sampling kernels store (triangle, raw weights) per sample and one common kernel reduces them, so the
+    # two search paths must give bit-identical tables
+    inp = problem.pairwise_inputs(5, 3, D=3)
+    cf, keep = problem.build_cost(ctx, inp, kind="multivariate")
+    cf.get_source_data()
+    U_ray = cf.computeUnaryCosts()
+    monkeypatch.setenv("MSMHIP_DISABLE_RAYTABLE", "1")
+    cf2, keep2 = problem.build_cost(ctx, inp, kind="multivariate")
+    cf2.get_source_data()
+    U_gen = cf2.computeUnaryCosts()
+    monkeypatch.delenv("MSMHIP_DISABLE_RAYTABLE")
+    assert np.array_equal(U_ray, U_gen)
+
+
+@pytest.mark.parametrize("scale", [1.0 + 5e-5, 1.003, 0.99])
+def test_sources_off_the_sphere(ctx, scale):
+    # the ray table only vouches for queries within 1e-4 of radius 100; anything else must take the complete search
+    # and still give the reference's answer (the octree descends with the point itself, not its direction)
+    inp = problem.pairwise_inputs(4, 2, D=1)
+    inp["source_xyz"] = inp["source_xyz"] * scale
+    cf, oc, _ = run_pair(ctx, inp, "univariate")
+    U, Uo = cf.computeUnaryCosts(), oc.unary_table()
+    both = np.isfinite(Uo)
+    assert np.array_equal(np.isfinite(U), both)
+    assert np.allclose(U[both], Uo[both], rtol=RTOL, atol=ATOL)
