@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MSM_ABI_VERSION 1
+#define MSM_ABI_VERSION 2
 
 #define MSM_OK 0
 #define MSM_ERR_INVALID (-1)  /* bad argument / inconsistent sizes */
@@ -153,7 +153,7 @@ int msm_nearest_neighbour(msm_mesh *orig, const double *data, int32_t D, const d
 
 typedef struct msm_cost_params { /* set_parameters M/DiscreteCostFunction.cpp:119-133 */
     int32_t kind;        /* MSM_COST_* (chosen in initialize_cost_function M/DiscreteModel.cpp:43-61) */
-    int32_t simmeasure;  /* "simmeasure": 1 SSD, 2 correlation (4/5 DICE are not offloaded) */
+    int32_t simmeasure;  /* "simmeasure": 1 SSD, 2 correlation, 4 DICE, 5 genDICE (get_sim_for_min M/similarities.h:48-58) */
     int32_t rmode;       /* "regularisermode": 1 pairwise angle, 2/3 triangle strain */
     int32_t reserved;
     double  lambda;      /* "lambda" */
@@ -162,6 +162,7 @@ typedef struct msm_cost_params { /* set_parameters M/DiscreteCostFunction.cpp:11
     double  k_exp;       /* "kexponent" */
     double  rexp;        /* "exponent" */
     double  range;       /* "range" (_controlptrange) */
+    double  percentile;  /* "percentile" (DICE measures; M/similarities.h:68 default 0.75, must lie in (0,1)) */
 } msm_cost_params;
 
 msm_cost *msm_cost_create(msm_ctx *ctx, const msm_cost_params *params);

@@ -34,7 +34,7 @@ class GroupParams(C.Structure):
 class CostParams(C.Structure):
     _fields_ = [("kind", C.c_int32), ("simmeasure", C.c_int32), ("rmode", C.c_int32), ("reserved", C.c_int32),
                 ("lambda_", C.c_double), ("mu", C.c_double), ("kappa", C.c_double), ("k_exp", C.c_double),
-                ("rexp", C.c_double), ("range", C.c_double)]
+                ("rexp", C.c_double), ("range", C.c_double), ("percentile", C.c_double)]
 
 
 # name -> (restype, argtypes); mirrors include/msmhip.h one to one

@@ -271,9 +271,10 @@ def nearest_neighbour_interpolation(orig_mesh, data, q):
 class DiscreteCostFunction:
     """NonLinearSRegDiscreteCostFunction family behind the DiscreteCostFunction evaluator interface."""
 
-    def __init__(self, ctx, kind="univariate", simmeasure=2, rmode=3, lambda_=0.1, mu=0.1, kappa=10.0, k_exp=2.0, rexp=2.0, range_=1.0):
+    def __init__(self, ctx, kind="univariate", simmeasure=2, rmode=3, lambda_=0.1, mu=0.1, kappa=10.0, k_exp=2.0, rexp=2.0, range_=1.0,
+                 percentile=0.75):
         self.ctx = ctx
-        self.params = CostParams(KINDS[kind], simmeasure, rmode, 0, lambda_, mu, kappa, k_exp, rexp, range_)
+        self.params = CostParams(KINDS[kind], simmeasure, rmode, 0, lambda_, mu, kappa, k_exp, rexp, range_, percentile)
         self.h = lib().msm_cost_create(ctx.h, C.byref(self.params))
         if not self.h:
             raise MsmError(-1, lib().msm_last_error().decode())

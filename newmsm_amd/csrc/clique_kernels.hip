@@ -62,7 +62,11 @@ __device__ double triplet_likelihood(const CliqueArgs &a, int t, const int *id, 
             const TriRec &r = a.tree.rec[tt];
             return wa * a.tfeat[(size_t)r.id[0] * D] + wb * a.tfeat[(size_t)r.id[1] * D] + wc * a.tfeat[(size_t)r.id[2] * D];
         };
-        if (a.simmeasure == 2) {
+        if (a.simmeasure == 4 || a.simmeasure == 5) {
+            // DICE ranks every value against every other one: sample each point once (bins longer than the cache re-sample)
+            for (int i = 0; i < n && i < kBinCache; ++i) cache[i] = B(i);
+            cost = dice_serial(a.simmeasure, n, a.percentile, A, [&](int i) { return i < kBinCache ? cache[i] : B(i); });
+        } else if (a.simmeasure == 2) {
             double prod = 0.0, varA = 0.0, varB = 0.0, meanA = 0.0, meanB = 0.0, sum = 0.0;
             for (int i = 0; i < n; ++i) sum += W(i);
             for (int i = 0; i < n; ++i) {
@@ -108,7 +112,7 @@ __device__ double triplet_likelihood(const CliqueArgs &a, int t, const int *id, 
             }
             const TriRec &r = a.tree.rec[tt];
             const double *f0 = a.tfeat + (size_t)r.id[0] * D, *f1 = a.tfeat + (size_t)r.id[1] * D, *f2 = a.tfeat + (size_t)r.id[2] * D;
-            cost += feature_vector_similarity(a.simmeasure, a.sfeat, a.cfw, a.cfw_rows, a.Nsrc, sv, D, f0, f1, f2, wa, wb, wc);
+            cost += feature_vector_similarity(a.simmeasure, a.percentile, a.sfeat, a.cfw, a.cfw_rows, a.Nsrc, sv, D, f0, f1, f2, wa, wb, wc);
         }
         if (n > 0) cost /= n;
     }

@@ -167,6 +167,7 @@ int ensure_unary_table(msm_cost *c) {
     u.absw = c->d_absw.p;
     u.pmax = c->pmax;
     u.simmeasure = c->p.simmeasure;
+    u.percentile = c->p.percentile;
     u.U = c->d_U.p;
     const size_t nsamp = (size_t)c->L * c->pidx.size();
     MSM_HIP(c->d_tval.ensure(nsamp));
@@ -224,8 +225,12 @@ msm_cost *msm_cost_create(msm_ctx *ctx, const msm_cost_params *params) {
         fail(MSM_ERR_INVALID, "msm_cost_create: unknown cost kind %d", params->kind);
         return nullptr;
     }
-    if (params->simmeasure != 1 && params->simmeasure != 2) {
-        fail(MSM_ERR_INVALID, "msm_cost_create: similarity measure %d is not offloaded (1 = SSD, 2 = correlation)", params->simmeasure);
+    if (params->simmeasure != 1 && params->simmeasure != 2 && params->simmeasure != 4 && params->simmeasure != 5) {
+        fail(MSM_ERR_INVALID, "Unknown similarity metric");  // get_sim_for_min, M/similarities.h:57
+        return nullptr;
+    }
+    if ((params->simmeasure == 4 || params->simmeasure == 5) && !(params->percentile > 0.0 + kEps && params->percentile < 1.0 - kEps)) {
+        fail(MSM_ERR_INVALID, "Percentile must be between 0 and 1.");  // M/mesh_registration.cpp:782-783
         return nullptr;
     }
     msm_cost *c = new msm_cost();

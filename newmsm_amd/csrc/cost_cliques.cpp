@@ -49,6 +49,7 @@ int clique_args(msm_cost *c, bool need_triplets, bool need_pairs, CliqueArgs &a)
     a.k_exp = c->p.k_exp;
     a.rexp = c->p.rexp;
     a.mvdmax = c->mvdmax;
+    a.percentile = c->p.percentile;
     a.tfeat = c->target->d_feat;
     a.D = c->D;
     a.src = c->source->d_xyz;

@@ -36,6 +36,7 @@ struct UnaryLaunch {
     const double *absw;
     int pmax;
     int simmeasure;
+    double percentile;     // DICE measures (sparsesimkernel::percentile)
     double *U;             // L x N
     // scratch owned by the cost object
     int ntri;                      // triangles in the target mesh
@@ -73,7 +74,7 @@ struct CliqueArgs {
     const int *cp_tri;        // 3 x Tc control grid triangles
     int Tc;
     const int *cp_tid_ptr, *cp_tid;  // triangles adjacent to each control point
-    double lambda, mu, kappa, k_exp, rexp, mvdmax;
+    double lambda, mu, kappa, k_exp, rexp, mvdmax, percentile;
     // HO likelihood
     DevTree tree;
     const double *tfeat;      // V x D

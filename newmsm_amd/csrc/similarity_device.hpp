@@ -12,12 +12,61 @@ __device__ __forceinline__ double interp_feature(const double *f0, const double 
     return wa * f0[d] + wb * f1[d] + wc * f2[d];
 }
 
+// ---- sparsesimkernel::DICE / genDICE, M/similarities.cpp:201-253 -------------------------------------------
+// Both threshold the two vectors at their idx-th smallest value, idx = floor(percentile * n) (:204), and count the
+// elements at or above the thresholds.  The reference sorts copies to find the thresholds; counting ranks gives
+// the same element without a sort: v is the idx-th smallest iff #(x < v) <= idx < #(x <= v).  Weights are ignored.
+__device__ __forceinline__ int dice_index(double percentile, int n) { return (int)floor(percentile * n); }
+
+__device__ __forceinline__ double dice_value(int sim, int size_a, int size_b, int common) {
+    if (sim == 4) return 1.0 - ((2.0 * common) / (size_a + size_b));  // :225
+    const double sb2 = (double)size_b * (double)size_b;               // pow(size_B, 2), exact
+    return 1.0 - (2.0 * ((common / sb2) / ((size_a + size_b) / sb2)));  // :252
+}
+
+template <class F>
+__device__ __forceinline__ double kth_smallest(int n, int idx, F val) {
+    for (int j = 0; j < n; ++j) {
+        const double v = val(j);
+        int less = 0, leq = 0;
+        for (int i = 0; i < n; ++i) {
+            const double x = val(i);
+            less += x < v;
+            leq += x <= v;
+        }
+        if (less <= idx && idx < leq) return v;
+    }
+    return __longlong_as_double(0x7ff8000000000000ll);  // idx out of range (percentile >= 1) or NaN data: undefined in the reference
+}
+
+template <class FA, class FB>
+__device__ __forceinline__ double dice_serial(int sim, int n, double percentile, FA A, FB B) {
+    const int idx = dice_index(percentile, n);
+    const double ta = kth_smallest(n, idx, A), tb = kth_smallest(n, idx, B);
+    int size_a = n, size_b = n, common = 0;
+    for (int i = 0; i < n; ++i) {
+        int ov = 1;
+        if (A(i) < ta) {
+            --size_a;
+            ov = 0;
+        }
+        if (B(i) < tb) {
+            --size_b;
+            ov = 0;
+        }
+        common += ov;
+    }
+    return dice_value(sim, size_a, size_b, common);
+}
+
 // serial over the D dimensions in the reference's order; the target values are recomputed in the second pass
 // instead of being stored (3 loads + 5 flops each)
-__device__ __forceinline__ double feature_vector_similarity(int sim, const double *sfeat, const double *cfw, int cfw_rows, int Nsrc, int sv, int D,
-                                                            const double *f0, const double *f1, const double *f2, double wa, double wb, double wc) {
+__device__ __forceinline__ double feature_vector_similarity(int sim, double percentile, const double *sfeat, const double *cfw, int cfw_rows, int Nsrc,
+                                                            int sv, int D, const double *f0, const double *f1, const double *f2, double wa, double wb,
+                                                            double wc) {
     auto W = [&](int d) { return (cfw && cfw_rows >= d + 1) ? cfw[(size_t)d * Nsrc + sv] : 1.0; };
     auto A = [&](int d) { return sfeat[(size_t)d * Nsrc + sv]; };
+    if (sim == 4 || sim == 5) return dice_serial(sim, D, percentile, A, [&](int d) { return interp_feature(f0, f1, f2, d, wa, wb, wc); });
     if (sim == 2) {  // sparsesimkernel::corr, M/similarities.cpp:129-158
         double prod = 0.0, varA = 0.0, varB = 0.0, meanA = 0.0, meanB = 0.0, sum = 0.0;
         for (int d = 0; d < D; ++d) sum += W(d);

@@ -78,6 +78,7 @@ struct SamplesArgs {
     const double *cfw;     // Nsrc (weight row 1) or nullptr
     const double *absw;    // N
     int simmeasure;
+    double percentile;     // DICE measures
     double *U;             // L x N
     int *redo_list;        // nodes whose reduction must wait for the fix-up kernel
     unsigned int *redo_count;
@@ -165,7 +166,44 @@ __device__ __forceinline__ void emit_failure(const SamplesArgs &a, size_t g, int
 
 // get_sim_for_min (M/similarities.h:48-58) of a moving patch A and a sampled target patch B with weights W,
 // evaluated by one wavefront (lane-strided sums + shuffle reduction)
-__device__ __forceinline__ double patch_similarity(const double *A, const double *W, const double *B, int P, int lane, int simmeasure) {
+__device__ __forceinline__ double wave_kth_smallest(const double *X, int P, int idx, int lane) {
+    double t = __longlong_as_double(0x7ff8000000000000ll);
+    for (int j0 = 0; j0 < P; j0 += 64) {  // wavefront-uniform loop: a lane per candidate value, ranks by counting
+        const int j = j0 + lane;
+        const double v = j < P ? X[j] : 0.0;
+        int less = 0, leq = 0;
+        for (int i = 0; i < P; ++i) {
+            const double x = X[i];
+            less += x < v;
+            leq += x <= v;
+        }
+        const unsigned long long bal = __ballot(j < P && less <= idx && idx < leq);
+        if (bal) {
+            const int src = __ffsll((long long)bal) - 1;
+            t = __shfl(v, src, 64);
+            break;
+        }
+    }
+    return t;
+}
+
+// DICE / genDICE of two patches by one wavefront (M/similarities.cpp:201-253; see similarity_device.hpp)
+__device__ __forceinline__ double patch_dice(const double *A, const double *B, int P, int lane, int simmeasure, double percentile) {
+    const int idx = dice_index(percentile, P);
+    const double ta = wave_kth_smallest(A, P, idx, lane), tb = wave_kth_smallest(B, P, idx, lane);
+    int da = 0, db = 0, cm = 0;  // elements below the thresholds, and elements at or above both
+    for (int i = lane; i < P; i += 64) {
+        const bool la = A[i] < ta, lb = B[i] < tb;
+        da += la;
+        db += lb;
+        cm += !la && !lb;
+    }
+    const int size_a = P - (int)wave_sum((double)da), size_b = P - (int)wave_sum((double)db), common = (int)wave_sum((double)cm);
+    return dice_value(simmeasure, size_a, size_b, common);
+}
+
+__device__ __forceinline__ double patch_similarity(const double *A, const double *W, const double *B, int P, int lane, int simmeasure, double percentile) {
+    if (simmeasure == 4 || simmeasure == 5) return patch_dice(A, B, P, lane, simmeasure, percentile);
     if (simmeasure == 2) {
         // sparsesimkernel::corr, M/similarities.cpp:129-158 (two passes: weighted means, then moments)
         double sw = 0, ma = 0, mb = 0;
@@ -389,7 +427,7 @@ __global__ __launch_bounds__(256) void k_unary_samples(SamplesArgs a) {
             if (s_ndefer == 0) {
                 const double absw = a.absw[node];
                 for (int l = l_beg + (tid >> 6); l < l_end; l += 4) {
-                    const double cost = patch_similarity(sA, sW, sT + l * a.pmax, P, lane, a.simmeasure);
+                    const double cost = patch_similarity(sA, sW, sT + l * a.pmax, P, lane, a.simmeasure, a.percentile);
                     if (lane == 0) a.U[(size_t)l * a.N + node] = absw * cost;
                 }
             } else if (tid == 0) {
@@ -668,6 +706,7 @@ struct ReduceArgs {
     const double *tval;
     int pmax;
     int simmeasure;
+    double percentile;
     double *U;
     const int *redo_list;            // nodes to reduce (nullptr: all N)
     const unsigned int *redo_count;
@@ -690,7 +729,7 @@ __global__ __launch_bounds__(256) void k_unary_reduce_univariate(ReduceArgs a) {
         __syncthreads();
         const double absw = a.absw[node];
         for (int l = wave; l < a.L; l += 4) {
-            const double cost = patch_similarity(sA, sW, a.tval + (size_t)a.L * beg + (size_t)l * P, P, lane, a.simmeasure);
+            const double cost = patch_similarity(sA, sW, a.tval + (size_t)a.L * beg + (size_t)l * P, P, lane, a.simmeasure, a.percentile);
             if (lane == 0) a.U[(size_t)l * a.N + node] = absw * cost;
         }
     }
@@ -841,7 +880,9 @@ struct ReduceMvArgs {
     const int *stri;
     const double *sw3;
     int simmeasure;
+    double percentile;
     int patchwise;
+    int pmax;
     double *U;
 };
 
@@ -865,7 +906,7 @@ __global__ __launch_bounds__(256) void k_unary_reduce_features(ReduceMvArgs a) {
                 }
                 const TriRec &r = a.rec[t];
                 const double *f0 = a.tfeat + (size_t)r.id[0] * a.D, *f1 = a.tfeat + (size_t)r.id[1] * a.D, *f2 = a.tfeat + (size_t)r.id[2] * a.D;
-                acc += feature_vector_similarity(a.simmeasure, a.sfeat, a.cfw, a.cfw_rows, a.Nsrc, a.pidx[beg + i], a.D, f0, f1, f2,
+                acc += feature_vector_similarity(a.simmeasure, a.percentile, a.sfeat, a.cfw, a.cfw_rows, a.Nsrc, a.pidx[beg + i], a.D, f0, f1, f2,
                                                  a.sw3[3 * (g0 + i)], a.sw3[3 * (g0 + i) + 1], a.sw3[3 * (g0 + i) + 2]);
             }
             acc = wave_sum(acc);
@@ -888,7 +929,20 @@ __global__ __launch_bounds__(256) void k_unary_reduce_features(ReduceMvArgs a) {
                 };
                 auto Wv = [&](int i) { return (a.cfw && a.cfw_rows >= 1) ? a.cfw[a.pidx[beg + i]] : 1.0; };
                 double c;
-                if (a.simmeasure == 2) {
+                if (a.simmeasure == 4 || a.simmeasure == 5) {
+                    // DICE ranks every value against every other one: stage the two patches of this channel in the
+                    // wavefront's LDS slice first (the wavefront runs in lockstep: its own LDS writes are visible to all
+                    // of its lanes once they have been issued and waited for)
+                    extern __shared__ __align__(16) double lds[];
+                    double *pa = lds + (size_t)wave * 2 * a.pmax, *pb = pa + a.pmax;
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    for (int i = lane; i < P; i += 64) {
+                        pa[i] = A[a.pidx[beg + i]];
+                        pb[i] = Bv(i);
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    c = patch_dice(pa, pb, P, lane, a.simmeasure, a.percentile);
+                } else if (a.simmeasure == 2) {
                     double sw = 0, ma = 0, mb = 0;
                     for (int i = lane; i < P; i += 64) {
                         const double w = Wv(i);
@@ -994,6 +1048,7 @@ static int launch_samples(msm_ctx *ctx, const UnaryLaunch &u, const UnaryWeights
     a.cfw = (u.cfw && u.cfw_rows >= 1) ? u.cfw : nullptr;
     a.absw = u.absw;
     a.simmeasure = u.simmeasure;
+    a.percentile = u.percentile;
     a.U = w ? nullptr : u.U;  // the fused reduction is the univariate one
     a.redo_list = u.redo_list;
     a.redo_count = u.fix_cnt;
@@ -1041,10 +1096,18 @@ int launch_unary_univariate(msm_ctx *ctx, const UnaryLaunch &u) {
     r.tval = u.tval;
     r.pmax = u.pmax;
     r.simmeasure = u.simmeasure;
+    r.percentile = u.percentile;
     r.U = u.U;
     r.redo_list = u.redo_list;
     r.redo_count = u.fix_cnt;
-    if (uses_ray_table(u.tree)) {
+    const bool dice = u.simmeasure == 4 || u.simmeasure == 5;
+    if (uses_ray_table(u.tree) && dice) {
+        // the rank-counting DICE reduction is the wavefront-per-label kernel; all control points
+        r.redo_list = nullptr;
+        r.redo_count = nullptr;
+        hipLaunchKernelGGL(k_unary_reduce_univariate, dim3(std::min(u.N, 2048)), dim3(256), sizeof(double) * 2 * (size_t)u.pmax, ctx->stream, r);
+        MSM_HIP(hipMemsetAsync(u.fix_cnt, 0, unary_fix_counter_words() * sizeof(unsigned), ctx->stream));
+    } else if (uses_ray_table(u.tree)) {
         r.redo_list = u.order;  // all control points, in launch order
         hipLaunchKernelGGL(k_unary_reduce_flat, dim3(u.N), dim3(256), sizeof(double) * 2 * (size_t)u.pmax, ctx->stream, r, u.fix_cnt,
                            (int)unary_fix_counter_words());
@@ -1077,8 +1140,11 @@ int launch_unary_multivariate(msm_ctx *ctx, const UnaryLaunch &u, const UnaryWei
     r.sw3 = w.sw3;
     r.simmeasure = u.simmeasure;
     r.patchwise = patchwise ? 1 : 0;
+    r.pmax = u.pmax;
+    r.percentile = u.percentile;
     r.U = u.U;
-    hipLaunchKernelGGL(k_unary_reduce_features, dim3(u.N), dim3(256), 0, ctx->stream, r);
+    const bool dice = u.simmeasure == 4 || u.simmeasure == 5;
+    hipLaunchKernelGGL(k_unary_reduce_features, dim3(u.N), dim3(256), (dice && patchwise) ? sizeof(double) * 8 * (size_t)u.pmax : 0, ctx->stream, r);
     MSM_HIP(hipGetLastError());
     MSM_HIP(hipMemsetAsync(u.fix_cnt, 0, unary_fix_counter_words() * sizeof(unsigned), ctx->stream));  // counters are zero between launches
     return MSM_OK;

@@ -76,7 +76,7 @@ static int gpu_checks(void) {
     double *feat = malloc(sizeof(double) * V);
     for (int i = 0; i < V; ++i) feat[i] = sin(xyz[i] / 20.0) + cos(xyz[V + i] / 15.0);
     CHECK(msm_mesh_set_features(target, feat, 1) == MSM_OK, "target features");
-    msm_cost_params p = {MSM_COST_UNIVARIATE, 2, 3, 0, 0.1, 0.1, 10.0, 2.0, 2.0, 1.0};
+    msm_cost_params p = {MSM_COST_UNIVARIATE, 2, 3, 0, 0.1, 0.1, 10.0, 2.0, 2.0, 1.0, 0.75};
     msm_cost *c = msm_cost_create(ctx, &p);
     CHECK(c != NULL, "cost");
     CHECK(msm_cost_get_source_data(c) == MSM_ERR_STATE, "call order must be enforced");
