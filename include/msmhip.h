@@ -154,7 +154,7 @@ int msm_nearest_neighbour(msm_mesh *orig, const double *data, int32_t D, const d
 typedef struct msm_cost_params { /* set_parameters M/DiscreteCostFunction.cpp:119-133 */
     int32_t kind;        /* MSM_COST_* (chosen in initialize_cost_function M/DiscreteModel.cpp:43-61) */
     int32_t simmeasure;  /* "simmeasure": 1 SSD, 2 correlation, 4 DICE, 5 genDICE (get_sim_for_min M/similarities.h:48-58) */
-    int32_t rmode;       /* "regularisermode": 1 pairwise angle, 2/3 triangle strain */
+    int32_t rmode;       /* "regularisermode": 1 pairwise angle, 2/3 triangle strain, 4/5 anatomical strain (msm_cost_set_anatomical) */
     int32_t reserved;
     double  lambda;      /* "lambda" */
     double  mu;          /* "shearmodulus" */
@@ -167,6 +167,14 @@ typedef struct msm_cost_params { /* set_parameters M/DiscreteCostFunction.cpp:11
 
 msm_cost *msm_cost_create(msm_ctx *ctx, const msm_cost_params *params);
 void      msm_cost_destroy(msm_cost *c);
+/* set_anatomical + set_anatomical_neighbourhood (M/DiscreteCostFunction.h:160-170), for regularisermode 4/5 (aMSM:
+ * computeTripletCost :169-182 with deform_anatomy :255-301).  sphere = _TARGEThi, the anatomical-resolution sphere
+ * (its octree is the reference's `anattree`); atarget_xyz = _aTARGET coordinates, 3 x (vertices of sphere) SoA;
+ * asource_* = _aSOURCE (3 x Vs SoA, 3 x Ts SoA); w_* = _ANATbaryweights as CSR over the Vs vertices, control point
+ * ids ascending within a row (std::map order); face_* = NEARESTFACES as CSR over the triplets (set_triplets first). */
+int msm_cost_set_anatomical(msm_cost *c, msm_mesh *sphere, const double *atarget_xyz, const double *asource_xyz, int32_t Vs,
+                            const int32_t *asource_tri, int32_t Ts, const int32_t *w_ptr, const int32_t *w_cp, const double *w_val,
+                            const int32_t *face_ptr, const int32_t *face_idx);
 /* set_meshes M/DiscreteCostFunction.h:196-198: captures _ORIG (source coords) and _oCPgrid */
 int msm_cost_set_meshes(msm_cost *c, msm_mesh *target, msm_mesh *source, msm_mesh *cpgrid);
 /* reset_source :208 / reset_CPgrid :209: pick up the meshes' current coordinates */

@@ -76,6 +76,7 @@ SIGNATURES = {
     "msm_cost_create": (_VP, [_VP, C.POINTER(CostParams)]),
     "msm_cost_destroy": (None, [_VP]),
     "msm_cost_set_meshes": (C.c_int, [_VP, _VP, _VP, _VP]),
+    "msm_cost_set_anatomical": (C.c_int, [_VP, _VP, c_dp, c_dp, C.c_int32, c_ip, C.c_int32, c_ip, c_ip, c_dp, c_ip, c_ip]),
     "msm_cost_reset_source": (C.c_int, [_VP, _VP]),
     "msm_cost_reset_cpgrid": (C.c_int, [_VP, _VP]),
     "msm_cost_set_source_features": (C.c_int, [_VP, c_dp, C.c_int32]),

@@ -293,6 +293,22 @@ class DiscreteCostFunction:
         self.N = cpgrid.V
         check(lib().msm_cost_set_meshes(self.h, target.h, source.h, cpgrid.h))
 
+    def set_anatomical(self, sphere, atarget_xyz, asource_xyz, asource_tri, w_ptr, w_cp, w_val, face_ptr, face_idx):
+        """set_anatomical + set_anatomical_neighbourhood (M/DiscreteCostFunction.h:160-170): sphere = _TARGEThi (a Mesh),
+        atarget_xyz = _aTARGET coordinates on the sphere's vertices, asource_* = _aSOURCE, w_* = _ANATbaryweights (CSR over
+        _aSOURCE vertices, control point ids ascending), face_* = NEARESTFACES (CSR over triplets)."""
+        at, pat = _soa(atarget_xyz)
+        asx, pas = _soa(asource_xyz)
+        tri, ptri = _tri_soa(asource_tri)
+        wp, pwp = _i(w_ptr)
+        wc, pwc = _i(w_cp)
+        wv, pwv = _d(w_val)
+        fp, pfp = _i(face_ptr)
+        fi, pfi = _i(face_idx)
+        assert at.shape[1] == sphere.V
+        self._keep.update(asphere=sphere)
+        check(lib().msm_cost_set_anatomical(self.h, sphere.h, pat, pas, asx.shape[1], ptri, tri.shape[1], pwp, pwc, pwv, pfp, pfi))
+
     def reset_source(self, source):
         self._keep["source"] = source
         check(lib().msm_cost_reset_source(self.h, source.h))

@@ -119,7 +119,49 @@ __device__ double triplet_likelihood(const CliqueArgs &a, int t, const int *id, 
     return wmean * cost;
 }
 
-// computeTripletCost, M/DiscreteCostFunction.cpp:135-188 (regoption 2/3)
+// deform_anatomy, M/DiscreteCostFunction.cpp:255-301, for one vertex of an anatomical face: the vertex follows the
+// proposed control triangle through its barycentric weights (a control point outside the triplet enters as the
+// default Point (0,0,0) that std::map::operator[] inserts, :269), is located on the anatomical-resolution sphere
+// and carried to the target anatomy with calc_barycentric_weights, summed in ascending vertex id (std::map, :290).
+// The reference's moved/transformed maps only cache this per evaluation.
+__device__ V3 deform_anatomy_vertex(const CliqueArgs &a, int tindex, const int *id, const V3 *moved, bool &failed) {
+    V3 np = mk(0.0, 0.0, 0.0);
+    for (int j = a.aw_ptr[tindex]; j < a.aw_ptr[tindex + 1]; ++j) {
+        const int cp = a.aw_cp[j];
+        const double w = a.aw_val[j];
+        V3 v = mk(0.0, 0.0, 0.0);
+        if (cp == id[0]) v = moved[0];
+        else if (cp == id[1]) v = moved[1];
+        else if (cp == id[2]) v = moved[2];
+        np = mk(np.x + v.x * w, np.y + v.y * w, np.z + v.z * w);
+    }
+    const double nan = __longlong_as_double(0x7ff8000000000000ll);
+    const int tt = find_closest_triangle(a.atree, np);
+    if (tt < 0) {  // the reference warns and continues with a zero triangle (:272-278): NaN weights
+        raise_status(a.status, tt);
+        failed = true;
+        return mk(nan, nan, nan);
+    }
+    const TriRec &r = a.atree.rec[tt];
+    const V3 v0 = rec_v0(r), v1 = rec_v1(r), v2 = rec_v2(r);
+    double w[3];
+    area_weights(v0, v1, v2, project_point(np, v0, v1, v2), w[0], w[1], w[2]);  // calc_barycentric_weights, R/triangle.cpp:124-145
+    int o0 = 0, o1 = 1, o2 = 2;  // ascending vertex id
+    if (r.id[o1] < r.id[o0]) { const int s = o0; o0 = o1; o1 = s; }
+    if (r.id[o2] < r.id[o0]) { const int s = o0; o0 = o2; o2 = s; }
+    if (r.id[o2] < r.id[o1]) { const int s = o1; o1 = o2; o2 = s; }
+    V3 out = mk(0.0, 0.0, 0.0);
+    const int ord[3] = {o0, o1, o2};
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const int vid = r.id[ord[q]];
+        const double wq = w[ord[q]];
+        out = mk(out.x + a.atarget[vid] * wq, out.y + a.atarget[a.Va + vid] * wq, out.z + a.atarget[2 * a.Va + vid] * wq);
+    }
+    return out;
+}
+
+// computeTripletCost, M/DiscreteCostFunction.cpp:135-188 (regoption 2/3: spherical strain; 4/5: anatomical strain)
 __device__ double triplet_cost(const CliqueArgs &a, int t, int la, int lb, int lc) {
     const int id[3] = {a.triplets[3 * t], a.triplets[3 * t + 1], a.triplets[3 * t + 2]};
     const V3 r[3] = {aos(a.moved, (size_t)id[0] * a.L + la), aos(a.moved, (size_t)id[1] * a.L + lb), aos(a.moved, (size_t)id[2] * a.L + lc)};
@@ -128,8 +170,26 @@ __device__ double triplet_cost(const CliqueArgs &a, int t, int la, int lb, int l
     if (dot(tri_normal(r[0], r[1], r[2]), tri_normal(cur[0], cur[1], cur[2])) < 0.0) return MSM_FOLDING * a.lambda;
     double likelihood = 0.0;
     if (a.kind == MSM_COST_HO_UNIVARIATE || a.kind == MSM_COST_HO_MULTIVARIATE) likelihood = triplet_likelihood(a, t, id, r[0], r[1], r[2]);
-    const V3 org[3] = {soa(a.orig, a.Norig, id[0]), soa(a.orig, a.Norig, id[1]), soa(a.orig, a.Norig, id[2])};
-    const double w = triangular_strain(org, r, a.mu, a.kappa, a.k_exp);
+    double w;
+    if (a.rmode == 4 || a.rmode == 5) {  // :169-182: mean strain of the anatomical faces under this control triangle
+        const int beg = a.af_ptr[t], nf = a.af_ptr[t + 1] - beg;
+        bool failed = false;
+        w = 0.0;
+        for (int n = 0; n < nf; ++n) {
+            const int f = a.af_idx[beg + n];
+            V3 o[3], d[3];
+            for (int k = 0; k < 3; ++k) {
+                const int v = a.asrc_tri[k * a.Ts + f];
+                o[k] = soa(a.asrc, a.Vs, v);
+                d[k] = deform_anatomy_vertex(a, v, id, r, failed);
+            }
+            w += triangular_strain(o, d, a.mu, a.kappa, a.k_exp);
+        }
+        w = w / (double)nf;
+    } else {
+        const V3 org[3] = {soa(a.orig, a.Norig, id[0]), soa(a.orig, a.Norig, id[1]), soa(a.orig, a.Norig, id[2])};
+        w = triangular_strain(org, r, a.mu, a.kappa, a.k_exp);
+    }
     return likelihood + a.lambda * pow(w, a.rexp);
 }
 

@@ -68,9 +68,30 @@ int clique_args(msm_cost *c, bool need_triplets, bool need_pairs, CliqueArgs &a)
         if (st) return st;
     }
     a.tree = dev_tree(c->target);
-    if (need_triplets && c->p.rmode != 2 && c->p.rmode != 3)
-        return fail(MSM_ERR_INVALID, "DiscreteModel computeTripletCost regoption does not exist (regularisermode %d; the anatomical modes are not offloaded)",
-                    c->p.rmode);
+    a.rmode = c->p.rmode;
+    a.atree = DevTree{};
+    a.atarget = a.asrc = a.aw_val = nullptr;
+    a.asrc_tri = a.aw_ptr = a.aw_cp = a.af_ptr = a.af_idx = nullptr;
+    a.Va = a.Vs = a.Ts = 0;
+    if (need_triplets && (c->p.rmode == 4 || c->p.rmode == 5)) {
+        if (!c->have_anat) return fail(MSM_ERR_STATE, "MeshREG ERROR:: regoption 5 requires anatomical meshes (msm_cost_set_anatomical)");  // M/mesh_registration.cpp:103
+        st = ensure_tree(c->asphere);
+        if (st) return st;
+        a.atree = dev_tree(c->asphere);
+        a.atarget = c->d_atarget.p;
+        a.Va = c->asphere->V;
+        a.asrc = c->d_asrc.p;
+        a.Vs = c->aVs;
+        a.asrc_tri = c->d_asrc_tri.p;
+        a.Ts = c->aTs;
+        a.aw_ptr = c->d_aw_ptr.p;
+        a.aw_cp = c->d_aw_cp.p;
+        a.aw_val = c->d_aw_val.p;
+        a.af_ptr = c->d_af_ptr.p;
+        a.af_idx = c->d_af_idx.p;
+    } else if (need_triplets && c->p.rmode != 2 && c->p.rmode != 3) {
+        return fail(MSM_ERR_INVALID, "DiscreteModel computeTripletCost regoption does not exist");  // M/DiscreteCostFunction.cpp:184
+    }
     return MSM_OK;
 }
 
@@ -82,6 +103,46 @@ int upload_ints(msm_ctx *ctx, DevBuf<int> &buf, const int32_t *host, size_t n) {
 }  // namespace
 
 extern "C" {
+
+int msm_cost_set_anatomical(msm_cost *c, msm_mesh *sphere, const double *atarget_xyz, const double *asource_xyz, int32_t Vs,
+                            const int32_t *asource_tri, int32_t Ts, const int32_t *w_ptr, const int32_t *w_cp, const double *w_val,
+                            const int32_t *face_ptr, const int32_t *face_idx) {
+    if (!c || !sphere || !atarget_xyz || !asource_xyz || !asource_tri || !w_ptr || !w_cp || !w_val || !face_ptr || !face_idx || Vs <= 0 || Ts <= 0)
+        return fail(MSM_ERR_INVALID, "msm_cost_set_anatomical: bad arguments");
+    const int T = (int)(c->triplets.size() / 3);
+    if (T == 0 || !c->cpgrid) return fail(MSM_ERR_STATE, "msm_cost_set_anatomical: set_meshes and set_triplets first");
+    const int N = c->cpgrid->V;
+    if (w_ptr[0] != 0 || face_ptr[0] != 0) return fail(MSM_ERR_INVALID, "msm_cost_set_anatomical: CSR rows must start at 0");
+    for (int v = 0; v < Vs; ++v)
+        if (w_ptr[v + 1] < w_ptr[v]) return fail(MSM_ERR_INVALID, "msm_cost_set_anatomical: weight rows are not monotone");
+    for (int j = 0; j < w_ptr[Vs]; ++j)
+        if (w_cp[j] < 0 || w_cp[j] >= N) return fail(MSM_ERR_INVALID, "msm_cost_set_anatomical: control point id %d out of range", w_cp[j]);
+    for (int v = 0; v < Vs; ++v)
+        for (int j = w_ptr[v] + 1; j < w_ptr[v + 1]; ++j)
+            if (w_cp[j] <= w_cp[j - 1]) return fail(MSM_ERR_INVALID, "msm_cost_set_anatomical: control point ids must ascend within a row (std::map order)");
+    for (int t = 0; t < T; ++t)
+        if (face_ptr[t + 1] < face_ptr[t]) return fail(MSM_ERR_INVALID, "msm_cost_set_anatomical: face rows are not monotone");
+    for (int j = 0; j < face_ptr[T]; ++j)
+        if (face_idx[j] < 0 || face_idx[j] >= Ts) return fail(MSM_ERR_INVALID, "msm_cost_set_anatomical: face id %d out of range", face_idx[j]);
+    for (int j = 0; j < 3 * Ts; ++j)
+        if (asource_tri[j] < 0 || asource_tri[j] >= Vs) return fail(MSM_ERR_INVALID, "msm_cost_set_anatomical: vertex id %d out of range", asource_tri[j]);
+    msm_ctx *ctx = c->ctx;
+    MSM_HIP(hipSetDevice(ctx->device));
+    MSM_HIP(c->d_atarget.upload(atarget_xyz, 3 * (size_t)sphere->V, ctx->stream));
+    MSM_HIP(c->d_asrc.upload(asource_xyz, 3 * (size_t)Vs, ctx->stream));
+    MSM_HIP(c->d_asrc_tri.upload(asource_tri, 3 * (size_t)Ts, ctx->stream));
+    MSM_HIP(c->d_aw_ptr.upload(w_ptr, (size_t)Vs + 1, ctx->stream));
+    MSM_HIP(c->d_aw_cp.upload(w_cp, std::max<size_t>(w_ptr[Vs], 1), ctx->stream));
+    MSM_HIP(c->d_aw_val.upload(w_val, std::max<size_t>(w_ptr[Vs], 1), ctx->stream));
+    MSM_HIP(c->d_af_ptr.upload(face_ptr, (size_t)T + 1, ctx->stream));
+    MSM_HIP(c->d_af_idx.upload(face_idx, std::max<size_t>(face_ptr[T], 1), ctx->stream));
+    MSM_HIP(hipStreamSynchronize(ctx->stream));  // the caller's arrays may go away
+    c->asphere = sphere;
+    c->aVs = Vs;
+    c->aTs = Ts;
+    c->have_anat = true;
+    return MSM_OK;
+}
 
 int msm_cost_triplet_batch(msm_cost *c, const int32_t *triplet, const int32_t *la, const int32_t *lb, const int32_t *lc, int32_t n, double *out) {
     if (!c || !triplet || !la || !lb || !lc || !out || n < 0) return fail(MSM_ERR_INVALID, "msm_cost_triplet_batch: bad arguments");

@@ -61,6 +61,12 @@ struct msm_cost {
     DevBuf<double> d_sw3;
     DevBuf<unsigned long long> d_fix_list;
     DevBuf<unsigned int> d_fix_count;
+    // anatomical regularisation (regularisermode 4/5)
+    msm_mesh *asphere = nullptr;
+    int aVs = 0, aTs = 0;
+    DevBuf<double> d_atarget, d_asrc, d_aw_val;
+    DevBuf<int32_t> d_asrc_tri, d_aw_ptr, d_aw_cp, d_af_ptr, d_af_idx;
+    bool have_anat = false;
     // optional event timing of the samples kernel
     bool timing = false;
     std::vector<hipEvent_t> ev0, ev1;

@@ -86,6 +86,18 @@ struct CliqueArgs {
     int cfw_rows;
     const int *bin_ptr, *bin_idx;  // source vertices per control-grid triangle
     const double *absw;
+    // anatomical strain (rmode 4/5)
+    int rmode;
+    DevTree atree;            // octree of the anatomical-resolution sphere (_TARGEThi)
+    const double *atarget;    // 3 x Va: _aTARGET
+    int Va;
+    const double *asrc;       // 3 x Vs: _aSOURCE
+    int Vs;
+    const int *asrc_tri;      // 3 x Ts
+    int Ts;
+    const int *aw_ptr, *aw_cp;  // _ANATbaryweights CSR
+    const double *aw_val;
+    const int *af_ptr, *af_idx;  // NEARESTFACES CSR
     int *status;
 };
 int launch_triplet_batch(msm_ctx *ctx, const CliqueArgs &a, const int *qt, const int *qa, const int *qb, const int *qc, int n, double *out);

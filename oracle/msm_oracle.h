@@ -153,6 +153,13 @@ void      orc_cost_destroy(orc_cost *c);
  * CP grid mesh; ORIG source / original CP grid are captured at this call like set_meshes() does. */
 void orc_cost_set_meshes(orc_cost *c, const orc_mesh *target, const orc_octree *ttree,
                          const orc_mesh *source, const orc_mesh *cpgrid);
+/* set_anatomical + set_anatomical_neighbourhood (M/DiscreteCostFunction.h:160-170) for regoption 4/5: the
+ * anatomical-resolution sphere _TARGEThi with its octree, _aTARGET coordinates (AoS, the sphere's vertex ids),
+ * _aSOURCE, _ANATbaryweights as CSR over _aSOURCE vertices (control point ids ascending), NEARESTFACES as CSR over
+ * triplets.  Pointers are borrowed. */
+void orc_cost_set_anatomical(orc_cost *c, const orc_mesh *sphere, const orc_octree *sphere_tree, const double *atarget_xyz,
+                             const orc_mesh *asource, const int *w_ptr, const int *w_cp, const double *w_val, const int *face_ptr,
+                             const int *face_idx);
 void orc_cost_reset_source(orc_cost *c, const orc_mesh *source);
 void orc_cost_reset_cpgrid(orc_cost *c, const orc_mesh *cpgrid);
 /* featurespace: input (source) D x Nsrc and reference (target) D x Ntgt */

@@ -313,6 +313,16 @@ class Cost:
         self.N = cpgrid.V
         lib().orc_cost_set_meshes(self.h, target.h, ttree.h, source.h, cpgrid.h)
 
+    def set_anatomical(self, sphere, sphere_tree, atarget_xyz, asource, w_ptr, w_cp, w_val, face_ptr, face_idx):
+        at, pat = _d(atarget_xyz)
+        wp, pwp = _i(w_ptr)
+        wc, pwc = _i(w_cp)
+        wv, pwv = _d(w_val)
+        fp, pfp = _i(face_ptr)
+        fi, pfi = _i(face_idx)
+        self._keep.update(asphere=sphere, atree=sphere_tree, at=at, asource=asource, wp=wp, wc=wc, wv=wv, fp=fp, fi=fi)
+        lib().orc_cost_set_anatomical(self.h, sphere.h, sphere_tree.h, pat, asource.h, pwp, pwc, pwv, pfp, pfi)
+
     def reset_source(self, source):
         self._keep["source"] = source
         lib().orc_cost_reset_source(self.h, source.h)

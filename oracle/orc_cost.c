@@ -388,6 +388,15 @@ struct orc_cost {
     /* scratch */
     double *tgt; /* target data for one group: maxgroup x D */
     int maxgroup;
+    /* anatomical regularisation (regoption 4/5): set_anatomical + set_anatomical_neighbourhood,
+     * M/DiscreteCostFunction.h:160-170 */
+    const orc_mesh *asphere;      /* _TARGEThi: the anatomical-resolution sphere (aICO) */
+    const orc_octree *anattree;   /* Octree(_TARGEThi), M/DiscreteCostFunction.h:162-163 */
+    const double *atarget_xyz;    /* _aTARGET coordinates, vertex ids of asphere */
+    const orc_mesh *asource;      /* _aSOURCE */
+    const int *aw_ptr, *aw_cp;    /* _ANATbaryweights: per _aSOURCE vertex (control point id, weight), ascending ids */
+    const double *aw_val;
+    const int *af_ptr, *af_idx;   /* NEARESTFACES: per triplet the _aSOURCE faces */
 };
 
 orc_cost *orc_cost_create(const orc_cost_params *p) {
@@ -675,7 +684,61 @@ static double triplet_likelihood(orc_cost *c, int t, const double n0[3], const d
     return (c->absw[id[0]] + c->absw[id[1]] + c->absw[id[2]]) / 3.0 * sim;
 }
 
-/* computeTripletCost, M/DiscreteCostFunction.cpp:135-188 (regoption 2/3; the aMSM modes 4/5 are out of scope) */
+void orc_cost_set_anatomical(orc_cost *c, const orc_mesh *sphere, const orc_octree *sphere_tree, const double *atarget_xyz,
+                             const orc_mesh *asource, const int *w_ptr, const int *w_cp, const double *w_val, const int *face_ptr,
+                             const int *face_idx) {
+    c->asphere = sphere;
+    c->anattree = sphere_tree;
+    c->atarget_xyz = atarget_xyz;
+    c->asource = asource;
+    c->aw_ptr = w_ptr;
+    c->aw_cp = w_cp;
+    c->aw_val = w_val;
+    c->af_ptr = face_ptr;
+    c->af_idx = face_idx;
+}
+
+/* deform_anatomy, M/DiscreteCostFunction.cpp:255-301, for one vertex of one anatomical face (the reference's
+ * moved/transformed maps only cache this per evaluation).  id / moved: the triplet's control points and their
+ * proposed positions; a control point outside the triplet enters as a default-constructed Point (0,0,0) through
+ * std::map::operator[] (:269).  Returns 0, or -1 when the search fails (the reference then substitutes a zero
+ * triangle, :272-278, and its weights are NaN). */
+static int deform_vertex(const orc_cost *c, int tindex, const int id[3], double moved[3][3], double out[3]) {
+    double np[3] = {0.0, 0.0, 0.0};
+    for (int j = c->aw_ptr[tindex]; j < c->aw_ptr[tindex + 1]; ++j) {
+        const int cp = c->aw_cp[j];
+        const double w = c->aw_val[j];
+        double v[3] = {0.0, 0.0, 0.0};
+        for (int k = 0; k < 3; ++k)
+            if (id[k] == cp) memcpy(v, moved[k], sizeof(v));
+        for (int a = 0; a < 3; ++a) np[a] += v[a] * w;
+    }
+    const int t = orc_octree_closest_triangle(c->anattree, np, NULL);
+    if (t < 0) {
+        out[0] = out[1] = out[2] = NAN;
+        return -1;
+    }
+    const int *n = &c->asphere->tri[3 * t];
+    double w[3];
+    orc_calc_barycentric_weights(&c->asphere->xyz[3 * n[0]], &c->asphere->xyz[3 * n[1]], &c->asphere->xyz[3 * n[2]], np, w);
+    /* std::map<int,double> weight: iterated in ascending vertex id (:290-291) */
+    int order[3] = {0, 1, 2};
+    for (int a = 0; a < 3; ++a)
+        for (int b = a + 1; b < 3; ++b)
+            if (n[order[b]] < n[order[a]]) {
+                int tmp = order[a];
+                order[a] = order[b];
+                order[b] = tmp;
+            }
+    out[0] = out[1] = out[2] = 0.0;
+    for (int q = 0; q < 3; ++q) {
+        const int vid = n[order[q]];
+        for (int a = 0; a < 3; ++a) out[a] += c->atarget_xyz[3 * vid + a] * w[order[q]];
+    }
+    return 0;
+}
+
+/* computeTripletCost, M/DiscreteCostFunction.cpp:135-188 (regoption 2/3: spherical strain; 4/5: anatomical strain) */
 double orc_cost_triplet(orc_cost *c, int t, int la, int lb, int lc) {
     const int *id = &c->triplets[3 * t];
     double r[3][3], cur[3][3], org[3][3], nd[3], nc[3];
@@ -690,8 +753,24 @@ double orc_cost_triplet(orc_cost *c, int t, int la, int lb, int lc) {
     orc_tri_normal(cur[0], cur[1], cur[2], nc);
     if (v_dot(nd, nc) < 0.0) return ORC_FOLDING * c->p.lambda;
     double likelihood = triplet_likelihood(c, t, r[0], r[1], r[2]);
-    if (c->p.rmode != 2 && c->p.rmode != 3) return NAN;
-    double cost = orc_triangular_strain(org, r, c->p.mu, c->p.kappa, c->p.k_exp);
+    double cost = 0.0;
+    if (c->p.rmode == 2 || c->p.rmode == 3) {
+        cost = orc_triangular_strain(org, r, c->p.mu, c->p.kappa, c->p.k_exp);
+    } else if ((c->p.rmode == 4 || c->p.rmode == 5) && c->asource) { /* :169-182 */
+        const int beg = c->af_ptr[t], nf = c->af_ptr[t + 1] - beg;
+        for (int n = 0; n < nf; ++n) {
+            const int *fv = &c->asource->tri[3 * c->af_idx[beg + n]];
+            double o[3][3], d[3][3];
+            for (int k = 0; k < 3; ++k) {
+                memcpy(o[k], &c->asource->xyz[3 * fv[k]], sizeof(double) * 3);
+                deform_vertex(c, fv[k], id, r, d[k]);
+            }
+            cost += orc_triangular_strain(o, d, c->p.mu, c->p.kappa, c->p.k_exp);
+        }
+        cost = cost / (double)nf;
+    } else {
+        return NAN;
+    }
     return likelihood + c->p.lambda * pow(cost, c->p.rexp);
 }
 

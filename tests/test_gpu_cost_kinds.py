@@ -149,3 +149,41 @@ def test_total_cost_sum(ctx, rmode):
     tot, parts = cf.evaluateTotalCostSum(labeling)
     otot, oparts = oc.total(labeling)
     assert np.allclose(parts, oparts, rtol=RTOL, atol=ATOL) and abs(tot - otot) <= ATOL + RTOL * abs(otot)
+
+
+@pytest.mark.parametrize("kind,D,rmode", [("univariate", 1, 5), ("ho_univariate", 1, 4)])
+def test_anatomical_strain_regoption5(ctx, kind, D, rmode):
+    # aMSM: computeTripletCost :169-182 with deform_anatomy :255-301 (one search on the anatomical sphere per face vertex)
+    import oracle.oracle as O
+
+    inp = problem.pairwise_inputs(4, 2, D=D)
+    an = problem.anatomical_inputs(ctx, inp)
+    cf, oc, keep = pair(ctx, inp, kind, rmode=rmode, lambda_=0.05, mu=0.4, kappa=1.6, k_exp=2.0, rexp=1.5)
+    sphere = M.Mesh(ctx, an["sphere_xyz"], an["sphere_tri"])
+    cf.set_anatomical(sphere, an["atarget_xyz"], an["asource_xyz"], an["sphere_tri"], an["w_ptr"], an["w_cp"], an["w_val"], an["face_ptr"], an["face_idx"])
+    osphere = O.Mesh(an["sphere_xyz"], an["sphere_tri"])
+    otree = O.Octree(osphere)
+    oasrc = O.Mesh(an["asource_xyz"], an["sphere_tri"])
+    oc.set_anatomical(osphere, otree, an["atarget_xyz"], oasrc, an["w_ptr"], an["w_cp"], an["w_val"], an["face_ptr"], an["face_idx"])
+    assert np.diff(an["face_ptr"]).min() >= 1
+    rng = np.random.default_rng(8)
+    t, la, lb, lc = random_queries(rng, 600, cf.T, cf.L, 3)
+    got = cf.computeTripletCost(t, la, lb, lc)
+    want = np.array([oc.triplet(*q) for q in zip(t, la, lb, lc)])
+    assert np.isfinite(want).all() and np.ptp(want) > 0
+    assert np.allclose(got, want, rtol=RTOL, atol=ATOL), np.max(np.abs(got - want))
+    # the fusion-move octets use the same evaluator
+    labeling = rng.integers(0, cf.L, cf.N).astype(np.int32)
+    E = cf.tripletOctets(labeling, 3)
+    tt = 17
+    ids = inp["triplets"][tt]
+    k = 5  # (A,B,C) = (1,0,1)
+    want_k = oc.triplet(tt, 3, int(labeling[ids[1]]), 3)
+    assert abs(E[tt, k] - want_k) <= ATOL + RTOL * abs(want_k)
+
+
+def test_anatomical_strain_needs_its_inputs(ctx):
+    inp = problem.pairwise_inputs(4, 2, D=1)
+    cf, _ = problem.build_cost(ctx, inp, kind="univariate", rmode=5)
+    with pytest.raises(M.MsmError, match="anatomical"):
+        cf.computeTripletCost(np.zeros(1, np.int32), np.zeros(1, np.int32), np.zeros(1, np.int32), np.zeros(1, np.int32))
