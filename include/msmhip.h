@@ -215,9 +215,12 @@ int msm_cost_triplet_octets(msm_cost *c, const int32_t *labeling, int32_t label,
  * computePairwiseCosts :228-234: paircosts[(pair*L + labelB)*L + labelA] */
 int msm_cost_pairwise_batch(msm_cost *c, const int32_t *pair, const int32_t *la, const int32_t *lb, int32_t n, double *out);
 int msm_cost_pairwise_table(msm_cost *c, double *paircosts);
+/* computeTripletCosts M/DiscreteCostFunction.cpp:245-253 (the MCMC optimiser's table, M/mcmc_opt.h:58): tcosts[((t - t0)*L + a)*L*L + b*L + c]
+ * for the triplets t0 <= t < t1 (the whole table is T * L^3 doubles, 281 MB at ico4 / 19 labels: fetch it in ranges) */
+int msm_cost_triplet_table(msm_cost *c, int32_t t0, int32_t t1, double *tcosts);
 /* evaluateTotalCostSum :55-77: parts = {unary, pairwise, triplet} sums in the reference's serial order */
 int msm_cost_total(msm_cost *c, const int32_t *labeling, double *total, double parts[3]);
-/* Optional HIP-event timing of the dominant kernel (k_unary_samples) of each unary-table launch, recorded on the
+/* Optional HIP-event timing of the sampling kernel (k_unary_rays or k_unary_samples) of each unary-table launch, recorded on the
  * context's stream.  msm_cost_kernel_times returns the durations (ms) of the last launches (most recent last; at most
  * 64 are kept) after synchronising the stream. */
 int msm_cost_enable_timing(msm_cost *c, int enable);

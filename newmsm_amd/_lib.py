@@ -96,6 +96,7 @@ SIGNATURES = {
     "msm_cost_triplet_octets": (C.c_int, [_VP, c_ip, C.c_int32, c_dp]),
     "msm_cost_pairwise_batch": (C.c_int, [_VP, c_ip, c_ip, c_ip, C.c_int32, c_dp]),
     "msm_cost_pairwise_table": (C.c_int, [_VP, c_dp]),
+    "msm_cost_triplet_table": (C.c_int, [_VP, C.c_int32, C.c_int32, c_dp]),
     "msm_cost_total": (C.c_int, [_VP, c_ip, c_dp, c_dp]),
     "msm_cost_enable_timing": (C.c_int, [_VP, C.c_int]),
     "msm_cost_kernel_times": (C.c_int, [_VP, c_dp, C.c_int32, c_ip]),

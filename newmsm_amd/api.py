@@ -401,6 +401,13 @@ class DiscreteCostFunction:
         check(lib().msm_cost_triplet_octets(self.h, pl, int(label), out.ctypes.data_as(c_dp)))
         return out
 
+    def computeTripletCosts(self, t0=0, t1=None):
+        """tcosts[t][a][b][c] (M/DiscreteCostFunction.cpp:245-253) for the triplets t0 <= t < t1."""
+        t1 = self.T if t1 is None else t1
+        out = np.zeros((t1 - t0, self.L, self.L, self.L))
+        check(lib().msm_cost_triplet_table(self.h, int(t0), int(t1), out.ctypes.data_as(c_dp)))
+        return out
+
     def computePairwiseCost(self, pair, la, lb):
         p, pp = _i(np.atleast_1d(pair))
         a, pa = _i(np.atleast_1d(la))

@@ -279,6 +279,24 @@ int launch_pairwise_batch(msm_ctx *ctx, const CliqueArgs &a, const int *qp, cons
     MSM_HIP(hipGetLastError());
     return MSM_OK;
 }
+// computeTripletCosts, M/DiscreteCostFunction.cpp:245-253: tcosts[t][a][b][c] for the triplets t0 <= t < t1
+__global__ __launch_bounds__(128) void k_triplet_table(CliqueArgs a, int t0, int t1, double *__restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t L = (size_t)a.L, per = L * L * L;
+    if (i >= (size_t)(t1 - t0) * per) return;
+    const int t = t0 + (int)(i / per);
+    const size_t r = i % per;
+    out[i] = triplet_cost(a, t, (int)(r / (L * L)), (int)((r / L) % L), (int)(r % L));
+}
+
+int launch_triplet_table(msm_ctx *ctx, const CliqueArgs &a, int t0, int t1, double *out) {
+    const size_t total = (size_t)(t1 - t0) * a.L * a.L * a.L;
+    if (total == 0) return MSM_OK;
+    hipLaunchKernelGGL(k_triplet_table, dim3((unsigned)((total + 127) / 128)), dim3(128), 0, ctx->stream, a, t0, t1, out);
+    MSM_HIP(hipGetLastError());
+    return MSM_OK;
+}
+
 int launch_pairwise_table(msm_ctx *ctx, const CliqueArgs &a, double *out) {
     const size_t total = (size_t)a.P * a.L * a.L;
     if (total == 0) return MSM_OK;

@@ -220,6 +220,24 @@ int msm_cost_pairwise_table(msm_cost *c, double *paircosts) {
     return check_status(ctx, "computePairwiseCosts");
 }
 
+int msm_cost_triplet_table(msm_cost *c, int32_t t0, int32_t t1, double *tcosts) {
+    if (!c || !tcosts) return fail(MSM_ERR_INVALID, "msm_cost_triplet_table: null argument");
+    CliqueArgs a;
+    int st = clique_args(c, true, false, a);
+    if (st) return st;
+    if (t0 < 0 || t1 < t0 || t1 > a.T) return fail(MSM_ERR_INVALID, "msm_cost_triplet_table: triplet range [%d, %d) out of [0, %d)", t0, t1, a.T);
+    msm_ctx *ctx = c->ctx;
+    const size_t total = (size_t)(t1 - t0) * a.L * a.L * a.L;
+    if (total == 0) return MSM_OK;
+    if (total > ((size_t)1 << 31)) return fail(MSM_ERR_CAPACITY, "msm_cost_triplet_table: %zu values in one call; ask for a smaller triplet range", total);
+    MSM_HIP(c->d_clique_out.ensure(total));
+    st = launch_triplet_table(ctx, a, t0, t1, c->d_clique_out.p);
+    if (st) return st;
+    MSM_HIP(c->d_clique_out.download(tcosts, total, ctx->stream));
+    c->counters[2] += (int64_t)total;
+    return check_status(ctx, "computeTripletCosts");
+}
+
 // evaluateTotalCostSum, M/DiscreteCostFunction.cpp:55-77: the three sums run in the reference's serial order on
 // the host over device-evaluated terms (N + P + T values), because the order defines the reported energy
 int msm_cost_total(msm_cost *c, const int32_t *labeling, double *total, double parts[3]) {

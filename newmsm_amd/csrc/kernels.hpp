@@ -104,6 +104,7 @@ int launch_triplet_batch(msm_ctx *ctx, const CliqueArgs &a, const int *qt, const
 int launch_triplet_octets(msm_ctx *ctx, const CliqueArgs &a, const int *labeling, int label, double *out);
 int launch_pairwise_batch(msm_ctx *ctx, const CliqueArgs &a, const int *qp, const int *qa, const int *qb, int n, double *out);
 int launch_pairwise_table(msm_ctx *ctx, const CliqueArgs &a, double *out);
+int launch_triplet_table(msm_ctx *ctx, const CliqueArgs &a, int t0, int t1, double *out);
 
 
 // groupwise (gMSM)

@@ -187,3 +187,19 @@ def test_anatomical_strain_needs_its_inputs(ctx):
     cf, _ = problem.build_cost(ctx, inp, kind="univariate", rmode=5)
     with pytest.raises(M.MsmError, match="anatomical"):
         cf.computeTripletCost(np.zeros(1, np.int32), np.zeros(1, np.int32), np.zeros(1, np.int32), np.zeros(1, np.int32))
+
+
+def test_triplet_table_matches_on_demand_evaluation(ctx):
+    # computeTripletCosts (the MCMC optimiser's tcosts[t][a][b][c], M/DiscreteCostFunction.cpp:245-253) in triplet ranges
+    inp = problem.pairwise_inputs(4, 2, D=1)
+    cf, oc, _ = pair(ctx, inp, "univariate", rmode=3, lambda_=0.2)
+    tab = cf.computeTripletCosts(5, 9)
+    assert tab.shape == (4, cf.L, cf.L, cf.L)
+    rng = np.random.default_rng(11)
+    t, la, lb, lc = random_queries(rng, 300, 4, cf.L, 3)
+    assert np.array_equal(tab[t, la, lb, lc], cf.computeTripletCost(t + 5, la, lb, lc))
+    for q in range(0, 300, 25):
+        want = oc.triplet(int(t[q]) + 5, int(la[q]), int(lb[q]), int(lc[q]))
+        assert abs(tab[t[q], la[q], lb[q], lc[q]] - want) <= ATOL + RTOL * abs(want)
+    with pytest.raises(M.MsmError):
+        cf.computeTripletCosts(0, cf.T + 1)
