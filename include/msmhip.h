@@ -137,6 +137,12 @@ int msm_sphere_project_warp(msm_mesh *from, const double *to_xyz, double *sphere
 /* surface_resample :284-302 / project_anatomical_mesh :260-282 core: out = sum_j w_j * coords[v_j] for the
  * barycentric weights of q against `from` (no renormalisation); coords 3 x V(from), out 3 x N */
 int msm_barycentric_coords_resample(msm_mesh *from, const double *coords_xyz, const double *q_xyz, int32_t N, double *out_xyz);
+/* smooth_data R/resampler.cpp:168-230: Gaussian smoothing (std sigma, geodesic) of D x V(orig) data rows onto the vertices
+ * of sphlow, with the reference's indexing (orig's octree finds the centre, whose id then indexes sphlow; neighbours
+ * run over sphlow's vertices and read orig's data by the same id -- i.e. meant for orig and sphlow being the same
+ * sphere).  excl (optional, V(orig) values) is the EXCL mesh's data and excl_out (optional, V(sphlow)) the smoothed
+ * mask the reference writes back.  check_scale (R/mesh.cpp:1198-1208) is left to the caller.  out: D x V(sphlow). */
+int msm_smooth_data(msm_mesh *orig, const double *data, int32_t D, msm_mesh *sphlow, double sigma, const double *excl, double *out, double *excl_out);
 /* nearest_neighbour_interpolation R/resampler.cpp:232-258 without exclusion: data D x V(orig) -> out D x N */
 int msm_nearest_neighbour(msm_mesh *orig, const double *data, int32_t D, const double *q_xyz, int32_t N, double *out);
 

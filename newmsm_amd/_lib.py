@@ -72,6 +72,7 @@ SIGNATURES = {
     "msm_metric_resample": (C.c_int, [_VP, c_dp, C.c_int32, _VP, c_dp]),
     "msm_sphere_project_warp": (C.c_int, [_VP, c_dp, c_dp, C.c_int32]),
     "msm_barycentric_coords_resample": (C.c_int, [_VP, c_dp, c_dp, C.c_int32, c_dp]),
+    "msm_smooth_data": (C.c_int, [_VP, c_dp, C.c_int32, _VP, C.c_double, c_dp, c_dp, c_dp]),
     "msm_nearest_neighbour": (C.c_int, [_VP, c_dp, C.c_int32, c_dp, C.c_int32, c_dp]),
     "msm_cost_create": (_VP, [_VP, C.POINTER(CostParams)]),
     "msm_cost_destroy": (None, [_VP]),

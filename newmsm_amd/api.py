@@ -259,6 +259,20 @@ def barycentric_coords_resample(from_mesh, coords, q):
     return np.ascontiguousarray(out.T)
 
 
+def smooth_data(orig_mesh, data, sph_low, sigma, excl=None):
+    """newresampler::smooth_data (R/resampler.cpp:168-230); returns the smoothed D x V rows (and the smoothed mask)."""
+    d, pd = _d(np.atleast_2d(data))
+    assert d.shape[1] == orig_mesh.V
+    out = np.zeros((d.shape[0], sph_low.V))
+    if excl is None:
+        check(lib().msm_smooth_data(orig_mesh.h, pd, d.shape[0], sph_low.h, float(sigma), None, out.ctypes.data_as(c_dp), None))
+        return out
+    e, pe = _d(excl)
+    eo = np.zeros(sph_low.V)
+    check(lib().msm_smooth_data(orig_mesh.h, pd, d.shape[0], sph_low.h, float(sigma), pe, out.ctypes.data_as(c_dp), eo.ctypes.data_as(c_dp)))
+    return out, eo
+
+
 def nearest_neighbour_interpolation(orig_mesh, data, q):
     d, pd = _d(np.atleast_2d(data))
     x, px = _soa(q)

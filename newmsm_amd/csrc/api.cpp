@@ -553,6 +553,33 @@ int msm_barycentric_coords_resample(msm_mesh *from, const double *coords, const 
     return bary_coords(from, coords, q, N, out, false, "msm_barycentric_coords_resample");
 }
 
+int msm_smooth_data(msm_mesh *orig, const double *data, int32_t D, msm_mesh *sphlow, double sigma, const double *excl, double *out, double *excl_out) {
+    if (!orig || !data || !sphlow || !out || D <= 0 || !(sigma > 0)) return fail(MSM_ERR_INVALID, "msm_smooth_data: bad arguments");
+    const int N = sphlow->V;
+    // the reference reads orig's data and the exclusion mask with sphLow's vertex ids (R/resampler.cpp:193-210)
+    if (orig->V < N) return fail(MSM_ERR_INVALID, "msm_smooth_data: the data mesh has %d vertices, the sphere %d", orig->V, N);
+    msm_ctx *ctx = orig->ctx;
+    int st = ensure_tree(orig);
+    if (st) return st;
+    DevBuf<double> dunit, ddata, dexcl, dout, dexo;
+    DevBuf<int> dcv;
+    MSM_HIP(dcv.ensure(N));
+    st = launch_closest_vertex(ctx, dev_tree(orig), sphlow->d_xyz, N, dcv.p);  // Octree(orig).get_closest_vertex_ID(ci), :182
+    if (st) return st;
+    MSM_HIP(dunit.ensure(3 * (size_t)N));
+    MSM_HIP(ddata.upload(data, (size_t)D * orig->V, ctx->stream));
+    if (excl) MSM_HIP(dexcl.upload(excl, (size_t)orig->V, ctx->stream));
+    MSM_HIP(dout.ensure((size_t)D * N));
+    if (excl && excl_out) MSM_HIP(dexo.ensure(N));
+    const double ang = 4 * asin(sigma / (2 * kRad));  // :175, with the host's libm like the reference
+    st = launch_smooth(ctx, sphlow->d_xyz, N, dunit.p, dcv.p, ddata.p, orig->V, D, sigma, cos(ang), excl ? dexcl.p : nullptr, dout.p,
+                       (excl && excl_out) ? dexo.p : nullptr);
+    if (st) return st;
+    MSM_HIP(dout.download(out, (size_t)D * N, ctx->stream));
+    if (excl && excl_out) MSM_HIP(dexo.download(excl_out, N, ctx->stream));
+    return check_status(ctx, "msm_smooth_data");
+}
+
 int msm_nearest_neighbour(msm_mesh *orig, const double *data, int32_t D, const double *q, int32_t N, double *out) {
     if (!orig || !data || !q || !out || D <= 0 || N < 0) return fail(MSM_ERR_INVALID, "msm_nearest_neighbour: bad arguments");
     std::vector<int32_t> cv(N);

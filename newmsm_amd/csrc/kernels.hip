@@ -155,6 +155,106 @@ __global__ __launch_bounds__(256) void k_closest_vertex(DevTree T, const double 
 }
 
 // ------------------------------------------------------------------------------------------------
+// smooth_data, R/resampler.cpp:168-230: Gaussian smoothing of the data over the geodesic neighbourhood of each
+// vertex.  The reference tests every vertex pair (N^2 = 1.7e9 at ico6) serially per output vertex; here a wavefront
+// owns an output vertex and sweeps the unit vectors of all vertices (precomputed once with Point::normalize's
+// arithmetic, so the membership test (actual | ref) >= cos(ang) sees the reference's bits), compacts the members in
+// ascending order into LDS and then sums weights and features over that list in the reference's order.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_unit_vectors(const double *__restrict__ xyz, int N, double *__restrict__ unit) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const V3 u = normalized(mk(xyz[i], xyz[N + i], xyz[2 * N + i]));
+    unit[i] = u.x;
+    unit[N + i] = u.y;
+    unit[2 * N + i] = u.z;
+}
+
+constexpr int kSmoothList = 512;  // neighbours per LDS pass of one wavefront
+
+__global__ __launch_bounds__(256) void k_smooth(const double *__restrict__ unit, int N, const int *__restrict__ cv, const double *__restrict__ data,
+                                                int Vorig, int D, double sigma, double cosang, const double *__restrict__ excl,
+                                                double *__restrict__ out, double *__restrict__ excl_out, int *status) {
+    __shared__ int s_n[4][kSmoothList];
+    __shared__ double s_w[4][kSmoothList];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + wave;
+    if (i >= N) return;
+    int *ln = s_n[wave];
+    double *lw = s_w[wave];
+    const int c = cv[i];
+    if (c < 0 || c >= N) {  // the reference indexes sphLow with the id found in orig's octree (:185)
+        if (lane == 0) raise_status(status, c < 0 ? c : MSM_ERR_INVALID);
+        for (int d = lane; d < D; d += 64) out[(size_t)d * N + i] = __longlong_as_double(0x7ff8000000000000ll);
+        return;
+    }
+    if (lane == 0 && excl_out) excl_out[i] = 0.0;
+    for (int d = lane; d < D; d += 64) out[(size_t)d * N + i] = 0.0;
+    if (excl && !(excl[c] > 0)) return;  // :200: excluded centre: data stays 0
+    const V3 ref = mk(unit[c], unit[N + c], unit[2 * N + c]);
+    const double gain = 1 / sqrt(2 * M_PI * sigma * sigma);
+    double SUM = 0.0, excl_sum = 0.0;
+    double acc = 0.0;  // lane d < D accumulates feature d (more than 64 features: extra passes below)
+    int count = 0;     // members in the LDS list (wavefront-uniform)
+    auto flush = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wavefront's LDS writes have landed
+        // weights in list order on every lane (same values everywhere), then the features
+        for (int k = 0; k < count; ++k) {
+            double w = lw[k];
+            excl_sum += w;
+            if (excl) w = excl[ln[k]] * w;
+            SUM += w;
+            for (int d = lane; d < D; d += 64) {
+                const double add = data[(size_t)d * Vorig + ln[k]] * w;
+                if (d < 64) acc += add;
+                else out[(size_t)d * N + i] += add;  // rare: more than 64 features
+            }
+        }
+        count = 0;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
+    for (int n0 = 0; n0 < N; n0 += 64) {
+        const int n = n0 + lane;
+        bool in = false;
+        double chord = 0.0;
+        if (n < N) {
+            const V3 a = mk(unit[n], unit[N + n], unit[2 * N + n]);
+            in = dot(a, ref) >= cosang;
+            if (in) chord = norm(sub(ref, a));
+        }
+        const unsigned long long bal = __ballot(in);
+        if (!bal) continue;
+        const int add = __popcll(bal);
+        if (count + add > kSmoothList) flush();
+        if (in) {
+            const double g = 2 * kRad * asin(chord / (2 * kRad));
+            const int at = count + __popcll(bal & ((1ull << lane) - 1ull));
+            ln[at] = n;
+            lw[at] = gain * exp(-(g * g) / (2 * sigma * sigma));
+        }
+        count += add;
+    }
+    flush();
+    if (lane == 0 && excl && excl_out && excl_sum != 0.0) excl_out[i] = SUM / excl_sum;
+    for (int d = lane; d < D; d += 64) {
+        double v = d < 64 ? acc : out[(size_t)d * N + i];
+        if (SUM != 0.0) v /= SUM;
+        out[(size_t)d * N + i] = v;
+    }
+}
+
+int launch_smooth(msm_ctx *ctx, const double *d_xyz, int N, double *d_unit, const int *d_cv, const double *d_data, int Vorig, int D, double sigma,
+                  double cosang, const double *d_excl, double *d_out, double *d_excl_out) {
+    if (N <= 0) return MSM_OK;
+    hipLaunchKernelGGL(k_unit_vectors, dim3((N + 255) / 256), dim3(256), 0, ctx->stream, d_xyz, N, d_unit);
+    MSM_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_smooth, dim3((N + 3) / 4), dim3(256), 0, ctx->stream, d_unit, N, d_cv, d_data, Vorig, D, sigma, cosang, d_excl, d_out,
+                       d_excl_out, ctx->d_status);
+    MSM_HIP(hipGetLastError());
+    return MSM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // get_source_data range test (within_controlpt_range, M/DiscreteCostFunction.cpp:102-107): one
 // workgroup per control point sweeps all source vertices and writes the in-range ones, in ascending
 // order, to the control point's slot.  The geodesic distance needs asin(); device and host libm may

@@ -11,6 +11,9 @@ int launch_build_masks(msm_ctx *ctx, const DevTree &T, const double4 *d_nodebox,
 int launch_build_raytri(msm_ctx *ctx, const TriRec *d_rec, const float4 *d_edge, int T, const double *d_feat1, float4 *d_out);
 int launch_query(msm_ctx *ctx, const DevTree &T, const double *d_q, int N, int *d_tri, int *d_vid, double *d_w, int mode);
 int launch_closest_vertex(msm_ctx *ctx, const DevTree &T, const double *d_q, int N, int *d_out);
+// smooth_data: unit vectors of the N vertices (d_unit: 3 x N scratch), then one wavefront per output vertex
+int launch_smooth(msm_ctx *ctx, const double *d_xyz, int N, double *d_unit, const int *d_cv, const double *d_data, int Vorig, int D, double sigma,
+                  double cosang, const double *d_excl, double *d_out, double *d_excl_out);
 int launch_range(msm_ctx *ctx, const double *d_cp, int Ncp, const double *d_src, int Nsrc, const double *d_maxsep, double range, int cap,
                  uint32_t *d_slots, int *d_counts);
 

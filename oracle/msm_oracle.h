@@ -105,6 +105,9 @@ void orc_apply_weights(const int *row_ptr, const int *col, const double *val, in
 int  orc_metric_resample(const orc_mesh *in_mesh, const double *data, int D, const orc_mesh *new_mesh, double *out);
 /* sphere_project_warp (:311-328): sphere[N] moved through from->to */
 int  orc_sphere_project_warp(double *sphere, int N, const orc_mesh *from, const double *to_xyz);
+/* smooth_data (:168-230): Gaussian smoothing over the geodesic neighbourhood (see orc_resample.c for the index quirks) */
+int  orc_smooth_data(const orc_mesh *orig, const double *data, int D, const orc_mesh *sphLow, double sigma, const double *excl, double *out,
+                     double *excl_out);
 /* nearest_neighbour_interpolation (:232-258) without exclusion */
 int  orc_nearest_neighbour(const orc_mesh *orig, const double *data, int D, const double *q, int N, double *out);
 

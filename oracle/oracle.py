@@ -237,6 +237,18 @@ def nearest_neighbour(orig_mesh, data, q):
     return out
 
 
+def smooth_data(orig_mesh, data, sph_low, sigma, excl=None):
+    data, pd = _d(np.atleast_2d(data))
+    out = np.zeros((data.shape[0], sph_low.V))
+    eo = np.zeros(sph_low.V) if excl is not None else None
+    pe = _d(excl)[1] if excl is not None else None
+    st = lib().orc_smooth_data(orig_mesh.h, pd, data.shape[0], sph_low.h, C.c_double(sigma), pe, out.ctypes.data_as(c_dp),
+                               eo.ctypes.data_as(c_dp) if eo is not None else None)
+    if st:
+        raise RuntimeError("smooth_data failed (%d)" % st)
+    return (out, eo) if excl is not None else out
+
+
 # ---------------------------------------------------------------- discrete model host logic
 def cp_spacings(cp_mesh):
     ms = np.zeros(cp_mesh.V)

@@ -212,3 +212,48 @@ int orc_nearest_neighbour(const orc_mesh *orig, const double *data, int D, const
     orc_octree_destroy(t);
     return st;
 }
+
+/* smooth_data, R/resampler.cpp:168-230, index for index: the octree is built over `orig`, but the closest vertex id it
+ * returns is then used to index sphLow's coordinates (:185) and the neighbour loop runs over sphLow's vertices while
+ * reading orig's data (:210) -- the function is meant for orig and sphLow being the same mesh (its callers pass
+ * that).  excl (optional, >= max(V) values) is the EXCL mesh's data; excl_out (optional, sphLow->V) receives the
+ * smoothed mask.  check_scale (R/mesh.cpp:1198-1208) is the caller's job here.  Returns 0, or a negative octree
+ * error, or -3 when a closest vertex id does not exist in sphLow. */
+int orc_smooth_data(const orc_mesh *orig, const double *data, int D, const orc_mesh *sphLow, double sigma, const double *excl, double *out,
+                    double *excl_out) {
+    const int N = sphLow->V;
+    const double ang = 4 * asin(sigma / (2 * ORC_RAD));
+    const double cosang = cos(ang);
+    orc_octree *t = orc_octree_build(orig);
+    int st = 0;
+    for (long k = 0; k < (long)D * N; ++k) out[k] = 0.0;
+    for (int i = 0; i < N && !st; ++i) {
+        if (excl_out) excl_out[i] = 0.0;
+        const int cv = orc_octree_closest_vertex(t, &sphLow->xyz[3 * i]);
+        if (cv < 0) { st = cv; break; }
+        if (cv >= N) { st = -3; break; }
+        double ref[3] = {sphLow->xyz[3 * cv], sphLow->xyz[3 * cv + 1], sphLow->xyz[3 * cv + 2]};
+        orc_normalize(ref);
+        double SUM = 0.0, excl_sum = 0.0;
+        if (!excl || excl[cv] > 0) {
+            for (int n = 0; n < N; ++n) {
+                double actual[3] = {sphLow->xyz[3 * n], sphLow->xyz[3 * n + 1], sphLow->xyz[3 * n + 2]};
+                orc_normalize(actual);
+                if (!((actual[0] * ref[0] + actual[1] * ref[1] + actual[2] * ref[2]) >= cosang)) continue;
+                const double dx = ref[0] - actual[0], dy = ref[1] - actual[1], dz = ref[2] - actual[2];
+                const double chord = sqrt(dx * dx + dy * dy + dz * dz);
+                const double g = 2 * ORC_RAD * asin(chord / (2 * ORC_RAD));
+                double weight = (1 / sqrt(2 * M_PI * sigma * sigma)) * exp(-(g * g) / (2 * sigma * sigma));
+                excl_sum += weight;
+                if (excl) weight = excl[n] * weight;
+                SUM += weight;
+                for (int d = 0; d < D; ++d) out[(long)d * N + i] += data[(long)d * orig->V + n] * weight;
+            }
+            if (excl_sum != 0.0 && excl && excl_out) excl_out[i] = SUM / excl_sum;
+            for (int d = 0; d < D; ++d)
+                if (SUM != 0.0) out[(long)d * N + i] /= SUM;
+        }
+    }
+    orc_octree_destroy(t);
+    return st;
+}

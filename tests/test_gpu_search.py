@@ -189,3 +189,36 @@ def test_repeated_coordinate_updates_grow_and_shrink_the_tree(ctx):
         ok = ot >= 0
         assert np.array_equal(wt[ok], ow[ok])
     assert len(sizes) > 1
+
+
+@pytest.mark.parametrize("order,sigma", [(4, 4.0), (5, 2.0)])
+def test_smooth_data(ctx, order, sigma):
+    # smooth_data, R/resampler.cpp:168-230: exact neighbourhoods (the membership test sees the reference's bits), weights
+    # through asin/exp (device libm vs glibc): rtol 1e-12
+    xyz, tri = M.make_mesh_from_icosa(order)
+    rng = np.random.default_rng(5)
+    data = np.stack([synthetic.smooth_feature(xyz, 0), rng.normal(size=len(xyz)), synthetic.smooth_feature(xyz, 2) ** 2])
+    m = M.Mesh(ctx, xyz, tri)
+    om = O.Mesh(xyz, tri)
+    got = M.smooth_data(m, data, m, sigma)
+    want = O.smooth_data(om, data, om, sigma)
+    assert got.shape == want.shape == (3, len(xyz))
+    assert np.allclose(got, want, rtol=1e-12, atol=1e-14), np.max(np.abs(got - want))
+    assert np.std(got[1]) < 0.5 * np.std(data[1])  # it does smooth
+    # with an exclusion mask: excluded centres stay 0, excluded neighbours do not contribute, the mask is smoothed too
+    excl = (rng.uniform(size=len(xyz)) > 0.2).astype(float)
+    got, gmask = M.smooth_data(m, data, m, sigma, excl)
+    want, wmask = O.smooth_data(om, data, om, sigma, excl)
+    assert np.array_equal(got == 0.0, want == 0.0)
+    assert np.allclose(got, want, rtol=1e-12, atol=1e-14) and np.allclose(gmask, wmask, rtol=1e-12, atol=1e-14)
+    assert np.all(got[:, excl == 0] == 0.0)
+
+
+def test_smooth_data_large_neighbourhoods(ctx):
+    # sigma so large that every vertex has more neighbours than one LDS pass holds (flush path), D > 64 features
+    xyz, tri = M.make_mesh_from_icosa(4)
+    rng = np.random.default_rng(6)
+    data = rng.normal(size=(70, len(xyz)))
+    m = M.Mesh(ctx, xyz, tri)
+    om = O.Mesh(xyz, tri)
+    assert np.allclose(M.smooth_data(m, data, m, 30.0), O.smooth_data(om, data, om, 30.0), rtol=1e-11, atol=1e-13)
