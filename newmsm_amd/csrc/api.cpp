@@ -27,10 +27,8 @@ int check_status(msm_ctx *ctx, const char *what) {
     return MSM_OK;
 }
 
-int ensure_tree(msm_mesh *m) {
-    if (m->tree_valid) return MSM_OK;
-    std::vector<TriRec> recs;
-    build_octree(m->xyz.data(), m->tri.data(), m->V, m->T, m->tree, recs);
+// uploads a built tree (m->tree, recs) to the device
+static int upload_tree(msm_mesh *m, const std::vector<TriRec> &recs) {
     msm_ctx *ctx = m->ctx;
     MSM_HIP(hipSetDevice(ctx->device));
     auto grow = [&](void **p, size_t &cap, size_t need, size_t elem) -> hipError_t {
@@ -47,19 +45,60 @@ int ensure_tree(msm_mesh *m) {
     MSM_HIP(grow((void **)&m->d_rec, m->cap_rec, recs.size(), sizeof(TriRec)));
     MSM_HIP(grow((void **)&m->d_grid, m->cap_grid, m->tree.grid.size(), sizeof(int32_t)));
     MSM_HIP(grow((void **)&m->d_nodebox, m->cap_box, m->tree.node.size(), sizeof(double4)));
-    // the staging vectors die at scope exit, so these copies must complete here
-    MSM_HIP(hipMemcpyAsync(m->d_node, m->tree.node.data(), m->tree.node.size() * sizeof(int4), hipMemcpyHostToDevice, ctx->stream));
-    MSM_HIP(hipMemcpyAsync(m->d_parent, m->tree.parent.data(), m->tree.parent.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
-    MSM_HIP(hipMemcpyAsync(m->d_leaf_tri, m->tree.leaf_tri.data(), m->tree.leaf_tri.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
-    MSM_HIP(hipMemcpyAsync(m->d_cone, m->tree.cone.data(), m->tree.cone.size() * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
-    MSM_HIP(hipMemcpyAsync(m->d_rec, recs.data(), recs.size() * sizeof(TriRec), hipMemcpyHostToDevice, ctx->stream));
-    MSM_HIP(hipMemcpyAsync(m->d_grid, m->tree.grid.data(), m->tree.grid.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
-    MSM_HIP(hipMemcpyAsync(m->d_nodebox, m->tree.nodebox.data(), m->tree.nodebox.size() * sizeof(double4), hipMemcpyHostToDevice, ctx->stream));
+    // all arrays go through one pinned staging buffer: a host memcpy each, then DMA at link speed
+    struct Part {
+        void *dst;
+        const void *src;
+        size_t bytes;
+    };
+    const Part parts[] = {
+        {m->d_node, m->tree.node.data(), m->tree.node.size() * sizeof(int4)},
+        {m->d_parent, m->tree.parent.data(), m->tree.parent.size() * sizeof(int32_t)},
+        {m->d_leaf_tri, m->tree.leaf_tri.data(), m->tree.leaf_tri.size() * sizeof(int32_t)},
+        {m->d_cone, m->tree.cone.data(), m->tree.cone.size() * sizeof(float4)},
+        {m->d_rec, recs.data(), recs.size() * sizeof(TriRec)},
+        {m->d_grid, m->tree.grid.data(), m->tree.grid.size() * sizeof(int32_t)},
+        {m->d_nodebox, m->tree.nodebox.data(), m->tree.nodebox.size() * sizeof(double4)},
+    };
+    size_t total = 0;
+    for (const Part &pt : parts) total += (pt.bytes + 255) & ~(size_t)255;
+    MSM_HIP(hipStreamSynchronize(ctx->stream));  // an earlier upload may still read the staging buffer
+    if (total > ctx->stage_cap) {
+        if (ctx->stage) (void)hipHostFree(ctx->stage);
+        ctx->stage = nullptr;
+        ctx->stage_cap = total + total / 4;
+        MSM_HIP(hipHostMalloc(&ctx->stage, ctx->stage_cap));
+    }
+    size_t off = 0;
+    for (const Part &pt : parts) {
+        if (pt.bytes == 0) continue;
+        std::memcpy((char *)ctx->stage + off, pt.src, pt.bytes);
+        MSM_HIP(hipMemcpyAsync(pt.dst, (char *)ctx->stage + off, pt.bytes, hipMemcpyHostToDevice, ctx->stream));
+        off += (pt.bytes + 255) & ~(size_t)255;
+    }
     m->masks_valid = false;
     m->rays_valid = false;
     MSM_HIP(hipStreamSynchronize(ctx->stream));
     m->tree_valid = true;
     return MSM_OK;
+}
+
+int ensure_tree(msm_mesh *m) {
+    if (m->tree_valid) return MSM_OK;
+    std::vector<TriRec> recs;
+    build_octree(m->xyz.data(), m->tri.data(), m->V, m->T, m->tree, recs);
+    return upload_tree(m, recs);
+}
+
+// new coordinates together with the search structure built for them elsewhere (e.g. on a worker thread)
+int install_coords_and_tree(msm_mesh *m, const double *xyz, FlatOctree &&tree, const std::vector<TriRec> &recs) {
+    msm_ctx *ctx = m->ctx;
+    MSM_HIP(hipStreamSynchronize(ctx->stream));
+    m->xyz.assign(xyz, xyz + 3 * (size_t)m->V);
+    MSM_HIP(hipMemcpyAsync(m->d_xyz, m->xyz.data(), sizeof(double) * 3 * (size_t)m->V, hipMemcpyHostToDevice, ctx->stream));
+    m->tree = std::move(tree);
+    m->rayrec_valid = false;
+    return upload_tree(m, recs);
 }
 
 int ensure_masks(msm_mesh *m) {
@@ -158,54 +197,75 @@ const Adjacency &mesh_adjacency(msm_mesh *m) {
 }
 
 // get_barycentric_weights on the device for host-resident query points
+static hipError_t ctx_scratch(msm_ctx *ctx, int slot, size_t bytes, void **out) {
+    if (bytes > ctx->q_cap[slot] || !ctx->q_buf[slot]) {
+        if (ctx->q_buf[slot]) (void)hipFree(ctx->q_buf[slot]);
+        ctx->q_buf[slot] = nullptr;
+        ctx->q_cap[slot] = bytes + bytes / 4 + 256;
+        hipError_t e = hipMalloc(&ctx->q_buf[slot], ctx->q_cap[slot]);
+        if (e != hipSuccess) {
+            ctx->q_cap[slot] = 0;
+            return e;
+        }
+    }
+    *out = ctx->q_buf[slot];
+    return hipSuccess;
+}
+
 int query_host(msm_mesh *target, const double *q, int N, int *tri_id, int *vid, double *w, int mode, const char *what) {
     msm_ctx *ctx = target->ctx;
     int st = ensure_tree(target);
     if (st) return st;
-    DevBuf<double> dq, dw;
-    DevBuf<int> dt, dv;
-    MSM_HIP(dq.upload(q, 3 * (size_t)N, ctx->stream));
-    if (tri_id) MSM_HIP(dt.ensure(N));
-    if (vid) MSM_HIP(dv.ensure(3 * (size_t)N));
-    if (w) MSM_HIP(dw.ensure(3 * (size_t)N));
-    st = launch_query(ctx, dev_tree(target), dq.p, N, tri_id ? dt.p : nullptr, vid ? dv.p : nullptr, w ? dw.p : nullptr, mode);
+    double *dq = nullptr, *dw = nullptr;
+    int *dt = nullptr, *dv = nullptr;
+    MSM_HIP(ctx_scratch(ctx, 0, sizeof(double) * 3 * (size_t)N, (void **)&dq));
+    MSM_HIP(hipMemcpyAsync(dq, q, sizeof(double) * 3 * (size_t)N, hipMemcpyHostToDevice, ctx->stream));
+    if (tri_id) MSM_HIP(ctx_scratch(ctx, 1, sizeof(int) * (size_t)N, (void **)&dt));
+    if (vid) MSM_HIP(ctx_scratch(ctx, 2, sizeof(int) * 3 * (size_t)N, (void **)&dv));
+    if (w) MSM_HIP(ctx_scratch(ctx, 3, sizeof(double) * 3 * (size_t)N, (void **)&dw));
+    st = launch_query(ctx, dev_tree(target), dq, N, dt, dv, dw, mode);
     if (st) return st;
-    if (tri_id) MSM_HIP(dt.download(tri_id, N, ctx->stream));
-    if (vid) MSM_HIP(dv.download(vid, 3 * (size_t)N, ctx->stream));
-    if (w) MSM_HIP(dw.download(w, 3 * (size_t)N, ctx->stream));
+    if (tri_id) MSM_HIP(hipMemcpyAsync(tri_id, dt, sizeof(int) * (size_t)N, hipMemcpyDeviceToHost, ctx->stream));
+    if (vid) MSM_HIP(hipMemcpyAsync(vid, dv, sizeof(int) * 3 * (size_t)N, hipMemcpyDeviceToHost, ctx->stream));
+    if (w) MSM_HIP(hipMemcpyAsync(w, dw, sizeof(double) * 3 * (size_t)N, hipMemcpyDeviceToHost, ctx->stream));
     return check_status(ctx, what);
 }
 
-int vertex_areas(msm_mesh *m, std::vector<double> &area) {
-    const Adjacency &a = mesh_adjacency(m);
-    const int V = m->V, T = m->T;
+// compute_vertex_area for every vertex (R/mesh.cpp:1275-1283): mean area of the adjacent faces, in trID order
+void vertex_areas_of(const double *xyz, const int32_t *tri, int V, int T, const Adjacency &a, std::vector<double> &area) {
     std::vector<double> ta(T);
-    auto pt = [&](int i) { return mk(m->xyz[i], m->xyz[V + i], m->xyz[2 * V + i]); };
-    for (int t = 0; t < T; ++t) ta[t] = tri_area(pt(m->tri[t]), pt(m->tri[T + t]), pt(m->tri[2 * T + t]));
+    auto pt = [&](int i) { return mk(xyz[i], xyz[V + i], xyz[2 * V + i]); };
+    for (int t = 0; t < T; ++t) ta[t] = tri_area(pt(tri[t]), pt(tri[T + t]), pt(tri[2 * T + t]));
     area.resize(V);
     for (int v = 0; v < V; ++v) {
         double sum = 0;
         for (int j = a.tid_ptr[v]; j < a.tid_ptr[v + 1]; ++j) sum += ta[a.tid[j]];
         area[v] = sum / (a.tid_ptr[v + 1] - a.tid_ptr[v]);
     }
+}
+
+int vertex_areas(msm_mesh *m, std::vector<double> &area) {
+    vertex_areas_of(m->xyz.data(), m->tri.data(), m->V, m->T, mesh_adjacency(m), area);
     return MSM_OK;
 }
 
-// Resampler::get_adaptive_barycentric_weights, R/resampler.cpp:72-140.  The 2 x N nearest-triangle
-// queries run on the GPU; the list surgery (transpose, pick, area correction) is done on the host in
-// the reference's serial order so that every sum has the same operand order.
-int adaptive_weights(msm_mesh *in_mesh, msm_mesh *new_mesh, const double *excl, std::vector<int32_t> &row_ptr,
-                     std::vector<int32_t> &col, std::vector<double> &val) {
+// Resampler::get_adaptive_barycentric_weights, R/resampler.cpp:72-140, in two halves: the 2 x N nearest-triangle
+// queries run on the GPU (adaptive_queries); the list surgery (transpose, pick, area correction) is done on the
+// host in the reference's serial order so that every sum has the same operand order (adaptive_surgery: touches
+// no handle, so callers may run several of them on worker threads).
+int adaptive_queries(msm_mesh *in_mesh, msm_mesh *new_mesh, bool with_closest, AdaptiveQueries &q) {
     const int nOld = in_mesh->V, nNew = new_mesh->V;
-    std::vector<int> fvid(3 * (size_t)nNew), rvid(3 * (size_t)nOld);
-    std::vector<double> fw(3 * (size_t)nNew), rw(3 * (size_t)nOld);
-    int st = query_host(in_mesh, new_mesh->xyz.data(), nNew, nullptr, fvid.data(), fw.data(), MSM_WEIGHTS_PROJECTED, "adaptive weights (forward)");
+    q.fvid.resize(3 * (size_t)nNew);
+    q.rvid.resize(3 * (size_t)nOld);
+    q.fw.resize(3 * (size_t)nNew);
+    q.rw.resize(3 * (size_t)nOld);
+    int st = query_host(in_mesh, new_mesh->xyz.data(), nNew, nullptr, q.fvid.data(), q.fw.data(), MSM_WEIGHTS_PROJECTED, "adaptive weights (forward)");
     if (st) return st;
-    st = query_host(new_mesh, in_mesh->xyz.data(), nOld, nullptr, rvid.data(), rw.data(), MSM_WEIGHTS_PROJECTED, "adaptive weights (reverse)");
+    st = query_host(new_mesh, in_mesh->xyz.data(), nOld, nullptr, q.rvid.data(), q.rw.data(), MSM_WEIGHTS_PROJECTED, "adaptive weights (reverse)");
     if (st) return st;
-    std::vector<int> closest;
-    if (excl) {
-        closest.resize(nNew);
+    q.closest.clear();
+    if (with_closest) {
+        q.closest.resize(nNew);
         msm_ctx *ctx = in_mesh->ctx;
         DevBuf<double> dq;
         DevBuf<int> dout;
@@ -213,14 +273,29 @@ int adaptive_weights(msm_mesh *in_mesh, msm_mesh *new_mesh, const double *excl, 
         MSM_HIP(dout.ensure(nNew));
         st = launch_closest_vertex(ctx, dev_tree(in_mesh), dq.p, nNew, dout.p);
         if (st) return st;
-        MSM_HIP(dout.download(closest.data(), nNew, ctx->stream));
+        MSM_HIP(dout.download(q.closest.data(), nNew, ctx->stream));
         st = check_status(ctx, "adaptive weights (exclusion)");
         if (st) return st;
     }
+    return MSM_OK;
+}
+
+int adaptive_weights(msm_mesh *in_mesh, msm_mesh *new_mesh, const double *excl, std::vector<int32_t> &row_ptr,
+                     std::vector<int32_t> &col, std::vector<double> &val) {
+    AdaptiveQueries q;
+    int st = adaptive_queries(in_mesh, new_mesh, excl != nullptr, q);
+    if (st) return st;
     std::vector<double> oldA, newA;
     vertex_areas(in_mesh, oldA);
     vertex_areas(new_mesh, newA);
+    adaptive_surgery(q, in_mesh->V, new_mesh->V, oldA, newA, excl, row_ptr, col, val);
+    return MSM_OK;
+}
 
+void adaptive_surgery(const AdaptiveQueries &q, int nOld, int nNew, const std::vector<double> &oldA, const std::vector<double> &newA,
+                      const double *excl, std::vector<int32_t> &row_ptr, std::vector<int32_t> &col, std::vector<double> &val) {
+    const std::vector<int> &fvid = q.fvid, &rvid = q.rvid, &closest = q.closest;
+    const std::vector<double> &fw = q.fw, &rw = q.rw;
     struct Entry {
         int32_t key;
         double w;
@@ -293,7 +368,6 @@ int adaptive_weights(msm_mesh *in_mesh, msm_mesh *new_mesh, const double *excl, 
         if (wsum != 0.0)
             for (int e = row_ptr[k]; e < row_ptr[k + 1]; ++e) val[e] /= wsum;
     }
-    return MSM_OK;
 }
 
 }  // namespace msm
@@ -340,6 +414,9 @@ void msm_ctx_destroy(msm_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (void *b : ctx->q_buf)
+        if (b) (void)hipFree(b);
+    if (ctx->stage) (void)hipHostFree(ctx->stage);
     if (ctx->d_status) (void)hipFree(ctx->d_status);
     if (ctx->h_status) (void)hipHostFree(ctx->h_status);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);

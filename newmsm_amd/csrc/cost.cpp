@@ -396,7 +396,7 @@ int msm_cost_get_source_data(msm_cost *c) {
     if (st) return st;
     msm_ctx *ctx = c->ctx;
     MSM_HIP(c->d_pptr.upload(c->pptr.data(), c->pptr.size(), ctx->stream));
-    MSM_HIP(c->d_pidx.upload(c->pidx.data(), std::max<size_t>(c->pidx.size(), 1), ctx->stream));
+    MSM_HIP(c->d_pidx.upload_vec(c->pidx, ctx->stream));
     MSM_HIP(c->d_absw.upload(c->absw.data(), c->absw.size(), ctx->stream));
     {
         // Launch order of the control points in the unary kernels: Morton order of their positions, so that the

@@ -1,6 +1,8 @@
 // devbuf.hpp -- minimal growable device buffer (HBM allocations are kept and reused across calls).
 #pragma once
 
+#include <vector>
+
 #include <hip/hip_runtime.h>
 
 #include <cstddef>
@@ -37,6 +39,12 @@ struct DevBuf {
         hipError_t e = ensure(n);
         if (e != hipSuccess) return e;
         return hipMemcpyAsync(p, host, n * sizeof(T), hipMemcpyHostToDevice, s);
+    }
+    // a whole vector; an empty one still leaves a valid (1-element) allocation behind so that kernels get a non-null pointer
+    hipError_t upload_vec(const std::vector<T> &v, hipStream_t s) {
+        hipError_t e = ensure(v.empty() ? 1 : v.size());
+        if (e != hipSuccess || v.empty()) return e;
+        return hipMemcpyAsync(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s);
     }
     hipError_t download(T *host, size_t n, hipStream_t s) const { return hipMemcpyAsync(host, p, n * sizeof(T), hipMemcpyDeviceToHost, s); }
     hipError_t zero(size_t n, hipStream_t s) {

@@ -5,9 +5,16 @@
 // an adaptive-barycentric resample of its features to the template.  All nearest-triangle queries run on the
 // GPU; the resampled feature maps F[subject][label] (D x V_template) and the patch lists stay in HBM, where the
 // pairwise kernel reads them (group_kernels.hip).
+#include <sched.h>
+
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cmath>
 #include <memory>
+#include <thread>
 
 #include "devbuf.hpp"
 #include "kernels.hpp"
@@ -113,7 +120,7 @@ int subject_patches(msm_group *g, int s) {
     }
     pp[M] = (int32_t)pi.size();
     MSM_HIP(g->pptr[s]->upload(pp.data(), pp.size(), ctx->stream));
-    MSM_HIP(g->pidx[s]->upload(pi.data(), std::max<size_t>(pi.size(), 1), ctx->stream));
+    MSM_HIP(g->pidx[s]->upload_vec(pi, ctx->stream));
     MSM_HIP(hipStreamSynchronize(ctx->stream));
     return MSM_OK;
 }
@@ -300,7 +307,7 @@ int group_common_setup(msm_group *g) {
                     ++pair;
                 }
     }
-    MSM_HIP(g->d_pairs.upload(g->pairs.data(), std::max<size_t>(g->pairs.size(), 1), ctx->stream));
+    MSM_HIP(g->d_pairs.upload_vec(g->pairs, ctx->stream));
     // get_spacings :123-139, get_rotations :77-86, and ROT * label for every (node, label)
     g->rot.resize(9 * (size_t)S * N);
     g->moved.resize(3 * (size_t)S * N * L);
@@ -333,46 +340,130 @@ int group_common_setup(msm_group *g) {
 }
 
 // get_patch_data for one subject, M/DiscreteGroupModel.cpp:88-121
+// host cores this process may use (cgroup / affinity aware), for the set-up's worker threads
+int host_workers() {
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    int n = 0;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) n = CPU_COUNT(&set);
+    if (n <= 0) n = (int)std::thread::hardware_concurrency();
+    if (const char *e = std::getenv("MSMHIP_HOST_THREADS")) n = std::atoi(e);
+    return std::max(1, std::min(n, 64));
+}
+
+// runs fn(0..n-1) on up to `workers` threads; fn must not touch HIP or any msm handle
+template <class F>
+void parallel_for(int n, int workers, F fn) {
+    workers = std::max(1, std::min(workers, n));
+    if (workers == 1) {
+        for (int i = 0; i < n; ++i) fn(i);
+        return;
+    }
+    std::atomic<int> next{0};
+    std::vector<std::thread> pool;
+    for (int w = 0; w < workers; ++w)
+        pool.emplace_back([&]() {
+            for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) fn(i);
+        });
+    for (auto &t : pool) t.join();
+}
+
+// DiscreteGroupModel::get_patch_data for one subject (M/DiscreteGroupModel.cpp:88-121).  Per label: rotate the data
+// mesh, build its octree, resample the features to the template with adaptive barycentric weights.  The rotations
+// and the 2 x N nearest-triangle queries run on the GPU; the octree builds (the reference's incremental insertion,
+// whose order decides the leaves) and the weight-list surgery are host work, independent per label, and are spread
+// over the host cores in two parallel phases around the GPU phase.
 int group_subject_setup(msm_group *g, int s) {
     if (!g->data[s]) return fail(MSM_ERR_STATE, "msm_group: subject %d has no data", s);
     msm_ctx *ctx = g->ctx;
     const int L = g->L, D = g->D, Vt = g->tmpl->V;
     const double centre[3] = {g->labels[0], g->labels[L], g->labels[2 * (size_t)L]};
     msm_mesh *dm = g->data[s], *sm = g->scratch[s];
-    const int V = dm->V;
-    std::vector<double> rotated(3 * (size_t)V), resampled((size_t)D * Vt);
-    std::vector<int32_t> rp, col;
-    std::vector<double> val;
-    DevBuf<double> d_rot;
-    MSM_HIP(d_rot.ensure(3 * (size_t)V));
-    for (int l = 0; l < L; ++l) {
-        if (l > 0) {
+    const int V = dm->V, T = dm->T;
+    const int workers = host_workers();
+    const bool timing = std::getenv("MSMHIP_TIMING") != nullptr;
+    auto tick = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "  group set-up, subject %d: %s %.1f ms (%d workers)\n", s, what, std::chrono::duration<double, std::milli>(now - tick).count(), workers);
+        tick = now;
+    };
+    // phase 1 (GPU): the L rotated meshes
+    std::vector<std::vector<double>> rotated(L);
+    {
+        DevBuf<double> d_rot;
+        MSM_HIP(d_rot.ensure(3 * (size_t)V));
+        for (int l = 0; l < L; ++l) {
+            if (l == 0) {
+                rotated[l] = dm->xyz;
+                continue;
+            }
+            rotated[l].resize(3 * (size_t)V);
             const double lab[3] = {g->labels[l], g->labels[L + l], g->labels[2 * (size_t)L + l]};
             int st = launch_rotate_to_label(ctx, dm->d_xyz, V, centre, lab, d_rot.p);
             if (st) return st;
-            MSM_HIP(d_rot.download(rotated.data(), rotated.size(), ctx->stream));
-            st = check_status(ctx, "get_patch_data (rotation)");
-            if (st) return st;
-        } else {
-            rotated = dm->xyz;
+            MSM_HIP(d_rot.download(rotated[l].data(), rotated[l].size(), ctx->stream));
+            MSM_HIP(hipStreamSynchronize(ctx->stream));
         }
-        int st = msm_mesh_update_coords(sm, rotated.data());
+        int st = check_status(ctx, "get_patch_data (rotation)");
         if (st) return st;
-        st = adaptive_weights(sm, g->tmpl, nullptr, rp, col, val);  // metric_resample(rotated_mesh, target_space)
+    }
+    lap("rotations");
+    // phase 2 (host threads): octrees and vertex areas of the rotated meshes
+    std::vector<FlatOctree> trees(L);
+    std::vector<std::vector<TriRec>> recs(L);
+    std::vector<std::vector<double>> oldA(L);
+    const Adjacency &adj = mesh_adjacency(sm);
+    std::vector<double> newA;
+    vertex_areas_of(g->tmpl->xyz.data(), g->tmpl->tri.data(), g->tmpl->V, g->tmpl->T, mesh_adjacency(g->tmpl), newA);
+    parallel_for(L, workers, [&](int l) {
+        build_octree(rotated[l].data(), sm->tri.data(), V, T, trees[l], recs[l]);
+        vertex_areas_of(rotated[l].data(), sm->tri.data(), V, T, adj, oldA[l]);
+    });
+    lap("octrees");
+    // phase 3 (GPU): forward and reverse queries of metric_resample(rotated_mesh, target_space)
+    std::vector<AdaptiveQueries> queries(L);
+    double t_install = 0, t_query = 0;
+    for (int l = 0; l < L; ++l) {
+        const auto t0 = std::chrono::steady_clock::now();
+        int st = install_coords_and_tree(sm, rotated[l].data(), std::move(trees[l]), recs[l]);
         if (st) return st;
+        std::vector<TriRec>().swap(recs[l]);
+        const auto t1 = std::chrono::steady_clock::now();
+        st = adaptive_queries(sm, g->tmpl, false, queries[l]);
+        if (st) return st;
+        const auto t2 = std::chrono::steady_clock::now();
+        t_install += std::chrono::duration<double, std::milli>(t1 - t0).count();
+        t_query += std::chrono::duration<double, std::milli>(t2 - t1).count();
+    }
+    if (timing) fprintf(stderr, "    install %.1f ms, queries %.1f ms\n", t_install, t_query);
+    lap("uploads + queries");
+    // phase 4 (host threads): weight lists and the resampled features
+    std::vector<std::vector<double>> resampled(L);
+    parallel_for(L, workers, [&](int l) {
+        std::vector<int32_t> rp, col;
+        std::vector<double> val;
+        adaptive_surgery(queries[l], V, Vt, oldA[l], newA, nullptr, rp, col, val);
+        std::vector<double> &out = resampled[l];
+        out.resize((size_t)D * Vt);
         for (int d = 0; d < D; ++d)
             for (int k = 0; k < Vt; ++k) {
                 double acc = 0.0;
                 for (int e = rp[k]; e < rp[k + 1]; ++e) acc += g->feat[s][(size_t)d * V + col[e]] * val[e];
-                resampled[(size_t)d * Vt + k] = acc;
+                out[(size_t)d * Vt + k] = acc;
             }
+    });
+    for (int l = 0; l < L; ++l) {
         auto &buf = g->F[(size_t)s * L + l];
         if (!buf) buf.reset(new DevBuf<double>());
-        MSM_HIP(buf->upload(resampled.data(), resampled.size(), ctx->stream));
-        MSM_HIP(hipStreamSynchronize(ctx->stream));
+        MSM_HIP(buf->upload(resampled[l].data(), resampled[l].size(), ctx->stream));
     }
+    MSM_HIP(hipStreamSynchronize(ctx->stream));
+    lap("weights + resample");
     int st = subject_patches(g, s);
     if (st) return st;
+    lap("patches");
     g->have_subject[s] = 1;
     return MSM_OK;
 }
@@ -427,7 +518,7 @@ int msm_group_import_subject(msm_group *g, int32_t s, const double *F, const int
     g->h_pptr[s].assign(pptr, pptr + M + 1);
     g->h_pidx[s].assign(pidx, pidx + npidx);
     MSM_HIP(g->pptr[s]->upload(g->h_pptr[s].data(), M + 1, ctx->stream));
-    MSM_HIP(g->pidx[s]->upload(g->h_pidx[s].data(), std::max<size_t>(g->h_pidx[s].size(), 1), ctx->stream));
+    MSM_HIP(g->pidx[s]->upload_vec(g->h_pidx[s], ctx->stream));
     MSM_HIP(hipStreamSynchronize(ctx->stream));
     g->have_subject[s] = 1;
     return MSM_OK;

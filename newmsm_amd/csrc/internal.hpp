@@ -115,6 +115,12 @@ struct msm_ctx {
     bool own_stream = false;
     int *d_status = nullptr;  // first error code raised by a kernel (atomicMin), 0 when clean
     int *h_status = nullptr;  // pinned
+    // grow-only scratch of the host-array query entry points (hipMalloc / hipFree per call cost more than the queries)
+    void *q_buf[4] = {nullptr, nullptr, nullptr, nullptr};
+    size_t q_cap[4] = {0, 0, 0, 0};
+    // pinned staging for the search-structure uploads (pageable copies of the 16 MB of an ico6 tree ran at < 1 GB/s)
+    void *stage = nullptr;
+    size_t stage_cap = 0;
 };
 
 struct msm_mesh {
@@ -151,6 +157,16 @@ struct msm_mesh {
 };
 
 namespace msm {
+// Resampler::get_adaptive_barycentric_weights in two halves (api.cpp)
+struct AdaptiveQueries {
+    std::vector<int> fvid, rvid, closest;  // forward (new -> old) and reverse (old -> new) hit-triangle vertex ids, 3 x N SoA
+    std::vector<double> fw, rw;            // and their projected barycentric weights
+};
+int adaptive_queries(msm_mesh *in_mesh, msm_mesh *new_mesh, bool with_closest, AdaptiveQueries &q);
+void adaptive_surgery(const AdaptiveQueries &q, int nOld, int nNew, const std::vector<double> &oldA, const std::vector<double> &newA,
+                      const double *excl, std::vector<int32_t> &row_ptr, std::vector<int32_t> &col, std::vector<double> &val);
+void vertex_areas_of(const double *xyz, const int32_t *tri, int V, int T, const Adjacency &a, std::vector<double> &area);
+int install_coords_and_tree(msm_mesh *m, const double *xyz, FlatOctree &&tree, const std::vector<TriRec> &recs);
 int ensure_tree(msm_mesh *m);  // build + upload the search structure if stale
 int ensure_masks(msm_mesh *m);  // + the per-leaf sub-cell masks the cost kernels use (built on the GPU)
 int ensure_rays(msm_mesh *m);   // + the ray table of a simple surface (unary table kernels)
