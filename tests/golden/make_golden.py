@@ -56,6 +56,44 @@ def main():
     out.update(g5_tris=tris, g5_strain=np.array([O.triangular_strain(a, b, 0.1, 10.0, 2.0) for a, b in tris]))
     np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "oracle_small.npz"), **out)
     print("wrote oracle_small.npz:", {k: v.shape for k, v in out.items()})
+    more(inp, inp1)
+
+
+def anatomy_case():
+    """Inputs of the anatomical-strain vectors (shared with tests/test_golden.py)."""
+    from tests.helpers import oracle_anatomy
+
+    cxyz, ctri, axyz, atri, w_ptr, w_cp, w_val, face_ptr, face_idx = oracle_anatomy(2, 4)
+    rs = 60.0 + 6.0 * synthetic.smooth_feature(axyz, 0, 99) + 3.0 * synthetic.smooth_feature(axyz, 1, 99)
+    rt = 62.0 + 5.0 * synthetic.smooth_feature(axyz, 2, 100) + 4.0 * synthetic.smooth_feature(axyz, 0, 101)
+    d = axyz / synthetic.RAD
+    return dict(sphere_xyz=axyz, sphere_tri=atri, asource_xyz=d * rs[:, None], atarget_xyz=d * rt[:, None], w_ptr=w_ptr, w_cp=w_cp, w_val=w_val,
+                face_ptr=face_ptr, face_idx=face_idx)
+
+
+def more(inp, inp1):
+    """Second file (later additions): DICE table, triclique likelihood, anatomical strain, smooth_data."""
+    out = {}
+    rng = np.random.default_rng(7)
+    od = oracle_cost(inp1, "univariate", simmeasure=4, percentile=0.6)
+    od.get_source_data()
+    out["g6_dice_unary"] = od.unary_table()
+    oh = oracle_cost(inp1, "ho_univariate", rmode=3, lambda_=0.1)
+    oh.get_source_data()
+    tq = np.stack([rng.integers(0, oh.T, 150), rng.integers(0, oh.L, 150), rng.integers(0, oh.L, 150), rng.integers(0, oh.L, 150)], 1)
+    out.update(g7_tq=tq, g7_triclique=np.array([oh.triplet(*r) for r in tq]))
+    an = anatomy_case()
+    oa = oracle_cost(inp1, "univariate", rmode=5, lambda_=0.05, mu=0.4, kappa=1.6, rexp=1.5)
+    sphere = O.Mesh(an["sphere_xyz"], an["sphere_tri"])
+    asrc = O.Mesh(an["asource_xyz"], an["sphere_tri"])
+    oa.set_anatomical(sphere, O.Octree(sphere), an["atarget_xyz"], asrc, an["w_ptr"], an["w_cp"], an["w_val"], an["face_ptr"], an["face_idx"])
+    out.update(g8_tq=tq, g8_anat_triplet=np.array([oa.triplet(*r) for r in tq]))
+    xyz, tri = O.icosphere(3)
+    data = np.stack([synthetic.smooth_feature(xyz, 0), rng.normal(size=len(xyz))])
+    m = O.Mesh(xyz, tri)
+    out.update(g9_data=data, g9_smooth=O.smooth_data(m, data, m, 12.0))
+    np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "oracle_more.npz"), **out)
+    print("wrote oracle_more.npz:", {k: v.shape for k, v in out.items()})
 
 
 if __name__ == "__main__":

@@ -57,3 +57,55 @@ def test_gpu_reproduces_golden(ctx):
     cp, _ = problem.build_cost(ctx, inp1, kind="univariate", rmode=1)
     pq = G["g4_pq"].astype(np.int32)
     assert np.allclose(cp.computePairwiseCost(pq[:, 0], pq[:, 1], pq[:, 2]), G["g4_pairwise"], rtol=1e-9, atol=1e-11)
+
+
+# ---- second file: later additions (DICE, triclique likelihood, anatomical strain, smooth_data)
+G2 = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_more.npz"))
+
+
+def _anatomy():
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "make_golden.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.anatomy_case()
+
+
+def test_oracle_reproduces_golden_more(built):
+    _, inp1 = inputs()
+    od = oracle_cost(inp1, "univariate", simmeasure=4, percentile=0.6)
+    od.get_source_data()
+    assert np.array_equal(od.unary_table(), G2["g6_dice_unary"])
+    oh = oracle_cost(inp1, "ho_univariate", rmode=3, lambda_=0.1)
+    oh.get_source_data()
+    assert np.array_equal(np.array([oh.triplet(*r) for r in G2["g7_tq"]]), G2["g7_triclique"])
+    an = _anatomy()
+    oa = oracle_cost(inp1, "univariate", rmode=5, lambda_=0.05, mu=0.4, kappa=1.6, rexp=1.5)
+    sphere = O.Mesh(an["sphere_xyz"], an["sphere_tri"])
+    asrc = O.Mesh(an["asource_xyz"], an["sphere_tri"])
+    oa.set_anatomical(sphere, O.Octree(sphere), an["atarget_xyz"], asrc, an["w_ptr"], an["w_cp"], an["w_val"], an["face_ptr"], an["face_idx"])
+    assert np.array_equal(np.array([oa.triplet(*r) for r in G2["g8_tq"]]), G2["g8_anat_triplet"])
+    xyz, tri = O.icosphere(3)
+    m = O.Mesh(xyz, tri)
+    assert np.array_equal(O.smooth_data(m, G2["g9_data"], m, 12.0), G2["g9_smooth"])
+
+
+@pytest.mark.gpu
+def test_gpu_reproduces_golden_more(ctx):
+    _, inp1 = inputs()
+    cd, _ = problem.build_cost(ctx, inp1, kind="univariate", simmeasure=4, percentile=0.6)
+    cd.get_source_data()
+    assert np.array_equal(cd.computeUnaryCosts(), G2["g6_dice_unary"])  # counting measure on bit-exact samples
+    ch, _ = problem.build_cost(ctx, inp1, kind="ho_univariate", rmode=3, lambda_=0.1)
+    ch.get_source_data()
+    tq = G2["g7_tq"].astype(np.int32)
+    assert np.allclose(ch.computeTripletCost(tq[:, 0], tq[:, 1], tq[:, 2], tq[:, 3]), G2["g7_triclique"], rtol=1e-9, atol=1e-11)
+    an = _anatomy()
+    ca, _ = problem.build_cost(ctx, inp1, kind="univariate", rmode=5, lambda_=0.05, mu=0.4, kappa=1.6, rexp=1.5)
+    sphere = M.Mesh(ctx, an["sphere_xyz"], an["sphere_tri"])
+    ca.set_anatomical(sphere, an["atarget_xyz"], an["asource_xyz"], an["sphere_tri"], an["w_ptr"], an["w_cp"], an["w_val"], an["face_ptr"], an["face_idx"])
+    assert np.allclose(ca.computeTripletCost(tq[:, 0], tq[:, 1], tq[:, 2], tq[:, 3]), G2["g8_anat_triplet"], rtol=1e-9, atol=1e-11)
+    xyz, tri = M.make_mesh_from_icosa(3)
+    m = M.Mesh(ctx, xyz, tri)
+    assert np.allclose(M.smooth_data(m, G2["g9_data"], m, 12.0), G2["g9_smooth"], rtol=1e-12, atol=1e-14)

@@ -5,6 +5,7 @@ import numpy as np
 import pytest
 
 from oracle import oracle as O
+from tests.helpers import oracle_anatomy
 
 
 def test_dice_known_answers():
@@ -47,28 +48,8 @@ def test_smooth_data_properties():
     assert np.all(mask[excl == 0] == 0.0) and np.all((mask[excl > 0] > 0.3) & (mask[excl > 0] <= 1.0)) and mask[excl > 0].mean() < 0.9
 
 
-def _anatomy(cp_order=2, anat_order=4):
-    cxyz, ctri = O.icosphere(cp_order)
-    axyz, atri = O.icosphere(anat_order)
-    cp = O.Mesh(cxyz, ctri)
-    tree = O.Octree(cp)
-    cen = axyz[atri].mean(axis=1)
-    cen = cen / np.linalg.norm(cen, axis=1, keepdims=True) * 100.0
-    ftri = tree.closest_triangle(cen)
-    face_ptr = np.zeros(len(ctri) + 1, dtype=np.int32)
-    np.add.at(face_ptr, ftri + 1, 1)
-    face_ptr = np.cumsum(face_ptr).astype(np.int32)
-    face_idx = np.argsort(ftri, kind="stable").astype(np.int32)
-    _, _, vid, w = tree.barycentric_weights(axyz)
-    key = np.argsort(vid, axis=1, kind="stable")
-    w_cp = np.take_along_axis(vid, key, axis=1).astype(np.int32).ravel()
-    w_val = np.take_along_axis(w, key, axis=1).ravel()
-    w_ptr = (3 * np.arange(len(axyz) + 1)).astype(np.int32)
-    return cxyz, ctri, axyz, atri, w_ptr, w_cp, w_val, face_ptr, face_idx
-
-
 def test_anatomical_strain_known_answers():
-    cxyz, ctri, axyz, atri, w_ptr, w_cp, w_val, face_ptr, face_idx = _anatomy()
+    cxyz, ctri, axyz, atri, w_ptr, w_cp, w_val, face_ptr, face_idx = oracle_anatomy()
     cp = O.Mesh(cxyz, ctri)
     data = O.Mesh(*O.icosphere(3))
     c = O.Cost("univariate", rmode=5, lambda_=1.0, mu=0.4, kappa=1.6, rexp=1.0)
