@@ -1,0 +1,96 @@
+"""The C++ host side (include/msmhip.hpp, the reference's interface names over the C ABI) driven by a compiled C++
+program (tests/cpp/host_mirror.cpp) with no Python in the loop; its results are compared with the oracle."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from newmsm_amd import problem
+from oracle import oracle as O
+from tests.helpers import oracle_cost
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "tests", "cpp", "host_mirror.cpp")
+EXE = os.path.join(ROOT, "tests", "cpp", "host_mirror")
+LIBDIR = os.path.join(ROOT, "newmsm_amd")
+
+
+def build_host_mirror():
+    cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"), SRC, "-o", EXE, "-L", LIBDIR, "-lmsmhip",
+           "-Wl,-rpath," + LIBDIR, "-Wl,-rpath,/opt/rocm/lib"]
+    subprocess.check_call(cmd)
+
+
+def write_bag(path, **arrays):
+    with open(path, "wb") as f:
+        for name, a in arrays.items():
+            a = np.ascontiguousarray(a)
+            dt = "f8" if a.dtype.kind == "f" else "i4"
+            a = a.astype(np.float64 if dt == "f8" else np.int32)
+            f.write(("%s %s %d\n" % (name, dt, a.size)).encode())
+            f.write(a.tobytes())
+
+
+def read_bag(path):
+    out = {}
+    with open(path, "rb") as f:
+        while True:
+            line = f.readline()
+            if not line:
+                break
+            name, dt, n = line.decode().split()
+            n = int(n)
+            out[name] = np.frombuffer(f.read(n * (8 if dt == "f8" else 4)), dtype=np.float64 if dt == "f8" else np.int32)
+    return out
+
+
+def test_header_compiles_without_gpu(built):
+    build_host_mirror()  # -Wall -Wextra -Werror: the header is clean C++17 and needs no HIP headers
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("D", [1, 3])
+def test_cpp_host_mirror_against_oracle(built, tmp_path, D):
+    build_host_mirror()
+    inp = problem.pairwise_inputs(4, 2, D=D)
+    rng = np.random.default_rng(12)
+    T, L, N = len(inp["triplets"]), len(inp["labels"]), len(inp["cp_xyz"])
+    tq = [rng.integers(0, T, 200), rng.integers(0, L, 200), rng.integers(0, L, 200), rng.integers(0, L, 200)]
+    labeling = rng.integers(0, L, N)
+    fin, fout = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+    write_bag(fin, orders=np.array([4, 2, D]), ref_feat=inp["ref_feat"], src_feat=inp["src_feat"], source_xyz=inp["source_xyz"],
+              labels=inp["labels"], samples0=inp["samples"][0], tq_t=tq[0], tq_a=tq[1], tq_b=tq[2], tq_c=tq[3], labeling=labeling)
+    run = subprocess.run([EXE, fin, fout], capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0, run.stderr + run.stdout
+    assert "expected error: Unknown similarity metric" in run.stdout
+    got = read_bag(fout)
+    assert got["error_code"][0] == -1
+
+    # the oracle on the same iteration: the control grid is carried through the warp by sphere_project_warp first
+    regular = O.Mesh(inp["source_orig_xyz"], inp["source_tri"])
+    cp_now = O.sphere_project_warp(inp["cp_orig_xyz"], regular, inp["source_xyz"])
+    assert np.array_equal(got["cp_now"].reshape(-1, 3), cp_now)
+    cpm = O.Mesh(cp_now, inp["cp_tri"])
+    maxsep, mvd = O.cp_spacings(cpm)
+    inp2 = dict(inp, cp_xyz=cp_now, maxsep=maxsep, mvdmax=mvd, rot=O.cp_rotations(inp["samples"][0], cp_now))
+    kind = "multivariate" if D > 1 else "univariate"
+    oc = oracle_cost(inp2, kind, lambda_=0.2)
+    oc.set_pairs(np.zeros((0, 2), dtype=np.int32))  # regoption 3: the model has triplets only
+    oc.get_source_data()
+    assert np.array_equal(got["absw"], oc.absolute_weights())
+    U = oc.unary_table()
+    assert np.allclose(got["unarycosts"].reshape(U.shape), U, rtol=1e-9, atol=1e-11)
+    assert abs(got["single"][0] - U[3, 5]) <= 1e-11 + 1e-9 * abs(U[3, 5])
+    want = np.array([oc.triplet(*q) for q in zip(*tq)])
+    assert np.allclose(got["triplet"], want, rtol=1e-9, atol=1e-11)
+    assert abs(got["single"][1] - oc.triplet(7, 1, 2, 3)) <= 1e-11 + 1e-9 * abs(got["single"][1])
+    E = got["octets"].reshape(T, 8)
+    for t in (0, 11, T - 1):
+        ids = inp["triplets"][t]
+        for k in range(8):
+            la, lb, lc = (4 if k & 4 else labeling[ids[0]]), (4 if k & 2 else labeling[ids[1]]), (4 if k & 1 else labeling[ids[2]])
+            assert abs(E[t, k] - oc.triplet(t, int(la), int(lb), int(lc))) <= 1e-11 + 1e-9 * abs(E[t, k])
+    assert abs(got["total"][0] - oc.total(labeling.astype(np.int32))[0]) <= 1e-9 * abs(got["total"][0])
+    src = O.Mesh(inp["source_xyz"], inp["source_tri"])
+    assert np.array_equal(got["resampled"].reshape(D, -1), O.metric_resample(src, inp["src_feat"], regular))
