@@ -18,7 +18,9 @@ __device__ __forceinline__ void raise_status(int *status, int code) { atomicMin(
 __device__ __forceinline__ V3 soa(const double *p, int n, int i) { return mk(p[i], p[n + i], p[2 * n + i]); }
 __device__ __forceinline__ V3 aos(const double *p, size_t i) { return mk(p[3 * i], p[3 * i + 1], p[3 * i + 2]); }
 
-constexpr int kBinCache = 64;  // sampled target values kept per lane; longer bins re-sample in the second pass
+// The complete search is the rare path behind the ray table; kept out of line so that the kernels around it do not pay
+// its ~170 registers (a call through the stack instead of inlining).
+__device__ __noinline__ int search_slow(const DevTree *T, double x, double y, double z) { return find_closest_triangle(*T, mk(x, y, z)); }
 
 // one point of an HO bin: the source vertex is projected on the current control triangle, carried to the moved
 // triangle by its barycentric coordinates, pushed back to the sphere and sampled on the target
@@ -29,61 +31,63 @@ __device__ __forceinline__ int ho_sample(const CliqueArgs &a, int sv, const V3 &
     area_weights(cp0, cp1, cp2, sp, wa, wb, wc);  // barycentric(), R/triangle.cpp:159-172
     V3 tmp = mk(n0.x * wa + n1.x * wb + n2.x * wc, n0.y * wa + n1.y * wb + n2.y * wc, n0.z * wa + n1.z * wb + n2.z * wc);
     tmp = scale(normalized(tmp), kRad);
-    const int tt = find_closest_triangle(a.tree, tmp);
+    int tt = ray_find(a.tree, tmp);  // simple-surface targets: settled by the ray table nearly always
+    if (tt < 0) {
+        const DevTree T = a.tree;
+        tt = search_slow(&T, tmp.x, tmp.y, tmp.z);
+    }
     if (tt < 0) return tt;
     const TriRec &r = a.tree.rec[tt];
     area_weights(rec_v0(r), rec_v1(r), rec_v2(r), tmp, wa, wb, wc);
     return tt;
 }
 
-// HO*::triplet_likelihood, M/DiscreteCostFunction.cpp:520-531 (univariate) / :601-618 (multivariate)
-__device__ double triplet_likelihood(const CliqueArgs &a, int t, const int *id, const V3 &n0, const V3 &n1, const V3 &n2) {
-    const V3 cp0 = soa(a.cp, a.N, id[0]), cp1 = soa(a.cp, a.N, id[1]), cp2 = soa(a.cp, a.N, id[2]);
+// One point of a bin: HO univariate -> the sampled target value; HO multivariate -> the point's feature-vector
+// similarity (HO*::triplet_likelihood, :520-531 / :601-618).  NaN (and the status word) on a failed search.
+__device__ double ho_point_value(const CliqueArgs &a, int sv, const V3 &cp0, const V3 &cp1, const V3 &cp2, const V3 &n0, const V3 &n1, const V3 &n2) {
+    double wa, wb, wc;
+    const int tt = ho_sample(a, sv, cp0, cp1, cp2, n0, n1, n2, wa, wb, wc);
+    if (tt < 0) {
+        raise_status(a.status, tt);
+        return __longlong_as_double(0x7ff8000000000000ll);
+    }
+    const TriRec &r = a.tree.rec[tt];
+    const int D = a.D;
+    if (a.kind == MSM_COST_HO_UNIVARIATE) return wa * a.tfeat[(size_t)r.id[0] * D] + wb * a.tfeat[(size_t)r.id[1] * D] + wc * a.tfeat[(size_t)r.id[2] * D];
+    const double *f0 = a.tfeat + (size_t)r.id[0] * D, *f1 = a.tfeat + (size_t)r.id[1] * D, *f2 = a.tfeat + (size_t)r.id[2] * D;
+    return feature_vector_similarity(a.simmeasure, a.percentile, a.sfeat, a.cfw, a.cfw_rows, a.Nsrc, sv, D, f0, f1, f2, wa, wb, wc);
+}
+
+// HO*::triplet_likelihood (:520-531 univariate, :601-618 multivariate) from the bin's point values vals[0..n) (see
+// ho_point_value), in the reference's serial operand order.
+__device__ double ho_likelihood(const CliqueArgs &a, int t, const int *id, const double *vals) {
     const int beg = a.bin_ptr[t], n = a.bin_ptr[t + 1] - beg;
     const double wmean = (a.absw[id[0]] + a.absw[id[1]] + a.absw[id[2]]) / 3.0;
-    const int D = a.D;
     const double nan = __longlong_as_double(0x7ff8000000000000ll);
+    for (int i = 0; i < n; ++i)
+        if (vals[i] != vals[i]) return nan;  // a failed search
     double cost = 0.0;
     if (a.kind == MSM_COST_HO_UNIVARIATE) {
-        // weighted similarity of the bin's moving values A with the sampled target values B, in the reference's
-        // serial order (sparsesimkernel::corr M/similarities.cpp:129-158: means first, then moments)
-        double cache[kBinCache];
         auto A = [&](int i) { return a.sfeat[a.bin_idx[beg + i]]; };
         auto W = [&](int i) { return a.cfw ? a.cfw[a.bin_idx[beg + i]] : 1.0; };
-        bool failed = false;
-        auto B = [&](int i) {
-            double wa, wb, wc;
-            const int tt = ho_sample(a, a.bin_idx[beg + i], cp0, cp1, cp2, n0, n1, n2, wa, wb, wc);
-            if (tt < 0) {
-                raise_status(a.status, tt);
-                failed = true;
-                return nan;
-            }
-            const TriRec &r = a.tree.rec[tt];
-            return wa * a.tfeat[(size_t)r.id[0] * D] + wb * a.tfeat[(size_t)r.id[1] * D] + wc * a.tfeat[(size_t)r.id[2] * D];
-        };
+        auto B = [&](int i) { return vals[i]; };
         if (a.simmeasure == 4 || a.simmeasure == 5) {
-            // DICE ranks every value against every other one: sample each point once (bins longer than the cache re-sample)
-            for (int i = 0; i < n && i < kBinCache; ++i) cache[i] = B(i);
-            cost = dice_serial(a.simmeasure, n, a.percentile, A, [&](int i) { return i < kBinCache ? cache[i] : B(i); });
-        } else if (a.simmeasure == 2) {
+            cost = dice_serial(a.simmeasure, n, a.percentile, A, B);
+        } else if (a.simmeasure == 2) {  // sparsesimkernel::corr, M/similarities.cpp:129-158
             double prod = 0.0, varA = 0.0, varB = 0.0, meanA = 0.0, meanB = 0.0, sum = 0.0;
             for (int i = 0; i < n; ++i) sum += W(i);
             for (int i = 0; i < n; ++i) {
-                const double b = B(i);
-                if (i < kBinCache) cache[i] = b;
                 meanA += W(i) * A(i);
-                meanB += W(i) * b;
+                meanB += W(i) * B(i);
             }
             if (sum > 0.0) {
                 meanA /= sum;
                 meanB /= sum;
             }
             for (int i = 0; i < n; ++i) {
-                const double b = (i < kBinCache) ? cache[i] : B(i);
-                prod += W(i) * (A(i) - meanA) * (b - meanB);
+                prod += W(i) * (A(i) - meanA) * (B(i) - meanB);
                 varA += W(i) * (A(i) - meanA) * (A(i) - meanA);
-                varB += W(i) * (b - meanB) * (b - meanB);
+                varB += W(i) * (B(i) - meanB) * (B(i) - meanB);
             }
             if (sum > 0.0) {
                 prod /= sum;
@@ -92,28 +96,13 @@ __device__ double triplet_likelihood(const CliqueArgs &a, int t, const int *id, 
             }
             const double r = (varA == 0.0 || varB == 0.0) ? 0.0 : prod / (sqrt(varA) * sqrt(varB));
             cost = 1 - (1 + r) * 0.5;
-        } else {
+        } else {  // sparsesimkernel::SSD, :179-188
             double prod = 0.0;
-            for (int i = 0; i < n; ++i) {
-                const double b = B(i);
-                prod += W(i) * (A(i) - b) * (A(i) - b);
-            }
+            for (int i = 0; i < n; ++i) prod += W(i) * (A(i) - B(i)) * (A(i) - B(i));
             cost = sqrt(prod) / n;
         }
-        if (failed) return nan;
     } else {
-        for (int i = 0; i < n; ++i) {
-            const int sv = a.bin_idx[beg + i];
-            double wa, wb, wc;
-            const int tt = ho_sample(a, sv, cp0, cp1, cp2, n0, n1, n2, wa, wb, wc);
-            if (tt < 0) {
-                raise_status(a.status, tt);
-                return nan;
-            }
-            const TriRec &r = a.tree.rec[tt];
-            const double *f0 = a.tfeat + (size_t)r.id[0] * D, *f1 = a.tfeat + (size_t)r.id[1] * D, *f2 = a.tfeat + (size_t)r.id[2] * D;
-            cost += feature_vector_similarity(a.simmeasure, a.percentile, a.sfeat, a.cfw, a.cfw_rows, a.Nsrc, sv, D, f0, f1, f2, wa, wb, wc);
-        }
+        for (int i = 0; i < n; ++i) cost += vals[i];
         if (n > 0) cost /= n;
     }
     return wmean * cost;
@@ -136,7 +125,8 @@ __device__ V3 deform_anatomy_vertex(const CliqueArgs &a, int tindex, const int *
         np = mk(np.x + v.x * w, np.y + v.y * w, np.z + v.z * w);
     }
     const double nan = __longlong_as_double(0x7ff8000000000000ll);
-    const int tt = find_closest_triangle(a.atree, np);
+    const DevTree AT = a.atree;
+    const int tt = search_slow(&AT, np.x, np.y, np.z);
     if (tt < 0) {  // the reference warns and continues with a zero triangle (:272-278): NaN weights
         raise_status(a.status, tt);
         failed = true;
@@ -161,15 +151,15 @@ __device__ V3 deform_anatomy_vertex(const CliqueArgs &a, int tindex, const int *
     return out;
 }
 
-// computeTripletCost, M/DiscreteCostFunction.cpp:135-188 (regoption 2/3: spherical strain; 4/5: anatomical strain)
-__device__ double triplet_cost(const CliqueArgs &a, int t, int la, int lb, int lc) {
+// computeTripletCost, M/DiscreteCostFunction.cpp:135-188 (regoption 2/3: spherical strain; 4/5: anatomical strain).
+// `vals`: the bin's point values for the HO classes (nullptr for the others, whose triplet_likelihood is 0).
+__device__ double triplet_cost(const CliqueArgs &a, int t, int la, int lb, int lc, const double *vals) {
     const int id[3] = {a.triplets[3 * t], a.triplets[3 * t + 1], a.triplets[3 * t + 2]};
     const V3 r[3] = {aos(a.moved, (size_t)id[0] * a.L + la), aos(a.moved, (size_t)id[1] * a.L + lb), aos(a.moved, (size_t)id[2] * a.L + lc)};
     const V3 cur[3] = {soa(a.cp, a.N, id[0]), soa(a.cp, a.N, id[1]), soa(a.cp, a.N, id[2])};
     // only estimate the cost if the move does not fold the triangle
     if (dot(tri_normal(r[0], r[1], r[2]), tri_normal(cur[0], cur[1], cur[2])) < 0.0) return MSM_FOLDING * a.lambda;
-    double likelihood = 0.0;
-    if (a.kind == MSM_COST_HO_UNIVARIATE || a.kind == MSM_COST_HO_MULTIVARIATE) likelihood = triplet_likelihood(a, t, id, r[0], r[1], r[2]);
+    const double likelihood = vals ? ho_likelihood(a, t, id, vals) : 0.0;
     double w;
     if (a.rmode == 4 || a.rmode == 5) {  // :169-182: mean strain of the anatomical faces under this control triangle
         const int beg = a.af_ptr[t], nf = a.af_ptr[t + 1] - beg;
@@ -232,7 +222,66 @@ __device__ double pairwise_cost(const CliqueArgs &a, int pair, int la, int lb) {
 __global__ __launch_bounds__(128) void k_triplet_batch(CliqueArgs a, const int *__restrict__ qt, const int *__restrict__ qa,
                                                         const int *__restrict__ qb, const int *__restrict__ qc, int n, double *__restrict__ out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = triplet_cost(a, qt[i], qa[i], qb[i], qc[i]);
+    if (i < n) out[i] = triplet_cost(a, qt[i], qa[i], qb[i], qc[i], nullptr);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Triclique (HO) evaluations, 16 lanes each.  A bin holds ~8 source vertices, each needing a nearest-triangle search;
+// with a lane per evaluation a fusion move (8 x T = 40 960 evaluations at ico4) is 640 wavefronts, each a serial
+// chain of 8 searches: 126 us, latency bound at less than one wavefront per SIMD.  Here the lanes of a 16-lane group
+// sample the bin's points side by side into the group's LDS slice; the group's first lane then runs the
+// reference's serial similarity over those values (same operand order as before) and adds the strain term.
+// Measured at ico6 / ico4 (bins of ~8): 1 lane 126 us, 4 lanes 111 us, 8 lanes 152 us, 16 lanes 215 us (univariate);
+// 395 / 294 / 298 / 323 us (32 features) -- the complete search behind the ray table costs 244 registers, two
+// wavefronts per SIMD, so wider groups only add idle lanes to the serial part.  Four lanes for bins up to 256 points,
+// sixteen for bins up to 1 024 (the LDS slices must fit).
+// ------------------------------------------------------------------------------------------------
+
+template <int kHoLanes>
+__device__ void ho_group_eval(const CliqueArgs &a, bool valid, int t, int la, int lb, int lc, double *out) {
+    extern __shared__ __align__(16) double s_vals[];  // (256 / kHoLanes) slices of a.bin_cap values
+    const int grp = threadIdx.x / kHoLanes, sub = threadIdx.x % kHoLanes;
+    double *vals = s_vals + (size_t)grp * a.bin_cap;
+    if (valid) {
+        const int id[3] = {a.triplets[3 * t], a.triplets[3 * t + 1], a.triplets[3 * t + 2]};
+        const V3 r0 = aos(a.moved, (size_t)id[0] * a.L + la), r1 = aos(a.moved, (size_t)id[1] * a.L + lb), r2 = aos(a.moved, (size_t)id[2] * a.L + lc);
+        const V3 cp0 = soa(a.cp, a.N, id[0]), cp1 = soa(a.cp, a.N, id[1]), cp2 = soa(a.cp, a.N, id[2]);
+        // a folded proposal never looks at the data (computeTripletCost, :151-152)
+        if (!(dot(tri_normal(r0, r1, r2), tri_normal(cp0, cp1, cp2)) < 0.0)) {
+            const int beg = a.bin_ptr[t], n = a.bin_ptr[t + 1] - beg;  // n <= a.bin_cap (host-checked)
+            for (int i = sub; i < n; i += kHoLanes) vals[i] = ho_point_value(a, a.bin_idx[beg + i], cp0, cp1, cp2, r0, r1, r2);
+        }
+    }
+    __syncthreads();
+    if (valid && sub == 0) *out = triplet_cost(a, t, la, lb, lc, vals);
+}
+
+template <int kHoLanes>
+__global__ __launch_bounds__(256) void k_triplet_batch_ho(CliqueArgs a, const int *__restrict__ qt, const int *__restrict__ qa,
+                                                           const int *__restrict__ qb, const int *__restrict__ qc, int n, double *__restrict__ out) {
+    const int i = blockIdx.x * (256 / kHoLanes) + threadIdx.x / kHoLanes;
+    const bool valid = i < n;
+    ho_group_eval<kHoLanes>(a, valid, valid ? qt[i] : 0, valid ? qa[i] : 0, valid ? qb[i] : 0, valid ? qc[i] : 0, out + (valid ? i : 0));
+}
+
+template <int kHoLanes>
+__global__ __launch_bounds__(256) void k_triplet_octets_ho(CliqueArgs a, const int *__restrict__ labeling, int label, double *__restrict__ out) {
+    const int i = blockIdx.x * (256 / kHoLanes) + threadIdx.x / kHoLanes;
+    const bool valid = i < 8 * a.T;
+    const int t = valid ? i >> 3 : 0, k = i & 7;
+    const int la = (k & 4) ? label : labeling[a.triplets[3 * t]];
+    const int lb = (k & 2) ? label : labeling[a.triplets[3 * t + 1]];
+    const int lc = (k & 1) ? label : labeling[a.triplets[3 * t + 2]];
+    ho_group_eval<kHoLanes>(a, valid, t, la, lb, lc, out + (valid ? i : 0));
+}
+
+template <int kHoLanes>
+__global__ __launch_bounds__(256) void k_triplet_table_ho(CliqueArgs a, int t0, int t1, double *__restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * (256 / kHoLanes) + threadIdx.x / kHoLanes;
+    const size_t L = (size_t)a.L, per = L * L * L;
+    const bool valid = i < (size_t)(t1 - t0) * per;
+    const size_t r = valid ? i % per : 0;
+    ho_group_eval<kHoLanes>(a, valid, valid ? t0 + (int)(i / per) : 0, (int)(r / (L * L)), (int)((r / L) % L), (int)(r % L), out + (valid ? i : 0));
 }
 
 // the 8 costs per triplet of one fusion move, I/Fusion/Fusion.h:181-196: bit order (A,B,C), 0 = current label
@@ -243,7 +292,7 @@ __global__ __launch_bounds__(128) void k_triplet_octets(CliqueArgs a, const int 
     const int la = (k & 4) ? label : labeling[a.triplets[3 * t]];
     const int lb = (k & 2) ? label : labeling[a.triplets[3 * t + 1]];
     const int lc = (k & 1) ? label : labeling[a.triplets[3 * t + 2]];
-    out[i] = triplet_cost(a, t, la, lb, lc);
+    out[i] = triplet_cost(a, t, la, lb, lc, nullptr);
 }
 
 __global__ __launch_bounds__(256) void k_pairwise_batch(CliqueArgs a, const int *__restrict__ qp, const int *__restrict__ qa,
@@ -261,15 +310,47 @@ __global__ __launch_bounds__(256) void k_pairwise_table(CliqueArgs a, double *__
     out[i] = pairwise_cost(a, pair, la, lb);
 }
 
+static bool is_ho(const CliqueArgs &a) { return a.kind == MSM_COST_HO_UNIVARIATE || a.kind == MSM_COST_HO_MULTIVARIATE; }
+static int ho_lanes(const CliqueArgs &a) { return a.bin_cap <= 256 ? 4 : 16; }
+// grid and dynamic LDS of an HO launch of `evals` evaluations with `lanes` lanes each
+template <class K>
+static int ho_config(const CliqueArgs &a, K kernel, int lanes, size_t evals, dim3 &grid, size_t &lds) {
+    const int per = 256 / lanes;
+    lds = sizeof(double) * per * (size_t)a.bin_cap;
+    grid = dim3((unsigned)((evals + per - 1) / per));
+    if (lds > 64 * 1024) MSM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    return MSM_OK;
+}
+#define MSM_HO_LAUNCH(kernel, evals, ...)                                                                   \
+    do {                                                                                                    \
+        dim3 grid_;                                                                                         \
+        size_t lds_;                                                                                        \
+        if (ho_lanes(a) == 4) {                                                                             \
+            int st_ = ho_config(a, kernel<4>, 4, evals, grid_, lds_);                                       \
+            if (st_) return st_;                                                                            \
+            hipLaunchKernelGGL(kernel<4>, grid_, dim3(256), lds_, ctx->stream, __VA_ARGS__);                \
+        } else {                                                                                            \
+            int st_ = ho_config(a, kernel<16>, 16, evals, grid_, lds_);                                     \
+            if (st_) return st_;                                                                            \
+            hipLaunchKernelGGL(kernel<16>, grid_, dim3(256), lds_, ctx->stream, __VA_ARGS__);               \
+        }                                                                                                   \
+    } while (0)
+
 int launch_triplet_batch(msm_ctx *ctx, const CliqueArgs &a, const int *qt, const int *qa, const int *qb, const int *qc, int n, double *out) {
     if (n <= 0) return MSM_OK;
-    hipLaunchKernelGGL(k_triplet_batch, dim3((n + 127) / 128), dim3(128), 0, ctx->stream, a, qt, qa, qb, qc, n, out);
+    if (is_ho(a))
+        MSM_HO_LAUNCH(k_triplet_batch_ho, (size_t)n, a, qt, qa, qb, qc, n, out);
+    else
+        hipLaunchKernelGGL(k_triplet_batch, dim3((n + 127) / 128), dim3(128), 0, ctx->stream, a, qt, qa, qb, qc, n, out);
     MSM_HIP(hipGetLastError());
     return MSM_OK;
 }
 int launch_triplet_octets(msm_ctx *ctx, const CliqueArgs &a, const int *labeling, int label, double *out) {
     if (a.T <= 0) return MSM_OK;
-    hipLaunchKernelGGL(k_triplet_octets, dim3((8 * a.T + 127) / 128), dim3(128), 0, ctx->stream, a, labeling, label, out);
+    if (is_ho(a))
+        MSM_HO_LAUNCH(k_triplet_octets_ho, (size_t)8 * a.T, a, labeling, label, out);
+    else
+        hipLaunchKernelGGL(k_triplet_octets, dim3((8 * a.T + 127) / 128), dim3(128), 0, ctx->stream, a, labeling, label, out);
     MSM_HIP(hipGetLastError());
     return MSM_OK;
 }
@@ -286,13 +367,17 @@ __global__ __launch_bounds__(128) void k_triplet_table(CliqueArgs a, int t0, int
     if (i >= (size_t)(t1 - t0) * per) return;
     const int t = t0 + (int)(i / per);
     const size_t r = i % per;
-    out[i] = triplet_cost(a, t, (int)(r / (L * L)), (int)((r / L) % L), (int)(r % L));
+    out[i] = triplet_cost(a, t, (int)(r / (L * L)), (int)((r / L) % L), (int)(r % L), nullptr);
 }
 
 int launch_triplet_table(msm_ctx *ctx, const CliqueArgs &a, int t0, int t1, double *out) {
     const size_t total = (size_t)(t1 - t0) * a.L * a.L * a.L;
     if (total == 0) return MSM_OK;
-    hipLaunchKernelGGL(k_triplet_table, dim3((unsigned)((total + 127) / 128)), dim3(128), 0, ctx->stream, a, t0, t1, out);
+    if (is_ho(a)) {
+        MSM_HO_LAUNCH(k_triplet_table_ho, total, a, t0, t1, out);
+    } else {
+        hipLaunchKernelGGL(k_triplet_table, dim3((unsigned)((total + 127) / 128)), dim3(128), 0, ctx->stream, a, t0, t1, out);
+    }
     MSM_HIP(hipGetLastError());
     return MSM_OK;
 }

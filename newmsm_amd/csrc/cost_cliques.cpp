@@ -59,13 +59,16 @@ int clique_args(msm_cost *c, bool need_triplets, bool need_pairs, CliqueArgs &a)
     a.cfw_rows = c->cfw_rows;
     a.bin_ptr = c->d_pptr.p;
     a.bin_idx = c->d_pidx.p;
+    a.bin_cap = std::max(c->pmax, 1);
     a.absw = c->d_absw.p;
     a.status = ctx->d_status;
     if (need_triplets && cost_is_ho(c)) {
         if (!c->have_source) return fail(MSM_ERR_STATE, "msm_cost: get_source_data() must be called first");
         if (!c->target->d_feat || c->target->D != c->D) return fail(MSM_ERR_STATE, "msm_cost: target features must match the source features");
-        st = ensure_tree(c->target);
+        st = ensure_rays(c->target);
         if (st) return st;
+        if (c->pmax > 1024)
+            return fail(MSM_ERR_CAPACITY, "msm_cost: %d source vertices under one control-grid triangle; the triclique kernels hold at most 1024 per evaluation", c->pmax);
     }
     a.tree = dev_tree(c->target);
     a.rmode = c->p.rmode;

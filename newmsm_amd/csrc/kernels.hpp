@@ -88,6 +88,7 @@ struct CliqueArgs {
     const double *cfw;
     int cfw_rows;
     const int *bin_ptr, *bin_idx;  // source vertices per control-grid triangle
+    int bin_cap;                   // largest bin (LDS slice per evaluation in the HO kernels)
     const double *absw;
     // anatomical strain (rmode 4/5)
     int rmode;

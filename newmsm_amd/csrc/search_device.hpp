@@ -199,6 +199,26 @@ __device__ __forceinline__ bool ray_vouches(const DevTree &T, const float4 &e1, 
     return clear;
 }
 
+// Ray-table search for one point: the triangle the reference's search returns, or -1 when the table cannot vouch for
+// it (then the caller runs find_closest_triangle).  Same test as k_unary_rays (unary_kernels.hip).
+__device__ __forceinline__ int ray_find(const DevTree &T, const V3 &p) {
+    if (T.ray_G <= 0) return -1;
+    float fx, fy, fz;
+    const int4 c = ray_cell_of(T, p, fx, fy, fz);
+    if (c.x < 0) return -1;
+    int4 mo = make_int4(c.w, -1, -1, -1);
+    if (c.w < -1) mo = T.ray_more[-2 - c.w];
+#pragma unroll 1
+    for (int k = 0; k < 7; ++k) {
+        const int ck = k == 0 ? c.x : (k == 1 ? c.y : (k == 2 ? c.z : (k == 3 ? mo.x : (k == 4 ? mo.y : (k == 5 ? mo.z : mo.w)))));
+        if (ck < 0) break;
+        const float4 *r = T.ray_tri + (size_t)kRayPieces * ck;
+        const float4 e0 = r[0], e1 = r[1], e2 = r[2];
+        if (ray_accepts(e0, e1, e2, fx, fy, fz)) return ray_vouches(T, e1, p) ? ck : -1;
+    }
+    return -1;
+}
+
 // Returns the triangle id (>= 0), or MSM_ERR_OUTSIDE / MSM_ERR_NOTFOUND.
 __device__ __forceinline__ int find_closest_triangle(const DevTree &T, const V3 &p, bool allow_fallback = true) {
     // Node::contains_point of the root, R/node.cpp:58-68 (written so that NaN behaves as in the reference)

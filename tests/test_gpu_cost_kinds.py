@@ -203,3 +203,19 @@ def test_triplet_table_matches_on_demand_evaluation(ctx):
         assert abs(tab[t[q], la[q], lb[q], lc[q]] - want) <= ATOL + RTOL * abs(want)
     with pytest.raises(M.MsmError):
         cf.computeTripletCosts(0, cf.T + 1)
+
+
+@pytest.mark.parametrize("data_order,cp_order", [(5, 1), (5, 0)])
+def test_triclique_large_bins(ctx, data_order, cp_order):
+    # coarse control grids (first levels of a multiresolution run): 128 and 512 source vertices per control triangle;
+    # 4- and 16-lane evaluation groups, LDS slices of one bin each
+    inp = problem.pairwise_inputs(data_order, cp_order, D=1, warp_amp=0.3, warp_rot=1.0)
+    cf, oc, _ = pair(ctx, inp, "ho_univariate", rmode=3, lambda_=0.1)
+    ptr, _ = cf.patches()
+    assert np.diff(ptr).max() > (256 if cp_order == 0 else 100)
+    rng = np.random.default_rng(13)
+    t, la, lb, lc = random_queries(rng, 120, cf.T, cf.L, 3)
+    got = cf.computeTripletCost(t, la, lb, lc)
+    want = np.array([oc.triplet(*q) for q in zip(t, la, lb, lc)])
+    assert np.isfinite(got).all()
+    assert np.allclose(got, want, rtol=RTOL, atol=ATOL), np.max(np.abs(got - want))
