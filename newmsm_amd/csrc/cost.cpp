@@ -197,6 +197,25 @@ int ensure_unary_table(msm_cost *c) {
         case MSM_COST_UNIVARIATE: st = launch_unary_univariate(ctx, u); break;
         case MSM_COST_MULTIVARIATE:
         case MSM_COST_PATCHWISE: {
+            if (c->p.kind == MSM_COST_MULTIVARIATE) {
+                if (!c->vm_valid) {  // vertex-major copies: a patch point's D values in one or two cache lines
+                    const int Ns = c->source->V, D = c->D, R = c->cfw_rows;
+                    std::vector<double> vm((size_t)Ns * D);
+                    for (int d = 0; d < D; ++d)
+                        for (int v = 0; v < Ns; ++v) vm[(size_t)v * D + d] = c->sfeat[(size_t)d * Ns + v];
+                    MSM_HIP(c->d_sfeat_vm.upload(vm.data(), vm.size(), ctx->stream));
+                    if (!c->cfw.empty()) {
+                        std::vector<double> wm((size_t)Ns * R);
+                        for (int r = 0; r < R; ++r)
+                            for (int v = 0; v < Ns; ++v) wm[(size_t)v * R + r] = c->cfw[(size_t)r * Ns + v];
+                        MSM_HIP(c->d_cfw_vm.upload(wm.data(), wm.size(), ctx->stream));
+                    }
+                    MSM_HIP(hipStreamSynchronize(ctx->stream));
+                    c->vm_valid = true;
+                }
+                u.sfeat_vm = c->d_sfeat_vm.p;
+                u.cfw_vm = c->cfw.empty() ? nullptr : c->d_cfw_vm.p;
+            }
             MSM_HIP(c->d_stri.ensure(nsamp));
             MSM_HIP(c->d_sw3.ensure(3 * nsamp));
             UnaryWeightsScratch w{c->d_stri.p, c->d_sw3.p};
@@ -301,6 +320,7 @@ int msm_cost_set_source_features(msm_cost *c, const double *feat, int32_t D) {
     c->D = D;
     MSM_HIP(hipStreamSynchronize(c->ctx->stream));
     c->sfeat.assign(feat, feat + (size_t)D * c->source->V);
+    c->vm_valid = false;
     MSM_HIP(c->d_sfeat.upload(c->sfeat.data(), c->sfeat.size(), c->ctx->stream));
     invalidate_table(c);
     return MSM_OK;
@@ -314,6 +334,7 @@ int msm_cost_set_cfweight(msm_cost *c, const double *w, int32_t rows) {
     if (!w) {
         c->cfw.clear();
         c->cfw_rows = 0;
+        c->vm_valid = false;
     } else {
         if (rows <= 0) return fail(MSM_ERR_INVALID, "msm_cost_set_cfweight: rows must be positive");
         // initialize(), M/DiscreteCostFunction.cpp:114-115
@@ -321,6 +342,7 @@ int msm_cost_set_cfweight(msm_cost *c, const double *w, int32_t rows) {
             return fail(MSM_ERR_INVALID, "DiscreteModel ERROR:: costfunction weighting has dimensions incompatible with data");
         c->cfw.assign(w, w + (size_t)rows * c->source->V);
         c->cfw_rows = rows;
+        c->vm_valid = false;
         MSM_HIP(c->d_cfw.upload(c->cfw.data(), c->cfw.size(), c->ctx->stream));
     }
     c->have_source = false;

@@ -17,6 +17,8 @@ struct msm_cost {
     int D = 0;
     std::vector<double> sfeat;
     DevBuf<double> d_sfeat;
+    DevBuf<double> d_sfeat_vm, d_cfw_vm;  // vertex-major copies for the multivariate reduction
+    bool vm_valid = false;
     std::vector<double> cfw;
     int cfw_rows = 0;
     DevBuf<double> d_cfw;

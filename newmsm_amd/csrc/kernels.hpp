@@ -34,6 +34,8 @@ struct UnaryLaunch {
     const double *sfeat;   // D x Nsrc
     const double *cfw;     // rows x Nsrc or nullptr
     int cfw_rows;
+    const double *sfeat_vm = nullptr;  // Nsrc x D and Nsrc x rows vertex-major copies (multivariate reduction), optional
+    const double *cfw_vm = nullptr;
     const int *pptr, *pidx;
     const int *order;      // launch order of the control points (a permutation of 0..N-1)
     const double *absw;

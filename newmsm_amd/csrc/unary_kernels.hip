@@ -993,6 +993,136 @@ __global__ __launch_bounds__(256) void k_unary_reduce_features(ReduceMvArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Multivariate reduction, D <= 64, SSD / correlation (M/DiscreteCostFunction.cpp:444-458): eight lanes per patch point.
+// With a lane per point and the D loop inside the lane (k_unary_reduce_features) every one of the ~4 D loads of a
+// point is its own cache-line lookup (moving features D x Nsrc row-major: a different line per dimension) -- about 250
+// lookups per sample, 1.9 ms per table at D = 32.  Here lane j of a group owns the dimensions j, j + 8, ...: the
+// group reads the three target rows (vertex-major) and the moving row (a vertex-major copy) as contiguous 64-byte
+// pieces, and the sums over the dimensions are 8-lane DPP reductions.  One wavefront per label, eight points at a time.
+// ------------------------------------------------------------------------------------------------
+constexpr int kMvLanes = 8;
+constexpr int kMvKeep = 8;  // dimensions per lane: D <= 64
+
+__device__ __forceinline__ double mv_group_sum(double v) {
+#pragma unroll
+    for (int off = kMvLanes / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, kMvLanes);
+    return v;
+}
+
+struct ReduceMv8Args {
+    int N, L, Nsrc, D;
+    const double *tfeat;    // V x D vertex-major
+    const TriRec *rec;
+    const double *sfeat_vm; // Nsrc x D vertex-major copy of the moving features
+    const double *cfw_vm;   // Nsrc x cfw_rows vertex-major copy of the weights, or nullptr
+    int cfw_rows;
+    const int *pptr, *pidx;
+    const int *order;
+    const double *absw;
+    const int *stri;
+    const double *sw3;
+    int simmeasure;
+    double *U;
+};
+
+__global__ __launch_bounds__(256) void k_unary_reduce_mv8(ReduceMv8Args a) {
+    const int node = a.order[blockIdx.x];
+    const int beg = a.pptr[node], P = a.pptr[node + 1] - beg;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int grp = lane / kMvLanes, j = lane % kMvLanes;
+    const double absw = a.absw[node];
+    const double nan = __longlong_as_double(0x7ff8000000000000ll);
+    const int D = a.D;
+    for (int l = wave; l < a.L; l += 4) {
+        const size_t g0 = (size_t)a.L * beg + (size_t)l * P;
+        double acc = 0.0;  // this group's points (lane 0 of the group holds the value)
+        bool bad = false;
+        for (int i0 = 0; i0 < P; i0 += 64 / kMvLanes) {  // wavefront-uniform: the group sums need all lanes
+            const int i = i0 + grp;
+            const bool have = i < P;
+            int t = -1, sv = 0;
+            double wa = 0, wb = 0, wc = 0;
+            if (have) {
+                t = a.stri[g0 + i];
+                sv = a.pidx[beg + i];
+                wa = a.sw3[3 * (g0 + i)], wb = a.sw3[3 * (g0 + i) + 1], wc = a.sw3[3 * (g0 + i) + 2];
+            }
+            if (have && t < 0) bad = true;
+            const bool go = have && t >= 0;
+            double A[kMvKeep], B[kMvKeep], W[kMvKeep];
+            if (go) {
+                const TriRec &r = a.rec[t];
+                const double *f0 = a.tfeat + (size_t)r.id[0] * D, *f1 = a.tfeat + (size_t)r.id[1] * D, *f2 = a.tfeat + (size_t)r.id[2] * D;
+                const double *sa = a.sfeat_vm + (size_t)sv * D;
+#pragma unroll
+                for (int k = 0; k < kMvKeep; ++k) {
+                    const int d = j + kMvLanes * k;
+                    const bool in = d < D;
+                    A[k] = in ? sa[d] : 0.0;
+                    B[k] = in ? wa * f0[d] + wb * f1[d] + wc * f2[d] : 0.0;  // barycentric_interpolation per dimension
+                    W[k] = !in ? 0.0 : ((a.cfw_vm && a.cfw_rows >= d + 1) ? a.cfw_vm[(size_t)sv * a.cfw_rows + d] : 1.0);
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < kMvKeep; ++k) A[k] = B[k] = W[k] = 0.0;
+            }
+            double c;
+            if (a.simmeasure == 2) {  // sparsesimkernel::corr over the D dimensions, M/similarities.cpp:129-158
+                double sum = 0, ma = 0, mb = 0;
+#pragma unroll
+                for (int k = 0; k < kMvKeep; ++k) {
+                    sum += W[k];
+                    ma += W[k] * A[k];
+                    mb += W[k] * B[k];
+                }
+                sum = mv_group_sum(sum);
+                ma = mv_group_sum(ma);
+                mb = mv_group_sum(mb);
+                if (sum > 0.0) {
+                    ma /= sum;
+                    mb /= sum;
+                }
+                double pr = 0, va = 0, vb = 0;
+#pragma unroll
+                for (int k = 0; k < kMvKeep; ++k) {
+                    const double da = A[k] - ma, db = B[k] - mb;
+                    pr += W[k] * da * db;
+                    va += W[k] * da * da;
+                    vb += W[k] * db * db;
+                }
+                pr = mv_group_sum(pr);
+                va = mv_group_sum(va);
+                vb = mv_group_sum(vb);
+                if (sum > 0.0) {
+                    pr /= sum;
+                    va /= sum;
+                    vb /= sum;
+                }
+                const double rr = (va == 0.0 || vb == 0.0) ? 0.0 : pr / (sqrt(va) * sqrt(vb));
+                c = 1 - (1 + rr) * 0.5;
+            } else {  // sparsesimkernel::SSD, :179-188
+                double pr = 0;
+#pragma unroll
+                for (int k = 0; k < kMvKeep; ++k) {
+                    const double df = A[k] - B[k];
+                    pr += W[k] * df * df;
+                }
+                pr = mv_group_sum(pr);
+                c = sqrt(pr) / D;
+            }
+            if (go && j == 0) acc += c;
+        }
+        // the groups' partial sums: one value per group in its lane 0
+        double tot = (j == 0) ? acc : 0.0;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off, 64);
+        double cost = P > 0 ? tot / P : tot;
+        if (__ballot(bad)) cost = nan;
+        if (lane == 0) a.U[(size_t)l * a.N + node] = absw * cost;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // launch
 // ------------------------------------------------------------------------------------------------
 static size_t samples_lds(int pmax, int L) {
@@ -1144,7 +1274,23 @@ int launch_unary_multivariate(msm_ctx *ctx, const UnaryLaunch &u, const UnaryWei
     r.percentile = u.percentile;
     r.U = u.U;
     const bool dice = u.simmeasure == 4 || u.simmeasure == 5;
-    hipLaunchKernelGGL(k_unary_reduce_features, dim3(u.N), dim3(256), (dice && patchwise) ? sizeof(double) * 8 * (size_t)u.pmax : 0, ctx->stream, r);
+    if (!patchwise && !dice && u.D >= 12 && u.D <= kMvLanes * kMvKeep && u.sfeat_vm) {  // few dimensions: a lane per point wastes less
+        ReduceMv8Args m;
+        m.N = u.N, m.L = u.L, m.Nsrc = u.Nsrc, m.D = u.D;
+        m.tfeat = u.tfeat;
+        m.rec = u.tree.rec;
+        m.sfeat_vm = u.sfeat_vm;
+        m.cfw_vm = u.cfw_vm;
+        m.cfw_rows = u.cfw_rows;
+        m.pptr = u.pptr, m.pidx = u.pidx, m.order = u.order;
+        m.absw = u.absw;
+        m.stri = w.stri, m.sw3 = w.sw3;
+        m.simmeasure = u.simmeasure;
+        m.U = u.U;
+        hipLaunchKernelGGL(k_unary_reduce_mv8, dim3(u.N), dim3(256), 0, ctx->stream, m);
+    } else {
+        hipLaunchKernelGGL(k_unary_reduce_features, dim3(u.N), dim3(256), (dice && patchwise) ? sizeof(double) * 8 * (size_t)u.pmax : 0, ctx->stream, r);
+    }
     MSM_HIP(hipGetLastError());
     MSM_HIP(hipMemsetAsync(u.fix_cnt, 0, unary_fix_counter_words() * sizeof(unsigned), ctx->stream));  // counters are zero between launches
     return MSM_OK;
