@@ -27,8 +27,8 @@ int check_status(msm_ctx *ctx, const char *what) {
     return MSM_OK;
 }
 
-// uploads a built tree (m->tree, recs) to the device
-static int upload_tree(msm_mesh *m, const std::vector<TriRec> &recs) {
+// uploads a built tree (m->tree) to the device and derives the triangle records and cones there
+static int upload_tree(msm_mesh *m) {
     msm_ctx *ctx = m->ctx;
     MSM_HIP(hipSetDevice(ctx->device));
     auto grow = [&](void **p, size_t &cap, size_t need, size_t elem) -> hipError_t {
@@ -42,7 +42,7 @@ static int upload_tree(msm_mesh *m, const std::vector<TriRec> &recs) {
     MSM_HIP(grow((void **)&m->d_parent, m->cap_parent, m->tree.node.size(), sizeof(int32_t)));
     MSM_HIP(grow((void **)&m->d_leaf_tri, m->cap_leaf, m->tree.leaf_tri.size(), sizeof(int32_t)));
     MSM_HIP(grow((void **)&m->d_cone, m->cap_cone, m->tree.leaf_tri.size(), sizeof(float4)));
-    MSM_HIP(grow((void **)&m->d_rec, m->cap_rec, recs.size(), sizeof(TriRec)));
+    MSM_HIP(grow((void **)&m->d_rec, m->cap_rec, (size_t)m->T, sizeof(TriRec)));
     MSM_HIP(grow((void **)&m->d_grid, m->cap_grid, m->tree.grid.size(), sizeof(int32_t)));
     MSM_HIP(grow((void **)&m->d_nodebox, m->cap_box, m->tree.node.size(), sizeof(double4)));
     // all arrays go through one pinned staging buffer: a host memcpy each, then DMA at link speed
@@ -55,8 +55,6 @@ static int upload_tree(msm_mesh *m, const std::vector<TriRec> &recs) {
         {m->d_node, m->tree.node.data(), m->tree.node.size() * sizeof(int4)},
         {m->d_parent, m->tree.parent.data(), m->tree.parent.size() * sizeof(int32_t)},
         {m->d_leaf_tri, m->tree.leaf_tri.data(), m->tree.leaf_tri.size() * sizeof(int32_t)},
-        {m->d_cone, m->tree.cone.data(), m->tree.cone.size() * sizeof(float4)},
-        {m->d_rec, recs.data(), recs.size() * sizeof(TriRec)},
         {m->d_grid, m->tree.grid.data(), m->tree.grid.size() * sizeof(int32_t)},
         {m->d_nodebox, m->tree.nodebox.data(), m->tree.nodebox.size() * sizeof(double4)},
     };
@@ -76,6 +74,10 @@ static int upload_tree(msm_mesh *m, const std::vector<TriRec> &recs) {
         MSM_HIP(hipMemcpyAsync(pt.dst, (char *)ctx->stage + off, pt.bytes, hipMemcpyHostToDevice, ctx->stream));
         off += (pt.bytes + 255) & ~(size_t)255;
     }
+    {
+        int st = launch_build_recs(ctx, m->d_xyz, m->V, m->d_tri, m->T, m->d_rec, m->d_tcone, m->d_leaf_tri, (int)m->tree.leaf_tri.size(), m->d_cone);
+        if (st) return st;
+    }
     m->masks_valid = false;
     m->rays_valid = false;
     MSM_HIP(hipStreamSynchronize(ctx->stream));
@@ -85,20 +87,19 @@ static int upload_tree(msm_mesh *m, const std::vector<TriRec> &recs) {
 
 int ensure_tree(msm_mesh *m) {
     if (m->tree_valid) return MSM_OK;
-    std::vector<TriRec> recs;
-    build_octree(m->xyz.data(), m->tri.data(), m->V, m->T, m->tree, recs);
-    return upload_tree(m, recs);
+    build_octree(m->xyz.data(), m->tri.data(), m->V, m->T, m->tree);
+    return upload_tree(m);
 }
 
 // new coordinates together with the search structure built for them elsewhere (e.g. on a worker thread)
-int install_coords_and_tree(msm_mesh *m, const double *xyz, FlatOctree &&tree, const std::vector<TriRec> &recs) {
+int install_coords_and_tree(msm_mesh *m, const double *xyz, FlatOctree &&tree) {
     msm_ctx *ctx = m->ctx;
     MSM_HIP(hipStreamSynchronize(ctx->stream));
     m->xyz.assign(xyz, xyz + 3 * (size_t)m->V);
     MSM_HIP(hipMemcpyAsync(m->d_xyz, m->xyz.data(), sizeof(double) * 3 * (size_t)m->V, hipMemcpyHostToDevice, ctx->stream));
     m->tree = std::move(tree);
     m->rayrec_valid = false;
-    return upload_tree(m, recs);
+    return upload_tree(m);
 }
 
 int ensure_masks(msm_mesh *m) {
@@ -450,7 +451,10 @@ msm_mesh *msm_mesh_create(msm_ctx *ctx, const double *xyz, int32_t V, const int3
     m->tri.assign(tri, tri + 3 * (size_t)T);
     (void)hipSetDevice(ctx->device);
     if (hipMalloc((void **)&m->d_xyz, sizeof(double) * 3 * (size_t)V) != hipSuccess ||
-        hipMemcpyAsync(m->d_xyz, m->xyz.data(), sizeof(double) * 3 * (size_t)V, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
+        hipMemcpyAsync(m->d_xyz, m->xyz.data(), sizeof(double) * 3 * (size_t)V, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+        hipMalloc((void **)&m->d_tri, sizeof(int32_t) * 3 * (size_t)T) != hipSuccess ||
+        hipMemcpyAsync(m->d_tri, m->tri.data(), sizeof(int32_t) * 3 * (size_t)T, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+        hipMalloc((void **)&m->d_tcone, sizeof(float4) * (size_t)T) != hipSuccess) {
         fail(MSM_ERR_HIP, "msm_mesh_create: device allocation failed");
         msm_mesh_destroy(m);
         return nullptr;
@@ -462,7 +466,7 @@ void msm_mesh_destroy(msm_mesh *m) {
     if (!m) return;
     (void)hipSetDevice(m->ctx->device);
     (void)hipStreamSynchronize(m->ctx->stream);
-    for (void *p : {(void *)m->d_xyz, (void *)m->d_feat, (void *)m->d_node, (void *)m->d_parent, (void *)m->d_leaf_tri, (void *)m->d_cone, (void *)m->d_rec, (void *)m->d_grid, (void *)m->d_nodebox, (void *)m->d_mask, (void *)m->d_ray_cell, (void *)m->d_ray_edge, (void *)m->d_ray_tri, (void *)m->d_ray_more, (void *)m->d_ray_excl})
+    for (void *p : {(void *)m->d_xyz, (void *)m->d_tri, (void *)m->d_tcone, (void *)m->d_feat, (void *)m->d_node, (void *)m->d_parent, (void *)m->d_leaf_tri, (void *)m->d_cone, (void *)m->d_rec, (void *)m->d_grid, (void *)m->d_nodebox, (void *)m->d_mask, (void *)m->d_ray_cell, (void *)m->d_ray_edge, (void *)m->d_ray_tri, (void *)m->d_ray_more, (void *)m->d_ray_excl})
         if (p) (void)hipFree(p);
     delete m;
 }

@@ -412,13 +412,12 @@ int group_subject_setup(msm_group *g, int s) {
     lap("rotations");
     // phase 2 (host threads): octrees and vertex areas of the rotated meshes
     std::vector<FlatOctree> trees(L);
-    std::vector<std::vector<TriRec>> recs(L);
     std::vector<std::vector<double>> oldA(L);
     const Adjacency &adj = mesh_adjacency(sm);
     std::vector<double> newA;
     vertex_areas_of(g->tmpl->xyz.data(), g->tmpl->tri.data(), g->tmpl->V, g->tmpl->T, mesh_adjacency(g->tmpl), newA);
     parallel_for(L, workers, [&](int l) {
-        build_octree(rotated[l].data(), sm->tri.data(), V, T, trees[l], recs[l]);
+        build_octree(rotated[l].data(), sm->tri.data(), V, T, trees[l]);
         vertex_areas_of(rotated[l].data(), sm->tri.data(), V, T, adj, oldA[l]);
     });
     lap("octrees");
@@ -427,9 +426,8 @@ int group_subject_setup(msm_group *g, int s) {
     double t_install = 0, t_query = 0;
     for (int l = 0; l < L; ++l) {
         const auto t0 = std::chrono::steady_clock::now();
-        int st = install_coords_and_tree(sm, rotated[l].data(), std::move(trees[l]), recs[l]);
+        int st = install_coords_and_tree(sm, rotated[l].data(), std::move(trees[l]));
         if (st) return st;
-        std::vector<TriRec>().swap(recs[l]);
         const auto t1 = std::chrono::steady_clock::now();
         st = adaptive_queries(sm, g->tmpl, false, queries[l]);
         if (st) return st;

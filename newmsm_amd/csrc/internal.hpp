@@ -62,7 +62,6 @@ struct FlatOctree {
     int nmask_blocks = 0;
     std::vector<int32_t> parent;
     std::vector<int32_t> leaf_tri;
-    std::vector<float4> cone;  // per padded leaf entry: unit cone axis (xyz) and |cos| threshold (w)
     // Dense top of the tree: the node reached after grid_depth levels of descent (or the leaf met earlier),
     // indexed [ix][iy][iz] with G = 2^grid_depth cells per axis over (-101, 101).  Child boxes are exact
     // halvings, so the cell of a point is found arithmetically and the descent starts there.
@@ -81,8 +80,7 @@ struct FlatOctree {
     int64_t stats[5] = {0, 0, 0, 0, 0};
 };
 // builds the tree exactly as Octree::initialize_tree / add_triangle do (R/octree.cpp:42-141)
-void build_octree(const double *xyz /*3 x V SoA*/, const int32_t *tri /*3 x T SoA*/, int V, int T, FlatOctree &out,
-                  std::vector<TriRec> &recs);
+void build_octree(const double *xyz /*3 x V SoA*/, const int32_t *tri /*3 x T SoA*/, int V, int T, FlatOctree &out);
 // decides FlatOctree::simple and, for a simple surface, fills the ray table of an already built tree
 void build_ray_table(const double *xyz, const int32_t *tri, int V, int T, FlatOctree &tree);
 
@@ -133,6 +131,8 @@ struct msm_mesh {
     msm::FlatOctree tree;
     // device
     double *d_xyz = nullptr;   // 3 x V SoA
+    int32_t *d_tri = nullptr;  // 3 x T SoA
+    float4 *d_tcone = nullptr; // per-triangle bounding cone (scratch of the record kernel)
     double *d_feat = nullptr;  // V x D (vertex-major: one row per vertex for gathers)
     int4 *d_node = nullptr;
     double4 *d_nodebox = nullptr;
@@ -166,7 +166,7 @@ int adaptive_queries(msm_mesh *in_mesh, msm_mesh *new_mesh, bool with_closest, A
 void adaptive_surgery(const AdaptiveQueries &q, int nOld, int nNew, const std::vector<double> &oldA, const std::vector<double> &newA,
                       const double *excl, std::vector<int32_t> &row_ptr, std::vector<int32_t> &col, std::vector<double> &val);
 void vertex_areas_of(const double *xyz, const int32_t *tri, int V, int T, const Adjacency &a, std::vector<double> &area);
-int install_coords_and_tree(msm_mesh *m, const double *xyz, FlatOctree &&tree, const std::vector<TriRec> &recs);
+int install_coords_and_tree(msm_mesh *m, const double *xyz, FlatOctree &&tree);
 int ensure_tree(msm_mesh *m);  // build + upload the search structure if stale
 int ensure_masks(msm_mesh *m);  // + the per-leaf sub-cell masks the cost kernels use (built on the GPU)
 int ensure_rays(msm_mesh *m);   // + the ray table of a simple surface (unary table kernels)

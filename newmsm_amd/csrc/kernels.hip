@@ -67,6 +67,83 @@ int launch_build_masks(msm_ctx *ctx, const DevTree &T, const double4 *d_nodebox,
     return MSM_OK;
 }
 
+// Conservative bounding cone of the set of directions for which the reference's inside test
+// (project_point + point_in_triangle with its -1e-8 slack, R/point.cpp:36-60) can succeed.
+// A point passes same_side for edge e iff its in-plane signed distance from the edge line exceeds
+// -1e-8 / (2 * area * |e|); the accepted region is the triangle grown by that band.
+__device__ float4 bounding_cone(const V3 &a, const V3 &b, const V3 &c, double plane_d) {
+    const float4 always = make_float4(0.f, 0.f, 1.f, -2.f);
+    V3 axis = mk(a.x + b.x + c.x, a.y + b.y + c.y, a.z + b.z + c.z);
+    double an = norm(axis);
+    if (!(an > 1e-12) || !isfinite(an)) return always;
+    axis = scale(axis, 1.0 / an);
+    double rho = 0.0;
+    for (const V3 *v : {&a, &b, &c}) {
+        double n = norm(*v);
+        if (!(n > 1e-12)) return always;
+        double cs = dot(axis, *v) / n;
+        cs = cs > 1 ? 1 : (cs < -1 ? -1 : cs);
+        rho = fmax(rho, acos(cs));
+    }
+    const double la = norm(sub(b, c)), lb = norm(sub(a, c)), lc = norm(sub(a, b));
+    const double area = 0.5 * norm(cross(sub(b, a), sub(c, a)));
+    const double lmin = fmin(la, fmin(lb, lc)), lmax = fmax(la, fmax(lb, lc));
+    if (!(area > 0) || !(lmin > 0)) return always;
+    // widest band over the three edges, plus rounding noise of the reference's own cross/dot products
+    const double band = 1e-8 / (2 * area * lmin) + 1e-9 * (1 + lmax);
+    // an offset polygon's corner moves by band / sin(angle/2); smallest interior angle from the altitude
+    // sin(smallest interior angle) = 2*area / (product of its two sides) >= 2*area / lmax^2
+    const double half = 0.5 * asin(fmin(1.0, 2 * area / (lmax * lmax)));
+    const double reach = band / fmax(sin(half), 1e-300);
+    const double h = fabs(plane_d);  // distance of the triangle's plane from the origin
+    if (!(h > 0) || !(reach / h < 0.25) || !isfinite(reach)) return always;
+    const double rho2 = rho + 1.0001 * asin(reach / h) + 1e-7;
+    if (!(rho2 < 1.5)) return always;
+    // 2e-6 absorbs float rounding of the query direction and of the dot product
+    return make_float4((float)axis.x, (float)axis.y, (float)axis.z, (float)(cos(rho2) - 2e-6));
+}
+
+
+
+// The per-triangle records of the exact test (vertices, the triangle-only half of project_point, ids) and the bounding
+// cones, from the mesh as it sits in HBM: 13.7 MB at ico6 that used to be computed on the host and copied over.
+__global__ __launch_bounds__(256) void k_build_recs(const double *__restrict__ xyz, int V, const int32_t *__restrict__ tri, int T, TriRec *__restrict__ recs,
+                                                     float4 *__restrict__ tcone) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    const int i0 = tri[t], i1 = tri[T + t], i2 = tri[2 * T + t];
+    const V3 v0 = mk(xyz[i0], xyz[V + i0], xyz[2 * V + i0]), v1 = mk(xyz[i1], xyz[V + i1], xyz[2 * V + i1]), v2 = mk(xyz[i2], xyz[V + i2], xyz[2 * V + i2]);
+    TriRec r;
+    r.v0[0] = v0.x, r.v0[1] = v0.y, r.v0[2] = v0.z;
+    r.v1[0] = v1.x, r.v1[1] = v1.y, r.v1[2] = v1.z;
+    r.v2[0] = v2.x, r.v2[1] = v2.y, r.v2[2] = v2.z;
+    V3 s3;
+    plane_of(v0, v1, v2, s3, r.d);  // distance_to_triangle calls project_point(pt, v0, v1, v2), R/octree.cpp:149
+    r.s3[0] = s3.x, r.s3[1] = s3.y, r.s3[2] = s3.z;
+    r.id[0] = i0, r.id[1] = i1, r.id[2] = i2;
+    r.tri = t;
+    r.reserved = 0.0;
+    recs[t] = r;
+    tcone[t] = bounding_cone(v0, v1, v2, r.d);
+}
+
+// cone per (padded) leaf entry; padding entries get a cone nothing passes (|dot| <= 1 < 2)
+__global__ __launch_bounds__(256) void k_expand_cones(const int32_t *__restrict__ leaf_tri, int n, const float4 *__restrict__ tcone, float4 *__restrict__ cone) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const int t = leaf_tri[e];
+    cone[e] = t >= 0 ? tcone[t] : make_float4(0.f, 0.f, 0.f, 2.f);
+}
+
+int launch_build_recs(msm_ctx *ctx, const double *d_xyz, int V, const int32_t *d_tri, int T, TriRec *d_rec, float4 *d_tcone, const int32_t *d_leaf_tri,
+                      int nentries, float4 *d_cone) {
+    if (T > 0) hipLaunchKernelGGL(k_build_recs, dim3((T + 255) / 256), dim3(256), 0, ctx->stream, d_xyz, V, d_tri, T, d_rec, d_tcone);
+    MSM_HIP(hipGetLastError());
+    if (nentries > 0) hipLaunchKernelGGL(k_expand_cones, dim3((nentries + 255) / 256), dim3(256), 0, ctx->stream, d_leaf_tri, nentries, d_tcone, d_cone);
+    MSM_HIP(hipGetLastError());
+    return MSM_OK;
+}
+
 __global__ __launch_bounds__(256) void k_build_raytri(const TriRec *__restrict__ rec, const float4 *__restrict__ edge, int T,
                                                        const double *__restrict__ feat1, float4 *__restrict__ out) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;

@@ -7,6 +7,9 @@ namespace msm {
 
 // per-leaf sub-cell masks (see FlatOctree::node); writes 64 words per mask block
 int launch_build_masks(msm_ctx *ctx, const DevTree &T, const double4 *d_nodebox, unsigned long long *d_mask);
+// triangle records and bounding cones (per triangle, then per padded leaf entry) from the mesh in HBM
+int launch_build_recs(msm_ctx *ctx, const double *d_xyz, int V, const int32_t *d_tri, int T, TriRec *d_rec, float4 *d_tcone, const int32_t *d_leaf_tri,
+                      int nentries, float4 *d_cone);
 // ray-table records (internal.hpp: kRayPieces) from the triangle records, the edge planes and, when given, a single feature row (V doubles)
 int launch_build_raytri(msm_ctx *ctx, const TriRec *d_rec, const float4 *d_edge, int T, const double *d_feat1, float4 *d_out);
 int launch_query(msm_ctx *ctx, const DevTree &T, const double *d_q, int N, int *d_tri, int *d_vid, double *d_w, int mode);

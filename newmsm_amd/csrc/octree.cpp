@@ -8,7 +8,8 @@
 // for the GPU:
 //   node[]      int4 per node (first child, or leaf entry range + mask block + depth) -> descent is arithmetic + 1 load/level
 //   leaf_tri[]  triangle ids of all leaves, contiguous per leaf, in insertion (= ascending id) order, padded to x8
-//   cone[]      float4 per (padded) leaf entry: conservative bounding cone of the triangle (cheap reject test)
+//   cone[]      float4 per (padded) leaf entry: conservative bounding cone of the triangle (cheap reject test; filled on the
+//               GPU together with recs[], kernels.hip k_build_recs / k_expand_cones)
 //   mask[]      per leaf 64 x 64-bit: which entries a query inside each of the leaf's 4x4x4 sub-cells can hit
 //               (filled on the GPU, kernels.hip k_build_masks)
 //   recs[]      128-byte record per triangle for the exact test
@@ -24,6 +25,9 @@
 
 #include "internal.hpp"
 
+// set-up timing to stderr when MSMHIP_TIMING is set
+#define TICK(name) do { if (std::getenv("MSMHIP_TIMING")) { auto now_ = std::chrono::steady_clock::now(); fprintf(stderr, "  %s %.1f ms\n", name, std::chrono::duration<double, std::milli>(now_ - tick_).count()); tick_ = now_; } } while (0)
+
 namespace msm {
 
 namespace {
@@ -33,6 +37,9 @@ struct BNode {
     int parent = -1;
     double b[3][3];  // per axis: lower, middle, upper (Node::bounds, R/node.h:42)
     std::vector<int32_t> tris;
+    // running sums of the split heuristic over `tris` (the reference recomputes them over the whole leaf at every
+    // insertion past MAX_TRIANGLES, R/octree.cpp:71-93; the node's midpoints never change, so they can be kept)
+    int total_size = 0, num_split = 0;
 };
 
 struct Builder {
@@ -40,15 +47,27 @@ struct Builder {
     const int32_t *tri;
     int V, T;
     std::deque<BNode> nodes;
+    std::vector<double> box;  // per triangle: lo[3], hi[3]
 
+    void precompute_boxes() {
+        box.resize((size_t)6 * T);
+        for (int t = 0; t < T; ++t) {
+            double *lo = &box[(size_t)6 * t], *hi = lo + 3;
+            for (int a = 0; a < 3; ++a) lo[a] = hi[a] = xyz[a * V + tri[t]];
+            for (int k = 1; k < 3; ++k)
+                for (int a = 0; a < 3; ++a) {
+                    double c = xyz[a * V + tri[k * T + t]];
+                    if (c < lo[a]) lo[a] = c;
+                    if (c > hi[a]) hi[a] = c;
+                }
+        }
+    }
     void aabb(int t, double lo[3], double hi[3]) const {
-        for (int a = 0; a < 3; ++a) lo[a] = hi[a] = xyz[a * V + tri[t]];
-        for (int k = 1; k < 3; ++k)
-            for (int a = 0; a < 3; ++a) {
-                double c = xyz[a * V + tri[k * T + t]];
-                if (c < lo[a]) lo[a] = c;
-                if (c > hi[a]) hi[a] = c;
-            }
+        const double *b = &box[(size_t)6 * t];
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = b[a];
+            hi[a] = b[3 + a];
+        }
     }
     // Node::can_contain, R/node.cpp:108-116
     bool overlaps(int n, const double lo[3], const double hi[3]) const {
@@ -78,19 +97,16 @@ struct Builder {
     void add(int n, int t, const double lo[3], const double hi[3]) {
         if (nodes[n].first_child < 0) {
             nodes[n].tris.push_back(t);
-            const int num = (int)nodes[n].tris.size();
-            if (num < kMaxTriangles) return;
-            int total_size = 0, num_split = 0;
-            for (int i = 0; i < num; ++i) {
-                double tlo[3], thi[3];
-                aabb(nodes[n].tris[i], tlo, thi);
+            {
                 int split_size = 8;
                 for (int d = 0; d < 3; ++d)  // containing_oct: coordinate < middle, R/node.cpp:70-82
-                    if ((tlo[d] < nodes[n].b[d][1]) == (thi[d] < nodes[n].b[d][1])) split_size >>= 1;
-                total_size += split_size;
-                if (split_size != 8) ++num_split;
+                    if ((lo[d] < nodes[n].b[d][1]) == (hi[d] < nodes[n].b[d][1])) split_size >>= 1;
+                nodes[n].total_size += split_size;
+                if (split_size != 8) ++nodes[n].num_split;
             }
-            if (!(num_split > 0 && total_size < 3 * num)) return;
+            const int num = (int)nodes[n].tris.size();
+            if (num < kMaxTriangles) return;
+            if (!(nodes[n].num_split > 0 && nodes[n].total_size < 3 * num)) return;
             split(n);
             std::vector<int32_t> held;
             held.swap(nodes[n].tris);  // clear_triangles() after redistribution
@@ -108,43 +124,6 @@ struct Builder {
 };
 
 inline V3 vtx(const double *xyz, int V, int i) { return mk(xyz[i], xyz[V + i], xyz[2 * V + i]); }
-
-// Conservative bounding cone of the set of directions for which the reference's inside test
-// (project_point + point_in_triangle with its -1e-8 slack, R/point.cpp:36-60) can succeed.
-// A point passes same_side for edge e iff its in-plane signed distance from the edge line exceeds
-// -1e-8 / (2 * area * |e|); the accepted region is the triangle grown by that band.
-float4 bounding_cone(const V3 &a, const V3 &b, const V3 &c, const TriRec &r) {
-    const float4 always = make_float4(0.f, 0.f, 1.f, -2.f);
-    V3 axis = mk(a.x + b.x + c.x, a.y + b.y + c.y, a.z + b.z + c.z);
-    double an = norm(axis);
-    if (!(an > 1e-12) || !std::isfinite(an)) return always;
-    axis = scale(axis, 1.0 / an);
-    double rho = 0.0;
-    for (const V3 *v : {&a, &b, &c}) {
-        double n = norm(*v);
-        if (!(n > 1e-12)) return always;
-        double cs = dot(axis, *v) / n;
-        cs = cs > 1 ? 1 : (cs < -1 ? -1 : cs);
-        rho = std::fmax(rho, std::acos(cs));
-    }
-    const double la = norm(sub(b, c)), lb = norm(sub(a, c)), lc = norm(sub(a, b));
-    const double area = 0.5 * norm(cross(sub(b, a), sub(c, a)));
-    const double lmin = std::fmin(la, std::fmin(lb, lc)), lmax = std::fmax(la, std::fmax(lb, lc));
-    if (!(area > 0) || !(lmin > 0)) return always;
-    // widest band over the three edges, plus rounding noise of the reference's own cross/dot products
-    const double band = 1e-8 / (2 * area * lmin) + 1e-9 * (1 + lmax);
-    // an offset polygon's corner moves by band / sin(angle/2); smallest interior angle from the altitude
-    // sin(smallest interior angle) = 2*area / (product of its two sides) >= 2*area / lmax^2
-    const double half = 0.5 * std::asin(std::fmin(1.0, 2 * area / (lmax * lmax)));
-    const double reach = band / std::fmax(std::sin(half), 1e-300);
-    const double h = std::fabs(r.d);  // distance of the triangle's plane from the origin
-    if (!(h > 0) || !(reach / h < 0.25) || !std::isfinite(reach)) return always;
-    const double rho2 = rho + 1.0001 * std::asin(reach / h) + 1e-7;
-    if (!(rho2 < 1.5)) return always;
-    // 2e-6 absorbs float rounding of the query direction and of the dot product
-    return make_float4((float)axis.x, (float)axis.y, (float)axis.z, (float)(std::cos(rho2) - 2e-6));
-}
-
 
 // True when every ray from the origin meets exactly one triangle: the mesh is a closed, consistently oriented
 // 2-manifold, every face is strictly front- (or every face strictly back-) facing seen from the origin, and the faces'
@@ -246,7 +225,6 @@ bool lacking_leaves(const FlatOctree &o, int n, const double lo[3], const double
 // ------------------------------------------------------------------------------------------------
 constexpr double kRayShell = 1e-4;
 
-#define TICK(name) do { if (std::getenv("MSMHIP_TIMING")) { auto now_ = std::chrono::steady_clock::now(); fprintf(stderr, "  %s %.1f ms\n", name, std::chrono::duration<double, std::milli>(now_ - tick_).count()); tick_ = now_; } } while (0)
 }  // namespace
 
 void build_ray_table(const double *xyz, const int32_t *tri, int V, int T, FlatOctree &out) {
@@ -438,8 +416,10 @@ void build_ray_table(const double *xyz, const int32_t *tri, int V, int T, FlatOc
     TICK("cells");
 }
 
-void build_octree(const double *xyz, const int32_t *tri, int V, int T, FlatOctree &out, std::vector<TriRec> &recs) {
-    Builder b{xyz, tri, V, T, {}};
+void build_octree(const double *xyz, const int32_t *tri, int V, int T, FlatOctree &out) {
+    auto tick_ = std::chrono::steady_clock::now();
+    Builder b{xyz, tri, V, T, {}, {}};
+    b.precompute_boxes();
     BNode root;
     for (int a = 0; a < 3; ++a) {
         root.b[a][0] = -kBounds;
@@ -454,22 +434,7 @@ void build_octree(const double *xyz, const int32_t *tri, int V, int T, FlatOctre
         b.add(0, t, lo, hi);
     }
 
-    recs.resize(T);
-    std::vector<float4> tcone(T);
-    for (int t = 0; t < T; ++t) {
-        const V3 v0 = vtx(xyz, V, tri[t]), v1 = vtx(xyz, V, tri[T + t]), v2 = vtx(xyz, V, tri[2 * T + t]);
-        TriRec &r = recs[t];
-        r.v0[0] = v0.x, r.v0[1] = v0.y, r.v0[2] = v0.z;
-        r.v1[0] = v1.x, r.v1[1] = v1.y, r.v1[2] = v1.z;
-        r.v2[0] = v2.x, r.v2[1] = v2.y, r.v2[2] = v2.z;
-        V3 s3;
-        plane_of(v0, v1, v2, s3, r.d);  // distance_to_triangle calls project_point(pt, v0, v1, v2), R/octree.cpp:149
-        r.s3[0] = s3.x, r.s3[1] = s3.y, r.s3[2] = s3.z;
-        r.id[0] = tri[t], r.id[1] = tri[T + t], r.id[2] = tri[2 * T + t];
-        r.tri = t;
-        r.reserved = 0.0;
-        tcone[t] = bounding_cone(v0, v1, v2, r);
-    }
+    TICK("octree: insertion");
     out.simple = false;  // decided together with the ray table (build_ray_table), which only the cost kernels need
     out.ray_G = 0;
     out.ray_cell.clear();
@@ -481,7 +446,6 @@ void build_octree(const double *xyz, const int32_t *tri, int V, int T, FlatOctre
     out.nodebox.resize(n);
     out.parent.resize(n);
     out.leaf_tri.clear();
-    out.cone.clear();
     out.nmask_blocks = 0;
     int64_t leaves = 0, maxleaf = 0, refs = 0;
     std::vector<int> depth(n, 0);
@@ -499,13 +463,7 @@ void build_octree(const double *xyz, const int32_t *tri, int V, int T, FlatOctre
             const int mblock = (cnt >= 1 && cnt <= 64) ? out.nmask_blocks++ : -1;
             out.node[i] = make_int4(-cnt - 1, (int)out.leaf_tri.size(), mblock, depth[i]);
             for (int e = 0; e < ((cnt + 7) & ~7); ++e) {
-                if (e < cnt) {
-                    out.leaf_tri.push_back(nd.tris[e]);
-                    out.cone.push_back(tcone[nd.tris[e]]);
-                } else {
-                    out.leaf_tri.push_back(-1);
-                    out.cone.push_back(make_float4(0.f, 0.f, 0.f, 2.f));  // |dot| <= 1 < 2: never passes
-                }
+                out.leaf_tri.push_back(e < cnt ? nd.tris[e] : -1);
             }
             ++leaves;
             refs += cnt;
@@ -535,6 +493,7 @@ void build_octree(const double *xyz, const int32_t *tri, int V, int T, FlatOctre
             }
         }
     }
+    TICK("octree: flatten + grid");
     out.stats[0] = n;
     out.stats[1] = leaves;
     out.stats[2] = maxdepth;
