@@ -5,8 +5,6 @@
 // an adaptive-barycentric resample of its features to the template.  All nearest-triangle queries run on the
 // GPU; the resampled feature maps F[subject][label] (D x V_template) and the patch lists stay in HBM, where the
 // pairwise kernel reads them (group_kernels.hip).
-#include <sched.h>
-
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -17,6 +15,7 @@
 #include <thread>
 
 #include "devbuf.hpp"
+#include "host_parallel.hpp"
 #include "kernels.hpp"
 
 using namespace msm;
@@ -340,34 +339,6 @@ int group_common_setup(msm_group *g) {
 }
 
 // get_patch_data for one subject, M/DiscreteGroupModel.cpp:88-121
-// host cores this process may use (cgroup / affinity aware), for the set-up's worker threads
-int host_workers() {
-    cpu_set_t set;
-    CPU_ZERO(&set);
-    int n = 0;
-    if (sched_getaffinity(0, sizeof(set), &set) == 0) n = CPU_COUNT(&set);
-    if (n <= 0) n = (int)std::thread::hardware_concurrency();
-    if (const char *e = std::getenv("MSMHIP_HOST_THREADS")) n = std::atoi(e);
-    return std::max(1, std::min(n, 64));
-}
-
-// runs fn(0..n-1) on up to `workers` threads; fn must not touch HIP or any msm handle
-template <class F>
-void parallel_for(int n, int workers, F fn) {
-    workers = std::max(1, std::min(workers, n));
-    if (workers == 1) {
-        for (int i = 0; i < n; ++i) fn(i);
-        return;
-    }
-    std::atomic<int> next{0};
-    std::vector<std::thread> pool;
-    for (int w = 0; w < workers; ++w)
-        pool.emplace_back([&]() {
-            for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) fn(i);
-        });
-    for (auto &t : pool) t.join();
-}
-
 // DiscreteGroupModel::get_patch_data for one subject (M/DiscreteGroupModel.cpp:88-121).  Per label: rotate the data
 // mesh, build its octree, resample the features to the template with adaptive barycentric weights.  The rotations
 // and the 2 x N nearest-triangle queries run on the GPU; the octree builds (the reference's incremental insertion,

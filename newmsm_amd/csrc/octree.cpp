@@ -23,6 +23,7 @@
 #include <deque>
 #include <unordered_map>
 
+#include "host_parallel.hpp"
 #include "internal.hpp"
 
 // set-up timing to stderr when MSMHIP_TIMING is set
@@ -241,11 +242,21 @@ void build_ray_table(const double *xyz, const int32_t *tri, int V, int T, FlatOc
     out.ray_edge.assign((size_t)3 * T, make_float4(0.f, 0.f, 0.f, 2.f));
     out.ray_excl.clear();
     out.ray_more.clear();
-    std::vector<int> lack;
     out.ray_r2lo = (kRad - kRayShell) * (kRad - kRayShell);
     out.ray_r2hi = (kRad + kRayShell) * (kRad + kRayShell);
     std::vector<char> usable(T, 0);
-    for (int t = 0; t < T; ++t) {
+    const int workers = host_workers();
+    // exclusion records are collected per chunk and numbered afterwards (chunks are contiguous triangle ranges, so the
+    // numbering does not depend on the number of threads)
+    struct Chunk {
+        std::vector<int4> excl;
+        std::vector<int> owner;
+    };
+    std::vector<Chunk> chunk_out(4 * (size_t)workers + 1);
+    parallel_chunks(T, workers, [&](int ci, int t_begin, int t_end) {
+    std::vector<int> lack;
+    Chunk &mine = chunk_out[ci];
+    for (int t = t_begin; t < t_end; ++t) {
         const V3 v[3] = {vtx(xyz, V, tri[t]), vtx(xyz, V, tri[T + t]), vtx(xyz, V, tri[2 * T + t])};
         V3 s3;
         double pd;
@@ -313,15 +324,23 @@ void build_ray_table(const double *xyz, const int32_t *tri, int V, int T, FlatOc
                 bx[j] = (d << 24) | (ix << 16) | (iy << 8) | iz;
             }
             if (!ok) continue;
-            excl = (int)out.ray_excl.size();
-            out.ray_excl.push_back(boxes);
+            excl = (int)mine.excl.size();  // chunk-local; renumbered below
+            mine.excl.push_back(boxes);
+            mine.owner.push_back(t);
         }
         e[1].w = __builtin_bit_cast(float, (int32_t)excl);
         e[2].w = 0.f;
         for (int k = 0; k < 3; ++k) out.ray_edge[(size_t)3 * t + k] = e[k];
         usable[t] = 1;
     }
-
+    });
+    for (const Chunk &c : chunk_out) {
+        const int base = (int)out.ray_excl.size();
+        for (size_t k = 0; k < c.excl.size(); ++k) {
+            out.ray_excl.push_back(c.excl[k]);
+            out.ray_edge[(size_t)3 * c.owner[k] + 1].w = __builtin_bit_cast(float, (int32_t)(base + (int)k));
+        }
+    }
     TICK("edges+robust");
     // cube map: face f = 2*axis + (negative side); (u, v) = the two other components over |major component|
     int G = 8;
@@ -334,11 +353,13 @@ void build_ray_table(const double *xyz, const int32_t *tri, int V, int T, FlatOc
         float score;
         int32_t tri;
     };
-    std::vector<Cand> found;
-    found.reserve((size_t)T * 8);
+    std::vector<std::vector<Cand>> found_by(4 * (size_t)workers + 1);
     std::vector<int32_t> count(ncell + 1, 0);
     const double m = 1e-5;  // cells are grown by this much (uv units) before the overlap test
-    for (int t = 0; t < T; ++t) {
+    parallel_chunks(T, workers, [&](int ci, int t_begin, int t_end) {
+    std::vector<Cand> &found = found_by[ci];
+    found.reserve((size_t)(t_end - t_begin) * 8);
+    for (int t = t_begin; t < t_end; ++t) {
         if (!usable[t]) continue;
         const V3 v[3] = {vtx(xyz, V, tri[t]), vtx(xyz, V, tri[T + t]), vtx(xyz, V, tri[2 * T + t])};
         const double ln[3] = {norm(v[0]), norm(v[1]), norm(v[2])};
@@ -384,22 +405,32 @@ void build_ray_table(const double *xyz, const int32_t *tri, int V, int T, FlatOc
                     const double cu = 0.5 * (x0 + x1) - gu, cv = 0.5 * (y0 + y1) - gv;
                     const size_t cell = ((size_t)f * G + iu) * G + iv;
                     found.push_back(Cand{(uint32_t)cell, (float)(cu * cu + cv * cv), t});
-                    ++count[cell + 1];
                 }
         }
     }
+    });
+    size_t nfound = 0;
+    for (const auto &f : found_by) {
+        nfound += f.size();
+        for (const Cand &c : f) ++count[c.cell + 1];
+    }
     TICK("raster");
     for (size_t c = 0; c < ncell; ++c) count[c + 1] += count[c];
-    std::vector<Cand> cand(found.size());
+    std::vector<Cand> cand(nfound);
     {
         std::vector<int32_t> fill(count.begin(), count.end() - 1);
-        for (const Cand &c : found) cand[(size_t)fill[c.cell]++] = c;
+        for (const auto &f : found_by)  // chunk order = triangle order: the same buckets as a serial pass
+            for (const Cand &c : f) cand[(size_t)fill[c.cell]++] = c;
     }
     TICK("bucket");
     out.ray_cell.assign(ncell, make_int4(-1, -1, -1, -1));
+    parallel_chunks((int)ncell, workers, [&](int, int c_begin, int c_end) {
+        for (int c = c_begin; c < c_end; ++c)
+            std::sort(cand.data() + count[c], cand.data() + count[c + 1],
+                      [](const Cand &x, const Cand &y) { return x.score < y.score || (x.score == y.score && x.tri < y.tri); });
+    });
     for (size_t c = 0; c < ncell; ++c) {
-        Cand *first = cand.data() + count[c], *last = cand.data() + count[c + 1];
-        std::sort(first, last, [](const Cand &x, const Cand &y) { return x.score < y.score || (x.score == y.score && x.tri < y.tri); });
+        const Cand *first = cand.data() + count[c], *last = cand.data() + count[c + 1];
         int32_t *slot = &out.ray_cell[c].x;
         const int ncand = (int)(last - first);
         if (ncand <= 4) {
