@@ -254,8 +254,9 @@ __global__ __launch_bounds__(256) void k_unary_samples(SamplesArgs a) {
     double *sx = lds, *sy = sx + a.pmax, *sz = sy + a.pmax;
     double *sA = sz + a.pmax, *sW = sA + a.pmax;                 // moving feature and weights of the patch
     double *sR = sW + a.pmax;                                    // L x 9
-    double *sT = sR + 9 * a.L;                                   // L x pmax sampled target values
-    unsigned *queue = reinterpret_cast<unsigned *>(sT + (size_t)a.L * a.pmax);  // kQueueCap
+    const int lper_all = (a.L + a.nsplit - 1) / a.nsplit;
+    double *sT = sR + 9 * a.L;                                   // (labels of this workgroup) x pmax sampled target values
+    unsigned *queue = reinterpret_cast<unsigned *>(sT + (size_t)lper_all * a.pmax);  // kQueueCap
     int *nin = reinterpret_cast<int *>(queue + kQueueCap);         // kChunk: containing triangles found
     int *win = nin + kChunk;                                        // kChunk: one of them
     __shared__ int s_qn, s_ndefer;
@@ -406,7 +407,7 @@ __global__ __launch_bounds__(256) void k_unary_samples(SamplesArgs a) {
                     const int l = fast_div(s, P, invP), i = s - l * P;
                     const V3 p = rotate(sR + 9 * l, mk(sx[i], sy[i], sz[i]));
                     const double v = emit_sample(a, gbase + s, p, win[sl]);
-                    if (a.U) sT[l * a.pmax + i] = v;
+                    if (a.U) sT[(l - l_beg) * a.pmax + i] = v;
                 } else if (n < 0) {
                     emit_failure(a, gbase + s, MSM_ERR_OUTSIDE);
                     atomicAdd(&s_ndefer, 1);
@@ -427,7 +428,7 @@ __global__ __launch_bounds__(256) void k_unary_samples(SamplesArgs a) {
             if (s_ndefer == 0) {
                 const double absw = a.absw[node];
                 for (int l = l_beg + (tid >> 6); l < l_end; l += 4) {
-                    const double cost = patch_similarity(sA, sW, sT + l * a.pmax, P, lane, a.simmeasure, a.percentile);
+                    const double cost = patch_similarity(sA, sW, sT + (l - l_beg) * a.pmax, P, lane, a.simmeasure, a.percentile);
                     if (lane == 0) a.U[(size_t)l * a.N + node] = absw * cost;
                 }
             } else if (tid == 0) {
@@ -1125,13 +1126,20 @@ __global__ __launch_bounds__(256) void k_unary_reduce_mv8(ReduceMv8Args a) {
 // ------------------------------------------------------------------------------------------------
 // launch
 // ------------------------------------------------------------------------------------------------
-static size_t samples_lds(int pmax, int L) {
-    return sizeof(double) * (5 * (size_t)pmax + 9 * (size_t)L + (size_t)L * pmax) + sizeof(unsigned) * kQueueCap + sizeof(int) * 2 * kChunk;
+// dynamic LDS of k_unary_samples when the labels are split over nsplit workgroups
+static size_t samples_lds(int pmax, int L, int nsplit) {
+    const size_t lper = (size_t)(L + nsplit - 1) / nsplit;
+    return sizeof(double) * (5 * (size_t)pmax + 9 * (size_t)L + lper * pmax) + sizeof(unsigned) * kQueueCap + sizeof(int) * 2 * kChunk;
 }
 
+// Workgroups per control point: enough that one workgroup's samples are about one LDS pass (at most 4 for that
+// reason), and more when the patch is so large (coarse control grid under a fine data grid) that the per-label target
+// values would not fit in LDS otherwise.
 int unary_nsplit(int L, int pmax) {
     if (const char *e = std::getenv("MSMHIP_NSPLIT")) return std::max(1, std::min(L, atoi(e)));  // experiments only
-    return std::max(1, std::min(4, (int)(((size_t)L * pmax + kChunk - 1) / kChunk)));
+    int n = std::max(1, std::min(4, (int)(((size_t)L * pmax + kChunk - 1) / kChunk)));
+    while (n < L && samples_lds(pmax, L, n) > 64 * 1024) ++n;
+    return std::min(n, std::max(L, 1));
 }
 int unary_fix_segments() { return kFixSegs; }
 size_t unary_fix_counter_words() { return (size_t)kCntStride * (1 + kFixSegs); }
@@ -1184,12 +1192,12 @@ static int launch_samples(msm_ctx *ctx, const UnaryLaunch &u, const UnaryWeights
     a.redo_count = u.fix_cnt;
     a.status = ctx->d_status;
     if (u.ntri >= (1 << kTriBits)) return fail(MSM_ERR_CAPACITY, "target mesh has %d triangles; the sample queue packs ids in %d bits", u.ntri, kTriBits);
-    const size_t lds = samples_lds(u.pmax, u.L);
-    if (lds > 64 * 1024) {
-        if (lds > 160 * 1024) return fail(MSM_ERR_CAPACITY, "patch of %d points x %d labels does not fit in LDS", u.pmax, u.L);
+    a.nsplit = unary_nsplit(u.L, u.pmax);
+    const size_t lds = samples_lds(u.pmax, u.L, a.nsplit);
+    if (!uses_ray_table(u.tree) && lds > 64 * 1024) {
+        if (lds > 160 * 1024) return fail(MSM_ERR_CAPACITY, "a patch of %d points does not fit in LDS", u.pmax);
         MSM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_unary_samples), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
-    a.nsplit = unary_nsplit(u.L, u.pmax);
     const int blocks = a.nsplit * 8 * ((u.N + 7) / 8);
     if (u.ev_start) MSM_HIP(hipEventRecord(u.ev_start, ctx->stream));
     if (uses_ray_table(u.tree)) {
@@ -1289,7 +1297,10 @@ int launch_unary_multivariate(msm_ctx *ctx, const UnaryLaunch &u, const UnaryWei
         m.U = u.U;
         hipLaunchKernelGGL(k_unary_reduce_mv8, dim3(u.N), dim3(256), 0, ctx->stream, m);
     } else {
-        hipLaunchKernelGGL(k_unary_reduce_features, dim3(u.N), dim3(256), (dice && patchwise) ? sizeof(double) * 8 * (size_t)u.pmax : 0, ctx->stream, r);
+        const size_t flds = (dice && patchwise) ? sizeof(double) * 8 * (size_t)u.pmax : 0;
+        if (flds > 160 * 1024) return fail(MSM_ERR_CAPACITY, "a patch of %d points does not fit in LDS (patchwise DICE)", u.pmax);
+        if (flds > 64 * 1024) MSM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_unary_reduce_features), hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
+        hipLaunchKernelGGL(k_unary_reduce_features, dim3(u.N), dim3(256), flds, ctx->stream, r);
     }
     MSM_HIP(hipGetLastError());
     MSM_HIP(hipMemsetAsync(u.fix_cnt, 0, unary_fix_counter_words() * sizeof(unsigned), ctx->stream));  // counters are zero between launches

@@ -9,7 +9,7 @@ from . import api, synthetic
 
 
 def pairwise_inputs(data_order=6, cp_order=4, sg_order=None, D=1, seed=1234, warp_amp=0.6, warp_rot=2.0, rescale=True,
-                    labeldist=0.5, target_noise=0.0, target_warp=0.0):
+                    labeldist=0.5, target_noise=0.0, target_warp=0.0, target_radial=0.0):
     """Inputs of one iteration: target / source / control grids, features, labels, rotations, cliques."""
     if sg_order is None:
         sg_order = cp_order + 2
@@ -21,6 +21,8 @@ def pairwise_inputs(data_order=6, cp_order=4, sg_order=None, D=1, seed=1234, war
         rng = np.random.default_rng(seed + 6)
         txyz = txyz + rng.normal(scale=target_noise, size=txyz.shape)
         txyz = txyz / np.linalg.norm(txyz, axis=1, keepdims=True) * synthetic.RAD
+    if target_radial > 0:  # star-shaped but not spherical: vertices move radially (still a simple surface; off the query shell)
+        txyz = txyz * (1.0 + target_radial * synthetic.smooth_feature(txyz, 1, seed + 7))[:, None]
     cxyz, ctri = api.make_mesh_from_icosa(cp_order)    # control grid
     # source: the data sphere part-way through a registration (smoothly warped), features of the moving image
     sxyz = synthetic.known_warp(txyz0, seed=seed + 1, rot_deg=warp_rot, amp=warp_amp)

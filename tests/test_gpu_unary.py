@@ -145,3 +145,39 @@ def test_sources_off_the_sphere(ctx, scale):
     both = np.isfinite(Uo)
     assert np.array_equal(np.isfinite(U), both)
     assert np.allclose(U[both], Uo[both], rtol=RTOL, atol=ATOL)
+
+
+@pytest.mark.parametrize("radial", [1e-4, 3e-3])
+def test_non_spherical_star_shaped_targets(ctx, radial):
+    # the target's vertices leave the sphere radially: still one triangle per ray (the ray table is built), but the
+    # triangles' boxes no longer sit where the radius-100 queries descend -> leaf membership decides, as in the reference
+    inp = problem.pairwise_inputs(5, 3, D=1, target_radial=radial)
+    cf, oc, _ = run_pair(ctx, inp, "univariate")
+    U, Uo = cf.computeUnaryCosts(), oc.unary_table()
+    both = np.isfinite(Uo)
+    assert np.array_equal(np.isfinite(U), both) and both.mean() > 0.9
+    assert np.allclose(U[both], Uo[both], rtol=RTOL, atol=ATOL), np.nanmax(np.abs(U - Uo))
+
+
+def test_randomised_configurations(ctx):
+    # a sweep over seeds, resolutions, warps and target shapes (regular / smoothly warped / radially perturbed / jittered)
+    rng = np.random.default_rng(2024)
+    for k in range(10):
+        data_order = int(rng.choice([3, 4, 5]))
+        cp_order = int(rng.integers(1, data_order - 1)) if data_order > 2 else 1
+        shape = k % 4
+        kw = dict(seed=int(rng.integers(1, 10**6)), warp_amp=float(rng.uniform(0.0, 1.2)), warp_rot=float(rng.uniform(0.0, 4.0)),
+                  labeldist=float(rng.uniform(0.3, 0.7)), rescale=bool(rng.integers(0, 2)))
+        if shape == 1:
+            kw["target_warp"] = float(rng.uniform(0.5, 3.0))
+        elif shape == 2:
+            kw["target_radial"] = float(10 ** rng.uniform(-5, -2.5))
+        elif shape == 3:
+            kw["target_noise"] = float(rng.uniform(0.1, 1.0))
+        sim = int(rng.choice([1, 2, 4]))
+        inp = problem.pairwise_inputs(data_order, cp_order, D=1, **kw)
+        cf, oc, _ = run_pair(ctx, inp, "univariate", simmeasure=sim)
+        U, Uo = cf.computeUnaryCosts(), oc.unary_table()
+        both = np.isfinite(Uo)
+        assert np.array_equal(np.isfinite(U), both), (k, kw)
+        assert np.allclose(U[both], Uo[both], rtol=RTOL, atol=ATOL), (k, kw, np.nanmax(np.abs(U - Uo)))
