@@ -418,7 +418,38 @@ int msm_cost_get_source_data(msm_cost *c) {
     if (st) return st;
     msm_ctx *ctx = c->ctx;
     MSM_HIP(c->d_pptr.upload(c->pptr.data(), c->pptr.size(), ctx->stream));
-    MSM_HIP(c->d_pidx.upload_vec(c->pidx, ctx->stream));
+    if (is_ho(c) || std::getenv("MSMHIP_NO_PATCH_SORT")) {
+        MSM_HIP(c->d_pidx.upload_vec(c->pidx, ctx->stream));
+    } else {
+        // Device-side order of the points of each patch: Morton order of their positions, so that the lanes of a wavefront
+        // sample neighbouring places of the target (neighbouring direction cells and triangle records share cache lines).
+        // The similarity does not depend on the order of the patch points; the API keeps reporting ascending ids.
+        const int Ns = c->source->V;
+        const double *sx = c->source->xyz.data();
+        auto spread = [](uint32_t v) {
+            v &= 0x3ff;
+            v = (v | (v << 16)) & 0x030000ff;
+            v = (v | (v << 8)) & 0x0300f00f;
+            v = (v | (v << 4)) & 0x030c30c3;
+            v = (v | (v << 2)) & 0x09249249;
+            return v;
+        };
+        std::vector<uint32_t> code(Ns);
+        for (int v = 0; v < Ns; ++v) {
+            uint32_t q[3];
+            for (int a = 0; a < 3; ++a) {
+                const double u = (sx[(size_t)a * Ns + v] + kBounds) / (2 * kBounds);
+                q[a] = (uint32_t)std::max(0.0, std::min(1023.0, u == u ? u * 1024.0 : 0.0));
+            }
+            code[v] = spread(q[0]) << 2 | spread(q[1]) << 1 | spread(q[2]);
+        }
+        std::vector<int32_t> sorted(c->pidx);
+        for (int g = 0; g < c->ngroups; ++g)
+            std::sort(sorted.begin() + c->pptr[g], sorted.begin() + c->pptr[g + 1],
+                      [&](int32_t x, int32_t y) { return code[x] < code[y] || (code[x] == code[y] && x < y); });
+        MSM_HIP(c->d_pidx.upload_vec(sorted, ctx->stream));
+        MSM_HIP(hipStreamSynchronize(ctx->stream));
+    }
     MSM_HIP(c->d_absw.upload(c->absw.data(), c->absw.size(), ctx->stream));
     {
         // Launch order of the control points in the unary kernels: Morton order of their positions, so that the
