@@ -88,6 +88,9 @@ int msm_cp_rotations(const double centre[3], const double *cp_xyz, int32_t N, do
  * the optimisers expect) and estimate_pairs :271-289 (pairs may be NULL to count; returns count) */
 int msm_estimate_triplets(const int32_t *tri, int32_t T, int32_t *triplets);
 int msm_estimate_pairs(const int32_t *tri, int32_t V, int32_t T, int32_t *pairs);
+/* testing hook: the search tree (newresampler::Octree, R/octree.cpp:31-141) of a mesh, built on the host without a GPU:
+ * stats as msm_mesh_octree_stats, and a signature of the leaves (box + triangle list in stored order of every leaf) */
+int msm_octree_signature(const double *xyz, const int32_t *tri, int32_t V, int32_t T, int64_t stats[5], uint64_t *signature);
 
 /* ------------------------------------------------------------------------------------------------
  * context: one per GPU

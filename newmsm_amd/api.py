@@ -123,6 +123,16 @@ def cp_rotations(centre, cp_xyz):
     return rot
 
 
+def octree_signature(xyz, tri):
+    """[host] statistics and leaf signature of the search tree of a mesh (testing hook)."""
+    x, px = _soa(xyz)
+    t, pt = _tri_soa(tri)
+    stats = (C.c_int64 * 5)()
+    sig = C.c_uint64(0)
+    check(lib().msm_octree_signature(px, pt, x.shape[1], t.shape[1], stats, C.byref(sig)))
+    return dict(nodes=stats[0], leaves=stats[1], depth=stats[2], refs=stats[3], max_leaf=stats[4]), sig.value
+
+
 def estimate_triplets(tri):
     t, pt = _tri_soa(tri)
     out = np.zeros((t.shape[1], 3), dtype=np.int32)

@@ -12,8 +12,12 @@
 
 namespace msm {
 
-// host cores this process may use (affinity aware; MSMHIP_HOST_THREADS overrides), at most 64
+// set inside a worker of parallel_for: nested set-up code then runs serially instead of multiplying the threads
+inline thread_local bool t_inside_worker = false;
+
+// host cores this process may use (affinity aware; MSMHIP_HOST_THREADS overrides), at most 64; 1 inside a worker
 inline int host_workers() {
+    if (t_inside_worker) return 1;
     cpu_set_t set;
     CPU_ZERO(&set);
     int n = 0;
@@ -35,6 +39,7 @@ void parallel_for(int n, int workers, F fn) {
     std::vector<std::thread> pool;
     for (int w = 0; w < workers; ++w)
         pool.emplace_back([&]() {
+            t_inside_worker = true;
             for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) fn(i);
         });
     for (auto &t : pool) t.join();

@@ -49,9 +49,11 @@ struct Builder {
     int V, T;
     std::deque<BNode> nodes;
     std::vector<double> box;  // per triangle: lo[3], hi[3]
+    const double *bxp = nullptr;  // = box.data(), or another builder's boxes (worker threads share them)
 
     void precompute_boxes() {
         box.resize((size_t)6 * T);
+        bxp = box.data();
         for (int t = 0; t < T; ++t) {
             double *lo = &box[(size_t)6 * t], *hi = lo + 3;
             for (int a = 0; a < 3; ++a) lo[a] = hi[a] = xyz[a * V + tri[t]];
@@ -64,7 +66,7 @@ struct Builder {
         }
     }
     void aabb(int t, double lo[3], double hi[3]) const {
-        const double *b = &box[(size_t)6 * t];
+        const double *b = &bxp[(size_t)6 * t];
         for (int a = 0; a < 3; ++a) {
             lo[a] = b[a];
             hi[a] = b[3 + a];
@@ -120,6 +122,50 @@ struct Builder {
         } else {
             for (int c = 0; c < 8; ++c)
                 if (overlaps(nodes[n].first_child + c, lo, hi)) add(nodes[n].first_child + c, t, lo, hi);
+        }
+    }
+
+    // ---- the same tree, top down ------------------------------------------------------------------------------
+    // Inserting the triangles one by one is equivalent to this: a node sees, in ascending id, every triangle whose box
+    // overlaps it (when a leaf splits, the triangles it holds are handed down in order and all later ones follow in
+    // order; a child never sees anything else, nor in another order).  It stays a leaf unless the split heuristic
+    // holds at some insertion from the MAX_TRIANGLES-th on -- the first such insertion splits it, and from then on only
+    // its children matter.  So a node is decided by one scan of its list, and its children by the sub-lists of the
+    // WHOLE list that overlap them: no per-triangle descent, and independent subtrees can be built on separate threads.
+    // `nodes` must hold node n with its box; children are appended to `nodes`.
+    void build_down(int n, std::vector<int32_t> &list) {
+        int total_size = 0, num_split = 0;
+        bool splits = false;
+        const int len = (int)list.size();
+        for (int i = 0; i < len; ++i) {
+            const double *bx = &bxp[(size_t)6 * list[i]];
+            int split_size = 8;
+            for (int d = 0; d < 3; ++d)
+                if ((bx[d] < nodes[n].b[d][1]) == (bx[3 + d] < nodes[n].b[d][1])) split_size >>= 1;
+            total_size += split_size;
+            if (split_size != 8) ++num_split;
+            if (i + 1 >= kMaxTriangles && num_split > 0 && total_size < 3 * (i + 1)) {
+                splits = true;
+                break;
+            }
+        }
+        if (!splits) {
+            nodes[n].tris = std::move(list);
+            return;
+        }
+        split(n);
+        const int first = nodes[n].first_child;
+        std::vector<int32_t> sub;
+        for (int c = 0; c < 8; ++c) {
+            sub.clear();
+            const BNode &ch = nodes[first + c];
+            for (int i = 0; i < len; ++i) {
+                const double *bx = &bxp[(size_t)6 * list[i]];
+                if (!(bx[3] < ch.b[0][0] || bx[0] > ch.b[0][2] || bx[4] < ch.b[1][0] || bx[1] > ch.b[1][2] || bx[5] < ch.b[2][0] || bx[2] > ch.b[2][2]))
+                    sub.push_back(list[i]);
+            }
+            std::vector<int32_t> mine(sub);
+            build_down(first + c, mine);
         }
     }
 };
@@ -447,9 +493,88 @@ void build_ray_table(const double *xyz, const int32_t *tri, int V, int T, FlatOc
     TICK("cells");
 }
 
+namespace {
+
+// build_down over the whole mesh; the subtrees below the first two levels are built on worker threads, each in its own
+// node store, and spliced into b.nodes afterwards (only the order of the nodes differs from the serial build).
+void build_top_down(Builder &b) {
+    std::vector<int32_t> all(b.T);
+    for (int t = 0; t < b.T; ++t) all[t] = t;
+    const int workers = host_workers();
+    if (workers == 1 || b.T < 20000) {  // threads cost more than they save on small meshes
+        b.build_down(0, all);
+        return;
+    }
+    struct Job {
+        int node;
+        std::vector<int32_t> list;
+    };
+    // levels 0 and 1: decide and split here, collect the (node, list) pairs of the next level instead of recursing
+    std::vector<Job> frontier, next;
+    frontier.push_back(Job{0, std::move(all)});
+    for (int level = 0; level < 2; ++level) {
+        next.clear();
+        for (Job &j : frontier) {
+            // a one-level build_down: scan, and on a split take the children's lists without descending
+            int total_size = 0, num_split = 0;
+            bool splits = false;
+            const int len = (int)j.list.size();
+            for (int i = 0; i < len && !splits; ++i) {
+                const double *bx = &b.bxp[(size_t)6 * j.list[i]];
+                int split_size = 8;
+                for (int d = 0; d < 3; ++d)
+                    if ((bx[d] < b.nodes[j.node].b[d][1]) == (bx[3 + d] < b.nodes[j.node].b[d][1])) split_size >>= 1;
+                total_size += split_size;
+                if (split_size != 8) ++num_split;
+                splits = i + 1 >= kMaxTriangles && num_split > 0 && total_size < 3 * (i + 1);
+            }
+            if (!splits) {
+                b.nodes[j.node].tris = std::move(j.list);
+                continue;
+            }
+            b.split(j.node);
+            const int first = b.nodes[j.node].first_child;
+            for (int c = 0; c < 8; ++c) {
+                const BNode &ch = b.nodes[first + c];
+                Job sub{first + c, {}};
+                for (int i = 0; i < len; ++i) {
+                    const double *bx = &b.bxp[(size_t)6 * j.list[i]];
+                    if (!(bx[3] < ch.b[0][0] || bx[0] > ch.b[0][2] || bx[4] < ch.b[1][0] || bx[1] > ch.b[1][2] || bx[5] < ch.b[2][0] || bx[2] > ch.b[2][2]))
+                        sub.list.push_back(j.list[i]);
+                }
+                next.push_back(std::move(sub));
+            }
+        }
+        frontier.swap(next);
+    }
+    // every remaining job builds its subtree in a private node store whose node 0 stands for the job's node
+    std::vector<Builder> part;
+    part.reserve(frontier.size());
+    for (const Job &j : frontier) {
+        part.push_back(Builder{b.xyz, b.tri, b.V, b.T, {}, {}, b.bxp});
+        part.back().nodes.push_back(b.nodes[j.node]);
+    }
+    parallel_for((int)frontier.size(), workers, [&](int k) { part[k].build_down(0, frontier[k].list); });
+    for (size_t k = 0; k < part.size(); ++k) {
+        const int root = frontier[k].node, base = (int)b.nodes.size() - 1;  // local i > 0 -> base + i
+        auto global = [&](int i) { return i == 0 ? root : base + i; };
+        std::deque<BNode> &ln = part[k].nodes;
+        b.nodes[root].tris = std::move(ln[0].tris);
+        b.nodes[root].first_child = ln[0].first_child < 0 ? -1 : global(ln[0].first_child);
+        for (size_t i = 1; i < ln.size(); ++i) {
+            BNode nd = std::move(ln[i]);
+            nd.parent = global(nd.parent);
+            if (nd.first_child >= 0) nd.first_child = global(nd.first_child);
+            b.nodes.push_back(std::move(nd));
+        }
+    }
+}
+
+}  // namespace
+
 void build_octree(const double *xyz, const int32_t *tri, int V, int T, FlatOctree &out) {
     auto tick_ = std::chrono::steady_clock::now();
-    Builder b{xyz, tri, V, T, {}, {}};
+    Builder b{xyz, tri, V, T, {}, {}, nullptr};
     b.precompute_boxes();
     BNode root;
     for (int a = 0; a < 3; ++a) {
@@ -459,10 +584,15 @@ void build_octree(const double *xyz, const int32_t *tri, int V, int T, FlatOctre
     }
     root.tris.reserve(kMaxTriangles);
     b.nodes.push_back(std::move(root));
-    for (int t = 0; t < T; ++t) {  // initialize_tree, R/octree.cpp:42-63
-        double lo[3], hi[3];
-        b.aabb(t, lo, hi);
-        b.add(0, t, lo, hi);
+    const char *incremental = std::getenv("MSMHIP_INCREMENTAL_OCTREE");  // the literal restatement, kept for cross-checks
+    if (incremental && incremental[0] == '1') {
+        for (int t = 0; t < T; ++t) {  // initialize_tree, R/octree.cpp:42-63
+            double lo[3], hi[3];
+            b.aabb(t, lo, hi);
+            b.add(0, t, lo, hi);
+        }
+    } else {
+        build_top_down(b);
     }
 
     TICK("octree: insertion");
@@ -533,3 +663,32 @@ void build_octree(const double *xyz, const int32_t *tri, int V, int T, FlatOctre
 }
 
 }  // namespace msm
+
+// [host] testing hook: the search tree of a mesh without a GPU -- its statistics and a signature of its leaves (box and
+// triangle list of every leaf, independent of the order in which the nodes were created)
+extern "C" int msm_octree_signature(const double *xyz, const int32_t *tri, int32_t V, int32_t T, int64_t stats[5], uint64_t *signature) {
+    if (!xyz || !tri || V <= 0 || T <= 0) return msm::fail(MSM_ERR_INVALID, "msm_octree_signature: bad arguments");
+    msm::FlatOctree o;
+    msm::build_octree(xyz, tri, V, T, o);
+    if (stats) std::copy(o.stats, o.stats + 5, stats);
+    if (signature) {
+        uint64_t sum = 0;
+        for (size_t n = 0; n < o.node.size(); ++n) {
+            if (o.node[n].x >= 0) continue;
+            uint64_t h = 1469598103934665603ull;
+            auto mix = [&](uint64_t v) {
+                for (int k = 0; k < 8; ++k) {
+                    h ^= (v >> (8 * k)) & 0xff;
+                    h *= 1099511628211ull;
+                }
+            };
+            const double4 b = o.nodebox[n];
+            for (double d : {b.x, b.y, b.z, b.w}) mix((uint64_t)__builtin_bit_cast(uint64_t, d));
+            for (int e = 0; e < -o.node[n].x - 1; ++e) mix((uint64_t)o.leaf_tri[o.node[n].y + e]);
+            sum += h;
+        }
+        *signature = sum;
+    }
+    return MSM_OK;
+}
+

@@ -59,3 +59,26 @@ def test_rotation_matrix_special_cases(built):
     a = np.array([0.3, -0.2, 0.9])
     assert np.array_equal(M.estimate_rotation_matrix(a, 3 * a), np.eye(3))          # identity branch
     assert np.array_equal(M.estimate_rotation_matrix(a, -a), O.rotation_matrix(a, -a))  # antipodal branch
+
+
+@pytest.mark.parametrize("order,shape", [(3, "regular"), (5, "regular"), (5, "warped"), (5, "jittered"), (6, "regular")])
+def test_top_down_octree_equals_incremental_insertion(built, monkeypatch, order, shape):
+    # the library builds the reference's tree top down (a node is decided by one scan of the triangles overlapping it, in
+    # id order) and on worker threads; the literal one-by-one insertion (R/octree.cpp:42-141) must give the same leaves
+    import newmsm_amd as M
+    from newmsm_amd import synthetic
+
+    xyz, tri = M.make_mesh_from_icosa(order)
+    if shape == "warped":
+        xyz = synthetic.known_warp(xyz, seed=3, rot_deg=4.0, amp=3.0)
+    elif shape == "jittered":
+        rng = np.random.default_rng(4)
+        xyz = xyz + rng.normal(scale=0.8, size=xyz.shape)
+    fast = M.octree_signature(xyz, tri)
+    monkeypatch.setenv("MSMHIP_HOST_THREADS", "1")
+    serial = M.octree_signature(xyz, tri)
+    monkeypatch.setenv("MSMHIP_INCREMENTAL_OCTREE", "1")
+    literal = M.octree_signature(xyz, tri)
+    assert fast == serial == literal
+    if shape == "regular" and order == 6:
+        assert fast[0] == dict(nodes=14281, leaves=12496, depth=6, refs=176096, max_leaf=49)  # SURVEY.md section 8 [probe]
