@@ -23,39 +23,43 @@ __device__ __forceinline__ V3 aos(const double *p, size_t i) { return mk(p[3 * i
 __device__ __noinline__ int search_slow(const DevTree *T, double x, double y, double z) { return find_closest_triangle(*T, mk(x, y, z)); }
 
 // one point of an HO bin: the source vertex is projected on the current control triangle, carried to the moved
-// triangle by its barycentric coordinates, pushed back to the sphere and sampled on the target
-// (HO*::get_target_data, M/DiscreteCostFunction.cpp:498-517 / :574-598).  Returns the hit triangle or an error code.
-__device__ __forceinline__ int ho_sample(const CliqueArgs &a, int sv, const V3 &cp0, const V3 &cp1, const V3 &cp2, const V3 &n0, const V3 &n1,
-                                         const V3 &n2, double &wa, double &wb, double &wc) {
+// triangle by its barycentric coordinates and pushed back to the sphere (HO*::get_target_data,
+// M/DiscreteCostFunction.cpp:498-510 / :574-590)
+__device__ __forceinline__ V3 ho_point_position(const CliqueArgs &a, int sv, const V3 &cp0, const V3 &cp1, const V3 &cp2, const V3 &n0, const V3 &n1,
+                                                const V3 &n2) {
     const V3 sp = project_point(soa(a.src, a.Nsrc, sv), cp0, cp1, cp2);
+    double wa, wb, wc;
     area_weights(cp0, cp1, cp2, sp, wa, wb, wc);  // barycentric(), R/triangle.cpp:159-172
-    V3 tmp = mk(n0.x * wa + n1.x * wb + n2.x * wc, n0.y * wa + n1.y * wb + n2.y * wc, n0.z * wa + n1.z * wb + n2.z * wc);
-    tmp = scale(normalized(tmp), kRad);
+    const V3 tmp = mk(n0.x * wa + n1.x * wb + n2.x * wc, n0.y * wa + n1.y * wb + n2.y * wc, n0.z * wa + n1.z * wb + n2.z * wc);
+    return scale(normalized(tmp), kRad);
+}
+
+// ... and sampled on the target triangle tt (:511-517 / :591-598): HO univariate -> the interpolated target value; HO
+// multivariate -> the point's feature-vector similarity (triplet_likelihood, :601-618)
+__device__ __forceinline__ double ho_value_on(const CliqueArgs &a, int sv, const V3 &tmp, int tt) {
+    const TriRec &r = a.tree.rec[tt];
+    double wa, wb, wc;
+    area_weights(rec_v0(r), rec_v1(r), rec_v2(r), tmp, wa, wb, wc);
+    const int D = a.D;
+    if (a.kind == MSM_COST_HO_UNIVARIATE) return wa * a.tfeat[(size_t)r.id[0] * D] + wb * a.tfeat[(size_t)r.id[1] * D] + wc * a.tfeat[(size_t)r.id[2] * D];
+    const double *f0 = a.tfeat + (size_t)r.id[0] * D, *f1 = a.tfeat + (size_t)r.id[1] * D, *f2 = a.tfeat + (size_t)r.id[2] * D;
+    if (a.sfeat_vm) return feature_vector_similarity(a.simmeasure, a.percentile, a.sfeat_vm, a.cfw_vm, a.cfw_rows, 0, sv, D, f0, f1, f2, wa, wb, wc);
+    return feature_vector_similarity(a.simmeasure, a.percentile, a.sfeat, a.cfw, a.cfw_rows, a.Nsrc, sv, D, f0, f1, f2, wa, wb, wc);
+}
+
+// One point of a bin, complete: NaN (and the status word) on a failed search.
+__device__ double ho_point_value(const CliqueArgs &a, int sv, const V3 &cp0, const V3 &cp1, const V3 &cp2, const V3 &n0, const V3 &n1, const V3 &n2) {
+    const V3 tmp = ho_point_position(a, sv, cp0, cp1, cp2, n0, n1, n2);
     int tt = ray_find(a.tree, tmp);  // simple-surface targets: settled by the ray table nearly always
     if (tt < 0) {
         const DevTree T = a.tree;
         tt = search_slow(&T, tmp.x, tmp.y, tmp.z);
     }
-    if (tt < 0) return tt;
-    const TriRec &r = a.tree.rec[tt];
-    area_weights(rec_v0(r), rec_v1(r), rec_v2(r), tmp, wa, wb, wc);
-    return tt;
-}
-
-// One point of a bin: HO univariate -> the sampled target value; HO multivariate -> the point's feature-vector
-// similarity (HO*::triplet_likelihood, :520-531 / :601-618).  NaN (and the status word) on a failed search.
-__device__ double ho_point_value(const CliqueArgs &a, int sv, const V3 &cp0, const V3 &cp1, const V3 &cp2, const V3 &n0, const V3 &n1, const V3 &n2) {
-    double wa, wb, wc;
-    const int tt = ho_sample(a, sv, cp0, cp1, cp2, n0, n1, n2, wa, wb, wc);
     if (tt < 0) {
         raise_status(a.status, tt);
         return __longlong_as_double(0x7ff8000000000000ll);
     }
-    const TriRec &r = a.tree.rec[tt];
-    const int D = a.D;
-    if (a.kind == MSM_COST_HO_UNIVARIATE) return wa * a.tfeat[(size_t)r.id[0] * D] + wb * a.tfeat[(size_t)r.id[1] * D] + wc * a.tfeat[(size_t)r.id[2] * D];
-    const double *f0 = a.tfeat + (size_t)r.id[0] * D, *f1 = a.tfeat + (size_t)r.id[1] * D, *f2 = a.tfeat + (size_t)r.id[2] * D;
-    return feature_vector_similarity(a.simmeasure, a.percentile, a.sfeat, a.cfw, a.cfw_rows, a.Nsrc, sv, D, f0, f1, f2, wa, wb, wc);
+    return ho_value_on(a, sv, tmp, tt);
 }
 
 // HO*::triplet_likelihood (:520-531 univariate, :601-618 multivariate) from the bin's point values vals[0..n) (see
@@ -153,6 +157,8 @@ __device__ V3 deform_anatomy_vertex(const CliqueArgs &a, int tindex, const int *
 
 // computeTripletCost, M/DiscreteCostFunction.cpp:135-188 (regoption 2/3: spherical strain; 4/5: anatomical strain).
 // `vals`: the bin's point values for the HO classes (nullptr for the others, whose triplet_likelihood is 0).
+// kAnat = false leaves the anatomical branch (and the complete search it drags in) out of the instantiation.
+template <bool kAnat>
 __device__ double triplet_cost(const CliqueArgs &a, int t, int la, int lb, int lc, const double *vals) {
     const int id[3] = {a.triplets[3 * t], a.triplets[3 * t + 1], a.triplets[3 * t + 2]};
     const V3 r[3] = {aos(a.moved, (size_t)id[0] * a.L + la), aos(a.moved, (size_t)id[1] * a.L + lb), aos(a.moved, (size_t)id[2] * a.L + lc)};
@@ -161,7 +167,7 @@ __device__ double triplet_cost(const CliqueArgs &a, int t, int la, int lb, int l
     if (dot(tri_normal(r[0], r[1], r[2]), tri_normal(cur[0], cur[1], cur[2])) < 0.0) return MSM_FOLDING * a.lambda;
     const double likelihood = vals ? ho_likelihood(a, t, id, vals) : 0.0;
     double w;
-    if (a.rmode == 4 || a.rmode == 5) {  // :169-182: mean strain of the anatomical faces under this control triangle
+    if (kAnat && (a.rmode == 4 || a.rmode == 5)) {  // :169-182: mean strain of the anatomical faces under this control triangle
         const int beg = a.af_ptr[t], nf = a.af_ptr[t + 1] - beg;
         bool failed = false;
         w = 0.0;
@@ -222,7 +228,7 @@ __device__ double pairwise_cost(const CliqueArgs &a, int pair, int la, int lb) {
 __global__ __launch_bounds__(128) void k_triplet_batch(CliqueArgs a, const int *__restrict__ qt, const int *__restrict__ qa,
                                                         const int *__restrict__ qb, const int *__restrict__ qc, int n, double *__restrict__ out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = triplet_cost(a, qt[i], qa[i], qb[i], qc[i], nullptr);
+    if (i < n) out[i] = triplet_cost<true>(a, qt[i], qa[i], qb[i], qc[i], nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -253,7 +259,7 @@ __device__ void ho_group_eval(const CliqueArgs &a, bool valid, int t, int la, in
         }
     }
     __syncthreads();
-    if (valid && sub == 0) *out = triplet_cost(a, t, la, lb, lc, vals);
+    if (valid && sub == 0) *out = triplet_cost<true>(a, t, la, lb, lc, vals);
 }
 
 template <int kHoLanes>
@@ -284,6 +290,99 @@ __global__ __launch_bounds__(256) void k_triplet_table_ho(CliqueArgs a, int t0, 
     ho_group_eval<kHoLanes>(a, valid, valid ? t0 + (int)(i / per) : 0, (int)(r / (L * L)), (int)((r / L) % L), (int)(r % L), out + (valid ? i : 0));
 }
 
+// ------------------------------------------------------------------------------------------------
+// Fusion move of the HO classes on a ray-table target, as three lean kernels (the unary table's split): sample every
+// (evaluation, bin point) with the ray table only (no complete search in the kernel: 8 waves/SIMD instead of 2),
+// complete search for the few the table could not settle, then the serial similarity + strain per evaluation.
+// The values live in a.ho_vals at 8 * bin_ptr[t] + k * n_t + i.
+// ------------------------------------------------------------------------------------------------
+struct OctetEval {
+    int t, la, lb, lc;
+    size_t offset;
+};
+__device__ __forceinline__ OctetEval octet_eval(const CliqueArgs &a, const int *labeling, int label, int e) {
+    OctetEval q;
+    q.t = e >> 3;
+    const int k = e & 7;
+    q.la = (k & 4) ? label : labeling[a.triplets[3 * q.t]];
+    q.lb = (k & 2) ? label : labeling[a.triplets[3 * q.t + 1]];
+    q.lc = (k & 1) ? label : labeling[a.triplets[3 * q.t + 2]];
+    const int beg = a.bin_ptr[q.t], n = a.bin_ptr[q.t + 1] - beg;
+    q.offset = (size_t)8 * beg + (size_t)k * n;
+    return q;
+}
+struct OctetGeometry {
+    V3 r0, r1, r2, cp0, cp1, cp2;
+    bool folded;
+};
+__device__ __forceinline__ OctetGeometry octet_geometry(const CliqueArgs &a, const OctetEval &q) {
+    const int id[3] = {a.triplets[3 * q.t], a.triplets[3 * q.t + 1], a.triplets[3 * q.t + 2]};
+    OctetGeometry g;
+    g.r0 = aos(a.moved, (size_t)id[0] * a.L + q.la), g.r1 = aos(a.moved, (size_t)id[1] * a.L + q.lb), g.r2 = aos(a.moved, (size_t)id[2] * a.L + q.lc);
+    g.cp0 = soa(a.cp, a.N, id[0]), g.cp1 = soa(a.cp, a.N, id[1]), g.cp2 = soa(a.cp, a.N, id[2]);
+    g.folded = dot(tri_normal(g.r0, g.r1, g.r2), tri_normal(g.cp0, g.cp1, g.cp2)) < 0.0;  // computeTripletCost, :151-152
+    return g;
+}
+
+constexpr int kOctLanes = 4;
+
+__global__ __launch_bounds__(256) void k_ho_octets_sample(CliqueArgs a, const int *__restrict__ labeling, int label) {
+    const int e = blockIdx.x * (256 / kOctLanes) + threadIdx.x / kOctLanes, sub = threadIdx.x % kOctLanes;
+    if (e >= 8 * a.T) return;
+    const OctetEval q = octet_eval(a, labeling, label, e);
+    const OctetGeometry g = octet_geometry(a, q);
+    if (g.folded) return;  // a folded proposal never looks at the data
+    const int beg = a.bin_ptr[q.t], n = a.bin_ptr[q.t + 1] - beg;
+    for (int i = sub; i < n; i += kOctLanes) {
+        const int sv = a.bin_idx[beg + i];
+        const V3 tmp = ho_point_position(a, sv, g.cp0, g.cp1, g.cp2, g.r0, g.r1, g.r2);
+        const int tt = ray_find(a.tree, tmp);
+        if (tt >= 0) a.ho_vals[q.offset + i] = ho_value_on(a, sv, tmp, tt);
+        else a.ho_pending[atomicAdd(a.ho_count, 1u)] = ((unsigned)e << 10) | (unsigned)i;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_ho_octets_fix(CliqueArgs a, const int *__restrict__ labeling, int label) {
+    const unsigned n = *a.ho_count;
+    const int lane = threadIdx.x & 63, sub = lane & 7, grp = lane >> 3;
+    const unsigned per_block = 256 / 8, stride = gridDim.x * per_block;
+    // eight lanes per pending point (search_device.hpp: group8_find); wavefront-uniform loop for its ballots
+    for (unsigned j0 = blockIdx.x * per_block + (threadIdx.x >> 6) * 8; j0 < n; j0 += stride) {
+        const unsigned j = j0 + grp;
+        const bool valid = j < n;
+        V3 tmp = mk(0.0, 0.0, 0.0);
+        size_t slot = 0;
+        int sv = 0;
+        if (valid) {
+            const unsigned p = a.ho_pending[j];
+            const int e = (int)(p >> 10), i = (int)(p & 1023u);
+            const OctetEval q = octet_eval(a, labeling, label, e);
+            const OctetGeometry g = octet_geometry(a, q);
+            sv = a.bin_idx[a.bin_ptr[q.t] + i];
+            tmp = ho_point_position(a, sv, g.cp0, g.cp1, g.cp2, g.r0, g.r1, g.r2);
+            slot = q.offset + i;
+        }
+        const int found = group8_find(a.tree, valid, tmp, lane);
+        if (valid && sub == 0) {
+            const int tt = found == kGroupUndecided ? find_closest_triangle(a.tree, tmp) : found;
+            if (tt < 0) {
+                raise_status(a.status, tt);
+                a.ho_vals[slot] = __longlong_as_double(0x7ff8000000000000ll);
+            } else {
+                a.ho_vals[slot] = ho_value_on(a, sv, tmp, tt);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(128) void k_ho_octets_reduce(CliqueArgs a, const int *__restrict__ labeling, int label, double *__restrict__ out) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e == 0) *a.ho_count = 0u;  // the pending list has been consumed: ready for the next move
+    if (e >= 8 * a.T) return;
+    const OctetEval q = octet_eval(a, labeling, label, e);
+    out[e] = triplet_cost<false>(a, q.t, q.la, q.lb, q.lc, a.ho_vals + q.offset);
+}
+
 // the 8 costs per triplet of one fusion move, I/Fusion/Fusion.h:181-196: bit order (A,B,C), 0 = current label
 __global__ __launch_bounds__(128) void k_triplet_octets(CliqueArgs a, const int *__restrict__ labeling, int label, double *__restrict__ out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -292,7 +391,7 @@ __global__ __launch_bounds__(128) void k_triplet_octets(CliqueArgs a, const int 
     const int la = (k & 4) ? label : labeling[a.triplets[3 * t]];
     const int lb = (k & 2) ? label : labeling[a.triplets[3 * t + 1]];
     const int lc = (k & 1) ? label : labeling[a.triplets[3 * t + 2]];
-    out[i] = triplet_cost(a, t, la, lb, lc, nullptr);
+    out[i] = triplet_cost<true>(a, t, la, lb, lc, nullptr);
 }
 
 __global__ __launch_bounds__(256) void k_pairwise_batch(CliqueArgs a, const int *__restrict__ qp, const int *__restrict__ qa,
@@ -347,7 +446,14 @@ int launch_triplet_batch(msm_ctx *ctx, const CliqueArgs &a, const int *qt, const
 }
 int launch_triplet_octets(msm_ctx *ctx, const CliqueArgs &a, const int *labeling, int label, double *out) {
     if (a.T <= 0) return MSM_OK;
-    if (is_ho(a))
+    if (is_ho(a) && a.ho_vals && a.tree.simple && a.tree.ray_G > 0 && a.rmode != 4 && a.rmode != 5) {
+        const int per = 256 / kOctLanes;
+        hipLaunchKernelGGL(k_ho_octets_sample, dim3((8 * a.T + per - 1) / per), dim3(256), 0, ctx->stream, a, labeling, label);
+        MSM_HIP(hipGetLastError());
+        hipLaunchKernelGGL(k_ho_octets_fix, dim3(64), dim3(256), 0, ctx->stream, a, labeling, label);
+        MSM_HIP(hipGetLastError());
+        hipLaunchKernelGGL(k_ho_octets_reduce, dim3((8 * a.T + 127) / 128), dim3(128), 0, ctx->stream, a, labeling, label, out);
+    } else if (is_ho(a))
         MSM_HO_LAUNCH(k_triplet_octets_ho, (size_t)8 * a.T, a, labeling, label, out);
     else
         hipLaunchKernelGGL(k_triplet_octets, dim3((8 * a.T + 127) / 128), dim3(128), 0, ctx->stream, a, labeling, label, out);
@@ -367,7 +473,7 @@ __global__ __launch_bounds__(128) void k_triplet_table(CliqueArgs a, int t0, int
     if (i >= (size_t)(t1 - t0) * per) return;
     const int t = t0 + (int)(i / per);
     const size_t r = i % per;
-    out[i] = triplet_cost(a, t, (int)(r / (L * L)), (int)((r / L) % L), (int)(r % L), nullptr);
+    out[i] = triplet_cost<true>(a, t, (int)(r / (L * L)), (int)((r / L) % L), (int)(r % L), nullptr);
 }
 
 int launch_triplet_table(msm_ctx *ctx, const CliqueArgs &a, int t0, int t1, double *out) {

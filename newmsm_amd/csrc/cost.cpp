@@ -12,6 +12,26 @@
 using namespace msm;
 
 namespace msm {
+// vertex-major copies of the moving features and their weights: the D values of a vertex in one or two cache lines
+int ensure_vertex_major(msm_cost *c) {
+    if (c->vm_valid) return MSM_OK;
+    msm_ctx *ctx = c->ctx;
+    const int Ns = c->source->V, D = c->D, R = c->cfw_rows;
+    std::vector<double> vm((size_t)Ns * D);
+    for (int d = 0; d < D; ++d)
+        for (int v = 0; v < Ns; ++v) vm[(size_t)v * D + d] = c->sfeat[(size_t)d * Ns + v];
+    MSM_HIP(c->d_sfeat_vm.upload(vm.data(), vm.size(), ctx->stream));
+    if (!c->cfw.empty()) {
+        std::vector<double> wm((size_t)Ns * R);
+        for (int r = 0; r < R; ++r)
+            for (int v = 0; v < Ns; ++v) wm[(size_t)v * R + r] = c->cfw[(size_t)r * Ns + v];
+        MSM_HIP(c->d_cfw_vm.upload(wm.data(), wm.size(), ctx->stream));
+    }
+    MSM_HIP(hipStreamSynchronize(ctx->stream));
+    c->vm_valid = true;
+    return MSM_OK;
+}
+
 int ensure_label_rotations(msm_cost *c) {
     if (c->rotations_valid) return MSM_OK;  // a pure function of the control grid, ROT and the label set
     if (c->L <= 0 || !c->cpgrid) return fail(MSM_ERR_STATE, "msm_cost: labels must be set first");
@@ -198,21 +218,8 @@ int ensure_unary_table(msm_cost *c) {
         case MSM_COST_MULTIVARIATE:
         case MSM_COST_PATCHWISE: {
             if (c->p.kind == MSM_COST_MULTIVARIATE) {
-                if (!c->vm_valid) {  // vertex-major copies: a patch point's D values in one or two cache lines
-                    const int Ns = c->source->V, D = c->D, R = c->cfw_rows;
-                    std::vector<double> vm((size_t)Ns * D);
-                    for (int d = 0; d < D; ++d)
-                        for (int v = 0; v < Ns; ++v) vm[(size_t)v * D + d] = c->sfeat[(size_t)d * Ns + v];
-                    MSM_HIP(c->d_sfeat_vm.upload(vm.data(), vm.size(), ctx->stream));
-                    if (!c->cfw.empty()) {
-                        std::vector<double> wm((size_t)Ns * R);
-                        for (int r = 0; r < R; ++r)
-                            for (int v = 0; v < Ns; ++v) wm[(size_t)v * R + r] = c->cfw[(size_t)r * Ns + v];
-                        MSM_HIP(c->d_cfw_vm.upload(wm.data(), wm.size(), ctx->stream));
-                    }
-                    MSM_HIP(hipStreamSynchronize(ctx->stream));
-                    c->vm_valid = true;
-                }
+                st = ensure_vertex_major(c);
+                if (st) return st;
                 u.sfeat_vm = c->d_sfeat_vm.p;
                 u.cfw_vm = c->cfw.empty() ? nullptr : c->d_cfw_vm.p;
             }

@@ -57,16 +57,35 @@ int clique_args(msm_cost *c, bool need_triplets, bool need_pairs, CliqueArgs &a)
     a.sfeat = c->d_sfeat.p;
     a.cfw = c->cfw.empty() ? nullptr : c->d_cfw.p;
     a.cfw_rows = c->cfw_rows;
+    a.sfeat_vm = a.cfw_vm = nullptr;
     a.bin_ptr = c->d_pptr.p;
     a.bin_idx = c->d_pidx.p;
     a.bin_cap = std::max(c->pmax, 1);
+    a.ho_vals = nullptr;
+    a.ho_pending = nullptr;
+    a.ho_count = nullptr;
     a.absw = c->d_absw.p;
     a.status = ctx->d_status;
     if (need_triplets && cost_is_ho(c)) {
         if (!c->have_source) return fail(MSM_ERR_STATE, "msm_cost: get_source_data() must be called first");
         if (!c->target->d_feat || c->target->D != c->D) return fail(MSM_ERR_STATE, "msm_cost: target features must match the source features");
-        st = ensure_rays(c->target);
+        st = ensure_rays(c->target);  // includes the sub-cell masks the group search uses
         if (st) return st;
+        if (c->p.kind == MSM_COST_HO_MULTIVARIATE) {
+            st = ensure_vertex_major(c);
+            if (st) return st;
+            a.sfeat_vm = c->d_sfeat_vm.p;
+            a.cfw_vm = c->cfw.empty() ? nullptr : c->d_cfw_vm.p;
+        }
+        if (c->target->tree.ray_G > 0 && c->pmax <= 1024 && a.T < (1 << 18)) {  // fusion moves: sample -> fix up -> reduce
+            const size_t nv = 8 * c->pidx.size();
+            MSM_HIP(c->d_ho_vals.ensure(std::max<size_t>(nv, 1)));
+            MSM_HIP(c->d_ho_pending.ensure(std::max<size_t>(nv, 1)));
+            if (!c->d_ho_count.p) MSM_HIP(c->d_ho_count.zero(1, ctx->stream));
+            a.ho_vals = c->d_ho_vals.p;
+            a.ho_pending = c->d_ho_pending.p;
+            a.ho_count = c->d_ho_count.p;
+        }
         if (c->pmax > 1024)
             return fail(MSM_ERR_CAPACITY, "msm_cost: %d source vertices under one control-grid triangle; the triclique kernels hold at most 1024 per evaluation", c->pmax);
     }

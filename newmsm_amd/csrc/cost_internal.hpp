@@ -37,6 +37,8 @@ struct msm_cost {
     bool cp_conn_valid = false;
     DevBuf<int32_t> d_labeling;
     DevBuf<double> d_clique_out;
+    DevBuf<double> d_ho_vals;
+    DevBuf<unsigned> d_ho_pending, d_ho_count;
     // get_source_data products
     bool have_source = false;
     int ngroups = 0, pmax = 0;
@@ -85,5 +87,6 @@ int query_host(msm_mesh *target, const double *q, int N, int *tri_id, int *vid, 
 const Adjacency &mesh_adjacency(msm_mesh *m);
 // (re)computes the per (control point, label) rotation matrices and moved control points if stale
 int ensure_label_rotations(msm_cost *c);
+int ensure_vertex_major(msm_cost *c);  // d_sfeat_vm / d_cfw_vm
 inline bool cost_is_ho(const msm_cost *c) { return c->p.kind == MSM_COST_HO_UNIVARIATE || c->p.kind == MSM_COST_HO_MULTIVARIATE; }
 }  // namespace msm

@@ -92,8 +92,13 @@ struct CliqueArgs {
     const double *sfeat;      // D x Nsrc
     const double *cfw;
     int cfw_rows;
+    const double *sfeat_vm, *cfw_vm;  // vertex-major copies (HO multivariate), or nullptr
     const int *bin_ptr, *bin_idx;  // source vertices per control-grid triangle
     int bin_cap;                   // largest bin (LDS slice per evaluation in the HO kernels)
+    // scratch of the three-kernel fusion-move path (ray-table targets): one value per (octet evaluation, bin point)
+    double *ho_vals;               // 8 x (all bin points) doubles, or nullptr
+    unsigned *ho_pending;          // same count: evaluation << 10 | point, for the complete search
+    unsigned *ho_count;            // 1 word, zero between calls
     const double *absw;
     // anatomical strain (rmode 4/5)
     int rmode;

@@ -260,4 +260,131 @@ __device__ __forceinline__ int find_closest_triangle(const DevTree &T, const V3 
     return fallback_search(T, n, p, fx, fy, fz);
 }
 
+
+__device__ __forceinline__ bool outside_root(const V3 &p) {
+    return p.x < -kBounds || p.x > kBounds || p.y < -kBounds || p.y > kBounds || p.z < -kBounds || p.z > kBounds;
+}
+
+
+// locate the octree leaf of p (same decisions as find_closest_triangle) and the sub-cell of p inside the leaf's
+// box: the box is cut 4x4x4 and the three cut positions per axis are exact dyadics, so plain comparisons place p
+// in the same (closed) sub-cell the mask builder reasoned about.
+__device__ __forceinline__ int4 locate_leaf(const DevTree &T, const V3 &p, int &subcell) {
+    const int G = 1 << T.grid_depth;
+    const double h = 2 * kBounds / G;
+    const int ix = grid_axis(p.x, G, h), iy = grid_axis(p.y, G, h), iz = grid_axis(p.z, G, h);
+    int4 nd = T.node[T.grid[((size_t)ix * G + iy) * G + iz]];
+    double lx, ly, lz, size;
+    if (nd.x < 0) {  // a leaf at depth w <= grid_depth: its box is the depth-w cell above this grid cell
+        const int up = T.grid_depth - nd.w;
+        size = ldexp(2 * kBounds, -nd.w);  // 202 / 2^w, exact
+        lx = -kBounds + (ix >> up) * size;
+        ly = -kBounds + (iy >> up) * size;
+        lz = -kBounds + (iz >> up) * size;
+    } else {
+        lx = -kBounds + ix * h;
+        ly = -kBounds + iy * h;
+        lz = -kBounds + iz * h;
+        double hx = lx + h, hy = ly + h, hz = lz + h;
+        while (nd.x >= 0) {
+            const double mx = (lx + hx) / 2.0, my = (ly + hy) / 2.0, mz = (lz + hz) / 2.0;
+            const int cx = !(p.x < mx), cy = !(p.y < my), cz = !(p.z < mz);
+            if (cx) lx = mx; else hx = mx;
+            if (cy) ly = my; else hy = my;
+            if (cz) lz = mz; else hz = mz;
+            nd = T.node[nd.x + 4 * cx + 2 * cy + cz];
+        }
+        size = hx - lx;
+    }
+    const double q = size / 4;
+    const int sx = (p.x >= lx + q) + (p.x >= lx + 2 * q) + (p.x >= lx + 3 * q);
+    const int sy = (p.y >= ly + q) + (p.y >= ly + 2 * q) + (p.y >= ly + 3 * q);
+    const int sz = (p.z >= lz + q) + (p.z >= lz + 2 * q) + (p.z >= lz + 3 * q);
+    subcell = 16 * sx + 4 * sy + sz;
+    return nd;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// The search of one point by the eight lanes of a group (lane & 7; all 64 lanes of the wavefront must call this
+// together, groups with valid == false just ride along).  The lanes share the point and split the set bits of the
+// leaf's sub-cell mask (cone test + exact inside test each).  Exactly one containing triangle = the reference's answer
+// (R/octree.cpp:166-178: a single passing triangle wins whatever its distance); several are resolved in entry order
+// with dist_to_point evaluated by the owner lanes (:172-178).  Returns the triangle, or kGroupUndecided when the
+// complete search is needed (nothing in the leaf, no masks, outside the root, NaN).  The value is the same in all
+// lanes of the group.  With a lane per point the exact tests of 64 lanes end up at 64 different loop positions and
+// run one after the other (32 us for 2 % of an ico6 table); what counts for these short lists is the length of one
+// wavefront's dependent chain.
+// ------------------------------------------------------------------------------------------------
+constexpr int kGroupUndecided = -100;
+
+__device__ __forceinline__ int group8_find(const DevTree &T, bool valid, const V3 &p, int lane) {
+    const int sub = lane & 7;
+    int4 leaf = make_int4(-1, 0, -1, 0);
+    unsigned long long mm = 0ull;
+    float fx = 0.f, fy = 0.f, fz = 0.f;
+    bool serial = !valid;
+    if (valid) {
+        if (outside_root(p) || !(p.x == p.x && p.y == p.y && p.z == p.z) || !T.mask) {
+            serial = true;
+        } else {
+            int subcell;
+            leaf = locate_leaf(T, p, subcell);
+            if (leaf.z < 0) {
+                serial = true;  // empty or oversized leaf: no masks
+            } else {
+                mm = T.mask[(size_t)leaf.z * 64 + subcell];
+                const float qx = (float)p.x, qy = (float)p.y, qz = (float)p.z;
+                const float inv = rsqrtf(qx * qx + qy * qy + qz * qz);
+                fx = qx * inv, fy = qy * inv, fz = qz * inv;
+            }
+        }
+    }
+    unsigned long long hits = 0ull;  // entries whose triangle contains the projection (same in all lanes of a group)
+    // lane `sub` of the group takes the sub-th, (sub+8)-th, ... set bit of the mask: ceil(popcount / 8) rounds
+    unsigned long long mine = serial ? 0ull : mm;
+    for (int k = 0; k < sub; ++k) mine &= mine - 1ull;
+    while (__any(mine != 0ull)) {
+        bool hit = false;
+        int e = 0;
+        if (mine) {
+            e = __ffsll((long long)mine) - 1;
+            const float4 c = T.cone[leaf.y + e];
+            const float dt = fabsf(__builtin_fmaf(c.z, fz, __builtin_fmaf(c.y, fy, c.x * fx)));
+            if (dt >= c.w) {
+                V3 mp;
+                hit = inside_test(T.rec[T.leaf_tri[leaf.y + e]], p, mp);
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) mine &= mine - 1ull;  // my next bit is eight set bits further
+        }
+        const unsigned long long bal = __ballot(hit);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int ek = __shfl(e, (lane & ~7) | k, 64);
+            if ((bal >> ((lane & ~7) | k)) & 1ull) hits |= 1ull << ek;
+        }
+    }
+    int win = -1;
+    double bestd = 0.0;
+    unsigned long long rest = (!serial && __popcll(hits) >= 2) ? hits : 0ull;
+    while (__any(rest != 0ull)) {
+        const int e = rest ? __ffsll((long long)rest) - 1 : 0;
+        double d = 0.0;
+        if (rest && (e & 7) == sub) d = candidate_distance(T, T.leaf_tri[leaf.y + e], p);
+        d = __shfl(d, (lane & ~7) | (e & 7), 64);
+        if (rest) {
+            if (win < 0 || (d > -1.0 && d < bestd)) {
+                win = e;
+                bestd = d;
+            }
+            rest &= rest - 1ull;
+        }
+    }
+    if (serial) return kGroupUndecided;
+    if (__popcll(hits) == 1) return T.leaf_tri[leaf.y + __ffsll((long long)hits) - 1];
+    if (win >= 0) return T.leaf_tri[leaf.y + win];
+    return kGroupUndecided;
+}
+
 }  // namespace msm

@@ -61,11 +61,13 @@ __device__ __forceinline__ double dice_serial(int sim, int n, double percentile,
 
 // serial over the D dimensions in the reference's order; the target values are recomputed in the second pass
 // instead of being stored (3 loads + 5 flops each)
+// Nsrc > 0: sfeat / cfw are D x Nsrc (rows x Nsrc) row-major, as the ABI takes them; Nsrc == 0: vertex-major copies
+// (Nsrc x D, Nsrc x rows), where the D values of a vertex are contiguous.
 __device__ __forceinline__ double feature_vector_similarity(int sim, double percentile, const double *sfeat, const double *cfw, int cfw_rows, int Nsrc,
                                                             int sv, int D, const double *f0, const double *f1, const double *f2, double wa, double wb,
                                                             double wc) {
-    auto W = [&](int d) { return (cfw && cfw_rows >= d + 1) ? cfw[(size_t)d * Nsrc + sv] : 1.0; };
-    auto A = [&](int d) { return sfeat[(size_t)d * Nsrc + sv]; };
+    auto W = [&](int d) { return (cfw && cfw_rows >= d + 1) ? (Nsrc ? cfw[(size_t)d * Nsrc + sv] : cfw[(size_t)sv * cfw_rows + d]) : 1.0; };
+    auto A = [&](int d) { return Nsrc ? sfeat[(size_t)d * Nsrc + sv] : sfeat[(size_t)sv * D + d]; };
     if (sim == 4 || sim == 5) return dice_serial(sim, D, percentile, A, [&](int d) { return interp_feature(f0, f1, f2, d, wa, wb, wc); });
     if (sim == 2) {  // sparsesimkernel::corr, M/similarities.cpp:129-158
         double prod = 0.0, varA = 0.0, varB = 0.0, meanA = 0.0, meanB = 0.0, sum = 0.0;

@@ -85,54 +85,12 @@ struct SamplesArgs {
     int *status;
 };
 
-// locate the octree leaf of p (same decisions as find_closest_triangle) and the sub-cell of p inside the leaf's
-// box: the box is cut 4x4x4 and the three cut positions per axis are exact dyadics, so plain comparisons place p
-// in the same (closed) sub-cell the mask builder reasoned about.
-__device__ __forceinline__ int4 locate_leaf(const DevTree &T, const V3 &p, int &subcell) {
-    const int G = 1 << T.grid_depth;
-    const double h = 2 * kBounds / G;
-    const int ix = grid_axis(p.x, G, h), iy = grid_axis(p.y, G, h), iz = grid_axis(p.z, G, h);
-    int4 nd = T.node[T.grid[((size_t)ix * G + iy) * G + iz]];
-    double lx, ly, lz, size;
-    if (nd.x < 0) {  // a leaf at depth w <= grid_depth: its box is the depth-w cell above this grid cell
-        const int up = T.grid_depth - nd.w;
-        size = ldexp(2 * kBounds, -nd.w);  // 202 / 2^w, exact
-        lx = -kBounds + (ix >> up) * size;
-        ly = -kBounds + (iy >> up) * size;
-        lz = -kBounds + (iz >> up) * size;
-    } else {
-        lx = -kBounds + ix * h;
-        ly = -kBounds + iy * h;
-        lz = -kBounds + iz * h;
-        double hx = lx + h, hy = ly + h, hz = lz + h;
-        while (nd.x >= 0) {
-            const double mx = (lx + hx) / 2.0, my = (ly + hy) / 2.0, mz = (lz + hz) / 2.0;
-            const int cx = !(p.x < mx), cy = !(p.y < my), cz = !(p.z < mz);
-            if (cx) lx = mx; else hx = mx;
-            if (cy) ly = my; else hy = my;
-            if (cz) lz = mz; else hz = mz;
-            nd = T.node[nd.x + 4 * cx + 2 * cy + cz];
-        }
-        size = hx - lx;
-    }
-    const double q = size / 4;
-    const int sx = (p.x >= lx + q) + (p.x >= lx + 2 * q) + (p.x >= lx + 3 * q);
-    const int sy = (p.y >= ly + q) + (p.y >= ly + 2 * q) + (p.y >= ly + 3 * q);
-    const int sz = (p.z >= lz + q) + (p.z >= lz + 2 * q) + (p.z >= lz + 3 * q);
-    subcell = 16 * sx + 4 * sy + sz;
-    return nd;
-}
-
 // s / P for 0 <= s < 2^22, P > 0, with a float reciprocal and an exact correction step
 __device__ __forceinline__ int fast_div(int s, int P, float invP) {
     int q = (int)((float)s * invP);
     if (q * P > s) --q;
     else if ((q + 1) * P <= s) ++q;
     return q;
-}
-
-__device__ __forceinline__ bool outside_root(const V3 &p) {
-    return p.x < -kBounds || p.x > kBounds || p.y < -kBounds || p.y > kBounds || p.z < -kBounds || p.z > kBounds;
 }
 
 // get_target_data's tail (:361-375): barycentric_interpolation on the raw (un-projected) point
@@ -604,10 +562,6 @@ __global__ __launch_bounds__(256) void k_unary_fixup(SamplesArgs a) {
         const bool valid = j < n;
         V3 p = mk(0.0, 0.0, 0.0);
         size_t g = 0;
-        int4 leaf = make_int4(-1, 0, -1, 0);
-        unsigned long long mm = 0ull;
-        float fx = 0.f, fy = 0.f, fz = 0.f;
-        bool serial = false;  // this sample needs the complete search
         if (valid) {
             int seg = 0;
 #pragma unroll
@@ -620,73 +574,10 @@ __global__ __launch_bounds__(256) void k_unary_fixup(SamplesArgs a) {
             const int sv = a.pidx[beg + i];
             p = rotate(a.rnl + ((size_t)node * a.L + l) * 9, mk(a.src[sv], a.src[a.Nsrc + sv], a.src[2 * a.Nsrc + sv]));
             g = (size_t)a.L * beg + s;
-            if (outside_root(p) || !(p.x == p.x && p.y == p.y && p.z == p.z)) {
-                serial = true;  // the complete search reports it
-            } else {
-                int subcell;
-                leaf = locate_leaf(a.tree, p, subcell);
-                if (leaf.z < 0) {
-                    serial = true;  // empty or oversized leaf: no masks
-                } else {
-                    mm = a.tree.mask[(size_t)leaf.z * 64 + subcell];
-                    const float qx = (float)p.x, qy = (float)p.y, qz = (float)p.z;
-                    const float inv = rsqrtf(qx * qx + qy * qy + qz * qz);
-                    fx = qx * inv, fy = qy * inv, fz = qz * inv;
-                }
-            }
         }
-        unsigned long long hits = 0ull;  // entries whose triangle contains the projection (same in all lanes of a group)
-        // lane `sub` of the group takes the sub-th, (sub+8)-th, ... set bit of the mask: ceil(popcount / 8) rounds
-        unsigned long long mine = (valid && !serial) ? mm : 0ull;
-        for (int k = 0; k < sub; ++k) mine &= mine - 1ull;
-        while (__any(mine != 0ull)) {
-            bool hit = false;
-            int e = 0;
-            if (mine) {
-                e = __ffsll((long long)mine) - 1;
-                const float4 c = a.tree.cone[leaf.y + e];
-                const float dt = fabsf(__builtin_fmaf(c.z, fz, __builtin_fmaf(c.y, fy, c.x * fx)));
-                if (dt >= c.w) {
-                    V3 mp;
-                    hit = inside_test(a.tree.rec[a.tree.leaf_tri[leaf.y + e]], p, mp);
-                }
-#pragma unroll
-                for (int k = 0; k < 8; ++k) mine &= mine - 1ull;  // my next bit is eight set bits further
-            }
-            // gather the group's hits: each lane contributes one entry index
-            const unsigned long long bal = __ballot(hit);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int ek = __shfl(e, (lane & ~7) | k, 64);
-                if ((bal >> ((lane & ~7) | k)) & 1ull) hits |= 1ull << ek;
-            }
-        }
-        // Several containing triangles (the point sits in the -1e-8 band of an edge): the reference keeps the first and
-        // replaces it by a later one only if that one's dist_to_point is strictly smaller (R/octree.cpp:172-178).
-        // The owner lane of each hit evaluates its distance, the group follows the hits in entry order.
-        int win = -1;
-        {
-            double bestd = 0.0;
-            unsigned long long rest = (valid && !serial && __popcll(hits) >= 2) ? hits : 0ull;
-            while (__any(rest != 0ull)) {
-                const int e = rest ? __ffsll((long long)rest) - 1 : 0;
-                double d = 0.0;
-                if (rest && (e & 7) == sub) d = candidate_distance(a.tree, a.tree.leaf_tri[leaf.y + e], p);
-                d = __shfl(d, (lane & ~7) | (e & 7), 64);
-                if (rest) {
-                    if (win < 0 || (d > -1.0 && d < bestd)) {
-                        win = e;
-                        bestd = d;
-                    }
-                    rest &= rest - 1ull;
-                }
-            }
-        }
+        const int found = group8_find(a.tree, valid, p, lane);
         if (valid && sub == 0) {
-            int t;
-            if (!serial && __popcll(hits) == 1) t = a.tree.leaf_tri[leaf.y + __ffsll((long long)hits) - 1];
-            else if (win >= 0) t = a.tree.leaf_tri[leaf.y + win];
-            else t = find_closest_triangle(a.tree, p);  // nothing in the leaf, no masks, outside the root: the complete search
+            const int t = found == kGroupUndecided ? find_closest_triangle(a.tree, p) : found;  // nothing in the leaf, no masks, outside the root
             if (t < 0) emit_failure(a, g, t);
             else emit_sample(a, g, p, t);
         }
