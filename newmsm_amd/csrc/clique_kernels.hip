@@ -326,8 +326,19 @@ __device__ __forceinline__ OctetGeometry octet_geometry(const CliqueArgs &a, con
 
 constexpr int kOctLanes = 4;
 
+// workgroup -> first evaluation: the workgroups of one XCD (blockIdx % 8, round-robin dispatch) take a contiguous range
+// of evaluations, i.e. of control-grid triangles, so that an XCD's L2 holds one region of the target and of the data
+__device__ __forceinline__ int xcd_block(int per_block_evals, int total_evals) {
+    const int nblocks = (total_evals + per_block_evals - 1) / per_block_evals;
+    const int per = (nblocks + 7) >> 3;
+    const int b = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    return b < nblocks ? b : -1;
+}
+
 __global__ __launch_bounds__(256) void k_ho_octets_sample(CliqueArgs a, const int *__restrict__ labeling, int label) {
-    const int e = blockIdx.x * (256 / kOctLanes) + threadIdx.x / kOctLanes, sub = threadIdx.x % kOctLanes;
+    const int blk = xcd_block(256 / kOctLanes, 8 * a.T);
+    if (blk < 0) return;
+    const int e = blk * (256 / kOctLanes) + threadIdx.x / kOctLanes, sub = threadIdx.x % kOctLanes;
     if (e >= 8 * a.T) return;
     const OctetEval q = octet_eval(a, labeling, label, e);
     const OctetGeometry g = octet_geometry(a, q);
@@ -339,6 +350,48 @@ __global__ __launch_bounds__(256) void k_ho_octets_sample(CliqueArgs a, const in
         const int tt = ray_find(a.tree, tmp);
         if (tt >= 0) a.ho_vals[q.offset + i] = ho_value_on(a, sv, tmp, tt);
         else a.ho_pending[atomicAdd(a.ho_count, 1u)] = ((unsigned)e << 10) | (unsigned)i;
+    }
+}
+
+// HO multivariate, D <= 64, SSD / correlation: a wavefront per evaluation, eight lanes per bin point.  The lanes of a
+// group share the point (position and ray-table lookup are computed redundantly, they are cheap) and split its D
+// dimensions (similarity_device.hpp: feature_vector_similarity8); 219 us -> see DESIGN.md with a lane per point.
+__global__ __launch_bounds__(256) void k_ho_octets_sample_mv8(CliqueArgs a, const int *__restrict__ labeling, int label) {
+    const int blk = xcd_block(4, 8 * a.T);
+    if (blk < 0) return;
+    const int e = blk * 4 + (threadIdx.x >> 6);
+    if (e >= 8 * a.T) return;  // wavefront-uniform
+    const int lane = threadIdx.x & 63, grp = lane >> 3, j = lane & 7;
+    const OctetEval q = octet_eval(a, labeling, label, e);
+    const OctetGeometry g = octet_geometry(a, q);
+    if (g.folded) return;
+    const int beg = a.bin_ptr[q.t], n = a.bin_ptr[q.t + 1] - beg;
+    const int D = a.D;
+    for (int i0 = 0; i0 < n; i0 += 8) {  // wavefront-uniform: the group sums need all lanes
+        const int i = i0 + grp;
+        const bool have = i < n;
+        int sv = 0, tt = -1;
+        V3 tmp = mk(0.0, 0.0, 0.0);
+        if (have) {
+            sv = a.bin_idx[beg + i];
+            tmp = ho_point_position(a, sv, g.cp0, g.cp1, g.cp2, g.r0, g.r1, g.r2);
+            tt = ray_find(a.tree, tmp);
+        }
+        const bool go = have && tt >= 0;
+        const double *f0 = a.tfeat, *f1 = a.tfeat, *f2 = a.tfeat, *sa = a.sfeat_vm, *cw = nullptr;
+        double wa = 0, wb = 0, wc = 0;
+        if (go) {
+            const TriRec &r = a.tree.rec[tt];
+            area_weights(rec_v0(r), rec_v1(r), rec_v2(r), tmp, wa, wb, wc);
+            f0 = a.tfeat + (size_t)r.id[0] * D, f1 = a.tfeat + (size_t)r.id[1] * D, f2 = a.tfeat + (size_t)r.id[2] * D;
+            sa = a.sfeat_vm + (size_t)sv * D;
+            cw = a.cfw_vm ? a.cfw_vm + (size_t)sv * a.cfw_rows : nullptr;
+        }
+        const double c = feature_vector_similarity8(a.simmeasure, go, j, D, sa, cw, a.cfw_rows, f0, f1, f2, wa, wb, wc);
+        if (j == 0 && have) {
+            if (go) a.ho_vals[q.offset + i] = c;
+            else a.ho_pending[atomicAdd(a.ho_count, 1u)] = ((unsigned)e << 10) | (unsigned)i;
+        }
     }
 }
 
@@ -376,8 +429,10 @@ __global__ __launch_bounds__(256) void k_ho_octets_fix(CliqueArgs a, const int *
 }
 
 __global__ __launch_bounds__(128) void k_ho_octets_reduce(CliqueArgs a, const int *__restrict__ labeling, int label, double *__restrict__ out) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e == 0) *a.ho_count = 0u;  // the pending list has been consumed: ready for the next move
+    if (blockIdx.x == 0 && threadIdx.x == 0) *a.ho_count = 0u;  // the pending list has been consumed: ready for the next move
+    const int blk = xcd_block(128, 8 * a.T);
+    if (blk < 0) return;
+    const int e = blk * 128 + threadIdx.x;
     if (e >= 8 * a.T) return;
     const OctetEval q = octet_eval(a, labeling, label, e);
     out[e] = triplet_cost<false>(a, q.t, q.la, q.lb, q.lc, a.ho_vals + q.offset);
@@ -448,11 +503,14 @@ int launch_triplet_octets(msm_ctx *ctx, const CliqueArgs &a, const int *labeling
     if (a.T <= 0) return MSM_OK;
     if (is_ho(a) && a.ho_vals && a.tree.simple && a.tree.ray_G > 0 && a.rmode != 4 && a.rmode != 5) {
         const int per = 256 / kOctLanes;
-        hipLaunchKernelGGL(k_ho_octets_sample, dim3((8 * a.T + per - 1) / per), dim3(256), 0, ctx->stream, a, labeling, label);
+        const bool mv8 = a.kind == MSM_COST_HO_MULTIVARIATE && a.sfeat_vm && a.D >= 12 && a.D <= kMvLanes * kMvKeep && (a.simmeasure == 1 || a.simmeasure == 2);
+        auto grid8 = [](int evals, int per_block) { return dim3((unsigned)(8 * (((evals + per_block - 1) / per_block + 7) / 8))); };  // 8 x blocks per XCD
+        if (mv8) hipLaunchKernelGGL(k_ho_octets_sample_mv8, grid8(8 * a.T, 4), dim3(256), 0, ctx->stream, a, labeling, label);
+        else hipLaunchKernelGGL(k_ho_octets_sample, grid8(8 * a.T, per), dim3(256), 0, ctx->stream, a, labeling, label);
         MSM_HIP(hipGetLastError());
         hipLaunchKernelGGL(k_ho_octets_fix, dim3(64), dim3(256), 0, ctx->stream, a, labeling, label);
         MSM_HIP(hipGetLastError());
-        hipLaunchKernelGGL(k_ho_octets_reduce, dim3((8 * a.T + 127) / 128), dim3(128), 0, ctx->stream, a, labeling, label, out);
+        hipLaunchKernelGGL(k_ho_octets_reduce, grid8(8 * a.T, 128), dim3(128), 0, ctx->stream, a, labeling, label, out);
     } else if (is_ho(a))
         MSM_HO_LAUNCH(k_triplet_octets_ho, (size_t)8 * a.T, a, labeling, label, out);
     else

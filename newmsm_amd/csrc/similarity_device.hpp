@@ -102,4 +102,73 @@ __device__ __forceinline__ double feature_vector_similarity(int sim, double perc
     return sqrt(prod) / D;
 }
 
+// ---- the same feature-vector similarity (SSD / correlation, D <= 64) by the eight lanes of a group ---------------
+// Lane j (0..7) owns the dimensions j, j + 8, ...: the group reads the three target rows and the moving row
+// (vertex-major copies) as contiguous 64-byte pieces, and the sums over the dimensions are 8-lane DPP reductions.
+// All 64 lanes of the wavefront must call this together; groups with go == false ride along (their result is unused).
+constexpr int kMvLanes = 8;
+constexpr int kMvKeep = 8;  // dimensions per lane: D <= 64
+
+__device__ __forceinline__ double mv_group_sum(double v) {
+#pragma unroll
+    for (int off = kMvLanes / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, kMvLanes);
+    return v;
+}
+
+__device__ __forceinline__ double feature_vector_similarity8(int sim, bool go, int j, int D, const double *sa /*moving row, D values*/,
+                                                             const double *cw /*weight row or nullptr*/, int cfw_rows, const double *f0, const double *f1,
+                                                             const double *f2, double wa, double wb, double wc) {
+    double A[kMvKeep], B[kMvKeep], W[kMvKeep];
+#pragma unroll
+    for (int k = 0; k < kMvKeep; ++k) {
+        const int d = j + kMvLanes * k;
+        const bool in = go && d < D;
+        A[k] = in ? sa[d] : 0.0;
+        B[k] = in ? wa * f0[d] + wb * f1[d] + wc * f2[d] : 0.0;  // barycentric_interpolation per dimension
+        W[k] = !in ? 0.0 : ((cw && cfw_rows >= d + 1) ? cw[d] : 1.0);
+    }
+    if (sim == 2) {  // sparsesimkernel::corr over the D dimensions, M/similarities.cpp:129-158
+        double sum = 0, ma = 0, mb = 0;
+#pragma unroll
+        for (int k = 0; k < kMvKeep; ++k) {
+            sum += W[k];
+            ma += W[k] * A[k];
+            mb += W[k] * B[k];
+        }
+        sum = mv_group_sum(sum);
+        ma = mv_group_sum(ma);
+        mb = mv_group_sum(mb);
+        if (sum > 0.0) {
+            ma /= sum;
+            mb /= sum;
+        }
+        double pr = 0, va = 0, vb = 0;
+#pragma unroll
+        for (int k = 0; k < kMvKeep; ++k) {
+            const double da = A[k] - ma, db = B[k] - mb;
+            pr += W[k] * da * db;
+            va += W[k] * da * da;
+            vb += W[k] * db * db;
+        }
+        pr = mv_group_sum(pr);
+        va = mv_group_sum(va);
+        vb = mv_group_sum(vb);
+        if (sum > 0.0) {
+            pr /= sum;
+            va /= sum;
+            vb /= sum;
+        }
+        const double rr = (va == 0.0 || vb == 0.0) ? 0.0 : pr / (sqrt(va) * sqrt(vb));
+        return 1 - (1 + rr) * 0.5;
+    }
+    double pr = 0;  // sparsesimkernel::SSD, :179-188
+#pragma unroll
+    for (int k = 0; k < kMvKeep; ++k) {
+        const double df = A[k] - B[k];
+        pr += W[k] * df * df;
+    }
+    pr = mv_group_sum(pr);
+    return sqrt(pr) / D;
+}
+
 }  // namespace msm

@@ -892,15 +892,6 @@ __global__ __launch_bounds__(256) void k_unary_reduce_features(ReduceMvArgs a) {
 // group reads the three target rows (vertex-major) and the moving row (a vertex-major copy) as contiguous 64-byte
 // pieces, and the sums over the dimensions are 8-lane DPP reductions.  One wavefront per label, eight points at a time.
 // ------------------------------------------------------------------------------------------------
-constexpr int kMvLanes = 8;
-constexpr int kMvKeep = 8;  // dimensions per lane: D <= 64
-
-__device__ __forceinline__ double mv_group_sum(double v) {
-#pragma unroll
-    for (int off = kMvLanes / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, kMvLanes);
-    return v;
-}
-
 struct ReduceMv8Args {
     int N, L, Nsrc, D;
     const double *tfeat;    // V x D vertex-major
@@ -941,67 +932,14 @@ __global__ __launch_bounds__(256) void k_unary_reduce_mv8(ReduceMv8Args a) {
             }
             if (have && t < 0) bad = true;
             const bool go = have && t >= 0;
-            double A[kMvKeep], B[kMvKeep], W[kMvKeep];
+            const double *f0 = a.tfeat, *f1 = a.tfeat, *f2 = a.tfeat, *sa = a.sfeat_vm, *cw = nullptr;
             if (go) {
                 const TriRec &r = a.rec[t];
-                const double *f0 = a.tfeat + (size_t)r.id[0] * D, *f1 = a.tfeat + (size_t)r.id[1] * D, *f2 = a.tfeat + (size_t)r.id[2] * D;
-                const double *sa = a.sfeat_vm + (size_t)sv * D;
-#pragma unroll
-                for (int k = 0; k < kMvKeep; ++k) {
-                    const int d = j + kMvLanes * k;
-                    const bool in = d < D;
-                    A[k] = in ? sa[d] : 0.0;
-                    B[k] = in ? wa * f0[d] + wb * f1[d] + wc * f2[d] : 0.0;  // barycentric_interpolation per dimension
-                    W[k] = !in ? 0.0 : ((a.cfw_vm && a.cfw_rows >= d + 1) ? a.cfw_vm[(size_t)sv * a.cfw_rows + d] : 1.0);
-                }
-            } else {
-#pragma unroll
-                for (int k = 0; k < kMvKeep; ++k) A[k] = B[k] = W[k] = 0.0;
+                f0 = a.tfeat + (size_t)r.id[0] * D, f1 = a.tfeat + (size_t)r.id[1] * D, f2 = a.tfeat + (size_t)r.id[2] * D;
+                sa = a.sfeat_vm + (size_t)sv * D;
+                cw = a.cfw_vm ? a.cfw_vm + (size_t)sv * a.cfw_rows : nullptr;
             }
-            double c;
-            if (a.simmeasure == 2) {  // sparsesimkernel::corr over the D dimensions, M/similarities.cpp:129-158
-                double sum = 0, ma = 0, mb = 0;
-#pragma unroll
-                for (int k = 0; k < kMvKeep; ++k) {
-                    sum += W[k];
-                    ma += W[k] * A[k];
-                    mb += W[k] * B[k];
-                }
-                sum = mv_group_sum(sum);
-                ma = mv_group_sum(ma);
-                mb = mv_group_sum(mb);
-                if (sum > 0.0) {
-                    ma /= sum;
-                    mb /= sum;
-                }
-                double pr = 0, va = 0, vb = 0;
-#pragma unroll
-                for (int k = 0; k < kMvKeep; ++k) {
-                    const double da = A[k] - ma, db = B[k] - mb;
-                    pr += W[k] * da * db;
-                    va += W[k] * da * da;
-                    vb += W[k] * db * db;
-                }
-                pr = mv_group_sum(pr);
-                va = mv_group_sum(va);
-                vb = mv_group_sum(vb);
-                if (sum > 0.0) {
-                    pr /= sum;
-                    va /= sum;
-                    vb /= sum;
-                }
-                const double rr = (va == 0.0 || vb == 0.0) ? 0.0 : pr / (sqrt(va) * sqrt(vb));
-                c = 1 - (1 + rr) * 0.5;
-            } else {  // sparsesimkernel::SSD, :179-188
-                double pr = 0;
-#pragma unroll
-                for (int k = 0; k < kMvKeep; ++k) {
-                    const double df = A[k] - B[k];
-                    pr += W[k] * df * df;
-                }
-                pr = mv_group_sum(pr);
-                c = sqrt(pr) / D;
-            }
+            const double c = feature_vector_similarity8(a.simmeasure, go, j, D, sa, cw, a.cfw_rows, f0, f1, f2, wa, wb, wc);
             if (go && j == 0) acc += c;
         }
         // the groups' partial sums: one value per group in its lane 0
