@@ -225,10 +225,11 @@ __device__ double pairwise_cost(const CliqueArgs &a, int pair, int la, int lb) {
 
 }  // namespace
 
+template <bool kAnat>
 __global__ __launch_bounds__(128) void k_triplet_batch(CliqueArgs a, const int *__restrict__ qt, const int *__restrict__ qa,
                                                         const int *__restrict__ qb, const int *__restrict__ qc, int n, double *__restrict__ out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = triplet_cost<true>(a, qt[i], qa[i], qb[i], qc[i], nullptr);
+    if (i < n) out[i] = triplet_cost<kAnat>(a, qt[i], qa[i], qb[i], qc[i], nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -439,6 +440,7 @@ __global__ __launch_bounds__(128) void k_ho_octets_reduce(CliqueArgs a, const in
 }
 
 // the 8 costs per triplet of one fusion move, I/Fusion/Fusion.h:181-196: bit order (A,B,C), 0 = current label
+template <bool kAnat>
 __global__ __launch_bounds__(128) void k_triplet_octets(CliqueArgs a, const int *__restrict__ labeling, int label, double *__restrict__ out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= 8 * a.T) return;
@@ -446,7 +448,7 @@ __global__ __launch_bounds__(128) void k_triplet_octets(CliqueArgs a, const int 
     const int la = (k & 4) ? label : labeling[a.triplets[3 * t]];
     const int lb = (k & 2) ? label : labeling[a.triplets[3 * t + 1]];
     const int lc = (k & 1) ? label : labeling[a.triplets[3 * t + 2]];
-    out[i] = triplet_cost<true>(a, t, la, lb, lc, nullptr);
+    out[i] = triplet_cost<kAnat>(a, t, la, lb, lc, nullptr);
 }
 
 __global__ __launch_bounds__(256) void k_pairwise_batch(CliqueArgs a, const int *__restrict__ qp, const int *__restrict__ qa,
@@ -494,8 +496,10 @@ int launch_triplet_batch(msm_ctx *ctx, const CliqueArgs &a, const int *qt, const
     if (n <= 0) return MSM_OK;
     if (is_ho(a))
         MSM_HO_LAUNCH(k_triplet_batch_ho, (size_t)n, a, qt, qa, qb, qc, n, out);
-    else
-        hipLaunchKernelGGL(k_triplet_batch, dim3((n + 127) / 128), dim3(128), 0, ctx->stream, a, qt, qa, qb, qc, n, out);
+    else {
+        if (a.rmode == 4 || a.rmode == 5) hipLaunchKernelGGL(k_triplet_batch<true>, dim3((n + 127) / 128), dim3(128), 0, ctx->stream, a, qt, qa, qb, qc, n, out);
+        else hipLaunchKernelGGL(k_triplet_batch<false>, dim3((n + 127) / 128), dim3(128), 0, ctx->stream, a, qt, qa, qb, qc, n, out);
+    }
     MSM_HIP(hipGetLastError());
     return MSM_OK;
 }
@@ -513,8 +517,10 @@ int launch_triplet_octets(msm_ctx *ctx, const CliqueArgs &a, const int *labeling
         hipLaunchKernelGGL(k_ho_octets_reduce, grid8(8 * a.T, 128), dim3(128), 0, ctx->stream, a, labeling, label, out);
     } else if (is_ho(a))
         MSM_HO_LAUNCH(k_triplet_octets_ho, (size_t)8 * a.T, a, labeling, label, out);
-    else
-        hipLaunchKernelGGL(k_triplet_octets, dim3((8 * a.T + 127) / 128), dim3(128), 0, ctx->stream, a, labeling, label, out);
+    else {
+        if (a.rmode == 4 || a.rmode == 5) hipLaunchKernelGGL(k_triplet_octets<true>, dim3((8 * a.T + 127) / 128), dim3(128), 0, ctx->stream, a, labeling, label, out);
+        else hipLaunchKernelGGL(k_triplet_octets<false>, dim3((8 * a.T + 127) / 128), dim3(128), 0, ctx->stream, a, labeling, label, out);
+    }
     MSM_HIP(hipGetLastError());
     return MSM_OK;
 }
@@ -525,13 +531,14 @@ int launch_pairwise_batch(msm_ctx *ctx, const CliqueArgs &a, const int *qp, cons
     return MSM_OK;
 }
 // computeTripletCosts, M/DiscreteCostFunction.cpp:245-253: tcosts[t][a][b][c] for the triplets t0 <= t < t1
+template <bool kAnat>
 __global__ __launch_bounds__(128) void k_triplet_table(CliqueArgs a, int t0, int t1, double *__restrict__ out) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t L = (size_t)a.L, per = L * L * L;
     if (i >= (size_t)(t1 - t0) * per) return;
     const int t = t0 + (int)(i / per);
     const size_t r = i % per;
-    out[i] = triplet_cost<true>(a, t, (int)(r / (L * L)), (int)((r / L) % L), (int)(r % L), nullptr);
+    out[i] = triplet_cost<kAnat>(a, t, (int)(r / (L * L)), (int)((r / L) % L), (int)(r % L), nullptr);
 }
 
 int launch_triplet_table(msm_ctx *ctx, const CliqueArgs &a, int t0, int t1, double *out) {
@@ -540,7 +547,8 @@ int launch_triplet_table(msm_ctx *ctx, const CliqueArgs &a, int t0, int t1, doub
     if (is_ho(a)) {
         MSM_HO_LAUNCH(k_triplet_table_ho, total, a, t0, t1, out);
     } else {
-        hipLaunchKernelGGL(k_triplet_table, dim3((unsigned)((total + 127) / 128)), dim3(128), 0, ctx->stream, a, t0, t1, out);
+        if (a.rmode == 4 || a.rmode == 5) hipLaunchKernelGGL(k_triplet_table<true>, dim3((unsigned)((total + 127) / 128)), dim3(128), 0, ctx->stream, a, t0, t1, out);
+        else hipLaunchKernelGGL(k_triplet_table<false>, dim3((unsigned)((total + 127) / 128)), dim3(128), 0, ctx->stream, a, t0, t1, out);
     }
     MSM_HIP(hipGetLastError());
     return MSM_OK;
