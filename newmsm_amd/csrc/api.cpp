@@ -10,6 +10,21 @@ using namespace msm;
 
 namespace msm {
 
+int ctx_io_pinned(msm_ctx *ctx, size_t bytes, void **out) {
+    if (bytes > ctx->io_cap || !ctx->io_pin) {
+        MSM_HIP(hipStreamSynchronize(ctx->stream));
+        if (ctx->io_pin) (void)hipHostFree(ctx->io_pin);
+        ctx->io_pin = nullptr;
+        ctx->io_cap = bytes + bytes / 4 + 4096;
+        if (hipHostMalloc(&ctx->io_pin, ctx->io_cap) != hipSuccess) {
+            ctx->io_cap = 0;
+            return fail(MSM_ERR_HIP, "pinned host allocation of %zu bytes failed", bytes);
+        }
+    }
+    *out = ctx->io_pin;
+    return MSM_OK;
+}
+
 int check_status(msm_ctx *ctx, const char *what) {
     MSM_HIP(hipMemcpyAsync(ctx->h_status, ctx->d_status, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     MSM_HIP(hipStreamSynchronize(ctx->stream));
@@ -63,6 +78,7 @@ static int upload_tree(msm_mesh *m) {
     MSM_HIP(hipStreamSynchronize(ctx->stream));  // an earlier upload may still read the staging buffer
     if (total > ctx->stage_cap) {
         if (ctx->stage) (void)hipHostFree(ctx->stage);
+    if (ctx->io_pin) (void)hipHostFree(ctx->io_pin);
         ctx->stage = nullptr;
         ctx->stage_cap = total + total / 4;
         MSM_HIP(hipHostMalloc(&ctx->stage, ctx->stage_cap));
@@ -418,6 +434,7 @@ void msm_ctx_destroy(msm_ctx *ctx) {
     for (void *b : ctx->q_buf)
         if (b) (void)hipFree(b);
     if (ctx->stage) (void)hipHostFree(ctx->stage);
+    if (ctx->io_pin) (void)hipHostFree(ctx->io_pin);
     if (ctx->d_status) (void)hipFree(ctx->d_status);
     if (ctx->h_status) (void)hipHostFree(ctx->h_status);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);

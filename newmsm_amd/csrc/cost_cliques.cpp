@@ -1,6 +1,7 @@
 // cost_cliques.cpp -- C ABI of the pairwise / triplet clique costs and of evaluateTotalCostSum
 // (include/msmhip.h).  Kernels: clique_kernels.hip.
 #include <algorithm>
+#include <cstring>
 
 #include "cost_internal.hpp"
 
@@ -198,13 +199,23 @@ int msm_cost_triplet_octets(msm_cost *c, const int32_t *labeling, int32_t label,
     for (int i = 0; i < a.N; ++i)
         if (labeling[i] < 0 || labeling[i] >= a.L) return fail(MSM_ERR_INVALID, "labeling[%d] out of range", i);
     msm_ctx *ctx = c->ctx;
-    MSM_HIP(c->d_labeling.upload(labeling, a.N, ctx->stream));
+    // this is the call of the optimisers' inner loop (once per label step): labeling and energies travel through pinned
+    // memory (pageable copies of these sizes cost more than the kernels)
+    const size_t in_bytes = sizeof(int32_t) * (size_t)a.N, out_bytes = sizeof(double) * 8 * (size_t)a.T, in_pad = (in_bytes + 255) & ~(size_t)255;
+    void *pin = nullptr;
+    st = ctx_io_pinned(ctx, in_pad + out_bytes, &pin);
+    if (st) return st;
+    std::memcpy(pin, labeling, in_bytes);
+    MSM_HIP(c->d_labeling.ensure(a.N));
+    MSM_HIP(hipMemcpyAsync(c->d_labeling.p, pin, in_bytes, hipMemcpyHostToDevice, ctx->stream));
     MSM_HIP(c->d_clique_out.ensure((size_t)8 * a.T));
     st = launch_triplet_octets(ctx, a, c->d_labeling.p, label, c->d_clique_out.p);
     if (st) return st;
-    MSM_HIP(c->d_clique_out.download(E, (size_t)8 * a.T, ctx->stream));
+    MSM_HIP(hipMemcpyAsync((char *)pin + in_pad, c->d_clique_out.p, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
     c->counters[2] += (int64_t)8 * a.T;
-    return check_status(ctx, "computeTripletCost");
+    st = check_status(ctx, "computeTripletCost");  // synchronises
+    std::memcpy(E, (char *)pin + in_pad, out_bytes);
+    return st;
 }
 
 int msm_cost_pairwise_batch(msm_cost *c, const int32_t *pair, const int32_t *la, const int32_t *lb, int32_t n, double *out) {

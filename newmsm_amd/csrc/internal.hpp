@@ -119,6 +119,9 @@ struct msm_ctx {
     // pinned staging for the search-structure uploads (pageable copies of the 16 MB of an ico6 tree ran at < 1 GB/s)
     void *stage = nullptr;
     size_t stage_cap = 0;
+    // small pinned buffers for the per-label-step calls (labeling in, fusion-move energies out)
+    void *io_pin = nullptr;
+    size_t io_cap = 0;
 };
 
 struct msm_mesh {
@@ -172,4 +175,5 @@ int ensure_masks(msm_mesh *m);  // + the per-leaf sub-cell masks the cost kernel
 int ensure_rays(msm_mesh *m);   // + the ray table of a simple surface (unary table kernels)
 DevTree dev_tree(const msm_mesh *m);
 int check_status(msm_ctx *ctx, const char *what);  // sync + read kernel status
+int ctx_io_pinned(msm_ctx *ctx, size_t bytes, void **out);  // grow-only pinned scratch for small per-call transfers
 }  // namespace msm
