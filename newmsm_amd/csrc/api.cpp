@@ -78,7 +78,6 @@ static int upload_tree(msm_mesh *m) {
     MSM_HIP(hipStreamSynchronize(ctx->stream));  // an earlier upload may still read the staging buffer
     if (total > ctx->stage_cap) {
         if (ctx->stage) (void)hipHostFree(ctx->stage);
-    if (ctx->io_pin) (void)hipHostFree(ctx->io_pin);
         ctx->stage = nullptr;
         ctx->stage_cap = total + total / 4;
         MSM_HIP(hipHostMalloc(&ctx->stage, ctx->stage_cap));
@@ -235,17 +234,30 @@ int query_host(msm_mesh *target, const double *q, int N, int *tri_id, int *vid, 
     if (st) return st;
     double *dq = nullptr, *dw = nullptr;
     int *dt = nullptr, *dv = nullptr;
-    MSM_HIP(ctx_scratch(ctx, 0, sizeof(double) * 3 * (size_t)N, (void **)&dq));
-    MSM_HIP(hipMemcpyAsync(dq, q, sizeof(double) * 3 * (size_t)N, hipMemcpyHostToDevice, ctx->stream));
-    if (tri_id) MSM_HIP(ctx_scratch(ctx, 1, sizeof(int) * (size_t)N, (void **)&dt));
-    if (vid) MSM_HIP(ctx_scratch(ctx, 2, sizeof(int) * 3 * (size_t)N, (void **)&dv));
-    if (w) MSM_HIP(ctx_scratch(ctx, 3, sizeof(double) * 3 * (size_t)N, (void **)&dw));
+    // host arrays travel through one pinned block: [queries | tri ids | vertex ids | weights]
+    const size_t bq = sizeof(double) * 3 * (size_t)N, bt = tri_id ? sizeof(int) * (size_t)N : 0, bv = vid ? sizeof(int) * 3 * (size_t)N : 0,
+                 bw = w ? sizeof(double) * 3 * (size_t)N : 0;
+    auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    void *pin = nullptr;
+    st = ctx_io_pinned(ctx, pad(bq) + pad(bt) + pad(bv) + pad(bw), &pin);
+    if (st) return st;
+    char *pq = (char *)pin, *pt = pq + pad(bq), *pv = pt + pad(bt), *pw = pv + pad(bv);
+    std::memcpy(pq, q, bq);
+    MSM_HIP(ctx_scratch(ctx, 0, bq, (void **)&dq));
+    MSM_HIP(hipMemcpyAsync(dq, pq, bq, hipMemcpyHostToDevice, ctx->stream));
+    if (tri_id) MSM_HIP(ctx_scratch(ctx, 1, bt, (void **)&dt));
+    if (vid) MSM_HIP(ctx_scratch(ctx, 2, bv, (void **)&dv));
+    if (w) MSM_HIP(ctx_scratch(ctx, 3, bw, (void **)&dw));
     st = launch_query(ctx, dev_tree(target), dq, N, dt, dv, dw, mode);
     if (st) return st;
-    if (tri_id) MSM_HIP(hipMemcpyAsync(tri_id, dt, sizeof(int) * (size_t)N, hipMemcpyDeviceToHost, ctx->stream));
-    if (vid) MSM_HIP(hipMemcpyAsync(vid, dv, sizeof(int) * 3 * (size_t)N, hipMemcpyDeviceToHost, ctx->stream));
-    if (w) MSM_HIP(hipMemcpyAsync(w, dw, sizeof(double) * 3 * (size_t)N, hipMemcpyDeviceToHost, ctx->stream));
-    return check_status(ctx, what);
+    if (tri_id) MSM_HIP(hipMemcpyAsync(pt, dt, bt, hipMemcpyDeviceToHost, ctx->stream));
+    if (vid) MSM_HIP(hipMemcpyAsync(pv, dv, bv, hipMemcpyDeviceToHost, ctx->stream));
+    if (w) MSM_HIP(hipMemcpyAsync(pw, dw, bw, hipMemcpyDeviceToHost, ctx->stream));
+    st = check_status(ctx, what);  // synchronises; the outputs are filled in either way (failed queries carry their code)
+    if (tri_id) std::memcpy(tri_id, pt, bt);
+    if (vid) std::memcpy(vid, pv, bv);
+    if (w) std::memcpy(w, pw, bw);
+    return st;
 }
 
 // compute_vertex_area for every vertex (R/mesh.cpp:1275-1283): mean area of the adjacent faces, in trID order

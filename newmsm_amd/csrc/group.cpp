@@ -96,8 +96,14 @@ int subject_patches(msm_group *g, int s) {
         if (attempt == 2) return fail(MSM_ERR_CAPACITY, "group patch capacity");
         cap = mx + 16;
     }
-    std::vector<uint32_t> slots((size_t)M * cap);
-    MSM_HIP(d_slots.download(slots.data(), slots.size(), ctx->stream));
+    // 50 MB at ico6 / 19 labels: through pinned memory (a pageable copy of this size took most of this function's time)
+    void *pin = nullptr;
+    {
+        int st = ctx_io_pinned(ctx, sizeof(uint32_t) * (size_t)M * cap, &pin);
+        if (st) return st;
+    }
+    const uint32_t *slots = static_cast<const uint32_t *>(pin);
+    MSM_HIP(hipMemcpyAsync(pin, d_slots.p, sizeof(uint32_t) * (size_t)M * cap, hipMemcpyDeviceToHost, ctx->stream));
     MSM_HIP(hipStreamSynchronize(ctx->stream));
     auto &pp = g->h_pptr[s];
     auto &pi = g->h_pidx[s];
