@@ -28,6 +28,7 @@ const Adjacency &mesh_adjacency(msm_mesh *m);
 
 struct msm_group {
     msm_ctx *ctx = nullptr;
+    int patch_cap_hint = 0;
     msm_group_params p{};
     int S = 0;
     msm_mesh *tmpl = nullptr;
@@ -83,7 +84,7 @@ int subject_patches(msm_group *g, int s) {
     MSM_HIP(d_c.upload(centres.data(), centres.size(), ctx->stream));
     MSM_HIP(d_sep.upload(sep.data(), sep.size(), ctx->stream));
     MSM_HIP(d_counts.ensure(M));
-    int cap = 256;
+    int cap = std::max(256, g->patch_cap_hint);  // the previous call's largest patch: one k_range pass instead of two
     std::vector<int> counts(M);
     for (int attempt = 0; attempt < 3; ++attempt) {
         MSM_HIP(d_slots.ensure((size_t)M * cap));
@@ -92,6 +93,7 @@ int subject_patches(msm_group *g, int s) {
         MSM_HIP(d_counts.download(counts.data(), M, ctx->stream));
         MSM_HIP(hipStreamSynchronize(ctx->stream));
         const int mx = *std::max_element(counts.begin(), counts.end());
+        g->patch_cap_hint = std::max(g->patch_cap_hint, mx + 16);
         if (mx <= cap) break;
         if (attempt == 2) return fail(MSM_ERR_CAPACITY, "group patch capacity");
         cap = mx + 16;
