@@ -217,7 +217,7 @@ int ensure_unary_table(msm_cost *c) {
         case MSM_COST_UNIVARIATE: st = launch_unary_univariate(ctx, u); break;
         case MSM_COST_MULTIVARIATE:
         case MSM_COST_PATCHWISE: {
-            if (c->p.kind == MSM_COST_MULTIVARIATE) {
+            {  // both classes: vertex-major copies for the eight-lanes-per-point reductions
                 st = ensure_vertex_major(c);
                 if (st) return st;
                 u.sfeat_vm = c->d_sfeat_vm.p;

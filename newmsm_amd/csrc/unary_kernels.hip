@@ -784,7 +784,8 @@ __global__ __launch_bounds__(256) void k_unary_reduce_features(ReduceMvArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const double absw = a.absw[node];
     const double nan = __longlong_as_double(0x7ff8000000000000ll);
-    for (int l = wave; l < a.L; l += 4) {
+    const int nwaves = blockDim.x >> 6;  // 4, or 1 when a patch is so large that only one wavefront's LDS slice fits
+    for (int l = wave; l < a.L; l += nwaves) {
         const size_t g0 = (size_t)a.L * beg + (size_t)l * P;
         double cost;
         if (!a.patchwise) {
@@ -953,6 +954,130 @@ __global__ __launch_bounds__(256) void k_unary_reduce_mv8(ReduceMv8Args a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Patchwise reduction, D <= 8 * K, SSD / correlation (M/DiscreteCostFunction.cpp:680-692: per feature channel a patch
+// similarity, averaged over the channels), in the layout of k_unary_reduce_mv8: eight lanes per patch point, lane j owns
+// the channels j, j + 8, ...; here the sums run over the POINTS, so every lane accumulates its channels over its group's
+// points and the eight groups of the wavefront are combined with three shuffle steps.  Two passes over the patch
+// (means, then moments); the second pass re-reads the rows (cache hits) instead of keeping them in registers.
+// ------------------------------------------------------------------------------------------------
+template <int K>
+__global__ __launch_bounds__(256) void k_unary_reduce_pw8(ReduceMv8Args a) {
+    const int node = a.order[blockIdx.x];
+    const int beg = a.pptr[node], P = a.pptr[node + 1] - beg;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int grp = lane / kMvLanes, j = lane % kMvLanes;
+    const double absw = a.absw[node];
+    const double nan = __longlong_as_double(0x7ff8000000000000ll);
+    const int D = a.D;
+    auto across_groups = [](double v) {  // lanes with the same j: the eight groups of the wavefront
+        v += __shfl_xor(v, 8, 64);
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        return v;
+    };
+    for (int l = wave; l < a.L; l += 4) {
+        const size_t g0 = (size_t)a.L * beg + (size_t)l * P;
+        bool bad = false;
+        // one point of the patch for this lane's group: moving row, interpolated target row (this lane's channels), weight
+        auto fetch = [&](int i, double *A, double *B, double &w) {
+            const int t = a.stri[g0 + i];
+            const int sv = a.pidx[beg + i];
+            w = (a.cfw_vm && a.cfw_rows >= 1) ? a.cfw_vm[(size_t)sv * a.cfw_rows] : 1.0;
+            if (t < 0) {
+                bad = true;
+#pragma unroll
+                for (int k = 0; k < K; ++k) A[k] = B[k] = nan;
+                return;
+            }
+            const TriRec &r = a.rec[t];
+            const double *f0 = a.tfeat + (size_t)r.id[0] * D, *f1 = a.tfeat + (size_t)r.id[1] * D, *f2 = a.tfeat + (size_t)r.id[2] * D;
+            const double *sa = a.sfeat_vm + (size_t)sv * D;
+            const double wa = a.sw3[3 * (g0 + i)], wb = a.sw3[3 * (g0 + i) + 1], wc = a.sw3[3 * (g0 + i) + 2];
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const int d = j + kMvLanes * k;
+                A[k] = d < D ? sa[d] : 0.0;
+                B[k] = d < D ? wa * f0[d] + wb * f1[d] + wc * f2[d] : 0.0;
+            }
+        };
+        double c[K];
+        if (a.simmeasure == 2) {  // sparsesimkernel::corr over the patch points, per channel
+            double sw = 0.0, ma[K], mb[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) ma[k] = mb[k] = 0.0;
+            for (int i = grp; i < P; i += 64 / kMvLanes) {
+                double A[K], B[K], w;
+                fetch(i, A, B, w);
+                sw += w;
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    ma[k] += w * A[k];
+                    mb[k] += w * B[k];
+                }
+            }
+            sw = across_groups(sw);
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                ma[k] = across_groups(ma[k]);
+                mb[k] = across_groups(mb[k]);
+                if (sw > 0.0) {
+                    ma[k] /= sw;
+                    mb[k] /= sw;
+                }
+            }
+            double pr[K], va[K], vb[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) pr[k] = va[k] = vb[k] = 0.0;
+            for (int i = grp; i < P; i += 64 / kMvLanes) {
+                double A[K], B[K], w;
+                fetch(i, A, B, w);
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    const double da = A[k] - ma[k], db = B[k] - mb[k];
+                    pr[k] += w * da * db;
+                    va[k] += w * da * da;
+                    vb[k] += w * db * db;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                double p = across_groups(pr[k]), x = across_groups(va[k]), y = across_groups(vb[k]);
+                if (sw > 0.0) {
+                    p /= sw;
+                    x /= sw;
+                    y /= sw;
+                }
+                const double rr = (x == 0.0 || y == 0.0) ? 0.0 : p / (sqrt(x) * sqrt(y));
+                c[k] = 1 - (1 + rr) * 0.5;
+            }
+        } else {  // sparsesimkernel::SSD
+            double pr[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) pr[k] = 0.0;
+            for (int i = grp; i < P; i += 64 / kMvLanes) {
+                double A[K], B[K], w;
+                fetch(i, A, B, w);
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    const double df = A[k] - B[k];
+                    pr[k] += w * df * df;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < K; ++k) c[k] = sqrt(across_groups(pr[k])) / P;
+        }
+        double total = 0.0;  // this lane's channels, then the eight lanes of the group (all groups hold the same values)
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+            if (j + kMvLanes * k < D) total += c[k];
+        total = mv_group_sum(total);
+        double cost = total / D;
+        if (__ballot(bad)) cost = nan;
+        if (lane == 0) a.U[(size_t)l * a.N + node] = absw * cost;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // launch
 // ------------------------------------------------------------------------------------------------
 // dynamic LDS of k_unary_samples when the labels are split over nsplit workgroups
@@ -1111,7 +1236,7 @@ int launch_unary_multivariate(msm_ctx *ctx, const UnaryLaunch &u, const UnaryWei
     r.percentile = u.percentile;
     r.U = u.U;
     const bool dice = u.simmeasure == 4 || u.simmeasure == 5;
-    if (!patchwise && !dice && u.D >= 12 && u.D <= kMvLanes * kMvKeep && u.sfeat_vm) {  // few dimensions: a lane per point wastes less
+    if (!dice && u.D >= 12 && u.D <= kMvLanes * kMvKeep && u.sfeat_vm) {  // few dimensions: a lane per point wastes less
         ReduceMv8Args m;
         m.N = u.N, m.L = u.L, m.Nsrc = u.Nsrc, m.D = u.D;
         m.tfeat = u.tfeat;
@@ -1124,12 +1249,19 @@ int launch_unary_multivariate(msm_ctx *ctx, const UnaryLaunch &u, const UnaryWei
         m.stri = w.stri, m.sw3 = w.sw3;
         m.simmeasure = u.simmeasure;
         m.U = u.U;
-        hipLaunchKernelGGL(k_unary_reduce_mv8, dim3(u.N), dim3(256), 0, ctx->stream, m);
+        if (!patchwise) hipLaunchKernelGGL(k_unary_reduce_mv8, dim3(u.N), dim3(256), 0, ctx->stream, m);
+        else if (u.D <= 32) hipLaunchKernelGGL(k_unary_reduce_pw8<4>, dim3(u.N), dim3(256), 0, ctx->stream, m);
+        else hipLaunchKernelGGL(k_unary_reduce_pw8<8>, dim3(u.N), dim3(256), 0, ctx->stream, m);
     } else {
-        const size_t flds = (dice && patchwise) ? sizeof(double) * 8 * (size_t)u.pmax : 0;
+        size_t flds = (dice && patchwise) ? sizeof(double) * 8 * (size_t)u.pmax : 0;
+        int threads = 256;
+        if (flds > 160 * 1024) {  // one wavefront per control point: a quarter of the LDS
+            flds /= 4;
+            threads = 64;
+        }
         if (flds > 160 * 1024) return fail(MSM_ERR_CAPACITY, "a patch of %d points does not fit in LDS (patchwise DICE)", u.pmax);
         if (flds > 64 * 1024) MSM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_unary_reduce_features), hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
-        hipLaunchKernelGGL(k_unary_reduce_features, dim3(u.N), dim3(256), flds, ctx->stream, r);
+        hipLaunchKernelGGL(k_unary_reduce_features, dim3(u.N), dim3(threads), flds, ctx->stream, r);
     }
     MSM_HIP(hipGetLastError());
     MSM_HIP(hipMemsetAsync(u.fix_cnt, 0, unary_fix_counter_words() * sizeof(unsigned), ctx->stream));  // counters are zero between launches

@@ -1,6 +1,6 @@
 """tools/fuzz_parity.py [seed] [count] -- random configurations (resolutions, warps, target shapes, cost classes, similarity
 measures) through the HIP path and the oracle; prints every mismatch.  Run on a GPU box; used to look for rare parity
-failures beyond what tests/ samples (round 1: 290 configurations, none)."""
+failures beyond what tests/ samples (round 1: 390 configurations, none)."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
