@@ -25,13 +25,20 @@ __device__ __noinline__ int search_slow(const DevTree *T, double x, double y, do
 // one point of an HO bin: the source vertex is projected on the current control triangle, carried to the moved
 // triangle by its barycentric coordinates and pushed back to the sphere (HO*::get_target_data,
 // M/DiscreteCostFunction.cpp:498-510 / :574-590)
-__device__ __forceinline__ V3 ho_point_position(const CliqueArgs &a, int sv, const V3 &cp0, const V3 &cp1, const V3 &cp2, const V3 &n0, const V3 &n1,
-                                                const V3 &n2) {
-    const V3 sp = project_point(soa(a.src, a.Nsrc, sv), cp0, cp1, cp2);
+__device__ __forceinline__ V3 ho_point_position_on(const CliqueArgs &a, int sv, const V3 &cp0, const V3 &cp1, const V3 &cp2, const V3 &s3, double pd,
+                                                   const V3 &n0, const V3 &n1, const V3 &n2) {
+    const V3 sp = project_with_plane(soa(a.src, a.Nsrc, sv), s3, pd);  // project_point(src, cp0, cp1, cp2) with the plane hoisted
     double wa, wb, wc;
     area_weights(cp0, cp1, cp2, sp, wa, wb, wc);  // barycentric(), R/triangle.cpp:159-172
     const V3 tmp = mk(n0.x * wa + n1.x * wb + n2.x * wc, n0.y * wa + n1.y * wb + n2.y * wc, n0.z * wa + n1.z * wb + n2.z * wc);
     return scale(normalized(tmp), kRad);
+}
+__device__ __forceinline__ V3 ho_point_position(const CliqueArgs &a, int sv, const V3 &cp0, const V3 &cp1, const V3 &cp2, const V3 &n0, const V3 &n1,
+                                                const V3 &n2) {
+    V3 s3;
+    double pd;
+    plane_of(cp0, cp1, cp2, s3, pd);  // the triangle-only half of project_point, R/point.cpp:46-60
+    return ho_point_position_on(a, sv, cp0, cp1, cp2, s3, pd, n0, n1, n2);
 }
 
 // ... and sampled on the target triangle tt (:511-517 / :591-598): HO univariate -> the interpolated target value; HO
@@ -48,8 +55,9 @@ __device__ __forceinline__ double ho_value_on(const CliqueArgs &a, int sv, const
 }
 
 // One point of a bin, complete: NaN (and the status word) on a failed search.
-__device__ double ho_point_value(const CliqueArgs &a, int sv, const V3 &cp0, const V3 &cp1, const V3 &cp2, const V3 &n0, const V3 &n1, const V3 &n2) {
-    const V3 tmp = ho_point_position(a, sv, cp0, cp1, cp2, n0, n1, n2);
+__device__ double ho_point_value(const CliqueArgs &a, int sv, const V3 &cp0, const V3 &cp1, const V3 &cp2, const V3 &s3, double pd, const V3 &n0,
+                                 const V3 &n1, const V3 &n2) {
+    const V3 tmp = ho_point_position_on(a, sv, cp0, cp1, cp2, s3, pd, n0, n1, n2);
     int tt = ray_find(a.tree, tmp);  // simple-surface targets: settled by the ray table nearly always
     if (tt < 0) {
         const DevTree T = a.tree;
@@ -256,7 +264,10 @@ __device__ void ho_group_eval(const CliqueArgs &a, bool valid, int t, int la, in
         // a folded proposal never looks at the data (computeTripletCost, :151-152)
         if (!(dot(tri_normal(r0, r1, r2), tri_normal(cp0, cp1, cp2)) < 0.0)) {
             const int beg = a.bin_ptr[t], n = a.bin_ptr[t + 1] - beg;  // n <= a.bin_cap (host-checked)
-            for (int i = sub; i < n; i += kHoLanes) vals[i] = ho_point_value(a, a.bin_idx[beg + i], cp0, cp1, cp2, r0, r1, r2);
+            V3 s3;
+            double pd;
+            plane_of(cp0, cp1, cp2, s3, pd);
+            for (int i = sub; i < n; i += kHoLanes) vals[i] = ho_point_value(a, a.bin_idx[beg + i], cp0, cp1, cp2, s3, pd, r0, r1, r2);
         }
     }
     __syncthreads();
@@ -314,6 +325,8 @@ __device__ __forceinline__ OctetEval octet_eval(const CliqueArgs &a, const int *
 }
 struct OctetGeometry {
     V3 r0, r1, r2, cp0, cp1, cp2;
+    V3 s3;      // plane of the current control triangle (the per-triangle half of project_point), shared by all its bin points
+    double pd;
     bool folded;
 };
 __device__ __forceinline__ OctetGeometry octet_geometry(const CliqueArgs &a, const OctetEval &q) {
@@ -322,6 +335,7 @@ __device__ __forceinline__ OctetGeometry octet_geometry(const CliqueArgs &a, con
     g.r0 = aos(a.moved, (size_t)id[0] * a.L + q.la), g.r1 = aos(a.moved, (size_t)id[1] * a.L + q.lb), g.r2 = aos(a.moved, (size_t)id[2] * a.L + q.lc);
     g.cp0 = soa(a.cp, a.N, id[0]), g.cp1 = soa(a.cp, a.N, id[1]), g.cp2 = soa(a.cp, a.N, id[2]);
     g.folded = dot(tri_normal(g.r0, g.r1, g.r2), tri_normal(g.cp0, g.cp1, g.cp2)) < 0.0;  // computeTripletCost, :151-152
+    plane_of(g.cp0, g.cp1, g.cp2, g.s3, g.pd);
     return g;
 }
 
@@ -347,51 +361,74 @@ __global__ __launch_bounds__(256) void k_ho_octets_sample(CliqueArgs a, const in
     const int beg = a.bin_ptr[q.t], n = a.bin_ptr[q.t + 1] - beg;
     for (int i = sub; i < n; i += kOctLanes) {
         const int sv = a.bin_idx[beg + i];
-        const V3 tmp = ho_point_position(a, sv, g.cp0, g.cp1, g.cp2, g.r0, g.r1, g.r2);
+        const V3 tmp = ho_point_position_on(a, sv, g.cp0, g.cp1, g.cp2, g.s3, g.pd, g.r0, g.r1, g.r2);
         const int tt = ray_find(a.tree, tmp);
         if (tt >= 0) a.ho_vals[q.offset + i] = ho_value_on(a, sv, tmp, tt);
         else a.ho_pending[atomicAdd(a.ho_count, 1u)] = ((unsigned)e << 10) | (unsigned)i;
     }
 }
 
-// HO multivariate, D <= 64, SSD / correlation: a wavefront per evaluation, eight lanes per bin point.  The lanes of a
-// group share the point (position and ray-table lookup are computed redundantly, they are cheap) and split its D
-// dimensions (similarity_device.hpp: feature_vector_similarity8); 219 us -> see DESIGN.md with a lane per point.
+// HO multivariate, D <= 64, SSD / correlation.  A wavefront takes eight evaluations; per round of eight bin points each:
+//   geometry   a lane per (evaluation, point): position on the moved triangle, ray-table lookup, barycentric weights
+//              (about 1 300 instructions of FP64 geometry -- with eight lanes per point from the start, as in the first
+//              version of this kernel, every one of them was issued for 8 points instead of 64: 204 us per move);
+//   similarity eight passes; in pass p the eight lanes of group g take the p-th point of evaluation g (its triangle,
+//              weights and vertex id come over from the lane that did its geometry) and split its D dimensions
+//              (similarity_device.hpp: feature_vector_similarity8).
 __global__ __launch_bounds__(256) void k_ho_octets_sample_mv8(CliqueArgs a, const int *__restrict__ labeling, int label) {
-    const int blk = xcd_block(4, 8 * a.T);
+    const int blk = xcd_block(32, 8 * a.T);
     if (blk < 0) return;
-    const int e = blk * 4 + (threadIdx.x >> 6);
-    if (e >= 8 * a.T) return;  // wavefront-uniform
     const int lane = threadIdx.x & 63, grp = lane >> 3, j = lane & 7;
-    const OctetEval q = octet_eval(a, labeling, label, e);
-    const OctetGeometry g = octet_geometry(a, q);
-    if (g.folded) return;
-    const int beg = a.bin_ptr[q.t], n = a.bin_ptr[q.t + 1] - beg;
+    const int e = blk * 32 + (threadIdx.x >> 6) * 8 + grp;  // this group's evaluation
+    const bool ev = e < 8 * a.T;
+    OctetEval q{0, 0, 0, 0, 0};
+    OctetGeometry g{};
+    g.folded = true;
+    int beg = 0, n = 0;
+    if (ev) {
+        q = octet_eval(a, labeling, label, e);
+        g = octet_geometry(a, q);
+        beg = a.bin_ptr[q.t];
+        n = g.folded ? 0 : a.bin_ptr[q.t + 1] - beg;  // a folded proposal never looks at the data
+    }
+    int nmax = n;  // wavefront-uniform round count
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) nmax = max(nmax, __shfl_xor(nmax, off, 64));
     const int D = a.D;
-    for (int i0 = 0; i0 < n; i0 += 8) {  // wavefront-uniform: the group sums need all lanes
-        const int i = i0 + grp;
+    for (int base = 0; base < nmax; base += 8) {
+        // ---- geometry: lane (grp, j) owns point base + j of evaluation grp
+        const int i = base + j;
         const bool have = i < n;
         int sv = 0, tt = -1;
-        V3 tmp = mk(0.0, 0.0, 0.0);
+        double wa = 0, wb = 0, wc = 0;
         if (have) {
             sv = a.bin_idx[beg + i];
-            tmp = ho_point_position(a, sv, g.cp0, g.cp1, g.cp2, g.r0, g.r1, g.r2);
+            const V3 tmp = ho_point_position_on(a, sv, g.cp0, g.cp1, g.cp2, g.s3, g.pd, g.r0, g.r1, g.r2);
             tt = ray_find(a.tree, tmp);
+            if (tt >= 0) {
+                const TriRec &r = a.tree.rec[tt];
+                area_weights(rec_v0(r), rec_v1(r), rec_v2(r), tmp, wa, wb, wc);
+            } else {
+                a.ho_pending[atomicAdd(a.ho_count, 1u)] = ((unsigned)e << 10) | (unsigned)i;
+            }
         }
-        const bool go = have && tt >= 0;
-        const double *f0 = a.tfeat, *f1 = a.tfeat, *f2 = a.tfeat, *sa = a.sfeat_vm, *cw = nullptr;
-        double wa = 0, wb = 0, wc = 0;
-        if (go) {
-            const TriRec &r = a.tree.rec[tt];
-            area_weights(rec_v0(r), rec_v1(r), rec_v2(r), tmp, wa, wb, wc);
-            f0 = a.tfeat + (size_t)r.id[0] * D, f1 = a.tfeat + (size_t)r.id[1] * D, f2 = a.tfeat + (size_t)r.id[2] * D;
-            sa = a.sfeat_vm + (size_t)sv * D;
-            cw = a.cfw_vm ? a.cfw_vm + (size_t)sv * a.cfw_rows : nullptr;
-        }
-        const double c = feature_vector_similarity8(a.simmeasure, go, j, D, sa, cw, a.cfw_rows, f0, f1, f2, wa, wb, wc);
-        if (j == 0 && have) {
-            if (go) a.ho_vals[q.offset + i] = c;
-            else a.ho_pending[atomicAdd(a.ho_count, 1u)] = ((unsigned)e << 10) | (unsigned)i;
+        // ---- similarity: pass p, group grp -> point base + p of evaluation grp
+#pragma unroll 1
+        for (int p = 0; p < 8; ++p) {
+            const int src = (lane & ~7) | p;
+            const int ptt = __shfl(tt, src, 64), psv = __shfl(sv, src, 64);
+            const double pwa = __shfl(wa, src, 64), pwb = __shfl(wb, src, 64), pwc = __shfl(wc, src, 64);
+            const bool go = ptt >= 0;
+            if (!__any(go)) continue;
+            const double *f0 = a.tfeat, *f1 = a.tfeat, *f2 = a.tfeat, *sa = a.sfeat_vm, *cw = nullptr;
+            if (go) {
+                const TriRec &r = a.tree.rec[ptt];
+                f0 = a.tfeat + (size_t)r.id[0] * D, f1 = a.tfeat + (size_t)r.id[1] * D, f2 = a.tfeat + (size_t)r.id[2] * D;
+                sa = a.sfeat_vm + (size_t)psv * D;
+                cw = a.cfw_vm ? a.cfw_vm + (size_t)psv * a.cfw_rows : nullptr;
+            }
+            const double c = feature_vector_similarity8(a.simmeasure, go, j, D, sa, cw, a.cfw_rows, f0, f1, f2, pwa, pwb, pwc);
+            if (go && j == 0) a.ho_vals[q.offset + base + p] = c;
         }
     }
 }
@@ -413,7 +450,7 @@ __global__ __launch_bounds__(256) void k_ho_octets_fix(CliqueArgs a, const int *
             const OctetEval q = octet_eval(a, labeling, label, e);
             const OctetGeometry g = octet_geometry(a, q);
             sv = a.bin_idx[a.bin_ptr[q.t] + i];
-            tmp = ho_point_position(a, sv, g.cp0, g.cp1, g.cp2, g.r0, g.r1, g.r2);
+            tmp = ho_point_position_on(a, sv, g.cp0, g.cp1, g.cp2, g.s3, g.pd, g.r0, g.r1, g.r2);
             slot = q.offset + i;
         }
         const int found = group8_find(a.tree, valid, tmp, lane);
@@ -509,7 +546,7 @@ int launch_triplet_octets(msm_ctx *ctx, const CliqueArgs &a, const int *labeling
         const int per = 256 / kOctLanes;
         const bool mv8 = a.kind == MSM_COST_HO_MULTIVARIATE && a.sfeat_vm && a.D >= 12 && a.D <= kMvLanes * kMvKeep && (a.simmeasure == 1 || a.simmeasure == 2);
         auto grid8 = [](int evals, int per_block) { return dim3((unsigned)(8 * (((evals + per_block - 1) / per_block + 7) / 8))); };  // 8 x blocks per XCD
-        if (mv8) hipLaunchKernelGGL(k_ho_octets_sample_mv8, grid8(8 * a.T, 4), dim3(256), 0, ctx->stream, a, labeling, label);
+        if (mv8) hipLaunchKernelGGL(k_ho_octets_sample_mv8, grid8(8 * a.T, 32), dim3(256), 0, ctx->stream, a, labeling, label);
         else hipLaunchKernelGGL(k_ho_octets_sample, grid8(8 * a.T, per), dim3(256), 0, ctx->stream, a, labeling, label);
         MSM_HIP(hipGetLastError());
         hipLaunchKernelGGL(k_ho_octets_fix, dim3(64), dim3(256), 0, ctx->stream, a, labeling, label);
