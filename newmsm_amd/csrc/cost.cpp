@@ -5,9 +5,12 @@
 // per-control-point patches, and the table / batch evaluators replace the OpenMP loops of
 // computeUnaryCosts, computeTripletCosts and Fusion's per-label sweeps with kernel launches.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
 
 #include "cost_internal.hpp"
+#include "host_parallel.hpp"
 
 using namespace msm;
 
@@ -417,12 +420,22 @@ int msm_cost_get_source_data(msm_cost *c) {
     if (st) return st;
     // NonLinearSRegDiscreteCostFunction::initialize, M/DiscreteCostFunction.cpp:109-117
     if (c->target->V == 0 || c->source->V == 0) return fail(MSM_ERR_STATE, "CostFunction::You must supply source and target meshes.");
+    const bool timing = std::getenv("MSMHIP_TIMING") != nullptr;
+    auto tick = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "  get_source_data: %s %.1f ms\n", what, std::chrono::duration<double, std::milli>(now - tick).count());
+        tick = now;
+    };
     st = is_ho(c) ? patches_by_triangle(c) : patches_by_range(c);
     if (st) return st;
+    lap("patches");
     c->pmax = 1;
     for (int g = 0; g < c->ngroups; ++g) c->pmax = std::max(c->pmax, c->pptr[g + 1] - c->pptr[g]);
     st = resample_weights(c);
     if (st) return st;
+    lap("resample_weights");
     msm_ctx *ctx = c->ctx;
     MSM_HIP(c->d_pptr.upload(c->pptr.data(), c->pptr.size(), ctx->stream));
     if (is_ho(c) || std::getenv("MSMHIP_NO_PATCH_SORT")) {
@@ -451,9 +464,11 @@ int msm_cost_get_source_data(msm_cost *c) {
             code[v] = spread(q[0]) << 2 | spread(q[1]) << 1 | spread(q[2]);
         }
         std::vector<int32_t> sorted(c->pidx);
-        for (int g = 0; g < c->ngroups; ++g)
-            std::sort(sorted.begin() + c->pptr[g], sorted.begin() + c->pptr[g + 1],
-                      [&](int32_t x, int32_t y) { return code[x] < code[y] || (code[x] == code[y] && x < y); });
+        parallel_chunks(c->ngroups, std::min(host_workers(), 8), [&](int, int g0, int g1) {
+            for (int g = g0; g < g1; ++g)
+                std::sort(sorted.begin() + c->pptr[g], sorted.begin() + c->pptr[g + 1],
+                          [&](int32_t x, int32_t y) { return code[x] < code[y] || (code[x] == code[y] && x < y); });
+        });
         MSM_HIP(c->d_pidx.upload_vec(sorted, ctx->stream));
         MSM_HIP(hipStreamSynchronize(ctx->stream));
     }
@@ -488,6 +503,7 @@ int msm_cost_get_source_data(msm_cost *c) {
         c->fix_off_valid = false;
     }
     MSM_HIP(hipStreamSynchronize(ctx->stream));
+    lap("orders + uploads");
     c->have_source = true;
     invalidate_table(c);
     return MSM_OK;
