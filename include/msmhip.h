@@ -246,9 +246,10 @@ int msm_cost_counters(msm_cost *c, int64_t counters[4]);
  * ---------------------------------------------------------------------------------------------- */
 typedef struct msm_group msm_group;
 typedef struct msm_group_params { /* set_parameters M/DiscreteCostFunction.cpp:119-133 */
-    int32_t simmeasure;  /* 1 SSD, 2 correlation */
+    int32_t simmeasure;  /* 1 SSD, 2 correlation, 4 DICE, 5 genDICE (get_sim_for_min, M/similarities.h:48-58) */
     int32_t fixnan;      /* "fixnan": NaN cost -> FIX_NAN = 1e7 (M/reg_tools.h:31) */
     double  lambda, mu, kappa, k_exp, rexp, range;
+    double  percentile;  /* "percentile" (M/DiscreteCostFunction.cpp:129): DICE threshold rank; 0 means the default 0.75 */
 } msm_group_params;
 msm_group *msm_group_create(msm_ctx *ctx, const msm_group_params *params, int32_t num_subjects);
 void       msm_group_destroy(msm_group *g);

@@ -337,13 +337,14 @@ struct GroupParameters {
     int simmeasure = 2;
     bool fixnan = false;
     double lambda = 0.1, shearmodulus = 0.1, bulkmodulus = 10.0, kexponent = 2.0, exponent = 2.0, range = 1.0;
+    double percentile = 0.75;
 };
 
 // DiscreteGroupModel (the optimisers' DiscreteModel) + DiscreteGroupCostFunction, M/DiscreteGroupModel.h:37-108
 class DiscreteGroupModel {
 public:
     DiscreteGroupModel(Context &ctx, const GroupParameters &P, int num_subjects) {
-        msm_group_params p{P.simmeasure, P.fixnan ? 1 : 0, P.lambda, P.shearmodulus, P.bulkmodulus, P.kexponent, P.exponent, P.range};
+        msm_group_params p{P.simmeasure, P.fixnan ? 1 : 0, P.lambda, P.shearmodulus, P.bulkmodulus, P.kexponent, P.exponent, P.range, P.percentile};
         h_ = msm_group_create(ctx.handle(), &p, num_subjects);
         if (!h_) throw Error(MSM_ERR_INVALID, msm_last_error());
     }

@@ -28,7 +28,7 @@ class MsmError(RuntimeError):
 
 class GroupParams(C.Structure):
     _fields_ = [("simmeasure", C.c_int32), ("fixnan", C.c_int32), ("lambda_", C.c_double), ("mu", C.c_double),
-                ("kappa", C.c_double), ("k_exp", C.c_double), ("rexp", C.c_double), ("range", C.c_double)]
+                ("kappa", C.c_double), ("k_exp", C.c_double), ("rexp", C.c_double), ("range", C.c_double), ("percentile", C.c_double)]
 
 
 class CostParams(C.Structure):

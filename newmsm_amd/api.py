@@ -472,12 +472,13 @@ class DiscreteGroupCostFunction:
     """DiscreteGroupModel::setupCostFunction + DiscreteGroupCostFunction's evaluators
     (/root/reference/libraries/msm-newmeshreg/src/DiscreteGroupModel.cpp:163-196, DiscreteGroupCostFunction.cpp:26-98)."""
 
-    def __init__(self, ctx, num_subjects, simmeasure=2, fixnan=False, lambda_=0.1, mu=0.1, kappa=10.0, k_exp=2.0, rexp=2.0, range_=1.0):
+    def __init__(self, ctx, num_subjects, simmeasure=2, fixnan=False, lambda_=0.1, mu=0.1, kappa=10.0, k_exp=2.0, rexp=2.0, range_=1.0,
+                 percentile=0.75):
         from ._lib import GroupParams
 
         self.ctx = ctx
         self.S = num_subjects
-        self.params = GroupParams(simmeasure, int(fixnan), lambda_, mu, kappa, k_exp, rexp, range_)
+        self.params = GroupParams(simmeasure, int(fixnan), lambda_, mu, kappa, k_exp, rexp, range_, percentile)
         self.h = lib().msm_group_create(ctx.h, C.byref(self.params), num_subjects)
         if not self.h:
             raise MsmError(-1, lib().msm_last_error().decode())

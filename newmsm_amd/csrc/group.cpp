@@ -29,6 +29,7 @@ const Adjacency &mesh_adjacency(msm_mesh *m);
 struct msm_group {
     msm_ctx *ctx = nullptr;
     int patch_cap_hint = 0;
+    int patch_max = 0;  // largest patch of any subject (msm_group_finalize)
     msm_group_params p{};
     int S = 0;
     msm_mesh *tmpl = nullptr;
@@ -157,6 +158,8 @@ int group_args(msm_group *g, GroupArgs &a) {
     a.k_exp = g->p.k_exp;
     a.rexp = g->p.rexp;
     a.subcorr = 0.1 * g->S;  // set_meshes, M/DiscreteGroupCostFunction.h:45
+    a.percentile = g->p.percentile;
+    a.patch_cap = g->patch_max;
     a.status = g->ctx->d_status;
     return MSM_OK;
 }
@@ -170,13 +173,19 @@ msm_group *msm_group_create(msm_ctx *ctx, const msm_group_params *params, int32_
         fail(MSM_ERR_INVALID, "msm_group_create: bad arguments");
         return nullptr;
     }
-    if (params->simmeasure != 1 && params->simmeasure != 2) {
-        fail(MSM_ERR_INVALID, "msm_group_create: similarity measure %d is not offloaded", params->simmeasure);
+    if (params->simmeasure != 1 && params->simmeasure != 2 && params->simmeasure != 4 && params->simmeasure != 5) {
+        fail(MSM_ERR_INVALID, "Unknown similarity metric");  // get_sim_for_min, M/similarities.h:57
+        return nullptr;
+    }
+    const double percentile = params->percentile == 0.0 ? 0.75 : params->percentile;  // sparsesimkernel's default, M/similarities.h:68
+    if ((params->simmeasure == 4 || params->simmeasure == 5) && !(percentile > 0.0 + 1e-8 && percentile < 1.0 - 1e-8)) {
+        fail(MSM_ERR_INVALID, "Percentile must be between 0 and 1.");  // M/mesh_registration.cpp:782-783
         return nullptr;
     }
     msm_group *g = new msm_group();
     g->ctx = ctx;
     g->p = *params;
+    g->p.percentile = percentile;
     g->S = S;
     g->cpmesh.assign(S, nullptr);
     g->data.assign(S, nullptr);
@@ -519,6 +528,9 @@ int msm_group_finalize(msm_group *g) {
     MSM_HIP(g->d_pptrp.upload(pp.data(), pp.size(), ctx->stream));
     MSM_HIP(g->d_pidxp.upload(pi.data(), pi.size(), ctx->stream));
     MSM_HIP(hipStreamSynchronize(ctx->stream));
+    g->patch_max = 0;
+    for (int s = 0; s < S; ++s)
+        for (size_t k = 0; k + 1 < g->h_pptr[s].size(); ++k) g->patch_max = std::max(g->patch_max, g->h_pptr[s][k + 1] - g->h_pptr[s][k]);
     g->ready = true;
     return MSM_OK;
 }

@@ -3,6 +3,7 @@
 // (DiscreteGroupCostFunction::computePairwiseCost, M/DiscreteGroupCostFunction.cpp:54-98) and the per-subject strain
 // triplet (:26-52).
 #include "kernels.hpp"
+#include "similarity_device.hpp"
 #include "strain_device.hpp"
 
 namespace msm {
@@ -42,10 +43,14 @@ int launch_rotate_to_label(msm_ctx *ctx, const double *d_xyz, int V, const doubl
 // One wavefront per query.  Patch A = template vertices in range of (subject A, control point, label A), ascending;
 // the lanes take A's entries, look each up in B's list by binary search (std::map::find), and the similarity of
 // the two subjects' resampled features over the intersection is reduced per feature dimension with shuffles.
+// kDice (DICE / genDICE): the common entries of one feature dimension are first packed, in patch order, into the
+// wavefront's LDS rows (2 x patch_cap doubles) and thresholded there by rank counting (similarity_device.hpp).
+template <bool kDice>
 __global__ __launch_bounds__(256) void k_group_pairwise(GroupArgs a, const int *__restrict__ qp, const int *__restrict__ qa,
                                                          const int *__restrict__ qb, int n, double *__restrict__ out) {
     const int q = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (q >= n) return;
+    extern __shared__ double s_common[];
     const int pair = qp[q], la = qa[q], lb = qb[q];
     const int ga = a.pairs[2 * pair], gb = a.pairs[2 * pair + 1];
     const int sa = ga / a.N, sb = gb / a.N, na = ga - sa * a.N, nb = gb - sb * a.N;
@@ -80,7 +85,26 @@ __global__ __launch_bounds__(256) void k_group_pairwise(GroupArgs a, const int *
         for (int d = 0; d < a.D; ++d) {
             const double *A = FA + (size_t)d * a.Vt, *B = FB + (size_t)d * a.Vt;
             double c;
-            if (a.simmeasure == 2) {  // sparsesimkernel::corr, M/similarities.cpp:129-158
+            if constexpr (kDice) {  // sparsesimkernel::DICE / genDICE, M/similarities.cpp:201-253 (weights unused)
+                double *SA = s_common + (size_t)(threadIdx.x >> 6) * 2 * a.patch_cap, *SB = SA + a.patch_cap;
+                int base = 0;
+                for (int r = 0, i0 = 0; i0 < cntA; i0 += 64, ++r) {
+                    const int i = i0 + lane;
+                    const bool m = i < cntA && (member >> r & 1u);
+                    const unsigned long long bal = __ballot(m);
+                    if (m) {
+                        const int pos = base + __popcll(bal & ((1ull << lane) - 1)), id = ia[i];
+                        SA[pos] = A[id];
+                        SB[pos] = B[id];
+                    }
+                    base += __popcll(bal);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                c = patch_dice(SA, SB, ncommon, lane, a.simmeasure, a.percentile);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            } else if (a.simmeasure == 2) {  // sparsesimkernel::corr, M/similarities.cpp:129-158
                 double sw = 0, ma = 0, mb = 0;
                 for (int r = 0, i = lane; i < cntA; i += 64, ++r)
                     if (member >> r & 1u) {
@@ -163,7 +187,14 @@ __global__ __launch_bounds__(128) void k_group_triplet(GroupArgs a, const int *_
 
 int launch_group_pairwise(msm_ctx *ctx, const GroupArgs &a, const int *qp, const int *qa, const int *qb, int n, double *out) {
     if (n <= 0) return MSM_OK;
-    hipLaunchKernelGGL(k_group_pairwise, dim3((n + 3) / 4), dim3(256), 0, ctx->stream, a, qp, qa, qb, n, out);
+    if (a.simmeasure == 4 || a.simmeasure == 5) {
+        const size_t lds = sizeof(double) * 4 * 2 * (size_t)std::max(a.patch_cap, 1);  // <= 128 KB: patches hold at most 2048 entries
+        if (lds > 160 * 1024) return fail(MSM_ERR_CAPACITY, "group patch of %d entries does not fit in LDS", a.patch_cap);
+        if (lds > 64 * 1024) MSM_HIP(hipFuncSetAttribute((const void *)k_group_pairwise<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_group_pairwise<true>, dim3((n + 3) / 4), dim3(256), lds, ctx->stream, a, qp, qa, qb, n, out);
+    } else {
+        hipLaunchKernelGGL(k_group_pairwise<false>, dim3((n + 3) / 4), dim3(256), 0, ctx->stream, a, qp, qa, qb, n, out);
+    }
     MSM_HIP(hipGetLastError());
     return MSM_OK;
 }

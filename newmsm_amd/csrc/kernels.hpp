@@ -135,6 +135,8 @@ struct GroupArgs {
     const double *cp;            // S x (3 x N) current control grids
     const double *orig;          // S x (3 x N) _ORIG_MESHES coordinates of the control-point ids
     double lambda, mu, kappa, k_exp, rexp, subcorr;
+    double percentile;           // DICE threshold rank
+    int patch_cap;               // largest patch of any subject (DICE: LDS staging of the common entries)
     int *status;
 };
 int launch_rotate_to_label(msm_ctx *ctx, const double *d_xyz, int V, const double centre[3], const double label[3], double *d_out);

@@ -59,6 +59,49 @@ __device__ __forceinline__ double dice_serial(int sim, int n, double percentile,
     return dice_value(sim, size_a, size_b, common);
 }
 
+// ---- the same by one wavefront over patches staged in memory (the unary patch kernels, the gMSM pairwise kernel)
+__device__ __forceinline__ int wave_count(int v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+__device__ __forceinline__ double wave_kth_smallest(const double *X, int P, int idx, int lane) {
+    double t = __longlong_as_double(0x7ff8000000000000ll);
+    for (int j0 = 0; j0 < P; j0 += 64) {  // wavefront-uniform loop: a lane per candidate value, ranks by counting
+        const int j = j0 + lane;
+        const double v = j < P ? X[j] : 0.0;
+        int less = 0, leq = 0;
+        for (int i = 0; i < P; ++i) {
+            const double x = X[i];
+            less += x < v;
+            leq += x <= v;
+        }
+        const unsigned long long bal = __ballot(j < P && less <= idx && idx < leq);
+        if (bal) {
+            const int src = __ffsll((long long)bal) - 1;
+            t = __shfl(v, src, 64);
+            break;
+        }
+    }
+    return t;
+}
+
+// DICE / genDICE of two patches by one wavefront (M/similarities.cpp:201-253; see similarity_device.hpp)
+__device__ __forceinline__ double patch_dice(const double *A, const double *B, int P, int lane, int simmeasure, double percentile) {
+    const int idx = dice_index(percentile, P);
+    const double ta = wave_kth_smallest(A, P, idx, lane), tb = wave_kth_smallest(B, P, idx, lane);
+    int da = 0, db = 0, cm = 0;  // elements below the thresholds, and elements at or above both
+    for (int i = lane; i < P; i += 64) {
+        const bool la = A[i] < ta, lb = B[i] < tb;
+        da += la;
+        db += lb;
+        cm += !la && !lb;
+    }
+    const int size_a = P - wave_count(da), size_b = P - wave_count(db), common = wave_count(cm);
+    return dice_value(simmeasure, size_a, size_b, common);
+}
+
 // serial over the D dimensions in the reference's order; the target values are recomputed in the second pass
 // instead of being stored (3 loads + 5 flops each)
 // Nsrc > 0: sfeat / cfw are D x Nsrc (rows x Nsrc) row-major, as the ABI takes them; Nsrc == 0: vertex-major copies

@@ -193,6 +193,7 @@ typedef struct orc_group orc_group;
 typedef struct {
     int    simmeasure, fixnan;
     double lambda, mu, kappa, k_exp, rexp, range;
+    double percentile; /* DICE threshold rank, sparsesimkernel::percentile (M/similarities.h:68; 0.75 by default) */
 } orc_group_params;
 orc_group *orc_group_create(const orc_group_params *p, int num_subjects);
 void       orc_group_destroy(orc_group *g);

@@ -422,20 +422,21 @@ class Cost:
 # ---------------------------------------------------------------- groupwise (gMSM)
 class GroupParams(C.Structure):
     _fields_ = [("simmeasure", C.c_int), ("fixnan", C.c_int), ("lambda_", C.c_double), ("mu", C.c_double), ("kappa", C.c_double),
-                ("k_exp", C.c_double), ("rexp", C.c_double), ("range", C.c_double)]
+                ("k_exp", C.c_double), ("rexp", C.c_double), ("range", C.c_double), ("percentile", C.c_double)]
 
 
 class Group:
     """Oracle mirror of DiscreteGroupModel + DiscreteGroupCostFunction."""
 
-    def __init__(self, num_subjects, simmeasure=2, fixnan=False, lambda_=0.1, mu=0.1, kappa=10.0, k_exp=2.0, rexp=2.0, range_=1.0):
+    def __init__(self, num_subjects, simmeasure=2, fixnan=False, lambda_=0.1, mu=0.1, kappa=10.0, k_exp=2.0, rexp=2.0, range_=1.0,
+                 percentile=0.75):
         L = lib()
         L.orc_group_create.restype = C.c_void_p
         L.orc_group_pairwise.restype = C.c_double
         L.orc_group_triplet.restype = C.c_double
         L.orc_group_pairs.restype = c_ip
         L.orc_group_triplets.restype = c_ip
-        self.params = GroupParams(simmeasure, int(fixnan), lambda_, mu, kappa, k_exp, rexp, range_)
+        self.params = GroupParams(simmeasure, int(fixnan), lambda_, mu, kappa, k_exp, rexp, range_, percentile)
         self.S = num_subjects
         self.h = C.c_void_p(L.orc_group_create(C.byref(self.params), num_subjects))
         self._keep = {}

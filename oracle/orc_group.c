@@ -250,7 +250,7 @@ double orc_group_pairwise(orc_group *g, int pair, int la, int lb) {
             A[i] = FA[(size_t)d * Vt + ids[i]];
             B[i] = FB[(size_t)d * Vt + ids[i]];
         }
-        cost += orc_sim_for_min(g->p.simmeasure, A, B, W, n, 0.75);
+        cost += orc_sim_for_min(g->p.simmeasure, A, B, W, n, g->p.percentile);
     }
     if (n > 0) cost /= D;
     free(ids);

@@ -14,15 +14,15 @@ pytestmark = pytest.mark.gpu
 RTOL, ATOL = 1e-9, 1e-11
 
 
-def build(ctx, S=3, data_order=4, cp_order=2, D=2, mask=False, sim=2):
+def build(ctx, S=3, data_order=4, cp_order=2, D=2, mask=False, sim=2, percentile=0.75):
     dxyz, dtri = M.make_mesh_from_icosa(data_order)
     cxyz, ctri = M.make_mesh_from_icosa(cp_order)
     txyz, ttri = dxyz, dtri  # template space = a regular sphere at data resolution
     _, mvd = M.cp_spacings(cxyz, ctri)
     samples, _ = M.label_sampling_grid(cp_order + 2, 0.5 * mvd)
     mk = (np.cos(txyz[:, 0] / 30.0) if mask else None)
-    g = M.DiscreteGroupCostFunction(ctx, S, simmeasure=sim, lambda_=0.2)
-    og = O.Group(S, simmeasure=sim, lambda_=0.2)
+    g = M.DiscreteGroupCostFunction(ctx, S, simmeasure=sim, lambda_=0.2, percentile=percentile)
+    og = O.Group(S, simmeasure=sim, lambda_=0.2, percentile=percentile)
     tm = M.Mesh(ctx, txyz, ttri)
     g.set_template(tm, mk)
     otm = O.Mesh(txyz, ttri)
@@ -76,6 +76,30 @@ def test_group_pairwise_costs(ctx, mask, sim):
     want = np.array([og.pairwise(*q) for q in zip(p, la, lb)])
     assert np.allclose(got, want, rtol=RTOL, atol=ATOL, equal_nan=True), np.nanmax(np.abs(got - want))
     assert np.isfinite(want).sum() > 300
+
+
+@pytest.mark.parametrize("sim,percentile", [(4, 0.75), (5, 0.75), (4, 0.3)])
+def test_group_pairwise_dice(ctx, sim, percentile):
+    """DICE / genDICE over the common entries of the two patches (get_sim_for_min, similarities.h:53-56): the costs are
+    ratios of counts, so they match the oracle exactly unless a resampled value sits within 1e-12 of a threshold."""
+    g, og, _ = build(ctx, sim=sim, percentile=percentile, mask=True)
+    rng = np.random.default_rng(2)
+    p = rng.integers(0, g.P, 400).astype(np.int32)
+    la = rng.integers(0, g.L, 400).astype(np.int32)
+    lb = rng.integers(0, g.L, 400).astype(np.int32)
+    got = g.computePairwiseCost(p, la, lb)
+    want = np.array([og.pairwise(*q) for q in zip(p, la, lb)])
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    ok = np.isfinite(want)
+    assert ok.sum() > 300 and np.unique(want[ok]).size > 20
+    assert np.array_equal(got[ok], want[ok]), np.abs(got[ok] - want[ok]).max()
+
+
+def test_group_rejects_bad_similarity(ctx):
+    with pytest.raises(M.MsmError, match="Unknown similarity metric"):
+        M.DiscreteGroupCostFunction(ctx, 2, simmeasure=3)
+    with pytest.raises(M.MsmError, match="Percentile"):
+        M.DiscreteGroupCostFunction(ctx, 2, simmeasure=4, percentile=1.0)
 
 
 def test_group_triplet_costs(ctx):
