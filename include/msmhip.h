@@ -150,6 +150,26 @@ int msm_smooth_data(msm_mesh *orig, const double *data, int32_t D, msm_mesh *sph
 int msm_nearest_neighbour(msm_mesh *orig, const double *data, int32_t D, const double *q_xyz, int32_t N, double *out);
 
 /* ------------------------------------------------------------------------------------------------
+ * the callers' side of one iteration (run_discrete_opt, M/mesh_registration.cpp:164-232): what sits between two
+ * evaluations of the cost tables besides the optimiser's own data structures
+ * ---------------------------------------------------------------------------------------------- */
+/* unfold M/reg_tools.cpp:131-178 on the mesh's current coordinates (sphere of the given radius; the reference uses RAD = 100):
+ * the fold test check_for_intersections :118-129 runs on the GPU for all vertices; when some are folded (rare) their
+ * gradients and the step-halving moves are applied on the host in the reference's serial order, and the test repeats
+ * (at most 1000 passes).  *passes = passes that moved vertices (0: nothing folded, coordinates untouched),
+ * *first_folded = folded vertices found by the first pass; both optional.  Read the result with msm_mesh_get_coords. */
+int msm_mesh_unfold(msm_mesh *m, double radius, int32_t *passes, int32_t *first_folded);
+/* [host] variance_normalise M/reg_tools.cpp:804-843: data D x V in place; excl (V values, > 0 keeps the vertex) or NULL.
+ * The running mean / variance recurrence of the reference is serial per feature row, so it stays on the host. */
+int msm_variance_normalise(double *data, int32_t D, int32_t V, const double *excl);
+/* [host] MCMC::optimise M/mcmc_opt.h:31-134 over the tables of msm_cost_unary_table (L x N) and msm_cost_triplet_table
+ * (T x L x L x L): `iters` sweeps over the triplets, each proposing one label drawn from std::geometric_distribution(mcparam)
+ * (std::mt19937 seeded with `seed`; the reference seeds from std::random_device) and keeping the cheapest of the eight
+ * combinations.  labeling (N) is read and updated.  The energy the reference returns is msm_cost_total(labeling). */
+int msm_mcmc_optimise(const double *unary, const double *tcosts, const int32_t *triplets, int32_t N, int32_t L, int32_t T, double mcparam,
+                      int32_t iters, uint64_t seed, int32_t *labeling);
+
+/* ------------------------------------------------------------------------------------------------
  * discrete cost function.  Replaces NonLinearSRegDiscreteCostFunction and its five subclasses
  * (M/DiscreteCostFunction.h:83-283) behind the DiscreteCostFunction evaluator interface
  * (M/DiscreteCostFunction.h:41-59) the optimisers call.

@@ -206,6 +206,12 @@ class Mesh:
         check(lib().msm_mesh_get_coords(self.h, out.ctypes.data_as(c_dp)))
         return np.ascontiguousarray(out.T)
 
+    def unfold(self, radius=100.0):
+        """unfold (M/reg_tools.cpp:131-178) on the current coordinates; returns (passes, folded vertices of the first pass)."""
+        passes, first = C.c_int32(), C.c_int32()
+        check(lib().msm_mesh_unfold(self.h, float(radius), C.byref(passes), C.byref(first)))
+        return passes.value, first.value
+
     def set_pvalues(self, feat):
         f, pf = _d(np.atleast_2d(feat))
         assert f.shape[1] == self.V
@@ -281,6 +287,27 @@ def smooth_data(orig_mesh, data, sph_low, sigma, excl=None):
     eo = np.zeros(sph_low.V)
     check(lib().msm_smooth_data(orig_mesh.h, pd, d.shape[0], sph_low.h, float(sigma), pe, out.ctypes.data_as(c_dp), eo.ctypes.data_as(c_dp)))
     return out, eo
+
+
+def variance_normalise(data, excl=None):
+    """variance_normalise (M/reg_tools.cpp:804-843) of a D x V matrix; returns the normalised copy."""
+    out = np.array(np.atleast_2d(data), dtype=np.float64, order="C")
+    pe = _d(excl)[1] if excl is not None else None
+    check(lib().msm_variance_normalise(out.ctypes.data_as(c_dp), out.shape[0], out.shape[1], pe))
+    return out
+
+
+def mcmc_optimise(unary, tcosts, triplets, labeling, mcparam=0.8, iters=100, seed=0):
+    """MCMC::optimise (M/mcmc_opt.h:31-134) over the unary (L x N) and triplet (T x L x L x L) tables; returns the new labeling."""
+    U, pu = _d(unary)
+    L, N = U.shape
+    tc, ptc = _d(tcosts)
+    tr = np.ascontiguousarray(triplets, dtype=np.int32)
+    T = tr.shape[0]
+    assert tc.size == T * L ** 3
+    lab = np.array(labeling, dtype=np.int32)
+    check(lib().msm_mcmc_optimise(pu, ptc, tr.ctypes.data_as(c_ip), N, L, T, float(mcparam), int(iters), int(seed), lab.ctypes.data_as(c_ip)))
+    return lab
 
 
 def nearest_neighbour_interpolation(orig_mesh, data, q):

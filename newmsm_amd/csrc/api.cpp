@@ -495,7 +495,7 @@ void msm_mesh_destroy(msm_mesh *m) {
     if (!m) return;
     (void)hipSetDevice(m->ctx->device);
     (void)hipStreamSynchronize(m->ctx->stream);
-    for (void *p : {(void *)m->d_xyz, (void *)m->d_tri, (void *)m->d_tcone, (void *)m->d_feat, (void *)m->d_node, (void *)m->d_parent, (void *)m->d_leaf_tri, (void *)m->d_cone, (void *)m->d_rec, (void *)m->d_grid, (void *)m->d_nodebox, (void *)m->d_mask, (void *)m->d_ray_cell, (void *)m->d_ray_edge, (void *)m->d_ray_tri, (void *)m->d_ray_more, (void *)m->d_ray_excl})
+    for (void *p : {(void *)m->d_xyz, (void *)m->d_tri, (void *)m->d_tcone, (void *)m->d_feat, (void *)m->d_node, (void *)m->d_parent, (void *)m->d_leaf_tri, (void *)m->d_cone, (void *)m->d_rec, (void *)m->d_grid, (void *)m->d_nodebox, (void *)m->d_mask, (void *)m->d_ray_cell, (void *)m->d_ray_edge, (void *)m->d_ray_tri, (void *)m->d_ray_more, (void *)m->d_ray_excl, (void *)m->d_tid_ptr, (void *)m->d_tid, (void *)m->d_fold})
         if (p) (void)hipFree(p);
     delete m;
 }

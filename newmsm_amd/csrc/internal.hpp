@@ -157,6 +157,8 @@ struct msm_mesh {
     size_t cap_node = 0, cap_parent = 0, cap_box = 0, cap_leaf = 0, cap_cone = 0, cap_rec = 0, cap_grid = 0, cap_mask = 0;  // one per buffer
     msm::Adjacency adj;
     bool adj_valid = false;
+    int32_t *d_tid_ptr = nullptr, *d_tid = nullptr;  // Mpoint::trID lists as CSR (unfold's fold test)
+    int32_t *d_fold = nullptr;                       // [0] folded count, [1] vertices without a triangle, then V flags
 };
 
 namespace msm {

@@ -411,6 +411,38 @@ int launch_label_rotations(msm_ctx *ctx, const double *d_cp, int N, const double
 }
 
 // ------------------------------------------------------------------------------------------------
+// check_for_intersections, M/reg_tools.cpp:118-129: a vertex is folded when the normal of its first triangle and the
+// normal of any of its triangles have a dot product <= 0.5.  One thread per vertex; the normals are recomputed per
+// vertex (Triangle::normal, same operation order as the host pass that moves the folded vertices).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_fold_detect(const double *__restrict__ xyz, int V, const int32_t *__restrict__ tri, int T,
+                                                      const int32_t *__restrict__ tid_ptr, const int32_t *__restrict__ tid, int32_t *__restrict__ fold) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= V) return;
+    auto normal_of = [&](int t) {
+        const int a = tri[t], b = tri[T + t], c = tri[2 * T + t];
+        return tri_normal(mk(xyz[a], xyz[V + a], xyz[2 * V + a]), mk(xyz[b], xyz[V + b], xyz[2 * V + b]), mk(xyz[c], xyz[V + c], xyz[2 * V + c]));
+    };
+    const int b = tid_ptr[i], e = tid_ptr[i + 1];
+    int folded = 0;
+    if (b == e) {
+        atomicAdd(fold + 1, 1);
+    } else {
+        const V3 n0 = normal_of(tid[b]);
+        for (int k = b; k < e; ++k) folded |= dot(n0, normal_of(tid[k])) <= 0.5;
+        if (folded) atomicAdd(fold, 1);
+    }
+    fold[2 + i] = folded;
+}
+
+int launch_fold_detect(msm_ctx *ctx, const double *d_xyz, int V, const int32_t *d_tri, int T, const int32_t *d_tid_ptr, const int32_t *d_tid, int32_t *d_fold) {
+    MSM_HIP(hipMemsetAsync(d_fold, 0, 2 * sizeof(int32_t), ctx->stream));
+    hipLaunchKernelGGL(k_fold_detect, dim3((V + 255) / 256), dim3(256), 0, ctx->stream, d_xyz, V, d_tri, T, d_tid_ptr, d_tid, d_fold);
+    MSM_HIP(hipGetLastError());
+    return MSM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // launch wrappers
 // ------------------------------------------------------------------------------------------------
 static inline int grid_for(int n, int block, int cap) {

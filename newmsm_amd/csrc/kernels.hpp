@@ -17,6 +17,8 @@ int launch_closest_vertex(msm_ctx *ctx, const DevTree &T, const double *d_q, int
 // smooth_data: unit vectors of the N vertices (d_unit: 3 x N scratch), then one wavefront per output vertex
 int launch_smooth(msm_ctx *ctx, const double *d_xyz, int N, double *d_unit, const int *d_cv, const double *d_data, int Vorig, int D, double sigma,
                   double cosang, const double *d_excl, double *d_out, double *d_excl_out);
+// check_for_intersections (M/reg_tools.cpp:118-129) of every vertex: fold[0] += folded, fold[1] += vertices without a triangle, fold[2 + v] = folded
+int launch_fold_detect(msm_ctx *ctx, const double *d_xyz, int V, const int32_t *d_tri, int T, const int32_t *d_tid_ptr, const int32_t *d_tid, int32_t *d_fold);
 int launch_range(msm_ctx *ctx, const double *d_cp, int Ncp, const double *d_src, int Nsrc, const double *d_maxsep, double range, int cap,
                  uint32_t *d_slots, int *d_counts);
 

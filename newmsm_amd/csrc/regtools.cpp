@@ -1,0 +1,188 @@
+// regtools.cpp -- the callers' side of one registration iteration that touches the meshes of the path:
+// unfold (M/reg_tools.cpp:59-178; fold test on the GPU, the serial repair of the few folded vertices on the host in the
+// reference's order), variance_normalise (:804-843, host) and the Monte Carlo optimiser that consumes the unary and
+// triplet tables (M/mcmc_opt.h:31-134, host).
+#include <algorithm>
+#include <cmath>
+#include <random>
+
+#include "devbuf.hpp"
+#include "kernels.hpp"
+
+using namespace msm;
+
+namespace msm {
+const Adjacency &mesh_adjacency(msm_mesh *m);
+}
+
+namespace {
+
+struct FoldMesh {
+    double *x;  // 3 x V SoA
+    const int32_t *tri;
+    const Adjacency *adj;
+    int V, T;
+    V3 at(int v) const { return mk(x[v], x[V + v], x[2 * (size_t)V + v]); }
+    void set(int v, const V3 &p) {
+        x[v] = p.x;
+        x[V + v] = p.y;
+        x[2 * (size_t)V + v] = p.z;
+    }
+    V3 normal_of(int t) const { return tri_normal(at(tri[t]), at(tri[T + t]), at(tri[2 * (size_t)T + t])); }
+    // check_for_intersections, M/reg_tools.cpp:118-129
+    bool folded(int v) const {
+        const int b = adj->tid_ptr[v], e = adj->tid_ptr[v + 1];
+        const V3 n0 = normal_of(adj->tid[b]);
+        for (int k = b; k < e; ++k)
+            if (dot(n0, normal_of(adj->tid[k])) <= 0.5) return true;
+        return false;
+    }
+};
+
+V3 unit_or_zero(const V3 &a) { return norm(a) > 1e-10 ? normalized(a) : mk(0, 0, 0); }
+
+// computeGradientOfBarycentricTriangle over computeNormal2EdgeOfTriangle, M/reg_tools.cpp:59-93
+V3 area_gradient(const V3 &v0, const V3 &v1, const V3 &v2) {
+    const V3 s1 = unit_or_zero(sub(v2, v0)), s2 = unit_or_zero(sub(v1, v0));
+    const V3 n = unit_or_zero(cross(s1, s2));
+    V3 n2e = cross(s2, n);
+    if (dot(s1, n2e) < 0) n2e = scale(n2e, -1);
+    const double base = norm(sub(v1, v0));
+    return scale(scale(n2e, 0.5), base);
+}
+
+// spatialgradient, :95-116
+V3 spatial_gradient(const FoldMesh &m, int v) {
+    const V3 ci = m.at(v);
+    V3 grad = mk(0, 0, 0);
+    for (int k = m.adj->tid_ptr[v]; k < m.adj->tid_ptr[v + 1]; ++k) {
+        const int t = m.adj->tid[k];
+        const V3 v0 = m.at(m.tri[t]), v1 = m.at(m.tri[m.T + t]), v2 = m.at(m.tri[2 * (size_t)m.T + t]);
+        V3 dA;
+        if (norm(sub(ci, v0)) == 0) dA = area_gradient(v1, v2, v0);
+        else if (norm(sub(ci, v1)) == 0) dA = area_gradient(v2, v0, v1);
+        else dA = area_gradient(v0, v1, v2);
+        grad = mk(grad.x + dA.x, grad.y + dA.y, grad.z + dA.z);
+    }
+    return grad;
+}
+
+}  // namespace
+
+extern "C" {
+
+int msm_mesh_unfold(msm_mesh *m, double radius, int32_t *passes, int32_t *first_folded) {
+    if (!m) return fail(MSM_ERR_INVALID, "msm_mesh_unfold: null mesh");
+    msm_ctx *ctx = m->ctx;
+    MSM_HIP(hipSetDevice(ctx->device));
+    const int V = m->V, T = m->T;
+    const Adjacency &adj = mesh_adjacency(m);
+    if (!m->d_tid_ptr) {
+        MSM_HIP(hipMalloc((void **)&m->d_tid_ptr, sizeof(int32_t) * adj.tid_ptr.size()));
+        MSM_HIP(hipMalloc((void **)&m->d_tid, sizeof(int32_t) * std::max<size_t>(adj.tid.size(), 1)));
+        MSM_HIP(hipMalloc((void **)&m->d_fold, sizeof(int32_t) * (2 + (size_t)V)));
+        MSM_HIP(hipMemcpyAsync(m->d_tid_ptr, adj.tid_ptr.data(), sizeof(int32_t) * adj.tid_ptr.size(), hipMemcpyHostToDevice, ctx->stream));
+        if (!adj.tid.empty()) MSM_HIP(hipMemcpyAsync(m->d_tid, adj.tid.data(), sizeof(int32_t) * adj.tid.size(), hipMemcpyHostToDevice, ctx->stream));
+    }
+    if (passes) *passes = 0;
+    if (first_folded) *first_folded = 0;
+    std::vector<int32_t> flags;
+    std::vector<int> folded;
+    std::vector<V3> grads;
+    FoldMesh fm{m->xyz.data(), m->tri.data(), &adj, V, T};
+    for (int it = 0;; ++it) {
+        int st = launch_fold_detect(ctx, m->d_xyz, V, m->d_tri, T, m->d_tid_ptr, m->d_tid, m->d_fold);
+        if (st) return st;
+        int32_t head[2];
+        MSM_HIP(hipMemcpyAsync(head, m->d_fold, sizeof(head), hipMemcpyDeviceToHost, ctx->stream));
+        MSM_HIP(hipStreamSynchronize(ctx->stream));
+        if (head[1] > 0) return fail(MSM_ERR_INVALID, "get_triangle: index exceeds face dimensions");  // a vertex without triangles, R/mesh.h:82-86
+        if (it == 0 && first_folded) *first_folded = head[0];
+        if (head[0] == 0) break;  // the usual case: nothing is folded and nothing leaves the GPU but two counters
+        flags.resize(V);
+        MSM_HIP(hipMemcpyAsync(flags.data(), m->d_fold + 2, sizeof(int32_t) * (size_t)V, hipMemcpyDeviceToHost, ctx->stream));
+        MSM_HIP(hipStreamSynchronize(ctx->stream));
+        folded.clear();
+        for (int v = 0; v < V; ++v)
+            if (flags[v]) folded.push_back(v);
+        // gradients of all folded vertices first (:152-154), then the moves one by one, each test seeing the earlier moves
+        grads.resize(folded.size());
+        for (size_t k = 0; k < folded.size(); ++k) grads[k] = spatial_gradient(fm, folded[k]);
+        for (size_t k = 0; k < folded.size(); ++k) {
+            double step = 1.0;
+            const V3 ci = fm.at(folded[k]), g = grads[k];
+            V3 pp;
+            do {
+                pp = normalized(sub(ci, scale(g, step)));
+                fm.set(folded[k], scale(pp, radius));
+                step *= 0.5;
+            } while (fm.folded(folded[k]) && step > 1e-3);
+            fm.set(folded[k], scale(pp, radius));
+        }
+        m->tree_valid = false;
+        MSM_HIP(hipMemcpyAsync(m->d_xyz, m->xyz.data(), sizeof(double) * 3 * (size_t)V, hipMemcpyHostToDevice, ctx->stream));
+        if (passes) *passes = it + 1;
+        if (it + 1 == 1000) break;
+    }
+    MSM_HIP(hipStreamSynchronize(ctx->stream));
+    return MSM_OK;
+}
+
+int msm_variance_normalise(double *data, int32_t D, int32_t V, const double *excl) {
+    if (!data || D < 0 || V < 0) return fail(MSM_ERR_INVALID, "msm_variance_normalise: bad arguments");
+    for (int d = 0; d < D; ++d) {
+        double *row = data + (size_t)d * V;
+        double mean = 0.0, var = 0.0;
+        size_t n = 0;
+        for (int i = 0; i < V; ++i) {
+            if (excl && !(excl[i] > 0.0)) continue;
+            const double delta = row[i] - mean;
+            mean += delta / (double)(n + 1);
+            var += delta * (row[i] - mean);
+            ++n;
+        }
+        var /= (double)(n - 1);  // unsigned, as _data[i].size() - 1 at :829
+        const double sd = std::sqrt(var);
+        for (int i = 0; i < V; ++i) {
+            if (excl && !(excl[i] > 0.0)) continue;
+            row[i] -= mean;
+            if (var > 0.0) row[i] /= sd;
+        }
+    }
+    return MSM_OK;
+}
+
+int msm_mcmc_optimise(const double *unary, const double *tcosts, const int32_t *triplets, int32_t N, int32_t L, int32_t T, double mcparam,
+                      int32_t iters, uint64_t seed, int32_t *labeling) {
+    if (!unary || !tcosts || !triplets || !labeling || N <= 0 || L <= 0 || T < 0 || iters < 0) return fail(MSM_ERR_INVALID, "msm_mcmc_optimise: bad arguments");
+    if (!(mcparam > 0.0 && mcparam <= 1.0)) return fail(MSM_ERR_INVALID, "msm_mcmc_optimise: the geometric distribution parameter must be in (0, 1]");
+    for (int i = 0; i < N; ++i)
+        if (labeling[i] < 0 || labeling[i] >= L) return fail(MSM_ERR_INVALID, "msm_mcmc_optimise: label of node %d out of range", i);
+    for (int64_t i = 0; i < 3 * (int64_t)T; ++i)
+        if (triplets[i] < 0 || triplets[i] >= N) return fail(MSM_ERR_INVALID, "msm_mcmc_optimise: triplet node out of range");
+    std::mt19937 gen((std::mt19937::result_type)seed);
+    std::geometric_distribution<> distribution(mcparam);
+    const size_t L2 = (size_t)L * L, L3 = L2 * L;
+    double costs[8];
+    for (int i = 0; i < iters; ++i)
+        for (int t = 0; t < T; ++t) {
+            int label;
+            do { label = distribution(gen); } while (label >= L);
+            const int node[3] = {triplets[3 * t], triplets[3 * t + 1], triplets[3 * t + 2]};
+            const int cur[3] = {labeling[node[0]], labeling[node[1]], labeling[node[2]]};
+            const double *tc = tcosts + (size_t)t * L3;
+            // costs[4a + 2b + c]: a/b/c = 1 takes the proposed label for node A/B/C (mcmc_opt.h:58-90)
+            for (int k = 0; k < 8; ++k) {
+                const int la = (k & 4) ? label : cur[0], lb = (k & 2) ? label : cur[1], lc = (k & 1) ? label : cur[2];
+                costs[k] = tc[(size_t)la * L2 + (size_t)lb * L + lc] +
+                           (unary[(size_t)la * N + node[0]] + unary[(size_t)lb * N + node[1]] + unary[(size_t)lc * N + node[2]]) / 3.0;
+            }
+            const int best = (int)(std::min_element(costs, costs + 8) - costs);
+            if (best & 4) labeling[node[0]] = label;
+            if (best & 2) labeling[node[1]] = label;
+            if (best & 1) labeling[node[2]] = label;
+        }
+    return MSM_OK;
+}
+
+}  // extern "C"

@@ -111,6 +111,13 @@ int  orc_smooth_data(const orc_mesh *orig, const double *data, int D, const orc_
 /* nearest_neighbour_interpolation (:232-258) without exclusion */
 int  orc_nearest_neighbour(const orc_mesh *orig, const double *data, int D, const double *q, int N, double *out);
 
+/* ------------------------------------------------------------------ mesh utilities around the path (M/reg_tools.cpp) */
+/* unfold (:131-178) on the mesh's coordinates, in place.  Returns the number of passes that moved vertices (0: not
+ * folded), -1 if a vertex has no triangle.  *first_folded (optional): folded vertices found by the first pass. */
+int  orc_unfold(orc_mesh *m, double rad, int *first_folded);
+/* variance_normalise (:804-843): data D x V in place, excl (length V, > 0 keeps) may be NULL */
+void orc_variance_normalise(double *data, int D, int V, const double *excl);
+
 /* ------------------------------------------------------------------ similarity (M/similarities.cpp) */
 double orc_corr_weighted(const double *A, const double *B, const double *w, int n);
 double orc_ssd_weighted(const double *A, const double *B, const double *w, int n);

@@ -249,6 +249,26 @@ def smooth_data(orig_mesh, data, sph_low, sigma, excl=None):
     return (out, eo) if excl is not None else out
 
 
+def unfold(mesh, rad=100.0):
+    """unfold (reg_tools.cpp:131-178) on the mesh's coordinates in place; returns (passes, folded vertices of the first pass)."""
+    L = lib()
+    L.orc_mesh_coords.restype = c_dp
+    first = C.c_int()
+    passes = L.orc_unfold(mesh.h, C.c_double(rad), C.byref(first))
+    if passes < 0:
+        raise RuntimeError("get_triangle: index exceeds face dimensions")
+    mesh.xyz = np.ctypeslib.as_array(L.orc_mesh_coords(mesh.h), (mesh.V, 3)).copy()
+    return passes, first.value
+
+
+def variance_normalise(data, excl=None):
+    """variance_normalise (reg_tools.cpp:804-843) of a D x V matrix; returns the normalised copy."""
+    out = np.array(np.atleast_2d(data), dtype=np.float64, order="C")
+    pe = _d(excl)[1] if excl is not None else None
+    lib().orc_variance_normalise(out.ctypes.data_as(c_dp), out.shape[0], out.shape[1], pe)
+    return out
+
+
 # ---------------------------------------------------------------- discrete model host logic
 def cp_spacings(cp_mesh):
     ms = np.zeros(cp_mesh.V)

@@ -82,3 +82,52 @@ def test_top_down_octree_equals_incremental_insertion(built, monkeypatch, order,
     assert fast == serial == literal
     if shape == "regular" and order == 6:
         assert fast[0] == dict(nodes=14281, leaves=12496, depth=6, refs=176096, max_leaf=49)  # SURVEY.md section 8 [probe]
+
+
+def test_variance_normalise_matches_oracle(built):
+    """variance_normalise (M/reg_tools.cpp:804-843): the serial mean / variance recurrence, with and without exclusion"""
+    rng = np.random.default_rng(5)
+    data = rng.normal(2.0, 3.0, size=(3, 642))
+    data[2] = 7.0  # zero variance: centred, not scaled
+    excl = (rng.random(642) > 0.25).astype(float)
+    for e in (None, excl):
+        got, want = M.variance_normalise(data, e), O.variance_normalise(data, e)
+        assert np.array_equal(got, want)
+        keep = np.ones(642, bool) if e is None else e > 0
+        assert np.allclose(got[:2, keep].mean(axis=1), 0, atol=1e-12) and np.allclose(got[:2, keep].std(axis=1, ddof=1), 1)
+        assert np.array_equal(got[2, keep], np.zeros(keep.sum())) and np.array_equal(got[:, ~keep], data[:, ~keep])
+
+
+def mcmc_problem(N, L, triplets, seed):
+    rng = np.random.default_rng(seed)
+    return rng.random((L, N)), rng.random((len(triplets), L, L, L)), np.asarray(triplets, dtype=np.int32)
+
+
+def mcmc_energy(U, tc, tr, lab):
+    e = sum(tc[t, lab[a], lab[b], lab[c]] + (U[lab[a], a] + U[lab[b], b] + U[lab[c], c]) / 3.0 for t, (a, b, c) in enumerate(tr))
+    return float(e)
+
+
+def test_mcmc_optimise_properties(built):
+    """MCMC::optimise (M/mcmc_opt.h:31-134): each visit keeps the cheapest of the eight label combinations of one triplet, so
+    with disjoint triplets the energy over the triplets never rises; the run is a pure function of the seed."""
+    tr = np.arange(30, dtype=np.int32).reshape(10, 3)
+    U, tc, tr = mcmc_problem(30, 7, tr, seed=1)
+    lab0 = np.zeros(30, dtype=np.int32)
+    assert np.array_equal(M.mcmc_optimise(U, tc, tr, lab0, iters=0), lab0)
+    prev, energies = lab0, [mcmc_energy(U, tc, tr, lab0)]
+    for sweeps in (1, 3, 10, 200):
+        lab = M.mcmc_optimise(U, tc, tr, lab0, mcparam=0.3, iters=sweeps, seed=11)
+        assert lab.min() >= 0 and lab.max() < 7
+        energies.append(mcmc_energy(U, tc, tr, lab))
+        prev = lab
+    assert all(b <= a + 1e-15 for a, b in zip(energies, energies[1:])) and energies[-1] < energies[0]
+    assert np.array_equal(prev, M.mcmc_optimise(U, tc, tr, lab0, mcparam=0.3, iters=200, seed=11))
+    # one triplet, two labels: the single visit that proposes label 1 must pick the arg-min of the 8 combinations (first on ties)
+    U1, tc1, tr1 = mcmc_problem(3, 2, [[0, 1, 2]], seed=3)
+    combos = [tc1[0, a, b, c] + (U1[a, 0] + U1[b, 1] + U1[c, 2]) / 3.0 for a in (0, 1) for b in (0, 1) for c in (0, 1)]
+    best = int(np.argmin(combos))
+    lab = M.mcmc_optimise(U1, tc1, tr1, np.zeros(3, np.int32), mcparam=0.5, iters=50, seed=0)
+    assert list(lab) == [best >> 2 & 1, best >> 1 & 1, best & 1]
+    with pytest.raises(M.MsmError):
+        M.mcmc_optimise(U, tc, tr, np.full(30, 7, np.int32))
