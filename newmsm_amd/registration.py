@@ -1,0 +1,182 @@
+"""One resolution level of a pairwise discrete registration, as the reference's callers drive the hot path:
+
+    Mesh_registration::run_discrete_opt                 M/mesh_registration.cpp:164-232
+    NonLinearSRegDiscreteModel::Initialize              M/DiscreteModel.cpp:63-108
+    NonLinearSRegDiscreteModel::setupCostFunction       M/DiscreteModel.cpp:216-262
+    NonLinearSRegDiscreteModel::applyLabeling           M/DiscreteModel.cpp:264-269
+    MCMC::optimise                                      M/mcmc_opt.h:31-134   (the optimiser without a licence restriction)
+
+The loop itself is caller logic; everything it calls goes through an `ops` object.  `ProductOps` (below) maps the calls to
+libmsmhip through the C ABI; the parity tests pass an oracle-backed object with the same methods, so that the two runs
+differ in nothing but the implementation of the path (tests/helpers.py, tests/test_gpu_registration.py).
+"""
+import time
+
+import numpy as np
+
+from . import api
+
+RAD = 100.0  # M/reg_tools.h
+
+
+class ProductOps:
+    """The calls of the level loop on the MI355X path (every method is one or two C-ABI calls)."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+
+    # --- meshes
+    def icosphere(self, order):
+        return api.make_mesh_from_icosa(order)
+
+    def mesh(self, xyz, tri, feat=None):
+        m = api.Mesh(self.ctx, xyz, tri)
+        if feat is not None:
+            m.set_pvalues(feat)
+        return m
+
+    def set_coords(self, mesh, xyz):
+        mesh.set_coords(xyz)
+
+    def coords(self, mesh):
+        return mesh.get_coords()
+
+    def unfold(self, mesh):
+        return mesh.unfold(RAD)
+
+    def sphere_project_warp(self, sphere_xyz, from_mesh, to_xyz):
+        return api.sphere_project_warp(sphere_xyz, from_mesh, to_xyz)
+
+    # --- model host logic
+    def cp_spacings(self, mesh, xyz, tri):
+        return api.cp_spacings(xyz, tri)
+
+    def estimate_triplets(self, mesh, tri):
+        return api.estimate_triplets(tri)
+
+    def label_sampling_grid(self, sg_order, max_dist):
+        return api.label_sampling_grid(sg_order, max_dist)
+
+    def rescale_sampling_grid(self, samples, scale):
+        return api.rescale_sampling_grid(samples, scale)
+
+    def cp_rotations(self, centre, cp_xyz):
+        return api.cp_rotations(centre, cp_xyz)
+
+    # --- cost function
+    def cost(self, kind, simmeasure, rmode, params, target, source, cpgrid, src_feat):
+        cf = api.DiscreteCostFunction(self.ctx, kind=kind, simmeasure=simmeasure, rmode=rmode, **params)
+        cf.set_meshes(target, source, cpgrid)
+        cf.set_featurespace(src_feat)
+        return _ProductCost(cf)
+
+    def mcmc(self, unary, tcosts, triplets, labeling, mcparam, iters, seed):
+        return api.mcmc_optimise(unary, tcosts, triplets, labeling, mcparam=mcparam, iters=iters, seed=seed)
+
+
+class _ProductCost:
+    def __init__(self, cf):
+        self.cf = cf
+
+    def reset_source(self, mesh):
+        self.cf.reset_source(mesh)
+
+    def reset_cpgrid(self, mesh):
+        self.cf.reset_CPgrid(mesh)
+
+    def set_spacings(self, maxsep, mvdmax):
+        self.cf.set_spacings(maxsep, mvdmax)
+
+    def set_labels(self, labels, rot):
+        self.cf.set_labels(labels, rot)
+
+    def set_triplets(self, triplets):
+        self.cf.setTriplets(triplets)
+
+    def get_source_data(self):
+        self.cf.get_source_data()
+
+    def unary_table(self):
+        return self.cf.computeUnaryCosts()
+
+    def triplet_table(self):
+        return self.cf.computeTripletCosts()
+
+    def total(self, labeling):
+        return self.cf.evaluateTotalCostSum(labeling)[0]
+
+
+def apply_labeling(rot, labels, labeling):
+    """m_CPgrid.set_coord(i, m_ROT[i] * m_labels[labeling[i]]), operator*(Matrix, Point) R/point.cpp:207-213 (row sums left to right)"""
+    R = np.asarray(rot).reshape(-1, 3, 3)
+    v = np.asarray(labels)[np.asarray(labeling)]
+    return R[:, :, 0] * v[:, None, 0] + R[:, :, 1] * v[:, None, 1] + R[:, :, 2] * v[:, None, 2]
+
+
+def run_discrete_level(ops, target_xyz, target_tri, ref_feat, source_xyz, source_tri, src_feat, sph_reg, cp_order, *, sg_order=None,
+                       iters=3, mciters=200, mcparam=0.8, seed=0, kind="univariate", simmeasure=2, rmode=3, labeldist=0.5,
+                       rescale_labels=False, cost_params=None, timings=None):
+    """Runs `iters` iterations of run_discrete_opt with the Monte Carlo optimiser for one level.
+
+    target / source: the reference and the moving sphere at the data resolution of this level (source_xyz = the sphere the
+    moving features live on, sph_reg = its current registered position).  Returns (sph_reg, cp_xyz, energies, labelings).
+    `timings` (optional dict) accumulates wall-clock seconds per phase."""
+    if sg_order is None:
+        sg_order = cp_order + 2
+    cost_params = dict(cost_params or {})
+    clock = timings if timings is not None else {}
+
+    def timed(name, fn, *a):
+        t0 = time.perf_counter()
+        out = fn(*a)
+        clock[name] = clock.get(name, 0.0) + time.perf_counter() - t0
+        return out
+
+    # --- initialize_level / Initialize(CONTROL)
+    cp_xyz, cp_tri = ops.icosphere(cp_order)
+    target = ops.mesh(target_xyz, target_tri, ref_feat)
+    source = ops.mesh(source_xyz, source_tri)
+    cpgrid = ops.mesh(cp_xyz, cp_tri)
+    maxsep, mvdmax = ops.cp_spacings(cpgrid, cp_xyz, cp_tri)
+    samples, barycentres = ops.label_sampling_grid(sg_order, labeldist * mvdmax)
+    centre = samples[0]
+    triplets = ops.estimate_triplets(cpgrid, cp_tri)
+    cost = ops.cost(kind, simmeasure, rmode, cost_params, target, source, cpgrid, src_feat)  # set_meshes: _ORIG, _oCPgrid
+    cost.set_spacings(maxsep, mvdmax)
+    m_iter, m_scale = 1, 1.0
+    energies, labelings = [], []
+    sph_reg = np.array(sph_reg, dtype=np.float64)
+    for it in range(iters):
+        # --- reset_meshspace + setupCostFunction
+        ops.set_coords(source, sph_reg)
+        cost.reset_source(source)
+        ops.set_coords(cpgrid, cp_xyz)
+        cost.reset_cpgrid(cpgrid)
+        rot = ops.cp_rotations(centre, cp_xyz)
+        if rescale_labels:
+            labels, m_scale = ops.rescale_sampling_grid(samples, m_scale)
+        elif m_iter % 2 == 0:
+            labels = samples
+        else:
+            labels = barycentres
+        cost.set_labels(labels, rot)
+        timed("get_source_data", cost.get_source_data)
+        cost.set_triplets(triplets)
+        m_iter += 1
+        # --- MCMC: computeUnaryCosts, computeTripletCosts, optimise
+        unary = timed("unary_table", cost.unary_table)
+        tcosts = timed("triplet_table", cost.triplet_table)
+        labeling = np.zeros(len(cp_xyz), dtype=np.int32)  # resetLabeling
+        labeling = timed("optimiser", ops.mcmc, unary, tcosts, triplets, labeling, mcparam, mciters, seed + it)
+        energies.append(timed("total_cost", cost.total, labeling))
+        labelings.append(labeling)
+        # --- applyLabeling, warp the source through the control grid move, unfold both
+        new_cp = apply_labeling(rot, labels, labeling)
+        sph_reg = timed("sphere_project_warp", ops.sphere_project_warp, sph_reg, cpgrid, new_cp)  # cpgrid still holds the previous grid
+        ops.set_coords(cpgrid, new_cp)
+        timed("unfold", ops.unfold, cpgrid)
+        cp_xyz = ops.coords(cpgrid)
+        ops.set_coords(source, sph_reg)
+        timed("unfold", ops.unfold, source)
+        sph_reg = ops.coords(source)
+    return sph_reg, cp_xyz, energies, labelings

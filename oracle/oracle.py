@@ -426,6 +426,12 @@ class Cost:
     def triplet(self, t, la, lb, lc):
         return lib().orc_cost_triplet(self.h, int(t), int(la), int(lb), int(lc))
 
+    def triplet_table(self, t0=0, t1=None):
+        t1 = self.T if t1 is None else t1
+        out = np.zeros((t1 - t0, self.L, self.L, self.L))
+        lib().orc_cost_triplet_table(self.h, int(t0), int(t1), out.ctypes.data_as(c_dp))
+        return out
+
     def pairwise(self, p, la, lb):
         return lib().orc_cost_pairwise(self.h, int(p), int(la), int(lb))
 

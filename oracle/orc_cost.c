@@ -830,3 +830,13 @@ double orc_cost_total(orc_cost *c, const int *labeling, double parts[3]) {
     }
     return u + pw + tc;
 }
+
+/* computeTripletCosts, M/DiscreteCostFunction.cpp:245-253: tcosts[t][a][b][c] for t0 <= t < t1 */
+void orc_cost_triplet_table(orc_cost *c, int t0, int t1, double *out) {
+    const int L = c->L;
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int t = t0; t < t1; ++t)
+        for (int a = 0; a < L; ++a)
+            for (int b = 0; b < L; ++b)
+                for (int l = 0; l < L; ++l) out[(((size_t)(t - t0) * L + a) * L + b) * L + l] = orc_cost_triplet(c, t, a, b, l);
+}

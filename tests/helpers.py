@@ -52,3 +52,90 @@ def oracle_anatomy(cp_order=2, anat_order=4):
     return cxyz, ctri, axyz, atri, w_ptr, w_cp, w_val, face_ptr, face_idx
 
 
+
+
+class OracleOps:
+    """The calls of newmsm_amd.registration.run_discrete_level answered by the oracle (same methods as ProductOps), so that the
+    very same caller loop drives the CPU restatement.  `optimiser` is the caller's optimiser (not part of the path): the
+    tests pass the library's host-side Monte Carlo routine to both runs."""
+
+    def __init__(self, optimiser):
+        self.optimiser = optimiser
+
+    def icosphere(self, order):
+        return O.icosphere(order)
+
+    def mesh(self, xyz, tri, feat=None):
+        m = O.Mesh(xyz, tri)
+        m.feat = feat
+        return m
+
+    def set_coords(self, mesh, xyz):
+        mesh.set_coords(xyz)
+
+    def coords(self, mesh):
+        return np.array(mesh.xyz)
+
+    def unfold(self, mesh):
+        return O.unfold(mesh, 100.0)
+
+    def sphere_project_warp(self, sphere_xyz, from_mesh, to_xyz):
+        return O.sphere_project_warp(sphere_xyz, from_mesh, to_xyz)
+
+    def cp_spacings(self, mesh, xyz, tri):
+        return O.cp_spacings(mesh)
+
+    def estimate_triplets(self, mesh, tri):
+        return O.estimate_triplets(mesh)
+
+    def label_sampling_grid(self, sg_order, max_dist):
+        _, s, b = O.label_sampling_grid(O.Mesh(*O.icosphere(sg_order)), max_dist)
+        return s, b
+
+    def rescale_sampling_grid(self, samples, scale):
+        return O.rescale_sampling_grid(samples, scale)
+
+    def cp_rotations(self, centre, cp_xyz):
+        return O.cp_rotations(centre, cp_xyz)
+
+    def cost(self, kind, simmeasure, rmode, params, target, source, cpgrid, src_feat):
+        c = O.Cost(kind, simmeasure=simmeasure, rmode=rmode, **params)
+        c.set_meshes(target, O.Octree(target), source, cpgrid)
+        c.set_features(src_feat, target.feat)
+        c.set_pairs(np.zeros((0, 2), dtype=np.int32))
+        return _OracleCost(c)
+
+    def mcmc(self, unary, tcosts, triplets, labeling, mcparam, iters, seed):
+        return self.optimiser(unary, tcosts, triplets, labeling, mcparam=mcparam, iters=iters, seed=seed)
+
+
+class _OracleCost:
+    def __init__(self, c):
+        self.c = c
+
+    def reset_source(self, mesh):
+        self.c.reset_source(mesh)
+
+    def reset_cpgrid(self, mesh):
+        self.c.reset_cpgrid(mesh)
+
+    def set_spacings(self, maxsep, mvdmax):
+        self.c.set_spacings(maxsep, mvdmax)
+
+    def set_labels(self, labels, rot):
+        self.c.set_labels(labels, rot)
+
+    def set_triplets(self, triplets):
+        self.c.set_triplets(triplets)
+
+    def get_source_data(self):
+        self.c.get_source_data()
+
+    def unary_table(self):
+        return self.c.unary_table(threads=8)
+
+    def triplet_table(self):
+        return self.c.triplet_table()
+
+    def total(self, labeling):
+        return self.c.total(labeling)[0]
