@@ -217,6 +217,25 @@ inline Matrix nearest_neighbour_interpolation(Mesh &orig, const Matrix &data, co
     return out;
 }
 
+// ---------------------------------------------------------------- around one iteration (M/reg_tools.h, M/mcmc_opt.h)
+// unfold(SOURCE, verbosity), M/reg_tools.cpp:131-178, on the mesh's current coordinates; returns the passes that moved vertices
+inline int unfold(Mesh &SOURCE, double RAD = 100.0, int *first_folded = nullptr) {
+    int32_t passes = 0, first = 0;
+    check(msm_mesh_unfold(SOURCE.handle(), RAD, &passes, &first));
+    if (first_folded) *first_folded = first;
+    return passes;
+}
+// variance_normalise(DATA, EXCL), M/reg_tools.cpp:804-843: DATA D x V in place
+inline void variance_normalise(Matrix &DATA, int V, const std::vector<double> *EXCL = nullptr) {
+    check(msm_variance_normalise(DATA.data(), (int32_t)(DATA.size() / V), V, EXCL ? EXCL->data() : nullptr));
+}
+// MCMC::optimise, M/mcmc_opt.h:31-134, over the tables of getUnaryCosts() (L x N) and getTCosts() (T x L x L x L)
+inline void mcmc_optimise(const Matrix &unary_costs, const Matrix &tcosts, const std::vector<int32_t> &triplets, int num_nodes, int num_labels,
+                          double dist_param, int mciters, uint64_t seed, std::vector<int32_t> &labeling) {
+    check(msm_mcmc_optimise(unary_costs.data(), tcosts.data(), triplets.data(), num_nodes, num_labels, (int32_t)(triplets.size() / 3), dist_param,
+                            mciters, seed, labeling.data()));
+}
+
 // ---------------------------------------------------------------- discrete cost function
 struct Parameters {  // what set_parameters reads from the myparam map, M/DiscreteCostFunction.cpp:119-133
     int kind = MSM_COST_UNIVARIATE;

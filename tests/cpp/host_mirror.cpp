@@ -113,6 +113,16 @@ int main(int argc, char **argv) {
         // ---- and on the way out: resample the moving data to the target sphere (metric_resample, R/resampler.cpp:304-309)
         put(out, "resampled", metric_resample(SOURCE, in.f["src_feat"], TARGET));
 
+        // ---- after the optimiser: unfold the moved control grid (run_discrete_opt, M/mesh_registration.cpp:226-229)
+        CPGRID.set_coords(in.f["folded_cp"]);
+        int first_folded = 0;
+        const int passes = unfold(CPGRID, 100.0, &first_folded);
+        put(out, "unfold_counts", std::vector<int32_t>{passes, first_folded});
+        put(out, "unfolded_cp", CPGRID.get_coords());
+        Matrix normed = in.f["src_feat"];
+        variance_normalise(normed, (int)(sphere.size() / 3));
+        put(out, "normed", normed);
+
         // ---- error behaviour: the reference's exception text arrives in what()
         try {
             Parameters bad;

@@ -58,9 +58,13 @@ def test_cpp_host_mirror_against_oracle(built, tmp_path, D):
     T, L, N = len(inp["triplets"]), len(inp["labels"]), len(inp["cp_xyz"])
     tq = [rng.integers(0, T, 200), rng.integers(0, L, 200), rng.integers(0, L, 200), rng.integers(0, L, 200)]
     labeling = rng.integers(0, L, N)
+    folded_cp = np.array(inp["cp_orig_xyz"])
+    for v, n in ((10, 11), (40, 41), (90, 12)):  # three control points pushed across a neighbour
+        p = folded_cp[n] + 1.4 * (folded_cp[n] - folded_cp[v])
+        folded_cp[v] = p * 100.0 / np.linalg.norm(p)
     fin, fout = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
     write_bag(fin, orders=np.array([4, 2, D]), ref_feat=inp["ref_feat"], src_feat=inp["src_feat"], source_xyz=inp["source_xyz"],
-              labels=inp["labels"], samples0=inp["samples"][0], tq_t=tq[0], tq_a=tq[1], tq_b=tq[2], tq_c=tq[3], labeling=labeling)
+              labels=inp["labels"], samples0=inp["samples"][0], folded_cp=folded_cp, tq_t=tq[0], tq_a=tq[1], tq_b=tq[2], tq_c=tq[3], labeling=labeling)
     run = subprocess.run([EXE, fin, fout], capture_output=True, text=True, timeout=300)
     assert run.returncode == 0, run.stderr + run.stdout
     assert "expected error: Unknown similarity metric" in run.stdout
@@ -94,3 +98,7 @@ def test_cpp_host_mirror_against_oracle(built, tmp_path, D):
     assert abs(got["total"][0] - oc.total(labeling.astype(np.int32))[0]) <= 1e-9 * abs(got["total"][0])
     src = O.Mesh(inp["source_xyz"], inp["source_tri"])
     assert np.array_equal(got["resampled"].reshape(D, -1), O.metric_resample(src, inp["src_feat"], regular))
+    fm = O.Mesh(folded_cp, inp["cp_tri"])
+    assert tuple(got["unfold_counts"]) == O.unfold(fm) and got["unfold_counts"][1] >= 1
+    assert np.array_equal(got["unfolded_cp"].reshape(-1, 3), fm.xyz)
+    assert np.array_equal(got["normed"].reshape(D, -1), O.variance_normalise(inp["src_feat"]))
