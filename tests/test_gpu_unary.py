@@ -8,7 +8,8 @@ import numpy as np
 import pytest
 
 import newmsm_amd as M
-from newmsm_amd import problem
+from newmsm_amd import problem, synthetic
+from oracle import oracle as O
 from tests.helpers import oracle_cost
 
 pytestmark = pytest.mark.gpu
@@ -181,3 +182,28 @@ def test_randomised_configurations(ctx):
         both = np.isfinite(Uo)
         assert np.array_equal(np.isfinite(U), both), (k, kw)
         assert np.allclose(U[both], Uo[both], rtol=RTOL, atol=ATOL), (k, kw, np.nanmax(np.abs(U - Uo)))
+
+
+def test_larger_than_baseline_ico7(ctx):
+    """one resolution above BASELINE (ico7 data: 163 842 vertices / 327 680 triangles, ico5 control grid: 10 242 control points,
+    12.7 M point samples per table): searches bit-exact on a sample of queries, table spot-checked against the oracle"""
+    inp = problem.pairwise_inputs(7, 5, D=1)
+    cf, keep = problem.build_cost(ctx, inp, kind="univariate")
+    cf.get_source_data()
+    ptr, idx = cf.patches()
+    assert len(ptr) == 10243 and np.diff(ptr).min() >= 40
+    U = cf.computeUnaryCosts()
+    assert U.shape == (len(inp["labels"]), 10242) and np.isfinite(U).all()
+    assert (U >= -1e-12).all() and (U <= 1.0 + 1e-9).all()
+    assert cf.counters()["samples"] == len(inp["labels"]) * int(ptr[-1])
+    oc = oracle_cost(inp, "univariate")
+    oc.get_source_data()
+    optr, oidx = oc.patches()
+    assert np.array_equal(ptr, optr) and np.array_equal(idx, oidx)
+    rng = np.random.default_rng(2)
+    for n, l in zip(rng.integers(0, 10242, 30), rng.integers(0, len(inp["labels"]), 30)):
+        assert abs(U[l, n] - oc.unary(n, l)) <= ATOL + RTOL * abs(U[l, n])
+    q = synthetic.random_sphere_points(20000, seed=4)
+    st, t, vid, w = keep["target"].query_triangles(q)
+    ost, ot, ovid, ow = O.Octree(O.Mesh(inp["target_xyz"], inp["target_tri"])).barycentric_weights(q)
+    assert st == ost == 0 and np.array_equal(t, ot) and np.array_equal(vid, ovid) and np.array_equal(w, ow)
