@@ -47,6 +47,16 @@ class ProductOps:
     def sphere_project_warp(self, sphere_xyz, from_mesh, to_xyz):
         return api.sphere_project_warp(sphere_xyz, from_mesh, to_xyz)
 
+    # --- featurespace::initialise
+    def metric_resample(self, in_mesh, data, new_mesh):
+        return api.metric_resample(in_mesh, data, new_mesh)
+
+    def smooth_data(self, mesh, data, sigma):
+        return api.smooth_data(mesh, data, mesh, sigma)
+
+    def variance_normalise(self, data):
+        return api.variance_normalise(data)
+
     # --- model host logic
     def cp_spacings(self, mesh, xyz, tri):
         return api.cp_spacings(xyz, tri)
@@ -115,12 +125,13 @@ def apply_labeling(rot, labels, labeling):
 
 def run_discrete_level(ops, target_xyz, target_tri, ref_feat, source_xyz, source_tri, src_feat, sph_reg, cp_order, *, sg_order=None,
                        iters=3, mciters=200, mcparam=0.8, seed=0, kind="univariate", simmeasure=2, rmode=3, labeldist=0.5,
-                       rescale_labels=False, cost_params=None, timings=None):
+                       rescale_labels=False, cost_params=None, timings=None, cp_start=None):
     """Runs `iters` iterations of run_discrete_opt with the Monte Carlo optimiser for one level.
 
     target / source: the reference and the moving sphere at the data resolution of this level (source_xyz = the sphere the
     moving features live on, sph_reg = its current registered position).  Returns (sph_reg, cp_xyz, energies, labelings).
-    `timings` (optional dict) accumulates wall-clock seconds per phase."""
+    `timings` (optional dict) accumulates wall-clock seconds per phase.  cp_start: the control grid after warp_CPgrid (the
+    warp of the previous level applied to it); the regular grid when None."""
     if sg_order is None:
         sg_order = cp_order + 2
     cost_params = dict(cost_params or {})
@@ -146,6 +157,8 @@ def run_discrete_level(ops, target_xyz, target_tri, ref_feat, source_xyz, source
     m_iter, m_scale = 1, 1.0
     energies, labelings = [], []
     sph_reg = np.array(sph_reg, dtype=np.float64)
+    if cp_start is not None:
+        cp_xyz = np.array(cp_start, dtype=np.float64)
     for it in range(iters):
         # --- reset_meshspace + setupCostFunction
         ops.set_coords(source, sph_reg)
@@ -180,3 +193,62 @@ def run_discrete_level(ops, target_xyz, target_tri, ref_feat, source_xyz, source
         timed("unfold", ops.unfold, source)
         sph_reg = ops.coords(source)
     return sph_reg, cp_xyz, energies, labelings
+
+
+def run_multiresolution(ops, in_xyz, in_tri, in_data, ref_xyz, ref_tri, ref_data, levels, *, varnorm=False, timings=None, **level_kw):
+    """Mesh_registration::run_multiresolutions (M/mesh_registration.cpp:30-50) for DISCRETE levels without file I/O:
+
+    per level  featurespace::initialise (M/featurespace.cpp:39-86: metric_resample of both data sets onto the level's
+               icosphere, smooth_data, variance_normalise), project_CPgrid (M/mesh_registration.cpp:131-162: the warp of the
+               previous level carried to the new data grid and control grid, unfold) and run_discrete_opt;
+    at the end transform (:352-356): the input sphere moved through the final warp ("sphere.reg").
+
+    in_* / ref_*: the input and reference spheres (radius 100) with their D x V data.  levels: dicts with data_order, cp_order
+    and optionally sg_order, sigma_in, sigma_ref, iters, mciters, cost_params.  recentre() of the regular spheres
+    (a shift of ~1e-15) is not applied.  Returns (sphere_reg, per-level registered data grids, per-level energies)."""
+    clock = timings if timings is not None else {}
+
+    def timed(name, fn, *a):
+        t0 = time.perf_counter()
+        out = fn(*a)
+        clock[name] = clock.get(name, 0.0) + time.perf_counter() - t0
+        return out
+
+    in_xyz = np.asarray(in_xyz, dtype=np.float64)
+    in_mesh, ref_mesh = ops.mesh(in_xyz, in_tri), ops.mesh(ref_xyz, ref_tri)
+    sph_reg_prev, prev_order, regs, all_energies = None, None, [], []
+    for lv in levels:
+        ico_xyz, ico_tri = ops.icosphere(lv["data_order"])
+        ico = ops.mesh(ico_xyz, ico_tri)
+        feats = []
+        for mesh, data, sigma in ((in_mesh, in_data, lv.get("sigma_in", 0.0)), (ref_mesh, ref_data, lv.get("sigma_ref", 0.0))):
+            f = timed("metric_resample", ops.metric_resample, mesh, data, ico)
+            if sigma > 0.0:
+                f = timed("smooth_data", ops.smooth_data, ico, f, sigma)
+            if varnorm:
+                f = ops.variance_normalise(f)
+            feats.append(f)
+        cp_start = None
+        if sph_reg_prev is None:
+            sph_in = ico_xyz  # level 1, no transformed mesh: project_CPgrid only unfolds the (regular) data grid
+        else:
+            prev_xyz, prev_tri = ops.icosphere(prev_order)
+            incurrent = timed("sphere_project_warp", ops.sphere_project_warp, in_xyz, ops.mesh(prev_xyz, prev_tri), sph_reg_prev)
+            sph_in = timed("sphere_project_warp", ops.sphere_project_warp, ico_xyz, in_mesh, incurrent)
+            cp_xyz, cp_tri = ops.icosphere(lv["cp_order"])
+            cpm = ops.mesh(timed("sphere_project_warp", ops.sphere_project_warp, cp_xyz, in_mesh, incurrent), cp_tri)  # warp_CPgrid
+            timed("unfold", ops.unfold, cpm)
+            cp_start = ops.coords(cpm)
+        moved = ops.mesh(sph_in, ico_tri)
+        timed("unfold", ops.unfold, moved)
+        sph_in = ops.coords(moved)
+        kw = dict(level_kw)
+        kw.update({k: lv[k] for k in ("sg_order", "iters", "mciters", "cost_params", "kind", "rescale_labels") if k in lv})
+        sph_reg, _, energies, _ = run_discrete_level(ops, ico_xyz, ico_tri, feats[1], ico_xyz, ico_tri, feats[0], sph_in, lv["cp_order"],
+                                                     cp_start=cp_start, timings=clock, **kw)
+        regs.append(sph_reg)
+        all_energies.append(energies)
+        sph_reg_prev, prev_order = sph_reg, lv["data_order"]
+    last_xyz, last_tri = ops.icosphere(levels[-1]["data_order"])
+    sphere_reg = timed("sphere_project_warp", ops.sphere_project_warp, in_xyz, ops.mesh(last_xyz, last_tri), sph_reg_prev)
+    return sphere_reg, regs, all_energies

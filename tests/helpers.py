@@ -82,6 +82,15 @@ class OracleOps:
     def sphere_project_warp(self, sphere_xyz, from_mesh, to_xyz):
         return O.sphere_project_warp(sphere_xyz, from_mesh, to_xyz)
 
+    def metric_resample(self, in_mesh, data, new_mesh):
+        return O.metric_resample(in_mesh, data, new_mesh)
+
+    def smooth_data(self, mesh, data, sigma):
+        return O.smooth_data(mesh, data, mesh, sigma)
+
+    def variance_normalise(self, data):
+        return O.variance_normalise(data)
+
     def cp_spacings(self, mesh, xyz, tri):
         return O.cp_spacings(mesh)
 

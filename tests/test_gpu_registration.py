@@ -51,3 +51,22 @@ def test_level_improves_the_similarity(ctx):
     before = np.corrcoef(ref[0], src[0])[0, 1]
     after = np.corrcoef(ref[0], M.metric_resample(sm, src, tm)[0])[0, 1]
     assert 1.0 - after < 0.6 * (1.0 - before), (before, after)  # the smooth synthetic pattern starts at r = 0.99
+
+
+def test_two_levels_match_oracle(ctx):
+    """run_multiresolutions over two DISCRETE levels: resample + smooth + normalise the data per level, carry the warp of level 1
+    to the data grid and control grid of level 2 (project_CPgrid), register, and move the input sphere through the result"""
+    in_xyz, in_tri = M.make_mesh_from_icosa(5)
+    ref_xyz = in_xyz
+    ref = synthetic.features(ref_xyz, 2, 31)
+    src = synthetic.features(synthetic.known_warp(in_xyz, seed=33, rot_deg=4.0, amp=2.5), 2, 31)
+    levels = [dict(data_order=3, cp_order=1, sigma_in=4.0, sigma_ref=4.0, iters=2, mciters=40),
+              dict(data_order=4, cp_order=2, sigma_in=2.0, sigma_ref=0.0, iters=2, mciters=40)]
+    kw = dict(varnorm=True, mcparam=0.3, seed=9, kind="multivariate", cost_params=dict(lambda_=0.05))
+    got = registration.run_multiresolution(registration.ProductOps(ctx), in_xyz, in_tri, src, ref_xyz, in_tri, ref, levels, **kw)
+    want = registration.run_multiresolution(OracleOps(M.mcmc_optimise), in_xyz, in_tri, src, ref_xyz, in_tri, ref, levels, **kw)
+    assert np.allclose(np.concatenate(got[2]), np.concatenate(want[2]), rtol=1e-9)
+    for a, b in zip(got[1], want[1]):
+        assert np.abs(a - b).max() < 1e-9
+    assert angles(got[0], want[0]).max() <= NORTH_STAR_TOL_RAD and np.abs(got[0] - want[0]).max() < 1e-9
+    assert angles(got[0], in_xyz).max() > 1e-3
