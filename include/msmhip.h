@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MSM_ABI_VERSION 2
+#define MSM_ABI_VERSION 3
 
 #define MSM_OK 0
 #define MSM_ERR_INVALID (-1)  /* bad argument / inconsistent sizes */
