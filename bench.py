@@ -120,6 +120,9 @@ def main():
     inp = problem.pairwise_inputs(args.data_order, args.cp_order, D=args.dims, seed=1234 + 17 * rank)
     cf, keep = problem.build_cost(ctx, inp, kind=kind)
     cf.get_source_data()
+    # steady state of many tables against one target: have the target's direction table in place before the first step
+    # (by default it is built in the background while the complete search serves the first tables)
+    keep["target"].prepare_search(wait=True)
     ptr, _ = cf.patches()
     evals = cf.L * cf.N
     samples = cf.L * int(ptr[-1])

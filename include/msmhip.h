@@ -115,6 +115,13 @@ int       msm_mesh_set_features(msm_mesh *m, const double *feat, int32_t D); /* 
 int       msm_mesh_sizes(const msm_mesh *m, int32_t *V, int32_t *T, int32_t *D);
 /* [host part] stats[0]=nodes [1]=leaves [2]=max depth (root 0) [3]=triangle references [4]=largest leaf */
 int       msm_mesh_octree_stats(msm_mesh *m, int64_t stats[5]);
+/* Builds the search structures a cost function uses on this mesh as its target (octree, and for a closed star-shaped
+ * surface the direction table that settles most searches with one lookup).  The direction table takes tens of ms of
+ * host time, so by default it is built on a background thread when a cost function first evaluates against the mesh,
+ * and the complete octree search serves until it is ready -- with bit-identical results.  wait != 0 blocks until
+ * everything is in place (benchmarks, many evaluations against one target); wait == 0 only starts the work.
+ * *ready (optional) = 1 when nothing is pending.  MSMHIP_RAYTABLE=sync|off changes the default for all meshes. */
+int       msm_mesh_prepare_search(msm_mesh *m, int wait, int32_t *ready);
 
 /* ------------------------------------------------------------------------------------------------
  * resampler (R/resampler.h:38-53)

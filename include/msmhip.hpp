@@ -140,6 +140,12 @@ public:
         check(msm_mesh_get_coords(h_, s.data()));
         return to_aos(s);
     }
+    // target-side search structures now instead of in the background (msm_mesh_prepare_search)
+    bool prepare_search(bool wait = true) {
+        int32_t ready = 0;
+        check(msm_mesh_prepare_search(h_, wait ? 1 : 0, &ready));
+        return ready != 0;
+    }
     void set_pvalues(const Matrix &data) { check(msm_mesh_set_features(h_, data.data(), (int32_t)(data.size() / V_))); }  // D x V
     msm_mesh *handle() const { return h_; }
 

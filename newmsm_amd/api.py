@@ -206,6 +206,12 @@ class Mesh:
         check(lib().msm_mesh_get_coords(self.h, out.ctypes.data_as(c_dp)))
         return np.ascontiguousarray(out.T)
 
+    def prepare_search(self, wait=True):
+        """builds the target-side search structures (msm_mesh_prepare_search); returns True when nothing is pending"""
+        ready = C.c_int32()
+        check(lib().msm_mesh_prepare_search(self.h, int(bool(wait)), C.byref(ready)))
+        return bool(ready.value)
+
     def unfold(self, radius=100.0):
         """unfold (M/reg_tools.cpp:131-178) on the current coordinates; returns (passes, folded vertices of the first pass)."""
         passes, first = C.c_int32(), C.c_int32()

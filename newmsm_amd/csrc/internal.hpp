@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -124,6 +125,10 @@ struct msm_ctx {
     size_t io_cap = 0;
 };
 
+namespace msm {
+struct RayJob;
+}
+
 struct msm_mesh {
     msm_ctx *ctx = nullptr;
     int V = 0, T = 0, D = 0;
@@ -159,6 +164,11 @@ struct msm_mesh {
     bool adj_valid = false;
     int32_t *d_tid_ptr = nullptr, *d_tid = nullptr;  // Mpoint::trID lists as CSR (unfold's fold test)
     int32_t *d_fold = nullptr;                       // [0] folded count, [1] vertices without a triangle, then V flags
+    // background build of the ray table (api.cpp: ensure_rays): the job of the current tree, and finished-with jobs of
+    // earlier trees that are joined when the mesh goes
+    uint64_t tree_gen = 0;
+    std::shared_ptr<msm::RayJob> ray_job;
+    std::vector<std::shared_ptr<msm::RayJob>> stale_jobs;
 };
 
 namespace msm {
@@ -174,7 +184,7 @@ void vertex_areas_of(const double *xyz, const int32_t *tri, int V, int T, const 
 int install_coords_and_tree(msm_mesh *m, const double *xyz, FlatOctree &&tree);
 int ensure_tree(msm_mesh *m);  // build + upload the search structure if stale
 int ensure_masks(msm_mesh *m);  // + the per-leaf sub-cell masks the cost kernels use (built on the GPU)
-int ensure_rays(msm_mesh *m);   // + the ray table of a simple surface (unary table kernels)
+int ensure_rays(msm_mesh *m, bool wait = false);   // + the ray table of a simple surface (unary table kernels); see api.cpp
 DevTree dev_tree(const msm_mesh *m);
 int check_status(msm_ctx *ctx, const char *what);  // sync + read kernel status
 int ctx_io_pinned(msm_ctx *ctx, size_t bytes, void **out);  // grow-only pinned scratch for small per-call transfers

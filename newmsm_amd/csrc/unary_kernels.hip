@@ -1081,7 +1081,7 @@ void unary_fix_offsets(int N, int L, int pmax, const int32_t *pptr, const int32_
 
 static bool uses_ray_table(const DevTree &t) { return t.simple && t.ray_G > 0 && t.ray_cell && t.ray_tri; }
 
-static int launch_samples(msm_ctx *ctx, const UnaryLaunch &u, const UnaryWeightsScratch *w, SamplesArgs &a) {
+static int launch_samples(msm_ctx *ctx, const UnaryLaunch &u, const UnaryWeightsScratch *w, SamplesArgs &a, bool fused_reduction = false) {
     if (u.tree.nnodes <= 0 || !u.tree.mask) return fail(MSM_ERR_STATE, "target search structure missing");
     a.tree = u.tree;
     a.tfeat = u.tfeat;
@@ -1105,7 +1105,7 @@ static int launch_samples(msm_ctx *ctx, const UnaryLaunch &u, const UnaryWeights
     a.absw = u.absw;
     a.simmeasure = u.simmeasure;
     a.percentile = u.percentile;
-    a.U = w ? nullptr : u.U;  // the fused reduction is the univariate one
+    a.U = (w || !fused_reduction) ? nullptr : u.U;  // the fused reduction is the univariate one
     a.redo_list = u.redo_list;
     a.redo_count = u.fix_cnt;
     a.status = ctx->d_status;
@@ -1136,7 +1136,11 @@ static int launch_samples(msm_ctx *ctx, const UnaryLaunch &u, const UnaryWeights
 
 int launch_unary_univariate(msm_ctx *ctx, const UnaryLaunch &u) {
     SamplesArgs a;
-    int st = launch_samples(ctx, u, nullptr, a);
+    const bool dice = u.simmeasure == 4 || u.simmeasure == 5;
+    // Correlation / SSD: both search paths only fill tval and one kernel reduces it, so the table does not depend on
+    // which of them ran (the ray table of a target arrives in the background, api.cpp: ensure_rays).  DICE costs are
+    // ratios of counts -- the same from any summation order -- and keep the reduction fused into the general kernel.
+    int st = launch_samples(ctx, u, nullptr, a, dice);
     if (st) return st;
     // control points that had deferred samples are reduced now that the fix-up kernel has filled them in
     ReduceArgs r;
@@ -1156,14 +1160,13 @@ int launch_unary_univariate(msm_ctx *ctx, const UnaryLaunch &u) {
     r.U = u.U;
     r.redo_list = u.redo_list;
     r.redo_count = u.fix_cnt;
-    const bool dice = u.simmeasure == 4 || u.simmeasure == 5;
     if (uses_ray_table(u.tree) && dice) {
         // the rank-counting DICE reduction is the wavefront-per-label kernel; all control points
         r.redo_list = nullptr;
         r.redo_count = nullptr;
         hipLaunchKernelGGL(k_unary_reduce_univariate, dim3(std::min(u.N, 2048)), dim3(256), sizeof(double) * 2 * (size_t)u.pmax, ctx->stream, r);
         MSM_HIP(hipMemsetAsync(u.fix_cnt, 0, unary_fix_counter_words() * sizeof(unsigned), ctx->stream));
-    } else if (uses_ray_table(u.tree)) {
+    } else if (!dice) {
         r.redo_list = u.order;  // all control points, in launch order
         hipLaunchKernelGGL(k_unary_reduce_flat, dim3(u.N), dim3(256), sizeof(double) * 2 * (size_t)u.pmax, ctx->stream, r, u.fix_cnt,
                            (int)unary_fix_counter_words());

@@ -8,6 +8,12 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# The direction table of a cost target is built in the background by default (api.cpp: ensure_rays) and the complete search
+# serves the first tables, so a test that evaluates one table would never reach the table kernels: build it on first use
+# here.  tests/test_gpu_unary.py::test_background_ray_table covers the default mode.
+os.environ.setdefault("MSMHIP_RAYTABLE", "sync")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
