@@ -70,7 +70,9 @@ int clique_args(msm_cost *c, bool need_triplets, bool need_pairs, CliqueArgs &a)
     if (need_triplets && cost_is_ho(c)) {
         if (!c->have_source) return fail(MSM_ERR_STATE, "msm_cost: get_source_data() must be called first");
         if (!c->target->d_feat || c->target->D != c->D) return fail(MSM_ERR_STATE, "msm_cost: target features must match the source features");
-        st = ensure_rays(c->target);  // includes the sub-cell masks the group search uses
+        // the triclique likelihood is evaluated by hundreds of fusion moves per level and its two kernel families sum in
+        // different orders, so this path waits for the direction table instead of switching to it mid-run
+        st = ensure_rays(c->target, true);  // includes the sub-cell masks the group search uses
         if (st) return st;
         if (c->p.kind == MSM_COST_HO_MULTIVARIATE) {
             st = ensure_vertex_major(c);
