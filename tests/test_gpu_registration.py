@@ -70,3 +70,28 @@ def test_two_levels_match_oracle(ctx):
         assert np.abs(a - b).max() < 1e-9
     assert angles(got[0], want[0]).max() <= NORTH_STAR_TOL_RAD and np.abs(got[0] - want[0]).max() < 1e-9
     assert angles(got[0], in_xyz).max() > 1e-3
+
+
+def test_files_in_files_out(ctx, tmp_path):
+    """GIFTI in, sphere.reg + transformed data out (tools/register_files.py), a small case"""
+    import subprocess
+    import sys
+
+    from newmsm_amd import meshio
+
+    xyz, tri = M.make_mesh_from_icosa(4)
+    ref = synthetic.features(xyz, 1, 5)
+    src = synthetic.features(synthetic.known_warp(xyz, seed=8, rot_deg=3.0, amp=2.0), 1, 5)
+    d = str(tmp_path) + "/"
+    meshio.save_surface(d + "in.surf.gii", xyz, tri)
+    meshio.save_metric(d + "in.func.gii", src)
+    meshio.save_metric(d + "ref.func.gii", ref)
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    run = subprocess.run([sys.executable, "tools/register_files.py", d + "in.surf.gii", d + "in.surf.gii", d + "in.func.gii", d + "ref.func.gii", d + "out.", "1", "20"],
+                         cwd=root, capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0, run.stderr
+    reg, rtri = meshio.load_surface(d + "out.sphere.reg.surf.gii")
+    assert np.array_equal(rtri, tri) and np.allclose(np.linalg.norm(reg, axis=1), 100.0, atol=1e-3) and angles(reg, xyz).max() > 1e-4
+    assert meshio.load_metric(d + "out.transformed_and_reprojected.func.gii").shape == (1, len(xyz))
