@@ -233,3 +233,22 @@ def test_background_ray_table(ctx, monkeypatch, kind, D):
     cf2, keep2 = problem.build_cost(ctx, inp, kind=kind)
     cf2.get_source_data()
     assert np.array_equal(cf2.computeUnaryCosts(), first) and keep2["target"].prepare_search(wait=True)
+
+
+def test_background_ray_table_lifetime(ctx, monkeypatch):
+    """meshes that go away, or move, while their direction table is still being built"""
+    monkeypatch.setenv("MSMHIP_RAYTABLE", "async")
+    inp = problem.pairwise_inputs(5, 3, D=1)
+    ref = None
+    for rep in range(4):
+        cf, keep = problem.build_cost(ctx, inp, kind="univariate")
+        cf.get_source_data()
+        U = cf.computeUnaryCosts()          # starts the build
+        ref = U if ref is None else ref
+        assert np.array_equal(U, ref)
+        if rep % 2:
+            keep["target"].set_coords(inp["target_xyz"])  # a new tree while the old table is in flight
+            assert np.array_equal(cf.computeUnaryCosts(), ref)
+        cf.close()
+        for m in keep.values():
+            m.close()                        # joins the build
