@@ -18,6 +18,8 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
+constexpr int kGroupStage = 256;  // ids of patch B staged in LDS per wavefront
+
 }  // namespace
 
 // every data vertex v is moved to estimate_rotation_matrix(centre, v) * label: "rigid rotation" of the mesh by the label
@@ -60,6 +62,16 @@ __global__ __launch_bounds__(256) void k_group_pairwise(GroupArgs a, const int *
     const int cntA = ea - ba, cntB = eb - bb;
     const double *FA = a.F[(size_t)sa * a.L + la], *FB = a.F[(size_t)sb * a.L + lb];
     const double nan = __longlong_as_double(0x7ff8000000000000ll);
+    // B's ids go to LDS first when they fit (patches hold ~65 entries at ico6 / ico4): the binary search below is a chain
+    // of dependent loads, and seven round trips to memory per query were most of this kernel's time
+    __shared__ int s_ids[4][kGroupStage];
+    int *stage = s_ids[threadIdx.x >> 6];
+    const bool staged = cntB <= kGroupStage;
+    if (staged)
+        for (int i = lane; i < cntB; i += 64) stage[i] = ib[i];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int *fb = staged ? stage : ib;
     // membership of A's entries in B, kept as a bit per (lane, round): patches hold at most 64 * 32 entries
     unsigned member = 0u;
     int common = 0;
@@ -68,10 +80,10 @@ __global__ __launch_bounds__(256) void k_group_pairwise(GroupArgs a, const int *
         int lo = 0, hi = cntB;
         while (lo < hi) {
             const int mid = (lo + hi) >> 1;
-            if (ib[mid] < id) lo = mid + 1;
+            if (fb[mid] < id) lo = mid + 1;
             else hi = mid;
         }
-        if (lo < cntB && ib[lo] == id) {
+        if (lo < cntB && fb[lo] == id) {
             member |= 1u << r;
             ++common;
         }
