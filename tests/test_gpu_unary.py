@@ -252,3 +252,22 @@ def test_background_ray_table_lifetime(ctx, monkeypatch):
         cf.close()
         for m in keep.values():
             m.close()                        # joins the build
+
+
+@pytest.mark.parametrize("range_", [0.0, 0.12, 0.3])
+@pytest.mark.parametrize("kind,D,sim", [("univariate", 1, 2), ("univariate", 1, 1), ("multivariate", 3, 2), ("patchwise", 3, 1), ("univariate", 1, 4)])
+def test_empty_and_single_point_patches(ctx, kind, D, sim, range_):
+    """range factors so small that a control point sees no source vertex (0), only the one it sits on (0.12), or a handful
+    (0.3): the reference then divides by an empty patch (SSD: sqrt(0) / 0 = NaN) or correlates a single point (variance 0 ->
+    r = 0); same values, NaN for NaN"""
+    inp = problem.pairwise_inputs(4, 2, D=D)
+    cf, oc, _ = run_pair(ctx, inp, kind, simmeasure=sim, range_=range_)
+    ptr, idx = cf.patches()
+    optr, oidx = oc.patches()
+    assert np.array_equal(ptr, optr) and np.array_equal(idx, oidx)
+    sizes = np.diff(ptr)
+    assert sizes.max() == (0 if range_ == 0.0 else 1) or (range_ == 0.3 and 1 < sizes.max() < 12)
+    U, Uo = cf.computeUnaryCosts(), oc.unary_table()
+    assert np.array_equal(np.isnan(U), np.isnan(Uo))
+    ok = ~np.isnan(Uo)
+    assert np.allclose(U[ok], Uo[ok], rtol=RTOL, atol=ATOL)
