@@ -139,9 +139,10 @@ int msm_closest_vertex(msm_mesh *target, const double *q_xyz, int32_t N, int32_t
  * from the meshes' current coordinates.  Call with col == NULL to obtain *nnz only. */
 int msm_adaptive_barycentric_weights(msm_mesh *in_mesh, msm_mesh *new_mesh, const double *excl,
                                      int32_t *row_ptr, int32_t *col, double *val, int64_t cap, int64_t *nnz);
-/* metric_resample R/resampler.cpp:304-309 (= barycentric_data_interpolation :30-70, no exclusion mask):
- * data D x V(in_mesh) -> out D x V(new_mesh) */
-int msm_metric_resample(msm_mesh *in_mesh, const double *data, int32_t D, msm_mesh *new_mesh, double *out);
+/* metric_resample R/resampler.cpp:304-309 (= barycentric_data_interpolation :30-70): data D x V(in_mesh) -> out D x V(new_mesh).
+ * excl (optional, V(in_mesh) values: the EXCL mesh's data, 0 = excluded) masks the weights and the sums as in :38-52;
+ * excl_out (optional, V(new_mesh)) is the resampled mask the reference writes back into EXCL (:54-67). */
+int msm_metric_resample(msm_mesh *in_mesh, const double *data, int32_t D, msm_mesh *new_mesh, const double *excl, double *out, double *excl_out);
 /* sphere_project_warp R/resampler.cpp:311-328: sphere (3 x N, in/out) is carried through from -> to_xyz (3 x V(from)) */
 int msm_sphere_project_warp(msm_mesh *from, const double *to_xyz, double *sphere_xyz, int32_t N);
 /* surface_resample :284-302 / project_anatomical_mesh :260-282 core: out = sum_j w_j * coords[v_j] for the
@@ -153,8 +154,12 @@ int msm_barycentric_coords_resample(msm_mesh *from, const double *coords_xyz, co
  * sphere).  excl (optional, V(orig) values) is the EXCL mesh's data and excl_out (optional, V(sphlow)) the smoothed
  * mask the reference writes back.  check_scale (R/mesh.cpp:1198-1208) is left to the caller.  out: D x V(sphlow). */
 int msm_smooth_data(msm_mesh *orig, const double *data, int32_t D, msm_mesh *sphlow, double sigma, const double *excl, double *out, double *excl_out);
-/* nearest_neighbour_interpolation R/resampler.cpp:232-258 without exclusion: data D x V(orig) -> out D x N */
-int msm_nearest_neighbour(msm_mesh *orig, const double *data, int32_t D, const double *q_xyz, int32_t N, double *out);
+/* nearest_neighbour_interpolation R/resampler.cpp:232-258: data D x V(orig) -> out D x N.  With excl (optional, V(orig)) a
+ * query whose closest vertex is excluded (0) gets zeros, and excl_out (optional, N) receives the mask at the queries. */
+int msm_nearest_neighbour(msm_mesh *orig, const double *data, int32_t D, const double *q_xyz, int32_t N, const double *excl, double *out, double *excl_out);
+/* [host] create_exclusion R/mesh.cpp:1257-1273: excl[i] = 1 when some feature of vertex i lies outside [thrl - EPSILON,
+ * thru + EPSILON], else 0 (as written in the reference: the mask marks the vertices to cut with 1).  data D x V. */
+int msm_create_exclusion(const double *data, int32_t D, int32_t V, double thrl, double thru, double *excl);
 
 /* ------------------------------------------------------------------------------------------------
  * the callers' side of one iteration (run_discrete_opt, M/mesh_registration.cpp:164-232): what sits between two

@@ -194,10 +194,12 @@ inline SparseWeights get_adaptive_barycentric_weights(Mesh &in_mesh, Mesh &new_m
     return w;
 }
 // metric_resample, R/resampler.cpp:304-309: data D x V(in) -> D x V(ref)
-inline Matrix metric_resample(Mesh &in_mesh, const Matrix &data, Mesh &ref) {
+inline Matrix metric_resample(Mesh &in_mesh, const Matrix &data, Mesh &ref, std::vector<double> *EXCL = nullptr) {
     const int32_t D = (int32_t)(data.size() / in_mesh.nvertices());
     Matrix out((size_t)D * ref.nvertices());
-    check(msm_metric_resample(in_mesh.handle(), data.data(), D, ref.handle(), out.data()));
+    std::vector<double> eo(EXCL ? ref.nvertices() : 0);
+    check(msm_metric_resample(in_mesh.handle(), data.data(), D, ref.handle(), EXCL ? EXCL->data() : nullptr, out.data(), EXCL ? eo.data() : nullptr));
+    if (EXCL) *EXCL = eo;  // the reference writes the resampled mask back (:66)
     return out;
 }
 // sphere_project_warp, R/resampler.cpp:311-328: `sphere` is carried through the deformation from -> to
@@ -216,11 +218,19 @@ inline Matrix smooth_data(Mesh &orig, const Matrix &data, Mesh &sphLow, double s
     return out;
 }
 // nearest_neighbour_interpolation, R/resampler.cpp:232-258
-inline Matrix nearest_neighbour_interpolation(Mesh &orig, const Matrix &data, const Points &q) {
+inline Matrix nearest_neighbour_interpolation(Mesh &orig, const Matrix &data, const Points &q, std::vector<double> *EXCL = nullptr) {
     const int32_t D = (int32_t)(data.size() / orig.nvertices()), N = (int32_t)(q.size() / 3);
     Matrix out((size_t)D * N);
-    check(msm_nearest_neighbour(orig.handle(), data.data(), D, to_soa(q).data(), N, out.data()));
+    std::vector<double> eo(EXCL ? N : 0);
+    check(msm_nearest_neighbour(orig.handle(), data.data(), D, to_soa(q).data(), N, EXCL ? EXCL->data() : nullptr, out.data(), EXCL ? eo.data() : nullptr));
+    if (EXCL) *EXCL = eo;
     return out;
+}
+// create_exclusion, R/mesh.cpp:1257-1273
+inline std::vector<double> create_exclusion(const Matrix &data, int V, double thrl, double thru) {
+    std::vector<double> excl((size_t)V);
+    check(msm_create_exclusion(data.data(), (int32_t)(data.size() / V), V, thrl, thru, excl.data()));
+    return excl;
 }
 
 // ---------------------------------------------------------------- around one iteration (M/reg_tools.h, M/mcmc_opt.h)

@@ -70,7 +70,8 @@ SIGNATURES = {
     "msm_query_triangles": (C.c_int, [_VP, c_dp, C.c_int32, c_ip, c_ip, c_dp, C.c_int]),
     "msm_closest_vertex": (C.c_int, [_VP, c_dp, C.c_int32, c_ip]),
     "msm_adaptive_barycentric_weights": (C.c_int, [_VP, _VP, c_dp, c_ip, c_ip, c_dp, C.c_int64, c_lp]),
-    "msm_metric_resample": (C.c_int, [_VP, c_dp, C.c_int32, _VP, c_dp]),
+    "msm_metric_resample": (C.c_int, [_VP, c_dp, C.c_int32, _VP, c_dp, c_dp, c_dp]),
+    "msm_create_exclusion": (C.c_int, [c_dp, C.c_int32, C.c_int32, C.c_double, C.c_double, c_dp]),
     "msm_sphere_project_warp": (C.c_int, [_VP, c_dp, c_dp, C.c_int32]),
     "msm_barycentric_coords_resample": (C.c_int, [_VP, c_dp, c_dp, C.c_int32, c_dp]),
     "msm_smooth_data": (C.c_int, [_VP, c_dp, C.c_int32, _VP, C.c_double, c_dp, c_dp, c_dp]),
@@ -78,7 +79,7 @@ SIGNATURES = {
     "msm_mesh_prepare_search": (C.c_int, [_VP, C.c_int, c_ip]),
     "msm_variance_normalise": (C.c_int, [c_dp, C.c_int32, C.c_int32, c_dp]),
     "msm_mcmc_optimise": (C.c_int, [c_dp, c_dp, c_ip, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_int32, C.c_uint64, c_ip]),
-    "msm_nearest_neighbour": (C.c_int, [_VP, c_dp, C.c_int32, c_dp, C.c_int32, c_dp]),
+    "msm_nearest_neighbour": (C.c_int, [_VP, c_dp, C.c_int32, c_dp, C.c_int32, c_dp, c_dp, c_dp]),
     "msm_cost_create": (_VP, [_VP, C.POINTER(CostParams)]),
     "msm_cost_destroy": (None, [_VP]),
     "msm_cost_set_meshes": (C.c_int, [_VP, _VP, _VP, _VP]),

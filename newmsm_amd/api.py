@@ -260,10 +260,23 @@ def get_adaptive_barycentric_weights(in_mesh, new_mesh, excl=None):
     return rp, col, val
 
 
-def metric_resample(in_mesh, data, new_mesh):
+def metric_resample(in_mesh, data, new_mesh, excl=None):
+    """metric_resample (R/resampler.cpp:304-309); with excl (the EXCL mesh's values on in_mesh) returns (data, resampled mask)."""
     d, pd = _d(np.atleast_2d(data))
     out = np.zeros((d.shape[0], new_mesh.V))
-    check(lib().msm_metric_resample(in_mesh.h, pd, d.shape[0], new_mesh.h, out.ctypes.data_as(c_dp)))
+    if excl is None:
+        check(lib().msm_metric_resample(in_mesh.h, pd, d.shape[0], new_mesh.h, None, out.ctypes.data_as(c_dp), None))
+        return out
+    eo = np.zeros(new_mesh.V)
+    check(lib().msm_metric_resample(in_mesh.h, pd, d.shape[0], new_mesh.h, _d(excl)[1], out.ctypes.data_as(c_dp), eo.ctypes.data_as(c_dp)))
+    return out, eo
+
+
+def create_exclusion(data, thrl, thru):
+    """create_exclusion (R/mesh.cpp:1257-1273) of a D x V matrix"""
+    d, pd = _d(np.atleast_2d(data))
+    out = np.zeros(d.shape[1])
+    check(lib().msm_create_exclusion(pd, d.shape[0], d.shape[1], float(thrl), float(thru), out.ctypes.data_as(c_dp)))
     return out
 
 
@@ -316,12 +329,16 @@ def mcmc_optimise(unary, tcosts, triplets, labeling, mcparam=0.8, iters=100, see
     return lab
 
 
-def nearest_neighbour_interpolation(orig_mesh, data, q):
+def nearest_neighbour_interpolation(orig_mesh, data, q, excl=None):
     d, pd = _d(np.atleast_2d(data))
     x, px = _soa(q)
     out = np.zeros((d.shape[0], x.shape[1]))
-    check(lib().msm_nearest_neighbour(orig_mesh.h, pd, d.shape[0], px, x.shape[1], out.ctypes.data_as(c_dp)))
-    return out
+    if excl is None:
+        check(lib().msm_nearest_neighbour(orig_mesh.h, pd, d.shape[0], px, x.shape[1], None, out.ctypes.data_as(c_dp), None))
+        return out
+    eo = np.zeros(x.shape[1])
+    check(lib().msm_nearest_neighbour(orig_mesh.h, pd, d.shape[0], px, x.shape[1], _d(excl)[1], out.ctypes.data_as(c_dp), eo.ctypes.data_as(c_dp)))
+    return out, eo
 
 
 # ------------------------------------------------------------------ cost function

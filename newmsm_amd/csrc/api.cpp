@@ -672,19 +672,42 @@ int msm_adaptive_barycentric_weights(msm_mesh *in_mesh, msm_mesh *new_mesh, cons
     return MSM_OK;
 }
 
-int msm_metric_resample(msm_mesh *in_mesh, const double *data, int32_t D, msm_mesh *new_mesh, double *out) {
+int msm_metric_resample(msm_mesh *in_mesh, const double *data, int32_t D, msm_mesh *new_mesh, const double *excl, double *out, double *excl_out) {
     if (!in_mesh || !new_mesh || !data || !out || D <= 0) return fail(MSM_ERR_INVALID, "msm_metric_resample: bad arguments");
     std::vector<int32_t> rp, c;
     std::vector<double> v;
-    int st = adaptive_weights(in_mesh, new_mesh, nullptr, rp, c, v);
+    int st = adaptive_weights(in_mesh, new_mesh, excl, rp, c, v);
     if (st) return st;
     const int Vin = in_mesh->V, Vn = new_mesh->V;
     for (int d = 0; d < D; ++d)  // barycentric_data_interpolation, R/resampler.cpp:40-52
         for (int k = 0; k < Vn; ++k) {
             double acc = 0.0;
-            for (int e = rp[k]; e < rp[k + 1]; ++e) acc += data[(size_t)d * Vin + c[e]] * v[e];
+            for (int e = rp[k]; e < rp[k + 1]; ++e)
+                if (!excl || excl[c[e]] != 0) acc += data[(size_t)d * Vin + c[e]] * v[e];
             out[(size_t)d * Vn + k] = acc;
         }
+    if (excl && excl_out)  // :54-67
+        for (int k = 0; k < Vn; ++k) {
+            double acc = 0.0;
+            for (int e = rp[k]; e < rp[k + 1]; ++e)
+                if (excl[c[e]] != 0) acc += excl[c[e]] * v[e];
+            excl_out[k] = acc;
+        }
+    return MSM_OK;
+}
+
+int msm_create_exclusion(const double *data, int32_t D, int32_t V, double thrl, double thru, double *excl) {
+    if (!data || !excl || D < 0 || V < 0) return fail(MSM_ERR_INVALID, "msm_create_exclusion: bad arguments");
+    for (int i = 0; i < V; ++i) {
+        excl[i] = 0.0;
+        for (int d = 0; d < D; ++d) {
+            const double x = data[(size_t)d * V + i];
+            if (!(x >= (thrl - kEps) && x <= (thru + kEps))) {
+                excl[i] = 1.0;
+                break;
+            }
+        }
+    }
     return MSM_OK;
 }
 
@@ -771,13 +794,15 @@ int msm_smooth_data(msm_mesh *orig, const double *data, int32_t D, msm_mesh *sph
     return check_status(ctx, "msm_smooth_data");
 }
 
-int msm_nearest_neighbour(msm_mesh *orig, const double *data, int32_t D, const double *q, int32_t N, double *out) {
+int msm_nearest_neighbour(msm_mesh *orig, const double *data, int32_t D, const double *q, int32_t N, const double *excl, double *out, double *excl_out) {
     if (!orig || !data || !q || !out || D <= 0 || N < 0) return fail(MSM_ERR_INVALID, "msm_nearest_neighbour: bad arguments");
     std::vector<int32_t> cv(N);
     int st = msm_closest_vertex(orig, q, N, cv.data());
     if (st) return st;
     for (int d = 0; d < D; ++d)
-        for (int i = 0; i < N; ++i) out[(size_t)d * N + i] = data[(size_t)d * orig->V + cv[i]];
+        for (int i = 0; i < N; ++i) out[(size_t)d * N + i] = (!excl || excl[cv[i]] != 0) ? data[(size_t)d * orig->V + cv[i]] : 0.0;  // :246-251
+    if (excl && excl_out)
+        for (int i = 0; i < N; ++i) excl_out[i] = excl[cv[i]] != 0 ? excl[cv[i]] : 0.0;
     return MSM_OK;
 }
 

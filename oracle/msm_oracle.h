@@ -103,6 +103,14 @@ void orc_apply_weights(const int *row_ptr, const int *col, const double *val, in
                        const double *data, int D, int Vin, const double *excl, double *out);
 /* metric_resample = adaptive weights + apply (excl NULL) */
 int  orc_metric_resample(const orc_mesh *in_mesh, const double *data, int D, const orc_mesh *new_mesh, double *out);
+/* the same with EXCL (values on in_mesh, 0 = excluded); excl_out (optional, V(new)) = the mask the reference writes back */
+int  orc_metric_resample_excl(const orc_mesh *in_mesh, const double *data, int D, const orc_mesh *new_mesh, const double *excl, double *out,
+                              double *excl_out);
+/* create_exclusion (R/mesh.cpp:1257-1273) */
+void orc_create_exclusion(const double *data, int D, int V, double thrl, double thru, double *excl);
+/* nearest_neighbour_interpolation with EXCL (:232-258) */
+int  orc_nearest_neighbour_excl(const orc_mesh *orig, const double *data, int D, const double *q, int N, const double *excl, double *out,
+                                double *excl_out);
 /* sphere_project_warp (:311-328): sphere[N] moved through from->to */
 int  orc_sphere_project_warp(double *sphere, int N, const orc_mesh *from, const double *to_xyz);
 /* smooth_data (:168-230): Gaussian smoothing over the geodesic neighbourhood (see orc_resample.c for the index quirks) */

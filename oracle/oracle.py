@@ -218,6 +218,32 @@ def metric_resample(in_mesh, data, new_mesh):
     return out
 
 
+def metric_resample_excl(in_mesh, data, new_mesh, excl):
+    data, pd = _d(np.atleast_2d(data))
+    out, eo = np.zeros((data.shape[0], new_mesh.V)), np.zeros(new_mesh.V)
+    st = lib().orc_metric_resample_excl(in_mesh.h, pd, data.shape[0], new_mesh.h, _d(excl)[1], out.ctypes.data_as(c_dp), eo.ctypes.data_as(c_dp))
+    if st:
+        raise RuntimeError("octree query failed")
+    return out, eo
+
+
+def create_exclusion(data, thrl, thru):
+    data, pd = _d(np.atleast_2d(data))
+    out = np.zeros(data.shape[1])
+    lib().orc_create_exclusion(pd, data.shape[0], data.shape[1], C.c_double(thrl), C.c_double(thru), out.ctypes.data_as(c_dp))
+    return out
+
+
+def nearest_neighbour_excl(orig_mesh, data, q, excl):
+    data, pd = _d(np.atleast_2d(data))
+    q, pq = _d(q)
+    out, eo = np.zeros((data.shape[0], len(q))), np.zeros(len(q))
+    st = lib().orc_nearest_neighbour_excl(orig_mesh.h, pd, data.shape[0], pq, len(q), _d(excl)[1], out.ctypes.data_as(c_dp), eo.ctypes.data_as(c_dp))
+    if st:
+        raise RuntimeError("octree query failed")
+    return out, eo
+
+
 def sphere_project_warp(sphere, from_mesh, to_xyz):
     s = np.array(sphere, dtype=np.float64, order="C")
     to, pt = _d(to_xyz)

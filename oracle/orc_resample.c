@@ -167,14 +167,59 @@ void orc_apply_weights(const int *row_ptr, const int *col, const double *val, in
 
 /* metric_resample, R/resampler.cpp:304-309 */
 int orc_metric_resample(const orc_mesh *in_mesh, const double *data, int D, const orc_mesh *new_mesh, double *out) {
-    long nnz = orc_adaptive_barycentric_weights(in_mesh, new_mesh, NULL, NULL, NULL, NULL);
+    return orc_metric_resample_excl(in_mesh, data, D, new_mesh, NULL, out, NULL);
+}
+
+/* barycentric_data_interpolation with EXCL, R/resampler.cpp:30-70: the mask enters the weights (:38), the sums (:45-47) and is
+ * itself resampled (:54-67) */
+int orc_metric_resample_excl(const orc_mesh *in_mesh, const double *data, int D, const orc_mesh *new_mesh, const double *excl, double *out,
+                             double *excl_out) {
+    long nnz = orc_adaptive_barycentric_weights(in_mesh, new_mesh, excl, NULL, NULL, NULL);
     if (nnz < 0) return -1;
     int *rp = (int *)malloc(sizeof(int) * (new_mesh->V + 1)), *col = (int *)malloc(sizeof(int) * (nnz + 1));
     double *val = (double *)malloc(sizeof(double) * (nnz + 1));
-    orc_adaptive_barycentric_weights(in_mesh, new_mesh, NULL, rp, col, val);
-    orc_apply_weights(rp, col, val, new_mesh->V, data, D, in_mesh->V, NULL, out);
+    orc_adaptive_barycentric_weights(in_mesh, new_mesh, excl, rp, col, val);
+    orc_apply_weights(rp, col, val, new_mesh->V, data, D, in_mesh->V, excl, out);
+    if (excl && excl_out)
+        for (int k = 0; k < new_mesh->V; ++k) {
+            double acc = 0.0;
+            for (int e = rp[k]; e < rp[k + 1]; ++e)
+                if (excl[col[e]] != 0) acc += excl[col[e]] * val[e];
+            excl_out[k] = acc;
+        }
     free(rp); free(col); free(val);
     return 0;
+}
+
+/* create_exclusion, R/mesh.cpp:1257-1273 */
+void orc_create_exclusion(const double *data, int D, int V, double thrl, double thru, double *excl) {
+    for (int i = 0; i < V; ++i) {
+        excl[i] = 0.0;
+        for (int d = 0; d < D; ++d)
+            if (!(data[(long)d * V + i] >= (thrl - ORC_EPSILON) && data[(long)d * V + i] <= (thru + ORC_EPSILON))) {
+                excl[i] = 1.0;
+                break;
+            }
+    }
+}
+
+/* nearest_neighbour_interpolation with EXCL, R/resampler.cpp:232-258 */
+int orc_nearest_neighbour_excl(const orc_mesh *orig, const double *data, int D, const double *q, int N, const double *excl, double *out,
+                               double *excl_out) {
+    orc_octree *t = orc_octree_build(orig);
+    int st = 0;
+    for (int i = 0; i < N; ++i) {
+        int cv = orc_octree_closest_vertex(t, &q[3 * i]);
+        if (cv < 0) { st = cv; break; }
+        if (excl_out) excl_out[i] = 0.0;
+        for (int d = 0; d < D; ++d) out[(long)d * N + i] = 0.0;
+        if (!excl || excl[cv] != 0) {
+            if (excl && excl_out) excl_out[i] = excl[cv];
+            for (int d = 0; d < D; ++d) out[(long)d * N + i] = data[(long)d * orig->V + cv];
+        }
+    }
+    orc_octree_destroy(t);
+    return st;
 }
 
 /* sphere_project_warp, R/resampler.cpp:311-328 */

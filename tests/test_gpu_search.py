@@ -222,3 +222,25 @@ def test_smooth_data_large_neighbourhoods(ctx):
     m = M.Mesh(ctx, xyz, tri)
     om = O.Mesh(xyz, tri)
     assert np.allclose(M.smooth_data(m, data, m, 30.0), O.smooth_data(om, data, om, 30.0), rtol=1e-11, atol=1e-13)
+
+
+def test_exclusion_masks_in_metric_resample_and_nearest_neighbour(ctx):
+    """featurespace::initialise with a cut (M/featurespace.cpp:62-74): create_exclusion, metric_resample and
+    nearest_neighbour_interpolation with EXCL -- masked weights, masked sums, and the mask carried to the new mesh"""
+    xyz, tri = M.make_mesh_from_icosa(5)
+    lo_xyz, lo_tri = M.make_mesh_from_icosa(4)
+    data = synthetic.features(xyz, 3, 11)
+    thr = np.quantile(data[0], 0.2)
+    excl = M.create_exclusion(data, thr, 1e9)
+    assert np.array_equal(excl, O.create_exclusion(data, thr, 1e9)) and 0.1 < excl.mean() < 0.9
+    src, dst = M.Mesh(ctx, xyz, tri), M.Mesh(ctx, lo_xyz, lo_tri)
+    osrc, odst = O.Mesh(xyz, tri), O.Mesh(lo_xyz, lo_tri)
+    got, gmask = M.metric_resample(src, data, dst, excl=excl)
+    want, wmask = O.metric_resample_excl(osrc, data, odst, excl)
+    assert np.array_equal(got, want, equal_nan=True) and np.array_equal(gmask, wmask, equal_nan=True)
+    assert np.isfinite(got).mean() > 0.5 and (gmask == 0).any() and (gmask > 0).any()
+    q = synthetic.random_sphere_points(3000, seed=5)
+    got, gmask = M.nearest_neighbour_interpolation(src, data, q, excl=excl)
+    want, wmask = O.nearest_neighbour_excl(osrc, data, q, excl)
+    assert np.array_equal(got, want) and np.array_equal(gmask, wmask) and (gmask == 0).any()
+    assert np.array_equal(M.nearest_neighbour_interpolation(src, data, q), O.nearest_neighbour(osrc, data, q))
