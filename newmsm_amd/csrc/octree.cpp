@@ -16,6 +16,7 @@
 //   ray table   (simple surfaces only) cube-map of directions -> candidate triangles, plus three float edge planes
 //               per triangle: decides most queries without touching the tree, with the reference's result
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <chrono>
 #include <cstdio>
@@ -177,31 +178,72 @@ inline V3 vtx(const double *xyz, int V, int i) { return mk(xyz[i], xyz[V + i], x
 // solid angles add up to one full sphere (degree of the radial projection = 1).
 bool simple_star_surface(const double *xyz, const int32_t *tri, int V, int T) {
     if (T < 4) return false;
-    std::vector<uint64_t> edge;  // directed edges
-    edge.reserve((size_t)T * 3);
+    // faces: orientation seen from the origin and solid angle, on worker threads (chunk sums added in chunk order)
+    const int workers = T < 20000 ? 1 : host_workers();
+    std::vector<double> part_solid(4 * (size_t)std::max(workers, 1), 0.0);
+    std::vector<int> part_sign(part_solid.size(), 0);  // +1 / -1: all faces of the chunk face that way; 2: the mesh fails
+    parallel_chunks(T, workers, [&](int c, int t0, int t1) {
+        double solid = 0.0;
+        int sign = 0;
+        for (int t = t0; t < t1; ++t) {
+            const int id[3] = {tri[t], tri[T + t], tri[2 * T + t]};
+            bool bad = id[0] == id[1] || id[1] == id[2] || id[0] == id[2];
+            for (int k = 0; k < 3; ++k) bad = bad || id[k] < 0 || id[k] >= V;
+            if (bad) {
+                sign = 2;
+                break;
+            }
+            const V3 a = vtx(xyz, V, id[0]), b = vtx(xyz, V, id[1]), cc = vtx(xyz, V, id[2]);
+            const double la = norm(a), lb = norm(b), lc = norm(cc);
+            const double triple = dot(a, cross(b, cc));
+            if (!(la > 0 && lb > 0 && lc > 0) || !std::isfinite(triple)) {
+                sign = 2;
+                break;
+            }
+            const int s = triple > 1e-12 * la * lb * lc ? 1 : (triple < -1e-12 * la * lb * lc ? -1 : 0);
+            if (s == 0 || (sign != 0 && s != sign)) {  // a face seen edge-on or from behind
+                sign = 2;
+                break;
+            }
+            sign = s;
+            // Van Oosterom-Strackee solid angle of the face
+            const double den = la * lb * lc + dot(a, b) * lc + dot(a, cc) * lb + dot(b, cc) * la;
+            solid += 2.0 * std::atan2(std::fabs(triple), den);
+        }
+        part_solid[c] = solid;
+        part_sign[c] = sign;
+    });
     double solid = 0.0;
     int sign = 0;
-    for (int t = 0; t < T; ++t) {
-        const int id[3] = {tri[t], tri[T + t], tri[2 * T + t]};
-        if (id[0] == id[1] || id[1] == id[2] || id[0] == id[2]) return false;
-        for (int k = 0; k < 3; ++k) edge.push_back(((uint64_t)(uint32_t)id[k] << 32) | (uint32_t)id[(k + 1) % 3]);
-        const V3 a = vtx(xyz, V, id[0]), b = vtx(xyz, V, id[1]), c = vtx(xyz, V, id[2]);
-        const double la = norm(a), lb = norm(b), lc = norm(c);
-        const double triple = dot(a, cross(b, c));
-        if (!(la > 0 && lb > 0 && lc > 0) || !std::isfinite(triple)) return false;
-        const int s = triple > 1e-12 * la * lb * lc ? 1 : (triple < -1e-12 * la * lb * lc ? -1 : 0);
-        if (s == 0 || (sign != 0 && s != sign)) return false;  // a face seen edge-on or from behind
-        sign = s;
-        // Van Oosterom-Strackee solid angle of the face
-        const double den = la * lb * lc + dot(a, b) * lc + dot(a, c) * lb + dot(b, c) * la;
-        solid += 2.0 * std::atan2(std::fabs(triple), den);
+    for (size_t c = 0; c < part_solid.size(); ++c) {
+        if (part_sign[c] == 0) continue;
+        if (part_sign[c] == 2 || (sign != 0 && part_sign[c] != sign)) return false;
+        sign = part_sign[c];
+        solid += part_solid[c];
     }
-    std::sort(edge.begin(), edge.end());
-    for (size_t i = 1; i < edge.size(); ++i)
-        if (edge[i] == edge[i - 1]) return false;  // same directed edge twice: not consistently oriented / not manifold
-    for (const uint64_t e : edge)  // every directed edge needs its opposite: closed surface
-        if (!std::binary_search(edge.begin(), edge.end(), (e << 32) | (e >> 32))) return false;
-    const long E = (long)edge.size() / 2;
+    // directed edges u -> v bucketed by u: each must be unique (consistent orientation, manifold) and have its opposite
+    // (closed surface).  Buckets hold a vertex's valence (six on an icosphere), so the checks are short scans.
+    std::vector<int32_t> ptr((size_t)V + 1, 0);
+    for (int k = 0; k < 3; ++k)
+        for (int t = 0; t < T; ++t) ++ptr[(size_t)tri[(size_t)k * T + t] + 1];
+    for (int v = 0; v < V; ++v) ptr[v + 1] += ptr[v];
+    std::vector<int32_t> head((size_t)3 * T), fill(ptr.begin(), ptr.end() - 1);
+    for (int t = 0; t < T; ++t)
+        for (int k = 0; k < 3; ++k) head[fill[tri[(size_t)k * T + t]]++] = tri[(size_t)((k + 1) % 3) * T + t];
+    std::atomic<bool> ok{true};
+    parallel_chunks(V, workers, [&](int, int v0, int v1) {
+        for (int u = v0; u < v1 && ok.load(std::memory_order_relaxed); ++u)
+            for (int e = ptr[u]; e < ptr[u + 1]; ++e) {
+                const int v = head[e];
+                for (int f = ptr[u]; f < e; ++f)
+                    if (head[f] == v) ok.store(false, std::memory_order_relaxed);  // the same directed edge twice
+                bool opposite = false;
+                for (int f = ptr[v]; f < ptr[v + 1]; ++f) opposite = opposite || head[f] == u;
+                if (!opposite) ok.store(false, std::memory_order_relaxed);
+            }
+    });
+    if (!ok.load()) return false;
+    const long E = (long)3 * T / 2;
     if ((long)V - E + (long)T != 2) return false;  // sphere topology (all vertices referenced is implied when this holds for a closed manifold)
     return std::fabs(solid - 4.0 * M_PI) < 1e-6;
 }
