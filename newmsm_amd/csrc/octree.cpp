@@ -55,16 +55,18 @@ struct Builder {
     void precompute_boxes() {
         box.resize((size_t)6 * T);
         bxp = box.data();
-        for (int t = 0; t < T; ++t) {
-            double *lo = &box[(size_t)6 * t], *hi = lo + 3;
-            for (int a = 0; a < 3; ++a) lo[a] = hi[a] = xyz[a * V + tri[t]];
-            for (int k = 1; k < 3; ++k)
-                for (int a = 0; a < 3; ++a) {
-                    double c = xyz[a * V + tri[k * T + t]];
-                    if (c < lo[a]) lo[a] = c;
-                    if (c > hi[a]) hi[a] = c;
-                }
-        }
+        parallel_chunks(T, T < 20000 ? 1 : std::min(host_workers(), 8), [&](int, int t0, int t1) {
+            for (int t = t0; t < t1; ++t) {
+                double *lo = &box[(size_t)6 * t], *hi = lo + 3;
+                for (int a = 0; a < 3; ++a) lo[a] = hi[a] = xyz[a * V + tri[t]];
+                for (int k = 1; k < 3; ++k)
+                    for (int a = 0; a < 3; ++a) {
+                        double c = xyz[a * V + tri[k * T + t]];
+                        if (c < lo[a]) lo[a] = c;
+                        if (c > hi[a]) hi[a] = c;
+                    }
+            }
+        });
     }
     void aabb(int t, double lo[3], double hi[3]) const {
         const double *b = &bxp[(size_t)6 * t];
@@ -540,6 +542,7 @@ namespace {
 // build_down over the whole mesh; the subtrees below the first two levels are built on worker threads, each in its own
 // node store, and spliced into b.nodes afterwards (only the order of the nodes differs from the serial build).
 void build_top_down(Builder &b) {
+    auto tick_ = std::chrono::steady_clock::now();
     std::vector<int32_t> all(b.T);
     for (int t = 0; t < b.T; ++t) all[t] = t;
     const int workers = host_workers();
@@ -556,8 +559,10 @@ void build_top_down(Builder &b) {
     frontier.push_back(Job{0, std::move(all)});
     for (int level = 0; level < 2; ++level) {
         next.clear();
-        for (Job &j : frontier) {
-            // a one-level build_down: scan, and on a split take the children's lists without descending
+        // decide every node of the level (a scan that stops at the split), create the children of those that split ...
+        std::vector<std::pair<int, int>> todo;  // (job, slot in next) of the children to fill
+        for (size_t jn = 0; jn < frontier.size(); ++jn) {
+            Job &j = frontier[jn];
             int total_size = 0, num_split = 0;
             bool splits = false;
             const int len = (int)j.list.size();
@@ -577,18 +582,26 @@ void build_top_down(Builder &b) {
             b.split(j.node);
             const int first = b.nodes[j.node].first_child;
             for (int c = 0; c < 8; ++c) {
-                const BNode &ch = b.nodes[first + c];
-                Job sub{first + c, {}};
-                for (int i = 0; i < len; ++i) {
-                    const double *bx = &b.bxp[(size_t)6 * j.list[i]];
-                    if (!(bx[3] < ch.b[0][0] || bx[0] > ch.b[0][2] || bx[4] < ch.b[1][0] || bx[1] > ch.b[1][2] || bx[5] < ch.b[2][0] || bx[2] > ch.b[2][2]))
-                        sub.list.push_back(j.list[i]);
-                }
-                next.push_back(std::move(sub));
+                todo.push_back({(int)jn, (int)next.size()});
+                next.push_back(Job{first + c, {}});
             }
         }
+        // ... and fill the children's lists (each a scan of the parent's whole list, in order) on the worker threads
+        parallel_for((int)todo.size(), workers, [&](int k) {
+            const Job &j = frontier[todo[k].first];
+            Job &sub = next[todo[k].second];
+            const BNode &ch = b.nodes[sub.node];
+            const int len = (int)j.list.size();
+            sub.list.reserve((size_t)len / 4 + 16);
+            for (int i = 0; i < len; ++i) {
+                const double *bx = &b.bxp[(size_t)6 * j.list[i]];
+                if (!(bx[3] < ch.b[0][0] || bx[0] > ch.b[0][2] || bx[4] < ch.b[1][0] || bx[1] > ch.b[1][2] || bx[5] < ch.b[2][0] || bx[2] > ch.b[2][2]))
+                    sub.list.push_back(j.list[i]);
+            }
+        });
         frontier.swap(next);
     }
+    TICK("octree: top levels");
     // every remaining job builds its subtree in a private node store whose node 0 stands for the job's node
     std::vector<Builder> part;
     part.reserve(frontier.size());
@@ -597,6 +610,7 @@ void build_top_down(Builder &b) {
         part.back().nodes.push_back(b.nodes[j.node]);
     }
     parallel_for((int)frontier.size(), workers, [&](int k) { part[k].build_down(0, frontier[k].list); });
+    TICK("octree: subtrees");
     for (size_t k = 0; k < part.size(); ++k) {
         const int root = frontier[k].node, base = (int)b.nodes.size() - 1;  // local i > 0 -> base + i
         auto global = [&](int i) { return i == 0 ? root : base + i; };
@@ -618,6 +632,7 @@ void build_octree(const double *xyz, const int32_t *tri, int V, int T, FlatOctre
     auto tick_ = std::chrono::steady_clock::now();
     Builder b{xyz, tri, V, T, {}, {}, nullptr};
     b.precompute_boxes();
+    TICK("octree: boxes");
     BNode root;
     for (int a = 0; a < 3; ++a) {
         root.b[a][0] = -kBounds;
