@@ -21,7 +21,9 @@ namespace msm {
 // set inside a worker of parallel_for: nested set-up code then runs serially instead of multiplying the threads
 inline thread_local bool t_inside_worker = false;
 
-// host cores this process may use (affinity aware; MSMHIP_HOST_THREADS overrides), at most 64; 1 inside a worker
+// host threads of one process: the cores it may run on (affinity aware), but no more than 16 by default -- one process
+// drives one GPU, and an 8-GPU node runs eight of them side by side; MSMHIP_HOST_THREADS overrides (at most 64).
+// 1 inside a worker.
 inline int host_workers() {
     if (t_inside_worker) return 1;
     cpu_set_t set;
@@ -29,6 +31,7 @@ inline int host_workers() {
     int n = 0;
     if (sched_getaffinity(0, sizeof(set), &set) == 0) n = CPU_COUNT(&set);
     if (n <= 0) n = (int)std::thread::hardware_concurrency();
+    n = std::min(n, 16);
     if (const char *e = std::getenv("MSMHIP_HOST_THREADS")) n = std::atoi(e);
     return std::max(1, std::min(n, 64));
 }
