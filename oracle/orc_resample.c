@@ -272,11 +272,16 @@ int orc_smooth_data(const orc_mesh *orig, const double *data, int D, const orc_m
     orc_octree *t = orc_octree_build(orig);
     int st = 0;
     for (long k = 0; k < (long)D * N; ++k) out[k] = 0.0;
-    for (int i = 0; i < N && !st; ++i) {
+    /* the reference's loop over the output vertices is an OpenMP loop too (:179); every vertex is computed as in the serial code */
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < N; ++i) {
         if (excl_out) excl_out[i] = 0.0;
         const int cv = orc_octree_closest_vertex(t, &sphLow->xyz[3 * i]);
-        if (cv < 0) { st = cv; break; }
-        if (cv >= N) { st = -3; break; }
+        if (cv < 0 || cv >= N) {
+#pragma omp critical
+            if (st == 0) st = cv < 0 ? cv : -3;
+            continue;
+        }
         double ref[3] = {sphLow->xyz[3 * cv], sphLow->xyz[3 * cv + 1], sphLow->xyz[3 * cv + 2]};
         orc_normalize(ref);
         double SUM = 0.0, excl_sum = 0.0;

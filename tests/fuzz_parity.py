@@ -1,4 +1,4 @@
-"""tools/fuzz_parity.py [seed] [count] -- random configurations (resolutions, warps, target shapes, cost classes, similarity
+"""tests/fuzz_parity.py [seed] [count] -- random configurations (resolutions, warps, target shapes, cost classes, similarity
 measures) through the HIP path and the oracle; prints every mismatch.  Run on a GPU box; used to look for rare parity
 failures beyond what tests/ samples (round 1: 510 configurations, with the direction table built up front and in the background, none)."""
 import sys, os, time
