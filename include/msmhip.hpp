@@ -89,6 +89,26 @@ inline std::vector<double> cp_rotations(const double centre[3], const Points &cp
     check(msm_cp_rotations(centre, to_soa(cp).data(), N, rot.data()));
     return rot;
 }
+// Initialize_sampling_grid + label_sampling_grid, M/DiscreteModel.cpp:110-190: {samples, barycentres}; samples[0] is the centre
+inline std::pair<Points, Points> label_sampling_grid(int sg_order, double max_dist, bool abs_is_int = false) {
+    const int32_t cap = 4096;
+    std::vector<double> s(3 * (size_t)cap), b(3 * (size_t)cap);
+    int32_t ns = 0, nb = 0;
+    check(msm_label_sampling_grid(sg_order, max_dist, abs_is_int ? 1 : 0, cap, s.data(), &ns, b.data(), &nb));
+    Points samples(3 * (size_t)ns), bary(3 * (size_t)nb);
+    for (int i = 0; i < ns; ++i)
+        for (int a = 0; a < 3; ++a) samples[3 * (size_t)i + a] = s[(size_t)a * cap + i];
+    for (int i = 0; i < nb; ++i)
+        for (int a = 0; a < 3; ++a) bary[3 * (size_t)i + a] = b[(size_t)a * cap + i];
+    return {samples, bary};
+}
+// rescale_sampling_grid, M/DiscreteModel.cpp:192-214: the labels of this iteration; `scale` is m_scale (read and updated)
+inline Points rescale_sampling_grid(const Points &samples, double &scale) {
+    const int32_t n = (int32_t)(samples.size() / 3);
+    std::vector<double> out(3 * (size_t)n);
+    check(msm_rescale_sampling_grid(to_soa(samples).data(), n, &scale, out.data()));
+    return to_aos(out);
+}
 // estimate_triplets / estimate_pairs, M/DiscreteModel.cpp:271-308
 inline std::vector<int32_t> estimate_triplets(const Triangles &tri) {
     const int32_t T = (int32_t)(tri.size() / 3);
@@ -333,6 +353,12 @@ public:
         const int32_t t = triplet, a = labelA, b = labelB, c = labelC;
         check(msm_cost_triplet_batch(h_, &t, &a, &b, &c, 1, &v));
         return v;
+    }
+    // computeTripletCosts, :245-253: tcosts[t][a][b][c] flat (the table MCMC::optimise reads)
+    std::vector<double> computeTripletCosts() {
+        std::vector<double> tcosts((size_t)T_ * L_ * L_ * L_);
+        if (!tcosts.empty()) check(msm_cost_triplet_table(h_, 0, T_, tcosts.data()));
+        return tcosts;
     }
     // the batched forms the optimisers' loops collapse to (I/Fusion/Fusion.h:138-196)
     std::vector<double> computeTripletCost(const std::vector<int32_t> &t, const std::vector<int32_t> &a, const std::vector<int32_t> &b,

@@ -16,10 +16,18 @@ EXE = os.path.join(ROOT, "tests", "cpp", "host_mirror")
 LIBDIR = os.path.join(ROOT, "newmsm_amd")
 
 
-def build_host_mirror():
-    cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"), SRC, "-o", EXE, "-L", LIBDIR, "-lmsmhip",
+def build_cpp(src, exe):
+    cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"), src, "-o", exe, "-L", LIBDIR, "-lmsmhip",
            "-Wl,-rpath," + LIBDIR, "-Wl,-rpath,/opt/rocm/lib"]
     subprocess.check_call(cmd)
+
+
+def build_host_mirror():
+    build_cpp(SRC, EXE)
+
+
+LEVEL_SRC = os.path.join(ROOT, "tests", "cpp", "level_driver.cpp")
+LEVEL_EXE = os.path.join(ROOT, "tests", "cpp", "level_driver")
 
 
 def write_bag(path, **arrays):
@@ -47,6 +55,33 @@ def read_bag(path):
 
 def test_header_compiles_without_gpu(built):
     build_host_mirror()  # -Wall -Wextra -Werror: the header is clean C++17 and needs no HIP headers
+    build_cpp(LEVEL_SRC, LEVEL_EXE)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("D,rescale", [(1, 0), (3, 1)])
+def test_cpp_level_driver_equals_python_loop(built, ctx, tmp_path, D, rescale):
+    """run_discrete_opt of include/msmhip_registration.hpp (compiled, no Python) against newmsm_amd/registration.py: the same
+    library calls in the same order with the same optimiser seeds, so labelings, energies and coordinates are identical"""
+    import newmsm_amd as M
+    from newmsm_amd import registration, synthetic
+
+    build_cpp(LEVEL_SRC, LEVEL_EXE)
+    xyz, tri = M.make_mesh_from_icosa(4)
+    ref = synthetic.features(xyz, D, 21)
+    src = synthetic.features(synthetic.known_warp(xyz, seed=23, rot_deg=4.0, amp=2.5), D, 21)
+    fin, fout = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+    write_bag(fin, orders=np.array([4, 2, D, 3, 40, 5, rescale]), params=np.array([0.3, 0.05]), ref_feat=ref, src_feat=src)
+    run = subprocess.run([LEVEL_EXE, fin, fout], capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0, run.stderr + run.stdout
+    got = read_bag(fout)
+    want = registration.run_discrete_level(registration.ProductOps(ctx), xyz, tri, ref, xyz, tri, src, xyz, cp_order=2, iters=3, mciters=40, mcparam=0.3,
+                                           seed=5, kind="multivariate" if D > 1 else "univariate", rescale_labels=bool(rescale),
+                                           cost_params=dict(lambda_=0.05))
+    assert np.array_equal(got["labelings"].reshape(3, -1), np.array(want[3]))
+    assert np.array_equal(got["energies"], np.array(want[2]))
+    assert np.array_equal(got["sph_reg"].reshape(-1, 3), want[0]) and np.array_equal(got["cpgrid"].reshape(-1, 3), want[1])
+    assert len({tuple(l) for l in want[3]}) > 1
 
 
 @pytest.mark.gpu
