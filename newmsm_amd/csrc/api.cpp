@@ -298,23 +298,31 @@ static hipError_t ctx_scratch(msm_ctx *ctx, int slot, size_t bytes, void **out) 
     return hipSuccess;
 }
 
-int query_host(msm_mesh *target, const double *q, int N, int *tri_id, int *vid, double *w, int mode, const char *what) {
+int query_host(msm_mesh *target, const double *q, int N, int *tri_id, int *vid, double *w, int mode, const char *what, const double *q_on_device = nullptr);
+
+// q_on_device (optional): the same 3 x N points already in HBM (the vertices of a mesh handle of this context); the host copy
+// then stays where it is
+int query_host(msm_mesh *target, const double *q, int N, int *tri_id, int *vid, double *w, int mode, const char *what, const double *q_on_device) {
     msm_ctx *ctx = target->ctx;
     int st = ensure_tree(target);
     if (st) return st;
     double *dq = nullptr, *dw = nullptr;
     int *dt = nullptr, *dv = nullptr;
     // host arrays travel through one pinned block: [queries | tri ids | vertex ids | weights]
-    const size_t bq = sizeof(double) * 3 * (size_t)N, bt = tri_id ? sizeof(int) * (size_t)N : 0, bv = vid ? sizeof(int) * 3 * (size_t)N : 0,
-                 bw = w ? sizeof(double) * 3 * (size_t)N : 0;
+    const size_t bq = q_on_device ? 0 : sizeof(double) * 3 * (size_t)N, bt = tri_id ? sizeof(int) * (size_t)N : 0,
+                 bv = vid ? sizeof(int) * 3 * (size_t)N : 0, bw = w ? sizeof(double) * 3 * (size_t)N : 0;
     auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
     void *pin = nullptr;
     st = ctx_io_pinned(ctx, pad(bq) + pad(bt) + pad(bv) + pad(bw), &pin);
     if (st) return st;
     char *pq = (char *)pin, *pt = pq + pad(bq), *pv = pt + pad(bt), *pw = pv + pad(bv);
-    std::memcpy(pq, q, bq);
-    MSM_HIP(ctx_scratch(ctx, 0, bq, (void **)&dq));
-    MSM_HIP(hipMemcpyAsync(dq, pq, bq, hipMemcpyHostToDevice, ctx->stream));
+    if (q_on_device) {
+        dq = const_cast<double *>(q_on_device);
+    } else {
+        std::memcpy(pq, q, bq);
+        MSM_HIP(ctx_scratch(ctx, 0, bq, (void **)&dq));
+        MSM_HIP(hipMemcpyAsync(dq, pq, bq, hipMemcpyHostToDevice, ctx->stream));
+    }
     if (tri_id) MSM_HIP(ctx_scratch(ctx, 1, bt, (void **)&dt));
     if (vid) MSM_HIP(ctx_scratch(ctx, 2, bv, (void **)&dv));
     if (w) MSM_HIP(ctx_scratch(ctx, 3, bw, (void **)&dw));
@@ -358,9 +366,13 @@ int adaptive_queries(msm_mesh *in_mesh, msm_mesh *new_mesh, bool with_closest, A
     q.rvid.resize(3 * (size_t)nOld);
     q.fw.resize(3 * (size_t)nNew);
     q.rw.resize(3 * (size_t)nOld);
-    int st = query_host(in_mesh, new_mesh->xyz.data(), nNew, nullptr, q.fvid.data(), q.fw.data(), MSM_WEIGHTS_PROJECTED, "adaptive weights (forward)");
+    // the query points are the other mesh's vertices, which its handle keeps in HBM (same context, same stream)
+    const bool same_ctx = in_mesh->ctx == new_mesh->ctx;
+    int st = query_host(in_mesh, new_mesh->xyz.data(), nNew, nullptr, q.fvid.data(), q.fw.data(), MSM_WEIGHTS_PROJECTED, "adaptive weights (forward)",
+                        same_ctx ? new_mesh->d_xyz : nullptr);
     if (st) return st;
-    st = query_host(new_mesh, in_mesh->xyz.data(), nOld, nullptr, q.rvid.data(), q.rw.data(), MSM_WEIGHTS_PROJECTED, "adaptive weights (reverse)");
+    st = query_host(new_mesh, in_mesh->xyz.data(), nOld, nullptr, q.rvid.data(), q.rw.data(), MSM_WEIGHTS_PROJECTED, "adaptive weights (reverse)",
+                    same_ctx ? in_mesh->d_xyz : nullptr);
     if (st) return st;
     q.closest.clear();
     if (with_closest) {

@@ -83,7 +83,7 @@ struct msm_cost {
 namespace msm {
 int adaptive_weights(msm_mesh *in_mesh, msm_mesh *new_mesh, const double *excl, std::vector<int32_t> &row_ptr, std::vector<int32_t> &col,
                      std::vector<double> &val);
-int query_host(msm_mesh *target, const double *q, int N, int *tri_id, int *vid, double *w, int mode, const char *what);
+int query_host(msm_mesh *target, const double *q, int N, int *tri_id, int *vid, double *w, int mode, const char *what, const double *q_on_device = nullptr);
 const Adjacency &mesh_adjacency(msm_mesh *m);
 // (re)computes the per (control point, label) rotation matrices and moved control points if stale
 int ensure_label_rotations(msm_cost *c);
