@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <cstring>
 #include <cstdio>
 #include <cstdlib>
 #include <cmath>
@@ -58,6 +59,8 @@ struct msm_group {
     std::vector<std::vector<int32_t>> h_pptr, h_pidx;
     DevBuf<const double *> d_Fp;
     DevBuf<const int *> d_pptrp, d_pidxp;
+    DevBuf<int> d_query[4];   // index columns of a batch of evaluations (kept between calls)
+    DevBuf<double> d_answer;
 };
 
 namespace {
@@ -161,6 +164,26 @@ int group_args(msm_group *g, GroupArgs &a) {
     a.percentile = g->p.percentile;
     a.patch_cap = g->patch_max;
     a.status = g->ctx->d_status;
+    return MSM_OK;
+}
+
+constexpr int kBatchChunk = 1 << 22;  // evaluations per launch of a batch call (84 MB of pinned staging at most)
+
+// the index columns of a batch go through the context's pinned block into buffers kept on the handle (no allocation and no
+// pageable copy per call); *pinned_out is where the caller's kernel output is to be copied for the way back
+int stage_batch(msm_group *g, const int32_t *const *cols, int ncols, int n, double **pinned_out) {
+    msm_ctx *ctx = g->ctx;
+    const size_t bi = (sizeof(int32_t) * (size_t)n + 255) & ~(size_t)255, bo = sizeof(double) * (size_t)n;
+    void *pin = nullptr;
+    int st = ctx_io_pinned(ctx, bi * ncols + bo, &pin);
+    if (st) return st;
+    for (int k = 0; k < ncols; ++k) {
+        MSM_HIP(g->d_query[k].ensure(n));
+        std::memcpy((char *)pin + bi * k, cols[k], sizeof(int32_t) * (size_t)n);
+        MSM_HIP(hipMemcpyAsync(g->d_query[k].p, (char *)pin + bi * k, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    }
+    MSM_HIP(g->d_answer.ensure(n));
+    *pinned_out = reinterpret_cast<double *>((char *)pin + bi * ncols);
     return MSM_OK;
 }
 
@@ -598,16 +621,20 @@ int msm_group_pairwise_batch(msm_group *g, const int32_t *pair, const int32_t *l
     for (int i = 0; i < n; ++i)
         if (pair[i] < 0 || pair[i] >= P || la[i] < 0 || la[i] >= g->L || lb[i] < 0 || lb[i] >= g->L) return fail(MSM_ERR_INVALID, "group pairwise query %d out of range", i);
     msm_ctx *ctx = g->ctx;
-    DevBuf<int> qp, qa, qb;
-    DevBuf<double> dout;
-    MSM_HIP(qp.upload(pair, n, ctx->stream));
-    MSM_HIP(qa.upload(la, n, ctx->stream));
-    MSM_HIP(qb.upload(lb, n, ctx->stream));
-    MSM_HIP(dout.ensure(n));
-    st = launch_group_pairwise(ctx, a, qp.p, qa.p, qb.p, n, dout.p);
-    if (st) return st;
-    MSM_HIP(dout.download(out, n, ctx->stream));
-    return check_status(ctx, "DiscreteGroupCostFunction::computePairwiseCost");
+    for (int off = 0; off < n; off += kBatchChunk) {  // bounded pinned staging, whatever the batch
+        const int m = std::min(kBatchChunk, n - off);
+        const int32_t *cols[3] = {pair + off, la + off, lb + off};
+        double *pinned_out = nullptr;
+        st = stage_batch(g, cols, 3, m, &pinned_out);
+        if (st) return st;
+        st = launch_group_pairwise(ctx, a, g->d_query[0].p, g->d_query[1].p, g->d_query[2].p, m, g->d_answer.p);
+        if (st) return st;
+        MSM_HIP(hipMemcpyAsync(pinned_out, g->d_answer.p, sizeof(double) * (size_t)m, hipMemcpyDeviceToHost, ctx->stream));
+        st = check_status(ctx, "DiscreteGroupCostFunction::computePairwiseCost");
+        std::memcpy(out + off, pinned_out, sizeof(double) * (size_t)m);
+        if (st) return st;
+    }
+    return MSM_OK;
 }
 
 int msm_group_triplet_batch(msm_group *g, const int32_t *t, const int32_t *la, const int32_t *lb, const int32_t *lc, int32_t n, double *out) {
@@ -621,17 +648,20 @@ int msm_group_triplet_batch(msm_group *g, const int32_t *t, const int32_t *la, c
         if (t[i] < 0 || t[i] >= T || la[i] < 0 || la[i] >= g->L || lb[i] < 0 || lb[i] >= g->L || lc[i] < 0 || lc[i] >= g->L)
             return fail(MSM_ERR_INVALID, "group triplet query %d out of range", i);
     msm_ctx *ctx = g->ctx;
-    DevBuf<int> qt, qa, qb, qc;
-    DevBuf<double> dout;
-    MSM_HIP(qt.upload(t, n, ctx->stream));
-    MSM_HIP(qa.upload(la, n, ctx->stream));
-    MSM_HIP(qb.upload(lb, n, ctx->stream));
-    MSM_HIP(qc.upload(lc, n, ctx->stream));
-    MSM_HIP(dout.ensure(n));
-    st = launch_group_triplet(ctx, a, qt.p, qa.p, qb.p, qc.p, n, dout.p);
-    if (st) return st;
-    MSM_HIP(dout.download(out, n, ctx->stream));
-    return check_status(ctx, "DiscreteGroupCostFunction::computeTripletCost");
+    for (int off = 0; off < n; off += kBatchChunk) {
+        const int m = std::min(kBatchChunk, n - off);
+        const int32_t *cols[4] = {t + off, la + off, lb + off, lc + off};
+        double *pinned_out = nullptr;
+        st = stage_batch(g, cols, 4, m, &pinned_out);
+        if (st) return st;
+        st = launch_group_triplet(ctx, a, g->d_query[0].p, g->d_query[1].p, g->d_query[2].p, g->d_query[3].p, m, g->d_answer.p);
+        if (st) return st;
+        MSM_HIP(hipMemcpyAsync(pinned_out, g->d_answer.p, sizeof(double) * (size_t)m, hipMemcpyDeviceToHost, ctx->stream));
+        st = check_status(ctx, "DiscreteGroupCostFunction::computeTripletCost");
+        std::memcpy(out + off, pinned_out, sizeof(double) * (size_t)m);
+        if (st) return st;
+    }
+    return MSM_OK;
 }
 
 }  // extern "C"
