@@ -316,6 +316,11 @@ int msm_group_patch(msm_group *g, int32_t subject, int32_t cp, int32_t label, in
 /* computePairwiseCost M/DiscreteGroupCostFunction.cpp:54-98 / computeTripletCost :26-52 for n queries */
 int msm_group_pairwise_batch(msm_group *g, const int32_t *pair, const int32_t *la, const int32_t *lb, int32_t n, double *out);
 int msm_group_triplet_batch(msm_group *g, const int32_t *triplet, const int32_t *la, const int32_t *lb, const int32_t *lc, int32_t n, double *out);
+/* One label step of Fusion::optimize (I/Fusion/Fusion.h:157-196) in one call: labeling (S * N, by global node id) is the
+ * current labeling, label the proposed one.  pair_quads[4 * p + k] = pair_data[p].buffer[k] (k = 2 * [A takes the label] +
+ * [B takes it]) and triplet_octets[8 * t + k] = triplet_data[t].buffer[k] (k = 000..111); either output may be NULL.
+ * Nothing but the labeling travels to the GPU. */
+int msm_group_fusion_move(msm_group *g, const int32_t *labeling, int32_t label, double *pair_quads, double *triplet_octets);
 
 #ifdef __cplusplus
 }

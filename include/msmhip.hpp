@@ -442,6 +442,14 @@ public:
         check(msm_group_get_triplets(h_, out.data()));
         return out;
     }
+    // one label step of Fusion::optimize (I/Fusion/Fusion.h:157-196): pair_data[p].buffer[0..3] and triplet_data[t].buffer[0..7]
+    void fusionMove(const std::vector<int32_t> &labeling, int label, std::vector<double> &pair_quads, std::vector<double> &triplet_octets) {
+        int32_t nodes = 0, pairs = 0, triplets = 0;
+        check(msm_group_sizes(h_, &nodes, &pairs, &triplets));
+        pair_quads.resize(4 * (size_t)pairs);
+        triplet_octets.resize(8 * (size_t)triplets);
+        check(msm_group_fusion_move(h_, labeling.data(), label, pair_quads.data(), triplet_octets.data()));
+    }
     std::vector<double> computePairwiseCost(const std::vector<int32_t> &pair, const std::vector<int32_t> &a, const std::vector<int32_t> &b) {
         std::vector<double> out(pair.size());
         check(msm_group_pairwise_batch(h_, pair.data(), a.data(), b.data(), (int32_t)pair.size(), out.data()));

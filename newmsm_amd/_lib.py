@@ -109,6 +109,7 @@ SIGNATURES = {
     "msm_cost_kernel_times": (C.c_int, [_VP, c_dp, C.c_int32, c_ip]),
     "msm_cost_counters": (C.c_int, [_VP, c_lp]),
     "msm_group_create": (_VP, [_VP, C.POINTER(GroupParams), C.c_int32]),
+    "msm_group_fusion_move": (C.c_int, [_VP, c_ip, C.c_int32, c_dp, c_dp]),
     "msm_group_destroy": (None, [_VP]),
     "msm_group_set_template": (C.c_int, [_VP, _VP, c_dp]),
     "msm_group_set_controlgrid": (C.c_int, [_VP, c_dp, c_ip, C.c_int32, C.c_int32]),

@@ -605,6 +605,13 @@ class DiscreteGroupCostFunction:
         check(lib().msm_group_get_pairs(self.h, out.ctypes.data_as(c_ip)))
         return out
 
+    def fusionMove(self, labeling, label):
+        """one label step of Fusion::optimize (Fusion.h:157-196): (pair_data buffers P x 4, triplet_data buffers T x 8)"""
+        lab, pl = _i(labeling)
+        quads, octets = np.zeros((self.P, 4)), np.zeros((self.T, 8))
+        check(lib().msm_group_fusion_move(self.h, pl, int(label), quads.ctypes.data_as(c_dp), octets.ctypes.data_as(c_dp)))
+        return quads, octets
+
     def getTriplets(self):
         out = np.zeros((self.T, 3), dtype=np.int32)
         check(lib().msm_group_get_triplets(self.h, out.ctypes.data_as(c_ip)))

@@ -162,6 +162,8 @@ int group_args(msm_group *g, GroupArgs &a) {
     a.rexp = g->p.rexp;
     a.subcorr = 0.1 * g->S;  // set_meshes, M/DiscreteGroupCostFunction.h:45
     a.percentile = g->p.percentile;
+    a.move_labeling = nullptr;
+    a.move_label = a.move_offset = 0;
     a.patch_cap = g->patch_max;
     a.status = g->ctx->d_status;
     return MSM_OK;
@@ -633,6 +635,43 @@ int msm_group_pairwise_batch(msm_group *g, const int32_t *pair, const int32_t *l
         st = check_status(ctx, "DiscreteGroupCostFunction::computePairwiseCost");
         std::memcpy(out + off, pinned_out, sizeof(double) * (size_t)m);
         if (st) return st;
+    }
+    return MSM_OK;
+}
+
+int msm_group_fusion_move(msm_group *g, const int32_t *labeling, int32_t label, double *pair_quads, double *triplet_octets) {
+    if (!g || !labeling) return fail(MSM_ERR_INVALID, "msm_group_fusion_move: null argument");
+    GroupArgs a;
+    int st = group_args(g, a);
+    if (st) return st;
+    const int nodes = g->S * g->N;
+    if (label < 0 || label >= g->L) return fail(MSM_ERR_INVALID, "msm_group_fusion_move: label %d out of range", label);
+    for (int i = 0; i < nodes; ++i)
+        if (labeling[i] < 0 || labeling[i] >= g->L) return fail(MSM_ERR_INVALID, "msm_group_fusion_move: label of node %d out of range", i);
+    msm_ctx *ctx = g->ctx;
+    MSM_HIP(g->d_query[0].upload(labeling, nodes, ctx->stream));
+    a.move_labeling = g->d_query[0].p;
+    a.move_label = label;
+    const int64_t P = (int64_t)(g->pairs.size() / 2), T = (int64_t)g->S * g->Tc;
+    for (int pass = 0; pass < 2; ++pass) {
+        double *out = pass == 0 ? pair_quads : triplet_octets;
+        const int64_t total = pass == 0 ? 4 * P : 8 * T;
+        if (!out) continue;
+        for (int64_t off = 0; off < total; off += kBatchChunk) {
+            const int m = (int)std::min<int64_t>(kBatchChunk, total - off);
+            void *pin = nullptr;
+            st = ctx_io_pinned(ctx, sizeof(double) * (size_t)m, &pin);
+            if (st) return st;
+            MSM_HIP(g->d_answer.ensure(m));
+            a.move_offset = (int)off;
+            st = pass == 0 ? launch_group_pairwise(ctx, a, nullptr, nullptr, nullptr, m, g->d_answer.p)
+                           : launch_group_triplet(ctx, a, nullptr, nullptr, nullptr, nullptr, m, g->d_answer.p);
+            if (st) return st;
+            MSM_HIP(hipMemcpyAsync(pin, g->d_answer.p, sizeof(double) * (size_t)m, hipMemcpyDeviceToHost, ctx->stream));
+            st = check_status(ctx, "DiscreteGroupCostFunction (fusion move)");
+            std::memcpy(out + off, pin, sizeof(double) * (size_t)m);
+            if (st) return st;
+        }
     }
     return MSM_OK;
 }

@@ -53,7 +53,15 @@ __global__ __launch_bounds__(256) void k_group_pairwise(GroupArgs a, const int *
     const int q = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (q >= n) return;
     extern __shared__ double s_common[];
-    const int pair = qp[q], la = qa[q], lb = qb[q];
+    int pair, la, lb;
+    if (a.move_labeling) {  // Fusion's pair_data[pair].buffer[k], I/Fusion/Fusion.h:170-173: k = 2 * (A takes the label) + (B takes it)
+        const int e = q + a.move_offset;
+        pair = e >> 2;
+        la = (e & 2) ? a.move_label : a.move_labeling[a.pairs[2 * pair]];
+        lb = (e & 1) ? a.move_label : a.move_labeling[a.pairs[2 * pair + 1]];
+    } else {
+        pair = qp[q], la = qa[q], lb = qb[q];
+    }
     const int ga = a.pairs[2 * pair], gb = a.pairs[2 * pair + 1];
     const int sa = ga / a.N, sb = gb / a.N, na = ga - sa * a.N, nb = gb - sb * a.N;
     const int *pa = a.pptr[sa], *pb = a.pptr[sb];
@@ -175,9 +183,16 @@ __global__ __launch_bounds__(128) void k_group_triplet(GroupArgs a, const int *_
                                                         const int *__restrict__ qb, const int *__restrict__ qc, int n, double *__restrict__ out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const int t = qt[i];
+    int t, lab[3];
+    if (a.move_labeling) {  // triplet_data[t].buffer[k], k = 000..111, I/Fusion/Fusion.h:188-195
+        const int e = i + a.move_offset;
+        t = e >> 3;
+        for (int k = 0; k < 3; ++k) lab[k] = (e >> (2 - k) & 1) ? a.move_label : a.move_labeling[a.triplets[3 * t + k]];
+    } else {
+        t = qt[i];
+        lab[0] = qa[i], lab[1] = qb[i], lab[2] = qc[i];
+    }
     const int s = t / a.Tc;
-    const int lab[3] = {qa[i], qb[i], qc[i]};
     V3 r[3], cur[3], org[3];
     for (int k = 0; k < 3; ++k) {
         const int gid = a.triplets[3 * t + k], v = gid - s * a.N;

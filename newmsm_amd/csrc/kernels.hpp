@@ -138,6 +138,10 @@ struct GroupArgs {
     const double *orig;          // S x (3 x N) _ORIG_MESHES coordinates of the control-point ids
     double lambda, mu, kappa, k_exp, rexp, subcorr;
     double percentile;           // DICE threshold rank
+    // fusion move (msm_group_fusion_move): evaluation e = move_offset + query index is pair e / 4 (triplet e / 8) with the
+    // proposed label where bit k of e % 4 (e % 8) is set and the current labeling elsewhere; nullptr: explicit index columns
+    const int *move_labeling;
+    int move_label, move_offset;
     int patch_cap;               // largest patch of any subject (DICE: LDS staging of the common entries)
     int *status;
 };

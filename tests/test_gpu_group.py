@@ -102,6 +102,32 @@ def test_group_rejects_bad_similarity(ctx):
         M.DiscreteGroupCostFunction(ctx, 2, simmeasure=4, percentile=1.0)
 
 
+def test_group_fusion_move(ctx):
+    """one label step of Fusion::optimize in one call: the four pair costs and eight triplet costs per clique, in the buffer
+    order of Fusion.h:170-173,188-195, equal to the explicit batches (same kernels) and to the oracle"""
+    g, og, _ = build(ctx, mask=True)
+    rng = np.random.default_rng(5)
+    labeling = rng.integers(0, g.L, g.num_nodes).astype(np.int32)
+    label = 7
+    quads, octets = g.fusionMove(labeling, label)
+    pairs, trips = g.getPairs(), g.getTriplets()
+    p = np.repeat(np.arange(g.P, dtype=np.int32), 4)
+    k = np.tile(np.arange(4), g.P)
+    la = np.where(k & 2, label, labeling[pairs[p, 0]]).astype(np.int32)
+    lb = np.where(k & 1, label, labeling[pairs[p, 1]]).astype(np.int32)
+    assert np.array_equal(quads.ravel(), g.computePairwiseCost(p, la, lb), equal_nan=True)
+    t = np.repeat(np.arange(g.T, dtype=np.int32), 8)
+    k = np.tile(np.arange(8), g.T)
+    lab3 = [np.where(k >> (2 - j) & 1, label, labeling[trips[t, j]]).astype(np.int32) for j in range(3)]
+    assert np.array_equal(octets.ravel(), g.computeTripletCost(t, *lab3))
+    for i in rng.integers(0, 4 * g.P, 60):
+        want = og.pairwise(int(p[i]), int(la[i]), int(lb[i]))
+        assert (np.isnan(want) and np.isnan(quads.ravel()[i])) or abs(quads.ravel()[i] - want) <= ATOL + RTOL * abs(want)
+    for i in rng.integers(0, 8 * g.T, 60):
+        want = og.triplet(int(t[i]), int(lab3[0][i]), int(lab3[1][i]), int(lab3[2][i]))
+        assert abs(octets.ravel()[i] - want) <= ATOL + RTOL * abs(want)
+
+
 def test_group_triplet_costs(ctx):
     g, og, _ = build(ctx, D=1)
     rng = np.random.default_rng(2)

@@ -40,3 +40,8 @@ p = rng.integers(0, g.P, n).astype(np.int32); la = rng.integers(0, g.L, n).astyp
 g.computePairwiseCost(p[:1000], la[:1000], lb[:1000])
 t0 = time.perf_counter(); g.computePairwiseCost(p, la, lb); dt = time.perf_counter() - t0
 print("group pairwise: %d evals in %.3f s = %.2f M evals/s (incl. host transfers)" % (n, dt, n / dt / 1e6))
+# one label step of Fusion::optimize: 4P pairwise + 8T triplet evaluations from the labeling alone
+lab = rng.integers(0, g.L, g.num_nodes).astype(np.int32)
+g.fusionMove(lab, 3)
+t0 = time.perf_counter(); quads, octets = g.fusionMove(lab, 5); dt = time.perf_counter() - t0
+print("fusion move: %d pairwise + %d triplet evals in %.4f s = %.1f M evals/s (incl. the copy of the results to the host)" % (quads.size, octets.size, dt, (quads.size + octets.size) / dt / 1e6))
