@@ -105,6 +105,20 @@ static int upload_tree(msm_mesh *m) {
     return MSM_OK;
 }
 
+int upload_staged(msm_ctx *ctx, void *dst, const void *src, size_t bytes) {
+    if (bytes == 0) return MSM_OK;
+    MSM_HIP(hipStreamSynchronize(ctx->stream));  // an earlier upload may still read the staging buffer
+    if (bytes > ctx->stage_cap) {
+        if (ctx->stage) (void)hipHostFree(ctx->stage);
+        ctx->stage = nullptr;
+        ctx->stage_cap = bytes + bytes / 4;
+        MSM_HIP(hipHostMalloc(&ctx->stage, ctx->stage_cap));
+    }
+    std::memcpy(ctx->stage, src, bytes);
+    MSM_HIP(hipMemcpyAsync(dst, ctx->stage, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return MSM_OK;
+}
+
 int ensure_tree(msm_mesh *m) {
     if (m->tree_valid) return MSM_OK;
     build_octree(m->xyz.data(), m->tri.data(), m->V, m->T, m->tree);

@@ -61,6 +61,10 @@ struct msm_group {
     DevBuf<const int *> d_pptrp, d_pidxp;
     DevBuf<int> d_query[4];   // index columns of a batch of evaluations (kept between calls)
     DevBuf<double> d_answer;
+    // scratch of subject_patches, kept between subjects
+    DevBuf<double> d_centres, d_sep;
+    DevBuf<uint32_t> d_slots;
+    DevBuf<int> d_counts;
 };
 
 namespace {
@@ -72,6 +76,14 @@ inline V3 pt(const double *xyz, int V, int i) { return mk(xyz[i], xyz[V + i], xy
 int subject_patches(msm_group *g, int s) {
     msm_ctx *ctx = g->ctx;
     const int N = g->N, L = g->L, M = N * L, Vt = g->tmpl->V;
+    const bool timing = std::getenv("MSMHIP_TIMING") != nullptr;
+    auto tick = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "      patches: %s %.1f ms\n", what, std::chrono::duration<double, std::milli>(now - tick).count());
+        tick = now;
+    };
     std::vector<double> centres(3 * (size_t)M), sep(M);
     for (int v = 0; v < N; ++v)
         for (int l = 0; l < L; ++l) {
@@ -82,9 +94,9 @@ int subject_patches(msm_group *g, int s) {
             centres[2 * (size_t)M + k] = m[2];
             sep[k] = g->spacing[s][v];
         }
-    DevBuf<double> d_c, d_sep;
-    DevBuf<uint32_t> d_slots;
-    DevBuf<int> d_counts;
+    DevBuf<double> &d_c = g->d_centres, &d_sep = g->d_sep;
+    DevBuf<uint32_t> &d_slots = g->d_slots;
+    DevBuf<int> &d_counts = g->d_counts;
     MSM_HIP(d_c.upload(centres.data(), centres.size(), ctx->stream));
     MSM_HIP(d_sep.upload(sep.data(), sep.size(), ctx->stream));
     MSM_HIP(d_counts.ensure(M));
@@ -102,6 +114,7 @@ int subject_patches(msm_group *g, int s) {
         if (attempt == 2) return fail(MSM_ERR_CAPACITY, "group patch capacity");
         cap = mx + 16;
     }
+    lap("range kernel");
     // 50 MB at ico6 / 19 labels: through pinned memory (a pageable copy of this size took most of this function's time)
     void *pin = nullptr;
     {
@@ -111,28 +124,46 @@ int subject_patches(msm_group *g, int s) {
     const uint32_t *slots = static_cast<const uint32_t *>(pin);
     MSM_HIP(hipMemcpyAsync(pin, d_slots.p, sizeof(uint32_t) * (size_t)M * cap, hipMemcpyDeviceToHost, ctx->stream));
     MSM_HIP(hipStreamSynchronize(ctx->stream));
+    lap("slots to the host");
     auto &pp = g->h_pptr[s];
     auto &pi = g->h_pidx[s];
     pp.assign(M + 1, 0);
-    pi.clear();
     const double *tx = g->tmpl->xyz.data();
-    for (int k = 0; k < M; ++k) {
-        pp[k] = (int32_t)pi.size();
+    // an entry flagged by the kernel sits within 1e-11 of the threshold: decided with the host libm, as the reference does
+    auto keeps = [&](int k, uint32_t e) {
+        if (!(e & 0x80000000u)) return true;
         const V3 c = mk(centres[k], centres[M + k], centres[2 * (size_t)M + k]);
-        for (int j = 0; j < counts[k]; ++j) {
-            const uint32_t e = slots[(size_t)k * cap + j];
-            const int i = (int)(e & 0x7fffffffu);
-            if (e & 0x80000000u) {
-                const double arc = chord_to_arc(norm(sub(c, pt(tx, Vt, i))));
-                if (!(arc < g->p.range * sep[k])) continue;
-            }
-            pi.push_back(i);
+        const double arc = chord_to_arc(norm(sub(c, pt(tx, Vt, (int)(e & 0x7fffffffu)))));
+        return arc < g->p.range * sep[k];
+    };
+    const int workers = host_workers();
+    parallel_chunks(M, workers, [&](int, int k0, int k1) {  // rows are independent: count, then (below) fill at the prefix sums
+        for (int k = k0; k < k1; ++k) {
+            int n = 0;
+            for (int j = 0; j < counts[k]; ++j) n += keeps(k, slots[(size_t)k * cap + j]) ? 1 : 0;
+            pp[k + 1] = n;
         }
-    }
-    pp[M] = (int32_t)pi.size();
+    });
+    for (int k = 0; k < M; ++k) pp[k + 1] += pp[k];
+    pi.resize((size_t)pp[M]);
+    parallel_chunks(M, workers, [&](int, int k0, int k1) {
+        for (int k = k0; k < k1; ++k) {
+            int32_t *dst = pi.data() + pp[k];
+            for (int j = 0; j < counts[k]; ++j) {
+                const uint32_t e = slots[(size_t)k * cap + j];
+                if (keeps(k, e)) *dst++ = (int32_t)(e & 0x7fffffffu);
+            }
+        }
+    });
+    lap("lists");
     MSM_HIP(g->pptr[s]->upload(pp.data(), pp.size(), ctx->stream));
-    MSM_HIP(g->pidx[s]->upload_vec(pi, ctx->stream));
+    MSM_HIP(g->pidx[s]->ensure(std::max<size_t>(pi.size(), 1)));
+    {
+        int st = upload_staged(ctx, g->pidx[s]->p, pi.data(), pi.size() * sizeof(int32_t));  // 12.7 MB at ico6 / 19 labels
+        if (st) return st;
+    }
     MSM_HIP(hipStreamSynchronize(ctx->stream));
+    lap("uploads");
     return MSM_OK;
 }
 
@@ -468,7 +499,9 @@ int group_subject_setup(msm_group *g, int s) {
     for (int l = 0; l < L; ++l) {
         auto &buf = g->F[(size_t)s * L + l];
         if (!buf) buf.reset(new DevBuf<double>());
-        MSM_HIP(buf->upload(resampled[l].data(), resampled[l].size(), ctx->stream));
+        MSM_HIP(buf->ensure(resampled[l].size()));
+        int st = upload_staged(ctx, buf->p, resampled[l].data(), resampled[l].size() * sizeof(double));
+        if (st) return st;
     }
     MSM_HIP(hipStreamSynchronize(ctx->stream));
     lap("weights + resample");

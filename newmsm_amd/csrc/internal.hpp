@@ -188,4 +188,7 @@ int ensure_rays(msm_mesh *m, bool wait = false);   // + the ray table of a simpl
 DevTree dev_tree(const msm_mesh *m);
 int check_status(msm_ctx *ctx, const char *what);  // sync + read kernel status
 int ctx_io_pinned(msm_ctx *ctx, size_t bytes, void **out);  // grow-only pinned scratch for small per-call transfers
+// host -> device through the context's pinned staging buffer (pageable copies of tens of MB ran at < 1 GB/s); waits for
+// earlier work on the stream first, returns with the copy queued
+int upload_staged(msm_ctx *ctx, void *dst, const void *src, size_t bytes);
 }  // namespace msm
