@@ -476,9 +476,14 @@ class DiscreteCostFunction:
         return out
 
     def computeTripletCosts(self, t0=0, t1=None):
-        """tcosts[t][a][b][c] (M/DiscreteCostFunction.cpp:245-253) for the triplets t0 <= t < t1."""
+        """tcosts[t][a][b][c] (M/DiscreteCostFunction.cpp:245-253) for the triplets t0 <= t < t1.  Like the reference's
+        tcosts member the table lives in the object: the returned array is reused by the next call of the same shape (a fresh
+        281 MB array per call costs more in page faults than the table takes to compute and copy)."""
         t1 = self.T if t1 is None else t1
-        out = np.zeros((t1 - t0, self.L, self.L, self.L))
+        shape = (t1 - t0, self.L, self.L, self.L)
+        out = self._keep.get("tcosts")
+        if out is None or out.shape != shape:
+            out = self._keep["tcosts"] = np.empty(shape)
         check(lib().msm_cost_triplet_table(self.h, int(t0), int(t1), out.ctypes.data_as(c_dp)))
         return out
 
