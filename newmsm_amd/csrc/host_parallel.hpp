@@ -39,8 +39,10 @@ inline int host_workers() {
 class WorkerPool {
 public:
     static WorkerPool &instance() {
-        static WorkerPool pool;
-        return pool;
+        // never destroyed: a background set-up job (api.cpp: RayJob) may still be running when the process exits, and its
+        // parallel sections must not find a pool that static destruction has taken apart; the idle threads end with the process
+        static WorkerPool *pool = new WorkerPool;
+        return *pool;
     }
     // runs fn(0..n-1) on the caller and up to workers-1 pool threads; false when the pool is in use (caller falls back)
     bool run(int n, int workers, const std::function<void(int)> &fn) {
