@@ -18,6 +18,14 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
+// sum over the kLanes lanes (64, or an aligned half of the wavefront) that share a query
+template <int kLanes>
+__device__ __forceinline__ double lanes_sum(double v) {
+#pragma unroll
+    for (int off = kLanes / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
 constexpr int kGroupStage = 256;  // ids of patch B staged in LDS per wavefront
 
 }  // namespace
@@ -47,10 +55,12 @@ int launch_rotate_to_label(msm_ctx *ctx, const double *d_xyz, int V, const doubl
 // the two subjects' resampled features over the intersection is reduced per feature dimension with shuffles.
 // kDice (DICE / genDICE): the common entries of one feature dimension are first packed, in patch order, into the
 // wavefront's LDS rows (2 x patch_cap doubles) and thresholded there by rank counting (similarity_device.hpp).
-template <bool kDice>
+template <bool kDice, int kLanes>
 __global__ __launch_bounds__(256) void k_group_pairwise(GroupArgs a, const int *__restrict__ qp, const int *__restrict__ qa,
                                                          const int *__restrict__ qb, int n, double *__restrict__ out) {
-    const int q = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    static_assert(kLanes == 64 || (kLanes == 32 && !kDice), "DICE uses whole wavefronts");
+    constexpr int kPerBlock = 256 / kLanes;
+    const int slot = threadIdx.x / kLanes, q = blockIdx.x * kPerBlock + slot, lane = threadIdx.x & (kLanes - 1);
     if (q >= n) return;
     extern __shared__ double s_common[];
     int pair, la, lb;
@@ -72,18 +82,18 @@ __global__ __launch_bounds__(256) void k_group_pairwise(GroupArgs a, const int *
     const double nan = __longlong_as_double(0x7ff8000000000000ll);
     // B's ids go to LDS first when they fit (patches hold ~65 entries at ico6 / ico4): the binary search below is a chain
     // of dependent loads, and seven round trips to memory per query were most of this kernel's time
-    __shared__ int s_ids[4][kGroupStage];
-    int *stage = s_ids[threadIdx.x >> 6];
+    __shared__ int s_ids[kPerBlock][kGroupStage];
+    int *stage = s_ids[slot];
     const bool staged = cntB <= kGroupStage;
     if (staged)
-        for (int i = lane; i < cntB; i += 64) stage[i] = ib[i];
+        for (int i = lane; i < cntB; i += kLanes) stage[i] = ib[i];
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     const int *fb = staged ? stage : ib;
-    // membership of A's entries in B, kept as a bit per (lane, round): patches hold at most 64 * 32 entries
-    unsigned member = 0u;
+    // membership of A's entries in B, kept as a bit per (lane, round): patches hold at most 2048 entries
+    unsigned long long member = 0ull;
     int common = 0;
-    for (int r = 0, i = lane; i < cntA; i += 64, ++r) {
+    for (int r = 0, i = lane; i < cntA; i += kLanes, ++r) {
         const int id = ia[i];
         int lo = 0, hi = cntB;
         while (lo < hi) {
@@ -92,12 +102,12 @@ __global__ __launch_bounds__(256) void k_group_pairwise(GroupArgs a, const int *
             else hi = mid;
         }
         if (lo < cntB && fb[lo] == id) {
-            member |= 1u << r;
+            member |= 1ull << r;
             ++common;
         }
     }
     if (cntA > 64 * 32) raise_status(a.status, MSM_ERR_CAPACITY);
-    const int ncommon = (int)wave_sum((double)common);
+    const int ncommon = (int)lanes_sum<kLanes>((double)common);
     double cost = 0.0;
     if (ncommon == 0) {
         cost = nan;  // the reference indexes an empty vector here (undefined behaviour)
@@ -106,11 +116,11 @@ __global__ __launch_bounds__(256) void k_group_pairwise(GroupArgs a, const int *
             const double *A = FA + (size_t)d * a.Vt, *B = FB + (size_t)d * a.Vt;
             double c;
             if constexpr (kDice) {  // sparsesimkernel::DICE / genDICE, M/similarities.cpp:201-253 (weights unused)
-                double *SA = s_common + (size_t)(threadIdx.x >> 6) * 2 * a.patch_cap, *SB = SA + a.patch_cap;
+                double *SA = s_common + (size_t)slot * 2 * a.patch_cap, *SB = SA + a.patch_cap;
                 int base = 0;
                 for (int r = 0, i0 = 0; i0 < cntA; i0 += 64, ++r) {
                     const int i = i0 + lane;
-                    const bool m = i < cntA && (member >> r & 1u);
+                    const bool m = i < cntA && (member >> r & 1ull);
                     const unsigned long long bal = __ballot(m);
                     if (m) {
                         const int pos = base + __popcll(bal & ((1ull << lane) - 1)), id = ia[i];
@@ -126,33 +136,33 @@ __global__ __launch_bounds__(256) void k_group_pairwise(GroupArgs a, const int *
                 __builtin_amdgcn_wave_barrier();
             } else if (a.simmeasure == 2) {  // sparsesimkernel::corr, M/similarities.cpp:129-158
                 double sw = 0, ma = 0, mb = 0;
-                for (int r = 0, i = lane; i < cntA; i += 64, ++r)
-                    if (member >> r & 1u) {
+                for (int r = 0, i = lane; i < cntA; i += kLanes, ++r)
+                    if (member >> r & 1ull) {
                         const int id = ia[i];
                         const double w = a.mask ? fabs(a.mask[id]) : 1.0;
                         sw += w;
                         ma += w * A[id];
                         mb += w * B[id];
                     }
-                sw = wave_sum(sw);
-                ma = wave_sum(ma);
-                mb = wave_sum(mb);
+                sw = lanes_sum<kLanes>(sw);
+                ma = lanes_sum<kLanes>(ma);
+                mb = lanes_sum<kLanes>(mb);
                 if (sw > 0.0) {
                     ma /= sw;
                     mb /= sw;
                 }
                 double pr = 0, va = 0, vb = 0;
-                for (int r = 0, i = lane; i < cntA; i += 64, ++r)
-                    if (member >> r & 1u) {
+                for (int r = 0, i = lane; i < cntA; i += kLanes, ++r)
+                    if (member >> r & 1ull) {
                         const int id = ia[i];
                         const double w = a.mask ? fabs(a.mask[id]) : 1.0, da = A[id] - ma, db = B[id] - mb;
                         pr += w * da * db;
                         va += w * da * da;
                         vb += w * db * db;
                     }
-                pr = wave_sum(pr);
-                va = wave_sum(va);
-                vb = wave_sum(vb);
+                pr = lanes_sum<kLanes>(pr);
+                va = lanes_sum<kLanes>(va);
+                vb = lanes_sum<kLanes>(vb);
                 if (sw > 0.0) {
                     pr /= sw;
                     va /= sw;
@@ -162,13 +172,13 @@ __global__ __launch_bounds__(256) void k_group_pairwise(GroupArgs a, const int *
                 c = 1 - (1 + rr) * 0.5;
             } else {  // sparsesimkernel::SSD, :179-188
                 double pr = 0;
-                for (int r = 0, i = lane; i < cntA; i += 64, ++r)
-                    if (member >> r & 1u) {
+                for (int r = 0, i = lane; i < cntA; i += kLanes, ++r)
+                    if (member >> r & 1ull) {
                         const int id = ia[i];
                         const double w = a.mask ? fabs(a.mask[id]) : 1.0, df = A[id] - B[id];
                         pr += w * df * df;
                     }
-                pr = wave_sum(pr);
+                pr = lanes_sum<kLanes>(pr);
                 c = sqrt(pr) / ncommon;
             }
             cost += c;
@@ -217,10 +227,11 @@ int launch_group_pairwise(msm_ctx *ctx, const GroupArgs &a, const int *qp, const
     if (a.simmeasure == 4 || a.simmeasure == 5) {
         const size_t lds = sizeof(double) * 4 * 2 * (size_t)std::max(a.patch_cap, 1);  // <= 128 KB: patches hold at most 2048 entries
         if (lds > 160 * 1024) return fail(MSM_ERR_CAPACITY, "group patch of %d entries does not fit in LDS", a.patch_cap);
-        if (lds > 64 * 1024) MSM_HIP(hipFuncSetAttribute((const void *)k_group_pairwise<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_group_pairwise<true>, dim3((n + 3) / 4), dim3(256), lds, ctx->stream, a, qp, qa, qb, n, out);
+        if (lds > 64 * 1024) MSM_HIP(hipFuncSetAttribute((const void *)k_group_pairwise<true, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((k_group_pairwise<true, 64>), dim3((n + 3) / 4), dim3(256), lds, ctx->stream, a, qp, qa, qb, n, out);
     } else {
-        hipLaunchKernelGGL(k_group_pairwise<false>, dim3((n + 3) / 4), dim3(256), 0, ctx->stream, a, qp, qa, qb, n, out);
+        // half a wavefront per query: patches hold ~65 entries, so two queries share a wavefront's latency
+        hipLaunchKernelGGL((k_group_pairwise<false, 32>), dim3((n + 7) / 8), dim3(256), 0, ctx->stream, a, qp, qa, qb, n, out);
     }
     MSM_HIP(hipGetLastError());
     return MSM_OK;
