@@ -96,5 +96,40 @@ def more(inp, inp1):
     print("wrote oracle_more.npz:", {k: v.shape for k, v in out.items()})
 
 
+def folded_ico3():
+    """an ico3 sphere with five vertices pushed across a neighbour (shared with tests/test_golden.py)"""
+    xyz, tri = O.icosphere(3)
+    m = O.Mesh(xyz, tri)
+    nbr_ptr, nbr, _, _ = m.adjacency()
+    bad = xyz.copy()
+    for v in (17, 101, 230, 400, 601):
+        n = nbr[nbr_ptr[v] + 1]
+        p = xyz[n] + 1.3 * (xyz[n] - xyz[v])
+        bad[v] = p * 100.0 / np.linalg.norm(p)
+    return xyz, tri, bad
+
+
+def around():
+    """Third file: what brackets the path each iteration -- unfold, variance_normalise, exclusion masks."""
+    out = {}
+    xyz, tri, bad = folded_ico3()
+    m = O.Mesh(bad, tri)
+    passes, first = O.unfold(m)
+    out.update(h1_counts=np.array([passes, first]), h1_unfolded=m.xyz)
+    rng = np.random.default_rng(11)
+    data = rng.normal(1.0, 2.0, size=(2, len(xyz)))
+    keep = (rng.random(len(xyz)) > 0.3).astype(float)
+    out.update(h2_data=data, h2_keep=keep, h2_normed=O.variance_normalise(data, keep))
+    excl = O.create_exclusion(data, -0.5, 1e9)
+    x2, t2 = O.icosphere(2)
+    res, mask = O.metric_resample_excl(O.Mesh(xyz, tri), data, O.Mesh(x2, t2), excl)
+    q = synthetic.random_sphere_points(200, seed=3)
+    nn, nmask = O.nearest_neighbour_excl(O.Mesh(xyz, tri), data, q, excl)
+    out.update(h3_excl=excl, h3_resampled=res, h3_mask=mask, h3_q=q, h3_nn=nn, h3_nnmask=nmask)
+    np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "oracle_around.npz"), **out)
+    print("wrote oracle_around.npz:", {k: v.shape for k, v in out.items()})
+
+
 if __name__ == "__main__":
     main()
+    around()

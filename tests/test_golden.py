@@ -109,3 +109,40 @@ def test_gpu_reproduces_golden_more(ctx):
     xyz, tri = M.make_mesh_from_icosa(3)
     m = M.Mesh(ctx, xyz, tri)
     assert np.allclose(M.smooth_data(m, G2["g9_data"], m, 12.0), G2["g9_smooth"], rtol=1e-12, atol=1e-14)
+
+
+G3 = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_around.npz"))
+
+
+def _folded():
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "make_golden.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.folded_ico3()
+
+
+def test_oracle_reproduces_golden_around(built):
+    xyz, tri, bad = _folded()
+    m = O.Mesh(bad, tri)
+    assert tuple(G3["h1_counts"]) == O.unfold(m) and np.array_equal(m.xyz, G3["h1_unfolded"])
+    assert np.array_equal(O.variance_normalise(G3["h2_data"], G3["h2_keep"]), G3["h2_normed"])
+    assert np.array_equal(M.variance_normalise(G3["h2_data"], G3["h2_keep"]), G3["h2_normed"])  # [host] entry point, no GPU
+    assert np.array_equal(M.create_exclusion(G3["h2_data"], -0.5, 1e9), G3["h3_excl"])
+    x2, t2 = O.icosphere(2)
+    res, mask = O.metric_resample_excl(O.Mesh(xyz, tri), G3["h2_data"], O.Mesh(x2, t2), G3["h3_excl"])
+    assert np.array_equal(res, G3["h3_resampled"], equal_nan=True) and np.array_equal(mask, G3["h3_mask"], equal_nan=True)
+
+
+@pytest.mark.gpu
+def test_gpu_reproduces_golden_around(ctx):
+    xyz, tri, bad = _folded()
+    m = M.Mesh(ctx, bad, tri)
+    assert m.unfold() == tuple(G3["h1_counts"]) and np.array_equal(m.get_coords(), G3["h1_unfolded"])
+    x2, t2 = M.make_mesh_from_icosa(2)
+    src, dst = M.Mesh(ctx, xyz, tri), M.Mesh(ctx, x2, t2)
+    res, mask = M.metric_resample(src, G3["h2_data"], dst, excl=G3["h3_excl"])
+    assert np.array_equal(res, G3["h3_resampled"], equal_nan=True) and np.array_equal(mask, G3["h3_mask"], equal_nan=True)
+    nn, nmask = M.nearest_neighbour_interpolation(src, G3["h2_data"], G3["h3_q"], excl=G3["h3_excl"])
+    assert np.array_equal(nn, G3["h3_nn"]) and np.array_equal(nmask, G3["h3_nnmask"])
