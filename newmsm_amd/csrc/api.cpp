@@ -374,7 +374,7 @@ int vertex_areas(msm_mesh *m, std::vector<double> &area) {
 // queries run on the GPU (adaptive_queries); the list surgery (transpose, pick, area correction) is done on the
 // host in the reference's serial order so that every sum has the same operand order (adaptive_surgery: touches
 // no handle, so callers may run several of them on worker threads).
-int adaptive_queries(msm_mesh *in_mesh, msm_mesh *new_mesh, bool with_closest, AdaptiveQueries &q) {
+int adaptive_queries(msm_mesh *in_mesh, msm_mesh *new_mesh, bool with_closest, AdaptiveQueries &q, int directions) {
     const int nOld = in_mesh->V, nNew = new_mesh->V;
     q.fvid.resize(3 * (size_t)nNew);
     q.rvid.resize(3 * (size_t)nOld);
@@ -382,11 +382,14 @@ int adaptive_queries(msm_mesh *in_mesh, msm_mesh *new_mesh, bool with_closest, A
     q.rw.resize(3 * (size_t)nOld);
     // the query points are the other mesh's vertices, which its handle keeps in HBM (same context, same stream)
     const bool same_ctx = in_mesh->ctx == new_mesh->ctx;
-    int st = query_host(in_mesh, new_mesh->xyz.data(), nNew, nullptr, q.fvid.data(), q.fw.data(), MSM_WEIGHTS_PROJECTED, "adaptive weights (forward)",
+    int st = MSM_OK;
+    if (directions & 1)
+        st = query_host(in_mesh, new_mesh->xyz.data(), nNew, nullptr, q.fvid.data(), q.fw.data(), MSM_WEIGHTS_PROJECTED, "adaptive weights (forward)",
                         same_ctx ? new_mesh->d_xyz : nullptr);
     if (st) return st;
-    st = query_host(new_mesh, in_mesh->xyz.data(), nOld, nullptr, q.rvid.data(), q.rw.data(), MSM_WEIGHTS_PROJECTED, "adaptive weights (reverse)",
-                    same_ctx ? in_mesh->d_xyz : nullptr);
+    if (directions & 2)
+        st = query_host(new_mesh, in_mesh->xyz.data(), nOld, nullptr, q.rvid.data(), q.rw.data(), MSM_WEIGHTS_PROJECTED, "adaptive weights (reverse)",
+                        same_ctx ? in_mesh->d_xyz : nullptr);
     if (st) return st;
     q.closest.clear();
     if (with_closest) {

@@ -25,6 +25,7 @@ namespace msm {
 int adaptive_weights(msm_mesh *in_mesh, msm_mesh *new_mesh, const double *excl, std::vector<int32_t> &row_ptr, std::vector<int32_t> &col,
                      std::vector<double> &val);
 const Adjacency &mesh_adjacency(msm_mesh *m);
+int query_host(msm_mesh *target, const double *q, int N, int *tri_id, int *vid, double *w, int mode, const char *what, const double *q_on_device);
 }  // namespace msm
 
 struct msm_group {
@@ -63,6 +64,7 @@ struct msm_group {
     DevBuf<double> d_answer;
     // scratch of subject_patches, kept between subjects
     DevBuf<double> d_centres, d_sep;
+    DevBuf<double> d_rotated;  // the L rotated data meshes of the subject being set up
     DevBuf<uint32_t> d_slots;
     DevBuf<int> d_counts;
 };
@@ -433,25 +435,32 @@ int group_subject_setup(msm_group *g, int s) {
         fprintf(stderr, "  group set-up, subject %d: %s %.1f ms (%d workers)\n", s, what, std::chrono::duration<double, std::milli>(now - tick).count(), workers);
         tick = now;
     };
-    // phase 1 (GPU): the L rotated meshes
+    // phase 1 (GPU): the L rotated meshes, side by side in one 3 x (L * V) array (x of label 0, x of label 1, ..., y of label 0, ...)
+    // that stays in HBM: it is also the query set of the reverse searches of phase 3
     std::vector<std::vector<double>> rotated(L);
+    const size_t LV = (size_t)L * V;
+    DevBuf<double> &d_rot = g->d_rotated;
     {
-        DevBuf<double> d_rot;
-        MSM_HIP(d_rot.ensure(3 * (size_t)V));
-        for (int l = 0; l < L; ++l) {
-            if (l == 0) {
-                rotated[l] = dm->xyz;
-                continue;
-            }
-            rotated[l].resize(3 * (size_t)V);
+        MSM_HIP(d_rot.ensure(3 * LV));
+        for (int a = 0; a < 3; ++a)  // label 0 is the centre of the sampling grid: no rotation
+            MSM_HIP(hipMemcpyAsync(d_rot.p + a * LV, dm->d_xyz + (size_t)a * V, sizeof(double) * (size_t)V, hipMemcpyDeviceToDevice, ctx->stream));
+        for (int l = 1; l < L; ++l) {
             const double lab[3] = {g->labels[l], g->labels[L + l], g->labels[2 * (size_t)L + l]};
-            int st = launch_rotate_to_label(ctx, dm->d_xyz, V, centre, lab, d_rot.p);
+            int st = launch_rotate_to_label(ctx, dm->d_xyz, V, centre, lab, d_rot.p + (size_t)l * V, LV);
             if (st) return st;
-            MSM_HIP(d_rot.download(rotated[l].data(), rotated[l].size(), ctx->stream));
-            MSM_HIP(hipStreamSynchronize(ctx->stream));
         }
-        int st = check_status(ctx, "get_patch_data (rotation)");
+        void *pin = nullptr;
+        int st = ctx_io_pinned(ctx, sizeof(double) * 3 * LV, &pin);
         if (st) return st;
+        MSM_HIP(hipMemcpyAsync(pin, d_rot.p, sizeof(double) * 3 * LV, hipMemcpyDeviceToHost, ctx->stream));
+        st = check_status(ctx, "get_patch_data (rotation)");
+        if (st) return st;
+        const double *big = static_cast<const double *>(pin);
+        parallel_for(L, workers, [&](int l) {
+            rotated[l].resize(3 * (size_t)V);
+            for (int a = 0; a < 3; ++a) std::memcpy(rotated[l].data() + (size_t)a * V, big + a * LV + (size_t)l * V, sizeof(double) * (size_t)V);
+        });
+        rotated[0] = dm->xyz;  // the same numbers; kept as the mesh's own copy
     }
     lap("rotations");
     // phase 2 (host threads): octrees and vertex areas of the rotated meshes
@@ -473,11 +482,26 @@ int group_subject_setup(msm_group *g, int s) {
         int st = install_coords_and_tree(sm, rotated[l].data(), std::move(trees[l]));
         if (st) return st;
         const auto t1 = std::chrono::steady_clock::now();
-        st = adaptive_queries(sm, g->tmpl, false, queries[l]);
+        st = adaptive_queries(sm, g->tmpl, false, queries[l], 1);  // forward: template vertices in this label's tree
         if (st) return st;
         const auto t2 = std::chrono::steady_clock::now();
         t_install += std::chrono::duration<double, std::milli>(t1 - t0).count();
         t_query += std::chrono::duration<double, std::milli>(t2 - t1).count();
+    }
+    {
+        // reverse: the vertices of all L rotated meshes in the template's tree, one launch over the array of phase 1
+        std::vector<int> rvid(3 * LV);
+        std::vector<double> rw(3 * LV);
+        const auto t0 = std::chrono::steady_clock::now();
+        int st = query_host(g->tmpl, nullptr, (int)LV, nullptr, rvid.data(), rw.data(), MSM_WEIGHTS_PROJECTED, "adaptive weights (reverse)", d_rot.p);
+        if (st) return st;
+        parallel_for(L, workers, [&](int l) {
+            for (int a = 0; a < 3; ++a) {
+                std::memcpy(queries[l].rvid.data() + (size_t)a * V, rvid.data() + a * LV + (size_t)l * V, sizeof(int) * (size_t)V);
+                std::memcpy(queries[l].rw.data() + (size_t)a * V, rw.data() + a * LV + (size_t)l * V, sizeof(double) * (size_t)V);
+            }
+        });
+        t_query += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
     if (timing) fprintf(stderr, "    install %.1f ms, queries %.1f ms\n", t_install, t_query);
     lap("uploads + queries");

@@ -32,20 +32,20 @@ constexpr int kGroupStage = 256;  // ids of patch B staged in LDS per wavefront
 
 // every data vertex v is moved to estimate_rotation_matrix(centre, v) * label: "rigid rotation" of the mesh by the label
 __global__ __launch_bounds__(256) void k_rotate_to_label(const double *__restrict__ xyz, int V, V3 centre, V3 label, double *__restrict__ out,
-                                                          int *status) {
+                                                          size_t stride, int *status) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= V) return;
     double R[9];
     if (!rotation_matrix(centre, mk(xyz[i], xyz[V + i], xyz[2 * V + i]), R)) raise_status(status, MSM_ERR_ROTATION);
     const V3 p = rotate(R, label);
     out[i] = p.x;
-    out[V + i] = p.y;
-    out[2 * V + i] = p.z;
+    out[stride + i] = p.y;
+    out[2 * stride + i] = p.z;
 }
 
-int launch_rotate_to_label(msm_ctx *ctx, const double *d_xyz, int V, const double centre[3], const double label[3], double *d_out) {
+int launch_rotate_to_label(msm_ctx *ctx, const double *d_xyz, int V, const double centre[3], const double label[3], double *d_out, size_t stride) {
     hipLaunchKernelGGL(k_rotate_to_label, dim3((V + 255) / 256), dim3(256), 0, ctx->stream, d_xyz, V, mk(centre[0], centre[1], centre[2]),
-                       mk(label[0], label[1], label[2]), d_out, ctx->d_status);
+                       mk(label[0], label[1], label[2]), d_out, stride ? stride : (size_t)V, ctx->d_status);
     MSM_HIP(hipGetLastError());
     return MSM_OK;
 }

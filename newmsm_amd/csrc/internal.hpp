@@ -177,7 +177,8 @@ struct AdaptiveQueries {
     std::vector<int> fvid, rvid, closest;  // forward (new -> old) and reverse (old -> new) hit-triangle vertex ids, 3 x N SoA
     std::vector<double> fw, rw;            // and their projected barycentric weights
 };
-int adaptive_queries(msm_mesh *in_mesh, msm_mesh *new_mesh, bool with_closest, AdaptiveQueries &q);
+// directions: 1 forward (new -> old), 2 reverse (old -> new), 3 both
+int adaptive_queries(msm_mesh *in_mesh, msm_mesh *new_mesh, bool with_closest, AdaptiveQueries &q, int directions = 3);
 void adaptive_surgery(const AdaptiveQueries &q, int nOld, int nNew, const std::vector<double> &oldA, const std::vector<double> &newA,
                       const double *excl, std::vector<int32_t> &row_ptr, std::vector<int32_t> &col, std::vector<double> &val);
 void vertex_areas_of(const double *xyz, const int32_t *tri, int V, int T, const Adjacency &a, std::vector<double> &area);

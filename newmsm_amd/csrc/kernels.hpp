@@ -145,7 +145,8 @@ struct GroupArgs {
     int patch_cap;               // largest patch of any subject (DICE: LDS staging of the common entries)
     int *status;
 };
-int launch_rotate_to_label(msm_ctx *ctx, const double *d_xyz, int V, const double centre[3], const double label[3], double *d_out);
+// out[i], out[stride + i], out[2 * stride + i] (stride 0: V)
+int launch_rotate_to_label(msm_ctx *ctx, const double *d_xyz, int V, const double centre[3], const double label[3], double *d_out, size_t stride = 0);
 int launch_group_pairwise(msm_ctx *ctx, const GroupArgs &a, const int *qp, const int *qa, const int *qb, int n, double *out);
 int launch_group_triplet(msm_ctx *ctx, const GroupArgs &a, const int *qt, const int *qa, const int *qb, const int *qc, int n, double *out);
 
