@@ -158,17 +158,26 @@ struct Builder {
         }
         split(n);
         const int first = nodes[n].first_child;
-        std::vector<int32_t> sub;
-        for (int c = 0; c < 8; ++c) {
-            sub.clear();
-            const BNode &ch = nodes[first + c];
-            for (int i = 0; i < len; ++i) {
-                const double *bx = &bxp[(size_t)6 * list[i]];
-                if (!(bx[3] < ch.b[0][0] || bx[0] > ch.b[0][2] || bx[4] < ch.b[1][0] || bx[1] > ch.b[1][2] || bx[5] < ch.b[2][0] || bx[2] > ch.b[2][2]))
-                    sub.push_back(list[i]);
-            }
-            std::vector<int32_t> mine(sub);
-            build_down(first + c, mine);
+        std::vector<int32_t> sub[8];
+        distribute(n, list, sub);
+        std::vector<int32_t>().swap(list);  // the parent's list is not needed below
+        for (int c = 0; c < 8; ++c) build_down(first + c, sub[c]);
+    }
+
+    // The children's lists of a node that has just been split: child c receives, in order, every triangle of `list` whose box
+    // overlaps the child's box (Node::can_contain on the child).  The eight tests of a triangle share their comparisons: per
+    // axis the child box is the parent's [lower, middle] or [middle, upper], so twelve comparisons decide all eight.
+    void distribute(int n, const std::vector<int32_t> &list, std::vector<int32_t> sub[8]) const {
+        const BNode &nd = nodes[n];
+        const size_t guess = list.size() / 5 + 8;
+        for (int c = 0; c < 8; ++c) sub[c].reserve(guess);
+        for (const int32_t t : list) {
+            const double *bx = &bxp[(size_t)6 * t];
+            unsigned half[3];  // bit 0: overlaps the lower half along the axis, bit 1: the upper half
+            for (int a = 0; a < 3; ++a)
+                half[a] = (!(bx[3 + a] < nd.b[a][0] || bx[a] > nd.b[a][1]) ? 1u : 0u) | (!(bx[3 + a] < nd.b[a][1] || bx[a] > nd.b[a][2]) ? 2u : 0u);
+            for (int c = 0; c < 8; ++c)
+                if ((half[0] >> ((c >> 2) & 1) & 1u) && (half[1] >> ((c >> 1) & 1) & 1u) && (half[2] >> (c & 1) & 1u)) sub[c].push_back(t);
         }
     }
 };
@@ -586,18 +595,12 @@ void build_top_down(Builder &b) {
                 next.push_back(Job{first + c, {}});
             }
         }
-        // ... and fill the children's lists (each a scan of the parent's whole list, in order) on the worker threads
-        parallel_for((int)todo.size(), workers, [&](int k) {
-            const Job &j = frontier[todo[k].first];
-            Job &sub = next[todo[k].second];
-            const BNode &ch = b.nodes[sub.node];
-            const int len = (int)j.list.size();
-            sub.list.reserve((size_t)len / 4 + 16);
-            for (int i = 0; i < len; ++i) {
-                const double *bx = &b.bxp[(size_t)6 * j.list[i]];
-                if (!(bx[3] < ch.b[0][0] || bx[0] > ch.b[0][2] || bx[4] < ch.b[1][0] || bx[1] > ch.b[1][2] || bx[5] < ch.b[2][0] || bx[2] > ch.b[2][2]))
-                    sub.list.push_back(j.list[i]);
-            }
+        // ... and fill the children's lists (one pass over the parent's list per split node) on the worker threads
+        parallel_for((int)todo.size() / 8, workers, [&](int k) {
+            const Job &j = frontier[todo[8 * k].first];
+            std::vector<int32_t> sub[8];
+            b.distribute(j.node, j.list, sub);
+            for (int c = 0; c < 8; ++c) next[todo[8 * k + c].second].list = std::move(sub[c]);
         });
         frontier.swap(next);
     }
