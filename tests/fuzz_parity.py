@@ -1,6 +1,6 @@
 """tests/fuzz_parity.py [seed] [count] -- random configurations (resolutions, warps, target shapes, cost classes, similarity
 measures) through the HIP path and the oracle; prints every mismatch.  Run on a GPU box; used to look for rare parity
-failures beyond what tests/ samples (round 1: 750 configurations, with the direction table built up front and in the background, none)."""
+failures beyond what tests/ samples (round 1: 1 950 configurations, with the direction table built up front and in the background, none)."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
