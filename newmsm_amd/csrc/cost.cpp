@@ -195,6 +195,7 @@ int ensure_unary_table(msm_cost *c) {
     const size_t nsamp = (size_t)c->L * c->pidx.size();
     MSM_HIP(c->d_tval.ensure(nsamp));
     MSM_HIP(c->d_fix_list.ensure(nsamp));
+    MSM_HIP(c->d_fix_pt.ensure(3 * nsamp));
     if (!c->d_fix_count.p) MSM_HIP(c->d_fix_count.zero(unary_fix_counter_words(), ctx->stream));  // every launch leaves them zero again
     if (!c->fix_off_valid) {
         std::vector<uint32_t> off;
@@ -207,6 +208,7 @@ int ensure_unary_table(msm_cost *c) {
     u.ntri = c->target->T;
     u.tval = c->d_tval.p;
     u.fix_list = c->d_fix_list.p;
+    u.fix_pt = c->d_fix_pt.p;
     u.fix_cnt = c->d_fix_count.p;
     u.fix_off = c->d_fix_off.p;
     u.redo_list = c->d_queues.p;

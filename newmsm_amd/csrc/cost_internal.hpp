@@ -64,6 +64,7 @@ struct msm_cost {
     DevBuf<int> d_stri;
     DevBuf<double> d_sw3;
     DevBuf<unsigned long long> d_fix_list;
+    DevBuf<double> d_fix_pt;  // rotated points of the listed samples
     DevBuf<unsigned int> d_fix_count;
     // anatomical regularisation (regularisermode 4/5)
     msm_mesh *asphere = nullptr;

@@ -52,6 +52,7 @@ struct UnaryLaunch {
     int ntri;                      // triangles in the target mesh
     double *tval;                  // one double per point sample (L * total patch points)
     unsigned long long *fix_list;  // one slot per point sample
+    double *fix_pt;                // three doubles per slot
     unsigned int *fix_cnt;         // unary_fix_counter_words() words (zeroed by the launch)
     const unsigned int *fix_off;   // unary_fix_segments() + 1 offsets from unary_fix_offsets()
     int *redo_list;                // N ints

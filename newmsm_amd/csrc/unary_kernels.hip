@@ -70,7 +70,8 @@ struct SamplesArgs {
     // Fix-up list: kFixSegs segments (a workgroup appends to segment blockIdx % kFixSegs, which is sized for all
     // samples of its workgroups: it cannot overflow).  One list with one counter would funnel every append of
     // the chip through a single address; measured: 10 ns per append, i.e. most of the kernel's time.
-    unsigned long long *fix_list;  // node << 32 | local sample
+    unsigned long long *fix_list;  // global sample id (L * pptr[node] + local sample)
+    double *fix_pt;                // the rotated point of the listed sample, 3 doubles per slot: the fix-up kernel starts from it
     unsigned int *fix_cnt;         // counter of segment s at fix_cnt[kCntStride * (1 + s)]; [0] is the redo counter
     const unsigned int *fix_off;   // kFixSegs + 1 segment offsets into fix_list
     // fused reduction (univariate): moving feature, weights, AbsoluteWeights, output table
@@ -337,8 +338,16 @@ __global__ __launch_bounds__(256) void k_unary_samples(SamplesArgs a) {
                     atomicAdd(&s_ndefer, 1);
                     const int seg = blockIdx.x % kFixSegs;
                     const unsigned slot = a.fix_off[seg] + atomicAdd(&a.fix_cnt[kCntStride * (1 + seg)], 1u);
-                    if (slot < a.fix_off[seg + 1]) a.fix_list[slot] = ((unsigned long long)node << 32) | (unsigned)s;
-                    else raise_status(a.status, MSM_ERR_CAPACITY);
+                    if (slot < a.fix_off[seg + 1]) {
+                        const int l = fast_div(s, P, invP), i = s - l * P;
+                        const V3 p = rotate(sR + 9 * l, mk(sx[i], sy[i], sz[i]));
+                        a.fix_list[slot] = gbase + (unsigned long long)s;
+                        a.fix_pt[3 * (size_t)slot] = p.x;
+                        a.fix_pt[3 * (size_t)slot + 1] = p.y;
+                        a.fix_pt[3 * (size_t)slot + 2] = p.z;
+                    } else {
+                        raise_status(a.status, MSM_ERR_CAPACITY);
+                    }
                 }
             }
             __syncthreads();
@@ -486,8 +495,17 @@ __global__ __launch_bounds__(256) void k_unary_rays(SamplesArgs a) {
         __syncthreads();
         const unsigned base = s_base, end = a.fix_off[seg + 1];
         for (int j = tid; j < nleft; j += 256) {
-            if (base + j < end) a.fix_list[base + j] = ((unsigned long long)node << 32) | (unsigned)sleft[j];
-            else raise_status(a.status, MSM_ERR_CAPACITY);
+            if (base + j < end) {
+                const int s = sleft[j];
+                const int l = fast_div(s, P, invP), i = s - l * P;
+                const V3 p = rotate(sR + 9 * l, mk(sx[i], sy[i], sz[i]));  // as in the loop above: the fix-up kernel need not look anything up
+                a.fix_list[base + j] = gbase + (unsigned long long)s;
+                a.fix_pt[3 * (size_t)(base + j)] = p.x;
+                a.fix_pt[3 * (size_t)(base + j) + 1] = p.y;
+                a.fix_pt[3 * (size_t)(base + j) + 2] = p.z;
+            } else {
+                raise_status(a.status, MSM_ERR_CAPACITY);
+            }
         }
     }
 }
@@ -531,13 +549,9 @@ __global__ __launch_bounds__(256) void k_unary_fixup(SamplesArgs a) {
 #pragma unroll
             for (int step = kFixSegs / 2; step > 0; step >>= 1)
                 if (s_pre[seg + step] <= j) seg += step;
-            const unsigned long long e = a.fix_list[a.fix_off[seg] + (j - s_pre[seg])];
-            const int node = (int)(e >> 32), s = (int)(e & 0xffffffffu);
-            const int beg = a.pptr[node], P = a.pptr[node + 1] - beg;
-            const int l = s / P, i = s - l * P;
-            const int sv = a.pidx[beg + i];
-            p = rotate(a.rnl + ((size_t)node * a.L + l) * 9, mk(a.src[sv], a.src[a.Nsrc + sv], a.src[2 * a.Nsrc + sv]));
-            g = (size_t)a.L * beg + s;
+            const size_t slot = a.fix_off[seg] + (j - s_pre[seg]);
+            g = (size_t)a.fix_list[slot];
+            p = mk(a.fix_pt[3 * slot], a.fix_pt[3 * slot + 1], a.fix_pt[3 * slot + 2]);
         }
         const int found = group8_find(a.tree, valid, p, lane);
         if (valid && sub == 0) {
@@ -1098,6 +1112,7 @@ static int launch_samples(msm_ctx *ctx, const UnaryLaunch &u, const UnaryWeights
     a.stri = w ? w->stri : nullptr;
     a.sw3 = w ? w->sw3 : nullptr;
     a.fix_list = u.fix_list;
+    a.fix_pt = u.fix_pt;
     a.fix_cnt = u.fix_cnt;
     a.fix_off = u.fix_off;
     a.sfeat = u.sfeat;
