@@ -30,7 +30,7 @@ def algorithmic_bytes(samples, evals, D):
 
 
 DOMINANT_KERNEL = "msm::k_unary_rays"  # the sampling kernel of a simple-surface target (newmsm_amd/csrc/unary_kernels.hip)
-PMC_PROFILE = os.path.join("profiles", "r1_m_unary_pmc.json")  # tools/collect_profile.sh on this workload
+PMC_PROFILE = os.path.join("profiles", "r1_n_unary_pmc.json")  # tools/collect_profile.sh on this workload
 
 
 def kernel_algorithmic_bytes(samples, evals, D):
