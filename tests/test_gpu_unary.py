@@ -271,3 +271,16 @@ def test_empty_and_single_point_patches(ctx, kind, D, sim, range_):
     assert np.array_equal(np.isnan(U), np.isnan(Uo))
     ok = ~np.isnan(Uo)
     assert np.allclose(U[ok], Uo[ok], rtol=RTOL, atol=ATOL)
+
+
+@pytest.mark.parametrize("kind,D", [("univariate", 1), ("multivariate", 4), ("patchwise", 4)])
+@pytest.mark.parametrize("sg_order,labeldist,lo,hi", [(5, 0.5, 60, 120), (6, 0.5, 250, 400), (4, 0.05, 1, 1)])
+def test_many_labels_and_a_single_label(ctx, kind, D, sg_order, labeldist, lo, hi):
+    """label sets far from the usual 19: a finer sampling grid (≈ 80 and ≈ 300 labels: several passes of the per-label groups,
+    more label ranges per control point) and a radius so small that only the centre is left"""
+    inp = problem.pairwise_inputs(4, 2, D=D, sg_order=sg_order, labeldist=labeldist, rescale=False)
+    assert lo <= len(inp["labels"]) <= hi, len(inp["labels"])
+    cf, oc, _ = run_pair(ctx, inp, kind)
+    U, Uo = cf.computeUnaryCosts(), oc.unary_table()
+    assert U.shape == Uo.shape == (len(inp["labels"]), 162)
+    assert np.allclose(U, Uo, rtol=1e-9, atol=1e-11), np.abs(U - Uo).max()
