@@ -219,3 +219,24 @@ def test_triclique_large_bins(ctx, data_order, cp_order):
     want = np.array([oc.triplet(*q) for q in zip(t, la, lb, lc)])
     assert np.isfinite(got).all()
     assert np.allclose(got, want, rtol=RTOL, atol=ATOL), np.max(np.abs(got - want))
+
+
+@pytest.mark.parametrize("kind,D", [("ho_univariate", 1), ("ho_multivariate", 3)])
+def test_triclique_with_many_labels(ctx, kind, D):
+    """≈ 80 labels (finer sampling grid): on-demand triplet costs and the eight-combination fusion move against the oracle"""
+    inp = problem.pairwise_inputs(4, 2, D=D, sg_order=5, rescale=False)
+    assert len(inp["labels"]) > 60
+    cf, oc, _ = pair(ctx, inp, kind, rmode=3, lambda_=0.1)
+    rng = np.random.default_rng(4)
+    t, la, lb, lc = random_queries(rng, 600, cf.T, cf.L, 3)
+    got = cf.computeTripletCost(t, la, lb, lc)
+    want = np.array([oc.triplet(*q) for q in zip(t, la, lb, lc)])
+    assert np.allclose(got, want, rtol=RTOL, atol=ATOL), np.max(np.abs(got - want))
+    labeling = rng.integers(0, cf.L, cf.N).astype(np.int32)
+    E = cf.tripletOctets(labeling, 57).reshape(cf.T, 8)
+    for tt in rng.integers(0, cf.T, 25):
+        ids = inp["triplets"][tt]
+        for k in range(8):
+            lab = [57 if k >> (2 - j) & 1 else int(labeling[ids[j]]) for j in range(3)]
+            w = oc.triplet(int(tt), *lab)
+            assert abs(E[tt, k] - w) <= ATOL + RTOL * abs(w)
