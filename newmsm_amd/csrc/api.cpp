@@ -157,7 +157,7 @@ static int ensure_rayrec(msm_mesh *m);
 
 }  // namespace msm
 
-// The ray table of a target takes tens of milliseconds of host time (32 ms at ico6 on 16 threads) and saves 0.15 ms per
+// The ray table of a target takes over ten milliseconds of host time (14 ms at ico6 on 16 threads) and saves 0.15 ms per
 // unary table, while a resolution level of a registration evaluates a few dozen tables at most.  By default it is
 // therefore built on a background thread from a private copy of the tree; until it is ready the cost kernels use the
 // complete search (k_unary_samples), and the tables are bit-identical either way (same triangles and weights, one common
