@@ -97,6 +97,9 @@ class _ProductCost:
     def set_spacings(self, maxsep, mvdmax):
         self.cf.set_spacings(maxsep, mvdmax)
 
+    def set_cfweight(self, w):
+        self.cf.set_dataaffintyweighting(w)
+
     def set_labels(self, labels, rot):
         self.cf.set_labels(labels, rot)
 
@@ -123,15 +126,28 @@ def apply_labeling(rot, labels, labeling):
     return R[:, :, 0] * v[:, None, 0] + R[:, :, 1] * v[:, None, 1] + R[:, :, 2] * v[:, None, 2]
 
 
+def combine_costfunction_weighting(sourceweight, resampledtargetweight):
+    """Mesh_registration::combine_costfunction_weighting, M/mesh_registration.cpp:849-869: the mean of the two weightings over
+    the rows both have; the rows only the larger one has are kept"""
+    a, b = np.atleast_2d(sourceweight), np.atleast_2d(resampledtargetweight)
+    new = np.array(a if a.shape[0] >= b.shape[0] else b, dtype=np.float64)
+    n = min(a.shape[0], b.shape[0])
+    new[:n] = (a[:n] + b[:n]) / 2.0
+    return new
+
+
 def run_discrete_level(ops, target_xyz, target_tri, ref_feat, source_xyz, source_tri, src_feat, sph_reg, cp_order, *, sg_order=None,
                        iters=3, mciters=200, mcparam=0.8, seed=0, kind="univariate", simmeasure=2, rmode=3, labeldist=0.5,
-                       rescale_labels=False, cost_params=None, timings=None, cp_start=None):
+                       rescale_labels=False, cost_params=None, timings=None, cp_start=None, in_weight=None, ref_weight=None):
     """Runs `iters` iterations of run_discrete_opt with the Monte Carlo optimiser for one level.
 
     target / source: the reference and the moving sphere at the data resolution of this level (source_xyz = the sphere the
     moving features live on, sph_reg = its current registered position).  Returns (sph_reg, cp_xyz, energies, labelings).
     `timings` (optional dict) accumulates wall-clock seconds per phase.  cp_start: the control grid after warp_CPgrid (the
-    warp of the previous level applied to it); the regular grid when None."""
+    warp of the previous level applied to it); the regular grid when None.  in_weight / ref_weight (rows x V, optional): the
+    cost-function weightings of the moving and the reference data at this resolution (SPHin_CFWEIGHTING / SPHref_CFWEIGHTING);
+    with both given every iteration resamples the reference weighting onto the moving sphere and averages the two
+    (combine_weighting, M/mesh_registration.cpp:234-248), otherwise the weighting is all ones."""
     if sg_order is None:
         sg_order = cp_order + 2
     cost_params = dict(cost_params or {})
@@ -162,6 +178,9 @@ def run_discrete_level(ops, target_xyz, target_tri, ref_feat, source_xyz, source
     for it in range(iters):
         # --- reset_meshspace + setupCostFunction
         ops.set_coords(source, sph_reg)
+        if in_weight is not None and ref_weight is not None:  # setupCostFunctionWeighting(combine_weighting())
+            resampled = timed("metric_resample", ops.metric_resample, target, ref_weight, source)
+            cost.set_cfweight(combine_costfunction_weighting(in_weight, resampled))
         cost.reset_source(source)
         ops.set_coords(cpgrid, cp_xyz)
         cost.reset_cpgrid(cpgrid)

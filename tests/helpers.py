@@ -131,6 +131,9 @@ class _OracleCost:
     def set_spacings(self, maxsep, mvdmax):
         self.c.set_spacings(maxsep, mvdmax)
 
+    def set_cfweight(self, w):
+        self.c.set_cfweight(w)
+
     def set_labels(self, labels, rot):
         self.c.set_labels(labels, rot)
 

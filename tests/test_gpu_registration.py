@@ -42,6 +42,21 @@ def test_level_matches_oracle(ctx, kind, D, rescale):
     assert np.abs(got[0] - want[0]).max() < 1e-9 and np.abs(got[1] - want[1]).max() < 1e-9
 
 
+def test_level_with_cost_function_weightings(ctx):
+    """--inweight / --refweight: every iteration resamples the reference weighting onto the moving sphere and combines the two"""
+    xyz, tri, ref, src = level_inputs(4, 3, seed=41)
+    w_in = 0.5 + 0.5 * np.abs(synthetic.features(xyz, 1, 43))
+    w_ref = 0.5 + 0.5 * np.abs(synthetic.features(xyz, 3, 44))  # per-dimension weighting of the reference
+    kw = dict(cp_order=2, iters=2, mciters=40, mcparam=0.3, seed=6, kind="multivariate", cost_params=dict(lambda_=0.05), in_weight=w_in, ref_weight=w_ref)
+    got = registration.run_discrete_level(registration.ProductOps(ctx), xyz, tri, ref, xyz, tri, src, xyz, **kw)
+    want = registration.run_discrete_level(OracleOps(M.mcmc_optimise), xyz, tri, ref, xyz, tri, src, xyz, **kw)
+    plain = registration.run_discrete_level(registration.ProductOps(ctx), xyz, tri, ref, xyz, tri, src, xyz, **dict(kw, in_weight=None, ref_weight=None))
+    for a, b in zip(got[3], want[3]):
+        assert np.array_equal(a, b)
+    assert np.allclose(got[2], want[2], rtol=1e-10) and np.abs(got[0] - want[0]).max() < 1e-9
+    assert not np.allclose(got[2], plain[2], rtol=1e-6)  # the weighting does change the energies
+
+
 def test_level_improves_the_similarity(ctx):
     """sanity of the assembled loop: a few iterations bring a displaced copy of the pattern closer to the reference"""
     xyz, tri, ref, src = level_inputs(5, 1, seed=3)
