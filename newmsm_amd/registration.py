@@ -57,6 +57,9 @@ class ProductOps:
     def variance_normalise(self, data):
         return api.variance_normalise(data)
 
+    def nearest_neighbour(self, mesh, data, q_xyz):
+        return api.nearest_neighbour_interpolation(mesh, data, q_xyz)
+
     # --- model host logic
     def cp_spacings(self, mesh, xyz, tri):
         return api.cp_spacings(xyz, tri)
@@ -214,7 +217,8 @@ def run_discrete_level(ops, target_xyz, target_tri, ref_feat, source_xyz, source
     return sph_reg, cp_xyz, energies, labelings
 
 
-def run_multiresolution(ops, in_xyz, in_tri, in_data, ref_xyz, ref_tri, ref_data, levels, *, varnorm=False, timings=None, **level_kw):
+def run_multiresolution(ops, in_xyz, in_tri, in_data, ref_xyz, ref_tri, ref_data, levels, *, varnorm=False, timings=None, in_cfweight=None,
+                        ref_cfweight=None, **level_kw):
     """Mesh_registration::run_multiresolutions (M/mesh_registration.cpp:30-50) for DISCRETE levels without file I/O:
 
     per level  featurespace::initialise (M/featurespace.cpp:39-86: metric_resample of both data sets onto the level's
@@ -223,7 +227,9 @@ def run_multiresolution(ops, in_xyz, in_tri, in_data, ref_xyz, ref_tri, ref_data
     at the end transform (:352-356): the input sphere moved through the final warp ("sphere.reg").
 
     in_* / ref_*: the input and reference spheres (radius 100) with their D x V data.  levels: dicts with data_order, cp_order
-    and optionally sg_order, sigma_in, sigma_ref, iters, mciters, cost_params.  recentre() of the regular spheres
+    and optionally sg_order, sigma_in, sigma_ref, iters, mciters, cost_params.  in_cfweight / ref_cfweight (rows x V on the
+    input / reference sphere, optional): cost-function weightings, brought to each level's grid by nearest-neighbour
+    interpolation (downsample_cfweighting, M/mesh_registration.cpp:334-350).  recentre() of the regular spheres
     (a shift of ~1e-15) is not applied.  Returns (sphere_reg, per-level registered data grids, per-level energies)."""
     clock = timings if timings is not None else {}
 
@@ -263,6 +269,9 @@ def run_multiresolution(ops, in_xyz, in_tri, in_data, ref_xyz, ref_tri, ref_data
         sph_in = ops.coords(moved)
         kw = dict(level_kw)
         kw.update({k: lv[k] for k in ("sg_order", "iters", "mciters", "cost_params", "kind", "rescale_labels") if k in lv})
+        if in_cfweight is not None and ref_cfweight is not None:
+            kw["in_weight"] = ops.nearest_neighbour(in_mesh, in_cfweight, ico_xyz)
+            kw["ref_weight"] = ops.nearest_neighbour(ref_mesh, ref_cfweight, ico_xyz)
         sph_reg, _, energies, _ = run_discrete_level(ops, ico_xyz, ico_tri, feats[1], ico_xyz, ico_tri, feats[0], sph_in, lv["cp_order"],
                                                      cp_start=cp_start, timings=clock, **kw)
         regs.append(sph_reg)

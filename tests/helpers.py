@@ -91,6 +91,9 @@ class OracleOps:
     def variance_normalise(self, data):
         return O.variance_normalise(data)
 
+    def nearest_neighbour(self, mesh, data, q_xyz):
+        return O.nearest_neighbour(mesh, data, q_xyz)
+
     def cp_spacings(self, mesh, xyz, tri):
         return O.cp_spacings(mesh)
 

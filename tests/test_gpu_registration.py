@@ -77,7 +77,8 @@ def test_two_levels_match_oracle(ctx):
     src = synthetic.features(synthetic.known_warp(in_xyz, seed=33, rot_deg=4.0, amp=2.5), 2, 31)
     levels = [dict(data_order=3, cp_order=1, sigma_in=4.0, sigma_ref=4.0, iters=2, mciters=40),
               dict(data_order=4, cp_order=2, sigma_in=2.0, sigma_ref=0.0, iters=2, mciters=40)]
-    kw = dict(varnorm=True, mcparam=0.3, seed=9, kind="multivariate", cost_params=dict(lambda_=0.05))
+    kw = dict(varnorm=True, mcparam=0.3, seed=9, kind="multivariate", cost_params=dict(lambda_=0.05),
+              in_cfweight=0.5 + 0.5 * np.abs(synthetic.features(in_xyz, 1, 35)), ref_cfweight=0.5 + 0.5 * np.abs(synthetic.features(ref_xyz, 1, 36)))
     got = registration.run_multiresolution(registration.ProductOps(ctx), in_xyz, in_tri, src, ref_xyz, in_tri, ref, levels, **kw)
     want = registration.run_multiresolution(OracleOps(M.mcmc_optimise), in_xyz, in_tri, src, ref_xyz, in_tri, ref, levels, **kw)
     assert np.allclose(np.concatenate(got[2]), np.concatenate(want[2]), rtol=1e-9)
