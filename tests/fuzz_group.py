@@ -1,0 +1,73 @@
+"""tests/fuzz_group.py [seed] [count] -- random groupwise (gMSM) configurations through the HIP path and the oracle: pair lists,
+patch index sets, inter-subject pairwise costs (all four similarity measures, with and without a mask) and strain triplets.
+A script, run by hand on a GPU box (round 1: 120 configurations, no mismatch)."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+
+import newmsm_amd as M  # noqa: E402
+from newmsm_amd import synthetic  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+
+ctx = M.Context(0)
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 3)
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+bad, t0 = 0, time.time()
+for k in range(n):
+    S = int(rng.integers(2, 5))
+    data_order = int(rng.choice([3, 4]))
+    cp_order = int(rng.integers(1, data_order - 1))
+    D = int(rng.integers(1, 4))
+    sim = int(rng.choice([1, 2, 4, 5]))
+    mask = bool(rng.integers(0, 2))
+    pct = float(rng.uniform(0.2, 0.9))
+    amp, rot = float(rng.uniform(0.0, 1.0)), float(rng.uniform(0.0, 4.0))
+    dxyz, dtri = M.make_mesh_from_icosa(data_order)
+    cxyz, ctri = M.make_mesh_from_icosa(cp_order)
+    _, mvd = M.cp_spacings(cxyz, ctri)
+    samples, _ = M.label_sampling_grid(cp_order + 2, float(rng.uniform(0.3, 0.6)) * mvd)
+    mk = np.cos(dxyz[:, 0] / 30.0) if mask else None
+    g = M.DiscreteGroupCostFunction(ctx, S, simmeasure=sim, lambda_=0.2, percentile=pct)
+    og = O.Group(S, simmeasure=sim, lambda_=0.2, percentile=pct)
+    tm, otm = M.Mesh(ctx, dxyz, dtri), O.Mesh(dxyz, dtri)
+    g.set_template(tm, mk)
+    og.set_template(otm, mk)
+    g.Initialize(cxyz, ctri)
+    og.set_controlgrid(O.Mesh(cxyz, ctri))
+    keep = []
+    for s in range(S):
+        seed = int(rng.integers(1, 10**6))
+        sph = synthetic.known_warp(dxyz, seed=seed, rot_deg=rot + s, amp=amp)
+        feat = synthetic.features(synthetic.known_warp(dxyz, seed=seed + 1, rot_deg=2.0, amp=1.0), D, seed=5)
+        regular, om = M.Mesh(ctx, dxyz, dtri), O.Mesh(dxyz, dtri)
+        g.reset_meshspace(s, regular, feat)
+        og.set_subject(s, om, feat)
+        regular.set_coords(sph)
+        om.set_coords(sph)
+        g.reset_meshspace(s, regular, feat)
+        og.set_subject(s, om, feat)
+        cp_s = synthetic.known_warp(cxyz, seed=seed, rot_deg=rot + s, amp=amp)
+        g.reset_CPgrid(s, cp_s)
+        og.reset_cpgrid(s, cp_s)
+        keep += [regular, om]
+    g.set_labels(samples)
+    og.set_labels(samples)
+    g.setupCostFunction()
+    og.setup()
+    ok = np.array_equal(g.getPairs(), og.pairs()) and np.array_equal(g.getTriplets(), og.triplets())
+    for s, v, l in zip(rng.integers(0, S, 6), rng.integers(0, len(cxyz), 6), rng.integers(0, g.L, 6)):
+        ok = ok and np.array_equal(g.patch(s, v, l)[0], og.patch(s, v, l)[0])
+    p, la, lb = (rng.integers(0, g.P, 150).astype(np.int32), rng.integers(0, g.L, 150).astype(np.int32), rng.integers(0, g.L, 150).astype(np.int32))
+    got, want = g.computePairwiseCost(p, la, lb), np.array([og.pairwise(*q) for q in zip(p, la, lb)])
+    fin = np.isfinite(want)
+    ok = ok and np.array_equal(np.isfinite(got), fin) and np.allclose(got[fin], want[fin], rtol=1e-9, atol=1e-11)
+    t, a, b, c = (rng.integers(0, g.T, 100).astype(np.int32), *[rng.integers(0, g.L, 100).astype(np.int32) for _ in range(3)])
+    got, want = g.computeTripletCost(t, a, b, c), np.array([og.triplet(*q) for q in zip(t, a, b, c)])
+    ok = ok and np.allclose(got, want, rtol=1e-9, atol=1e-11)
+    if not ok:
+        bad += 1
+    print("ok" if ok else "MISMATCH", k, "S=%d data=%d cp=%d D=%d sim=%d mask=%s pct=%.2f" % (S, data_order, cp_order, D, sim, mask, pct), flush=True)
+print("fuzz_group: %d configs, %d mismatches, %.0f s" % (n, bad, time.time() - t0))
