@@ -13,7 +13,7 @@ def timeit(f, n=5):
     return (time.perf_counter()-t)/n*1e3
 for kind, D in (("multivariate", 32), ("patchwise", 32), ("multivariate", 3)):
     inp = problem.pairwise_inputs(6, 4, D=D)
-    cf, keep = problem.build_cost(ctx, inp, kind=kind); cf.get_source_data()
+    cf, keep = problem.build_cost(ctx, inp, kind=kind); cf.get_source_data(); keep["target"].prepare_search(wait=True)  # steady state: direction table in place
     ms = timeit(lambda: cf.computeUnaryCosts_async())
     print('%s D=%d unary table %.3f ms -> %.1f M evals/s' % (kind, D, ms, 48678/ms/1e3))
 for kind, D in (("ho_univariate", 1), ("ho_multivariate", 32)):
