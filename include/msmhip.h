@@ -16,6 +16,10 @@
  *    available from msm_last_error() (thread-local).  No exception crosses this boundary;
  *  - handles are opaque; a handle belongs to one context (one GPU, one HIP stream); calls on one
  *    context must be serialised by the caller (the reference's OpenMP loops become one launch);
+ *  - lifetimes: a cost function / group keeps plain pointers to the meshes handed to it (target, source,
+ *    control grid, anatomical sphere, template, subjects' data meshes): they must outlive it, and all of
+ *    them must belong to its context (checked: MSM_ERR_INVALID).  Destroy cost functions and groups
+ *    first, then meshes, then the context;
  *  - functions marked [host] need no GPU and may be called on a machine without one.  Everything
  *    else fails with MSM_ERR_NOGPU when no device is present: there is no CPU fallback.
  */

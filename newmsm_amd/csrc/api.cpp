@@ -260,7 +260,7 @@ static int ensure_rayrec(msm_mesh *m) {
         m->cap_ray_rec = (size_t)m->T + m->T / 4 + 16;
         MSM_HIP(hipMalloc((void **)&m->d_ray_tri, m->cap_ray_rec * kRayPieces * sizeof(float4)));
     }
-    int st = launch_build_raytri(m->ctx, m->d_rec, m->d_ray_edge, m->T, m->D == 1 ? m->d_feat : nullptr, m->d_ray_tri);
+    int st = launch_build_raytri(m->ctx, m->d_rec, m->d_ray_edge, m->T, m->D >= 1 ? m->d_feat : nullptr, m->D, m->d_ray_tri);
     if (st) return st;
     m->rayrec_valid = true;
     return MSM_OK;

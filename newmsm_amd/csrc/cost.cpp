@@ -305,6 +305,7 @@ int msm_cost_set_meshes(msm_cost *c, msm_mesh *target, msm_mesh *source, msm_mes
 
 int msm_cost_reset_source(msm_cost *c, msm_mesh *source) {
     if (!c || !source) return fail(MSM_ERR_INVALID, "msm_cost_reset_source: null argument");
+    if (source->ctx != c->ctx) return fail(MSM_ERR_INVALID, "msm_cost_reset_source: the mesh belongs to another context");
     if (c->source && source->V != c->source->V) return fail(MSM_ERR_INVALID, "source mesh size changed");
     c->source = source;
     c->have_source = false;
@@ -314,6 +315,7 @@ int msm_cost_reset_source(msm_cost *c, msm_mesh *source) {
 
 int msm_cost_reset_cpgrid(msm_cost *c, msm_mesh *cpgrid) {
     if (!c || !cpgrid) return fail(MSM_ERR_INVALID, "msm_cost_reset_cpgrid: null argument");
+    if (cpgrid->ctx != c->ctx) return fail(MSM_ERR_INVALID, "msm_cost_reset_cpgrid: the mesh belongs to another context");
     if (c->cpgrid && cpgrid->V != c->cpgrid->V) return fail(MSM_ERR_INVALID, "control grid size changed");
     c->cpgrid = cpgrid;
     c->cp_conn_valid = false;
@@ -326,9 +328,8 @@ int msm_cost_set_source_features(msm_cost *c, const double *feat, int32_t D) {
     if (!c || !feat || D <= 0) return fail(MSM_ERR_INVALID, "msm_cost_set_source_features: bad arguments");
     int st = need(c, c->source != nullptr, "meshes");
     if (st) return st;
-    if ((c->p.kind == MSM_COST_UNIVARIATE || c->p.kind == MSM_COST_HO_UNIVARIATE) && D != 1) {
-        // the univariate classes read feature row 1 only (M/DiscreteCostFunction.cpp:343, :477)
-    }
+    // the univariate classes read feature row 1 only (M/DiscreteCostFunction.cpp:343-347, :371, :477-481): with D > 1 their
+    // kernels index row 0 of this D x V array and column 0 of the target's vertex-major features
     c->D = D;
     MSM_HIP(hipStreamSynchronize(c->ctx->stream));
     c->sfeat.assign(feat, feat + (size_t)D * c->source->V);

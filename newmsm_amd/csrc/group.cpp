@@ -577,7 +577,13 @@ int msm_group_import_subject(msm_group *g, int32_t s, const double *F, const int
     msm_ctx *ctx = g->ctx;
     const size_t per = (size_t)g->D * g->tmpl->V;
     const size_t M = (size_t)g->N * g->L;
-    if (pptr[M] != npidx) return fail(MSM_ERR_INVALID, "patch CSR of subject %d is inconsistent", s);
+    // the arrays come from another rank: nothing of them is trusted before it indexes device or host memory
+    if (pptr[0] != 0 || pptr[M] != npidx) return fail(MSM_ERR_INVALID, "patch CSR of subject %d is inconsistent", s);
+    for (size_t r = 0; r < M; ++r)
+        if (pptr[r + 1] < pptr[r]) return fail(MSM_ERR_INVALID, "patch CSR of subject %d: row %zu has a negative length", s, r);
+    const int32_t Vt = g->tmpl->V;
+    for (int64_t j = 0; j < npidx; ++j)
+        if (pidx[j] < 0 || pidx[j] >= Vt) return fail(MSM_ERR_INVALID, "patch CSR of subject %d: template vertex id %d out of range [0,%d)", s, pidx[j], Vt);
     for (int l = 0; l < g->L; ++l) {
         auto &buf = g->F[(size_t)s * g->L + l];
         if (!buf) buf.reset(new DevBuf<double>());

@@ -126,6 +126,14 @@ static inline V3 pt(const double *xyz, int V, int i) { return mk(xyz[i], xyz[V +
 
 using namespace msm;
 
+// every [host] entry point that takes a triangle list checks it before indexing with it
+static int check_triangles(const char *who, const int32_t *tri, int32_t V, int32_t T) {
+    if (!tri || V <= 0 || T <= 0) return fail(MSM_ERR_INVALID, "%s: bad arguments", who);
+    for (int64_t i = 0; i < 3 * (int64_t)T; ++i)
+        if (tri[i] < 0 || tri[i] >= V) return fail(MSM_ERR_INVALID, "%s: triangle vertex id %d out of range [0,%d)", who, tri[i], V);
+    return MSM_OK;
+}
+
 extern "C" {
 
 int msm_abi_version(void) { return MSM_ABI_VERSION; }
@@ -170,9 +178,7 @@ int msm_icosphere(int order, double radius, double *xyz, int32_t *tri) {
 }
 
 int msm_mesh_adjacency(const int32_t *tri, int32_t V, int32_t T, int32_t *nbr_ptr, int32_t *nbr, int32_t *tid_ptr, int32_t *tid) {
-    if (!tri || V <= 0 || T <= 0) return fail(MSM_ERR_INVALID, "msm_mesh_adjacency: bad mesh");
-    for (int i = 0; i < 3 * T; ++i)
-        if (tri[i] < 0 || tri[i] >= V) return fail(MSM_ERR_INVALID, "triangle vertex id %d out of range", tri[i]);
+    if (int st = check_triangles("msm_mesh_adjacency", tri, V, T)) return st;
     Adjacency a;
     build_adjacency(tri, V, T, a);
     if (nbr_ptr) std::copy(a.nbr_ptr.begin(), a.nbr_ptr.end(), nbr_ptr);
@@ -183,7 +189,8 @@ int msm_mesh_adjacency(const int32_t *tri, int32_t V, int32_t T, int32_t *nbr_pt
 }
 
 int msm_vertex_areas(const double *xyz, const int32_t *tri, int32_t V, int32_t T, double *area) {
-    if (!xyz || !tri || !area || V <= 0 || T <= 0) return fail(MSM_ERR_INVALID, "msm_vertex_areas: bad arguments");
+    if (!xyz || !area) return fail(MSM_ERR_INVALID, "msm_vertex_areas: bad arguments");
+    if (int st = check_triangles("msm_vertex_areas", tri, V, T)) return st;
     Adjacency a;
     build_adjacency(tri, V, T, a);
     std::vector<double> ta(T);
@@ -197,7 +204,8 @@ int msm_vertex_areas(const double *xyz, const int32_t *tri, int32_t V, int32_t T
 }
 
 int msm_cp_spacings(const double *xyz, const int32_t *tri, int32_t V, int32_t T, double *maxsep, double *mvdmax) {
-    if (!xyz || !tri || !maxsep || !mvdmax) return fail(MSM_ERR_INVALID, "msm_cp_spacings: null argument");
+    if (!xyz || !maxsep || !mvdmax) return fail(MSM_ERR_INVALID, "msm_cp_spacings: null argument");
+    if (int st = check_triangles("msm_cp_spacings", tri, V, T)) return st;
     Adjacency a;
     build_adjacency(tri, V, T, a);
     double best = -DBL_MAX;  // calculate_MaxVD starts from lowest()
@@ -330,7 +338,7 @@ int msm_estimate_triplets(const int32_t *tri, int32_t T, int32_t *triplets) {
 }
 
 int msm_estimate_pairs(const int32_t *tri, int32_t V, int32_t T, int32_t *pairs) {
-    if (!tri) return fail(MSM_ERR_INVALID, "msm_estimate_pairs: null argument");
+    if (int st = check_triangles("msm_estimate_pairs", tri, V, T)) return st;
     Adjacency a;
     build_adjacency(tri, V, T, a);
     int n = 0;

@@ -145,7 +145,7 @@ int launch_build_recs(msm_ctx *ctx, const double *d_xyz, int V, const int32_t *d
 }
 
 __global__ __launch_bounds__(256) void k_build_raytri(const TriRec *__restrict__ rec, const float4 *__restrict__ edge, int T,
-                                                       const double *__restrict__ feat1, float4 *__restrict__ out) {
+                                                       const double *__restrict__ feat1, int D, float4 *__restrict__ out) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= T) return;
     const TriRec &r = rec[t];
@@ -156,15 +156,15 @@ __global__ __launch_bounds__(256) void k_build_raytri(const TriRec *__restrict__
         d[k] = r.v0[k];
         d[3 + k] = r.v1[k];
         d[6 + k] = r.v2[k];
-        d[9 + k] = feat1 ? feat1[r.id[k]] : 0.0;
+        d[9 + k] = feat1 ? feat1[(size_t)r.id[k] * D] : 0.0;  // feature row 1 (vertex-major storage: column 0)
     }
     double2 *od = reinterpret_cast<double2 *>(o + 3);
     for (int k = 0; k < 6; ++k) od[k] = make_double2(d[2 * k], d[2 * k + 1]);
 }
 
-int launch_build_raytri(msm_ctx *ctx, const TriRec *d_rec, const float4 *d_edge, int T, const double *d_feat1, float4 *d_out) {
+int launch_build_raytri(msm_ctx *ctx, const TriRec *d_rec, const float4 *d_edge, int T, const double *d_feat1, int D, float4 *d_out) {
     if (T <= 0) return MSM_OK;
-    hipLaunchKernelGGL(k_build_raytri, dim3((T + 255) / 256), dim3(256), 0, ctx->stream, d_rec, d_edge, T, d_feat1, d_out);
+    hipLaunchKernelGGL(k_build_raytri, dim3((T + 255) / 256), dim3(256), 0, ctx->stream, d_rec, d_edge, T, d_feat1, D, d_out);
     MSM_HIP(hipGetLastError());
     return MSM_OK;
 }

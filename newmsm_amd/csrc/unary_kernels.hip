@@ -54,7 +54,8 @@ __device__ __forceinline__ double wave_sum(double v) {
 
 struct SamplesArgs {
     DevTree tree;
-    const double *tfeat;   // target feature (D == 1: V doubles) or nullptr when only weights are wanted
+    const double *tfeat;   // target features, V x tD vertex-major (the univariate class reads row 1 = column 0 only,
+    int tD;                // M/DiscreteCostFunction.cpp:371), or nullptr when only weights are wanted
     int N, L;
     const double *rnl;     // N x L x 9
     const double *src;     // 3 x Nsrc SoA
@@ -100,7 +101,7 @@ __device__ __forceinline__ double emit_sample(const SamplesArgs &a, size_t g, co
     double wa, wb, wc;
     area_weights(rec_v0(r), rec_v1(r), rec_v2(r), p, wa, wb, wc);
     if (a.tval) {
-        const double v = wa * a.tfeat[r.id[0]] + wb * a.tfeat[r.id[1]] + wc * a.tfeat[r.id[2]];
+        const double v = wa * a.tfeat[(size_t)r.id[0] * a.tD] + wb * a.tfeat[(size_t)r.id[1] * a.tD] + wc * a.tfeat[(size_t)r.id[2] * a.tD];
         a.tval[g] = v;
         return v;
     } else {
@@ -1099,6 +1100,7 @@ static int launch_samples(msm_ctx *ctx, const UnaryLaunch &u, const UnaryWeights
     if (u.tree.nnodes <= 0 || !u.tree.mask) return fail(MSM_ERR_STATE, "target search structure missing");
     a.tree = u.tree;
     a.tfeat = u.tfeat;
+    a.tD = u.D > 0 ? u.D : 1;
     a.N = u.N;
     a.L = u.L;
     a.rnl = u.rnl;

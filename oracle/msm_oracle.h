@@ -198,6 +198,8 @@ double orc_cost_unary(orc_cost *c, int node, int label);
 void   orc_cost_unary_table(orc_cost *c, double *U /* L x N, label*N+node */);
 void   orc_cost_unary_table_omp(orc_cost *c, double *U, int nthreads);
 double orc_cost_triplet(orc_cost *c, int triplet, int la, int lb, int lc);
+/* one fusion move's octets, I/Fusion/Fusion.h:181-196: E[8*t + k], k = 000..111 (A,B,C), OpenMP over triplets */
+void   orc_cost_triplet_octets(orc_cost *c, const int *labeling, int label, double *E, int nthreads);
 /* computeTripletCosts (:245-253): out[(t - t0) x L x L x L] */
 void   orc_cost_triplet_table(orc_cost *c, int t0, int t1, double *out);
 double orc_cost_pairwise(orc_cost *c, int pair, int la, int lb);

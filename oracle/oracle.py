@@ -452,6 +452,13 @@ class Cost:
     def triplet(self, t, la, lb, lc):
         return lib().orc_cost_triplet(self.h, int(t), int(la), int(lb), int(lc))
 
+    def triplet_octets(self, labeling, label, threads=1):
+        """One fusion move (I/Fusion/Fusion.h:181-196): E[t, k], k = 000..111 over (A,B,C)."""
+        lab, pl = _i(labeling)
+        E = np.zeros((self.T, 8))
+        lib().orc_cost_triplet_octets(self.h, pl, int(label), E.ctypes.data_as(c_dp), int(threads))
+        return E
+
     def triplet_table(self, t0=0, t1=None):
         t1 = self.T if t1 is None else t1
         out = np.zeros((t1 - t0, self.L, self.L, self.L))

@@ -667,7 +667,7 @@ void orc_cost_unary_table_omp(orc_cost *c, double *U, int nthreads) {
 }
 
 /* triplet_likelihood of the HO classes: get_target_data :487-518 / :565-599, likelihood :520-531 / :601-618 */
-static double triplet_likelihood(orc_cost *c, int t, const double n0[3], const double n1[3], const double n2[3]) {
+static double triplet_likelihood(const orc_cost *c, int t, const double n0[3], const double n1[3], const double n2[3], double *tgt, long *nsamples) {
     if (c->p.kind != ORC_HO_UNIVARIATE && c->p.kind != ORC_HO_MULTIVARIATE) return 0.0;
     const int *id = &c->triplets[3 * t];
     const double *cp0 = &c->cpgrid->xyz[3 * id[0]], *cp1 = &c->cpgrid->xyz[3 * id[1]], *cp2 = &c->cpgrid->xyz[3 * id[2]];
@@ -678,9 +678,9 @@ static double triplet_likelihood(orc_cost *c, int t, const double n0[3], const d
         orc_barycentric_point(cp0, cp1, cp2, sp, n0, n1, n2, tmp);
         orc_normalize(tmp);
         for (int a = 0; a < 3; ++a) tmp[a] *= ORC_RAD;
-        if (sample_target(c, tmp, &c->tgt[(long)i * c->D], &c->samples) < 0) return NAN;
+        if (sample_target(c, tmp, &tgt[(long)i * c->D], nsamples) < 0) return NAN;
     }
-    double sim = group_similarity(c, t, c->tgt);
+    double sim = group_similarity(c, t, tgt);
     return (c->absw[id[0]] + c->absw[id[1]] + c->absw[id[2]]) / 3.0 * sim;
 }
 
@@ -739,7 +739,7 @@ static int deform_vertex(const orc_cost *c, int tindex, const int id[3], double 
 }
 
 /* computeTripletCost, M/DiscreteCostFunction.cpp:135-188 (regoption 2/3: spherical strain; 4/5: anatomical strain) */
-double orc_cost_triplet(orc_cost *c, int t, int la, int lb, int lc) {
+static double triplet_eval(const orc_cost *c, int t, int la, int lb, int lc, double *tgt, long *nsamples) {
     const int *id = &c->triplets[3 * t];
     double r[3][3], cur[3][3], org[3][3], nd[3], nc[3];
     m_apply(&c->rot[9 * id[0]], &c->labels[3 * la], r[0]);
@@ -752,7 +752,7 @@ double orc_cost_triplet(orc_cost *c, int t, int la, int lb, int lc) {
     orc_tri_normal(r[0], r[1], r[2], nd);
     orc_tri_normal(cur[0], cur[1], cur[2], nc);
     if (v_dot(nd, nc) < 0.0) return ORC_FOLDING * c->p.lambda;
-    double likelihood = triplet_likelihood(c, t, r[0], r[1], r[2]);
+    double likelihood = triplet_likelihood(c, t, r[0], r[1], r[2], tgt, nsamples);
     double cost = 0.0;
     if (c->p.rmode == 2 || c->p.rmode == 3) {
         cost = orc_triangular_strain(org, r, c->p.mu, c->p.kappa, c->p.k_exp);
@@ -772,6 +772,38 @@ double orc_cost_triplet(orc_cost *c, int t, int la, int lb, int lc) {
         return NAN;
     }
     return likelihood + c->p.lambda * pow(cost, c->p.rexp);
+}
+
+double orc_cost_triplet(orc_cost *c, int t, int la, int lb, int lc) { return triplet_eval(c, t, la, lb, lc, c->tgt, &c->samples); }
+
+/* the eight computeTripletCost calls per triplet of one fusion move, I/Fusion/Fusion.h:181-196 (the reference's
+ * OpenMP loop over the triplets; every thread evaluates whole triplets): E[8*t + k], k = 000..111 with bit order
+ * (A,B,C), 0 = labeling[node], 1 = label */
+void orc_cost_triplet_octets(orc_cost *c, const int *labeling, int label, double *E, int nthreads) {
+    long total = 0;
+    if (nthreads < 1) nthreads = 1;
+#pragma omp parallel num_threads(nthreads) reduction(+ : total)
+    {
+        double *tgt = (double *)malloc(sizeof(double) * (long)(c->maxgroup > 0 ? c->maxgroup : 1) * (c->D > 0 ? c->D : 1));
+        long mine = 0;
+#pragma omp for schedule(static)
+        for (int t = 0; t < c->T; ++t) {
+            const int *id = &c->triplets[3 * t];
+            const int a = labeling[id[0]], b = labeling[id[1]], cc = labeling[id[2]];
+            double *e = &E[8 * (long)t];
+            e[0] = triplet_eval(c, t, a, b, cc, tgt, &mine);
+            e[1] = triplet_eval(c, t, a, b, label, tgt, &mine);
+            e[2] = triplet_eval(c, t, a, label, cc, tgt, &mine);
+            e[3] = triplet_eval(c, t, a, label, label, tgt, &mine);
+            e[4] = triplet_eval(c, t, label, b, cc, tgt, &mine);
+            e[5] = triplet_eval(c, t, label, b, label, tgt, &mine);
+            e[6] = triplet_eval(c, t, label, label, cc, tgt, &mine);
+            e[7] = triplet_eval(c, t, label, label, label, tgt, &mine);
+        }
+        total += mine;
+        free(tgt);
+    }
+    c->samples += total;
 }
 
 /* computePairwiseCost, M/DiscreteCostFunction.cpp:190-226, restated without mutating the CP grid */
@@ -834,9 +866,18 @@ double orc_cost_total(orc_cost *c, const int *labeling, double parts[3]) {
 /* computeTripletCosts, M/DiscreteCostFunction.cpp:245-253: tcosts[t][a][b][c] for t0 <= t < t1 */
 void orc_cost_triplet_table(orc_cost *c, int t0, int t1, double *out) {
     const int L = c->L;
-#pragma omp parallel for schedule(dynamic, 4)
-    for (int t = t0; t < t1; ++t)
-        for (int a = 0; a < L; ++a)
-            for (int b = 0; b < L; ++b)
-                for (int l = 0; l < L; ++l) out[(((size_t)(t - t0) * L + a) * L + b) * L + l] = orc_cost_triplet(c, t, a, b, l);
+    long total = 0;
+#pragma omp parallel reduction(+ : total)
+    {
+        double *tgt = (double *)malloc(sizeof(double) * (long)(c->maxgroup > 0 ? c->maxgroup : 1) * (c->D > 0 ? c->D : 1));
+        long mine = 0;
+#pragma omp for schedule(dynamic, 4)
+        for (int t = t0; t < t1; ++t)
+            for (int a = 0; a < L; ++a)
+                for (int b = 0; b < L; ++b)
+                    for (int l = 0; l < L; ++l) out[(((size_t)(t - t0) * L + a) * L + b) * L + l] = triplet_eval(c, t, a, b, l, tgt, &mine);
+        total += mine;
+        free(tgt);
+    }
+    c->samples += total;
 }
