@@ -26,13 +26,14 @@
 #ifndef MSMHIP_H
 #define MSMHIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
 extern "C" {
 #endif
 
-#define MSM_ABI_VERSION 3
+#define MSM_ABI_VERSION 4
 
 #define MSM_OK 0
 #define MSM_ERR_INVALID (-1)  /* bad argument / inconsistent sizes */
@@ -104,6 +105,13 @@ msm_ctx *msm_ctx_create_on_stream(int device, void *hip_stream); /* launches on 
 void     msm_ctx_destroy(msm_ctx *ctx);
 int      msm_ctx_synchronize(msm_ctx *ctx);
 void    *msm_ctx_stream(msm_ctx *ctx);                        /* hipStream_t, for event timing */
+/* Pinned host memory mapped into the GPU's address space.  An output array that lies inside such a block is written by the
+ * kernels directly (no staging copy, no copy-engine command): use it for the arrays of the optimisers' inner loop --
+ * msm_cost_triplet_octets' E, msm_group_fusion_move's pair_quads / triplet_octets -- the counterpart of the buffers
+ * Fusion::optimize keeps per label step (I/Fusion/Fusion.h:142-146).  Plain malloc'ed arrays keep working everywhere.
+ * The block belongs to the context and is released with it at the latest. */
+void    *msm_host_alloc(msm_ctx *ctx, size_t bytes);
+void     msm_host_free(msm_ctx *ctx, void *p);
 
 /* ------------------------------------------------------------------------------------------------
  * mesh + search structure.  Replaces newresampler::Mesh (coords/triangles/pvalues) as seen by the

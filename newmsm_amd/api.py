@@ -168,6 +168,16 @@ class Context:
     def stream(self):
         return lib().msm_ctx_stream(self.h)
 
+    def host_array(self, shape, dtype=np.float64):
+        """A numpy array in pinned host memory mapped into the GPU's address space (msm_host_alloc): passed as an output array
+        the kernels write it directly.  Lives as long as the context."""
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = lib().msm_host_alloc(self.h, max(n, 8))
+        if not p:
+            raise MsmError(-2, lib().msm_last_error().decode())
+        buf = (C.c_char * max(n, 8)).from_address(p)
+        return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
     def close(self):
         if getattr(self, "h", None):
             lib().msm_ctx_destroy(self.h)
@@ -469,9 +479,13 @@ class DiscreteCostFunction:
         check(lib().msm_cost_triplet_batch(self.h, pt, pa, pb, pc, len(t), out.ctypes.data_as(c_dp)))
         return out
 
-    def tripletOctets(self, labeling, label):
+    def tripletOctets(self, labeling, label, out=None):
+        """One label step of Fusion (Fusion.h:181-196).  `out` (optional, T x 8): the array to fill, e.g. Context.host_array((T, 8))
+        -- mapped pinned memory the kernels write directly, as the optimiser's per-step buffer would be."""
         lab, pl = _i(labeling)
-        out = np.zeros((self.T, 8))
+        if out is None:
+            out = np.zeros((self.T, 8))
+        assert out.shape == (self.T, 8) and out.dtype == np.float64 and out.flags.c_contiguous
         check(lib().msm_cost_triplet_octets(self.h, pl, int(label), out.ctypes.data_as(c_dp)))
         return out
 

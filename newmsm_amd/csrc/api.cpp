@@ -20,12 +20,32 @@ int ctx_io_pinned(msm_ctx *ctx, size_t bytes, void **out) {
         if (ctx->io_pin) (void)hipHostFree(ctx->io_pin);
         ctx->io_pin = nullptr;
         ctx->io_cap = bytes + bytes / 4 + 4096;
-        if (hipHostMalloc(&ctx->io_pin, ctx->io_cap) != hipSuccess) {
+        if (hipHostMalloc(&ctx->io_pin, ctx->io_cap, hipHostMallocMapped) != hipSuccess) {
             ctx->io_cap = 0;
             return fail(MSM_ERR_HIP, "pinned host allocation of %zu bytes failed", bytes);
         }
+        if (hipHostGetDevicePointer(&ctx->io_dev, ctx->io_pin, 0) != hipSuccess) ctx->io_dev = nullptr;
     }
     *out = ctx->io_pin;
+    return MSM_OK;
+}
+
+void *ctx_mapped(msm_ctx *ctx, const void *p, size_t bytes) {
+    const char *q = (const char *)p;
+    for (const auto &b : ctx->host_blocks)
+        if (q >= b.host && q + bytes <= b.host + b.bytes) return b.dev + (q - b.host);
+    return nullptr;
+}
+
+int ctx_flag(msm_ctx *ctx) {
+    if (ctx->h_flag) return MSM_OK;
+    MSM_HIP(hipHostMalloc((void **)&ctx->h_flag, 64, hipHostMallocMapped));
+    *ctx->h_flag = 0;
+    if (hipHostGetDevicePointer((void **)&ctx->d_flag_map, ctx->h_flag, 0) != hipSuccess) {
+        (void)hipHostFree(ctx->h_flag);
+        ctx->h_flag = nullptr;
+        return fail(MSM_ERR_HIP, "hipHostGetDevicePointer failed");
+    }
     return MSM_OK;
 }
 
@@ -546,6 +566,8 @@ void msm_ctx_destroy(msm_ctx *ctx) {
         if (b) (void)hipFree(b);
     if (ctx->stage) (void)hipHostFree(ctx->stage);
     if (ctx->io_pin) (void)hipHostFree(ctx->io_pin);
+    if (ctx->h_flag) (void)hipHostFree(ctx->h_flag);
+    for (auto &b : ctx->host_blocks) (void)hipHostFree(b.host);
     if (ctx->d_status) (void)hipFree(ctx->d_status);
     if (ctx->h_status) (void)hipHostFree(ctx->h_status);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -559,6 +581,38 @@ int msm_ctx_synchronize(msm_ctx *ctx) {
 }
 
 void *msm_ctx_stream(msm_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+void *msm_host_alloc(msm_ctx *ctx, size_t bytes) {
+    if (!ctx || bytes == 0) {
+        fail(MSM_ERR_INVALID, "msm_host_alloc: bad arguments");
+        return nullptr;
+    }
+    (void)hipSetDevice(ctx->device);
+    msm_ctx::HostBlock b{nullptr, nullptr, bytes};
+    if (hipHostMalloc((void **)&b.host, bytes, hipHostMallocMapped) != hipSuccess) {
+        fail(MSM_ERR_HIP, "msm_host_alloc: pinned allocation of %zu bytes failed", bytes);
+        return nullptr;
+    }
+    if (hipHostGetDevicePointer((void **)&b.dev, b.host, 0) != hipSuccess) {
+        (void)hipHostFree(b.host);
+        fail(MSM_ERR_HIP, "msm_host_alloc: the block cannot be mapped into the device's address space");
+        return nullptr;
+    }
+    ctx->host_blocks.push_back(b);
+    return b.host;
+}
+
+void msm_host_free(msm_ctx *ctx, void *p) {
+    if (!ctx || !p) return;
+    for (size_t i = 0; i < ctx->host_blocks.size(); ++i)
+        if (ctx->host_blocks[i].host == (char *)p) {
+            (void)hipSetDevice(ctx->device);
+            (void)hipStreamSynchronize(ctx->stream);
+            (void)hipHostFree(p);
+            ctx->host_blocks.erase(ctx->host_blocks.begin() + i);
+            return;
+        }
+}
 
 // ------------------------------------------------------------------ mesh
 msm_mesh *msm_mesh_create(msm_ctx *ctx, const double *xyz, int32_t V, const int32_t *tri, int32_t T) {

@@ -51,6 +51,7 @@ int ensure_label_rotations(msm_cost *c) {
 namespace {
 
 void invalidate_table(msm_cost *c) {
+    c->move_valid = false;
     c->table_valid = false;
     c->rotations_valid = false;
     c->h_U.clear();
@@ -397,6 +398,7 @@ int msm_cost_set_triplets(msm_cost *c, const int32_t *triplets, int32_t T) {
         if (triplets[i] < 0 || triplets[i] >= c->cpgrid->V) return fail(MSM_ERR_INVALID, "triplet node id out of range");
     MSM_HIP(hipStreamSynchronize(c->ctx->stream));
     c->triplets.assign(triplets, triplets + 3 * (size_t)T);
+    c->move_valid = false;
     if (T > 0) MSM_HIP(c->d_triplets.upload(c->triplets.data(), c->triplets.size(), c->ctx->stream));
     return MSM_OK;
 }

@@ -1,6 +1,7 @@
 // cost_cliques.cpp -- C ABI of the pairwise / triplet clique costs and of evaluateTotalCostSum
 // (include/msmhip.h).  Kernels: clique_kernels.hip.
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 #include "cost_internal.hpp"
@@ -120,6 +121,52 @@ int clique_args(msm_cost *c, bool need_triplets, bool need_pairs, CliqueArgs &a)
     return MSM_OK;
 }
 
+// ---- fused fusion move of the HO classes (move_kernels.hip) ----
+constexpr int kMoveSlots = 32, kMoveTriangles = 8;  // bin slots and control triangles per workgroup (256 lanes = 8 combinations x 32 slots)
+
+bool fused_move_applies(const msm_cost *c, const CliqueArgs &a) {
+    static const bool split = [] {
+        const char *e = std::getenv("MSMHIP_MOVE");  // "split": the three-kernel path of round 1 (kept for comparison)
+        return e && std::strcmp(e, "split") == 0;
+    }();
+    return !split && cost_is_ho(c) && a.ho_vals && a.tree.simple && a.tree.ray_G > 0 && a.rmode != 4 && a.rmode != 5 && c->pmax <= 128 && a.T > 0;
+}
+
+// per get_source_data(): the workgroups' runs of control triangles and the label-independent part of every bin point
+int ensure_move(msm_cost *c, const CliqueArgs &a) {
+    if (c->move_valid) return MSM_OK;
+    msm_ctx *ctx = c->ctx;
+    const int T = a.T;
+    std::vector<int32_t> blk{0};
+    int slots = 0, nt = 0, cap = kMoveSlots;
+    for (int t = 0; t < T; ++t) {
+        const int n = c->pptr[t + 1] - c->pptr[t];
+        if (nt > 0 && (slots + n > kMoveSlots || nt == kMoveTriangles)) {
+            blk.push_back(t);
+            slots = nt = 0;
+        }
+        slots += n;
+        ++nt;
+        cap = std::max(cap, slots);
+    }
+    blk.push_back(T);
+    const size_t ns = std::max<size_t>(c->pidx.size(), 1);
+    MSM_HIP(c->d_blk_t.upload(blk.data(), blk.size(), ctx->stream));
+    MSM_HIP(c->d_slot_tri.ensure(ns));
+    MSM_HIP(c->d_slot_w.ensure(3 * ns));
+    MSM_HIP(c->d_slot_sf.ensure(ns));
+    if (a.cfw) MSM_HIP(c->d_slot_cw.ensure(ns));
+    MSM_HIP(c->d_defer_list.ensure((size_t)8 * T));
+    if (!c->d_defer_cnt.p) MSM_HIP(c->d_defer_cnt.zero(2, ctx->stream));
+    int st = launch_move_prepare(ctx, a, (int)c->pidx.size(), c->d_slot_tri.p, c->d_slot_w.p, c->d_slot_sf.p, a.cfw ? c->d_slot_cw.p : nullptr);
+    if (st) return st;
+    MSM_HIP(hipStreamSynchronize(ctx->stream));  // blk is a local
+    c->move_nblk = (int)blk.size() - 1;
+    c->move_cap = cap;
+    c->move_valid = true;
+    return MSM_OK;
+}
+
 int upload_ints(msm_ctx *ctx, DevBuf<int> &buf, const int32_t *host, size_t n) {
     MSM_HIP(buf.upload(host, n, ctx->stream));
     return MSM_OK;
@@ -198,12 +245,85 @@ int msm_cost_triplet_octets(msm_cost *c, const int32_t *labeling, int32_t label,
     int st = clique_args(c, true, false, a);
     if (st) return st;
     if (label < 0 || label >= a.L) return fail(MSM_ERR_INVALID, "label %d out of range", label);
+    msm_ctx *ctx = c->ctx;
+    const size_t in_bytes = sizeof(int32_t) * (size_t)a.N, out_bytes = sizeof(double) * 8 * (size_t)a.T, in_pad = (in_bytes + 255) & ~(size_t)255;
+    if (fused_move_applies(c, a)) {
+        // The call of the optimisers' inner loop (once per label step).  Two launches and one synchronisation: the labeling
+        // rides in the kernel arguments, the costs are written into mapped pinned memory (the caller's own array when it
+        // came from msm_host_alloc), a raised status shows up in a mapped flag.
+        st = ensure_move(c, a);
+        if (st) return st;
+        st = ctx_flag(ctx);
+        if (st) return st;
+        const bool packed = a.N <= 4 * kMoveLabelWords && a.L <= 256;
+        MoveLabels lab;
+        if (packed) std::memset(lab.w, 0, sizeof(uint32_t) * (size_t)((a.N + 3) / 4));
+        for (int i = 0; i < a.N; ++i) {
+            if (labeling[i] < 0 || labeling[i] >= a.L) return fail(MSM_ERR_INVALID, "labeling[%d] out of range", i);
+            if (packed) lab.w[i >> 2] |= (uint32_t)labeling[i] << ((i & 3) * 8);
+        }
+        void *pin = nullptr;
+        double *out_dev = (double *)ctx_mapped(ctx, E, out_bytes);
+        const bool direct = out_dev != nullptr;
+        if (!direct || !packed) {
+            st = ctx_io_pinned(ctx, in_pad + out_bytes, &pin);
+            if (st) return st;
+        }
+        bool staged_copy = false;  // the costs come back with a copy command (the pinned block could not be mapped)
+        if (!direct) {
+            if (ctx->io_dev) {
+                out_dev = (double *)((char *)ctx->io_dev + in_pad);
+            } else {
+                MSM_HIP(c->d_clique_out.ensure((size_t)8 * a.T));
+                out_dev = c->d_clique_out.p;
+                staged_copy = true;
+            }
+        }
+        if (!packed) {
+            std::memcpy(pin, labeling, in_bytes);
+            MSM_HIP(c->d_labeling.ensure(a.N));
+            MSM_HIP(hipMemcpyAsync(c->d_labeling.p, pin, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+        }
+        MoveArgs m;
+        m.slot_tri = c->d_slot_tri.p;
+        m.slot_w = c->d_slot_w.p;
+        m.slot_sf = c->d_slot_sf.p;
+        m.slot_cw = a.cfw ? c->d_slot_cw.p : nullptr;
+        m.blk_t = c->d_blk_t.p;
+        m.nblk = c->move_nblk;
+        m.cap = c->move_cap;
+        m.labeling = packed ? nullptr : c->d_labeling.p;
+        m.label = label;
+        m.vals = c->d_ho_vals.p;
+        m.defer_list = c->d_defer_list.p;
+        m.defer_cnt = c->d_defer_cnt.p;
+        m.parity = c->move_parity;
+        c->move_parity ^= 1;
+        m.out = out_dev;
+        m.host_status = ctx->d_flag_map;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (c->timing) {
+            e0 = c->ev0[c->ev_next];
+            e1 = c->ev1[c->ev_next];
+            c->ev_next = (c->ev_next + 1) % (int)c->ev0.size();
+            c->ev_count = std::min(c->ev_count + 1, (int)c->ev0.size());
+        }
+        st = launch_move(ctx, a, m, packed ? &lab : nullptr, e0, e1);
+        if (st) return st;
+        if (staged_copy) MSM_HIP(hipMemcpyAsync((char *)pin + in_pad, out_dev, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+        c->counters[2] += (int64_t)8 * a.T;
+        MSM_HIP(hipStreamSynchronize(ctx->stream));
+        st = MSM_OK;
+        if (*(volatile int *)ctx->h_flag != 0) {
+            *(volatile int *)ctx->h_flag = 0;
+            st = check_status(ctx, "computeTripletCost");
+        }
+        if (!direct) std::memcpy(E, (char *)pin + in_pad, out_bytes);
+        return st;
+    }
     for (int i = 0; i < a.N; ++i)
         if (labeling[i] < 0 || labeling[i] >= a.L) return fail(MSM_ERR_INVALID, "labeling[%d] out of range", i);
-    msm_ctx *ctx = c->ctx;
-    // this is the call of the optimisers' inner loop (once per label step): labeling and energies travel through pinned
-    // memory (pageable copies of these sizes cost more than the kernels)
-    const size_t in_bytes = sizeof(int32_t) * (size_t)a.N, out_bytes = sizeof(double) * 8 * (size_t)a.T, in_pad = (in_bytes + 255) & ~(size_t)255;
+    // labeling and energies travel through pinned memory (pageable copies of these sizes cost more than the kernels)
     void *pin = nullptr;
     st = ctx_io_pinned(ctx, in_pad + out_bytes, &pin);
     if (st) return st;

@@ -122,7 +122,18 @@ struct msm_ctx {
     size_t stage_cap = 0;
     // small pinned buffers for the per-label-step calls (labeling in, fusion-move energies out)
     void *io_pin = nullptr;
+    void *io_dev = nullptr;  // its device address (the block is mapped), or nullptr
     size_t io_cap = 0;
+    // a mapped pinned word kernels of the per-label-step calls store a raised status into (no status copy on their fast path)
+    int *h_flag = nullptr;
+    int *d_flag_map = nullptr;  // its device address
+    // msm_host_alloc blocks: pinned host memory the GPU writes results into directly
+    struct HostBlock {
+        char *host;
+        char *dev;
+        size_t bytes;
+    };
+    std::vector<HostBlock> host_blocks;
 };
 
 namespace msm {
@@ -189,6 +200,9 @@ int ensure_rays(msm_mesh *m, bool wait = false);   // + the ray table of a simpl
 DevTree dev_tree(const msm_mesh *m);
 int check_status(msm_ctx *ctx, const char *what);  // sync + read kernel status
 int ctx_io_pinned(msm_ctx *ctx, size_t bytes, void **out);  // grow-only pinned scratch for small per-call transfers
+// device address of [p, p + bytes) when it lies in a msm_host_alloc block of this context, else nullptr
+void *ctx_mapped(msm_ctx *ctx, const void *p, size_t bytes);
+int ctx_flag(msm_ctx *ctx);  // makes ctx->h_flag / d_flag_map available
 // host -> device through the context's pinned staging buffer (pageable copies of tens of MB ran at < 1 GB/s); waits for
 // earlier work on the stream first, returns with the copy queued
 int upload_staged(msm_ctx *ctx, void *dst, const void *src, size_t bytes);

@@ -117,6 +117,33 @@ struct CliqueArgs {
     const int *af_ptr, *af_idx;  // NEARESTFACES CSR
     int *status;
 };
+// ---- fused fusion move of the HO (triclique) classes on a direction-table target (move_kernels.hip) ----
+// The labeling travels in the kernel arguments, one byte per control point (no copy engine on the call's critical path).
+constexpr int kMoveLabelWords = 704;  // N <= 2816 control points (ico4: 2562), L <= 256
+struct MoveLabels {
+    uint32_t w[kMoveLabelWords];
+};
+struct MoveArgs {
+    // prepared once per get_source_data() by launch_move_prepare: per bin slot (a source vertex in its control triangle's bin)
+    const int *slot_tri;     // the control triangle of the slot
+    const double *slot_w;    // 3 per slot: barycentric coordinates of the projected source vertex in the CURRENT control triangle
+    const double *slot_sf;   // univariate: moving feature (row 1) of the slot's vertex
+    const double *slot_cw;   // univariate: its cost-function weight (row 1), or nullptr
+    const int *blk_t;        // nblk + 1: first control triangle of every workgroup
+    int nblk;
+    int cap;                 // bin slots one workgroup holds at most
+    const int *labeling;     // device copy of the labeling, or nullptr when it is packed into MoveLabels
+    int label;
+    double *vals;            // 8 x (all bin slots): values of the evaluations left to the tail kernel
+    unsigned *defer_list;    // 8 x T evaluation ids
+    unsigned *defer_cnt;     // two counters; a move uses [parity] and clears [parity ^ 1]
+    int parity;
+    double *out;             // 8 x T costs (device memory or mapped pinned host memory)
+    int *host_status;        // mapped pinned host word: non-zero when a kernel raised a status
+};
+int launch_move_prepare(msm_ctx *ctx, const CliqueArgs &a, int nslots, int *slot_tri, double *slot_w, double *slot_sf, double *slot_cw);
+int launch_move(msm_ctx *ctx, const CliqueArgs &a, const MoveArgs &m, const MoveLabels *labels, hipEvent_t ev_start, hipEvent_t ev_stop);
+
 int launch_triplet_batch(msm_ctx *ctx, const CliqueArgs &a, const int *qt, const int *qa, const int *qb, const int *qc, int n, double *out);
 int launch_triplet_octets(msm_ctx *ctx, const CliqueArgs &a, const int *labeling, int label, double *out);
 int launch_pairwise_batch(msm_ctx *ctx, const CliqueArgs &a, const int *qp, const int *qa, const int *qb, int n, double *out);

@@ -1,0 +1,345 @@
+// move_kernels.hip -- one label step of Fusion::optimize for the triclique (HO) cost classes (I/Fusion/Fusion.h:181-196:
+// eight computeTripletCost calls per control triangle, M/DiscreteCostFunction.cpp:135-188 with HO*::triplet_likelihood
+// :487-531 / :565-618) on a direction-table target, as ONE kernel plus a short tail.
+//
+// What every HCP configuration evaluates 38 times per iteration.  Per move: 8 x T evaluations, each sampling the ~8 source
+// vertices binned under its control triangle.  The three-kernel version of round 1 (sample / fix up / reduce, 31 + 15 + 16
+// us at ico6 / ico4) spent its time in per-point geometry that does not depend on the labels and in two extra passes
+// over the values.  Here:
+//   * the part of get_target_data that only depends on the CURRENT control triangle -- project the source vertex on its
+//     plane, its barycentric coordinates there (:498-505 / :574-583) -- is computed once per get_source_data()
+//     (k_move_prepare, same arithmetic, same bits); a sample starts from three weights;
+//   * a lane per (combination, bin point): workgroups take runs of consecutive control triangles (<= 32 bin slots, host
+//     packed), 8 lanes per triangle first set up the eight proposed triangles (fold test included) in LDS, then all
+//     lanes sample, then the same 8 lanes per triangle reduce their evaluation from LDS -- similarity in the reference's
+//     serial order + strain -- and write the cost.  No value goes through HBM;
+//   * samples the direction table cannot settle (0.2 %) mark their evaluation; it is appended to a short list with its
+//     values, and the tail kernel (a wavefront per listed evaluation, 8 lanes per unsettled point: search_device.hpp
+//     group8_find) finishes those ~1.6 % of the evaluations;
+//   * the labeling arrives in the kernel arguments (a byte per control point) and the costs can be written straight
+//     into mapped pinned host memory, so a call is two launches and one synchronisation.
+#include "clique_device.hpp"
+
+namespace msm {
+
+namespace {
+
+constexpr unsigned long long kPendingBits = 0x7ff8dead0badc0deull;  // a NaN no computation produces: "this sample is left to the tail"
+__device__ __forceinline__ double pending_value() { return __longlong_as_double((long long)kPendingBits); }
+__device__ __forceinline__ bool is_pending(double v) { return (unsigned long long)__double_as_longlong(v) == kPendingBits; }
+
+template <bool kPacked>
+__device__ __forceinline__ int label_of(const MoveArgs &m, const MoveLabels &lab, int node) {
+    if (kPacked) return (int)((lab.w[node >> 2] >> ((node & 3) * 8)) & 255u);
+    return m.labeling[node];
+}
+
+__device__ __forceinline__ void raise_both(const CliqueArgs &a, const MoveArgs &m, int code) {
+    atomicMin(a.status, code);
+    __hip_atomic_store(m.host_status, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// s / P for 0 <= s < 2^22, P > 0, with a float reciprocal and an exact correction step
+__device__ __forceinline__ int fast_div(int s, int P, float invP) {
+    int q = (int)((float)s * invP);
+    if (q * P > s) --q;
+    else if ((q + 1) * P <= s) ++q;
+    return q;
+}
+
+// position of a bin point for a proposed triangle (n0, n1, n2 = g[0..9)): HO*::get_target_data :506-510 / :584-590 from
+// the point's barycentric coordinates in the current control triangle
+__device__ __forceinline__ V3 moved_point(const double *g, double wa, double wb, double wc) {
+    const V3 tmp = mk(g[0] * wa + g[3] * wb + g[6] * wc, g[1] * wa + g[4] * wb + g[7] * wc, g[2] * wa + g[5] * wb + g[8] * wc);
+    return scale(normalized(tmp), kRad);
+}
+
+// Direction-table search that also hands back the winning triangle's vertices (and single feature) from its table
+// record: the first candidate's vertices are requested together with its edge planes, as in k_unary_rays.
+__device__ __forceinline__ int ray_find_rec(const DevTree &T, const V3 &p, double2 &d0, double2 &d1, double2 &d2, double2 &d3, double2 &d4, double2 &d5) {
+    float fx, fy, fz;
+    const int4 c = ray_cell_of(T, p, fx, fy, fz);
+    if (c.x < 0) return -1;
+    const float4 *rec = T.ray_tri + (size_t)kRayPieces * c.x;
+    const float4 e0 = rec[0], e1 = rec[1], e2 = rec[2];
+    const double2 *dv = reinterpret_cast<const double2 *>(rec + 3);
+    d0 = dv[0], d1 = dv[1], d2 = dv[2], d3 = dv[3], d4 = dv[4], d5 = dv[5];
+    int t = c.x;
+    float4 ev = e1;
+    if (!ray_accepts(e0, e1, e2, fx, fy, fz)) {
+        t = -1;
+        int4 mo = make_int4(c.w, -1, -1, -1);
+        if (c.w < -1) mo = T.ray_more[-2 - c.w];
+#pragma unroll 1
+        for (int k = 0; k < 6 && t < 0; ++k) {
+            const int ck = k == 0 ? c.y : (k == 1 ? c.z : (k == 2 ? mo.x : (k == 3 ? mo.y : (k == 4 ? mo.z : mo.w))));
+            if (ck < 0) break;
+            const float4 *r2 = T.ray_tri + (size_t)kRayPieces * ck;
+            const float4 g0 = r2[0], g1 = r2[1], g2 = r2[2];
+            if (ray_accepts(g0, g1, g2, fx, fy, fz)) {
+                t = ck;
+                ev = g1;
+            }
+        }
+        if (t >= 0) {
+            dv = reinterpret_cast<const double2 *>(T.ray_tri + (size_t)kRayPieces * t + 3);
+            d0 = dv[0], d1 = dv[1], d2 = dv[2], d3 = dv[3], d4 = dv[4], d5 = dv[5];
+        }
+    }
+    if (t >= 0 && __float_as_int(ev.w) >= 0 && !ray_vouches(T, ev, p)) t = -1;  // its leaf may not list the triangle
+    return t;
+}
+
+// the eight proposed triangles of control triangle t: combination k (bits A,B,C; 0 = current label), I/Fusion/Fusion.h:188-195
+template <bool kPacked>
+__device__ __forceinline__ bool proposed_triangle(const CliqueArgs &a, const MoveArgs &m, const MoveLabels &lab, int t, int k, int *id, V3 *r) {
+    id[0] = a.triplets[3 * t], id[1] = a.triplets[3 * t + 1], id[2] = a.triplets[3 * t + 2];
+    const int la = (k & 4) ? m.label : label_of<kPacked>(m, lab, id[0]);
+    const int lb = (k & 2) ? m.label : label_of<kPacked>(m, lab, id[1]);
+    const int lc = (k & 1) ? m.label : label_of<kPacked>(m, lab, id[2]);
+    r[0] = aos(a.moved, (size_t)id[0] * a.L + la), r[1] = aos(a.moved, (size_t)id[1] * a.L + lb), r[2] = aos(a.moved, (size_t)id[2] * a.L + lc);
+    const V3 c0 = soa(a.cp, a.N, id[0]), c1 = soa(a.cp, a.N, id[1]), c2 = soa(a.cp, a.N, id[2]);
+    return dot(tri_normal(r[0], r[1], r[2]), tri_normal(c0, c1, c2)) < 0.0;  // computeTripletCost :151-152
+}
+
+// likelihood + lambda * strain^rexp of one evaluation whose point values are all in vals[0..n)
+__device__ __forceinline__ double finish_evaluation(const CliqueArgs &a, const MoveArgs &m, int t, const int *id, const V3 *r, const double *vals) {
+    const int beg = a.bin_ptr[t], n = a.bin_ptr[t + 1] - beg;
+    const double wmean = (a.absw[id[0]] + a.absw[id[1]] + a.absw[id[2]]) / 3.0;
+    const double *sf = m.slot_sf + beg, *cw = m.slot_cw ? m.slot_cw + beg : nullptr;
+    const double likelihood = ho_likelihood_core(
+        a.kind == MSM_COST_HO_UNIVARIATE, a.simmeasure, a.percentile, n, wmean, [&](int i) { return sf[i]; }, [&](int i) { return cw ? cw[i] : 1.0; },
+        [&](int i) { return vals[i]; });
+    const V3 org[3] = {soa(a.orig, a.Norig, id[0]), soa(a.orig, a.Norig, id[1]), soa(a.orig, a.Norig, id[2])};
+    const double w = triangular_strain(org, r, a.mu, a.kappa, a.k_exp);
+    return likelihood + a.lambda * pow(w, a.rexp);
+}
+
+}  // namespace
+
+// per control triangle: the label-independent half of HO*::get_target_data for each of its bin points
+__global__ __launch_bounds__(256) void k_move_prepare(CliqueArgs a, int *__restrict__ slot_tri, double *__restrict__ slot_w, double *__restrict__ slot_sf,
+                                                       double *__restrict__ slot_cw) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= a.T) return;
+    const int id[3] = {a.triplets[3 * t], a.triplets[3 * t + 1], a.triplets[3 * t + 2]};
+    const V3 cp0 = soa(a.cp, a.N, id[0]), cp1 = soa(a.cp, a.N, id[1]), cp2 = soa(a.cp, a.N, id[2]);
+    V3 s3;
+    double pd;
+    plane_of(cp0, cp1, cp2, s3, pd);
+    for (int s = a.bin_ptr[t]; s < a.bin_ptr[t + 1]; ++s) {
+        const int sv = a.bin_idx[s];
+        const V3 sp = project_with_plane(soa(a.src, a.Nsrc, sv), s3, pd);  // project_point(src, cp0, cp1, cp2)
+        double wa, wb, wc;
+        area_weights(cp0, cp1, cp2, sp, wa, wb, wc);  // barycentric(), R/triangle.cpp:159-172
+        slot_tri[s] = t;
+        slot_w[3 * (size_t)s] = wa, slot_w[3 * (size_t)s + 1] = wb, slot_w[3 * (size_t)s + 2] = wc;
+        slot_sf[s] = a.sfeat[sv];                 // feature row 1 (the univariate classes; unused by the multivariate one)
+        if (slot_cw) slot_cw[s] = a.cfw[sv];      // weight row 1
+    }
+}
+
+// kMode 0: HO univariate (value = interpolated target feature, from the table record)
+//       1: HO multivariate, a lane per sample (any D, any measure): ho_value_on
+//       2: HO multivariate, 12 <= D <= 64, SSD / correlation: eight lanes per sample split the dimensions
+template <bool kPacked, int kMode>
+__global__ __launch_bounds__(256) void k_ho_move(CliqueArgs a, MoveArgs m, MoveLabels lab) {
+    extern __shared__ __align__(16) double lds[];
+    double *s_geo = lds;                            // 64 evaluations x 9: the proposed triangles
+    double *s_vals = s_geo + 64 * 9;                // 8 combinations x cap bin slots
+    double *s_w = s_vals + 8 * (size_t)m.cap;       // kMode 2: 3 weights per sample of a round
+    int *s_flag = reinterpret_cast<int *>(s_w + (kMode == 2 ? 3 * 256 : 0));  // [0,64) folded, [64,128) deferred
+    int *s_tt = s_flag + 128;                       // kMode 2: triangle per sample of a round
+
+    const int tid = threadIdx.x;
+    if (blockIdx.x == 0 && tid == 0) m.defer_cnt[m.parity ^ 1] = 0u;  // the previous move's list has been consumed
+    const int per = (m.nblk + 7) >> 3;  // the workgroups of an XCD (blockIdx % 8) take a contiguous run of control triangles
+    const int blk = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if (blk >= m.nblk) return;
+    const int t0 = m.blk_t[blk], ntrip = m.blk_t[blk + 1] - t0;
+    const int s0 = a.bin_ptr[t0], nslots = a.bin_ptr[t0 + ntrip] - s0;
+
+    // ---- the eight proposed triangles of each control triangle
+    const bool ev = tid < 8 * ntrip;
+    int id[3] = {0, 0, 0};
+    V3 r[3];
+    r[0] = r[1] = r[2] = mk(0.0, 0.0, 0.0);
+    const int t = t0 + (tid >> 3), k = tid & 7;
+    bool folded = false;
+    if (ev) {
+        folded = proposed_triangle<kPacked>(a, m, lab, t, k, id, r);
+        double *g = s_geo + 9 * tid;
+        g[0] = r[0].x, g[1] = r[0].y, g[2] = r[0].z, g[3] = r[1].x, g[4] = r[1].y, g[5] = r[1].z, g[6] = r[2].x, g[7] = r[2].y, g[8] = r[2].z;
+        s_flag[tid] = folded ? 1 : 0;
+        s_flag[64 + tid] = 0;
+    }
+    __syncthreads();
+
+    // ---- samples: s = combination * nslots + slot (neighbouring lanes = neighbouring bin points of one combination)
+    const int total = 8 * nslots;
+    const float inv = 1.0f / (float)max(nslots, 1);
+    for (int base = 0; base < total; base += 256) {
+        const int s = base + tid;
+        int tt = -2;  // -2: nothing to do (past the end, or a folded proposal: it never looks at the data); -1: left to the tail
+        int kk = 0, j = 0, el = 0;
+        if (s < total) {
+            kk = fast_div(s, nslots, inv), j = s - kk * nslots;
+            el = (m.slot_tri[s0 + j] - t0) * 8 + kk;
+            if (!s_flag[el]) {
+                const size_t slot = (size_t)(s0 + j);
+                const V3 p = moved_point(s_geo + 9 * el, m.slot_w[3 * slot], m.slot_w[3 * slot + 1], m.slot_w[3 * slot + 2]);
+                double2 d0, d1, d2, d3, d4, d5;
+                tt = ray_find_rec(a.tree, p, d0, d1, d2, d3, d4, d5);
+                if (tt >= 0) {
+                    double wa, wb, wc;
+                    area_weights(mk(d0.x, d0.y, d1.x), mk(d1.y, d2.x, d2.y), mk(d3.x, d3.y, d4.x), p, wa, wb, wc);
+                    if (kMode == 0) {
+                        s_vals[kk * m.cap + j] = wa * d4.y + wb * d5.x + wc * d5.y;
+                    } else if (kMode == 1) {
+                        s_vals[kk * m.cap + j] = ho_value_on(a, a.bin_idx[slot], p, tt);
+                    } else {
+                        s_w[3 * tid] = wa, s_w[3 * tid + 1] = wb, s_w[3 * tid + 2] = wc;
+                    }
+                } else {
+                    s_vals[kk * m.cap + j] = pending_value();
+                    s_flag[64 + el] = 1;
+                }
+            }
+        }
+        if (kMode == 2) {
+            // eight lanes per sample: 32 groups x 8 passes cover the round's 256 samples
+            s_tt[tid] = tt;
+            __syncthreads();
+            const int grp = tid >> 3, jj = tid & 7, D = a.D;
+#pragma unroll 1
+            for (int pass = 0; pass < 8; ++pass) {
+                const int q = pass * 32 + grp, sq = base + q;
+                const int qt = s_tt[q];
+                const bool go = qt >= 0;
+                if (!__any(go)) continue;
+                const double *f0 = a.tfeat, *f1 = a.tfeat, *f2 = a.tfeat, *sa = a.sfeat_vm, *cw = nullptr;
+                int qk = 0, qj = 0;
+                if (go) {
+                    qk = fast_div(sq, nslots, inv), qj = sq - qk * nslots;
+                    const int sv = a.bin_idx[s0 + qj];
+                    const TriRec &rr = a.tree.rec[qt];
+                    f0 = a.tfeat + (size_t)rr.id[0] * D, f1 = a.tfeat + (size_t)rr.id[1] * D, f2 = a.tfeat + (size_t)rr.id[2] * D;
+                    sa = a.sfeat_vm + (size_t)sv * D;
+                    cw = a.cfw_vm ? a.cfw_vm + (size_t)sv * a.cfw_rows : nullptr;
+                }
+                const double c = feature_vector_similarity8(a.simmeasure, go, jj, D, sa, cw, a.cfw_rows, f0, f1, f2, s_w[3 * q], s_w[3 * q + 1], s_w[3 * q + 2]);
+                if (go && jj == 0) s_vals[qk * m.cap + qj] = c;
+            }
+            __syncthreads();
+        }
+    }
+    if (kMode != 2) __syncthreads();
+
+    // ---- one lane per evaluation: similarity in the reference's serial order + strain
+    if (!ev) return;
+    const int e = 8 * t + k;
+    if (folded) {
+        m.out[e] = MSM_FOLDING * a.lambda;
+        return;
+    }
+    const int beg = a.bin_ptr[t], n = a.bin_ptr[t + 1] - beg;
+    const double *vals = s_vals + k * m.cap + (beg - s0);
+    if (s_flag[64 + tid]) {  // some point is unsettled: hand the evaluation and what is known of it to the tail kernel
+        const unsigned at = atomicAdd(&m.defer_cnt[m.parity], 1u);
+        m.defer_list[at] = (unsigned)e;
+        double *gv = m.vals + (size_t)8 * beg + (size_t)k * n;
+        for (int i = 0; i < n; ++i) gv[i] = vals[i];
+        return;
+    }
+    m.out[e] = finish_evaluation(a, m, t, id, r, vals);
+}
+
+// The listed evaluations: a wavefront each, eight lanes per unsettled point (complete search), then the same reduction.
+template <bool kPacked>
+__global__ __launch_bounds__(256) void k_ho_move_tail(CliqueArgs a, MoveArgs m, MoveLabels lab) {
+    extern __shared__ __align__(16) double lds[];  // 4 wavefronts x bin_cap values
+    const unsigned n = m.defer_cnt[m.parity];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, grp = lane >> 3, sub = lane & 7;
+    double *vals = lds + (size_t)wave * a.bin_cap;
+    const unsigned stride = gridDim.x * 4;
+    for (unsigned base = blockIdx.x * 4; base < n; base += stride) {  // workgroup-uniform
+        const unsigned idx = base + wave;
+        const bool have = idx < n;
+        int t = 0, k = 0, id[3] = {0, 0, 0}, beg = 0, cnt = 0;
+        V3 r[3];
+        r[0] = r[1] = r[2] = mk(0.0, 0.0, 0.0);
+        if (have) {
+            const int e = (int)m.defer_list[idx];
+            t = e >> 3, k = e & 7;
+            proposed_triangle<kPacked>(a, m, lab, t, k, id, r);  // not folded: a folded proposal is never listed
+            beg = a.bin_ptr[t], cnt = a.bin_ptr[t + 1] - beg;
+        }
+        const double g[9] = {r[0].x, r[0].y, r[0].z, r[1].x, r[1].y, r[1].z, r[2].x, r[2].y, r[2].z};
+        double *gv = m.vals + (size_t)8 * beg + (size_t)k * cnt;
+        for (int i0 = 0; i0 < cnt; i0 += 8) {  // wavefront-uniform: all lanes of a wavefront share the evaluation
+            const int i = i0 + grp;
+            const bool in = i < cnt;
+            double v = in ? gv[i] : 0.0;
+            const bool pend = in && is_pending(v);
+            V3 p = mk(0.0, 0.0, 0.0);
+            if (pend) {
+                const size_t slot = (size_t)(beg + i);
+                p = moved_point(g, m.slot_w[3 * slot], m.slot_w[3 * slot + 1], m.slot_w[3 * slot + 2]);
+            }
+            if (__any(pend)) {
+                const int found = group8_find(a.tree, pend, p, lane);
+                if (pend && sub == 0) {
+                    const int tt = found == kGroupUndecided ? find_closest_triangle(a.tree, p) : found;
+                    if (tt < 0) {
+                        raise_both(a, m, tt);
+                        v = __longlong_as_double(0x7ff8000000000000ll);
+                    } else {
+                        v = ho_value_on(a, a.bin_idx[beg + i], p, tt);
+                    }
+                }
+            }
+            if (in && sub == 0) vals[i] = v;
+        }
+        __syncthreads();
+        if (have && lane == 0) m.out[8 * t + k] = finish_evaluation(a, m, t, id, r, vals);
+        __syncthreads();
+    }
+}
+
+int launch_move_prepare(msm_ctx *ctx, const CliqueArgs &a, int nslots, int *slot_tri, double *slot_w, double *slot_sf, double *slot_cw) {
+    if (a.T <= 0 || nslots <= 0) return MSM_OK;
+    hipLaunchKernelGGL(k_move_prepare, dim3((a.T + 255) / 256), dim3(256), 0, ctx->stream, a, slot_tri, slot_w, slot_sf, slot_cw);
+    MSM_HIP(hipGetLastError());
+    return MSM_OK;
+}
+
+static_assert(sizeof(CliqueArgs) + sizeof(MoveArgs) + sizeof(MoveLabels) <= 4096, "the fusion move's arguments must fit the 4 KB kernel-argument segment");
+
+int launch_move(msm_ctx *ctx, const CliqueArgs &a, const MoveArgs &m, const MoveLabels *labels, hipEvent_t ev_start, hipEvent_t ev_stop) {
+    if (a.T <= 0 || m.nblk <= 0) return MSM_OK;
+    const bool mv = a.kind == MSM_COST_HO_MULTIVARIATE;
+    const int mode = !mv ? 0 : ((a.sfeat_vm && a.D >= 12 && a.D <= kMvLanes * kMvKeep && (a.simmeasure == 1 || a.simmeasure == 2)) ? 2 : 1);
+    const dim3 grid((unsigned)(8 * ((m.nblk + 7) / 8))), block(256);
+    const size_t lds = sizeof(double) * (64 * 9 + 8 * (size_t)m.cap + (mode == 2 ? 3 * 256 : 0)) + sizeof(int) * (128 + (mode == 2 ? 256 : 0));
+    const size_t lds_tail = sizeof(double) * 4 * (size_t)std::max(a.bin_cap, 1);
+    if (lds > 64 * 1024 || lds_tail > 64 * 1024) return fail(MSM_ERR_CAPACITY, "fusion move: %d bin slots per workgroup do not fit LDS", m.cap);
+    static MoveLabels none;  // only read when the labeling is packed
+    const MoveLabels &lab = labels ? *labels : none;
+    if (ev_start) MSM_HIP(hipEventRecord(ev_start, ctx->stream));
+#define MSM_MOVE_LAUNCH(PACKED)                                                                                         \
+    do {                                                                                                                \
+        if (mode == 0) hipLaunchKernelGGL((k_ho_move<PACKED, 0>), grid, block, lds, ctx->stream, a, m, lab);              \
+        else if (mode == 1) hipLaunchKernelGGL((k_ho_move<PACKED, 1>), grid, block, lds, ctx->stream, a, m, lab);         \
+        else hipLaunchKernelGGL((k_ho_move<PACKED, 2>), grid, block, lds, ctx->stream, a, m, lab);                        \
+        MSM_HIP(hipGetLastError());                                                                                     \
+        hipLaunchKernelGGL((k_ho_move_tail<PACKED>), dim3(256), block, lds_tail, ctx->stream, a, m, lab);                 \
+    } while (0)
+    if (labels) MSM_MOVE_LAUNCH(true);
+    else MSM_MOVE_LAUNCH(false);
+#undef MSM_MOVE_LAUNCH
+    MSM_HIP(hipGetLastError());
+    if (ev_stop) MSM_HIP(hipEventRecord(ev_stop, ctx->stream));
+    return MSM_OK;
+}
+
+}  // namespace msm
