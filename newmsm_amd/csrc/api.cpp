@@ -40,7 +40,7 @@ void *ctx_mapped(msm_ctx *ctx, const void *p, size_t bytes) {
 int ctx_flag(msm_ctx *ctx) {
     if (ctx->h_flag) return MSM_OK;
     MSM_HIP(hipHostMalloc((void **)&ctx->h_flag, 64, hipHostMallocMapped));
-    *ctx->h_flag = 0;
+    ctx->h_flag[0] = ctx->h_flag[1] = 0;
     if (hipHostGetDevicePointer((void **)&ctx->d_flag_map, ctx->h_flag, 0) != hipSuccess) {
         (void)hipHostFree(ctx->h_flag);
         ctx->h_flag = nullptr;

@@ -199,7 +199,7 @@ __device__ double triplet_cost(const CliqueArgs &a, int t, int la, int lb, int l
         const V3 org[3] = {soa(a.orig, a.Norig, id[0]), soa(a.orig, a.Norig, id[1]), soa(a.orig, a.Norig, id[2])};
         w = triangular_strain(org, r, a.mu, a.kappa, a.k_exp);
     }
-    return likelihood + a.lambda * pow(w, a.rexp);
+    return likelihood + a.lambda * pow_exp(w, a.rexp);
 }
 
 // computePairwiseCost, M/DiscreteCostFunction.cpp:190-226, without mutating the control grid

@@ -137,31 +137,34 @@ int ensure_move(msm_cost *c, const CliqueArgs &a) {
     if (c->move_valid) return MSM_OK;
     msm_ctx *ctx = c->ctx;
     const int T = a.T;
-    std::vector<int32_t> blk{0};
-    int slots = 0, nt = 0, cap = kMoveSlots;
+    std::vector<int4> blk;
+    int slots = 0, nt = 0, cap = kMoveSlots, first = 0;
+    auto close = [&](int t_end) {
+        if (nt > 0) blk.push_back(make_int4(first, nt, c->pptr[first], c->pptr[t_end] - c->pptr[first]));
+        first = t_end;
+        slots = nt = 0;
+    };
     for (int t = 0; t < T; ++t) {
         const int n = c->pptr[t + 1] - c->pptr[t];
-        if (nt > 0 && (slots + n > kMoveSlots || nt == kMoveTriangles)) {
-            blk.push_back(t);
-            slots = nt = 0;
-        }
+        if (nt > 0 && (slots + n > kMoveSlots || nt == kMoveTriangles)) close(t);
         slots += n;
         ++nt;
         cap = std::max(cap, slots);
     }
-    blk.push_back(T);
+    close(T);
     const size_t ns = std::max<size_t>(c->pidx.size(), 1);
-    MSM_HIP(c->d_blk_t.upload(blk.data(), blk.size(), ctx->stream));
+    MSM_HIP(c->d_blk.upload(blk.data(), blk.size(), ctx->stream));
+    MSM_HIP(c->d_tri_frame.ensure(5 * (size_t)T));
     MSM_HIP(c->d_slot_tri.ensure(ns));
     MSM_HIP(c->d_slot_w.ensure(3 * ns));
     MSM_HIP(c->d_slot_sf.ensure(ns));
     if (a.cfw) MSM_HIP(c->d_slot_cw.ensure(ns));
     MSM_HIP(c->d_defer_list.ensure((size_t)8 * T));
     if (!c->d_defer_cnt.p) MSM_HIP(c->d_defer_cnt.zero(2, ctx->stream));
-    int st = launch_move_prepare(ctx, a, (int)c->pidx.size(), c->d_slot_tri.p, c->d_slot_w.p, c->d_slot_sf.p, a.cfw ? c->d_slot_cw.p : nullptr);
+    int st = launch_move_prepare(ctx, a, (int)c->pidx.size(), c->d_slot_tri.p, c->d_slot_w.p, c->d_slot_sf.p, a.cfw ? c->d_slot_cw.p : nullptr, c->d_tri_frame.p);
     if (st) return st;
     MSM_HIP(hipStreamSynchronize(ctx->stream));  // blk is a local
-    c->move_nblk = (int)blk.size() - 1;
+    c->move_nblk = (int)blk.size();
     c->move_cap = cap;
     c->move_valid = true;
     return MSM_OK;
@@ -255,7 +258,10 @@ int msm_cost_triplet_octets(msm_cost *c, const int32_t *labeling, int32_t label,
         if (st) return st;
         st = ctx_flag(ctx);
         if (st) return st;
-        const bool packed = a.N <= 4 * kMoveLabelWords && a.L <= 256;
+        // diagnostics: MSMHIP_MOVE_LABELS=device sends the labeling with a copy command, MSMHIP_MOVE_OUT=device brings the costs back with one
+        static const bool labels_by_copy = [] { const char *e = std::getenv("MSMHIP_MOVE_LABELS"); return e && std::strcmp(e, "device") == 0; }();
+        static const bool out_by_copy = [] { const char *e = std::getenv("MSMHIP_MOVE_OUT"); return e && std::strcmp(e, "device") == 0; }();
+        const bool packed = a.N <= 4 * kMoveLabelWords && a.L <= 256 && !labels_by_copy;
         MoveLabels lab;
         if (packed) std::memset(lab.w, 0, sizeof(uint32_t) * (size_t)((a.N + 3) / 4));
         for (int i = 0; i < a.N; ++i) {
@@ -263,7 +269,7 @@ int msm_cost_triplet_octets(msm_cost *c, const int32_t *labeling, int32_t label,
             if (packed) lab.w[i >> 2] |= (uint32_t)labeling[i] << ((i & 3) * 8);
         }
         void *pin = nullptr;
-        double *out_dev = (double *)ctx_mapped(ctx, E, out_bytes);
+        double *out_dev = out_by_copy ? nullptr : (double *)ctx_mapped(ctx, E, out_bytes);
         const bool direct = out_dev != nullptr;
         if (!direct || !packed) {
             st = ctx_io_pinned(ctx, in_pad + out_bytes, &pin);
@@ -271,7 +277,7 @@ int msm_cost_triplet_octets(msm_cost *c, const int32_t *labeling, int32_t label,
         }
         bool staged_copy = false;  // the costs come back with a copy command (the pinned block could not be mapped)
         if (!direct) {
-            if (ctx->io_dev) {
+            if (ctx->io_dev && !out_by_copy) {
                 out_dev = (double *)((char *)ctx->io_dev + in_pad);
             } else {
                 MSM_HIP(c->d_clique_out.ensure((size_t)8 * a.T));
@@ -289,7 +295,8 @@ int msm_cost_triplet_octets(msm_cost *c, const int32_t *labeling, int32_t label,
         m.slot_w = c->d_slot_w.p;
         m.slot_sf = c->d_slot_sf.p;
         m.slot_cw = a.cfw ? c->d_slot_cw.p : nullptr;
-        m.blk_t = c->d_blk_t.p;
+        m.tri_frame = c->d_tri_frame.p;
+        m.blk = c->d_blk.p;
         m.nblk = c->move_nblk;
         m.cap = c->move_cap;
         m.labeling = packed ? nullptr : c->d_labeling.p;
@@ -300,7 +307,7 @@ int msm_cost_triplet_octets(msm_cost *c, const int32_t *labeling, int32_t label,
         m.parity = c->move_parity;
         c->move_parity ^= 1;
         m.out = out_dev;
-        m.host_status = ctx->d_flag_map;
+        m.host_flags = ctx->d_flag_map;
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (c->timing) {
             e0 = c->ev0[c->ev_next];
@@ -313,9 +320,18 @@ int msm_cost_triplet_octets(msm_cost *c, const int32_t *labeling, int32_t label,
         if (staged_copy) MSM_HIP(hipMemcpyAsync((char *)pin + in_pad, out_dev, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
         c->counters[2] += (int64_t)8 * a.T;
         MSM_HIP(hipStreamSynchronize(ctx->stream));
+        volatile int *flags = ctx->h_flag;
+        if (flags[1] != 0) {  // rare: some evaluations need the complete search (sibling leaves, nearest vertex)
+            flags[1] = 0;
+            st = launch_move_tail(ctx, a, m, packed ? &lab : nullptr);
+            if (st) return st;
+            if (staged_copy) MSM_HIP(hipMemcpyAsync((char *)pin + in_pad, out_dev, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+            MSM_HIP(hipStreamSynchronize(ctx->stream));
+            c->move_tails++;
+        }
         st = MSM_OK;
-        if (*(volatile int *)ctx->h_flag != 0) {
-            *(volatile int *)ctx->h_flag = 0;
+        if (flags[0] != 0) {
+            flags[0] = 0;
             st = check_status(ctx, "computeTripletCost");
         }
         if (!direct) std::memcpy(E, (char *)pin + in_pad, out_bytes);

@@ -40,8 +40,10 @@ struct msm_cost {
     DevBuf<double> d_ho_vals;
     DevBuf<unsigned> d_ho_pending, d_ho_count;
     // fused fusion move of the HO classes (move_kernels.hip): per bin slot data prepared once per get_source_data()
-    DevBuf<int32_t> d_slot_tri, d_blk_t;
-    DevBuf<double> d_slot_w, d_slot_sf, d_slot_cw;
+    DevBuf<int32_t> d_slot_tri;
+    DevBuf<int4> d_blk;
+    DevBuf<double> d_slot_w, d_slot_sf, d_slot_cw, d_tri_frame;
+    int64_t move_tails = 0;  // moves that needed the tail kernel
     DevBuf<unsigned> d_defer_list, d_defer_cnt;
     int move_nblk = 0, move_cap = 0, move_parity = 0;
     bool move_valid = false;

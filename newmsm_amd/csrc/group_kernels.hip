@@ -217,7 +217,7 @@ __global__ __launch_bounds__(128) void k_group_triplet(GroupArgs a, const int *_
         cost = MSM_FOLDING;
     } else {
         const double e = triangular_strain(org, r, a.mu, a.kappa, a.k_exp);
-        cost = (a.fixnan && e != e) ? 1e7 : a.subcorr * a.lambda * pow(e, a.rexp);
+        cost = (a.fixnan && e != e) ? 1e7 : a.subcorr * a.lambda * pow_exp(e, a.rexp);
     }
     out[i] = cost;
 }

@@ -129,7 +129,8 @@ struct MoveArgs {
     const double *slot_w;    // 3 per slot: barycentric coordinates of the projected source vertex in the CURRENT control triangle
     const double *slot_sf;   // univariate: moving feature (row 1) of the slot's vertex
     const double *slot_cw;   // univariate: its cost-function weight (row 1), or nullptr
-    const int *blk_t;        // nblk + 1: first control triangle of every workgroup
+    const double *tri_frame; // 5 per control triangle: the original triangle's half of the strain (strain_device.hpp: StrainFrame)
+    const int4 *blk;         // per workgroup: first control triangle, their number, first bin slot, number of slots
     int nblk;
     int cap;                 // bin slots one workgroup holds at most
     const int *labeling;     // device copy of the labeling, or nullptr when it is packed into MoveLabels
@@ -139,10 +140,12 @@ struct MoveArgs {
     unsigned *defer_cnt;     // two counters; a move uses [parity] and clears [parity ^ 1]
     int parity;
     double *out;             // 8 x T costs (device memory or mapped pinned host memory)
-    int *host_status;        // mapped pinned host word: non-zero when a kernel raised a status
+    int *host_flags;         // mapped pinned host words: [0] a raised status, [1] set when evaluations were left to the tail kernel
 };
-int launch_move_prepare(msm_ctx *ctx, const CliqueArgs &a, int nslots, int *slot_tri, double *slot_w, double *slot_sf, double *slot_cw);
+// launch_move runs the main kernel; the host launches the tail (launch_move_tail) only when host_flags[1] was set
+int launch_move_prepare(msm_ctx *ctx, const CliqueArgs &a, int nslots, int *slot_tri, double *slot_w, double *slot_sf, double *slot_cw, double *tri_frame);
 int launch_move(msm_ctx *ctx, const CliqueArgs &a, const MoveArgs &m, const MoveLabels *labels, hipEvent_t ev_start, hipEvent_t ev_stop);
+int launch_move_tail(msm_ctx *ctx, const CliqueArgs &a, const MoveArgs &m, const MoveLabels *labels);
 
 int launch_triplet_batch(msm_ctx *ctx, const CliqueArgs &a, const int *qt, const int *qa, const int *qb, const int *qc, int n, double *out);
 int launch_triplet_octets(msm_ctx *ctx, const CliqueArgs &a, const int *labeling, int label, double *out);

@@ -36,7 +36,7 @@ __device__ __forceinline__ int label_of(const MoveArgs &m, const MoveLabels &lab
 
 __device__ __forceinline__ void raise_both(const CliqueArgs &a, const MoveArgs &m, int code) {
     atomicMin(a.status, code);
-    __hip_atomic_store(m.host_status, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(m.host_flags, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // s / P for 0 <= s < 2^22, P > 0, with a float reciprocal and an exact correction step
@@ -107,22 +107,30 @@ __device__ __forceinline__ double finish_evaluation(const CliqueArgs &a, const M
     const int beg = a.bin_ptr[t], n = a.bin_ptr[t + 1] - beg;
     const double wmean = (a.absw[id[0]] + a.absw[id[1]] + a.absw[id[2]]) / 3.0;
     const double *sf = m.slot_sf + beg, *cw = m.slot_cw ? m.slot_cw + beg : nullptr;
+    const double *fp = m.tri_frame + 5 * (size_t)t;
+    StrainFrame fr;
+    fr.i00 = fp[0], fr.i01 = fp[1], fr.i10 = fp[2], fr.i11 = fp[3];
+    fr.dswap = fp[4] != 0.0;
     const double likelihood = ho_likelihood_core(
         a.kind == MSM_COST_HO_UNIVARIATE, a.simmeasure, a.percentile, n, wmean, [&](int i) { return sf[i]; }, [&](int i) { return cw ? cw[i] : 1.0; },
         [&](int i) { return vals[i]; });
-    const V3 org[3] = {soa(a.orig, a.Norig, id[0]), soa(a.orig, a.Norig, id[1]), soa(a.orig, a.Norig, id[2])};
-    const double w = triangular_strain(org, r, a.mu, a.kappa, a.k_exp);
-    return likelihood + a.lambda * pow(w, a.rexp);
+    const double w = triangular_strain_from(fr, r, a.mu, a.kappa, a.k_exp);
+    return likelihood + a.lambda * pow_exp(w, a.rexp);
 }
 
 }  // namespace
 
-// per control triangle: the label-independent half of HO*::get_target_data for each of its bin points
+// per control triangle: the label-independent half of HO*::get_target_data for each of its bin points, and the original
+// triangle's half of the strain energy
 __global__ __launch_bounds__(256) void k_move_prepare(CliqueArgs a, int *__restrict__ slot_tri, double *__restrict__ slot_w, double *__restrict__ slot_sf,
-                                                       double *__restrict__ slot_cw) {
+                                                       double *__restrict__ slot_cw, double *__restrict__ tri_frame) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= a.T) return;
     const int id[3] = {a.triplets[3 * t], a.triplets[3 * t + 1], a.triplets[3 * t + 2]};
+    const V3 org[3] = {soa(a.orig, a.Norig, id[0]), soa(a.orig, a.Norig, id[1]), soa(a.orig, a.Norig, id[2])};
+    const StrainFrame fr = strain_frame(org);
+    double *fp = tri_frame + 5 * (size_t)t;
+    fp[0] = fr.i00, fp[1] = fr.i01, fp[2] = fr.i10, fp[3] = fr.i11, fp[4] = fr.dswap ? 1.0 : 0.0;
     const V3 cp0 = soa(a.cp, a.N, id[0]), cp1 = soa(a.cp, a.N, id[1]), cp2 = soa(a.cp, a.N, id[2]);
     V3 s3;
     double pd;
@@ -142,68 +150,81 @@ __global__ __launch_bounds__(256) void k_move_prepare(CliqueArgs a, int *__restr
 // kMode 0: HO univariate (value = interpolated target feature, from the table record)
 //       1: HO multivariate, a lane per sample (any D, any measure): ho_value_on
 //       2: HO multivariate, 12 <= D <= 64, SSD / correlation: eight lanes per sample split the dimensions
+#ifndef MSM_MOVE_VARIANT
+#define MSM_MOVE_VARIANT 0
+#endif
+#if MSM_MOVE_VARIANT == 1
+#define MSM_MOVE_BOUNDS __launch_bounds__(256, 6)
+#elif MSM_MOVE_VARIANT == 4
+#define MSM_MOVE_BOUNDS __launch_bounds__(256, 5)
+#else
+#define MSM_MOVE_BOUNDS __launch_bounds__(256)
+#endif
 template <bool kPacked, int kMode>
-__global__ __launch_bounds__(256) void k_ho_move(CliqueArgs a, MoveArgs m, MoveLabels lab) {
+__global__ MSM_MOVE_BOUNDS void k_ho_move(CliqueArgs a, MoveArgs m, MoveLabels lab) {
     extern __shared__ __align__(16) double lds[];
     double *s_geo = lds;                            // 64 evaluations x 9: the proposed triangles
     double *s_vals = s_geo + 64 * 9;                // 8 combinations x cap bin slots
     double *s_w = s_vals + 8 * (size_t)m.cap;       // kMode 2: 3 weights per sample of a round
     int *s_flag = reinterpret_cast<int *>(s_w + (kMode == 2 ? 3 * 256 : 0));  // [0,64) folded, [64,128) deferred
-    int *s_tt = s_flag + 128;                       // kMode 2: triangle per sample of a round
+    int *s_pend = s_flag + 128;                     // samples the direction table left open (at most all of a round... of the block: 8 * cap)
+    int *s_tt = s_pend + 8 * m.cap;                 // kMode 2: triangle and its vertex ids per sample of a round (4 x 256)
+    __shared__ int s_npend;
 
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
     if (blockIdx.x == 0 && tid == 0) m.defer_cnt[m.parity ^ 1] = 0u;  // the previous move's list has been consumed
     const int per = (m.nblk + 7) >> 3;  // the workgroups of an XCD (blockIdx % 8) take a contiguous run of control triangles
     const int blk = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
     if (blk >= m.nblk) return;
-    const int t0 = m.blk_t[blk], ntrip = m.blk_t[blk + 1] - t0;
-    const int s0 = a.bin_ptr[t0], nslots = a.bin_ptr[t0 + ntrip] - s0;
+    const int4 bk = m.blk[blk];
+    const int t0 = bk.x, ntrip = bk.y, s0 = bk.z, nslots = bk.w;
+    const int total = 8 * nslots;
+    const float inv = 1.0f / (float)max(nslots, 1);
 
-    // ---- the eight proposed triangles of each control triangle
+    // ---- the eight proposed triangles of each control triangle (lanes 0 .. 8 * ntrip); the other lanes meanwhile fetch their
+    // first sample's slot data, which does not depend on the labels
     const bool ev = tid < 8 * ntrip;
-    int id[3] = {0, 0, 0};
-    V3 r[3];
-    r[0] = r[1] = r[2] = mk(0.0, 0.0, 0.0);
-    const int t = t0 + (tid >> 3), k = tid & 7;
-    bool folded = false;
+    if (tid == 0) s_npend = 0;
     if (ev) {
-        folded = proposed_triangle<kPacked>(a, m, lab, t, k, id, r);
+        int id[3];
+        V3 r[3];
+        const bool folded = proposed_triangle<kPacked>(a, m, lab, t0 + (tid >> 3), tid & 7, id, r);
         double *g = s_geo + 9 * tid;
         g[0] = r[0].x, g[1] = r[0].y, g[2] = r[0].z, g[3] = r[1].x, g[4] = r[1].y, g[5] = r[1].z, g[6] = r[2].x, g[7] = r[2].y, g[8] = r[2].z;
         s_flag[tid] = folded ? 1 : 0;
         s_flag[64 + tid] = 0;
     }
-    __syncthreads();
 
     // ---- samples: s = combination * nslots + slot (neighbouring lanes = neighbouring bin points of one combination)
-    const int total = 8 * nslots;
-    const float inv = 1.0f / (float)max(nslots, 1);
     for (int base = 0; base < total; base += 256) {
         const int s = base + tid;
-        int tt = -2;  // -2: nothing to do (past the end, or a folded proposal: it never looks at the data); -1: left to the tail
+        int tt = -2;  // -2: nothing to do (past the end, or a folded proposal: it never looks at the data); -1: left open
         int kk = 0, j = 0, el = 0;
+        double wa = 0.0, wb = 0.0, wc = 0.0;
         if (s < total) {
             kk = fast_div(s, nslots, inv), j = s - kk * nslots;
-            el = (m.slot_tri[s0 + j] - t0) * 8 + kk;
-            if (!s_flag[el]) {
-                const size_t slot = (size_t)(s0 + j);
-                const V3 p = moved_point(s_geo + 9 * el, m.slot_w[3 * slot], m.slot_w[3 * slot + 1], m.slot_w[3 * slot + 2]);
-                double2 d0, d1, d2, d3, d4, d5;
-                tt = ray_find_rec(a.tree, p, d0, d1, d2, d3, d4, d5);
-                if (tt >= 0) {
-                    double wa, wb, wc;
-                    area_weights(mk(d0.x, d0.y, d1.x), mk(d1.y, d2.x, d2.y), mk(d3.x, d3.y, d4.x), p, wa, wb, wc);
-                    if (kMode == 0) {
-                        s_vals[kk * m.cap + j] = wa * d4.y + wb * d5.x + wc * d5.y;
-                    } else if (kMode == 1) {
-                        s_vals[kk * m.cap + j] = ho_value_on(a, a.bin_idx[slot], p, tt);
-                    } else {
-                        s_w[3 * tid] = wa, s_w[3 * tid + 1] = wb, s_w[3 * tid + 2] = wc;
-                    }
+            const size_t slot = (size_t)(s0 + j);
+            el = (m.slot_tri[slot] - t0) * 8 + kk;
+            wa = m.slot_w[3 * slot], wb = m.slot_w[3 * slot + 1], wc = m.slot_w[3 * slot + 2];
+        }
+        if (base == 0) __syncthreads();  // the proposed triangles are in LDS
+        if (s < total && !s_flag[el] && MSM_MOVE_VARIANT != 3) {
+            const V3 p = moved_point(s_geo + 9 * el, wa, wb, wc);
+            double2 d0, d1, d2, d3, d4, d5;
+            tt = ray_find_rec(a.tree, p, d0, d1, d2, d3, d4, d5);
+            if (tt >= 0) {
+                area_weights(mk(d0.x, d0.y, d1.x), mk(d1.y, d2.x, d2.y), mk(d3.x, d3.y, d4.x), p, wa, wb, wc);
+                if (kMode == 0) {
+                    s_vals[kk * m.cap + j] = wa * d4.y + wb * d5.x + wc * d5.y;
+                } else if (kMode == 1) {
+                    s_vals[kk * m.cap + j] = ho_value_on(a, a.bin_idx[s0 + j], p, tt);
                 } else {
-                    s_vals[kk * m.cap + j] = pending_value();
-                    s_flag[64 + el] = 1;
+                    const TriRec &rr = a.tree.rec[tt];
+                    s_w[3 * tid] = wa, s_w[3 * tid + 1] = wb, s_w[3 * tid + 2] = wc;
+                    s_tt[256 + 3 * tid] = rr.id[0], s_tt[256 + 3 * tid + 1] = rr.id[1], s_tt[256 + 3 * tid + 2] = rr.id[2];
                 }
+            } else {
+                s_pend[atomicAdd(&s_npend, 1)] = s;
             }
         }
         if (kMode == 2) {
@@ -211,19 +232,17 @@ __global__ __launch_bounds__(256) void k_ho_move(CliqueArgs a, MoveArgs m, MoveL
             s_tt[tid] = tt;
             __syncthreads();
             const int grp = tid >> 3, jj = tid & 7, D = a.D;
-#pragma unroll 1
+#pragma unroll 2
             for (int pass = 0; pass < 8; ++pass) {
                 const int q = pass * 32 + grp, sq = base + q;
-                const int qt = s_tt[q];
-                const bool go = qt >= 0;
+                const bool go = s_tt[q] >= 0;
                 if (!__any(go)) continue;
                 const double *f0 = a.tfeat, *f1 = a.tfeat, *f2 = a.tfeat, *sa = a.sfeat_vm, *cw = nullptr;
                 int qk = 0, qj = 0;
                 if (go) {
                     qk = fast_div(sq, nslots, inv), qj = sq - qk * nslots;
                     const int sv = a.bin_idx[s0 + qj];
-                    const TriRec &rr = a.tree.rec[qt];
-                    f0 = a.tfeat + (size_t)rr.id[0] * D, f1 = a.tfeat + (size_t)rr.id[1] * D, f2 = a.tfeat + (size_t)rr.id[2] * D;
+                    f0 = a.tfeat + (size_t)s_tt[256 + 3 * q] * D, f1 = a.tfeat + (size_t)s_tt[256 + 3 * q + 1] * D, f2 = a.tfeat + (size_t)s_tt[256 + 3 * q + 2] * D;
                     sa = a.sfeat_vm + (size_t)sv * D;
                     cw = a.cfw_vm ? a.cfw_vm + (size_t)sv * a.cfw_rows : nullptr;
                 }
@@ -233,28 +252,67 @@ __global__ __launch_bounds__(256) void k_ho_move(CliqueArgs a, MoveArgs m, MoveL
             __syncthreads();
         }
     }
-    if (kMode != 2) __syncthreads();
+    if (total == 0) __syncthreads();  // the barrier of the first round, for a run of empty bins
+    __syncthreads();
+
+    // ---- the samples the direction table left open (0.2 %): the octree leaf's candidates, eight lanes per sample
+    // (search_device.hpp: group8_find); what even that cannot decide (no candidate in the leaf: sibling leaves, nearest vertex)
+    // is left to the tail kernel, which the host launches only when told to
+    const int npend = s_npend;
+    for (int q0 = 0; q0 < npend; q0 += 32) {  // workgroup-uniform
+        const int q = q0 + (tid >> 3);
+        const bool valid = q < npend;
+        int kk = 0, j = 0, el = 0;
+        V3 p = mk(0.0, 0.0, 0.0);
+        if (valid) {
+            const int s = s_pend[q];
+            kk = fast_div(s, nslots, inv), j = s - kk * nslots;
+            const size_t slot = (size_t)(s0 + j);
+            el = (m.slot_tri[slot] - t0) * 8 + kk;
+            p = moved_point(s_geo + 9 * el, m.slot_w[3 * slot], m.slot_w[3 * slot + 1], m.slot_w[3 * slot + 2]);
+        }
+        if (!__any(valid)) continue;
+        const int found = group8_find(a.tree, valid, p, lane);
+        if (valid && (lane & 7) == 0) {
+            if (found >= 0) {
+                s_vals[kk * m.cap + j] = ho_value_on(a, a.bin_idx[s0 + j], p, found);
+            } else {
+                s_vals[kk * m.cap + j] = pending_value();
+                s_flag[64 + el] = 1;
+            }
+        }
+    }
+    if (npend > 0) __syncthreads();
 
     // ---- one lane per evaluation: similarity in the reference's serial order + strain
     if (!ev) return;
-    const int e = 8 * t + k;
-    if (folded) {
+    const int t = t0 + (tid >> 3), k = tid & 7, e = 8 * t + k;
+    if (s_flag[tid]) {
         m.out[e] = MSM_FOLDING * a.lambda;
         return;
     }
     const int beg = a.bin_ptr[t], n = a.bin_ptr[t + 1] - beg;
     const double *vals = s_vals + k * m.cap + (beg - s0);
-    if (s_flag[64 + tid]) {  // some point is unsettled: hand the evaluation and what is known of it to the tail kernel
+    if (s_flag[64 + tid]) {  // some point is still open: hand the evaluation and what is known of it to the tail kernel
         const unsigned at = atomicAdd(&m.defer_cnt[m.parity], 1u);
         m.defer_list[at] = (unsigned)e;
         double *gv = m.vals + (size_t)8 * beg + (size_t)k * n;
         for (int i = 0; i < n; ++i) gv[i] = vals[i];
+        __hip_atomic_store(m.host_flags + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         return;
     }
+    const int id[3] = {a.triplets[3 * t], a.triplets[3 * t + 1], a.triplets[3 * t + 2]};
+    const double *g = s_geo + 9 * tid;
+    const V3 r[3] = {mk(g[0], g[1], g[2]), mk(g[3], g[4], g[5]), mk(g[6], g[7], g[8])};
+#if MSM_MOVE_VARIANT == 2
+    m.out[e] = vals[0] + r[0].x + id[0];
+#else
     m.out[e] = finish_evaluation(a, m, t, id, r, vals);
+#endif
 }
 
-// The listed evaluations: a wavefront each, eight lanes per unsettled point (complete search), then the same reduction.
+// The evaluations the main kernel could not finish: a wavefront each, eight lanes per open point (complete search), then the
+// same reduction.  Launched by the host only when the main kernel said so (host_flags[1]).
 template <bool kPacked>
 __global__ __launch_bounds__(256) void k_ho_move_tail(CliqueArgs a, MoveArgs m, MoveLabels lab) {
     extern __shared__ __align__(16) double lds[];  // 4 wavefronts x bin_cap values
@@ -286,16 +344,13 @@ __global__ __launch_bounds__(256) void k_ho_move_tail(CliqueArgs a, MoveArgs m, 
                 const size_t slot = (size_t)(beg + i);
                 p = moved_point(g, m.slot_w[3 * slot], m.slot_w[3 * slot + 1], m.slot_w[3 * slot + 2]);
             }
-            if (__any(pend)) {
-                const int found = group8_find(a.tree, pend, p, lane);
-                if (pend && sub == 0) {
-                    const int tt = found == kGroupUndecided ? find_closest_triangle(a.tree, p) : found;
-                    if (tt < 0) {
-                        raise_both(a, m, tt);
-                        v = __longlong_as_double(0x7ff8000000000000ll);
-                    } else {
-                        v = ho_value_on(a, a.bin_idx[beg + i], p, tt);
-                    }
+            if (pend && sub == 0) {
+                const int tt = find_closest_triangle(a.tree, p);
+                if (tt < 0) {
+                    raise_both(a, m, tt);
+                    v = __longlong_as_double(0x7ff8000000000000ll);
+                } else {
+                    v = ho_value_on(a, a.bin_idx[beg + i], p, tt);
                 }
             }
             if (in && sub == 0) vals[i] = v;
@@ -306,39 +361,50 @@ __global__ __launch_bounds__(256) void k_ho_move_tail(CliqueArgs a, MoveArgs m, 
     }
 }
 
-int launch_move_prepare(msm_ctx *ctx, const CliqueArgs &a, int nslots, int *slot_tri, double *slot_w, double *slot_sf, double *slot_cw) {
-    if (a.T <= 0 || nslots <= 0) return MSM_OK;
-    hipLaunchKernelGGL(k_move_prepare, dim3((a.T + 255) / 256), dim3(256), 0, ctx->stream, a, slot_tri, slot_w, slot_sf, slot_cw);
+int launch_move_prepare(msm_ctx *ctx, const CliqueArgs &a, int nslots, int *slot_tri, double *slot_w, double *slot_sf, double *slot_cw, double *tri_frame) {
+    if (a.T <= 0) return MSM_OK;
+    hipLaunchKernelGGL(k_move_prepare, dim3((a.T + 255) / 256), dim3(256), 0, ctx->stream, a, slot_tri, slot_w, slot_sf, slot_cw, tri_frame);
     MSM_HIP(hipGetLastError());
     return MSM_OK;
 }
 
 static_assert(sizeof(CliqueArgs) + sizeof(MoveArgs) + sizeof(MoveLabels) <= 4096, "the fusion move's arguments must fit the 4 KB kernel-argument segment");
 
+static int move_mode(const CliqueArgs &a) {
+    if (a.kind != MSM_COST_HO_MULTIVARIATE) return 0;
+    return (a.sfeat_vm && a.D >= 12 && a.D <= kMvLanes * kMvKeep && (a.simmeasure == 1 || a.simmeasure == 2)) ? 2 : 1;
+}
+static MoveLabels g_no_labels;  // handed over (and never read) when the labeling comes as a device array
+
 int launch_move(msm_ctx *ctx, const CliqueArgs &a, const MoveArgs &m, const MoveLabels *labels, hipEvent_t ev_start, hipEvent_t ev_stop) {
     if (a.T <= 0 || m.nblk <= 0) return MSM_OK;
-    const bool mv = a.kind == MSM_COST_HO_MULTIVARIATE;
-    const int mode = !mv ? 0 : ((a.sfeat_vm && a.D >= 12 && a.D <= kMvLanes * kMvKeep && (a.simmeasure == 1 || a.simmeasure == 2)) ? 2 : 1);
+    const int mode = move_mode(a);
     const dim3 grid((unsigned)(8 * ((m.nblk + 7) / 8))), block(256);
-    const size_t lds = sizeof(double) * (64 * 9 + 8 * (size_t)m.cap + (mode == 2 ? 3 * 256 : 0)) + sizeof(int) * (128 + (mode == 2 ? 256 : 0));
-    const size_t lds_tail = sizeof(double) * 4 * (size_t)std::max(a.bin_cap, 1);
-    if (lds > 64 * 1024 || lds_tail > 64 * 1024) return fail(MSM_ERR_CAPACITY, "fusion move: %d bin slots per workgroup do not fit LDS", m.cap);
-    static MoveLabels none;  // only read when the labeling is packed
-    const MoveLabels &lab = labels ? *labels : none;
+    const size_t lds = sizeof(double) * (64 * 9 + 8 * (size_t)m.cap + (mode == 2 ? 3 * 256 : 0)) + sizeof(int) * (128 + 8 * (size_t)m.cap + (mode == 2 ? 4 * 256 : 0));
+    if (lds > 64 * 1024) return fail(MSM_ERR_CAPACITY, "fusion move: %d bin slots per workgroup do not fit LDS", m.cap);
+    const MoveLabels &lab = labels ? *labels : g_no_labels;
     if (ev_start) MSM_HIP(hipEventRecord(ev_start, ctx->stream));
-#define MSM_MOVE_LAUNCH(PACKED)                                                                                         \
-    do {                                                                                                                \
-        if (mode == 0) hipLaunchKernelGGL((k_ho_move<PACKED, 0>), grid, block, lds, ctx->stream, a, m, lab);              \
-        else if (mode == 1) hipLaunchKernelGGL((k_ho_move<PACKED, 1>), grid, block, lds, ctx->stream, a, m, lab);         \
-        else hipLaunchKernelGGL((k_ho_move<PACKED, 2>), grid, block, lds, ctx->stream, a, m, lab);                        \
-        MSM_HIP(hipGetLastError());                                                                                     \
-        hipLaunchKernelGGL((k_ho_move_tail<PACKED>), dim3(256), block, lds_tail, ctx->stream, a, m, lab);                 \
+#define MSM_MOVE_LAUNCH(PACKED)                                                                                     \
+    do {                                                                                                            \
+        if (mode == 0) hipLaunchKernelGGL((k_ho_move<PACKED, 0>), grid, block, lds, ctx->stream, a, m, lab);          \
+        else if (mode == 1) hipLaunchKernelGGL((k_ho_move<PACKED, 1>), grid, block, lds, ctx->stream, a, m, lab);     \
+        else hipLaunchKernelGGL((k_ho_move<PACKED, 2>), grid, block, lds, ctx->stream, a, m, lab);                    \
     } while (0)
     if (labels) MSM_MOVE_LAUNCH(true);
     else MSM_MOVE_LAUNCH(false);
 #undef MSM_MOVE_LAUNCH
     MSM_HIP(hipGetLastError());
     if (ev_stop) MSM_HIP(hipEventRecord(ev_stop, ctx->stream));
+    return MSM_OK;
+}
+
+int launch_move_tail(msm_ctx *ctx, const CliqueArgs &a, const MoveArgs &m, const MoveLabels *labels) {
+    const size_t lds_tail = sizeof(double) * 4 * (size_t)std::max(a.bin_cap, 1);
+    if (lds_tail > 64 * 1024) return fail(MSM_ERR_CAPACITY, "fusion move: bins of %d points do not fit LDS", a.bin_cap);
+    const MoveLabels &lab = labels ? *labels : g_no_labels;
+    if (labels) hipLaunchKernelGGL((k_ho_move_tail<true>), dim3(64), dim3(256), lds_tail, ctx->stream, a, m, lab);
+    else hipLaunchKernelGGL((k_ho_move_tail<false>), dim3(64), dim3(256), lds_tail, ctx->stream, a, m, lab);
+    MSM_HIP(hipGetLastError());
     return MSM_OK;
 }
 
