@@ -1,6 +1,7 @@
 // cost_cliques.cpp -- C ABI of the pairwise / triplet clique costs and of evaluateTotalCostSum
 // (include/msmhip.h).  Kernels: clique_kernels.hip.
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
@@ -122,7 +123,7 @@ int clique_args(msm_cost *c, bool need_triplets, bool need_pairs, CliqueArgs &a)
 }
 
 // ---- fused fusion move of the HO classes (move_kernels.hip) ----
-constexpr int kMoveSlots = 32, kMoveTriangles = 8;  // bin slots and control triangles per workgroup (256 lanes = 8 combinations x 32 slots)
+constexpr int kMoveSlots = 64, kMoveTriangles = 8;  // bin slots and control triangles per workgroup: two rounds of 256 samples, 64 evaluations
 
 bool fused_move_applies(const msm_cost *c, const CliqueArgs &a) {
     static const bool split = [] {
@@ -155,13 +156,16 @@ int ensure_move(msm_cost *c, const CliqueArgs &a) {
     const size_t ns = std::max<size_t>(c->pidx.size(), 1);
     MSM_HIP(c->d_blk.upload(blk.data(), blk.size(), ctx->stream));
     MSM_HIP(c->d_tri_frame.ensure(5 * (size_t)T));
+    MSM_HIP(c->d_tri_stat.ensure(3 * (size_t)T));
+    MSM_HIP(c->d_slot_wda.ensure(ns));
     MSM_HIP(c->d_slot_tri.ensure(ns));
     MSM_HIP(c->d_slot_w.ensure(3 * ns));
     MSM_HIP(c->d_slot_sf.ensure(ns));
     if (a.cfw) MSM_HIP(c->d_slot_cw.ensure(ns));
     MSM_HIP(c->d_defer_list.ensure((size_t)8 * T));
     if (!c->d_defer_cnt.p) MSM_HIP(c->d_defer_cnt.zero(2, ctx->stream));
-    int st = launch_move_prepare(ctx, a, (int)c->pidx.size(), c->d_slot_tri.p, c->d_slot_w.p, c->d_slot_sf.p, a.cfw ? c->d_slot_cw.p : nullptr, c->d_tri_frame.p);
+    int st = launch_move_prepare(ctx, a, (int)c->pidx.size(), c->d_slot_tri.p, c->d_slot_w.p, c->d_slot_sf.p, a.cfw ? c->d_slot_cw.p : nullptr, c->d_slot_wda.p,
+                                 c->d_tri_frame.p, c->d_tri_stat.p);
     if (st) return st;
     MSM_HIP(hipStreamSynchronize(ctx->stream));  // blk is a local
     c->move_nblk = (int)blk.size();
@@ -295,7 +299,9 @@ int msm_cost_triplet_octets(msm_cost *c, const int32_t *labeling, int32_t label,
         m.slot_w = c->d_slot_w.p;
         m.slot_sf = c->d_slot_sf.p;
         m.slot_cw = a.cfw ? c->d_slot_cw.p : nullptr;
+        m.slot_wda = c->d_slot_wda.p;
         m.tri_frame = c->d_tri_frame.p;
+        m.tri_stat = c->d_tri_stat.p;
         m.blk = c->d_blk.p;
         m.nblk = c->move_nblk;
         m.cap = c->move_cap;
@@ -308,6 +314,13 @@ int msm_cost_triplet_octets(msm_cost *c, const int32_t *labeling, int32_t label,
         c->move_parity ^= 1;
         m.out = out_dev;
         m.host_flags = ctx->d_flag_map;
+        m.trace = nullptr;
+#ifdef MSM_MOVE_TRACE
+        static DevBuf<unsigned long long> trace_buf;
+        const size_t trace_words = 8 * (size_t)(8 * ((c->move_nblk + 7) / 8));
+        MSM_HIP(trace_buf.zero(trace_words, ctx->stream));
+        m.trace = trace_buf.p;
+#endif
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (c->timing) {
             e0 = c->ev0[c->ev_next];
@@ -320,6 +333,16 @@ int msm_cost_triplet_octets(msm_cost *c, const int32_t *labeling, int32_t label,
         if (staged_copy) MSM_HIP(hipMemcpyAsync((char *)pin + in_pad, out_dev, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
         c->counters[2] += (int64_t)8 * a.T;
         MSM_HIP(hipStreamSynchronize(ctx->stream));
+#ifdef MSM_MOVE_TRACE
+        if (const char *path = std::getenv("MSMHIP_MOVE_TRACE")) {
+            std::vector<unsigned long long> h(trace_words);
+            MSM_HIP(hipMemcpy(h.data(), trace_buf.p, sizeof(unsigned long long) * trace_words, hipMemcpyDeviceToHost));
+            if (FILE *f = std::fopen(path, "wb")) {
+                std::fwrite(h.data(), sizeof(unsigned long long), trace_words, f);
+                std::fclose(f);
+            }
+        }
+#endif
         volatile int *flags = ctx->h_flag;
         if (flags[1] != 0) {  // rare: some evaluations need the complete search (sibling leaves, nearest vertex)
             flags[1] = 0;

@@ -42,7 +42,7 @@ struct msm_cost {
     // fused fusion move of the HO classes (move_kernels.hip): per bin slot data prepared once per get_source_data()
     DevBuf<int32_t> d_slot_tri;
     DevBuf<int4> d_blk;
-    DevBuf<double> d_slot_w, d_slot_sf, d_slot_cw, d_tri_frame;
+    DevBuf<double> d_slot_w, d_slot_sf, d_slot_cw, d_slot_wda, d_tri_frame, d_tri_stat;
     int64_t move_tails = 0;  // moves that needed the tail kernel
     DevBuf<unsigned> d_defer_list, d_defer_cnt;
     int move_nblk = 0, move_cap = 0, move_parity = 0;

@@ -129,7 +129,9 @@ struct MoveArgs {
     const double *slot_w;    // 3 per slot: barycentric coordinates of the projected source vertex in the CURRENT control triangle
     const double *slot_sf;   // univariate: moving feature (row 1) of the slot's vertex
     const double *slot_cw;   // univariate: its cost-function weight (row 1), or nullptr
+    const double *slot_wda;  // univariate: weight x (moving feature - weighted mean of its bin), M/similarities.cpp:146
     const double *tri_frame; // 5 per control triangle: the original triangle's half of the strain (strain_device.hpp: StrainFrame)
+    const double *tri_stat;  // 3 per control triangle: sum of weights, weighted mean and variance of the moving patch (:135-150)
     const int4 *blk;         // per workgroup: first control triangle, their number, first bin slot, number of slots
     int nblk;
     int cap;                 // bin slots one workgroup holds at most
@@ -141,9 +143,11 @@ struct MoveArgs {
     int parity;
     double *out;             // 8 x T costs (device memory or mapped pinned host memory)
     int *host_flags;         // mapped pinned host words: [0] a raised status, [1] set when evaluations were left to the tail kernel
+    unsigned long long *trace;  // diagnostics (MSM_MOVE_TRACE builds): 8 timestamps per workgroup, or nullptr
 };
 // launch_move runs the main kernel; the host launches the tail (launch_move_tail) only when host_flags[1] was set
-int launch_move_prepare(msm_ctx *ctx, const CliqueArgs &a, int nslots, int *slot_tri, double *slot_w, double *slot_sf, double *slot_cw, double *tri_frame);
+int launch_move_prepare(msm_ctx *ctx, const CliqueArgs &a, int nslots, int *slot_tri, double *slot_w, double *slot_sf, double *slot_cw, double *slot_wda,
+                        double *tri_frame, double *tri_stat);
 int launch_move(msm_ctx *ctx, const CliqueArgs &a, const MoveArgs &m, const MoveLabels *labels, hipEvent_t ev_start, hipEvent_t ev_stop);
 int launch_move_tail(msm_ctx *ctx, const CliqueArgs &a, const MoveArgs &m, const MoveLabels *labels);
 

@@ -1,23 +1,29 @@
 // move_kernels.hip -- one label step of Fusion::optimize for the triclique (HO) cost classes (I/Fusion/Fusion.h:181-196:
 // eight computeTripletCost calls per control triangle, M/DiscreteCostFunction.cpp:135-188 with HO*::triplet_likelihood
-// :487-531 / :565-618) on a direction-table target, as ONE kernel plus a short tail.
+// :487-531 / :565-618) on a direction-table target, as ONE kernel.
 //
 // What every HCP configuration evaluates 38 times per iteration.  Per move: 8 x T evaluations, each sampling the ~8 source
-// vertices binned under its control triangle.  The three-kernel version of round 1 (sample / fix up / reduce, 31 + 15 + 16
-// us at ico6 / ico4) spent its time in per-point geometry that does not depend on the labels and in two extra passes
-// over the values.  Here:
-//   * the part of get_target_data that only depends on the CURRENT control triangle -- project the source vertex on its
-//     plane, its barycentric coordinates there (:498-505 / :574-583) -- is computed once per get_source_data()
-//     (k_move_prepare, same arithmetic, same bits); a sample starts from three weights;
-//   * a lane per (combination, bin point): workgroups take runs of consecutive control triangles (<= 32 bin slots, host
-//     packed), 8 lanes per triangle first set up the eight proposed triangles (fold test included) in LDS, then all
-//     lanes sample, then the same 8 lanes per triangle reduce their evaluation from LDS -- similarity in the reference's
-//     serial order + strain -- and write the cost.  No value goes through HBM;
-//   * samples the direction table cannot settle (0.2 %) mark their evaluation; it is appended to a short list with its
-//     values, and the tail kernel (a wavefront per listed evaluation, 8 lanes per unsettled point: search_device.hpp
-//     group8_find) finishes those ~1.6 % of the evaluations;
-//   * the labeling arrives in the kernel arguments (a byte per control point) and the costs can be written straight
-//     into mapped pinned host memory, so a call is two launches and one synchronisation.
+// vertices binned under its control triangle: 327 696 samples at ico6 / ico4 -- too few to be a throughput problem on 256
+// CUs; the move is a chain of dependent steps (labels -> proposed triangle -> sample position -> direction cell -> triangle
+// record -> value -> similarity -> cost), and its time is the length of that chain times the number of rounds the
+// workgroups need to get onto the chip.  The three-kernel version of round 1 (sample / fix up / reduce: 31 + 15 + 16 us,
+// plus 58 us of copy commands and status read-backs per call) is replaced by:
+//   * k_move_prepare, once per get_source_data(): everything that only depends on the CURRENT control grid -- the source
+//     vertex projected on its control triangle and its barycentric coordinates there (:498-505 / :574-583), the moving
+//     patch's weighted mean / variance (M/similarities.cpp:135-150), the original triangle's half of the strain energy
+//     (M/reg_tools.cpp:698-715) -- same arithmetic, same bits, just not 38 x 8 times per iteration;
+//   * k_ho_move, one launch per move.  A workgroup takes a run of <= 8 control triangles (<= 64 bin slots, host packed:
+//     640 workgroups at ico4, all resident at once -- a second round of workgroups would double the chain).  A lane per
+//     (triangle, combination) sets up the proposed triangles in LDS (fold test included); then every lane samples
+//     (combination, bin point) pairs, neighbouring lanes taking neighbouring bin points; then the lane per evaluation
+//     reduces it from LDS (similarity in the reference's serial order + strain) and writes the cost.  No value goes
+//     through HBM;
+//   * samples the direction table cannot settle (0.2 %) are listed in LDS and searched in the octree leaf by eight lanes
+//     each (search_device.hpp: group8_find) before the reduction; what even that cannot decide (no candidate in the leaf: sibling
+//     leaves, nearest vertex -- a handful per registration) marks the evaluation for the tail kernel, which the HOST
+//     launches only when the main kernel raised the flag;
+//   * the labeling arrives in the kernel arguments (a byte per control point) and the costs are written straight into
+//     mapped pinned host memory, so a call is one launch and one synchronisation.
 #include "clique_device.hpp"
 
 namespace msm {
@@ -102,28 +108,60 @@ __device__ __forceinline__ bool proposed_triangle(const CliqueArgs &a, const Mov
     return dot(tri_normal(r[0], r[1], r[2]), tri_normal(c0, c1, c2)) < 0.0;  // computeTripletCost :151-152
 }
 
-// likelihood + lambda * strain^rexp of one evaluation whose point values are all in vals[0..n)
-__device__ __forceinline__ double finish_evaluation(const CliqueArgs &a, const MoveArgs &m, int t, const int *id, const V3 *r, const double *vals) {
+// HO*::triplet_likelihood of one evaluation from its point values vals[0..n), in the reference's serial operand order;
+// the moving patch's half of the correlation (sum of weights, weighted mean, weighted variance, M/similarities.cpp:135-150)
+// comes from k_move_prepare: st[0..3), and W * (A - meanA) per slot
+__device__ __forceinline__ double move_likelihood(const CliqueArgs &a, const MoveArgs &m, int t, double wmean, const double *vals) {
     const int beg = a.bin_ptr[t], n = a.bin_ptr[t + 1] - beg;
-    const double wmean = (a.absw[id[0]] + a.absw[id[1]] + a.absw[id[2]]) / 3.0;
-    const double *sf = m.slot_sf + beg, *cw = m.slot_cw ? m.slot_cw + beg : nullptr;
+    for (int i = 0; i < n; ++i)
+        if (vals[i] != vals[i]) return __longlong_as_double(0x7ff8000000000000ll);  // a failed search
+    double cost = 0.0;
+    if (a.kind == MSM_COST_HO_UNIVARIATE) {
+        const double *cw = m.slot_cw ? m.slot_cw + beg : nullptr;
+        if (a.simmeasure == 2) {
+            const double *st = m.tri_stat + 3 * (size_t)t, *wda = m.slot_wda + beg;
+            const double sum = st[0], varA = st[2];
+            double meanB = 0.0, prod = 0.0, varB = 0.0;
+            for (int i = 0; i < n; ++i) meanB += (cw ? cw[i] : 1.0) * vals[i];
+            if (sum > 0.0) meanB /= sum;
+            for (int i = 0; i < n; ++i) {
+                prod += wda[i] * (vals[i] - meanB);
+                varB += (cw ? cw[i] : 1.0) * (vals[i] - meanB) * (vals[i] - meanB);
+            }
+            if (sum > 0.0) {
+                prod /= sum;
+                varB /= sum;
+            }
+            const double r = (varA == 0.0 || varB == 0.0) ? 0.0 : prod / (sqrt(varA) * sqrt(varB));
+            cost = 1 - (1 + r) * 0.5;
+        } else {  // sparsesimkernel::SSD, :179-188
+            const double *sf = m.slot_sf + beg;
+            double prod = 0.0;
+            for (int i = 0; i < n; ++i) prod += (cw ? cw[i] : 1.0) * (sf[i] - vals[i]) * (sf[i] - vals[i]);
+            cost = sqrt(prod) / n;
+        }
+    } else {
+        for (int i = 0; i < n; ++i) cost += vals[i];
+        if (n > 0) cost /= n;
+    }
+    return wmean * cost;
+}
+
+__device__ __forceinline__ double move_strain(const CliqueArgs &a, const MoveArgs &m, int t, const V3 *r) {
     const double *fp = m.tri_frame + 5 * (size_t)t;
     StrainFrame fr;
     fr.i00 = fp[0], fr.i01 = fp[1], fr.i10 = fp[2], fr.i11 = fp[3];
     fr.dswap = fp[4] != 0.0;
-    const double likelihood = ho_likelihood_core(
-        a.kind == MSM_COST_HO_UNIVARIATE, a.simmeasure, a.percentile, n, wmean, [&](int i) { return sf[i]; }, [&](int i) { return cw ? cw[i] : 1.0; },
-        [&](int i) { return vals[i]; });
-    const double w = triangular_strain_from(fr, r, a.mu, a.kappa, a.k_exp);
-    return likelihood + a.lambda * pow_exp(w, a.rexp);
+    return a.lambda * pow_exp(triangular_strain_from(fr, r, a.mu, a.kappa, a.k_exp), a.rexp);
 }
 
 }  // namespace
 
-// per control triangle: the label-independent half of HO*::get_target_data for each of its bin points, and the original
-// triangle's half of the strain energy
+// per control triangle: the label-independent half of HO*::get_target_data for each of its bin points, the moving patch's
+// half of the correlation, and the original triangle's half of the strain energy
 __global__ __launch_bounds__(256) void k_move_prepare(CliqueArgs a, int *__restrict__ slot_tri, double *__restrict__ slot_w, double *__restrict__ slot_sf,
-                                                       double *__restrict__ slot_cw, double *__restrict__ tri_frame) {
+                                                       double *__restrict__ slot_cw, double *__restrict__ slot_wda, double *__restrict__ tri_frame,
+                                                       double *__restrict__ tri_stat) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= a.T) return;
     const int id[3] = {a.triplets[3 * t], a.triplets[3 * t + 1], a.triplets[3 * t + 2]};
@@ -135,7 +173,8 @@ __global__ __launch_bounds__(256) void k_move_prepare(CliqueArgs a, int *__restr
     V3 s3;
     double pd;
     plane_of(cp0, cp1, cp2, s3, pd);
-    for (int s = a.bin_ptr[t]; s < a.bin_ptr[t + 1]; ++s) {
+    const int beg = a.bin_ptr[t], end = a.bin_ptr[t + 1];
+    for (int s = beg; s < end; ++s) {
         const int sv = a.bin_idx[s];
         const V3 sp = project_with_plane(soa(a.src, a.Nsrc, sv), s3, pd);  // project_point(src, cp0, cp1, cp2)
         double wa, wb, wc;
@@ -145,23 +184,26 @@ __global__ __launch_bounds__(256) void k_move_prepare(CliqueArgs a, int *__restr
         slot_sf[s] = a.sfeat[sv];                 // feature row 1 (the univariate classes; unused by the multivariate one)
         if (slot_cw) slot_cw[s] = a.cfw[sv];      // weight row 1
     }
+    // sparsesimkernel::corr, M/similarities.cpp:135-150, the sums that involve the moving patch only (serial, as there)
+    auto W = [&](int s) { return a.cfw ? a.cfw[a.bin_idx[s]] : 1.0; };
+    auto A = [&](int s) { return a.sfeat[a.bin_idx[s]]; };
+    double sum = 0.0, meanA = 0.0, varA = 0.0;
+    for (int s = beg; s < end; ++s) sum += W(s);
+    for (int s = beg; s < end; ++s) meanA += W(s) * A(s);
+    if (sum > 0.0) meanA /= sum;
+    for (int s = beg; s < end; ++s) {
+        varA += W(s) * (A(s) - meanA) * (A(s) - meanA);
+        slot_wda[s] = W(s) * (A(s) - meanA);
+    }
+    if (sum > 0.0) varA /= sum;
+    tri_stat[3 * (size_t)t] = sum, tri_stat[3 * (size_t)t + 1] = meanA, tri_stat[3 * (size_t)t + 2] = varA;
 }
 
 // kMode 0: HO univariate (value = interpolated target feature, from the table record)
 //       1: HO multivariate, a lane per sample (any D, any measure): ho_value_on
-//       2: HO multivariate, 12 <= D <= 64, SSD / correlation: eight lanes per sample split the dimensions
-#ifndef MSM_MOVE_VARIANT
-#define MSM_MOVE_VARIANT 0
-#endif
-#if MSM_MOVE_VARIANT == 1
-#define MSM_MOVE_BOUNDS __launch_bounds__(256, 6)
-#elif MSM_MOVE_VARIANT == 4
-#define MSM_MOVE_BOUNDS __launch_bounds__(256, 5)
-#else
-#define MSM_MOVE_BOUNDS __launch_bounds__(256)
-#endif
+//       2: HO multivariate, 12 <= D <= 64 and even, SSD / correlation: eight lanes per sample split the dimensions
 template <bool kPacked, int kMode>
-__global__ MSM_MOVE_BOUNDS void k_ho_move(CliqueArgs a, MoveArgs m, MoveLabels lab) {
+__global__ __launch_bounds__(256) void k_ho_move(CliqueArgs a, MoveArgs m, MoveLabels lab) {
     extern __shared__ __align__(16) double lds[];
     double *s_geo = lds;                            // 64 evaluations x 9: the proposed triangles
     double *s_vals = s_geo + 64 * 9;                // 8 combinations x cap bin slots
@@ -172,6 +214,12 @@ __global__ MSM_MOVE_BOUNDS void k_ho_move(CliqueArgs a, MoveArgs m, MoveLabels l
     __shared__ int s_npend;
 
     const int tid = threadIdx.x, lane = tid & 63;
+#ifdef MSM_MOVE_TRACE  // diagnostics: phase time stamps of every workgroup (tools/move_trace.py)
+#define MSM_STAMP(k) do { if (m.trace && tid == 0) m.trace[8 * (size_t)blockIdx.x + (k)] = wall_clock64(); } while (0)
+#else
+#define MSM_STAMP(k) do { } while (0)
+#endif
+    MSM_STAMP(0);
     if (blockIdx.x == 0 && tid == 0) m.defer_cnt[m.parity ^ 1] = 0u;  // the previous move's list has been consumed
     const int per = (m.nblk + 7) >> 3;  // the workgroups of an XCD (blockIdx % 8) take a contiguous run of control triangles
     const int blk = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
@@ -185,15 +233,18 @@ __global__ MSM_MOVE_BOUNDS void k_ho_move(CliqueArgs a, MoveArgs m, MoveLabels l
     // first sample's slot data, which does not depend on the labels
     const bool ev = tid < 8 * ntrip;
     if (tid == 0) s_npend = 0;
+    int id[3] = {0, 0, 0};
+    double wmean = 0.0;  // mean AbsoluteWeight of the triangle's control points (HO*::triplet_likelihood :530 / :616)
     if (ev) {
-        int id[3];
         V3 r[3];
         const bool folded = proposed_triangle<kPacked>(a, m, lab, t0 + (tid >> 3), tid & 7, id, r);
+        wmean = (a.absw[id[0]] + a.absw[id[1]] + a.absw[id[2]]) / 3.0;
         double *g = s_geo + 9 * tid;
         g[0] = r[0].x, g[1] = r[0].y, g[2] = r[0].z, g[3] = r[1].x, g[4] = r[1].y, g[5] = r[1].z, g[6] = r[2].x, g[7] = r[2].y, g[8] = r[2].z;
         s_flag[tid] = folded ? 1 : 0;
         s_flag[64 + tid] = 0;
     }
+    MSM_STAMP(1);
 
     // ---- samples: s = combination * nslots + slot (neighbouring lanes = neighbouring bin points of one combination)
     for (int base = 0; base < total; base += 256) {
@@ -201,14 +252,15 @@ __global__ MSM_MOVE_BOUNDS void k_ho_move(CliqueArgs a, MoveArgs m, MoveLabels l
         int tt = -2;  // -2: nothing to do (past the end, or a folded proposal: it never looks at the data); -1: left open
         int kk = 0, j = 0, el = 0;
         double wa = 0.0, wb = 0.0, wc = 0.0;
-        if (s < total) {
+        if (s < total) {  // the slot data do not depend on the labels: requested before the first barrier
             kk = fast_div(s, nslots, inv), j = s - kk * nslots;
             const size_t slot = (size_t)(s0 + j);
             el = (m.slot_tri[slot] - t0) * 8 + kk;
             wa = m.slot_w[3 * slot], wb = m.slot_w[3 * slot + 1], wc = m.slot_w[3 * slot + 2];
         }
         if (base == 0) __syncthreads();  // the proposed triangles are in LDS
-        if (s < total && !s_flag[el] && MSM_MOVE_VARIANT != 3) {
+        if (base == 0) MSM_STAMP(2);
+        if (s < total && !s_flag[el]) {
             const V3 p = moved_point(s_geo + 9 * el, wa, wb, wc);
             double2 d0, d1, d2, d3, d4, d5;
             tt = ray_find_rec(a.tree, p, d0, d1, d2, d3, d4, d5);
@@ -228,7 +280,8 @@ __global__ MSM_MOVE_BOUNDS void k_ho_move(CliqueArgs a, MoveArgs m, MoveLabels l
             }
         }
         if (kMode == 2) {
-            // eight lanes per sample: 32 groups x 8 passes cover the round's 256 samples
+            // eight lanes per sample: 32 groups x 8 passes cover the round's 256 samples (four lanes per sample and half the
+            // passes took 112 instead of 95 us at D = 32: the passes are bound by the rows' way through L2, not by their number)
             s_tt[tid] = tt;
             __syncthreads();
             const int grp = tid >> 3, jj = tid & 7, D = a.D;
@@ -246,14 +299,16 @@ __global__ MSM_MOVE_BOUNDS void k_ho_move(CliqueArgs a, MoveArgs m, MoveLabels l
                     sa = a.sfeat_vm + (size_t)sv * D;
                     cw = a.cfw_vm ? a.cfw_vm + (size_t)sv * a.cfw_rows : nullptr;
                 }
-                const double c = feature_vector_similarity8(a.simmeasure, go, jj, D, sa, cw, a.cfw_rows, f0, f1, f2, s_w[3 * q], s_w[3 * q + 1], s_w[3 * q + 2]);
+                const double c = feature_vector_similarity8x2(a.simmeasure, go, jj, D, sa, cw, a.cfw_rows, f0, f1, f2, s_w[3 * q], s_w[3 * q + 1], s_w[3 * q + 2]);
                 if (go && jj == 0) s_vals[qk * m.cap + qj] = c;
             }
             __syncthreads();
         }
     }
+    MSM_STAMP(3);
     if (total == 0) __syncthreads();  // the barrier of the first round, for a run of empty bins
     __syncthreads();
+    MSM_STAMP(4);
 
     // ---- the samples the direction table left open (0.2 %): the octree leaf's candidates, eight lanes per sample
     // (search_device.hpp: group8_find); what even that cannot decide (no candidate in the leaf: sibling leaves, nearest vertex)
@@ -283,6 +338,7 @@ __global__ MSM_MOVE_BOUNDS void k_ho_move(CliqueArgs a, MoveArgs m, MoveLabels l
         }
     }
     if (npend > 0) __syncthreads();
+    MSM_STAMP(5);
 
     // ---- one lane per evaluation: similarity in the reference's serial order + strain
     if (!ev) return;
@@ -301,14 +357,10 @@ __global__ MSM_MOVE_BOUNDS void k_ho_move(CliqueArgs a, MoveArgs m, MoveLabels l
         __hip_atomic_store(m.host_flags + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         return;
     }
-    const int id[3] = {a.triplets[3 * t], a.triplets[3 * t + 1], a.triplets[3 * t + 2]};
     const double *g = s_geo + 9 * tid;
     const V3 r[3] = {mk(g[0], g[1], g[2]), mk(g[3], g[4], g[5]), mk(g[6], g[7], g[8])};
-#if MSM_MOVE_VARIANT == 2
-    m.out[e] = vals[0] + r[0].x + id[0];
-#else
-    m.out[e] = finish_evaluation(a, m, t, id, r, vals);
-#endif
+    m.out[e] = move_likelihood(a, m, t, wmean, vals) + move_strain(a, m, t, r);
+    MSM_STAMP(6);
 }
 
 // The evaluations the main kernel could not finish: a wavefront each, eight lanes per open point (complete search), then the
@@ -356,14 +408,16 @@ __global__ __launch_bounds__(256) void k_ho_move_tail(CliqueArgs a, MoveArgs m, 
             if (in && sub == 0) vals[i] = v;
         }
         __syncthreads();
-        if (have && lane == 0) m.out[8 * t + k] = finish_evaluation(a, m, t, id, r, vals);
+        if (have && lane == 0)
+            m.out[8 * t + k] = move_likelihood(a, m, t, (a.absw[id[0]] + a.absw[id[1]] + a.absw[id[2]]) / 3.0, vals) + move_strain(a, m, t, r);
         __syncthreads();
     }
 }
 
-int launch_move_prepare(msm_ctx *ctx, const CliqueArgs &a, int nslots, int *slot_tri, double *slot_w, double *slot_sf, double *slot_cw, double *tri_frame) {
+int launch_move_prepare(msm_ctx *ctx, const CliqueArgs &a, int nslots, int *slot_tri, double *slot_w, double *slot_sf, double *slot_cw, double *slot_wda,
+                        double *tri_frame, double *tri_stat) {
     if (a.T <= 0) return MSM_OK;
-    hipLaunchKernelGGL(k_move_prepare, dim3((a.T + 255) / 256), dim3(256), 0, ctx->stream, a, slot_tri, slot_w, slot_sf, slot_cw, tri_frame);
+    hipLaunchKernelGGL(k_move_prepare, dim3((a.T + 255) / 256), dim3(256), 0, ctx->stream, a, slot_tri, slot_w, slot_sf, slot_cw, slot_wda, tri_frame, tri_stat);
     MSM_HIP(hipGetLastError());
     return MSM_OK;
 }
@@ -372,7 +426,7 @@ static_assert(sizeof(CliqueArgs) + sizeof(MoveArgs) + sizeof(MoveLabels) <= 4096
 
 static int move_mode(const CliqueArgs &a) {
     if (a.kind != MSM_COST_HO_MULTIVARIATE) return 0;
-    return (a.sfeat_vm && a.D >= 12 && a.D <= kMvLanes * kMvKeep && (a.simmeasure == 1 || a.simmeasure == 2)) ? 2 : 1;
+    return (a.sfeat_vm && a.D >= 12 && a.D <= 64 && a.D % 2 == 0 && (a.simmeasure == 1 || a.simmeasure == 2)) ? 2 : 1;
 }
 static MoveLabels g_no_labels;  // handed over (and never read) when the labeling comes as a device array
 

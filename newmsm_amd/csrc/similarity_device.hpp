@@ -214,4 +214,68 @@ __device__ __forceinline__ double feature_vector_similarity8(int sim, bool go, i
     return sqrt(pr) / D;
 }
 
+// The same with 16-byte loads: lane j owns the dimension pairs (16 k + 2 j, 16 k + 2 j + 1), so one load instruction of the
+// group reads 128 contiguous bytes of a row.  D even (rows of vertex-major arrays are then 16-byte aligned), D <= 64.
+__device__ __forceinline__ double feature_vector_similarity8x2(int sim, bool go, int j, int D, const double *sa, const double *cw, int cfw_rows, const double *f0,
+                                                               const double *f1, const double *f2, double wa, double wb, double wc) {
+    constexpr int kPairs = 4;
+    double A[2 * kPairs], B[2 * kPairs], W[2 * kPairs];
+#pragma unroll
+    for (int k = 0; k < kPairs; ++k) {
+        const int d = 16 * k + 2 * j;
+        const bool in = go && d < D;
+        const double2 z = make_double2(0.0, 0.0);
+        const double2 a2 = in ? *reinterpret_cast<const double2 *>(sa + d) : z;
+        const double2 x0 = in ? *reinterpret_cast<const double2 *>(f0 + d) : z, x1 = in ? *reinterpret_cast<const double2 *>(f1 + d) : z,
+                      x2 = in ? *reinterpret_cast<const double2 *>(f2 + d) : z;
+        A[2 * k] = a2.x, A[2 * k + 1] = a2.y;
+        B[2 * k] = in ? wa * x0.x + wb * x1.x + wc * x2.x : 0.0;  // barycentric_interpolation per dimension
+        B[2 * k + 1] = in ? wa * x0.y + wb * x1.y + wc * x2.y : 0.0;
+        W[2 * k] = !in ? 0.0 : ((cw && cfw_rows >= d + 1) ? cw[d] : 1.0);
+        W[2 * k + 1] = !in ? 0.0 : ((cw && cfw_rows >= d + 2) ? cw[d + 1] : 1.0);
+    }
+    if (sim == 2) {  // sparsesimkernel::corr over the D dimensions, M/similarities.cpp:129-158
+        double sum = 0, ma = 0, mb = 0;
+#pragma unroll
+        for (int k = 0; k < 2 * kPairs; ++k) {
+            sum += W[k];
+            ma += W[k] * A[k];
+            mb += W[k] * B[k];
+        }
+        sum = mv_group_sum(sum);
+        ma = mv_group_sum(ma);
+        mb = mv_group_sum(mb);
+        if (sum > 0.0) {
+            ma /= sum;
+            mb /= sum;
+        }
+        double pr = 0, va = 0, vb = 0;
+#pragma unroll
+        for (int k = 0; k < 2 * kPairs; ++k) {
+            const double da = A[k] - ma, db = B[k] - mb;
+            pr += W[k] * da * db;
+            va += W[k] * da * da;
+            vb += W[k] * db * db;
+        }
+        pr = mv_group_sum(pr);
+        va = mv_group_sum(va);
+        vb = mv_group_sum(vb);
+        if (sum > 0.0) {
+            pr /= sum;
+            va /= sum;
+            vb /= sum;
+        }
+        const double rr = (va == 0.0 || vb == 0.0) ? 0.0 : pr / (sqrt(va) * sqrt(vb));
+        return 1 - (1 + rr) * 0.5;
+    }
+    double pr = 0;  // sparsesimkernel::SSD, :179-188
+#pragma unroll
+    for (int k = 0; k < 2 * kPairs; ++k) {
+        const double df = A[k] - B[k];
+        pr += W[k] * df * df;
+    }
+    pr = mv_group_sum(pr);
+    return sqrt(pr) / D;
+}
+
 }  // namespace msm
