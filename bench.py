@@ -1,14 +1,25 @@
 #!/usr/bin/env python3
-"""bench.py -- label-cost evals/sec of the MI355X hot path (BASELINE.json metric).
+"""bench.py -- the BASELINE.json metrics of the MI355X hot path: label-cost evals/sec, wall-clock per ico6 pairwise
+registration, gMSM subjects/hour.
 
-One "step" = one computeUnaryCosts() pass (the full unary label-cost table: every control point x every
-label) of BASELINE config 2: pairwise sulc (D = 1) registration, ico6 data grid (40 962 vertices),
-ico4 control grid (2 562 nodes), 19 labels -> 48 678 evals = 3.18 M point samples per step.  All inputs
-are resident in HBM before the timed region starts.
+Default mode (--mode pairwise): one "step" = one computeUnaryCosts() of BASELINE config 2 -- pairwise sulc (D = 1) registration,
+ico6 data grid (40 962 vertices), ico4 control grid (2 562 nodes), 19 labels -> 48 678 evals = 3.18 M point samples -- as an
+iteration of a registration pays for it: the per (control point, label) rotations (estimate_rotation_matrix R/point.cpp:97-152:
+new every iteration), the three table kernels, and the 389 KB table delivered to host memory (the optimiser reads it there).
+All inputs are resident in HBM before the timed region starts.  The same JSON line carries, as extra objects (rank 0, N = 1):
+  steady            the table kernels alone, enqueued back to back (the round-1 headline definition)
+  triclique_move    one label step of Fusion (I/Fusion/Fusion.h:181-196) of the triclique classes: BASELINE config 4 (D = 1) and
+                    config 3 (HCP MSMAll, D = 32) at ico6 / ico4 -- per call and per kernel, with their rooflines
+  registration      wall-clock of a three-level ico6 pairwise registration driven by the reference's caller loop
+  gmsm              one groupwise iteration per level for 64 subjects on this GPU and the subjects/hour it implies
+  cpu_baseline      the CPU port (oracle/) on the host cores, on a bounded sample of the headline workload
 
-Multi-GPU (--gpus N, one process per GPU under torch.distributed.run): a pairwise registration does not
-shard; ranks are independent replicas working on different synthetic subjects --
-no data-path collective, weak scaling.  value = evals of all ranks / max-over-ranks wall time.
+Multi-GPU (--gpus N, one process per GPU under torch.distributed.run):
+  --mode pairwise   a pairwise registration does not shard: ranks are independent replicas working on
+                    different synthetic subjects -- no data-path collective, weak scaling.  value = evals of all ranks / max-over-
+                    ranks wall time.
+  --mode gmsm       BASELINE config 5: 64 synthetic subjects, set-up sharded by subject, every label step sharded by clique,
+                    RCCL all-gather / gather over xGMI (newmsm_amd/dist.py); strong scaling.  value = subjects/hour.
 """
 import argparse
 import json
@@ -21,6 +32,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+HCP = dict(rmode=3, mu=0.4, kappa=1.6, k_exp=2.0, rexp=2.0)  # --shearmod --bulkmod --k_exponent --regexp of the HCP / NeuroImage2017 configs
 
 
 def algorithmic_bytes(samples, evals, D):
@@ -70,97 +82,244 @@ def cpu_baseline(inp, kind, threads):
     return U, reps * U.size / dt, dt, reps
 
 
+def bench_triclique_move(ctx, D, calls, threads):
+    """One label step of Fusion for a triclique (HO) cost class at ico6 / ico4: msm_cost_triplet_octets, 8 x T evaluations."""
+    import numpy as np
+
+    from newmsm_amd import problem
+
+    kind = "ho_univariate" if D == 1 else "ho_multivariate"
+    lam = 0.025 if D == 1 else 0.01  # --lambda of config/NeuroImage2017_configs/sMSM_STR... / HCP MSMAllStrainFinalconf (last level)
+    inp = problem.pairwise_inputs(6, 4, D=D)
+    cf, keep = problem.build_cost(ctx, inp, kind=kind, lambda_=lam, **HCP)
+    cf.get_source_data()
+    rng = np.random.default_rng(0)
+    lab = rng.integers(0, cf.L, cf.N).astype(np.int32)
+    E = ctx.host_array((cf.T, 8))  # the optimiser's per-step buffer: mapped pinned memory the kernel writes directly
+    for _ in range(5):
+        cf.tripletOctets(lab, 3, E)
+    cf.enable_timing(True)
+    ts = []
+    for i in range(calls):
+        t0 = time.perf_counter()
+        cf.tripletOctets(lab, i % cf.L, E)
+        ts.append(time.perf_counter() - t0)
+    kt = cf.kernel_times() * 1e-3  # HIP events around the move's kernel(s), on the launch stream
+    cf.enable_timing(False)
+    call_s, kern_s = float(np.median(ts)), float(np.median(kt))
+    evals = 8 * cf.T
+    samples = 8 * len(inp["source_xyz"])  # every source vertex lies in one control triangle's bin; 8 combinations each
+    nbytes = samples * (116 + 32 * D) + evals * 72  # SURVEY 8(d): per triclique eval its points x (116 + 32 D) + 3 x 24 B of control points
+    out = {
+        "workload": "%s, D=%d, ico6 data / ico4 control grid: %d evals = %d point samples per move" % (kind, D, evals, samples),
+        "evals_per_s_call": evals / call_s, "us_per_call": call_s * 1e6, "evals_per_s_kernel": evals / kern_s, "kernel_us": kern_s * 1e6,
+        "calls": calls, "algorithmic_bytes_per_move": nbytes,
+        "roofline": {"bound": "hbm", "achieved": nbytes / kern_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nbytes / kern_s / 1e9 / HBM_PEAK_GBS,
+                     "frac_per_call": nbytes / call_s / 1e9 / HBM_PEAK_GBS, "kernel": "msm::k_ho_move",
+                     "note": "kernel time = HIP events around the move's launch(es) on its stream; the working set is cache resident, so this is a nominal figure"},
+    }
+    if threads:
+        from tests.helpers import oracle_cost
+
+        oc = oracle_cost(inp, kind, lambda_=lam, **HCP)
+        oc.get_source_data()
+        t0 = time.perf_counter()
+        ref = oc.triplet_octets(lab, 3, threads=threads)
+        dt = time.perf_counter() - t0
+        got = cf.tripletOctets(lab, 3, E)
+        out["cpu_port"] = {"evals_per_s": evals / dt, "cores": threads, "sample": "one move (%d evals, %.2f s), OpenMP over triplets as I/Fusion/Fusion.h:181" % (evals, dt),
+                           "max_rel_diff_vs_gpu": float(np.max(np.abs(got - ref) / np.maximum(np.abs(ref), 1e-300)))}
+    cf.close()
+    return out
+
+
+def bench_registration(ctx):
+    """Wall-clock of a pairwise registration (tools/time_registration.py): three DISCRETE levels as in config/basic_configs (data grids
+    ico4/5/6, control grids ico2/3/4, sigma 4/2/1, variance normalisation), 3 iterations per level, input and reference spheres ico6."""
+    import newmsm_amd as M
+    from newmsm_amd import registration, synthetic
+
+    xyz, tri = M.make_mesh_from_icosa(6)
+    ref = synthetic.features(xyz, 1, 7)
+    src = synthetic.features(synthetic.known_warp(xyz, seed=9, rot_deg=3.0, amp=2.0), 1, 7)
+    levels = [dict(data_order=4, cp_order=2, sigma_in=4.0, sigma_ref=4.0), dict(data_order=5, cp_order=3, sigma_in=2.0, sigma_ref=2.0),
+              dict(data_order=6, cp_order=4, sigma_in=1.0, sigma_ref=1.0)]
+    ops = registration.ProductOps(ctx)
+    for _ in range(2):  # the first run pays for allocations
+        clock = {}
+        t0 = time.perf_counter()
+        registration.run_multiresolution(ops, xyz, tri, src, xyz, tri, ref, levels, varnorm=True, timings=clock, iters=3, mciters=50, mcparam=0.8,
+                                         seed=1, cost_params=dict(lambda_=0.1))
+        wall = time.perf_counter() - t0
+    return {"wall_s": wall, "path_s": sum(v for k, v in clock.items() if k != "optimiser"), "phases_s": {k: round(v, 4) for k, v in sorted(clock.items())},
+            "workload": "run_multiresolutions, 3 DISCRETE levels (data ico4/5/6, control ico2/3/4), 3 iterations each, sulc-like D=1, ico6 spheres",
+            "optimiser": "the library's Monte Carlo optimiser (M/mcmc_opt.h) at 50 sweeps over the unary + T x L^3 triplet tables; FastPD / HOCR are "
+                         "licence-restricted and FSL-bound: not runnable here"}
+
+
+GMSM_LEVELS = [(4, 2), (5, 3), (6, 4)]  # --datagrid / --CPgrid of the gMSM configuration of docs/guide.md:390-407
+GMSM_ITERATIONS = 9                      # --it=9,9,9
+
+
+def gmsm_iteration(ctx, S, data_order, cp_order, comm, label_steps):
+    """One iteration of group registration at one level: setupCostFunction (M/DiscreteGroupModel.cpp:163-196) + the cost evaluations of
+    Fusion::optimize (2 sweeps x L label steps, I/Fusion/Fusion.h:138-196).  Returns (set-up s, per-label-step s, steps in an iteration)."""
+    import numpy as np
+
+    from newmsm_amd import dist as D
+    from newmsm_amd import problem
+
+    mine = list(D.shard(S, comm.rank, comm.world))
+    g, keep = problem.build_group(ctx, S, data_order, cp_order, D=2, subjects=mine)
+    comm.barrier()
+    t0 = time.perf_counter()
+    D.sharded_group_setup(g, S, comm)
+    comm.barrier()
+    setup_s = time.perf_counter() - t0
+    mover = D.ShardedMove(g, comm)
+    rng = np.random.default_rng(3)
+    lab = rng.integers(0, g.L, g.num_nodes).astype(np.int32)
+    mover.move(lab, 1)
+    comm.barrier()
+    t0 = time.perf_counter()
+    for i in range(label_steps):
+        q, o = mover.move(lab, (2 + i) % g.L)
+    comm.barrier()
+    step_s = (time.perf_counter() - t0) / label_steps
+    sizes = dict(L=g.L, pairs=g.P, triplets=g.T, nodes=g.num_nodes)
+    g.close()
+    return setup_s, step_s, 2 * sizes["L"], sizes
+
+
+def bench_gmsm(ctx, S, comm, label_steps=6):
+    from newmsm_amd import dist as D
+
+    levels, total = [], 0.0
+    for data_order, cp_order in GMSM_LEVELS:
+        setup_s, step_s, steps, sizes = gmsm_iteration(ctx, S, data_order, cp_order, comm, label_steps)
+        setup_s, step_s = D.max_over_ranks(setup_s, comm), D.max_over_ranks(step_s, comm)
+        it_s = setup_s + steps * step_s
+        total += GMSM_ITERATIONS * it_s
+        levels.append({"data_order": data_order, "cp_order": cp_order, "setup_s": setup_s, "label_step_s": step_s, "label_steps_per_iteration": steps,
+                       "iteration_s": it_s, "pair_evals_per_step": 4 * sizes["pairs"], "triplet_evals_per_step": 8 * sizes["triplets"]})
+    return {"subjects": S, "levels": levels, "iterations_per_level": GMSM_ITERATIONS, "path_s_per_group": total, "subjects_per_hour": S / total * 3600.0,
+            "definition": "cost-function side of a groupwise registration (docs/guide.md:390-407: 3 levels x 9 iterations): per iteration one "
+                          "setupCostFunction (get_patch_data for every subject) + 2 x L label steps of 4 P pair + 8 T triplet costs delivered to the optimiser's "
+                          "rank; measured on one iteration per level (set-up) and %d label steps.  The MRF solve (ELC / FastPD, licence-restricted, serial) is not "
+                          "part of the path and not in this figure" % label_steps}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--mode", choices=["pairwise", "gmsm"], default="pairwise")
     ap.add_argument("--data-order", type=int, default=6)
     ap.add_argument("--cp-order", type=int, default=4)
     ap.add_argument("--dims", type=int, default=1)
+    ap.add_argument("--subjects", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="headline line only (profiling runs)")
     args = ap.parse_args()
 
     import numpy as np
     import torch
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    from newmsm_amd import dist as D
+
+    rank, local_rank, world = D.env()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     # rehearsal of the N > 1 path on a one-GPU box: all ranks share cuda:0 and talk over gloo
     rehearse = os.environ.get("MSM_BENCH_REHEARSAL") == "1"
     device_index = 0 if rehearse else local_rank
     torch.cuda.set_device(device_index)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if rehearse:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))  # nccl = RCCL over xGMI
-    reduce_device = "cpu" if rehearse else "cuda"
+    comm = D.init("gloo" if rehearse else "nccl", device_index) if world > 1 else D.Comm()
 
     import __graft_entry__ as g
 
     if rank == 0:
         g.build()
-    if dist is not None:
-        dist.barrier()
+    comm.barrier()
     import newmsm_amd as M
     from newmsm_amd import problem
 
-    kind = "univariate" if args.dims == 1 else "multivariate"
     stream = torch.cuda.Stream()
     ctx = M.Context(device_index, stream=stream.cuda_stream)
+
+    def sync_all():
+        comm.barrier()
+        torch.cuda.synchronize()
+
+    if args.mode == "gmsm":
+        # strong scaling: the same 64-subject group whatever N.  One "step" = the cost-function side of one iteration at the last level
+        # (ico6 / ico4); --warmup iterations untimed, --steps timed ones are folded into the per-level measurement (set-up once per level)
+        sync_all()
+        t0 = time.perf_counter()
+        res = bench_gmsm(ctx, args.subjects, comm, label_steps=max(2, min(args.steps, 8)))
+        sync_all()
+        if rank == 0:
+            last = res["levels"][-1]
+            print(json.dumps({
+                "metric": "gMSM subjects/hour", "value": res["subjects_per_hour"], "unit": "subjects/hour", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": last["iteration_s"] * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                "config": {"workload": "gMSM groupwise, %d synthetic subjects (D=2), levels data ico4/5/6 / control ico2/3/4, %d iterations per level, sharded over %d GPU(s) "
+                                       "(BASELINE config 5); a step = one iteration at ico6 / ico4" % (args.subjects, GMSM_ITERATIONS, world),
+                           "sharding": "set-up by subject (all-gather of resampled feature maps + patch lists), label steps by clique (gather to rank 0)"},
+                "gmsm": res, "bench_wall_s": time.perf_counter() - t0,
+            }))
+        comm.close()
+        ctx.close()
+        return
+
+    kind = "univariate" if args.dims == 1 else "multivariate"
     # one synthetic subject per rank (different warp / feature phase)
     inp = problem.pairwise_inputs(args.data_order, args.cp_order, D=args.dims, seed=1234 + 17 * rank)
     cf, keep = problem.build_cost(ctx, inp, kind=kind)
     cf.get_source_data()
-    # steady state of many tables against one target: have the target's direction table in place before the first step
-    # (by default it is built in the background while the complete search serves the first tables)
+    # many tables against one target: have the target's direction table in place before the first step (by default it is built
+    # in the background while the complete search serves the first tables, DESIGN.md section 5.2: 14 ms of host time, once per
+    # resolution level -- reported below as set-up, not part of a step)
+    t0 = time.perf_counter()
     keep["target"].prepare_search(wait=True)
+    raytable_ms = (time.perf_counter() - t0) * 1e3
     ptr, _ = cf.patches()
     evals = cf.L * cf.N
     samples = cf.L * int(ptr[-1])
-
-    def sync_all():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+    U = ctx.host_array((cf.L, cf.N))  # pinned: the table's copy to the host is one copy-engine command
 
     cf.enable_timing(True)  # HIP events around the dominant kernel of every launch, on the launch stream
     with torch.cuda.stream(stream):
         for _ in range(args.warmup):
+            cf.computeUnaryCosts(U)
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            cf.computeUnaryCosts(U)  # rotations + table kernels + table on the host, synchronous: what an iteration pays
+        sync_all()
+        wall = time.perf_counter() - t0
+        # the kernels alone, enqueued back to back (no rotation kernel between them would be wrong: every call recomputes it)
+        for _ in range(args.warmup):
             cf.computeUnaryCosts_async()
         ctx.synchronize()
-        sync_all()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        t0 = time.perf_counter()
+        ts = time.perf_counter()
         e0.record(stream)
         for _ in range(args.steps):
             cf.computeUnaryCosts_async()
         e1.record(stream)
         ctx.synchronize()
-        sync_all()
-        wall = time.perf_counter() - t0
-    step_ms = e0.elapsed_time(e1) / args.steps  # HIP events on the launch stream: whole step (all kernels of one table)
+        steady_wall = time.perf_counter() - ts
+    step_ms = e0.elapsed_time(e1) / args.steps  # HIP events on the launch stream: rotations + the three table kernels
     kt = cf.kernel_times()[-min(args.steps, 64):]
-    kernel_ms = float(np.mean(kt))  # k_unary_samples alone (the dominant kernel), last <= 64 launches of the timed region
-    U = cf.getUnaryCosts()
+    kernel_ms = float(np.mean(kt))  # the sampling kernel alone (the dominant kernel), last <= 64 launches of the timed region
     if not np.isfinite(U).all() and not os.environ.get("MSM_BENCH_NOCHECK"):
         raise SystemExit("non-finite unary costs")
+    Ucopy = np.array(U)
 
-    if dist is not None:
-        t = torch.tensor([wall], device=reduce_device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall = float(t.item())
-        k = torch.tensor([kernel_ms], device=reduce_device, dtype=torch.float64)
-        dist.all_reduce(k, op=dist.ReduceOp.MAX)
-        kernel_ms = float(k.item())
+    wall = D.max_over_ranks(wall, comm)
+    kernel_ms = D.max_over_ranks(kernel_ms, comm)
 
     if rank == 0:
         value = world * evals * args.steps / wall
@@ -184,30 +343,38 @@ def main():
                 "workload": "pairwise sulc (D=%d) unary label-cost table, ico%d data grid / ico%d control grid, %d labels, "
                             "%d evals = %d point samples per step (BASELINE config 2)" % (args.dims, args.data_order, args.cp_order, cf.L, evals, samples),
                 "kind": kind, "simmeasure": "correlation", "replicas": world,
+                "step": "label rotations + sampling / fix-up / reduction kernels + the table copied to pinned host memory, one synchronous call",
+                "setup_not_in_step_ms": {"direction_table_of_the_target_once_per_level": raytable_ms},
             },
+            "steady": {"ms_per_step": steady_wall / args.steps * 1e3, "value": world * evals * args.steps / steady_wall,
+                       "definition": "table kernels (incl. the rotation kernel) enqueued back to back, no copy of the table to the host, one synchronisation at the end"},
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": pmc_traffic(args), "kernel": DOMINANT_KERNEL,
-                "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": kbytes,
-                # the whole table (sampling + fix-up + reduction kernels, HIP events around one step) against the full 8(d) figure
+                "traffic": pmc_traffic(args), "traffic_source": PMC_PROFILE + " (rocprofv3 --pmc passes of round 1: the sampling kernel is unchanged since)",
+                "kernel": DOMINANT_KERNEL, "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": kbytes,
+                "note": "nominal: the level's working set (tens of MB) lives in L2 / Infinity Cache, counter traffic is far below the algorithmic bytes; "
+                        "the kernel is bound by the L1 lookup rate of its divergent gathers (DESIGN.md section 5.2)",
+                # the whole table (rotation + sampling + fix-up + reduction kernels, HIP events around one step) against the full 8(d) figure
                 "step_ms_events": step_ms, "algorithmic_bytes_per_table": abytes,
                 "table_achieved": abytes / (step_ms * 1e-3) / 1e9, "table_frac": abytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             },
         }
+        threads = D.host_cores()  # cgroup / affinity aware: the GPU box gives one GPU's share of the host
+        if world == 1 and not args.no_extras:
+            with torch.cuda.stream(stream):
+                out["triclique_move"] = {"d1": bench_triclique_move(ctx, 1, 200, 0 if args.no_cpu_baseline else threads),
+                                         "d32": bench_triclique_move(ctx, 32, 200, 0 if args.no_cpu_baseline else threads)}
+                out["registration"] = bench_registration(ctx)
+                out["gmsm"] = bench_gmsm(ctx, args.subjects, comm)
         if world == 1 and not args.no_cpu_baseline:
-            from newmsm_amd.dist import host_cores
-
-            threads = host_cores()  # cgroup / affinity aware: the GPU box gives one GPU's share of the host
             Uo, rate, dt, reps = cpu_baseline(inp, kind, threads)
             out["cpu_baseline"] = {
                 "value": rate, "unit": "evals/s", "cores": threads, "kind": "port",
                 "sample": "%d full unary tables (%d evals each, %.1f s in total) of the same workload, OpenMP over control points" % (reps, Uo.size, dt),
-                "max_abs_diff_vs_gpu": float(np.max(np.abs(Uo - U))),
+                "max_abs_diff_vs_gpu": float(np.max(np.abs(Uo - Ucopy))),
             }
         print(json.dumps(out))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    comm.close()
     ctx.close()
 
 

@@ -319,6 +319,10 @@ int msm_group_setup(msm_group *g);
 int msm_group_setup_subjects(msm_group *g, const int32_t *subjects, int32_t n);
 int msm_group_export_subject(msm_group *g, int32_t subject, double *F, int32_t *pptr, int32_t *pidx, int64_t cap, int64_t *npidx);
 int msm_group_import_subject(msm_group *g, int32_t subject, const double *F, const int32_t *pptr, const int32_t *pidx, int64_t npidx);
+/* the same exchange with the caller's buffers in DEVICE memory of this context's GPU (what an RCCL all-gather reads and writes):
+ * no host copy in between.  F_dev / pptr_dev / pidx_dev as above; any of them may be NULL on export. */
+int msm_group_export_subject_dev(msm_group *g, int32_t subject, double *F_dev, int32_t *pptr_dev, int32_t *pidx_dev, int64_t cap, int64_t *npidx);
+int msm_group_import_subject_dev(msm_group *g, int32_t subject, const double *F_dev, const int32_t *pptr_dev, const int32_t *pidx_dev, int64_t npidx);
 int msm_group_finalize(msm_group *g);
 int msm_group_sizes(msm_group *g, int32_t *nodes, int32_t *pairs, int32_t *triplets);
 int msm_group_get_pairs(msm_group *g, int32_t *pairs /* P x 2 */);
@@ -333,6 +337,14 @@ int msm_group_triplet_batch(msm_group *g, const int32_t *triplet, const int32_t 
  * [B takes it]) and triplet_octets[8 * t + k] = triplet_data[t].buffer[k] (k = 000..111); either output may be NULL.
  * Nothing but the labeling travels to the GPU. */
 int msm_group_fusion_move(msm_group *g, const int32_t *labeling, int32_t label, double *pair_quads, double *triplet_octets);
+
+/* A slice of one label step for a multi-GPU run: every rank evaluates ITS slice of the pair list and of the triplet list
+ * (the loop of M/DiscreteGroupCostFunction.cpp:54-98 over N_cp * S (S - 1) / 2 pairs is what a 64-subject iteration spends its
+ * time in) and leaves the results in DEVICE memory, from where the caller gathers them to the optimiser's rank (RCCL gather).
+ * pairs [pair0, pair1) -> quads_dev[4 * (pair1 - pair0)], triplets [trip0, trip1) -> octets_dev[8 * (trip1 - trip0)], both in
+ * the buffer order of msm_group_fusion_move. */
+int msm_group_fusion_move_dev(msm_group *g, const int32_t *labeling, int32_t label, int64_t pair0, int64_t pair1, int64_t trip0, int64_t trip1,
+                              double *quads_dev, double *octets_dev);
 
 #ifdef __cplusplus
 }

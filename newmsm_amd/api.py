@@ -450,8 +450,11 @@ class DiscreteCostFunction:
         return out
 
     # computeUnaryCosts() + getUnaryCosts(): table[label, node]
-    def computeUnaryCosts(self):
-        U = np.zeros((self.L, self.N))
+    def computeUnaryCosts(self, out=None):
+        """computeUnaryCosts() + getUnaryCosts().  `out` (optional, L x N): the array to fill, e.g. Context.host_array((L, N)):
+        pinned memory the copy engine writes directly."""
+        U = np.zeros((self.L, self.N)) if out is None else out
+        assert U.shape == (self.L, self.N) and U.dtype == np.float64 and U.flags.c_contiguous
         check(lib().msm_cost_unary_table(self.h, U.ctypes.data_as(c_dp)))
         return U
 
@@ -612,6 +615,26 @@ class DiscreteGroupCostFunction:
         pp, ppp = _i(pptr)
         pi, ppi = _i(pidx)
         check(lib().msm_group_import_subject(self.h, int(subject), pF, ppp, ppi if len(pi) else None, len(pi)))
+
+    # device-resident variants: the buffers are torch tensors on this context's GPU (data_ptr()), see newmsm_amd.dist
+    def subject_index_count(self, subject):
+        n = C.c_int64()
+        check(lib().msm_group_export_subject_dev(self.h, int(subject), None, None, None, 0, C.byref(n)))
+        return n.value
+
+    def export_subject_dev(self, subject, F_ptr, pptr_ptr, pidx_ptr, cap):
+        n = C.c_int64()
+        check(lib().msm_group_export_subject_dev(self.h, int(subject), C.c_void_p(F_ptr), C.c_void_p(pptr_ptr), C.c_void_p(pidx_ptr), int(cap), C.byref(n)))
+        return n.value
+
+    def import_subject_dev(self, subject, F_ptr, pptr_ptr, pidx_ptr, npidx):
+        check(lib().msm_group_import_subject_dev(self.h, int(subject), C.c_void_p(F_ptr), C.c_void_p(pptr_ptr), C.c_void_p(pidx_ptr), int(npidx)))
+
+    def fusionMove_dev(self, labeling, label, pair_range, triplet_range, quads_ptr, octets_ptr):
+        """a slice of a label step, results left in device memory (quads_ptr / octets_ptr: device addresses)"""
+        lab, pl = _i(labeling)
+        check(lib().msm_group_fusion_move_dev(self.h, pl, int(label), int(pair_range[0]), int(pair_range[1]), int(triplet_range[0]), int(triplet_range[1]),
+                                              C.c_void_p(quads_ptr), C.c_void_p(octets_ptr)))
 
     def finalize(self):
         check(lib().msm_group_finalize(self.h))

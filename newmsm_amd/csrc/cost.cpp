@@ -537,7 +537,10 @@ int msm_cost_absolute_weights(msm_cost *c, double *absw) {
 
 int msm_cost_unary_table_async(msm_cost *c) {
     if (!c) return fail(MSM_ERR_INVALID, "null cost");
-    c->table_valid = false;  // every call is a fresh computeUnaryCosts() (inputs unchanged: the label rotations are kept)
+    // every call is a fresh computeUnaryCosts(): the per (control point, label) rotations are recomputed too, as they are in
+    // every iteration of a registration (new labels / a moved control grid each time)
+    c->table_valid = false;
+    c->rotations_valid = false;
     c->h_U.clear();
     return ensure_unary_table(c);
 }

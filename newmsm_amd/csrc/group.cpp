@@ -598,6 +598,69 @@ int msm_group_import_subject(msm_group *g, int32_t s, const double *F, const int
     return MSM_OK;
 }
 
+// The same exchange without the host in between: the caller's buffers are DEVICE memory on this context's GPU (e.g. torch
+// tensors about to go through an RCCL all-gather, or just out of one).
+int msm_group_export_subject_dev(msm_group *g, int32_t s, double *F_dev, int32_t *pptr_dev, int32_t *pidx_dev, int64_t cap, int64_t *npidx) {
+    if (!g || s < 0 || s >= g->S) return fail(MSM_ERR_INVALID, "msm_group_export_subject_dev: bad arguments");
+    if (!g->common_ready || !g->have_subject[s]) return fail(MSM_ERR_STATE, "msm_group: subject %d has not been set up on this rank", s);
+    msm_ctx *ctx = g->ctx;
+    const size_t per = (size_t)g->D * g->tmpl->V, M = (size_t)g->N * g->L;
+    const int64_t n = (int64_t)g->h_pptr[s][M];
+    if (npidx) *npidx = n;
+    if (F_dev)
+        for (int l = 0; l < g->L; ++l)
+            MSM_HIP(hipMemcpyAsync(F_dev + per * l, g->F[(size_t)s * g->L + l]->p, sizeof(double) * per, hipMemcpyDeviceToDevice, ctx->stream));
+    if (pptr_dev) MSM_HIP(hipMemcpyAsync(pptr_dev, g->pptr[s]->p, sizeof(int32_t) * (M + 1), hipMemcpyDeviceToDevice, ctx->stream));
+    if (pidx_dev) {
+        if (n > cap) return fail(MSM_ERR_CAPACITY, "patch index buffer too small");
+        if (n > 0) MSM_HIP(hipMemcpyAsync(pidx_dev, g->pidx[s]->p, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    MSM_HIP(hipStreamSynchronize(ctx->stream));  // the buffers may go straight into a collective on another stream
+    return MSM_OK;
+}
+
+namespace {
+__global__ void k_check_patch_csr(const int32_t *__restrict__ pptr, size_t M, const int32_t *__restrict__ pidx, int64_t npidx, int32_t Vt, int *bad) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0 && (pptr[0] != 0 || pptr[M] != npidx)) atomicOr(bad, 1);
+    if (i < M && pptr[i + 1] < pptr[i]) atomicOr(bad, 2);
+    if ((int64_t)i < npidx && (pidx[i] < 0 || pidx[i] >= Vt)) atomicOr(bad, 4);
+}
+}  // namespace
+
+int msm_group_import_subject_dev(msm_group *g, int32_t s, const double *F_dev, const int32_t *pptr_dev, const int32_t *pidx_dev, int64_t npidx) {
+    if (!g || !F_dev || !pptr_dev || (!pidx_dev && npidx > 0) || s < 0 || s >= g->S || npidx < 0) return fail(MSM_ERR_INVALID, "msm_group_import_subject_dev: bad arguments");
+    if (!g->common_ready) return fail(MSM_ERR_STATE, "msm_group: msm_group_setup_subjects() must be called first (an empty list is fine)");
+    msm_ctx *ctx = g->ctx;
+    const size_t per = (size_t)g->D * g->tmpl->V, M = (size_t)g->N * g->L;
+    // the arrays come from another rank: checked (on the device, where they are) before any kernel indexes with them
+    DevBuf<int> bad;
+    MSM_HIP(bad.zero(1, ctx->stream));
+    const size_t span = std::max<size_t>(M + 1, (size_t)npidx);
+    hipLaunchKernelGGL(k_check_patch_csr, dim3((unsigned)((span + 255) / 256)), dim3(256), 0, ctx->stream, pptr_dev, M, pidx_dev, npidx, g->tmpl->V, bad.p);
+    MSM_HIP(hipGetLastError());
+    int hbad = 0;
+    MSM_HIP(hipMemcpyAsync(&hbad, bad.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    MSM_HIP(hipStreamSynchronize(ctx->stream));
+    if (hbad) return fail(MSM_ERR_INVALID, "patch CSR of subject %d is inconsistent (code %d: 1 ends, 2 row lengths, 4 vertex ids)", s, hbad);
+    for (int l = 0; l < g->L; ++l) {
+        auto &buf = g->F[(size_t)s * g->L + l];
+        if (!buf) buf.reset(new DevBuf<double>());
+        MSM_HIP(buf->ensure(per));
+        MSM_HIP(hipMemcpyAsync(buf->p, F_dev + per * l, sizeof(double) * per, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    MSM_HIP(g->pptr[s]->ensure(M + 1));
+    MSM_HIP(hipMemcpyAsync(g->pptr[s]->p, pptr_dev, sizeof(int32_t) * (M + 1), hipMemcpyDeviceToDevice, ctx->stream));
+    MSM_HIP(g->pidx[s]->ensure(std::max<size_t>((size_t)npidx, 1)));
+    if (npidx > 0) MSM_HIP(hipMemcpyAsync(g->pidx[s]->p, pidx_dev, sizeof(int32_t) * (size_t)npidx, hipMemcpyDeviceToDevice, ctx->stream));
+    g->h_pptr[s].resize(M + 1);  // the row lengths are host knowledge too (largest patch, msm_group_patch)
+    MSM_HIP(hipMemcpyAsync(g->h_pptr[s].data(), pptr_dev, sizeof(int32_t) * (M + 1), hipMemcpyDeviceToHost, ctx->stream));
+    g->h_pidx[s].clear();        // fetched on demand by msm_group_patch
+    MSM_HIP(hipStreamSynchronize(ctx->stream));
+    g->have_subject[s] = 1;
+    return MSM_OK;
+}
+
 int msm_group_finalize(msm_group *g) {
     if (!g) return fail(MSM_ERR_INVALID, "null group");
     if (!g->common_ready) return fail(MSM_ERR_STATE, "msm_group: nothing has been set up");
@@ -659,6 +722,11 @@ int msm_group_patch(msm_group *g, int32_t s, int32_t v, int32_t l, int32_t *ids,
     if (s < 0 || s >= g->S || v < 0 || v >= g->N || l < 0 || l >= g->L) return fail(MSM_ERR_INVALID, "msm_group_patch: index out of range");
     const int beg = g->h_pptr[s][v * g->L + l], cnt = g->h_pptr[s][v * g->L + l + 1] - beg;
     *n = cnt;
+    if (g->h_pidx[s].empty() && g->h_pptr[s].back() > 0) {  // a subject imported from device memory: its index list is fetched when first asked for
+        g->h_pidx[s].resize((size_t)g->h_pptr[s].back());
+        MSM_HIP(g->pidx[s]->download(g->h_pidx[s].data(), g->h_pidx[s].size(), g->ctx->stream));
+        MSM_HIP(hipStreamSynchronize(g->ctx->stream));
+    }
     if (!ids && !data) return MSM_OK;
     const int Vt = g->tmpl->V;
     std::vector<double> F;
@@ -737,6 +805,44 @@ int msm_group_fusion_move(msm_group *g, const int32_t *labeling, int32_t label, 
         }
     }
     return MSM_OK;
+}
+
+// A slice of a label step with the results left in DEVICE memory (the caller's buffers, e.g. torch tensors that go into an
+// RCCL gather): pairs [pair0, pair1) -> quads_dev[4 * (pair1 - pair0)], triplets [trip0, trip1) -> octets_dev[8 * (trip1 - trip0)].
+int msm_group_fusion_move_dev(msm_group *g, const int32_t *labeling, int32_t label, int64_t pair0, int64_t pair1, int64_t trip0, int64_t trip1,
+                              double *quads_dev, double *octets_dev) {
+    if (!g || !labeling) return fail(MSM_ERR_INVALID, "msm_group_fusion_move_dev: null argument");
+    GroupArgs a;
+    int st = group_args(g, a);
+    if (st) return st;
+    const int nodes = g->S * g->N;
+    const int64_t P = (int64_t)(g->pairs.size() / 2), T = (int64_t)g->S * g->Tc;
+    if (label < 0 || label >= g->L) return fail(MSM_ERR_INVALID, "msm_group_fusion_move_dev: label %d out of range", label);
+    if (pair0 < 0 || pair1 < pair0 || pair1 > P || trip0 < 0 || trip1 < trip0 || trip1 > T) return fail(MSM_ERR_INVALID, "msm_group_fusion_move_dev: range out of bounds");
+    if ((pair1 > pair0 && !quads_dev) || (trip1 > trip0 && !octets_dev)) return fail(MSM_ERR_INVALID, "msm_group_fusion_move_dev: missing output buffer");
+    for (int i = 0; i < nodes; ++i)
+        if (labeling[i] < 0 || labeling[i] >= g->L) return fail(MSM_ERR_INVALID, "msm_group_fusion_move_dev: label of node %d out of range", i);
+    msm_ctx *ctx = g->ctx;
+    void *pin = nullptr;
+    st = ctx_io_pinned(ctx, sizeof(int32_t) * (size_t)nodes, &pin);
+    if (st) return st;
+    std::memcpy(pin, labeling, sizeof(int32_t) * (size_t)nodes);
+    MSM_HIP(g->d_query[0].ensure(nodes));
+    MSM_HIP(hipMemcpyAsync(g->d_query[0].p, pin, sizeof(int32_t) * (size_t)nodes, hipMemcpyHostToDevice, ctx->stream));
+    a.move_labeling = g->d_query[0].p;
+    a.move_label = label;
+    for (int pass = 0; pass < 2; ++pass) {
+        const int64_t first = pass == 0 ? 4 * pair0 : 8 * trip0, total = pass == 0 ? 4 * (pair1 - pair0) : 8 * (trip1 - trip0);
+        double *out = pass == 0 ? quads_dev : octets_dev;
+        for (int64_t off = 0; off < total; off += kBatchChunk) {
+            const int m = (int)std::min<int64_t>(kBatchChunk, total - off);
+            if (first + off > 0x7fffffffll - kBatchChunk) return fail(MSM_ERR_CAPACITY, "msm_group_fusion_move_dev: evaluation index beyond 2^31");
+            a.move_offset = (int)(first + off);
+            st = pass == 0 ? launch_group_pairwise(ctx, a, nullptr, nullptr, nullptr, m, out + off) : launch_group_triplet(ctx, a, nullptr, nullptr, nullptr, nullptr, m, out + off);
+            if (st) return st;
+        }
+    }
+    return check_status(ctx, "DiscreteGroupCostFunction (fusion move)");  // synchronises: the buffers may go into a collective on another stream
 }
 
 int msm_group_triplet_batch(msm_group *g, const int32_t *t, const int32_t *la, const int32_t *lb, const int32_t *lc, int32_t n, double *out) {

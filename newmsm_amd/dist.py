@@ -1,8 +1,19 @@
 """One-process-per-GPU plumbing (torch.distributed: "nccl" = RCCL over xGMI on the GPU box, "gloo" on CPU).
 
-The pairwise path does not shard: ranks are replicas.  Groupwise (gMSM) work shards by subject, and the one
-exchange is the template update -- an all-reduce(sum) of per-rank accumulators (the
-reference does this step with files + wb_command, gMSM_scripts/run_gMSM.sh:66-139).
+The pairwise path does not shard: ranks are replicas.  Groupwise (gMSM) work shards twice:
+
+  set-up      by SUBJECT: every rank runs get_patch_data (M/DiscreteGroupModel.cpp:88-121: a rigid rotation + an adaptive-
+              barycentric resample per label) for its subjects only; the resampled feature maps and patch lists of all
+              subjects are then all-gathered (three collectives for the whole group, device buffer to device buffer with
+              the nccl backend) so that every rank can evaluate any inter-subject pair;
+  evaluation  by CLIQUE: in every label step of Fusion (I/Fusion/Fusion.h:157-196) rank r evaluates its contiguous slice of
+              the pair list (M/DiscreteGroupCostFunction.cpp:54-98 over N_cp * S (S - 1) / 2 pairs) and of the triplet list;
+              the slices are gathered to the optimiser's rank;
+  template    the group-mean update -- what gMSM_scripts/run_gMSM.sh:66-139 does with files and wb_command -- is one
+              all-reduce(sum) of per-rank accumulators.
+
+`Comm` carries the process group and the device its tensors live on: cuda:<local rank> for nccl (RCCL cannot reduce host
+tensors), cpu for gloo (the world-size-2 rehearsal on CPU / on a one-GPU box).
 """
 import os
 
@@ -25,11 +36,42 @@ def host_cores():
     return max(1, n)
 
 
-def init(backend=None):
-    """Initialise the default process group when WORLD_SIZE > 1.  Returns torch.distributed or None."""
+class Comm:
+    """torch.distributed process group + the device collectives run on.  `dist` is None for a single process."""
+
+    def __init__(self, dist=None, backend=None, device="cpu", rank=0, world=1):
+        self.dist, self.backend, self.device, self.rank, self.world = dist, backend, device, rank, world
+
+    @property
+    def on_gpu(self):
+        return self.backend == "nccl"
+
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier()
+
+    def close(self):
+        if self.dist is not None:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+            self.dist = None
+
+    destroy_process_group = close
+
+    def all_gather(self, out, inp):
+        """out[r] = rank r's inp (out: world x inp.shape), one collective"""
+        try:
+            self.dist.all_gather_into_tensor(out, inp)
+        except (RuntimeError, NotImplementedError):  # a backend without the flat form
+            self.dist.all_gather(list(out.unbind(0)), inp)
+
+
+def init(backend=None, device_index=None):
+    """Initialise the default process group when WORLD_SIZE > 1 (a single process gets a Comm without one).
+    backend None: nccl when a GPU is visible, else gloo.  device_index: the GPU of this rank (default LOCAL_RANK)."""
     rank, local_rank, world = env()
-    if world <= 1:
-        return None
+    if world <= 1 and backend is None:
+        return Comm()
     import torch
     import torch.distributed as dist
 
@@ -38,44 +80,54 @@ def init(backend=None):
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"
     if backend == "nccl":
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    else:
-        dist.init_process_group(backend)
-    return dist
+        dev = local_rank if device_index is None else device_index
+        torch.cuda.set_device(dev)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", dev), rank=rank, world_size=world)
+        return Comm(dist, "nccl", "cuda:%d" % dev, rank, world)
+    dist.init_process_group(backend, rank=rank, world_size=world)
+    return Comm(dist, backend, "cpu", rank, world)
+
+
+def _comm(c):
+    """accepts a Comm, None, or (older call sites) a bare torch.distributed module initialised with gloo"""
+    if c is None:
+        return Comm()
+    if isinstance(c, Comm):
+        return c
+    return Comm(c, c.get_backend(), "cpu" if c.get_backend() == "gloo" else "cuda:%d" % env()[1], c.get_rank(), c.get_world_size())
 
 
 def shard(n_items, rank, world):
-    """Contiguous, balanced shard of range(n_items) (subjects) for this rank."""
+    """Contiguous, balanced shard of range(n_items) (subjects, pairs, triplets) for this rank."""
     base, extra = divmod(n_items, world)
     lo = rank * base + min(rank, extra)
     return range(lo, lo + base + (1 if rank < extra else 0))
 
 
-def _tensor(x, device):
+def all_reduce_sum(arr, comm=None):
+    """Sum of a numpy array over all ranks (identity without a process group)."""
+    c = _comm(comm)
+    if c.dist is None:
+        return np.array(arr, dtype=np.float64)
     import torch
 
-    return torch.as_tensor(np.ascontiguousarray(x, dtype=np.float64), device=device)
-
-
-def all_reduce_sum(arr, dist=None, device="cpu"):
-    """Sum of a numpy array over all ranks (identity without a process group)."""
-    if dist is None:
-        return np.array(arr, dtype=np.float64)
-    t = _tensor(arr, device)
-    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    t = torch.as_tensor(np.ascontiguousarray(arr, dtype=np.float64), device=c.device)
+    c.dist.all_reduce(t, op=c.dist.ReduceOp.SUM)
     return t.cpu().numpy()
 
 
-def max_over_ranks(value, dist=None, device="cpu"):
-    if dist is None:
+def max_over_ranks(value, comm=None):
+    c = _comm(comm)
+    if c.dist is None:
         return float(value)
-    t = _tensor([value], device)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    import torch
+
+    t = torch.tensor([float(value)], dtype=torch.float64, device=c.device)
+    c.dist.all_reduce(t, op=c.dist.ReduceOp.MAX)
     return float(t.item())
 
 
-def group_template_update(local_spheres, local_features=None, dist=None, device="cpu", radius=100.0):
+def group_template_update(local_spheres, local_features=None, comm=None, radius=100.0):
     """Template update of a groupwise run: every rank holds the registered spheres (n_local x V x 3) and
     resampled feature maps (n_local x D x V) of ITS subjects.  One all-reduce(sum) of the accumulators
     [sum xyz | sum f | sum f^2 | count] yields, on every rank, the mean sphere (re-projected to `radius`), the
@@ -90,7 +142,7 @@ def group_template_update(local_spheres, local_features=None, dist=None, device=
         D = local_features.shape[1]
         parts += [local_features.sum(axis=0).ravel(), (local_features ** 2).sum(axis=0).ravel()]
     parts.append(np.array([float(local_spheres.shape[0])]))
-    acc = all_reduce_sum(np.concatenate(parts), dist, device)
+    acc = all_reduce_sum(np.concatenate(parts), comm)
     n = acc[-1]
     mean_xyz = acc[: 3 * V].reshape(V, 3) / n
     norm = np.linalg.norm(mean_xyz, axis=1, keepdims=True)
@@ -105,36 +157,107 @@ def group_template_update(local_spheres, local_features=None, dist=None, device=
     return out
 
 
-def sharded_group_setup(group, n_subjects, dist=None, device="cpu"):
+def sharded_group_setup(group, n_subjects, comm=None):
     """Groupwise set-up with the subjects sharded over the ranks.
 
-    `group` offers setup_subjects(list), export_subject(s) -> (F, pptr, pidx), import_subject(s, F, pptr, pidx) and
-    finalize() (newmsm_amd.DiscreteGroupCostFunction).  Every rank runs the expensive per-subject work -- one rigid
-    rotation + adaptive-barycentric resample per label -- for ITS subjects only; the resampled feature maps and
-    patch lists are then broadcast from their owner (RCCL over xGMI with the nccl backend; F is L x D x V doubles,
-    12.5 MB per subject at ico6 / 19 labels / D = 2) so that every rank can evaluate any inter-subject pair."""
-    rank, _, world = env() if dist is not None else (0, 0, 1)
-    mine = list(shard(n_subjects, rank, world))
+    `group` is a newmsm_amd.DiscreteGroupCostFunction.  Every rank runs the expensive per-subject work for ITS subjects only,
+    then three all-gathers move every subject's resampled feature maps F (L x D x V doubles, 12.5 MB per subject at ico6 /
+    19 labels / D = 2), patch row pointers and patch index lists to every rank: shards are padded to the largest one, so
+    each collective is one call for the whole group.  With the nccl backend the buffers are torch tensors on the GPU that
+    libmsmhip fills and reads with device-to-device copies (msm_group_export_subject_dev / _import_subject_dev): nothing
+    goes through the host.  With gloo (CPU rehearsal) the same code runs on host tensors through the host entry points."""
+    c = _comm(comm)
+    mine = list(shard(n_subjects, c.rank, c.world))
     group.setup_subjects(mine)
-    if dist is not None and world > 1:
+    if c.dist is not None and c.world > 1:
         import torch
 
-        for s in range(n_subjects):
-            owner = next(r for r in range(world) if s in shard(n_subjects, r, world))
-            if owner == rank:
-                F, pptr, pidx = group.export_subject(s)
-                meta = torch.tensor([F.size, len(pptr), len(pidx)] + list(F.shape), dtype=torch.int64, device=device)
+        L, D, V, M = group.L, group.D, group._keep["template"].V, group.N * group.L + 1
+        nmax = max(len(shard(n_subjects, r, c.world)) for r in range(c.world))
+        counts = torch.zeros(nmax, dtype=torch.int64, device=c.device)
+        local_counts = [group.subject_index_count(s) for s in mine]
+        if mine:
+            counts[: len(mine)] = torch.tensor(local_counts, dtype=torch.int64, device=c.device)
+        all_counts = torch.zeros((c.world, nmax), dtype=torch.int64, device=c.device)
+        c.all_gather(all_counts, counts)
+        all_counts = all_counts.cpu().numpy()
+        imax = int(all_counts.max())
+        F = torch.zeros((nmax, L, D, V), dtype=torch.float64, device=c.device)
+        pp = torch.zeros((nmax, M), dtype=torch.int32, device=c.device)
+        pi = torch.zeros((nmax, max(imax, 1)), dtype=torch.int32, device=c.device)
+        for k, s in enumerate(mine):
+            if c.on_gpu:
+                group.export_subject_dev(s, F[k].data_ptr(), pp[k].data_ptr(), pi[k].data_ptr(), imax)
             else:
-                meta = torch.zeros(6, dtype=torch.int64, device=device)
-            dist.broadcast(meta, src=owner)
-            nF, npp, npi, L, D, V = (int(x) for x in meta.cpu().tolist())
-            tF = _tensor(F.ravel(), device) if owner == rank else torch.zeros(nF, dtype=torch.float64, device=device)
-            tI = (torch.as_tensor(np.concatenate([pptr, pidx]).astype(np.int32), device=device) if owner == rank
-                  else torch.zeros(npp + npi, dtype=torch.int32, device=device))
-            dist.broadcast(tF, src=owner)
-            dist.broadcast(tI, src=owner)
-            if owner != rank:
-                ints = tI.cpu().numpy()
-                group.import_subject(s, tF.cpu().numpy().reshape(L, D, V), ints[:npp], ints[npp:])
+                f, p, i = group.export_subject(s)
+                F[k] = torch.from_numpy(f)
+                pp[k] = torch.from_numpy(p)
+                pi[k, : len(i)] = torch.from_numpy(i)
+        if c.on_gpu:
+            torch.cuda.synchronize()
+        aF = torch.empty((c.world,) + tuple(F.shape), dtype=F.dtype, device=c.device)
+        app = torch.empty((c.world,) + tuple(pp.shape), dtype=pp.dtype, device=c.device)
+        api = torch.empty((c.world,) + tuple(pi.shape), dtype=pi.dtype, device=c.device)
+        c.all_gather(aF, F)
+        c.all_gather(app, pp)
+        c.all_gather(api, pi)
+        if c.on_gpu:
+            torch.cuda.synchronize()
+        for r in range(c.world):
+            if r == c.rank:
+                continue
+            for k, s in enumerate(shard(n_subjects, r, c.world)):
+                n = int(all_counts[r, k])
+                if c.on_gpu:
+                    group.import_subject_dev(s, aF[r, k].data_ptr(), app[r, k].data_ptr(), api[r, k].data_ptr(), n)
+                else:
+                    group.import_subject(s, aF[r, k].numpy(), app[r, k].numpy(), api[r, k, :n].numpy())
     group.finalize()
     return mine
+
+
+class ShardedMove:
+    """One label step of Fusion for the group with the cliques sharded over the ranks (see the module docstring).
+
+    move(labeling, label) evaluates this rank's slice of the 4 P pair costs and 8 T triplet costs and gathers all slices on
+    rank `dst`, which gets (pair_quads P x 4, triplet_octets T x 8) exactly as msm_group_fusion_move returns them; the other
+    ranks get (None, None).  Slices are padded to the largest one so that the gather is one fixed-size collective; with the
+    nccl backend the kernels write into the tensor the gather sends (no host copy on the sending ranks)."""
+
+    def __init__(self, group, comm=None, dst=0):
+        import torch
+
+        self.g, self.c, self.dst = group, _comm(comm), dst
+        c = self.c
+        self.prange = [shard(group.P, r, c.world) for r in range(c.world)]
+        self.trange = [shard(group.T, r, c.world) for r in range(c.world)]
+        self.pmax = max(len(r) for r in self.prange)
+        self.tmax = max(len(r) for r in self.trange)
+        dev = c.device if c.on_gpu else "cpu"
+        self.send = torch.zeros(4 * self.pmax + 8 * self.tmax, dtype=torch.float64, device=dev)
+        self.recv = torch.zeros((c.world, 4 * self.pmax + 8 * self.tmax), dtype=torch.float64, device=dev) if (c.rank == dst and c.world > 1) else None
+        self.gpu_scratch = None
+        if not c.on_gpu:  # rehearsal: the kernels still need device buffers; results are staged through the host
+            self.gpu_scratch = (torch.zeros(4 * self.pmax + 8 * self.tmax, dtype=torch.float64, device="cuda:%d" % torch.cuda.current_device())
+                                if torch.cuda.is_available() else None)
+
+    def move(self, labeling, label):
+        import torch
+
+        c, g = self.c, self.g
+        pr, tr = self.prange[c.rank], self.trange[c.rank]
+        buf = self.send if c.on_gpu else self.gpu_scratch
+        g.fusionMove_dev(labeling, label, (pr.start, pr.stop), (tr.start, tr.stop), buf.data_ptr(), buf.data_ptr() + 8 * 4 * self.pmax)
+        if not c.on_gpu:
+            self.send.copy_(buf)  # device -> host (gloo gathers host tensors)
+        if c.world == 1 or c.dist is None:
+            allbuf = self.send.reshape(1, -1)
+        else:
+            c.dist.gather(self.send, list(self.recv.unbind(0)) if c.rank == self.dst else None, dst=self.dst)
+            if c.rank != self.dst:
+                return None, None
+            allbuf = self.recv
+        host = allbuf.cpu().numpy()
+        quads = np.concatenate([host[r, : 4 * len(self.prange[r])] for r in range(c.world)]).reshape(g.P, 4)
+        octets = np.concatenate([host[r, 4 * self.pmax: 4 * self.pmax + 8 * len(self.trange[r])] for r in range(c.world)]).reshape(g.T, 8)
+        return quads, octets

@@ -98,3 +98,32 @@ def anatomical_inputs(ctx, inp, anat_order=None, seed=99):
     rt = 62.0 + 5.0 * synthetic.smooth_feature(axyz, 2, seed + 1) + 4.0 * synthetic.smooth_feature(axyz, 0, seed + 2)
     return dict(anat_order=anat_order, sphere_xyz=axyz, sphere_tri=atri, asource_xyz=d * rs[:, None], atarget_xyz=d * rt[:, None],
                 w_ptr=w_ptr, w_cp=w_cp, w_val=w_val, face_ptr=face_ptr, face_idx=face_idx)
+
+
+def build_group(ctx, S, data_order=6, cp_order=4, D=2, subjects=None, lambda_=0.2, simmeasure=2, seed=40):
+    """A synthetic groupwise (gMSM) problem part-way through a registration, BASELINE config 5 shape: S subjects on the data grid
+    ico<data_order>, each with its own smooth warp so far and D feature rows, the template = the regular sphere at data
+    resolution, control grid ico<cp_order>, the unrescaled sampling-grid labels (DiscreteGroupModel::setupCostFunction
+    M/DiscreteGroupModel.cpp:163-196).  `subjects` (optional): the subjects whose data this process holds (a shard); the others
+    are registered with their control grids only and must be imported.  Returns (group, keep-alive list)."""
+    dxyz, dtri = api.make_mesh_from_icosa(data_order)
+    cxyz, ctri = api.make_mesh_from_icosa(cp_order)
+    _, mvd = api.cp_spacings(cxyz, ctri)
+    samples, _ = api.label_sampling_grid(cp_order + 2, 0.5 * mvd)
+    g = api.DiscreteGroupCostFunction(ctx, S, simmeasure=simmeasure, lambda_=lambda_)
+    tm = api.Mesh(ctx, dxyz, dtri)
+    g.set_template(tm, None)
+    g.Initialize(cxyz, ctri)
+    keep = [tm]
+    mine = range(S) if subjects is None else subjects
+    for s in range(S):
+        if s in mine:
+            feat = synthetic.features(synthetic.known_warp(dxyz, seed=seed + 50 + s, rot_deg=2.0, amp=1.0), D, seed=5)
+            regular = api.Mesh(ctx, dxyz, dtri)
+            g.reset_meshspace(s, regular, feat)   # first call: _ORIG_MESHES = the regular sphere
+            regular.set_coords(synthetic.known_warp(dxyz, seed=seed + s, rot_deg=1.0 + 0.1 * s, amp=0.5))
+            g.reset_meshspace(s, regular, feat)
+            keep.append(regular)
+        g.reset_CPgrid(s, synthetic.known_warp(cxyz, seed=seed + s, rot_deg=1.0 + 0.1 * s, amp=0.5))
+    g.set_labels(samples)
+    return g, keep

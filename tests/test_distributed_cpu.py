@@ -76,7 +76,11 @@ GROUP_WORKER = textwrap.dedent("""
 
     class FakeGroup:
         \"\"\"stands in for DiscreteGroupCostFunction: per-subject products are deterministic functions of the subject id\"\"\"
+        L, D, N = 3, 2, 4                                    # 12 patch rows per subject
+        class _T: V = 42
+        _keep = {"template": _T}
         def __init__(self): self.have = {}; self.final = False
+        def subject_index_count(self, s): return len(self.have[s][2])
         @staticmethod
         def make(s):
             rng = np.random.default_rng(100 + s)

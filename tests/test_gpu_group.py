@@ -128,6 +128,36 @@ def test_group_fusion_move(ctx):
         assert abs(octets.ravel()[i] - want) <= ATOL + RTOL * abs(want)
 
 
+def test_group_eight_subjects_ico5(ctx):
+    """a larger group (BASELINE config 5 at its middle level: 8 subjects, ico5 data / ico3 control grid): pair list, patch
+    lists, inter-subject costs and a whole label step of Fusion against the oracle"""
+    g, og, _ = build(ctx, S=8, data_order=5, cp_order=3, D=2)
+    assert (g.num_nodes, g.P, g.T) == (8 * 642, 642 * 28, 8 * 1280)
+    assert np.array_equal(g.getPairs(), og.pairs())
+    rng = np.random.default_rng(21)
+    for s, v, l in zip(rng.integers(0, 8, 12), rng.integers(0, 642, 12), rng.integers(0, g.L, 12)):
+        ids, data = g.patch(s, v, l)
+        oids, odata = og.patch(s, v, l)
+        assert np.array_equal(ids, oids) and np.allclose(data, odata, rtol=1e-10, atol=1e-11)
+    labeling = rng.integers(0, g.L, g.num_nodes).astype(np.int32)
+    label = 11
+    quads, octets = g.fusionMove(labeling, label)
+    pairs, trips = g.getPairs(), g.getTriplets()
+    assert np.isfinite(quads).mean() > 0.9
+    for p in rng.integers(0, g.P, 300):
+        for k in range(4):
+            la = label if k & 2 else int(labeling[pairs[p, 0]])
+            lb = label if k & 1 else int(labeling[pairs[p, 1]])
+            want = og.pairwise(int(p), la, lb)
+            got = quads[p, k]
+            assert (np.isnan(want) and np.isnan(got)) or abs(got - want) <= ATOL + RTOL * abs(want), (p, k, got, want)
+    for t in rng.integers(0, g.T, 200):
+        for k in range(8):
+            lab3 = [label if k >> (2 - j) & 1 else int(labeling[trips[t, j]]) for j in range(3)]
+            want = og.triplet(int(t), *lab3)
+            assert abs(octets[t, k] - want) <= ATOL + RTOL * abs(want)
+
+
 def test_group_triplet_costs(ctx):
     g, og, _ = build(ctx, D=1)
     rng = np.random.default_rng(2)
@@ -172,9 +202,15 @@ p = rng.integers(0, g.P, 300).astype(np.int32); la = rng.integers(0, g.L, 300).a
 sharded = g.computePairwiseCost(p, la, lb)
 g1, keep1 = make(); g1.setupCostFunction()
 single = g1.computePairwiseCost(p, la, lb)
+# a label step with the pair and triplet lists sharded over the two ranks, gathered on rank 0 (M/DiscreteGroupCostFunction.cpp:54-98)
+lab = rng.integers(0, g.L, g.num_nodes).astype(np.int32)
+sm = D.ShardedMove(g, dist)
+q, o = sm.move(lab, 4)
+q1, o1 = g1.fusionMove(lab, 4)
+move_ok = True if rank != 0 else bool(np.array_equal(q, q1, equal_nan=True) and np.array_equal(o, o1))
 tmpl = D.group_template_update(np.stack([keep[1 + s].get_coords() for s in mine]), None, dist)
 dist.barrier()
-print(json.dumps({"rank": rank, "mine": mine, "equal": bool(np.array_equal(sharded, single, equal_nan=True)), "finite": int(np.isfinite(single).sum()),
+print(json.dumps({"rank": rank, "mine": mine, "equal": bool(np.array_equal(sharded, single, equal_nan=True)), "finite": int(np.isfinite(single).sum()), "move_ok": move_ok,
                   "template_radius_ok": bool(np.allclose(np.linalg.norm(tmpl["template"], axis=1), 100.0)), "n": tmpl["n_subjects"]}))
 dist.destroy_process_group()
 '''
@@ -196,5 +232,5 @@ def test_sharded_group_two_ranks_match_single_rank(tmp_path):
         so, se = pr.communicate(timeout=500)
         assert pr.returncode == 0, se[-3000:]
         outs.append(eval(so.strip().splitlines()[-1].replace("true", "True").replace("false", "False")))
-    assert all(o["equal"] and o["template_radius_ok"] and o["n"] == 4 and o["finite"] > 200 for o in outs), outs
+    assert all(o["equal"] and o["move_ok"] and o["template_radius_ok"] and o["n"] == 4 and o["finite"] > 200 for o in outs), outs
     assert sorted(outs[0]["mine"] + outs[1]["mine"]) == [0, 1, 2, 3]
