@@ -1,17 +1,16 @@
 #!/bin/bash
-# tools/collect_profile.sh TAG -- on the GPU box: per-kernel times (rocprofv3 --kernel-trace --stats) and the PMC
-# passes of MI355X_MICROARCH.md (one counter set per run, never together with API traces) for the default bench.py
-# workload; writes gpurun_out/prof_TAG, gpurun_out/pmc_TAG_* and the two summaries that get copied into profiles/:
-#   gpurun_out/TAG_kernel_stats.csv   gpurun_out/TAG_pmc.json
+# tools/collect_move_profile.sh TAG KIND D -- on the GPU box: per-kernel times (rocprofv3 --kernel-trace --stats) and the PMC passes of
+# MI355X_MICROARCH.md (one counter set per run) for the fusion move of an HO cost class (tools/time_fusion_move.py KIND D);
+# writes gpurun_out/TAG_kernel_stats.csv and gpurun_out/TAG_pmc.json (copied into profiles/ by hand).
 export TMPDIR=/tmp
-tag=$1
-B="python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extras"
+tag=$1; kind=$2; D=$3
+B="python3 tools/time_fusion_move.py $kind $D 100"
 run() { timeout -k 5 150 rocprofv3 "$@" -- $B > /dev/null 2>&1; }
-timeout -k 5 150 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$tag -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-extras > gpurun_out/prof_$tag.log 2>&1 || exit 1
+timeout -k 5 150 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$tag -- $B > gpurun_out/prof_$tag.log 2>&1 || exit 1
 run --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM_RD --output-format csv -d gpurun_out/pmc_${tag}_1 || exit 1
 run --kernel-trace --pmc SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_THREAD_CYCLES_VALU SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_WR --output-format csv -d gpurun_out/pmc_${tag}_2 || exit 1
 run --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_${tag}_3 || exit 1
 run --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d gpurun_out/pmc_${tag}_4 || exit 1
 run --kernel-trace --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/pmc_${tag}_5 || exit 1
 cp "$(find gpurun_out/prof_$tag -name '*kernel_stats.csv' | head -1)" gpurun_out/${tag}_kernel_stats.csv
-python3 tools/summarise_pmc.py $tag
+python3 tools/summarise_pmc.py $tag msm::k_ho_move "$B"

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/summarise_pmc.py TAG -- averages the rocprofv3 counter_collection.csv files of tools/collect_profile.sh per
+"""tools/summarise_pmc.py TAG [KERNEL_PREFIX [COMMAND]] -- averages the rocprofv3 counter_collection.csv files of tools/collect_profile.sh per
 kernel and writes gpurun_out/TAG_pmc.json (per-launch means, HBM traffic per launch, kernel time from the stats pass)."""
 import collections
 import csv
@@ -8,6 +8,8 @@ import json
 import sys
 
 tag = sys.argv[1]
+prefix = sys.argv[2] if len(sys.argv) > 2 else "msm::k_unary"
+command = sys.argv[3] if len(sys.argv) > 3 else "python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extras"
 per = collections.defaultdict(dict)
 for d in sorted(glob.glob("gpurun_out/pmc_%s_*" % tag)):
     for f in glob.glob(d + "/*/*counter_collection.csv"):
@@ -20,13 +22,13 @@ avg_ns = {}
 for r in csv.DictReader(open("gpurun_out/%s_kernel_stats.csv" % tag)):
     avg_ns[r["Name"].split("(")[0]] = float(r["AverageNs"])
 out = {
-    "command": "rocprofv3 --kernel-trace --pmc <one counter set per pass> -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline",
+    "command": "rocprofv3 --kernel-trace --pmc <one counter set per pass> -- " + command,
     "traffic_formula": "(2 * FETCH_SIZE + WRITE_SIZE) * 1024: FETCH_SIZE/WRITE_SIZE are reported in KiB; gfx950 FETCH_SIZE counts "
                        "half of the bytes of wide reads (MI355X_MICROARCH.md, HBM section)",
     "kernels": {},
 }
 for k, v in per.items():
-    if not k.startswith("msm::k_unary"):
+    if prefix not in k:
         continue
     e = {"per_launch_mean": v, "kernel_avg_ns_from_kernel_stats": avg_ns.get(k)}
     if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
