@@ -11,13 +11,19 @@
 //                                        the NonLinearSRegDiscreteCostFunction setters (:82-224); `kind` selects which of
 //                                        the five subclasses (:226-283) it stands for
 //   msmhip::DiscreteGroupModel           DiscreteGroupModel + DiscreteGroupCostFunction (M/DiscreteGroupModel.h:37-108)
+//   msmhip::FusionModel / GroupFusionModel   newmeshreg::DiscreteModel AS THE UNMODIFIED OPTIMISERS CALL IT (M/DiscreteModel.h:31-88):
+//                                        per-clique evaluators that are thread safe and O(1) -- Fusion::optimize's OpenMP
+//                                        loops (I/Fusion/Fusion.h:148-196) turn into ONE ABI call per label step behind them
 //
 // Conventions: points are AoS (x0 y0 z0 x1 ...) as in newresampler::Point containers and are transposed to the
 // ABI's SoA here; triangles are AoS (3 ids per triangle); data matrices are row-major D x V like
 // newresampler::Mesh::pvalues.  Errors are thrown as msmhip::Error carrying the reference's exception text.
 #pragma once
 
+#include <atomic>
 #include <cstdint>
+#include <mutex>
+#include <shared_mutex>
 #include <stdexcept>
 #include <string>
 #include <utility>
@@ -465,6 +471,258 @@ public:
 
 private:
     msm_group *h_ = nullptr;
+};
+
+// ---------------------------------------------------------------- the optimisers' view: newmeshreg::DiscreteModel
+// Fusion::optimize (I/Fusion/Fusion.h:122-244) asks for costs one clique at a time from OpenMP threads:
+//     2 N  computeUnaryCost(node, labeling[node] | label)                            :148-155
+//     4 P  computePairwiseCost(pair, labeling[A] | label, labeling[B] | label)       :164-174
+//     8 T  computeTripletCost(triplet, ... the eight combinations ...)               :181-196
+// per label step; FPD::FastPD reads getUnaryCosts() and calls computePairwiseCost on demand (I/FastPD/FastPD.h:126,213,224).
+// The classes below answer those calls without an edit of Fusion.h / FastPD.h: the first clique call of a label step finds
+// that its labels are not in the cached step, takes the lock, evaluates the WHOLE step with one ABI call (the proposed label
+// is the argument that differs from the model's labeling -- or, for the all-current combination Fusion asks first, the label
+// the unary sweep has just proposed) and every further call of the step, from any thread, is a table look-up under a shared
+// lock.  Correctness never depends on that guess: a call is served from the cache only if each of its labels equals the
+// cached labeling's or the cached proposed label at its node; anything else (total-cost sweeps with arbitrary labels, another
+// optimiser) is evaluated on its own.
+namespace detail {
+// pinned, GPU-mapped memory for the per-step buffers (msm_host_alloc): the kernels write the costs where the optimiser reads them
+class HostBuffer {
+public:
+    HostBuffer() = default;
+    HostBuffer(const HostBuffer &) = delete;
+    HostBuffer &operator=(const HostBuffer &) = delete;
+    ~HostBuffer() { release(); }
+    double *ensure(msm_ctx *ctx, size_t n) {
+        if (n > cap_) {
+            release();
+            ctx_ = ctx;
+            p_ = static_cast<double *>(msm_host_alloc(ctx, sizeof(double) * (n ? n : 1)));
+            if (!p_) throw Error(MSM_ERR_HIP, msm_last_error());
+            cap_ = n;
+        }
+        return p_;
+    }
+    double *data() const { return p_; }
+
+private:
+    void release() {
+        if (p_) msm_host_free(ctx_, p_);
+        p_ = nullptr;
+        cap_ = 0;
+    }
+    msm_ctx *ctx_ = nullptr;
+    double *p_ = nullptr;
+    size_t cap_ = 0;
+};
+}  // namespace detail
+
+struct FusionCounters {
+    std::atomic<long> step_calls{0};    // whole label steps evaluated (one ABI call each)
+    std::atomic<long> served{0};        // clique costs answered from a cached step / table
+    std::atomic<long> single_calls{0};  // clique costs that had to be evaluated on their own
+};
+
+// Pairwise registration: NonLinearSRegDiscreteModel (M/DiscreteModel.h:90-190) over a msmhip::DiscreteCostFunction.
+class FusionModel {
+public:
+    // costfct: fully set up (meshes, features, labels, cliques, get_source_data()); the model keeps the labeling
+    FusionModel(Context &ctx, DiscreteCostFunction &costfct, const std::vector<int32_t> &triplets, const std::vector<int32_t> &pairs)
+        : ctx_(ctx.handle()), cf_(costfct), triplets_(triplets), pairs_(pairs), labeling_(costfct.getNumNodes(), 0) {}
+
+    int getNumNodes() const { return cf_.getNumNodes(); }
+    int getNumLabels() const { return cf_.getNumLabels(); }
+    int getNumPairs() const { return (int)(pairs_.size() / 2); }
+    int getNumTriplets() const { return (int)(triplets_.size() / 3); }
+    int *getLabeling() { return labeling_.data(); }  // mutable, owned by the model (M/DiscreteModel.h:48)
+    const int *getPairs() const { return pairs_.data(); }
+    const int *getTriplets() const { return triplets_.data(); }
+
+    // setupCostFunction's tail (M/DiscreteModel.cpp:216-262): new labels / grid -> the cached step is void; the tables the
+    // optimisers read (unarycosts for FastPD / MCMC and the 2 N look-ups of Fusion; paircosts for FastPD's PAIR macro) are
+    // computed once here
+    void setupCostFunction(bool with_pair_table = false) {
+        std::unique_lock<std::shared_mutex> wr(mu_);
+        step_valid_ = false;
+        hint_.store(-1, std::memory_order_relaxed);
+        cf_.computeUnaryCosts();
+        have_pairs_ = false;
+        if (with_pair_table && getNumPairs() > 0) {
+            cf_.computePairwiseCosts();
+            have_pairs_ = true;
+        }
+    }
+    const double *getUnaryCosts() const { return cf_.unarycosts.data(); }  // unarycosts[label * numNodes + node]
+
+    double computeUnaryCost(int node, int label) {  // I/Fusion/Fusion.h:151-152
+        if (label != labeling_[(size_t)node]) hint_.store(label, std::memory_order_relaxed);  // the label this step proposes
+        counters.served.fetch_add(1, std::memory_order_relaxed);
+        return cf_.unarycosts[(size_t)label * getNumNodes() + node];
+    }
+    double computePairwiseCost(int pair, int labelA, int labelB) {  // regoption 1: I/FastPD/FastPD.h:213,224 / I/Fusion/Fusion.h:170-173
+        if (have_pairs_) {
+            counters.served.fetch_add(1, std::memory_order_relaxed);
+            return cf_.paircosts[((size_t)pair * getNumLabels() + labelB) * getNumLabels() + labelA];
+        }
+        std::unique_lock<std::shared_mutex> wr(mu_);
+        counters.single_calls.fetch_add(1, std::memory_order_relaxed);
+        return cf_.computePairwiseCost(pair, labelA, labelB);
+    }
+    double computeTripletCost(int triplet, int labelA, int labelB, int labelC) {  // I/Fusion/Fusion.h:188-195
+        const int32_t *n = &triplets_[3 * (size_t)triplet];
+        double v;
+        {
+            std::shared_lock<std::shared_mutex> rd(mu_);
+            if (lookup(triplet, n, labelA, labelB, labelC, v)) return v;
+        }
+        std::unique_lock<std::shared_mutex> wr(mu_);
+        if (lookup(triplet, n, labelA, labelB, labelC, v)) return v;  // another thread has evaluated the step meanwhile
+        int label = labelA != labeling_[n[0]] ? labelA : (labelB != labeling_[n[1]] ? labelB : (labelC != labeling_[n[2]] ? labelC : hint_.load(std::memory_order_relaxed)));
+        const bool fits = label >= 0 && label < getNumLabels() && (labelA == labeling_[n[0]] || labelA == label) && (labelB == labeling_[n[1]] || labelB == label) &&
+                          (labelC == labeling_[n[2]] || labelC == label);
+        if (fits) {  // a new label step: all 8 T costs with one call, into the buffer the kernel writes directly
+            step_lab_ = labeling_;
+            step_label_ = label;
+            double *E = octets_.ensure(ctx_, 8 * triplets_.size() / 3);
+            check(msm_cost_triplet_octets(cf_.handle(), step_lab_.data(), label, E));
+            step_valid_ = true;
+            counters.step_calls.fetch_add(1, std::memory_order_relaxed);
+            if (lookup(triplet, n, labelA, labelB, labelC, v)) return v;
+        }
+        counters.single_calls.fetch_add(1, std::memory_order_relaxed);  // not part of a fusion move: on its own
+        return cf_.computeTripletCost(triplet, labelA, labelB, labelC);
+    }
+    double evaluateTotalCostSum() {  // M/DiscreteCostFunction.cpp:55-77 over the model's labeling
+        std::unique_lock<std::shared_mutex> wr(mu_);
+        return cf_.evaluateTotalCostSum(labeling_);
+    }
+    FusionCounters counters;
+
+private:
+    bool lookup(int t, const int32_t *n, int la, int lb, int lc, double &v) {
+        if (!step_valid_) return false;
+        int k = 0;
+        const int arg[3] = {la, lb, lc};
+        for (int j = 0; j < 3; ++j) {
+            const int cur = step_lab_[(size_t)n[j]];
+            if (arg[j] == cur) k = 2 * k;  // also when cur == the proposed label: both combinations cost the same
+            else if (arg[j] == step_label_) k = 2 * k + 1;
+            else return false;
+        }
+        v = octets_.data()[8 * (size_t)t + k];
+        counters.served.fetch_add(1, std::memory_order_relaxed);
+        return true;
+    }
+    msm_ctx *ctx_;
+    DiscreteCostFunction &cf_;
+    std::vector<int32_t> triplets_, pairs_, labeling_;
+    std::shared_mutex mu_;
+    std::atomic<int> hint_{-1};
+    bool step_valid_ = false, have_pairs_ = false;
+    std::vector<int32_t> step_lab_;
+    int step_label_ = -1;
+    detail::HostBuffer octets_;
+};
+
+// Groupwise registration: DiscreteGroupModel (M/DiscreteGroupModel.h:37-108) as Fusion::optimize calls it.  computeUnaryCost is 0
+// (M/DiscreteGroupCostFunction.h), pairs and triplets of a label step come from one msm_group_fusion_move.
+class GroupFusionModel {
+public:
+    GroupFusionModel(Context &ctx, DiscreteGroupModel &model) : ctx_(ctx.handle()), m_(model) { refresh_sizes(); }
+    void setupCostFunction() {  // M/DiscreteGroupModel.cpp:163-196
+        std::unique_lock<std::shared_mutex> wr(mu_);
+        m_.setupCostFunction();
+        refresh_sizes();
+        pairs_ = m_.getPairs();
+        triplets_ = m_.getTriplets();
+        step_valid_ = false;
+        hint_.store(-1, std::memory_order_relaxed);
+    }
+    int getNumNodes() const { return nodes_; }
+    int getNumPairs() const { return (int)(pairs_.size() / 2); }
+    int getNumTriplets() const { return (int)(triplets_.size() / 3); }
+    int *getLabeling() { return labeling_.data(); }
+    const int *getPairs() const { return pairs_.data(); }
+    const int *getTriplets() const { return triplets_.data(); }
+
+    double computeUnaryCost(int node, int label) {
+        if (label != labeling_[(size_t)node]) hint_.store(label, std::memory_order_relaxed);
+        return 0.0;
+    }
+    double computePairwiseCost(int pair, int labelA, int labelB) {  // M/DiscreteGroupCostFunction.cpp:54-98
+        const int32_t *n = &pairs_[2 * (size_t)pair];
+        const int arg[2] = {labelA, labelB};
+        double v;
+        {
+            std::shared_lock<std::shared_mutex> rd(mu_);
+            if (lookup(quads_.data(), 4, pair, n, arg, 2, v)) return v;
+        }
+        std::unique_lock<std::shared_mutex> wr(mu_);
+        if (lookup(quads_.data(), 4, pair, n, arg, 2, v)) return v;
+        if (new_step(n, arg, 2) && lookup(quads_.data(), 4, pair, n, arg, 2, v)) return v;
+        counters.single_calls.fetch_add(1, std::memory_order_relaxed);
+        return m_.computePairwiseCost({pair}, {labelA}, {labelB})[0];
+    }
+    double computeTripletCost(int triplet, int labelA, int labelB, int labelC) {  // M/DiscreteGroupCostFunction.cpp:26-52
+        const int32_t *n = &triplets_[3 * (size_t)triplet];
+        const int arg[3] = {labelA, labelB, labelC};
+        double v;
+        {
+            std::shared_lock<std::shared_mutex> rd(mu_);
+            if (lookup(octets_.data(), 8, triplet, n, arg, 3, v)) return v;
+        }
+        std::unique_lock<std::shared_mutex> wr(mu_);
+        if (lookup(octets_.data(), 8, triplet, n, arg, 3, v)) return v;
+        if (new_step(n, arg, 3) && lookup(octets_.data(), 8, triplet, n, arg, 3, v)) return v;
+        counters.single_calls.fetch_add(1, std::memory_order_relaxed);
+        return m_.computeTripletCost({triplet}, {labelA}, {labelB}, {labelC})[0];
+    }
+    FusionCounters counters;
+
+private:
+    void refresh_sizes() {
+        nodes_ = m_.getNumNodes();
+        labeling_.resize((size_t)nodes_, 0);
+    }
+    bool lookup(const double *buf, int width, int clique, const int32_t *n, const int *arg, int arity, double &v) {
+        if (!step_valid_) return false;
+        int k = 0;
+        for (int j = 0; j < arity; ++j) {
+            const int cur = step_lab_[(size_t)n[j]];
+            if (arg[j] == cur) k = 2 * k;
+            else if (arg[j] == step_label_) k = 2 * k + 1;
+            else return false;
+        }
+        v = buf[(size_t)width * clique + k];
+        counters.served.fetch_add(1, std::memory_order_relaxed);
+        return true;
+    }
+    bool new_step(const int32_t *n, const int *arg, int arity) {  // called with the lock held
+        int label = hint_.load(std::memory_order_relaxed);
+        for (int j = arity - 1; j >= 0; --j)
+            if (arg[j] != labeling_[(size_t)n[j]]) label = arg[j];
+        if (label < 0) return false;
+        for (int j = 0; j < arity; ++j)
+            if (arg[j] != labeling_[(size_t)n[j]] && arg[j] != label) return false;
+        step_lab_ = labeling_;
+        step_label_ = label;
+        double *q = quads_.ensure(ctx_, 4 * pairs_.size() / 2), *o = octets_.ensure(ctx_, 8 * triplets_.size() / 3);
+        check(msm_group_fusion_move(m_.handle(), step_lab_.data(), label, q, o));
+        step_valid_ = true;
+        counters.step_calls.fetch_add(1, std::memory_order_relaxed);
+        return true;
+    }
+    msm_ctx *ctx_;
+    DiscreteGroupModel &m_;
+    int nodes_ = 0;
+    std::vector<int32_t> pairs_, triplets_, labeling_;
+    std::shared_mutex mu_;
+    std::atomic<int> hint_{-1};
+    bool step_valid_ = false;
+    std::vector<int32_t> step_lab_;
+    int step_label_ = -1;
+    detail::HostBuffer quads_, octets_;
 };
 
 }  // namespace msmhip

@@ -137,3 +137,140 @@ def test_cpp_host_mirror_against_oracle(built, tmp_path, D):
     assert tuple(got["unfold_counts"]) == O.unfold(fm) and got["unfold_counts"][1] >= 1
     assert np.array_equal(got["unfolded_cp"].reshape(-1, 3), fm.xyz)
     assert np.array_equal(got["normed"].reshape(D, -1), O.variance_normalise(inp["src_feat"]))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The unmodified optimiser's call pattern against msmhip::FusionModel / GroupFusionModel (tests/cpp/fusion_replay.cpp)
+FUSION_SRC = os.path.join(ROOT, "tests", "cpp", "fusion_replay.cpp")
+FUSION_EXE = os.path.join(ROOT, "tests", "cpp", "fusion_replay")
+
+
+def build_fusion_replay():
+    cmd = ["g++", "-std=c++17", "-O1", "-fopenmp", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"), FUSION_SRC, "-o", FUSION_EXE, "-L", LIBDIR,
+           "-lmsmhip", "-Wl,-rpath," + LIBDIR, "-Wl,-rpath,/opt/rocm/lib"]
+    subprocess.check_call(cmd)
+
+
+def test_fusion_replay_compiles_without_gpu(built):
+    build_fusion_replay()
+
+
+def pseudo_optimiser(labeling, label, rng_state):
+    """the stand-in for ELC + FastPD of fusion_replay.cpp: a fixed pseudo-random third of the nodes takes the proposed label"""
+    lab = labeling.copy()
+    for node in range(len(lab)):
+        rng_state = (rng_state * 1664525 + 1013904223) & 0xFFFFFFFF
+        if lab[node] != label and (rng_state >> 24) % 3 == 0:
+            lab[node] = label
+    return lab, rng_state
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,D,rmode", [("ho_univariate", 1, 3), ("ho_multivariate", 16, 3), ("univariate", 1, 3), ("univariate", 1, 1)])
+def test_fusion_loops_through_the_adapter(built, tmp_path, kind, D, rmode):
+    """Fusion::optimize's three OpenMP loops (8 threads, 2 sweeps over all labels), unmodified, over msmhip::FusionModel: every buffer
+    they fill equals the oracle's replay of the same calls, with ONE ABI call per label step and no clique evaluated on its own"""
+    from newmsm_amd.api import KINDS
+
+    build_fusion_replay()
+    inp = problem.pairwise_inputs(4, 2, D=D)
+    par = dict(lambda_=0.05, mu=0.4, kappa=1.6, k_exp=2.0, rexp=2.0)
+    fin, fout = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+    write_bag(fin, orders=np.array([0, 4, 2, D, 8, 2, KINDS[kind], rmode]), params=np.array([par["lambda_"], par["mu"], par["kappa"], par["k_exp"], par["rexp"]]),
+              target_xyz=inp["target_xyz"], ref_feat=inp["ref_feat"], src_feat=inp["src_feat"], source_xyz=inp["source_xyz"], cp_xyz=inp["cp_xyz"],
+              maxsep=inp["maxsep"], mvdmax=np.array([inp["mvdmax"]]), labels=inp["labels"], rot=inp["rot"], triplets=inp["triplets"], pairs=inp["pairs"])
+    run = subprocess.run([FUSION_EXE, fin, fout], capture_output=True, text=True, timeout=600, env=dict(os.environ, OMP_NUM_THREADS="8"))
+    assert run.returncode == 0, run.stderr + run.stdout
+    got = read_bag(fout)
+    oc = oracle_cost(inp, kind, rmode=rmode, **par)
+    if rmode == 1:
+        oc.set_triplets(np.zeros((0, 3), dtype=np.int32))
+    else:
+        oc.set_pairs(np.zeros((0, 2), dtype=np.int32))
+    oc.get_source_data()
+    N, L, T, P = len(inp["cp_xyz"]), len(inp["labels"]), (len(inp["triplets"]) if rmode != 1 else 0), (len(inp["pairs"]) if rmode == 1 else 0)
+    steps = got["steps"]
+    labelings = got["labelings"].reshape(len(steps), N)
+    assert len(steps) >= 2 * L - 2  # a step is skipped only when every node already holds its label
+    U = oc.unary_table()
+    lab, state = np.zeros(N, dtype=np.int32), 12345
+    unary, trip, pairs = got["unary"].reshape(len(steps), N, 2), got["triplets"].reshape(len(steps), T, 8), got["pairs"].reshape(len(steps), P, 4)
+    si = 0
+    for sweep in range(2):
+        for label in range(L):
+            if np.abs(label - lab).sum() == 0:
+                continue
+            assert steps[si] == label and np.array_equal(labelings[si], lab)
+            assert np.allclose(unary[si, :, 0], U[lab, np.arange(N)], rtol=1e-9, atol=1e-11) and np.allclose(unary[si, :, 1], U[label], rtol=1e-9, atol=1e-11)
+            if T and si % 7 == 0:  # the oracle's replay of the 8 T calls (every seventh step: the oracle is the slow side)
+                want = oc.triplet_octets(lab, label, threads=8)
+                assert np.allclose(trip[si], want, rtol=1e-9, atol=1e-11), np.abs(trip[si] - want).max()
+            if P and si % 7 == 0:
+                pr = inp["pairs"]
+                for p in range(0, P, 5):
+                    a, b = int(lab[pr[p, 0]]), int(lab[pr[p, 1]])
+                    want = [oc.pairwise(p, a, b), oc.pairwise(p, a, label), oc.pairwise(p, label, b), oc.pairwise(p, label, label)]
+                    assert np.allclose(pairs[si, p], want, rtol=1e-9, atol=1e-11)
+            lab, state = pseudo_optimiser(lab, label, state)
+            si += 1
+    assert si == len(steps)
+    want_total = oc.total(lab)[0]
+    assert abs(got["total"][0] - want_total) <= 1e-9 * abs(want_total) + 1e-11
+    step_calls, single_calls, served = got["counts"]
+    assert single_calls == 0
+    assert step_calls == (len(steps) if T else 0)  # exactly one msm_cost_triplet_octets per label step; pair costs come from the table
+
+
+@pytest.mark.gpu
+def test_group_fusion_loops_through_the_adapter(built, tmp_path):
+    """the same for gMSM: 4 P pair + 8 T triplet calls per label step from 8 threads over msmhip::GroupFusionModel -> one
+    msm_group_fusion_move per step; buffers against the oracle's evaluators"""
+    import newmsm_amd as M
+    from newmsm_amd import synthetic
+
+    build_fusion_replay()
+    S, D, data_order, cp_order = 3, 2, 4, 2
+    dxyz, dtri = M.make_mesh_from_icosa(data_order)
+    cxyz, ctri = M.make_mesh_from_icosa(cp_order)
+    _, mvd = M.cp_spacings(cxyz, ctri)
+    samples, _ = M.label_sampling_grid(cp_order + 2, 0.5 * mvd)
+    sph = np.stack([synthetic.known_warp(dxyz, seed=40 + s, rot_deg=1.0 + s, amp=0.5) for s in range(S)])
+    feat = np.stack([synthetic.features(synthetic.known_warp(dxyz, seed=90 + s, rot_deg=2.0, amp=1.0), D, seed=5) for s in range(S)])
+    cps = np.stack([synthetic.known_warp(cxyz, seed=40 + s, rot_deg=1.0 + s, amp=0.5) for s in range(S)])
+    fin, fout = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+    write_bag(fin, orders=np.array([1, data_order, cp_order, D, 8, 1, S]), params=np.array([0.2]), labels=samples, sph=sph, feat=feat, cp=cps)
+    run = subprocess.run([FUSION_EXE, fin, fout], capture_output=True, text=True, timeout=600, env=dict(os.environ, OMP_NUM_THREADS="8"))
+    assert run.returncode == 0, run.stderr + run.stdout
+    got = read_bag(fout)
+    og = O.Group(S, simmeasure=2, lambda_=0.2)
+    keep = [O.Mesh(dxyz, dtri)]
+    og.set_template(keep[0], None)
+    og.set_controlgrid(O.Mesh(cxyz, ctri))
+    for s in range(S):
+        om = O.Mesh(dxyz, dtri)
+        og.set_subject(s, om, feat[s])
+        om.set_coords(sph[s])
+        og.set_subject(s, om, feat[s])
+        og.reset_cpgrid(s, cps[s])
+        keep.append(om)
+    og.set_labels(samples)
+    og.setup()
+    N, L, P, T = og.num_nodes, len(samples), og.P, og.T
+    steps = got["steps"]
+    labelings = got["labelings"].reshape(len(steps), N)
+    quads, octs = got["pairs"].reshape(len(steps), P, 4), got["triplets"].reshape(len(steps), T, 8)
+    pr, tr = og.pairs(), og.triplets()
+    rng = np.random.default_rng(3)
+    for si in range(0, len(steps), 5):
+        lab, label = labelings[si], int(steps[si])
+        for p in rng.integers(0, P, 40):
+            a, b = int(lab[pr[p, 0]]), int(lab[pr[p, 1]])
+            want = np.array([og.pairwise(int(p), a, b), og.pairwise(int(p), a, label), og.pairwise(int(p), label, b), og.pairwise(int(p), label, label)])
+            assert np.allclose(quads[si, p], want, rtol=1e-9, atol=1e-11, equal_nan=True)
+        for t in rng.integers(0, T, 40):
+            for k in range(8):
+                l3 = [label if k >> (2 - j) & 1 else int(lab[tr[t, j]]) for j in range(3)]
+                w = og.triplet(int(t), *l3)
+                assert abs(octs[si, t, k] - w) <= 1e-11 + 1e-9 * abs(w)
+    step_calls, single_calls, served = got["counts"]
+    assert single_calls == 0 and step_calls == len(steps)
