@@ -127,6 +127,10 @@ int       msm_mesh_set_features(msm_mesh *m, const double *feat, int32_t D); /* 
 int       msm_mesh_sizes(const msm_mesh *m, int32_t *V, int32_t *T, int32_t *D);
 /* [host part] stats[0]=nodes [1]=leaves [2]=max depth (root 0) [3]=triangle references [4]=largest leaf */
 int       msm_mesh_octree_stats(msm_mesh *m, int64_t stats[5]);
+/* testing hook: stats + the leaf signature of msm_octree_signature, computed from the tree as it sits in HBM.  Trees of
+ * meshes with >= 8192 triangles are built on the GPU (level by level, the same leaves in the same order); MSMHIP_OCTREE=host|gpu
+ * forces one of the two builds. */
+int       msm_mesh_octree_signature(msm_mesh *m, int64_t stats[5], uint64_t *signature);
 /* Builds the search structures a cost function uses on this mesh as its target (octree, and for a closed star-shaped
  * surface the direction table that settles most searches with one lookup).  The direction table takes tens of ms of
  * host time, so by default it is built on a background thread when a cost function first evaluates against the mesh,

@@ -69,6 +69,7 @@ SIGNATURES = {
     "msm_mesh_set_features": (C.c_int, [_VP, c_dp, C.c_int32]),
     "msm_mesh_sizes": (C.c_int, [_VP, c_ip, c_ip, c_ip]),
     "msm_mesh_octree_stats": (C.c_int, [_VP, c_lp]),
+    "msm_mesh_octree_signature": (C.c_int, [_VP, c_lp, C.POINTER(C.c_uint64)]),
     "msm_query_triangles": (C.c_int, [_VP, c_dp, C.c_int32, c_ip, c_ip, c_dp, C.c_int]),
     "msm_closest_vertex": (C.c_int, [_VP, c_dp, C.c_int32, c_ip]),
     "msm_adaptive_barycentric_weights": (C.c_int, [_VP, _VP, c_dp, c_ip, c_ip, c_dp, C.c_int64, c_lp]),

@@ -238,6 +238,13 @@ class Mesh:
         check(lib().msm_mesh_octree_stats(self.h, s))
         return dict(nodes=s[0], leaves=s[1], depth=s[2], refs=s[3], max_leaf=s[4])
 
+    def octree_signature(self):
+        """(stats, leaf signature) of the tree as it sits in HBM -- comparable with octree_signature(xyz, tri) of the host build"""
+        s = (C.c_int64 * 5)()
+        sig = C.c_uint64()
+        check(lib().msm_mesh_octree_signature(self.h, s, C.byref(sig)))
+        return dict(nodes=s[0], leaves=s[1], depth=s[2], refs=s[3], max_leaf=s[4]), sig.value
+
     # Octree::get_closest_triangle + get_barycentric_weights
     def query_triangles(self, q, mode=WEIGHTS_PROJECTED, check_status=True):
         x, px = _soa(q)

@@ -117,12 +117,27 @@ static int upload_tree(msm_mesh *m) {
         int st = launch_build_recs(ctx, m->d_xyz, m->V, m->d_tri, m->T, m->d_rec, m->d_tcone, m->d_leaf_tri, (int)m->tree.leaf_tri.size(), m->d_cone);
         if (st) return st;
     }
+    MSM_HIP(hipStreamSynchronize(ctx->stream));
+    return finish_tree(m);
+}
+
+int finish_tree(msm_mesh *m) {
     m->masks_valid = false;
     m->rays_valid = false;
+    m->rayrec_valid = false;
     ++m->tree_gen;  // a ray table still being built for the previous tree will be dropped
-    MSM_HIP(hipStreamSynchronize(ctx->stream));
     m->tree_valid = true;
     return MSM_OK;
+}
+
+// Meshes of this size and above get their tree built on the GPU (octree_kernels.hip): below it the host build takes less
+// than the dozen launches of the level loop.  MSMHIP_OCTREE=host|gpu forces one of them (tests compare the two).
+static bool tree_on_gpu(const msm_mesh *m) {
+    static const int mode = [] {
+        const char *e = std::getenv("MSMHIP_OCTREE");
+        return !e ? 0 : (std::strcmp(e, "host") == 0 ? 1 : (std::strcmp(e, "gpu") == 0 ? 2 : 0));
+    }();
+    return mode == 2 || (mode == 0 && m->T >= 8192);
 }
 
 int upload_staged(msm_ctx *ctx, void *dst, const void *src, size_t bytes) {
@@ -141,6 +156,11 @@ int upload_staged(msm_ctx *ctx, void *dst, const void *src, size_t bytes) {
 
 int ensure_tree(msm_mesh *m) {
     if (m->tree_valid) return MSM_OK;
+    if (tree_on_gpu(m)) {
+        const int st = gpu_build_octree(m);
+        if (st == MSM_OK) return finish_tree(m);
+        if (st != MSM_ERR_CAPACITY) return st;  // a tree that outgrew the preallocated arrays (a degenerate mesh): the host build below
+    }
     build_octree(m->xyz.data(), m->tri.data(), m->V, m->T, m->tree);
     return upload_tree(m);
 }
@@ -216,8 +236,25 @@ int ensure_rays(msm_mesh *m, bool wait) {
     if (m->ray_job && m->ray_job->gen != m->tree_gen) retire_ray_job(m);
     const char *mode = std::getenv("MSMHIP_RAYTABLE");
     if (mode && std::strcmp(mode, "off") == 0) return MSM_OK;
+    auto take_rays = [&](FlatOctree &b) {
+        m->tree.simple = b.simple;
+        m->tree.ray_G = b.ray_G;
+        m->tree.ray_r2lo = b.ray_r2lo;
+        m->tree.ray_r2hi = b.ray_r2hi;
+        m->tree.ray_cell = std::move(b.ray_cell);
+        m->tree.ray_edge = std::move(b.ray_edge);
+        m->tree.ray_more = std::move(b.ray_more);
+        m->tree.ray_excl = std::move(b.ray_excl);
+    };
     if (!m->ray_job && (wait || !ray_build_in_background())) {
-        build_ray_table(m->xyz.data(), m->tri.data(), m->V, m->T, m->tree);
+        if (m->tree.node.empty()) {  // the tree was built on the GPU: the table's builder walks a host copy of the same tree
+            FlatOctree host_tree;
+            build_octree(m->xyz.data(), m->tri.data(), m->V, m->T, host_tree);
+            build_ray_table(m->xyz.data(), m->tri.data(), m->V, m->T, host_tree);
+            take_rays(host_tree);
+        } else {
+            build_ray_table(m->xyz.data(), m->tri.data(), m->V, m->T, m->tree);
+        }
     } else {
         if (!m->ray_job) {
             auto job = std::make_shared<RayJob>();
@@ -228,6 +265,7 @@ int ensure_rays(msm_mesh *m, bool wait) {
             const int32_t *tri = m->tri.data();  // triangles never change; the job is joined before the mesh goes
             const int V = m->V, T = m->T;
             job->th = std::thread([j, tri, V, T]() {
+                if (j->tree.node.empty()) build_octree(j->xyz.data(), tri, V, T, j->tree);  // a GPU-built tree has no host arrays
                 build_ray_table(j->xyz.data(), tri, V, T, j->tree);
                 j->done.store(true, std::memory_order_release);
             });
@@ -235,15 +273,7 @@ int ensure_rays(msm_mesh *m, bool wait) {
         }
         if (!wait && !m->ray_job->done.load(std::memory_order_acquire)) return MSM_OK;  // not yet: the complete search serves this call
         m->ray_job->th.join();
-        FlatOctree &b = m->ray_job->tree;
-        m->tree.simple = b.simple;
-        m->tree.ray_G = b.ray_G;
-        m->tree.ray_r2lo = b.ray_r2lo;
-        m->tree.ray_r2hi = b.ray_r2hi;
-        m->tree.ray_cell = std::move(b.ray_cell);
-        m->tree.ray_edge = std::move(b.ray_edge);
-        m->tree.ray_more = std::move(b.ray_more);
-        m->tree.ray_excl = std::move(b.ray_excl);
+        take_rays(m->ray_job->tree);
         m->ray_job.reset();
     }
     if (m->tree.ray_G > 0) {
@@ -297,7 +327,7 @@ DevTree dev_tree(const msm_mesh *m) {
     t.grid_depth = m->tree.grid_depth;
     t.mask = m->masks_valid ? m->d_mask : nullptr;
     t.simple = m->tree.simple ? 1 : 0;
-    t.nnodes = (int)m->tree.node.size();
+    t.nnodes = m->tree.nnodes();
     t.ray_G = m->rays_valid ? m->tree.ray_G : 0;
     t.ray_cell = m->d_ray_cell;
     t.ray_tri = m->d_ray_tri;
@@ -567,6 +597,10 @@ void msm_ctx_destroy(msm_ctx *ctx) {
     if (ctx->stage) (void)hipHostFree(ctx->stage);
     if (ctx->io_pin) (void)hipHostFree(ctx->io_pin);
     if (ctx->h_flag) (void)hipHostFree(ctx->h_flag);
+    if (ctx->oct_box) (void)hipFree(ctx->oct_box);
+    if (ctx->oct_ints) (void)hipFree(ctx->oct_ints);
+    if (ctx->oct_counters) (void)hipFree(ctx->oct_counters);
+    if (ctx->oct_hcounters) (void)hipHostFree(ctx->oct_hcounters);
     for (auto &b : ctx->host_blocks) (void)hipHostFree(b.host);
     if (ctx->d_status) (void)hipFree(ctx->d_status);
     if (ctx->h_status) (void)hipHostFree(ctx->h_status);
@@ -712,6 +746,37 @@ int msm_mesh_octree_stats(msm_mesh *m, int64_t stats[5]) {
     int st = ensure_tree(m);
     if (st) return st;
     std::copy(m->tree.stats, m->tree.stats + 5, stats);
+    return MSM_OK;
+}
+
+// testing hook: the tree as it sits in HBM (whichever build made it) -- the same leaf signature as msm_octree_signature
+int msm_mesh_octree_signature(msm_mesh *m, int64_t stats[5], uint64_t *signature) {
+    if (!m || !signature) return fail(MSM_ERR_INVALID, "msm_mesh_octree_signature: null argument");
+    int st = ensure_tree(m);
+    if (st) return st;
+    if (stats) std::copy(m->tree.stats, m->tree.stats + 5, stats);
+    const int n = m->tree.nnodes(), ne = m->tree.nentries();
+    std::vector<int4> node(n);
+    std::vector<double4> box(n);
+    std::vector<int32_t> leaf((size_t)std::max(ne, 1));
+    MSM_HIP(hipMemcpy(node.data(), m->d_node, sizeof(int4) * (size_t)n, hipMemcpyDeviceToHost));
+    MSM_HIP(hipMemcpy(box.data(), m->d_nodebox, sizeof(double4) * (size_t)n, hipMemcpyDeviceToHost));
+    if (ne > 0) MSM_HIP(hipMemcpy(leaf.data(), m->d_leaf_tri, sizeof(int32_t) * (size_t)ne, hipMemcpyDeviceToHost));
+    uint64_t sum = 0;
+    for (int i = 0; i < n; ++i) {
+        if (node[i].x >= 0) continue;
+        uint64_t h = 1469598103934665603ull;
+        auto mix = [&](uint64_t v) {
+            for (int k = 0; k < 8; ++k) {
+                h ^= (v >> (8 * k)) & 0xff;
+                h *= 1099511628211ull;
+            }
+        };
+        for (double d : {box[i].x, box[i].y, box[i].z, box[i].w}) mix((uint64_t)__builtin_bit_cast(uint64_t, d));
+        for (int e = 0; e < -node[i].x - 1; ++e) mix((uint64_t)leaf[node[i].y + e]);
+        sum += h;
+    }
+    *signature = sum;
     return MSM_OK;
 }
 

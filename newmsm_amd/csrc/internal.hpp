@@ -79,6 +79,10 @@ struct FlatOctree {
     std::vector<int4> ray_excl;      // up to three leaf boxes a query must not lie in for its triangle to be vouched for (.w = count)
     double ray_r2lo = 0, ray_r2hi = 0;  // squared radius range of the query points the table is valid for
     int64_t stats[5] = {0, 0, 0, 0, 0};
+    // a tree built on the GPU (octree_kernels.hip) has no host arrays: `node` etc. stay empty and these describe it
+    int dev_nnodes = 0, dev_entries = 0;
+    int nnodes() const { return node.empty() ? dev_nnodes : (int)node.size(); }
+    int nentries() const { return node.empty() ? dev_entries : (int)leaf_tri.size(); }
 };
 // builds the tree exactly as Octree::initialize_tree / add_triangle do (R/octree.cpp:42-141)
 void build_octree(const double *xyz /*3 x V SoA*/, const int32_t *tri /*3 x T SoA*/, int V, int T, FlatOctree &out);
@@ -127,6 +131,10 @@ struct msm_ctx {
     // a mapped pinned word kernels of the per-label-step calls store a raised status into (no status copy on their fast path)
     int *h_flag = nullptr;
     int *d_flag_map = nullptr;  // its device address
+    // scratch of the GPU octree build (octree_kernels.hip), grow only
+    double *oct_box = nullptr;
+    int *oct_ints = nullptr, *oct_counters = nullptr, *oct_hcounters = nullptr;
+    size_t oct_cap_box = 0, oct_cap_ints = 0;
     // msm_host_alloc blocks: pinned host memory the GPU writes results into directly
     struct HostBlock {
         char *host;
@@ -195,6 +203,8 @@ void adaptive_surgery(const AdaptiveQueries &q, int nOld, int nNew, const std::v
 void vertex_areas_of(const double *xyz, const int32_t *tri, int V, int T, const Adjacency &a, std::vector<double> &area);
 int install_coords_and_tree(msm_mesh *m, const double *xyz, FlatOctree &&tree);
 int ensure_tree(msm_mesh *m);  // build + upload the search structure if stale
+int gpu_build_octree(msm_mesh *m);  // octree_kernels.hip: the same tree built in HBM from the mesh's device coordinates (MSM_ERR_CAPACITY: use the host build)
+int finish_tree(msm_mesh *m);       // what follows either build: validity flags, generation
 int ensure_masks(msm_mesh *m);  // + the per-leaf sub-cell masks the cost kernels use (built on the GPU)
 int ensure_rays(msm_mesh *m, bool wait = false);   // + the ray table of a simple surface (unary table kernels); see api.cpp
 DevTree dev_tree(const msm_mesh *m);

@@ -1,0 +1,430 @@
+// octree_kernels.hip -- newresampler::Octree (R/octree.cpp:31-141, R/node.cpp) built on the GPU, level by level.
+//
+// The reference inserts the triangles one by one; the tree that results is decided per node by one scan of the triangles
+// whose boxes overlap it, in ascending id (octree.cpp: Builder::build_down states why): a node becomes internal iff the
+// split heuristic `num_split > 0 && total_size < 3 n` holds at some insertion from the 50th on, and its children then
+// receive, in order, the triangles of its WHOLE list that overlap them.  That is a level-synchronous computation:
+//   k_oct_decide   a wavefront per open node scans its list (wave prefix sums of the heuristic's two running sums) and,
+//                  for a node that splits, counts what each child will receive;
+//   k_oct_scan     one workgroup turns the decisions of the level into node numbers, list offsets and leaf slots
+//                  (prefix sums in node order: the tree's numbering does not depend on scheduling);
+//   k_oct_fill     a wavefront per open node writes the children's lists (ballot-ordered compaction, ids stay
+//                  ascending) or, for a leaf, its entries into the leaf array (padded to 8 with -1).
+// Child boxes are exact halvings of (-101, 101), so every box is reproduced bit for bit from (lower corner, edge).
+// The host build (octree.cpp) takes 3.5 ms per ico6 mesh on sixteen threads -- every iteration of a registration builds one
+// for the moved source, gMSM nineteen per subject -- plus the upload of its arrays; this one leaves them where the search
+// kernels read them.  tests/test_gpu_search.py compares the leaves (boxes and ordered lists) of both builds.
+#include <algorithm>
+#include <cstring>
+
+#include "kernels.hpp"
+
+namespace msm {
+
+namespace {
+
+constexpr int kWave = 64;
+enum { C_NNODES = 0, C_NOPEN, C_ARENA, C_NMASK, C_MAXDEPTH, C_OVERFLOW, C_REFS, C_MAXLEAF, C_NLEAVES, C_NEXT_TOTAL, C_COUNT };
+
+__device__ __forceinline__ int wave_incl_scan(int v, int lane) {
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+        const int o = __shfl_up(v, off, kWave);
+        if (lane >= off) v += o;
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(256) void k_oct_boxes(const double *__restrict__ xyz, int V, const int32_t *__restrict__ tri, int T, double *__restrict__ box,
+                                                    int *__restrict__ list) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    double lo[3], hi[3];
+    for (int a = 0; a < 3; ++a) lo[a] = hi[a] = xyz[(size_t)a * V + tri[t]];
+    for (int k = 1; k < 3; ++k)
+        for (int a = 0; a < 3; ++a) {
+            const double c = xyz[(size_t)a * V + tri[(size_t)k * T + t]];
+            if (c < lo[a]) lo[a] = c;
+            if (c > hi[a]) hi[a] = c;
+        }
+    for (int a = 0; a < 3; ++a) box[(size_t)6 * t + a] = lo[a], box[(size_t)6 * t + 3 + a] = hi[a];
+    list[t] = t;  // the root's list
+}
+
+struct OctWork {
+    const double *box;     // 6 per triangle
+    int4 *node;            // the mesh's node array (FlatOctree::node layout)
+    int32_t *parent;
+    double4 *nodebox;      // lower corner, edge
+    int *counters;
+    int *open_node[2];     // node ids of the level's open nodes / of the next level's
+    int *open_off[2];      // start of each open node's list
+    int *open_len[2];
+    int *list[2];          // the lists themselves
+    int *split;            // per open node
+    int *ccnt;             // 8 per open node: what each child receives
+    int32_t *leaf_tri;     // the mesh's leaf array
+    int cap_nodes, cap_refs, cap_arena, cap_open;
+};
+
+// the 8 overlap flags of a triangle box against the children of a node (Node::can_contain on each child, R/node.cpp:108-116):
+// per axis the child box is the parent's [lower, middle] or [middle, upper]
+__device__ __forceinline__ unsigned child_flags(const double *bx, const double lo[3], const double mid[3], const double hi[3]) {
+    unsigned half[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+        half[a] = (!(bx[3 + a] < lo[a] || bx[a] > mid[a]) ? 1u : 0u) | (!(bx[3 + a] < mid[a] || bx[a] > hi[a]) ? 2u : 0u);
+    unsigned f = 0u;
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+        if ((half[0] >> ((c >> 2) & 1) & 1u) && (half[1] >> ((c >> 1) & 1) & 1u) && (half[2] >> (c & 1) & 1u)) f |= 1u << c;
+    return f;
+}
+
+__device__ __forceinline__ void node_box(const double4 b, double lo[3], double mid[3], double hi[3]) {
+    lo[0] = b.x, lo[1] = b.y, lo[2] = b.z;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        hi[a] = lo[a] + b.w;               // exact: boxes are dyadic subdivisions of (-101, 101)
+        mid[a] = (lo[a] + hi[a]) / 2.0;    // Node::bounds[a][1], R/node.cpp:40-44
+    }
+}
+
+__global__ __launch_bounds__(256) void k_oct_decide(OctWork w, int cur) {
+    const int nopen = w.counters[C_NOPEN];
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+    for (int o = wave; o < nopen; o += nwaves) {
+        const int n = w.open_node[cur][o], off = w.open_off[cur][o], len = w.open_len[cur][o];
+        const int *list = w.list[cur] + off;
+        double lo[3], mid[3], hi[3];
+        node_box(w.nodebox[n], lo, mid, hi);
+        bool splits = false;
+        if (len >= kMaxTriangles) {
+            // Octree::add_triangle, R/octree.cpp:65-131: running total_size / num_split over the list, tested from the 50th entry on
+            int tot = 0, ns = 0;
+            for (int base = 0; base < len && !splits; base += kWave) {
+                const int i = base + lane;
+                int s = 0, q = 0;
+                if (i < len) {
+                    const double *bx = w.box + (size_t)6 * list[i];
+                    s = 8;
+#pragma unroll
+                    for (int d = 0; d < 3; ++d)
+                        if ((bx[d] < mid[d]) == (bx[3 + d] < mid[d])) s >>= 1;
+                    q = s != 8 ? 1 : 0;
+                }
+                const int ts = tot + wave_incl_scan(s, lane), nq = ns + wave_incl_scan(q, lane);
+                const bool hit = i < len && i + 1 >= kMaxTriangles && nq > 0 && ts < 3 * (i + 1);
+                splits = __any(hit);
+                tot = __shfl(ts, kWave - 1, kWave);
+                ns = __shfl(nq, kWave - 1, kWave);
+            }
+        }
+        int cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (splits) {
+            for (int base = 0; base < len; base += kWave) {
+                const int i = base + lane;
+                const unsigned f = i < len ? child_flags(w.box + (size_t)6 * list[i], lo, mid, hi) : 0u;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) cnt[c] += __popcll(__ballot((f >> c) & 1u));
+            }
+        }
+        if (lane == 0) {
+            w.split[o] = splits ? 1 : 0;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) w.ccnt[8 * (size_t)o + c] = cnt[c];
+        }
+    }
+}
+
+// block-wide exclusive scan of one value per thread (1024 threads), returns the exclusive prefix; *total = sum
+__device__ int block_excl_scan(int v, int *total) {
+    __shared__ int s_w[16];
+    __shared__ int s_tot;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int incl = wave_incl_scan(v, lane);
+    if (lane == kWave - 1) s_w[wv] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int acc = 0;
+        for (int k = 0; k < (int)(blockDim.x >> 6); ++k) {
+            const int t = s_w[k];
+            s_w[k] = acc;
+            acc += t;
+        }
+        s_tot = acc;
+    }
+    __syncthreads();
+    const int excl = incl - v + s_w[wv];
+    *total = s_tot;
+    __syncthreads();
+    return excl;
+}
+
+__global__ __launch_bounds__(1024) void k_oct_scan(OctWork w, int cur, int depth) {
+    const int nopen = w.counters[C_NOPEN];
+    if (nopen == 0) return;
+    const int nxt = cur ^ 1, tid = threadIdx.x;
+    const int nnodes0 = w.counters[C_NNODES], arena0 = w.counters[C_ARENA], nmask0 = w.counters[C_NMASK];
+    __shared__ int s_over;
+    if (tid == 0) s_over = 0;
+    __syncthreads();
+    int carry_rank = 0, carry_arena = 0, carry_mask = 0, carry_list = 0, refs = 0, maxleaf = 0, nleaves = 0;
+    for (int base = 0; base < nopen; base += 1024) {  // uniform
+        const int o = base + tid;
+        const bool in = o < nopen;
+        const int sp = in ? w.split[o] : 0;
+        const int len = in ? w.open_len[cur][o] : 0;
+        const bool leaf = in && !sp;
+        int ctot = 0;
+        if (sp)
+            for (int c = 0; c < 8; ++c) ctot += w.ccnt[8 * (size_t)o + c];
+        int t1, t2, t3, t4;
+        const int rank = carry_rank + block_excl_scan(sp, &t1);
+        const int aoff = carry_arena + block_excl_scan(leaf ? ((len + 7) & ~7) : 0, &t2);
+        const int hasmask = leaf && len >= 1 && len <= 64;
+        const int mblk = carry_mask + block_excl_scan(hasmask, &t3);
+        const int loff = carry_list + block_excl_scan(ctot, &t4);
+        carry_rank += t1, carry_arena += t2, carry_mask += t3, carry_list += t4;
+        if (in) {
+            const int n = w.open_node[cur][o];
+            if (sp) {
+                const int child_base = nnodes0 + 8 * rank;
+                if (child_base + 8 > w.cap_nodes || 8 * rank + 8 > w.cap_open || loff + ctot > w.cap_refs) {
+                    s_over = 1;
+                } else {
+                    w.node[n] = make_int4(child_base, 0, -1, depth);
+                    const double4 pb = w.nodebox[n];
+                    const double h = pb.w / 2.0;  // the children's edge; lower corners = the parent's lower bound or its middle
+                    int lo = loff;
+                    for (int c = 0; c < 8; ++c) {
+                        const int id = child_base + c;
+                        w.parent[id] = n;
+                        const double cx = ((c >> 2) & 1) ? (pb.x + (pb.x + pb.w)) / 2.0 : pb.x;
+                        const double cy = ((c >> 1) & 1) ? (pb.y + (pb.y + pb.w)) / 2.0 : pb.y;
+                        const double cz = (c & 1) ? (pb.z + (pb.z + pb.w)) / 2.0 : pb.z;
+                        w.nodebox[id] = make_double4(cx, cy, cz, h);
+                        w.node[id] = make_int4(-1, 0, -1, depth + 1);  // provisional: an empty leaf (overwritten when the next level decides it)
+                        w.open_node[nxt][8 * rank + c] = id;
+                        w.open_off[nxt][8 * rank + c] = lo;
+                        w.open_len[nxt][8 * rank + c] = w.ccnt[8 * (size_t)o + c];
+                        lo += w.ccnt[8 * (size_t)o + c];
+                    }
+                }
+            } else {
+                if (arena0 + aoff + ((len + 7) & ~7) > w.cap_arena) s_over = 1;
+                else w.node[n] = make_int4(-len - 1, arena0 + aoff, hasmask ? nmask0 + mblk : -1, depth);
+                // the fill kernel finds its slot in node[n].y
+            }
+        }
+        // level statistics (Octree stats: leaves, references, largest leaf)
+        int r = leaf ? len : 0, t5;
+        (void)block_excl_scan(r, &t5);
+        refs += t5;
+        int l1 = leaf ? 1 : 0, t6;
+        (void)block_excl_scan(l1, &t6);
+        nleaves += t6;
+        __shared__ int s_max;
+        if (tid == 0) s_max = 0;
+        __syncthreads();
+        if (leaf) atomicMax(&s_max, len);
+        __syncthreads();
+        maxleaf = max(maxleaf, s_max);
+        __syncthreads();
+    }
+    __syncthreads();
+    if (tid == 0) {
+        if (s_over) {
+            w.counters[C_OVERFLOW] = 1;
+            w.counters[C_NOPEN] = 0;
+        } else {
+            w.counters[C_NNODES] = nnodes0 + 8 * carry_rank;
+            w.counters[C_NOPEN] = 8 * carry_rank;
+            w.counters[C_ARENA] = arena0 + carry_arena;
+            w.counters[C_NMASK] = nmask0 + carry_mask;
+            w.counters[C_MAXDEPTH] = depth;
+            w.counters[C_REFS] += refs;
+            w.counters[C_MAXLEAF] = max(w.counters[C_MAXLEAF], maxleaf);
+            w.counters[C_NLEAVES] += nleaves;
+            w.counters[C_NEXT_TOTAL] = carry_list;
+        }
+    }
+}
+
+// runs right after k_oct_scan with the level's open list still in `cur`: the number of open nodes of THIS level is passed by
+// the scan through split[] / node[] (counters[C_NOPEN] already holds the next level's count), so the grid walks `nopen_level`
+__global__ __launch_bounds__(256) void k_oct_fill(OctWork w, int cur, const int *__restrict__ nopen_level) {
+    const int nopen = *nopen_level;
+    if (w.counters[C_OVERFLOW]) return;
+    const int nxt = cur ^ 1;
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+    for (int o = wave; o < nopen; o += nwaves) {
+        const int n = w.open_node[cur][o], off = w.open_off[cur][o], len = w.open_len[cur][o];
+        const int *list = w.list[cur] + off;
+        const int4 nd = w.node[n];
+        if (nd.x < 0) {  // a leaf: its entries, in order, padded to a multiple of eight with -1
+            const int cnt = -nd.x - 1, padded = (cnt + 7) & ~7;
+            for (int i = lane; i < padded; i += kWave) w.leaf_tri[nd.y + i] = i < cnt ? list[i] : -1;
+            continue;
+        }
+        // the children's lists: child c receives, in order, every triangle of the list whose box overlaps the child's box
+        double lo[3], mid[3], hi[3];
+        node_box(w.nodebox[n], lo, mid, hi);
+        int at[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) at[c] = w.open_off[nxt][(nd.x - w.open_node[nxt][0]) + c];  // children are consecutive in the next open list
+        int *out = w.list[nxt];
+        for (int base = 0; base < len; base += kWave) {
+            const int i = base + lane;
+            const int t = i < len ? list[i] : 0;
+            const unsigned f = i < len ? child_flags(w.box + (size_t)6 * t, lo, mid, hi) : 0u;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const unsigned long long b = __ballot((f >> c) & 1u);
+                if ((f >> c) & 1u) out[at[c] + __popcll(b & ((1ull << lane) - 1ull))] = t;
+                at[c] += __popcll(b);
+            }
+        }
+    }
+}
+
+__global__ void k_oct_begin_level(int *counters, int *nopen_level) { *nopen_level = counters[C_NOPEN]; }
+
+// dense top grid (FlatOctree::grid): the node a point of each depth-gd cell reaches after gd levels of descent, or the leaf met earlier
+__global__ __launch_bounds__(256) void k_oct_grid(const int4 *__restrict__ node, int gd, int32_t *__restrict__ grid) {
+    const int G = 1 << gd;
+    const size_t cell = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (cell >= (size_t)G * G * G) return;
+    const int iz = (int)(cell % G), iy = (int)((cell / G) % G), ix = (int)(cell / ((size_t)G * G));
+    int n = 0;
+    for (int d = 0; d < gd; ++d) {
+        const int4 nd = node[n];
+        if (nd.x < 0) break;
+        const int sh = gd - 1 - d;
+        n = nd.x + 4 * ((ix >> sh) & 1) + 2 * ((iy >> sh) & 1) + ((iz >> sh) & 1);
+    }
+    grid[cell] = n;
+}
+
+}  // namespace
+
+// Builds the search tree of m's current device coordinates into m's device arrays.  Returns MSM_OK, or MSM_ERR_CAPACITY when
+// the tree outgrows the preallocated arrays (degenerate meshes: the caller falls back to the host build).
+int gpu_build_octree(msm_mesh *m) {
+    msm_ctx *ctx = m->ctx;
+    const int T = m->T, V = m->V;
+    const int cap_nodes = T + 64, cap_refs = 6 * T + 256, cap_arena = 8 * T + 512, cap_open = cap_nodes;
+    MSM_HIP(hipSetDevice(ctx->device));
+    if ((size_t)6 * T > ctx->oct_cap_box) {
+        if (ctx->oct_box) (void)hipFree(ctx->oct_box);
+        ctx->oct_box = nullptr;
+        ctx->oct_cap_box = (size_t)6 * T + 1024;
+        MSM_HIP(hipMalloc((void **)&ctx->oct_box, ctx->oct_cap_box * sizeof(double)));
+    }
+    const size_t need_ints = (size_t)2 * cap_refs + (size_t)6 * cap_open + (size_t)cap_open + (size_t)8 * cap_open;
+    if (need_ints > ctx->oct_cap_ints) {
+        if (ctx->oct_ints) (void)hipFree(ctx->oct_ints);
+        ctx->oct_ints = nullptr;
+        ctx->oct_cap_ints = need_ints + 4096;
+        MSM_HIP(hipMalloc((void **)&ctx->oct_ints, ctx->oct_cap_ints * sizeof(int)));
+    }
+    if (!ctx->oct_counters) {
+        MSM_HIP(hipMalloc((void **)&ctx->oct_counters, sizeof(int) * (C_COUNT + 1)));
+        MSM_HIP(hipHostMalloc((void **)&ctx->oct_hcounters, sizeof(int) * (C_COUNT + 1)));
+    }
+    struct {
+        double *box;
+        int *ints, *counters, *nopen_level, *h_counters;
+    } s{ctx->oct_box, ctx->oct_ints, ctx->oct_counters, ctx->oct_counters + C_COUNT, ctx->oct_hcounters};
+    auto grow = [&](void **p, size_t &cap, size_t need, size_t elem) -> hipError_t {
+        if (need <= cap && *p) return hipSuccess;
+        if (*p) (void)hipFree(*p);
+        *p = nullptr;
+        cap = need;
+        return hipMalloc(p, cap * elem);
+    };
+    MSM_HIP(grow((void **)&m->d_node, m->cap_node, cap_nodes, sizeof(int4)));
+    MSM_HIP(grow((void **)&m->d_parent, m->cap_parent, cap_nodes, sizeof(int32_t)));
+    MSM_HIP(grow((void **)&m->d_nodebox, m->cap_box, cap_nodes, sizeof(double4)));
+    MSM_HIP(grow((void **)&m->d_leaf_tri, m->cap_leaf, cap_arena, sizeof(int32_t)));
+    MSM_HIP(grow((void **)&m->d_cone, m->cap_cone, cap_arena, sizeof(float4)));
+    MSM_HIP(grow((void **)&m->d_rec, m->cap_rec, (size_t)T, sizeof(TriRec)));
+    MSM_HIP(grow((void **)&m->d_grid, m->cap_grid, (size_t)64 * 64 * 64, sizeof(int32_t)));
+
+    OctWork w;
+    w.box = s.box;
+    w.node = m->d_node;
+    w.parent = m->d_parent;
+    w.nodebox = m->d_nodebox;
+    w.counters = s.counters;
+    int *p = s.ints;
+    w.list[0] = p, p += cap_refs;
+    w.list[1] = p, p += cap_refs;
+    for (int k = 0; k < 2; ++k) {
+        w.open_node[k] = p, p += cap_open;
+        w.open_off[k] = p, p += cap_open;
+        w.open_len[k] = p, p += cap_open;
+    }
+    w.split = p, p += cap_open;
+    w.ccnt = p;
+    w.leaf_tri = m->d_leaf_tri;
+    w.cap_nodes = cap_nodes, w.cap_refs = cap_refs, w.cap_arena = cap_arena, w.cap_open = cap_open;
+
+    // root: node 0 with the cube (-101, 101) and every triangle
+    int h0[C_COUNT + 1] = {0};
+    h0[C_NNODES] = 1, h0[C_NOPEN] = 1;
+    std::memcpy(s.h_counters, h0, sizeof(h0));
+    MSM_HIP(hipMemcpyAsync(s.counters, s.h_counters, sizeof(h0), hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_oct_boxes, dim3((T + 255) / 256), dim3(256), 0, ctx->stream, m->d_xyz, V, m->d_tri, T, s.box, w.list[0]);
+    {
+        const int4 root_node = make_int4(-1, 0, -1, 0);
+        const double4 root_box = make_double4(-kBounds, -kBounds, -kBounds, 2 * kBounds);
+        const int32_t root_parent = -1;
+        const int zero = 0;
+        MSM_HIP(hipMemcpyAsync(m->d_node, &root_node, sizeof(root_node), hipMemcpyHostToDevice, ctx->stream));
+        MSM_HIP(hipMemcpyAsync(m->d_nodebox, &root_box, sizeof(root_box), hipMemcpyHostToDevice, ctx->stream));
+        MSM_HIP(hipMemcpyAsync(m->d_parent, &root_parent, sizeof(root_parent), hipMemcpyHostToDevice, ctx->stream));
+        MSM_HIP(hipMemcpyAsync(w.open_node[0], &zero, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+        MSM_HIP(hipMemcpyAsync(w.open_off[0], &zero, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+        MSM_HIP(hipMemcpyAsync(w.open_len[0], &T, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+        MSM_HIP(hipStreamSynchronize(ctx->stream));  // the sources above are locals
+    }
+    constexpr int kMaxLevels = 24, kSureLevels = 6;
+    int cur = 0;
+    bool done = false;
+    for (int depth = 0; depth < kMaxLevels && !done; ++depth) {
+        hipLaunchKernelGGL(k_oct_begin_level, dim3(1), dim3(1), 0, ctx->stream, s.counters, s.nopen_level);
+        hipLaunchKernelGGL(k_oct_decide, dim3(512), dim3(256), 0, ctx->stream, w, cur);
+        hipLaunchKernelGGL(k_oct_scan, dim3(1), dim3(1024), 0, ctx->stream, w, cur, depth);
+        hipLaunchKernelGGL(k_oct_fill, dim3(512), dim3(256), 0, ctx->stream, w, cur, s.nopen_level);
+        MSM_HIP(hipGetLastError());
+        cur ^= 1;
+        if (depth + 1 >= kSureLevels) {  // ico-derived meshes finish at depth 6: from here on look whether anything is still open
+            MSM_HIP(hipMemcpyAsync(s.h_counters, s.counters, sizeof(int) * C_COUNT, hipMemcpyDeviceToHost, ctx->stream));
+            MSM_HIP(hipStreamSynchronize(ctx->stream));
+            done = s.h_counters[C_NOPEN] == 0;
+        }
+    }
+    if (!done) {
+        MSM_HIP(hipMemcpyAsync(s.h_counters, s.counters, sizeof(int) * C_COUNT, hipMemcpyDeviceToHost, ctx->stream));
+        MSM_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    const int *hc = s.h_counters;
+    if (hc[C_OVERFLOW] || hc[C_NOPEN] != 0) return MSM_ERR_CAPACITY;
+    FlatOctree &o = m->tree;
+    o = FlatOctree{};  // no host arrays: the tree lives on the device (dev_nnodes etc. below describe it)
+    o.dev_nnodes = hc[C_NNODES];
+    o.dev_entries = hc[C_ARENA];
+    o.nmask_blocks = hc[C_NMASK];
+    o.grid_depth = std::min(hc[C_MAXDEPTH], 6);
+    o.stats[0] = hc[C_NNODES], o.stats[1] = hc[C_NLEAVES], o.stats[2] = hc[C_MAXDEPTH], o.stats[3] = hc[C_REFS], o.stats[4] = hc[C_MAXLEAF];
+    const int G = 1 << o.grid_depth;
+    const size_t cells = (size_t)G * G * G;
+    hipLaunchKernelGGL(k_oct_grid, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, ctx->stream, m->d_node, o.grid_depth, m->d_grid);
+    MSM_HIP(hipGetLastError());
+    return launch_build_recs(ctx, m->d_xyz, V, m->d_tri, T, m->d_rec, m->d_tcone, m->d_leaf_tri, o.dev_entries, m->d_cone);
+}
+
+}  // namespace msm

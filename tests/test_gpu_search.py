@@ -244,3 +244,34 @@ def test_exclusion_masks_in_metric_resample_and_nearest_neighbour(ctx):
     want, wmask = O.nearest_neighbour_excl(osrc, data, q, excl)
     assert np.array_equal(got, want) and np.array_equal(gmask, wmask) and (gmask == 0).any()
     assert np.array_equal(M.nearest_neighbour_interpolation(src, data, q), O.nearest_neighbour(osrc, data, q))
+
+
+@pytest.mark.parametrize("case", ["ico6", "ico5_warped", "ico6_jittered", "ico5_radial", "ico4_small"])
+def test_gpu_built_octree_has_the_reference_leaves(ctx, case):
+    """The level-by-level GPU build (octree_kernels.hip) against the host build (the reference's insertion order restated,
+    octree.cpp): same node / leaf / reference counts, same depth, and the same leaves -- box and ordered triangle list of
+    every leaf (signature).  ico4 is below the size at which the GPU build is chosen: there both paths are the host's."""
+    from newmsm_amd import synthetic
+
+    order = int(case[3])
+    xyz, tri = M.make_mesh_from_icosa(order)
+    if "warped" in case:
+        xyz = synthetic.known_warp(xyz, seed=3, rot_deg=5.0, amp=1.5)
+    if "jittered" in case:  # folds and slivers: boxes overlap many cells, deeper splits
+        rng = np.random.default_rng(5)
+        xyz = xyz + rng.normal(scale=0.4, size=xyz.shape)
+        xyz = xyz / np.linalg.norm(xyz, axis=1, keepdims=True) * 100.0
+    if "radial" in case:
+        xyz = xyz * (1.0 + 0.01 * synthetic.smooth_feature(xyz, 1, 11))[:, None]
+    stats_host, sig_host = M.octree_signature(xyz, tri)
+    m = M.Mesh(ctx, xyz, tri)
+    stats_dev, sig_dev = m.octree_signature()
+    assert stats_dev == stats_host, (stats_dev, stats_host)
+    assert sig_dev == sig_host
+    if case == "ico6":
+        assert (stats_dev["nodes"], stats_dev["leaves"], stats_dev["depth"], stats_dev["refs"]) == (14281, 12496, 6, 176096)
+    # new coordinates: the tree is rebuilt from the device copy
+    xyz2 = synthetic.known_warp(xyz, seed=8, rot_deg=1.0, amp=0.5)
+    m.set_coords(xyz2)
+    s2, g2 = m.octree_signature()
+    assert (s2, g2) == M.octree_signature(xyz2, tri)
