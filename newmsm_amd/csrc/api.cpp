@@ -132,7 +132,9 @@ int finish_tree(msm_mesh *m) {
 
 // Meshes of this size and above get their tree built on the GPU (octree_kernels.hip): below it the host build takes less
 // than the dozen launches of the level loop.  MSMHIP_OCTREE=host|gpu forces one of them (tests compare the two).
-static bool tree_on_gpu(const msm_mesh *m) {
+bool mesh_tree_on_gpu(const msm_mesh *m);
+static bool tree_on_gpu(const msm_mesh *m) { return mesh_tree_on_gpu(m); }
+bool mesh_tree_on_gpu(const msm_mesh *m) {
     static const int mode = [] {
         const char *e = std::getenv("MSMHIP_OCTREE");
         return !e ? 0 : (std::strcmp(e, "host") == 0 ? 1 : (std::strcmp(e, "gpu") == 0 ? 2 : 0));

@@ -26,6 +26,7 @@ int adaptive_weights(msm_mesh *in_mesh, msm_mesh *new_mesh, const double *excl, 
                      std::vector<double> &val);
 const Adjacency &mesh_adjacency(msm_mesh *m);
 int query_host(msm_mesh *target, const double *q, int N, int *tri_id, int *vid, double *w, int mode, const char *what, const double *q_on_device);
+bool mesh_tree_on_gpu(const msm_mesh *m);
 }  // namespace msm
 
 struct msm_group {
@@ -463,23 +464,34 @@ int group_subject_setup(msm_group *g, int s) {
         rotated[0] = dm->xyz;  // the same numbers; kept as the mesh's own copy
     }
     lap("rotations");
-    // phase 2 (host threads): octrees and vertex areas of the rotated meshes
-    std::vector<FlatOctree> trees(L);
+    // phase 2: vertex areas of the rotated meshes (host threads), and -- for data meshes below the size at which the tree is
+    // built on the GPU -- their octrees
+    const bool gpu_trees = mesh_tree_on_gpu(sm);
+    std::vector<FlatOctree> trees(gpu_trees ? 0 : L);
     std::vector<std::vector<double>> oldA(L);
     const Adjacency &adj = mesh_adjacency(sm);
     std::vector<double> newA;
     vertex_areas_of(g->tmpl->xyz.data(), g->tmpl->tri.data(), g->tmpl->V, g->tmpl->T, mesh_adjacency(g->tmpl), newA);
     parallel_for(L, workers, [&](int l) {
-        build_octree(rotated[l].data(), sm->tri.data(), V, T, trees[l]);
+        if (!gpu_trees) build_octree(rotated[l].data(), sm->tri.data(), V, T, trees[l]);
         vertex_areas_of(rotated[l].data(), sm->tri.data(), V, T, adj, oldA[l]);
     });
-    lap("octrees");
-    // phase 3 (GPU): forward and reverse queries of metric_resample(rotated_mesh, target_space)
+    lap(gpu_trees ? "vertex areas" : "octrees");
+    // phase 3 (GPU): forward and reverse queries of metric_resample(rotated_mesh, target_space); the tree of each rotated mesh
+    // is built in HBM from the coordinates of phase 1 (octree_kernels.hip), or installed from the host build
     std::vector<AdaptiveQueries> queries(L);
     double t_install = 0, t_query = 0;
     for (int l = 0; l < L; ++l) {
         const auto t0 = std::chrono::steady_clock::now();
-        int st = install_coords_and_tree(sm, rotated[l].data(), std::move(trees[l]));
+        int st;
+        if (gpu_trees) {
+            for (int a = 0; a < 3; ++a)
+                MSM_HIP(hipMemcpyAsync(sm->d_xyz + (size_t)a * V, d_rot.p + a * LV + (size_t)l * V, sizeof(double) * (size_t)V, hipMemcpyDeviceToDevice, ctx->stream));
+            sm->tree_valid = false;  // rebuilt by the first query below
+            st = MSM_OK;
+        } else {
+            st = install_coords_and_tree(sm, rotated[l].data(), std::move(trees[l]));
+        }
         if (st) return st;
         const auto t1 = std::chrono::steady_clock::now();
         st = adaptive_queries(sm, g->tmpl, false, queries[l], 1);  // forward: template vertices in this label's tree

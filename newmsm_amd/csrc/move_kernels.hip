@@ -134,6 +134,9 @@ __device__ __forceinline__ double move_likelihood(const CliqueArgs &a, const Mov
             }
             const double r = (varA == 0.0 || varB == 0.0) ? 0.0 : prod / (sqrt(varA) * sqrt(varB));
             cost = 1 - (1 + r) * 0.5;
+        } else if (a.simmeasure == 4 || a.simmeasure == 5) {  // sparsesimkernel::DICE / genDICE, :201-253 (weights unused)
+            const double *sf = m.slot_sf + beg;
+            cost = dice_serial(a.simmeasure, n, a.percentile, [&](int i) { return sf[i]; }, [&](int i) { return vals[i]; });
         } else {  // sparsesimkernel::SSD, :179-188
             const double *sf = m.slot_sf + beg;
             double prod = 0.0;

@@ -4,18 +4,20 @@
 // whose boxes overlap it, in ascending id (octree.cpp: Builder::build_down states why): a node becomes internal iff the
 // split heuristic `num_split > 0 && total_size < 3 n` holds at some insertion from the 50th on, and its children then
 // receive, in order, the triangles of its WHOLE list that overlap them.  That is a level-synchronous computation:
-//   k_oct_decide   a wavefront per open node scans its list (wave prefix sums of the heuristic's two running sums) and,
-//                  for a node that splits, counts what each child will receive;
-//   k_oct_scan     one workgroup turns the decisions of the level into node numbers, list offsets and leaf slots
+//   k_oct_decide   a wavefront per open node scans its list (wave prefix sums of the heuristic's two running sums, stopping at
+//                  the first entry that triggers the split);
+//   k_oct_count    a workgroup per 256-entry chunk of a splitting node counts what each child receives from the chunk;
+//   k_oct_scan     one workgroup turns the decisions of the level into node numbers, list offsets, chunk tables and leaf slots
 //                  (prefix sums in node order: the tree's numbering does not depend on scheduling);
-//   k_oct_fill     a wavefront per open node writes the children's lists (ballot-ordered compaction, ids stay
-//                  ascending) or, for a leaf, its entries into the leaf array (padded to 8 with -1).
+//   k_oct_fill     a workgroup per chunk writes its entries into the children's lists (ballot-ordered compaction behind the
+//                  chunk's start: ids stay ascending) or, for a leaf, into the leaf array (padded to 8 with -1).
 // Child boxes are exact halvings of (-101, 101), so every box is reproduced bit for bit from (lower corner, edge).
 // The host build (octree.cpp) takes 3.5 ms per ico6 mesh on sixteen threads -- every iteration of a registration builds one
 // for the moved source, gMSM nineteen per subject -- plus the upload of its arrays; this one leaves them where the search
 // kernels read them.  tests/test_gpu_search.py compares the leaves (boxes and ordered lists) of both builds.
 #include <algorithm>
 #include <cstring>
+#include <vector>
 
 #include "kernels.hpp"
 
@@ -24,7 +26,7 @@ namespace msm {
 namespace {
 
 constexpr int kWave = 64;
-enum { C_NNODES = 0, C_NOPEN, C_ARENA, C_NMASK, C_MAXDEPTH, C_OVERFLOW, C_REFS, C_MAXLEAF, C_NLEAVES, C_NEXT_TOTAL, C_COUNT };
+enum { C_NNODES = 0, C_NOPEN, C_ARENA, C_NMASK, C_MAXDEPTH, C_OVERFLOW, C_REFS, C_MAXLEAF, C_NLEAVES, C_NCHUNK, C_NCHUNK_NEXT, C_COUNT };
 
 __device__ __forceinline__ int wave_incl_scan(int v, int lane) {
 #pragma unroll
@@ -51,6 +53,8 @@ __global__ __launch_bounds__(256) void k_oct_boxes(const double *__restrict__ xy
     list[t] = t;  // the root's list
 }
 
+constexpr int kChunk = 256;  // list entries a workgroup of k_oct_count / k_oct_fill takes
+
 struct OctWork {
     const double *box;     // 6 per triangle
     int4 *node;            // the mesh's node array (FlatOctree::node layout)
@@ -60,11 +64,14 @@ struct OctWork {
     int *open_node[2];     // node ids of the level's open nodes / of the next level's
     int *open_off[2];      // start of each open node's list
     int *open_len[2];
+    int *open_chunk[2];    // first chunk of each open node
+    int *chunk_open[2];    // per chunk: its open node (index into open_*), and where it starts in that node's list
+    int *chunk_beg[2];
     int *list[2];          // the lists themselves
     int *split;            // per open node
-    int *ccnt;             // 8 per open node: what each child receives
+    int *cc;               // 8 per chunk: what each child receives from this chunk, then (after the scan) where the chunk's share starts
     int32_t *leaf_tri;     // the mesh's leaf array
-    int cap_nodes, cap_refs, cap_arena, cap_open;
+    int cap_nodes, cap_refs, cap_arena, cap_open, cap_chunks;
 };
 
 // the 8 overlap flags of a triangle box against the children of a node (Node::can_contain on each child, R/node.cpp:108-116):
@@ -90,6 +97,9 @@ __device__ __forceinline__ void node_box(const double4 b, double lo[3], double m
     }
 }
 
+// Does the node split?  Octree::add_triangle, R/octree.cpp:65-131: running total_size / num_split over the node's list in id
+// order, tested from the 50th entry on.  A wavefront per open node; the scan stops at the first entry that triggers the split
+// (for the large nodes of the top levels that is within the first chunk).
 __global__ __launch_bounds__(256) void k_oct_decide(OctWork w, int cur) {
     const int nopen = w.counters[C_NOPEN];
     const int lane = threadIdx.x & 63;
@@ -101,7 +111,6 @@ __global__ __launch_bounds__(256) void k_oct_decide(OctWork w, int cur) {
         node_box(w.nodebox[n], lo, mid, hi);
         bool splits = false;
         if (len >= kMaxTriangles) {
-            // Octree::add_triangle, R/octree.cpp:65-131: running total_size / num_split over the list, tested from the 50th entry on
             int tot = 0, ns = 0;
             for (int base = 0; base < len && !splits; base += kWave) {
                 const int i = base + lane;
@@ -121,20 +130,32 @@ __global__ __launch_bounds__(256) void k_oct_decide(OctWork w, int cur) {
                 ns = __shfl(nq, kWave - 1, kWave);
             }
         }
-        int cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (splits) {
-            for (int base = 0; base < len; base += kWave) {
-                const int i = base + lane;
-                const unsigned f = i < len ? child_flags(w.box + (size_t)6 * list[i], lo, mid, hi) : 0u;
+        if (lane == 0) w.split[o] = splits ? 1 : 0;
+    }
+}
+
+// per chunk of a splitting node: how many of its entries each child receives
+__global__ __launch_bounds__(256) void k_oct_count(OctWork w, int cur) {
+    __shared__ int s_cnt[4][8];
+    const int nchunks = w.counters[C_NCHUNK];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int k = blockIdx.x; k < nchunks; k += gridDim.x) {  // uniform
+        const int o = w.chunk_open[cur][k];
+        if (!w.split[o]) continue;
+        const int n = w.open_node[cur][o], beg = w.chunk_beg[cur][k], len = w.open_len[cur][o];
+        const int *list = w.list[cur] + w.open_off[cur][o];
+        double lo[3], mid[3], hi[3];
+        node_box(w.nodebox[n], lo, mid, hi);
+        const int i = beg + threadIdx.x;
+        const unsigned f = i < len ? child_flags(w.box + (size_t)6 * list[i], lo, mid, hi) : 0u;
 #pragma unroll
-                for (int c = 0; c < 8; ++c) cnt[c] += __popcll(__ballot((f >> c) & 1u));
-            }
+        for (int c = 0; c < 8; ++c) {
+            const int pc = __popcll(__ballot((f >> c) & 1u));
+            if (lane == 0) s_cnt[wv][c] = pc;
         }
-        if (lane == 0) {
-            w.split[o] = splits ? 1 : 0;
-#pragma unroll
-            for (int c = 0; c < 8; ++c) w.ccnt[8 * (size_t)o + c] = cnt[c];
-        }
+        __syncthreads();
+        if (threadIdx.x < 8) w.cc[8 * (size_t)k + threadIdx.x] = s_cnt[0][threadIdx.x] + s_cnt[1][threadIdx.x] + s_cnt[2][threadIdx.x] + s_cnt[3][threadIdx.x];
+        __syncthreads();
     }
 }
 
@@ -162,135 +183,148 @@ __device__ int block_excl_scan(int v, int *total) {
     return excl;
 }
 
+// One workgroup turns the level's decisions into node numbers, list offsets, chunk tables and leaf slots -- prefix sums in
+// open-node order, so the numbering of the tree does not depend on scheduling.
 __global__ __launch_bounds__(1024) void k_oct_scan(OctWork w, int cur, int depth) {
     const int nopen = w.counters[C_NOPEN];
     if (nopen == 0) return;
     const int nxt = cur ^ 1, tid = threadIdx.x;
     const int nnodes0 = w.counters[C_NNODES], arena0 = w.counters[C_ARENA], nmask0 = w.counters[C_NMASK];
-    __shared__ int s_over;
-    if (tid == 0) s_over = 0;
+    __shared__ int s_over, s_max;
+    if (tid == 0) s_over = 0, s_max = 0;
     __syncthreads();
-    int carry_rank = 0, carry_arena = 0, carry_mask = 0, carry_list = 0, refs = 0, maxleaf = 0, nleaves = 0;
+    int carry_rank = 0, carry_arena = 0, carry_mask = 0, carry_list = 0, carry_chunk = 0, refs = 0, nleaves = 0;
     for (int base = 0; base < nopen; base += 1024) {  // uniform
         const int o = base + tid;
         const bool in = o < nopen;
         const int sp = in ? w.split[o] : 0;
         const int len = in ? w.open_len[cur][o] : 0;
         const bool leaf = in && !sp;
-        int ctot = 0;
-        if (sp)
-            for (int c = 0; c < 8; ++c) ctot += w.ccnt[8 * (size_t)o + c];
-        int t1, t2, t3, t4;
+        // what the children of a splitting node receive: the sums over its chunks; each chunk's counts become its share's start
+        int ct[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (sp) {
+            const int k0 = w.open_chunk[cur][o], nk = (len + kChunk - 1) / kChunk;
+            for (int k = k0; k < k0 + nk; ++k)
+                for (int c = 0; c < 8; ++c) {
+                    const int v = w.cc[8 * (size_t)k + c];
+                    w.cc[8 * (size_t)k + c] = ct[c];
+                    ct[c] += v;
+                }
+        }
+        int ctot = 0, cchunks = 0;
+        for (int c = 0; c < 8; ++c) ctot += ct[c], cchunks += (ct[c] + kChunk - 1) / kChunk;
+        int t1, t2, t3, t4, t5, t6, t7;
         const int rank = carry_rank + block_excl_scan(sp, &t1);
         const int aoff = carry_arena + block_excl_scan(leaf ? ((len + 7) & ~7) : 0, &t2);
         const int hasmask = leaf && len >= 1 && len <= 64;
         const int mblk = carry_mask + block_excl_scan(hasmask, &t3);
         const int loff = carry_list + block_excl_scan(ctot, &t4);
-        carry_rank += t1, carry_arena += t2, carry_mask += t3, carry_list += t4;
+        const int koff = carry_chunk + block_excl_scan(cchunks, &t5);
+        (void)block_excl_scan(leaf ? len : 0, &t6);
+        (void)block_excl_scan(leaf ? 1 : 0, &t7);
+        carry_rank += t1, carry_arena += t2, carry_mask += t3, carry_list += t4, carry_chunk += t5, refs += t6, nleaves += t7;
+        if (leaf) atomicMax(&s_max, len);
         if (in) {
             const int n = w.open_node[cur][o];
             if (sp) {
                 const int child_base = nnodes0 + 8 * rank;
-                if (child_base + 8 > w.cap_nodes || 8 * rank + 8 > w.cap_open || loff + ctot > w.cap_refs) {
+                if (child_base + 8 > w.cap_nodes || 8 * rank + 8 > w.cap_open || loff + ctot > w.cap_refs || koff + cchunks > w.cap_chunks) {
                     s_over = 1;
                 } else {
                     w.node[n] = make_int4(child_base, 0, -1, depth);
                     const double4 pb = w.nodebox[n];
                     const double h = pb.w / 2.0;  // the children's edge; lower corners = the parent's lower bound or its middle
-                    int lo = loff;
+                    int lo = loff, kk = koff;
                     for (int c = 0; c < 8; ++c) {
-                        const int id = child_base + c;
+                        const int id = child_base + c, oc = 8 * rank + c;
                         w.parent[id] = n;
                         const double cx = ((c >> 2) & 1) ? (pb.x + (pb.x + pb.w)) / 2.0 : pb.x;
                         const double cy = ((c >> 1) & 1) ? (pb.y + (pb.y + pb.w)) / 2.0 : pb.y;
                         const double cz = (c & 1) ? (pb.z + (pb.z + pb.w)) / 2.0 : pb.z;
                         w.nodebox[id] = make_double4(cx, cy, cz, h);
-                        w.node[id] = make_int4(-1, 0, -1, depth + 1);  // provisional: an empty leaf (overwritten when the next level decides it)
-                        w.open_node[nxt][8 * rank + c] = id;
-                        w.open_off[nxt][8 * rank + c] = lo;
-                        w.open_len[nxt][8 * rank + c] = w.ccnt[8 * (size_t)o + c];
-                        lo += w.ccnt[8 * (size_t)o + c];
+                        w.node[id] = make_int4(-1, 0, -1, depth + 1);  // provisional: an empty leaf (the next level decides it)
+                        w.open_node[nxt][oc] = id;
+                        w.open_off[nxt][oc] = lo;
+                        w.open_len[nxt][oc] = ct[c];
+                        w.open_chunk[nxt][oc] = kk;
+                        for (int j = 0; j * kChunk < ct[c]; ++j) {
+                            w.chunk_open[nxt][kk] = oc;
+                            w.chunk_beg[nxt][kk] = j * kChunk;
+                            ++kk;
+                        }
+                        lo += ct[c];
                     }
                 }
             } else {
                 if (arena0 + aoff + ((len + 7) & ~7) > w.cap_arena) s_over = 1;
-                else w.node[n] = make_int4(-len - 1, arena0 + aoff, hasmask ? nmask0 + mblk : -1, depth);
-                // the fill kernel finds its slot in node[n].y
+                else w.node[n] = make_int4(-len - 1, arena0 + aoff, hasmask ? nmask0 + mblk : -1, depth);  // k_oct_fill finds its slot here
             }
         }
-        // level statistics (Octree stats: leaves, references, largest leaf)
-        int r = leaf ? len : 0, t5;
-        (void)block_excl_scan(r, &t5);
-        refs += t5;
-        int l1 = leaf ? 1 : 0, t6;
-        (void)block_excl_scan(l1, &t6);
-        nleaves += t6;
-        __shared__ int s_max;
-        if (tid == 0) s_max = 0;
-        __syncthreads();
-        if (leaf) atomicMax(&s_max, len);
-        __syncthreads();
-        maxleaf = max(maxleaf, s_max);
-        __syncthreads();
     }
     __syncthreads();
     if (tid == 0) {
         if (s_over) {
             w.counters[C_OVERFLOW] = 1;
             w.counters[C_NOPEN] = 0;
+            w.counters[C_NCHUNK_NEXT] = 0;
         } else {
             w.counters[C_NNODES] = nnodes0 + 8 * carry_rank;
             w.counters[C_NOPEN] = 8 * carry_rank;
+            w.counters[C_NCHUNK_NEXT] = carry_chunk;
             w.counters[C_ARENA] = arena0 + carry_arena;
             w.counters[C_NMASK] = nmask0 + carry_mask;
             w.counters[C_MAXDEPTH] = depth;
             w.counters[C_REFS] += refs;
-            w.counters[C_MAXLEAF] = max(w.counters[C_MAXLEAF], maxleaf);
+            w.counters[C_MAXLEAF] = max(w.counters[C_MAXLEAF], s_max);
             w.counters[C_NLEAVES] += nleaves;
-            w.counters[C_NEXT_TOTAL] = carry_list;
         }
     }
 }
 
-// runs right after k_oct_scan with the level's open list still in `cur`: the number of open nodes of THIS level is passed by
-// the scan through split[] / node[] (counters[C_NOPEN] already holds the next level's count), so the grid walks `nopen_level`
-__global__ __launch_bounds__(256) void k_oct_fill(OctWork w, int cur, const int *__restrict__ nopen_level) {
-    const int nopen = *nopen_level;
+// per chunk: a splitting node's entries go to its children's lists (ballot-ordered compaction behind the chunk's start in each
+// child list: ids stay ascending); a leaf's entries go to the leaf array, padded to a multiple of eight with -1
+__global__ __launch_bounds__(256) void k_oct_fill(OctWork w, int cur) {
+    __shared__ int s_cnt[4][8];
     if (w.counters[C_OVERFLOW]) return;
+    const int nchunks = w.counters[C_NCHUNK];
     const int nxt = cur ^ 1;
-    const int lane = threadIdx.x & 63;
-    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
-    for (int o = wave; o < nopen; o += nwaves) {
-        const int n = w.open_node[cur][o], off = w.open_off[cur][o], len = w.open_len[cur][o];
-        const int *list = w.list[cur] + off;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int k = blockIdx.x; k < nchunks; k += gridDim.x) {  // uniform
+        const int o = w.chunk_open[cur][k];
+        const int n = w.open_node[cur][o], beg = w.chunk_beg[cur][k], len = w.open_len[cur][o];
+        const int *list = w.list[cur] + w.open_off[cur][o];
         const int4 nd = w.node[n];
-        if (nd.x < 0) {  // a leaf: its entries, in order, padded to a multiple of eight with -1
+        const int i = beg + threadIdx.x;
+        if (nd.x < 0) {
             const int cnt = -nd.x - 1, padded = (cnt + 7) & ~7;
-            for (int i = lane; i < padded; i += kWave) w.leaf_tri[nd.y + i] = i < cnt ? list[i] : -1;
+            if (i < padded) w.leaf_tri[nd.y + i] = i < cnt ? list[i] : -1;
             continue;
         }
-        // the children's lists: child c receives, in order, every triangle of the list whose box overlaps the child's box
         double lo[3], mid[3], hi[3];
         node_box(w.nodebox[n], lo, mid, hi);
-        int at[8];
+        const int t = i < len ? list[i] : 0;
+        const unsigned f = i < len ? child_flags(w.box + (size_t)6 * t, lo, mid, hi) : 0u;
+        unsigned long long bal[8];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) at[c] = w.open_off[nxt][(nd.x - w.open_node[nxt][0]) + c];  // children are consecutive in the next open list
-        int *out = w.list[nxt];
-        for (int base = 0; base < len; base += kWave) {
-            const int i = base + lane;
-            const int t = i < len ? list[i] : 0;
-            const unsigned f = i < len ? child_flags(w.box + (size_t)6 * t, lo, mid, hi) : 0u;
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const unsigned long long b = __ballot((f >> c) & 1u);
-                if ((f >> c) & 1u) out[at[c] + __popcll(b & ((1ull << lane) - 1ull))] = t;
-                at[c] += __popcll(b);
-            }
+        for (int c = 0; c < 8; ++c) {
+            bal[c] = __ballot((f >> c) & 1u);
+            if (lane == 0) s_cnt[wv][c] = __popcll(bal[c]);
         }
+        __syncthreads();
+        const int oc0 = nd.x - w.open_node[nxt][0];  // the children's places in the next open list (consecutive)
+        int *out = w.list[nxt];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            if (!((f >> c) & 1u)) continue;
+            int at = w.open_off[nxt][oc0 + c] + w.cc[8 * (size_t)k + c];
+            for (int q = 0; q < wv; ++q) at += s_cnt[q][c];
+            out[at + __popcll(bal[c] & ((1ull << lane) - 1ull))] = t;
+        }
+        __syncthreads();
     }
 }
 
-__global__ void k_oct_begin_level(int *counters, int *nopen_level) { *nopen_level = counters[C_NOPEN]; }
+__global__ void k_oct_begin_level(int *counters) { counters[C_NCHUNK] = counters[C_NCHUNK_NEXT]; }
 
 // dense top grid (FlatOctree::grid): the node a point of each depth-gd cell reaches after gd levels of descent, or the leaf met earlier
 __global__ __launch_bounds__(256) void k_oct_grid(const int4 *__restrict__ node, int gd, int32_t *__restrict__ grid) {
@@ -315,7 +349,7 @@ __global__ __launch_bounds__(256) void k_oct_grid(const int4 *__restrict__ node,
 int gpu_build_octree(msm_mesh *m) {
     msm_ctx *ctx = m->ctx;
     const int T = m->T, V = m->V;
-    const int cap_nodes = T + 64, cap_refs = 6 * T + 256, cap_arena = 8 * T + 512, cap_open = cap_nodes;
+    const int cap_nodes = T + 64, cap_refs = 6 * T + 256, cap_arena = 8 * T + 512, cap_open = cap_nodes, cap_chunks = cap_refs / kChunk + cap_open + 64;
     MSM_HIP(hipSetDevice(ctx->device));
     if ((size_t)6 * T > ctx->oct_cap_box) {
         if (ctx->oct_box) (void)hipFree(ctx->oct_box);
@@ -323,7 +357,7 @@ int gpu_build_octree(msm_mesh *m) {
         ctx->oct_cap_box = (size_t)6 * T + 1024;
         MSM_HIP(hipMalloc((void **)&ctx->oct_box, ctx->oct_cap_box * sizeof(double)));
     }
-    const size_t need_ints = (size_t)2 * cap_refs + (size_t)6 * cap_open + (size_t)cap_open + (size_t)8 * cap_open;
+    const size_t need_ints = (size_t)2 * cap_refs + (size_t)8 * cap_open + (size_t)cap_open + (size_t)4 * cap_chunks + (size_t)8 * cap_chunks;
     if (need_ints > ctx->oct_cap_ints) {
         if (ctx->oct_ints) (void)hipFree(ctx->oct_ints);
         ctx->oct_ints = nullptr;
@@ -336,8 +370,8 @@ int gpu_build_octree(msm_mesh *m) {
     }
     struct {
         double *box;
-        int *ints, *counters, *nopen_level, *h_counters;
-    } s{ctx->oct_box, ctx->oct_ints, ctx->oct_counters, ctx->oct_counters + C_COUNT, ctx->oct_hcounters};
+        int *ints, *counters, *h_counters;
+    } s{ctx->oct_box, ctx->oct_ints, ctx->oct_counters, ctx->oct_hcounters};
     auto grow = [&](void **p, size_t &cap, size_t need, size_t elem) -> hipError_t {
         if (need <= cap && *p) return hipSuccess;
         if (*p) (void)hipFree(*p);
@@ -366,15 +400,19 @@ int gpu_build_octree(msm_mesh *m) {
         w.open_node[k] = p, p += cap_open;
         w.open_off[k] = p, p += cap_open;
         w.open_len[k] = p, p += cap_open;
+        w.open_chunk[k] = p, p += cap_open;
+        w.chunk_open[k] = p, p += cap_chunks;
+        w.chunk_beg[k] = p, p += cap_chunks;
     }
     w.split = p, p += cap_open;
-    w.ccnt = p;
+    w.cc = p;
     w.leaf_tri = m->d_leaf_tri;
-    w.cap_nodes = cap_nodes, w.cap_refs = cap_refs, w.cap_arena = cap_arena, w.cap_open = cap_open;
+    w.cap_nodes = cap_nodes, w.cap_refs = cap_refs, w.cap_arena = cap_arena, w.cap_open = cap_open, w.cap_chunks = cap_chunks;
 
     // root: node 0 with the cube (-101, 101) and every triangle
+    const int root_chunks = (T + kChunk - 1) / kChunk;
     int h0[C_COUNT + 1] = {0};
-    h0[C_NNODES] = 1, h0[C_NOPEN] = 1;
+    h0[C_NNODES] = 1, h0[C_NOPEN] = 1, h0[C_NCHUNK_NEXT] = root_chunks;
     std::memcpy(s.h_counters, h0, sizeof(h0));
     MSM_HIP(hipMemcpyAsync(s.counters, s.h_counters, sizeof(h0), hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(k_oct_boxes, dim3((T + 255) / 256), dim3(256), 0, ctx->stream, m->d_xyz, V, m->d_tri, T, s.box, w.list[0]);
@@ -389,16 +427,22 @@ int gpu_build_octree(msm_mesh *m) {
         MSM_HIP(hipMemcpyAsync(w.open_node[0], &zero, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
         MSM_HIP(hipMemcpyAsync(w.open_off[0], &zero, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
         MSM_HIP(hipMemcpyAsync(w.open_len[0], &T, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+        MSM_HIP(hipMemcpyAsync(w.open_chunk[0], &zero, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+        std::vector<int> cb(root_chunks);
+        for (int j = 0; j < root_chunks; ++j) cb[j] = j * kChunk;
+        MSM_HIP(hipMemsetAsync(w.chunk_open[0], 0, sizeof(int) * (size_t)root_chunks, ctx->stream));
+        MSM_HIP(hipMemcpyAsync(w.chunk_beg[0], cb.data(), sizeof(int) * (size_t)root_chunks, hipMemcpyHostToDevice, ctx->stream));
         MSM_HIP(hipStreamSynchronize(ctx->stream));  // the sources above are locals
     }
     constexpr int kMaxLevels = 24, kSureLevels = 6;
     int cur = 0;
     bool done = false;
     for (int depth = 0; depth < kMaxLevels && !done; ++depth) {
-        hipLaunchKernelGGL(k_oct_begin_level, dim3(1), dim3(1), 0, ctx->stream, s.counters, s.nopen_level);
+        hipLaunchKernelGGL(k_oct_begin_level, dim3(1), dim3(1), 0, ctx->stream, s.counters);
         hipLaunchKernelGGL(k_oct_decide, dim3(512), dim3(256), 0, ctx->stream, w, cur);
+        hipLaunchKernelGGL(k_oct_count, dim3(1024), dim3(256), 0, ctx->stream, w, cur);
         hipLaunchKernelGGL(k_oct_scan, dim3(1), dim3(1024), 0, ctx->stream, w, cur, depth);
-        hipLaunchKernelGGL(k_oct_fill, dim3(512), dim3(256), 0, ctx->stream, w, cur, s.nopen_level);
+        hipLaunchKernelGGL(k_oct_fill, dim3(1024), dim3(256), 0, ctx->stream, w, cur);
         MSM_HIP(hipGetLastError());
         cur ^= 1;
         if (depth + 1 >= kSureLevels) {  // ico-derived meshes finish at depth 6: from here on look whether anything is still open

@@ -17,7 +17,7 @@ for k in range(n):
     cp_order = int(rng.integers(0, data_order - 1))
     shape = int(rng.integers(0, 4))
     kind = str(rng.choice(["univariate", "multivariate", "patchwise", "ho_univariate", "ho_multivariate"]))
-    D = 1 if "uni" in kind else int(rng.integers(2, 20))
+    D = 1 if "uni" in kind else int(rng.integers(2, 41))
     rmode = int(rng.choice([3, 3, 2, 1])) if not kind.startswith("ho") else 3
     lam = float(rng.uniform(0.01, 0.5))
     kw = dict(seed=int(rng.integers(1, 10**6)), warp_amp=float(rng.uniform(0.0, 1.2)), warp_rot=float(rng.uniform(0.0, 4.0)),
@@ -38,6 +38,15 @@ for k in range(n):
             T, L = cf.T, cf.L
             q = [rng.integers(0, T, 150).astype(np.int32)] + [rng.integers(0, L, 150).astype(np.int32) for _ in range(3)]
             got = cf.computeTripletCost(*q); want = np.array([oc.triplet(*r) for r in zip(*q)])
+            # a whole label step of Fusion (I/Fusion/Fusion.h:181-196): the fused fusion-move kernel (direction-table targets, bins of
+            # <= 128 points) or the split path, against the oracle's replay of the 8 T calls
+            lab = rng.integers(0, L, cf.N).astype(np.int32)
+            label = int(rng.integers(0, L))
+            E, Eo = cf.tripletOctets(lab, label), oc.triplet_octets(lab, label, threads=8)
+            fin = np.isfinite(Eo)
+            if not (np.array_equal(np.isfinite(E), fin) and np.allclose(E[fin], Eo[fin], rtol=1e-9, atol=1e-11)):
+                print("   octets differ: max %.3e" % np.nanmax(np.abs(E - Eo)))
+                got = np.full_like(want, np.inf)  # counted as a mismatch below
         else:
             got, want = cf.computeUnaryCosts(), oc.unary_table()
         both = np.isfinite(want)

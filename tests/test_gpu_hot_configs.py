@@ -176,3 +176,15 @@ def test_univariate_reads_the_first_feature_row(ctx, monkeypatch, path):
     oh = oracle_cost(inp, "ho_univariate", lambda_=0.025, **HCP)
     oh.get_source_data()
     check_moves(ch, oh, inp["triplets"], seed=71, full=True)
+
+
+@pytest.mark.parametrize("sim", [4, 5, 1])
+def test_fusion_move_univariate_dice_and_ssd(ctx, sim):
+    """the triclique univariate class with DICE / genDICE (rank thresholds over a bin's values: serial in the reduction of the
+    fused kernel) and SSD, whole label steps against the oracle's replay"""
+    inp = problem.pairwise_inputs(5, 3, D=1)
+    cf, keep = problem.build_cost(ctx, inp, kind="ho_univariate", simmeasure=sim, lambda_=0.05, **HCP)
+    cf.get_source_data()
+    oc = oracle_cost(inp, "ho_univariate", simmeasure=sim, lambda_=0.05, **HCP)
+    oc.get_source_data()
+    check_moves(cf, oc, inp["triplets"], seed=81 + sim, full=True)
