@@ -3,8 +3,9 @@
 config 3  HCP MSMAll (config/HCP_multimodal_alignment/MSMAllStrainFinalconf1to1_1to3_2: --triclique, HOCR, regoption 3,
           shearmod 0.4, bulkmod 1.6, k_exponent 2, regexp 2): HOMultivariate triplet_likelihood
           (M/DiscreteCostFunction.cpp:565-618) called 8 x T times per label step by Fusion (I/Fusion/Fusion.h:181-196).
-          With 32 feature rows that is k_ho_octets_sample_mv8 -> k_ho_octets_fix -> k_ho_octets_reduce.
-config 4  NeuroImage2017 sMSM_STR (same options, one feature): HOUnivariate, k_ho_octets_sample.
+          That is the fused fusion-move kernel k_ho_move<., 2> (move_kernels.hip), with the tail kernel on demand.
+config 4  NeuroImage2017 sMSM_STR (same options, one feature): HOUnivariate, k_ho_move<., 0>.
+coarse    control grids whose bins exceed 128 points keep the three-kernel path k_ho_octets_sample / _fix / _reduce.
 patchwise the PatchwiseMultivariate class with 16 and 48 feature rows (k_unary_reduce_pw8<4> / <8>).
 gMSM      8 subjects at ico5 data / ico3 control grid, including a whole label step of Fusion.
 
@@ -188,3 +189,13 @@ def test_fusion_move_univariate_dice_and_ssd(ctx, sim):
     oc = oracle_cost(inp, "ho_univariate", simmeasure=sim, lambda_=0.05, **HCP)
     oc.get_source_data()
     check_moves(cf, oc, inp["triplets"], seed=81 + sim, full=True)
+
+
+@pytest.mark.parametrize("cp_order,kind,D", [(1, "ho_univariate", 1), (0, "ho_univariate", 1), (1, "ho_multivariate", 16)])
+def test_fusion_move_coarse_control_grid(ctx, cp_order, kind, D):
+    """first levels of a multiresolution run with a fine data grid: 128 / 512 source vertices per control triangle -- beyond what a
+    workgroup of the fused kernel holds, so the three-kernel path (sample / fix up / reduce, clique_kernels.hip) evaluates the move"""
+    inp = problem.pairwise_inputs(5, cp_order, D=D, warp_amp=0.3, warp_rot=1.0)
+    cf, oc, _ = ho_pair(ctx, inp, kind, 0.05)
+    assert np.diff(cf.patches()[0]).max() > 128
+    check_moves(cf, oc, inp["triplets"], seed=91 + cp_order, full=True)
