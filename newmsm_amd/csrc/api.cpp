@@ -796,14 +796,23 @@ int msm_closest_vertex(msm_mesh *target, const double *q, int32_t N, int32_t *v_
     msm_ctx *ctx = target->ctx;
     int st = ensure_tree(target);
     if (st) return st;
-    DevBuf<double> dq;
-    DevBuf<int> dout;
-    MSM_HIP(dq.upload(q, 3 * (size_t)N, ctx->stream));
-    MSM_HIP(dout.ensure(N));
-    st = launch_closest_vertex(ctx, dev_tree(target), dq.p, N, dout.p);
+    // queries and answers travel through the context's pinned block and grow-only scratch (no allocation per call)
+    const size_t bq = sizeof(double) * 3 * (size_t)N, bo = sizeof(int32_t) * (size_t)N, pq = (bq + 255) & ~(size_t)255;
+    void *pin = nullptr;
+    st = ctx_io_pinned(ctx, pq + bo, &pin);
     if (st) return st;
-    MSM_HIP(dout.download(v_id, N, ctx->stream));
-    return check_status(ctx, "msm_closest_vertex");
+    double *dq = nullptr;
+    int *dout = nullptr;
+    MSM_HIP(ctx_scratch(ctx, 0, bq, (void **)&dq));
+    MSM_HIP(ctx_scratch(ctx, 1, bo, (void **)&dout));
+    std::memcpy(pin, q, bq);
+    MSM_HIP(hipMemcpyAsync(dq, pin, bq, hipMemcpyHostToDevice, ctx->stream));
+    st = launch_closest_vertex(ctx, dev_tree(target), dq, N, dout);
+    if (st) return st;
+    MSM_HIP(hipMemcpyAsync((char *)pin + pq, dout, bo, hipMemcpyDeviceToHost, ctx->stream));
+    st = check_status(ctx, "msm_closest_vertex");
+    std::memcpy(v_id, (char *)pin + pq, bo);
+    return st;
 }
 
 int msm_adaptive_barycentric_weights(msm_mesh *in_mesh, msm_mesh *new_mesh, const double *excl, int32_t *row_ptr, int32_t *col, double *val,

@@ -366,13 +366,21 @@ int group_common_setup(msm_group *g) {
     // estimate_pairs, M/DiscreteGroupModel.cpp:37-55: closest control point of subject B for every control point of A
     g->pairs.resize((size_t)N * S * (S - 1));
     {
+        // one search per TARGET subject b over the control points of all earlier subjects (S - 1 launches instead of S (S - 1) / 2)
         std::vector<std::vector<int32_t>> closest((size_t)S * S);
-        for (int a = 0; a < S; ++a)
-            for (int b = a + 1; b < S; ++b) {
-                closest[(size_t)a * S + b].resize(N);
-                int st = msm_closest_vertex(g->cpmesh[b], g->cpmesh[a]->xyz.data(), N, closest[(size_t)a * S + b].data());
-                if (st) return st;
-            }
+        std::vector<double> q;
+        std::vector<int32_t> found;
+        for (int b = 1; b < S; ++b) {
+            const size_t Mq = (size_t)b * N;
+            q.resize(3 * Mq);
+            for (int a = 0; a < b; ++a)
+                for (int ax = 0; ax < 3; ++ax)
+                    std::copy(g->cpmesh[a]->xyz.begin() + (size_t)ax * N, g->cpmesh[a]->xyz.begin() + (size_t)(ax + 1) * N, q.begin() + ax * Mq + (size_t)a * N);
+            found.resize(Mq);
+            int st = msm_closest_vertex(g->cpmesh[b], q.data(), (int32_t)Mq, found.data());
+            if (st) return st;
+            for (int a = 0; a < b; ++a) closest[(size_t)a * S + b].assign(found.begin() + (size_t)a * N, found.begin() + (size_t)(a + 1) * N);
+        }
         size_t pair = 0;
         for (int a = 0; a < S; ++a)
             for (int v = 0; v < N; ++v)
