@@ -460,8 +460,119 @@ int adaptive_queries(msm_mesh *in_mesh, msm_mesh *new_mesh, bool with_closest, A
     return MSM_OK;
 }
 
+int ensure_adjacency_dev(msm_mesh *m) {
+    if (m->d_tid_ptr) return MSM_OK;
+    msm_ctx *ctx = m->ctx;
+    const Adjacency &adj = mesh_adjacency(m);
+    MSM_HIP(hipMalloc((void **)&m->d_tid_ptr, sizeof(int32_t) * adj.tid_ptr.size()));
+    MSM_HIP(hipMalloc((void **)&m->d_tid, sizeof(int32_t) * std::max<size_t>(adj.tid.size(), 1)));
+    MSM_HIP(hipMalloc((void **)&m->d_fold, sizeof(int32_t) * (2 + (size_t)m->V)));
+    MSM_HIP(hipMemcpyAsync(m->d_tid_ptr, adj.tid_ptr.data(), sizeof(int32_t) * adj.tid_ptr.size(), hipMemcpyHostToDevice, ctx->stream));
+    if (!adj.tid.empty()) MSM_HIP(hipMemcpyAsync(m->d_tid, adj.tid.data(), sizeof(int32_t) * adj.tid.size(), hipMemcpyHostToDevice, ctx->stream));
+    MSM_HIP(hipStreamSynchronize(ctx->stream));
+    return MSM_OK;
+}
+
+namespace {
+struct ResampleScratch {
+    DevBuf<int> fvid, rvid, roff, rfill, rkey, coff, cfill, ckey, row_ptr, col, tkey;
+    DevBuf<double> fw, rw, oldA, newA, ta, rwt, cval, correction, val, data, out, tval;
+};
+ResampleScratch &resample_scratch(msm_ctx *ctx) {
+    if (!ctx->resample_scratch) ctx->resample_scratch = std::shared_ptr<void>(new ResampleScratch(), [](void *p) { delete static_cast<ResampleScratch *>(p); });
+    return *static_cast<ResampleScratch *>(ctx->resample_scratch.get());
+}
+}  // namespace
+
+int adaptive_weights_dev(msm_mesh *in_mesh, msm_mesh *new_mesh, AdaptiveDev &out, bool check) {
+    if (in_mesh->ctx != new_mesh->ctx) return fail(MSM_ERR_INVALID, "adaptive weights: the two meshes belong to different contexts");
+    msm_ctx *ctx = in_mesh->ctx;
+    const int nOld = in_mesh->V, nNew = new_mesh->V;
+    int st = ensure_tree(in_mesh);
+    if (st) return st;
+    st = ensure_tree(new_mesh);
+    if (st) return st;
+    if ((st = ensure_adjacency_dev(in_mesh)) || (st = ensure_adjacency_dev(new_mesh))) return st;
+    ResampleScratch &s = resample_scratch(ctx);
+    const size_t cap = 3 * (size_t)nNew + 3 * (size_t)nOld;
+    MSM_HIP(s.fvid.ensure(3 * (size_t)nNew));
+    MSM_HIP(s.fw.ensure(3 * (size_t)nNew));
+    MSM_HIP(s.rvid.ensure(3 * (size_t)nOld));
+    MSM_HIP(s.rw.ensure(3 * (size_t)nOld));
+    MSM_HIP(s.oldA.ensure(nOld));
+    MSM_HIP(s.newA.ensure(nNew));
+    MSM_HIP(s.ta.ensure((size_t)std::max(in_mesh->T, new_mesh->T)));
+    MSM_HIP(s.roff.ensure((size_t)nNew + 1));
+    MSM_HIP(s.rfill.ensure(nNew));
+    MSM_HIP(s.rkey.ensure(3 * (size_t)nOld));
+    MSM_HIP(s.rwt.ensure(3 * (size_t)nOld));
+    MSM_HIP(s.coff.ensure((size_t)nOld + 1));
+    MSM_HIP(s.cfill.ensure(nOld));
+    MSM_HIP(s.ckey.ensure(cap));
+    MSM_HIP(s.cval.ensure(cap));
+    MSM_HIP(s.correction.ensure(nOld));
+    MSM_HIP(s.row_ptr.ensure((size_t)nNew + 1));
+    MSM_HIP(s.col.ensure(cap));
+    MSM_HIP(s.val.ensure(cap));
+    MSM_HIP(s.tkey.ensure(cap));
+    MSM_HIP(s.tval.ensure(cap));
+    // forward: the new mesh's vertices in the old mesh's tree; reverse: the old vertices in the new mesh's tree (:74-78)
+    st = launch_query(ctx, dev_tree(in_mesh), new_mesh->d_xyz, nNew, nullptr, s.fvid.p, s.fw.p, MSM_WEIGHTS_PROJECTED);
+    if (st) return st;
+    st = launch_query(ctx, dev_tree(new_mesh), in_mesh->d_xyz, nOld, nullptr, s.rvid.p, s.rw.p, MSM_WEIGHTS_PROJECTED);
+    if (st) return st;
+    st = launch_vertex_areas(ctx, in_mesh->d_xyz, nOld, in_mesh->d_tri, in_mesh->T, in_mesh->d_tid_ptr, in_mesh->d_tid, s.ta.p, s.oldA.p);
+    if (st) return st;
+    st = launch_vertex_areas(ctx, new_mesh->d_xyz, nNew, new_mesh->d_tri, new_mesh->T, new_mesh->d_tid_ptr, new_mesh->d_tid, s.ta.p, s.newA.p);
+    if (st) return st;
+    AdaptiveDevArgs a;
+    a.nOld = nOld, a.nNew = nNew;
+    a.fvid = s.fvid.p, a.rvid = s.rvid.p, a.fw = s.fw.p, a.rw = s.rw.p, a.oldA = s.oldA.p, a.newA = s.newA.p;
+    a.roff = s.roff.p, a.rfill = s.rfill.p, a.rkey = s.rkey.p, a.rwt = s.rwt.p;
+    a.coff = s.coff.p, a.cfill = s.cfill.p, a.ckey = s.ckey.p, a.cval = s.cval.p, a.correction = s.correction.p;
+    a.row_ptr = s.row_ptr.p, a.col = s.col.p, a.val = s.val.p, a.tkey = s.tkey.p, a.tval = s.tval.p;
+    st = launch_adaptive_surgery(ctx, a);
+    if (st) return st;
+    if (check) {
+        st = check_status(ctx, "adaptive weights");  // a failed search in either direction (synchronises)
+        if (st) return st;
+    }
+    out.nOld = nOld, out.nNew = nNew, out.row_ptr = s.row_ptr.p, out.col = s.col.p, out.val = s.val.p;
+    return MSM_OK;
+}
+
+int apply_weights_dev(msm_ctx *ctx, const AdaptiveDev &w, const double *d_data, int D, double *d_out) {
+    return launch_apply_rows(ctx, w.nNew, w.nOld, D, w.row_ptr, w.col, w.val, d_data, d_out);
+}
+
+// weights as host CSR through the device surgery (no exclusion mask)
+static int adaptive_weights_via_device(msm_mesh *in_mesh, msm_mesh *new_mesh, std::vector<int32_t> &row_ptr, std::vector<int32_t> &col, std::vector<double> &val) {
+    AdaptiveDev w;
+    int st = adaptive_weights_dev(in_mesh, new_mesh, w);
+    if (st) return st;
+    msm_ctx *ctx = in_mesh->ctx;
+    row_ptr.resize((size_t)w.nNew + 1);
+    MSM_HIP(hipMemcpyAsync(row_ptr.data(), w.row_ptr, sizeof(int32_t) * row_ptr.size(), hipMemcpyDeviceToHost, ctx->stream));
+    MSM_HIP(hipStreamSynchronize(ctx->stream));
+    const size_t nnz = (size_t)row_ptr.back();
+    col.resize(nnz);
+    val.resize(nnz);
+    if (nnz) {
+        MSM_HIP(hipMemcpyAsync(col.data(), w.col, sizeof(int32_t) * nnz, hipMemcpyDeviceToHost, ctx->stream));
+        MSM_HIP(hipMemcpyAsync(val.data(), w.val, sizeof(double) * nnz, hipMemcpyDeviceToHost, ctx->stream));
+        MSM_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return MSM_OK;
+}
+
+static bool surgery_on_device() {
+    static const bool host = [] { const char *e = std::getenv("MSMHIP_SURGERY"); return e && std::strcmp(e, "host") == 0; }();
+    return !host;
+}
+
 int adaptive_weights(msm_mesh *in_mesh, msm_mesh *new_mesh, const double *excl, std::vector<int32_t> &row_ptr,
                      std::vector<int32_t> &col, std::vector<double> &val) {
+    if (!excl && in_mesh->ctx == new_mesh->ctx && surgery_on_device()) return adaptive_weights_via_device(in_mesh, new_mesh, row_ptr, col, val);
     AdaptiveQueries q;
     int st = adaptive_queries(in_mesh, new_mesh, excl != nullptr, q);
     if (st) return st;
@@ -833,6 +944,28 @@ int msm_adaptive_barycentric_weights(msm_mesh *in_mesh, msm_mesh *new_mesh, cons
 
 int msm_metric_resample(msm_mesh *in_mesh, const double *data, int32_t D, msm_mesh *new_mesh, const double *excl, double *out, double *excl_out) {
     if (!in_mesh || !new_mesh || !data || !out || D <= 0) return fail(MSM_ERR_INVALID, "msm_metric_resample: bad arguments");
+    if (!excl && !excl_out && in_mesh->ctx == new_mesh->ctx && surgery_on_device()) {
+        // queries, list surgery and the weighted sums on the device; only the data go up and the resampled data come back
+        msm_ctx *ctx = in_mesh->ctx;
+        AdaptiveDev w;
+        int st = adaptive_weights_dev(in_mesh, new_mesh, w);
+        if (st) return st;
+        ResampleScratch &s = resample_scratch(ctx);
+        const size_t nin = (size_t)D * in_mesh->V, nout = (size_t)D * new_mesh->V;
+        MSM_HIP(s.data.ensure(nin));
+        MSM_HIP(s.out.ensure(nout));
+        st = upload_staged(ctx, s.data.p, data, sizeof(double) * nin);
+        if (st) return st;
+        st = apply_weights_dev(ctx, w, s.data.p, D, s.out.p);
+        if (st) return st;
+        void *pin = nullptr;
+        st = ctx_io_pinned(ctx, sizeof(double) * nout, &pin);
+        if (st) return st;
+        MSM_HIP(hipMemcpyAsync(pin, s.out.p, sizeof(double) * nout, hipMemcpyDeviceToHost, ctx->stream));
+        MSM_HIP(hipStreamSynchronize(ctx->stream));
+        std::memcpy(out, pin, sizeof(double) * nout);
+        return MSM_OK;
+    }
     std::vector<int32_t> rp, c;
     std::vector<double> v;
     int st = adaptive_weights(in_mesh, new_mesh, excl, rp, c, v);

@@ -8,6 +8,8 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
+#include <cstring>
 
 #include "cost_internal.hpp"
 #include "host_parallel.hpp"
@@ -137,6 +139,24 @@ int resample_weights(msm_cost *c) {
         for (int j = 0; j < cfw_nrows(c); ++j)
             if (cfw_at(c, j, k) > best) best = cfw_at(c, j, k);
         mw[k] = best;
+    }
+    static const bool host_surgery = [] { const char *e = std::getenv("MSMHIP_SURGERY"); return e && std::strcmp(e, "host") == 0; }();
+    if (!host_surgery) {
+        // queries, weight lists and the weighted sum in HBM (resample_kernels.hip); the N sums come back for msm_cost_absolute_weights
+        msm_ctx *ctx = c->ctx;
+        AdaptiveDev w;
+        int st = adaptive_weights_dev(c->source, c->cpgrid, w);
+        if (st) return st;
+        MSM_HIP(c->d_maxw.ensure(Ns));
+        MSM_HIP(c->d_absw.ensure(N));
+        st = upload_staged(ctx, c->d_maxw.p, mw.data(), sizeof(double) * (size_t)Ns);
+        if (st) return st;
+        st = apply_weights_dev(ctx, w, c->d_maxw.p, 1, c->d_absw.p);
+        if (st) return st;
+        c->absw.resize(N);
+        MSM_HIP(hipMemcpyAsync(c->absw.data(), c->d_absw.p, sizeof(double) * (size_t)N, hipMemcpyDeviceToHost, ctx->stream));
+        MSM_HIP(hipStreamSynchronize(ctx->stream));
+        return MSM_OK;
     }
     std::vector<int32_t> rp, col;
     std::vector<double> val;
@@ -549,8 +569,26 @@ int msm_cost_unary_table_fetch(msm_cost *c, double *U) {
     if (!c || !U) return fail(MSM_ERR_INVALID, "msm_cost_unary_table_fetch: null argument");
     int st = need(c, c->table_valid, "msm_cost_unary_table_async()");
     if (st) return st;
-    MSM_HIP(c->d_U.download(U, (size_t)c->L * c->cpgrid->V, c->ctx->stream));
-    return check_status(c->ctx, "computeUnaryCosts");
+    msm_ctx *ctx = c->ctx;
+    const size_t n = (size_t)c->L * c->cpgrid->V;
+    void *mapped = ctx_mapped(ctx, U, sizeof(double) * n);
+    if (mapped && reinterpret_cast<uintptr_t>(mapped) % 16 == 0) {
+        // U lies in a msm_host_alloc block: a copy KERNEL writes it there (and the status word into the mapped flag) -- a copy-engine
+        // command of this size costs 15 us of latency plus a second one for the status
+        st = ctx_flag(ctx);
+        if (st) return st;
+        st = launch_copy_to_mapped(ctx, c->d_U.p, static_cast<double *>(mapped), n, ctx->d_flag_map);
+        if (st) return st;
+        MSM_HIP(hipStreamSynchronize(ctx->stream));
+        volatile int *flags = ctx->h_flag;
+        if (flags[0] != 0) {
+            flags[0] = 0;
+            return check_status(ctx, "computeUnaryCosts");
+        }
+        return MSM_OK;
+    }
+    MSM_HIP(c->d_U.download(U, n, ctx->stream));
+    return check_status(ctx, "computeUnaryCosts");
 }
 
 int msm_cost_unary_table(msm_cost *c, double *U) {

@@ -57,7 +57,7 @@ struct msm_cost {
     DevBuf<uint32_t> d_fix_off;  // segment offsets of the fix-up list for (patches, L)
     bool fix_off_valid = false;
     std::vector<double> absw;
-    DevBuf<double> d_absw;
+    DevBuf<double> d_absw, d_maxw;  // resample_weights: per control point / its input per source vertex
     // unary table
     DevBuf<double> d_U;
     bool table_valid = false;

@@ -66,6 +66,7 @@ struct msm_group {
     // scratch of subject_patches, kept between subjects
     DevBuf<double> d_centres, d_sep;
     DevBuf<double> d_rotated;  // the L rotated data meshes of the subject being set up
+    DevBuf<double> d_subject_feat;  // its features (D x V), the input of the device resampling
     DevBuf<uint32_t> d_slots;
     DevBuf<int> d_counts;
 };
@@ -449,6 +450,45 @@ int group_subject_setup(msm_group *g, int s) {
     std::vector<std::vector<double>> rotated(L);
     const size_t LV = (size_t)L * V;
     DevBuf<double> &d_rot = g->d_rotated;
+    static const bool host_surgery = [] { const char *e = std::getenv("MSMHIP_SURGERY"); return e && std::strcmp(e, "host") == 0; }();
+    if (mesh_tree_on_gpu(sm) && !host_surgery) {
+        // Everything in HBM (data meshes large enough for the GPU octree build): per label the rotated coordinates become the
+        // scratch mesh's, its tree is rebuilt there, and queries, weight-list surgery (resample_kernels.hip) and the weighted sums
+        // write F[s][l] directly.  Only the subject's features go up; nothing comes back.
+        MSM_HIP(d_rot.ensure(3 * LV));
+        for (int a = 0; a < 3; ++a)
+            MSM_HIP(hipMemcpyAsync(d_rot.p + a * LV, dm->d_xyz + (size_t)a * V, sizeof(double) * (size_t)V, hipMemcpyDeviceToDevice, ctx->stream));
+        for (int l = 1; l < L; ++l) {
+            const double lab[3] = {g->labels[l], g->labels[L + l], g->labels[2 * (size_t)L + l]};
+            int st = launch_rotate_to_label(ctx, dm->d_xyz, V, centre, lab, d_rot.p + (size_t)l * V, LV);
+            if (st) return st;
+        }
+        MSM_HIP(g->d_subject_feat.ensure((size_t)D * V));
+        int st = upload_staged(ctx, g->d_subject_feat.p, g->feat[s].data(), sizeof(double) * (size_t)D * V);
+        if (st) return st;
+        lap("rotations + feature upload");
+        for (int l = 0; l < L; ++l) {
+            for (int a = 0; a < 3; ++a)
+                MSM_HIP(hipMemcpyAsync(sm->d_xyz + (size_t)a * V, d_rot.p + a * LV + (size_t)l * V, sizeof(double) * (size_t)V, hipMemcpyDeviceToDevice, ctx->stream));
+            sm->tree_valid = false;  // rebuilt by adaptive_weights_dev
+            AdaptiveDev w;
+            st = adaptive_weights_dev(sm, g->tmpl, w, false);
+            if (st) return st;
+            auto &buf = g->F[(size_t)s * L + l];
+            if (!buf) buf.reset(new DevBuf<double>());
+            MSM_HIP(buf->ensure((size_t)D * Vt));
+            st = apply_weights_dev(ctx, w, g->d_subject_feat.p, D, buf->p);
+            if (st) return st;
+        }
+        st = check_status(ctx, "get_patch_data (resampling)");
+        if (st) return st;
+        lap("trees + queries + weights + resample (device)");
+        st = subject_patches(g, s);
+        if (st) return st;
+        lap("patches");
+        g->have_subject[s] = 1;
+        return MSM_OK;
+    }
     {
         MSM_HIP(d_rot.ensure(3 * LV));
         for (int a = 0; a < 3; ++a)  // label 0 is the centre of the sampling grid: no rotation

@@ -131,6 +131,7 @@ struct msm_ctx {
     // a mapped pinned word kernels of the per-label-step calls store a raised status into (no status copy on their fast path)
     int *h_flag = nullptr;
     int *d_flag_map = nullptr;  // its device address
+    std::shared_ptr<void> resample_scratch;  // api.cpp: device buffers of adaptive_weights_dev, kept between calls
     // scratch of the GPU octree build (octree_kernels.hip), grow only
     double *oct_box = nullptr;
     int *oct_ints = nullptr, *oct_counters = nullptr, *oct_hcounters = nullptr;
@@ -198,6 +199,16 @@ struct AdaptiveQueries {
 };
 // directions: 1 forward (new -> old), 2 reverse (old -> new), 3 both
 int adaptive_queries(msm_mesh *in_mesh, msm_mesh *new_mesh, bool with_closest, AdaptiveQueries &q, int directions = 3);
+// The same weights with queries AND list surgery on the device (resample_kernels.hip; no exclusion mask): the CSR stays in HBM.
+struct AdaptiveDev {
+    int nOld = 0, nNew = 0;
+    const int *row_ptr = nullptr, *col = nullptr;  // device; valid until the next adaptive_weights_dev on this context
+    const double *val = nullptr;
+};
+int adaptive_weights_dev(msm_mesh *in_mesh, msm_mesh *new_mesh, AdaptiveDev &out, bool check = true);  // check = false: the caller checks the status word
+// out (device, D x V(new)) = the weights applied to d_data (device, D x V(in)): barycentric_data_interpolation R/resampler.cpp:40-52
+int apply_weights_dev(msm_ctx *ctx, const AdaptiveDev &w, const double *d_data, int D, double *d_out);
+int ensure_adjacency_dev(msm_mesh *m);  // Mpoint::trID lists as CSR in HBM (d_tid_ptr / d_tid)
 void adaptive_surgery(const AdaptiveQueries &q, int nOld, int nNew, const std::vector<double> &oldA, const std::vector<double> &newA,
                       const double *excl, std::vector<int32_t> &row_ptr, std::vector<int32_t> &col, std::vector<double> &val);
 void vertex_areas_of(const double *xyz, const int32_t *tri, int V, int T, const Adjacency &a, std::vector<double> &area);

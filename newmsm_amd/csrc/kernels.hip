@@ -3,6 +3,8 @@
 // All arithmetic that decides an index (which triangle, which patch) is FP64 in the reference's own
 // operation order (this file is compiled with -ffp-contract=off).  No MFMA: the path is gather /
 // compare / short reductions.  Wavefront = 64 lanes throughout.
+#include <algorithm>
+
 #include "kernels.hpp"
 #include "search_device.hpp"
 
@@ -160,6 +162,27 @@ __global__ __launch_bounds__(256) void k_build_raytri(const TriRec *__restrict__
     }
     double2 *od = reinterpret_cast<double2 *>(o + 3);
     for (int k = 0; k < 6; ++k) od[k] = make_double2(d[2 * k], d[2 * k + 1]);
+}
+
+__global__ __launch_bounds__(256) void k_copy_to_mapped(const double2 *__restrict__ src, double2 *__restrict__ dst, size_t n2, const double *__restrict__ src1,
+                                                         double *__restrict__ dst1, const int *__restrict__ status, int *__restrict__ flags) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n2) dst[i] = src[i];
+    if (i == 0) {
+        if (src1) *dst1 = *src1;  // the odd element
+        const int st = *status;
+        if (st != 0) __hip_atomic_store(flags, st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+int launch_copy_to_mapped(msm_ctx *ctx, const double *d_src, double *mapped_dst, size_t n, int *flags_mapped) {
+    const size_t n2 = n / 2;
+    const bool odd = (n & 1) != 0;
+    hipLaunchKernelGGL(k_copy_to_mapped, dim3((unsigned)((std::max<size_t>(n2, 1) + 255) / 256)), dim3(256), 0, ctx->stream,
+                       reinterpret_cast<const double2 *>(d_src), reinterpret_cast<double2 *>(mapped_dst), n2, odd ? d_src + n - 1 : nullptr,
+                       odd ? mapped_dst + n - 1 : nullptr, ctx->d_status, flags_mapped);
+    MSM_HIP(hipGetLastError());
+    return MSM_OK;
 }
 
 int launch_build_raytri(msm_ctx *ctx, const TriRec *d_rec, const float4 *d_edge, int T, const double *d_feat1, int D, float4 *d_out) {

@@ -12,6 +12,27 @@ int launch_build_recs(msm_ctx *ctx, const double *d_xyz, int V, const int32_t *d
                       int nentries, float4 *d_cone);
 // ray-table records (internal.hpp: kRayPieces) from the triangle records, the edge planes and, when given, a single feature row (V doubles)
 int launch_build_raytri(msm_ctx *ctx, const TriRec *d_rec, const float4 *d_edge, int T, const double *d_feat1, int D, float4 *d_out);
+// ---- adaptive barycentric weights on the device (resample_kernels.hip): Resampler::get_adaptive_barycentric_weights R/resampler.cpp:72-140
+struct AdaptiveDevArgs {
+    int nOld, nNew;
+    const int *fvid, *rvid;        // forward (new -> old) / reverse (old -> new) hit-triangle vertex ids, 3 x N SoA
+    const double *fw, *rw;         // their projected barycentric weights
+    const double *oldA, *newA;     // vertex areas
+    int *roff, *rfill, *rkey;      // transposed reverse lists: offsets (nNew + 1), fill counters (nNew), old vertex ids (3 nOld)
+    double *rwt;
+    int *coff, *cfill, *ckey;      // columns of the result: offsets (nOld + 1), fill counters (nOld), new vertex ids (3 nNew + 3 nOld)
+    double *cval, *correction;     // (nOld)
+    int *tkey;                     // scratch of the long-list sort, 3 nNew + 3 nOld
+    double *tval;
+    int *row_ptr, *col;            // the result as CSR: nNew + 1, 3 nNew + 3 nOld
+    double *val;
+};
+int launch_vertex_areas(msm_ctx *ctx, const double *d_xyz, int V, const int32_t *d_tri, int T, const int32_t *d_tid_ptr, const int32_t *d_tid, double *d_ta,
+                        double *d_area);
+int launch_adaptive_surgery(msm_ctx *ctx, const AdaptiveDevArgs &a);
+int launch_apply_rows(msm_ctx *ctx, int nNew, int nOld, int D, const int *row_ptr, const int *col, const double *val, const double *d_data, double *d_out);
+// n doubles from device memory into mapped pinned host memory, and the context's status word into flags_mapped[0] when it is set
+int launch_copy_to_mapped(msm_ctx *ctx, const double *d_src, double *mapped_dst, size_t n, int *flags_mapped);
 int launch_query(msm_ctx *ctx, const DevTree &T, const double *d_q, int N, int *d_tri, int *d_vid, double *d_w, int mode);
 int launch_closest_vertex(msm_ctx *ctx, const DevTree &T, const double *d_q, int N, int *d_out);
 // smooth_data: unit vectors of the N vertices (d_unit: 3 x N scratch), then one wavefront per output vertex

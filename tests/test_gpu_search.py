@@ -132,6 +132,22 @@ def test_adaptive_barycentric_weights_bit_exact(ctx, oin, onew):
     assert np.allclose(sums, 1.0, atol=1e-14)
 
 
+@pytest.mark.parametrize("oin,onew", [(6, 2), (1, 5), (6, 6), (0, 4)])
+def test_adaptive_weights_long_lists_bit_exact(ctx, oin, onew):
+    """The device list surgery (resample_kernels.hip) across very different resolutions: hundreds of entries per
+    transposed reverse list (fine -> coarse, sorted by the workgroup rank sort) or per correction column (coarse -> fine),
+    and two warped ico6 meshes (the gMSM set-up case).  Same CSR and same bits as the reference's serial std::map surgery."""
+    xin, tin = M.make_mesh_from_icosa(oin)
+    xnew, tnew = M.make_mesh_from_icosa(onew)
+    xin = synthetic.known_warp(xin, seed=33, rot_deg=4.0, amp=1.5)
+    min_, mnew = M.Mesh(ctx, xin, tin), M.Mesh(ctx, xnew, tnew)
+    rp, col, val = M.get_adaptive_barycentric_weights(min_, mnew)
+    orp, ocol, oval = O.adaptive_barycentric_weights(O.Mesh(xin, tin), O.Mesh(xnew, tnew))
+    assert np.array_equal(rp, orp) and np.array_equal(col, ocol) and np.array_equal(val, oval)
+    data = synthetic.features(xin, 2)
+    assert np.array_equal(M.metric_resample(min_, data, mnew), O.metric_resample(O.Mesh(xin, tin), data, O.Mesh(xnew, tnew)))
+
+
 def test_adaptive_weights_with_exclusion(ctx):
     xin, tin = M.make_mesh_from_icosa(4)
     xnew, tnew = M.make_mesh_from_icosa(3)

@@ -58,6 +58,25 @@ def test_unary_table_univariate(ctx, data_order, cp_order, sim):
     assert np.array_equal(cf.computeUnaryCost(nodes, labels), U[labels, nodes])
 
 
+def test_unary_table_into_mapped_host_memory(ctx):
+    """computeUnaryCosts(out=Context.host_array(...)): the table is written by a copy kernel straight into mapped pinned host
+    memory (no staging copy); repeated calls, a table after a coordinate change, and the default path give the same numbers."""
+    inp = problem.pairwise_inputs(5, 3, D=1)
+    cf, keep = problem.build_cost(ctx, inp, kind="univariate")
+    cf.get_source_data()
+    plain = cf.computeUnaryCosts().copy()
+    out = ctx.host_array((cf.L, cf.N))
+    out[:] = -1.0
+    got = cf.computeUnaryCosts(out=out)
+    assert got is out and np.array_equal(out, plain)
+    out[:] = -2.0
+    cf.reset_source(keep["source"])  # invalidates the table: recomputed, same inputs
+    cf.get_source_data()
+    assert np.array_equal(cf.computeUnaryCosts(out=out), plain)
+    odd = ctx.host_array((cf.L * cf.N + 1,))[1:].reshape(cf.L, cf.N)  # 8-byte aligned only: the staged route
+    assert np.array_equal(cf.computeUnaryCosts(out=odd), plain)
+
+
 def test_unary_table_with_cfweight_and_samples_set(ctx):
     inp = problem.pairwise_inputs(5, 3, D=1, rescale=False)
     rng = np.random.default_rng(0)
