@@ -156,10 +156,29 @@ int upload_staged(msm_ctx *ctx, void *dst, const void *src, size_t bytes) {
     return MSM_OK;
 }
 
-int ensure_tree(msm_mesh *m) {
+static int ensure_tree_overlapped(msm_mesh *m, const std::function<void()> *overlap);
+int ensure_tree(msm_mesh *m) { return ensure_tree_overlapped(m, nullptr); }
+
+int ensure_tree_pair(msm_mesh *a, msm_mesh *b) {
+    if (a->tree_valid || b->tree_valid || a == b || tree_on_gpu(a) == tree_on_gpu(b)) {
+        const int st = ensure_tree(a);
+        return st ? st : ensure_tree(b);
+    }
+    msm_mesh *dev = tree_on_gpu(a) ? a : b, *host = dev == a ? b : a;
+    bool built = false;
+    const std::function<void()> work = [&] {
+        build_octree(host->xyz.data(), host->tri.data(), host->V, host->T, host->tree);
+        built = true;
+    };
+    int st = ensure_tree_overlapped(dev, &work);
+    if (st) return st;
+    return built ? upload_tree(host) : ensure_tree(host);
+}
+
+static int ensure_tree_overlapped(msm_mesh *m, const std::function<void()> *overlap) {
     if (m->tree_valid) return MSM_OK;
     if (tree_on_gpu(m)) {
-        const int st = gpu_build_octree(m);
+        const int st = gpu_build_octree(m, overlap);
         if (st == MSM_OK) return finish_tree(m);
         if (st != MSM_ERR_CAPACITY) return st;  // a tree that outgrew the preallocated arrays (a degenerate mesh): the host build below
     }
@@ -488,9 +507,7 @@ int adaptive_weights_dev(msm_mesh *in_mesh, msm_mesh *new_mesh, AdaptiveDev &out
     if (in_mesh->ctx != new_mesh->ctx) return fail(MSM_ERR_INVALID, "adaptive weights: the two meshes belong to different contexts");
     msm_ctx *ctx = in_mesh->ctx;
     const int nOld = in_mesh->V, nNew = new_mesh->V;
-    int st = ensure_tree(in_mesh);
-    if (st) return st;
-    st = ensure_tree(new_mesh);
+    int st = ensure_tree_pair(in_mesh, new_mesh);
     if (st) return st;
     if ((st = ensure_adjacency_dev(in_mesh)) || (st = ensure_adjacency_dev(new_mesh))) return st;
     ResampleScratch &s = resample_scratch(ctx);

@@ -75,20 +75,41 @@ int patches_by_range(msm_cost *c) {
     msm_ctx *ctx = c->ctx;
     const int N = c->cpgrid->V, Ns = c->source->V;
     MSM_HIP(c->d_maxsep.upload(c->maxsep.data(), N, ctx->stream));
-    MSM_HIP(c->d_counts.ensure(N));
-    int cap = 128;
-    std::vector<int> counts(N);
+    MSM_HIP(c->d_counts.ensure((size_t)N + 1));  // + the number of undecided entries
+    MSM_HIP(c->d_chunkb.ensure((size_t)(Ns + 63) / 64 + 1));
+    int cap = std::max(128, c->patch_cap_hint);  // the previous call's largest patch: one k_range pass instead of two
+    std::vector<int> counts((size_t)N + 1);
     std::vector<uint32_t> slots;
+    c->pidx_asc_on_device = false;
     for (int attempt = 0; attempt < 3; ++attempt) {
         MSM_HIP(c->d_slots.ensure((size_t)N * cap));
-        int st = launch_range(ctx, c->cpgrid->d_xyz, N, c->source->d_xyz, Ns, c->d_maxsep.p, c->p.range, cap, c->d_slots.p, c->d_counts.p);
+        int st = launch_range(ctx, c->cpgrid->d_xyz, N, c->source->d_xyz, Ns, c->d_maxsep.p, c->p.range, cap, c->d_slots.p, c->d_counts.p, c->d_chunkb.p,
+                              c->d_counts.p + N);
         if (st) return st;
-        MSM_HIP(c->d_counts.download(counts.data(), N, ctx->stream));
+        MSM_HIP(c->d_counts.download(counts.data(), (size_t)N + 1, ctx->stream));
         MSM_HIP(hipStreamSynchronize(ctx->stream));
-        const int mx = *std::max_element(counts.begin(), counts.end());
+        const int mx = *std::max_element(counts.begin(), counts.begin() + N);
+        c->patch_cap_hint = std::max(c->patch_cap_hint, mx + 16);
         if (mx <= cap) break;
         if (attempt == 2) return fail(MSM_ERR_CAPACITY, "patch capacity");
         cap = mx + 16;
+    }
+    if (counts[N] == 0) {
+        // nothing sits on the threshold: the rows are final, and the list is put together where it is used (the host receives
+        // the compact list, a third of a megabyte at ico6 / ico4, instead of the slot array)
+        c->pptr.assign((size_t)N + 1, 0);
+        for (int k = 0; k < N; ++k) c->pptr[k + 1] = c->pptr[k] + counts[k];
+        const size_t total = (size_t)c->pptr[N];
+        MSM_HIP(c->d_pptr.upload(c->pptr.data(), c->pptr.size(), ctx->stream));
+        MSM_HIP(c->d_pidx_asc.ensure(std::max<size_t>(total, 1)));
+        int st = launch_patch_compact(ctx, c->d_slots.p, cap, c->d_pptr.p, N, c->d_pidx_asc.p);
+        if (st) return st;
+        c->pidx.resize(total);
+        if (total) MSM_HIP(c->d_pidx_asc.download(c->pidx.data(), total, ctx->stream));
+        MSM_HIP(hipStreamSynchronize(ctx->stream));
+        c->pidx_asc_on_device = true;
+        c->ngroups = N;
+        return MSM_OK;
     }
     slots.resize((size_t)N * cap);
     MSM_HIP(c->d_slots.download(slots.data(), slots.size(), ctx->stream));
@@ -466,36 +487,15 @@ int msm_cost_get_source_data(msm_cost *c) {
     if (is_ho(c) || std::getenv("MSMHIP_NO_PATCH_SORT")) {
         MSM_HIP(c->d_pidx.upload_vec(c->pidx, ctx->stream));
     } else {
-        // Device-side order of the points of each patch: Morton order of their positions, so that the lanes of a wavefront
-        // sample neighbouring places of the target (neighbouring direction cells and triangle records share cache lines).
-        // The similarity does not depend on the order of the patch points; the API keeps reporting ascending ids.
-        const int Ns = c->source->V;
-        const double *sx = c->source->xyz.data();
-        auto spread = [](uint32_t v) {
-            v &= 0x3ff;
-            v = (v | (v << 16)) & 0x030000ff;
-            v = (v | (v << 8)) & 0x0300f00f;
-            v = (v | (v << 4)) & 0x030c30c3;
-            v = (v | (v << 2)) & 0x09249249;
-            return v;
-        };
-        std::vector<uint32_t> code(Ns);
-        for (int v = 0; v < Ns; ++v) {
-            uint32_t q[3];
-            for (int a = 0; a < 3; ++a) {
-                const double u = (sx[(size_t)a * Ns + v] + kBounds) / (2 * kBounds);
-                q[a] = (uint32_t)std::max(0.0, std::min(1023.0, u == u ? u * 1024.0 : 0.0));
-            }
-            code[v] = spread(q[0]) << 2 | spread(q[1]) << 1 | spread(q[2]);
-        }
-        std::vector<int32_t> sorted(c->pidx);
-        parallel_chunks(c->ngroups, std::min(host_workers(), 8), [&](int, int g0, int g1) {
-            for (int g = g0; g < g1; ++g)
-                std::sort(sorted.begin() + c->pptr[g], sorted.begin() + c->pptr[g + 1],
-                          [&](int32_t x, int32_t y) { return code[x] < code[y] || (code[x] == code[y] && x < y); });
-        });
-        MSM_HIP(c->d_pidx.upload_vec(sorted, ctx->stream));
-        MSM_HIP(hipStreamSynchronize(ctx->stream));
+        // Device-side order of the points of each patch: Morton order of their positions (launch_sort_patches), so that the
+        // lanes of a wavefront sample neighbouring places of the target (neighbouring direction cells and triangle records
+        // share cache lines).  The similarity does not depend on the order of the patch points; the API keeps reporting
+        // ascending ids.
+        if (!c->pidx_asc_on_device) MSM_HIP(c->d_pidx_asc.upload_vec(c->pidx, ctx->stream));
+        MSM_HIP(c->d_pidx.ensure(std::max<size_t>(c->pidx.size(), 1)));
+        MSM_HIP(c->d_code.ensure(c->source->V));
+        st = launch_sort_patches(ctx, c->source->d_xyz, c->source->V, c->d_pptr.p, c->ngroups, c->d_pidx_asc.p, c->d_code.p, c->d_pidx.p);
+        if (st) return st;
     }
     MSM_HIP(c->d_absw.upload(c->absw.data(), c->absw.size(), ctx->stream));
     {

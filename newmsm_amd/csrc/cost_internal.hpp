@@ -57,6 +57,11 @@ struct msm_cost {
     DevBuf<uint32_t> d_fix_off;  // segment offsets of the fix-up list for (patches, L)
     bool fix_off_valid = false;
     std::vector<double> absw;
+    DevBuf<int32_t> d_pidx_asc;  // patch members in ascending id (the host order); d_pidx holds the device order
+    DevBuf<uint32_t> d_code;     // Morton codes of the source vertices
+    DevBuf<double4> d_chunkb;    // k_range: bounding balls of the source vertices, 64 ids at a time
+    bool pidx_asc_on_device = false;
+    int patch_cap_hint = 0;
     DevBuf<double> d_absw, d_maxw;  // resample_weights: per control point / its input per source vertex
     // unary table
     DevBuf<double> d_U;

@@ -66,6 +66,7 @@ struct msm_group {
     // scratch of subject_patches, kept between subjects
     DevBuf<double> d_centres, d_sep;
     DevBuf<double> d_rotated;  // the L rotated data meshes of the subject being set up
+    DevBuf<double4> d_chunkb;       // k_range: bounding balls of the template's vertices, 64 ids at a time
     DevBuf<double> d_subject_feat;  // its features (D x V), the input of the device resampling
     DevBuf<uint32_t> d_slots;
     DevBuf<int> d_counts;
@@ -103,22 +104,38 @@ int subject_patches(msm_group *g, int s) {
     DevBuf<int> &d_counts = g->d_counts;
     MSM_HIP(d_c.upload(centres.data(), centres.size(), ctx->stream));
     MSM_HIP(d_sep.upload(sep.data(), sep.size(), ctx->stream));
-    MSM_HIP(d_counts.ensure(M));
+    MSM_HIP(d_counts.ensure((size_t)M + 1));  // + the number of undecided entries
+    MSM_HIP(g->d_chunkb.ensure((size_t)(Vt + 63) / 64 + 1));
     int cap = std::max(256, g->patch_cap_hint);  // the previous call's largest patch: one k_range pass instead of two
-    std::vector<int> counts(M);
+    std::vector<int> counts((size_t)M + 1);
     for (int attempt = 0; attempt < 3; ++attempt) {
         MSM_HIP(d_slots.ensure((size_t)M * cap));
-        int st = launch_range(ctx, d_c.p, M, g->tmpl->d_xyz, Vt, d_sep.p, g->p.range, cap, d_slots.p, d_counts.p);
+        int st = launch_range(ctx, d_c.p, M, g->tmpl->d_xyz, Vt, d_sep.p, g->p.range, cap, d_slots.p, d_counts.p, g->d_chunkb.p, d_counts.p + M);
         if (st) return st;
-        MSM_HIP(d_counts.download(counts.data(), M, ctx->stream));
+        MSM_HIP(d_counts.download(counts.data(), (size_t)M + 1, ctx->stream));
         MSM_HIP(hipStreamSynchronize(ctx->stream));
-        const int mx = *std::max_element(counts.begin(), counts.end());
+        const int mx = *std::max_element(counts.begin(), counts.begin() + M);
         g->patch_cap_hint = std::max(g->patch_cap_hint, mx + 16);
         if (mx <= cap) break;
         if (attempt == 2) return fail(MSM_ERR_CAPACITY, "group patch capacity");
         cap = mx + 16;
     }
     lap("range kernel");
+    if (counts[M] == 0) {
+        // nothing sits on the threshold: the rows are final.  The list is compacted where it is used; the host keeps the row
+        // offsets and fetches the 12.7 MB of indices only if msm_group_patch / msm_group_export_subject ask for them.
+        auto &pp = g->h_pptr[s];
+        pp.assign((size_t)M + 1, 0);
+        for (int k = 0; k < M; ++k) pp[k + 1] = pp[k] + counts[k];
+        g->h_pidx[s].clear();
+        MSM_HIP(g->pptr[s]->upload(pp.data(), pp.size(), ctx->stream));
+        MSM_HIP(g->pidx[s]->ensure(std::max<size_t>((size_t)pp[M], 1)));
+        int st = launch_patch_compact(ctx, d_slots.p, cap, g->pptr[s]->p, M, g->pidx[s]->p);
+        if (st) return st;
+        MSM_HIP(hipStreamSynchronize(ctx->stream));
+        lap("lists (device)");
+        return MSM_OK;
+    }
     // 50 MB at ico6 / 19 labels: through pinned memory (a pageable copy of this size took most of this function's time)
     void *pin = nullptr;
     {
@@ -614,11 +631,24 @@ int msm_group_setup_subjects(msm_group *g, const int32_t *subjects, int32_t n) {
     return MSM_OK;
 }
 
+// the host copy of a subject's index list is fetched when first asked for (set up or imported on the device)
+static int fetch_host_pidx(msm_group *g, int s) {
+    if (!g->h_pidx[s].empty() || g->h_pptr[s].empty() || g->h_pptr[s].back() <= 0) return MSM_OK;
+    g->h_pidx[s].resize((size_t)g->h_pptr[s].back());
+    MSM_HIP(g->pidx[s]->download(g->h_pidx[s].data(), g->h_pidx[s].size(), g->ctx->stream));
+    MSM_HIP(hipStreamSynchronize(g->ctx->stream));
+    return MSM_OK;
+}
+
 int msm_group_export_subject(msm_group *g, int32_t s, double *F, int32_t *pptr, int32_t *pidx, int64_t cap, int64_t *npidx) {
     if (!g || s < 0 || s >= g->S) return fail(MSM_ERR_INVALID, "msm_group_export_subject: bad arguments");
     if (!g->common_ready || !g->have_subject[s]) return fail(MSM_ERR_STATE, "msm_group: subject %d has not been set up on this rank", s);
     const size_t per = (size_t)g->D * g->tmpl->V;
-    if (npidx) *npidx = (int64_t)g->h_pidx[s].size();
+    if (npidx) *npidx = (int64_t)g->h_pptr[s].back();
+    if (pidx) {
+        int st = fetch_host_pidx(g, s);
+        if (st) return st;
+    }
     if (F) {
         for (int l = 0; l < g->L; ++l) MSM_HIP(g->F[(size_t)s * g->L + l]->download(F + per * l, per, g->ctx->stream));
         MSM_HIP(hipStreamSynchronize(g->ctx->stream));

@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <functional>
 #include <memory>
 #include <string>
 #include <vector>
@@ -208,13 +209,14 @@ struct AdaptiveDev {
 int adaptive_weights_dev(msm_mesh *in_mesh, msm_mesh *new_mesh, AdaptiveDev &out, bool check = true);  // check = false: the caller checks the status word
 // out (device, D x V(new)) = the weights applied to d_data (device, D x V(in)): barycentric_data_interpolation R/resampler.cpp:40-52
 int apply_weights_dev(msm_ctx *ctx, const AdaptiveDev &w, const double *d_data, int D, double *d_out);
-int ensure_adjacency_dev(msm_mesh *m);  // Mpoint::trID lists as CSR in HBM (d_tid_ptr / d_tid)
+int ensure_adjacency_dev(msm_mesh *m);
+int ensure_tree_pair(msm_mesh *a, msm_mesh *b);  // both trees; a host build of one runs while the GPU builds the other  // Mpoint::trID lists as CSR in HBM (d_tid_ptr / d_tid)
 void adaptive_surgery(const AdaptiveQueries &q, int nOld, int nNew, const std::vector<double> &oldA, const std::vector<double> &newA,
                       const double *excl, std::vector<int32_t> &row_ptr, std::vector<int32_t> &col, std::vector<double> &val);
 void vertex_areas_of(const double *xyz, const int32_t *tri, int V, int T, const Adjacency &a, std::vector<double> &area);
 int install_coords_and_tree(msm_mesh *m, const double *xyz, FlatOctree &&tree);
 int ensure_tree(msm_mesh *m);  // build + upload the search structure if stale
-int gpu_build_octree(msm_mesh *m);  // octree_kernels.hip: the same tree built in HBM from the mesh's device coordinates (MSM_ERR_CAPACITY: use the host build)
+int gpu_build_octree(msm_mesh *m, const std::function<void()> *overlap = nullptr);  // octree_kernels.hip: the same tree built in HBM from the mesh's device coordinates (MSM_ERR_CAPACITY: use the host build)
 int finish_tree(msm_mesh *m);       // what follows either build: validity flags, generation
 int ensure_masks(msm_mesh *m);  // + the per-leaf sub-cell masks the cost kernels use (built on the GPU)
 int ensure_rays(msm_mesh *m, bool wait = false);   // + the ray table of a simple surface (unary table kernels); see api.cpp

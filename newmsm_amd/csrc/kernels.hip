@@ -361,44 +361,107 @@ int launch_smooth(msm_ctx *ctx, const double *d_xyz, int N, double *d_unit, cons
 // differ in the last bit, and this workload has exact ties (a control point's farthest neighbour
 // sits exactly at range*MAXSEP), so entries within 1e-11 of the threshold are only flagged (bit 31)
 // and the host decides them with its own libm, like the reference would.
-// ------------------------------------------------------------------------------------------------
+//
+// The sweep is pruned without changing what it finds: the source vertices are taken in chunks of 64 consecutive ids, each with a
+// bounding ball (k_chunk_bounds); a chunk whose ball lies farther from the control point than the threshold chord cannot hold
+// an in-range vertex (arc >= chord >= distance to the ball) and is skipped.  Ico-derived meshes number neighbouring vertices
+// close together, so a control point looks at a few per cent of the chunks.  The surviving chunks are visited in ascending
+// order, four at a time (one per wavefront), which keeps the slot order ascending.
+__global__ __launch_bounds__(256) void k_chunk_bounds(const double *__restrict__ src, int Nsrc, double4 *__restrict__ cb) {
+    const int lane = threadIdx.x & 63, ch = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nchunks = (Nsrc + 63) >> 6;
+    if (ch >= nchunks) return;
+    const int i = ch * 64 + lane;
+    const bool in = i < Nsrc;
+    const V3 p = in ? mk(src[i], src[Nsrc + i], src[2 * (size_t)Nsrc + i]) : mk(0, 0, 0);
+    const double n = (double)min(64, Nsrc - ch * 64);
+    const V3 c = mk(wave_sum(p.x) / n, wave_sum(p.y) / n, wave_sum(p.z) / n);
+    double r = in ? norm(sub(p, c)) : 0.0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double o = __shfl_xor(r, off, 64);
+        r = (o > r || o != o) ? o : r;  // a NaN coordinate makes the whole chunk a candidate
+    }
+    if (lane == 0) cb[ch] = make_double4(c.x, c.y, c.z, r * (1 + 1e-12) + 1e-12);
+}
+
 __global__ __launch_bounds__(256) void k_range(const double *__restrict__ cp, int Ncp, const double *__restrict__ src, int Nsrc,
-                                                const double *__restrict__ maxsep, double range, int cap,
-                                                uint32_t *__restrict__ slots, int *__restrict__ counts) {
+                                                const double4 *__restrict__ cb, const double *__restrict__ maxsep, double range, int cap,
+                                                uint32_t *__restrict__ slots, int *__restrict__ counts, int *__restrict__ nflag) {
     const int k = blockIdx.x;
     if (k >= Ncp) return;
     const V3 c = mk(cp[k], cp[Ncp + k], cp[2 * Ncp + k]);
     const double thr = range * maxsep[k];
     const double slack = fabs(thr) * 1e-11;
     const double lo = thr - slack, hi = thr + slack;
+    const double reach = hi * (1 + 1e-12) + 1e-12;  // a chunk is skipped only if even its ball's nearest point is beyond hi
+    const int nchunks = (Nsrc + 63) >> 6;
+    constexpr int kTile = 1024;
+    __shared__ int cand[kTile];
     __shared__ int wave_count[4];
-    __shared__ int running;
+    __shared__ int running, ncand;
     if (threadIdx.x == 0) running = 0;
-    __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int base = 0; base < Nsrc; base += 256) {
-        const int i = base + threadIdx.x;
-        int state = 0;  // 0 out, 1 in, 2 undecided
-        if (i < Nsrc) {
-            const double d = norm(sub(c, mk(src[i], src[Nsrc + i], src[2 * Nsrc + i])));
-            if (!(d > hi)) {  // arc >= chord, so chord > hi is certainly out of range
-                const double arc = chord_to_arc(d);
-                state = (arc < lo) ? 1 : ((arc > hi) ? 0 : 2);
+    for (int tile = 0; tile < nchunks; tile += kTile) {
+        __syncthreads();
+        if (threadIdx.x == 0) ncand = 0;
+        __syncthreads();
+        for (int sub = 0; sub < kTile && tile + sub < nchunks; sub += 256) {  // uniform
+            const int ch = tile + sub + threadIdx.x;
+            bool keep = false;
+            if (ch < nchunks) {
+                const double4 b = cb[ch];
+                keep = !(norm(sub(c, mk(b.x, b.y, b.z))) - b.w > reach);
             }
+            const unsigned long long ball = __ballot(keep);
+            if (lane == 0) wave_count[wave] = __popcll(ball);
+            __syncthreads();
+            if (keep) {
+                int pos = ncand + __popcll(ball & ((1ull << lane) - 1));
+                for (int wv = 0; wv < wave; ++wv) pos += wave_count[wv];
+                cand[pos] = ch;
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) ncand += wave_count[0] + wave_count[1] + wave_count[2] + wave_count[3];
+            __syncthreads();
         }
-        const unsigned long long ball = __ballot(state != 0);
-        if (lane == 0) wave_count[wave] = __popcll(ball);
-        __syncthreads();
-        if (state != 0) {
-            int pos = running + __popcll(ball & ((1ull << lane) - 1));
-            for (int wv = 0; wv < wave; ++wv) pos += wave_count[wv];
-            if (pos < cap) slots[(size_t)k * cap + pos] = (uint32_t)i | (state == 2 ? 0x80000000u : 0u);
+        const int nc = ncand;
+        for (int it = 0; it < nc; it += 4) {  // uniform
+            const int ci = it + wave;
+            const int i = ci < nc ? cand[ci] * 64 + lane : Nsrc;
+            int state = 0;  // 0 out, 1 in, 2 undecided
+            if (i < Nsrc) {
+                const double d = norm(sub(c, mk(src[i], src[Nsrc + i], src[2 * Nsrc + i])));
+                if (!(d > hi)) {  // arc >= chord, so chord > hi is certainly out of range
+                    const double arc = chord_to_arc(d);
+                    state = (arc < lo) ? 1 : ((arc > hi) ? 0 : 2);
+                }
+            }
+            const unsigned long long ball = __ballot(state != 0);
+            if (lane == 0) wave_count[wave] = __popcll(ball);
+            __syncthreads();
+            if (state != 0) {
+                int pos = running + __popcll(ball & ((1ull << lane) - 1));
+                for (int wv = 0; wv < wave; ++wv) pos += wave_count[wv];
+                if (pos < cap) slots[(size_t)k * cap + pos] = (uint32_t)i | (state == 2 ? 0x80000000u : 0u);
+                if (state == 2) atomicAdd(nflag, 1);
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) running += wave_count[0] + wave_count[1] + wave_count[2] + wave_count[3];
+            __syncthreads();
         }
-        __syncthreads();
-        if (threadIdx.x == 0) running += wave_count[0] + wave_count[1] + wave_count[2] + wave_count[3];
-        __syncthreads();
     }
+    __syncthreads();
     if (threadIdx.x == 0) counts[k] = running;
+}
+
+// slot rows -> one contiguous list (CSR offsets pptr already scanned from the counts); only used when no entry was flagged
+__global__ __launch_bounds__(256) void k_patch_compact(const uint32_t *__restrict__ slots, int cap, const int32_t *__restrict__ pptr, int M,
+                                                        int32_t *__restrict__ pidx) {
+    const int lane = threadIdx.x & 63, k = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (k >= M) return;
+    const int b = pptr[k], n = pptr[k + 1] - b;
+    for (int j = lane; j < n; j += 64) pidx[b + j] = (int32_t)(slots[(size_t)k * cap + j] & 0x7fffffffu);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -487,9 +550,70 @@ int launch_closest_vertex(msm_ctx *ctx, const DevTree &T, const double *d_q, int
     return MSM_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Device-side order of the points of each patch (unary kernels): Morton order of their positions, ties by id, so that the
+// lanes of a wavefront sample neighbouring places of the target.  A wavefront per patch ranks its entries by the 64-bit key
+// (code << 32 | id); the keys of a patch are distinct, so an entry's place is the number of smaller keys.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t spread10(uint32_t v) {  // 10 bits -> every third bit
+    v &= 0x3ff;
+    v = (v | (v << 16)) & 0x030000ff;
+    v = (v | (v << 8)) & 0x0300f00f;
+    v = (v | (v << 4)) & 0x030c30c3;
+    v = (v | (v << 2)) & 0x09249249;
+    return v;
+}
+__global__ __launch_bounds__(256) void k_morton_codes(const double *__restrict__ xyz, int n, uint32_t *__restrict__ code) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n) return;
+    uint32_t q[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const double u = (xyz[(size_t)a * n + v] + kBounds) / (2 * kBounds);
+        q[a] = (uint32_t)fmax(0.0, fmin(1023.0, u == u ? u * 1024.0 : 0.0));
+    }
+    code[v] = spread10(q[0]) << 2 | spread10(q[1]) << 1 | spread10(q[2]);
+}
+__global__ __launch_bounds__(64) void k_sort_patches(const int32_t *__restrict__ pptr, int ngroups, const int32_t *__restrict__ pidx,
+                                                      const uint32_t *__restrict__ code, int32_t *__restrict__ sorted) {
+    const int g = blockIdx.x;
+    if (g >= ngroups) return;
+    const int b = pptr[g], len = pptr[g + 1] - b;
+    for (int i = threadIdx.x; i < len; i += 64) {
+        const int32_t id = pidx[b + i];
+        const unsigned long long mine = (unsigned long long)code[id] << 32 | (uint32_t)id;
+        int rank = 0;
+        for (int j = 0; j < len; ++j) {
+            const int32_t o = pidx[b + j];
+            rank += ((unsigned long long)code[o] << 32 | (uint32_t)o) < mine;
+        }
+        sorted[b + rank] = id;
+    }
+}
+
+int launch_sort_patches(msm_ctx *ctx, const double *d_xyz, int n, const int32_t *d_pptr, int ngroups, const int32_t *d_pidx, uint32_t *d_code,
+                        int32_t *d_sorted) {
+    if (n <= 0 || ngroups <= 0) return MSM_OK;
+    hipLaunchKernelGGL(k_morton_codes, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d_xyz, n, d_code);
+    hipLaunchKernelGGL(k_sort_patches, dim3(ngroups), dim3(64), 0, ctx->stream, d_pptr, ngroups, d_pidx, d_code, d_sorted);
+    MSM_HIP(hipGetLastError());
+    return MSM_OK;
+}
+
 int launch_range(msm_ctx *ctx, const double *d_cp, int Ncp, const double *d_src, int Nsrc, const double *d_maxsep, double range,
-                 int cap, uint32_t *d_slots, int *d_counts) {
-    hipLaunchKernelGGL(k_range, dim3(Ncp), dim3(256), 0, ctx->stream, d_cp, Ncp, d_src, Nsrc, d_maxsep, range, cap, d_slots, d_counts);
+                 int cap, uint32_t *d_slots, int *d_counts, double4 *d_chunk_bounds, int *d_nflag) {
+    if (Ncp <= 0) return MSM_OK;
+    const int nchunks = (Nsrc + 63) / 64;
+    MSM_HIP(hipMemsetAsync(d_nflag, 0, sizeof(int), ctx->stream));
+    if (nchunks > 0) hipLaunchKernelGGL(k_chunk_bounds, dim3((nchunks + 3) / 4), dim3(256), 0, ctx->stream, d_src, Nsrc, d_chunk_bounds);
+    hipLaunchKernelGGL(k_range, dim3(Ncp), dim3(256), 0, ctx->stream, d_cp, Ncp, d_src, Nsrc, d_chunk_bounds, d_maxsep, range, cap, d_slots, d_counts, d_nflag);
+    MSM_HIP(hipGetLastError());
+    return MSM_OK;
+}
+
+int launch_patch_compact(msm_ctx *ctx, const uint32_t *d_slots, int cap, const int32_t *d_pptr, int M, int32_t *d_pidx) {
+    if (M <= 0) return MSM_OK;
+    hipLaunchKernelGGL(k_patch_compact, dim3((M + 3) / 4), dim3(256), 0, ctx->stream, d_slots, cap, d_pptr, M, d_pidx);
     MSM_HIP(hipGetLastError());
     return MSM_OK;
 }

@@ -40,8 +40,14 @@ int launch_smooth(msm_ctx *ctx, const double *d_xyz, int N, double *d_unit, cons
                   double cosang, const double *d_excl, double *d_out, double *d_excl_out);
 // check_for_intersections (M/reg_tools.cpp:118-129) of every vertex: fold[0] += folded, fold[1] += vertices without a triangle, fold[2 + v] = folded
 int launch_fold_detect(msm_ctx *ctx, const double *d_xyz, int V, const int32_t *d_tri, int T, const int32_t *d_tid_ptr, const int32_t *d_tid, int32_t *d_fold);
+// d_sorted = each patch's members (d_pidx, CSR d_pptr) in Morton order of their positions d_xyz (3 x n SoA); d_code: n scratch words
+int launch_sort_patches(msm_ctx *ctx, const double *d_xyz, int n, const int32_t *d_pptr, int ngroups, const int32_t *d_pidx, uint32_t *d_code,
+                        int32_t *d_sorted);
+// d_chunk_bounds: scratch, one double4 per 64 source vertices; *d_nflag (device int) = entries flagged as undecided (bit 31)
 int launch_range(msm_ctx *ctx, const double *d_cp, int Ncp, const double *d_src, int Nsrc, const double *d_maxsep, double range, int cap,
-                 uint32_t *d_slots, int *d_counts);
+                 uint32_t *d_slots, int *d_counts, double4 *d_chunk_bounds, int *d_nflag);
+// rows of slots -> the contiguous list d_pidx at the offsets d_pptr (M + 1, already summed); valid when nothing was flagged
+int launch_patch_compact(msm_ctx *ctx, const uint32_t *d_slots, int cap, const int32_t *d_pptr, int M, int32_t *d_pidx);
 
 // rnl[(node*L + l)*9..] = estimate_rotation_matrix(cp[node], rot[node]*labels[l]); moved (optional, N x L x 3 AoS) = rot[node]*labels[l]
 int launch_label_rotations(msm_ctx *ctx, const double *d_cp, int N, const double *d_rot, const double *d_labels, int L, double *d_rnl,

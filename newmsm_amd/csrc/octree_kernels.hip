@@ -17,6 +17,7 @@
 // kernels read them.  tests/test_gpu_search.py compares the leaves (boxes and ordered lists) of both builds.
 #include <algorithm>
 #include <cstring>
+#include <functional>
 #include <vector>
 
 #include "kernels.hpp"
@@ -326,6 +327,25 @@ __global__ __launch_bounds__(256) void k_oct_fill(OctWork w, int cur) {
 
 __global__ void k_oct_begin_level(int *counters) { counters[C_NCHUNK] = counters[C_NCHUNK_NEXT]; }
 
+// the state before level 0: node 0 with the cube (-101, 101) and every triangle (k_oct_boxes wrote the list), in chunks
+__global__ __launch_bounds__(256) void k_oct_init(OctWork w, int T, int root_chunks) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < root_chunks) {
+        w.chunk_open[0][i] = 0;
+        w.chunk_beg[0][i] = i * kChunk;
+    }
+    if (i <= C_COUNT) w.counters[i] = i == C_NNODES || i == C_NOPEN ? 1 : i == C_NCHUNK_NEXT ? root_chunks : 0;
+    if (i == 0) {
+        w.node[0] = make_int4(-1, 0, -1, 0);
+        w.nodebox[0] = make_double4(-kBounds, -kBounds, -kBounds, 2 * kBounds);
+        w.parent[0] = -1;
+        w.open_node[0][0] = 0;
+        w.open_off[0][0] = 0;
+        w.open_len[0][0] = T;
+        w.open_chunk[0][0] = 0;
+    }
+}
+
 // dense top grid (FlatOctree::grid): the node a point of each depth-gd cell reaches after gd levels of descent, or the leaf met earlier
 __global__ __launch_bounds__(256) void k_oct_grid(const int4 *__restrict__ node, int gd, int32_t *__restrict__ grid) {
     const int G = 1 << gd;
@@ -346,7 +366,7 @@ __global__ __launch_bounds__(256) void k_oct_grid(const int4 *__restrict__ node,
 
 // Builds the search tree of m's current device coordinates into m's device arrays.  Returns MSM_OK, or MSM_ERR_CAPACITY when
 // the tree outgrows the preallocated arrays (degenerate meshes: the caller falls back to the host build).
-int gpu_build_octree(msm_mesh *m) {
+int gpu_build_octree(msm_mesh *m, const std::function<void()> *overlap) {
     msm_ctx *ctx = m->ctx;
     const int T = m->T, V = m->V;
     const int cap_nodes = T + 64, cap_refs = 6 * T + 256, cap_arena = 8 * T + 512, cap_open = cap_nodes, cap_chunks = cap_refs / kChunk + cap_open + 64;
@@ -411,49 +431,31 @@ int gpu_build_octree(msm_mesh *m) {
 
     // root: node 0 with the cube (-101, 101) and every triangle
     const int root_chunks = (T + kChunk - 1) / kChunk;
-    int h0[C_COUNT + 1] = {0};
-    h0[C_NNODES] = 1, h0[C_NOPEN] = 1, h0[C_NCHUNK_NEXT] = root_chunks;
-    std::memcpy(s.h_counters, h0, sizeof(h0));
-    MSM_HIP(hipMemcpyAsync(s.counters, s.h_counters, sizeof(h0), hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(k_oct_boxes, dim3((T + 255) / 256), dim3(256), 0, ctx->stream, m->d_xyz, V, m->d_tri, T, s.box, w.list[0]);
-    {
-        const int4 root_node = make_int4(-1, 0, -1, 0);
-        const double4 root_box = make_double4(-kBounds, -kBounds, -kBounds, 2 * kBounds);
-        const int32_t root_parent = -1;
-        const int zero = 0;
-        MSM_HIP(hipMemcpyAsync(m->d_node, &root_node, sizeof(root_node), hipMemcpyHostToDevice, ctx->stream));
-        MSM_HIP(hipMemcpyAsync(m->d_nodebox, &root_box, sizeof(root_box), hipMemcpyHostToDevice, ctx->stream));
-        MSM_HIP(hipMemcpyAsync(m->d_parent, &root_parent, sizeof(root_parent), hipMemcpyHostToDevice, ctx->stream));
-        MSM_HIP(hipMemcpyAsync(w.open_node[0], &zero, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-        MSM_HIP(hipMemcpyAsync(w.open_off[0], &zero, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-        MSM_HIP(hipMemcpyAsync(w.open_len[0], &T, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-        MSM_HIP(hipMemcpyAsync(w.open_chunk[0], &zero, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-        std::vector<int> cb(root_chunks);
-        for (int j = 0; j < root_chunks; ++j) cb[j] = j * kChunk;
-        MSM_HIP(hipMemsetAsync(w.chunk_open[0], 0, sizeof(int) * (size_t)root_chunks, ctx->stream));
-        MSM_HIP(hipMemcpyAsync(w.chunk_beg[0], cb.data(), sizeof(int) * (size_t)root_chunks, hipMemcpyHostToDevice, ctx->stream));
-        MSM_HIP(hipStreamSynchronize(ctx->stream));  // the sources above are locals
-    }
-    constexpr int kMaxLevels = 24, kSureLevels = 6;
-    int cur = 0;
+    hipLaunchKernelGGL(k_oct_init, dim3((std::max(root_chunks, C_COUNT + 1) + 255) / 256), dim3(256), 0, ctx->stream, w, T, root_chunks);
+    // Levels are queued in batches without looking at the outcome in between: a level with nothing open costs five empty
+    // launches, a look costs a round trip.  Ico-derived meshes finish at depth 6 or 7, i.e. within the first batch.
+    constexpr int kMaxLevels = 24, kFirstBatch = 8, kNextBatch = 4;
+    int cur = 0, depth = 0;
     bool done = false;
-    for (int depth = 0; depth < kMaxLevels && !done; ++depth) {
-        hipLaunchKernelGGL(k_oct_begin_level, dim3(1), dim3(1), 0, ctx->stream, s.counters);
-        hipLaunchKernelGGL(k_oct_decide, dim3(512), dim3(256), 0, ctx->stream, w, cur);
-        hipLaunchKernelGGL(k_oct_count, dim3(1024), dim3(256), 0, ctx->stream, w, cur);
-        hipLaunchKernelGGL(k_oct_scan, dim3(1), dim3(1024), 0, ctx->stream, w, cur, depth);
-        hipLaunchKernelGGL(k_oct_fill, dim3(1024), dim3(256), 0, ctx->stream, w, cur);
-        MSM_HIP(hipGetLastError());
-        cur ^= 1;
-        if (depth + 1 >= kSureLevels) {  // ico-derived meshes finish at depth 6: from here on look whether anything is still open
-            MSM_HIP(hipMemcpyAsync(s.h_counters, s.counters, sizeof(int) * C_COUNT, hipMemcpyDeviceToHost, ctx->stream));
-            MSM_HIP(hipStreamSynchronize(ctx->stream));
-            done = s.h_counters[C_NOPEN] == 0;
+    while (!done && depth < kMaxLevels) {
+        const int upto = std::min(kMaxLevels, depth + (depth == 0 ? kFirstBatch : kNextBatch));
+        for (; depth < upto; ++depth) {
+            hipLaunchKernelGGL(k_oct_begin_level, dim3(1), dim3(1), 0, ctx->stream, s.counters);
+            hipLaunchKernelGGL(k_oct_decide, dim3(512), dim3(256), 0, ctx->stream, w, cur);
+            hipLaunchKernelGGL(k_oct_count, dim3(1024), dim3(256), 0, ctx->stream, w, cur);
+            hipLaunchKernelGGL(k_oct_scan, dim3(1), dim3(1024), 0, ctx->stream, w, cur, depth);
+            hipLaunchKernelGGL(k_oct_fill, dim3(1024), dim3(256), 0, ctx->stream, w, cur);
+            cur ^= 1;
         }
-    }
-    if (!done) {
+        MSM_HIP(hipGetLastError());
         MSM_HIP(hipMemcpyAsync(s.h_counters, s.counters, sizeof(int) * C_COUNT, hipMemcpyDeviceToHost, ctx->stream));
+        if (overlap && *overlap) {  // host work of the caller that does not depend on this tree, while the GPU builds it
+            (*overlap)();
+            overlap = nullptr;
+        }
         MSM_HIP(hipStreamSynchronize(ctx->stream));
+        done = s.h_counters[C_NOPEN] == 0;
     }
     const int *hc = s.h_counters;
     if (hc[C_OVERFLOW] || hc[C_NOPEN] != 0) return MSM_ERR_CAPACITY;
