@@ -406,8 +406,8 @@ __global__ __launch_bounds__(256) void k_range(const double *__restrict__ cp, in
         __syncthreads();
         if (threadIdx.x == 0) ncand = 0;
         __syncthreads();
-        for (int sub = 0; sub < kTile && tile + sub < nchunks; sub += 256) {  // uniform
-            const int ch = tile + sub + threadIdx.x;
+        for (int part = 0; part < kTile && tile + part < nchunks; part += 256) {  // uniform
+            const int ch = tile + part + threadIdx.x;
             bool keep = false;
             if (ch < nchunks) {
                 const double4 b = cb[ch];
