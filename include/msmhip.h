@@ -112,6 +112,10 @@ void    *msm_ctx_stream(msm_ctx *ctx);                        /* hipStream_t, fo
  * The block belongs to the context and is released with it at the latest. */
 void    *msm_host_alloc(msm_ctx *ctx, size_t bytes);
 void     msm_host_free(msm_ctx *ctx, void *p);
+/* The same for memory the caller owns -- e.g. a POSIX shared-memory segment that the processes of one node (one per GPU) map, so
+ * that every rank's kernels deliver their slice of a label step into the optimiser rank's address space without a collective.
+ * msm_host_free(ctx, p) undoes the registration (the memory stays the caller's). */
+int      msm_host_register(msm_ctx *ctx, void *p, size_t bytes);
 
 /* ------------------------------------------------------------------------------------------------
  * mesh + search structure.  Replaces newresampler::Mesh (coords/triangles/pvalues) as seen by the

@@ -62,6 +62,7 @@ SIGNATURES = {
     "msm_ctx_stream": (_VP, [_VP]),
     "msm_host_alloc": (_VP, [_VP, C.c_size_t]),
     "msm_host_free": (None, [_VP, _VP]),
+    "msm_host_register": (C.c_int, [_VP, _VP, C.c_size_t]),
     "msm_mesh_create": (_VP, [_VP, c_dp, C.c_int32, c_ip, C.c_int32]),
     "msm_mesh_destroy": (None, [_VP]),
     "msm_mesh_update_coords": (C.c_int, [_VP, c_dp]),

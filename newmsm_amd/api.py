@@ -178,6 +178,14 @@ class Context:
         buf = (C.c_char * max(n, 8)).from_address(p)
         return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
 
+    def register_host(self, address, nbytes):
+        """Pin caller-owned host memory (e.g. a shared-memory mapping) and map it into the GPU's address space
+        (msm_host_register): arrays inside it are then written by the GPU directly, like Context.host_array's."""
+        check(lib().msm_host_register(self.h, C.c_void_p(address), nbytes))
+
+    def unregister_host(self, address):
+        lib().msm_host_free(self.h, C.c_void_p(address))
+
     def close(self):
         if getattr(self, "h", None):
             lib().msm_ctx_destroy(self.h)
@@ -654,10 +662,14 @@ class DiscreteGroupCostFunction:
         check(lib().msm_group_get_pairs(self.h, out.ctypes.data_as(c_ip)))
         return out
 
-    def fusionMove(self, labeling, label):
-        """one label step of Fusion::optimize (Fusion.h:157-196): (pair_data buffers P x 4, triplet_data buffers T x 8)"""
+    def fusionMove(self, labeling, label, out=None):
+        """one label step of Fusion::optimize (Fusion.h:157-196): (pair_data buffers P x 4, triplet_data buffers T x 8).
+        `out` (optional): the pair (quads, octets) of arrays to fill, e.g. Context.host_array((P, 4)) and ((T, 8)) -- pinned
+        memory a copy kernel writes directly."""
         lab, pl = _i(labeling)
-        quads, octets = np.zeros((self.P, 4)), np.zeros((self.T, 8))
+        quads, octets = (np.zeros((self.P, 4)), np.zeros((self.T, 8))) if out is None else out
+        assert quads.shape == (self.P, 4) and octets.shape == (self.T, 8) and quads.dtype == octets.dtype == np.float64
+        assert quads.flags.c_contiguous and octets.flags.c_contiguous
         check(lib().msm_group_fusion_move(self.h, pl, int(label), quads.ctypes.data_as(c_dp), octets.ctypes.data_as(c_dp)))
         return quads, octets
 

@@ -731,7 +731,7 @@ void msm_ctx_destroy(msm_ctx *ctx) {
     if (ctx->oct_ints) (void)hipFree(ctx->oct_ints);
     if (ctx->oct_counters) (void)hipFree(ctx->oct_counters);
     if (ctx->oct_hcounters) (void)hipHostFree(ctx->oct_hcounters);
-    for (auto &b : ctx->host_blocks) (void)hipHostFree(b.host);
+    for (auto &b : ctx->host_blocks) (void)(b.registered ? hipHostUnregister(b.host) : hipHostFree(b.host));
     if (ctx->d_status) (void)hipFree(ctx->d_status);
     if (ctx->h_status) (void)hipHostFree(ctx->h_status);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -752,7 +752,7 @@ void *msm_host_alloc(msm_ctx *ctx, size_t bytes) {
         return nullptr;
     }
     (void)hipSetDevice(ctx->device);
-    msm_ctx::HostBlock b{nullptr, nullptr, bytes};
+    msm_ctx::HostBlock b{nullptr, nullptr, bytes, false};
     if (hipHostMalloc((void **)&b.host, bytes, hipHostMallocMapped) != hipSuccess) {
         fail(MSM_ERR_HIP, "msm_host_alloc: pinned allocation of %zu bytes failed", bytes);
         return nullptr;
@@ -772,10 +772,27 @@ void msm_host_free(msm_ctx *ctx, void *p) {
         if (ctx->host_blocks[i].host == (char *)p) {
             (void)hipSetDevice(ctx->device);
             (void)hipStreamSynchronize(ctx->stream);
-            (void)hipHostFree(p);
+            (void)(ctx->host_blocks[i].registered ? hipHostUnregister(p) : hipHostFree(p));
             ctx->host_blocks.erase(ctx->host_blocks.begin() + i);
             return;
         }
+}
+
+int msm_host_register(msm_ctx *ctx, void *p, size_t bytes) {
+    if (!ctx || !p || bytes == 0) return fail(MSM_ERR_INVALID, "msm_host_register: bad arguments");
+    MSM_HIP(hipSetDevice(ctx->device));
+    msm_ctx::HostBlock b{static_cast<char *>(p), nullptr, bytes, true};
+    if (hipHostRegister(p, bytes, hipHostRegisterMapped | hipHostRegisterPortable) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(MSM_ERR_HIP, "msm_host_register: %zu bytes at %p cannot be pinned", bytes, p);
+    }
+    if (hipHostGetDevicePointer((void **)&b.dev, p, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipHostUnregister(p);
+        return fail(MSM_ERR_HIP, "msm_host_register: the block cannot be mapped into the device's address space");
+    }
+    ctx->host_blocks.push_back(b);
+    return MSM_OK;
 }
 
 // ------------------------------------------------------------------ mesh

@@ -63,6 +63,10 @@ struct msm_group {
     DevBuf<const int *> d_pptrp, d_pidxp;
     DevBuf<int> d_query[4];   // index columns of a batch of evaluations (kept between calls)
     DevBuf<double> d_answer;
+    DevBuf<double> d_move_out;           // msm_group_fusion_move: the step's 4 P + 8 T results before they go to the host
+    std::vector<int32_t> pair_order;     // the pair list in processing order (control points along a space-filling curve)
+    DevBuf<int> d_pair_order;            // ... restricted to the slice [order_p0, order_p1) last asked for
+    int64_t order_p0 = -1, order_p1 = -1;
     // scratch of subject_patches, kept between subjects
     DevBuf<double> d_centres, d_sep;
     DevBuf<double> d_rotated;  // the L rotated data meshes of the subject being set up
@@ -216,6 +220,8 @@ int group_args(msm_group *g, GroupArgs &a) {
     a.percentile = g->p.percentile;
     a.move_labeling = nullptr;
     a.move_label = a.move_offset = 0;
+    a.move_order = nullptr;
+    a.move_base = 0;
     a.patch_cap = g->patch_max;
     a.status = g->ctx->d_status;
     return MSM_OK;
@@ -409,6 +415,43 @@ int group_common_setup(msm_group *g) {
                 }
     }
     MSM_HIP(g->d_pairs.upload_vec(g->pairs, ctx->stream));
+    {
+        // Processing order of a label step's pairs.  The list above runs subject A, control point, subject B: neighbours in it
+        // share A's patch, but consecutive control-point ids are not neighbours on the sphere and every pair pulls another
+        // subject's patch in, so at S = 16 a step fetched 2.9 GB through an L2 hit rate of 69 %.  Processed control point by
+        // control point along a space-filling curve -- all S (S - 1) / 2 subject pairs of one, then the next -- the patches of a
+        // neighbourhood (S subjects x 2 labels x a few KB) stay in the L2 while every pair that needs them runs.  Results keep
+        // the list's positions (GroupArgs::move_order).
+        const double *c0 = g->cpmesh[0]->xyz.data();
+        auto spread = [](uint32_t v) {
+            v &= 0x3ff;
+            v = (v | (v << 16)) & 0x030000ff;
+            v = (v | (v << 8)) & 0x0300f00f;
+            v = (v | (v << 4)) & 0x030c30c3;
+            v = (v | (v << 2)) & 0x09249249;
+            return v;
+        };
+        std::vector<std::pair<uint32_t, int>> key(N);
+        for (int v = 0; v < N; ++v) {
+            uint32_t q[3];
+            for (int ax = 0; ax < 3; ++ax) {
+                const double u = (c0[(size_t)ax * N + v] + kBounds) / (2 * kBounds);
+                q[ax] = (uint32_t)std::max(0.0, std::min(1023.0, u == u ? u * 1024.0 : 0.0));
+            }
+            key[v] = {spread(q[0]) << 2 | spread(q[1]) << 1 | spread(q[2]), v};
+        }
+        std::sort(key.begin(), key.end());
+        std::vector<int64_t> base(S, 0);
+        for (int a = 1; a < S; ++a) base[a] = base[a - 1] + (int64_t)N * (S - a);
+        g->pair_order.resize(g->pairs.size() / 2);
+        size_t at = 0;
+        for (int i = 0; i < N; ++i) {
+            const int v = key[i].second;
+            for (int a = 0; a + 1 < S; ++a)
+                for (int b = a + 1; b < S; ++b) g->pair_order[at++] = (int32_t)(base[a] + (int64_t)v * (S - 1 - a) + (b - a - 1));
+        }
+        g->order_p0 = g->order_p1 = -1;
+    }
     // get_spacings :123-139, get_rotations :77-86, and ROT * label for every (node, label)
     g->rot.resize(9 * (size_t)S * N);
     g->moved.resize(3 * (size_t)S * N * L);
@@ -860,78 +903,139 @@ int msm_group_pairwise_batch(msm_group *g, const int32_t *pair, const int32_t *l
     return MSM_OK;
 }
 
-int msm_group_fusion_move(msm_group *g, const int32_t *labeling, int32_t label, double *pair_quads, double *triplet_octets) {
-    if (!g || !labeling) return fail(MSM_ERR_INVALID, "msm_group_fusion_move: null argument");
-    GroupArgs a;
-    int st = group_args(g, a);
-    if (st) return st;
-    const int nodes = g->S * g->N;
-    if (label < 0 || label >= g->L) return fail(MSM_ERR_INVALID, "msm_group_fusion_move: label %d out of range", label);
-    for (int i = 0; i < nodes; ++i)
-        if (labeling[i] < 0 || labeling[i] >= g->L) return fail(MSM_ERR_INVALID, "msm_group_fusion_move: label of node %d out of range", i);
-    msm_ctx *ctx = g->ctx;
-    MSM_HIP(g->d_query[0].upload(labeling, nodes, ctx->stream));
-    a.move_labeling = g->d_query[0].p;
-    a.move_label = label;
-    const int64_t P = (int64_t)(g->pairs.size() / 2), T = (int64_t)g->S * g->Tc;
-    for (int pass = 0; pass < 2; ++pass) {
-        double *out = pass == 0 ? pair_quads : triplet_octets;
-        const int64_t total = pass == 0 ? 4 * P : 8 * T;
-        if (!out) continue;
-        for (int64_t off = 0; off < total; off += kBatchChunk) {
-            const int m = (int)std::min<int64_t>(kBatchChunk, total - off);
-            void *pin = nullptr;
-            st = ctx_io_pinned(ctx, sizeof(double) * (size_t)m, &pin);
-            if (st) return st;
-            MSM_HIP(g->d_answer.ensure(m));
-            a.move_offset = (int)off;
-            st = pass == 0 ? launch_group_pairwise(ctx, a, nullptr, nullptr, nullptr, m, g->d_answer.p)
-                           : launch_group_triplet(ctx, a, nullptr, nullptr, nullptr, nullptr, m, g->d_answer.p);
-            if (st) return st;
-            MSM_HIP(hipMemcpyAsync(pin, g->d_answer.p, sizeof(double) * (size_t)m, hipMemcpyDeviceToHost, ctx->stream));
-            st = check_status(ctx, "DiscreteGroupCostFunction (fusion move)");
-            std::memcpy(out + off, pin, sizeof(double) * (size_t)m);
-            if (st) return st;
+// the slice [pair0, pair1) of the pair list in processing order, on the device
+static int slice_pair_order(msm_group *g, int64_t pair0, int64_t pair1, const int **d_order) {
+    if (g->order_p0 != pair0 || g->order_p1 != pair1) {
+        msm_ctx *ctx = g->ctx;
+        MSM_HIP(hipStreamSynchronize(ctx->stream));
+        if (pair0 == 0 && pair1 == (int64_t)g->pair_order.size()) {
+            MSM_HIP(g->d_pair_order.upload_vec(g->pair_order, ctx->stream));
+        } else {
+            std::vector<int32_t> part;
+            part.reserve((size_t)(pair1 - pair0));
+            for (int32_t p : g->pair_order)
+                if (p >= pair0 && p < pair1) part.push_back(p);
+            MSM_HIP(g->d_pair_order.ensure(std::max<size_t>(part.size(), 1)));
+            if (!part.empty()) MSM_HIP(hipMemcpyAsync(g->d_pair_order.p, part.data(), sizeof(int32_t) * part.size(), hipMemcpyHostToDevice, ctx->stream));
         }
+        MSM_HIP(hipStreamSynchronize(ctx->stream));
+        g->order_p0 = pair0, g->order_p1 = pair1;
     }
+    *d_order = g->d_pair_order.p;
     return MSM_OK;
 }
 
-// A slice of a label step with the results left in DEVICE memory (the caller's buffers, e.g. torch tensors that go into an
-// RCCL gather): pairs [pair0, pair1) -> quads_dev[4 * (pair1 - pair0)], triplets [trip0, trip1) -> octets_dev[8 * (trip1 - trip0)].
-int msm_group_fusion_move_dev(msm_group *g, const int32_t *labeling, int32_t label, int64_t pair0, int64_t pair1, int64_t trip0, int64_t trip1,
-                              double *quads_dev, double *octets_dev) {
-    if (!g || !labeling) return fail(MSM_ERR_INVALID, "msm_group_fusion_move_dev: null argument");
+// the evaluations of a (slice of a) label step, queued on the stream; results in device memory
+static int group_move_compute(msm_group *g, const int32_t *labeling, int32_t label, int64_t pair0, int64_t pair1, int64_t trip0, int64_t trip1,
+                              double *quads_dev, double *octets_dev, const char *who) {
     GroupArgs a;
     int st = group_args(g, a);
     if (st) return st;
     const int nodes = g->S * g->N;
-    const int64_t P = (int64_t)(g->pairs.size() / 2), T = (int64_t)g->S * g->Tc;
-    if (label < 0 || label >= g->L) return fail(MSM_ERR_INVALID, "msm_group_fusion_move_dev: label %d out of range", label);
-    if (pair0 < 0 || pair1 < pair0 || pair1 > P || trip0 < 0 || trip1 < trip0 || trip1 > T) return fail(MSM_ERR_INVALID, "msm_group_fusion_move_dev: range out of bounds");
-    if ((pair1 > pair0 && !quads_dev) || (trip1 > trip0 && !octets_dev)) return fail(MSM_ERR_INVALID, "msm_group_fusion_move_dev: missing output buffer");
+    if (label < 0 || label >= g->L) return fail(MSM_ERR_INVALID, "%s: label %d out of range", who, label);
     for (int i = 0; i < nodes; ++i)
-        if (labeling[i] < 0 || labeling[i] >= g->L) return fail(MSM_ERR_INVALID, "msm_group_fusion_move_dev: label of node %d out of range", i);
+        if (labeling[i] < 0 || labeling[i] >= g->L) return fail(MSM_ERR_INVALID, "%s: label of node %d out of range", who, i);
     msm_ctx *ctx = g->ctx;
     void *pin = nullptr;
     st = ctx_io_pinned(ctx, sizeof(int32_t) * (size_t)nodes, &pin);
     if (st) return st;
+    MSM_HIP(hipStreamSynchronize(ctx->stream));  // the staging buffer may still be the source of an earlier copy
     std::memcpy(pin, labeling, sizeof(int32_t) * (size_t)nodes);
     MSM_HIP(g->d_query[0].ensure(nodes));
     MSM_HIP(hipMemcpyAsync(g->d_query[0].p, pin, sizeof(int32_t) * (size_t)nodes, hipMemcpyHostToDevice, ctx->stream));
     a.move_labeling = g->d_query[0].p;
     a.move_label = label;
-    for (int pass = 0; pass < 2; ++pass) {
-        const int64_t first = pass == 0 ? 4 * pair0 : 8 * trip0, total = pass == 0 ? 4 * (pair1 - pair0) : 8 * (trip1 - trip0);
-        double *out = pass == 0 ? quads_dev : octets_dev;
+    if (pair1 > pair0) {
+        st = slice_pair_order(g, pair0, pair1, &a.move_order);
+        if (st) return st;
+        a.move_base = (int)pair0;
+        const int64_t total = 4 * (pair1 - pair0);
         for (int64_t off = 0; off < total; off += kBatchChunk) {
             const int m = (int)std::min<int64_t>(kBatchChunk, total - off);
-            if (first + off > 0x7fffffffll - kBatchChunk) return fail(MSM_ERR_CAPACITY, "msm_group_fusion_move_dev: evaluation index beyond 2^31");
-            a.move_offset = (int)(first + off);
-            st = pass == 0 ? launch_group_pairwise(ctx, a, nullptr, nullptr, nullptr, m, out + off) : launch_group_triplet(ctx, a, nullptr, nullptr, nullptr, nullptr, m, out + off);
+            if (off > 0x7fffffffll - kBatchChunk) return fail(MSM_ERR_CAPACITY, "%s: evaluation index beyond 2^31", who);
+            a.move_offset = (int)off;
+            st = launch_group_pairwise(ctx, a, nullptr, nullptr, nullptr, m, quads_dev);
             if (st) return st;
         }
     }
+    a.move_order = nullptr;
+    const int64_t first = 8 * trip0, total = 8 * (trip1 - trip0);
+    for (int64_t off = 0; off < total; off += kBatchChunk) {
+        const int m = (int)std::min<int64_t>(kBatchChunk, total - off);
+        if (first + off > 0x7fffffffll - kBatchChunk) return fail(MSM_ERR_CAPACITY, "%s: evaluation index beyond 2^31", who);
+        a.move_offset = (int)(first + off);
+        st = launch_group_triplet(ctx, a, nullptr, nullptr, nullptr, nullptr, m, octets_dev + off);
+        if (st) return st;
+    }
+    return MSM_OK;
+}
+
+int msm_group_fusion_move(msm_group *g, const int32_t *labeling, int32_t label, double *pair_quads, double *triplet_octets) {
+    if (!g || !labeling) return fail(MSM_ERR_INVALID, "msm_group_fusion_move: null argument");
+    if (!g->ready) return fail(MSM_ERR_STATE, "msm_group: msm_group_setup() must be called first");
+    msm_ctx *ctx = g->ctx;
+    const int64_t P = (int64_t)(g->pairs.size() / 2), T = (int64_t)g->S * g->Tc;
+    MSM_HIP(g->d_move_out.ensure((size_t)(4 * P + 8 * T) + 2));
+    double *dq = g->d_move_out.p, *dt = dq + ((4 * P + 1) & ~1ll);  // both 16-byte aligned
+    int st = group_move_compute(g, labeling, label, 0, pair_quads ? P : 0, 0, triplet_octets ? T : 0, dq, dt, "msm_group_fusion_move");
+    if (st) return st;
+    // delivery: arrays inside a msm_host_alloc / msm_host_register block are written by a copy kernel (full-width stores over
+    // PCIe, no staging); others go through the pinned staging buffer in chunks
+    bool flagged = false;
+    for (int pass = 0; pass < 2; ++pass) {
+        double *out = pass == 0 ? pair_quads : triplet_octets;
+        const double *src = pass == 0 ? dq : dt;
+        const size_t total = (size_t)(pass == 0 ? 4 * P : 8 * T);
+        if (!out || total == 0) continue;
+        double *mapped = static_cast<double *>(ctx_mapped(ctx, out, sizeof(double) * total));
+        if (mapped && reinterpret_cast<uintptr_t>(mapped) % 16 == 0) {
+            st = ctx_flag(ctx);
+            if (st) return st;
+            st = launch_copy_to_mapped(ctx, src, mapped, total, ctx->d_flag_map);
+            if (st) return st;
+            flagged = true;
+            continue;
+        }
+        for (size_t off = 0; off < total; off += kBatchChunk) {
+            const size_t m = std::min<size_t>(kBatchChunk, total - off);
+            void *pin = nullptr;
+            st = ctx_io_pinned(ctx, sizeof(double) * m, &pin);
+            if (st) return st;
+            MSM_HIP(hipMemcpyAsync(pin, src + off, sizeof(double) * m, hipMemcpyDeviceToHost, ctx->stream));
+            MSM_HIP(hipStreamSynchronize(ctx->stream));
+            std::memcpy(out + off, pin, sizeof(double) * m);
+        }
+    }
+    st = check_status(ctx, "DiscreteGroupCostFunction (fusion move)");
+    if (flagged) ctx->h_flag[0] = 0;
+    return st;
+}
+
+// A slice of a label step with the results left in DEVICE memory (the caller's buffers, e.g. torch tensors that go into an
+// RCCL gather, or the device address of mapped host memory): pairs [pair0, pair1) -> quads_dev[4 * (pair1 - pair0)],
+// triplets [trip0, trip1) -> octets_dev[8 * (trip1 - trip0)].
+int msm_group_fusion_move_dev(msm_group *g, const int32_t *labeling, int32_t label, int64_t pair0, int64_t pair1, int64_t trip0, int64_t trip1,
+                              double *quads_dev, double *octets_dev) {
+    if (!g || !labeling) return fail(MSM_ERR_INVALID, "msm_group_fusion_move_dev: null argument");
+    if (!g->ready) return fail(MSM_ERR_STATE, "msm_group: msm_group_setup() must be called first");
+    const int64_t P = (int64_t)(g->pairs.size() / 2), T = (int64_t)g->S * g->Tc;
+    if (pair0 < 0 || pair1 < pair0 || pair1 > P || trip0 < 0 || trip1 < trip0 || trip1 > T) return fail(MSM_ERR_INVALID, "msm_group_fusion_move_dev: range out of bounds");
+    if ((pair1 > pair0 && !quads_dev) || (trip1 > trip0 && !octets_dev)) return fail(MSM_ERR_INVALID, "msm_group_fusion_move_dev: missing output buffer");
+    // an output inside a msm_host_alloc / msm_host_register block (pinned host memory, possibly shared with other processes): the
+    // kernels' scattered 8-byte results are gathered in HBM first and cross PCIe as one copy
+    msm_ctx *ctx = g->ctx;
+    const size_t nq = (size_t)(4 * (pair1 - pair0)), nt = (size_t)(8 * (trip1 - trip0));
+    const bool host_q = nq && ctx_mapped(ctx, quads_dev, sizeof(double) * nq), host_t = nt && ctx_mapped(ctx, octets_dev, sizeof(double) * nt);
+    double *cq = quads_dev, *ct = octets_dev;
+    if (host_q || host_t) {
+        MSM_HIP(g->d_move_out.ensure(nq + nt + 2));
+        if (host_q) cq = g->d_move_out.p;
+        if (host_t) ct = g->d_move_out.p + ((nq + 1) & ~(size_t)1);
+    }
+    int st = group_move_compute(g, labeling, label, pair0, pair1, trip0, trip1, cq, ct, "msm_group_fusion_move_dev");
+    if (st) return st;
+    if (host_q) MSM_HIP(hipMemcpyAsync(quads_dev, cq, sizeof(double) * nq, hipMemcpyDeviceToHost, ctx->stream));
+    if (host_t) MSM_HIP(hipMemcpyAsync(octets_dev, ct, sizeof(double) * nt, hipMemcpyDeviceToHost, ctx->stream));
     return check_status(ctx, "DiscreteGroupCostFunction (fusion move)");  // synchronises: the buffers may go into a collective on another stream
 }
 

@@ -60,13 +60,21 @@ __global__ __launch_bounds__(256) void k_group_pairwise(GroupArgs a, const int *
                                                          const int *__restrict__ qb, int n, double *__restrict__ out) {
     static_assert(kLanes == 64 || (kLanes == 32 && !kDice), "DICE uses whole wavefronts");
     constexpr int kPerBlock = 256 / kLanes;
-    const int slot = threadIdx.x / kLanes, q = blockIdx.x * kPerBlock + slot, lane = threadIdx.x & (kLanes - 1);
+    // workgroups are dealt to the 8 XCDs in turn: give each XCD (its own L2) a contiguous eighth of the launch's queries
+    int blk = blockIdx.x;
+    {
+        const int per = gridDim.x >> 3;
+        if (blk < (per << 3)) blk = (blk & 7) * per + (blk >> 3);
+    }
+    const int slot = threadIdx.x / kLanes, q = blk * kPerBlock + slot, lane = threadIdx.x & (kLanes - 1);
     if (q >= n) return;
     extern __shared__ double s_common[];
     int pair, la, lb;
+    size_t at = (size_t)q;
     if (a.move_labeling) {  // Fusion's pair_data[pair].buffer[k], I/Fusion/Fusion.h:170-173: k = 2 * (A takes the label) + (B takes it)
         const int e = q + a.move_offset;
-        pair = e >> 2;
+        pair = a.move_order ? a.move_order[e >> 2] : e >> 2;
+        if (a.move_order) at = 4 * (size_t)(pair - a.move_base) + (e & 3);
         la = (e & 2) ? a.move_label : a.move_labeling[a.pairs[2 * pair]];
         lb = (e & 1) ? a.move_label : a.move_labeling[a.pairs[2 * pair + 1]];
     } else {
@@ -90,6 +98,112 @@ __global__ __launch_bounds__(256) void k_group_pairwise(GroupArgs a, const int *
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     const int *fb = staged ? stage : ib;
+    if constexpr (!kDice) {
+        // The usual case -- patches of up to 4 entries per lane, one or two feature rows -- keeps everything in registers: ids
+        // loaded once, all gathers of both passes and both rows issued together.  The general code below reads ids and values
+        // again in every pass of every row: thirteen dependent round trips to memory per query against five here, and this
+        // kernel is bound by exactly that latency (64 % of its wave cycles were waits; its L2 misses did not matter: changing
+        // the order of the pairs to cut them left the time unchanged).  Same per-lane accumulation order, same shuffles: the
+        // results are bit-identical to the general code's.
+        constexpr int kRounds = 4;
+        if (cntA <= kRounds * kLanes && a.D <= 2 && a.simmeasure != 4 && a.simmeasure != 5) {
+            int id[kRounds];
+            bool mem[kRounds];
+#pragma unroll
+            for (int r = 0; r < kRounds; ++r) {
+                const int i = lane + r * kLanes;
+                id[r] = i < cntA ? ia[i] : -1;
+            }
+            int common = 0;
+#pragma unroll
+            for (int r = 0; r < kRounds; ++r) {
+                int lo = 0, hi = cntB;
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (fb[mid] < id[r]) lo = mid + 1;
+                    else hi = mid;
+                }
+                mem[r] = id[r] >= 0 && lo < cntB && fb[lo] == id[r];
+                common += mem[r] ? 1 : 0;
+            }
+            const int ncommon = (int)lanes_sum<kLanes>((double)common);
+            double cost = 0.0;
+            if (ncommon == 0) {
+                cost = nan;
+            } else {
+                double va[kRounds][2], vb[kRounds][2], w[kRounds];
+#pragma unroll
+                for (int r = 0; r < kRounds; ++r) {
+                    w[r] = 1.0;
+#pragma unroll
+                    for (int d = 0; d < 2; ++d) {
+                        va[r][d] = vb[r][d] = 0.0;
+                        if (mem[r] && d < a.D) {
+                            va[r][d] = FA[(size_t)d * a.Vt + id[r]];
+                            vb[r][d] = FB[(size_t)d * a.Vt + id[r]];
+                        }
+                    }
+                    if (mem[r] && a.mask) w[r] = fabs(a.mask[id[r]]);
+                }
+#pragma unroll
+                for (int d = 0; d < 2; ++d) {
+                    if (d >= a.D) break;
+                    double c;
+                    if (a.simmeasure == 2) {  // sparsesimkernel::corr, M/similarities.cpp:129-158
+                        double sw = 0, ma = 0, mb = 0;
+#pragma unroll
+                        for (int r = 0; r < kRounds; ++r)
+                            if (mem[r]) {
+                                sw += w[r];
+                                ma += w[r] * va[r][d];
+                                mb += w[r] * vb[r][d];
+                            }
+                        sw = lanes_sum<kLanes>(sw);
+                        ma = lanes_sum<kLanes>(ma);
+                        mb = lanes_sum<kLanes>(mb);
+                        if (sw > 0.0) {
+                            ma /= sw;
+                            mb /= sw;
+                        }
+                        double pr = 0, sa2 = 0, sb2 = 0;
+#pragma unroll
+                        for (int r = 0; r < kRounds; ++r)
+                            if (mem[r]) {
+                                const double da = va[r][d] - ma, db = vb[r][d] - mb;
+                                pr += w[r] * da * db;
+                                sa2 += w[r] * da * da;
+                                sb2 += w[r] * db * db;
+                            }
+                        pr = lanes_sum<kLanes>(pr);
+                        sa2 = lanes_sum<kLanes>(sa2);
+                        sb2 = lanes_sum<kLanes>(sb2);
+                        if (sw > 0.0) {
+                            pr /= sw;
+                            sa2 /= sw;
+                            sb2 /= sw;
+                        }
+                        const double rr = (sa2 == 0.0 || sb2 == 0.0) ? 0.0 : pr / (sqrt(sa2) * sqrt(sb2));
+                        c = 1 - (1 + rr) * 0.5;
+                    } else {  // sparsesimkernel::SSD, :179-188
+                        double pr = 0;
+#pragma unroll
+                        for (int r = 0; r < kRounds; ++r)
+                            if (mem[r]) {
+                                const double df = va[r][d] - vb[r][d];
+                                pr += w[r] * df * df;
+                            }
+                        pr = lanes_sum<kLanes>(pr);
+                        c = sqrt(pr) / ncommon;
+                    }
+                    cost += c;
+                }
+                cost /= a.D;
+            }
+            if (a.fixnan && cost != cost) cost = 1e7;  // FIX_NAN, M/reg_tools.h:31
+            if (lane == 0) out[at] = cost;
+            return;
+        }
+    }
     // membership of A's entries in B, kept as a bit per (lane, round): patches hold at most 2048 entries
     unsigned long long member = 0ull;
     int common = 0;
@@ -186,7 +300,7 @@ __global__ __launch_bounds__(256) void k_group_pairwise(GroupArgs a, const int *
         cost /= a.D;
     }
     if (a.fixnan && cost != cost) cost = 1e7;  // FIX_NAN, M/reg_tools.h:31
-    if (lane == 0) out[q] = cost;
+    if (lane == 0) out[at] = cost;
 }
 
 __global__ __launch_bounds__(128) void k_group_triplet(GroupArgs a, const int *__restrict__ qt, const int *__restrict__ qa,

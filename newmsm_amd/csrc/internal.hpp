@@ -142,6 +142,7 @@ struct msm_ctx {
         char *host;
         char *dev;
         size_t bytes;
+        bool registered = false;  // msm_host_register: the caller's memory, unregistered (not freed) on release
     };
     std::vector<HostBlock> host_blocks;
 };

@@ -204,6 +204,11 @@ struct GroupArgs {
     // proposed label where bit k of e % 4 (e % 8) is set and the current labeling elsewhere; nullptr: explicit index columns
     const int *move_labeling;
     int move_label, move_offset;
+    // processing order of a move's pairs (nullptr: list order): query i of a launch evaluates combination (move_offset + i) % 4 of
+    // pair move_order[(move_offset + i) / 4] and writes out[4 * (pair - move_base) + combination] -- the results keep the list's
+    // order, the work runs control-point tile by tile (group.cpp: pair_order)
+    const int *move_order;
+    int move_base;
     int patch_cap;               // largest patch of any subject (DICE: LDS staging of the common entries)
     int *status;
 };

@@ -216,15 +216,111 @@ def sharded_group_setup(group, n_subjects, comm=None):
     return mine
 
 
+_SEGMENTS = [0]
+
+
+def same_node(comm):
+    """do all ranks of `comm` run on one node (so that they can share host memory)?"""
+    c = _comm(comm)
+    if c.dist is None or c.world == 1:
+        return True
+    lw = os.environ.get("LOCAL_WORLD_SIZE")
+    if lw is not None:
+        return int(lw) == c.world
+    names = [None] * c.world
+    c.dist.all_gather_object(names, os.uname().nodename)
+    return len(set(names)) == 1
+
+
+class SharedStepBuffer:
+    """Result buffers of the ranks of ONE node in a POSIX shared-memory file that every rank maps: `slots` alternating buffers of
+    `n` doubles and one progress counter per rank.  The ranks deliver their slices of a step straight into the consumer's address
+    space (each GPU writes over its own PCIe link, in parallel) and publish a counter; the consumer waits on the counters -- no
+    collective and no copy on the data path.  Flow control: begin(step) on the consumer releases the slot of step - slots (with
+    two slots the results of a step stay valid until the next-but-one begin), and holds every producer until then.
+
+    The file is created by rank `dst`, opened by the others after a barrier, and unlinked once everyone has it mapped."""
+
+    HEADER = 4096
+
+    def __init__(self, comm, n, dst=0, slots=2):
+        import mmap
+
+        c = self.c = _comm(comm)
+        self.n, self.dst, self.slots = int(n), dst, slots
+        self.stride = (self.n * 8 + 4095) // 4096 * 4096
+        self.nbytes = self.HEADER + slots * self.stride
+        _SEGMENTS[0] += 1
+        self.path = "/dev/shm/msmhip-%d-%s-%d" % (os.getuid(), os.environ.get("MASTER_PORT", "0"), _SEGMENTS[0])
+        if c.rank == dst:
+            try:
+                os.unlink(self.path)
+            except FileNotFoundError:
+                pass
+            fd = os.open(self.path, os.O_CREAT | os.O_EXCL | os.O_RDWR, 0o600)
+            os.ftruncate(fd, self.nbytes)
+        c.barrier()
+        if c.rank != dst:
+            fd = os.open(self.path, os.O_RDWR)
+        self.mm = mmap.mmap(fd, self.nbytes)
+        os.close(fd)
+        c.barrier()
+        if c.rank == dst:
+            os.unlink(self.path)  # stays alive through the mappings; nothing is left behind if a rank dies from here on
+        self.counters = np.frombuffer(self.mm, dtype=np.int64, count=c.world, offset=0)
+        self.released = np.frombuffer(self.mm, dtype=np.int64, count=1, offset=8 * c.world)  # steps <= released[0] may be overwritten
+        self.data = [np.frombuffer(self.mm, dtype=np.float64, count=self.n, offset=self.HEADER + k * self.stride) for k in range(slots)]
+        import ctypes
+
+        self.address = ctypes.addressof(ctypes.c_char.from_buffer(self.mm))
+
+    def slot_address(self, k):
+        return self.address + self.HEADER + k * self.stride
+
+    def _spin(self, done, what, timeout_s=600.0):
+        import time
+
+        t0 = time.monotonic()
+        spins = 0
+        while not done():
+            spins += 1
+            if spins > 2000:
+                time.sleep(0.00005)
+                if time.monotonic() - t0 > timeout_s:
+                    raise TimeoutError("SharedStepBuffer: " + what())
+
+    def begin(self, step):
+        """before this rank writes its slice of `step` (1, 2, ...): the slot must be free"""
+        if self.c.rank == self.dst:
+            self.released[0] = max(int(self.released[0]), step - self.slots)
+        self._spin(lambda: int(self.released[0]) >= step - self.slots, lambda: "the consumer has not released the slot of step %d" % step)
+
+    def publish(self, step):
+        """this rank's slice of `step` (1, 2, ...) is complete in slot (step - 1) % slots"""
+        self.counters[self.c.rank] = step
+
+    def wait(self, step):
+        """the consumer: block until every rank has published `step`; returns the slot's array"""
+        self._spin(lambda: int(self.counters.min()) >= step,
+                   lambda: "step %d not delivered by ranks %s" % (step, np.nonzero(self.counters < step)[0].tolist()))
+        return self.data[(step - 1) % self.slots]
+
+
 class ShardedMove:
     """One label step of Fusion for the group with the cliques sharded over the ranks (see the module docstring).
 
-    move(labeling, label) evaluates this rank's slice of the 4 P pair costs and 8 T triplet costs and gathers all slices on
+    move(labeling, label) evaluates this rank's slice of the 4 P pair costs and 8 T triplet costs and delivers all slices to
     rank `dst`, which gets (pair_quads P x 4, triplet_octets T x 8) exactly as msm_group_fusion_move returns them; the other
-    ranks get (None, None).  Slices are padded to the largest one so that the gather is one fixed-size collective; with the
-    nccl backend the kernels write into the tensor the gather sends (no host copy on the sending ranks)."""
+    ranks get (None, None).  Transports:
+      "local"   one process: the results are copied into pinned arrays of this process (Context.host_array);
+      "shm"     the ranks of one node (the 8 GPUs of an MI355X box): every rank's GPU copies its slice over its own PCIe link
+                into a shared-memory buffer at the slice's final position (SharedStepBuffer) -- the optimiser is host code, so
+                the host is where the costs are needed; no collective, no concatenation.  The arrays returned are views of
+                that buffer: valid until the next-but-one move() (the producers are held back until then);
+      "gather"  ranks on several nodes: slices padded to the largest, one gather to `dst`; with the nccl backend the kernels write
+                into the tensor the gather sends."""
 
-    def __init__(self, group, comm=None, dst=0):
+    def __init__(self, group, comm=None, dst=0, transport=None):
         import torch
 
         self.g, self.c, self.dst = group, _comm(comm), dst
@@ -233,6 +329,18 @@ class ShardedMove:
         self.trange = [shard(group.T, r, c.world) for r in range(c.world)]
         self.pmax = max(len(r) for r in self.prange)
         self.tmax = max(len(r) for r in self.trange)
+        if transport is None:
+            transport = "local" if c.world == 1 else ("shm" if same_node(c) and hasattr(group, "ctx") else "gather")
+        self.transport = transport
+        self.step = 0
+        if transport == "local":
+            self.out = (group.ctx.host_array((group.P, 4)), group.ctx.host_array((group.T, 8)))
+            return
+        if transport == "shm":
+            self.off_t = (4 * group.P + 1) // 2 * 2  # doubles; keeps the triplet part 16-byte aligned
+            self.shared = SharedStepBuffer(c, self.off_t + 8 * group.T, dst)
+            group.ctx.register_host(self.shared.address, self.shared.nbytes)
+            return
         dev = c.device if c.on_gpu else "cpu"
         self.send = torch.zeros(4 * self.pmax + 8 * self.tmax, dtype=torch.float64, device=dev)
         self.recv = torch.zeros((c.world, 4 * self.pmax + 8 * self.tmax), dtype=torch.float64, device=dev) if (c.rank == dst and c.world > 1) else None
@@ -241,11 +349,26 @@ class ShardedMove:
             self.gpu_scratch = (torch.zeros(4 * self.pmax + 8 * self.tmax, dtype=torch.float64, device="cuda:%d" % torch.cuda.current_device())
                                 if torch.cuda.is_available() else None)
 
-    def move(self, labeling, label):
-        import torch
+    def close(self):
+        if self.transport == "shm" and self.shared is not None:
+            self.g.ctx.unregister_host(self.shared.address)
+            self.shared = None
 
+    def move(self, labeling, label):
         c, g = self.c, self.g
         pr, tr = self.prange[c.rank], self.trange[c.rank]
+        self.step += 1
+        if self.transport == "local":
+            return g.fusionMove(labeling, label, out=self.out)
+        if self.transport == "shm":
+            self.shared.begin(self.step)
+            base = self.shared.slot_address((self.step - 1) % self.shared.slots)
+            g.fusionMove_dev(labeling, label, (pr.start, pr.stop), (tr.start, tr.stop), base + 8 * 4 * pr.start, base + 8 * (self.off_t + 8 * tr.start))
+            self.shared.publish(self.step)  # fusionMove_dev returned: this rank's copies have completed
+            if c.rank != self.dst:
+                return None, None
+            buf = self.shared.wait(self.step)
+            return buf[: 4 * g.P].reshape(g.P, 4), buf[self.off_t: self.off_t + 8 * g.T].reshape(g.T, 8)
         buf = self.send if c.on_gpu else self.gpu_scratch
         g.fusionMove_dev(labeling, label, (pr.start, pr.stop), (tr.start, tr.stop), buf.data_ptr(), buf.data_ptr() + 8 * 4 * self.pmax)
         if not c.on_gpu:

@@ -100,7 +100,7 @@ def anatomical_inputs(ctx, inp, anat_order=None, seed=99):
                 w_ptr=w_ptr, w_cp=w_cp, w_val=w_val, face_ptr=face_ptr, face_idx=face_idx)
 
 
-def build_group(ctx, S, data_order=6, cp_order=4, D=2, subjects=None, lambda_=0.2, simmeasure=2, seed=40):
+def build_group(ctx, S, data_order=6, cp_order=4, D=2, subjects=None, lambda_=0.2, simmeasure=2, seed=40, template_order=None):
     """A synthetic groupwise (gMSM) problem part-way through a registration, BASELINE config 5 shape: S subjects on the data grid
     ico<data_order>, each with its own smooth warp so far and D feature rows, the template = the regular sphere at data
     resolution, control grid ico<cp_order>, the unrescaled sampling-grid labels (DiscreteGroupModel::setupCostFunction
@@ -111,7 +111,18 @@ def build_group(ctx, S, data_order=6, cp_order=4, D=2, subjects=None, lambda_=0.
     _, mvd = api.cp_spacings(cxyz, ctri)
     samples, _ = api.label_sampling_grid(cp_order + 2, 0.5 * mvd)
     g = api.DiscreteGroupCostFunction(ctx, S, simmeasure=simmeasure, lambda_=lambda_)
-    tm = api.Mesh(ctx, dxyz, dtri)
+    txyz, ttri = dxyz, dtri
+    if template_order == "morton":  # the same template with its vertices renumbered along a space-filling curve
+        q = np.clip(((dxyz + 101.0) / 202.0 * 1024.0).astype(np.int64), 0, 1023)
+        code = np.zeros(len(dxyz), dtype=np.int64)
+        for b in range(10):
+            for a in range(3):
+                code |= ((q[:, a] >> b) & 1) << (3 * b + 2 - a)
+        perm = np.argsort(code, kind="stable")
+        rank = np.empty_like(perm)
+        rank[perm] = np.arange(len(perm))
+        txyz, ttri = dxyz[perm], rank[dtri].astype(np.int32)
+    tm = api.Mesh(ctx, txyz, ttri)
     g.set_template(tm, None)
     g.Initialize(cxyz, ctri)
     keep = [tm]

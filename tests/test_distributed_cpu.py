@@ -1,5 +1,6 @@
 """The N > 1 path on CPU: two gloo ranks (world_size 2) exercise sharding, the max-over-ranks timing reduction
 and the group template all-reduce that the GPU box runs over RCCL."""
+import json
 import os
 import subprocess
 import sys
@@ -120,3 +121,44 @@ def test_sharded_group_exchange_two_gloo_ranks(tmp_path):
         outs.append(eval(so.strip().splitlines()[-1].replace("true", "True").replace("false", "False")))
     assert all(o["ok"] for o in outs)
     assert sorted(outs[0]["mine"] + outs[1]["mine"]) == list(range(5))
+
+
+SHM_WORKER = textwrap.dedent("""
+    import os, sys, json
+    import numpy as np
+    sys.path.insert(0, %r)
+    from newmsm_amd import dist as D
+
+    rank, _, world = D.env()
+    dist = D.init("gloo")
+    n = 1000
+    buf = D.SharedStepBuffer(dist, n, dst=0)
+    lo, hi = D.shard(n, rank, world).start, D.shard(n, rank, world).stop
+    ok = D.same_node(dist)
+    for step in range(1, 8):                                       # seven steps over two alternating slots
+        buf.begin(step)                                            # producers wait for the consumer to release the slot
+        slot = buf.data[(step - 1) %% buf.slots]
+        slot[lo:hi] = 1000.0 * step + np.arange(lo, hi)            # this rank's slice, at its final position
+        buf.publish(step)
+        if rank == 0:
+            got = buf.wait(step)
+            ok = ok and np.array_equal(got, 1000.0 * step + np.arange(n))
+    dist.barrier()
+    ok = ok and not os.path.exists(buf.path)                       # unlinked once everyone had it mapped
+    print(json.dumps({"rank": rank, "ok": bool(ok)}))
+    dist.destroy_process_group()
+""")
+
+
+def test_shared_step_buffer_two_ranks(tmp_path):
+    """dist.SharedStepBuffer (the single-node transport of ShardedMove): slices written by two processes arrive at rank 0 without
+    a collective; the backing file is gone from /dev/shm as soon as both have mapped it."""
+    script = tmp_path / "shm.py"
+    script.write_text(SHM_WORKER % ROOT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29549", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True) for r in range(2)]
+    for p in procs:
+        so, se = p.communicate(timeout=240)
+        assert p.returncode == 0, se[-2000:]
+        assert json.loads(so.strip().splitlines()[-1])["ok"]

@@ -204,10 +204,21 @@ g1, keep1 = make(); g1.setupCostFunction()
 single = g1.computePairwiseCost(p, la, lb)
 # a label step with the pair and triplet lists sharded over the two ranks, gathered on rank 0 (M/DiscreteGroupCostFunction.cpp:54-98)
 lab = rng.integers(0, g.L, g.num_nodes).astype(np.int32)
-sm = D.ShardedMove(g, dist)
-q, o = sm.move(lab, 4)
+move_ok, transports = True, []
+for transport in (None, "gather"):   # None: the ranks share a node -> every rank's GPU writes its slice into shared host memory
+    sm = D.ShardedMove(g, dist, transport=transport)
+    transports.append(sm.transport)
+    for step, label in enumerate((4, 1, 7)):   # three steps: both alternating buffers of the shared transport are reused
+        lab_s = (lab + step) %% g.L
+        q, o = sm.move(lab_s, label)
+        q1, o1 = g1.fusionMove(lab_s, label)
+        if rank == 0:
+            move_ok = move_ok and bool(np.array_equal(q, q1, equal_nan=True) and np.array_equal(o, o1))
+    sm.close()
+# the single-process transport: pinned arrays of this process
+q, o = D.ShardedMove(g1, None).move(lab, 4)
 q1, o1 = g1.fusionMove(lab, 4)
-move_ok = True if rank != 0 else bool(np.array_equal(q, q1, equal_nan=True) and np.array_equal(o, o1))
+move_ok = move_ok and bool(np.array_equal(q, q1, equal_nan=True) and np.array_equal(o, o1)) and transports == ["shm", "gather"]
 tmpl = D.group_template_update(np.stack([keep[1 + s].get_coords() for s in mine]), None, dist)
 dist.barrier()
 print(json.dumps({"rank": rank, "mine": mine, "equal": bool(np.array_equal(sharded, single, equal_nan=True)), "finite": int(np.isfinite(single).sum()), "move_ok": move_ok,

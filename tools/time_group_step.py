@@ -1,0 +1,31 @@
+"""one label step of Fusion for a group at ico6 / ico4: kernels only (results left in HBM), the C call that delivers them to
+the host, and dist.ShardedMove at world size 1.  usage: time_group_step.py [S] [data_order cp_order]"""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import newmsm_amd as M
+from newmsm_amd import problem, dist as D
+S = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+do, co = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (6, 4)
+ctx = M.Context(0)
+g, keep = problem.build_group(ctx, S, do, co, D=2, subjects=list(range(S)), template_order=os.environ.get("TEMPLATE_ORDER"))
+t0 = time.perf_counter(); g.setupCostFunction(); print("set-up %.3f s (%.1f ms per subject)" % (time.perf_counter() - t0, (time.perf_counter() - t0) / S * 1e3), flush=True)
+rng = np.random.default_rng(3)
+lab = rng.integers(0, g.L, g.num_nodes).astype(np.int32)
+buf = torch.zeros(4 * g.P + 8 * g.T, dtype=torch.float64, device="cuda:0")
+def dev_step(label):
+    g.fusionMove_dev(lab, label, (0, g.P), (0, g.T), buf.data_ptr(), buf.data_ptr() + 8 * 4 * g.P)
+    torch.cuda.synchronize()
+pinned = (ctx.host_array((g.P, 4)), ctx.host_array((g.T, 8)))
+for name, fn in (("kernels (results in HBM)", dev_step), ("msm_group_fusion_move (host arrays)", lambda l: g.fusionMove(lab, l)),
+                 ("msm_group_fusion_move (msm_host_alloc arrays)", lambda l: g.fusionMove(lab, l, out=pinned)),
+                 ("ShardedMove.move, world 1", None)):
+    if fn is None:
+        mover = D.ShardedMove(g, D.Comm(None, "nccl", "cuda:0", 0, 1))
+        fn = lambda l: mover.move(lab, l)
+    fn(1)
+    t0 = time.perf_counter()
+    for i in range(5): fn(2 + i)
+    dt = (time.perf_counter() - t0) / 5
+    print("%-48s %.2f ms per step: %.0f M pair + triplet evals/s" % (name, dt * 1e3, (4 * g.P + 8 * g.T) / dt / 1e6), flush=True)
