@@ -22,6 +22,7 @@ struct AdaptiveDevArgs {
     double *rwt;
     int *coff, *cfill, *ckey;      // columns of the result: offsets (nOld + 1), fill counters (nOld), new vertex ids (3 nNew + 3 nOld)
     double *cval, *correction;     // (nOld)
+    int *scan_tmp;                 // scratch of the prefix sums, max(nNew, nOld) / 4096 + 2
     int *tkey;                     // scratch of the long-list sort, 3 nNew + 3 nOld
     double *tval;
     int *row_ptr, *col;            // the result as CSR: nNew + 1, 3 nNew + 3 nOld

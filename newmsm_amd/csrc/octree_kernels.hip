@@ -70,7 +70,8 @@ struct OctWork {
     int *chunk_beg[2];
     int *list[2];          // the lists themselves
     int *split;            // per open node
-    int *cc;               // 8 per chunk: what each child receives from this chunk, then (after the scan) where the chunk's share starts
+    int *cc;               // 8 per chunk: what each child receives from this chunk, then (after k_oct_chunk_scan) where the chunk's share starts
+    int *ctot;             // 8 per open node: what each child of a splitting node receives in all
     int32_t *leaf_tri;     // the mesh's leaf array
     int cap_nodes, cap_refs, cap_arena, cap_open, cap_chunks;
 };
@@ -160,6 +161,69 @@ __global__ __launch_bounds__(256) void k_oct_count(OctWork w, int cur) {
     }
 }
 
+// per splitting node: its chunks' counts become exclusive prefixes (where each chunk's share of a child's list starts), the sums
+// go to ctot.  A wavefront per node, 64 chunks at a time -- the root of an ico6 mesh has 320 chunks, and one thread of
+// k_oct_scan walking them with dependent loads and stores took up to 100 us per level.
+__global__ __launch_bounds__(256) void k_oct_chunk_scan(OctWork w, int cur) {
+    const int nopen = w.counters[C_NOPEN];
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+    for (int o = wave; o < nopen; o += nwaves) {
+        if (!w.split[o]) continue;
+        const int len = w.open_len[cur][o], k0 = w.open_chunk[cur][o], nk = (len + kChunk - 1) / kChunk;
+        int carry[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int base = 0; base < nk; base += kWave) {  // uniform
+            const int j = base + lane;
+            int v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (j < nk) {
+                const int4 a = *reinterpret_cast<const int4 *>(w.cc + 8 * (size_t)(k0 + j)), b = *reinterpret_cast<const int4 *>(w.cc + 8 * (size_t)(k0 + j) + 4);
+                v[0] = a.x, v[1] = a.y, v[2] = a.z, v[3] = a.w, v[4] = b.x, v[5] = b.y, v[6] = b.z, v[7] = b.w;
+            }
+            int e[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const int incl = wave_incl_scan(v[c], lane);
+                e[c] = carry[c] + incl - v[c];
+                carry[c] += __shfl(incl, kWave - 1, kWave);
+            }
+            if (j < nk) {
+                *reinterpret_cast<int4 *>(w.cc + 8 * (size_t)(k0 + j)) = make_int4(e[0], e[1], e[2], e[3]);
+                *reinterpret_cast<int4 *>(w.cc + 8 * (size_t)(k0 + j) + 4) = make_int4(e[4], e[5], e[6], e[7]);
+            }
+        }
+        if (lane == 0) {
+            *reinterpret_cast<int4 *>(w.ctot + 8 * (size_t)o) = make_int4(carry[0], carry[1], carry[2], carry[3]);
+            *reinterpret_cast<int4 *>(w.ctot + 8 * (size_t)o + 4) = make_int4(carry[4], carry[5], carry[6], carry[7]);
+        }
+    }
+}
+
+// block-wide exclusive scans of kN values per thread at once (1024 threads): v[] becomes the exclusive prefixes, total[] the sums
+template <int kN>
+__device__ void block_excl_scan_n(int v[kN], int total[kN]) {
+    __shared__ int s_w[kN][16];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = (int)(blockDim.x >> 6);
+    int incl[kN];
+#pragma unroll
+    for (int q = 0; q < kN; ++q) {
+        incl[q] = wave_incl_scan(v[q], lane);
+        if (lane == kWave - 1) s_w[q][wv] = incl[q];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < kN; ++q) {
+        int before = 0, all = 0;
+        for (int k = 0; k < nw; ++k) {
+            const int t = s_w[q][k];
+            before += k < wv ? t : 0;
+            all += t;
+        }
+        v[q] = incl[q] - v[q] + before;
+        total[q] = all;
+    }
+    __syncthreads();
+}
+
 // block-wide exclusive scan of one value per thread (1024 threads), returns the exclusive prefix; *total = sum
 __device__ int block_excl_scan(int v, int *total) {
     __shared__ int s_w[16];
@@ -201,29 +265,19 @@ __global__ __launch_bounds__(1024) void k_oct_scan(OctWork w, int cur, int depth
         const int sp = in ? w.split[o] : 0;
         const int len = in ? w.open_len[cur][o] : 0;
         const bool leaf = in && !sp;
-        // what the children of a splitting node receive: the sums over its chunks; each chunk's counts become its share's start
+        // what the children of a splitting node receive (k_oct_chunk_scan summed its chunks)
         int ct[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         if (sp) {
-            const int k0 = w.open_chunk[cur][o], nk = (len + kChunk - 1) / kChunk;
-            for (int k = k0; k < k0 + nk; ++k)
-                for (int c = 0; c < 8; ++c) {
-                    const int v = w.cc[8 * (size_t)k + c];
-                    w.cc[8 * (size_t)k + c] = ct[c];
-                    ct[c] += v;
-                }
+            const int4 a = *reinterpret_cast<const int4 *>(w.ctot + 8 * (size_t)o), b = *reinterpret_cast<const int4 *>(w.ctot + 8 * (size_t)o + 4);
+            ct[0] = a.x, ct[1] = a.y, ct[2] = a.z, ct[3] = a.w, ct[4] = b.x, ct[5] = b.y, ct[6] = b.z, ct[7] = b.w;
         }
         int ctot = 0, cchunks = 0;
         for (int c = 0; c < 8; ++c) ctot += ct[c], cchunks += (ct[c] + kChunk - 1) / kChunk;
-        int t1, t2, t3, t4, t5, t6, t7;
-        const int rank = carry_rank + block_excl_scan(sp, &t1);
-        const int aoff = carry_arena + block_excl_scan(leaf ? ((len + 7) & ~7) : 0, &t2);
         const int hasmask = leaf && len >= 1 && len <= 64;
-        const int mblk = carry_mask + block_excl_scan(hasmask, &t3);
-        const int loff = carry_list + block_excl_scan(ctot, &t4);
-        const int koff = carry_chunk + block_excl_scan(cchunks, &t5);
-        (void)block_excl_scan(leaf ? len : 0, &t6);
-        (void)block_excl_scan(leaf ? 1 : 0, &t7);
-        carry_rank += t1, carry_arena += t2, carry_mask += t3, carry_list += t4, carry_chunk += t5, refs += t6, nleaves += t7;
+        int sc[7] = {sp, leaf ? ((len + 7) & ~7) : 0, hasmask, ctot, cchunks, leaf ? len : 0, leaf ? 1 : 0}, tot[7];
+        block_excl_scan_n<7>(sc, tot);
+        const int rank = carry_rank + sc[0], aoff = carry_arena + sc[1], mblk = carry_mask + sc[2], loff = carry_list + sc[3], koff = carry_chunk + sc[4];
+        carry_rank += tot[0], carry_arena += tot[1], carry_mask += tot[2], carry_list += tot[3], carry_chunk += tot[4], refs += tot[5], nleaves += tot[6];
         if (leaf) atomicMax(&s_max, len);
         if (in) {
             const int n = w.open_node[cur][o];
@@ -377,7 +431,7 @@ int gpu_build_octree(msm_mesh *m, const std::function<void()> *overlap) {
         ctx->oct_cap_box = (size_t)6 * T + 1024;
         MSM_HIP(hipMalloc((void **)&ctx->oct_box, ctx->oct_cap_box * sizeof(double)));
     }
-    const size_t need_ints = (size_t)2 * cap_refs + (size_t)8 * cap_open + (size_t)cap_open + (size_t)4 * cap_chunks + (size_t)8 * cap_chunks;
+    const size_t need_ints = (size_t)2 * cap_refs + (size_t)8 * cap_open + (size_t)cap_open + (size_t)8 * cap_open + (size_t)4 * cap_chunks + (size_t)8 * cap_chunks + 16;
     if (need_ints > ctx->oct_cap_ints) {
         if (ctx->oct_ints) (void)hipFree(ctx->oct_ints);
         ctx->oct_ints = nullptr;
@@ -425,6 +479,8 @@ int gpu_build_octree(msm_mesh *m, const std::function<void()> *overlap) {
         w.chunk_beg[k] = p, p += cap_chunks;
     }
     w.split = p, p += cap_open;
+    p += (4 - ((p - s.ints) & 3)) & 3;  // 16-byte alignment of the int4 accesses below
+    w.ctot = p, p += (size_t)8 * cap_open;
     w.cc = p;
     w.leaf_tri = m->d_leaf_tri;
     w.cap_nodes = cap_nodes, w.cap_refs = cap_refs, w.cap_arena = cap_arena, w.cap_open = cap_open, w.cap_chunks = cap_chunks;
@@ -444,6 +500,7 @@ int gpu_build_octree(msm_mesh *m, const std::function<void()> *overlap) {
             hipLaunchKernelGGL(k_oct_begin_level, dim3(1), dim3(1), 0, ctx->stream, s.counters);
             hipLaunchKernelGGL(k_oct_decide, dim3(512), dim3(256), 0, ctx->stream, w, cur);
             hipLaunchKernelGGL(k_oct_count, dim3(1024), dim3(256), 0, ctx->stream, w, cur);
+            hipLaunchKernelGGL(k_oct_chunk_scan, dim3(256), dim3(256), 0, ctx->stream, w, cur);
             hipLaunchKernelGGL(k_oct_scan, dim3(1), dim3(1024), 0, ctx->stream, w, cur, depth);
             hipLaunchKernelGGL(k_oct_fill, dim3(1024), dim3(256), 0, ctx->stream, w, cur);
             cur ^= 1;
