@@ -13,6 +13,7 @@ template <typename T>
 struct DevBuf {
     T *p = nullptr;
     size_t cap = 0;
+    bool owned = true;  // false: a window into another allocation (view())
 
     DevBuf() = default;
     DevBuf(const DevBuf &) = delete;
@@ -20,9 +21,17 @@ struct DevBuf {
     ~DevBuf() { release(); }
 
     void release() {
-        if (p) (void)hipFree(p);  // hipFree waits for work that may still use the buffer
+        if (p && owned) (void)hipFree(p);  // hipFree waits for work that may still use the buffer
         p = nullptr;
         cap = 0;
+        owned = true;
+    }
+    // n elements at ptr, which belongs to another buffer that outlives this one
+    void view(T *ptr, size_t n) {
+        release();
+        p = ptr;
+        cap = n;
+        owned = false;
     }
     hipError_t ensure(size_t n) {
         if (n <= cap && p) return hipSuccess;

@@ -56,7 +56,9 @@ struct msm_group {
     std::vector<double> rot, moved;              // (S*N) x 9, (S*N) x L x 3
     DevBuf<double> d_moved, d_cp, d_orig;
     std::vector<std::vector<double>> spacing;
-    std::vector<std::unique_ptr<DevBuf<double>>> F;  // S * L
+    std::vector<std::unique_ptr<DevBuf<double>>> F;  // S * L: windows into Fslab[subject]
+    std::vector<std::unique_ptr<DevBuf<double>>> Fslab;  // per subject: its L resampled feature maps in one allocation (one hipMalloc instead of nineteen per subject
+                                                         // and set-up, and large pages under the label steps' gathers)
     std::vector<std::unique_ptr<DevBuf<int32_t>>> pptr, pidx;  // per subject
     std::vector<std::vector<int32_t>> h_pptr, h_pidx;
     DevBuf<const double *> d_Fp;
@@ -82,6 +84,20 @@ inline V3 pt(const double *xyz, int V, int i) { return mk(xyz[i], xyz[V + i], xy
 
 // patch lists of one subject: template vertices within range*spacing of each rotated control point
 // (get_patch_data, M/DiscreteGroupModel.cpp:109-117), via the range kernel + host tie resolution (see k_range)
+// F[s][0..L) as windows of `per` doubles each into the subject's slab
+int subject_feature_slab(msm_group *g, int s, size_t per) {
+    auto &slab = g->Fslab[s];
+    if (!slab) slab.reset(new DevBuf<double>());
+    const double *before = slab->p;
+    MSM_HIP(slab->ensure(per * g->L));
+    for (int l = 0; l < g->L; ++l) {
+        auto &buf = g->F[(size_t)s * g->L + l];
+        if (!buf) buf.reset(new DevBuf<double>());
+        if (buf->p != slab->p + per * l || slab->p != before || buf->cap != per) buf->view(slab->p + per * l, per);
+    }
+    return MSM_OK;
+}
+
 int subject_patches(msm_group *g, int s) {
     msm_ctx *ctx = g->ctx;
     const int N = g->N, L = g->L, M = N * L, Vt = g->tmpl->V;
@@ -387,6 +403,14 @@ int group_common_setup(msm_group *g) {
     msm_ctx *ctx = g->ctx;
     const int S = g->S, N = g->N, L = g->L;
     const double centre[3] = {g->labels[0], g->labels[L], g->labels[2 * (size_t)L]};
+    const bool timing = std::getenv("MSMHIP_TIMING") != nullptr;
+    auto tick = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "  group set-up, common: %s %.1f ms\n", what, std::chrono::duration<double, std::milli>(now - tick).count());
+        tick = now;
+    };
     // estimate_pairs, M/DiscreteGroupModel.cpp:37-55: closest control point of subject B for every control point of A
     g->pairs.resize((size_t)N * S * (S - 1));
     {
@@ -415,6 +439,7 @@ int group_common_setup(msm_group *g) {
                 }
     }
     MSM_HIP(g->d_pairs.upload_vec(g->pairs, ctx->stream));
+    lap("estimate_pairs");
     {
         // Processing order of a label step's pairs.  The list above runs subject A, control point, subject B: neighbours in it
         // share A's patch, but consecutive control-point ids are not neighbours on the sphere and every pair pulls another
@@ -452,6 +477,7 @@ int group_common_setup(msm_group *g) {
         }
         g->order_p0 = g->order_p1 = -1;
     }
+    lap("pair order");
     // get_spacings :123-139, get_rotations :77-86, and ROT * label for every (node, label)
     g->rot.resize(9 * (size_t)S * N);
     g->moved.resize(3 * (size_t)S * N * L);
@@ -478,8 +504,10 @@ int group_common_setup(msm_group *g) {
     MSM_HIP(g->d_orig.upload(orig_all.data(), orig_all.size(), ctx->stream));
     MSM_HIP(hipStreamSynchronize(ctx->stream));
     g->F.resize((size_t)S * L);
+    g->Fslab.resize(S);
     g->have_subject.assign(S, 0);
     g->common_ready = true;
+    lap("spacings, rotations, uploads");
     return MSM_OK;
 }
 
@@ -526,6 +554,8 @@ int group_subject_setup(msm_group *g, int s) {
         MSM_HIP(g->d_subject_feat.ensure((size_t)D * V));
         int st = upload_staged(ctx, g->d_subject_feat.p, g->feat[s].data(), sizeof(double) * (size_t)D * V);
         if (st) return st;
+        st = subject_feature_slab(g, s, (size_t)D * Vt);
+        if (st) return st;
         lap("rotations + feature upload");
         for (int l = 0; l < L; ++l) {
             for (int a = 0; a < 3; ++a)
@@ -534,10 +564,7 @@ int group_subject_setup(msm_group *g, int s) {
             AdaptiveDev w;
             st = adaptive_weights_dev(sm, g->tmpl, w, false);
             if (st) return st;
-            auto &buf = g->F[(size_t)s * L + l];
-            if (!buf) buf.reset(new DevBuf<double>());
-            MSM_HIP(buf->ensure((size_t)D * Vt));
-            st = apply_weights_dev(ctx, w, g->d_subject_feat.p, D, buf->p);
+            st = apply_weights_dev(ctx, w, g->d_subject_feat.p, D, g->F[(size_t)s * L + l]->p);
             if (st) return st;
         }
         st = check_status(ctx, "get_patch_data (resampling)");
@@ -640,11 +667,12 @@ int group_subject_setup(msm_group *g, int s) {
                 out[(size_t)d * Vt + k] = acc;
             }
     });
+    {
+        int st = subject_feature_slab(g, s, (size_t)D * Vt);
+        if (st) return st;
+    }
     for (int l = 0; l < L; ++l) {
-        auto &buf = g->F[(size_t)s * L + l];
-        if (!buf) buf.reset(new DevBuf<double>());
-        MSM_HIP(buf->ensure(resampled[l].size()));
-        int st = upload_staged(ctx, buf->p, resampled[l].data(), resampled[l].size() * sizeof(double));
+        int st = upload_staged(ctx, g->F[(size_t)s * L + l]->p, resampled[l].data(), resampled[l].size() * sizeof(double));
         if (st) return st;
     }
     MSM_HIP(hipStreamSynchronize(ctx->stream));
@@ -717,11 +745,11 @@ int msm_group_import_subject(msm_group *g, int32_t s, const double *F, const int
     const int32_t Vt = g->tmpl->V;
     for (int64_t j = 0; j < npidx; ++j)
         if (pidx[j] < 0 || pidx[j] >= Vt) return fail(MSM_ERR_INVALID, "patch CSR of subject %d: template vertex id %d out of range [0,%d)", s, pidx[j], Vt);
-    for (int l = 0; l < g->L; ++l) {
-        auto &buf = g->F[(size_t)s * g->L + l];
-        if (!buf) buf.reset(new DevBuf<double>());
-        MSM_HIP(buf->upload(F + per * l, per, ctx->stream));
+    {
+        int st = subject_feature_slab(g, s, per);
+        if (st) return st;
     }
+    for (int l = 0; l < g->L; ++l) MSM_HIP(hipMemcpyAsync(g->F[(size_t)s * g->L + l]->p, F + per * l, sizeof(double) * per, hipMemcpyHostToDevice, ctx->stream));
     g->h_pptr[s].assign(pptr, pptr + M + 1);
     g->h_pidx[s].assign(pidx, pidx + npidx);
     MSM_HIP(g->pptr[s]->upload(g->h_pptr[s].data(), M + 1, ctx->stream));
@@ -776,12 +804,12 @@ int msm_group_import_subject_dev(msm_group *g, int32_t s, const double *F_dev, c
     MSM_HIP(hipMemcpyAsync(&hbad, bad.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     MSM_HIP(hipStreamSynchronize(ctx->stream));
     if (hbad) return fail(MSM_ERR_INVALID, "patch CSR of subject %d is inconsistent (code %d: 1 ends, 2 row lengths, 4 vertex ids)", s, hbad);
-    for (int l = 0; l < g->L; ++l) {
-        auto &buf = g->F[(size_t)s * g->L + l];
-        if (!buf) buf.reset(new DevBuf<double>());
-        MSM_HIP(buf->ensure(per));
-        MSM_HIP(hipMemcpyAsync(buf->p, F_dev + per * l, sizeof(double) * per, hipMemcpyDeviceToDevice, ctx->stream));
+    {
+        int st = subject_feature_slab(g, s, per);
+        if (st) return st;
     }
+    for (int l = 0; l < g->L; ++l)
+        MSM_HIP(hipMemcpyAsync(g->F[(size_t)s * g->L + l]->p, F_dev + per * l, sizeof(double) * per, hipMemcpyDeviceToDevice, ctx->stream));
     MSM_HIP(g->pptr[s]->ensure(M + 1));
     MSM_HIP(hipMemcpyAsync(g->pptr[s]->p, pptr_dev, sizeof(int32_t) * (M + 1), hipMemcpyDeviceToDevice, ctx->stream));
     MSM_HIP(g->pidx[s]->ensure(std::max<size_t>((size_t)npidx, 1)));
