@@ -123,7 +123,14 @@ int clique_args(msm_cost *c, bool need_triplets, bool need_pairs, CliqueArgs &a)
 }
 
 // ---- fused fusion move of the HO classes (move_kernels.hip) ----
-constexpr int kMoveSlots = 64, kMoveTriangles = 8;  // bin slots and control triangles per workgroup: two rounds of 256 samples, 64 evaluations
+// bin slots and control triangles per workgroup (at most 64 and 8: the kernel's LDS holds 64 proposed triangles)
+static int env_int(const char *name, int dflt, int lo, int hi) {
+    const char *e = std::getenv(name);
+    if (!e) return dflt;
+    const int v = std::atoi(e);
+    return v < lo ? lo : (v > hi ? hi : v);
+}
+static const int kMoveSlots = env_int("MSMHIP_MOVE_SLOTS", 64, 8, 64), kMoveTriangles = env_int("MSMHIP_MOVE_TRIANGLES", 8, 1, 8);
 
 bool fused_move_applies(const msm_cost *c, const CliqueArgs &a) {
     static const bool split = [] {

@@ -205,15 +205,15 @@ __global__ __launch_bounds__(256) void k_move_prepare(CliqueArgs a, int *__restr
 // kMode 0: HO univariate (value = interpolated target feature, from the table record)
 //       1: HO multivariate, a lane per sample (any D, any measure): ho_value_on
 //       2: HO multivariate, 12 <= D <= 64 and even, SSD / correlation: eight lanes per sample split the dimensions
-template <bool kPacked, int kMode>
-__global__ __launch_bounds__(256) void k_ho_move(CliqueArgs a, MoveArgs m, MoveLabels lab) {
+template <bool kPacked, int kMode, int kThreads>
+__global__ __launch_bounds__(kThreads) void k_ho_move(CliqueArgs a, MoveArgs m, MoveLabels lab) {
     extern __shared__ __align__(16) double lds[];
     double *s_geo = lds;                            // 64 evaluations x 9: the proposed triangles
     double *s_vals = s_geo + 64 * 9;                // 8 combinations x cap bin slots
     double *s_w = s_vals + 8 * (size_t)m.cap;       // kMode 2: 3 weights per sample of a round
-    int *s_flag = reinterpret_cast<int *>(s_w + (kMode == 2 ? 3 * 256 : 0));  // [0,64) folded, [64,128) deferred
+    int *s_flag = reinterpret_cast<int *>(s_w + (kMode == 2 ? 3 * kThreads : 0));  // [0,64) folded, [64,128) deferred
     int *s_pend = s_flag + 128;                     // samples the direction table left open (at most all of a round... of the block: 8 * cap)
-    int *s_tt = s_pend + 8 * m.cap;                 // kMode 2: triangle and its vertex ids per sample of a round (4 x 256)
+    int *s_tt = s_pend + 8 * m.cap;                 // kMode 2: triangle and its vertex ids per sample of a round (4 x kThreads)
     __shared__ int s_npend;
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256) void k_ho_move(CliqueArgs a, MoveArgs m, MoveL
     MSM_STAMP(1);
 
     // ---- samples: s = combination * nslots + slot (neighbouring lanes = neighbouring bin points of one combination)
-    for (int base = 0; base < total; base += 256) {
+    for (int base = 0; base < total; base += kThreads) {
         const int s = base + tid;
         int tt = -2;  // -2: nothing to do (past the end, or a folded proposal: it never looks at the data); -1: left open
         int kk = 0, j = 0, el = 0;
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(256) void k_ho_move(CliqueArgs a, MoveArgs m, MoveL
                 } else {
                     const TriRec &rr = a.tree.rec[tt];
                     s_w[3 * tid] = wa, s_w[3 * tid + 1] = wb, s_w[3 * tid + 2] = wc;
-                    s_tt[256 + 3 * tid] = rr.id[0], s_tt[256 + 3 * tid + 1] = rr.id[1], s_tt[256 + 3 * tid + 2] = rr.id[2];
+                    s_tt[kThreads + 3 * tid] = rr.id[0], s_tt[kThreads + 3 * tid + 1] = rr.id[1], s_tt[kThreads + 3 * tid + 2] = rr.id[2];
                 }
             } else {
                 s_pend[atomicAdd(&s_npend, 1)] = s;
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(256) void k_ho_move(CliqueArgs a, MoveArgs m, MoveL
             const int grp = tid >> 3, jj = tid & 7, D = a.D;
 #pragma unroll 2
             for (int pass = 0; pass < 8; ++pass) {
-                const int q = pass * 32 + grp, sq = base + q;
+                const int q = pass * (kThreads / 8) + grp, sq = base + q;
                 const bool go = s_tt[q] >= 0;
                 if (!__any(go)) continue;
                 const double *f0 = a.tfeat, *f1 = a.tfeat, *f2 = a.tfeat, *sa = a.sfeat_vm, *cw = nullptr;
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(256) void k_ho_move(CliqueArgs a, MoveArgs m, MoveL
                 if (go) {
                     qk = fast_div(sq, nslots, inv), qj = sq - qk * nslots;
                     const int sv = a.bin_idx[s0 + qj];
-                    f0 = a.tfeat + (size_t)s_tt[256 + 3 * q] * D, f1 = a.tfeat + (size_t)s_tt[256 + 3 * q + 1] * D, f2 = a.tfeat + (size_t)s_tt[256 + 3 * q + 2] * D;
+                    f0 = a.tfeat + (size_t)s_tt[kThreads + 3 * q] * D, f1 = a.tfeat + (size_t)s_tt[kThreads + 3 * q + 1] * D, f2 = a.tfeat + (size_t)s_tt[kThreads + 3 * q + 2] * D;
                     sa = a.sfeat_vm + (size_t)sv * D;
                     cw = a.cfw_vm ? a.cfw_vm + (size_t)sv * a.cfw_rows : nullptr;
                 }
@@ -317,7 +317,7 @@ __global__ __launch_bounds__(256) void k_ho_move(CliqueArgs a, MoveArgs m, MoveL
     // (search_device.hpp: group8_find); what even that cannot decide (no candidate in the leaf: sibling leaves, nearest vertex)
     // is left to the tail kernel, which the host launches only when told to
     const int npend = s_npend;
-    for (int q0 = 0; q0 < npend; q0 += 32) {  // workgroup-uniform
+    for (int q0 = 0; q0 < npend; q0 += kThreads / 8) {  // workgroup-uniform
         const int q = q0 + (tid >> 3);
         const bool valid = q < npend;
         int kk = 0, j = 0, el = 0;
@@ -436,16 +436,27 @@ static MoveLabels g_no_labels;  // handed over (and never read) when the labelin
 int launch_move(msm_ctx *ctx, const CliqueArgs &a, const MoveArgs &m, const MoveLabels *labels, hipEvent_t ev_start, hipEvent_t ev_stop) {
     if (a.T <= 0 || m.nblk <= 0) return MSM_OK;
     const int mode = move_mode(a);
-    const dim3 grid((unsigned)(8 * ((m.nblk + 7) / 8))), block(256);
-    const size_t lds = sizeof(double) * (64 * 9 + 8 * (size_t)m.cap + (mode == 2 ? 3 * 256 : 0)) + sizeof(int) * (128 + 8 * (size_t)m.cap + (mode == 2 ? 4 * 256 : 0));
+    // 256 threads and two rounds of samples per workgroup.  Measured alternatives (D = 1 / D = 32 kernel time against 32 / 95 us):
+    // 512 threads, all samples of the 8 triangles in flight at once (MSMHIP_MOVE_THREADS=512) 37 / 102; 4 triangles and one round per
+    // workgroup 34.5 / 91, 2 triangles 46 / 107; the records of a wavefront's 64 first candidates fetched as a team through LDS
+    // (neighbouring lanes reading neighbouring 16-byte pieces) 33 / 142.
+    static const int threads = [] { const char *e = std::getenv("MSMHIP_MOVE_THREADS"); return e && std::atoi(e) == 512 ? 512 : 256; }();
+    const dim3 grid((unsigned)(8 * ((m.nblk + 7) / 8))), block(threads);
+    const size_t lds = sizeof(double) * (64 * 9 + 8 * (size_t)m.cap + (mode == 2 ? 3 * threads : 0)) + sizeof(int) * (128 + 8 * (size_t)m.cap + (mode == 2 ? 4 * threads : 0));
     if (lds > 64 * 1024) return fail(MSM_ERR_CAPACITY, "fusion move: %d bin slots per workgroup do not fit LDS", m.cap);
     const MoveLabels &lab = labels ? *labels : g_no_labels;
     if (ev_start) MSM_HIP(hipEventRecord(ev_start, ctx->stream));
 #define MSM_MOVE_LAUNCH(PACKED)                                                                                     \
     do {                                                                                                            \
-        if (mode == 0) hipLaunchKernelGGL((k_ho_move<PACKED, 0>), grid, block, lds, ctx->stream, a, m, lab);          \
-        else if (mode == 1) hipLaunchKernelGGL((k_ho_move<PACKED, 1>), grid, block, lds, ctx->stream, a, m, lab);     \
-        else hipLaunchKernelGGL((k_ho_move<PACKED, 2>), grid, block, lds, ctx->stream, a, m, lab);                    \
+        if (threads == 512) {                                                                                       \
+            if (mode == 0) hipLaunchKernelGGL((k_ho_move<PACKED, 0, 512>), grid, block, lds, ctx->stream, a, m, lab);     \
+            else if (mode == 1) hipLaunchKernelGGL((k_ho_move<PACKED, 1, 512>), grid, block, lds, ctx->stream, a, m, lab); \
+            else hipLaunchKernelGGL((k_ho_move<PACKED, 2, 512>), grid, block, lds, ctx->stream, a, m, lab);                \
+        } else {                                                                                                    \
+            if (mode == 0) hipLaunchKernelGGL((k_ho_move<PACKED, 0, 256>), grid, block, lds, ctx->stream, a, m, lab);     \
+            else if (mode == 1) hipLaunchKernelGGL((k_ho_move<PACKED, 1, 256>), grid, block, lds, ctx->stream, a, m, lab); \
+            else hipLaunchKernelGGL((k_ho_move<PACKED, 2, 256>), grid, block, lds, ctx->stream, a, m, lab);                \
+        }                                                                                                           \
     } while (0)
     if (labels) MSM_MOVE_LAUNCH(true);
     else MSM_MOVE_LAUNCH(false);
