@@ -175,12 +175,27 @@ int ensure_tree_pair(msm_mesh *a, msm_mesh *b) {
     return built ? upload_tree(host) : ensure_tree(host);
 }
 
+int ensure_tree_begin(msm_mesh *m) {
+    if (m->tree_valid || m->oct_job || !tree_on_gpu(m)) return MSM_OK;
+    return gpu_build_octree_begin(m);
+}
+
 static int ensure_tree_overlapped(msm_mesh *m, const std::function<void()> *overlap) {
     if (m->tree_valid) return MSM_OK;
     if (tree_on_gpu(m)) {
-        const int st = gpu_build_octree(m, overlap);
+        int st;
+        if (m->oct_job) {  // begun by ensure_tree_begin
+            if (overlap && *overlap) (*overlap)();
+            st = gpu_build_octree_finish(m);
+        } else {
+            st = gpu_build_octree(m, overlap);
+        }
         if (st == MSM_OK) return finish_tree(m);
         if (st != MSM_ERR_CAPACITY) return st;  // a tree that outgrew the preallocated arrays (a degenerate mesh): the host build below
+    }
+    if (m->host_xyz_stale) {
+        MSM_HIP(hipMemcpy(m->xyz.data(), m->d_xyz, sizeof(double) * 3 * (size_t)m->V, hipMemcpyDeviceToHost));
+        m->host_xyz_stale = false;
     }
     build_octree(m->xyz.data(), m->tri.data(), m->V, m->T, m->tree);
     return upload_tree(m);
@@ -504,10 +519,14 @@ ResampleScratch &resample_scratch(msm_ctx *ctx) {
 }  // namespace
 
 int adaptive_weights_dev(msm_mesh *in_mesh, msm_mesh *new_mesh, AdaptiveDev &out, bool check) {
-    if (in_mesh->ctx != new_mesh->ctx) return fail(MSM_ERR_INVALID, "adaptive weights: the two meshes belong to different contexts");
+    // Everything is queued on in_mesh's context.  new_mesh may belong to another context of the same GPU (a lane of the gMSM
+    // set-up against the group's template) if its tree and adjacency are complete and synchronised: they are only read.
+    const bool foreign = in_mesh->ctx != new_mesh->ctx;
+    if (foreign && (in_mesh->ctx->device != new_mesh->ctx->device || !new_mesh->tree_valid || !new_mesh->d_tid_ptr))
+        return fail(MSM_ERR_INVALID, "adaptive weights: the two meshes belong to different contexts");
     msm_ctx *ctx = in_mesh->ctx;
     const int nOld = in_mesh->V, nNew = new_mesh->V;
-    int st = ensure_tree_pair(in_mesh, new_mesh);
+    int st = foreign ? ensure_tree(in_mesh) : ensure_tree_pair(in_mesh, new_mesh);
     if (st) return st;
     if ((st = ensure_adjacency_dev(in_mesh)) || (st = ensure_adjacency_dev(new_mesh))) return st;
     ResampleScratch &s = resample_scratch(ctx);

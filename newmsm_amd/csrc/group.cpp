@@ -65,6 +65,13 @@ struct msm_group {
     DevBuf<const int *> d_pptrp, d_pidxp;
     DevBuf<int> d_query[4];   // index columns of a batch of evaluations (kept between calls)
     DevBuf<double> d_answer;
+    // the lanes of the set-up: contexts with streams of their own and a scratch copy of the data mesh each, so that the per-label
+    // pipelines of a subject (some eighty small kernels in a dependent chain each) run side by side
+    struct Lane {
+        msm_ctx *ctx = nullptr;
+        msm_mesh *mesh = nullptr;
+    };
+    std::vector<Lane> lanes;
     DevBuf<double> d_move_out;           // msm_group_fusion_move: the step's 4 P + 8 T results before they go to the host
     std::vector<int32_t> pair_order;     // the pair list in processing order (control points along a space-filling curve)
     DevBuf<int> d_pair_order;            // ... restricted to the slice [order_p0, order_p1) last asked for
@@ -307,6 +314,11 @@ void msm_group_destroy(msm_group *g) {
     (void)hipStreamSynchronize(g->ctx->stream);
     for (msm_mesh *m : g->cpmesh) msm_mesh_destroy(m);
     for (msm_mesh *m : g->scratch) msm_mesh_destroy(m);
+    for (auto &lane : g->lanes) {
+        if (lane.ctx) (void)hipStreamSynchronize(lane.ctx->stream);
+        msm_mesh_destroy(lane.mesh);
+        msm_ctx_destroy(lane.ctx);
+    }
     delete g;
 }
 
@@ -511,6 +523,40 @@ int group_common_setup(msm_group *g) {
     return MSM_OK;
 }
 
+// the lanes, each with a scratch mesh of dm's topology (kept from subject to subject while the topology stays the same)
+int ensure_lanes(msm_group *g, const msm_mesh *dm) {
+    static const int want = [] {
+        const char *e = std::getenv("MSMHIP_GROUP_LANES");
+        const int v = e ? std::atoi(e) : 6;  // 14.1 ms per ico6 subject with one lane, 8.2 with two, 7.8 with four, 6.0-6.4 with six to eight
+        return v < 1 ? 1 : (v > 8 ? 8 : v);
+    }();
+    if ((int)g->lanes.size() != want) {
+        for (auto &lane : g->lanes) {
+            msm_mesh_destroy(lane.mesh);
+            msm_ctx_destroy(lane.ctx);
+        }
+        g->lanes.assign(want, msm_group::Lane{});
+    }
+    for (auto &lane : g->lanes) {
+        if (!lane.ctx) {
+            lane.ctx = msm_ctx_create(g->ctx->device);
+            if (!lane.ctx) return MSM_ERR_HIP;
+        }
+        if (lane.mesh && (lane.mesh->V != dm->V || lane.mesh->T != dm->T || lane.mesh->tri != dm->tri)) {
+            MSM_HIP(hipStreamSynchronize(lane.ctx->stream));
+            msm_mesh_destroy(lane.mesh);
+            lane.mesh = nullptr;
+        }
+        if (!lane.mesh) {
+            lane.mesh = msm_mesh_create(lane.ctx, dm->xyz.data(), dm->V, dm->tri.data(), dm->T);
+            if (!lane.mesh) return MSM_ERR_HIP;
+            int st = ensure_adjacency_dev(lane.mesh);
+            if (st) return st;
+        }
+    }
+    return MSM_OK;
+}
+
 // get_patch_data for one subject, M/DiscreteGroupModel.cpp:88-121
 // DiscreteGroupModel::get_patch_data for one subject (M/DiscreteGroupModel.cpp:88-121).  Per label: rotate the data
 // mesh, build its octree, resample the features to the template with adaptive barycentric weights.  The rotations
@@ -556,19 +602,73 @@ int group_subject_setup(msm_group *g, int s) {
         if (st) return st;
         st = subject_feature_slab(g, s, (size_t)D * Vt);
         if (st) return st;
-        lap("rotations + feature upload");
-        for (int l = 0; l < L; ++l) {
-            for (int a = 0; a < 3; ++a)
-                MSM_HIP(hipMemcpyAsync(sm->d_xyz + (size_t)a * V, d_rot.p + a * LV + (size_t)l * V, sizeof(double) * (size_t)V, hipMemcpyDeviceToDevice, ctx->stream));
-            sm->tree_valid = false;  // rebuilt by adaptive_weights_dev
-            AdaptiveDev w;
-            st = adaptive_weights_dev(sm, g->tmpl, w, false);
-            if (st) return st;
-            st = apply_weights_dev(ctx, w, g->d_subject_feat.p, D, g->F[(size_t)s * L + l]->p);
-            if (st) return st;
-        }
-        st = check_status(ctx, "get_patch_data (resampling)");
+        // the template's search structure and adjacency are read by every lane: complete before they start
+        st = ensure_tree(g->tmpl);
         if (st) return st;
+        st = ensure_adjacency_dev(g->tmpl);
+        if (st) return st;
+        st = ensure_lanes(g, dm);
+        if (st) return st;
+        MSM_HIP(hipStreamSynchronize(ctx->stream));  // rotations and features are where the lanes will read them
+        lap("rotations + feature upload");
+        // Per label: the rotated coordinates become a lane mesh's, its tree is built, then queries, surgery and the weighted sums.
+        // One such pipeline is a dependent chain of some eighty kernels of a few microseconds each; the lanes run K of them side
+        // by side.  The host queues the first half of K labels (up to where the tree build's outcome is looked at), then the second
+        // half of each, so that it never waits for work it has only just submitted.
+        // Submitting eighty launches per label is itself 0.4 ms of host time, so the lanes are driven by (two) host threads, each
+        // with its share of the lanes and every other label.
+        const int K = (int)g->lanes.size();
+        static const int want_threads = [] {
+            const char *e = std::getenv("MSMHIP_GROUP_THREADS");
+            const int v = e ? std::atoi(e) : 2;
+            return v < 1 ? 1 : (v > 4 ? 4 : v);
+        }();
+        const int nthreads = std::max(1, std::min(want_threads, K));
+        std::vector<int> status(nthreads, MSM_OK);
+        std::vector<std::string> message(nthreads);
+        auto drive = [&](int th) {
+            int st = MSM_OK;
+            (void)hipSetDevice(ctx->device);
+            const int k0 = th * K / nthreads, k1 = (th + 1) * K / nthreads, Kt = k1 - k0;
+            std::vector<int> mine;
+            for (int l = th; l < L; l += nthreads) mine.push_back(l);
+            for (size_t i0 = 0; i0 < mine.size() && !st; i0 += Kt) {
+                for (int k = 0; k < Kt && i0 + k < mine.size() && !st; ++k) {
+                    const int l = mine[i0 + k];
+                    msm_group::Lane &lane = g->lanes[k0 + k];
+                    for (int a = 0; a < 3 && !st; ++a)
+                        if (hipMemcpyAsync(lane.mesh->d_xyz + (size_t)a * V, d_rot.p + a * LV + (size_t)l * V, sizeof(double) * (size_t)V, hipMemcpyDeviceToDevice,
+                                           lane.ctx->stream) != hipSuccess)
+                            st = fail(MSM_ERR_HIP, "get_patch_data: device copy of the rotated coordinates failed");
+                    lane.mesh->tree_valid = false;
+                    lane.mesh->host_xyz_stale = true;
+                    if (!st) st = ensure_tree_begin(lane.mesh);
+                }
+                for (int k = 0; k < Kt && i0 + k < mine.size() && !st; ++k) {
+                    const int l = mine[i0 + k];
+                    msm_group::Lane &lane = g->lanes[k0 + k];
+                    AdaptiveDev w;
+                    st = adaptive_weights_dev(lane.mesh, g->tmpl, w, false);
+                    if (!st) st = apply_weights_dev(lane.ctx, w, g->d_subject_feat.p, D, g->F[(size_t)s * L + l]->p);
+                }
+            }
+            for (int k = k0; k < k1; ++k) {
+                const int st2 = check_status(g->lanes[k].ctx, "get_patch_data (resampling)");  // synchronises the lane
+                if (!st) st = st2;
+            }
+            status[th] = st;
+            if (st) message[th] = msm_last_error();  // the error text is per thread
+        };
+        if (nthreads == 1) {
+            drive(0);
+        } else {
+            std::vector<std::thread> pool;
+            for (int th = 1; th < nthreads; ++th) pool.emplace_back(drive, th);
+            drive(0);
+            for (auto &t : pool) t.join();
+        }
+        for (int th = 0; th < nthreads; ++th)
+            if (status[th]) return fail(status[th], "%s", message[th].c_str());
         lap("trees + queries + weights + resample (device)");
         st = subject_patches(g, s);
         if (st) return st;

@@ -158,6 +158,8 @@ struct msm_mesh {
     std::vector<int32_t> tri;  // 3 x T SoA
     std::vector<double> feat;  // D x V host copy
     bool tree_valid = false;
+    bool host_xyz_stale = false;    // the coordinates were last written on the device only (group.cpp): fetched before any host-side use
+    std::shared_ptr<void> oct_job;  // a GPU build that has been queued but not looked at yet (octree_kernels.hip)
     msm::FlatOctree tree;
     // device
     double *d_xyz = nullptr;   // 3 x V SoA
@@ -217,7 +219,10 @@ void adaptive_surgery(const AdaptiveQueries &q, int nOld, int nNew, const std::v
 void vertex_areas_of(const double *xyz, const int32_t *tri, int V, int T, const Adjacency &a, std::vector<double> &area);
 int install_coords_and_tree(msm_mesh *m, const double *xyz, FlatOctree &&tree);
 int ensure_tree(msm_mesh *m);  // build + upload the search structure if stale
-int gpu_build_octree(msm_mesh *m, const std::function<void()> *overlap = nullptr);  // octree_kernels.hip: the same tree built in HBM from the mesh's device coordinates (MSM_ERR_CAPACITY: use the host build)
+int gpu_build_octree(msm_mesh *m, const std::function<void()> *overlap = nullptr);
+int gpu_build_octree_begin(msm_mesh *m);   // the same in two halves: queue the build ... 
+int gpu_build_octree_finish(msm_mesh *m);  // ... wait for it (one build at a time per context)
+int ensure_tree_begin(msm_mesh *m);        // api.cpp: starts the GPU build of an invalid tree (no-op otherwise); ensure_tree() completes it  // octree_kernels.hip: the same tree built in HBM from the mesh's device coordinates (MSM_ERR_CAPACITY: use the host build)
 int finish_tree(msm_mesh *m);       // what follows either build: validity flags, generation
 int ensure_masks(msm_mesh *m);  // + the per-leaf sub-cell masks the cost kernels use (built on the GPU)
 int ensure_rays(msm_mesh *m, bool wait = false);   // + the ray table of a simple surface (unary table kernels); see api.cpp

@@ -420,7 +420,36 @@ __global__ __launch_bounds__(256) void k_oct_grid(const int4 *__restrict__ node,
 
 // Builds the search tree of m's current device coordinates into m's device arrays.  Returns MSM_OK, or MSM_ERR_CAPACITY when
 // the tree outgrows the preallocated arrays (degenerate meshes: the caller falls back to the host build).
-int gpu_build_octree(msm_mesh *m, const std::function<void()> *overlap) {
+namespace {
+struct OctJob {  // a build between gpu_build_octree_begin and _finish
+    OctWork w;
+    int cur = 0, depth = 0;
+};
+constexpr int kMaxLevels = 24, kFirstBatch = 8, kNextBatch = 4;
+// Levels are queued in batches without looking at the outcome in between: a level with nothing open costs six empty launches, a
+// look costs a round trip.  Ico-derived meshes finish at depth 6 or 7, i.e. within the first batch.
+int queue_levels(msm_ctx *ctx, OctJob &j, int count) {
+    const int upto = std::min(kMaxLevels, j.depth + count);
+    for (; j.depth < upto; ++j.depth) {
+        hipLaunchKernelGGL(k_oct_begin_level, dim3(1), dim3(1), 0, ctx->stream, j.w.counters);
+        hipLaunchKernelGGL(k_oct_decide, dim3(512), dim3(256), 0, ctx->stream, j.w, j.cur);
+        hipLaunchKernelGGL(k_oct_count, dim3(1024), dim3(256), 0, ctx->stream, j.w, j.cur);
+        hipLaunchKernelGGL(k_oct_chunk_scan, dim3(256), dim3(256), 0, ctx->stream, j.w, j.cur);
+        hipLaunchKernelGGL(k_oct_scan, dim3(1), dim3(1024), 0, ctx->stream, j.w, j.cur, j.depth);
+        hipLaunchKernelGGL(k_oct_fill, dim3(1024), dim3(256), 0, ctx->stream, j.w, j.cur);
+        j.cur ^= 1;
+    }
+    MSM_HIP(hipGetLastError());
+    MSM_HIP(hipMemcpyAsync(ctx->oct_hcounters, j.w.counters, sizeof(int) * C_COUNT, hipMemcpyDeviceToHost, ctx->stream));
+    return MSM_OK;
+}
+}  // namespace
+
+// The build in two halves, so that a caller with several streams (group.cpp: the lanes of the gMSM set-up) can queue the levels of
+// one mesh and go on with another before looking at the outcome.  begin: everything up to and including the first batch of
+// levels, nothing waited for; finish: waits, queues more levels for deeper trees, then the grid, records and cones.  One build at a
+// time per context (the scratch arrays and the counters' landing place belong to the context).
+int gpu_build_octree_begin(msm_mesh *m) {
     msm_ctx *ctx = m->ctx;
     const int T = m->T, V = m->V;
     const int cap_nodes = T + 64, cap_refs = 6 * T + 256, cap_arena = 8 * T + 512, cap_open = cap_nodes, cap_chunks = cap_refs / kChunk + cap_open + 64;
@@ -489,31 +518,29 @@ int gpu_build_octree(msm_mesh *m, const std::function<void()> *overlap) {
     const int root_chunks = (T + kChunk - 1) / kChunk;
     hipLaunchKernelGGL(k_oct_boxes, dim3((T + 255) / 256), dim3(256), 0, ctx->stream, m->d_xyz, V, m->d_tri, T, s.box, w.list[0]);
     hipLaunchKernelGGL(k_oct_init, dim3((std::max(root_chunks, C_COUNT + 1) + 255) / 256), dim3(256), 0, ctx->stream, w, T, root_chunks);
-    // Levels are queued in batches without looking at the outcome in between: a level with nothing open costs five empty
-    // launches, a look costs a round trip.  Ico-derived meshes finish at depth 6 or 7, i.e. within the first batch.
-    constexpr int kMaxLevels = 24, kFirstBatch = 8, kNextBatch = 4;
-    int cur = 0, depth = 0;
-    bool done = false;
-    while (!done && depth < kMaxLevels) {
-        const int upto = std::min(kMaxLevels, depth + (depth == 0 ? kFirstBatch : kNextBatch));
-        for (; depth < upto; ++depth) {
-            hipLaunchKernelGGL(k_oct_begin_level, dim3(1), dim3(1), 0, ctx->stream, s.counters);
-            hipLaunchKernelGGL(k_oct_decide, dim3(512), dim3(256), 0, ctx->stream, w, cur);
-            hipLaunchKernelGGL(k_oct_count, dim3(1024), dim3(256), 0, ctx->stream, w, cur);
-            hipLaunchKernelGGL(k_oct_chunk_scan, dim3(256), dim3(256), 0, ctx->stream, w, cur);
-            hipLaunchKernelGGL(k_oct_scan, dim3(1), dim3(1024), 0, ctx->stream, w, cur, depth);
-            hipLaunchKernelGGL(k_oct_fill, dim3(1024), dim3(256), 0, ctx->stream, w, cur);
-            cur ^= 1;
-        }
-        MSM_HIP(hipGetLastError());
-        MSM_HIP(hipMemcpyAsync(s.h_counters, s.counters, sizeof(int) * C_COUNT, hipMemcpyDeviceToHost, ctx->stream));
-        if (overlap && *overlap) {  // host work of the caller that does not depend on this tree, while the GPU builds it
-            (*overlap)();
-            overlap = nullptr;
-        }
+    auto job = std::make_shared<OctJob>();
+    job->w = w;
+    m->oct_job = job;
+    return queue_levels(ctx, *job, kFirstBatch);
+}
+
+int gpu_build_octree_finish(msm_mesh *m) {
+    msm_ctx *ctx = m->ctx;
+    if (!m->oct_job) return fail(MSM_ERR_STATE, "octree build: nothing was begun");
+    const std::shared_ptr<void> keep = m->oct_job;
+    OctJob &job = *static_cast<OctJob *>(keep.get());
+    m->oct_job.reset();
+    const int T = m->T, V = m->V;
+    MSM_HIP(hipSetDevice(ctx->device));
+    MSM_HIP(hipStreamSynchronize(ctx->stream));
+    while (ctx->oct_hcounters[C_NOPEN] != 0 && !ctx->oct_hcounters[C_OVERFLOW] && job.depth < kMaxLevels) {
+        int st = queue_levels(ctx, job, kNextBatch);
+        if (st) return st;
         MSM_HIP(hipStreamSynchronize(ctx->stream));
-        done = s.h_counters[C_NOPEN] == 0;
     }
+    struct {
+        int *h_counters;
+    } s{ctx->oct_hcounters};
     const int *hc = s.h_counters;
     if (hc[C_OVERFLOW] || hc[C_NOPEN] != 0) return MSM_ERR_CAPACITY;
     FlatOctree &o = m->tree;
@@ -528,6 +555,13 @@ int gpu_build_octree(msm_mesh *m, const std::function<void()> *overlap) {
     hipLaunchKernelGGL(k_oct_grid, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, ctx->stream, m->d_node, o.grid_depth, m->d_grid);
     MSM_HIP(hipGetLastError());
     return launch_build_recs(ctx, m->d_xyz, V, m->d_tri, T, m->d_rec, m->d_tcone, m->d_leaf_tri, o.dev_entries, m->d_cone);
+}
+
+int gpu_build_octree(msm_mesh *m, const std::function<void()> *overlap) {
+    int st = gpu_build_octree_begin(m);
+    if (st) return st;
+    if (overlap && *overlap) (*overlap)();  // host work of the caller that does not depend on this tree, while the GPU builds it
+    return gpu_build_octree_finish(m);
 }
 
 }  // namespace msm
