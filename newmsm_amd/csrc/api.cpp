@@ -139,7 +139,7 @@ bool mesh_tree_on_gpu(const msm_mesh *m) {
         const char *e = std::getenv("MSMHIP_OCTREE");
         return !e ? 0 : (std::strcmp(e, "host") == 0 ? 1 : (std::strcmp(e, "gpu") == 0 ? 2 : 0));
     }();
-    return mode == 2 || (mode == 0 && m->T >= 8192);
+    return mode == 2 || (mode != 1 && m->gpu_tree_always) || (mode == 0 && m->T >= 8192);
 }
 
 int upload_staged(msm_ctx *ctx, void *dst, const void *src, size_t bytes) {

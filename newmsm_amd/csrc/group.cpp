@@ -550,6 +550,7 @@ int ensure_lanes(msm_group *g, const msm_mesh *dm) {
         if (!lane.mesh) {
             lane.mesh = msm_mesh_create(lane.ctx, dm->xyz.data(), dm->V, dm->tri.data(), dm->T);
             if (!lane.mesh) return MSM_ERR_HIP;
+            lane.mesh->gpu_tree_always = true;
             int st = ensure_adjacency_dev(lane.mesh);
             if (st) return st;
         }
@@ -585,7 +586,8 @@ int group_subject_setup(msm_group *g, int s) {
     const size_t LV = (size_t)L * V;
     DevBuf<double> &d_rot = g->d_rotated;
     static const bool host_surgery = [] { const char *e = std::getenv("MSMHIP_SURGERY"); return e && std::strcmp(e, "host") == 0; }();
-    if (mesh_tree_on_gpu(sm) && !host_surgery) {
+    static const bool host_trees = [] { const char *e = std::getenv("MSMHIP_OCTREE"); return e && std::strcmp(e, "host") == 0; }();
+    if (!host_trees && !host_surgery) {
         // Everything in HBM (data meshes large enough for the GPU octree build): per label the rotated coordinates become the
         // scratch mesh's, its tree is rebuilt there, and queries, weight-list surgery (resample_kernels.hip) and the weighted sums
         // write F[s][l] directly.  Only the subject's features go up; nothing comes back.

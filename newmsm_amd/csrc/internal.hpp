@@ -158,6 +158,7 @@ struct msm_mesh {
     std::vector<int32_t> tri;  // 3 x T SoA
     std::vector<double> feat;  // D x V host copy
     bool tree_valid = false;
+    bool gpu_tree_always = false;   // build the tree on the GPU whatever the size (the lane meshes of the gMSM set-up: the host never sees their coordinates)
     bool host_xyz_stale = false;    // the coordinates were last written on the device only (group.cpp): fetched before any host-side use
     std::shared_ptr<void> oct_job;  // a GPU build that has been queued but not looked at yet (octree_kernels.hip)
     msm::FlatOctree tree;
