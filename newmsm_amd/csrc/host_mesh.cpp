@@ -93,31 +93,52 @@ void icosphere_unit(int order, std::vector<double> &xyz, std::vector<int32_t> &t
 }
 
 // Mesh::push_triangle applied to every triangle in order, R/mesh.cpp:115-134
+// Mesh::initialize's neighbour and triangle lists (R/mesh.cpp: push_triangle): per vertex the triangles in ascending id, and the
+// neighbours in first-seen order -- vertex n[0] of a triangle meets n[1] then n[2], n[1] meets n[0] then n[2], n[2] meets n[0] then
+// n[1].  Flat arrays only (a counting sort for the triangles, then one walk over each vertex's triangles for the neighbours): the
+// first version kept two std::vectors per vertex and took 2-3 ms at ico6, which every fresh mesh of a registration level paid.
 void build_adjacency(const int32_t *tri, int V, int T, Adjacency &adj) {
-    std::vector<std::vector<int32_t>> nb(V), tr(V);
-    for (int t = 0; t < T; ++t) {
-        const int32_t n[3] = {tri[t], tri[T + t], tri[2 * T + t]};
-        for (int k = 0; k < 3; ++k) tr[n[k]].push_back(t);
-        static const int ord[6][2] = {{0, 1}, {0, 2}, {1, 0}, {1, 2}, {2, 0}, {2, 1}};
-        for (auto &q : ord) {
-            auto &list = nb[n[q[0]]];
-            if (std::find(list.begin(), list.end(), n[q[1]]) == list.end()) list.push_back(n[q[1]]);
+    adj.tid_ptr.assign((size_t)V + 1, 0);
+    for (int k = 0; k < 3; ++k)
+        for (int t = 0; t < T; ++t) adj.tid_ptr[(size_t)tri[(size_t)k * T + t] + 1]++;
+    for (int v = 0; v < V; ++v) adj.tid_ptr[v + 1] += adj.tid_ptr[v];
+    adj.tid.resize((size_t)adj.tid_ptr[V]);
+    std::vector<int32_t> fill(adj.tid_ptr.begin(), adj.tid_ptr.end() - 1);
+    for (int t = 0; t < T; ++t)
+        for (int k = 0; k < 3; ++k) {
+            const int32_t v = tri[(size_t)k * T + t];
+            // a vertex listed twice in one (degenerate) triangle is listed twice here too, as push_back did
+            adj.tid[(size_t)fill[v]++] = t;
         }
-    }
-    adj.nbr_ptr.assign(V + 1, 0);
-    adj.tid_ptr.assign(V + 1, 0);
+    // neighbours: at most two new ones per incident triangle
+    adj.nbr_ptr.assign((size_t)V + 1, 0);
+    std::vector<int32_t> scratch(2 * adj.tid.size());
+    std::vector<int32_t> count(V, 0);
     for (int v = 0; v < V; ++v) {
-        adj.nbr_ptr[v + 1] = adj.nbr_ptr[v] + (int32_t)nb[v].size();
-        adj.tid_ptr[v + 1] = adj.tid_ptr[v] + (int32_t)tr[v].size();
+        int32_t *list = scratch.data() + 2 * (size_t)adj.tid_ptr[v];
+        int n = 0;
+        int32_t last_t = -1;
+        for (int j = adj.tid_ptr[v]; j < adj.tid_ptr[v + 1]; ++j) {
+            const int32_t t = adj.tid[j];
+            if (t == last_t) continue;  // degenerate triangle: handled once, for each position below
+            last_t = t;
+            const int32_t nn[3] = {tri[t], tri[(size_t)T + t], tri[2 * (size_t)T + t]};
+            for (int k = 0; k < 3; ++k) {
+                if (nn[k] != v) continue;
+                for (int q = 0; q < 3; ++q) {
+                    if (q == k) continue;
+                    const int32_t o = nn[q];
+                    bool seen = false;
+                    for (int i = 0; i < n && !seen; ++i) seen = list[i] == o;
+                    if (!seen) list[n++] = o;
+                }
+            }
+        }
+        count[v] = n;
+        adj.nbr_ptr[v + 1] = adj.nbr_ptr[v] + n;
     }
-    adj.nbr.clear();
-    adj.tid.clear();
-    adj.nbr.reserve(adj.nbr_ptr[V]);
-    adj.tid.reserve(adj.tid_ptr[V]);
-    for (int v = 0; v < V; ++v) {
-        adj.nbr.insert(adj.nbr.end(), nb[v].begin(), nb[v].end());
-        adj.tid.insert(adj.tid.end(), tr[v].begin(), tr[v].end());
-    }
+    adj.nbr.resize((size_t)adj.nbr_ptr[V]);
+    for (int v = 0; v < V; ++v) std::copy_n(scratch.data() + 2 * (size_t)adj.tid_ptr[v], count[v], adj.nbr.begin() + adj.nbr_ptr[v]);
 }
 
 static inline V3 pt(const double *xyz, int V, int i) { return mk(xyz[i], xyz[V + i], xyz[2 * V + i]); }

@@ -131,3 +131,33 @@ def test_mcmc_optimise_properties(built):
     assert list(lab) == [best >> 2 & 1, best >> 1 & 1, best & 1]
     with pytest.raises(M.MsmError):
         M.mcmc_optimise(U, tc, tr, np.full(30, 7, np.int32))
+
+
+def test_adjacency_flat_build_matches_the_literal_lists_on_irregular_and_degenerate_input():
+    """msm_mesh_adjacency (flat counting-sort build) against Mesh::initialize's literal push_back logic: shuffled triangle order and
+    triangles that list a vertex twice or three times (the literal code then records the triangle, and the vertex as its own
+    neighbour, as often as it is listed)."""
+    def literal(tri, V):
+        nb, tr = [[] for _ in range(V)], [[] for _ in range(V)]
+        for t, n in enumerate(tri):
+            for k in range(3):
+                tr[n[k]].append(t)
+            for a, b in ((0, 1), (0, 2), (1, 0), (1, 2), (2, 0), (2, 1)):
+                if n[b] not in nb[n[a]]:
+                    nb[n[a]].append(n[b])
+        return nb, tr
+
+    rng = np.random.default_rng(1)
+    for order in (1, 2, 3):
+        xyz, tri = M.make_mesh_from_icosa(order)
+        V = len(xyz)
+        extra = rng.integers(0, V, (5, 3))
+        extra[0, 1] = extra[0, 0]
+        extra[1, 2] = extra[1, 0]
+        extra[2, :] = extra[2, 0]
+        tri2 = np.vstack([tri[rng.permutation(len(tri))], extra]).astype(np.int32)
+        nbr_ptr, nbr, tid_ptr, tid = M.mesh_adjacency(tri2, V)
+        nb, tr = literal(tri2, V)
+        for v in range(V):
+            assert list(nbr[nbr_ptr[v]:nbr_ptr[v + 1]]) == nb[v]
+            assert list(tid[tid_ptr[v]:tid_ptr[v + 1]]) == tr[v]
