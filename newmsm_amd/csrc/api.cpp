@@ -72,10 +72,10 @@ static int upload_tree(msm_mesh *m) {
     MSM_HIP(hipSetDevice(ctx->device));
     auto grow = [&](void **p, size_t &cap, size_t need, size_t elem) -> hipError_t {
         if (need <= cap && *p) return hipSuccess;
-        if (*p) (void)hipFree(*p);
+        if (*p) (void)msm::pool_free(*p);
         *p = nullptr;
         cap = need + need / 4 + 16;
-        return hipMalloc(p, cap * elem);
+        return msm::pool_malloc(p, cap * elem);
     };
     MSM_HIP(grow((void **)&m->d_node, m->cap_node, m->tree.node.size(), sizeof(int4)));
     MSM_HIP(grow((void **)&m->d_parent, m->cap_parent, m->tree.node.size(), sizeof(int32_t)));
@@ -218,10 +218,10 @@ int ensure_masks(msm_mesh *m) {
     if (m->masks_valid) return MSM_OK;
     const size_t need = (size_t)std::max(m->tree.nmask_blocks, 1) * 64;
     if (need > m->cap_mask || !m->d_mask) {
-        if (m->d_mask) (void)hipFree(m->d_mask);
+        if (m->d_mask) (void)msm::pool_free(m->d_mask);
         m->d_mask = nullptr;
         m->cap_mask = need + need / 4;
-        MSM_HIP(hipMalloc((void **)&m->d_mask, m->cap_mask * sizeof(unsigned long long)));
+        MSM_HIP(msm::pool_malloc((void **)&m->d_mask, m->cap_mask * sizeof(unsigned long long)));
     }
     st = launch_build_masks(m->ctx, dev_tree(m), m->d_nodebox, m->d_mask);
     if (st) return st;
@@ -315,10 +315,10 @@ int ensure_rays(msm_mesh *m, bool wait) {
     if (m->tree.ray_G > 0) {
         auto grow = [&](void **p, size_t &cap, size_t need, size_t elem) -> hipError_t {
             if (need <= cap && *p) return hipSuccess;
-            if (*p) (void)hipFree(*p);
+            if (*p) (void)msm::pool_free(*p);
             *p = nullptr;
             cap = need + need / 4 + 16;
-            return hipMalloc(p, cap * elem);
+            return msm::pool_malloc(p, cap * elem);
         };
         MSM_HIP(grow((void **)&m->d_ray_cell, m->cap_ray_cell, m->tree.ray_cell.size(), sizeof(int4)));
         MSM_HIP(grow((void **)&m->d_ray_edge, m->cap_ray_edge, m->tree.ray_edge.size(), sizeof(float4)));
@@ -341,10 +341,10 @@ int ensure_rays(msm_mesh *m, bool wait) {
 static int ensure_rayrec(msm_mesh *m) {
     if (m->tree.ray_G <= 0 || m->rayrec_valid) return MSM_OK;
     if ((size_t)m->T > m->cap_ray_rec || !m->d_ray_tri) {
-        if (m->d_ray_tri) (void)hipFree(m->d_ray_tri);
+        if (m->d_ray_tri) (void)msm::pool_free(m->d_ray_tri);
         m->d_ray_tri = nullptr;
         m->cap_ray_rec = (size_t)m->T + m->T / 4 + 16;
-        MSM_HIP(hipMalloc((void **)&m->d_ray_tri, m->cap_ray_rec * kRayPieces * sizeof(float4)));
+        MSM_HIP(msm::pool_malloc((void **)&m->d_ray_tri, m->cap_ray_rec * kRayPieces * sizeof(float4)));
     }
     int st = launch_build_raytri(m->ctx, m->d_rec, m->d_ray_edge, m->T, m->D >= 1 ? m->d_feat : nullptr, m->D, m->d_ray_tri);
     if (st) return st;
@@ -385,10 +385,10 @@ const Adjacency &mesh_adjacency(msm_mesh *m) {
 // get_barycentric_weights on the device for host-resident query points
 static hipError_t ctx_scratch(msm_ctx *ctx, int slot, size_t bytes, void **out) {
     if (bytes > ctx->q_cap[slot] || !ctx->q_buf[slot]) {
-        if (ctx->q_buf[slot]) (void)hipFree(ctx->q_buf[slot]);
+        if (ctx->q_buf[slot]) (void)msm::pool_free(ctx->q_buf[slot]);
         ctx->q_buf[slot] = nullptr;
         ctx->q_cap[slot] = bytes + bytes / 4 + 256;
-        hipError_t e = hipMalloc(&ctx->q_buf[slot], ctx->q_cap[slot]);
+        hipError_t e = msm::pool_malloc(&ctx->q_buf[slot], ctx->q_cap[slot]);
         if (e != hipSuccess) {
             ctx->q_cap[slot] = 0;
             return e;
@@ -498,9 +498,9 @@ int ensure_adjacency_dev(msm_mesh *m) {
     if (m->d_tid_ptr) return MSM_OK;
     msm_ctx *ctx = m->ctx;
     const Adjacency &adj = mesh_adjacency(m);
-    MSM_HIP(hipMalloc((void **)&m->d_tid_ptr, sizeof(int32_t) * adj.tid_ptr.size()));
-    MSM_HIP(hipMalloc((void **)&m->d_tid, sizeof(int32_t) * std::max<size_t>(adj.tid.size(), 1)));
-    MSM_HIP(hipMalloc((void **)&m->d_fold, sizeof(int32_t) * (2 + (size_t)m->V)));
+    MSM_HIP(msm::pool_malloc((void **)&m->d_tid_ptr, sizeof(int32_t) * adj.tid_ptr.size()));
+    MSM_HIP(msm::pool_malloc((void **)&m->d_tid, sizeof(int32_t) * std::max<size_t>(adj.tid.size(), 1)));
+    MSM_HIP(msm::pool_malloc((void **)&m->d_fold, sizeof(int32_t) * (2 + (size_t)m->V)));
     MSM_HIP(hipMemcpyAsync(m->d_tid_ptr, adj.tid_ptr.data(), sizeof(int32_t) * adj.tid_ptr.size(), hipMemcpyHostToDevice, ctx->stream));
     if (!adj.tid.empty()) MSM_HIP(hipMemcpyAsync(m->d_tid, adj.tid.data(), sizeof(int32_t) * adj.tid.size(), hipMemcpyHostToDevice, ctx->stream));
     MSM_HIP(hipStreamSynchronize(ctx->stream));
@@ -703,6 +703,8 @@ void adaptive_surgery(const AdaptiveQueries &q, int nOld, int nNew, const std::v
 extern "C" {
 
 // ------------------------------------------------------------------ context
+static std::atomic<int> g_live_contexts{0};  // the memory pool is emptied when the last one goes
+
 static msm_ctx *ctx_make(int device, hipStream_t stream, bool own) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
@@ -726,7 +728,8 @@ static msm_ctx *ctx_make(int device, hipStream_t stream, bool own) {
         fail(MSM_ERR_HIP, "hipStreamCreate failed");
         return nullptr;
     }
-    if (hipMalloc((void **)&ctx->d_status, sizeof(int)) != hipSuccess || hipHostMalloc((void **)&ctx->h_status, sizeof(int)) != hipSuccess ||
+    g_live_contexts.fetch_add(1);
+    if (msm::pool_malloc((void **)&ctx->d_status, sizeof(int)) != hipSuccess || hipHostMalloc((void **)&ctx->h_status, sizeof(int)) != hipSuccess ||
         hipMemsetAsync(ctx->d_status, 0, sizeof(int), ctx->stream) != hipSuccess) {
         fail(MSM_ERR_HIP, "context allocation failed");
         msm_ctx_destroy(ctx);
@@ -743,19 +746,20 @@ void msm_ctx_destroy(msm_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (void *b : ctx->q_buf)
-        if (b) (void)hipFree(b);
+        if (b) (void)msm::pool_free(b);
     if (ctx->stage) (void)hipHostFree(ctx->stage);
     if (ctx->io_pin) (void)hipHostFree(ctx->io_pin);
     if (ctx->h_flag) (void)hipHostFree(ctx->h_flag);
-    if (ctx->oct_box) (void)hipFree(ctx->oct_box);
-    if (ctx->oct_ints) (void)hipFree(ctx->oct_ints);
-    if (ctx->oct_counters) (void)hipFree(ctx->oct_counters);
+    if (ctx->oct_box) (void)msm::pool_free(ctx->oct_box);
+    if (ctx->oct_ints) (void)msm::pool_free(ctx->oct_ints);
+    if (ctx->oct_counters) (void)msm::pool_free(ctx->oct_counters);
     if (ctx->oct_hcounters) (void)hipHostFree(ctx->oct_hcounters);
     for (auto &b : ctx->host_blocks) (void)(b.registered ? hipHostUnregister(b.host) : hipHostFree(b.host));
-    if (ctx->d_status) (void)hipFree(ctx->d_status);
+    if (ctx->d_status) (void)msm::pool_free(ctx->d_status);
     if (ctx->h_status) (void)hipHostFree(ctx->h_status);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
+    if (g_live_contexts.fetch_sub(1) == 1) msm::pool_trim();
 }
 
 int msm_ctx_synchronize(msm_ctx *ctx) {
@@ -833,11 +837,11 @@ msm_mesh *msm_mesh_create(msm_ctx *ctx, const double *xyz, int32_t V, const int3
     m->xyz.assign(xyz, xyz + 3 * (size_t)V);
     m->tri.assign(tri, tri + 3 * (size_t)T);
     (void)hipSetDevice(ctx->device);
-    if (hipMalloc((void **)&m->d_xyz, sizeof(double) * 3 * (size_t)V) != hipSuccess ||
+    if (msm::pool_malloc((void **)&m->d_xyz, sizeof(double) * 3 * (size_t)V) != hipSuccess ||
         hipMemcpyAsync(m->d_xyz, m->xyz.data(), sizeof(double) * 3 * (size_t)V, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
-        hipMalloc((void **)&m->d_tri, sizeof(int32_t) * 3 * (size_t)T) != hipSuccess ||
+        msm::pool_malloc((void **)&m->d_tri, sizeof(int32_t) * 3 * (size_t)T) != hipSuccess ||
         hipMemcpyAsync(m->d_tri, m->tri.data(), sizeof(int32_t) * 3 * (size_t)T, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
-        hipMalloc((void **)&m->d_tcone, sizeof(float4) * (size_t)T) != hipSuccess) {
+        msm::pool_malloc((void **)&m->d_tcone, sizeof(float4) * (size_t)T) != hipSuccess) {
         fail(MSM_ERR_HIP, "msm_mesh_create: device allocation failed");
         msm_mesh_destroy(m);
         return nullptr;
@@ -850,7 +854,7 @@ void msm_mesh_destroy(msm_mesh *m) {
     (void)hipSetDevice(m->ctx->device);
     (void)hipStreamSynchronize(m->ctx->stream);
     for (void *p : {(void *)m->d_xyz, (void *)m->d_tri, (void *)m->d_tcone, (void *)m->d_feat, (void *)m->d_node, (void *)m->d_parent, (void *)m->d_leaf_tri, (void *)m->d_cone, (void *)m->d_rec, (void *)m->d_grid, (void *)m->d_nodebox, (void *)m->d_mask, (void *)m->d_ray_cell, (void *)m->d_ray_edge, (void *)m->d_ray_tri, (void *)m->d_ray_more, (void *)m->d_ray_excl, (void *)m->d_tid_ptr, (void *)m->d_tid, (void *)m->d_fold})
-        if (p) (void)hipFree(p);
+        if (p) (void)msm::pool_free(p);
     delete m;
 }
 
@@ -889,10 +893,10 @@ int msm_mesh_set_features(msm_mesh *m, const double *feat, int32_t D) {
     for (int d = 0; d < D; ++d)
         for (int v = 0; v < V; ++v) vm[(size_t)v * D + d] = feat[(size_t)d * V + v];
     if (m->d_feat && m->D != D) {
-        (void)hipFree(m->d_feat);
+        (void)msm::pool_free(m->d_feat);
         m->d_feat = nullptr;
     }
-    if (!m->d_feat) MSM_HIP(hipMalloc((void **)&m->d_feat, sizeof(double) * (size_t)D * V));
+    if (!m->d_feat) MSM_HIP(msm::pool_malloc((void **)&m->d_feat, sizeof(double) * (size_t)D * V));
     m->D = D;
     m->rayrec_valid = false;
     MSM_HIP(hipMemcpyAsync(m->d_feat, vm.data(), sizeof(double) * (size_t)D * V, hipMemcpyHostToDevice, m->ctx->stream));

@@ -9,6 +9,10 @@
 
 namespace msm {
 
+// pool.cpp
+hipError_t pool_malloc(void **p, size_t bytes);
+hipError_t pool_free(void *p);
+
 template <typename T>
 struct DevBuf {
     T *p = nullptr;
@@ -21,7 +25,7 @@ struct DevBuf {
     ~DevBuf() { release(); }
 
     void release() {
-        if (p && owned) (void)hipFree(p);  // hipFree waits for work that may still use the buffer
+        if (p && owned) (void)msm::pool_free(p);  // waits, like hipFree, for work that may still use the buffer
         p = nullptr;
         cap = 0;
         owned = true;
@@ -37,7 +41,7 @@ struct DevBuf {
         if (n <= cap && p) return hipSuccess;
         release();
         cap = n + n / 4 + 16;
-        hipError_t e = hipMalloc((void **)&p, cap * sizeof(T));
+        hipError_t e = msm::pool_malloc((void **)&p, cap * sizeof(T));
         if (e != hipSuccess) {
             p = nullptr;
             cap = 0;

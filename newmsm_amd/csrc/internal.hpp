@@ -19,6 +19,11 @@ namespace msm {
 // ---------------------------------------------------------------- errors
 void set_error(const char *fmt, ...);
 int fail(int code, const char *fmt, ...);
+// pool.cpp: device memory of the handles (size-classed free lists over hipMalloc / hipFree)
+hipError_t pool_malloc(void **p, size_t bytes);
+hipError_t pool_free(void *p);
+void pool_trim();
+size_t pool_idle_bytes();
 
 #define MSM_HIP(call)                                                                                 \
     do {                                                                                              \

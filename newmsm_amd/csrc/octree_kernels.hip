@@ -455,20 +455,20 @@ int gpu_build_octree_begin(msm_mesh *m) {
     const int cap_nodes = T + 64, cap_refs = 6 * T + 256, cap_arena = 8 * T + 512, cap_open = cap_nodes, cap_chunks = cap_refs / kChunk + cap_open + 64;
     MSM_HIP(hipSetDevice(ctx->device));
     if ((size_t)6 * T > ctx->oct_cap_box) {
-        if (ctx->oct_box) (void)hipFree(ctx->oct_box);
+        if (ctx->oct_box) (void)msm::pool_free(ctx->oct_box);
         ctx->oct_box = nullptr;
         ctx->oct_cap_box = (size_t)6 * T + 1024;
-        MSM_HIP(hipMalloc((void **)&ctx->oct_box, ctx->oct_cap_box * sizeof(double)));
+        MSM_HIP(msm::pool_malloc((void **)&ctx->oct_box, ctx->oct_cap_box * sizeof(double)));
     }
     const size_t need_ints = (size_t)2 * cap_refs + (size_t)8 * cap_open + (size_t)cap_open + (size_t)8 * cap_open + (size_t)4 * cap_chunks + (size_t)8 * cap_chunks + 16;
     if (need_ints > ctx->oct_cap_ints) {
-        if (ctx->oct_ints) (void)hipFree(ctx->oct_ints);
+        if (ctx->oct_ints) (void)msm::pool_free(ctx->oct_ints);
         ctx->oct_ints = nullptr;
         ctx->oct_cap_ints = need_ints + 4096;
-        MSM_HIP(hipMalloc((void **)&ctx->oct_ints, ctx->oct_cap_ints * sizeof(int)));
+        MSM_HIP(msm::pool_malloc((void **)&ctx->oct_ints, ctx->oct_cap_ints * sizeof(int)));
     }
     if (!ctx->oct_counters) {
-        MSM_HIP(hipMalloc((void **)&ctx->oct_counters, sizeof(int) * (C_COUNT + 1)));
+        MSM_HIP(msm::pool_malloc((void **)&ctx->oct_counters, sizeof(int) * (C_COUNT + 1)));
         MSM_HIP(hipHostMalloc((void **)&ctx->oct_hcounters, sizeof(int) * (C_COUNT + 1)));
     }
     struct {
@@ -477,10 +477,10 @@ int gpu_build_octree_begin(msm_mesh *m) {
     } s{ctx->oct_box, ctx->oct_ints, ctx->oct_counters, ctx->oct_hcounters};
     auto grow = [&](void **p, size_t &cap, size_t need, size_t elem) -> hipError_t {
         if (need <= cap && *p) return hipSuccess;
-        if (*p) (void)hipFree(*p);
+        if (*p) (void)msm::pool_free(*p);
         *p = nullptr;
         cap = need;
-        return hipMalloc(p, cap * elem);
+        return msm::pool_malloc(p, cap * elem);
     };
     MSM_HIP(grow((void **)&m->d_node, m->cap_node, cap_nodes, sizeof(int4)));
     MSM_HIP(grow((void **)&m->d_parent, m->cap_parent, cap_nodes, sizeof(int32_t)));

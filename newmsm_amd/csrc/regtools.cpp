@@ -78,9 +78,9 @@ int msm_mesh_unfold(msm_mesh *m, double radius, int32_t *passes, int32_t *first_
     const int V = m->V, T = m->T;
     const Adjacency &adj = mesh_adjacency(m);
     if (!m->d_tid_ptr) {
-        MSM_HIP(hipMalloc((void **)&m->d_tid_ptr, sizeof(int32_t) * adj.tid_ptr.size()));
-        MSM_HIP(hipMalloc((void **)&m->d_tid, sizeof(int32_t) * std::max<size_t>(adj.tid.size(), 1)));
-        MSM_HIP(hipMalloc((void **)&m->d_fold, sizeof(int32_t) * (2 + (size_t)V)));
+        MSM_HIP(msm::pool_malloc((void **)&m->d_tid_ptr, sizeof(int32_t) * adj.tid_ptr.size()));
+        MSM_HIP(msm::pool_malloc((void **)&m->d_tid, sizeof(int32_t) * std::max<size_t>(adj.tid.size(), 1)));
+        MSM_HIP(msm::pool_malloc((void **)&m->d_fold, sizeof(int32_t) * (2 + (size_t)V)));
         MSM_HIP(hipMemcpyAsync(m->d_tid_ptr, adj.tid_ptr.data(), sizeof(int32_t) * adj.tid_ptr.size(), hipMemcpyHostToDevice, ctx->stream));
         if (!adj.tid.empty()) MSM_HIP(hipMemcpyAsync(m->d_tid, adj.tid.data(), sizeof(int32_t) * adj.tid.size(), hipMemcpyHostToDevice, ctx->stream));
     }
