@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MSM_ABI_VERSION 4
+#define MSM_ABI_VERSION 5
 
 #define MSM_OK 0
 #define MSM_ERR_INVALID (-1)  /* bad argument / inconsistent sizes */
@@ -333,6 +333,8 @@ int msm_group_export_subject_dev(msm_group *g, int32_t subject, double *F_dev, i
 int msm_group_import_subject_dev(msm_group *g, int32_t subject, const double *F_dev, const int32_t *pptr_dev, const int32_t *pidx_dev, int64_t npidx);
 int msm_group_finalize(msm_group *g);
 int msm_group_sizes(msm_group *g, int32_t *nodes, int32_t *pairs, int32_t *triplets);
+/* S subjects, N control points each, L labels, D feature rows, V(template): the sizes of the exchange buffers above (any pointer may be NULL) */
+int msm_group_dims(msm_group *g, int32_t *S, int32_t *N, int32_t *L, int32_t *D, int32_t *Vt);
 int msm_group_get_pairs(msm_group *g, int32_t *pairs /* P x 2 */);
 int msm_group_get_triplets(msm_group *g, int32_t *triplets /* T x 3 */);
 /* one patch (subject, control point, label): ascending template vertex ids and their D values (cap entries); *n = size */

@@ -129,6 +129,7 @@ SIGNATURES = {
     "msm_group_fusion_move_dev": (C.c_int, [_VP, c_ip, C.c_int32, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _VP, _VP]),
     "msm_group_finalize": (C.c_int, [_VP]),
     "msm_group_sizes": (C.c_int, [_VP, c_ip, c_ip, c_ip]),
+    "msm_group_dims": (C.c_int, [_VP, c_ip, c_ip, c_ip, c_ip, c_ip]),
     "msm_group_get_pairs": (C.c_int, [_VP, c_ip]),
     "msm_group_get_triplets": (C.c_int, [_VP, c_ip]),
     "msm_group_patch": (C.c_int, [_VP, C.c_int32, C.c_int32, C.c_int32, c_ip, c_dp, C.c_int32, c_ip]),

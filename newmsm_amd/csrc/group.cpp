@@ -966,6 +966,16 @@ int msm_group_sizes(msm_group *g, int32_t *nodes, int32_t *pairs, int32_t *tripl
     return MSM_OK;
 }
 
+int msm_group_dims(msm_group *g, int32_t *S, int32_t *N, int32_t *L, int32_t *D, int32_t *Vt) {
+    if (!g) return fail(MSM_ERR_INVALID, "null group");
+    if (S) *S = g->S;
+    if (N) *N = g->N;
+    if (L) *L = g->L;
+    if (D) *D = g->D;
+    if (Vt) *Vt = g->tmpl ? g->tmpl->V : 0;
+    return MSM_OK;
+}
+
 int msm_group_get_pairs(msm_group *g, int32_t *pairs) {
     if (!g || !pairs) return fail(MSM_ERR_INVALID, "msm_group_get_pairs: null argument");
     if (!g->ready) return fail(MSM_ERR_STATE, "msm_group: msm_group_setup() must be called first");
