@@ -9,6 +9,7 @@
 #include <atomic>
 #include <chrono>
 #include <cstring>
+#include <functional>
 #include <cstdio>
 #include <cstdlib>
 #include <cmath>
@@ -76,6 +77,9 @@ struct msm_group {
     std::vector<int32_t> pair_order;     // the pair list in processing order (control points along a space-filling curve)
     DevBuf<int> d_pair_order;            // ... restricted to the slice [order_p0, order_p1) last asked for
     int64_t order_p0 = -1, order_p1 = -1;
+    std::vector<int64_t> order_chunk;    // the slice's order is cut into pieces by OUTPUT range: piece k holds the pairs [order_chunk[k], order_chunk[k+1]) of the slice
+    hipStream_t copy_stream = nullptr;   // the finished pieces of a label step leave for the host while the next ones are computed
+    std::vector<hipEvent_t> copy_events;
     // scratch of subject_patches, kept between subjects
     DevBuf<double> d_centres, d_sep;
     DevBuf<double> d_rotated;  // the L rotated data meshes of the subject being set up
@@ -319,6 +323,11 @@ void msm_group_destroy(msm_group *g) {
         msm_mesh_destroy(lane.mesh);
         msm_ctx_destroy(lane.ctx);
     }
+    if (g->copy_stream) {
+        (void)hipStreamSynchronize(g->copy_stream);
+        (void)hipStreamDestroy(g->copy_stream);
+    }
+    for (hipEvent_t e : g->copy_events) (void)hipEventDestroy(e);
     delete g;
 }
 
@@ -1043,20 +1052,31 @@ int msm_group_pairwise_batch(msm_group *g, const int32_t *pair, const int32_t *l
     return MSM_OK;
 }
 
-// the slice [pair0, pair1) of the pair list in processing order, on the device
+// the slice [pair0, pair1) of the pair list in processing order, on the device.  The order is cut into pieces by output range
+// (a quarter of the slice each, for slices worth overlapping): within a piece the pairs run control point by control point, and a
+// piece's results are one contiguous range of the output, which can leave for the host while the next piece is computed.
 static int slice_pair_order(msm_group *g, int64_t pair0, int64_t pair1, const int **d_order) {
     if (g->order_p0 != pair0 || g->order_p1 != pair1) {
         msm_ctx *ctx = g->ctx;
         MSM_HIP(hipStreamSynchronize(ctx->stream));
-        if (pair0 == 0 && pair1 == (int64_t)g->pair_order.size()) {
-            MSM_HIP(g->d_pair_order.upload_vec(g->pair_order, ctx->stream));
-        } else {
-            std::vector<int32_t> part;
-            part.reserve((size_t)(pair1 - pair0));
-            for (int32_t p : g->pair_order)
-                if (p >= pair0 && p < pair1) part.push_back(p);
-            MSM_HIP(g->d_pair_order.ensure(std::max<size_t>(part.size(), 1)));
-            if (!part.empty()) MSM_HIP(hipMemcpyAsync(g->d_pair_order.p, part.data(), sizeof(int32_t) * part.size(), hipMemcpyHostToDevice, ctx->stream));
+        const int64_t n = pair1 - pair0;
+        const int pieces = n >= (1 << 18) ? 4 : 1;
+        g->order_chunk.assign(pieces + 1, 0);
+        for (int k = 0; k <= pieces; ++k) g->order_chunk[k] = n * k / pieces;
+        std::vector<std::vector<int32_t>> part(pieces);
+        for (auto &v : part) v.reserve((size_t)(n / pieces + 1));
+        for (int32_t p : g->pair_order) {
+            if (p < pair0 || p >= pair1) continue;
+            int k = (int)((int64_t)(p - pair0) * pieces / std::max<int64_t>(n, 1));
+            while (k + 1 < pieces && p - pair0 >= g->order_chunk[k + 1]) ++k;
+            while (k > 0 && p - pair0 < g->order_chunk[k]) --k;
+            part[k].push_back(p);
+        }
+        MSM_HIP(g->d_pair_order.ensure(std::max<size_t>((size_t)n, 1)));
+        size_t at = 0;
+        for (auto &v : part) {
+            if (!v.empty()) MSM_HIP(hipMemcpyAsync(g->d_pair_order.p + at, v.data(), sizeof(int32_t) * v.size(), hipMemcpyHostToDevice, ctx->stream));
+            at += v.size();
         }
         MSM_HIP(hipStreamSynchronize(ctx->stream));
         g->order_p0 = pair0, g->order_p1 = pair1;
@@ -1066,8 +1086,9 @@ static int slice_pair_order(msm_group *g, int64_t pair0, int64_t pair1, const in
 }
 
 // the evaluations of a (slice of a) label step, queued on the stream; results in device memory
+// after_piece(k, lo, hi): the kernels of piece k (pairs [pair0 + lo, pair0 + hi) of the output) have been queued; k = -1: the triplets
 static int group_move_compute(msm_group *g, const int32_t *labeling, int32_t label, int64_t pair0, int64_t pair1, int64_t trip0, int64_t trip1,
-                              double *quads_dev, double *octets_dev, const char *who) {
+                              double *quads_dev, double *octets_dev, const char *who, const std::function<int(int, int64_t, int64_t)> *after_piece = nullptr) {
     GroupArgs a;
     int st = group_args(g, a);
     if (st) return st;
@@ -1089,13 +1110,19 @@ static int group_move_compute(msm_group *g, const int32_t *labeling, int32_t lab
         st = slice_pair_order(g, pair0, pair1, &a.move_order);
         if (st) return st;
         a.move_base = (int)pair0;
-        const int64_t total = 4 * (pair1 - pair0);
-        for (int64_t off = 0; off < total; off += kBatchChunk) {
-            const int m = (int)std::min<int64_t>(kBatchChunk, total - off);
-            if (off > 0x7fffffffll - kBatchChunk) return fail(MSM_ERR_CAPACITY, "%s: evaluation index beyond 2^31", who);
-            a.move_offset = (int)off;
-            st = launch_group_pairwise(ctx, a, nullptr, nullptr, nullptr, m, quads_dev);
-            if (st) return st;
+        for (size_t k = 0; k + 1 < g->order_chunk.size(); ++k) {
+            const int64_t q0 = 4 * g->order_chunk[k], q1 = 4 * g->order_chunk[k + 1];
+            for (int64_t off = q0; off < q1; off += kBatchChunk) {
+                const int m = (int)std::min<int64_t>(kBatchChunk, q1 - off);
+                if (off > 0x7fffffffll - kBatchChunk) return fail(MSM_ERR_CAPACITY, "%s: evaluation index beyond 2^31", who);
+                a.move_offset = (int)off;
+                st = launch_group_pairwise(ctx, a, nullptr, nullptr, nullptr, m, quads_dev);
+                if (st) return st;
+            }
+            if (after_piece) {
+                st = (*after_piece)((int)k, g->order_chunk[k], g->order_chunk[k + 1]);
+                if (st) return st;
+            }
         }
     }
     a.move_order = nullptr;
@@ -1107,6 +1134,27 @@ static int group_move_compute(msm_group *g, const int32_t *labeling, int32_t lab
         st = launch_group_triplet(ctx, a, nullptr, nullptr, nullptr, nullptr, m, octets_dev + off);
         if (st) return st;
     }
+    if (after_piece && total > 0) return (*after_piece)(-1, 0, 0);
+    return MSM_OK;
+}
+
+// the copy stream and its events (one per piece + one for the triplets)
+static int ensure_copy_stream(msm_group *g) {
+    if (!g->copy_stream) MSM_HIP(hipStreamCreateWithFlags(&g->copy_stream, hipStreamNonBlocking));
+    while (g->copy_events.size() < 8) {
+        hipEvent_t e;
+        MSM_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        g->copy_events.push_back(e);
+    }
+    return MSM_OK;
+}
+// finished results leave for pinned host memory on the copy stream while the compute stream goes on
+static int copy_behind(msm_group *g, int slot, double *host_dst, const double *dev_src, size_t n) {
+    msm_ctx *ctx = g->ctx;
+    hipEvent_t e = g->copy_events[(size_t)slot % g->copy_events.size()];
+    MSM_HIP(hipEventRecord(e, ctx->stream));
+    MSM_HIP(hipStreamWaitEvent(g->copy_stream, e, 0));
+    MSM_HIP(hipMemcpyAsync(host_dst, dev_src, sizeof(double) * n, hipMemcpyDeviceToHost, g->copy_stream));
     return MSM_OK;
 }
 
@@ -1117,7 +1165,26 @@ int msm_group_fusion_move(msm_group *g, const int32_t *labeling, int32_t label, 
     const int64_t P = (int64_t)(g->pairs.size() / 2), T = (int64_t)g->S * g->Tc;
     MSM_HIP(g->d_move_out.ensure((size_t)(4 * P + 8 * T) + 2));
     double *dq = g->d_move_out.p, *dt = dq + ((4 * P + 1) & ~1ll);  // both 16-byte aligned
-    int st = group_move_compute(g, labeling, label, 0, pair_quads ? P : 0, 0, triplet_octets ? T : 0, dq, dt, "msm_group_fusion_move");
+    int st;
+    const bool pinned_q = !pair_quads || P == 0 || ctx_mapped(ctx, pair_quads, sizeof(double) * 4 * (size_t)P);
+    const bool pinned_t = !triplet_octets || T == 0 || ctx_mapped(ctx, triplet_octets, sizeof(double) * 8 * (size_t)T);
+    if (pinned_q && pinned_t) {
+        // Both arrays lie in msm_host_alloc / msm_host_register blocks: the results of each quarter of the pair list (and of the
+        // triplets) are copied out by the DMA engine while the kernels of the next quarter run -- 186 MB at S = 64, 3.7 ms that
+        // used to follow the kernels.
+        st = ensure_copy_stream(g);
+        if (st) return st;
+        const std::function<int(int, int64_t, int64_t)> deliver = [&](int k, int64_t lo, int64_t hi) -> int {
+            if (k < 0) return triplet_octets ? copy_behind(g, 7, triplet_octets, dt, 8 * (size_t)T) : MSM_OK;
+            return copy_behind(g, k, pair_quads + 4 * lo, dq + 4 * lo, 4 * (size_t)(hi - lo));
+        };
+        st = group_move_compute(g, labeling, label, 0, pair_quads ? P : 0, 0, triplet_octets ? T : 0, dq, dt, "msm_group_fusion_move", &deliver);
+        if (st) return st;
+        st = check_status(ctx, "DiscreteGroupCostFunction (fusion move)");
+        MSM_HIP(hipStreamSynchronize(g->copy_stream));
+        return st;
+    }
+    st = group_move_compute(g, labeling, label, 0, pair_quads ? P : 0, 0, triplet_octets ? T : 0, dq, dt, "msm_group_fusion_move");
     if (st) return st;
     // delivery: arrays inside a msm_host_alloc / msm_host_register block are written by a copy kernel (full-width stores over
     // PCIe, no staging); others go through the pinned staging buffer in chunks
@@ -1172,10 +1239,22 @@ int msm_group_fusion_move_dev(msm_group *g, const int32_t *labeling, int32_t lab
         if (host_q) cq = g->d_move_out.p;
         if (host_t) ct = g->d_move_out.p + ((nq + 1) & ~(size_t)1);
     }
-    int st = group_move_compute(g, labeling, label, pair0, pair1, trip0, trip1, cq, ct, "msm_group_fusion_move_dev");
+    int st;
+    if (host_q || host_t) {  // pieces leave for the host behind the kernels (see msm_group_fusion_move)
+        st = ensure_copy_stream(g);
+        if (st) return st;
+        const std::function<int(int, int64_t, int64_t)> deliver = [&](int k, int64_t lo, int64_t hi) -> int {
+            if (k < 0) return host_t ? copy_behind(g, 7, octets_dev, ct, nt) : MSM_OK;
+            return host_q ? copy_behind(g, k, quads_dev + 4 * lo, cq + 4 * lo, 4 * (size_t)(hi - lo)) : MSM_OK;
+        };
+        st = group_move_compute(g, labeling, label, pair0, pair1, trip0, trip1, cq, ct, "msm_group_fusion_move_dev", &deliver);
+        if (st) return st;
+        st = check_status(ctx, "DiscreteGroupCostFunction (fusion move)");
+        MSM_HIP(hipStreamSynchronize(g->copy_stream));
+        return st;
+    }
+    st = group_move_compute(g, labeling, label, pair0, pair1, trip0, trip1, cq, ct, "msm_group_fusion_move_dev");
     if (st) return st;
-    if (host_q) MSM_HIP(hipMemcpyAsync(quads_dev, cq, sizeof(double) * nq, hipMemcpyDeviceToHost, ctx->stream));
-    if (host_t) MSM_HIP(hipMemcpyAsync(octets_dev, ct, sizeof(double) * nt, hipMemcpyDeviceToHost, ctx->stream));
     return check_status(ctx, "DiscreteGroupCostFunction (fusion move)");  // synchronises: the buffers may go into a collective on another stream
 }
 
