@@ -26,6 +26,40 @@ __device__ __forceinline__ double lanes_sum(double v) {
     return v;
 }
 
+// Sums of N values over the 32 lanes of a half wavefront at once.  The plain butterfly costs five exchanges per value; here the
+// first three steps also halve the number of values a lane carries (at the xor-16 step the lower lanes go on with the even values
+// and hand the odd ones over, and so on), so N values cost ceil(N/2) + ceil(N/4) + ceil(N/8) + 2 exchanges plus N broadcasts -- 13
+// instead of 25 for the five sums of a two-row correlation.  Every sum pairs the same lanes in the same order as the butterfly
+// (16, 8, 4, 2, 1), so the results are the butterfly's bit for bit.  All 64 lanes call it; `lane` is the lane within the half.
+template <int N>
+__device__ __forceinline__ void half_sums(double (&v)[N], int lane) {
+    static_assert(N >= 1 && N <= 8, "at most eight values");
+    constexpr int N1 = (N + 1) / 2, N2 = (N1 + 1) / 2, N3 = (N2 + 1) / 2;
+    static_assert(N3 == 1, "three halving steps");
+    double w[N1], x[N2], y;
+    const bool u16 = lane & 16, u8 = lane & 8, u4 = lane & 4;
+#pragma unroll
+    for (int j = 0; j < N1; ++j) {
+        const double e = v[2 * j], o = 2 * j + 1 < N ? v[2 * j + 1] : 0.0;
+        w[j] = (u16 ? o : e) + __shfl_xor(u16 ? e : o, 16, 64);
+    }
+#pragma unroll
+    for (int j = 0; j < N2; ++j) {
+        const double e = w[2 * j], o = 2 * j + 1 < N1 ? w[2 * j + 1] : 0.0;
+        x[j] = (u8 ? o : e) + __shfl_xor(u8 ? e : o, 8, 64);
+    }
+    {
+        const double e = x[0], o = N2 > 1 ? x[N2 - 1] : 0.0;
+        y = (u4 ? o : e) + __shfl_xor(u4 ? e : o, 4, 64);
+    }
+    y += __shfl_xor(y, 2, 64);
+    y += __shfl_xor(y, 1, 64);
+    // value k ended up in the lanes whose bits 16 / 8 / 4 are bits 0 / 1 / 2 of k
+    const int half = (threadIdx.x & 63) & 32;
+#pragma unroll
+    for (int k = 0; k < N; ++k) v[k] = __shfl(y, half | ((k & 1) << 4) | (((k >> 1) & 1) << 3) | (((k >> 2) & 1) << 2), 64);
+}
+
 constexpr int kGroupStage = 256;  // ids of patch B staged in LDS per wavefront
 
 }  // namespace
@@ -126,7 +160,14 @@ __global__ __launch_bounds__(256) void k_group_pairwise(GroupArgs a, const int *
                 mem[r] = id[r] >= 0 && lo < cntB && fb[lo] == id[r];
                 common += mem[r] ? 1 : 0;
             }
-            const int ncommon = (int)lanes_sum<kLanes>((double)common);
+            // size of the intersection: the set bits of the rounds' ballots within this half wavefront
+            int ncommon = 0;
+            {
+                const unsigned long long halfmask = 0xffffffffull << ((threadIdx.x & 63) & 32);
+#pragma unroll
+                for (int r = 0; r < kRounds; ++r) ncommon += __popcll(__ballot(mem[r]) & halfmask);
+            }
+            (void)common;
             double cost = 0.0;
             if (ncommon == 0) {
                 cost = nan;
@@ -145,57 +186,68 @@ __global__ __launch_bounds__(256) void k_group_pairwise(GroupArgs a, const int *
                     }
                     if (mem[r] && a.mask) w[r] = fabs(a.mask[id[r]]);
                 }
+                const bool two = a.D == 2;
+                if (a.simmeasure == 2) {  // sparsesimkernel::corr, M/similarities.cpp:129-158, both feature rows side by side
+                    double s1[5] = {0.0, 0.0, 0.0, 0.0, 0.0};  // sum of weights, then weighted sums of A and B per row
 #pragma unroll
-                for (int d = 0; d < 2; ++d) {
-                    if (d >= a.D) break;
-                    double c;
-                    if (a.simmeasure == 2) {  // sparsesimkernel::corr, M/similarities.cpp:129-158
-                        double sw = 0, ma = 0, mb = 0;
+                    for (int r = 0; r < kRounds; ++r)
+                        if (mem[r]) {
+                            s1[0] += w[r];
 #pragma unroll
-                        for (int r = 0; r < kRounds; ++r)
-                            if (mem[r]) {
-                                sw += w[r];
-                                ma += w[r] * va[r][d];
-                                mb += w[r] * vb[r][d];
+                            for (int d = 0; d < 2; ++d) {
+                                s1[1 + 2 * d] += w[r] * va[r][d];
+                                s1[2 + 2 * d] += w[r] * vb[r][d];
                             }
-                        sw = lanes_sum<kLanes>(sw);
-                        ma = lanes_sum<kLanes>(ma);
-                        mb = lanes_sum<kLanes>(mb);
-                        if (sw > 0.0) {
-                            ma /= sw;
-                            mb /= sw;
                         }
-                        double pr = 0, sa2 = 0, sb2 = 0;
+                    half_sums<5>(s1, lane);
+                    const double sw = s1[0];
+                    double ma[2] = {s1[1], s1[3]}, mb[2] = {s1[2], s1[4]};
+                    if (sw > 0.0) {
 #pragma unroll
-                        for (int r = 0; r < kRounds; ++r)
-                            if (mem[r]) {
-                                const double da = va[r][d] - ma, db = vb[r][d] - mb;
-                                pr += w[r] * da * db;
-                                sa2 += w[r] * da * da;
-                                sb2 += w[r] * db * db;
+                        for (int d = 0; d < 2; ++d) {
+                            ma[d] /= sw;
+                            mb[d] /= sw;
+                        }
+                    }
+                    double s2[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};  // per row: products, variance of A, variance of B
+#pragma unroll
+                    for (int r = 0; r < kRounds; ++r)
+                        if (mem[r]) {
+#pragma unroll
+                            for (int d = 0; d < 2; ++d) {
+                                const double da = va[r][d] - ma[d], db = vb[r][d] - mb[d];
+                                s2[3 * d] += w[r] * da * db;
+                                s2[3 * d + 1] += w[r] * da * da;
+                                s2[3 * d + 2] += w[r] * db * db;
                             }
-                        pr = lanes_sum<kLanes>(pr);
-                        sa2 = lanes_sum<kLanes>(sa2);
-                        sb2 = lanes_sum<kLanes>(sb2);
+                        }
+                    half_sums<6>(s2, lane);
+#pragma unroll
+                    for (int d = 0; d < 2; ++d) {
+                        if (d == 1 && !two) break;
+                        double pr = s2[3 * d], sa2 = s2[3 * d + 1], sb2 = s2[3 * d + 2];
                         if (sw > 0.0) {
                             pr /= sw;
                             sa2 /= sw;
                             sb2 /= sw;
                         }
                         const double rr = (sa2 == 0.0 || sb2 == 0.0) ? 0.0 : pr / (sqrt(sa2) * sqrt(sb2));
-                        c = 1 - (1 + rr) * 0.5;
-                    } else {  // sparsesimkernel::SSD, :179-188
-                        double pr = 0;
-#pragma unroll
-                        for (int r = 0; r < kRounds; ++r)
-                            if (mem[r]) {
-                                const double df = va[r][d] - vb[r][d];
-                                pr += w[r] * df * df;
-                            }
-                        pr = lanes_sum<kLanes>(pr);
-                        c = sqrt(pr) / ncommon;
+                        cost += 1 - (1 + rr) * 0.5;
                     }
-                    cost += c;
+                } else {  // sparsesimkernel::SSD, :179-188
+                    double s1[2] = {0.0, 0.0};
+#pragma unroll
+                    for (int r = 0; r < kRounds; ++r)
+                        if (mem[r]) {
+#pragma unroll
+                            for (int d = 0; d < 2; ++d) {
+                                const double df = va[r][d] - vb[r][d];
+                                s1[d] += w[r] * df * df;
+                            }
+                        }
+                    half_sums<2>(s1, lane);
+                    cost = sqrt(s1[0]) / ncommon;
+                    if (two) cost += sqrt(s1[1]) / ncommon;
                 }
                 cost /= a.D;
             }
