@@ -148,17 +148,25 @@ __global__ __launch_bounds__(256) void k_group_pairwise(GroupArgs a, const int *
                 const int i = lane + r * kLanes;
                 id[r] = i < cntA ? ia[i] : -1;
             }
-            int common = 0;
+            // lower_bound of every round's id in B, all rounds in lockstep (independent LDS reads per step instead of one
+            // dependent chain per round), rounds beyond the end of A skipped
+            int base[kRounds];
+#pragma unroll
+            for (int r = 0; r < kRounds; ++r) base[r] = 0;
+            for (int n = cntB; n > 1;) {  // the same trip count for every lane of the half wavefront
+                const int half = n >> 1;
+#pragma unroll
+                for (int r = 0; r < kRounds; ++r)
+                    if (r * kLanes < cntA) base[r] += fb[base[r] + half - 1] < id[r] ? half : 0;
+                n -= half;
+            }
 #pragma unroll
             for (int r = 0; r < kRounds; ++r) {
-                int lo = 0, hi = cntB;
-                while (lo < hi) {
-                    const int mid = (lo + hi) >> 1;
-                    if (fb[mid] < id[r]) lo = mid + 1;
-                    else hi = mid;
+                mem[r] = false;
+                if (r * kLanes < cntA && cntB > 0 && id[r] >= 0) {
+                    const int pos = base[r] + (fb[base[r]] < id[r] ? 1 : 0);
+                    mem[r] = pos < cntB && fb[pos] == id[r];
                 }
-                mem[r] = id[r] >= 0 && lo < cntB && fb[lo] == id[r];
-                common += mem[r] ? 1 : 0;
             }
             // size of the intersection: the set bits of the rounds' ballots within this half wavefront
             int ncommon = 0;
@@ -167,7 +175,6 @@ __global__ __launch_bounds__(256) void k_group_pairwise(GroupArgs a, const int *
 #pragma unroll
                 for (int r = 0; r < kRounds; ++r) ncommon += __popcll(__ballot(mem[r]) & halfmask);
             }
-            (void)common;
             double cost = 0.0;
             if (ncommon == 0) {
                 cost = nan;
