@@ -31,8 +31,11 @@ __device__ __forceinline__ double lanes_sum(double v) {
 // and hand the odd ones over, and so on), so N values cost ceil(N/2) + ceil(N/4) + ceil(N/8) + 2 exchanges plus N broadcasts -- 13
 // instead of 25 for the five sums of a two-row correlation.  Every sum pairs the same lanes in the same order as the butterfly
 // (16, 8, 4, 2, 1), so the results are the butterfly's bit for bit.  All 64 lanes call it; `lane` is the lane within the half.
+// half_reduce leaves value k, complete, in the lanes whose bits 16 / 8 / 4 are bits 0 / 1 / 2 of k (four lanes each); half_get
+// fetches one.  Keeping the sums where they land lets the per-query scalar arithmetic that follows (divisions by the sum of
+// weights, square roots) run ONCE with a different value in every lane group, instead of once per value in all lanes.
 template <int N>
-__device__ __forceinline__ void half_sums(double (&v)[N], int lane) {
+__device__ __forceinline__ double half_reduce(const double (&v)[N], int lane) {
     static_assert(N >= 1 && N <= 8, "at most eight values");
     constexpr int N1 = (N + 1) / 2, N2 = (N1 + 1) / 2, N3 = (N2 + 1) / 2;
     static_assert(N3 == 1, "three halving steps");
@@ -54,10 +57,17 @@ __device__ __forceinline__ void half_sums(double (&v)[N], int lane) {
     }
     y += __shfl_xor(y, 2, 64);
     y += __shfl_xor(y, 1, 64);
-    // value k ended up in the lanes whose bits 16 / 8 / 4 are bits 0 / 1 / 2 of k
-    const int half = (threadIdx.x & 63) & 32;
+    return y;
+}
+// which value a lane holds after half_reduce, and a lane that holds value k
+__device__ __forceinline__ int half_slot(int lane) { return ((lane >> 4) & 1) | (((lane >> 3) & 1) << 1) | (((lane >> 2) & 1) << 2); }
+__device__ __forceinline__ int half_lane_of(int k) { return ((k & 1) << 4) | (((k >> 1) & 1) << 3) | (((k >> 2) & 1) << 2); }
+__device__ __forceinline__ double half_get(double y, int k) { return __shfl(y, ((threadIdx.x & 63) & 32) | half_lane_of(k), 64); }
+template <int N>
+__device__ __forceinline__ void half_sums(double (&v)[N], int lane) {
+    const double y = half_reduce<N>(v, lane);
 #pragma unroll
-    for (int k = 0; k < N; ++k) v[k] = __shfl(y, half | ((k & 1) << 4) | (((k >> 1) & 1) << 3) | (((k >> 2) & 1) << 2), 64);
+    for (int k = 0; k < N; ++k) v[k] = half_get(y, k);
 }
 
 constexpr int kGroupStage = 256;  // ids of patch B staged in LDS per wavefront
@@ -194,6 +204,8 @@ __global__ __launch_bounds__(256) void k_group_pairwise(GroupArgs a, const int *
                     if (mem[r] && a.mask) w[r] = fabs(a.mask[id[r]]);
                 }
                 const bool two = a.D == 2;
+                const int row = (lane >> 4) & 1;  // the tail of feature row 0 runs in the lower sixteen lanes, of row 1 in the upper
+                double c_row;                     // this lane's row's similarity
                 if (a.simmeasure == 2) {  // sparsesimkernel::corr, M/similarities.cpp:129-158, both feature rows side by side
                     double s1[5] = {0.0, 0.0, 0.0, 0.0, 0.0};  // sum of weights, then weighted sums of A and B per row
 #pragma unroll
@@ -206,16 +218,11 @@ __global__ __launch_bounds__(256) void k_group_pairwise(GroupArgs a, const int *
                                 s1[2 + 2 * d] += w[r] * vb[r][d];
                             }
                         }
-                    half_sums<5>(s1, lane);
-                    const double sw = s1[0];
-                    double ma[2] = {s1[1], s1[3]}, mb[2] = {s1[2], s1[4]};
-                    if (sw > 0.0) {
-#pragma unroll
-                        for (int d = 0; d < 2; ++d) {
-                            ma[d] /= sw;
-                            mb[d] /= sw;
-                        }
-                    }
+                    // every lane group divides ITS sum by the sum of weights: one division for the four means
+                    double y = half_reduce<5>(s1, lane);
+                    const double sw = half_get(y, 0);
+                    if (sw > 0.0) y /= sw;
+                    const double ma[2] = {half_get(y, 1), half_get(y, 3)}, mb[2] = {half_get(y, 2), half_get(y, 4)};
                     double s2[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};  // per row: products, variance of A, variance of B
 #pragma unroll
                     for (int r = 0; r < kRounds; ++r)
@@ -228,19 +235,16 @@ __global__ __launch_bounds__(256) void k_group_pairwise(GroupArgs a, const int *
                                 s2[3 * d + 2] += w[r] * db * db;
                             }
                         }
-                    half_sums<6>(s2, lane);
-#pragma unroll
-                    for (int d = 0; d < 2; ++d) {
-                        if (d == 1 && !two) break;
-                        double pr = s2[3 * d], sa2 = s2[3 * d + 1], sb2 = s2[3 * d + 2];
-                        if (sw > 0.0) {
-                            pr /= sw;
-                            sa2 /= sw;
-                            sb2 /= sw;
-                        }
-                        const double rr = (sa2 == 0.0 || sb2 == 0.0) ? 0.0 : pr / (sqrt(sa2) * sqrt(sb2));
-                        cost += 1 - (1 + rr) * 0.5;
-                    }
+                    // likewise one division for the six second moments and one square root for the four variances
+                    double z = half_reduce<6>(s2, lane);
+                    if (sw > 0.0) z /= sw;
+                    const double rt = sqrt(z);  // of a product sum in the lanes that hold one: not used
+                    const int src = (threadIdx.x & 63) & 32;
+                    const double pr = __shfl(z, src | half_lane_of(3 * row), 64);
+                    const double sa = __shfl(rt, src | half_lane_of(3 * row + 1), 64), sb = __shfl(rt, src | half_lane_of(3 * row + 2), 64);
+                    // sqrt(x) == 0 exactly when x == 0: the reference's test on the variances
+                    const double rr = (sa == 0.0 || sb == 0.0) ? 0.0 : pr / (sa * sb);
+                    c_row = 1 - (1 + rr) * 0.5;
                 } else {  // sparsesimkernel::SSD, :179-188
                     double s1[2] = {0.0, 0.0};
 #pragma unroll
@@ -252,10 +256,12 @@ __global__ __launch_bounds__(256) void k_group_pairwise(GroupArgs a, const int *
                                 s1[d] += w[r] * df * df;
                             }
                         }
-                    half_sums<2>(s1, lane);
-                    cost = sqrt(s1[0]) / ncommon;
-                    if (two) cost += sqrt(s1[1]) / ncommon;
+                    const double y = half_reduce<2>(s1, lane);  // row 0 in the lower sixteen lanes, row 1 in the upper
+                    c_row = sqrt(y) / ncommon;
                 }
+                // cost = (row 0 [+ row 1]) / D, the rows added in the reference's order
+                const double c0 = __shfl(c_row, ((threadIdx.x & 63) & 32), 64), c1 = __shfl(c_row, ((threadIdx.x & 63) & 32) | 16, 64);
+                cost = two ? c0 + c1 : c0;
                 cost /= a.D;
             }
             if (a.fixnan && cost != cost) cost = 1e7;  // FIX_NAN, M/reg_tools.h:31
