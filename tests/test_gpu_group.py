@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 RTOL, ATOL = 1e-9, 1e-11
 
 
-def build(ctx, S=3, data_order=4, cp_order=2, D=2, mask=False, sim=2, percentile=0.75):
+def build(ctx, S=3, data_order=4, cp_order=2, D=2, mask=False, sim=2, percentile=0.75, subject_orders=None):
     dxyz, dtri = M.make_mesh_from_icosa(data_order)
     cxyz, ctri = M.make_mesh_from_icosa(cp_order)
     txyz, ttri = dxyz, dtri  # template space = a regular sphere at data resolution
@@ -30,7 +30,10 @@ def build(ctx, S=3, data_order=4, cp_order=2, D=2, mask=False, sim=2, percentile
     g.Initialize(cxyz, ctri)
     og.set_controlgrid(O.Mesh(cxyz, ctri))
     keep = [tm, otm]
+    txyz0, ttri0 = dxyz, dtri
     for s in range(S):
+        if subject_orders is not None:  # subjects on data meshes of their own (different sizes: the set-up's scratch meshes follow)
+            dxyz, dtri = (txyz0, ttri0) if subject_orders[s] == data_order else M.make_mesh_from_icosa(subject_orders[s])
         sph = synthetic.known_warp(dxyz, seed=40 + s, rot_deg=1.0 + s, amp=0.5)   # this subject's registered sphere so far
         feat = synthetic.features(synthetic.known_warp(dxyz, seed=90 + s, rot_deg=2.0, amp=1.0), D, seed=5)
         regular = M.Mesh(ctx, dxyz, dtri)
@@ -63,6 +66,23 @@ def test_group_structure_and_patches(ctx):
         oids, odata = og.patch(s, v, l)
         assert np.array_equal(ids, oids)
         assert np.allclose(data, odata, rtol=1e-10, atol=1e-11)
+
+
+def test_group_subjects_on_different_data_meshes(ctx):
+    """get_patch_data per subject resamples THAT subject's data mesh onto the template: subjects need not share a mesh.  The lanes of
+    the set-up keep scratch meshes per topology and rebuild them when the next subject's differs."""
+    g, og, _ = build(ctx, subject_orders=[4, 3, 4])
+    rng = np.random.default_rng(5)
+    for s, v, l in zip(rng.integers(0, 3, 30), rng.integers(0, 162, 30), rng.integers(0, g.L, 30)):
+        ids, data = g.patch(s, v, l)
+        oids, odata = og.patch(s, v, l)
+        assert np.array_equal(ids, oids)
+        assert np.allclose(data, odata, rtol=1e-10, atol=1e-11)
+    p = rng.integers(0, g.P, 300).astype(np.int32)
+    la, lb = rng.integers(0, g.L, 300).astype(np.int32), rng.integers(0, g.L, 300).astype(np.int32)
+    got, want = g.computePairwiseCost(p, la, lb), np.array([og.pairwise(*q) for q in zip(p, la, lb)])
+    both = np.isnan(want) & np.isnan(got)
+    assert np.allclose(got[~both], want[~both], rtol=RTOL, atol=ATOL)
 
 
 @pytest.mark.parametrize("mask,sim", [(False, 2), (True, 2), (False, 1)])
