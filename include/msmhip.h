@@ -135,6 +135,9 @@ int       msm_mesh_octree_stats(msm_mesh *m, int64_t stats[5]);
  * meshes with >= 8192 triangles are built on the GPU (level by level, the same leaves in the same order); MSMHIP_OCTREE=host|gpu
  * forces one of the two builds. */
 int       msm_mesh_octree_signature(msm_mesh *m, int64_t stats[5], uint64_t *signature);
+/* The same signature for B coordinate sets (xyz: B consecutive 3 x V SoA blocks) over one triangle list, the B trees built together
+ * as one forest -- how the gMSM set-up builds the trees of a subject's data mesh rotated to every label (testing aid). */
+int       msm_octree_forest_signatures(msm_ctx *ctx, const double *xyz, int32_t V, const int32_t *tri, int32_t T, int32_t B, uint64_t *signatures);
 /* Builds the search structures a cost function uses on this mesh as its target (octree, and for a closed star-shaped
  * surface the direction table that settles most searches with one lookup).  The direction table takes tens of ms of
  * host time, so by default it is built on a background thread when a cost function first evaluates against the mesh,

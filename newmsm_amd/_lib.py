@@ -71,6 +71,7 @@ SIGNATURES = {
     "msm_mesh_sizes": (C.c_int, [_VP, c_ip, c_ip, c_ip]),
     "msm_mesh_octree_stats": (C.c_int, [_VP, c_lp]),
     "msm_mesh_octree_signature": (C.c_int, [_VP, c_lp, C.POINTER(C.c_uint64)]),
+    "msm_octree_forest_signatures": (C.c_int, [_VP, c_dp, C.c_int32, c_ip, C.c_int32, C.c_int32, C.POINTER(C.c_uint64)]),
     "msm_query_triangles": (C.c_int, [_VP, c_dp, C.c_int32, c_ip, c_ip, c_dp, C.c_int]),
     "msm_closest_vertex": (C.c_int, [_VP, c_dp, C.c_int32, c_ip]),
     "msm_adaptive_barycentric_weights": (C.c_int, [_VP, _VP, c_dp, c_ip, c_ip, c_dp, C.c_int64, c_lp]),

@@ -178,6 +178,15 @@ class Context:
         buf = (C.c_char * max(n, 8)).from_address(p)
         return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
 
+    def forest_signatures(self, xyz_sets, tri):
+        """leaf signatures (Mesh.octree_signature) of the trees of B coordinate sets over one triangle list, built together as a forest"""
+        sets = [np.ascontiguousarray(np.asarray(x, dtype=np.float64).T) for x in xyz_sets]
+        big = np.ascontiguousarray(np.stack(sets))  # B x 3 x V
+        t, pt = _tri_soa(tri)
+        sig = (C.c_uint64 * len(sets))()
+        check(lib().msm_octree_forest_signatures(self.h, big.ctypes.data_as(c_dp), big.shape[2], pt, t.shape[1], len(sets), sig))
+        return [int(v) for v in sig]
+
     def register_host(self, address, nbytes):
         """Pin caller-owned host memory (e.g. a shared-memory mapping) and map it into the GPU's address space
         (msm_host_register): arrays inside it are then written by the GPU directly, like Context.host_array's."""

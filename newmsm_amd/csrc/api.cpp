@@ -518,7 +518,7 @@ ResampleScratch &resample_scratch(msm_ctx *ctx) {
 }
 }  // namespace
 
-int adaptive_weights_dev(msm_mesh *in_mesh, msm_mesh *new_mesh, AdaptiveDev &out, bool check) {
+int adaptive_weights_dev(msm_mesh *in_mesh, msm_mesh *new_mesh, AdaptiveDev &out, bool check, const DevTree *in_tree) {
     // Everything is queued on in_mesh's context.  new_mesh may belong to another context of the same GPU (a lane of the gMSM
     // set-up against the group's template) if its tree and adjacency are complete and synchronised: they are only read.
     const bool foreign = in_mesh->ctx != new_mesh->ctx;
@@ -526,7 +526,8 @@ int adaptive_weights_dev(msm_mesh *in_mesh, msm_mesh *new_mesh, AdaptiveDev &out
         return fail(MSM_ERR_INVALID, "adaptive weights: the two meshes belong to different contexts");
     msm_ctx *ctx = in_mesh->ctx;
     const int nOld = in_mesh->V, nNew = new_mesh->V;
-    int st = foreign ? ensure_tree(in_mesh) : ensure_tree_pair(in_mesh, new_mesh);
+    // in_tree: the search structure of in_mesh's current coordinates built elsewhere (a tree of a forest)
+    int st = in_tree ? (foreign ? MSM_OK : ensure_tree(new_mesh)) : (foreign ? ensure_tree(in_mesh) : ensure_tree_pair(in_mesh, new_mesh));
     if (st) return st;
     if ((st = ensure_adjacency_dev(in_mesh)) || (st = ensure_adjacency_dev(new_mesh))) return st;
     ResampleScratch &s = resample_scratch(ctx);
@@ -554,7 +555,7 @@ int adaptive_weights_dev(msm_mesh *in_mesh, msm_mesh *new_mesh, AdaptiveDev &out
     MSM_HIP(s.scan_tmp.ensure((size_t)std::max(nNew, nOld) / 4096 + 2));
     MSM_HIP(s.tval.ensure(cap));
     // forward: the new mesh's vertices in the old mesh's tree; reverse: the old vertices in the new mesh's tree (:74-78)
-    st = launch_query(ctx, dev_tree(in_mesh), new_mesh->d_xyz, nNew, nullptr, s.fvid.p, s.fw.p, MSM_WEIGHTS_PROJECTED);
+    st = launch_query(ctx, in_tree ? *in_tree : dev_tree(in_mesh), new_mesh->d_xyz, nNew, nullptr, s.fvid.p, s.fw.p, MSM_WEIGHTS_PROJECTED);
     if (st) return st;
     st = launch_query(ctx, dev_tree(new_mesh), in_mesh->d_xyz, nOld, nullptr, s.rvid.p, s.rw.p, MSM_WEIGHTS_PROJECTED);
     if (st) return st;
@@ -948,6 +949,48 @@ int msm_mesh_octree_signature(msm_mesh *m, int64_t stats[5], uint64_t *signature
         sum += h;
     }
     *signature = sum;
+    return MSM_OK;
+}
+
+// B coordinate sets over one triangle list built as a forest (one set of launches for all trees): per tree the same leaf signature
+// msm_mesh_octree_signature gives for a mesh with those coordinates.  xyz: B consecutive 3 x V SoA blocks.
+int msm_octree_forest_signatures(msm_ctx *ctx, const double *xyz, int32_t V, const int32_t *tri, int32_t T, int32_t B, uint64_t *signatures) {
+    if (!ctx || !xyz || !tri || !signatures || V <= 0 || T <= 0 || B <= 0) return fail(MSM_ERR_INVALID, "msm_octree_forest_signatures: bad arguments");
+    for (int64_t i = 0; i < 3 * (int64_t)T; ++i)
+        if (tri[i] < 0 || tri[i] >= V) return fail(MSM_ERR_INVALID, "msm_octree_forest_signatures: triangle vertex id %d out of range [0,%d)", tri[i], V);
+    MSM_HIP(hipSetDevice(ctx->device));
+    DevBuf<double> d_xyz;
+    DevBuf<int32_t> d_tri;
+    MSM_HIP(d_xyz.upload(xyz, (size_t)3 * V * B, ctx->stream));
+    MSM_HIP(d_tri.upload(tri, (size_t)3 * T, ctx->stream));
+    Forest f;
+    int st = gpu_build_forest(ctx, f, d_xyz.p, (size_t)V, (size_t)3 * V, V, d_tri.p, T, B);
+    if (st) return st == MSM_ERR_CAPACITY ? fail(st, "msm_octree_forest_signatures: a tree outgrew the preallocated arrays") : st;
+    MSM_HIP(hipStreamSynchronize(ctx->stream));
+    for (int b = 0; b < B; ++b) {
+        const int n = f.info[b].nnodes, ne = f.info[b].entries;
+        std::vector<int4> node(n);
+        std::vector<double4> box(n);
+        std::vector<int32_t> leaf((size_t)std::max(ne, 1));
+        MSM_HIP(hipMemcpy(node.data(), f.node.p + (size_t)b * f.s_node, sizeof(int4) * (size_t)n, hipMemcpyDeviceToHost));
+        MSM_HIP(hipMemcpy(box.data(), f.nodebox.p + (size_t)b * f.s_node, sizeof(double4) * (size_t)n, hipMemcpyDeviceToHost));
+        if (ne > 0) MSM_HIP(hipMemcpy(leaf.data(), f.leaf_tri.p + (size_t)b * f.s_leaf, sizeof(int32_t) * (size_t)ne, hipMemcpyDeviceToHost));
+        uint64_t sum = 0;
+        for (int i = 0; i < n; ++i) {
+            if (node[i].x >= 0) continue;
+            uint64_t h = 1469598103934665603ull;
+            auto mix = [&](uint64_t v) {
+                for (int k = 0; k < 8; ++k) {
+                    h ^= (v >> (8 * k)) & 0xff;
+                    h *= 1099511628211ull;
+                }
+            };
+            for (double d : {box[i].x, box[i].y, box[i].z, box[i].w}) mix((uint64_t)__builtin_bit_cast(uint64_t, d));
+            for (int e = 0; e < -node[i].x - 1; ++e) mix((uint64_t)leaf[node[i].y + e]);
+            sum += h;
+        }
+        signatures[b] = sum;
+    }
     return MSM_OK;
 }
 

@@ -73,6 +73,7 @@ struct msm_group {
         msm_mesh *mesh = nullptr;
     };
     std::vector<Lane> lanes;
+    Forest forest;  // the trees of the subject being set up: its data mesh rotated to every label, built together
     DevBuf<double> d_move_out;           // msm_group_fusion_move: the step's 4 P + 8 T results before they go to the host
     std::vector<int32_t> pair_order;     // the pair list in processing order (control points along a space-filling curve)
     DevBuf<int> d_pair_order;            // ... restricted to the slice [order_p0, order_p1) last asked for
@@ -620,8 +621,17 @@ int group_subject_setup(msm_group *g, int s) {
         if (st) return st;
         st = ensure_lanes(g, dm);
         if (st) return st;
-        MSM_HIP(hipStreamSynchronize(ctx->stream));  // rotations and features are where the lanes will read them
-        lap("rotations + feature upload");
+        // the L trees of the rotated meshes, built together (one chain of launches per subject instead of one per label); a tree
+        // that outgrows its arrays (a degenerate mesh) sends the subject down the per-label builds of the lanes
+        static const bool no_forest = [] { const char *e = std::getenv("MSMHIP_GROUP_FOREST"); return e && std::strcmp(e, "off") == 0; }();
+        bool forest = !no_forest;
+        if (forest) {
+            st = gpu_build_forest(ctx, g->forest, d_rot.p, LV, (size_t)V, V, dm->d_tri, T, L);
+            if (st == MSM_ERR_CAPACITY) forest = false;
+            else if (st) return st;
+        }
+        MSM_HIP(hipStreamSynchronize(ctx->stream));  // rotations, features and trees are where the lanes will read them
+        lap(forest ? "rotations + feature upload + forest" : "rotations + feature upload");
         // Per label: the rotated coordinates become a lane mesh's, its tree is built, then queries, surgery and the weighted sums.
         // One such pipeline is a dependent chain of some eighty kernels of a few microseconds each; the lanes run K of them side
         // by side.  The host queues the first half of K labels (up to where the tree build's outcome is looked at), then the second
@@ -653,13 +663,15 @@ int group_subject_setup(msm_group *g, int s) {
                             st = fail(MSM_ERR_HIP, "get_patch_data: device copy of the rotated coordinates failed");
                     lane.mesh->tree_valid = false;
                     lane.mesh->host_xyz_stale = true;
-                    if (!st) st = ensure_tree_begin(lane.mesh);
+                    if (!st && !forest) st = ensure_tree_begin(lane.mesh);
                 }
                 for (int k = 0; k < Kt && i0 + k < mine.size() && !st; ++k) {
                     const int l = mine[i0 + k];
                     msm_group::Lane &lane = g->lanes[k0 + k];
                     AdaptiveDev w;
-                    st = adaptive_weights_dev(lane.mesh, g->tmpl, w, false);
+                    DevTree tree;
+                    if (forest) tree = forest_tree(g->forest, l);
+                    st = adaptive_weights_dev(lane.mesh, g->tmpl, w, false, forest ? &tree : nullptr);
                     if (!st) st = apply_weights_dev(lane.ctx, w, g->d_subject_feat.p, D, g->F[(size_t)s * L + l]->p);
                 }
             }

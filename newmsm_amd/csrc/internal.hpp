@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "../../include/msmhip.h"
+#include "devbuf.hpp"
 #include "geom.hpp"
 
 namespace msm {
@@ -215,7 +216,7 @@ struct AdaptiveDev {
     const int *row_ptr = nullptr, *col = nullptr;  // device; valid until the next adaptive_weights_dev on this context
     const double *val = nullptr;
 };
-int adaptive_weights_dev(msm_mesh *in_mesh, msm_mesh *new_mesh, AdaptiveDev &out, bool check = true);  // check = false: the caller checks the status word
+int adaptive_weights_dev(msm_mesh *in_mesh, msm_mesh *new_mesh, AdaptiveDev &out, bool check = true, const DevTree *in_tree = nullptr);  // check = false: the caller checks the status word
 // out (device, D x V(new)) = the weights applied to d_data (device, D x V(in)): barycentric_data_interpolation R/resampler.cpp:40-52
 int apply_weights_dev(msm_ctx *ctx, const AdaptiveDev &w, const double *d_data, int D, double *d_out);
 int ensure_adjacency_dev(msm_mesh *m);
@@ -226,6 +227,31 @@ void vertex_areas_of(const double *xyz, const int32_t *tri, int V, int T, const 
 int install_coords_and_tree(msm_mesh *m, const double *xyz, FlatOctree &&tree);
 int ensure_tree(msm_mesh *m);  // build + upload the search structure if stale
 int gpu_build_octree(msm_mesh *m, const std::function<void()> *overlap = nullptr);
+// B trees over one triangle list and B coordinate sets, built together (octree_kernels.hip: gpu_build_forest); the arrays of tree b
+// start b * s_* elements into the shared buffers
+struct Forest {
+    int B = 0, T = 0, V = 0;
+    size_t s_node = 0, s_leaf = 0, s_rec = 0, s_grid = 0;
+    DevBuf<int4> node;
+    DevBuf<int32_t> parent, leaf_tri, grid;
+    DevBuf<double4> nodebox;
+    DevBuf<float4> cone, tcone;
+    DevBuf<TriRec> rec;
+    DevBuf<double> box;
+    DevBuf<int> ints, counters;
+    int *h_counters = nullptr;  // pinned
+    size_t h_counters_cap = 0;
+    struct Info {
+        int nnodes = 0, entries = 0, grid_depth = 0;
+    };
+    std::vector<Info> info;
+    ~Forest() {
+        if (h_counters) (void)hipHostFree(h_counters);
+    }
+};
+// component a of vertex i of tree b at d_xyz[a * comp_stride + b * tree_stride + i]; MSM_ERR_CAPACITY: a tree outgrew its arrays
+int gpu_build_forest(msm_ctx *ctx, Forest &f, const double *d_xyz, size_t comp_stride, size_t tree_stride, int V, const int32_t *d_tri, int T, int B);
+DevTree forest_tree(const Forest &f, int b);
 int gpu_build_octree_begin(msm_mesh *m);   // the same in two halves: queue the build ... 
 int gpu_build_octree_finish(msm_mesh *m);  // ... wait for it (one build at a time per context)
 int ensure_tree_begin(msm_mesh *m);        // api.cpp: starts the GPU build of an invalid tree (no-op otherwise); ensure_tree() completes it  // octree_kernels.hip: the same tree built in HBM from the mesh's device coordinates (MSM_ERR_CAPACITY: use the host build)

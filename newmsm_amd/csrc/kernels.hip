@@ -137,6 +137,49 @@ __global__ __launch_bounds__(256) void k_expand_cones(const int32_t *__restrict_
     cone[e] = t >= 0 ? tcone[t] : make_float4(0.f, 0.f, 0.f, 2.f);
 }
 
+// the same for every tree of a forest (blockIdx.y)
+__global__ __launch_bounds__(256) void k_build_recs_forest(const double *__restrict__ xyz, size_t comp, size_t tree, const int32_t *__restrict__ tri, int T,
+                                                            TriRec *__restrict__ recs, float4 *__restrict__ tcone, size_t s_rec) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    xyz += blockIdx.y * tree;
+    recs += blockIdx.y * s_rec;
+    tcone += blockIdx.y * s_rec;
+    const int i0 = tri[t], i1 = tri[T + t], i2 = tri[2 * T + t];
+    const V3 v0 = mk(xyz[i0], xyz[comp + i0], xyz[2 * comp + i0]), v1 = mk(xyz[i1], xyz[comp + i1], xyz[2 * comp + i1]), v2 = mk(xyz[i2], xyz[comp + i2], xyz[2 * comp + i2]);
+    TriRec r;
+    r.v0[0] = v0.x, r.v0[1] = v0.y, r.v0[2] = v0.z;
+    r.v1[0] = v1.x, r.v1[1] = v1.y, r.v1[2] = v1.z;
+    r.v2[0] = v2.x, r.v2[1] = v2.y, r.v2[2] = v2.z;
+    V3 s3;
+    plane_of(v0, v1, v2, s3, r.d);
+    r.s3[0] = s3.x, r.s3[1] = s3.y, r.s3[2] = s3.z;
+    r.id[0] = i0, r.id[1] = i1, r.id[2] = i2;
+    r.tri = t;
+    r.reserved = 0.0;
+    recs[t] = r;
+    tcone[t] = bounding_cone(v0, v1, v2, r.d);
+}
+__global__ __launch_bounds__(256) void k_expand_cones_forest(const int32_t *__restrict__ leaf_tri, size_t s_leaf, const int *__restrict__ entries, size_t entries_stride,
+                                                              const float4 *__restrict__ tcone, size_t s_rec, float4 *__restrict__ cone) {
+    const int n = entries[blockIdx.y * entries_stride];
+    leaf_tri += blockIdx.y * s_leaf;
+    cone += blockIdx.y * s_leaf;
+    tcone += blockIdx.y * s_rec;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
+        const int t = leaf_tri[e];
+        cone[e] = t >= 0 ? tcone[t] : make_float4(0.f, 0.f, 0.f, 2.f);
+    }
+}
+int launch_build_recs_forest(msm_ctx *ctx, const double *d_xyz, size_t comp_stride, size_t tree_stride, const int32_t *d_tri, int T, int B, TriRec *d_rec, float4 *d_tcone,
+                             size_t s_rec, const int32_t *d_leaf_tri, float4 *d_cone, size_t s_leaf, const int *d_entries, size_t entries_stride) {
+    if (T <= 0 || B <= 0) return MSM_OK;
+    hipLaunchKernelGGL(k_build_recs_forest, dim3((T + 255) / 256, (unsigned)B), dim3(256), 0, ctx->stream, d_xyz, comp_stride, tree_stride, d_tri, T, d_rec, d_tcone, s_rec);
+    hipLaunchKernelGGL(k_expand_cones_forest, dim3(512, (unsigned)B), dim3(256), 0, ctx->stream, d_leaf_tri, s_leaf, d_entries, entries_stride, d_tcone, s_rec, d_cone);
+    MSM_HIP(hipGetLastError());
+    return MSM_OK;
+}
+
 int launch_build_recs(msm_ctx *ctx, const double *d_xyz, int V, const int32_t *d_tri, int T, TriRec *d_rec, float4 *d_tcone, const int32_t *d_leaf_tri,
                       int nentries, float4 *d_cone) {
     if (T > 0) hipLaunchKernelGGL(k_build_recs, dim3((T + 255) / 256), dim3(256), 0, ctx->stream, d_xyz, V, d_tri, T, d_rec, d_tcone);

@@ -11,6 +11,9 @@ int launch_build_masks(msm_ctx *ctx, const DevTree &T, const double4 *d_nodebox,
 int launch_build_recs(msm_ctx *ctx, const double *d_xyz, int V, const int32_t *d_tri, int T, TriRec *d_rec, float4 *d_tcone, const int32_t *d_leaf_tri,
                       int nentries, float4 *d_cone);
 // ray-table records (internal.hpp: kRayPieces) from the triangle records, the edge planes and, when given, a single feature row (V doubles)
+// records and cones of every tree of a forest (the entry counts are read from the device: entries[b * entries_stride])
+int launch_build_recs_forest(msm_ctx *ctx, const double *d_xyz, size_t comp_stride, size_t tree_stride, const int32_t *d_tri, int T, int B, TriRec *d_rec, float4 *d_tcone,
+                             size_t s_rec, const int32_t *d_leaf_tri, float4 *d_cone, size_t s_leaf, const int *d_entries, size_t entries_stride);
 int launch_build_raytri(msm_ctx *ctx, const TriRec *d_rec, const float4 *d_edge, int T, const double *d_feat1, int D, float4 *d_out);
 // ---- adaptive barycentric weights on the device (resample_kernels.hip): Resampler::get_adaptive_barycentric_weights R/resampler.cpp:72-140
 struct AdaptiveDevArgs {

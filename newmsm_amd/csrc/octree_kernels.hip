@@ -38,15 +38,19 @@ __device__ __forceinline__ int wave_incl_scan(int v, int lane) {
     return v;
 }
 
-__global__ __launch_bounds__(256) void k_oct_boxes(const double *__restrict__ xyz, int V, const int32_t *__restrict__ tri, int T, double *__restrict__ box,
-                                                    int *__restrict__ list) {
+// xyz: component a of vertex i of tree b at xyz[a * comp + b * tree + i] (one mesh: comp = V, tree = 0)
+__global__ __launch_bounds__(256) void k_oct_boxes(const double *__restrict__ xyz, size_t comp, size_t tree, const int32_t *__restrict__ tri, int T, double *__restrict__ box,
+                                                    int *__restrict__ list, size_t s_box, size_t s_list) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= T) return;
+    xyz += blockIdx.y * tree;
+    box += blockIdx.y * s_box;
+    list += blockIdx.y * s_list;
     double lo[3], hi[3];
-    for (int a = 0; a < 3; ++a) lo[a] = hi[a] = xyz[(size_t)a * V + tri[t]];
+    for (int a = 0; a < 3; ++a) lo[a] = hi[a] = xyz[(size_t)a * comp + tri[t]];
     for (int k = 1; k < 3; ++k)
         for (int a = 0; a < 3; ++a) {
-            const double c = xyz[(size_t)a * V + tri[(size_t)k * T + t]];
+            const double c = xyz[(size_t)a * comp + tri[(size_t)k * T + t]];
             if (c < lo[a]) lo[a] = c;
             if (c > hi[a]) hi[a] = c;
         }
@@ -74,7 +78,35 @@ struct OctWork {
     int *ctot;             // 8 per open node: what each child of a splitting node receives in all
     int32_t *leaf_tri;     // the mesh's leaf array
     int cap_nodes, cap_refs, cap_arena, cap_open, cap_chunks;
+    // a forest (gpu_build_forest): tree blockIdx.y of the launch uses the arrays `stride` elements further on; all zero for one tree
+    size_t s_box, s_node, s_cnt, s_ints, s_leaf;  // s_ints: every int work array of a tree lies in one block, the blocks s_ints apart
 };
+
+// the arrays of this workgroup's tree
+__device__ __forceinline__ OctWork tree_view(OctWork w) {
+    const size_t b = blockIdx.y;
+    if (b == 0) return w;
+    w.box += b * w.s_box;
+    w.node += b * w.s_node;
+    w.parent += b * w.s_node;
+    w.nodebox += b * w.s_node;
+    w.counters += b * w.s_cnt;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        w.open_node[k] += b * w.s_ints;
+        w.open_off[k] += b * w.s_ints;
+        w.open_len[k] += b * w.s_ints;
+        w.open_chunk[k] += b * w.s_ints;
+        w.chunk_open[k] += b * w.s_ints;
+        w.chunk_beg[k] += b * w.s_ints;
+        w.list[k] += b * w.s_ints;
+    }
+    w.split += b * w.s_ints;
+    w.ctot += b * w.s_ints;
+    w.cc += b * w.s_ints;
+    w.leaf_tri += b * w.s_leaf;
+    return w;
+}
 
 // the 8 overlap flags of a triangle box against the children of a node (Node::can_contain on each child, R/node.cpp:108-116):
 // per axis the child box is the parent's [lower, middle] or [middle, upper]
@@ -102,7 +134,9 @@ __device__ __forceinline__ void node_box(const double4 b, double lo[3], double m
 // Does the node split?  Octree::add_triangle, R/octree.cpp:65-131: running total_size / num_split over the node's list in id
 // order, tested from the 50th entry on.  A wavefront per open node; the scan stops at the first entry that triggers the split
 // (for the large nodes of the top levels that is within the first chunk).
-__global__ __launch_bounds__(256) void k_oct_decide(OctWork w, int cur) {
+template <int cur>  // which of the two open lists this level reads (a template parameter: a run-time index into the views' pointer pairs sent the kernels to scratch)
+__global__ __launch_bounds__(256) void k_oct_decide(OctWork w) {
+    w = tree_view(w);
     const int nopen = w.counters[C_NOPEN];
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
@@ -137,7 +171,9 @@ __global__ __launch_bounds__(256) void k_oct_decide(OctWork w, int cur) {
 }
 
 // per chunk of a splitting node: how many of its entries each child receives
-__global__ __launch_bounds__(256) void k_oct_count(OctWork w, int cur) {
+template <int cur>  // which of the two open lists this level reads (a template parameter: a run-time index into the views' pointer pairs sent the kernels to scratch)
+__global__ __launch_bounds__(256) void k_oct_count(OctWork w) {
+    w = tree_view(w);
     __shared__ int s_cnt[4][8];
     const int nchunks = w.counters[C_NCHUNK];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -164,7 +200,9 @@ __global__ __launch_bounds__(256) void k_oct_count(OctWork w, int cur) {
 // per splitting node: its chunks' counts become exclusive prefixes (where each chunk's share of a child's list starts), the sums
 // go to ctot.  A wavefront per node, 64 chunks at a time -- the root of an ico6 mesh has 320 chunks, and one thread of
 // k_oct_scan walking them with dependent loads and stores took up to 100 us per level.
-__global__ __launch_bounds__(256) void k_oct_chunk_scan(OctWork w, int cur) {
+template <int cur>  // which of the two open lists this level reads (a template parameter: a run-time index into the views' pointer pairs sent the kernels to scratch)
+__global__ __launch_bounds__(256) void k_oct_chunk_scan(OctWork w) {
+    w = tree_view(w);
     const int nopen = w.counters[C_NOPEN];
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
@@ -250,7 +288,9 @@ __device__ int block_excl_scan(int v, int *total) {
 
 // One workgroup turns the level's decisions into node numbers, list offsets, chunk tables and leaf slots -- prefix sums in
 // open-node order, so the numbering of the tree does not depend on scheduling.
-__global__ __launch_bounds__(1024) void k_oct_scan(OctWork w, int cur, int depth) {
+template <int cur>
+__global__ __launch_bounds__(1024) void k_oct_scan(OctWork w, int depth) {
+    w = tree_view(w);
     const int nopen = w.counters[C_NOPEN];
     if (nopen == 0) return;
     const int nxt = cur ^ 1, tid = threadIdx.x;
@@ -338,7 +378,9 @@ __global__ __launch_bounds__(1024) void k_oct_scan(OctWork w, int cur, int depth
 
 // per chunk: a splitting node's entries go to its children's lists (ballot-ordered compaction behind the chunk's start in each
 // child list: ids stay ascending); a leaf's entries go to the leaf array, padded to a multiple of eight with -1
-__global__ __launch_bounds__(256) void k_oct_fill(OctWork w, int cur) {
+template <int cur>  // which of the two open lists this level reads (a template parameter: a run-time index into the views' pointer pairs sent the kernels to scratch)
+__global__ __launch_bounds__(256) void k_oct_fill(OctWork w) {
+    w = tree_view(w);
     __shared__ int s_cnt[4][8];
     if (w.counters[C_OVERFLOW]) return;
     const int nchunks = w.counters[C_NCHUNK];
@@ -379,10 +421,14 @@ __global__ __launch_bounds__(256) void k_oct_fill(OctWork w, int cur) {
     }
 }
 
-__global__ void k_oct_begin_level(int *counters) { counters[C_NCHUNK] = counters[C_NCHUNK_NEXT]; }
+__global__ void k_oct_begin_level(int *counters, size_t stride) {
+    counters += blockIdx.y * stride;
+    counters[C_NCHUNK] = counters[C_NCHUNK_NEXT];
+}
 
 // the state before level 0: node 0 with the cube (-101, 101) and every triangle (k_oct_boxes wrote the list), in chunks
 __global__ __launch_bounds__(256) void k_oct_init(OctWork w, int T, int root_chunks) {
+    w = tree_view(w);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < root_chunks) {
         w.chunk_open[0][i] = 0;
@@ -398,6 +444,25 @@ __global__ __launch_bounds__(256) void k_oct_init(OctWork w, int T, int root_chu
         w.open_len[0][0] = T;
         w.open_chunk[0][0] = 0;
     }
+}
+
+// the same for every tree of a forest, the depth taken from the tree's counters
+__global__ __launch_bounds__(256) void k_oct_grid_forest(const int4 *__restrict__ node, size_t s_node, const int *__restrict__ counters, size_t s_cnt, int32_t *__restrict__ grid,
+                                                          size_t s_grid) {
+    node += blockIdx.y * s_node;
+    grid += blockIdx.y * s_grid;
+    const int gd = min(counters[blockIdx.y * s_cnt + C_MAXDEPTH], 6), G = 1 << gd;
+    const size_t cell = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (cell >= (size_t)G * G * G) return;
+    const int iz = (int)(cell % G), iy = (int)((cell / G) % G), ix = (int)(cell / ((size_t)G * G));
+    int n = 0;
+    for (int d = 0; d < gd; ++d) {
+        const int4 nd = node[n];
+        if (nd.x < 0) break;
+        const int sh = gd - 1 - d;
+        n = nd.x + 4 * ((ix >> sh) & 1) + 2 * ((iy >> sh) & 1) + ((iz >> sh) & 1);
+    }
+    grid[cell] = n;
 }
 
 // dense top grid (FlatOctree::grid): the node a point of each depth-gd cell reaches after gd levels of descent, or the leaf met earlier
@@ -424,23 +489,36 @@ namespace {
 struct OctJob {  // a build between gpu_build_octree_begin and _finish
     OctWork w;
     int cur = 0, depth = 0;
+    int trees = 1;
+    int *h_counters = nullptr;  // pinned, trees x (C_COUNT + 1)
 };
 constexpr int kMaxLevels = 24, kFirstBatch = 8, kNextBatch = 4;
 // Levels are queued in batches without looking at the outcome in between: a level with nothing open costs six empty launches, a
 // look costs a round trip.  Ico-derived meshes finish at depth 6 or 7, i.e. within the first batch.
 int queue_levels(msm_ctx *ctx, OctJob &j, int count) {
     const int upto = std::min(kMaxLevels, j.depth + count);
+    const unsigned B = (unsigned)j.trees;
+    const unsigned div = B > 1 ? 4 : 1;  // a forest's trees share the machine
     for (; j.depth < upto; ++j.depth) {
-        hipLaunchKernelGGL(k_oct_begin_level, dim3(1), dim3(1), 0, ctx->stream, j.w.counters);
-        hipLaunchKernelGGL(k_oct_decide, dim3(512), dim3(256), 0, ctx->stream, j.w, j.cur);
-        hipLaunchKernelGGL(k_oct_count, dim3(1024), dim3(256), 0, ctx->stream, j.w, j.cur);
-        hipLaunchKernelGGL(k_oct_chunk_scan, dim3(256), dim3(256), 0, ctx->stream, j.w, j.cur);
-        hipLaunchKernelGGL(k_oct_scan, dim3(1), dim3(1024), 0, ctx->stream, j.w, j.cur, j.depth);
-        hipLaunchKernelGGL(k_oct_fill, dim3(1024), dim3(256), 0, ctx->stream, j.w, j.cur);
+        hipLaunchKernelGGL(k_oct_begin_level, dim3(1, B), dim3(1), 0, ctx->stream, j.w.counters, j.w.s_cnt);
+        if (j.cur == 0) {
+            hipLaunchKernelGGL(k_oct_decide<0>, dim3(512 / div, B), dim3(256), 0, ctx->stream, j.w);
+            hipLaunchKernelGGL(k_oct_count<0>, dim3(1024 / div, B), dim3(256), 0, ctx->stream, j.w);
+            hipLaunchKernelGGL(k_oct_chunk_scan<0>, dim3(256 / div, B), dim3(256), 0, ctx->stream, j.w);
+            hipLaunchKernelGGL(k_oct_scan<0>, dim3(1, B), dim3(1024), 0, ctx->stream, j.w, j.depth);
+            hipLaunchKernelGGL(k_oct_fill<0>, dim3(1024 / div, B), dim3(256), 0, ctx->stream, j.w);
+        } else {
+            hipLaunchKernelGGL(k_oct_decide<1>, dim3(512 / div, B), dim3(256), 0, ctx->stream, j.w);
+            hipLaunchKernelGGL(k_oct_count<1>, dim3(1024 / div, B), dim3(256), 0, ctx->stream, j.w);
+            hipLaunchKernelGGL(k_oct_chunk_scan<1>, dim3(256 / div, B), dim3(256), 0, ctx->stream, j.w);
+            hipLaunchKernelGGL(k_oct_scan<1>, dim3(1, B), dim3(1024), 0, ctx->stream, j.w, j.depth);
+            hipLaunchKernelGGL(k_oct_fill<1>, dim3(1024 / div, B), dim3(256), 0, ctx->stream, j.w);
+        }
         j.cur ^= 1;
     }
     MSM_HIP(hipGetLastError());
-    MSM_HIP(hipMemcpyAsync(ctx->oct_hcounters, j.w.counters, sizeof(int) * C_COUNT, hipMemcpyDeviceToHost, ctx->stream));
+    // a forest's counters are consecutive (s_cnt = C_COUNT + 1)
+    MSM_HIP(hipMemcpyAsync(j.h_counters, j.w.counters, sizeof(int) * (B == 1 ? (size_t)C_COUNT : (size_t)B * (C_COUNT + 1)), hipMemcpyDeviceToHost, ctx->stream));
     return MSM_OK;
 }
 }  // namespace
@@ -516,10 +594,12 @@ int gpu_build_octree_begin(msm_mesh *m) {
 
     // root: node 0 with the cube (-101, 101) and every triangle
     const int root_chunks = (T + kChunk - 1) / kChunk;
-    hipLaunchKernelGGL(k_oct_boxes, dim3((T + 255) / 256), dim3(256), 0, ctx->stream, m->d_xyz, V, m->d_tri, T, s.box, w.list[0]);
+    w.s_box = w.s_node = w.s_cnt = w.s_ints = w.s_leaf = 0;
+    hipLaunchKernelGGL(k_oct_boxes, dim3((T + 255) / 256), dim3(256), 0, ctx->stream, m->d_xyz, (size_t)V, (size_t)0, m->d_tri, T, s.box, w.list[0], (size_t)0, (size_t)0);
     hipLaunchKernelGGL(k_oct_init, dim3((std::max(root_chunks, C_COUNT + 1) + 255) / 256), dim3(256), 0, ctx->stream, w, T, root_chunks);
     auto job = std::make_shared<OctJob>();
     job->w = w;
+    job->h_counters = ctx->oct_hcounters;
     m->oct_job = job;
     return queue_levels(ctx, *job, kFirstBatch);
 }
@@ -555,6 +635,116 @@ int gpu_build_octree_finish(msm_mesh *m) {
     hipLaunchKernelGGL(k_oct_grid, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, ctx->stream, m->d_node, o.grid_depth, m->d_grid);
     MSM_HIP(hipGetLastError());
     return launch_build_recs(ctx, m->d_xyz, V, m->d_tri, T, m->d_rec, m->d_tcone, m->d_leaf_tri, o.dev_entries, m->d_cone);
+}
+
+// B trees at once: the same triangle list over B coordinate sets (gMSM: a subject's data mesh rotated to every label), every level's
+// kernels launched once with the tree as the second grid dimension.  The per-label chain of ~55 launches of a few microseconds
+// each becomes one chain per subject.  Each tree is numbered by prefix sums over ITS open nodes (one workgroup of k_oct_scan per
+// tree), so every tree is what gpu_build_octree builds for that coordinate set, node for node.
+int gpu_build_forest(msm_ctx *ctx, Forest &f, const double *d_xyz, size_t comp_stride, size_t tree_stride, int V, const int32_t *d_tri, int T, int B) {
+    if (B <= 0 || T <= 0) return fail(MSM_ERR_INVALID, "gpu_build_forest: bad arguments");
+    MSM_HIP(hipSetDevice(ctx->device));
+    const int cap_nodes = T + 64, cap_refs = 6 * T + 256, cap_arena = 8 * T + 512, cap_open = cap_nodes, cap_chunks = cap_refs / kChunk + cap_open + 64;
+    const size_t per_ints = ((size_t)2 * cap_refs + (size_t)8 * cap_open + (size_t)cap_open + (size_t)8 * cap_open + (size_t)4 * cap_chunks + (size_t)8 * cap_chunks + 16 + 3) & ~(size_t)3;
+    f.B = B, f.T = T, f.V = V;
+    f.s_node = (size_t)cap_nodes, f.s_leaf = (size_t)cap_arena, f.s_rec = (size_t)T, f.s_grid = (size_t)64 * 64 * 64;
+    MSM_HIP(f.node.ensure(f.s_node * B));
+    MSM_HIP(f.parent.ensure(f.s_node * B));
+    MSM_HIP(f.nodebox.ensure(f.s_node * B));
+    MSM_HIP(f.leaf_tri.ensure(f.s_leaf * B));
+    MSM_HIP(f.cone.ensure(f.s_leaf * B));
+    MSM_HIP(f.rec.ensure(f.s_rec * B));
+    MSM_HIP(f.tcone.ensure(f.s_rec * B));
+    MSM_HIP(f.grid.ensure(f.s_grid * B));
+    MSM_HIP(f.box.ensure((size_t)6 * T * B));
+    MSM_HIP(f.ints.ensure(per_ints * B));
+    MSM_HIP(f.counters.ensure((size_t)(C_COUNT + 1) * B));
+    if (f.h_counters_cap < (size_t)(C_COUNT + 1) * B) {
+        if (f.h_counters) (void)hipHostFree(f.h_counters);
+        f.h_counters = nullptr;
+        f.h_counters_cap = (size_t)(C_COUNT + 1) * B;
+        MSM_HIP(hipHostMalloc((void **)&f.h_counters, sizeof(int) * f.h_counters_cap));
+    }
+    OctWork w;
+    w.box = f.box.p;
+    w.node = f.node.p;
+    w.parent = f.parent.p;
+    w.nodebox = f.nodebox.p;
+    w.counters = f.counters.p;
+    // within a tree's block of ints the arrays lie as in gpu_build_octree_begin; the blocks of consecutive trees per_ints apart,
+    // so every array's stride is per_ints
+    int *p = f.ints.p;
+    w.list[0] = p, p += cap_refs;
+    w.list[1] = p, p += cap_refs;
+    for (int k = 0; k < 2; ++k) {
+        w.open_node[k] = p, p += cap_open;
+        w.open_off[k] = p, p += cap_open;
+        w.open_len[k] = p, p += cap_open;
+        w.open_chunk[k] = p, p += cap_open;
+        w.chunk_open[k] = p, p += cap_chunks;
+        w.chunk_beg[k] = p, p += cap_chunks;
+    }
+    w.split = p, p += cap_open;
+    p += (4 - ((p - f.ints.p) & 3)) & 3;
+    w.ctot = p, p += (size_t)8 * cap_open;
+    w.cc = p;
+    w.leaf_tri = f.leaf_tri.p;
+    w.cap_nodes = cap_nodes, w.cap_refs = cap_refs, w.cap_arena = cap_arena, w.cap_open = cap_open, w.cap_chunks = cap_chunks;
+    w.s_box = (size_t)6 * T, w.s_node = f.s_node, w.s_cnt = (size_t)(C_COUNT + 1), w.s_ints = per_ints, w.s_leaf = f.s_leaf;
+    const unsigned UB = (unsigned)B;
+    const int root_chunks = (T + kChunk - 1) / kChunk;
+    hipLaunchKernelGGL(k_oct_boxes, dim3((T + 255) / 256, UB), dim3(256), 0, ctx->stream, d_xyz, comp_stride, tree_stride, d_tri, T, f.box.p, w.list[0], w.s_box, w.s_ints);
+    hipLaunchKernelGGL(k_oct_init, dim3((std::max(root_chunks, C_COUNT + 1) + 255) / 256, UB), dim3(256), 0, ctx->stream, w, T, root_chunks);
+    OctJob job;
+    job.w = w;
+    job.trees = B;
+    job.h_counters = f.h_counters;
+    int st = queue_levels(ctx, job, kFirstBatch);
+    if (st) return st;
+    MSM_HIP(hipStreamSynchronize(ctx->stream));
+    auto open_somewhere = [&] {
+        for (int b = 0; b < B; ++b) {
+            const int *hc = f.h_counters + (size_t)b * (C_COUNT + 1);
+            if (hc[C_NOPEN] != 0 && !hc[C_OVERFLOW]) return true;
+        }
+        return false;
+    };
+    while (open_somewhere() && job.depth < kMaxLevels) {
+        st = queue_levels(ctx, job, kNextBatch);
+        if (st) return st;
+        MSM_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    f.info.assign(B, Forest::Info{});
+    for (int b = 0; b < B; ++b) {
+        const int *hc = f.h_counters + (size_t)b * (C_COUNT + 1);
+        if (hc[C_OVERFLOW] || hc[C_NOPEN] != 0) return MSM_ERR_CAPACITY;
+        f.info[b].nnodes = hc[C_NNODES];
+        f.info[b].entries = hc[C_ARENA];
+        f.info[b].grid_depth = std::min(hc[C_MAXDEPTH], 6);
+    }
+    hipLaunchKernelGGL(k_oct_grid_forest, dim3((unsigned)((f.s_grid + 255) / 256), UB), dim3(256), 0, ctx->stream, f.node.p, f.s_node, f.counters.p, (size_t)(C_COUNT + 1),
+                       f.grid.p, f.s_grid);
+    MSM_HIP(hipGetLastError());
+    return launch_build_recs_forest(ctx, d_xyz, comp_stride, tree_stride, d_tri, T, B, f.rec.p, f.tcone.p, f.s_rec, f.leaf_tri.p, f.cone.p, f.s_leaf, f.counters.p + C_ARENA,
+                                    (size_t)(C_COUNT + 1));
+}
+
+DevTree forest_tree(const Forest &f, int b) {
+    DevTree t{};
+    t.node = f.node.p + (size_t)b * f.s_node;
+    t.parent = f.parent.p + (size_t)b * f.s_node;
+    t.leaf_tri = f.leaf_tri.p + (size_t)b * f.s_leaf;
+    t.cone = f.cone.p + (size_t)b * f.s_leaf;
+    t.rec = f.rec.p + (size_t)b * f.s_rec;
+    t.grid = f.grid.p + (size_t)b * f.s_grid;
+    t.grid_depth = f.info[b].grid_depth;
+    t.simple = 0;
+    t.mask = nullptr;
+    t.nnodes = f.info[b].nnodes;
+    t.ray_G = 0;
+    t.ray_cell = nullptr, t.ray_tri = nullptr, t.ray_more = nullptr, t.ray_excl = nullptr;
+    t.ray_r2lo = t.ray_r2hi = 0.0;
+    return t;
 }
 
 int gpu_build_octree(msm_mesh *m, const std::function<void()> *overlap) {

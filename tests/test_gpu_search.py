@@ -291,3 +291,17 @@ def test_gpu_built_octree_has_the_reference_leaves(ctx, case):
     m.set_coords(xyz2)
     s2, g2 = m.octree_signature()
     assert (s2, g2) == M.octree_signature(xyz2, tri)
+
+
+def test_forest_build_gives_every_tree_of_the_single_builds(ctx):
+    """gpu_build_forest (the gMSM set-up: a subject's data mesh rotated to every label, all trees built by one set of launches) against
+    one GPU build per coordinate set: identical leaves (boxes and ordered triangle lists) for every tree, at two sizes."""
+    for order, B in ((4, 5), (6, 3)):
+        xyz, tri = M.make_mesh_from_icosa(order)
+        sets = [xyz] + [synthetic.known_warp(xyz, seed=70 + b, rot_deg=2.0 * b, amp=0.4 * b) for b in range(1, B)]
+        got = ctx.forest_signatures(sets, tri)
+        want = []
+        for x in sets:
+            m = M.Mesh(ctx, x, tri)
+            want.append(m.octree_signature()[1])
+        assert got == want
