@@ -73,7 +73,14 @@ struct msm_group {
         msm_mesh *mesh = nullptr;
     };
     std::vector<Lane> lanes;
-    Forest forest;  // the trees of the subject being set up: its data mesh rotated to every label, built together
+    // what the set-up of ONE subject needs before its per-label work can start: the L rotated copies of its data mesh, their trees
+    // (a forest), its features.  Two of them: while the lanes work through subject i the main stream prepares subject i + 1.
+    struct Stage {
+        DevBuf<double> d_rot, d_feat;
+        Forest forest;
+        bool forest_ok = false;
+    };
+    Stage stage[2];
     DevBuf<double> d_move_out;           // msm_group_fusion_move: the step's 4 P + 8 T results before they go to the host
     std::vector<int32_t> pair_order;     // the pair list in processing order (control points along a space-filling curve)
     DevBuf<int> d_pair_order;            // ... restricted to the slice [order_p0, order_p1) last asked for
@@ -85,7 +92,6 @@ struct msm_group {
     DevBuf<double> d_centres, d_sep;
     DevBuf<double> d_rotated;  // the L rotated data meshes of the subject being set up
     DevBuf<double4> d_chunkb;       // k_range: bounding balls of the template's vertices, 64 ids at a time
-    DevBuf<double> d_subject_feat;  // its features (D x V), the input of the device resampling
     DevBuf<uint32_t> d_slots;
     DevBuf<int> d_counts;
 };
@@ -568,6 +574,165 @@ int ensure_lanes(msm_group *g, const msm_mesh *dm) {
     return MSM_OK;
 }
 
+static bool group_device_path() {
+    static const bool host_surgery = [] { const char *e = std::getenv("MSMHIP_SURGERY"); return e && std::strcmp(e, "host") == 0; }();
+    static const bool host_trees = [] { const char *e = std::getenv("MSMHIP_OCTREE"); return e && std::strcmp(e, "host") == 0; }();
+    return !host_trees && !host_surgery;
+}
+
+// get_patch_data of one subject with everything in HBM, in three stages (msm_group_setup_subjects runs them as a pipeline):
+//   prepare   main stream: the L rotated copies of the data mesh side by side in one 3 x (L * V) array (x of label 0, x of label
+//             1, ..., y of label 0, ...), the subject's features, the L trees built together as a forest; ends synchronised
+//   lanes     per label: the rotated coordinates become a lane mesh's, then queries, weight-list surgery (resample_kernels.hip) and
+//             the weighted sums write F[s][l] directly.  One such pipeline is a dependent chain of some thirty kernels of a few
+//             microseconds each (eighty with the tree build, when the forest could not be used); the lanes run K of them side by
+//             side, driven by (two) host threads, each with its share of the lanes and every other label -- submitting the launches
+//             is itself a third of a millisecond of host time per label.  A thread queues the first half of its lanes' labels
+//             (up to where a tree build's outcome is looked at), then the second half of each, so that it never waits for work it
+//             has only just submitted.
+//   patches   main stream: subject_patches
+static int stage_prepare(msm_group *g, int s, msm_group::Stage &b) {
+    if (!g->data[s]) return fail(MSM_ERR_STATE, "msm_group: subject %d has no data", s);
+    msm_ctx *ctx = g->ctx;
+    const int L = g->L, D = g->D, Vt = g->tmpl->V;
+    const double centre[3] = {g->labels[0], g->labels[L], g->labels[2 * (size_t)L]};
+    msm_mesh *dm = g->data[s];
+    const int V = dm->V, T = dm->T;
+    const size_t LV = (size_t)L * V;
+    MSM_HIP(b.d_rot.ensure(3 * LV));
+    for (int a = 0; a < 3; ++a)  // label 0 is the centre of the sampling grid: no rotation
+        MSM_HIP(hipMemcpyAsync(b.d_rot.p + a * LV, dm->d_xyz + (size_t)a * V, sizeof(double) * (size_t)V, hipMemcpyDeviceToDevice, ctx->stream));
+    for (int l = 1; l < L; ++l) {
+        const double lab[3] = {g->labels[l], g->labels[L + l], g->labels[2 * (size_t)L + l]};
+        int st = launch_rotate_to_label(ctx, dm->d_xyz, V, centre, lab, b.d_rot.p + (size_t)l * V, LV);
+        if (st) return st;
+    }
+    MSM_HIP(b.d_feat.ensure((size_t)D * V));
+    int st = upload_staged(ctx, b.d_feat.p, g->feat[s].data(), sizeof(double) * (size_t)D * V);
+    if (st) return st;
+    st = subject_feature_slab(g, s, (size_t)D * Vt);
+    if (st) return st;
+    // the L trees, built together (one chain of launches per subject instead of one per label); a tree that outgrows its arrays
+    // (a degenerate mesh) sends the subject down the per-label builds of the lanes
+    static const bool no_forest = [] { const char *e = std::getenv("MSMHIP_GROUP_FOREST"); return e && std::strcmp(e, "off") == 0; }();
+    b.forest_ok = !no_forest;
+    if (b.forest_ok) {
+        st = gpu_build_forest(ctx, b.forest, b.d_rot.p, LV, (size_t)V, V, dm->d_tri, T, L);
+        if (st == MSM_ERR_CAPACITY) b.forest_ok = false;
+        else if (st) return st;
+    }
+    st = check_status(ctx, "get_patch_data (rotation)");  // synchronises: rotations, features and trees are where the lanes will read them
+    return st;
+}
+
+static int stage_lanes(msm_group *g, int s, msm_group::Stage &b) {
+    msm_ctx *ctx = g->ctx;
+    const int L = g->L, D = g->D;
+    msm_mesh *dm = g->data[s];
+    const int V = dm->V;
+    const size_t LV = (size_t)L * V;
+    int st = ensure_lanes(g, dm);
+    if (st) return st;
+    const bool forest = b.forest_ok;
+    const int K = (int)g->lanes.size();
+    static const int want_threads = [] {
+        const char *e = std::getenv("MSMHIP_GROUP_THREADS");
+        const int v = e ? std::atoi(e) : 2;
+        return v < 1 ? 1 : (v > 4 ? 4 : v);
+    }();
+    const int nthreads = std::max(1, std::min(want_threads, K));
+    std::vector<int> status(nthreads, MSM_OK);
+    std::vector<std::string> message(nthreads);
+    auto drive = [&](int th) {
+        int st = MSM_OK;
+        (void)hipSetDevice(ctx->device);
+        const int k0 = th * K / nthreads, k1 = (th + 1) * K / nthreads, Kt = k1 - k0;
+        std::vector<int> mine;
+        for (int l = th; l < L; l += nthreads) mine.push_back(l);
+        for (size_t i0 = 0; i0 < mine.size() && !st; i0 += Kt) {
+            for (int k = 0; k < Kt && i0 + k < mine.size() && !st; ++k) {
+                const int l = mine[i0 + k];
+                msm_group::Lane &lane = g->lanes[k0 + k];
+                for (int a = 0; a < 3 && !st; ++a)
+                    if (hipMemcpyAsync(lane.mesh->d_xyz + (size_t)a * V, b.d_rot.p + a * LV + (size_t)l * V, sizeof(double) * (size_t)V, hipMemcpyDeviceToDevice,
+                                       lane.ctx->stream) != hipSuccess)
+                        st = fail(MSM_ERR_HIP, "get_patch_data: device copy of the rotated coordinates failed");
+                lane.mesh->tree_valid = false;
+                lane.mesh->host_xyz_stale = true;
+                if (!st && !forest) st = ensure_tree_begin(lane.mesh);
+            }
+            for (int k = 0; k < Kt && i0 + k < mine.size() && !st; ++k) {
+                const int l = mine[i0 + k];
+                msm_group::Lane &lane = g->lanes[k0 + k];
+                AdaptiveDev w;
+                DevTree tree;
+                if (forest) tree = forest_tree(b.forest, l);
+                st = adaptive_weights_dev(lane.mesh, g->tmpl, w, false, forest ? &tree : nullptr);
+                if (!st) st = apply_weights_dev(lane.ctx, w, b.d_feat.p, D, g->F[(size_t)s * L + l]->p);
+            }
+        }
+        for (int k = k0; k < k1; ++k) {
+            const int st2 = check_status(g->lanes[k].ctx, "get_patch_data (resampling)");  // synchronises the lane
+            if (!st) st = st2;
+        }
+        status[th] = st;
+        if (st) message[th] = msm_last_error();  // the error text is per thread
+    };
+    if (nthreads == 1) {
+        drive(0);
+    } else {
+        std::vector<std::thread> pool;
+        for (int th = 1; th < nthreads; ++th) pool.emplace_back(drive, th);
+        drive(0);
+        for (auto &t : pool) t.join();
+    }
+    for (int th = 0; th < nthreads; ++th)
+        if (status[th]) return fail(status[th], "%s", message[th].c_str());
+    return MSM_OK;
+}
+
+// The subjects of this rank, pipelined: while the lanes work through subject i, the main stream prepares subject i + 1 (rotations,
+// forest) and builds subject i's patch lists (which only need the template and the control grid).
+static int group_setup_pipeline(msm_group *g, const int32_t *subjects, int n) {
+    if (n <= 0) return MSM_OK;
+    msm_ctx *ctx = g->ctx;
+    const bool timing = std::getenv("MSMHIP_TIMING") != nullptr;
+    // the template's search structure and adjacency are read by every lane: complete before they start
+    int st = ensure_tree(g->tmpl);
+    if (st) return st;
+    st = ensure_adjacency_dev(g->tmpl);
+    if (st) return st;
+    MSM_HIP(hipStreamSynchronize(ctx->stream));
+    auto t0 = std::chrono::steady_clock::now();
+    st = stage_prepare(g, subjects[0], g->stage[0]);
+    if (st) return st;
+    for (int i = 0; i < n; ++i) {
+        const int s = subjects[i];
+        msm_group::Stage &cur = g->stage[i & 1];
+        int st_lanes = MSM_OK;
+        std::string msg_lanes;
+        std::thread lanes([&] {
+            (void)hipSetDevice(ctx->device);
+            st_lanes = stage_lanes(g, s, cur);
+            if (st_lanes) msg_lanes = msm_last_error();
+        });
+        int st_main = MSM_OK;
+        if (i + 1 < n) st_main = stage_prepare(g, subjects[i + 1], g->stage[(i + 1) & 1]);
+        if (!st_main) st_main = subject_patches(g, s);
+        lanes.join();
+        if (st_lanes) return fail(st_lanes, "%s", msg_lanes.c_str());
+        if (st_main) return st_main;
+        g->have_subject[s] = 1;
+        if (timing) {
+            const auto now = std::chrono::steady_clock::now();
+            fprintf(stderr, "  group set-up, subject %d: %.1f ms (lanes || next subject's rotations + forest, this subject's patches)\n", s,
+                    std::chrono::duration<double, std::milli>(now - t0).count());
+            t0 = now;
+        }
+    }
+    return MSM_OK;
+}
+
 // get_patch_data for one subject, M/DiscreteGroupModel.cpp:88-121
 // DiscreteGroupModel::get_patch_data for one subject (M/DiscreteGroupModel.cpp:88-121).  Per label: rotate the data
 // mesh, build its octree, resample the features to the template with adaptive barycentric weights.  The rotations
@@ -595,110 +760,6 @@ int group_subject_setup(msm_group *g, int s) {
     std::vector<std::vector<double>> rotated(L);
     const size_t LV = (size_t)L * V;
     DevBuf<double> &d_rot = g->d_rotated;
-    static const bool host_surgery = [] { const char *e = std::getenv("MSMHIP_SURGERY"); return e && std::strcmp(e, "host") == 0; }();
-    static const bool host_trees = [] { const char *e = std::getenv("MSMHIP_OCTREE"); return e && std::strcmp(e, "host") == 0; }();
-    if (!host_trees && !host_surgery) {
-        // Everything in HBM (data meshes large enough for the GPU octree build): per label the rotated coordinates become the
-        // scratch mesh's, its tree is rebuilt there, and queries, weight-list surgery (resample_kernels.hip) and the weighted sums
-        // write F[s][l] directly.  Only the subject's features go up; nothing comes back.
-        MSM_HIP(d_rot.ensure(3 * LV));
-        for (int a = 0; a < 3; ++a)
-            MSM_HIP(hipMemcpyAsync(d_rot.p + a * LV, dm->d_xyz + (size_t)a * V, sizeof(double) * (size_t)V, hipMemcpyDeviceToDevice, ctx->stream));
-        for (int l = 1; l < L; ++l) {
-            const double lab[3] = {g->labels[l], g->labels[L + l], g->labels[2 * (size_t)L + l]};
-            int st = launch_rotate_to_label(ctx, dm->d_xyz, V, centre, lab, d_rot.p + (size_t)l * V, LV);
-            if (st) return st;
-        }
-        MSM_HIP(g->d_subject_feat.ensure((size_t)D * V));
-        int st = upload_staged(ctx, g->d_subject_feat.p, g->feat[s].data(), sizeof(double) * (size_t)D * V);
-        if (st) return st;
-        st = subject_feature_slab(g, s, (size_t)D * Vt);
-        if (st) return st;
-        // the template's search structure and adjacency are read by every lane: complete before they start
-        st = ensure_tree(g->tmpl);
-        if (st) return st;
-        st = ensure_adjacency_dev(g->tmpl);
-        if (st) return st;
-        st = ensure_lanes(g, dm);
-        if (st) return st;
-        // the L trees of the rotated meshes, built together (one chain of launches per subject instead of one per label); a tree
-        // that outgrows its arrays (a degenerate mesh) sends the subject down the per-label builds of the lanes
-        static const bool no_forest = [] { const char *e = std::getenv("MSMHIP_GROUP_FOREST"); return e && std::strcmp(e, "off") == 0; }();
-        bool forest = !no_forest;
-        if (forest) {
-            st = gpu_build_forest(ctx, g->forest, d_rot.p, LV, (size_t)V, V, dm->d_tri, T, L);
-            if (st == MSM_ERR_CAPACITY) forest = false;
-            else if (st) return st;
-        }
-        MSM_HIP(hipStreamSynchronize(ctx->stream));  // rotations, features and trees are where the lanes will read them
-        lap(forest ? "rotations + feature upload + forest" : "rotations + feature upload");
-        // Per label: the rotated coordinates become a lane mesh's, its tree is built, then queries, surgery and the weighted sums.
-        // One such pipeline is a dependent chain of some eighty kernels of a few microseconds each; the lanes run K of them side
-        // by side.  The host queues the first half of K labels (up to where the tree build's outcome is looked at), then the second
-        // half of each, so that it never waits for work it has only just submitted.
-        // Submitting eighty launches per label is itself 0.4 ms of host time, so the lanes are driven by (two) host threads, each
-        // with its share of the lanes and every other label.
-        const int K = (int)g->lanes.size();
-        static const int want_threads = [] {
-            const char *e = std::getenv("MSMHIP_GROUP_THREADS");
-            const int v = e ? std::atoi(e) : 2;
-            return v < 1 ? 1 : (v > 4 ? 4 : v);
-        }();
-        const int nthreads = std::max(1, std::min(want_threads, K));
-        std::vector<int> status(nthreads, MSM_OK);
-        std::vector<std::string> message(nthreads);
-        auto drive = [&](int th) {
-            int st = MSM_OK;
-            (void)hipSetDevice(ctx->device);
-            const int k0 = th * K / nthreads, k1 = (th + 1) * K / nthreads, Kt = k1 - k0;
-            std::vector<int> mine;
-            for (int l = th; l < L; l += nthreads) mine.push_back(l);
-            for (size_t i0 = 0; i0 < mine.size() && !st; i0 += Kt) {
-                for (int k = 0; k < Kt && i0 + k < mine.size() && !st; ++k) {
-                    const int l = mine[i0 + k];
-                    msm_group::Lane &lane = g->lanes[k0 + k];
-                    for (int a = 0; a < 3 && !st; ++a)
-                        if (hipMemcpyAsync(lane.mesh->d_xyz + (size_t)a * V, d_rot.p + a * LV + (size_t)l * V, sizeof(double) * (size_t)V, hipMemcpyDeviceToDevice,
-                                           lane.ctx->stream) != hipSuccess)
-                            st = fail(MSM_ERR_HIP, "get_patch_data: device copy of the rotated coordinates failed");
-                    lane.mesh->tree_valid = false;
-                    lane.mesh->host_xyz_stale = true;
-                    if (!st && !forest) st = ensure_tree_begin(lane.mesh);
-                }
-                for (int k = 0; k < Kt && i0 + k < mine.size() && !st; ++k) {
-                    const int l = mine[i0 + k];
-                    msm_group::Lane &lane = g->lanes[k0 + k];
-                    AdaptiveDev w;
-                    DevTree tree;
-                    if (forest) tree = forest_tree(g->forest, l);
-                    st = adaptive_weights_dev(lane.mesh, g->tmpl, w, false, forest ? &tree : nullptr);
-                    if (!st) st = apply_weights_dev(lane.ctx, w, g->d_subject_feat.p, D, g->F[(size_t)s * L + l]->p);
-                }
-            }
-            for (int k = k0; k < k1; ++k) {
-                const int st2 = check_status(g->lanes[k].ctx, "get_patch_data (resampling)");  // synchronises the lane
-                if (!st) st = st2;
-            }
-            status[th] = st;
-            if (st) message[th] = msm_last_error();  // the error text is per thread
-        };
-        if (nthreads == 1) {
-            drive(0);
-        } else {
-            std::vector<std::thread> pool;
-            for (int th = 1; th < nthreads; ++th) pool.emplace_back(drive, th);
-            drive(0);
-            for (auto &t : pool) t.join();
-        }
-        for (int th = 0; th < nthreads; ++th)
-            if (status[th]) return fail(status[th], "%s", message[th].c_str());
-        lap("trees + queries + weights + resample (device)");
-        st = subject_patches(g, s);
-        if (st) return st;
-        lap("patches");
-        g->have_subject[s] = 1;
-        return MSM_OK;
-    }
     {
         MSM_HIP(d_rot.ensure(3 * LV));
         for (int a = 0; a < 3; ++a)  // label 0 is the centre of the sampling grid: no rotation
@@ -817,8 +878,10 @@ int msm_group_setup_subjects(msm_group *g, const int32_t *subjects, int32_t n) {
     g->common_ready = false;
     int st = group_common_setup(g);
     if (st) return st;
-    for (int i = 0; i < n; ++i) {
+    for (int i = 0; i < n; ++i)
         if (subjects[i] < 0 || subjects[i] >= g->S) return fail(MSM_ERR_INVALID, "subject %d out of range", subjects[i]);
+    if (group_device_path()) return group_setup_pipeline(g, subjects, n);
+    for (int i = 0; i < n; ++i) {
         st = group_subject_setup(g, subjects[i]);
         if (st) return st;
     }
