@@ -265,3 +265,50 @@ def test_sharded_group_two_ranks_match_single_rank(tmp_path):
         outs.append(eval(so.strip().splitlines()[-1].replace("true", "True").replace("false", "False")))
     assert all(o["equal"] and o["move_ok"] and o["template_radius_ok"] and o["n"] == 4 and o["finite"] > 200 for o in outs), outs
     assert sorted(outs[0]["mine"] + outs[1]["mine"]) == [0, 1, 2, 3]
+
+
+def test_group_full_size_properties_64_subjects_ico6(ctx):
+    """BASELINE config 5 at full size (64 subjects, ico6 data / ico4 control grid, 19 labels; the oracle takes minutes per subject
+    here, so this is checked through size-independent properties): a whole label step (20.7 M pair + 2.6 M triplet costs, processed
+    control point by control point in four pieces, delivered into pinned memory behind the kernels) equals the explicit batch
+    evaluators on sampled cliques, slices of the step equal the whole, no cost is left unwritten, and a second set-up
+    (pipelined, forest build, six lanes) reproduces the first bit for bit."""
+    from newmsm_amd import problem
+
+    S = 64
+    g, keep = problem.build_group(ctx, S, 6, 4, D=2)
+    g.setupCostFunction()
+    assert (g.num_nodes, g.P, g.T) == (S * 2562, 2562 * S * (S - 1) // 2, S * 5120)
+    rng = np.random.default_rng(9)
+    labeling = rng.integers(0, g.L, g.num_nodes).astype(np.int32)
+    label = 11
+    out = (ctx.host_array((g.P, 4)), ctx.host_array((g.T, 8)))
+    out[0][:] = -7.0
+    out[1][:] = -7.0
+    quads, octets = g.fusionMove(labeling, label, out=out)
+    assert not (quads == -7.0).any() and not (octets == -7.0).any()
+    pairs, trips = g.getPairs(), g.getTriplets()
+    p = rng.integers(0, g.P, 20000).astype(np.int32)
+    k = rng.integers(0, 4, 20000)
+    la = np.where(k & 2, label, labeling[pairs[p, 0]]).astype(np.int32)
+    lb = np.where(k & 1, label, labeling[pairs[p, 1]]).astype(np.int32)
+    assert np.array_equal(quads[p, k], g.computePairwiseCost(p, la, lb), equal_nan=True)
+    t = rng.integers(0, g.T, 20000).astype(np.int32)
+    k = rng.integers(0, 8, 20000)
+    lab3 = [np.where(k >> (2 - j) & 1, label, labeling[trips[t, j]]).astype(np.int32) for j in range(3)]
+    assert np.array_equal(octets[t, k], g.computeTripletCost(t, *lab3))
+    finite = np.isfinite(quads)
+    assert finite.mean() > 0.99 and (quads[finite] >= 0).all() and (quads[finite] <= 1.0 + 1e-12).all()  # 1 - (1 + r) / 2
+    # a rank's slice of the step (pairs and triplets of the middle eighth), delivered into pinned memory as the ranks of a node do
+    p0, p1, t0, t1 = 3 * g.P // 8, 4 * g.P // 8, 3 * g.T // 8, 4 * g.T // 8
+    part = ctx.host_array((4 * (p1 - p0) + 8 * (t1 - t0),))
+    part[:] = -7.0
+    g.fusionMove_dev(labeling, label, (p0, p1), (t0, t1), part.ctypes.data, part.ctypes.data + 8 * 4 * (p1 - p0))
+    assert np.array_equal(part[: 4 * (p1 - p0)].reshape(-1, 4), quads[p0:p1], equal_nan=True)
+    assert np.array_equal(part[4 * (p1 - p0):].reshape(-1, 8), octets[t0:t1])
+    # the set-up is deterministic: the second one (buffers allocated, pipeline warm) gives the same step
+    first = quads.copy(), octets.copy()
+    g.setupCostFunction()
+    q2, o2 = g.fusionMove(labeling, label, out=out)
+    assert np.array_equal(q2, first[0], equal_nan=True) and np.array_equal(o2, first[1])
+    g.close()
