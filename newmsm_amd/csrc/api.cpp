@@ -456,10 +456,11 @@ int vertex_areas(msm_mesh *m, std::vector<double> &area) {
     return MSM_OK;
 }
 
-// Resampler::get_adaptive_barycentric_weights, R/resampler.cpp:72-140, in two halves: the 2 x N nearest-triangle
-// queries run on the GPU (adaptive_queries); the list surgery (transpose, pick, area correction) is done on the
-// host in the reference's serial order so that every sum has the same operand order (adaptive_surgery: touches
-// no handle, so callers may run several of them on worker threads).
+// Resampler::get_adaptive_barycentric_weights, R/resampler.cpp:72-140, the variant with an exclusion mask (and the comparison
+// path MSMHIP_SURGERY=host), in two halves: the 2 x N nearest-triangle queries run on the GPU (adaptive_queries); the list
+// surgery (transpose, pick, area correction) is done on the host in the reference's serial order so that every sum has the
+// same operand order (adaptive_surgery: touches no handle, so callers may run several of them on worker threads).  Without a
+// mask everything runs on the device: adaptive_weights_dev below.
 int adaptive_queries(msm_mesh *in_mesh, msm_mesh *new_mesh, bool with_closest, AdaptiveQueries &q, int directions) {
     const int nOld = in_mesh->V, nNew = new_mesh->V;
     q.fvid.resize(3 * (size_t)nNew);

@@ -2,9 +2,10 @@
 //
 // DiscreteGroupModel::setupCostFunction (M/DiscreteGroupModel.cpp:163-196) is per-iteration set-up: closest
 // control points between subjects, and for every (subject, label) a rigid rotation of the data mesh followed by
-// an adaptive-barycentric resample of its features to the template.  All nearest-triangle queries run on the
-// GPU; the resampled feature maps F[subject][label] (D x V_template) and the patch lists stay in HBM, where the
-// pairwise kernel reads them (group_kernels.hip).
+// an adaptive-barycentric resample of its features to the template.  All of it runs on the GPU (trees as a forest,
+// queries, weight-list surgery, weighted sums, patch lists: DESIGN.md section 5.6); the resampled feature maps
+// F[subject][label] (D x V_template) and the patch lists stay in HBM, where the pairwise kernel reads them
+// (group_kernels.hip).
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -733,12 +734,11 @@ static int group_setup_pipeline(msm_group *g, const int32_t *subjects, int n) {
     return MSM_OK;
 }
 
-// get_patch_data for one subject, M/DiscreteGroupModel.cpp:88-121
-// DiscreteGroupModel::get_patch_data for one subject (M/DiscreteGroupModel.cpp:88-121).  Per label: rotate the data
-// mesh, build its octree, resample the features to the template with adaptive barycentric weights.  The rotations
-// and the 2 x N nearest-triangle queries run on the GPU; the octree builds (the reference's incremental insertion,
-// whose order decides the leaves) and the weight-list surgery are host work, independent per label, and are spread
-// over the host cores in two parallel phases around the GPU phase.
+// DiscreteGroupModel::get_patch_data for one subject (M/DiscreteGroupModel.cpp:88-121), the comparison path of
+// MSMHIP_OCTREE=host / MSMHIP_SURGERY=host (round 1's division of labour; the default is group_setup_pipeline above).  Per label:
+// rotate the data mesh, build its octree, resample the features to the template with adaptive barycentric weights.  The
+// rotations and the 2 x N nearest-triangle queries run on the GPU; the octree builds and the weight-list surgery are host
+// work here, independent per label, spread over the host cores in two parallel phases around the GPU phase.
 int group_subject_setup(msm_group *g, int s) {
     if (!g->data[s]) return fail(MSM_ERR_STATE, "msm_group: subject %d has no data", s);
     msm_ctx *ctx = g->ctx;
