@@ -86,6 +86,11 @@ struct msm_group {
     std::vector<int32_t> pair_order;     // the pair list in processing order (control points along a space-filling curve)
     DevBuf<int> d_pair_order;            // ... restricted to the slice [order_p0, order_p1) last asked for
     int64_t order_p0 = -1, order_p1 = -1;
+    // the (current, current) pair costs of the last label step and the labeling they were computed for (GroupArgs::move_e00)
+    DevBuf<double> d_e00;
+    DevBuf<int> d_prev_labeling;
+    bool e00_valid = false;
+    int64_t e00_p0 = -1, e00_p1 = -1;
     std::vector<int64_t> order_chunk;    // the slice's order is cut into pieces by OUTPUT range: piece k holds the pairs [order_chunk[k], order_chunk[k+1]) of the slice
     hipStream_t copy_stream = nullptr;   // the finished pieces of a label step leave for the host while the next ones are computed
     std::vector<hipEvent_t> copy_events;
@@ -257,6 +262,9 @@ int group_args(msm_group *g, GroupArgs &a) {
     a.move_label = a.move_offset = 0;
     a.move_order = nullptr;
     a.move_base = 0;
+    a.move_combos = 0;
+    a.move_prev = nullptr;
+    a.move_e00 = nullptr;
     a.patch_cap = g->patch_max;
     a.status = g->ctx->d_status;
     return MSM_OK;
@@ -350,6 +358,7 @@ int msm_group_set_template(msm_group *g, msm_mesh *t, const double *mask) {
     }
     g->ready = false;
     g->common_ready = false;
+    g->e00_valid = false;
     return MSM_OK;
 }
 
@@ -375,6 +384,7 @@ int msm_group_set_controlgrid(msm_group *g, const double *xyz, const int32_t *tr
     MSM_HIP(hipStreamSynchronize(g->ctx->stream));
     g->ready = false;
     g->common_ready = false;
+    g->e00_valid = false;
     return MSM_OK;
 }
 
@@ -403,6 +413,7 @@ int msm_group_set_subject(msm_group *g, int32_t s, msm_mesh *data, const double 
     }
     g->ready = false;
     g->common_ready = false;
+    g->e00_valid = false;
     return MSM_OK;
 }
 
@@ -410,6 +421,7 @@ int msm_group_reset_cpgrid(msm_group *g, int32_t s, const double *xyz) {
     if (!g || !xyz || s < 0 || s >= g->S || !g->cpmesh[s]) return fail(MSM_ERR_INVALID, "msm_group_reset_cpgrid: bad arguments");
     g->ready = false;
     g->common_ready = false;
+    g->e00_valid = false;
     return msm_mesh_update_coords(g->cpmesh[s], xyz);
 }
 
@@ -419,6 +431,7 @@ int msm_group_set_labels(msm_group *g, const double *labels, int32_t L) {
     g->labels.assign(labels, labels + 3 * (size_t)L);
     g->ready = false;
     g->common_ready = false;
+    g->e00_valid = false;
     return MSM_OK;
 }
 
@@ -876,6 +889,7 @@ int msm_group_setup_subjects(msm_group *g, const int32_t *subjects, int32_t n) {
     if (!g || (n > 0 && !subjects) || n < 0) return fail(MSM_ERR_INVALID, "msm_group_setup_subjects: bad arguments");
     g->ready = false;
     g->common_ready = false;
+    g->e00_valid = false;
     int st = group_common_setup(g);
     if (st) return st;
     for (int i = 0; i < n; ++i)
@@ -1026,6 +1040,7 @@ int msm_group_finalize(msm_group *g) {
     MSM_HIP(g->d_pptrp.upload(pp.data(), pp.size(), ctx->stream));
     MSM_HIP(g->d_pidxp.upload(pi.data(), pi.size(), ctx->stream));
     MSM_HIP(hipStreamSynchronize(ctx->stream));
+    g->e00_valid = false;  // new patches: nothing kept from earlier label steps applies
     g->patch_max = 0;
     for (int s = 0; s < S; ++s)
         for (size_t k = 0; k + 1 < g->h_pptr[s].size(); ++k) g->patch_max = std::max(g->patch_max, g->h_pptr[s][k + 1] - g->h_pptr[s][k]);
@@ -1185,20 +1200,46 @@ static int group_move_compute(msm_group *g, const int32_t *labeling, int32_t lab
         st = slice_pair_order(g, pair0, pair1, &a.move_order);
         if (st) return st;
         a.move_base = (int)pair0;
+        // The (current, current) combination of a pair does not depend on the proposed label: it is evaluated in a pass of its own
+        // (whole wavefronts of pairs whose two nodes kept their labels since the last step leave at once with the kept cost), the
+        // three combinations with the proposed label in a second pass.  MSMHIP_GROUP_E00=off: all four together, nothing kept.
+        static const bool keep_e00 = [] { const char *e = std::getenv("MSMHIP_GROUP_E00"); return !(e && std::strcmp(e, "off") == 0); }();
+        const bool dice = g->p.simmeasure == 4 || g->p.simmeasure == 5;
+        const bool two_pass = keep_e00 && !dice;
+        if (two_pass) {
+            const int64_t P = (int64_t)(g->pairs.size() / 2);
+            MSM_HIP(g->d_e00.ensure((size_t)std::max<int64_t>(P, 1)));
+            MSM_HIP(g->d_prev_labeling.ensure(nodes));
+            a.move_e00 = g->d_e00.p;
+            a.move_prev = (g->e00_valid && g->e00_p0 == pair0 && g->e00_p1 == pair1) ? g->d_prev_labeling.p : nullptr;
+            g->e00_valid = false;  // until this step has gone through: a failure half way leaves nothing to rely on
+        }
         for (size_t k = 0; k + 1 < g->order_chunk.size(); ++k) {
-            const int64_t q0 = 4 * g->order_chunk[k], q1 = 4 * g->order_chunk[k + 1];
-            for (int64_t off = q0; off < q1; off += kBatchChunk) {
-                const int m = (int)std::min<int64_t>(kBatchChunk, q1 - off);
-                if (off > 0x7fffffffll - kBatchChunk) return fail(MSM_ERR_CAPACITY, "%s: evaluation index beyond 2^31", who);
-                a.move_offset = (int)off;
-                st = launch_group_pairwise(ctx, a, nullptr, nullptr, nullptr, m, quads_dev);
-                if (st) return st;
+            const int64_t n0 = g->order_chunk[k], n1 = g->order_chunk[k + 1];  // pairs of the piece, in processing order
+            for (int pass = two_pass ? 1 : 0; pass <= (two_pass ? 2 : 0); ++pass) {
+                const int64_t mult = pass == 0 ? 4 : (pass == 1 ? 1 : 3), q0 = mult * n0, q1 = mult * n1;
+                a.move_combos = pass;
+                for (int64_t off = q0; off < q1; off += kBatchChunk) {
+                    const int m = (int)std::min<int64_t>(kBatchChunk, q1 - off);
+                    if (off > 0x7fffffffll - kBatchChunk) return fail(MSM_ERR_CAPACITY, "%s: evaluation index beyond 2^31", who);
+                    a.move_offset = (int)off;
+                    st = launch_group_pairwise(ctx, a, nullptr, nullptr, nullptr, m, quads_dev);
+                    if (st) return st;
+                }
             }
             if (after_piece) {
-                st = (*after_piece)((int)k, g->order_chunk[k], g->order_chunk[k + 1]);
+                st = (*after_piece)((int)k, n0, n1);
                 if (st) return st;
             }
         }
+        if (two_pass) {  // what the next step compares with
+            MSM_HIP(hipMemcpyAsync(g->d_prev_labeling.p, g->d_query[0].p, sizeof(int32_t) * (size_t)nodes, hipMemcpyDeviceToDevice, ctx->stream));
+            g->e00_valid = true;
+            g->e00_p0 = pair0, g->e00_p1 = pair1;
+        }
+        a.move_combos = 0;
+        a.move_prev = nullptr;
+        a.move_e00 = nullptr;
     }
     a.move_order = nullptr;
     const int64_t first = 8 * trip0, total = 8 * (trip1 - trip0);

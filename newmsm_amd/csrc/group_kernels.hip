@@ -115,12 +115,24 @@ __global__ __launch_bounds__(256) void k_group_pairwise(GroupArgs a, const int *
     extern __shared__ double s_common[];
     int pair, la, lb;
     size_t at = (size_t)q;
+    double *keep = nullptr;  // where this query's cost is kept for the next label step
     if (a.move_labeling) {  // Fusion's pair_data[pair].buffer[k], I/Fusion/Fusion.h:170-173: k = 2 * (A takes the label) + (B takes it)
         const int e = q + a.move_offset;
-        pair = a.move_order ? a.move_order[e >> 2] : e >> 2;
-        if (a.move_order) at = 4 * (size_t)(pair - a.move_base) + (e & 3);
-        la = (e & 2) ? a.move_label : a.move_labeling[a.pairs[2 * pair]];
-        lb = (e & 1) ? a.move_label : a.move_labeling[a.pairs[2 * pair + 1]];
+        const int idx = a.move_combos == 0 ? e >> 2 : (a.move_combos == 1 ? e : e / 3);
+        const int k = a.move_combos == 0 ? (e & 3) : (a.move_combos == 1 ? 0 : 1 + (e - 3 * idx));
+        pair = a.move_order ? a.move_order[idx] : idx;
+        if (a.move_order) at = 4 * (size_t)(pair - a.move_base) + k;
+        const int nodeA = a.pairs[2 * pair], nodeB = a.pairs[2 * pair + 1];
+        const int curA = a.move_labeling[nodeA], curB = a.move_labeling[nodeB];
+        if (k == 0 && a.move_e00) {
+            if (a.move_prev && a.move_prev[nodeA] == curA && a.move_prev[nodeB] == curB) {  // same patches as in the previous step
+                if (lane == 0) out[at] = a.move_e00[pair];
+                return;
+            }
+            keep = a.move_e00 + pair;
+        }
+        la = (k & 2) ? a.move_label : curA;
+        lb = (k & 1) ? a.move_label : curB;
     } else {
         pair = qp[q], la = qa[q], lb = qb[q];
     }
@@ -265,7 +277,10 @@ __global__ __launch_bounds__(256) void k_group_pairwise(GroupArgs a, const int *
                 cost /= a.D;
             }
             if (a.fixnan && cost != cost) cost = 1e7;  // FIX_NAN, M/reg_tools.h:31
-            if (lane == 0) out[at] = cost;
+            if (lane == 0) {
+                out[at] = cost;
+                if (keep) *keep = cost;
+            }
             return;
         }
     }
@@ -365,7 +380,10 @@ __global__ __launch_bounds__(256) void k_group_pairwise(GroupArgs a, const int *
         cost /= a.D;
     }
     if (a.fixnan && cost != cost) cost = 1e7;  // FIX_NAN, M/reg_tools.h:31
-    if (lane == 0) out[at] = cost;
+    if (lane == 0) {
+        out[at] = cost;
+        if (keep) *keep = cost;
+    }
 }
 
 __global__ __launch_bounds__(128) void k_group_triplet(GroupArgs a, const int *__restrict__ qt, const int *__restrict__ qa,

@@ -213,6 +213,14 @@ struct GroupArgs {
     // order, the work runs control-point tile by tile (group.cpp: pair_order)
     const int *move_order;
     int move_base;
+    // which combinations of a pair a launch evaluates: 0 all four (query i -> pair i / 4, combination i % 4), 1 only (current,
+    // current) (query i -> pair i), 2 the three with the proposed label (query i -> pair i / 3, combination 1 + i % 3).  The
+    // (current, current) cost of a pair does not depend on the proposed label: move_e00[pair] keeps it from one label step to the
+    // next, and a pair neither of whose nodes changed its label since (move_prev: the previous step's labeling, nullptr: nothing
+    // kept yet) takes it from there.
+    int move_combos;
+    const int *move_prev;
+    double *move_e00;
     int patch_cap;               // largest patch of any subject (DICE: LDS staging of the common entries)
     int *status;
 };

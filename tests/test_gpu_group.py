@@ -312,3 +312,36 @@ def test_group_full_size_properties_64_subjects_ico6(ctx):
     q2, o2 = g.fusionMove(labeling, label, out=out)
     assert np.array_equal(q2, first[0], equal_nan=True) and np.array_equal(o2, first[1])
     g.close()
+
+
+def test_group_label_steps_reuse_the_current_current_costs(ctx):
+    """A run of label steps as Fusion makes them: the labeling changes at some nodes between steps.  The (current, current) cost of a
+    pair is kept from the previous step and reused when neither node changed its label; every step must equal the step evaluated
+    from scratch (explicit batches), including the first, a step with an unchanged labeling, one after a new set-up and a sliced
+    step in between (which has a cache of its own extent)."""
+    g, og, _ = build(ctx, S=4, data_order=4, cp_order=2, D=2)
+    rng = np.random.default_rng(17)
+    pairs = g.getPairs()
+    p = np.repeat(np.arange(g.P, dtype=np.int32), 4)
+    k = np.tile(np.arange(4), g.P)
+
+    def from_scratch(labeling, label):
+        la = np.where(k & 2, label, labeling[pairs[p, 0]]).astype(np.int32)
+        lb = np.where(k & 1, label, labeling[pairs[p, 1]]).astype(np.int32)
+        return g.computePairwiseCost(p, la, lb).reshape(g.P, 4)
+
+    labeling = rng.integers(0, g.L, g.num_nodes).astype(np.int32)
+    for step in range(8):
+        label = int(rng.integers(0, g.L))
+        quads, _ = g.fusionMove(labeling, label)
+        assert np.array_equal(quads, from_scratch(labeling, label), equal_nan=True), step
+        if step == 3:
+            g.setupCostFunction()  # new patches: nothing kept applies
+        if step == 5:  # a slice of a step in between
+            import ctypes
+            part = ctx.host_array((4 * (g.P // 2),))
+            g.fusionMove_dev(labeling, label, (0, g.P // 2), (0, 0), part.ctypes.data, 0)
+            assert np.array_equal(part.reshape(-1, 4), quads[: g.P // 2], equal_nan=True)
+        if step != 2:  # step 2 -> 3: the same labeling again
+            change = rng.random(g.num_nodes) < 0.15
+            labeling = np.where(change, rng.integers(0, g.L, g.num_nodes), labeling).astype(np.int32)
