@@ -86,6 +86,11 @@ struct msm_group {
     std::vector<int32_t> pair_order;     // the pair list in processing order (control points along a space-filling curve)
     DevBuf<int> d_pair_order;            // ... restricted to the slice [order_p0, order_p1) last asked for
     int64_t order_p0 = -1, order_p1 = -1;
+    Forest cp_forest;                    // the search trees of the S control grids, built together (estimate_pairs)
+    DevBuf<double> d_cp_soa, d_rot, d_spacing, d_labels3;  // control points by component; ROT per node; spacing per node; labels 3 x L
+    DevBuf<int2> d_forest_info;
+    int64_t npairs = 0;                  // N * S * (S - 1) / 2; the host copy of the list (pairs) is fetched when asked for
+    bool moved_on_host = false;          // g->moved mirrors d_moved (fetched for the rare host decisions of subject_patches)
     // the (current, current) pair costs of the last label step and the labeling they were computed for (GroupArgs::move_e00)
     DevBuf<double> d_e00;
     DevBuf<int> d_prev_labeling;
@@ -133,21 +138,15 @@ int subject_patches(msm_group *g, int s) {
         fprintf(stderr, "      patches: %s %.1f ms\n", what, std::chrono::duration<double, std::milli>(now - tick).count());
         tick = now;
     };
-    std::vector<double> centres(3 * (size_t)M), sep(M);
-    for (int v = 0; v < N; ++v)
-        for (int l = 0; l < L; ++l) {
-            const double *m = &g->moved[(((size_t)s * N + v) * L + l) * 3];
-            const int k = v * L + l;
-            centres[k] = m[0];
-            centres[M + k] = m[1];
-            centres[2 * (size_t)M + k] = m[2];
-            sep[k] = g->spacing[s][v];
-        }
     DevBuf<double> &d_c = g->d_centres, &d_sep = g->d_sep;
     DevBuf<uint32_t> &d_slots = g->d_slots;
     DevBuf<int> &d_counts = g->d_counts;
-    MSM_HIP(d_c.upload(centres.data(), centres.size(), ctx->stream));
-    MSM_HIP(d_sep.upload(sep.data(), sep.size(), ctx->stream));
+    MSM_HIP(d_c.ensure(3 * (size_t)M));
+    MSM_HIP(d_sep.ensure(M));
+    {
+        int st = launch_group_centres(ctx, g->d_moved.p + 3 * (size_t)s * M, g->d_spacing.p + (size_t)s * N, N, L, d_c.p, d_sep.p);
+        if (st) return st;
+    }
     MSM_HIP(d_counts.ensure((size_t)M + 1));  // + the number of undecided entries
     MSM_HIP(g->d_chunkb.ensure((size_t)(Vt + 63) / 64 + 1));
     int cap = std::max(256, g->patch_cap_hint);  // the previous call's largest patch: one k_range pass instead of two
@@ -194,6 +193,11 @@ int subject_patches(msm_group *g, int s) {
     auto &pi = g->h_pidx[s];
     pp.assign(M + 1, 0);
     const double *tx = g->tmpl->xyz.data();
+    // the centres and spacings the kernel used, for the host's decisions (this branch is rare: exact ties)
+    std::vector<double> centres(3 * (size_t)M), sep(M);
+    MSM_HIP(d_c.download(centres.data(), centres.size(), ctx->stream));
+    MSM_HIP(d_sep.download(sep.data(), sep.size(), ctx->stream));
+    MSM_HIP(hipStreamSynchronize(ctx->stream));
     // an entry flagged by the kernel sits within 1e-11 of the threshold: decided with the host libm, as the reference does
     auto keeps = [&](int k, uint32_t e) {
         if (!(e & 0x80000000u)) return true;
@@ -453,10 +457,45 @@ int group_common_setup(msm_group *g) {
         fprintf(stderr, "  group set-up, common: %s %.1f ms\n", what, std::chrono::duration<double, std::milli>(now - tick).count());
         tick = now;
     };
-    // estimate_pairs, M/DiscreteGroupModel.cpp:37-55: closest control point of subject B for every control point of A
-    g->pairs.resize((size_t)N * S * (S - 1));
+    // estimate_pairs, M/DiscreteGroupModel.cpp:37-55: closest control point of subject B for every control point of A.  The S
+    // control grids share their triangle list, so their search trees are built together as a forest and one kernel writes the
+    // whole list (N S (S - 1) / 2 pairs: 5.2 M at S = 64) where the cost kernels read it.  Round 1 / the first half of round 2:
+    // S - 1 search calls with host trees and host loops, 67 ms at S = 64 on every rank.
+    g->npairs = (int64_t)N * S * (S - 1) / 2;
+    g->pairs.clear();
+    std::vector<double> cp_soa(3 * (size_t)S * N);
+    for (int s = 0; s < S; ++s)
+        for (int ax = 0; ax < 3; ++ax)
+            std::copy(g->cpmesh[s]->xyz.begin() + (size_t)ax * N, g->cpmesh[s]->xyz.begin() + (size_t)(ax + 1) * N, cp_soa.begin() + (size_t)ax * S * N + (size_t)s * N);
+    MSM_HIP(g->d_cp_soa.ensure(cp_soa.size()));
     {
-        // one search per TARGET subject b over the control points of all earlier subjects (S - 1 launches instead of S (S - 1) / 2)
+        int st = upload_staged(ctx, g->d_cp_soa.p, cp_soa.data(), sizeof(double) * cp_soa.size());
+        if (st) return st;
+    }
+    MSM_HIP(g->d_pairs.ensure(std::max<size_t>(2 * (size_t)g->npairs, 1)));
+    bool pairs_done = false;
+    if (S >= 2) {
+        int st = gpu_build_forest(ctx, g->cp_forest, g->d_cp_soa.p, (size_t)S * N, (size_t)N, N, g->cpmesh[0]->d_tri, g->Tc, S);
+        if (st == MSM_OK) {
+            std::vector<int2> info(S);
+            for (int b = 0; b < S; ++b) info[b] = make_int2(g->cp_forest.info[b].nnodes, g->cp_forest.info[b].grid_depth);
+            MSM_HIP(g->d_forest_info.upload(info.data(), info.size(), ctx->stream));
+            ForestDev fd;
+            fd.node = g->cp_forest.node.p, fd.parent = g->cp_forest.parent.p, fd.leaf_tri = g->cp_forest.leaf_tri.p, fd.grid = g->cp_forest.grid.p;
+            fd.cone = g->cp_forest.cone.p, fd.rec = g->cp_forest.rec.p;
+            fd.s_node = g->cp_forest.s_node, fd.s_leaf = g->cp_forest.s_leaf, fd.s_rec = g->cp_forest.s_rec, fd.s_grid = g->cp_forest.s_grid;
+            fd.info = g->d_forest_info.p;
+            st = launch_group_pairs(ctx, fd, g->d_cp_soa.p, S, N, g->d_pairs.p);
+            if (st) return st;
+            st = check_status(ctx, "estimate_pairs");  // synchronises (info is a local)
+            if (st) return st;
+            pairs_done = true;
+        } else if (st != MSM_ERR_CAPACITY) {
+            return st;
+        }
+    }
+    if (!pairs_done && S >= 2) {  // a control grid whose tree outgrew the forest's arrays: one search per target subject, as before
+        g->pairs.resize(2 * (size_t)g->npairs);
         std::vector<std::vector<int32_t>> closest((size_t)S * S);
         std::vector<double> q;
         std::vector<int32_t> found;
@@ -479,8 +518,8 @@ int group_common_setup(msm_group *g) {
                     g->pairs[2 * pair + 1] = b * N + closest[(size_t)a * S + b][v];
                     ++pair;
                 }
+        MSM_HIP(g->d_pairs.upload_vec(g->pairs, ctx->stream));
     }
-    MSM_HIP(g->d_pairs.upload_vec(g->pairs, ctx->stream));
     lap("estimate_pairs");
     {
         // Processing order of a label step's pairs.  The list above runs subject A, control point, subject B: neighbours in it
@@ -510,7 +549,7 @@ int group_common_setup(msm_group *g) {
         std::sort(key.begin(), key.end());
         std::vector<int64_t> base(S, 0);
         for (int a = 1; a < S; ++a) base[a] = base[a - 1] + (int64_t)N * (S - a);
-        g->pair_order.resize(g->pairs.size() / 2);
+        g->pair_order.resize((size_t)g->npairs);
         size_t at = 0;
         for (int i = 0; i < N; ++i) {
             const int v = key[i].second;
@@ -520,30 +559,42 @@ int group_common_setup(msm_group *g) {
         g->order_p0 = g->order_p1 = -1;
     }
     lap("pair order");
-    // get_spacings :123-139, get_rotations :77-86, and ROT * label for every (node, label)
+    // get_spacings :123-139 and get_rotations :77-86 on the host (their asin / acos decide patch membership to the last bit, so
+    // they use the host's libm as the reference does), subjects spread over the host threads; ROT * label for every (node, label)
+    // -- 3.1 M products at S = 64, 75 MB -- on the device from the uploaded rotations (multiplications and additions only, in
+    // the host's order: the same bits)
     g->rot.resize(9 * (size_t)S * N);
-    g->moved.resize(3 * (size_t)S * N * L);
-    std::vector<double> cp_all(3 * (size_t)S * N), orig_all(3 * (size_t)S * N, 0.0);
-    for (int s = 0; s < S; ++s) {
+    g->moved.clear();
+    g->moved_on_host = false;
+    std::vector<double> cp_all(3 * (size_t)S * N), orig_all(3 * (size_t)S * N, 0.0), spacing_all((size_t)S * N);
+    std::vector<int> sub_status(S, MSM_OK);
+    parallel_for(S, host_workers(), [&](int s) {
         msm_mesh *cm = g->cpmesh[s];
         g->spacing[s].resize(N);
         double mvd;
         int st = msm_cp_spacings(cm->xyz.data(), cm->tri.data(), N, g->Tc, g->spacing[s].data(), &mvd);
-        if (st) return st;
-        st = msm_cp_rotations(centre, cm->xyz.data(), N, &g->rot[9 * (size_t)s * N]);
-        if (st) return st;
-        for (int v = 0; v < N; ++v)
-            for (int l = 0; l < L; ++l) {
-                const V3 m = rotate(&g->rot[9 * ((size_t)s * N + v)], mk(g->labels[l], g->labels[L + l], g->labels[2 * (size_t)L + l]));
-                double *o = &g->moved[(((size_t)s * N + v) * L + l) * 3];
-                o[0] = m.x, o[1] = m.y, o[2] = m.z;
-            }
+        if (!st) st = msm_cp_rotations(centre, cm->xyz.data(), N, &g->rot[9 * (size_t)s * N]);
+        sub_status[s] = st;
+        std::copy(g->spacing[s].begin(), g->spacing[s].end(), spacing_all.begin() + (size_t)s * N);
         std::copy(cm->xyz.begin(), cm->xyz.end(), cp_all.begin() + 3 * (size_t)s * N);
         if (g->have_orig[s]) std::copy(g->orig[s].begin(), g->orig[s].end(), orig_all.begin() + 3 * (size_t)s * N);
+    });
+    for (int s = 0; s < S; ++s)
+        if (sub_status[s]) return fail(sub_status[s], "msm_group: spacings / rotations of subject %d's control grid failed", s);
+    MSM_HIP(g->d_rot.ensure(g->rot.size()));
+    MSM_HIP(g->d_moved.ensure(3 * (size_t)S * N * L));
+    {
+        int st = upload_staged(ctx, g->d_rot.p, g->rot.data(), sizeof(double) * g->rot.size());
+        if (st) return st;
     }
-    MSM_HIP(g->d_moved.upload(g->moved.data(), g->moved.size(), ctx->stream));
+    MSM_HIP(g->d_labels3.upload(g->labels.data(), 3 * (size_t)L, ctx->stream));
+    MSM_HIP(g->d_spacing.upload(spacing_all.data(), spacing_all.size(), ctx->stream));
     MSM_HIP(g->d_cp.upload(cp_all.data(), cp_all.size(), ctx->stream));
     MSM_HIP(g->d_orig.upload(orig_all.data(), orig_all.size(), ctx->stream));
+    {
+        int st = launch_group_moved(ctx, g->d_rot.p, S * N, g->d_labels3.p, L, g->d_moved.p);
+        if (st) return st;
+    }
     MSM_HIP(hipStreamSynchronize(ctx->stream));
     g->F.resize((size_t)S * L);
     g->Fslab.resize(S);
@@ -1078,6 +1129,11 @@ int msm_group_dims(msm_group *g, int32_t *S, int32_t *N, int32_t *L, int32_t *D,
 int msm_group_get_pairs(msm_group *g, int32_t *pairs) {
     if (!g || !pairs) return fail(MSM_ERR_INVALID, "msm_group_get_pairs: null argument");
     if (!g->ready) return fail(MSM_ERR_STATE, "msm_group: msm_group_setup() must be called first");
+    if (g->pairs.size() != 2 * (size_t)g->npairs) {  // the list was written on the device: fetched when first asked for
+        g->pairs.resize(2 * (size_t)g->npairs);
+        if (g->npairs > 0) MSM_HIP(g->d_pairs.download(g->pairs.data(), g->pairs.size(), g->ctx->stream));
+        MSM_HIP(hipStreamSynchronize(g->ctx->stream));
+    }
     std::copy(g->pairs.begin(), g->pairs.end(), pairs);
     return MSM_OK;
 }
@@ -1122,7 +1178,7 @@ int msm_group_pairwise_batch(msm_group *g, const int32_t *pair, const int32_t *l
     GroupArgs a;
     int st = group_args(g, a);
     if (st) return st;
-    const int P = (int)(g->pairs.size() / 2);
+    const int P = (int)g->npairs;
     for (int i = 0; i < n; ++i)
         if (pair[i] < 0 || pair[i] >= P || la[i] < 0 || la[i] >= g->L || lb[i] < 0 || lb[i] >= g->L) return fail(MSM_ERR_INVALID, "group pairwise query %d out of range", i);
     msm_ctx *ctx = g->ctx;
@@ -1207,7 +1263,7 @@ static int group_move_compute(msm_group *g, const int32_t *labeling, int32_t lab
         const bool dice = g->p.simmeasure == 4 || g->p.simmeasure == 5;
         const bool two_pass = keep_e00 && !dice;
         if (two_pass) {
-            const int64_t P = (int64_t)(g->pairs.size() / 2);
+            const int64_t P = g->npairs;
             MSM_HIP(g->d_e00.ensure((size_t)std::max<int64_t>(P, 1)));
             MSM_HIP(g->d_prev_labeling.ensure(nodes));
             a.move_e00 = g->d_e00.p;
@@ -1278,7 +1334,7 @@ int msm_group_fusion_move(msm_group *g, const int32_t *labeling, int32_t label, 
     if (!g || !labeling) return fail(MSM_ERR_INVALID, "msm_group_fusion_move: null argument");
     if (!g->ready) return fail(MSM_ERR_STATE, "msm_group: msm_group_setup() must be called first");
     msm_ctx *ctx = g->ctx;
-    const int64_t P = (int64_t)(g->pairs.size() / 2), T = (int64_t)g->S * g->Tc;
+    const int64_t P = g->npairs, T = (int64_t)g->S * g->Tc;
     MSM_HIP(g->d_move_out.ensure((size_t)(4 * P + 8 * T) + 2));
     double *dq = g->d_move_out.p, *dt = dq + ((4 * P + 1) & ~1ll);  // both 16-byte aligned
     int st;
@@ -1341,7 +1397,7 @@ int msm_group_fusion_move_dev(msm_group *g, const int32_t *labeling, int32_t lab
                               double *quads_dev, double *octets_dev) {
     if (!g || !labeling) return fail(MSM_ERR_INVALID, "msm_group_fusion_move_dev: null argument");
     if (!g->ready) return fail(MSM_ERR_STATE, "msm_group: msm_group_setup() must be called first");
-    const int64_t P = (int64_t)(g->pairs.size() / 2), T = (int64_t)g->S * g->Tc;
+    const int64_t P = g->npairs, T = (int64_t)g->S * g->Tc;
     if (pair0 < 0 || pair1 < pair0 || pair1 > P || trip0 < 0 || trip1 < trip0 || trip1 > T) return fail(MSM_ERR_INVALID, "msm_group_fusion_move_dev: range out of bounds");
     if ((pair1 > pair0 && !quads_dev) || (trip1 > trip0 && !octets_dev)) return fail(MSM_ERR_INVALID, "msm_group_fusion_move_dev: missing output buffer");
     // an output inside a msm_host_alloc / msm_host_register block (pinned host memory, possibly shared with other processes): the

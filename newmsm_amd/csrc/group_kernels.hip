@@ -3,6 +3,7 @@
 // (DiscreteGroupCostFunction::computePairwiseCost, M/DiscreteGroupCostFunction.cpp:54-98) and the per-subject strain
 // triplet (:26-52).
 #include "kernels.hpp"
+#include "search_device.hpp"
 #include "similarity_device.hpp"
 #include "strain_device.hpp"
 
@@ -417,6 +418,101 @@ __global__ __launch_bounds__(128) void k_group_triplet(GroupArgs a, const int *_
         cost = (a.fixnan && e != e) ? 1e7 : a.subcorr * a.lambda * pow_exp(e, a.rexp);
     }
     out[i] = cost;
+}
+
+// ------------------------------------------------------------------------------------------------
+// the parts of setupCostFunction that need every subject's control grid (identical on every rank)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ DevTree forest_tree_dev(const ForestDev &f, int b) {
+    DevTree t;
+    t.node = f.node + (size_t)b * f.s_node;
+    t.parent = f.parent + (size_t)b * f.s_node;
+    t.leaf_tri = f.leaf_tri + (size_t)b * f.s_leaf;
+    t.cone = f.cone + (size_t)b * f.s_leaf;
+    t.rec = f.rec + (size_t)b * f.s_rec;
+    t.grid = f.grid + (size_t)b * f.s_grid;
+    t.nnodes = f.info[b].x;
+    t.grid_depth = f.info[b].y;
+    t.simple = 0;
+    t.mask = nullptr;
+    t.ray_G = 0;
+    t.ray_cell = nullptr, t.ray_tri = nullptr, t.ray_more = nullptr, t.ray_excl = nullptr;
+    t.ray_r2lo = t.ray_r2hi = 0.0;
+    return t;
+}
+// blockIdx.y = subject a; a thread per (v, b > a), v-major as in the list
+__global__ __launch_bounds__(256) void k_group_pairs(ForestDev f, const double *__restrict__ cp, int S, int N, int *__restrict__ pairs, int *status) {
+    const int a = blockIdx.y, nb = S - 1 - a;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)N * nb) return;
+    const int v = (int)(i / nb), b = a + 1 + (int)(i - (long long)v * nb);
+    // pairs before subject a: N * sum_{a' < a} (S - 1 - a')
+    const long long base = (long long)N * ((long long)a * (S - 1) - (long long)a * (a - 1) / 2);
+    const long long p = base + i;
+    const size_t comp = (size_t)S * N;
+    const V3 q = mk(cp[(size_t)a * N + v], cp[comp + (size_t)a * N + v], cp[2 * comp + (size_t)a * N + v]);
+    const DevTree T = forest_tree_dev(f, b);
+    const int t = find_closest_triangle(T, q);
+    int best = t;
+    if (t < 0) {
+        raise_status(status, t);
+    } else {  // Octree::get_closest_vertex_ID, R/octree.cpp:216-233
+        const TriRec &r = T.rec[t];
+        double dist = DBL_MAX;
+        const V3 vv[3] = {rec_v0(r), rec_v1(r), rec_v2(r)};
+        const int ids[3] = {r.id[0], r.id[1], r.id[2]};
+        best = 0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const double d = norm(sub(q, vv[k]));
+            if (d < dist) {
+                best = ids[k];
+                dist = d;
+            }
+        }
+    }
+    pairs[2 * p] = a * N + v;
+    pairs[2 * p + 1] = b * N + best;
+}
+int launch_group_pairs(msm_ctx *ctx, const ForestDev &f, const double *d_cp, int S, int N, int *d_pairs) {
+    if (S < 2) return MSM_OK;
+    const long long most = (long long)N * (S - 1);
+    hipLaunchKernelGGL(k_group_pairs, dim3((unsigned)((most + 255) / 256), (unsigned)(S - 1)), dim3(256), 0, ctx->stream, f, d_cp, S, N, d_pairs, ctx->d_status);
+    MSM_HIP(hipGetLastError());
+    return MSM_OK;
+}
+
+__global__ __launch_bounds__(256) void k_group_moved(const double *__restrict__ rot, int nodes, const double *__restrict__ labels, int L, double *__restrict__ moved) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)nodes * L) return;
+    const size_t node = i / L;
+    const int l = (int)(i - node * L);
+    const V3 m = rotate(rot + 9 * node, mk(labels[l], labels[L + l], labels[2 * (size_t)L + l]));
+    moved[3 * i] = m.x, moved[3 * i + 1] = m.y, moved[3 * i + 2] = m.z;
+}
+int launch_group_moved(msm_ctx *ctx, const double *d_rot, int nodes, const double *d_labels, int L, double *d_moved) {
+    const size_t n = (size_t)nodes * L;
+    if (n == 0) return MSM_OK;
+    hipLaunchKernelGGL(k_group_moved, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_rot, nodes, d_labels, L, d_moved);
+    MSM_HIP(hipGetLastError());
+    return MSM_OK;
+}
+
+__global__ __launch_bounds__(256) void k_group_centres(const double *__restrict__ moved, const double *__restrict__ spacing, int N, int L, double *__restrict__ centres,
+                                                        double *__restrict__ sep) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x, M = N * L;
+    if (k >= M) return;
+    centres[k] = moved[3 * (size_t)k];
+    centres[M + k] = moved[3 * (size_t)k + 1];
+    centres[2 * (size_t)M + k] = moved[3 * (size_t)k + 2];
+    sep[k] = spacing[k / L];
+}
+int launch_group_centres(msm_ctx *ctx, const double *d_moved_subject, const double *d_spacing_subject, int N, int L, double *d_centres, double *d_sep) {
+    const int M = N * L;
+    if (M <= 0) return MSM_OK;
+    hipLaunchKernelGGL(k_group_centres, dim3((M + 255) / 256), dim3(256), 0, ctx->stream, d_moved_subject, d_spacing_subject, N, L, d_centres, d_sep);
+    MSM_HIP(hipGetLastError());
+    return MSM_OK;
 }
 
 int launch_group_pairwise(msm_ctx *ctx, const GroupArgs &a, const int *qp, const int *qa, const int *qb, int n, double *out) {

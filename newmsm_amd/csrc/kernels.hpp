@@ -228,5 +228,22 @@ struct GroupArgs {
 int launch_rotate_to_label(msm_ctx *ctx, const double *d_xyz, int V, const double centre[3], const double label[3], double *d_out, size_t stride = 0);
 int launch_group_pairwise(msm_ctx *ctx, const GroupArgs &a, const int *qp, const int *qa, const int *qb, int n, double *out);
 int launch_group_triplet(msm_ctx *ctx, const GroupArgs &a, const int *qt, const int *qa, const int *qb, const int *qc, int n, double *out);
+// the search trees of the S control grids as one forest (arrays of tree b start b * s_* elements in), as the kernels below see it
+struct ForestDev {
+    const int4 *node;
+    const int32_t *parent, *leaf_tri, *grid;
+    const float4 *cone;
+    const TriRec *rec;
+    size_t s_node, s_leaf, s_rec, s_grid;
+    const int2 *info;  // per tree: number of nodes, grid depth
+};
+// estimate_pairs (M/DiscreteGroupModel.cpp:37-55) for the whole group: pair (a, v, b > a) = (a * N + v, b * N + the control point of
+// subject b closest to control point v of subject a, Octree::get_closest_vertex_ID), in the reference's list order.  cp: component
+// c of control point v of subject s at cp[c * S * N + s * N + v].
+int launch_group_pairs(msm_ctx *ctx, const ForestDev &f, const double *d_cp, int S, int N, int *d_pairs);
+// moved[((s * N + v) * L + l) * 3 ..] = rot[s * N + v] (row-major 3 x 3) * label l: the control points' candidate positions
+int launch_group_moved(msm_ctx *ctx, const double *d_rot, int nodes, const double *d_labels /* 3 x L SoA */, int L, double *d_moved);
+// the patch centres of one subject as k_range takes them: centres 3 x (N * L) SoA and the per-centre spacing
+int launch_group_centres(msm_ctx *ctx, const double *d_moved_subject, const double *d_spacing_subject, int N, int L, double *d_centres, double *d_sep);
 
 }  // namespace msm
