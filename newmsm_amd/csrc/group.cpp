@@ -86,6 +86,7 @@ struct msm_group {
     std::vector<int32_t> pair_order;     // the pair list in processing order (control points along a space-filling curve)
     DevBuf<int> d_pair_order;            // ... restricted to the slice [order_p0, order_p1) last asked for
     int64_t order_p0 = -1, order_p1 = -1;
+    int order_S = 0, order_N = 0;        // the sizes pair_order was built for
     Forest cp_forest;                    // the search trees of the S control grids, built together (estimate_pairs)
     DevBuf<double> d_cp_soa, d_rot, d_spacing, d_labels3;  // control points by component; ROT per node; spacing per node; labels 3 x L
     DevBuf<int2> d_forest_info;
@@ -528,35 +529,40 @@ int group_common_setup(msm_group *g) {
         // control point along a space-filling curve -- all S (S - 1) / 2 subject pairs of one, then the next -- the patches of a
         // neighbourhood (S subjects x 2 labels x a few KB) stay in the L2 while every pair that needs them runs.  Results keep
         // the list's positions (GroupArgs::move_order).
-        const double *c0 = g->cpmesh[0]->xyz.data();
-        auto spread = [](uint32_t v) {
-            v &= 0x3ff;
-            v = (v | (v << 16)) & 0x030000ff;
-            v = (v | (v << 8)) & 0x0300f00f;
-            v = (v | (v << 4)) & 0x030c30c3;
-            v = (v | (v << 2)) & 0x09249249;
-            return v;
-        };
-        std::vector<std::pair<uint32_t, int>> key(N);
-        for (int v = 0; v < N; ++v) {
-            uint32_t q[3];
-            for (int ax = 0; ax < 3; ++ax) {
-                const double u = (c0[(size_t)ax * N + v] + kBounds) / (2 * kBounds);
-                q[ax] = (uint32_t)std::max(0.0, std::min(1023.0, u == u ? u * 1024.0 : 0.0));
+        // The order only serves locality: any permutation is correct, and the control grids move little from one iteration to the
+        // next, so the order of the first set-up with these sizes is kept (with it the slice on the device and its four pieces).
+        if (g->pair_order.size() != (size_t)g->npairs || g->order_S != S || g->order_N != N) {
+            const double *c0 = g->cpmesh[0]->xyz.data();
+            auto spread = [](uint32_t v) {
+                v &= 0x3ff;
+                v = (v | (v << 16)) & 0x030000ff;
+                v = (v | (v << 8)) & 0x0300f00f;
+                v = (v | (v << 4)) & 0x030c30c3;
+                v = (v | (v << 2)) & 0x09249249;
+                return v;
+            };
+            std::vector<std::pair<uint32_t, int>> key(N);
+            for (int v = 0; v < N; ++v) {
+                uint32_t q[3];
+                for (int ax = 0; ax < 3; ++ax) {
+                    const double u = (c0[(size_t)ax * N + v] + kBounds) / (2 * kBounds);
+                    q[ax] = (uint32_t)std::max(0.0, std::min(1023.0, u == u ? u * 1024.0 : 0.0));
+                }
+                key[v] = {spread(q[0]) << 2 | spread(q[1]) << 1 | spread(q[2]), v};
             }
-            key[v] = {spread(q[0]) << 2 | spread(q[1]) << 1 | spread(q[2]), v};
+            std::sort(key.begin(), key.end());
+            std::vector<int64_t> base(S, 0);
+            for (int a = 1; a < S; ++a) base[a] = base[a - 1] + (int64_t)N * (S - a);
+            g->pair_order.resize((size_t)g->npairs);
+            size_t at = 0;
+            for (int i = 0; i < N; ++i) {
+                const int v = key[i].second;
+                for (int a = 0; a + 1 < S; ++a)
+                    for (int b = a + 1; b < S; ++b) g->pair_order[at++] = (int32_t)(base[a] + (int64_t)v * (S - 1 - a) + (b - a - 1));
+            }
+            g->order_S = S, g->order_N = N;
+            g->order_p0 = g->order_p1 = -1;
         }
-        std::sort(key.begin(), key.end());
-        std::vector<int64_t> base(S, 0);
-        for (int a = 1; a < S; ++a) base[a] = base[a - 1] + (int64_t)N * (S - a);
-        g->pair_order.resize((size_t)g->npairs);
-        size_t at = 0;
-        for (int i = 0; i < N; ++i) {
-            const int v = key[i].second;
-            for (int a = 0; a + 1 < S; ++a)
-                for (int b = a + 1; b < S; ++b) g->pair_order[at++] = (int32_t)(base[a] + (int64_t)v * (S - 1 - a) + (b - a - 1));
-        }
-        g->order_p0 = g->order_p1 = -1;
     }
     lap("pair order");
     // get_spacings :123-139 and get_rotations :77-86 on the host (their asin / acos decide patch membership to the last bit, so
