@@ -339,8 +339,24 @@ class ShardedMove:
         if transport == "shm":
             self.off_t = (4 * group.P + 1) // 2 * 2  # doubles; keeps the triplet part 16-byte aligned
             self.shared = SharedStepBuffer(c, self.off_t + 8 * group.T, dst)
-            group.ctx.register_host(self.shared.address, self.shared.nbytes)
-            return
+            ok = 1
+            try:
+                group.ctx.register_host(self.shared.address, self.shared.nbytes)
+            except Exception:  # the driver cannot pin this mapping: every rank falls back to the gather together
+                ok = 0
+            if c.dist is not None and c.world > 1:
+                flags = [None] * c.world
+                c.dist.all_gather_object(flags, ok)
+                ok = min(flags)
+            if ok:
+                return
+            if self.shared is not None:
+                try:
+                    group.ctx.unregister_host(self.shared.address)
+                except Exception:
+                    pass
+            self.shared = None
+            self.transport = transport = "gather"
         dev = c.device if c.on_gpu else "cpu"
         self.send = torch.zeros(4 * self.pmax + 8 * self.tmax, dtype=torch.float64, device=dev)
         self.recv = torch.zeros((c.world, 4 * self.pmax + 8 * self.tmax), dtype=torch.float64, device=dev) if (c.rank == dst and c.world > 1) else None
