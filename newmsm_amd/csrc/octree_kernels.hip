@@ -7,10 +7,15 @@
 //   k_oct_decide   a wavefront per open node scans its list (wave prefix sums of the heuristic's two running sums, stopping at
 //                  the first entry that triggers the split);
 //   k_oct_count    a workgroup per 256-entry chunk of a splitting node counts what each child receives from the chunk;
-//   k_oct_scan     one workgroup turns the decisions of the level into node numbers, list offsets, chunk tables and leaf slots
-//                  (prefix sums in node order: the tree's numbering does not depend on scheduling);
+//   k_oct_chunk_scan a wavefront per splitting node turns its chunks' counts into prefixes (where each chunk's share of a child's
+//                  list starts) and totals;
+//   k_oct_scan     one workgroup per tree turns the decisions of the level into node numbers, list offsets, chunk tables and leaf
+//                  slots (prefix sums in node order: the tree's numbering does not depend on scheduling);
 //   k_oct_fill     a workgroup per chunk writes its entries into the children's lists (ballot-ordered compaction behind the
 //                  chunk's start: ids stay ascending) or, for a leaf, into the leaf array (padded to 8 with -1).
+// The levels are queued in batches without looking at the outcome in between; the build comes in two halves (begin / finish) for
+// callers with several streams, and as a FOREST (gpu_build_forest): B coordinate sets over one triangle list, the tree as the
+// second grid dimension of every launch -- the L rotated copies of a gMSM subject's data mesh, the S control grids of a group.
 // Child boxes are exact halvings of (-101, 101), so every box is reproduced bit for bit from (lower corner, edge).
 // The host build (octree.cpp) takes 3.5 ms per ico6 mesh on sixteen threads -- every iteration of a registration builds one
 // for the moved source, gMSM nineteen per subject -- plus the upload of its arrays; this one leaves them where the search
