@@ -146,7 +146,12 @@ int ensure_move(msm_cost *c, const CliqueArgs &a) {
     msm_ctx *ctx = c->ctx;
     const int T = a.T;
     std::vector<int4> blk;
-    int slots = 0, nt = 0, cap = kMoveSlots, first = 0;
+    // with many features per sample (the eight-lanes-per-sample passes of k_ho_move<., 2>) smaller workgroups do better: 88 against
+    // 95 us at D = 32 with 48 slots / 6 triangles; with one feature the two shapes are level in the kernel and the larger is cheaper to launch
+    const bool wide = a.kind == MSM_COST_HO_MULTIVARIATE && a.D >= 12;
+    const bool env_s = std::getenv("MSMHIP_MOVE_SLOTS") != nullptr, env_t = std::getenv("MSMHIP_MOVE_TRIANGLES") != nullptr;
+    const int max_slots = (wide && !env_s) ? 48 : kMoveSlots, max_tris = (wide && !env_t) ? 6 : kMoveTriangles;
+    int slots = 0, nt = 0, cap = max_slots, first = 0;
     auto close = [&](int t_end) {
         if (nt > 0) blk.push_back(make_int4(first, nt, c->pptr[first], c->pptr[t_end] - c->pptr[first]));
         first = t_end;
@@ -154,7 +159,7 @@ int ensure_move(msm_cost *c, const CliqueArgs &a) {
     };
     for (int t = 0; t < T; ++t) {
         const int n = c->pptr[t + 1] - c->pptr[t];
-        if (nt > 0 && (slots + n > kMoveSlots || nt == kMoveTriangles)) close(t);
+        if (nt > 0 && (slots + n > max_slots || nt == max_tris)) close(t);
         slots += n;
         ++nt;
         cap = std::max(cap, slots);

@@ -111,15 +111,13 @@ __device__ __forceinline__ bool proposed_triangle(const CliqueArgs &a, const Mov
 // HO*::triplet_likelihood of one evaluation from its point values vals[0..n), in the reference's serial operand order;
 // the moving patch's half of the correlation (sum of weights, weighted mean, weighted variance, M/similarities.cpp:135-150)
 // comes from k_move_prepare: st[0..3), and W * (A - meanA) per slot
-__device__ __forceinline__ double move_likelihood(const CliqueArgs &a, const MoveArgs &m, int t, double wmean, const double *vals) {
-    const int beg = a.bin_ptr[t], n = a.bin_ptr[t + 1] - beg;
+__device__ __forceinline__ double move_likelihood(const CliqueArgs &a, int n, const double *st, const double *wda, const double *cw, const double *sf, double wmean,
+                                                  const double *vals) {
     for (int i = 0; i < n; ++i)
         if (vals[i] != vals[i]) return __longlong_as_double(0x7ff8000000000000ll);  // a failed search
     double cost = 0.0;
     if (a.kind == MSM_COST_HO_UNIVARIATE) {
-        const double *cw = m.slot_cw ? m.slot_cw + beg : nullptr;
         if (a.simmeasure == 2) {
-            const double *st = m.tri_stat + 3 * (size_t)t, *wda = m.slot_wda + beg;
             const double sum = st[0], varA = st[2];
             double meanB = 0.0, prod = 0.0, varB = 0.0;
             for (int i = 0; i < n; ++i) meanB += (cw ? cw[i] : 1.0) * vals[i];
@@ -135,10 +133,8 @@ __device__ __forceinline__ double move_likelihood(const CliqueArgs &a, const Mov
             const double r = (varA == 0.0 || varB == 0.0) ? 0.0 : prod / (sqrt(varA) * sqrt(varB));
             cost = 1 - (1 + r) * 0.5;
         } else if (a.simmeasure == 4 || a.simmeasure == 5) {  // sparsesimkernel::DICE / genDICE, :201-253 (weights unused)
-            const double *sf = m.slot_sf + beg;
             cost = dice_serial(a.simmeasure, n, a.percentile, [&](int i) { return sf[i]; }, [&](int i) { return vals[i]; });
         } else {  // sparsesimkernel::SSD, :179-188
-            const double *sf = m.slot_sf + beg;
             double prod = 0.0;
             for (int i = 0; i < n; ++i) prod += (cw ? cw[i] : 1.0) * (sf[i] - vals[i]) * (sf[i] - vals[i]);
             cost = sqrt(prod) / n;
@@ -150,8 +146,7 @@ __device__ __forceinline__ double move_likelihood(const CliqueArgs &a, const Mov
     return wmean * cost;
 }
 
-__device__ __forceinline__ double move_strain(const CliqueArgs &a, const MoveArgs &m, int t, const V3 *r) {
-    const double *fp = m.tri_frame + 5 * (size_t)t;
+__device__ __forceinline__ double move_strain(const CliqueArgs &a, const double *fp, const V3 *r) {
     StrainFrame fr;
     fr.i00 = fp[0], fr.i01 = fp[1], fr.i10 = fp[2], fr.i11 = fp[3];
     fr.dswap = fp[4] != 0.0;
@@ -210,10 +205,15 @@ __global__ __launch_bounds__(kThreads) void k_ho_move(CliqueArgs a, MoveArgs m, 
     extern __shared__ __align__(16) double lds[];
     double *s_geo = lds;                            // 64 evaluations x 9: the proposed triangles
     double *s_vals = s_geo + 64 * 9;                // 8 combinations x cap bin slots
-    double *s_w = s_vals + 8 * (size_t)m.cap;       // kMode 2: 3 weights per sample of a round
+    // what the last phase needs besides the samples -- label independent, fetched at the very start by the lanes that have nothing
+    // to do while lanes 0 .. 8 * ntrip set up the proposed triangles, so that the last phase starts without dependent global loads
+    double *s_wda = s_vals + 8 * (size_t)m.cap, *s_cw = s_wda + m.cap, *s_sf = s_cw + m.cap;  // per bin slot
+    double *s_stat = s_sf + m.cap, *s_frame = s_stat + 24, *s_strain = s_frame + 40;            // 8 x 3, 8 x 5, 64
+    double *s_w = s_strain + 64;                     // kMode 2: 3 weights per sample of a round
     int *s_flag = reinterpret_cast<int *>(s_w + (kMode == 2 ? 3 * kThreads : 0));  // [0,64) folded, [64,128) deferred
     int *s_pend = s_flag + 128;                     // samples the direction table left open (at most all of a round... of the block: 8 * cap)
     int *s_tt = s_pend + 8 * m.cap;                 // kMode 2: triangle and its vertex ids per sample of a round (4 x kThreads)
+    int *s_bin = s_tt + (kMode == 2 ? 4 * kThreads : 0);  // bin_ptr[t0 .. t0 + ntrip]
     __shared__ int s_npend;
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -236,6 +236,17 @@ __global__ __launch_bounds__(kThreads) void k_ho_move(CliqueArgs a, MoveArgs m, 
     // first sample's slot data, which does not depend on the labels
     const bool ev = tid < 8 * ntrip;
     if (tid == 0) s_npend = 0;
+    if (tid >= kThreads - 64) {  // the last wavefront: the last phase's operands
+        const int h = tid - (kThreads - 64);
+        for (int j = h; j < nslots; j += 64) {
+            s_wda[j] = m.slot_wda[s0 + j];
+            s_sf[j] = m.slot_sf[s0 + j];
+            if (m.slot_cw) s_cw[j] = m.slot_cw[s0 + j];
+        }
+        if (h < 3 * ntrip) s_stat[h] = m.tri_stat[3 * (size_t)t0 + h];
+        if (h < 5 * ntrip) s_frame[h] = m.tri_frame[5 * (size_t)t0 + h];
+        if (h <= ntrip) s_bin[h] = a.bin_ptr[t0 + h];
+    }
     int id[3] = {0, 0, 0};
     double wmean = 0.0;  // mean AbsoluteWeight of the triangle's control points (HO*::triplet_likelihood :530 / :616)
     if (ev) {
@@ -317,6 +328,17 @@ __global__ __launch_bounds__(kThreads) void k_ho_move(CliqueArgs a, MoveArgs m, 
     // (search_device.hpp: group8_find); what even that cannot decide (no candidate in the leaf: sibling leaves, nearest vertex)
     // is left to the tail kernel, which the host launches only when told to
     const int npend = s_npend;
+    // the strain of the 64 evaluations (a chain of some hundred dependent FP64 operations that only needs the proposed triangles) is
+    // computed by the last wavefront here, while the first ones search for the open samples and then start on the similarities:
+    // it used to follow the similarity in every evaluation's lane, 2 us of the 4.3 us last phase
+    if (tid >= kThreads - 64) {
+        const int h = tid - (kThreads - 64);
+        if (h < 8 * ntrip) {
+            const double *gp = s_geo + 9 * h;
+            const V3 rr[3] = {mk(gp[0], gp[1], gp[2]), mk(gp[3], gp[4], gp[5]), mk(gp[6], gp[7], gp[8])};
+            s_strain[h] = s_flag[h] ? 0.0 : move_strain(a, s_frame + 5 * (h >> 3), rr);
+        }
+    }
     for (int q0 = 0; q0 < npend; q0 += kThreads / 8) {  // workgroup-uniform
         const int q = q0 + (tid >> 3);
         const bool valid = q < npend;
@@ -340,7 +362,7 @@ __global__ __launch_bounds__(kThreads) void k_ho_move(CliqueArgs a, MoveArgs m, 
             }
         }
     }
-    if (npend > 0) __syncthreads();
+    __syncthreads();  // the open samples' values and the strains are in LDS
     MSM_STAMP(5);
 
     // ---- one lane per evaluation: similarity in the reference's serial order + strain
@@ -350,7 +372,7 @@ __global__ __launch_bounds__(kThreads) void k_ho_move(CliqueArgs a, MoveArgs m, 
         m.out[e] = MSM_FOLDING * a.lambda;
         return;
     }
-    const int beg = a.bin_ptr[t], n = a.bin_ptr[t + 1] - beg;
+    const int beg = s_bin[tid >> 3], n = s_bin[(tid >> 3) + 1] - beg;
     const double *vals = s_vals + k * m.cap + (beg - s0);
     if (s_flag[64 + tid]) {  // some point is still open: hand the evaluation and what is known of it to the tail kernel
         const unsigned at = atomicAdd(&m.defer_cnt[m.parity], 1u);
@@ -360,9 +382,7 @@ __global__ __launch_bounds__(kThreads) void k_ho_move(CliqueArgs a, MoveArgs m, 
         __hip_atomic_store(m.host_flags + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         return;
     }
-    const double *g = s_geo + 9 * tid;
-    const V3 r[3] = {mk(g[0], g[1], g[2]), mk(g[3], g[4], g[5]), mk(g[6], g[7], g[8])};
-    m.out[e] = move_likelihood(a, m, t, wmean, vals) + move_strain(a, m, t, r);
+    m.out[e] = move_likelihood(a, n, s_stat + 3 * (tid >> 3), s_wda + (beg - s0), m.slot_cw ? s_cw + (beg - s0) : nullptr, s_sf + (beg - s0), wmean, vals) + s_strain[tid];
     MSM_STAMP(6);
 }
 
@@ -412,7 +432,9 @@ __global__ __launch_bounds__(256) void k_ho_move_tail(CliqueArgs a, MoveArgs m, 
         }
         __syncthreads();
         if (have && lane == 0)
-            m.out[8 * t + k] = move_likelihood(a, m, t, (a.absw[id[0]] + a.absw[id[1]] + a.absw[id[2]]) / 3.0, vals) + move_strain(a, m, t, r);
+            m.out[8 * t + k] = move_likelihood(a, cnt, m.tri_stat + 3 * (size_t)t, m.slot_wda + beg, m.slot_cw ? m.slot_cw + beg : nullptr, m.slot_sf + beg,
+                                               (a.absw[id[0]] + a.absw[id[1]] + a.absw[id[2]]) / 3.0, vals) +
+                               move_strain(a, m.tri_frame + 5 * (size_t)t, r);
         __syncthreads();
     }
 }
@@ -442,7 +464,8 @@ int launch_move(msm_ctx *ctx, const CliqueArgs &a, const MoveArgs &m, const Move
     // (neighbouring lanes reading neighbouring 16-byte pieces) 33 / 142.
     static const int threads = [] { const char *e = std::getenv("MSMHIP_MOVE_THREADS"); return e && std::atoi(e) == 512 ? 512 : 256; }();
     const dim3 grid((unsigned)(8 * ((m.nblk + 7) / 8))), block(threads);
-    const size_t lds = sizeof(double) * (64 * 9 + 8 * (size_t)m.cap + (mode == 2 ? 3 * threads : 0)) + sizeof(int) * (128 + 8 * (size_t)m.cap + (mode == 2 ? 4 * threads : 0));
+    const size_t lds = sizeof(double) * (64 * 9 + 8 * (size_t)m.cap + 3 * (size_t)m.cap + 24 + 40 + 64 + (mode == 2 ? 3 * threads : 0)) +
+                       sizeof(int) * (128 + 8 * (size_t)m.cap + (mode == 2 ? 4 * threads : 0) + 16);
     if (lds > 64 * 1024) return fail(MSM_ERR_CAPACITY, "fusion move: %d bin slots per workgroup do not fit LDS", m.cap);
     const MoveLabels &lab = labels ? *labels : g_no_labels;
     if (ev_start) MSM_HIP(hipEventRecord(ev_start, ctx->stream));
