@@ -82,6 +82,13 @@ struct msm_group {
         bool forest_ok = false;
     };
     Stage stage[2];
+    // the per-label remainder of a subject's set-up with the label as the second grid dimension of every launch (stage_batch)
+    struct Batch {
+        msm_ctx *ctx = nullptr;  // a stream of its own: runs beside the main stream's preparation of the next subject
+        DevBuf<int> fvid, rvid, roff, rfill, rkey, coff, cfill, ckey, row_ptr, col, tkey, scan_tmp;
+        DevBuf<double> fw, rw, oldA, newA, ta, rwt, cval, correction, val, tval;
+        DevBuf<int2> info[2];
+    } batch;
     DevBuf<double> d_move_out;           // msm_group_fusion_move: the step's 4 P + 8 T results before they go to the host
     std::vector<int32_t> pair_order;     // the pair list in processing order (control points along a space-filling curve)
     DevBuf<int> d_pair_order;            // ... restricted to the slice [order_p0, order_p1) last asked for
@@ -343,6 +350,11 @@ void msm_group_destroy(msm_group *g) {
         if (lane.ctx) (void)hipStreamSynchronize(lane.ctx->stream);
         msm_mesh_destroy(lane.mesh);
         msm_ctx_destroy(lane.ctx);
+    }
+    if (g->batch.ctx) {
+        (void)hipStreamSynchronize(g->batch.ctx->stream);
+        msm_ctx_destroy(g->batch.ctx);
+        g->batch.ctx = nullptr;
     }
     if (g->copy_stream) {
         (void)hipStreamSynchronize(g->copy_stream);
@@ -696,6 +708,84 @@ static int stage_prepare(msm_group *g, int s, msm_group::Stage &b) {
     return st;
 }
 
+// The per-label remainder with all L labels in every launch (the trees came from the forest): forward queries of the template's
+// vertices in every tree, reverse queries of all rotated vertices in the template's tree (one launch over the L * V points of
+// d_rot), vertex areas, weight-list surgery and the weighted sums into the subject's slab -- some forty launches per SUBJECT
+// where the lanes made thirty per label.  On a stream of its own (batch.ctx), beside the main stream's work on the next subject.
+static int stage_batch(msm_group *g, int s, msm_group::Stage &b, int which) {
+    msm_group::Batch &w = g->batch;
+    if (!w.ctx) {
+        w.ctx = msm_ctx_create(g->ctx->device);
+        if (!w.ctx) return MSM_ERR_HIP;
+    }
+    msm_ctx *ctx = w.ctx;
+    const int L = g->L, D = g->D;
+    msm_mesh *dm = g->data[s], *tm = g->tmpl;
+    const int V = dm->V, T = dm->T, Vt = tm->V, Tt = tm->T;
+    const size_t LV = (size_t)L * V, LVt = (size_t)L * Vt, cap = 3 * (size_t)Vt + 3 * (size_t)V;
+    int st = ensure_adjacency_dev(dm);
+    if (st) return st;
+    const size_t nscan = (size_t)std::max(V, Vt) / 4096 + 2;
+    MSM_HIP(w.fvid.ensure(3 * LVt));
+    MSM_HIP(w.fw.ensure(3 * LVt));
+    MSM_HIP(w.rvid.ensure(3 * LV));
+    MSM_HIP(w.rw.ensure(3 * LV));
+    MSM_HIP(w.oldA.ensure(LV));
+    MSM_HIP(w.newA.ensure(Vt));
+    MSM_HIP(w.ta.ensure((size_t)L * std::max(T, Tt)));
+    MSM_HIP(w.roff.ensure((size_t)L * (Vt + 1)));
+    MSM_HIP(w.rfill.ensure(LVt));
+    MSM_HIP(w.rkey.ensure(3 * LV));
+    MSM_HIP(w.rwt.ensure(3 * LV));
+    MSM_HIP(w.coff.ensure((size_t)L * (V + 1)));
+    MSM_HIP(w.cfill.ensure(LV));
+    MSM_HIP(w.ckey.ensure(L * cap));
+    MSM_HIP(w.cval.ensure(L * cap));
+    MSM_HIP(w.correction.ensure(LV));
+    MSM_HIP(w.row_ptr.ensure((size_t)L * (Vt + 1)));
+    MSM_HIP(w.col.ensure(L * cap));
+    MSM_HIP(w.val.ensure(L * cap));
+    MSM_HIP(w.tkey.ensure(L * cap));
+    MSM_HIP(w.tval.ensure(L * cap));
+    MSM_HIP(w.scan_tmp.ensure((size_t)L * nscan));
+    std::vector<int2> info(L);
+    for (int l = 0; l < L; ++l) info[l] = make_int2(b.forest.info[l].nnodes, b.forest.info[l].grid_depth);
+    MSM_HIP(w.info[which].ensure(L));
+    MSM_HIP(hipMemcpyAsync(w.info[which].p, info.data(), sizeof(int2) * (size_t)L, hipMemcpyHostToDevice, ctx->stream));
+    MSM_HIP(hipStreamSynchronize(ctx->stream));  // info is a local (and the previous subject's batch has finished with the scratch)
+    ForestDev fd;
+    fd.node = b.forest.node.p, fd.parent = b.forest.parent.p, fd.leaf_tri = b.forest.leaf_tri.p, fd.grid = b.forest.grid.p;
+    fd.cone = b.forest.cone.p, fd.rec = b.forest.rec.p;
+    fd.s_node = b.forest.s_node, fd.s_leaf = b.forest.s_leaf, fd.s_rec = b.forest.s_rec, fd.s_grid = b.forest.s_grid;
+    fd.info = w.info[which].p;
+    // forward: the template's vertices in every label's tree; reverse: every label's vertices in the template's tree (:74-78)
+    st = launch_query_forest(ctx, fd, L, tm->d_xyz, Vt, w.fvid.p, w.fw.p, LVt);
+    if (st) return st;
+    st = launch_query(ctx, dev_tree(tm), b.d_rot.p, (int)LV, nullptr, w.rvid.p, w.rw.p, MSM_WEIGHTS_PROJECTED);
+    if (st) return st;
+    st = launch_vertex_areas_batch(ctx, b.d_rot.p, LV, (size_t)V, V, dm->d_tri, T, dm->d_tid_ptr, dm->d_tid, L, w.ta.p, w.oldA.p);
+    if (st) return st;
+    st = launch_vertex_areas_batch(ctx, tm->d_xyz, (size_t)Vt, 0, Vt, tm->d_tri, Tt, tm->d_tid_ptr, tm->d_tid, 1, w.ta.p, w.newA.p);
+    if (st) return st;
+    AdaptiveDevArgs a;
+    a.nOld = V, a.nNew = Vt;
+    a.fvid = w.fvid.p, a.fw = w.fw.p, a.rvid = w.rvid.p, a.rw = w.rw.p, a.oldA = w.oldA.p, a.newA = w.newA.p;
+    a.roff = w.roff.p, a.rfill = w.rfill.p, a.rkey = w.rkey.p, a.rwt = w.rwt.p;
+    a.coff = w.coff.p, a.cfill = w.cfill.p, a.ckey = w.ckey.p, a.cval = w.cval.p, a.correction = w.correction.p;
+    a.scan_tmp = w.scan_tmp.p, a.tkey = w.tkey.p, a.tval = w.tval.p;
+    a.row_ptr = w.row_ptr.p, a.col = w.col.p, a.val = w.val.p;
+    a.B = L;
+    a.fstride = LVt, a.rstride = LV;
+    a.s_f = (size_t)Vt, a.s_r = (size_t)V, a.s_oldA = (size_t)V, a.s_newA = 0;
+    a.s_roff = (size_t)Vt + 1, a.s_rfill = (size_t)Vt, a.s_r3 = 3 * (size_t)V;
+    a.s_coff = (size_t)V + 1, a.s_cfill = (size_t)V, a.s_cap = cap, a.s_corr = (size_t)V, a.s_rowptr = (size_t)Vt + 1, a.s_scan = nscan;
+    st = launch_adaptive_surgery(ctx, a);
+    if (st) return st;
+    st = launch_apply_rows_batch(ctx, a, D, b.d_feat.p, g->Fslab[s]->p, (size_t)D * Vt);
+    if (st) return st;
+    return check_status(ctx, "get_patch_data (resampling)");  // synchronises the batch stream
+}
+
 static int stage_lanes(msm_group *g, int s, msm_group::Stage &b) {
     msm_ctx *ctx = g->ctx;
     const int L = g->L, D = g->D;
@@ -782,9 +872,11 @@ static int group_setup_pipeline(msm_group *g, const int32_t *subjects, int n) {
         msm_group::Stage &cur = g->stage[i & 1];
         int st_lanes = MSM_OK;
         std::string msg_lanes;
+        static const bool no_batch = [] { const char *e = std::getenv("MSMHIP_GROUP_BATCH"); return e && std::strcmp(e, "off") == 0; }();
+        const int which = i & 1;
         std::thread lanes([&] {
             (void)hipSetDevice(ctx->device);
-            st_lanes = stage_lanes(g, s, cur);
+            st_lanes = (cur.forest_ok && !no_batch) ? stage_batch(g, s, cur, which) : stage_lanes(g, s, cur);
             if (st_lanes) msg_lanes = msm_last_error();
         });
         int st_main = MSM_OK;

@@ -440,6 +440,36 @@ __device__ __forceinline__ DevTree forest_tree_dev(const ForestDev &f, int b) {
     t.ray_r2lo = t.ray_r2hi = 0.0;
     return t;
 }
+// every query point in every tree (blockIdx.y)
+__global__ __launch_bounds__(256) void k_query_forest(ForestDev f, const double *__restrict__ q, int N, int *__restrict__ vid, double *__restrict__ w, size_t comp, int *status) {
+    const int b = blockIdx.y;
+    const DevTree T = forest_tree_dev(f, b);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
+        const V3 p = mk(q[i], q[N + i], q[2 * (size_t)N + i]);
+        const size_t at = (size_t)b * N + i;
+        const int t = find_closest_triangle(T, p);
+        if (t < 0) {
+            raise_status(status, t);
+            vid[at] = vid[comp + at] = vid[2 * comp + at] = -1;
+            w[at] = w[comp + at] = w[2 * comp + at] = 0.0;
+            continue;
+        }
+        const TriRec &r = T.rec[t];
+        vid[at] = r.id[0], vid[comp + at] = r.id[1], vid[2 * comp + at] = r.id[2];
+        const V3 v0 = rec_v0(r), v1 = rec_v1(r), v2 = rec_v2(r);
+        const V3 pp = project_point(p, v0, v1, v2);  // calc_barycentric_weights projects the query first (R/triangle.cpp:130)
+        double wa, wb, wc;
+        area_weights(v0, v1, v2, pp, wa, wb, wc);
+        w[at] = wa, w[comp + at] = wb, w[2 * comp + at] = wc;
+    }
+}
+int launch_query_forest(msm_ctx *ctx, const ForestDev &f, int B, const double *d_q, int N, int *d_vid, double *d_w, size_t comp) {
+    if (N <= 0 || B <= 0) return MSM_OK;
+    hipLaunchKernelGGL(k_query_forest, dim3((unsigned)std::min((N + 255) / 256, 1024), (unsigned)B), dim3(256), 0, ctx->stream, f, d_q, N, d_vid, d_w, comp, ctx->d_status);
+    MSM_HIP(hipGetLastError());
+    return MSM_OK;
+}
+
 // blockIdx.y = subject a; a thread per (v, b > a), v-major as in the list
 __global__ __launch_bounds__(256) void k_group_pairs(ForestDev f, const double *__restrict__ cp, int S, int N, int *__restrict__ pairs, int *status) {
     const int a = blockIdx.y, nb = S - 1 - a;

@@ -30,7 +30,19 @@ struct AdaptiveDevArgs {
     double *tval;
     int *row_ptr, *col;            // the result as CSR: nNew + 1, 3 nNew + 3 nOld
     double *val;
+    // B problems at once (gMSM: a subject's data mesh rotated to every label against the one template): problem b = blockIdx.y of
+    // every launch uses the arrays b * stride elements further on.  fstride / rstride: distance between the three components of
+    // fvid / fw and rvid / rw (nNew and nOld for one problem).  All strides 0 and B = 1 for one problem.
+    int B = 1;
+    size_t fstride = 0, rstride = 0;
+    size_t s_f = 0, s_r = 0, s_oldA = 0, s_newA = 0, s_roff = 0, s_rfill = 0, s_r3 = 0, s_coff = 0, s_cfill = 0, s_cap = 0, s_corr = 0, s_rowptr = 0, s_scan = 0;
 };
+// vertex areas of B coordinate sets over one triangle list: component c of vertex i of set b at xyz[c * comp + b * set + i];
+// ta: scratch, B x T; area: B x V
+int launch_vertex_areas_batch(msm_ctx *ctx, const double *d_xyz, size_t comp, size_t set, int V, const int32_t *d_tri, int T, const int32_t *d_tid_ptr, const int32_t *d_tid,
+                              int B, double *d_ta, double *d_area);
+// out[b][d][k] = problem b's weights applied to data (D x nOld, shared by the problems); out: B blocks of out_stride doubles
+int launch_apply_rows_batch(msm_ctx *ctx, const AdaptiveDevArgs &a, int D, const double *d_data, double *d_out, size_t out_stride);
 int launch_vertex_areas(msm_ctx *ctx, const double *d_xyz, int V, const int32_t *d_tri, int T, const int32_t *d_tid_ptr, const int32_t *d_tid, double *d_ta,
                         double *d_area);
 int launch_adaptive_surgery(msm_ctx *ctx, const AdaptiveDevArgs &a);
@@ -237,6 +249,9 @@ struct ForestDev {
     size_t s_node, s_leaf, s_rec, s_grid;
     const int2 *info;  // per tree: number of nodes, grid depth
 };
+// N query points (3 x N SoA) in every tree of a forest: hit-triangle vertex ids and projected barycentric weights of point i in tree
+// b at vid / w [c * comp + b * N + i] (Resampler::get_barycentric_weights, R/resampler.cpp:142-167)
+int launch_query_forest(msm_ctx *ctx, const ForestDev &f, int B, const double *d_q, int N, int *d_vid, double *d_w, size_t comp);
 // estimate_pairs (M/DiscreteGroupModel.cpp:37-55) for the whole group: pair (a, v, b > a) = (a * N + v, b * N + the control point of
 // subject b closest to control point v of subject a, Octree::get_closest_vertex_ID), in the reference's list order.  cp: component
 // c of control point v of subject s at cp[c * S * N + s * N + v].

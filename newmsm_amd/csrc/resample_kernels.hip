@@ -48,17 +48,22 @@ __device__ __forceinline__ int small_map(const int *__restrict__ vid, const doub
     return n;
 }
 
-__global__ __launch_bounds__(256) void k_tri_areas(const double *__restrict__ xyz, int V, const int32_t *__restrict__ tri, int T, double *__restrict__ ta) {
+// component c of vertex i of coordinate set blockIdx.y at xyz[c * comp + blockIdx.y * set + i] (one mesh: comp = V, set = 0)
+__global__ __launch_bounds__(256) void k_tri_areas(const double *__restrict__ xyz, size_t comp, size_t set, const int32_t *__restrict__ tri, int T, double *__restrict__ ta) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= T) return;
+    xyz += blockIdx.y * set;
+    ta += (size_t)blockIdx.y * T;
     const int a = tri[t], b = tri[T + t], c = tri[2 * (size_t)T + t];
-    ta[t] = tri_area(mk(xyz[a], xyz[V + a], xyz[2 * (size_t)V + a]), mk(xyz[b], xyz[V + b], xyz[2 * (size_t)V + b]), mk(xyz[c], xyz[V + c], xyz[2 * (size_t)V + c]));
+    ta[t] = tri_area(mk(xyz[a], xyz[comp + a], xyz[2 * comp + a]), mk(xyz[b], xyz[comp + b], xyz[2 * comp + b]), mk(xyz[c], xyz[comp + c], xyz[2 * comp + c]));
 }
 // compute_vertex_area, R/mesh.cpp:1275-1283: mean area of the adjacent faces, in trID order
-__global__ __launch_bounds__(256) void k_vertex_areas(const double *__restrict__ ta, const int32_t *__restrict__ tid_ptr, const int32_t *__restrict__ tid, int V,
+__global__ __launch_bounds__(256) void k_vertex_areas(const double *__restrict__ ta, int T, const int32_t *__restrict__ tid_ptr, const int32_t *__restrict__ tid, int V,
                                                        double *__restrict__ area) {
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= V) return;
+    ta += (size_t)blockIdx.y * T;
+    area += (size_t)blockIdx.y * V;
     double sum = 0;
     for (int j = tid_ptr[v]; j < tid_ptr[v + 1]; ++j) sum += ta[tid[j]];
     area[v] = sum / (tid_ptr[v + 1] - tid_ptr[v]);
@@ -67,6 +72,7 @@ __global__ __launch_bounds__(256) void k_vertex_areas(const double *__restrict__
 // in-place exclusive prefix sum of n ints, data[n] receives the total.  Two launches: sums of 4096-item blocks, then every block
 // adds up the sums before it and scans its items (coalesced rows of 256; a first version with one workgroup and a contiguous
 // piece per thread read with a 160-byte stride between lanes and took 60 us per call, three calls per resampling).
+// blockIdx.y: problem (data and sums s_data / s_sums further on).
 constexpr int kScanBlock = 4096;
 __device__ __forceinline__ int wave_incl_scan_i(int v, int lane) {
 #pragma unroll
@@ -76,8 +82,10 @@ __device__ __forceinline__ int wave_incl_scan_i(int v, int lane) {
     }
     return v;
 }
-__global__ __launch_bounds__(256) void k_scan_block_sums(const int *__restrict__ data, int n, int *__restrict__ sums) {
+__global__ __launch_bounds__(256) void k_scan_block_sums(const int *__restrict__ data, int n, int *__restrict__ sums, size_t s_data, size_t s_sums) {
     __shared__ int s_w[4];
+    data += blockIdx.y * s_data;
+    sums += blockIdx.y * s_sums;
     const int base = blockIdx.x * kScanBlock, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     int acc = 0;
     for (int j = threadIdx.x; j < kScanBlock && base + j < n; j += 256) acc += data[base + j];
@@ -87,8 +95,10 @@ __global__ __launch_bounds__(256) void k_scan_block_sums(const int *__restrict__
     __syncthreads();
     if (threadIdx.x == 0) sums[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
 }
-__global__ __launch_bounds__(256) void k_scan_apply(int *__restrict__ data, int n, const int *__restrict__ sums) {
+__global__ __launch_bounds__(256) void k_scan_apply(int *__restrict__ data, int n, const int *__restrict__ sums, size_t s_data, size_t s_sums) {
     __shared__ int s_w[4], s_before;
+    data += blockIdx.y * s_data;
+    sums += blockIdx.y * s_sums;
     const int base = blockIdx.x * kScanBlock, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     int acc = 0;
     for (int k = threadIdx.x; k < (int)blockIdx.x; k += 256) acc += sums[k];
@@ -114,31 +124,51 @@ __global__ __launch_bounds__(256) void k_scan_apply(int *__restrict__ data, int 
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) data[n] = run;
 }
 
-__global__ __launch_bounds__(256) void k_rev_count(const int *__restrict__ rvid, const double *__restrict__ rw, int nOld, int *__restrict__ rcount) {
-    const int o = blockIdx.x * blockDim.x + threadIdx.x;
-    if (o >= nOld) return;
-    Entry e[3];
-    const int n = small_map(rvid, rw, nOld, o, e);
-    for (int j = 0; j < n; ++j)
-        if (e[j].key >= 0) atomicAdd(&rcount[e[j].key], 1);
+// the arrays of problem blockIdx.y
+__device__ __forceinline__ AdaptiveDevArgs problem_view(AdaptiveDevArgs a) {
+    const size_t b = blockIdx.y;
+    if (b == 0) return a;
+    a.fvid += b * a.s_f, a.fw += b * a.s_f;
+    a.rvid += b * a.s_r, a.rw += b * a.s_r;
+    a.oldA += b * a.s_oldA, a.newA += b * a.s_newA;
+    a.roff += b * a.s_roff, a.rfill += b * a.s_rfill, a.rkey += b * a.s_r3, a.rwt += b * a.s_r3;
+    a.coff += b * a.s_coff, a.cfill += b * a.s_cfill, a.ckey += b * a.s_cap, a.cval += b * a.s_cap, a.correction += b * a.s_corr;
+    a.tkey += b * a.s_cap, a.tval += b * a.s_cap;
+    a.row_ptr += b * a.s_rowptr, a.col += b * a.s_cap, a.val += b * a.s_cap;
+    return a;
 }
-__global__ __launch_bounds__(256) void k_rev_fill(const int *__restrict__ rvid, const double *__restrict__ rw, int nOld, const int *__restrict__ roff,
-                                                   int *__restrict__ rfill, int *__restrict__ rkey, double *__restrict__ rwt) {
+
+__global__ __launch_bounds__(256) void k_rev_count(AdaptiveDevArgs a) {
+    a = problem_view(a);
     const int o = blockIdx.x * blockDim.x + threadIdx.x;
-    if (o >= nOld) return;
+    if (o >= a.nOld) return;
     Entry e[3];
-    const int n = small_map(rvid, rw, nOld, o, e);
+    const int n = small_map(a.rvid, a.rw, (int)a.rstride, o, e);
+    for (int j = 0; j < n; ++j)
+        if (e[j].key >= 0) atomicAdd(&a.roff[e[j].key], 1);
+}
+__global__ __launch_bounds__(256) void k_rev_fill(AdaptiveDevArgs a) {
+    a = problem_view(a);
+    const int o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= a.nOld) return;
+    Entry e[3];
+    const int n = small_map(a.rvid, a.rw, (int)a.rstride, o, e);
     for (int j = 0; j < n; ++j) {
         if (e[j].key < 0) continue;
-        const int pos = roff[e[j].key] + atomicAdd(&rfill[e[j].key], 1);
-        rkey[pos] = o;
-        rwt[pos] = e[j].w;
+        const int pos = a.roff[e[j].key] + atomicAdd(&a.rfill[e[j].key], 1);
+        a.rkey[pos] = o;
+        a.rwt[pos] = e[j].w;
     }
 }
 // each list sorted by its int key.  Lists of up to kShortList entries (all of them when the two meshes have similar
-// resolutions): a thread per list, insertion sort in place.
+// resolutions): a thread per list, insertion sort in place.  which: 0 the transposed reverse lists, 1 the columns.
 constexpr int kShortList = 16;
-__global__ __launch_bounds__(256) void k_sort_lists(const int *__restrict__ off, int n, int *__restrict__ key, double *__restrict__ val) {
+__global__ __launch_bounds__(256) void k_sort_lists(AdaptiveDevArgs a, int which) {
+    a = problem_view(a);
+    const int *off = which ? a.coff : a.roff;
+    const int n = which ? a.nOld : a.nNew;
+    int *key = which ? a.ckey : a.rkey;
+    double *val = which ? a.cval : a.rwt;
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     const int b = off[k], e = off[k + 1];
@@ -158,147 +188,174 @@ __global__ __launch_bounds__(256) void k_sort_lists(const int *__restrict__ off,
 }
 // Longer lists (a coarse mesh against a fine one: hundreds of entries per list): a workgroup per list, rank sort -- the keys of
 // a list are distinct, so an entry's place is the number of smaller keys -- through a scratch copy.
-__global__ __launch_bounds__(256) void k_sort_long_lists(const int *__restrict__ off, int n, int *__restrict__ key, double *__restrict__ val, int *__restrict__ tkey,
-                                                          double *__restrict__ tval) {
-    const int k = blockIdx.x;
-    const int b = off[k], len = off[k + 1] - b;
-    if (len <= kShortList) return;
-    for (int i = threadIdx.x; i < len; i += blockDim.x) {
-        const int mine = key[b + i];
-        int rank = 0;
-        for (int j = 0; j < len; ++j) rank += key[b + j] < mine;
-        tkey[b + rank] = mine;
-        tval[b + rank] = val[b + i];
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < len; i += blockDim.x) {
-        key[b + i] = tkey[b + i];
-        val[b + i] = tval[b + i];
+__global__ __launch_bounds__(256) void k_sort_long_lists(AdaptiveDevArgs a, int which) {
+    a = problem_view(a);
+    const int *off = which ? a.coff : a.roff;
+    int *key = which ? a.ckey : a.rkey;
+    double *val = which ? a.cval : a.rwt;
+    int *tkey = a.tkey;
+    double *tval = a.tval;
+    const int n = which ? a.nOld : a.nNew;
+    for (int k = blockIdx.x; k < n; k += gridDim.x) {  // uniform
+        const int b = off[k], len = off[k + 1] - b;
+        if (len <= kShortList) continue;
+        for (int i = threadIdx.x; i < len; i += blockDim.x) {
+            const int mine = key[b + i];
+            int rank = 0;
+            for (int j = 0; j < len; ++j) rank += key[b + j] < mine;
+            tkey[b + rank] = mine;
+            tval[b + rank] = val[b + i];
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < len; i += blockDim.x) {
+            key[b + i] = tkey[b + i];
+            val[b + i] = tval[b + i];
+        }
+        __syncthreads();
     }
 }
 // :105-109: the forward list unless the transposed reverse list is longer
-__global__ __launch_bounds__(256) void k_row_len(const int *__restrict__ fvid, const double *__restrict__ fw, int nNew, const int *__restrict__ roff,
-                                                  int *__restrict__ len) {
+__global__ __launch_bounds__(256) void k_row_len(AdaptiveDevArgs a) {
+    a = problem_view(a);
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= nNew) return;
+    if (k >= a.nNew) return;
     Entry f[3];
-    const int nf = small_map(fvid, fw, nNew, k, f), nr = roff[k + 1] - roff[k];
-    len[k] = nr <= nf ? nf : nr;
+    const int nf = small_map(a.fvid, a.fw, (int)a.fstride, k, f), nr = a.roff[k + 1] - a.roff[k];
+    a.row_ptr[k] = nr <= nf ? nf : nr;
 }
-__global__ __launch_bounds__(256) void k_row_write(const int *__restrict__ fvid, const double *__restrict__ fw, int nNew, const int *__restrict__ roff,
-                                                    const int *__restrict__ rkey, const double *__restrict__ rwt, const double *__restrict__ newA,
-                                                    const int *__restrict__ row_ptr, int *__restrict__ col, double *__restrict__ val, int *__restrict__ ccount) {
+__global__ __launch_bounds__(256) void k_row_write(AdaptiveDevArgs a) {
+    a = problem_view(a);
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= nNew) return;
+    if (k >= a.nNew) return;
     Entry f[3];
-    const int nf = small_map(fvid, fw, nNew, k, f), nr = roff[k + 1] - roff[k];
-    const int n = nr <= nf ? nf : nr, at = row_ptr[k];
+    const int nf = small_map(a.fvid, a.fw, (int)a.fstride, k, f), nr = a.roff[k + 1] - a.roff[k];
+    const int n = nr <= nf ? nf : nr, at = a.row_ptr[k];
     for (int j = 0; j < n; ++j) {
-        const int key = nr <= nf ? f[j].key : rkey[roff[k] + j];
-        const double w = nr <= nf ? f[j].w : rwt[roff[k] + j];
-        col[at + j] = key;
-        val[at + j] = w * newA[k];
-        if (key >= 0) atomicAdd(&ccount[key], 1);
+        const int key = nr <= nf ? f[j].key : a.rkey[a.roff[k] + j];
+        const double w = nr <= nf ? f[j].w : a.rwt[a.roff[k] + j];
+        a.col[at + j] = key;
+        a.val[at + j] = w * a.newA[k];
+        if (key >= 0) atomicAdd(&a.coff[key], 1);
     }
 }
-__global__ __launch_bounds__(256) void k_col_fill(int nNew, const int *__restrict__ row_ptr, const int *__restrict__ col, const double *__restrict__ val,
-                                                   const int *__restrict__ coff, int *__restrict__ cfill, int *__restrict__ ckey, double *__restrict__ cval) {
+__global__ __launch_bounds__(256) void k_col_fill(AdaptiveDevArgs a) {
+    a = problem_view(a);
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= nNew) return;
-    for (int e = row_ptr[k]; e < row_ptr[k + 1]; ++e) {
-        if (col[e] < 0) continue;
-        const int pos = coff[col[e]] + atomicAdd(&cfill[col[e]], 1);
-        ckey[pos] = k;
-        cval[pos] = val[e];
+    if (k >= a.nNew) return;
+    for (int e = a.row_ptr[k]; e < a.row_ptr[k + 1]; ++e) {
+        if (a.col[e] < 0) continue;
+        const int pos = a.coff[a.col[e]] + atomicAdd(&a.cfill[a.col[e]], 1);
+        a.ckey[pos] = k;
+        a.cval[pos] = a.val[e];
     }
 }
 // correction[j] = the column's contributions summed in ascending new-vertex order (:111-116 visits k = 0, 1, ...)
-__global__ __launch_bounds__(256) void k_col_sum(const int *__restrict__ coff, int nOld, const double *__restrict__ cval, double *__restrict__ correction) {
+__global__ __launch_bounds__(256) void k_col_sum(AdaptiveDevArgs a) {
+    a = problem_view(a);
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= nOld) return;
+    if (j >= a.nOld) return;
     double s = 0.0;
-    for (int e = coff[j]; e < coff[j + 1]; ++e) s += cval[e];
-    correction[j] = s;
+    for (int e = a.coff[j]; e < a.coff[j + 1]; ++e) s += a.cval[e];
+    a.correction[j] = s;
 }
 // :120-137: rescale by oldArea / correction, normalise the row
-__global__ __launch_bounds__(256) void k_row_finish(int nNew, const int *__restrict__ row_ptr, const int *__restrict__ col, double *__restrict__ val,
-                                                     const double *__restrict__ oldA, const double *__restrict__ correction) {
+__global__ __launch_bounds__(256) void k_row_finish(AdaptiveDevArgs a) {
+    a = problem_view(a);
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= nNew) return;
+    if (k >= a.nNew) return;
     double wsum = 0.0;
-    for (int e = row_ptr[k]; e < row_ptr[k + 1]; ++e) {
-        if (col[e] < 0) continue;  // a failed search (reported through the status word)
-        val[e] *= oldA[col[e]] / correction[col[e]];
-        wsum += val[e];
+    for (int e = a.row_ptr[k]; e < a.row_ptr[k + 1]; ++e) {
+        if (a.col[e] < 0) continue;  // a failed search (reported through the status word)
+        a.val[e] *= a.oldA[a.col[e]] / a.correction[a.col[e]];
+        wsum += a.val[e];
     }
     if (wsum != 0.0)
-        for (int e = row_ptr[k]; e < row_ptr[k + 1]; ++e) val[e] /= wsum;
+        for (int e = a.row_ptr[k]; e < a.row_ptr[k + 1]; ++e) a.val[e] /= wsum;
 }
 // barycentric_data_interpolation, R/resampler.cpp:40-52: out[d][k] = sum over the row, in entry order
-__global__ __launch_bounds__(256) void k_apply_rows(int nNew, int nOld, int D, const int *__restrict__ row_ptr, const int *__restrict__ col,
-                                                     const double *__restrict__ val, const double *__restrict__ data, double *__restrict__ out) {
+__global__ __launch_bounds__(256) void k_apply_rows(AdaptiveDevArgs a, int D, const double *__restrict__ data, double *__restrict__ out, size_t out_stride) {
+    out += blockIdx.y * out_stride;
+    a = problem_view(a);
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (size_t)nNew * D) return;
-    const int d = (int)(i / nNew), k = (int)(i - (size_t)d * nNew);
+    if (i >= (size_t)a.nNew * D) return;
+    const int d = (int)(i / a.nNew), k = (int)(i - (size_t)d * a.nNew);
     double acc = 0.0;
-    for (int e = row_ptr[k]; e < row_ptr[k + 1]; ++e)
-        if (col[e] >= 0) acc += data[(size_t)d * nOld + col[e]] * val[e];
+    for (int e = a.row_ptr[k]; e < a.row_ptr[k + 1]; ++e)
+        if (a.col[e] >= 0) acc += data[(size_t)d * a.nOld + a.col[e]] * a.val[e];
     out[i] = acc;
 }
 
 }  // namespace
 
-#define MSM_LAUNCH1D(kernel, n, ...)                                                                      \
-    do {                                                                                                  \
-        if ((n) > 0) hipLaunchKernelGGL(kernel, dim3((unsigned)(((n) + 255) / 256)), dim3(256), 0, ctx->stream, __VA_ARGS__); \
+#define MSM_LAUNCH2D(kernel, n, B, ...)                                                                                          \
+    do {                                                                                                                         \
+        if ((n) > 0) hipLaunchKernelGGL(kernel, dim3((unsigned)(((n) + 255) / 256), (unsigned)(B)), dim3(256), 0, ctx->stream, __VA_ARGS__); \
     } while (0)
 
-static void scan_excl(msm_ctx *ctx, int *data, int n, int *tmp) {
+static void scan_excl(msm_ctx *ctx, int *data, int n, int *tmp, int B, size_t s_data, size_t s_tmp) {
     const int nb = std::max(1, (n + kScanBlock - 1) / kScanBlock);
-    hipLaunchKernelGGL(k_scan_block_sums, dim3(nb), dim3(256), 0, ctx->stream, data, n, tmp);
-    hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(256), 0, ctx->stream, data, n, tmp);
+    hipLaunchKernelGGL(k_scan_block_sums, dim3(nb, (unsigned)B), dim3(256), 0, ctx->stream, data, n, tmp, s_data, s_tmp);
+    hipLaunchKernelGGL(k_scan_apply, dim3(nb, (unsigned)B), dim3(256), 0, ctx->stream, data, n, tmp, s_data, s_tmp);
 }
-
+int launch_vertex_areas_batch(msm_ctx *ctx, const double *d_xyz, size_t comp, size_t set, int V, const int32_t *d_tri, int T, const int32_t *d_tid_ptr, const int32_t *d_tid,
+                              int B, double *d_ta, double *d_area) {
+    MSM_LAUNCH2D(k_tri_areas, T, B, d_xyz, comp, set, d_tri, T, d_ta);
+    MSM_LAUNCH2D(k_vertex_areas, V, B, d_ta, T, d_tid_ptr, d_tid, V, d_area);
+    MSM_HIP(hipGetLastError());
+    return MSM_OK;
+}
 int launch_vertex_areas(msm_ctx *ctx, const double *d_xyz, int V, const int32_t *d_tri, int T, const int32_t *d_tid_ptr, const int32_t *d_tid, double *d_ta,
                         double *d_area) {
-    MSM_LAUNCH1D(k_tri_areas, T, d_xyz, V, d_tri, T, d_ta);
-    MSM_LAUNCH1D(k_vertex_areas, V, d_ta, d_tid_ptr, d_tid, V, d_area);
+    return launch_vertex_areas_batch(ctx, d_xyz, (size_t)V, 0, V, d_tri, T, d_tid_ptr, d_tid, 1, d_ta, d_area);
+}
+
+// the surgery: every argument is device memory; the caller sizes col / val for 3 * nNew + 3 * nOld entries per problem (a row is
+// the forward list, at most 3, or the transposed reverse list, whose lengths add up to at most 3 * nOld)
+int launch_adaptive_surgery(msm_ctx *ctx, const AdaptiveDevArgs &arg) {
+    AdaptiveDevArgs a = arg;
+    const int nOld = a.nOld, nNew = a.nNew, B = std::max(a.B, 1);
+    if (a.fstride == 0) a.fstride = (size_t)nNew;
+    if (a.rstride == 0) a.rstride = (size_t)nOld;
+    if (B == 1) {
+        MSM_HIP(hipMemsetAsync(a.roff, 0, sizeof(int) * ((size_t)nNew + 1), ctx->stream));
+        MSM_HIP(hipMemsetAsync(a.rfill, 0, sizeof(int) * (size_t)nNew, ctx->stream));
+        MSM_HIP(hipMemsetAsync(a.coff, 0, sizeof(int) * ((size_t)nOld + 1), ctx->stream));
+        MSM_HIP(hipMemsetAsync(a.cfill, 0, sizeof(int) * (size_t)nOld, ctx->stream));
+    } else {  // the problems' arrays lie one after the other
+        MSM_HIP(hipMemsetAsync(a.roff, 0, sizeof(int) * a.s_roff * B, ctx->stream));
+        MSM_HIP(hipMemsetAsync(a.rfill, 0, sizeof(int) * a.s_rfill * B, ctx->stream));
+        MSM_HIP(hipMemsetAsync(a.coff, 0, sizeof(int) * a.s_coff * B, ctx->stream));
+        MSM_HIP(hipMemsetAsync(a.cfill, 0, sizeof(int) * a.s_cfill * B, ctx->stream));
+    }
+    MSM_LAUNCH2D(k_rev_count, nOld, B, a);
+    scan_excl(ctx, a.roff, nNew, a.scan_tmp, B, a.s_roff, a.s_scan);
+    MSM_LAUNCH2D(k_rev_fill, nOld, B, a);
+    MSM_LAUNCH2D(k_sort_lists, nNew, B, a, 0);
+    hipLaunchKernelGGL(k_sort_long_lists, dim3((unsigned)std::min(nNew, 2048), (unsigned)B), dim3(256), 0, ctx->stream, a, 0);
+    MSM_LAUNCH2D(k_row_len, nNew, B, a);
+    scan_excl(ctx, a.row_ptr, nNew, a.scan_tmp, B, a.s_rowptr, a.s_scan);
+    MSM_LAUNCH2D(k_row_write, nNew, B, a);
+    scan_excl(ctx, a.coff, nOld, a.scan_tmp, B, a.s_coff, a.s_scan);
+    MSM_LAUNCH2D(k_col_fill, nNew, B, a);
+    MSM_LAUNCH2D(k_sort_lists, nOld, B, a, 1);
+    hipLaunchKernelGGL(k_sort_long_lists, dim3((unsigned)std::min(nOld, 2048), (unsigned)B), dim3(256), 0, ctx->stream, a, 1);
+    MSM_LAUNCH2D(k_col_sum, nOld, B, a);
+    MSM_LAUNCH2D(k_row_finish, nNew, B, a);
     MSM_HIP(hipGetLastError());
     return MSM_OK;
 }
 
-// the surgery: every argument is device memory; the caller sizes col / val for 3 * nNew + 3 * nOld entries (a row is the
-// forward list, at most 3, or the transposed reverse list, whose lengths add up to at most 3 * nOld).  *d_nnz_out (device int)
-// = row_ptr[nNew].
-int launch_adaptive_surgery(msm_ctx *ctx, const AdaptiveDevArgs &a) {
-    const int nOld = a.nOld, nNew = a.nNew;
-    MSM_HIP(hipMemsetAsync(a.roff, 0, sizeof(int) * ((size_t)nNew + 1), ctx->stream));
-    MSM_HIP(hipMemsetAsync(a.rfill, 0, sizeof(int) * (size_t)nNew, ctx->stream));
-    MSM_HIP(hipMemsetAsync(a.coff, 0, sizeof(int) * ((size_t)nOld + 1), ctx->stream));
-    MSM_HIP(hipMemsetAsync(a.cfill, 0, sizeof(int) * (size_t)nOld, ctx->stream));
-    MSM_LAUNCH1D(k_rev_count, nOld, a.rvid, a.rw, nOld, a.roff);
-    scan_excl(ctx, a.roff, nNew, a.scan_tmp);
-    MSM_LAUNCH1D(k_rev_fill, nOld, a.rvid, a.rw, nOld, a.roff, a.rfill, a.rkey, a.rwt);
-    MSM_LAUNCH1D(k_sort_lists, nNew, a.roff, nNew, a.rkey, a.rwt);
-    hipLaunchKernelGGL(k_sort_long_lists, dim3(nNew), dim3(256), 0, ctx->stream, a.roff, nNew, a.rkey, a.rwt, a.tkey, a.tval);
-    MSM_LAUNCH1D(k_row_len, nNew, a.fvid, a.fw, nNew, a.roff, a.row_ptr);
-    scan_excl(ctx, a.row_ptr, nNew, a.scan_tmp);
-    MSM_LAUNCH1D(k_row_write, nNew, a.fvid, a.fw, nNew, a.roff, a.rkey, a.rwt, a.newA, a.row_ptr, a.col, a.val, a.coff);
-    scan_excl(ctx, a.coff, nOld, a.scan_tmp);
-    MSM_LAUNCH1D(k_col_fill, nNew, nNew, a.row_ptr, a.col, a.val, a.coff, a.cfill, a.ckey, a.cval);
-    MSM_LAUNCH1D(k_sort_lists, nOld, a.coff, nOld, a.ckey, a.cval);
-    hipLaunchKernelGGL(k_sort_long_lists, dim3(nOld), dim3(256), 0, ctx->stream, a.coff, nOld, a.ckey, a.cval, a.tkey, a.tval);
-    MSM_LAUNCH1D(k_col_sum, nOld, a.coff, nOld, a.cval, a.correction);
-    MSM_LAUNCH1D(k_row_finish, nNew, nNew, a.row_ptr, a.col, a.val, a.oldA, a.correction);
+int launch_apply_rows_batch(msm_ctx *ctx, const AdaptiveDevArgs &a, int D, const double *d_data, double *d_out, size_t out_stride) {
+    const size_t total = (size_t)a.nNew * D;
+    MSM_LAUNCH2D(k_apply_rows, total, std::max(a.B, 1), a, D, d_data, d_out, out_stride);
     MSM_HIP(hipGetLastError());
     return MSM_OK;
 }
-
 int launch_apply_rows(msm_ctx *ctx, int nNew, int nOld, int D, const int *row_ptr, const int *col, const double *val, const double *d_data, double *d_out) {
-    const size_t total = (size_t)nNew * D;
-    MSM_LAUNCH1D(k_apply_rows, total, nNew, nOld, D, row_ptr, col, val, d_data, d_out);
-    MSM_HIP(hipGetLastError());
-    return MSM_OK;
+    AdaptiveDevArgs a{};
+    a.nNew = nNew, a.nOld = nOld, a.B = 1;
+    a.row_ptr = const_cast<int *>(row_ptr), a.col = const_cast<int *>(col), a.val = const_cast<double *>(val);
+    return launch_apply_rows_batch(ctx, a, D, d_data, d_out, 0);
 }
 
 }  // namespace msm
