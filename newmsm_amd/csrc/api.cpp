@@ -510,7 +510,7 @@ int ensure_adjacency_dev(msm_mesh *m) {
 
 namespace {
 struct ResampleScratch {
-    DevBuf<int> fvid, rvid, roff, rfill, rkey, coff, cfill, ckey, row_ptr, col, tkey, scan_tmp;
+    DevBuf<int> fvid, rvid, roff, rfill, rkey, coff, cfill, ckey, row_ptr, col, tkey, scan_tmp, long_flag;
     DevBuf<double> fw, rw, oldA, newA, ta, rwt, cval, correction, val, data, out, tval;
 };
 ResampleScratch &resample_scratch(msm_ctx *ctx) {
@@ -554,6 +554,7 @@ int adaptive_weights_dev(msm_mesh *in_mesh, msm_mesh *new_mesh, AdaptiveDev &out
     MSM_HIP(s.val.ensure(cap));
     MSM_HIP(s.tkey.ensure(cap));
     MSM_HIP(s.scan_tmp.ensure((size_t)std::max(nNew, nOld) / 4096 + 2));
+    MSM_HIP(s.long_flag.ensure(2));
     MSM_HIP(s.tval.ensure(cap));
     // forward: the new mesh's vertices in the old mesh's tree; reverse: the old vertices in the new mesh's tree (:74-78)
     st = launch_query(ctx, in_tree ? *in_tree : dev_tree(in_mesh), new_mesh->d_xyz, nNew, nullptr, s.fvid.p, s.fw.p, MSM_WEIGHTS_PROJECTED);
@@ -569,7 +570,7 @@ int adaptive_weights_dev(msm_mesh *in_mesh, msm_mesh *new_mesh, AdaptiveDev &out
     a.fvid = s.fvid.p, a.rvid = s.rvid.p, a.fw = s.fw.p, a.rw = s.rw.p, a.oldA = s.oldA.p, a.newA = s.newA.p;
     a.roff = s.roff.p, a.rfill = s.rfill.p, a.rkey = s.rkey.p, a.rwt = s.rwt.p;
     a.coff = s.coff.p, a.cfill = s.cfill.p, a.ckey = s.ckey.p, a.cval = s.cval.p, a.correction = s.correction.p;
-    a.row_ptr = s.row_ptr.p, a.col = s.col.p, a.val = s.val.p, a.tkey = s.tkey.p, a.tval = s.tval.p, a.scan_tmp = s.scan_tmp.p;
+    a.row_ptr = s.row_ptr.p, a.col = s.col.p, a.val = s.val.p, a.tkey = s.tkey.p, a.tval = s.tval.p, a.scan_tmp = s.scan_tmp.p, a.long_flag = s.long_flag.p;
     st = launch_adaptive_surgery(ctx, a);
     if (st) return st;
     if (check) {

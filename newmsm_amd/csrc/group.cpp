@@ -85,7 +85,7 @@ struct msm_group {
     // the per-label remainder of a subject's set-up with the label as the second grid dimension of every launch (stage_batch)
     struct Batch {
         msm_ctx *ctx = nullptr;  // a stream of its own: runs beside the main stream's preparation of the next subject
-        DevBuf<int> fvid, rvid, roff, rfill, rkey, coff, cfill, ckey, row_ptr, col, tkey, scan_tmp;
+        DevBuf<int> fvid, rvid, roff, rfill, rkey, coff, cfill, ckey, row_ptr, col, tkey, scan_tmp, long_flag;
         DevBuf<double> fw, rw, oldA, newA, ta, rwt, cval, correction, val, tval;
         DevBuf<int2> info[2];
     } batch;
@@ -748,6 +748,7 @@ static int stage_batch(msm_group *g, int s, msm_group::Stage &b, int which) {
     MSM_HIP(w.tkey.ensure(L * cap));
     MSM_HIP(w.tval.ensure(L * cap));
     MSM_HIP(w.scan_tmp.ensure((size_t)L * nscan));
+    MSM_HIP(w.long_flag.ensure(2 * (size_t)L));
     std::vector<int2> info(L);
     for (int l = 0; l < L; ++l) info[l] = make_int2(b.forest.info[l].nnodes, b.forest.info[l].grid_depth);
     MSM_HIP(w.info[which].ensure(L));
@@ -772,7 +773,7 @@ static int stage_batch(msm_group *g, int s, msm_group::Stage &b, int which) {
     a.fvid = w.fvid.p, a.fw = w.fw.p, a.rvid = w.rvid.p, a.rw = w.rw.p, a.oldA = w.oldA.p, a.newA = w.newA.p;
     a.roff = w.roff.p, a.rfill = w.rfill.p, a.rkey = w.rkey.p, a.rwt = w.rwt.p;
     a.coff = w.coff.p, a.cfill = w.cfill.p, a.ckey = w.ckey.p, a.cval = w.cval.p, a.correction = w.correction.p;
-    a.scan_tmp = w.scan_tmp.p, a.tkey = w.tkey.p, a.tval = w.tval.p;
+    a.scan_tmp = w.scan_tmp.p, a.long_flag = w.long_flag.p, a.tkey = w.tkey.p, a.tval = w.tval.p;
     a.row_ptr = w.row_ptr.p, a.col = w.col.p, a.val = w.val.p;
     a.B = L;
     a.fstride = LVt, a.rstride = LV;

@@ -26,6 +26,7 @@ struct AdaptiveDevArgs {
     int *coff, *cfill, *ckey;      // columns of the result: offsets (nOld + 1), fill counters (nOld), new vertex ids (3 nNew + 3 nOld)
     double *cval, *correction;     // (nOld)
     int *scan_tmp;                 // scratch of the prefix sums, max(nNew, nOld) / 4096 + 2
+    int *long_flag;                // 2 per problem: does any transposed reverse list / any column exceed the short sort's limit?
     int *tkey;                     // scratch of the long-list sort, 3 nNew + 3 nOld
     double *tval;
     int *row_ptr, *col;            // the result as CSR: nNew + 1, 3 nNew + 3 nOld

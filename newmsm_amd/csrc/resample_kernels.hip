@@ -172,7 +172,10 @@ __global__ __launch_bounds__(256) void k_sort_lists(AdaptiveDevArgs a, int which
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     const int b = off[k], e = off[k + 1];
-    if (e - b > kShortList) return;  // k_sort_long_lists
+    if (e - b > kShortList) {  // k_sort_long_lists, which only runs when somebody says so
+        a.long_flag[2 * blockIdx.y + which] = 1;
+        return;
+    }
     for (int i = b + 1; i < e; ++i) {
         const int kk = key[i];
         const double vv = val[i];
@@ -195,6 +198,7 @@ __global__ __launch_bounds__(256) void k_sort_long_lists(AdaptiveDevArgs a, int 
     double *val = which ? a.cval : a.rwt;
     int *tkey = a.tkey;
     double *tval = a.tval;
+    if (!a.long_flag[2 * blockIdx.y + which]) return;  // no long list in this problem (the usual case: meshes of similar resolution)
     const int n = which ? a.nOld : a.nNew;
     for (int k = blockIdx.x; k < n; k += gridDim.x) {  // uniform
         const int b = off[k], len = off[k + 1] - b;
@@ -327,6 +331,7 @@ int launch_adaptive_surgery(msm_ctx *ctx, const AdaptiveDevArgs &arg) {
         MSM_HIP(hipMemsetAsync(a.coff, 0, sizeof(int) * a.s_coff * B, ctx->stream));
         MSM_HIP(hipMemsetAsync(a.cfill, 0, sizeof(int) * a.s_cfill * B, ctx->stream));
     }
+    MSM_HIP(hipMemsetAsync(a.long_flag, 0, sizeof(int) * 2 * (size_t)B, ctx->stream));
     MSM_LAUNCH2D(k_rev_count, nOld, B, a);
     scan_excl(ctx, a.roff, nNew, a.scan_tmp, B, a.s_roff, a.s_scan);
     MSM_LAUNCH2D(k_rev_fill, nOld, B, a);
