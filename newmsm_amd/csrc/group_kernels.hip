@@ -205,7 +205,7 @@ __global__ __launch_bounds__(256) void k_group_pairwise(GroupArgs a, const int *
                 double va[kRounds][2], vb[kRounds][2], w[kRounds];
 #pragma unroll
                 for (int r = 0; r < kRounds; ++r) {
-                    w[r] = 1.0;
+                    w[r] = mem[r] ? 1.0 : 0.0;  // an entry outside the intersection takes part with weight 0 and values 0: sums unchanged, no branches
 #pragma unroll
                     for (int d = 0; d < 2; ++d) {
                         va[r][d] = vb[r][d] = 0.0;
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256) void k_group_pairwise(GroupArgs a, const int *
                     double s1[5] = {0.0, 0.0, 0.0, 0.0, 0.0};  // sum of weights, then weighted sums of A and B per row
 #pragma unroll
                     for (int r = 0; r < kRounds; ++r)
-                        if (mem[r]) {
+                        {
                             s1[0] += w[r];
 #pragma unroll
                             for (int d = 0; d < 2; ++d) {
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(256) void k_group_pairwise(GroupArgs a, const int *
                     double s2[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};  // per row: products, variance of A, variance of B
 #pragma unroll
                     for (int r = 0; r < kRounds; ++r)
-                        if (mem[r]) {
+                        {
 #pragma unroll
                             for (int d = 0; d < 2; ++d) {
                                 const double da = va[r][d] - ma[d], db = vb[r][d] - mb[d];
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(256) void k_group_pairwise(GroupArgs a, const int *
                     double s1[2] = {0.0, 0.0};
 #pragma unroll
                     for (int r = 0; r < kRounds; ++r)
-                        if (mem[r]) {
+                        {
 #pragma unroll
                             for (int d = 0; d < 2; ++d) {
                                 const double df = va[r][d] - vb[r][d];
