@@ -243,7 +243,9 @@ def main():
     rehearse = os.environ.get("MSM_BENCH_REHEARSAL") == "1"
     device_index = 0 if rehearse else local_rank
     torch.cuda.set_device(device_index)
-    comm = D.init("gloo" if rehearse else "nccl", device_index) if world > 1 else D.Comm()
+    # MSM_BENCH_FORCE_DIST=1: a one-rank process group, so that a one-GPU box runs the RCCL collectives of the N > 1 path
+    force = os.environ.get("MSM_BENCH_FORCE_DIST") == "1"
+    comm = D.init("gloo" if rehearse else "nccl", device_index) if (world > 1 or force) else D.Comm()
 
     import __graft_entry__ as g
 

@@ -169,7 +169,7 @@ def sharded_group_setup(group, n_subjects, comm=None):
     c = _comm(comm)
     mine = list(shard(n_subjects, c.rank, c.world))
     group.setup_subjects(mine)
-    if c.dist is not None and c.world > 1:
+    if c.dist is not None:  # also with ONE rank in a process group: the same collectives run (the one-GPU test of the nccl path)
         import torch
 
         L, D, V, M = group.L, group.D, group._keep["template"].V, group.N * group.L + 1
@@ -359,7 +359,7 @@ class ShardedMove:
             self.transport = transport = "gather"
         dev = c.device if c.on_gpu else "cpu"
         self.send = torch.zeros(4 * self.pmax + 8 * self.tmax, dtype=torch.float64, device=dev)
-        self.recv = torch.zeros((c.world, 4 * self.pmax + 8 * self.tmax), dtype=torch.float64, device=dev) if (c.rank == dst and c.world > 1) else None
+        self.recv = torch.zeros((c.world, 4 * self.pmax + 8 * self.tmax), dtype=torch.float64, device=dev) if (c.rank == dst and c.dist is not None) else None
         self.gpu_scratch = None
         if not c.on_gpu:  # rehearsal: the kernels still need device buffers; results are staged through the host
             self.gpu_scratch = (torch.zeros(4 * self.pmax + 8 * self.tmax, dtype=torch.float64, device="cuda:%d" % torch.cuda.current_device())
@@ -389,7 +389,7 @@ class ShardedMove:
         g.fusionMove_dev(labeling, label, (pr.start, pr.stop), (tr.start, tr.stop), buf.data_ptr(), buf.data_ptr() + 8 * 4 * self.pmax)
         if not c.on_gpu:
             self.send.copy_(buf)  # device -> host (gloo gathers host tensors)
-        if c.world == 1 or c.dist is None:
+        if c.dist is None:
             allbuf = self.send.reshape(1, -1)
         else:
             c.dist.gather(self.send, list(self.recv.unbind(0)) if c.rank == self.dst else None, dst=self.dst)

@@ -267,6 +267,28 @@ def test_sharded_group_two_ranks_match_single_rank(tmp_path):
     assert sorted(outs[0]["mine"] + outs[1]["mine"]) == [0, 1, 2, 3]
 
 
+NCCL_WORKER = SHARDED_WORKER.replace('dist = D.init("gloo")', 'dist = D.init("nccl", 0)').replace('for transport in (None, "gather"):', 'for transport in ("gather", "gather"):') \
+    .replace('transports == ["shm", "gather"]', 'transports == ["gather", "gather"] and dist.on_gpu')
+
+
+def test_sharded_group_one_rank_over_rccl(tmp_path):
+    """The same worker with the nccl backend (RCCL) and ONE rank: the test box has one GPU, so this is as far as the device-resident
+    exchange can be driven here -- subjects exported into torch tensors on the GPU, all_gather_into_tensor of float64 / int32 device
+    buffers, the label step written by the kernels into the tensor that dist.gather sends, the template all-reduce on the GPU."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "sharded_nccl.py"
+    script.write_text(NCCL_WORKER % root)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29563", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    pr = subprocess.run([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=500)
+    assert pr.returncode == 0, pr.stderr[-3000:]
+    o = eval(pr.stdout.strip().splitlines()[-1].replace("true", "True").replace("false", "False"))
+    assert o["equal"] and o["move_ok"] and o["template_radius_ok"] and o["n"] == 4 and o["finite"] > 200 and o["mine"] == [0, 1, 2, 3], o
+
+
 def test_group_full_size_properties_64_subjects_ico6(ctx):
     """BASELINE config 5 at full size (64 subjects, ico6 data / ico4 control grid, 19 labels; the oracle takes minutes per subject
     here, so this is checked through size-independent properties): a whole label step (20.7 M pair + 2.6 M triplet costs, processed
