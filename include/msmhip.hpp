@@ -518,6 +518,16 @@ private:
 };
 }  // namespace detail
 
+#ifndef MSMHIP_STEP_COSTS_DEFINED
+#define MSMHIP_STEP_COSTS_DEFINED
+// The costs of one label step as the kernels deliver them (also declared by msmhip_fusion.hpp, whose fusion_optimize reads them)
+struct StepCosts {
+    const double *unary_table = nullptr;     // unarycosts[label * num_nodes + node], or null: every unary cost is 0
+    const double *pair_quads = nullptr;      // [4 p + k], k = 00 01 10 11 (I/Fusion/Fusion.h:170-173)
+    const double *triplet_octets = nullptr;  // [8 t + k], k = 000 .. 111 (I/Fusion/Fusion.h:188-195)
+};
+#endif
+
 struct FusionCounters {
     std::atomic<long> step_calls{0};    // whole label steps evaluated (one ABI call each)
     std::atomic<long> served{0};        // clique costs answered from a cached step / table
@@ -597,6 +607,42 @@ public:
         std::unique_lock<std::shared_mutex> wr(mu_);
         return cf_.evaluateTotalCostSum(labeling_);
     }
+    // A whole label step for a caller that reads buffers instead of asking clique by clique (msmhip::fusion_optimize): one ABI call for the
+    // 8 T triplet costs; the 4 P pairwise costs of regoption 1 are read out of the pair table.  Valid until the next labelStep / setup.
+    StepCosts labelStep(int label) {
+        std::unique_lock<std::shared_mutex> wr(mu_);
+        const int L = getNumLabels(), P = getNumPairs(), T = getNumTriplets();
+        if (label < 0 || label >= L) throw Error(MSM_ERR_INVALID, "labelStep: label out of range");
+        StepCosts out;
+        out.unary_table = cf_.unarycosts.data();
+        step_lab_ = labeling_;
+        step_label_ = label;
+        if (P > 0) {
+            if (!have_pairs_) {
+                cf_.computePairwiseCosts();
+                have_pairs_ = true;
+            }
+            step_quads_.resize(4 * (size_t)P);
+            for (int p = 0; p < P; ++p) {
+                const int a = labeling_[(size_t)pairs_[2 * (size_t)p]], b = labeling_[(size_t)pairs_[2 * (size_t)p + 1]];
+                const double *tab = &cf_.paircosts[(size_t)p * L * L];  // [labelB * L + labelA]
+                double *q = &step_quads_[4 * (size_t)p];
+                q[0] = tab[(size_t)b * L + a];
+                q[1] = tab[(size_t)label * L + a];
+                q[2] = tab[(size_t)b * L + label];
+                q[3] = tab[(size_t)label * L + label];
+            }
+            out.pair_quads = step_quads_.data();
+        }
+        if (T > 0) {
+            double *E = octets_.ensure(ctx_, 8 * (size_t)T);
+            check(msm_cost_triplet_octets(cf_.handle(), step_lab_.data(), label, E));
+            step_valid_ = true;
+            out.triplet_octets = E;
+        }
+        counters.step_calls.fetch_add(1, std::memory_order_relaxed);
+        return out;
+    }
     FusionCounters counters;
 
 private:
@@ -621,6 +667,7 @@ private:
     std::atomic<int> hint_{-1};
     bool step_valid_ = false, have_pairs_ = false;
     std::vector<int32_t> step_lab_;
+    std::vector<double> step_quads_;
     int step_label_ = -1;
     detail::HostBuffer octets_;
 };
@@ -649,6 +696,52 @@ public:
     double computeUnaryCost(int node, int label) {
         if (label != labeling_[(size_t)node]) hint_.store(label, std::memory_order_relaxed);
         return 0.0;
+    }
+    int getNumLabels() const { return labels_; }
+    // DiscreteCostFunction::evaluateTotalCostSum (M/DiscreteCostFunction.cpp:55-77) over the model's labeling: pairs, then triplets, each
+    // summed serially in clique order (the unary costs of the group model are 0)
+    double evaluateTotalCostSum() {
+        std::unique_lock<std::shared_mutex> wr(mu_);
+        const size_t P = pairs_.size() / 2, T = triplets_.size() / 3;
+        std::vector<int32_t> id(std::max(P, T)), la(std::max(P, T)), lb(std::max(P, T)), lc(T);
+        double total = 0.0;
+        if (P) {
+            for (size_t p = 0; p < P; ++p) {
+                id[p] = (int32_t)p;
+                la[p] = labeling_[(size_t)pairs_[2 * p]];
+                lb[p] = labeling_[(size_t)pairs_[2 * p + 1]];
+            }
+            std::vector<double> c(P);
+            check(msm_group_pairwise_batch(m_.handle(), id.data(), la.data(), lb.data(), (int32_t)P, c.data()));
+            for (size_t p = 0; p < P; ++p) total += c[p];
+        }
+        if (T) {
+            for (size_t t = 0; t < T; ++t) {
+                id[t] = (int32_t)t;
+                la[t] = labeling_[(size_t)triplets_[3 * t]];
+                lb[t] = labeling_[(size_t)triplets_[3 * t + 1]];
+                lc[t] = labeling_[(size_t)triplets_[3 * t + 2]];
+            }
+            std::vector<double> c(T);
+            check(msm_group_triplet_batch(m_.handle(), id.data(), la.data(), lb.data(), lc.data(), (int32_t)T, c.data()));
+            for (size_t t = 0; t < T; ++t) total += c[t];
+        }
+        return total;
+    }
+    // a whole label step for msmhip::fusion_optimize: one msm_group_fusion_move into the pinned buffers
+    StepCosts labelStep(int label) {
+        std::unique_lock<std::shared_mutex> wr(mu_);
+        if (label < 0 || label >= labels_) throw Error(MSM_ERR_INVALID, "labelStep: label out of range");
+        step_lab_ = labeling_;
+        step_label_ = label;
+        double *q = quads_.ensure(ctx_, 4 * pairs_.size() / 2), *o = octets_.ensure(ctx_, 8 * triplets_.size() / 3);
+        check(msm_group_fusion_move(m_.handle(), step_lab_.data(), label, q, o));
+        step_valid_ = true;
+        counters.step_calls.fetch_add(1, std::memory_order_relaxed);
+        StepCosts out;
+        out.pair_quads = q;
+        out.triplet_octets = o;
+        return out;
     }
     double computePairwiseCost(int pair, int labelA, int labelB) {  // M/DiscreteGroupCostFunction.cpp:54-98
         const int32_t *n = &pairs_[2 * (size_t)pair];
@@ -684,6 +777,8 @@ private:
     void refresh_sizes() {
         nodes_ = m_.getNumNodes();
         labeling_.resize((size_t)nodes_, 0);
+        int32_t S = 0, N = 0, L = 0, D = 0, Vt = 0;
+        if (msm_group_dims(m_.handle(), &S, &N, &L, &D, &Vt) == MSM_OK) labels_ = L;
     }
     bool lookup(const double *buf, int width, int clique, const int32_t *n, const int *arg, int arity, double &v) {
         if (!step_valid_) return false;
@@ -715,7 +810,7 @@ private:
     }
     msm_ctx *ctx_;
     DiscreteGroupModel &m_;
-    int nodes_ = 0;
+    int nodes_ = 0, labels_ = 0;
     std::vector<int32_t> pairs_, triplets_, labeling_;
     std::shared_mutex mu_;
     std::atomic<int> hint_{-1};

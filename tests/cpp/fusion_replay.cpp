@@ -10,6 +10,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <fstream>
 #include <map>
 #include <memory>
@@ -17,6 +18,8 @@
 #include <string>
 
 #include "msmhip.hpp"
+#include "msmhip_fusion.hpp"
+#include "mini_pbf.hpp"
 
 using namespace msmhip;
 
@@ -114,6 +117,50 @@ static void replay(Model &energy, int num_labels, int numthreads, int sweeps, st
     }
 }
 
+// the same model with only the per-clique interface visible: msmhip::fusion_optimize then runs the reference's three loops against it
+template <class Model>
+struct PerClique {
+    Model &m;
+    int getNumNodes() const { return m.getNumNodes(); }
+    int getNumLabels() const { return m.getNumLabels(); }
+    int getNumPairs() const { return m.getNumPairs(); }
+    int getNumTriplets() const { return m.getNumTriplets(); }
+    int *getLabeling() { return m.getLabeling(); }
+    const int *getPairs() const { return m.getPairs(); }
+    const int *getTriplets() const { return m.getTriplets(); }
+    double computeUnaryCost(int n, int l) { return m.computeUnaryCost(n, l); }
+    double computePairwiseCost(int p, int a, int b) { return m.computePairwiseCost(p, a, b); }
+    double computeTripletCost(int t, int a, int b, int c) { return m.computeTripletCost(t, a, b, c); }
+    double evaluateTotalCostSum() { return m.evaluateTotalCostSum(); }
+};
+
+// A whole Fusion::optimize through msmhip::fusion_optimize (stand-in PBF and solver, tests/cpp/mini_pbf.hpp), twice from the zero
+// labeling: from whole-step buffers (labelStep) and through the per-clique evaluators.  Same labelings, one ABI call per step taken.
+template <class Model>
+static void fused(Model &model, int threads, std::vector<int32_t> &labeling_out, std::vector<double> &info) {
+    using BinaryModel = FlatBinaryModel<mini::MockModelBase, mini::MockCostBase>;
+    const int n = model.getNumNodes();
+    std::fill(model.getLabeling(), model.getLabeling() + n, 0);
+    const long calls0 = model.counters.step_calls.load();
+    FusionTrace ta, tb;
+    const double ea = fusion_optimize<mini::MiniPBF, mini::MiniSolver<BinaryModel>, BinaryModel>(model, false, threads, &ta);
+    const long calls_a = model.counters.step_calls.load() - calls0;
+    std::vector<int32_t> la(model.getLabeling(), model.getLabeling() + n);
+    std::fill(model.getLabeling(), model.getLabeling() + n, 0);
+    PerClique<Model> pc{model};
+    const long single0 = model.counters.single_calls.load();
+    const double eb = fusion_optimize<mini::MiniPBF, mini::MiniSolver<BinaryModel>, BinaryModel>(pc, false, threads, &tb);
+    std::vector<int32_t> lb(model.getLabeling(), model.getLabeling() + n);
+    auto bits = [](const std::vector<double> &x, const std::vector<double> &y) {  // NaN costs (empty patch intersections) compare equal
+        return x.size() == y.size() && (x.empty() || std::memcmp(x.data(), y.data(), x.size() * sizeof(double)) == 0);
+    };
+    const bool same = la == lb && bits(ta.step_energy, tb.step_energy) && ta.nodes_changed == tb.nodes_changed && bits({ea}, {eb});
+    labeling_out = la;
+    int moved = 0;
+    for (int v : la) moved += v != 0;
+    info = {same ? 1.0 : 0.0, (double)ta.step_energy.size(), (double)calls_a, ea, (double)moved, (double)(model.counters.single_calls.load() - single0)};
+}
+
 int main(int argc, char **argv) {
     if (argc != 3) return 2;
     try {
@@ -123,7 +170,8 @@ int main(int argc, char **argv) {
         Context ctx(0);
         std::vector<double> unary_log, pair_log, triplet_log;
         std::vector<int32_t> labeling_log, step_log, counts;
-        std::vector<double> totals;
+        std::vector<double> totals, fused_info;
+        std::vector<int32_t> fused_labeling;
         auto [dxyz, dtri] = make_mesh_from_icosa(data_order);
         auto [cxyz, ctri] = make_mesh_from_icosa(cp_order);
         if (mode == 0) {  // pairwise registration: one iteration's cost function as problem.build_cost assembles it
@@ -151,6 +199,7 @@ int main(int argc, char **argv) {
             replay(model, model.getNumLabels(), threads, sweeps, unary_log, pair_log, triplet_log, labeling_log, step_log);
             totals.push_back(model.evaluateTotalCostSum());
             counts = {(int32_t)model.counters.step_calls.load(), (int32_t)model.counters.single_calls.load(), (int32_t)(model.counters.served.load() & 0x7fffffff)};
+            fused(model, threads, fused_labeling, fused_info);
         } else {  // groupwise: S subjects as tests/test_gpu_group.py builds them
             const int S = I["orders"][6], L = (int)(F["labels"].size() / 3);
             GroupParameters GP;
@@ -174,6 +223,7 @@ int main(int argc, char **argv) {
             model.setupCostFunction();
             replay(model, L, threads, sweeps, unary_log, pair_log, triplet_log, labeling_log, step_log);
             counts = {(int32_t)model.counters.step_calls.load(), (int32_t)model.counters.single_calls.load(), (int32_t)(model.counters.served.load() & 0x7fffffff)};
+            fused(model, threads, fused_labeling, fused_info);
         }
         std::ofstream out(argv[2], std::ios::binary);
         put(out, "total", "f8", totals);
@@ -183,6 +233,8 @@ int main(int argc, char **argv) {
         put(out, "labelings", "i4", labeling_log);
         put(out, "steps", "i4", step_log);
         put(out, "counts", "i4", counts);
+        put(out, "fused_labeling", "i4", fused_labeling);
+        put(out, "fused_info", "f8", fused_info);
         std::puts("ok");
         return 0;
     } catch (const std::exception &e) {

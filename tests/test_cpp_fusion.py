@@ -1,0 +1,22 @@
+"""include/msmhip_fusion.hpp -- the fusion move's host glue in arrays -- against the map-based restatement of
+the reference's glue (oracle/fusion_literal.hpp, I/Fusion/Fusion.h:14-244), compiled into tests/cpp/fusion_flat.cpp.  CPU only: the third-party
+PBF and solver are stand-ins on both sides (tests/cpp/mini_pbf.hpp), the energy is synthetic.  The GPU side of the same header (whole label
+steps from msmhip::FusionModel / GroupFusionModel) is covered by tests/test_cpp_host.py."""
+import json
+import os
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "tests", "cpp", "fusion_flat.cpp")
+EXE = os.path.join(ROOT, "tests", "cpp", "fusion_flat")
+
+
+def test_flat_fusion_glue_equals_the_map_based_restatement():
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-fopenmp", "-Wall", "-Wextra", "-Werror", SRC, "-o", EXE])
+    out = subprocess.run([EXE, "4", "30000", "200000"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    res = json.loads(out.stdout.strip().splitlines()[-1])
+    assert res["bad_models"] == 0 and res["bad_reduction"] == 0 and res["bad_drivers"] == 0
+    assert res["steps"] == 13 and res["skipped"] == 1 and res["nodes_moved"] > 0 and res["energy_end"] < res["energy_start"]
+    t = res["timing"]
+    assert t["checksums_equal"] and t["assemble_ms_flat"] < t["assemble_ms_map"] and t["lookup_ns_flat"] < t["lookup_ns_map"]

@@ -219,6 +219,12 @@ def test_fusion_loops_through_the_adapter(built, tmp_path, kind, D, rmode):
     step_calls, single_calls, served = got["counts"]
     assert single_calls == 0
     assert step_calls == (len(steps) if T else 0)  # exactly one msm_cost_triplet_octets per label step; pair costs come from the table
+    # msmhip::fusion_optimize (include/msmhip_fusion.hpp) over the same model with a stand-in PBF / solver: from whole-step buffers and
+    # through the per-clique evaluators the same labelings; one ABI call per step taken; the energy it returns is the oracle's
+    same, nsteps, abi_calls, energy, moved, singles = got["fused_info"]
+    assert same == 1.0 and abi_calls == nsteps >= 2 * L - 2 and moved > 0 and singles == 0
+    want_total = oc.total(got["fused_labeling"])[0]
+    assert abs(energy - want_total) <= 1e-9 * abs(want_total) + 1e-11
 
 
 @pytest.mark.gpu
@@ -274,3 +280,8 @@ def test_group_fusion_loops_through_the_adapter(built, tmp_path):
                 assert abs(octs[si, t, k] - w) <= 1e-11 + 1e-9 * abs(w)
     step_calls, single_calls, served = got["counts"]
     assert single_calls == 0 and step_calls == len(steps)
+    same, nsteps, abi_calls, energy, moved, singles = got["fused_info"]  # msmhip::fusion_optimize over the group model, see above
+    assert same == 1.0 and abi_calls == nsteps >= 2 * L - 2 and singles == 0
+    lab = got["fused_labeling"]
+    want = sum(og.pairwise(p, int(lab[pr[p, 0]]), int(lab[pr[p, 1]])) for p in range(P)) + sum(og.triplet(t, *(int(lab[v]) for v in tr[t])) for t in range(T))
+    assert (np.isnan(want) and np.isnan(energy)) or abs(energy - want) <= 1e-9 * abs(want) + 1e-11
