@@ -104,6 +104,15 @@ struct msm_group {
     DevBuf<int> d_prev_labeling;
     bool e00_valid = false;
     int64_t e00_p0 = -1, e00_p1 = -1;
+    // the (proposed, proposed) pair costs per label of the slice [e11_p0, e11_p1): valid from the label's step in the first sweep of
+    // Fusion until the next set-up (GroupArgs::move_e11)
+    DevBuf<double> d_e11;
+    std::vector<unsigned char> e11_have;
+    int64_t e11_p0 = -1, e11_p1 = -1;
+    void drop_kept() {
+        e00_valid = false;
+        std::fill(e11_have.begin(), e11_have.end(), (unsigned char)0);
+    }
     std::vector<int64_t> order_chunk;    // the slice's order is cut into pieces by OUTPUT range: piece k holds the pairs [order_chunk[k], order_chunk[k+1]) of the slice
     hipStream_t copy_stream = nullptr;   // the finished pieces of a label step leave for the host while the next ones are computed
     std::vector<hipEvent_t> copy_events;
@@ -277,6 +286,7 @@ int group_args(msm_group *g, GroupArgs &a) {
     a.move_combos = 0;
     a.move_prev = nullptr;
     a.move_e00 = nullptr;
+    a.move_e11 = nullptr;
     a.patch_cap = g->patch_max;
     a.status = g->ctx->d_status;
     return MSM_OK;
@@ -375,7 +385,7 @@ int msm_group_set_template(msm_group *g, msm_mesh *t, const double *mask) {
     }
     g->ready = false;
     g->common_ready = false;
-    g->e00_valid = false;
+    g->drop_kept();
     return MSM_OK;
 }
 
@@ -401,7 +411,7 @@ int msm_group_set_controlgrid(msm_group *g, const double *xyz, const int32_t *tr
     MSM_HIP(hipStreamSynchronize(g->ctx->stream));
     g->ready = false;
     g->common_ready = false;
-    g->e00_valid = false;
+    g->drop_kept();
     return MSM_OK;
 }
 
@@ -430,7 +440,7 @@ int msm_group_set_subject(msm_group *g, int32_t s, msm_mesh *data, const double 
     }
     g->ready = false;
     g->common_ready = false;
-    g->e00_valid = false;
+    g->drop_kept();
     return MSM_OK;
 }
 
@@ -438,7 +448,7 @@ int msm_group_reset_cpgrid(msm_group *g, int32_t s, const double *xyz) {
     if (!g || !xyz || s < 0 || s >= g->S || !g->cpmesh[s]) return fail(MSM_ERR_INVALID, "msm_group_reset_cpgrid: bad arguments");
     g->ready = false;
     g->common_ready = false;
-    g->e00_valid = false;
+    g->drop_kept();
     return msm_mesh_update_coords(g->cpmesh[s], xyz);
 }
 
@@ -448,7 +458,7 @@ int msm_group_set_labels(msm_group *g, const double *labels, int32_t L) {
     g->labels.assign(labels, labels + 3 * (size_t)L);
     g->ready = false;
     g->common_ready = false;
-    g->e00_valid = false;
+    g->drop_kept();
     return MSM_OK;
 }
 
@@ -1039,7 +1049,7 @@ int msm_group_setup_subjects(msm_group *g, const int32_t *subjects, int32_t n) {
     if (!g || (n > 0 && !subjects) || n < 0) return fail(MSM_ERR_INVALID, "msm_group_setup_subjects: bad arguments");
     g->ready = false;
     g->common_ready = false;
-    g->e00_valid = false;
+    g->drop_kept();
     int st = group_common_setup(g);
     if (st) return st;
     for (int i = 0; i < n; ++i)
@@ -1190,7 +1200,7 @@ int msm_group_finalize(msm_group *g) {
     MSM_HIP(g->d_pptrp.upload(pp.data(), pp.size(), ctx->stream));
     MSM_HIP(g->d_pidxp.upload(pi.data(), pi.size(), ctx->stream));
     MSM_HIP(hipStreamSynchronize(ctx->stream));
-    g->e00_valid = false;  // new patches: nothing kept from earlier label steps applies
+    g->drop_kept();  // new patches: nothing kept from earlier label steps applies
     g->patch_max = 0;
     for (int s = 0; s < S; ++s)
         for (size_t k = 0; k + 1 < g->h_pptr[s].size(); ++k) g->patch_max = std::max(g->patch_max, g->h_pptr[s][k + 1] - g->h_pptr[s][k]);
@@ -1369,11 +1379,32 @@ static int group_move_compute(msm_group *g, const int32_t *labeling, int32_t lab
             a.move_prev = (g->e00_valid && g->e00_p0 == pair0 && g->e00_p1 == pair1) ? g->d_prev_labeling.p : nullptr;
             g->e00_valid = false;  // until this step has gone through: a failure half way leaves nothing to rely on
         }
+        // The (proposed, proposed) combination depends on the label alone: the second sweep of Fusion over the labels (I/Fusion/Fusion.h:136-138)
+        // takes it from the first (kept per label for this slice until the next set-up; 8 bytes x pairs x labels: 0.8 GB for 64 subjects at
+        // ico4).  MSMHIP_GROUP_E11=off, or a slice whose table would pass MSMHIP_GROUP_E11_MB (default 16384): evaluated every time.
+        static const bool keep_e11 = [] { const char *e = std::getenv("MSMHIP_GROUP_E11"); return !(e && std::strcmp(e, "off") == 0); }();
+        static const double e11_cap_mb = [] { const char *e = std::getenv("MSMHIP_GROUP_E11_MB"); return e ? std::atof(e) : 16384.0; }();
+        const int64_t nslice = pair1 - pair0;
+        bool have11 = false;
+        if (two_pass && keep_e11 && 8.0 * (double)nslice * g->L <= e11_cap_mb * 1048576.0) {
+            if (g->e11_p0 != pair0 || g->e11_p1 != pair1 || (int)g->e11_have.size() != g->L) {
+                g->e11_have.assign((size_t)g->L, 0);
+                g->e11_p0 = pair0, g->e11_p1 = pair1;
+            }
+            MSM_HIP(g->d_e11.ensure((size_t)nslice * g->L));
+            a.move_e11 = g->d_e11.p + (size_t)label * nslice;
+            have11 = g->e11_have[(size_t)label] != 0;
+            g->e11_have[(size_t)label] = 0;  // until this step has gone through
+        }
         for (size_t k = 0; k + 1 < g->order_chunk.size(); ++k) {
             const int64_t n0 = g->order_chunk[k], n1 = g->order_chunk[k + 1];  // pairs of the piece, in processing order
+            if (have11) {
+                st = launch_group_kept(ctx, a.move_order + n0, (int)pair0, a.move_e11, (int)(n1 - n0), quads_dev);
+                if (st) return st;
+            }
             for (int pass = two_pass ? 1 : 0; pass <= (two_pass ? 2 : 0); ++pass) {
-                const int64_t mult = pass == 0 ? 4 : (pass == 1 ? 1 : 3), q0 = mult * n0, q1 = mult * n1;
-                a.move_combos = pass;
+                const int64_t mult = pass == 0 ? 4 : (pass == 1 ? 1 : (have11 ? 2 : 3)), q0 = mult * n0, q1 = mult * n1;
+                a.move_combos = pass == 2 && have11 ? 3 : pass;
                 for (int64_t off = q0; off < q1; off += kBatchChunk) {
                     const int m = (int)std::min<int64_t>(kBatchChunk, q1 - off);
                     if (off > 0x7fffffffll - kBatchChunk) return fail(MSM_ERR_CAPACITY, "%s: evaluation index beyond 2^31", who);
@@ -1392,9 +1423,11 @@ static int group_move_compute(msm_group *g, const int32_t *labeling, int32_t lab
             g->e00_valid = true;
             g->e00_p0 = pair0, g->e00_p1 = pair1;
         }
+        if (a.move_e11) g->e11_have[(size_t)label] = 1;
         a.move_combos = 0;
         a.move_prev = nullptr;
         a.move_e00 = nullptr;
+        a.move_e11 = nullptr;
     }
     a.move_order = nullptr;
     const int64_t first = 8 * trip0, total = 8 * (trip1 - trip0);

@@ -119,8 +119,8 @@ __global__ __launch_bounds__(256) void k_group_pairwise(GroupArgs a, const int *
     double *keep = nullptr;  // where this query's cost is kept for the next label step
     if (a.move_labeling) {  // Fusion's pair_data[pair].buffer[k], I/Fusion/Fusion.h:170-173: k = 2 * (A takes the label) + (B takes it)
         const int e = q + a.move_offset;
-        const int idx = a.move_combos == 0 ? e >> 2 : (a.move_combos == 1 ? e : e / 3);
-        const int k = a.move_combos == 0 ? (e & 3) : (a.move_combos == 1 ? 0 : 1 + (e - 3 * idx));
+        const int idx = a.move_combos == 0 ? e >> 2 : (a.move_combos == 1 ? e : (a.move_combos == 2 ? e / 3 : e >> 1));
+        const int k = a.move_combos == 0 ? (e & 3) : (a.move_combos == 1 ? 0 : (a.move_combos == 2 ? 1 + (e - 3 * idx) : 1 + (e & 1)));
         pair = a.move_order ? a.move_order[idx] : idx;
         if (a.move_order) at = 4 * (size_t)(pair - a.move_base) + k;
         const int nodeA = a.pairs[2 * pair], nodeB = a.pairs[2 * pair + 1];
@@ -132,6 +132,7 @@ __global__ __launch_bounds__(256) void k_group_pairwise(GroupArgs a, const int *
             }
             keep = a.move_e00 + pair;
         }
+        if (k == 3 && a.move_e11) keep = a.move_e11 + (pair - a.move_base);
         la = (k & 2) ? a.move_label : curA;
         lb = (k & 1) ? a.move_label : curB;
     } else {
@@ -556,6 +557,20 @@ int launch_group_pairwise(msm_ctx *ctx, const GroupArgs &a, const int *qp, const
         // half a wavefront per query: patches hold ~65 entries, so two queries share a wavefront's latency
         hipLaunchKernelGGL((k_group_pairwise<false, 32>), dim3((n + 7) / 8), dim3(256), 0, ctx->stream, a, qp, qa, qb, n, out);
     }
+    MSM_HIP(hipGetLastError());
+    return MSM_OK;
+}
+
+__global__ __launch_bounds__(256) void k_group_kept(const int *__restrict__ order, int base, const double *__restrict__ kept, int n, double *__restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int at = order[i] - base;
+    out[4 * (size_t)at + 3] = kept[at];
+}
+
+int launch_group_kept(msm_ctx *ctx, const int *order, int base, const double *kept, int n, double *out) {
+    if (n <= 0) return MSM_OK;
+    hipLaunchKernelGGL(k_group_kept, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, order, base, kept, n, out);
     MSM_HIP(hipGetLastError());
     return MSM_OK;
 }

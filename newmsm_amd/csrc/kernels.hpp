@@ -231,15 +231,21 @@ struct GroupArgs {
     // (current, current) cost of a pair does not depend on the proposed label: move_e00[pair] keeps it from one label step to the
     // next, and a pair neither of whose nodes changed its label since (move_prev: the previous step's labeling, nullptr: nothing
     // kept yet) takes it from there.
+    // The (proposed, proposed) cost of a pair depends on the proposed label only: move_e11[pair - move_base] keeps it per label
+    // from the first sweep of Fusion to the second (set with combination 3 evaluated: written; with move_combos 3: the launch evaluates
+    // only combinations 1 and 2, query i -> pair i / 2, combination 1 + i % 2, and launch_group_kept copies the kept costs).
     int move_combos;
     const int *move_prev;
     double *move_e00;
+    double *move_e11;
     int patch_cap;               // largest patch of any subject (DICE: LDS staging of the common entries)
     int *status;
 };
 // out[i], out[stride + i], out[2 * stride + i] (stride 0: V)
 int launch_rotate_to_label(msm_ctx *ctx, const double *d_xyz, int V, const double centre[3], const double label[3], double *d_out, size_t stride = 0);
 int launch_group_pairwise(msm_ctx *ctx, const GroupArgs &a, const int *qp, const int *qa, const int *qb, int n, double *out);
+// out[4 * (pair - base) + 3] = kept[pair - base] for the n pairs order[0 .. n)
+int launch_group_kept(msm_ctx *ctx, const int *order, int base, const double *kept, int n, double *out);
 int launch_group_triplet(msm_ctx *ctx, const GroupArgs &a, const int *qt, const int *qa, const int *qb, const int *qc, int n, double *out);
 // the search trees of the S control grids as one forest (arrays of tree b start b * s_* elements in), as the kernels below see it
 struct ForestDev {

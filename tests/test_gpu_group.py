@@ -367,3 +367,44 @@ def test_group_label_steps_reuse_the_current_current_costs(ctx):
         if step != 2:  # step 2 -> 3: the same labeling again
             change = rng.random(g.num_nodes) < 0.15
             labeling = np.where(change, rng.integers(0, g.L, g.num_nodes), labeling).astype(np.int32)
+
+
+def test_group_second_sweep_takes_the_proposed_proposed_costs_from_the_first(ctx):
+    """Fusion makes two sweeps over the labels (I/Fusion/Fusion.h:136-138).  The (label, label) cost of a pair depends on the label alone, so
+    the second sweep's come from the first; the labeling keeps changing in between.  Every step of both sweeps must equal the step
+    evaluated from scratch -- and after a set-up with different patches (a subject's control grid moved) nothing kept may survive."""
+    g, og, keep = build(ctx, S=4, data_order=4, cp_order=2, D=2)
+    rng = np.random.default_rng(23)
+    pairs = g.getPairs()
+    p = np.repeat(np.arange(g.P, dtype=np.int32), 4)
+    k = np.tile(np.arange(4), g.P)
+
+    def from_scratch(labeling, label):
+        la = np.where(k & 2, label, labeling[pairs[p, 0]]).astype(np.int32)
+        lb = np.where(k & 1, label, labeling[pairs[p, 1]]).astype(np.int32)
+        return g.computePairwiseCost(p, la, lb).reshape(g.P, 4)
+
+    labeling = rng.integers(0, g.L, g.num_nodes).astype(np.int32)
+    first = {}
+    for sweep in range(2):
+        for label in range(g.L):
+            quads, _ = g.fusionMove(labeling, label)
+            assert np.array_equal(quads, from_scratch(labeling, label), equal_nan=True), (sweep, label)
+            if sweep == 0:
+                first[label] = quads[:, 3].copy()
+            else:
+                assert np.array_equal(quads[:, 3], first[label], equal_nan=True)
+            change = rng.random(g.num_nodes) < 0.2
+            labeling = np.where(change, label, labeling).astype(np.int32)
+    # new patches: subject 1's control grid somewhere else
+    cxyz, _ = M.make_mesh_from_icosa(2)
+    g.reset_CPgrid(1, synthetic.known_warp(cxyz, seed=777, rot_deg=3.0, amp=0.8))
+    g.setupCostFunction()
+    pairs = g.getPairs()
+    changed = 0
+    for label in (3, 0, 11):
+        quads, _ = g.fusionMove(labeling, label)
+        assert np.array_equal(quads, from_scratch(labeling, label), equal_nan=True), label
+        changed += int((~np.isclose(quads[:, 3], first[label], equal_nan=True)).sum())
+    assert changed > 0  # the set-up did change these costs: a stale table would have been seen
+    g.close()
