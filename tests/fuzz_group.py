@@ -67,6 +67,17 @@ for k in range(n):
     t, a, b, c = (rng.integers(0, g.T, 100).astype(np.int32), *[rng.integers(0, g.L, 100).astype(np.int32) for _ in range(3)])
     got, want = g.computeTripletCost(t, a, b, c), np.array([og.triplet(*q) for q in zip(t, a, b, c)])
     ok = ok and np.allclose(got, want, rtol=1e-9, atol=1e-11)
+    # label steps as Fusion makes them, labels revisited (second sweep) with the labeling changing in between: the step's kept
+    # (current, current) and (label, label) costs against the explicit batch evaluation of all 4 P combinations
+    lab = rng.integers(0, g.L, g.num_nodes).astype(np.int32)
+    pr, pp, kk = g.getPairs(), np.repeat(np.arange(g.P, dtype=np.int32), 4), np.tile(np.arange(4), g.P)
+    l1, l2 = (int(x) for x in rng.integers(0, g.L, 2))
+    for label in (l1, l2, l1, l2):
+        quads, _ = g.fusionMove(lab, label)
+        la = np.where(kk & 2, label, lab[pr[pp, 0]]).astype(np.int32)
+        lb = np.where(kk & 1, label, lab[pr[pp, 1]]).astype(np.int32)
+        ok = ok and np.array_equal(quads.ravel(), g.computePairwiseCost(pp, la, lb), equal_nan=True)
+        lab = np.where(rng.random(g.num_nodes) < 0.2, label, lab).astype(np.int32)
     if not ok:
         bad += 1
     print("ok" if ok else "MISMATCH", k, "S=%d data=%d cp=%d D=%d sim=%d mask=%s pct=%.2f" % (S, data_order, cp_order, D, sim, mask, pct), flush=True)
