@@ -20,6 +20,8 @@ Multi-GPU (--gpus N, one process per GPU under torch.distributed.run):
                     ranks wall time.
   --mode gmsm       BASELINE config 5: 64 synthetic subjects, set-up sharded by subject, every label step sharded by clique,
                     RCCL all-gather / gather over xGMI (newmsm_amd/dist.py); strong scaling.  value = subjects/hour.
+                    The default mode at N > 1 runs this as well and reports it as the "gmsm" object of its line (the group is the
+                    path that shards; MSM_BENCH_GMSM_SCALING=0 leaves it out).
 """
 import argparse
 import json
@@ -334,6 +336,16 @@ def main():
 
     wall = D.max_over_ranks(wall, comm)
     kernel_ms = D.max_over_ranks(kernel_ms, comm)
+    # N > 1: the pairwise headline above is N independent replicas (weak scaling, no collective).  The path that does shard is the
+    # groupwise one, so the same run also measures it -- the SAME 64-subject group on N GPUs (strong scaling: set-up by subject with
+    # the RCCL all-gathers, label steps by clique) -- and reports it next to the headline; compare with "gmsm" of the N = 1 line.
+    gmsm_scaling = None
+    if world > 1 and not args.no_extras and os.environ.get("MSM_BENCH_GMSM_SCALING", "1") != "0":
+        try:
+            gmsm_scaling = bench_gmsm(ctx, args.subjects, comm)
+            gmsm_scaling["scaling"] = "strong"
+        except Exception as e:  # reported, not fatal: the headline of this run stands
+            gmsm_scaling = {"error": repr(e)}
 
     if rank == 0:
         value = world * evals * args.steps / wall
@@ -373,6 +385,8 @@ def main():
                 "table_achieved": abytes / (step_ms * 1e-3) / 1e9, "table_frac": abytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             },
         }
+        if gmsm_scaling is not None:
+            out["gmsm"] = gmsm_scaling
         threads = D.host_cores()  # cgroup / affinity aware: the GPU box gives one GPU's share of the host
         if world == 1 and not args.no_extras:
             with torch.cuda.stream(stream):

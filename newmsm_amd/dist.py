@@ -66,6 +66,13 @@ class Comm:
             self.dist.all_gather(list(out.unbind(0)), inp)
 
 
+def _timeout():
+    """a collective that does not complete within MSMHIP_DIST_TIMEOUT_S (default 300 s) ends the job instead of hanging it"""
+    import datetime
+
+    return datetime.timedelta(seconds=float(os.environ.get("MSMHIP_DIST_TIMEOUT_S", "300")))
+
+
 def init(backend=None, device_index=None):
     """Initialise the default process group when WORLD_SIZE > 1 (a single process gets a Comm without one).
     backend None: nccl when a GPU is visible, else gloo.  device_index: the GPU of this rank (default LOCAL_RANK)."""
@@ -82,9 +89,9 @@ def init(backend=None, device_index=None):
     if backend == "nccl":
         dev = local_rank if device_index is None else device_index
         torch.cuda.set_device(dev)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", dev), rank=rank, world_size=world)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", dev), rank=rank, world_size=world, timeout=_timeout())
         return Comm(dist, "nccl", "cuda:%d" % dev, rank, world)
-    dist.init_process_group(backend, rank=rank, world_size=world)
+    dist.init_process_group(backend, rank=rank, world_size=world, timeout=_timeout())
     return Comm(dist, backend, "cpu", rank, world)
 
 

@@ -289,6 +289,86 @@ def test_sharded_group_one_rank_over_rccl(tmp_path):
     assert o["equal"] and o["move_ok"] and o["template_radius_ok"] and o["n"] == 4 and o["finite"] > 200 and o["mine"] == [0, 1, 2, 3], o
 
 
+EXCHANGE_WORKER = '''
+import os, sys, json
+import numpy as np
+import torch
+sys.path.insert(0, %r)
+import newmsm_amd as M
+from newmsm_amd import dist as D, synthetic
+
+ctx = M.Context(0)
+S, Dm = 4, 2
+dxyz, dtri = M.make_mesh_from_icosa(3)
+cxyz, ctri = M.make_mesh_from_icosa(1)
+_, mvd = M.cp_spacings(cxyz, ctri)
+samples, _ = M.label_sampling_grid(3, 0.5 * mvd)
+def make():
+    g = M.DiscreteGroupCostFunction(ctx, S, lambda_=0.2)
+    tm = M.Mesh(ctx, dxyz, dtri); g.set_template(tm); g.Initialize(cxyz, ctri); keep = [tm]
+    for s in range(S):
+        m = M.Mesh(ctx, dxyz, dtri)
+        feat = synthetic.features(synthetic.known_warp(dxyz, seed=90 + s, rot_deg=2.0, amp=1.0), Dm, seed=5)
+        g.reset_meshspace(s, m, feat)
+        m.set_coords(synthetic.known_warp(dxyz, seed=40 + s, rot_deg=1.0 + s, amp=0.5)); g.reset_meshspace(s, m, feat)
+        g.reset_CPgrid(s, synthetic.known_warp(cxyz, seed=40 + s, rot_deg=1.0 + s, amp=0.5)); keep.append(m)
+    g.set_labels(samples)
+    return g, keep
+# two "ranks" in one process: each sets up its shard, exports it into device tensors (what the all-gather would carry) and
+# imports the other's from them
+ranks = [make(), make()]
+shards = [[0, 1], [2, 3]]
+V, M_ = len(dxyz), len(cxyz) * len(samples) + 1
+wire = {}
+for (g, _), mine in zip(ranks, shards):
+    g.setup_subjects(mine)
+    for s in mine:
+        n = g.subject_index_count(s)
+        F = torch.zeros((g.L, g.D, V), dtype=torch.float64, device="cuda:0")
+        pp = torch.zeros(M_, dtype=torch.int32, device="cuda:0")
+        pi = torch.zeros(n + 7, dtype=torch.int32, device="cuda:0")   # a padded slot, as in the padded all-gather
+        g.export_subject_dev(s, F.data_ptr(), pp.data_ptr(), pi.data_ptr(), n + 7)
+        wire[s] = (F, pp, pi, n)
+torch.cuda.synchronize()
+for (g, _), mine in zip(ranks, shards):
+    for s in range(S):
+        if s not in mine:
+            F, pp, pi, n = wire[s]
+            g.import_subject_dev(s, F.data_ptr(), pp.data_ptr(), pi.data_ptr(), n)
+    g.finalize()
+g1, keep1 = make(); g1.setupCostFunction()
+rng = np.random.default_rng(3)
+p = rng.integers(0, g1.P, 400).astype(np.int32); la = rng.integers(0, g1.L, 400).astype(np.int32); lb = rng.integers(0, g1.L, 400).astype(np.int32)
+single = g1.computePairwiseCost(p, la, lb)
+lab = rng.integers(0, g1.L, g1.num_nodes).astype(np.int32)
+q1, o1 = g1.fusionMove(lab, 5)
+ok = []
+for g, _ in ranks:
+    q, o = g.fusionMove(lab, 5)
+    ok.append(bool(np.array_equal(g.computePairwiseCost(p, la, lb), single, equal_nan=True) and np.array_equal(q, q1, equal_nan=True) and np.array_equal(o, o1)))
+    f0, p0, i0 = g.export_subject(3)   # what arrived for (or was computed for) subject 3 equals the full set-up's
+    f1, p1, i1 = g1.export_subject(3)
+    ok.append(bool(np.array_equal(f0, f1) and np.array_equal(p0, p1) and np.array_equal(i0, i1)))
+print(json.dumps({"ok": ok, "finite": int(np.isfinite(single).sum())}))
+'''
+
+
+def test_device_resident_exchange_between_two_shards(tmp_path):
+    """msm_group_export_subject_dev -> device buffers -> msm_group_import_subject_dev, the path an RCCL all-gather takes between two GPUs,
+    driven between two shards of one process on the one GPU of the test box: both shards end up equal to the unsharded set-up."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "exchange.py"
+    script.write_text(EXCHANGE_WORKER % root)
+    pr = subprocess.run([sys.executable, str(script)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=500)
+    assert pr.returncode == 0, pr.stderr[-3000:]
+    o = eval(pr.stdout.strip().splitlines()[-1].replace("true", "True").replace("false", "False"))
+    assert o["ok"] == [True] * 4 and o["finite"] > 200, o
+
+
 def test_group_full_size_properties_64_subjects_ico6(ctx):
     """BASELINE config 5 at full size (64 subjects, ico6 data / ico4 control grid, 19 labels; the oracle takes minutes per subject
     here, so this is checked through size-independent properties): a whole label step (20.7 M pair + 2.6 M triplet costs, processed
