@@ -11,6 +11,7 @@ All inputs are resident in HBM before the timed region starts.  The same JSON li
   triclique_move    one label step of Fusion (I/Fusion/Fusion.h:181-196) of the triclique classes: BASELINE config 4 (D = 1) and
                     config 3 (HCP MSMAll, D = 32) at ico6 / ico4 -- per call and per kernel, with their rooflines
   registration      wall-clock of a three-level ico6 pairwise registration driven by the reference's caller loop
+  registration_msmall  the same for the HCP MSMAll schedule (BASELINE config 3: triclique cost over 32 features, 40 iterations of fusion moves)
   gmsm              one groupwise iteration per level for 64 subjects on this GPU and the subjects/hour it implies
   cpu_baseline      the CPU port (oracle/) on the host cores, on a bounded sample of the headline workload
 
@@ -157,6 +158,31 @@ def bench_registration(ctx):
             "workload": "run_multiresolutions, 3 DISCRETE levels (data ico4/5/6, control ico2/3/4), 3 iterations each, sulc-like D=1, ico6 spheres",
             "optimiser": "the library's Monte Carlo optimiser (M/mcmc_opt.h) at 50 sweeps over the unary + T x L^3 triplet tables; FastPD / HOCR are "
                          "licence-restricted and FSL-bound: not runnable here"}
+
+
+def bench_registration_msmall(ctx):
+    """Wall-clock of an HCP MSMAll-shaped pairwise registration (BASELINE config 3): the schedule of
+    config/HCP_multimodal_alignment/MSMAllStrainFinalconf1to1_1to3_2 -- three levels, 10 / 15 / 15 iterations, triclique cost over 32
+    features, rescaled labels, variance normalisation -- on ico6 spheres, driven as --dopt=HOCR drives it: per iteration one set-up and
+    2 x L fusion moves (tools/time_registration_msmall.py)."""
+    import newmsm_amd as M
+    from newmsm_amd import registration, synthetic
+
+    xyz, tri = M.make_mesh_from_icosa(6)
+    ref = synthetic.features(xyz, 32, 7)
+    src = synthetic.features(synthetic.known_warp(xyz, seed=9, rot_deg=3.0, amp=2.0), 32, 7)
+    ops = registration.ProductOps(ctx)
+    for _ in range(2):  # the first run pays for allocations
+        clock = {}
+        t0 = time.perf_counter()
+        registration.run_multiresolution(ops, xyz, tri, src, xyz, tri, ref, registration.hcp_msmall_levels(), varnorm=True, timings=clock)
+        wall = time.perf_counter() - t0
+    return {"wall_s": wall, "path_s": sum(v for k, v in clock.items() if k != "optimiser"), "phases_s": {k: round(v, 4) for k, v in sorted(clock.items())},
+            "workload": "run_multiresolutions, the HCP MSMAll schedule (data ico4/5/6, control ico2/3/4, 10 / 15 / 15 iterations, ho_multivariate D=32, "
+                        "--triclique --rescaleL --VN), ico6 spheres: 40 set-ups + 1 520 fusion moves",
+            "optimiser": "the label loop of Fusion::optimize with a stand-in for its binary solve (msm_fusion_icm_step: iterated conditional modes on the "
+                         "host; ELC + FastPD are licence-restricted and FSL-bound): the path is exercised and timed as HOCR drives it, the labelings are "
+                         "not HOCR's"}
 
 
 GMSM_LEVELS = [(4, 2), (5, 3), (6, 4)]  # --datagrid / --CPgrid of the gMSM configuration of docs/guide.md:390-407
@@ -393,6 +419,7 @@ def main():
                 out["triclique_move"] = {"d1": bench_triclique_move(ctx, 1, 200, 0 if args.no_cpu_baseline else threads),
                                          "d32": bench_triclique_move(ctx, 32, 200, 0 if args.no_cpu_baseline else threads)}
                 out["registration"] = bench_registration(ctx)
+                out["registration_msmall"] = bench_registration_msmall(ctx)
                 out["gmsm"] = bench_gmsm(ctx, args.subjects, comm)
         if world == 1 and not args.no_cpu_baseline:
             Uo, rate, dt, reps = cpu_baseline(inp, kind, threads)

@@ -203,6 +203,15 @@ int msm_variance_normalise(double *data, int32_t D, int32_t V, const double *exc
  * combinations.  labeling (N) is read and updated.  The energy the reference returns is msm_cost_total(labeling). */
 int msm_mcmc_optimise(const double *unary, const double *tcosts, const int32_t *triplets, int32_t N, int32_t L, int32_t T, double mcparam,
                       int32_t iters, uint64_t seed, int32_t *labeling);
+/* [host] A STAND-IN for the binary solve of one label step of Fusion::optimize (I/Fusion/Fusion.h:198-229 hands the step to ELC's
+ * reduction + FastPD, which are licence-restricted and FSL-bound: not reproduced).  Iterated conditional modes over x in {0,1}^N
+ * (0: the node keeps its label, 1: it takes the proposed one) for
+ *     E(x) = sum_i unary2[2 i + x_i] + sum_t octets[8 t + 4 x_a + 2 x_b + x_c]        (octets as msm_cost_triplet_octets writes them)
+ * from x = 0, nodes in ascending order, a node flips only when that lowers E strictly, at most max_passes passes.  Deterministic; it
+ * exists so that the fusion-move path can be driven end to end (tools, tests, bench) the way the HCP configurations drive it -- a
+ * registration run with it is NOT the reference's optimisation result. */
+int msm_fusion_icm_step(const double *unary2 /* N x 2 */, const double *octets /* T x 8 */, const int32_t *triplets /* T x 3 */, int32_t N, int32_t T,
+                        int32_t max_passes, int32_t *x /* N, out */);
 
 /* ------------------------------------------------------------------------------------------------
  * discrete cost function.  Replaces NonLinearSRegDiscreteCostFunction and its five subclasses

@@ -363,6 +363,19 @@ def mcmc_optimise(unary, tcosts, triplets, labeling, mcparam=0.8, iters=100, see
     return lab
 
 
+def fusion_icm_step(unary2, octets, triplets, passes=5):
+    """msm_fusion_icm_step: the stand-in binary solve of one label step (iterated conditional modes; NOT ELC + FastPD).  unary2 N x 2
+    (current, proposed), octets T x 8 as tripletOctets returns them; returns x (N): 1 where the proposed label is taken."""
+    u = np.ascontiguousarray(unary2, dtype=np.float64)
+    e = np.ascontiguousarray(octets, dtype=np.float64)
+    tr = np.ascontiguousarray(triplets, dtype=np.int32)
+    N, T = u.shape[0], tr.shape[0]
+    assert u.shape == (N, 2) and e.size == 8 * T
+    x = np.zeros(N, dtype=np.int32)
+    check(lib().msm_fusion_icm_step(u.ctypes.data_as(c_dp), e.ctypes.data_as(c_dp), tr.ctypes.data_as(c_ip), N, T, int(passes), x.ctypes.data_as(c_ip)))
+    return x
+
+
 def nearest_neighbour_interpolation(orig_mesh, data, q, excl=None):
     d, pd = _d(np.atleast_2d(data))
     x, px = _soa(q)

@@ -185,4 +185,41 @@ int msm_mcmc_optimise(const double *unary, const double *tcosts, const int32_t *
     return MSM_OK;
 }
 
+int msm_fusion_icm_step(const double *unary2, const double *octets, const int32_t *triplets, int32_t N, int32_t T, int32_t max_passes, int32_t *x) {
+    if (!unary2 || !triplets || !x || N <= 0 || T < 0 || max_passes < 0 || (T > 0 && !octets)) return fail(MSM_ERR_INVALID, "msm_fusion_icm_step: bad arguments");
+    for (int64_t i = 0; i < 3 * (int64_t)T; ++i)
+        if (triplets[i] < 0 || triplets[i] >= N) return fail(MSM_ERR_INVALID, "msm_fusion_icm_step: triplet node out of range");
+    // the triplets of every node (counting sort by node, triplets ascending within a node)
+    std::vector<int32_t> ptr((size_t)N + 1, 0), inc(3 * (size_t)T);
+    for (int64_t i = 0; i < 3 * (int64_t)T; ++i) ++ptr[(size_t)triplets[i] + 1];
+    for (int v = 0; v < N; ++v) ptr[(size_t)v + 1] += ptr[(size_t)v];
+    {
+        std::vector<int32_t> fill(ptr.begin(), ptr.end() - 1);
+        for (int t = 0; t < T; ++t)
+            for (int j = 0; j < 3; ++j) inc[(size_t)fill[(size_t)triplets[3 * t + j]]++] = 3 * t + j;  // triplet and the node's position in it
+    }
+    std::fill(x, x + N, 0);
+    for (int pass = 0; pass < max_passes; ++pass) {
+        bool changed = false;
+        for (int v = 0; v < N; ++v) {
+            double e[2] = {unary2[2 * (size_t)v], unary2[2 * (size_t)v + 1]};
+            for (int32_t k = ptr[(size_t)v]; k < ptr[(size_t)v + 1]; ++k) {
+                const int t = inc[(size_t)k] / 3, j = inc[(size_t)k] - 3 * t;
+                int bits = 0;  // the combination with x_v = 0: 4 x_a + 2 x_b + x_c
+                for (int q = 0; q < 3; ++q)
+                    if (q != j) bits |= x[triplets[3 * t + q]] << (2 - q);
+                e[0] += octets[8 * (size_t)t + bits];
+                e[1] += octets[8 * (size_t)t + (bits | (1 << (2 - j)))];
+            }
+            const int cur = x[v];
+            if (e[1 - cur] < e[cur]) {  // strictly lower (never for NaN)
+                x[v] = 1 - cur;
+                changed = true;
+            }
+        }
+        if (!changed) break;
+    }
+    return MSM_OK;
+}
+
 }  // extern "C"

@@ -86,6 +86,9 @@ class ProductOps:
     def mcmc(self, unary, tcosts, triplets, labeling, mcparam, iters, seed):
         return api.mcmc_optimise(unary, tcosts, triplets, labeling, mcparam=mcparam, iters=iters, seed=seed)
 
+    def fusion_step(self, unary2, octets, triplets, passes):
+        return api.fusion_icm_step(unary2, octets, triplets, passes)
+
 
 class _ProductCost:
     def __init__(self, cf):
@@ -118,8 +121,23 @@ class _ProductCost:
     def triplet_table(self):
         return self.cf.computeTripletCosts()
 
+    def triplet_octets(self, labeling, label):
+        if getattr(self, "_octets", None) is None or self._octets.shape[0] != self.cf.T:
+            self._octets = self.cf.ctx.host_array((self.cf.T, 8))  # the optimiser's per-step buffer: mapped pinned memory the kernel writes
+        return self.cf.tripletOctets(labeling, label, self._octets)
+
     def total(self, labeling):
         return self.cf.evaluateTotalCostSum(labeling)[0]
+
+
+def hcp_msmall_levels(iterations=(10, 15, 15)):
+    """The schedule of config/HCP_multimodal_alignment/MSMAllStrainFinalconf1to1_1to3_2 (BASELINE config 3) for run_multiresolution:
+    --CPgrid=2,3,4 --datagrid=4,5,6 --SGgrid=4,5,6 --it=10,15,15 --lambda=0.00001,0.0075,0.01 --regoption=3 --regexp=2 --k_exponent=2
+    --bulkmod=1.6 --shearmod=0.4 --sigma_in/ref=0 --simval=2, with --triclique (the HO classes), --rescaleL, --VN (pass varnorm=True) and
+    --dopt=HOCR (optimiser "fusion": the label loop of Fusion::optimize; its binary solve is a stand-in, see run_discrete_level)."""
+    hcp = dict(mu=0.4, kappa=1.6, k_exp=2.0, rexp=2.0)
+    return [dict(data_order=4 + k, cp_order=2 + k, sg_order=4 + k, iters=iterations[k], kind="ho_multivariate", rescale_labels=True, optimiser="fusion",
+                 cost_params=dict(lambda_=lam, **hcp)) for k, lam in enumerate((0.00001, 0.0075, 0.01))]
 
 
 def apply_labeling(rot, labels, labeling):
@@ -141,8 +159,14 @@ def combine_costfunction_weighting(sourceweight, resampledtargetweight):
 
 def run_discrete_level(ops, target_xyz, target_tri, ref_feat, source_xyz, source_tri, src_feat, sph_reg, cp_order, *, sg_order=None,
                        iters=3, mciters=200, mcparam=0.8, seed=0, kind="univariate", simmeasure=2, rmode=3, labeldist=0.5,
-                       rescale_labels=False, cost_params=None, timings=None, cp_start=None, in_weight=None, ref_weight=None):
-    """Runs `iters` iterations of run_discrete_opt with the Monte Carlo optimiser for one level.
+                       rescale_labels=False, cost_params=None, timings=None, cp_start=None, in_weight=None, ref_weight=None,
+                       optimiser="mcmc", icm_passes=5):
+    """Runs `iters` iterations of run_discrete_opt for one level.  optimiser: "mcmc" -- the reference's Monte Carlo optimiser over the
+    unary and T x L^3 triplet tables (M/mcmc_opt.h:31-134) -- or "fusion": the label loop of Fusion::optimize (I/Fusion/Fusion.h:136-229: two
+    sweeps over the labels, per label step 2 N unary and 8 T triplet costs -- ONE fusion-move call on the MI355X path --, nodes that the
+    binary solve gives 1 take the label), which is how every HCP configuration drives the hot path (--dopt=HOCR).  The binary solve itself
+    (ELC + FastPD, licence-restricted) is replaced by a stand-in (ops.fusion_step: iterated conditional modes, icm_passes passes): such a run
+    exercises and times the path as HOCR would, its result is not the reference's optimum.
 
     target / source: the reference and the moving sphere at the data resolution of this level (source_xyz = the sphere the
     moving features live on, sph_reg = its current registered position).  Returns (sph_reg, cp_xyz, energies, labelings).
@@ -198,11 +222,21 @@ def run_discrete_level(ops, target_xyz, target_tri, ref_feat, source_xyz, source
         timed("get_source_data", cost.get_source_data)
         cost.set_triplets(triplets)
         m_iter += 1
-        # --- MCMC: computeUnaryCosts, computeTripletCosts, optimise
         unary = timed("unary_table", cost.unary_table)
-        tcosts = timed("triplet_table", cost.triplet_table)
         labeling = np.zeros(len(cp_xyz), dtype=np.int32)  # resetLabeling
-        labeling = timed("optimiser", ops.mcmc, unary, tcosts, triplets, labeling, mcparam, mciters, seed + it)
+        if optimiser == "fusion":  # --- Fusion::optimize: computeUnaryCosts, then per label step the 8 T combinations
+            nodes = np.arange(len(cp_xyz))
+            for sweep in range(2):
+                for label in range(len(labels)):
+                    if not np.any(labeling != label):
+                        continue
+                    octets = timed("fusion_moves", cost.triplet_octets, labeling, label)
+                    unary2 = np.stack([unary[labeling, nodes], unary[label]], axis=1)
+                    x = timed("optimiser", ops.fusion_step, unary2, octets, triplets, icm_passes)
+                    labeling = np.where((x == 1) & (labeling != label), label, labeling).astype(np.int32)
+        else:  # --- MCMC: computeUnaryCosts, computeTripletCosts, optimise
+            tcosts = timed("triplet_table", cost.triplet_table)
+            labeling = timed("optimiser", ops.mcmc, unary, tcosts, triplets, labeling, mcparam, mciters, seed + it)
         energies.append(timed("total_cost", cost.total, labeling))
         labelings.append(labeling)
         # --- applyLabeling, warp the source through the control grid move, unfold both
@@ -268,7 +302,7 @@ def run_multiresolution(ops, in_xyz, in_tri, in_data, ref_xyz, ref_tri, ref_data
         timed("unfold", ops.unfold, moved)
         sph_in = ops.coords(moved)
         kw = dict(level_kw)
-        kw.update({k: lv[k] for k in ("sg_order", "iters", "mciters", "cost_params", "kind", "rescale_labels") if k in lv})
+        kw.update({k: lv[k] for k in ("sg_order", "iters", "mciters", "cost_params", "kind", "rescale_labels", "optimiser") if k in lv})
         if in_cfweight is not None and ref_cfweight is not None:
             kw["in_weight"] = ops.nearest_neighbour(in_mesh, in_cfweight, ico_xyz)
             kw["ref_weight"] = ops.nearest_neighbour(ref_mesh, ref_cfweight, ico_xyz)

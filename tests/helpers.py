@@ -1,5 +1,7 @@
 """Test-side glue: builds ORACLE objects (oracle/ is test infrastructure) from the numpy inputs that
 newmsm_amd.problem prepares for the product path."""
+import os
+
 import numpy as np
 
 from oracle import oracle as O
@@ -52,6 +54,9 @@ def oracle_anatomy(cp_order=2, anat_order=4):
     return cxyz, ctri, axyz, atri, w_ptr, w_cp, w_val, face_ptr, face_idx
 
 
+
+
+ORACLE_THREADS = int(os.environ.get("MSM_ORACLE_THREADS", "8"))  # OpenMP threads of the oracle's table / octet evaluations
 
 
 class OracleOps:
@@ -120,6 +125,11 @@ class OracleOps:
     def mcmc(self, unary, tcosts, triplets, labeling, mcparam, iters, seed):
         return self.optimiser(unary, tcosts, triplets, labeling, mcparam=mcparam, iters=iters, seed=seed)
 
+    def fusion_step(self, unary2, octets, triplets, passes):
+        from newmsm_amd import api  # the caller's stand-in solver (not part of the path), the same for both runs
+
+        return api.fusion_icm_step(unary2, octets, triplets, passes)
+
 
 class _OracleCost:
     def __init__(self, c):
@@ -147,10 +157,13 @@ class _OracleCost:
         self.c.get_source_data()
 
     def unary_table(self):
-        return self.c.unary_table(threads=8)
+        return self.c.unary_table(threads=ORACLE_THREADS)
 
     def triplet_table(self):
         return self.c.triplet_table()
+
+    def triplet_octets(self, labeling, label):
+        return self.c.triplet_octets(labeling, label, threads=ORACLE_THREADS)
 
     def total(self, labeling):
         return self.c.total(labeling)[0]

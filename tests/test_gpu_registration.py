@@ -111,3 +111,24 @@ def test_files_in_files_out(ctx, tmp_path):
     reg, rtri = meshio.load_surface(d + "out.sphere.reg.surf.gii")
     assert np.array_equal(rtri, tri) and np.allclose(np.linalg.norm(reg, axis=1), 100.0, atol=1e-3) and angles(reg, xyz).max() > 1e-4
     assert meshio.load_metric(d + "out.transformed_and_reprojected.func.gii").shape == (1, len(xyz))
+
+
+@pytest.mark.parametrize("kind,D", [("ho_univariate", 1), ("ho_multivariate", 16)])
+def test_fusion_driven_level_matches_oracle(ctx, kind, D):
+    """The label loop of Fusion::optimize (I/Fusion/Fusion.h:136-229) over the triclique classes -- what every HCP configuration runs: per
+    label step ONE fusion move (8 T triplet costs for the evolving labeling), here with a stand-in for the licence-restricted binary solve
+    (iterated conditional modes, the same for both runs).  The MI355X path and the oracle take the same decisions in every one of the
+    2 x L x iterations steps and end within the north star's 1e-4 rad."""
+    xyz, tri, ref, src = level_inputs(4, D, seed=27)
+    hcp = dict(lambda_=0.01, mu=0.4, kappa=1.6, k_exp=2.0, rexp=2.0)  # --shearmod --bulkmod --k_exponent --regexp of the HCP configurations
+    kw = dict(cp_order=2, iters=2, seed=5, kind=kind, rescale_labels=True, cost_params=hcp, optimiser="fusion")
+    t = {}
+    got = registration.run_discrete_level(registration.ProductOps(ctx), xyz, tri, ref, xyz, tri, src, xyz, timings=t, **kw)
+    want = registration.run_discrete_level(OracleOps(M.mcmc_optimise), xyz, tri, ref, xyz, tri, src, xyz, **kw)
+    for a, b in zip(got[3], want[3]):
+        assert np.array_equal(a, b)
+    assert np.allclose(got[2], want[2], rtol=1e-9)
+    assert "fusion_moves" in t and "triplet_table" not in t  # the fusion path, not the T x L^3 tables
+    assert angles(got[0], xyz).max() > 1e-3 and any(l.any() for l in got[3])
+    assert angles(got[0], want[0]).max() <= NORTH_STAR_TOL_RAD
+    assert np.abs(got[0] - want[0]).max() < 1e-9

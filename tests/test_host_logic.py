@@ -161,3 +161,38 @@ def test_adjacency_flat_build_matches_the_literal_lists_on_irregular_and_degener
         for v in range(V):
             assert list(nbr[nbr_ptr[v]:nbr_ptr[v + 1]]) == nb[v]
             assert list(tid[tid_ptr[v]:tid_ptr[v + 1]]) == tr[v]
+
+
+def test_fusion_icm_step_against_a_plain_python_version(built):
+    """msm_fusion_icm_step (the stand-in binary solve that lets tests and tools drive the fusion-move path end to end) against the
+    same rule written out in Python: ascending node order, strict improvement, passes until nothing changes"""
+    rng = np.random.default_rng(12)
+    for trial in range(6):
+        N = int(rng.integers(5, 60))
+        T = int(rng.integers(0, 3 * N))
+        tr = np.sort(np.stack([rng.choice(N, 3, replace=False) for _ in range(T)]).reshape(T, 3), axis=1).astype(np.int32) if T else np.zeros((0, 3), np.int32)
+        u2 = rng.normal(size=(N, 2))
+        oc = rng.normal(size=(T, 8))
+        if trial == 3 and T:
+            oc[rng.integers(0, T), :] = np.nan  # a failed evaluation: comparisons with NaN never flip a node
+        passes = int(rng.integers(1, 6))
+        got = M.fusion_icm_step(u2, oc, tr, passes)
+        x = np.zeros(N, dtype=np.int32)
+        for _ in range(passes):
+            changed = False
+            for v in range(N):
+                e = [u2[v, 0], u2[v, 1]]
+                for t in range(T):
+                    if v in tr[t]:
+                        for val in (0, 1):
+                            bits = 0
+                            for q in range(3):
+                                xv = val if tr[t, q] == v else x[tr[t, q]]
+                                bits |= int(xv) << (2 - q)
+                            e[val] += oc[t, bits]
+                if e[1 - x[v]] < e[x[v]]:
+                    x[v] = 1 - x[v]
+                    changed = True
+            if not changed:
+                break
+        assert np.array_equal(got, x), trial
