@@ -206,12 +206,14 @@ int msm_mcmc_optimise(const double *unary, const double *tcosts, const int32_t *
 /* [host] A STAND-IN for the binary solve of one label step of Fusion::optimize (I/Fusion/Fusion.h:198-229 hands the step to ELC's
  * reduction + FastPD, which are licence-restricted and FSL-bound: not reproduced).  Iterated conditional modes over x in {0,1}^N
  * (0: the node keeps its label, 1: it takes the proposed one) for
- *     E(x) = sum_i unary2[2 i + x_i] + sum_t octets[8 t + 4 x_a + 2 x_b + x_c]        (octets as msm_cost_triplet_octets writes them)
- * from x = 0, nodes in ascending order, a node flips only when that lowers E strictly, at most max_passes passes.  Deterministic; it
- * exists so that the fusion-move path can be driven end to end (tools, tests, bench) the way the HCP configurations drive it -- a
- * registration run with it is NOT the reference's optimisation result. */
-int msm_fusion_icm_step(const double *unary2 /* N x 2 */, const double *octets /* T x 8 */, const int32_t *triplets /* T x 3 */, int32_t N, int32_t T,
-                        int32_t max_passes, int32_t *x /* N, out */);
+ *     E(x) = sum_i unary2[2 i + x_i] + sum_p quads[4 p + 2 x_a + x_b] + sum_t octets[8 t + 4 x_a + 2 x_b + x_c]
+ * (quads / octets as msm_group_fusion_move and msm_cost_triplet_octets write them; unary2 NULL: no unary costs; P or T may be 0) from
+ * x = 0, nodes in ascending order, a node flips only when that lowers E strictly, at most max_passes passes.  Deterministic; it exists
+ * so that the fusion-move path can be driven end to end (tools, tests, bench) the way the HCP configurations drive it -- a registration
+ * run with it is NOT the reference's optimisation result. */
+int msm_fusion_icm_step(const double *unary2 /* N x 2 or NULL */, const double *quads /* P x 4 */, const int32_t *pairs /* P x 2 */, int32_t P,
+                        const double *octets /* T x 8 */, const int32_t *triplets /* T x 3 */, int32_t T, int32_t N, int32_t max_passes,
+                        int32_t *x /* N, out */);
 
 /* ------------------------------------------------------------------------------------------------
  * discrete cost function.  Replaces NonLinearSRegDiscreteCostFunction and its five subclasses

@@ -363,16 +363,25 @@ def mcmc_optimise(unary, tcosts, triplets, labeling, mcparam=0.8, iters=100, see
     return lab
 
 
-def fusion_icm_step(unary2, octets, triplets, passes=5):
+def fusion_icm_step(unary2, octets, triplets, passes=5, quads=None, pairs=None):
     """msm_fusion_icm_step: the stand-in binary solve of one label step (iterated conditional modes; NOT ELC + FastPD).  unary2 N x 2
-    (current, proposed), octets T x 8 as tripletOctets returns them; returns x (N): 1 where the proposed label is taken."""
-    u = np.ascontiguousarray(unary2, dtype=np.float64)
-    e = np.ascontiguousarray(octets, dtype=np.float64)
-    tr = np.ascontiguousarray(triplets, dtype=np.int32)
-    N, T = u.shape[0], tr.shape[0]
-    assert u.shape == (N, 2) and e.size == 8 * T
+    (current, proposed) or an int N (no unary costs), octets T x 8 / quads P x 4 as tripletOctets / fusionMove return them; returns x (N):
+    1 where the proposed label is taken."""
+    if np.ndim(unary2) == 0:
+        N, u, pu = int(unary2), None, None
+    else:
+        u = np.ascontiguousarray(unary2, dtype=np.float64)
+        N, pu = u.shape[0], u.ctypes.data_as(c_dp)
+        assert u.shape == (N, 2)
+    tr = np.ascontiguousarray(triplets if triplets is not None else np.zeros((0, 3)), dtype=np.int32)
+    e = np.ascontiguousarray(octets if octets is not None else np.zeros((0, 8)), dtype=np.float64)
+    pr = np.ascontiguousarray(pairs if pairs is not None else np.zeros((0, 2)), dtype=np.int32)
+    q = np.ascontiguousarray(quads if quads is not None else np.zeros((0, 4)), dtype=np.float64)
+    T, P = tr.shape[0], pr.shape[0]
+    assert e.size == 8 * T and q.size == 4 * P
     x = np.zeros(N, dtype=np.int32)
-    check(lib().msm_fusion_icm_step(u.ctypes.data_as(c_dp), e.ctypes.data_as(c_dp), tr.ctypes.data_as(c_ip), N, T, int(passes), x.ctypes.data_as(c_ip)))
+    check(lib().msm_fusion_icm_step(pu, q.ctypes.data_as(c_dp), pr.ctypes.data_as(c_ip), P, e.ctypes.data_as(c_dp), tr.ctypes.data_as(c_ip), T, N, int(passes),
+                                    x.ctypes.data_as(c_ip)))
     return x
 
 

@@ -185,26 +185,44 @@ int msm_mcmc_optimise(const double *unary, const double *tcosts, const int32_t *
     return MSM_OK;
 }
 
-int msm_fusion_icm_step(const double *unary2, const double *octets, const int32_t *triplets, int32_t N, int32_t T, int32_t max_passes, int32_t *x) {
-    if (!unary2 || !triplets || !x || N <= 0 || T < 0 || max_passes < 0 || (T > 0 && !octets)) return fail(MSM_ERR_INVALID, "msm_fusion_icm_step: bad arguments");
+int msm_fusion_icm_step(const double *unary2, const double *quads, const int32_t *pairs, int32_t P, const double *octets, const int32_t *triplets, int32_t T,
+                        int32_t N, int32_t max_passes, int32_t *x) {
+    if (!x || N <= 0 || T < 0 || P < 0 || max_passes < 0 || (T > 0 && (!octets || !triplets)) || (P > 0 && (!quads || !pairs)))
+        return fail(MSM_ERR_INVALID, "msm_fusion_icm_step: bad arguments");
     for (int64_t i = 0; i < 3 * (int64_t)T; ++i)
         if (triplets[i] < 0 || triplets[i] >= N) return fail(MSM_ERR_INVALID, "msm_fusion_icm_step: triplet node out of range");
-    // the triplets of every node (counting sort by node, triplets ascending within a node)
-    std::vector<int32_t> ptr((size_t)N + 1, 0), inc(3 * (size_t)T);
-    for (int64_t i = 0; i < 3 * (int64_t)T; ++i) ++ptr[(size_t)triplets[i] + 1];
-    for (int v = 0; v < N; ++v) ptr[(size_t)v + 1] += ptr[(size_t)v];
+    for (int64_t i = 0; i < 2 * (int64_t)P; ++i)
+        if (pairs[i] < 0 || pairs[i] >= N) return fail(MSM_ERR_INVALID, "msm_fusion_icm_step: pair node out of range");
+    // the cliques of every node (counting sort by node; pairs first, then triplets, each ascending): entry = clique * arity + position
+    std::vector<int64_t> pptr((size_t)N + 1, 0), tptr((size_t)N + 1, 0);
+    for (int64_t i = 0; i < 2 * (int64_t)P; ++i) ++pptr[(size_t)pairs[i] + 1];
+    for (int64_t i = 0; i < 3 * (int64_t)T; ++i) ++tptr[(size_t)triplets[i] + 1];
+    for (int v = 0; v < N; ++v) pptr[(size_t)v + 1] += pptr[(size_t)v], tptr[(size_t)v + 1] += tptr[(size_t)v];
+    std::vector<int64_t> pinc(2 * (size_t)P), tinc(3 * (size_t)T);
     {
-        std::vector<int32_t> fill(ptr.begin(), ptr.end() - 1);
-        for (int t = 0; t < T; ++t)
-            for (int j = 0; j < 3; ++j) inc[(size_t)fill[(size_t)triplets[3 * t + j]]++] = 3 * t + j;  // triplet and the node's position in it
+        std::vector<int64_t> fill(pptr.begin(), pptr.end() - 1);
+        for (int64_t p = 0; p < P; ++p)
+            for (int j = 0; j < 2; ++j) pinc[(size_t)fill[(size_t)pairs[2 * p + j]]++] = 2 * p + j;
+        fill.assign(tptr.begin(), tptr.end() - 1);
+        for (int64_t t = 0; t < T; ++t)
+            for (int j = 0; j < 3; ++j) tinc[(size_t)fill[(size_t)triplets[3 * t + j]]++] = 3 * t + j;
     }
     std::fill(x, x + N, 0);
     for (int pass = 0; pass < max_passes; ++pass) {
         bool changed = false;
         for (int v = 0; v < N; ++v) {
-            double e[2] = {unary2[2 * (size_t)v], unary2[2 * (size_t)v + 1]};
-            for (int32_t k = ptr[(size_t)v]; k < ptr[(size_t)v + 1]; ++k) {
-                const int t = inc[(size_t)k] / 3, j = inc[(size_t)k] - 3 * t;
+            double e[2] = {unary2 ? unary2[2 * (size_t)v] : 0.0, unary2 ? unary2[2 * (size_t)v + 1] : 0.0};
+            for (int64_t k = pptr[(size_t)v]; k < pptr[(size_t)v + 1]; ++k) {
+                const int64_t p = pinc[(size_t)k] >> 1;
+                const int j = (int)(pinc[(size_t)k] & 1);
+                const int other = x[pairs[2 * p + (1 - j)]];
+                // quads[4 p + 2 x_a + x_b]
+                e[0] += quads[4 * (size_t)p + (j == 0 ? other : 2 * other)];
+                e[1] += quads[4 * (size_t)p + (j == 0 ? 2 + other : 2 * other + 1)];
+            }
+            for (int64_t k = tptr[(size_t)v]; k < tptr[(size_t)v + 1]; ++k) {
+                const int64_t t = tinc[(size_t)k] / 3;
+                const int j = (int)(tinc[(size_t)k] - 3 * t);
                 int bits = 0;  // the combination with x_v = 0: 4 x_a + 2 x_b + x_c
                 for (int q = 0; q < 3; ++q)
                     if (q != j) bits |= x[triplets[3 * t + q]] << (2 - q);

@@ -86,8 +86,8 @@ class ProductOps:
     def mcmc(self, unary, tcosts, triplets, labeling, mcparam, iters, seed):
         return api.mcmc_optimise(unary, tcosts, triplets, labeling, mcparam=mcparam, iters=iters, seed=seed)
 
-    def fusion_step(self, unary2, octets, triplets, passes):
-        return api.fusion_icm_step(unary2, octets, triplets, passes)
+    def fusion_step(self, unary2, octets, triplets, passes, quads=None, pairs=None):
+        return api.fusion_icm_step(unary2, octets, triplets, passes, quads=quads, pairs=pairs)
 
 
 class _ProductCost:

@@ -125,10 +125,60 @@ class OracleOps:
     def mcmc(self, unary, tcosts, triplets, labeling, mcparam, iters, seed):
         return self.optimiser(unary, tcosts, triplets, labeling, mcparam=mcparam, iters=iters, seed=seed)
 
-    def fusion_step(self, unary2, octets, triplets, passes):
+    def fusion_step(self, unary2, octets, triplets, passes, quads=None, pairs=None):
         from newmsm_amd import api  # the caller's stand-in solver (not part of the path), the same for both runs
 
-        return api.fusion_icm_step(unary2, octets, triplets, passes)
+        return api.fusion_icm_step(unary2, octets, triplets, passes, quads=quads, pairs=pairs)
+
+    def group(self, S, simmeasure, lambda_, fixnan):
+        return _OracleGroup(O.Group(S, simmeasure=simmeasure, lambda_=lambda_, fixnan=fixnan))
+
+
+class _OracleGroup:
+    """newmsm_amd.group_registration's group object answered by the oracle (scalar evaluators: small groups only)"""
+
+    def __init__(self, g):
+        self.g, self.keep = g, []
+
+    def set_template(self, mesh):
+        self.keep.append(mesh)
+        self.g.set_template(mesh, None)
+
+    def initialize(self, cp_mesh, cp_xyz, cp_tri):
+        self.keep.append(cp_mesh)
+        self.g.set_controlgrid(cp_mesh)
+
+    def set_subject(self, s, mesh, feat):
+        self.keep.append(mesh)
+        self.g.set_subject(s, mesh, feat)
+
+    def reset_cpgrid(self, s, xyz):
+        self.g.reset_cpgrid(s, xyz)
+
+    def set_labels(self, labels):
+        self.g.set_labels(labels)
+
+    def setup(self):
+        self.g.setup()
+
+    def pairs(self):
+        return self.g.pairs()
+
+    def triplets(self):
+        return self.g.triplets()
+
+    def fusion_move(self, labeling, label):
+        pr, tr = self.g.pairs(), self.g.triplets()
+        quads = np.empty((len(pr), 4))
+        for p in range(len(pr)):
+            a, b = int(labeling[pr[p, 0]]), int(labeling[pr[p, 1]])
+            quads[p] = [self.g.pairwise(p, a, b), self.g.pairwise(p, a, label), self.g.pairwise(p, label, b), self.g.pairwise(p, label, label)]
+        octets = np.empty((len(tr), 8))
+        for t in range(len(tr)):
+            cur = [int(labeling[v]) for v in tr[t]]
+            for k in range(8):
+                octets[t, k] = self.g.triplet(t, *[label if k >> (2 - j) & 1 else cur[j] for j in range(3)])
+        return quads, octets
 
 
 class _OracleCost:

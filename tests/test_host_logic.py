@@ -167,21 +167,30 @@ def test_fusion_icm_step_against_a_plain_python_version(built):
     """msm_fusion_icm_step (the stand-in binary solve that lets tests and tools drive the fusion-move path end to end) against the
     same rule written out in Python: ascending node order, strict improvement, passes until nothing changes"""
     rng = np.random.default_rng(12)
-    for trial in range(6):
+    for trial in range(8):
         N = int(rng.integers(5, 60))
         T = int(rng.integers(0, 3 * N))
+        P = int(rng.integers(0, 3 * N)) if trial % 2 else 0
         tr = np.sort(np.stack([rng.choice(N, 3, replace=False) for _ in range(T)]).reshape(T, 3), axis=1).astype(np.int32) if T else np.zeros((0, 3), np.int32)
-        u2 = rng.normal(size=(N, 2))
+        pr = np.stack([rng.choice(N, 2, replace=False) for _ in range(P)]).reshape(P, 2).astype(np.int32) if P else np.zeros((0, 2), np.int32)
+        u2 = rng.normal(size=(N, 2)) if trial != 5 else None
         oc = rng.normal(size=(T, 8))
+        qd = rng.normal(size=(P, 4))
         if trial == 3 and T:
             oc[rng.integers(0, T), :] = np.nan  # a failed evaluation: comparisons with NaN never flip a node
         passes = int(rng.integers(1, 6))
-        got = M.fusion_icm_step(u2, oc, tr, passes)
+        got = M.fusion_icm_step(u2 if u2 is not None else N, oc, tr, passes, quads=qd, pairs=pr)
         x = np.zeros(N, dtype=np.int32)
         for _ in range(passes):
             changed = False
             for v in range(N):
-                e = [u2[v, 0], u2[v, 1]]
+                e = [u2[v, 0], u2[v, 1]] if u2 is not None else [0.0, 0.0]
+                for p in range(P):
+                    if v in pr[p]:
+                        for val in (0, 1):
+                            xa = val if pr[p, 0] == v else x[pr[p, 0]]
+                            xb = val if pr[p, 1] == v else x[pr[p, 1]]
+                            e[val] += qd[p, 2 * int(xa) + int(xb)]
                 for t in range(T):
                     if v in tr[t]:
                         for val in (0, 1):
