@@ -278,6 +278,16 @@ inline void mcmc_optimise(const Matrix &unary_costs, const Matrix &tcosts, const
                             mciters, seed, labeling.data()));
 }
 
+// The stand-in for the binary solve of one label step of Fusion::optimize (msm_fusion_icm_step: iterated conditional modes, NOT ELC +
+// FastPD): x[node] = 1 where the proposed label is taken.  unary2 N x 2 (may be empty: no unary costs), quads P x 4, octets T x 8.
+inline std::vector<int32_t> fusion_icm_step(int num_nodes, const std::vector<double> &unary2, const double *quads, const std::vector<int32_t> &pairs,
+                                            const double *octets, const std::vector<int32_t> &triplets, int max_passes = 5) {
+    std::vector<int32_t> x((size_t)num_nodes, 0);
+    check(msm_fusion_icm_step(unary2.empty() ? nullptr : unary2.data(), quads, pairs.data(), (int32_t)(pairs.size() / 2), octets, triplets.data(),
+                              (int32_t)(triplets.size() / 3), num_nodes, max_passes, x.data()));
+    return x;
+}
+
 // ---------------------------------------------------------------- discrete cost function
 struct Parameters {  // what set_parameters reads from the myparam map, M/DiscreteCostFunction.cpp:119-133
     int kind = MSM_COST_UNIVARIATE;

@@ -23,6 +23,11 @@ struct LevelOptions {
     double labeldist = 0.5;
     bool rescale_labels = false;
     Parameters cost;    // kind, similarity measure, regulariser
+    // false: MCMC::optimise over the unary and T x L^3 triplet tables.  true: the label loop of Fusion::optimize (I/Fusion/Fusion.h:136-229),
+    // per label step ONE msm_cost_triplet_octets for the 8 T combinations -- how --dopt=HOCR drives the path -- with a stand-in for the
+    // licence-restricted binary solve (msm_fusion_icm_step, icm_passes passes): the path is exercised as HOCR would, the result is not HOCR's
+    bool fusion = false;
+    int icm_passes = 5;
 };
 
 struct LevelResult {
@@ -64,6 +69,7 @@ inline LevelResult run_discrete_opt(Context &ctx, const Points &target_xyz, cons
     double m_scale = 1.0;
     if (cp_start) cp_xyz = *cp_start;
     LevelResult res;
+    detail::HostBuffer octets;
     for (int it = 0; it < o.iters; ++it) {
         // ---- reset_meshspace + setupCostFunction
         SOURCE.set_coords(sph_reg);
@@ -78,11 +84,31 @@ inline LevelResult run_discrete_opt(Context &ctx, const Points &target_xyz, cons
         costfct.get_source_data();
         costfct.setTriplets(triplets);
         ++m_iter;
-        // ---- MCMC: computeUnaryCosts, computeTripletCosts, optimise
         costfct.computeUnaryCosts();
-        const std::vector<double> tcosts = costfct.computeTripletCosts();
         std::vector<int32_t> labeling((size_t)N, 0);  // resetLabeling
-        mcmc_optimise(costfct.unarycosts, tcosts, triplets, N, (int)(labels.size() / 3), o.mcparam, o.mciters, o.seed + (uint64_t)it, labeling);
+        const int L = (int)(labels.size() / 3), T = (int)(triplets.size() / 3);
+        if (o.fusion) {  // ---- Fusion::optimize: two sweeps over the labels, a fusion move per label step
+            double *E = octets.ensure(ctx.handle(), 8 * (size_t)T);  // pinned, GPU-mapped: the kernel writes the costs where the solve reads them
+            std::vector<double> unary2(2 * (size_t)N);
+            const std::vector<int32_t> no_pairs;
+            for (int sweep = 0; sweep < 2; ++sweep)
+                for (int label = 0; label < L; ++label) {
+                    bool any = false;
+                    for (int i = 0; i < N; ++i) any = any || labeling[(size_t)i] != label;
+                    if (!any) continue;
+                    check(msm_cost_triplet_octets(costfct.handle(), labeling.data(), label, E));
+                    for (int i = 0; i < N; ++i) {
+                        unary2[2 * (size_t)i] = costfct.unarycosts[(size_t)labeling[(size_t)i] * N + i];
+                        unary2[2 * (size_t)i + 1] = costfct.unarycosts[(size_t)label * N + i];
+                    }
+                    const std::vector<int32_t> x = fusion_icm_step(N, unary2, nullptr, no_pairs, E, triplets, o.icm_passes);
+                    for (int i = 0; i < N; ++i)
+                        if (x[(size_t)i] == 1 && labeling[(size_t)i] != label) labeling[(size_t)i] = label;
+                }
+        } else {  // ---- MCMC: computeUnaryCosts, computeTripletCosts, optimise
+            const std::vector<double> tcosts = costfct.computeTripletCosts();
+            mcmc_optimise(costfct.unarycosts, tcosts, triplets, N, L, o.mcparam, o.mciters, o.seed + (uint64_t)it, labeling);
+        }
         res.energies.push_back(costfct.evaluateTotalCostSum(labeling));
         res.labelings.push_back(labeling);
         // ---- applyLabeling, warp the source through the control grid's move, unfold both (:219-230)

@@ -55,6 +55,11 @@ int main(int argc, char **argv) {
         o.mcparam = F["params"][0];
         o.cost.lambda = F["params"][1];
         o.cost.kind = D > 1 ? MSM_COST_MULTIVARIATE : MSM_COST_UNIVARIATE;
+        if (I["orders"].size() > 7 && I["orders"][7] != 0) {  // the fusion-driven loop over the triclique classes with the HCP regulariser
+            o.fusion = true;
+            o.cost.kind = D > 1 ? MSM_COST_HO_MULTIVARIATE : MSM_COST_HO_UNIVARIATE;
+            o.cost.shearmodulus = 0.4, o.cost.bulkmodulus = 1.6, o.cost.kexponent = 2.0, o.cost.exponent = 2.0;
+        }
         const LevelResult r = run_discrete_opt(ctx, xyz, tri, F["ref_feat"], xyz, tri, F["src_feat"], D, xyz, cp_order, o);
         std::ofstream out(argv[2], std::ios::binary);
         put(out, "sph_reg", "f8", r.sph_reg);

@@ -85,6 +85,32 @@ def test_cpp_level_driver_equals_python_loop(built, ctx, tmp_path, D, rescale):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("D", [1, 16])
+def test_cpp_level_driver_fusion_loop_equals_python_loop(built, ctx, tmp_path, D):
+    """the same for the fusion-driven loop over the triclique classes (LevelOptions::fusion: per label step one msm_cost_triplet_octets into
+    a pinned buffer + the stand-in solve): identical to registration.run_discrete_level(optimiser="fusion")"""
+    import newmsm_amd as M
+    from newmsm_amd import registration, synthetic
+
+    build_cpp(LEVEL_SRC, LEVEL_EXE)
+    xyz, tri = M.make_mesh_from_icosa(4)
+    ref = synthetic.features(xyz, D, 21)
+    src = synthetic.features(synthetic.known_warp(xyz, seed=23, rot_deg=4.0, amp=2.5), D, 21)
+    fin, fout = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+    write_bag(fin, orders=np.array([4, 2, D, 2, 0, 5, 1, 1]), params=np.array([0.3, 0.01]), ref_feat=ref, src_feat=src)
+    run = subprocess.run([LEVEL_EXE, fin, fout], capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0, run.stderr + run.stdout
+    got = read_bag(fout)
+    want = registration.run_discrete_level(registration.ProductOps(ctx), xyz, tri, ref, xyz, tri, src, xyz, cp_order=2, iters=2, seed=5,
+                                           kind="ho_multivariate" if D > 1 else "ho_univariate", rescale_labels=True, optimiser="fusion",
+                                           cost_params=dict(lambda_=0.01, mu=0.4, kappa=1.6, k_exp=2.0, rexp=2.0))
+    assert np.array_equal(got["labelings"].reshape(2, -1), np.array(want[3]))
+    assert np.array_equal(got["energies"], np.array(want[2]))
+    assert np.array_equal(got["sph_reg"].reshape(-1, 3), want[0]) and np.array_equal(got["cpgrid"].reshape(-1, 3), want[1])
+    assert any(l.any() for l in want[3])
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("D", [1, 3])
 def test_cpp_host_mirror_against_oracle(built, tmp_path, D):
     build_host_mirror()
