@@ -20,14 +20,20 @@ bad, flips, t0 = 0, 0, time.time()
 for k in range(n):
     data_order = int(rng.choice([3, 4]))
     cp_order = int(rng.integers(1, data_order - 1))
-    kind = str(rng.choice(["univariate", "multivariate", "patchwise"]))
-    D = 1 if kind == "univariate" else int(rng.integers(2, 5))
+    kind = str(rng.choice(["univariate", "multivariate", "patchwise", "ho_univariate", "ho_multivariate"]))
+    D = 1 if kind in ("univariate", "ho_univariate") else int(rng.integers(2, 5) if kind != "ho_multivariate" else rng.choice([2, 5, 13, 20]))
+    # the triclique classes are driven as --dopt=HOCR drives them: the label loop of Fusion over fusion moves (stand-in binary solve); the others
+    # by either optimiser
+    optimiser = "fusion" if kind.startswith("ho_") or rng.integers(0, 3) == 0 else "mcmc"
     xyz, tri = M.make_mesh_from_icosa(data_order)
     seed = int(rng.integers(1, 10**6))
     ref = synthetic.features(xyz, D, seed)
     src = synthetic.features(synthetic.known_warp(xyz, seed=seed + 2, rot_deg=float(rng.uniform(1, 5)), amp=float(rng.uniform(0.5, 3))), D, seed)
     kw = dict(cp_order=cp_order, iters=int(rng.integers(1, 4)), mciters=int(rng.integers(5, 60)), mcparam=float(rng.uniform(0.2, 0.9)), seed=seed, kind=kind,
-              rescale_labels=bool(rng.integers(0, 2)), simmeasure=int(rng.choice([1, 2])), cost_params=dict(lambda_=float(rng.uniform(0.01, 0.3))))
+              rescale_labels=bool(rng.integers(0, 2)), simmeasure=int(rng.choice([1, 2])), cost_params=dict(lambda_=float(rng.uniform(0.01, 0.3))),
+              optimiser=optimiser)
+    if kind.startswith("ho_"):
+        kw["cost_params"].update(lambda_=float(rng.uniform(0.001, 0.05)), mu=0.4, kappa=1.6, k_exp=2.0, rexp=2.0)
     got = registration.run_discrete_level(registration.ProductOps(ctx), xyz, tri, ref, xyz, tri, src, xyz, **kw)
     want = registration.run_discrete_level(OracleOps(M.mcmc_optimise), xyz, tri, ref, xyz, tri, src, xyz, **kw)
     same = all(np.array_equal(a, b) for a, b in zip(got[3], want[3]))
@@ -36,5 +42,5 @@ for k in range(n):
     ok = ang <= 1e-4
     flips += not same
     bad += not ok
-    print("ok" if ok and same else ("FLIP" if ok else "MISMATCH"), k, kind, D, data_order, cp_order, "max angle %.2e rad" % ang, {a: kw[a] for a in ("iters", "mciters", "rescale_labels", "simmeasure")}, flush=True)
+    print("ok" if ok and same else ("FLIP" if ok else "MISMATCH"), k, kind, D, data_order, cp_order, "max angle %.2e rad" % ang, {a: kw[a] for a in ("iters", "mciters", "rescale_labels", "simmeasure", "optimiser")}, flush=True)
 print("fuzz_registration: %d configs, %d beyond 1e-4 rad, %d with a different labeling, %.0f s" % (n, bad, flips, time.time() - t0))
