@@ -150,7 +150,20 @@ int ensure_move(msm_cost *c, const CliqueArgs &a) {
     // 95 us at D = 32 with 48 slots / 6 triangles; with one feature the two shapes are level in the kernel and the larger is cheaper to launch
     const bool wide = a.kind == MSM_COST_HO_MULTIVARIATE && a.D >= 12;
     const bool env_s = std::getenv("MSMHIP_MOVE_SLOTS") != nullptr, env_t = std::getenv("MSMHIP_MOVE_TRIANGLES") != nullptr;
-    const int max_slots = (wide && !env_s) ? 48 : kMoveSlots, max_tris = (wide && !env_t) ? 6 : kMoveTriangles;
+    int max_slots = (wide && !env_s) ? 48 : kMoveSlots, max_tris = (wide && !env_t) ? 6 : kMoveTriangles;
+    if (!env_s && !env_t) {
+        // A workgroup's time is a chain (proposed triangles, sampling rounds, similarity passes, last phase) whose length grows with the
+        // triangles it holds, and the whole grid is resident at once up to ~1000 workgroups: on the coarser control grids of a registration's
+        // first levels fewer triangles per workgroup shorten every chain at no cost (D = 32: 55 -> 41 us at ico3, 55 -> 34 us at ico2; the
+        // ico4 grid keeps 6 / 8).  The smallest run of triangles that still fits the grid into one residency round:
+        const int most = max_tris;
+        for (int t : {1, 2, 4, 6, 8})
+            if ((T + most - 1) / most <= 512 && t <= most && (T + t - 1) / t <= 1024) {  // only when the usual run leaves half the GPU empty
+                max_tris = t;
+                max_slots = 8 * t;
+                break;
+            }
+    }
     int slots = 0, nt = 0, cap = max_slots, first = 0;
     auto close = [&](int t_end) {
         if (nt > 0) blk.push_back(make_int4(first, nt, c->pptr[first], c->pptr[t_end] - c->pptr[first]));

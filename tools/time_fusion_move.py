@@ -1,4 +1,4 @@
-"""tools/time_fusion_move.py KIND D [calls] -- wall time per msm_cost_triplet_octets call (one label step of Fusion, I/Fusion/Fusion.h:181-196)
+"""tools/time_fusion_move.py KIND D [calls [data_order cp_order]] -- wall time per msm_cost_triplet_octets call (one label step of Fusion, I/Fusion/Fusion.h:181-196)
 at ico6 / ico4 for an HO cost class; run under rocprofv3 --kernel-trace --stats for the per-kernel split."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -9,7 +9,8 @@ from newmsm_amd import problem
 kind, D = sys.argv[1], int(sys.argv[2])
 calls = int(sys.argv[3]) if len(sys.argv) > 3 else 200
 ctx = M.Context(0)
-inp = problem.pairwise_inputs(6, 4, D=D)
+do, co = (int(sys.argv[4]), int(sys.argv[5])) if len(sys.argv) > 5 else (6, 4)
+inp = problem.pairwise_inputs(do, co, D=D)
 cf, keep = problem.build_cost(ctx, inp, kind=kind, rmode=3, lambda_=0.01, mu=0.4, kappa=1.6)
 cf.get_source_data()
 rng = np.random.default_rng(0)
