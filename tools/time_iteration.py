@@ -1,4 +1,4 @@
-"""per-iteration set-up of a pairwise registration at ico6 / ico4: reset_source (new source coordinates) + get_source_data + table"""
+"""tools/time_iteration.py [kind [data_order cp_order [D]]] -- per-iteration set-up of a pairwise registration (default ico6 / ico4): reset_source (new source coordinates) + get_source_data + table"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -6,7 +6,8 @@ import newmsm_amd as M
 from newmsm_amd import problem, synthetic
 ctx = M.Context(0)
 kind = sys.argv[1] if len(sys.argv) > 1 else "univariate"
-inp = problem.pairwise_inputs(6, 4, D=1)
+do, co = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (6, 4)
+inp = problem.pairwise_inputs(do, co, D=int(sys.argv[4]) if len(sys.argv) > 4 else 1)
 cf, keep = problem.build_cost(ctx, inp, kind=kind, rmode=3)
 cf.get_source_data(); cf.computeUnaryCosts()
 src, cpg = keep["source"], keep["cpgrid"]
