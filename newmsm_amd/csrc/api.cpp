@@ -5,6 +5,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <list>
+#include <mutex>
 #include <thread>
 
 #include "devbuf.hpp"
@@ -256,6 +258,75 @@ static bool ray_build_in_background() {
     return !(e && (std::strcmp(e, "sync") == 0 || std::strcmp(e, "off") == 0));
 }
 
+// Direction tables by mesh content.  A table is a pure function of the target's coordinates and triangles, and a pipeline registers
+// many subjects against the SAME targets (every level's target is the regular icosphere of its resolution; the template of a group):
+// the host arrays of the last few tables built in this process are kept (coordinates and triangles compared in full on a hit, so a
+// hash collision cannot hand out the wrong table), and a mesh with the same content takes a copy instead of the 10 - 14 ms of
+// build_octree + build_ray_table at ico6.  MSMHIP_RAY_CACHE=off | number of tables kept (default 8, ~10 MB of host memory each at ico6).
+struct RayCacheEntry {
+    uint64_t hash = 0;
+    int V = 0, T = 0;
+    std::vector<double> xyz;
+    std::vector<int32_t> tri;
+    bool simple = false;
+    int ray_G = 0;
+    double ray_r2lo = 0, ray_r2hi = 0;
+    decltype(FlatOctree::ray_cell) ray_cell;
+    decltype(FlatOctree::ray_edge) ray_edge;
+    decltype(FlatOctree::ray_more) ray_more;
+    decltype(FlatOctree::ray_excl) ray_excl;
+};
+static std::mutex g_ray_cache_mu;
+static std::list<std::shared_ptr<const RayCacheEntry>> g_ray_cache;  // most recently used first
+
+static size_t ray_cache_capacity() {
+    static const size_t cap = [] {
+        const char *e = std::getenv("MSMHIP_RAY_CACHE");
+        if (!e) return (size_t)8;
+        if (std::strcmp(e, "off") == 0) return (size_t)0;
+        return (size_t)std::max(0, std::atoi(e));
+    }();
+    return cap;
+}
+
+static uint64_t content_hash(const msm_mesh *m) {
+    auto mix = [](uint64_t h, const void *p, size_t bytes) {
+        const uint64_t *w = static_cast<const uint64_t *>(p);
+        for (size_t i = 0; i < bytes / 8; ++i) {
+            h ^= w[i] + 0x9e3779b97f4a7c15ull + (h << 6) + (h >> 2);
+            h *= 0xff51afd7ed558ccdull;
+        }
+        return h ^ (h >> 32);
+    };
+    uint64_t h = 0x243f6a8885a308d3ull ^ ((uint64_t)m->V << 32) ^ (uint64_t)m->T;
+    h = mix(h, m->xyz.data(), m->xyz.size() * sizeof(double));
+    return mix(h, m->tri.data(), m->tri.size() * sizeof(int32_t) / 8 * 8);
+}
+
+static std::shared_ptr<const RayCacheEntry> ray_cache_find(const msm_mesh *m, uint64_t h) {
+    std::lock_guard<std::mutex> lock(g_ray_cache_mu);
+    for (auto it = g_ray_cache.begin(); it != g_ray_cache.end(); ++it) {
+        const RayCacheEntry &e = **it;
+        if (e.hash == h && e.V == m->V && e.T == m->T && e.xyz == m->xyz && e.tri == m->tri) {
+            g_ray_cache.splice(g_ray_cache.begin(), g_ray_cache, it);
+            return g_ray_cache.front();
+        }
+    }
+    return nullptr;
+}
+
+static void ray_cache_store(const msm_mesh *m, uint64_t h) {  // m->tree holds a freshly built table
+    if (ray_cache_capacity() == 0) return;
+    auto e = std::make_shared<RayCacheEntry>();
+    e->hash = h, e->V = m->V, e->T = m->T;
+    e->xyz = m->xyz, e->tri = m->tri;
+    e->simple = m->tree.simple, e->ray_G = m->tree.ray_G, e->ray_r2lo = m->tree.ray_r2lo, e->ray_r2hi = m->tree.ray_r2hi;
+    e->ray_cell = m->tree.ray_cell, e->ray_edge = m->tree.ray_edge, e->ray_more = m->tree.ray_more, e->ray_excl = m->tree.ray_excl;
+    std::lock_guard<std::mutex> lock(g_ray_cache_mu);
+    g_ray_cache.push_front(std::move(e));
+    while (g_ray_cache.size() > ray_cache_capacity()) g_ray_cache.pop_back();
+}
+
 static void retire_ray_job(msm_mesh *m) {
     if (m->ray_job) m->stale_jobs.push_back(std::move(m->ray_job));
     m->ray_job.reset();
@@ -282,7 +353,15 @@ int ensure_rays(msm_mesh *m, bool wait) {
         m->tree.ray_more = std::move(b.ray_more);
         m->tree.ray_excl = std::move(b.ray_excl);
     };
-    if (!m->ray_job && (wait || !ray_build_in_background())) {
+    // (the switches that change what build_ray_table produces are read per call -- the tests flip them within a process: no cache then)
+    const char *no_table = std::getenv("MSMHIP_DISABLE_RAYTABLE");
+    const bool cache_ok = ray_cache_capacity() > 0 && !(no_table && no_table[0] == '1') && !std::getenv("MSMHIP_RAY_G");
+    const uint64_t chash = cache_ok ? content_hash(m) : 0;
+    std::shared_ptr<const RayCacheEntry> hit = (!m->ray_job && cache_ok) ? ray_cache_find(m, chash) : nullptr;
+    if (hit) {  // a mesh with these coordinates and triangles has had its table built in this process
+        m->tree.simple = hit->simple, m->tree.ray_G = hit->ray_G, m->tree.ray_r2lo = hit->ray_r2lo, m->tree.ray_r2hi = hit->ray_r2hi;
+        m->tree.ray_cell = hit->ray_cell, m->tree.ray_edge = hit->ray_edge, m->tree.ray_more = hit->ray_more, m->tree.ray_excl = hit->ray_excl;
+    } else if (!m->ray_job && (wait || !ray_build_in_background())) {
         if (m->tree.node.empty()) {  // the tree was built on the GPU: the table's builder walks a host copy of the same tree
             FlatOctree host_tree;
             build_octree(m->xyz.data(), m->tri.data(), m->V, m->T, host_tree);
@@ -312,6 +391,7 @@ int ensure_rays(msm_mesh *m, bool wait) {
         take_rays(m->ray_job->tree);
         m->ray_job.reset();
     }
+    if (!hit && cache_ok) ray_cache_store(m, chash);
     if (m->tree.ray_G > 0) {
         auto grow = [&](void **p, size_t &cap, size_t need, size_t elem) -> hipError_t {
             if (need <= cap && *p) return hipSuccess;

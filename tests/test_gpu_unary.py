@@ -303,3 +303,25 @@ def test_many_labels_and_a_single_label(ctx, kind, D, sg_order, labeldist, lo, h
     U, Uo = cf.computeUnaryCosts(), oc.unary_table()
     assert U.shape == Uo.shape == (len(inp["labels"]), 162)
     assert np.allclose(U, Uo, rtol=1e-9, atol=1e-11), np.abs(U - Uo).max()
+
+
+def test_direction_table_is_shared_by_content(ctx):
+    """a second target with the same coordinates and triangles takes the first one's direction table (kept by content in the process,
+    compared in full on a hit): same costs bit for bit and no second build; a target that differs in one coordinate builds its own"""
+    import time
+
+    inp = problem.pairwise_inputs(5, 3, D=1, seed=77)
+    tables, times = [], []
+    for k in range(3):
+        txyz = inp["target_xyz"].copy()
+        txyz[17] = txyz[17] * (1.0 + (3e-9 if k < 2 else 1e-9))  # off the shell by ~1e-7 mm: meshes no other test has built; the third differs
+        cf, keep = problem.build_cost(ctx, dict(inp, target_xyz=txyz), kind="univariate")
+        cf.get_source_data()
+        t0 = time.perf_counter()
+        keep["target"].prepare_search(wait=True)
+        times.append(time.perf_counter() - t0)
+        tables.append(cf.computeUnaryCosts().copy())
+        cf.close()
+    assert np.array_equal(tables[0], tables[1])
+    assert times[1] < 0.7 * times[0] and times[2] > 0.7 * times[0], times  # the copy is cheaper than the build; the changed mesh was built
+    assert np.allclose(tables[2], tables[0], rtol=0, atol=1e-6) and not np.array_equal(tables[2], tables[0])
