@@ -255,6 +255,7 @@ DevTree forest_tree(const Forest &f, int b);
 int gpu_build_octree_begin(msm_mesh *m);   // the same in two halves: queue the build ... 
 int gpu_build_octree_finish(msm_mesh *m);  // ... wait for it (one build at a time per context)
 int ensure_tree_begin(msm_mesh *m);        // api.cpp: starts the GPU build of an invalid tree (no-op otherwise); ensure_tree() completes it  // octree_kernels.hip: the same tree built in HBM from the mesh's device coordinates (MSM_ERR_CAPACITY: use the host build)
+bool mesh_tree_on_gpu(const msm_mesh *m);  // api.cpp: is this mesh's tree built by the GPU kernels (large meshes) or on the host
 int finish_tree(msm_mesh *m);       // what follows either build: validity flags, generation
 int ensure_masks(msm_mesh *m);  // + the per-leaf sub-cell masks the cost kernels use (built on the GPU)
 int ensure_rays(msm_mesh *m, bool wait = false);   // + the ray table of a simple surface (unary table kernels); see api.cpp
