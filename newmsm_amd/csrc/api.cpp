@@ -1255,7 +1255,7 @@ int msm_smooth_data(msm_mesh *orig, const double *data, int32_t D, msm_mesh *sph
     MSM_HIP(dcv.ensure(N));
     st = launch_closest_vertex(ctx, dev_tree(orig), sphlow->d_xyz, N, dcv.p);  // Octree(orig).get_closest_vertex_ID(ci), :182
     if (st) return st;
-    MSM_HIP(dunit.ensure(3 * (size_t)N));
+    MSM_HIP(dunit.ensure(smooth_scratch_doubles(N)));
     MSM_HIP(ddata.upload(data, (size_t)D * orig->V, ctx->stream));
     if (excl) MSM_HIP(dexcl.upload(excl, (size_t)orig->V, ctx->stream));
     MSM_HIP(dout.ensure((size_t)D * N));

@@ -315,9 +315,11 @@ __global__ __launch_bounds__(256) void k_unit_vectors(const double *__restrict__
 
 constexpr int kSmoothList = 512;  // neighbours per LDS pass of one wavefront
 
+__global__ __launch_bounds__(256) void k_chunk_bounds(const double *__restrict__ src, int Nsrc, double4 *__restrict__ cb);
+
 __global__ __launch_bounds__(256) void k_smooth(const double *__restrict__ unit, int N, const int *__restrict__ cv, const double *__restrict__ data,
                                                 int Vorig, int D, double sigma, double cosang, const double *__restrict__ excl,
-                                                double *__restrict__ out, double *__restrict__ excl_out, int *status) {
+                                                double *__restrict__ out, double *__restrict__ excl_out, const double4 *__restrict__ cb, int *status) {
     __shared__ int s_n[4][kSmoothList];
     __shared__ double s_w[4][kSmoothList];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -356,26 +358,41 @@ __global__ __launch_bounds__(256) void k_smooth(const double *__restrict__ unit,
         count = 0;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     };
-    for (int n0 = 0; n0 < N; n0 += 64) {
-        const int n = n0 + lane;
-        bool in = false;
-        double chord = 0.0;
-        if (n < N) {
-            const V3 a = mk(unit[n], unit[N + n], unit[2 * N + n]);
-            in = dot(a, ref) >= cosang;
-            if (in) chord = norm(sub(ref, a));
+    // The sweep is pruned without changing what it finds or the order it finds it in: the unit vectors are taken 64 consecutive ids at a
+    // time with a bounding ball (k_chunk_bounds); (a | ref) <= (centre | ref) + radius for every member a, so a chunk whose bound stays
+    // below cos(ang) holds no member and is skipped (a NaN anywhere keeps the chunk).  The lanes test 64 chunks at once; the surviving
+    // ones -- a few per cent on ico-derived meshes, whose numbering keeps neighbours close -- are swept in ascending order as before.
+    const int nchunks = (N + 63) >> 6;
+    for (int c0 = 0; c0 < nchunks; c0 += 64) {
+        bool cand = false;
+        if (c0 + lane < nchunks) {
+            const double4 b = cb[c0 + lane];
+            cand = !(b.x * ref.x + b.y * ref.y + b.z * ref.z + b.w < cosang);
         }
-        const unsigned long long bal = __ballot(in);
-        if (!bal) continue;
-        const int add = __popcll(bal);
-        if (count + add > kSmoothList) flush();
-        if (in) {
-            const double g = 2 * kRad * asin(chord / (2 * kRad));
-            const int at = count + __popcll(bal & ((1ull << lane) - 1ull));
-            ln[at] = n;
-            lw[at] = gain * exp(-(g * g) / (2 * sigma * sigma));
+        unsigned long long todo = __ballot(cand);
+        while (todo) {
+            const int n0 = (c0 + __ffsll((long long)todo) - 1) << 6;
+            todo &= todo - 1ull;
+            const int n = n0 + lane;
+            bool in = false;
+            double chord = 0.0;
+            if (n < N) {
+                const V3 a = mk(unit[n], unit[N + n], unit[2 * N + n]);
+                in = dot(a, ref) >= cosang;
+                if (in) chord = norm(sub(ref, a));
+            }
+            const unsigned long long bal = __ballot(in);
+            if (!bal) continue;
+            const int add = __popcll(bal);
+            if (count + add > kSmoothList) flush();
+            if (in) {
+                const double g = 2 * kRad * asin(chord / (2 * kRad));
+                const int at = count + __popcll(bal & ((1ull << lane) - 1ull));
+                ln[at] = n;
+                lw[at] = gain * exp(-(g * g) / (2 * sigma * sigma));
+            }
+            count += add;
         }
-        count += add;
     }
     flush();
     if (lane == 0 && excl && excl_out && excl_sum != 0.0) excl_out[i] = SUM / excl_sum;
@@ -391,8 +408,12 @@ int launch_smooth(msm_ctx *ctx, const double *d_xyz, int N, double *d_unit, cons
     if (N <= 0) return MSM_OK;
     hipLaunchKernelGGL(k_unit_vectors, dim3((N + 255) / 256), dim3(256), 0, ctx->stream, d_xyz, N, d_unit);
     MSM_HIP(hipGetLastError());
+    // the chunks' bounding balls live behind the unit vectors in the caller's buffer (3 N doubles rounded up to a 32-byte boundary + 4 per chunk)
+    double4 *cb = reinterpret_cast<double4 *>(d_unit + smooth_bounds_offset(N));
+    hipLaunchKernelGGL(k_chunk_bounds, dim3((N + 255) / 256), dim3(256), 0, ctx->stream, d_unit, N, cb);
+    MSM_HIP(hipGetLastError());
     hipLaunchKernelGGL(k_smooth, dim3((N + 3) / 4), dim3(256), 0, ctx->stream, d_unit, N, d_cv, d_data, Vorig, D, sigma, cosang, d_excl, d_out,
-                       d_excl_out, ctx->d_status);
+                       d_excl_out, cb, ctx->d_status);
     MSM_HIP(hipGetLastError());
     return MSM_OK;
 }

@@ -53,6 +53,9 @@ int launch_copy_to_mapped(msm_ctx *ctx, const double *d_src, double *mapped_dst,
 int launch_query(msm_ctx *ctx, const DevTree &T, const double *d_q, int N, int *d_tri, int *d_vid, double *d_w, int mode);
 int launch_closest_vertex(msm_ctx *ctx, const DevTree &T, const double *d_q, int N, int *d_out);
 // smooth_data: unit vectors of the N vertices (d_unit: 3 x N scratch), then one wavefront per output vertex
+// d_unit of launch_smooth holds smooth_scratch_doubles(N) doubles: the unit vectors and, from smooth_bounds_offset(N), a bounding ball per 64 of them
+inline size_t smooth_bounds_offset(int N) { return ((size_t)3 * N + 3) / 4 * 4; }
+inline size_t smooth_scratch_doubles(int N) { return smooth_bounds_offset(N) + 4 * (((size_t)N + 63) / 64) + 4; }
 int launch_smooth(msm_ctx *ctx, const double *d_xyz, int N, double *d_unit, const int *d_cv, const double *d_data, int Vorig, int D, double sigma,
                   double cosang, const double *d_excl, double *d_out, double *d_excl_out);
 // check_for_intersections (M/reg_tools.cpp:118-129) of every vertex: fold[0] += folded, fold[1] += vertices without a triangle, fold[2 + v] = folded
