@@ -178,6 +178,22 @@ class Context:
         buf = (C.c_char * max(n, 8)).from_address(p)
         return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
 
+    def scratch_host_array(self, name, shape, dtype=np.float64):
+        """a view of a grow-only pinned buffer kept per `name` on this context (reallocated, the old one freed, when it has to grow)"""
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        bufs = self.__dict__.setdefault("_scratch_pinned", {})
+        cur = bufs.get(name)
+        if cur is None or cur[1] < n:
+            if cur is not None:
+                lib().msm_host_free(self.h, C.c_void_p(cur[0]))
+            cap = max(n + n // 8, 4096)
+            p = lib().msm_host_alloc(self.h, cap)
+            if not p:
+                raise MsmError(-2, lib().msm_last_error().decode())
+            cur = bufs[name] = (p, cap)
+        buf = (C.c_char * cur[1]).from_address(cur[0])
+        return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
     def forest_signatures(self, xyz_sets, tri):
         """leaf signatures (Mesh.octree_signature) of the trees of B coordinate sets over one triangle list, built together as a forest"""
         sets = [np.ascontiguousarray(np.asarray(x, dtype=np.float64).T) for x in xyz_sets]
@@ -538,15 +554,19 @@ class DiscreteCostFunction:
         check(lib().msm_cost_triplet_octets(self.h, pl, int(label), out.ctypes.data_as(c_dp)))
         return out
 
-    def computeTripletCosts(self, t0=0, t1=None):
+    def computeTripletCosts(self, t0=0, t1=None, pinned=False):
         """tcosts[t][a][b][c] (M/DiscreteCostFunction.cpp:245-253) for the triplets t0 <= t < t1.  Like the reference's
         tcosts member the table lives in the object: the returned array is reused by the next call of the same shape (a fresh
-        281 MB array per call costs more in page faults than the table takes to compute and copy)."""
+        281 MB array per call costs more in page faults than the table takes to compute and copy).  pinned=True: the table is delivered into
+        a pinned buffer of the CONTEXT instead -- valid until the next pinned table of any cost function on this context."""
         t1 = self.T if t1 is None else t1
         shape = (t1 - t0, self.L, self.L, self.L)
-        out = self._keep.get("tcosts")
-        if out is None or out.shape != shape:
-            out = self._keep["tcosts"] = np.empty(shape)
+        if pinned:  # one grow-only pinned buffer per context: the 281 MB of an ico4 table arrive at PCIe speed (5 ms; 25 ms into pageable memory)
+            out = self.ctx.scratch_host_array("tcosts", shape)
+        else:
+            out = self._keep.get("tcosts")
+            if out is None or out.shape != shape:
+                out = self._keep["tcosts"] = np.empty(shape)
         check(lib().msm_cost_triplet_table(self.h, int(t0), int(t1), out.ctypes.data_as(c_dp)))
         return out
 

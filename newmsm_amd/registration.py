@@ -119,7 +119,7 @@ class _ProductCost:
         return self.cf.computeUnaryCosts()
 
     def triplet_table(self):
-        return self.cf.computeTripletCosts()
+        return self.cf.computeTripletCosts(pinned=True)  # consumed by the optimiser before the next table is computed
 
     def triplet_octets(self, labeling, label):
         if getattr(self, "_octets", None) is None or self._octets.shape[0] != self.cf.T:
