@@ -6,6 +6,8 @@
 // /root/reference/libraries/).
 #include <algorithm>
 #include <map>
+#include <memory>
+#include <mutex>
 #include <unordered_map>
 
 #include "internal.hpp"
@@ -183,9 +185,25 @@ int msm_icosphere(int order, double radius, double *xyz, int32_t *tri) {
     int st = msm_icosphere_counts(order, &V, &T);
     if (st) return st;
     if (!xyz || !tri) return fail(MSM_ERR_INVALID, "msm_icosphere: null output");
-    std::vector<double> p;
-    std::vector<int32_t> f;
-    icosphere_unit(order, p, f);
+    // the unit icosphere of an order is a constant: a registration asks for the same few orders at every level (data grid, control grid,
+    // sampling grid, project_CPgrid), 2.4 ms each at order 6 -- kept per order for the life of the process
+    static std::mutex mu;
+    static std::map<int, std::shared_ptr<const std::pair<std::vector<double>, std::vector<int32_t>>>> kept;
+    std::shared_ptr<const std::pair<std::vector<double>, std::vector<int32_t>>> unit;
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        auto it = kept.find(order);
+        if (it != kept.end()) unit = it->second;
+    }
+    if (!unit) {
+        auto fresh = std::make_shared<std::pair<std::vector<double>, std::vector<int32_t>>>();
+        icosphere_unit(order, fresh->first, fresh->second);
+        unit = fresh;
+        std::lock_guard<std::mutex> lock(mu);
+        kept.emplace(order, unit);
+    }
+    const std::vector<double> &p = unit->first;
+    const std::vector<int32_t> &f = unit->second;
     for (int i = 0; i < V; ++i) {
         V3 c = mk(p[3 * i], p[3 * i + 1], p[3 * i + 2]);
         if (radius > 0) c = scale(normalized(c), radius);  // true_rescale, R/mesh.cpp:1210-1219

@@ -7,6 +7,7 @@
 #include <random>
 
 #include "devbuf.hpp"
+#include "host_parallel.hpp"
 #include "kernels.hpp"
 
 using namespace msm;
@@ -130,7 +131,9 @@ int msm_mesh_unfold(msm_mesh *m, double radius, int32_t *passes, int32_t *first_
 
 int msm_variance_normalise(double *data, int32_t D, int32_t V, const double *excl) {
     if (!data || D < 0 || V < 0) return fail(MSM_ERR_INVALID, "msm_variance_normalise: bad arguments");
-    for (int d = 0; d < D; ++d) {
+    // the recurrence of a row is serial (a division per value: 0.4 ms per ico6 row); the rows are independent and run on the host workers
+    parallel_chunks(D, D >= 4 ? host_workers() : 1, [&](int, int d_begin, int d_end) {
+    for (int d = d_begin; d < d_end; ++d) {
         double *row = data + (size_t)d * V;
         double mean = 0.0, var = 0.0;
         size_t n = 0;
@@ -149,6 +152,7 @@ int msm_variance_normalise(double *data, int32_t D, int32_t V, const double *exc
             if (var > 0.0) row[i] /= sd;
         }
     }
+    });
     return MSM_OK;
 }
 
