@@ -143,7 +143,8 @@ int patches_by_triangle(msm_cost *c) {
     // tree for the queries below (0.4 ms at ico4) -- the overlap ensure_tree_pair gives the classes that bin by range
     int st = mesh_tree_on_gpu(c->cpgrid) ? MSM_OK : ensure_tree_begin(c->source);
     if (st) return st;
-    st = query_host(c->cpgrid, c->source->xyz.data(), Ns, tri.data(), nullptr, nullptr, MSM_WEIGHTS_RAW, "get_source_data (HO)");
+    st = query_host(c->cpgrid, c->source->xyz.data(), Ns, tri.data(), nullptr, nullptr, MSM_WEIGHTS_RAW, "get_source_data (HO)",
+                    c->source->ctx == c->cpgrid->ctx ? c->source->d_xyz : nullptr);  // the source's vertices are in HBM already
     if (st) return st;
     c->pptr.assign(Tc + 1, 0);
     for (int i = 0; i < Ns; ++i) c->pptr[tri[i] + 1]++;
