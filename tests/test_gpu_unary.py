@@ -312,9 +312,9 @@ def test_direction_table_is_shared_by_content(ctx):
 
     inp = problem.pairwise_inputs(5, 3, D=1, seed=77)
     tables, times = [], []
-    for k in range(3):
+    for k in range(5):  # A (built), A, A, A (copies), B (built)
         txyz = inp["target_xyz"].copy()
-        txyz[17] = txyz[17] * (1.0 + (3e-9 if k < 2 else 1e-9))  # off the shell by ~1e-7 mm: meshes no other test has built; the third differs
+        txyz[17] = txyz[17] * (1.0 + (3e-9 if k < 4 else 1e-9))  # off the shell by ~1e-7 mm: meshes no other test has built; the last differs
         cf, keep = problem.build_cost(ctx, dict(inp, target_xyz=txyz), kind="univariate")
         cf.get_source_data()
         t0 = time.perf_counter()
@@ -322,6 +322,6 @@ def test_direction_table_is_shared_by_content(ctx):
         times.append(time.perf_counter() - t0)
         tables.append(cf.computeUnaryCosts().copy())
         cf.close()
-    assert np.array_equal(tables[0], tables[1])
-    assert times[1] < 0.7 * times[0] and times[2] > 0.7 * times[0], times  # the copy is cheaper than the build; the changed mesh was built
-    assert np.allclose(tables[2], tables[0], rtol=0, atol=1e-6) and not np.array_equal(tables[2], tables[0])
+    assert all(np.array_equal(tables[0], t) for t in tables[1:4])
+    assert min(times[1:4]) < 0.5 * min(times[0], times[4]), times  # the copy is cheaper than either build (the best of three copies: no flake on a busy box)
+    assert np.allclose(tables[4], tables[0], rtol=0, atol=1e-6) and not np.array_equal(tables[4], tables[0])
