@@ -10,7 +10,8 @@ All inputs are resident in HBM before the timed region starts.  The same JSON li
   steady            the table kernels alone, enqueued back to back (the round-1 headline definition)
   triclique_move    one label step of Fusion (I/Fusion/Fusion.h:181-196) of the triclique classes: BASELINE config 4 (D = 1) and
                     config 3 (HCP MSMAll, D = 32) at ico6 / ico4 -- per call and per kernel, with their rooflines
-  registration      wall-clock of a three-level ico6 pairwise registration driven by the reference's caller loop
+  registration      wall-clock of a three-level ico6 pairwise registration driven by the reference's caller loop (Monte Carlo optimiser)
+  registration_fusion  the same driven by fusion moves, as --dopt=HOCR drives BASELINE config 2
   registration_msmall  the same for the HCP MSMAll schedule (BASELINE config 3: triclique cost over 32 features, 40 iterations of fusion moves)
   gmsm              one groupwise iteration per level for 64 subjects on this GPU and the subjects/hour it implies
   cpu_baseline      the CPU port (oracle/) on the host cores, on a bounded sample of the headline workload
@@ -136,7 +137,7 @@ def bench_triclique_move(ctx, D, calls, threads):
     return out
 
 
-def bench_registration(ctx):
+def bench_registration(ctx, optimiser="mcmc"):
     """Wall-clock of a pairwise registration (tools/time_registration.py): three DISCRETE levels as in config/basic_configs (data grids
     ico4/5/6, control grids ico2/3/4, sigma 4/2/1, variance normalisation), 3 iterations per level, input and reference spheres ico6."""
     import newmsm_amd as M
@@ -152,12 +153,15 @@ def bench_registration(ctx):
         clock = {}
         t0 = time.perf_counter()
         registration.run_multiresolution(ops, xyz, tri, src, xyz, tri, ref, levels, varnorm=True, timings=clock, iters=3, mciters=50, mcparam=0.8,
-                                         seed=1, cost_params=dict(lambda_=0.1))
+                                         seed=1, cost_params=dict(lambda_=0.1), optimiser=optimiser)
         wall = time.perf_counter() - t0
+    how = ("the library's Monte Carlo optimiser (M/mcmc_opt.h) at 50 sweeps over the unary + T x L^3 triplet tables; FastPD / HOCR are "
+           "licence-restricted and FSL-bound: not runnable here") if optimiser == "mcmc" else (
+           "driven as --dopt=HOCR drives it (BASELINE config 2): per iteration the unary table and 2 x L fusion moves of 8 T strain costs, the "
+           "label loop of Fusion::optimize with a stand-in for its licence-restricted binary solve (msm_fusion_icm_step)")
     return {"wall_s": wall, "path_s": sum(v for k, v in clock.items() if k != "optimiser"), "phases_s": {k: round(v, 4) for k, v in sorted(clock.items())},
             "workload": "run_multiresolutions, 3 DISCRETE levels (data ico4/5/6, control ico2/3/4), 3 iterations each, sulc-like D=1, ico6 spheres",
-            "optimiser": "the library's Monte Carlo optimiser (M/mcmc_opt.h) at 50 sweeps over the unary + T x L^3 triplet tables; FastPD / HOCR are "
-                         "licence-restricted and FSL-bound: not runnable here"}
+            "optimiser": how}
 
 
 def bench_registration_msmall(ctx):
@@ -419,6 +423,7 @@ def main():
                 out["triclique_move"] = {"d1": bench_triclique_move(ctx, 1, 200, 0 if args.no_cpu_baseline else threads),
                                          "d32": bench_triclique_move(ctx, 32, 200, 0 if args.no_cpu_baseline else threads)}
                 out["registration"] = bench_registration(ctx)
+                out["registration_fusion"] = bench_registration(ctx, "fusion")
                 out["registration_msmall"] = bench_registration_msmall(ctx)
                 out["gmsm"] = bench_gmsm(ctx, args.subjects, comm)
         if world == 1 and not args.no_cpu_baseline:

@@ -264,6 +264,26 @@ __global__ __launch_bounds__(128) void k_triplet_octets(CliqueArgs a, const int 
     out[i] = triplet_cost<kAnat>(a, t, la, lb, lc, nullptr);
 }
 
+// The same with the labeling in the kernel arguments (a byte per control point, as the fused move of the triclique classes has it) and
+// the costs written where the optimiser reads them (mapped pinned memory, contiguous stores): the strain-only label step of a
+// --regoption=3 registration is one launch and one synchronisation, no copy command.  A status raised by an earlier kernel of the
+// context goes to the mapped flag the host looks at.
+template <bool kAnat>
+__global__ __launch_bounds__(128) void k_triplet_octets_packed(CliqueArgs a, MoveLabels lab, int label, double *__restrict__ out, int *host_flag) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0 && host_flag) {
+        const int raised = *a.status;
+        if (raised) __hip_atomic_store(host_flag, raised, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (i >= 8 * a.T) return;
+    const int t = i >> 3, k = i & 7;
+    auto cur = [&](int node) { return (int)((lab.w[node >> 2] >> ((node & 3) * 8)) & 255u); };
+    const int la = (k & 4) ? label : cur(a.triplets[3 * t]);
+    const int lb = (k & 2) ? label : cur(a.triplets[3 * t + 1]);
+    const int lc = (k & 1) ? label : cur(a.triplets[3 * t + 2]);
+    out[i] = triplet_cost<kAnat>(a, t, la, lb, lc, nullptr);
+}
+
 __global__ __launch_bounds__(256) void k_pairwise_batch(CliqueArgs a, const int *__restrict__ qp, const int *__restrict__ qa,
                                                          const int *__restrict__ qb, int n, double *__restrict__ out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -334,6 +354,14 @@ int launch_triplet_octets(msm_ctx *ctx, const CliqueArgs &a, const int *labeling
         if (a.rmode == 4 || a.rmode == 5) hipLaunchKernelGGL(k_triplet_octets<true>, dim3((8 * a.T + 127) / 128), dim3(128), 0, ctx->stream, a, labeling, label, out);
         else hipLaunchKernelGGL(k_triplet_octets<false>, dim3((8 * a.T + 127) / 128), dim3(128), 0, ctx->stream, a, labeling, label, out);
     }
+    MSM_HIP(hipGetLastError());
+    return MSM_OK;
+}
+int launch_triplet_octets_packed(msm_ctx *ctx, const CliqueArgs &a, const MoveLabels &lab, int label, double *out, int *host_flag) {
+    if (a.T <= 0) return MSM_OK;
+    if (is_ho(a)) return fail(MSM_ERR_INVALID, "launch_triplet_octets_packed: the triclique classes have their own move kernel");
+    if (a.rmode == 4 || a.rmode == 5) hipLaunchKernelGGL(k_triplet_octets_packed<true>, dim3((8 * a.T + 127) / 128), dim3(128), 0, ctx->stream, a, lab, label, out, host_flag);
+    else hipLaunchKernelGGL(k_triplet_octets_packed<false>, dim3((8 * a.T + 127) / 128), dim3(128), 0, ctx->stream, a, lab, label, out, host_flag);
     MSM_HIP(hipGetLastError());
     return MSM_OK;
 }

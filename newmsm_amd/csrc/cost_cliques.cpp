@@ -391,6 +391,33 @@ int msm_cost_triplet_octets(msm_cost *c, const int32_t *labeling, int32_t label,
     void *pin = nullptr;
     st = ctx_io_pinned(ctx, in_pad + out_bytes, &pin);
     if (st) return st;
+    static const bool octets_by_copy = [] { const char *e = std::getenv("MSMHIP_OCTETS"); return e && std::strcmp(e, "copy") == 0; }();
+    if (!cost_is_ho(c) && a.N <= 4 * kMoveLabelWords && a.L <= 256 && !octets_by_copy && ctx_flag(ctx) == MSM_OK) {
+        // The strain-only label step (--regoption=3 without --triclique: BASELINE config 2) like the triclique move: the labeling rides in
+        // the kernel arguments, the costs land in mapped pinned memory -- the caller's array when it came from msm_host_alloc --, a raised
+        // status in the mapped flag: one launch + one synchronisation instead of two copy commands around the kernel and a status read-back
+        // (57 -> 25 us per call at ico4; MSMHIP_OCTETS=copy: the old way)
+        double *out_dev = static_cast<double *>(ctx_mapped(ctx, E, out_bytes));
+        const bool direct = out_dev != nullptr;
+        if (!direct && ctx->io_dev) out_dev = reinterpret_cast<double *>(static_cast<char *>(ctx->io_dev) + in_pad);
+        if (out_dev) {
+            MoveLabels lab;
+            std::memset(lab.w, 0, sizeof(uint32_t) * (size_t)((a.N + 3) / 4));
+            for (int i = 0; i < a.N; ++i) lab.w[i >> 2] |= (uint32_t)labeling[i] << ((i & 3) * 8);
+            st = launch_triplet_octets_packed(ctx, a, lab, label, out_dev, ctx->d_flag_map);
+            if (st) return st;
+            c->counters[2] += (int64_t)8 * a.T;
+            MSM_HIP(hipStreamSynchronize(ctx->stream));
+            volatile int *flags = ctx->h_flag;
+            st = MSM_OK;
+            if (flags[0] != 0) {
+                flags[0] = 0;
+                st = check_status(ctx, "computeTripletCost");
+            }
+            if (!direct) std::memcpy(E, static_cast<char *>(pin) + in_pad, out_bytes);
+            return st;
+        }
+    }
     std::memcpy(pin, labeling, in_bytes);
     MSM_HIP(c->d_labeling.ensure(a.N));
     MSM_HIP(hipMemcpyAsync(c->d_labeling.p, pin, in_bytes, hipMemcpyHostToDevice, ctx->stream));

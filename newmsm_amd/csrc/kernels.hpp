@@ -200,6 +200,9 @@ int launch_move_tail(msm_ctx *ctx, const CliqueArgs &a, const MoveArgs &m, const
 
 int launch_triplet_batch(msm_ctx *ctx, const CliqueArgs &a, const int *qt, const int *qa, const int *qb, const int *qc, int n, double *out);
 int launch_triplet_octets(msm_ctx *ctx, const CliqueArgs &a, const int *labeling, int label, double *out);
+struct MoveLabels;
+// the strain-only classes: labeling in the kernel arguments, costs to `out` (device or mapped host memory), raised statuses to host_flag
+int launch_triplet_octets_packed(msm_ctx *ctx, const CliqueArgs &a, const MoveLabels &lab, int label, double *out, int *host_flag);
 int launch_pairwise_batch(msm_ctx *ctx, const CliqueArgs &a, const int *qp, const int *qa, const int *qb, int n, double *out);
 int launch_pairwise_table(msm_ctx *ctx, const CliqueArgs &a, double *out);
 int launch_triplet_table(msm_ctx *ctx, const CliqueArgs &a, int t0, int t1, double *out);

@@ -122,9 +122,8 @@ class _ProductCost:
         return self.cf.computeTripletCosts(pinned=True)  # consumed by the optimiser before the next table is computed
 
     def triplet_octets(self, labeling, label):
-        if getattr(self, "_octets", None) is None or self._octets.shape[0] != self.cf.T:
-            self._octets = self.cf.ctx.host_array((self.cf.T, 8))  # the optimiser's per-step buffer: mapped pinned memory the kernel writes
-        return self.cf.tripletOctets(labeling, label, self._octets)
+        # the optimiser's per-step buffer: mapped pinned memory the kernel writes (one grow-only buffer per context, consumed before the next step)
+        return self.cf.tripletOctets(labeling, label, self.cf.ctx.scratch_host_array("octets", (self.cf.T, 8)))
 
     def total(self, labeling):
         return self.cf.evaluateTotalCostSum(labeling)[0]
