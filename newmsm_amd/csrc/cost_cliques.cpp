@@ -391,7 +391,8 @@ int msm_cost_triplet_octets(msm_cost *c, const int32_t *labeling, int32_t label,
     void *pin = nullptr;
     st = ctx_io_pinned(ctx, in_pad + out_bytes, &pin);
     if (st) return st;
-    static const bool octets_by_copy = [] { const char *e = std::getenv("MSMHIP_OCTETS"); return e && std::strcmp(e, "copy") == 0; }();
+    const char *octets_env = std::getenv("MSMHIP_OCTETS");  // read per call: the tests run both ways in one process
+    const bool octets_by_copy = octets_env && std::strcmp(octets_env, "copy") == 0;
     if (!cost_is_ho(c) && a.N <= 4 * kMoveLabelWords && a.L <= 256 && !octets_by_copy && ctx_flag(ctx) == MSM_OK) {
         // The strain-only label step (--regoption=3 without --triclique: BASELINE config 2) like the triclique move: the labeling rides in
         // the kernel arguments, the costs land in mapped pinned memory -- the caller's array when it came from msm_host_alloc --, a raised

@@ -441,54 +441,53 @@ __device__ __forceinline__ DevTree forest_tree_dev(const ForestDev &f, int b) {
     t.ray_r2lo = t.ray_r2hi = 0.0;
     return t;
 }
-// every query point in every tree (blockIdx.y)
+// every query point in every tree (blockIdx.y), eight lanes per query (search_device.hpp: group_search)
+struct ForestQueryPayload {
+    int id0, id1, id2;
+    double wa, wb, wc;
+    __device__ __forceinline__ void compute(const TriRec &r, const V3 &, const V3 &mp) {
+        id0 = r.id[0], id1 = r.id[1], id2 = r.id[2];
+        area_weights(rec_v0(r), rec_v1(r), rec_v2(r), mp, wa, wb, wc);  // calc_barycentric_weights projects the query first (R/triangle.cpp:130)
+    }
+};
+template <int G>
 __global__ __launch_bounds__(256) void k_query_forest(ForestDev f, const double *__restrict__ q, int N, int *__restrict__ vid, double *__restrict__ w, size_t comp, int *status) {
-    const int b = blockIdx.y;
+    const int b = blockIdx.y, lane = threadIdx.x & 63;
     const DevTree T = forest_tree_dev(f, b);
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
-        const V3 p = mk(q[i], q[N + i], q[2 * (size_t)N + i]);
+    constexpr int per_block = 256 / G;
+    for (int base = blockIdx.x * per_block; base < N; base += gridDim.x * per_block) {
+        const int i = base + threadIdx.x / G;
+        const bool valid = i < N;
+        const V3 p = valid ? mk(q[i], q[N + i], q[2 * (size_t)N + i]) : mk(0.0, 0.0, 0.0);
+        ForestQueryPayload out;
+        bool owner;
+        const int t = group_search<G>(T, valid, p, lane, out, owner);
+        if (!owner) continue;
         const size_t at = (size_t)b * N + i;
-        const int t = find_closest_triangle(T, p);
         if (t < 0) {
             raise_status(status, t);
             vid[at] = vid[comp + at] = vid[2 * comp + at] = -1;
             w[at] = w[comp + at] = w[2 * comp + at] = 0.0;
             continue;
         }
-        const TriRec &r = T.rec[t];
-        vid[at] = r.id[0], vid[comp + at] = r.id[1], vid[2 * comp + at] = r.id[2];
-        const V3 v0 = rec_v0(r), v1 = rec_v1(r), v2 = rec_v2(r);
-        const V3 pp = project_point(p, v0, v1, v2);  // calc_barycentric_weights projects the query first (R/triangle.cpp:130)
-        double wa, wb, wc;
-        area_weights(v0, v1, v2, pp, wa, wb, wc);
-        w[at] = wa, w[comp + at] = wb, w[2 * comp + at] = wc;
+        vid[at] = out.id0, vid[comp + at] = out.id1, vid[2 * comp + at] = out.id2;
+        w[at] = out.wa, w[comp + at] = out.wb, w[2 * comp + at] = out.wc;
     }
 }
 int launch_query_forest(msm_ctx *ctx, const ForestDev &f, int B, const double *d_q, int N, int *d_vid, double *d_w, size_t comp) {
     if (N <= 0 || B <= 0) return MSM_OK;
-    hipLaunchKernelGGL(k_query_forest, dim3((unsigned)std::min((N + 255) / 256, 1024), (unsigned)B), dim3(256), 0, ctx->stream, f, d_q, N, d_vid, d_w, comp, ctx->d_status);
+    if (query_lanes((long long)N * B) == 4)
+        hipLaunchKernelGGL(k_query_forest<4>, dim3((unsigned)std::min((N + 63) / 64, 8192), (unsigned)B), dim3(256), 0, ctx->stream, f, d_q, N, d_vid, d_w, comp, ctx->d_status);
+    else
+        hipLaunchKernelGGL(k_query_forest<8>, dim3((unsigned)std::min((N + 31) / 32, 8192), (unsigned)B), dim3(256), 0, ctx->stream, f, d_q, N, d_vid, d_w, comp, ctx->d_status);
     MSM_HIP(hipGetLastError());
     return MSM_OK;
 }
 
-// blockIdx.y = subject a; a thread per (v, b > a), v-major as in the list
-__global__ __launch_bounds__(256) void k_group_pairs(ForestDev f, const double *__restrict__ cp, int S, int N, int *__restrict__ pairs, int *status) {
-    const int a = blockIdx.y, nb = S - 1 - a;
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long long)N * nb) return;
-    const int v = (int)(i / nb), b = a + 1 + (int)(i - (long long)v * nb);
-    // pairs before subject a: N * sum_{a' < a} (S - 1 - a')
-    const long long base = (long long)N * ((long long)a * (S - 1) - (long long)a * (a - 1) / 2);
-    const long long p = base + i;
-    const size_t comp = (size_t)S * N;
-    const V3 q = mk(cp[(size_t)a * N + v], cp[comp + (size_t)a * N + v], cp[2 * comp + (size_t)a * N + v]);
-    const DevTree T = forest_tree_dev(f, b);
-    const int t = find_closest_triangle(T, q);
-    int best = t;
-    if (t < 0) {
-        raise_status(status, t);
-    } else {  // Octree::get_closest_vertex_ID, R/octree.cpp:216-233
-        const TriRec &r = T.rec[t];
+// blockIdx.y = subject a; eight lanes per (v, b > a), v-major as in the list
+struct PairVertexPayload {  // Octree::get_closest_vertex_ID, R/octree.cpp:216-233
+    int best;
+    __device__ __forceinline__ void compute(const TriRec &r, const V3 &q, const V3 &) {
         double dist = DBL_MAX;
         const V3 vv[3] = {rec_v0(r), rec_v1(r), rec_v2(r)};
         const int ids[3] = {r.id[0], r.id[1], r.id[2]};
@@ -502,13 +501,36 @@ __global__ __launch_bounds__(256) void k_group_pairs(ForestDev f, const double *
             }
         }
     }
+};
+template <int G>
+__global__ __launch_bounds__(256) void k_group_pairs(ForestDev f, const double *__restrict__ cp, int S, int N, int *__restrict__ pairs, int *status) {
+    const int a = blockIdx.y, nb = S - 1 - a, lane = threadIdx.x & 63;
+    const long long i = (long long)blockIdx.x * (256 / G) + threadIdx.x / G;
+    const bool valid = i < (long long)N * nb;
+    if (!__syncthreads_or(valid)) return;
+    const int v = valid ? (int)(i / nb) : 0, b = valid ? a + 1 + (int)(i - (long long)v * nb) : a;
+    // pairs before subject a: N * sum_{a' < a} (S - 1 - a')
+    const long long base = (long long)N * ((long long)a * (S - 1) - (long long)a * (a - 1) / 2);
+    const long long p = base + i;
+    const size_t comp = (size_t)S * N;
+    const V3 q = mk(cp[(size_t)a * N + v], cp[comp + (size_t)a * N + v], cp[2 * comp + (size_t)a * N + v]);
+    const DevTree T = forest_tree_dev(f, b);  // differs between the groups of a wavefront: fine, the group exchanges carry no tree state
+    PairVertexPayload out;
+    out.best = 0;
+    bool owner;
+    const int t = group_search<G>(T, valid, q, lane, out, owner);
+    if (!owner) return;
+    if (t < 0) raise_status(status, t);
     pairs[2 * p] = a * N + v;
-    pairs[2 * p + 1] = b * N + best;
+    pairs[2 * p + 1] = b * N + (t < 0 ? t : out.best);
 }
 int launch_group_pairs(msm_ctx *ctx, const ForestDev &f, const double *d_cp, int S, int N, int *d_pairs) {
     if (S < 2) return MSM_OK;
     const long long most = (long long)N * (S - 1);
-    hipLaunchKernelGGL(k_group_pairs, dim3((unsigned)((most + 255) / 256), (unsigned)(S - 1)), dim3(256), 0, ctx->stream, f, d_cp, S, N, d_pairs, ctx->d_status);
+    if (query_lanes(most * (S - 1) / 2) == 4)
+        hipLaunchKernelGGL(k_group_pairs<4>, dim3((unsigned)((most + 63) / 64), (unsigned)(S - 1)), dim3(256), 0, ctx->stream, f, d_cp, S, N, d_pairs, ctx->d_status);
+    else
+        hipLaunchKernelGGL(k_group_pairs<8>, dim3((unsigned)((most + 31) / 32), (unsigned)(S - 1)), dim3(256), 0, ctx->stream, f, d_cp, S, N, d_pairs, ctx->d_status);
     MSM_HIP(hipGetLastError());
     return MSM_OK;
 }

@@ -236,55 +236,56 @@ int launch_build_raytri(msm_ctx *ctx, const TriRec *d_rec, const float4 *d_edge,
 }
 
 // ------------------------------------------------------------------------------------------------
-// msm_query_triangles: one lane per query point (Resampler::get_barycentric_weights, R/resampler.cpp:142-167)
+// msm_query_triangles (Resampler::get_barycentric_weights, R/resampler.cpp:142-167): G lanes per query point
+// (search_device.hpp: group_search).  The lane whose exact test finds the containing triangle has the record and
+// the projected point in registers and computes the weights right there (calc_barycentric_weights' projection IS
+// the inside test's: the record's plane is plane_of(v0, v1, v2) in the same arithmetic).
 // ------------------------------------------------------------------------------------------------
+struct QueryPayload {
+    int mode;
+    int id0, id1, id2;
+    double wa, wb, wc;
+    __device__ __forceinline__ void compute(const TriRec &r, const V3 &p, const V3 &mp) {
+        id0 = r.id[0], id1 = r.id[1], id2 = r.id[2];
+        // calc_barycentric_weights projects the query first (R/triangle.cpp:130); barycentric_interpolation does not
+        area_weights(rec_v0(r), rec_v1(r), rec_v2(r), mode == MSM_WEIGHTS_PROJECTED ? mp : p, wa, wb, wc);
+    }
+};
+
+template <int G>
 __global__ __launch_bounds__(256) void k_query(DevTree T, const double *__restrict__ q, int N, int *__restrict__ tri_id,
                                                 int *__restrict__ vid, double *__restrict__ w, int mode, int *status) {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
-        const V3 p = mk(q[i], q[N + i], q[2 * N + i]);
-        const int t = find_closest_triangle(T, p);
+    constexpr int per_block = 256 / G;
+    const int lane = threadIdx.x & 63;
+    for (int base = blockIdx.x * per_block; base < N; base += gridDim.x * per_block) {  // block-uniform: every lane takes part in the group's exchanges
+        const int i = base + threadIdx.x / G;
+        const bool valid = i < N;
+        const V3 p = valid ? mk(q[i], q[N + i], q[2 * (size_t)N + i]) : mk(0.0, 0.0, 0.0);
+        QueryPayload out;
+        out.mode = mode;
+        bool owner;
+        const int t = group_search<G>(T, valid, p, lane, out, owner);
+        if (!owner) continue;
+        if (tri_id) tri_id[i] = t;
         if (t < 0) {
             raise_status(status, t);
-            if (tri_id) tri_id[i] = t;
-            if (vid) vid[i] = vid[N + i] = vid[2 * N + i] = -1;
-            if (w) w[i] = w[N + i] = w[2 * N + i] = 0.0;
+            if (vid) vid[i] = vid[N + i] = vid[2 * (size_t)N + i] = -1;
+            if (w) w[i] = w[N + i] = w[2 * (size_t)N + i] = 0.0;
             continue;
         }
-        const TriRec &r = T.rec[t];
-        if (tri_id) tri_id[i] = t;
-        if (vid) {
-            vid[i] = r.id[0];
-            vid[N + i] = r.id[1];
-            vid[2 * N + i] = r.id[2];
-        }
-        if (w) {
-            // calc_barycentric_weights projects the query first (R/triangle.cpp:130); barycentric_interpolation does not
-            const V3 v0 = rec_v0(r), v1 = rec_v1(r), v2 = rec_v2(r);
-            const V3 pp = (mode == MSM_WEIGHTS_PROJECTED) ? project_point(p, v0, v1, v2) : p;
-            double wa, wb, wc;
-            area_weights(v0, v1, v2, pp, wa, wb, wc);
-            w[i] = wa;
-            w[N + i] = wb;
-            w[2 * N + i] = wc;
-        }
+        if (vid) vid[i] = out.id0, vid[N + i] = out.id1, vid[2 * (size_t)N + i] = out.id2;
+        if (w) w[i] = out.wa, w[N + i] = out.wb, w[2 * (size_t)N + i] = out.wc;
     }
 }
 
 // Octree::get_closest_vertex_ID, R/octree.cpp:216-233
-__global__ __launch_bounds__(256) void k_closest_vertex(DevTree T, const double *__restrict__ q, int N, int *__restrict__ out, int *status) {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
-        const V3 p = mk(q[i], q[N + i], q[2 * N + i]);
-        const int t = find_closest_triangle(T, p);
-        if (t < 0) {
-            raise_status(status, t);
-            out[i] = t;
-            continue;
-        }
-        const TriRec &r = T.rec[t];
+struct ClosestVertexPayload {
+    int best;
+    __device__ __forceinline__ void compute(const TriRec &r, const V3 &p, const V3 &) {
         double dist = DBL_MAX;
-        int best = 0;
         const V3 vv[3] = {rec_v0(r), rec_v1(r), rec_v2(r)};
         const int ids[3] = {r.id[0], r.id[1], r.id[2]};
+        best = 0;
 #pragma unroll
         for (int v = 0; v < 3; ++v) {
             const double d = norm(sub(p, vv[v]));
@@ -293,7 +294,24 @@ __global__ __launch_bounds__(256) void k_closest_vertex(DevTree T, const double 
                 dist = d;
             }
         }
-        out[i] = best;
+    }
+};
+
+template <int G>
+__global__ __launch_bounds__(256) void k_closest_vertex(DevTree T, const double *__restrict__ q, int N, int *__restrict__ out, int *status) {
+    constexpr int per_block = 256 / G;
+    const int lane = threadIdx.x & 63;
+    for (int base = blockIdx.x * per_block; base < N; base += gridDim.x * per_block) {
+        const int i = base + threadIdx.x / G;
+        const bool valid = i < N;
+        const V3 p = valid ? mk(q[i], q[N + i], q[2 * (size_t)N + i]) : mk(0.0, 0.0, 0.0);
+        ClosestVertexPayload cv;
+        cv.best = 0;
+        bool owner;
+        const int t = group_search<G>(T, valid, p, lane, cv, owner);
+        if (!owner) continue;
+        if (t < 0) raise_status(status, t);
+        out[i] = t < 0 ? t : cv.best;
     }
 }
 
@@ -600,16 +618,35 @@ static inline int grid_for(int n, int block, int cap) {
     return g < 1 ? 1 : (g > cap ? cap : g);
 }
 
+// lanes per query of the search kernels (search_device.hpp: group_search).  Eight while all wavefronts of the launch are resident at once
+// (4 per SIMD at the kernels' 124 registers: 32 768 queries) -- the launch is then one dependent chain, which eight lanes keep shortest
+// (2 562 queries: 7.4 us against 9.2 with four) --, four beyond that, where instruction issue counts as well (40 962 queries on an ico6
+// tree: 13.3 us against 17.2).  MSMHIP_QUERY_LANES=4|8 forces one.
+int query_lanes(long long N) {
+    static const int forced = [] {
+        const char *e = std::getenv("MSMHIP_QUERY_LANES");
+        return e ? std::atoi(e) : 0;
+    }();
+    if (forced == 4 || forced == 8) return forced;
+    return N <= 32768 ? 8 : 4;
+}
+
 int launch_query(msm_ctx *ctx, const DevTree &T, const double *d_q, int N, int *d_tri, int *d_vid, double *d_w, int mode) {
     if (N <= 0) return MSM_OK;
-    hipLaunchKernelGGL(k_query, dim3(grid_for(N, 256, 4096)), dim3(256), 0, ctx->stream, T, d_q, N, d_tri, d_vid, d_w, mode, ctx->d_status);
+    if (query_lanes(N) == 4)
+        hipLaunchKernelGGL(k_query<4>, dim3(grid_for(N, 64, 32768)), dim3(256), 0, ctx->stream, T, d_q, N, d_tri, d_vid, d_w, mode, ctx->d_status);
+    else
+        hipLaunchKernelGGL(k_query<8>, dim3(grid_for(N, 32, 32768)), dim3(256), 0, ctx->stream, T, d_q, N, d_tri, d_vid, d_w, mode, ctx->d_status);
     MSM_HIP(hipGetLastError());
     return MSM_OK;
 }
 
 int launch_closest_vertex(msm_ctx *ctx, const DevTree &T, const double *d_q, int N, int *d_out) {
     if (N <= 0) return MSM_OK;
-    hipLaunchKernelGGL(k_closest_vertex, dim3(grid_for(N, 256, 4096)), dim3(256), 0, ctx->stream, T, d_q, N, d_out, ctx->d_status);
+    if (query_lanes(N) == 4)
+        hipLaunchKernelGGL(k_closest_vertex<4>, dim3(grid_for(N, 64, 32768)), dim3(256), 0, ctx->stream, T, d_q, N, d_out, ctx->d_status);
+    else
+        hipLaunchKernelGGL(k_closest_vertex<8>, dim3(grid_for(N, 32, 32768)), dim3(256), 0, ctx->stream, T, d_q, N, d_out, ctx->d_status);
     MSM_HIP(hipGetLastError());
     return MSM_OK;
 }

@@ -387,4 +387,210 @@ __device__ __forceinline__ int group8_find(const DevTree &T, bool valid, const V
     return kGroupUndecided;
 }
 
+// ------------------------------------------------------------------------------------------------
+// The COMPLETE search of one point by a group of G = 4 or 8 neighbouring lanes (lane & (G - 1)); all 64 lanes of the
+// wavefront must call this together, groups with valid == false ride along.  Unlike group8_find it needs no sub-cell
+// masks (a tree built a moment ago has none) and ends with the reference's answer in every case, without a serial path:
+//   descent (arithmetic, as find_closest_triangle) -> the leaf's cone filter, G entries per load round, two rounds in
+//   flight -> the entries that pass are dealt out to the lanes in entry order (about 2.4 per query: one round of exact
+//   FP64 tests) -> the containing triangles are taken in entry order as R/octree.cpp:166-178 does: the first one, then
+//   every strictly closer one (dist_to_point is only evaluated when a second triangle shows up; every lane of the group
+//   computes it -- same instructions, same value, no exchange) -> none: the same over the sibling leaves with one running
+//   minimum (:180-193), then the nearest vertex of their triangles (:195-208: entries split over the lanes, first minimum
+//   in the reference's visiting order).
+// With a lane per query the 34 cone tests and the exact tests of 64 lanes run at 64 different loop positions (75 us for
+// the 40 962 queries of an ico6 mesh); what counts for such a launch is the length of one wavefront's dependent chain.
+// `out.compute(rec, p, projected p)` is called by the lane that finds a containing triangle (the record and the projection
+// are in its registers then); on return `owner` is true in exactly one lane of every valid group -- a lane whose `out`
+// belongs to the returned triangle (for an error code: the group's first lane).  The result is the same in all lanes
+// of a group: a triangle id, MSM_ERR_OUTSIDE or MSM_ERR_NOTFOUND.
+// ------------------------------------------------------------------------------------------------
+template <int G>
+__device__ __forceinline__ unsigned or_group(unsigned v) {
+    static_assert(G == 4 || G == 8, "groups of 4 or 8 lanes");
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true);  // quad_perm [1,0,3,2]
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, true);  // quad_perm [2,3,0,1]
+    if (G == 8) v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, true);  // row_half_mirror: lane i <-> 7 - i of each eight
+    return v;
+}
+template <int G>
+__device__ __forceinline__ unsigned long long or_group64(unsigned long long v) {
+    return ((unsigned long long)or_group<G>((unsigned)(v >> 32)) << 32) | or_group<G>((unsigned)v);
+}
+
+// out of line: asin inlined three times costs the search kernels 34 registers for a path that almost never runs
+__device__ __noinline__ double arc_of_chord_slow(double c) { return chord_to_arc(c); }
+
+template <int G, class Payload>
+__device__ __forceinline__ int group_search(const DevTree &T, bool valid, const V3 &p, int lane, Payload &out, bool &owner) {
+    const int sl = lane & (G - 1);
+    int n = 0, res = MSM_ERR_NOTFOUND;
+    int4 nd = make_int4(-1, 0, -1, 0);  // an empty leaf
+    float fx = 0.f, fy = 0.f, fz = 0.f;
+    bool scan = false;
+    owner = false;
+    if (valid) {
+        if (outside_root(p)) {
+            res = MSM_ERR_OUTSIDE;
+        } else {  // the descent of find_closest_triangle
+            const int Gd = 1 << T.grid_depth;
+            const double h = 2 * kBounds / Gd;
+            const int ix = grid_axis(p.x, Gd, h), iy = grid_axis(p.y, Gd, h), iz = grid_axis(p.z, Gd, h);
+            n = T.grid[((size_t)ix * Gd + iy) * Gd + iz];
+            nd = T.node[n];
+            if (nd.x >= 0) {
+                double lx = -kBounds + ix * h, hx = -kBounds + (ix + 1) * h;
+                double ly = -kBounds + iy * h, hy = -kBounds + (iy + 1) * h;
+                double lz = -kBounds + iz * h, hz = -kBounds + (iz + 1) * h;
+                while (nd.x >= 0) {
+                    const double mx = (lx + hx) / 2.0, my = (ly + hy) / 2.0, mz = (lz + hz) / 2.0;
+                    const int cx = !(p.x < mx), cy = !(p.y < my), cz = !(p.z < mz);
+                    if (cx) lx = mx; else hx = mx;
+                    if (cy) ly = my; else hy = my;
+                    if (cz) lz = mz; else hz = mz;
+                    n = nd.x + 4 * cx + 2 * cy + cz;
+                    nd = T.node[n];
+                }
+            }
+            const float qx = (float)p.x, qy = (float)p.y, qz = (float)p.z;
+            const float inv = rsqrtf(qx * qx + qy * qy + qz * qz);
+            fx = qx * inv, fy = qy * inv, fz = qz * inv;
+            scan = true;
+        }
+    }
+    int win = -1, myt = -2, sib0 = 0;
+    bool have_d = false;
+    double bestd = DBL_MAX;
+    // pass 0: the leaf of p; passes 1..8 (only for groups that found nothing): the children of its parent, R/octree.cpp:180-193
+    for (int pass = 0; pass <= 8; ++pass) {
+        if (pass == 1) {
+            const int par = scan && win < 0 ? T.parent[n] : -1;  // no parent: the reference dereferences a null pointer here; MSM_ERR_NOTFOUND
+            scan = par >= 0;
+            if (!__any(scan)) break;
+            sib0 = scan ? T.node[par].x : 0;
+        }
+        if (pass >= 1) nd = scan ? T.node[sib0 + pass - 1] : make_int4(-1, 0, -1, 0);
+        const int cnt = scan && nd.x < 0 ? -nd.x - 1 : 0;
+        // 64 entries at a time (a leaf has more only when the split heuristic refused to split it: degenerate meshes)
+        for (int eb = 0; __any(eb < cnt); eb += 64) {
+            // --- cone filter: entry eb + G * round + sl; lists are padded to multiples of eight with cones nothing passes
+            const int left = min(cnt - eb, 64), rounds = left > 0 ? (left + G - 1) / G : 0;
+            const float4 *cb = T.cone + nd.y + eb;
+            unsigned long long cand = 0ull;
+            for (int r = 0; __any(r < rounds); r += 2) {
+                float4 c0 = make_float4(0.f, 0.f, 0.f, 2.f), c1 = c0;
+                if (r < rounds) c0 = cb[G * r + sl];
+                if (r + 1 < rounds) c1 = cb[G * (r + 1) + sl];
+                if (cone_pass(c0, fx, fy, fz)) cand |= 1ull << (G * r + sl);
+                if (cone_pass(c1, fx, fy, fz)) cand |= 1ull << (G * (r + 1) + sl);
+            }
+            cand = or_group64<G>(cand);
+            // --- exact tests: the k-th candidate in entry order goes to lane k % G in round k / G
+            const int ncand = __popcll(cand);
+            unsigned long long hits = 0ull;
+            unsigned onehit = 0u;
+            for (int r = 0; __any(r * G < ncand); ++r) {
+                unsigned long long hb = 0ull;
+                unsigned ht = 0u;
+                const int want = r * G + sl;
+                if (want < ncand) {
+                    unsigned long long c = cand;
+                    for (int k = 0; k < want; ++k) c &= c - 1ull;
+                    const int e = __ffsll((long long)c) - 1;
+                    const int t = T.leaf_tri[nd.y + eb + e];
+                    const TriRec &rec = T.rec[t];
+                    V3 mp;
+                    if (inside_test(rec, p, mp)) {
+                        hb = 1ull << e;
+                        ht = (unsigned)t + 1u;
+                        myt = t;
+                        out.compute(rec, p, mp);
+                    }
+                }
+                hits |= or_group64<G>(hb);
+                onehit |= or_group<G>(ht);
+            }
+            // --- the containing triangles in entry order (every lane of the group does the same)
+            if (win < 0 && __popcll(hits) == 1) {
+                win = (int)onehit - 1;
+                hits = 0ull;
+            }
+            while (__any(hits != 0ull)) {
+                if (hits) {
+                    const int t = T.leaf_tri[nd.y + eb + __ffsll((long long)hits) - 1];
+                    hits &= hits - 1ull;
+                    if (win < 0) {
+                        win = t;
+                    } else {
+                        double d = 0.0;
+                        for (int k = have_d ? 1 : 0; k < 2; ++k) {
+                            d = candidate_distance(T, k == 0 ? win : t, p);
+                            if (k == 0) bestd = d;
+                        }
+                        have_d = true;
+                        if (d > -1.0 && d < bestd) {
+                            win = t;
+                            bestd = d;
+                        }
+                    }
+                }
+            }
+        }
+        if (pass == 0 && !__any(scan && win < 0)) break;
+    }
+    // --- the closest vertex among the siblings' triangles by geodesic distance (R/octree.cpp:195-208); scan: the group has a parent
+    if (__any(scan && win < 0)) {
+        const bool need = scan && win < 0;
+        double vd = DBL_MAX;
+        long long vord = 0x7fffffffffffffffll;
+        int vt = -1;
+        for (int c = 0; c < 8; ++c) {
+            const int4 sib = need ? T.node[sib0 + c] : make_int4(0, 0, 0, 0);
+            const int cnt = sib.x < 0 ? -sib.x - 1 : 0;
+            for (int e0 = 0; __any(e0 < cnt); e0 += G) {
+                const int e = e0 + sl;
+                if (e < cnt) {
+                    const int t = T.leaf_tri[sib.y + e];
+                    const TriRec &r = T.rec[t];
+                    for (int v = 0; v < 3; ++v) {
+                        const double *vv = v == 0 ? r.v0 : (v == 1 ? r.v1 : r.v2);
+                        const double d = arc_of_chord_slow(norm(sub(mk(vv[0], vv[1], vv[2]), p)));
+                        if (d < vd) {  // within a lane the visiting order is ascending: the first minimum stays
+                            vd = d;
+                            vord = ((long long)c << 40) | ((long long)e << 2) | v;
+                            vt = t;
+                        }
+                    }
+                }
+            }
+        }
+        for (int off = 1; off < G; off <<= 1) {  // the smallest distance, ties to the earliest in the reference's order
+            const double od = __shfl_xor(vd, off, 64);
+            const long long oo = __shfl_xor(vord, off, 64);
+            const int ot = __shfl_xor(vt, off, 64);
+            if (od < vd || (od == vd && oo < vord)) vd = od, vord = oo, vt = ot;
+        }
+        if (need) win = vt;
+    }
+    int t = res;
+    if (win >= 0) {
+        t = win;
+        owner = myt == win;
+    }
+    // the winner's lane went on to another entry that also passed, the winner came from the nearest-vertex step, or an error: the first lane
+    const bool orphan = valid && or_group<G>(owner ? 1u : 0u) == 0u;
+    if (__any(orphan)) {
+        if (orphan && sl == 0) {
+            if (t >= 0) {
+                const TriRec &rec = T.rec[t];
+                V3 mp;
+                inside_test(rec, p, mp);
+                out.compute(rec, p, mp);
+            }
+            owner = true;
+        }
+    }
+    return t;
+}
+
 }  // namespace msm

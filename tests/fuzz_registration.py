@@ -24,7 +24,7 @@ for k in range(n):
     D = 1 if kind in ("univariate", "ho_univariate") else int(rng.integers(2, 5) if kind != "ho_multivariate" else rng.choice([2, 5, 13, 20]))
     # the triclique classes are driven as --dopt=HOCR drives them: the label loop of Fusion over fusion moves (stand-in binary solve); the others
     # by either optimiser
-    optimiser = "fusion" if kind.startswith("ho_") or rng.integers(0, 3) == 0 else "mcmc"
+    optimiser = "fusion" if kind.startswith("ho_") or rng.integers(0, 2) == 0 else "mcmc"
     xyz, tri = M.make_mesh_from_icosa(data_order)
     seed = int(rng.integers(1, 10**6))
     ref = synthetic.features(xyz, D, seed)

@@ -240,3 +240,70 @@ def test_triclique_with_many_labels(ctx, kind, D):
             lab = [57 if k >> (2 - j) & 1 else int(labeling[ids[j]]) for j in range(3)]
             w = oc.triplet(int(tt), *lab)
             assert abs(E[tt, k] - w) <= ATOL + RTOL * abs(w)
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# BASELINE config 2's --dopt=HOCR label step at its own size: the strain-only fusion move (k_triplet_octets_packed: the
+# labeling in the kernel arguments -- 2 562 bytes of the 2 816 the argument block holds --, the costs written into mapped
+# pinned memory) over all T x 8 evaluations against the oracle's replay of I/Fusion/Fusion.h:181-196.
+# ------------------------------------------------------------------------------------------------------------------------
+def fusion_labelings(cf, seed):
+    rng = np.random.default_rng(seed)
+    return [(np.zeros(cf.N, dtype=np.int32), int(rng.integers(1, cf.L))), (rng.integers(0, cf.L, cf.N).astype(np.int32), int(rng.integers(0, cf.L)))]
+
+
+def check_octets_all_ways(ctx, cf, oc, monkeypatch, seed):
+    for labeling, label in fusion_labelings(cf, seed):
+        want = oc.triplet_octets(labeling, label, threads=8)
+        folded = want >= 1e6 * oc.params.lambda_
+        got = {"pageable": np.array(cf.tripletOctets(labeling, label)),          # staging block + memcpy
+               "mapped": np.array(cf.tripletOctets(labeling, label, ctx.host_array((cf.T, 8))))}  # the kernel writes the caller's array
+        monkeypatch.setenv("MSMHIP_OCTETS", "copy")  # the round-1 route: labeling and costs by copy commands, k_triplet_octets
+        got["copy"] = np.array(cf.tripletOctets(labeling, label))
+        monkeypatch.delenv("MSMHIP_OCTETS")
+        for how, E in got.items():
+            assert E.shape == (cf.T, 8) and np.isfinite(E).all(), how
+            assert np.allclose(E, want, rtol=RTOL, atol=ATOL), (how, np.abs(E - want).max())
+            assert np.array_equal(E >= 1e6 * oc.params.lambda_, folded), how
+        assert np.array_equal(got["pageable"], got["mapped"]) and np.array_equal(got["pageable"], got["copy"])  # one evaluator, three deliveries
+    return folded
+
+
+def test_strain_only_fusion_move_config2_full_size(ctx, monkeypatch):
+    inp = problem.pairwise_inputs(6, 4, D=1)
+    cf, oc, _ = pair(ctx, inp, "univariate", rmode=3, lambda_=0.1, mu=0.4, kappa=1.6, k_exp=2.0, rexp=2.0)
+    assert (cf.N, cf.T, cf.L) == (2562, 5120, 19)
+    check_octets_all_ways(ctx, cf, oc, monkeypatch, seed=61)
+    # long label moves: folded proposals (the 1e7 * lambda sentinel of computeTripletCost :141-146) must be flagged identically
+    inp = problem.pairwise_inputs(6, 4, D=1, labeldist=2.5)
+    cf, oc, _ = pair(ctx, inp, "univariate", rmode=3, lambda_=0.1, mu=0.4, kappa=1.6, k_exp=2.0, rexp=2.0)
+    folded = check_octets_all_ways(ctx, cf, oc, monkeypatch, seed=62)
+    assert folded.any() and not folded.all()
+
+
+def test_anatomical_strain_fusion_move_full_size(ctx, monkeypatch):
+    """regoption 5 (aMSM) through the same packed label step at ico6 data / ico4 control grid / ico6 anatomical sphere"""
+    import oracle.oracle as O
+
+    inp = problem.pairwise_inputs(6, 4, D=1)
+    an = problem.anatomical_inputs(ctx, inp)
+    cf, oc, keep = pair(ctx, inp, "univariate", rmode=5, lambda_=0.05, mu=0.4, kappa=1.6, k_exp=2.0, rexp=2.0)
+    sphere = M.Mesh(ctx, an["sphere_xyz"], an["sphere_tri"])
+    cf.set_anatomical(sphere, an["atarget_xyz"], an["asource_xyz"], an["sphere_tri"], an["w_ptr"], an["w_cp"], an["w_val"], an["face_ptr"], an["face_idx"])
+    osphere = O.Mesh(an["sphere_xyz"], an["sphere_tri"])
+    oc.set_anatomical(osphere, O.Octree(osphere), an["atarget_xyz"], O.Mesh(an["asource_xyz"], an["sphere_tri"]), an["w_ptr"], an["w_cp"], an["w_val"],
+                      an["face_ptr"], an["face_idx"])
+    check_octets_all_ways(ctx, cf, oc, monkeypatch, seed=63)
+
+
+def test_strain_only_fusion_move_beyond_the_kernel_argument_block(ctx, monkeypatch):
+    """N > 2 816 control points (the labeling no longer fits the kernel arguments) and L > 256 labels (a label no longer fits a byte):
+    both fall back to the labeling in device memory -- same costs"""
+    inp = problem.pairwise_inputs(5, 5, D=1)  # 10 242 control points
+    cf, oc, _ = pair(ctx, inp, "univariate", rmode=3, lambda_=0.1, mu=0.4, kappa=1.6, k_exp=2.0, rexp=2.0)
+    assert cf.N > 2816
+    check_octets_all_ways(ctx, cf, oc, monkeypatch, seed=64)
+    inp = problem.pairwise_inputs(4, 2, D=1, sg_order=6, rescale=False)
+    assert len(inp["labels"]) > 256
+    cf, oc, _ = pair(ctx, inp, "univariate", rmode=3, lambda_=0.1, mu=0.4, kappa=1.6, k_exp=2.0, rexp=2.0)
+    check_octets_all_ways(ctx, cf, oc, monkeypatch, seed=65)

@@ -113,12 +113,13 @@ def test_files_in_files_out(ctx, tmp_path):
     assert meshio.load_metric(d + "out.transformed_and_reprojected.func.gii").shape == (1, len(xyz))
 
 
-@pytest.mark.parametrize("kind,D", [("ho_univariate", 1), ("ho_multivariate", 16)])
+@pytest.mark.parametrize("kind,D", [("ho_univariate", 1), ("ho_multivariate", 16), ("univariate", 1)])
 def test_fusion_driven_level_matches_oracle(ctx, kind, D):
     """The label loop of Fusion::optimize (I/Fusion/Fusion.h:136-229) over the triclique classes -- what every HCP configuration runs: per
     label step ONE fusion move (8 T triplet costs for the evolving labeling), here with a stand-in for the licence-restricted binary solve
     (iterated conditional modes, the same for both runs).  The MI355X path and the oracle take the same decisions in every one of the
-    2 x L x iterations steps and end within the north star's 1e-4 rad."""
+    2 x L x iterations steps and end within the north star's 1e-4 rad.  ("univariate", 1) is BASELINE config 2's shape: the unary table +
+    strain-only fusion moves (k_triplet_octets_packed).)"""
     xyz, tri, ref, src = level_inputs(4, D, seed=27)
     hcp = dict(lambda_=0.01, mu=0.4, kappa=1.6, k_exp=2.0, rexp=2.0)  # --shearmod --bulkmod --k_exponent --regexp of the HCP configurations
     kw = dict(cp_order=2, iters=2, seed=5, kind=kind, rescale_labels=True, cost_params=hcp, optimiser="fusion")
