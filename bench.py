@@ -8,6 +8,8 @@ iteration of a registration pays for it: the per (control point, label) rotation
 new every iteration), the three table kernels, and the 389 KB table delivered to host memory (the optimiser reads it there).
 All inputs are resident in HBM before the timed region starts.  The same JSON line carries, as extra objects (rank 0, N = 1):
   steady            the table kernels alone, enqueued back to back (the round-1 headline definition)
+  resample          Resampler::get_barycentric_weights for the 40 962 vertices of an ico6 sphere: queries/s per kernel and per call, its roofline,
+                    the CPU port's rate beside it
   triclique_move    one label step of Fusion (I/Fusion/Fusion.h:181-196) of the triclique classes: BASELINE config 4 (D = 1) and
                     config 3 (HCP MSMAll, D = 32) at ico6 / ico4 -- per call and per kernel, with their rooflines
   registration      wall-clock of a three-level ico6 pairwise registration driven by the reference's caller loop (Monte Carlo optimiser)
@@ -137,7 +139,63 @@ def bench_triclique_move(ctx, D, calls, threads):
     return out
 
 
-def bench_registration(ctx, optimiser="mcmc"):
+def bench_resample(ctx, calls, cpu):
+    """The resampler half of the path: Resampler::get_barycentric_weights (R/resampler.cpp:142-167 = Octree::get_closest_triangle
+    R/octree.cpp:156-214 + calc_barycentric_weights R/triangle.cpp:124-143), the 40 962 vertices of the regular ico6 sphere located on a
+    warped ico6 sphere whose octree was built for this run -- what every metric_resample / sphere_project_warp / get_source_data of a
+    registration is made of.  SURVEY 8(d): 144 algorithmic bytes per query (query 24 + vertex ids 12 + vertices 72 + weights 24 + ids 12)."""
+    import numpy as np
+
+    import newmsm_amd as M
+    from newmsm_amd import synthetic
+
+    xyz, tri = M.make_mesh_from_icosa(6)
+    warped = synthetic.known_warp(xyz, seed=3, rot_deg=2.0, amp=0.6)
+    mesh = M.Mesh(ctx, warped, tri)
+    mesh.query_triangles(xyz)
+    ctx.time_queries(True)
+    kt, ct = [], []
+    for _ in range(calls):
+        t0 = time.perf_counter()
+        st, t_id, vid, w = mesh.query_triangles(xyz)
+        ct.append(time.perf_counter() - t0)
+        kt.append(ctx.query_kernel_ms() * 1e-3)
+    ctx.time_queries(False)
+    N = len(xyz)
+    kern_s, call_s = float(np.median(kt)), float(np.median(ct))
+    nbytes = 144 * N
+    out = {"workload": "get_barycentric_weights: %d queries (regular ico6 vertices) on a warped ico6 mesh (81 920 triangles, fresh octree)" % N,
+           "queries_per_s_kernel": N / kern_s, "kernel_us": kern_s * 1e6, "queries_per_s_call": N / call_s, "us_per_call": call_s * 1e6, "calls": calls,
+           "call": "msm_query_triangles with host arrays in and out: upload of the queries, kernel, three result arrays back, one synchronisation",
+           "roofline": {"bound": "hbm", "achieved": nbytes / kern_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nbytes / kern_s / 1e9 / HBM_PEAK_GBS,
+                        "kernel": "msm::k_query<4>", "algorithmic_bytes_per_launch": nbytes,
+                        "note": "kernel time = HIP events around the launch on its stream; a launch of this size (2 561 wavefronts) is a dependent chain of "
+                                "six memory accesses per query (query, grid cell, node, cones, triangle id, record), not a stream: see DESIGN.md section 5.1"}}
+    if cpu:
+        from oracle import oracle as O
+
+        om = O.Mesh(warped, tri)
+        tree = O.Octree(om)
+        t0 = time.perf_counter()
+        st, otri, ovid, ow = tree.barycentric_weights(xyz)
+        dt = time.perf_counter() - t0
+        out["cpu_port"] = {"queries_per_s": N / dt, "cores": 1, "sample": "the same %d queries, one thread (the reference's callers pass nthreads = 1, R/resampler.cpp:75,78)" % N,
+                           "triangles_identical": bool(np.array_equal(otri, t_id)), "weights_identical": bool(np.array_equal(ow, w))}
+    mesh.close()
+    return out
+
+
+def registration_check(ctx, levels, D, note, **kw):
+    """The same registration with fewer iterations per level over the MI355X path and over the CPU port (tests/helpers.py:
+    registration_parity -- the checker of tests/test_gpu_registration.py): north_star's bar is 1e-4 rad between the registered spheres."""
+    from tests.helpers import registration_parity
+
+    r = registration_parity(ctx, levels, D, **kw)
+    return {"max_angle_rad_vs_cpu_port": r["max_angle_rad"], "labelings_identical": r["labelings_identical"], "labelings_compared": r["labelings"],
+            "energies_max_rel_diff": r["energies_rel_diff"], "cpu_port_s": r["cpu_port_s"], "run": note, "tolerance_rad": 1e-4}
+
+
+def bench_registration(ctx, optimiser="mcmc", check=True):
     """Wall-clock of a pairwise registration (tools/time_registration.py): three DISCRETE levels as in config/basic_configs (data grids
     ico4/5/6, control grids ico2/3/4, sigma 4/2/1, variance normalisation), 3 iterations per level, input and reference spheres ico6."""
     import newmsm_amd as M
@@ -146,25 +204,28 @@ def bench_registration(ctx, optimiser="mcmc"):
     xyz, tri = M.make_mesh_from_icosa(6)
     ref = synthetic.features(xyz, 1, 7)
     src = synthetic.features(synthetic.known_warp(xyz, seed=9, rot_deg=3.0, amp=2.0), 1, 7)
-    levels = [dict(data_order=4, cp_order=2, sigma_in=4.0, sigma_ref=4.0), dict(data_order=5, cp_order=3, sigma_in=2.0, sigma_ref=2.0),
-              dict(data_order=6, cp_order=4, sigma_in=1.0, sigma_ref=1.0)]
+    kw = dict(mciters=50, mcparam=0.8, seed=1, cost_params=dict(lambda_=0.1), optimiser=optimiser)
     ops = registration.ProductOps(ctx)
     for _ in range(2):  # the first run pays for allocations
         clock = {}
         t0 = time.perf_counter()
-        registration.run_multiresolution(ops, xyz, tri, src, xyz, tri, ref, levels, varnorm=True, timings=clock, iters=3, mciters=50, mcparam=0.8,
-                                         seed=1, cost_params=dict(lambda_=0.1), optimiser=optimiser)
+        registration.run_multiresolution(ops, xyz, tri, src, xyz, tri, ref, registration.basic_levels((3, 3, 3)), varnorm=True, timings=clock, **kw)
         wall = time.perf_counter() - t0
     how = ("the library's Monte Carlo optimiser (M/mcmc_opt.h) at 50 sweeps over the unary + T x L^3 triplet tables; FastPD / HOCR are "
            "licence-restricted and FSL-bound: not runnable here") if optimiser == "mcmc" else (
            "driven as --dopt=HOCR drives it (BASELINE config 2): per iteration the unary table and 2 x L fusion moves of 8 T strain costs, the "
            "label loop of Fusion::optimize with a stand-in for its licence-restricted binary solve (msm_fusion_icm_step)")
-    return {"wall_s": wall, "path_s": sum(v for k, v in clock.items() if k != "optimiser"), "phases_s": {k: round(v, 4) for k, v in sorted(clock.items())},
-            "workload": "run_multiresolutions, 3 DISCRETE levels (data ico4/5/6, control ico2/3/4), 3 iterations each, sulc-like D=1, ico6 spheres",
-            "optimiser": how}
+    out = {"wall_s": wall, "path_s": sum(v for k, v in clock.items() if k != "optimiser"), "phases_s": {k: round(v, 4) for k, v in sorted(clock.items())},
+           "workload": "run_multiresolutions, 3 DISCRETE levels (data ico4/5/6, control ico2/3/4), 3 iterations each, sulc-like D=1, ico6 spheres",
+           "optimiser": how}
+    if check:
+        iters = (1, 1, 1) if optimiser == "mcmc" else (2, 2, 2)
+        out["check"] = registration_check(ctx, registration.basic_levels(iters), 1, "the same schedule and subject, %d iteration(s) per level" % iters[0], **kw)
+        out["max_angle_rad_vs_cpu_port"] = out["check"]["max_angle_rad_vs_cpu_port"]
+    return out
 
 
-def bench_registration_msmall(ctx):
+def bench_registration_msmall(ctx, check=True):
     """Wall-clock of an HCP MSMAll-shaped pairwise registration (BASELINE config 3): the schedule of
     config/HCP_multimodal_alignment/MSMAllStrainFinalconf1to1_1to3_2 -- three levels, 10 / 15 / 15 iterations, triclique cost over 32
     features, rescaled labels, variance normalisation -- on ico6 spheres, driven as --dopt=HOCR drives it: per iteration one set-up and
@@ -181,12 +242,16 @@ def bench_registration_msmall(ctx):
         t0 = time.perf_counter()
         registration.run_multiresolution(ops, xyz, tri, src, xyz, tri, ref, registration.hcp_msmall_levels(), varnorm=True, timings=clock)
         wall = time.perf_counter() - t0
-    return {"wall_s": wall, "path_s": sum(v for k, v in clock.items() if k != "optimiser"), "phases_s": {k: round(v, 4) for k, v in sorted(clock.items())},
-            "workload": "run_multiresolutions, the HCP MSMAll schedule (data ico4/5/6, control ico2/3/4, 10 / 15 / 15 iterations, ho_multivariate D=32, "
-                        "--triclique --rescaleL --VN), ico6 spheres: 40 set-ups + 1 520 fusion moves",
-            "optimiser": "the label loop of Fusion::optimize with a stand-in for its binary solve (msm_fusion_icm_step: iterated conditional modes on the "
-                         "host; ELC + FastPD are licence-restricted and FSL-bound): the path is exercised and timed as HOCR drives it, the labelings are "
-                         "not HOCR's"}
+    out = {"wall_s": wall, "path_s": sum(v for k, v in clock.items() if k != "optimiser"), "phases_s": {k: round(v, 4) for k, v in sorted(clock.items())},
+           "workload": "run_multiresolutions, the HCP MSMAll schedule (data ico4/5/6, control ico2/3/4, 10 / 15 / 15 iterations, ho_multivariate D=32, "
+                       "--triclique --rescaleL --VN), ico6 spheres: 40 set-ups + 1 520 fusion moves",
+           "optimiser": "the label loop of Fusion::optimize with a stand-in for its binary solve (msm_fusion_icm_step: iterated conditional modes on the "
+                        "host; ELC + FastPD are licence-restricted and FSL-bound): the path is exercised and timed as HOCR drives it, the labelings are "
+                        "not HOCR's"}
+    if check:
+        out["check"] = registration_check(ctx, registration.hcp_msmall_levels((1, 1, 1)), 32, "the same schedule and subject, 1 iteration per level")
+        out["max_angle_rad_vs_cpu_port"] = out["check"]["max_angle_rad_vs_cpu_port"]
+    return out
 
 
 GMSM_LEVELS = [(4, 2), (5, 3), (6, 4)]  # --datagrid / --CPgrid of the gMSM configuration of docs/guide.md:390-407
@@ -422,9 +487,11 @@ def main():
             with torch.cuda.stream(stream):
                 out["triclique_move"] = {"d1": bench_triclique_move(ctx, 1, 200, 0 if args.no_cpu_baseline else threads),
                                          "d32": bench_triclique_move(ctx, 32, 200, 0 if args.no_cpu_baseline else threads)}
-                out["registration"] = bench_registration(ctx)
-                out["registration_fusion"] = bench_registration(ctx, "fusion")
-                out["registration_msmall"] = bench_registration_msmall(ctx)
+                out["resample"] = bench_resample(ctx, 100, not args.no_cpu_baseline)
+                chk = not args.no_cpu_baseline  # the checks run the CPU port (a few seconds each)
+                out["registration"] = bench_registration(ctx, check=chk)
+                out["registration_fusion"] = bench_registration(ctx, "fusion", check=chk)
+                out["registration_msmall"] = bench_registration_msmall(ctx, check=chk)
                 out["gmsm"] = bench_gmsm(ctx, args.subjects, comm)
         if world == 1 and not args.no_cpu_baseline:
             Uo, rate, dt, reps = cpu_baseline(inp, kind, threads)

@@ -105,6 +105,17 @@ msm_ctx *msm_ctx_create_on_stream(int device, void *hip_stream); /* launches on 
 void     msm_ctx_destroy(msm_ctx *ctx);
 int      msm_ctx_synchronize(msm_ctx *ctx);
 void    *msm_ctx_stream(msm_ctx *ctx);                        /* hipStream_t, for event timing */
+/* Optional HIP-event timing of the search kernel of msm_query_triangles / msm_closest_vertex (bench.py's `resample` object): with
+ * enable != 0 every such call records two events around its kernel on the context's stream; msm_ctx_query_kernel_ms returns the
+ * duration of the most recent one in milliseconds (-1 when none was timed). */
+/* [host] Release / acquire accesses to 64-bit counters in memory shared between the ranks of a node (newmsm_amd/dist.py:
+ * SharedStepBuffer: a producer's slice of a label step must be visible before its progress counter, the consumer's reads must not
+ * move before its look at the counters).  __atomic_store_n(.., __ATOMIC_RELEASE) / __atomic_load_n(.., __ATOMIC_ACQUIRE). */
+void     msm_store_release_i64(int64_t *addr, int64_t value);
+int64_t  msm_load_acquire_i64(const int64_t *addr);
+int64_t  msm_min_acquire_i64(const int64_t *addr, int32_t n);   /* the smallest of n counters, each read with acquire semantics */
+int      msm_ctx_time_queries(msm_ctx *ctx, int enable);
+int      msm_ctx_query_kernel_ms(msm_ctx *ctx, double *ms);
 /* Pinned host memory mapped into the GPU's address space.  An output array that lies inside such a block is written by the
  * kernels directly (no staging copy, no copy-engine command): use it for the arrays of the optimisers' inner loop --
  * msm_cost_triplet_octets' E, msm_group_fusion_move's pair_quads / triplet_octets -- the counterpart of the buffers

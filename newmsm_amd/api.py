@@ -179,20 +179,34 @@ class Context:
         return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
 
     def scratch_host_array(self, name, shape, dtype=np.float64):
-        """a view of a grow-only pinned buffer kept per `name` on this context (reallocated, the old one freed, when it has to grow)"""
+        """a view of a grow-only pinned buffer kept per `name` on this context.  When it has to grow a new block is taken and the old
+        one is NOT freed: arrays handed out earlier may still be referenced by the caller (a freed block is unmapped -- reading such a
+        view would fault).  Blocks grow by doubling, so what stays behind is less than the final block; all go with the context."""
         n = int(np.prod(shape)) * np.dtype(dtype).itemsize
         bufs = self.__dict__.setdefault("_scratch_pinned", {})
         cur = bufs.get(name)
         if cur is None or cur[1] < n:
-            if cur is not None:
-                lib().msm_host_free(self.h, C.c_void_p(cur[0]))
-            cap = max(n + n // 8, 4096)
+            cap = max(2 * n, 4096) if cur is not None else max(n + n // 8, 4096)
             p = lib().msm_host_alloc(self.h, cap)
             if not p:
                 raise MsmError(-2, lib().msm_last_error().decode())
             cur = bufs[name] = (p, cap)
         buf = (C.c_char * cur[1]).from_address(cur[0])
         return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+    def release_host_array(self, arr):
+        """gives a Context.host_array block back (msm_host_free); the caller guarantees that no view of it is used afterwards"""
+        if getattr(self, "h", None):
+            lib().msm_host_free(self.h, C.c_void_p(arr.ctypes.data))
+
+    def time_queries(self, on=True):
+        """HIP events around the search kernel of query_triangles / closest_vertex calls (msm_ctx_time_queries)"""
+        check(lib().msm_ctx_time_queries(self.h, int(on)))
+
+    def query_kernel_ms(self):
+        ms = C.c_double(-1.0)
+        check(lib().msm_ctx_query_kernel_ms(self.h, C.byref(ms)))
+        return ms.value
 
     def forest_signatures(self, xyz_sets, tri):
         """leaf signatures (Mesh.octree_signature) of the trees of B coordinate sets over one triangle list, built together as a forest"""

@@ -338,6 +338,10 @@ static void retire_ray_job(msm_mesh *m) {
 int ensure_rays(msm_mesh *m, bool wait) {
     int st = ensure_masks(m);  // what the ray table cannot settle goes through the masked search
     if (st) return st;
+    if (m->host_xyz_stale) {  // coordinates written on the device (group.cpp: lane meshes): the table is keyed by and built from the host copy
+        MSM_HIP(hipMemcpy(m->xyz.data(), m->d_xyz, sizeof(double) * 3 * (size_t)m->V, hipMemcpyDeviceToHost));
+        m->host_xyz_stale = false;
+    }
     if (m->rays_valid) return ensure_rayrec(m);
     msm_ctx *ctx = m->ctx;
     if (m->ray_job && m->ray_job->gen != m->tree_gen) retire_ray_job(m);
@@ -506,8 +510,13 @@ int query_host(msm_mesh *target, const double *q, int N, int *tri_id, int *vid, 
     if (tri_id) MSM_HIP(ctx_scratch(ctx, 1, bt, (void **)&dt));
     if (vid) MSM_HIP(ctx_scratch(ctx, 2, bv, (void **)&dv));
     if (w) MSM_HIP(ctx_scratch(ctx, 3, bw, (void **)&dw));
+    if (ctx->q_timing) MSM_HIP(hipEventRecord(ctx->q_ev0, ctx->stream));
     st = launch_query(ctx, dev_tree(target), dq, N, dt, dv, dw, mode);
     if (st) return st;
+    if (ctx->q_timing) {
+        MSM_HIP(hipEventRecord(ctx->q_ev1, ctx->stream));
+        ctx->q_timed = true;
+    }
     if (tri_id) MSM_HIP(hipMemcpyAsync(pt, dt, bt, hipMemcpyDeviceToHost, ctx->stream));
     if (vid) MSM_HIP(hipMemcpyAsync(pv, dv, bv, hipMemcpyDeviceToHost, ctx->stream));
     if (w) MSM_HIP(hipMemcpyAsync(pw, dw, bw, hipMemcpyDeviceToHost, ctx->stream));
@@ -590,7 +599,7 @@ int ensure_adjacency_dev(msm_mesh *m) {
 
 namespace {
 struct ResampleScratch {
-    DevBuf<int> fvid, rvid, roff, rfill, rkey, coff, cfill, ckey, row_ptr, col, tkey, scan_tmp, long_flag;
+    DevBuf<int> fvid, rvid, counters, rkey, ckey, row_ptr, col, tkey, scan_tmp;  // counters: roff | rfill | coff | cfill | long_flag, zeroed together
     DevBuf<double> fw, rw, oldA, newA, ta, rwt, cval, correction, val, data, out, tval;
 };
 ResampleScratch &resample_scratch(msm_ctx *ctx) {
@@ -620,12 +629,9 @@ int adaptive_weights_dev(msm_mesh *in_mesh, msm_mesh *new_mesh, AdaptiveDev &out
     MSM_HIP(s.oldA.ensure(nOld));
     MSM_HIP(s.newA.ensure(nNew));
     MSM_HIP(s.ta.ensure((size_t)std::max(in_mesh->T, new_mesh->T)));
-    MSM_HIP(s.roff.ensure((size_t)nNew + 1));
-    MSM_HIP(s.rfill.ensure(nNew));
+    MSM_HIP(s.counters.ensure(2 * (size_t)nNew + 2 * (size_t)nOld + 4));
     MSM_HIP(s.rkey.ensure(3 * (size_t)nOld));
     MSM_HIP(s.rwt.ensure(3 * (size_t)nOld));
-    MSM_HIP(s.coff.ensure((size_t)nOld + 1));
-    MSM_HIP(s.cfill.ensure(nOld));
     MSM_HIP(s.ckey.ensure(cap));
     MSM_HIP(s.cval.ensure(cap));
     MSM_HIP(s.correction.ensure(nOld));
@@ -634,7 +640,6 @@ int adaptive_weights_dev(msm_mesh *in_mesh, msm_mesh *new_mesh, AdaptiveDev &out
     MSM_HIP(s.val.ensure(cap));
     MSM_HIP(s.tkey.ensure(cap));
     MSM_HIP(s.scan_tmp.ensure((size_t)std::max(nNew, nOld) / 4096 + 2));
-    MSM_HIP(s.long_flag.ensure(2));
     MSM_HIP(s.tval.ensure(cap));
     // forward: the new mesh's vertices in the old mesh's tree; reverse: the old vertices in the new mesh's tree (:74-78)
     st = launch_query(ctx, in_tree ? *in_tree : dev_tree(in_mesh), new_mesh->d_xyz, nNew, nullptr, s.fvid.p, s.fw.p, MSM_WEIGHTS_PROJECTED);
@@ -648,9 +653,10 @@ int adaptive_weights_dev(msm_mesh *in_mesh, msm_mesh *new_mesh, AdaptiveDev &out
     AdaptiveDevArgs a;
     a.nOld = nOld, a.nNew = nNew;
     a.fvid = s.fvid.p, a.rvid = s.rvid.p, a.fw = s.fw.p, a.rw = s.rw.p, a.oldA = s.oldA.p, a.newA = s.newA.p;
-    a.roff = s.roff.p, a.rfill = s.rfill.p, a.rkey = s.rkey.p, a.rwt = s.rwt.p;
-    a.coff = s.coff.p, a.cfill = s.cfill.p, a.ckey = s.ckey.p, a.cval = s.cval.p, a.correction = s.correction.p;
-    a.row_ptr = s.row_ptr.p, a.col = s.col.p, a.val = s.val.p, a.tkey = s.tkey.p, a.tval = s.tval.p, a.scan_tmp = s.scan_tmp.p, a.long_flag = s.long_flag.p;
+    a.roff = s.counters.p, a.rfill = a.roff + nNew + 1, a.coff = a.rfill + nNew, a.cfill = a.coff + nOld + 1, a.long_flag = a.cfill + nOld;
+    a.rkey = s.rkey.p, a.rwt = s.rwt.p;
+    a.ckey = s.ckey.p, a.cval = s.cval.p, a.correction = s.correction.p;
+    a.row_ptr = s.row_ptr.p, a.col = s.col.p, a.val = s.val.p, a.tkey = s.tkey.p, a.tval = s.tval.p, a.scan_tmp = s.scan_tmp.p;
     st = launch_adaptive_surgery(ctx, a);
     if (st) return st;
     if (check) {
@@ -833,6 +839,8 @@ void msm_ctx_destroy(msm_ctx *ctx) {
     if (ctx->stage) (void)hipHostFree(ctx->stage);
     if (ctx->io_pin) (void)hipHostFree(ctx->io_pin);
     if (ctx->h_flag) (void)hipHostFree(ctx->h_flag);
+    if (ctx->q_ev0) (void)hipEventDestroy(ctx->q_ev0);
+    if (ctx->q_ev1) (void)hipEventDestroy(ctx->q_ev1);
     if (ctx->oct_box) (void)msm::pool_free(ctx->oct_box);
     if (ctx->oct_ints) (void)msm::pool_free(ctx->oct_ints);
     if (ctx->oct_counters) (void)msm::pool_free(ctx->oct_counters);
@@ -852,6 +860,37 @@ int msm_ctx_synchronize(msm_ctx *ctx) {
 }
 
 void *msm_ctx_stream(msm_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+void msm_store_release_i64(int64_t *addr, int64_t value) { __atomic_store_n(addr, value, __ATOMIC_RELEASE); }
+int64_t msm_load_acquire_i64(const int64_t *addr) { return __atomic_load_n(addr, __ATOMIC_ACQUIRE); }
+int64_t msm_min_acquire_i64(const int64_t *addr, int32_t n) {
+    int64_t m = INT64_MAX;
+    for (int32_t i = 0; i < n; ++i) m = std::min<int64_t>(m, __atomic_load_n(addr + i, __ATOMIC_ACQUIRE));
+    return m;
+}
+
+int msm_ctx_time_queries(msm_ctx *ctx, int enable) {
+    if (!ctx) return fail(MSM_ERR_INVALID, "null context");
+    (void)hipSetDevice(ctx->device);
+    if (enable && !ctx->q_ev0) {
+        MSM_HIP(hipEventCreate(&ctx->q_ev0));
+        MSM_HIP(hipEventCreate(&ctx->q_ev1));
+    }
+    ctx->q_timing = enable != 0;
+    ctx->q_timed = false;
+    return MSM_OK;
+}
+
+int msm_ctx_query_kernel_ms(msm_ctx *ctx, double *ms) {
+    if (!ctx || !ms) return fail(MSM_ERR_INVALID, "msm_ctx_query_kernel_ms: null argument");
+    *ms = -1.0;
+    if (!ctx->q_timed) return MSM_OK;
+    MSM_HIP(hipEventSynchronize(ctx->q_ev1));
+    float f = 0.f;
+    MSM_HIP(hipEventElapsedTime(&f, ctx->q_ev0, ctx->q_ev1));
+    *ms = f;
+    return MSM_OK;
+}
 
 void *msm_host_alloc(msm_ctx *ctx, size_t bytes) {
     if (!ctx || bytes == 0) {

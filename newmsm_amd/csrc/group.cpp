@@ -1480,7 +1480,7 @@ static int copy_behind(msm_group *g, int slot, double *host_dst, const double *d
     return MSM_OK;
 }
 
-int msm_group_fusion_move(msm_group *g, const int32_t *labeling, int32_t label, double *pair_quads, double *triplet_octets) {
+static int group_fusion_move_impl(msm_group *g, const int32_t *labeling, int32_t label, double *pair_quads, double *triplet_octets) {
     if (!g || !labeling) return fail(MSM_ERR_INVALID, "msm_group_fusion_move: null argument");
     if (!g->ready) return fail(MSM_ERR_STATE, "msm_group: msm_group_setup() must be called first");
     msm_ctx *ctx = g->ctx;
@@ -1543,8 +1543,17 @@ int msm_group_fusion_move(msm_group *g, const int32_t *labeling, int32_t label, 
 // A slice of a label step with the results left in DEVICE memory (the caller's buffers, e.g. torch tensors that go into an
 // RCCL gather, or the device address of mapped host memory): pairs [pair0, pair1) -> quads_dev[4 * (pair1 - pair0)],
 // triplets [trip0, trip1) -> octets_dev[8 * (trip1 - trip0)].
-int msm_group_fusion_move_dev(msm_group *g, const int32_t *labeling, int32_t label, int64_t pair0, int64_t pair1, int64_t trip0, int64_t trip1,
-                              double *quads_dev, double *octets_dev) {
+// The kept (current, current) and (label, label) pair costs are marked valid when their kernels are queued; a step that then fails -- a status
+// raised by a kernel (e.g. MSM_ERR_CAPACITY), a failed copy -- must not leave them behind for later steps to deliver: an entry point that
+// returns an error drops everything kept.
+int msm_group_fusion_move(msm_group *g, const int32_t *labeling, int32_t label, double *pair_quads, double *triplet_octets) {
+    const int st = group_fusion_move_impl(g, labeling, label, pair_quads, triplet_octets);
+    if (st && g) g->drop_kept();
+    return st;
+}
+
+static int group_fusion_move_dev_impl(msm_group *g, const int32_t *labeling, int32_t label, int64_t pair0, int64_t pair1, int64_t trip0, int64_t trip1,
+                                      double *quads_dev, double *octets_dev) {
     if (!g || !labeling) return fail(MSM_ERR_INVALID, "msm_group_fusion_move_dev: null argument");
     if (!g->ready) return fail(MSM_ERR_STATE, "msm_group: msm_group_setup() must be called first");
     const int64_t P = g->npairs, T = (int64_t)g->S * g->Tc;
@@ -1578,6 +1587,13 @@ int msm_group_fusion_move_dev(msm_group *g, const int32_t *labeling, int32_t lab
     st = group_move_compute(g, labeling, label, pair0, pair1, trip0, trip1, cq, ct, "msm_group_fusion_move_dev");
     if (st) return st;
     return check_status(ctx, "DiscreteGroupCostFunction (fusion move)");  // synchronises: the buffers may go into a collective on another stream
+}
+
+int msm_group_fusion_move_dev(msm_group *g, const int32_t *labeling, int32_t label, int64_t pair0, int64_t pair1, int64_t trip0, int64_t trip1,
+                              double *quads_dev, double *octets_dev) {
+    const int st = group_fusion_move_dev_impl(g, labeling, label, pair0, pair1, trip0, trip1, quads_dev, octets_dev);
+    if (st && g) g->drop_kept();
+    return st;
 }
 
 int msm_group_triplet_batch(msm_group *g, const int32_t *t, const int32_t *la, const int32_t *lb, const int32_t *lc, int32_t n, double *out) {

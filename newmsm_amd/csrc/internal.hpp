@@ -139,6 +139,9 @@ struct msm_ctx {
     int *h_flag = nullptr;
     int *d_flag_map = nullptr;  // its device address
     std::shared_ptr<void> resample_scratch;  // api.cpp: device buffers of adaptive_weights_dev, kept between calls
+    // msm_ctx_time_queries: events around the search kernel of the host-array query entry points
+    hipEvent_t q_ev0 = nullptr, q_ev1 = nullptr;
+    bool q_timing = false, q_timed = false;
     // scratch of the GPU octree build (octree_kernels.hip), grow only
     double *oct_box = nullptr;
     int *oct_ints = nullptr, *oct_counters = nullptr, *oct_hcounters = nullptr;

@@ -227,78 +227,142 @@ __global__ __launch_bounds__(256) void k_row_len(AdaptiveDevArgs a) {
     const int nf = small_map(a.fvid, a.fw, (int)a.fstride, k, f), nr = a.roff[k + 1] - a.roff[k];
     a.row_ptr[k] = nr <= nf ? nf : nr;
 }
+// The four kernels below walk a row (a column) of the result.  With meshes of similar resolution a row has 3 - 6 entries and a thread per
+// row is right; a coarse new mesh under a fine old one (resample_weights of every iteration: ico6 source -> ico4 control grid) has rows of
+// 3 nOld / nNew = 48 entries (768 at ico6 -> ico2) and a thread per row turns the kernel into 40 wavefronts walking dependent loads
+// (60 - 90 us each at ico6 -> ico4).  LPR = 1, 8 or 64 lanes share a row; where the reference's sum runs over the row in entry order the
+// lanes compute their terms side by side and every lane of the row adds them up in that order (broadcast term by term: same operands,
+// same order, same bits).
+template <int LPR>
 __global__ __launch_bounds__(256) void k_row_write(AdaptiveDevArgs a) {
     a = problem_view(a);
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x, k = gid / LPR, sub = gid % LPR;
     if (k >= a.nNew) return;
     Entry f[3];
     const int nf = small_map(a.fvid, a.fw, (int)a.fstride, k, f), nr = a.roff[k + 1] - a.roff[k];
     const int n = nr <= nf ? nf : nr, at = a.row_ptr[k];
-    for (int j = 0; j < n; ++j) {
-        const int key = nr <= nf ? f[j].key : a.rkey[a.roff[k] + j];
-        const double w = nr <= nf ? f[j].w : a.rwt[a.roff[k] + j];
+    const double area = a.newA[k];
+    for (int j = sub; j < n; j += LPR) {
+        int key;
+        double w;
+        if (nr <= nf) {
+            key = j == 0 ? f[0].key : (j == 1 ? f[1].key : f[2].key);
+            w = j == 0 ? f[0].w : (j == 1 ? f[1].w : f[2].w);
+        } else {
+            key = a.rkey[a.roff[k] + j];
+            w = a.rwt[a.roff[k] + j];
+        }
         a.col[at + j] = key;
-        a.val[at + j] = w * a.newA[k];
+        a.val[at + j] = w * area;
         if (key >= 0) atomicAdd(&a.coff[key], 1);
     }
 }
+template <int LPR>
 __global__ __launch_bounds__(256) void k_col_fill(AdaptiveDevArgs a) {
     a = problem_view(a);
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x, k = gid / LPR, sub = gid % LPR;
     if (k >= a.nNew) return;
-    for (int e = a.row_ptr[k]; e < a.row_ptr[k + 1]; ++e) {
-        if (a.col[e] < 0) continue;
-        const int pos = a.coff[a.col[e]] + atomicAdd(&a.cfill[a.col[e]], 1);
+    for (int e = a.row_ptr[k] + sub; e < a.row_ptr[k + 1]; e += LPR) {
+        const int c = a.col[e];
+        if (c < 0) continue;
+        const int pos = a.coff[c] + atomicAdd(&a.cfill[c], 1);
         a.ckey[pos] = k;
         a.cval[pos] = a.val[e];
     }
 }
+// the sum of the terms of a row's (column's) entries b <= e < end in entry order; term(e, ok) is evaluated by the lane that owns
+// entry e.  All LPR lanes of the row must call this together (LPR lanes of one wavefront, LPR | 64); every lane returns the sum.
+template <int LPR, class Term>
+__device__ __forceinline__ double ordered_sum(int b, int end, int sub, Term term) {
+    double acc = 0.0;
+    if (LPR == 1) {
+        for (int e = b; e < end; ++e) {
+            bool ok;
+            const double v = term(e, ok);
+            if (ok) acc += v;
+        }
+        return acc;
+    }
+    const int first = (threadIdx.x & 63) & ~(LPR - 1);
+    for (int c = b; __any(c < end); c += LPR) {
+        bool ok = false;
+        double v = 0.0;
+        if (c + sub < end) v = term(c + sub, ok);
+        const unsigned long long oks = __ballot(ok) >> first;
+#pragma unroll 8
+        for (int j = 0; j < LPR; ++j) {
+            const double vj = __shfl(v, first + j, 64);
+            if ((oks >> j) & 1ull) acc += vj;
+        }
+    }
+    return acc;
+}
 // correction[j] = the column's contributions summed in ascending new-vertex order (:111-116 visits k = 0, 1, ...)
+template <int LPR>
 __global__ __launch_bounds__(256) void k_col_sum(AdaptiveDevArgs a) {
     a = problem_view(a);
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= a.nOld) return;
-    double s = 0.0;
-    for (int e = a.coff[j]; e < a.coff[j + 1]; ++e) s += a.cval[e];
-    a.correction[j] = s;
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x, j = gid / LPR, sub = gid % LPR;
+    const bool live = j < a.nOld;
+    if (LPR == 1 && !live) return;
+    const int b = live ? a.coff[j] : 0, end = live ? a.coff[j + 1] : 0;
+    const double s = ordered_sum<LPR>(b, end, sub, [&](int e, bool &ok) {
+        ok = true;
+        return a.cval[e];
+    });
+    if (live && sub == 0) a.correction[j] = s;
 }
 // :120-137: rescale by oldArea / correction, normalise the row
+template <int LPR>
 __global__ __launch_bounds__(256) void k_row_finish(AdaptiveDevArgs a) {
     a = problem_view(a);
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= a.nNew) return;
-    double wsum = 0.0;
-    for (int e = a.row_ptr[k]; e < a.row_ptr[k + 1]; ++e) {
-        if (a.col[e] < 0) continue;  // a failed search (reported through the status word)
-        a.val[e] *= a.oldA[a.col[e]] / a.correction[a.col[e]];
-        wsum += a.val[e];
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x, k = gid / LPR, sub = gid % LPR;
+    const bool live = k < a.nNew;
+    if (LPR == 1 && !live) return;
+    const int b = live ? a.row_ptr[k] : 0, end = live ? a.row_ptr[k + 1] : 0;
+    // a failed search (col < 0, reported through the status word) takes no part in the sum
+    const double wsum = ordered_sum<LPR>(b, end, sub, [&](int e, bool &ok) {
+        const int c = a.col[e];
+        ok = c >= 0;
+        return ok ? a.val[e] * (a.oldA[c] / a.correction[c]) : 0.0;
+    });
+    for (int e = b + sub; e < end; e += LPR) {  // the same product again (same operands: same bits), then the division
+        const int c = a.col[e];
+        double v = a.val[e];
+        if (c >= 0) v *= a.oldA[c] / a.correction[c];
+        if (wsum != 0.0) v /= wsum;
+        a.val[e] = v;
     }
-    if (wsum != 0.0)
-        for (int e = a.row_ptr[k]; e < a.row_ptr[k + 1]; ++e) a.val[e] /= wsum;
 }
 // barycentric_data_interpolation, R/resampler.cpp:40-52: out[d][k] = sum over the row, in entry order
+template <int LPR>
 __global__ __launch_bounds__(256) void k_apply_rows(AdaptiveDevArgs a, int D, const double *__restrict__ data, double *__restrict__ out, size_t out_stride) {
     out += blockIdx.y * out_stride;
     a = problem_view(a);
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (size_t)a.nNew * D) return;
-    const int d = (int)(i / a.nNew), k = (int)(i - (size_t)d * a.nNew);
-    double acc = 0.0;
-    for (int e = a.row_ptr[k]; e < a.row_ptr[k + 1]; ++e)
-        if (a.col[e] >= 0) acc += data[(size_t)d * a.nOld + a.col[e]] * a.val[e];
-    out[i] = acc;
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, i = gid / LPR;
+    const int sub = (int)(gid % LPR);
+    const bool live = i < (size_t)a.nNew * D;
+    if (LPR == 1 && !live) return;
+    const int d = live ? (int)(i / a.nNew) : 0, k = live ? (int)(i - (size_t)d * a.nNew) : 0;
+    const int b = live ? a.row_ptr[k] : 0, end = live ? a.row_ptr[k + 1] : 0;
+    const double acc = ordered_sum<LPR>(b, end, sub, [&](int e, bool &ok) {
+        const int c = a.col[e];
+        ok = c >= 0;
+        return ok ? data[(size_t)d * a.nOld + c] * a.val[e] : 0.0;
+    });
+    if (live && sub == 0) out[i] = acc;
 }
 
 }  // namespace
 
 #define MSM_LAUNCH2D(kernel, n, B, ...)                                                                                          \
     do {                                                                                                                         \
-        if ((n) > 0) hipLaunchKernelGGL(kernel, dim3((unsigned)(((n) + 255) / 256), (unsigned)(B)), dim3(256), 0, ctx->stream, __VA_ARGS__); \
+        if ((n) > 0) hipLaunchKernelGGL((kernel), dim3((unsigned)(((n) + 255) / 256), (unsigned)(B)), dim3(256), 0, ctx->stream, __VA_ARGS__); \
     } while (0)
 
 static void scan_excl(msm_ctx *ctx, int *data, int n, int *tmp, int B, size_t s_data, size_t s_tmp) {
     const int nb = std::max(1, (n + kScanBlock - 1) / kScanBlock);
-    hipLaunchKernelGGL(k_scan_block_sums, dim3(nb, (unsigned)B), dim3(256), 0, ctx->stream, data, n, tmp, s_data, s_tmp);
+    if (nb > 1)  // a single block adds up no sums before it
+        hipLaunchKernelGGL(k_scan_block_sums, dim3(nb, (unsigned)B), dim3(256), 0, ctx->stream, data, n, tmp, s_data, s_tmp);
     hipLaunchKernelGGL(k_scan_apply, dim3(nb, (unsigned)B), dim3(256), 0, ctx->stream, data, n, tmp, s_data, s_tmp);
 }
 int launch_vertex_areas_batch(msm_ctx *ctx, const double *d_xyz, size_t comp, size_t set, int V, const int32_t *d_tri, int T, const int32_t *d_tid_ptr, const int32_t *d_tid,
@@ -315,23 +379,39 @@ int launch_vertex_areas(msm_ctx *ctx, const double *d_xyz, int V, const int32_t 
 
 // the surgery: every argument is device memory; the caller sizes col / val for 3 * nNew + 3 * nOld entries per problem (a row is
 // the forward list, at most 3, or the transposed reverse list, whose lengths add up to at most 3 * nOld)
+// lanes per row for rows of about `len` entries
+static int lanes_per_row(double len) { return len <= 6.0 ? 1 : (len <= 96.0 ? 8 : 64); }
+#define MSM_LAUNCH_LPR(kernel, lpr, n, B, ...)                               \
+    do {                                                                      \
+        if ((lpr) == 64) MSM_LAUNCH2D(kernel<64>, (size_t)(n) * 64, B, __VA_ARGS__); \
+        else if ((lpr) == 8) MSM_LAUNCH2D(kernel<8>, (size_t)(n) * 8, B, __VA_ARGS__); \
+        else MSM_LAUNCH2D(kernel<1>, (size_t)(n), B, __VA_ARGS__);            \
+    } while (0)
+
 int launch_adaptive_surgery(msm_ctx *ctx, const AdaptiveDevArgs &arg) {
     AdaptiveDevArgs a = arg;
     const int nOld = a.nOld, nNew = a.nNew, B = std::max(a.B, 1);
     if (a.fstride == 0) a.fstride = (size_t)nNew;
     if (a.rstride == 0) a.rstride = (size_t)nOld;
+    // rows: the forward list (3) or the transposed reverse list (3 nOld / nNew on average); columns: 3 nNew / nOld or the reverse list's 3
+    const int row_lpr = lanes_per_row(3.0 * nOld / std::max(nNew, 1)), col_lpr = lanes_per_row(3.0 * nNew / std::max(nOld, 1));
     if (B == 1) {
-        MSM_HIP(hipMemsetAsync(a.roff, 0, sizeof(int) * ((size_t)nNew + 1), ctx->stream));
-        MSM_HIP(hipMemsetAsync(a.rfill, 0, sizeof(int) * (size_t)nNew, ctx->stream));
-        MSM_HIP(hipMemsetAsync(a.coff, 0, sizeof(int) * ((size_t)nOld + 1), ctx->stream));
-        MSM_HIP(hipMemsetAsync(a.cfill, 0, sizeof(int) * (size_t)nOld, ctx->stream));
+        if (a.rfill == a.roff + nNew + 1 && a.coff == a.rfill + nNew && a.cfill == a.coff + nOld + 1 && a.long_flag == a.cfill + nOld) {
+            MSM_HIP(hipMemsetAsync(a.roff, 0, sizeof(int) * (2 * (size_t)nNew + 2 * (size_t)nOld + 4), ctx->stream));  // one block (adaptive_weights_dev)
+        } else {
+            MSM_HIP(hipMemsetAsync(a.roff, 0, sizeof(int) * ((size_t)nNew + 1), ctx->stream));
+            MSM_HIP(hipMemsetAsync(a.rfill, 0, sizeof(int) * (size_t)nNew, ctx->stream));
+            MSM_HIP(hipMemsetAsync(a.coff, 0, sizeof(int) * ((size_t)nOld + 1), ctx->stream));
+            MSM_HIP(hipMemsetAsync(a.cfill, 0, sizeof(int) * (size_t)nOld, ctx->stream));
+            MSM_HIP(hipMemsetAsync(a.long_flag, 0, sizeof(int) * 2, ctx->stream));
+        }
     } else {  // the problems' arrays lie one after the other
         MSM_HIP(hipMemsetAsync(a.roff, 0, sizeof(int) * a.s_roff * B, ctx->stream));
         MSM_HIP(hipMemsetAsync(a.rfill, 0, sizeof(int) * a.s_rfill * B, ctx->stream));
         MSM_HIP(hipMemsetAsync(a.coff, 0, sizeof(int) * a.s_coff * B, ctx->stream));
         MSM_HIP(hipMemsetAsync(a.cfill, 0, sizeof(int) * a.s_cfill * B, ctx->stream));
+        MSM_HIP(hipMemsetAsync(a.long_flag, 0, sizeof(int) * 2 * (size_t)B, ctx->stream));
     }
-    MSM_HIP(hipMemsetAsync(a.long_flag, 0, sizeof(int) * 2 * (size_t)B, ctx->stream));
     MSM_LAUNCH2D(k_rev_count, nOld, B, a);
     scan_excl(ctx, a.roff, nNew, a.scan_tmp, B, a.s_roff, a.s_scan);
     MSM_LAUNCH2D(k_rev_fill, nOld, B, a);
@@ -339,20 +419,21 @@ int launch_adaptive_surgery(msm_ctx *ctx, const AdaptiveDevArgs &arg) {
     hipLaunchKernelGGL(k_sort_long_lists, dim3((unsigned)std::min(nNew, 2048), (unsigned)B), dim3(256), 0, ctx->stream, a, 0);
     MSM_LAUNCH2D(k_row_len, nNew, B, a);
     scan_excl(ctx, a.row_ptr, nNew, a.scan_tmp, B, a.s_rowptr, a.s_scan);
-    MSM_LAUNCH2D(k_row_write, nNew, B, a);
+    MSM_LAUNCH_LPR(k_row_write, row_lpr, nNew, B, a);
     scan_excl(ctx, a.coff, nOld, a.scan_tmp, B, a.s_coff, a.s_scan);
-    MSM_LAUNCH2D(k_col_fill, nNew, B, a);
+    MSM_LAUNCH_LPR(k_col_fill, row_lpr, nNew, B, a);
     MSM_LAUNCH2D(k_sort_lists, nOld, B, a, 1);
     hipLaunchKernelGGL(k_sort_long_lists, dim3((unsigned)std::min(nOld, 2048), (unsigned)B), dim3(256), 0, ctx->stream, a, 1);
-    MSM_LAUNCH2D(k_col_sum, nOld, B, a);
-    MSM_LAUNCH2D(k_row_finish, nNew, B, a);
+    MSM_LAUNCH_LPR(k_col_sum, col_lpr, nOld, B, a);
+    MSM_LAUNCH_LPR(k_row_finish, row_lpr, nNew, B, a);
     MSM_HIP(hipGetLastError());
     return MSM_OK;
 }
 
 int launch_apply_rows_batch(msm_ctx *ctx, const AdaptiveDevArgs &a, int D, const double *d_data, double *d_out, size_t out_stride) {
     const size_t total = (size_t)a.nNew * D;
-    MSM_LAUNCH2D(k_apply_rows, total, std::max(a.B, 1), a, D, d_data, d_out, out_stride);
+    const int lpr = lanes_per_row(3.0 * a.nOld / std::max(a.nNew, 1));
+    MSM_LAUNCH_LPR(k_apply_rows, lpr, total, std::max(a.B, 1), a, D, d_data, d_out, out_stride);
     MSM_HIP(hipGetLastError());
     return MSM_OK;
 }

@@ -59,11 +59,18 @@ class Comm:
     destroy_process_group = close
 
     def all_gather(self, out, inp):
-        """out[r] = rank r's inp (out: world x inp.shape), one collective"""
-        try:
+        """out[r] = rank r's inp (out: world x inp.shape), one collective.  Which form of the collective is used is decided once per
+        communicator from the backend (every rank decides the same way); an error of the collective itself -- a communicator fault, a
+        time-out, mismatched shapes -- propagates instead of turning into a different collective on this rank only."""
+        if self.flat_all_gather:
             self.dist.all_gather_into_tensor(out, inp)
-        except (RuntimeError, NotImplementedError):  # a backend without the flat form
+        else:
             self.dist.all_gather(list(out.unbind(0)), inp)
+
+    @property
+    def flat_all_gather(self):
+        # nccl (RCCL) has the flat form; gloo of this torch build raises for it
+        return self.backend == "nccl" and hasattr(self.dist, "all_gather_into_tensor")
 
 
 def _timeout():
@@ -296,19 +303,36 @@ class SharedStepBuffer:
                 if time.monotonic() - t0 > timeout_s:
                     raise TimeoutError("SharedStepBuffer: " + what())
 
+    # The counters are written with release and read with acquire semantics (msm_store_release_i64 / msm_load_acquire_i64 of the
+    # library: __atomic builtins): a producer's slice is visible before its counter says so, the consumer's reads of the slot cannot
+    # move before its look at the counters, and the consumer's release of a slot orders its reads of that slot before a producer's
+    # next writes.  (Plain numpy stores would do on x86's total store order only.)
+    def _store(self, view, index, value):
+        from ._lib import lib
+
+        lib().msm_store_release_i64(view.ctypes.data + 8 * index, int(value))
+
+    def _load(self, view, index=0):
+        from ._lib import lib
+
+        return int(lib().msm_load_acquire_i64(view.ctypes.data + 8 * index))
+
     def begin(self, step):
         """before this rank writes its slice of `step` (1, 2, ...): the slot must be free"""
         if self.c.rank == self.dst:
-            self.released[0] = max(int(self.released[0]), step - self.slots)
-        self._spin(lambda: int(self.released[0]) >= step - self.slots, lambda: "the consumer has not released the slot of step %d" % step)
+            self._store(self.released, 0, max(self._load(self.released), step - self.slots))
+        self._spin(lambda: self._load(self.released) >= step - self.slots, lambda: "the consumer has not released the slot of step %d" % step)
 
     def publish(self, step):
         """this rank's slice of `step` (1, 2, ...) is complete in slot (step - 1) % slots"""
-        self.counters[self.c.rank] = step
+        self._store(self.counters, self.c.rank, step)
 
     def wait(self, step):
         """the consumer: block until every rank has published `step`; returns the slot's array"""
-        self._spin(lambda: int(self.counters.min()) >= step,
+        from ._lib import lib
+
+        L, addr, n = lib(), self.counters.ctypes.data, self.c.world
+        self._spin(lambda: int(L.msm_min_acquire_i64(addr, n)) >= step,
                    lambda: "step %d not delivered by ranks %s" % (step, np.nonzero(self.counters < step)[0].tolist()))
         return self.data[(step - 1) % self.slots]
 
@@ -340,6 +364,7 @@ class ShardedMove:
             transport = "local" if c.world == 1 else ("shm" if same_node(c) and hasattr(group, "ctx") else "gather")
         self.transport = transport
         self.step = 0
+        self.out = None
         if transport == "local":
             self.out = (group.ctx.host_array((group.P, 4)), group.ctx.host_array((group.T, 8)))
             return
@@ -376,6 +401,10 @@ class ShardedMove:
         if self.transport == "shm" and self.shared is not None:
             self.g.ctx.unregister_host(self.shared.address)
             self.shared = None
+        if self.transport == "local" and self.out is not None:  # 4 P + 8 T doubles of pinned memory (186 MB at 64 subjects)
+            for arr in self.out:
+                self.g.ctx.release_host_array(arr)
+            self.out = None
 
     def move(self, labeling, label):
         c, g = self.c, self.g

@@ -139,6 +139,12 @@ def hcp_msmall_levels(iterations=(10, 15, 15)):
                  cost_params=dict(lambda_=lam, **hcp)) for k, lam in enumerate((0.00001, 0.0075, 0.01))]
 
 
+def basic_levels(iterations=(3, 3, 3)):
+    """Three DISCRETE levels shaped like config/basic_configs/config_standard_MSM_strain (--CPgrid=2,3,4 --datagrid=4,5,6 --SGgrid=4,5,6,
+    --sigma_in/ref=4,2,1, pass varnorm=True for its --VN); optimiser, cost class and regulariser come from the caller's keyword arguments."""
+    return [dict(data_order=4 + k, cp_order=2 + k, sigma_in=s, sigma_ref=s, iters=iterations[k]) for k, s in enumerate((4.0, 2.0, 1.0))]
+
+
 def apply_labeling(rot, labels, labeling):
     """m_CPgrid.set_coord(i, m_ROT[i] * m_labels[labeling[i]]), operator*(Matrix, Point) R/point.cpp:207-213 (row sums left to right)"""
     R = np.asarray(rot).reshape(-1, 3, 3)
@@ -251,7 +257,7 @@ def run_discrete_level(ops, target_xyz, target_tri, ref_feat, source_xyz, source
 
 
 def run_multiresolution(ops, in_xyz, in_tri, in_data, ref_xyz, ref_tri, ref_data, levels, *, varnorm=False, timings=None, in_cfweight=None,
-                        ref_cfweight=None, **level_kw):
+                        ref_cfweight=None, labelings_out=None, **level_kw):
     """Mesh_registration::run_multiresolutions (M/mesh_registration.cpp:30-50) for DISCRETE levels without file I/O:
 
     per level  featurespace::initialise (M/featurespace.cpp:39-86: metric_resample of both data sets onto the level's
@@ -262,7 +268,8 @@ def run_multiresolution(ops, in_xyz, in_tri, in_data, ref_xyz, ref_tri, ref_data
     in_* / ref_*: the input and reference spheres (radius 100) with their D x V data.  levels: dicts with data_order, cp_order
     and optionally sg_order, sigma_in, sigma_ref, iters, mciters, cost_params.  in_cfweight / ref_cfweight (rows x V on the
     input / reference sphere, optional): cost-function weightings, brought to each level's grid by nearest-neighbour
-    interpolation (downsample_cfweighting, M/mesh_registration.cpp:334-350).  recentre() of the regular spheres
+    interpolation (downsample_cfweighting, M/mesh_registration.cpp:334-350).  labelings_out (optional list): receives every iteration's labeling, level
+    after level (the parity tests compare the optimiser's decisions of two runs).  recentre() of the regular spheres
     (a shift of ~1e-15) is not applied.  Returns (sphere_reg, per-level registered data grids, per-level energies)."""
     clock = timings if timings is not None else {}
 
@@ -305,8 +312,10 @@ def run_multiresolution(ops, in_xyz, in_tri, in_data, ref_xyz, ref_tri, ref_data
         if in_cfweight is not None and ref_cfweight is not None:
             kw["in_weight"] = ops.nearest_neighbour(in_mesh, in_cfweight, ico_xyz)
             kw["ref_weight"] = ops.nearest_neighbour(ref_mesh, ref_cfweight, ico_xyz)
-        sph_reg, _, energies, _ = run_discrete_level(ops, ico_xyz, ico_tri, feats[1], ico_xyz, ico_tri, feats[0], sph_in, lv["cp_order"],
-                                                     cp_start=cp_start, timings=clock, **kw)
+        sph_reg, _, energies, labelings = run_discrete_level(ops, ico_xyz, ico_tri, feats[1], ico_xyz, ico_tri, feats[0], sph_in, lv["cp_order"],
+                                                             cp_start=cp_start, timings=clock, **kw)
+        if labelings_out is not None:
+            labelings_out.extend(labelings)
         regs.append(sph_reg)
         all_energies.append(energies)
         sph_reg_prev, prev_order = sph_reg, lv["data_order"]

@@ -217,3 +217,33 @@ class _OracleCost:
 
     def total(self, labeling):
         return self.c.total(labeling)[0]
+
+
+def angles(a, b):
+    """angle (rad) between corresponding vertices of two spheres: the unit of north_star's 1e-4 rad bar"""
+    ua = a / np.linalg.norm(a, axis=1, keepdims=True)
+    ub = b / np.linalg.norm(b, axis=1, keepdims=True)
+    return 2.0 * np.arcsin(np.minimum(1.0, 0.5 * np.linalg.norm(ua - ub, axis=1)))
+
+
+def registration_parity(ctx, levels, D, **kw):
+    """One multiresolution registration of the synthetic ico6 subject of bench.py (seeds 7 / 9) over the MI355X path and over the
+    oracle, same caller loop, same optimiser: (max angle between the two registered spheres in rad, labelings identical?, number of
+    labelings compared, seconds the oracle run took)."""
+    import time
+
+    import newmsm_amd as M
+    from newmsm_amd import registration, synthetic
+
+    xyz, tri = M.make_mesh_from_icosa(6)
+    ref = synthetic.features(xyz, D, 7)
+    src = synthetic.features(synthetic.known_warp(xyz, seed=9, rot_deg=3.0, amp=2.0), D, 7)
+    lg, lw = [], []
+    got = registration.run_multiresolution(registration.ProductOps(ctx), xyz, tri, src, xyz, tri, ref, levels, varnorm=True, labelings_out=lg, **kw)
+    t0 = time.perf_counter()
+    want = registration.run_multiresolution(OracleOps(M.mcmc_optimise), xyz, tri, src, xyz, tri, ref, levels, varnorm=True, labelings_out=lw, **kw)
+    cpu_s = time.perf_counter() - t0
+    same = len(lg) == len(lw) and all(np.array_equal(a, b) for a, b in zip(lg, lw))
+    moved = float(angles(got[0], xyz).max())
+    return dict(max_angle_rad=float(angles(got[0], want[0]).max()), labelings_identical=bool(same), labelings=len(lg), cpu_port_s=cpu_s,
+                moved_rad=moved, energies_rel_diff=float(max(abs(a - b) / max(abs(b), 1e-300) for ea, eb in zip(got[2], want[2]) for a, b in zip(ea, eb))))

@@ -14,10 +14,7 @@ pytestmark = pytest.mark.gpu
 NORTH_STAR_TOL_RAD = 1e-4
 
 
-def angles(a, b):
-    ua = a / np.linalg.norm(a, axis=1, keepdims=True)
-    ub = b / np.linalg.norm(b, axis=1, keepdims=True)
-    return 2.0 * np.arcsin(np.minimum(1.0, 0.5 * np.linalg.norm(ua - ub, axis=1)))
+from helpers import angles  # noqa: E402
 
 
 def level_inputs(data_order, D, seed):
@@ -133,3 +130,31 @@ def test_fusion_driven_level_matches_oracle(ctx, kind, D):
     assert angles(got[0], xyz).max() > 1e-3 and any(l.any() for l in got[3])
     assert angles(got[0], want[0]).max() <= NORTH_STAR_TOL_RAD
     assert np.abs(got[0] - want[0]).max() < 1e-9
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# Full size: the ico6 subject and schedules bench.py times (BASELINE configs 2 and 3), two iterations per level, over the MI355X
+# path and over the oracle -- the optimiser must take the same decisions in every iteration of every level, and the registered
+# spheres must agree within north_star's 1e-4 rad.  (M/mesh_registration.cpp:30-50,164-232, I/Fusion/Fusion.h:136-229.)
+# ------------------------------------------------------------------------------------------------------------------------
+from helpers import registration_parity  # noqa: E402
+
+
+@pytest.mark.parametrize("optimiser", ["mcmc", "fusion"])
+def test_full_size_three_level_schedule_matches_oracle(ctx, optimiser):
+    """bench.py's `registration` (Monte Carlo optimiser over the unary + T x L^3 tables) and `registration_fusion` (BASELINE config 2 as
+    --dopt=HOCR drives it: unary table + strain-only fusion moves): data ico4/5/6, control ico2/3/4, sigma 4/2/1, --VN, sulc-like D = 1"""
+    iters = (1, 1, 1) if optimiser == "mcmc" else (2, 2, 2)  # the oracle's T x L^3 triplet tables of the MCMC run are its slow part
+    r = registration_parity(ctx, registration.basic_levels(iters), 1, mciters=50, mcparam=0.8, seed=1, cost_params=dict(lambda_=0.1), optimiser=optimiser)
+    assert r["labelings"] == sum(iters) and r["labelings_identical"], r
+    assert r["max_angle_rad"] <= NORTH_STAR_TOL_RAD and r["moved_rad"] > 1e-3, r
+    assert r["energies_rel_diff"] < 1e-9, r
+
+
+def test_full_size_msmall_schedule_matches_oracle(ctx):
+    """BASELINE config 3: the HCP MSMAll schedule (triclique cost over 32 features, rescaled labels, --VN, fusion moves) at ico6,
+    two iterations per level instead of 10 / 15 / 15"""
+    r = registration_parity(ctx, registration.hcp_msmall_levels((2, 2, 2)), 32)
+    assert r["labelings"] == 6 and r["labelings_identical"], r
+    assert r["max_angle_rad"] <= NORTH_STAR_TOL_RAD and r["moved_rad"] > 1e-3, r
+    assert r["energies_rel_diff"] < 1e-9, r
