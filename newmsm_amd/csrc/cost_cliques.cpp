@@ -271,6 +271,120 @@ int msm_cost_triplet_batch(msm_cost *c, const int32_t *triplet, const int32_t *l
     return check_status(ctx, "computeTripletCost");
 }
 
+// The fused fusion move of the triclique classes (move_kernels.hip) for one labeling: all eight combinations of every control triangle
+// (E: 8 x T, a label step of Fusion) or, single, combination 000 only (E: T values -- the triplet part of evaluateTotalCostSum,
+// M/DiscreteCostFunction.cpp:55-77, which used to go through the general on-demand kernel at 143 us per call at ico4 / 32 features).
+static int fused_move(msm_cost *c, const CliqueArgs &a, const int32_t *labeling, int32_t label, double *E, bool single) {
+    msm_ctx *ctx = c->ctx;
+    int st;
+    const size_t in_bytes = sizeof(int32_t) * (size_t)a.N, out_bytes = sizeof(double) * (single ? 1 : 8) * (size_t)a.T, in_pad = (in_bytes + 255) & ~(size_t)255;
+    // The call of the optimisers' inner loop (once per label step).  Two launches and one synchronisation: the labeling
+    // rides in the kernel arguments, the costs are written into mapped pinned memory (the caller's own array when it
+    // came from msm_host_alloc), a raised status shows up in a mapped flag.
+    st = ensure_move(c, a);
+    if (st) return st;
+    st = ctx_flag(ctx);
+    if (st) return st;
+    // diagnostics: MSMHIP_MOVE_LABELS=device sends the labeling with a copy command, MSMHIP_MOVE_OUT=device brings the costs back with one
+    static const bool labels_by_copy = [] { const char *e = std::getenv("MSMHIP_MOVE_LABELS"); return e && std::strcmp(e, "device") == 0; }();
+    static const bool out_by_copy = [] { const char *e = std::getenv("MSMHIP_MOVE_OUT"); return e && std::strcmp(e, "device") == 0; }();
+    const bool packed = a.N <= 4 * kMoveLabelWords && a.L <= 256 && !labels_by_copy;
+    MoveLabels lab;
+    if (packed) std::memset(lab.w, 0, sizeof(uint32_t) * (size_t)((a.N + 3) / 4));
+    for (int i = 0; i < a.N; ++i) {
+        if (labeling[i] < 0 || labeling[i] >= a.L) return fail(MSM_ERR_INVALID, "labeling[%d] out of range", i);
+        if (packed) lab.w[i >> 2] |= (uint32_t)labeling[i] << ((i & 3) * 8);
+    }
+    void *pin = nullptr;
+    double *out_dev = out_by_copy ? nullptr : (double *)ctx_mapped(ctx, E, out_bytes);
+    const bool direct = out_dev != nullptr;
+    if (!direct || !packed) {
+        st = ctx_io_pinned(ctx, in_pad + out_bytes, &pin);
+        if (st) return st;
+    }
+    bool staged_copy = false;  // the costs come back with a copy command (the pinned block could not be mapped)
+    if (!direct) {
+        if (ctx->io_dev && !out_by_copy) {
+            out_dev = (double *)((char *)ctx->io_dev + in_pad);
+        } else {
+            MSM_HIP(c->d_clique_out.ensure((size_t)8 * a.T));  // (also large enough for the T values of a single-combination call)
+            out_dev = c->d_clique_out.p;
+            staged_copy = true;
+        }
+    }
+    if (!packed) {
+        std::memcpy(pin, labeling, in_bytes);
+        MSM_HIP(c->d_labeling.ensure(a.N));
+        MSM_HIP(hipMemcpyAsync(c->d_labeling.p, pin, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+    }
+    MoveArgs m;
+    m.slot_tri = c->d_slot_tri.p;
+    m.slot_w = c->d_slot_w.p;
+    m.slot_sf = c->d_slot_sf.p;
+    m.slot_cw = a.cfw ? c->d_slot_cw.p : nullptr;
+    m.slot_wda = c->d_slot_wda.p;
+    m.tri_frame = c->d_tri_frame.p;
+    m.tri_stat = c->d_tri_stat.p;
+    m.blk = c->d_blk.p;
+    m.nblk = c->move_nblk;
+    m.cap = c->move_cap;
+    m.labeling = packed ? nullptr : c->d_labeling.p;
+    m.label = label;
+    m.vals = c->d_ho_vals.p;
+    m.defer_list = c->d_defer_list.p;
+    m.defer_cnt = c->d_defer_cnt.p;
+    m.parity = c->move_parity;
+    c->move_parity ^= 1;
+    m.out = out_dev;
+    m.host_flags = ctx->d_flag_map;
+    m.trace = nullptr;
+    m.single = single ? 1 : 0;
+#ifdef MSM_MOVE_TRACE
+    static DevBuf<unsigned long long> trace_buf;
+    const size_t trace_words = 8 * (size_t)(8 * ((c->move_nblk + 7) / 8));
+    MSM_HIP(trace_buf.zero(trace_words, ctx->stream));
+    m.trace = trace_buf.p;
+#endif
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (c->timing) {
+        e0 = c->ev0[c->ev_next];
+        e1 = c->ev1[c->ev_next];
+        c->ev_next = (c->ev_next + 1) % (int)c->ev0.size();
+        c->ev_count = std::min(c->ev_count + 1, (int)c->ev0.size());
+    }
+    st = launch_move(ctx, a, m, packed ? &lab : nullptr, e0, e1);
+    if (st) return st;
+    if (staged_copy) MSM_HIP(hipMemcpyAsync((char *)pin + in_pad, out_dev, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    c->counters[2] += (int64_t)(single ? 1 : 8) * a.T;
+    MSM_HIP(hipStreamSynchronize(ctx->stream));
+#ifdef MSM_MOVE_TRACE
+    if (const char *path = std::getenv("MSMHIP_MOVE_TRACE")) {
+        std::vector<unsigned long long> h(trace_words);
+        MSM_HIP(hipMemcpy(h.data(), trace_buf.p, sizeof(unsigned long long) * trace_words, hipMemcpyDeviceToHost));
+        if (FILE *f = std::fopen(path, "wb")) {
+            std::fwrite(h.data(), sizeof(unsigned long long), trace_words, f);
+            std::fclose(f);
+        }
+    }
+#endif
+    volatile int *flags = ctx->h_flag;
+    if (flags[1] != 0) {  // rare: some evaluations need the complete search (sibling leaves, nearest vertex)
+        flags[1] = 0;
+        st = launch_move_tail(ctx, a, m, packed ? &lab : nullptr);
+        if (st) return st;
+        if (staged_copy) MSM_HIP(hipMemcpyAsync((char *)pin + in_pad, out_dev, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+        MSM_HIP(hipStreamSynchronize(ctx->stream));
+        c->move_tails++;
+    }
+    st = MSM_OK;
+    if (flags[0] != 0) {
+        flags[0] = 0;
+        st = check_status(ctx, "computeTripletCost");
+    }
+    if (!direct) std::memcpy(E, (char *)pin + in_pad, out_bytes);
+    return st;
+}
+
 int msm_cost_triplet_octets(msm_cost *c, const int32_t *labeling, int32_t label, double *E) {
     if (!c || !labeling || !E) return fail(MSM_ERR_INVALID, "msm_cost_triplet_octets: null argument");
     CliqueArgs a;
@@ -279,112 +393,7 @@ int msm_cost_triplet_octets(msm_cost *c, const int32_t *labeling, int32_t label,
     if (label < 0 || label >= a.L) return fail(MSM_ERR_INVALID, "label %d out of range", label);
     msm_ctx *ctx = c->ctx;
     const size_t in_bytes = sizeof(int32_t) * (size_t)a.N, out_bytes = sizeof(double) * 8 * (size_t)a.T, in_pad = (in_bytes + 255) & ~(size_t)255;
-    if (fused_move_applies(c, a)) {
-        // The call of the optimisers' inner loop (once per label step).  Two launches and one synchronisation: the labeling
-        // rides in the kernel arguments, the costs are written into mapped pinned memory (the caller's own array when it
-        // came from msm_host_alloc), a raised status shows up in a mapped flag.
-        st = ensure_move(c, a);
-        if (st) return st;
-        st = ctx_flag(ctx);
-        if (st) return st;
-        // diagnostics: MSMHIP_MOVE_LABELS=device sends the labeling with a copy command, MSMHIP_MOVE_OUT=device brings the costs back with one
-        static const bool labels_by_copy = [] { const char *e = std::getenv("MSMHIP_MOVE_LABELS"); return e && std::strcmp(e, "device") == 0; }();
-        static const bool out_by_copy = [] { const char *e = std::getenv("MSMHIP_MOVE_OUT"); return e && std::strcmp(e, "device") == 0; }();
-        const bool packed = a.N <= 4 * kMoveLabelWords && a.L <= 256 && !labels_by_copy;
-        MoveLabels lab;
-        if (packed) std::memset(lab.w, 0, sizeof(uint32_t) * (size_t)((a.N + 3) / 4));
-        for (int i = 0; i < a.N; ++i) {
-            if (labeling[i] < 0 || labeling[i] >= a.L) return fail(MSM_ERR_INVALID, "labeling[%d] out of range", i);
-            if (packed) lab.w[i >> 2] |= (uint32_t)labeling[i] << ((i & 3) * 8);
-        }
-        void *pin = nullptr;
-        double *out_dev = out_by_copy ? nullptr : (double *)ctx_mapped(ctx, E, out_bytes);
-        const bool direct = out_dev != nullptr;
-        if (!direct || !packed) {
-            st = ctx_io_pinned(ctx, in_pad + out_bytes, &pin);
-            if (st) return st;
-        }
-        bool staged_copy = false;  // the costs come back with a copy command (the pinned block could not be mapped)
-        if (!direct) {
-            if (ctx->io_dev && !out_by_copy) {
-                out_dev = (double *)((char *)ctx->io_dev + in_pad);
-            } else {
-                MSM_HIP(c->d_clique_out.ensure((size_t)8 * a.T));
-                out_dev = c->d_clique_out.p;
-                staged_copy = true;
-            }
-        }
-        if (!packed) {
-            std::memcpy(pin, labeling, in_bytes);
-            MSM_HIP(c->d_labeling.ensure(a.N));
-            MSM_HIP(hipMemcpyAsync(c->d_labeling.p, pin, in_bytes, hipMemcpyHostToDevice, ctx->stream));
-        }
-        MoveArgs m;
-        m.slot_tri = c->d_slot_tri.p;
-        m.slot_w = c->d_slot_w.p;
-        m.slot_sf = c->d_slot_sf.p;
-        m.slot_cw = a.cfw ? c->d_slot_cw.p : nullptr;
-        m.slot_wda = c->d_slot_wda.p;
-        m.tri_frame = c->d_tri_frame.p;
-        m.tri_stat = c->d_tri_stat.p;
-        m.blk = c->d_blk.p;
-        m.nblk = c->move_nblk;
-        m.cap = c->move_cap;
-        m.labeling = packed ? nullptr : c->d_labeling.p;
-        m.label = label;
-        m.vals = c->d_ho_vals.p;
-        m.defer_list = c->d_defer_list.p;
-        m.defer_cnt = c->d_defer_cnt.p;
-        m.parity = c->move_parity;
-        c->move_parity ^= 1;
-        m.out = out_dev;
-        m.host_flags = ctx->d_flag_map;
-        m.trace = nullptr;
-#ifdef MSM_MOVE_TRACE
-        static DevBuf<unsigned long long> trace_buf;
-        const size_t trace_words = 8 * (size_t)(8 * ((c->move_nblk + 7) / 8));
-        MSM_HIP(trace_buf.zero(trace_words, ctx->stream));
-        m.trace = trace_buf.p;
-#endif
-        hipEvent_t e0 = nullptr, e1 = nullptr;
-        if (c->timing) {
-            e0 = c->ev0[c->ev_next];
-            e1 = c->ev1[c->ev_next];
-            c->ev_next = (c->ev_next + 1) % (int)c->ev0.size();
-            c->ev_count = std::min(c->ev_count + 1, (int)c->ev0.size());
-        }
-        st = launch_move(ctx, a, m, packed ? &lab : nullptr, e0, e1);
-        if (st) return st;
-        if (staged_copy) MSM_HIP(hipMemcpyAsync((char *)pin + in_pad, out_dev, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
-        c->counters[2] += (int64_t)8 * a.T;
-        MSM_HIP(hipStreamSynchronize(ctx->stream));
-#ifdef MSM_MOVE_TRACE
-        if (const char *path = std::getenv("MSMHIP_MOVE_TRACE")) {
-            std::vector<unsigned long long> h(trace_words);
-            MSM_HIP(hipMemcpy(h.data(), trace_buf.p, sizeof(unsigned long long) * trace_words, hipMemcpyDeviceToHost));
-            if (FILE *f = std::fopen(path, "wb")) {
-                std::fwrite(h.data(), sizeof(unsigned long long), trace_words, f);
-                std::fclose(f);
-            }
-        }
-#endif
-        volatile int *flags = ctx->h_flag;
-        if (flags[1] != 0) {  // rare: some evaluations need the complete search (sibling leaves, nearest vertex)
-            flags[1] = 0;
-            st = launch_move_tail(ctx, a, m, packed ? &lab : nullptr);
-            if (st) return st;
-            if (staged_copy) MSM_HIP(hipMemcpyAsync((char *)pin + in_pad, out_dev, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
-            MSM_HIP(hipStreamSynchronize(ctx->stream));
-            c->move_tails++;
-        }
-        st = MSM_OK;
-        if (flags[0] != 0) {
-            flags[0] = 0;
-            st = check_status(ctx, "computeTripletCost");
-        }
-        if (!direct) std::memcpy(E, (char *)pin + in_pad, out_bytes);
-        return st;
-    }
+    if (fused_move_applies(c, a)) return fused_move(c, a, labeling, label, E, false);  // the call of the optimisers' inner loop (once per label step)
     for (int i = 0; i < a.N; ++i)
         if (labeling[i] < 0 || labeling[i] >= a.L) return fail(MSM_ERR_INVALID, "labeling[%d] out of range", i);
     // labeling and energies travel through pinned memory (pageable copies of these sizes cost more than the kernels)
@@ -492,7 +501,7 @@ int msm_cost_total(msm_cost *c, const int32_t *labeling, double *total, double p
     if (!c->cpgrid) return fail(MSM_ERR_STATE, "msm_cost: meshes must be set first");
     const int N = c->cpgrid->V;
     double u = 0.0, pw = 0.0, tc = 0.0;
-    {
+    if (!cost_is_ho(c)) {  // the HO classes' computeUnaryCost returns 0 (M/DiscreteCostFunction.h:249,258): a sum of N zeros
         std::vector<int32_t> nodes(N);
         std::vector<double> vals(N);
         for (int i = 0; i < N; ++i) nodes[i] = i;
@@ -513,7 +522,22 @@ int msm_cost_total(msm_cost *c, const int32_t *labeling, double *total, double p
         if (st) return st;
         for (int p = 0; p < P; ++p) pw += vals[p];
     }
-    if (T > 0) {
+    bool triplets_done = false;
+    if (T > 0 && cost_is_ho(c)) {
+        // combination 000 of a fusion move IS computeTripletCost(t, labeling[a], labeling[b], labeling[c]): the fused move kernel with one
+        // combination per control triangle instead of the general on-demand kernel (143 -> about 20 us at ico4 / 32 features)
+        CliqueArgs a;
+        int st = clique_args(c, true, false, a);
+        if (st) return st;
+        if (fused_move_applies(c, a)) {
+            std::vector<double> vals(T);
+            st = fused_move(c, a, labeling, 0, vals.data(), true);
+            if (st) return st;
+            for (int t = 0; t < T; ++t) tc += vals[t];  // serial, in triplet order (:70-75)
+            triplets_done = true;
+        }
+    }
+    if (T > 0 && !triplets_done) {
         std::vector<int32_t> id(T), la(T), lb(T), lc(T);
         std::vector<double> vals(T);
         for (int t = 0; t < T; ++t) {

@@ -189,9 +189,10 @@ struct MoveArgs {
     unsigned *defer_list;    // 8 x T evaluation ids
     unsigned *defer_cnt;     // two counters; a move uses [parity] and clears [parity ^ 1]
     int parity;
-    double *out;             // 8 x T costs (device memory or mapped pinned host memory)
+    double *out;             // 8 x T costs, or T with `single` (device memory or mapped pinned host memory)
     int *host_flags;         // mapped pinned host words: [0] a raised status, [1] set when evaluations were left to the tail kernel
     unsigned long long *trace;  // diagnostics (MSM_MOVE_TRACE builds): 8 timestamps per workgroup, or nullptr
+    int single;              // 1: combination 000 only (the labeling's own cost of every control triangle); out holds T values
 };
 // launch_move runs the main kernel; the host launches the tail (launch_move_tail) only when host_flags[1] was set
 int launch_move_prepare(msm_ctx *ctx, const CliqueArgs &a, int nslots, int *slot_tri, double *slot_w, double *slot_sf, double *slot_cw, double *slot_wda,

@@ -229,12 +229,12 @@ __global__ __launch_bounds__(kThreads) void k_ho_move(CliqueArgs a, MoveArgs m, 
     if (blk >= m.nblk) return;
     const int4 bk = m.blk[blk];
     const int t0 = bk.x, ntrip = bk.y, s0 = bk.z, nslots = bk.w;
-    const int total = 8 * nslots;
+    const int total = (m.single ? 1 : 8) * nslots;  // single: combination 000 only (evaluateTotalCostSum's triplet part)
     const float inv = 1.0f / (float)max(nslots, 1);
 
     // ---- the eight proposed triangles of each control triangle (lanes 0 .. 8 * ntrip); the other lanes meanwhile fetch their
     // first sample's slot data, which does not depend on the labels
-    const bool ev = tid < 8 * ntrip;
+    const bool ev = tid < 8 * ntrip && !(m.single && (tid & 7));
     if (tid == 0) s_npend = 0;
     if (tid >= kThreads - 64) {  // the last wavefront: the last phase's operands
         const int h = tid - (kThreads - 64);
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(kThreads) void k_ho_move(CliqueArgs a, MoveArgs m, 
     // it used to follow the similarity in every evaluation's lane, 2 us of the 4.3 us last phase
     if (tid >= kThreads - 64) {
         const int h = tid - (kThreads - 64);
-        if (h < 8 * ntrip) {
+        if (h < 8 * ntrip && !(m.single && (h & 7))) {
             const double *gp = s_geo + 9 * h;
             const V3 rr[3] = {mk(gp[0], gp[1], gp[2]), mk(gp[3], gp[4], gp[5]), mk(gp[6], gp[7], gp[8])};
             s_strain[h] = s_flag[h] ? 0.0 : move_strain(a, s_frame + 5 * (h >> 3), rr);
@@ -368,8 +368,9 @@ __global__ __launch_bounds__(kThreads) void k_ho_move(CliqueArgs a, MoveArgs m, 
     // ---- one lane per evaluation: similarity in the reference's serial order + strain
     if (!ev) return;
     const int t = t0 + (tid >> 3), k = tid & 7, e = 8 * t + k;
+    double *dst = m.out + (m.single ? t : e);
     if (s_flag[tid]) {
-        m.out[e] = MSM_FOLDING * a.lambda;
+        *dst = MSM_FOLDING * a.lambda;
         return;
     }
     const int beg = s_bin[tid >> 3], n = s_bin[(tid >> 3) + 1] - beg;
@@ -382,7 +383,7 @@ __global__ __launch_bounds__(kThreads) void k_ho_move(CliqueArgs a, MoveArgs m, 
         __hip_atomic_store(m.host_flags + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         return;
     }
-    m.out[e] = move_likelihood(a, n, s_stat + 3 * (tid >> 3), s_wda + (beg - s0), m.slot_cw ? s_cw + (beg - s0) : nullptr, s_sf + (beg - s0), wmean, vals) + s_strain[tid];
+    *dst = move_likelihood(a, n, s_stat + 3 * (tid >> 3), s_wda + (beg - s0), m.slot_cw ? s_cw + (beg - s0) : nullptr, s_sf + (beg - s0), wmean, vals) + s_strain[tid];
     MSM_STAMP(6);
 }
 
@@ -432,7 +433,7 @@ __global__ __launch_bounds__(256) void k_ho_move_tail(CliqueArgs a, MoveArgs m, 
         }
         __syncthreads();
         if (have && lane == 0)
-            m.out[8 * t + k] = move_likelihood(a, cnt, m.tri_stat + 3 * (size_t)t, m.slot_wda + beg, m.slot_cw ? m.slot_cw + beg : nullptr, m.slot_sf + beg,
+            m.out[m.single ? t : 8 * t + k] = move_likelihood(a, cnt, m.tri_stat + 3 * (size_t)t, m.slot_wda + beg, m.slot_cw ? m.slot_cw + beg : nullptr, m.slot_sf + beg,
                                                (a.absw[id[0]] + a.absw[id[1]] + a.absw[id[2]]) / 3.0, vals) +
                                move_strain(a, m.tri_frame + 5 * (size_t)t, r);
         __syncthreads();

@@ -20,3 +20,23 @@ def test_flat_fusion_glue_equals_the_map_based_restatement():
     assert res["steps"] == 13 and res["skipped"] == 1 and res["nodes_moved"] > 0 and res["energy_end"] < res["energy_start"]
     t = res["timing"]
     assert t["checksums_equal"] and t["assemble_ms_flat"] < t["assemble_ms_map"] and t["lookup_ns_flat"] < t["lookup_ns_map"]
+
+
+REF_INCLUDE = "/root/reference/libraries/msm-newmeshreg/include"
+
+
+def test_fusion_glue_with_the_references_own_elc():
+    """The same comparison with ELCReduce::PBF<double> of I/ELC/ELC.h itself as the PBF (std headers only, so it compiles here; taken
+    from /root/reference by include path: nothing copied, nothing shipped -- skipped where the reference is absent, e.g. on the GPU box).
+    FPD::FastPD needs FSL (I/FastPD/FastPD.h:35-36) and stays a stand-in on both sides."""
+    import pytest
+
+    if not os.path.exists(os.path.join(REF_INCLUDE, "ELC", "ELC.h")):
+        pytest.skip("the reference tree is not present")
+    src, exe = os.path.join(ROOT, "tests", "cpp", "fusion_elc.cpp"), os.path.join(ROOT, "tests", "cpp", "fusion_elc")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-fopenmp", "-Wall", "-isystem", REF_INCLUDE, src, "-o", exe])
+    out = subprocess.run([exe, "4"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    res = json.loads(out.stdout.strip().splitlines()[-1])
+    assert res["bad_models"] == 0 and res["bad_drivers"] == 0
+    assert res["aux_variables"] > 0 and res["edges"] > 0 and res["steps"] > 0 and res["nodes_moved"] > 0 and res["energy_end"] < res["energy_start"]

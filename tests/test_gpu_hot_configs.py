@@ -199,3 +199,25 @@ def test_fusion_move_coarse_control_grid(ctx, cp_order, kind, D):
     cf, oc, _ = ho_pair(ctx, inp, kind, 0.05)
     assert np.diff(cf.patches()[0]).max() > 128
     check_moves(cf, oc, inp["triplets"], seed=91 + cp_order, full=True)
+
+
+@pytest.mark.parametrize("kind,D", [("ho_univariate", 1), ("ho_multivariate", 32)])
+@pytest.mark.parametrize("search", ["raytable", "complete"])
+def test_total_cost_of_the_triclique_classes(ctx, monkeypatch, kind, D, search):
+    """evaluateTotalCostSum (M/DiscreteCostFunction.cpp:55-77) of the HO classes: unary part 0, triplet part = computeTripletCost of every
+    control triangle at the labeling -- on the direction-table path the fused move kernel with ONE combination per triangle, otherwise the
+    general on-demand kernel; both against the oracle, and against column 000 of a whole move"""
+    if search == "complete":
+        monkeypatch.setenv("MSMHIP_DISABLE_RAYTABLE", "1")
+    inp = problem.pairwise_inputs(5, 3, D=D, labeldist=1.2)  # long label moves: some proposals fold (1e7 x lambda)
+    cf, oc, _ = ho_pair(ctx, inp, kind, 0.0075)
+    oc.set_pairs(np.zeros((0, 2), dtype=np.int32))
+    rng = np.random.default_rng(71)
+    for labeling in (np.zeros(cf.N, dtype=np.int32), rng.integers(0, cf.L, cf.N).astype(np.int32)):
+        tot, parts = cf.evaluateTotalCostSum(labeling)
+        otot, oparts = oc.total(labeling)
+        assert parts[0] == 0.0 and parts[1] == 0.0
+        assert abs(parts[2] - oparts[2]) <= 1e-9 * abs(oparts[2]) and abs(tot - otot) <= 1e-9 * abs(otot), (parts, oparts)
+        E = cf.tripletOctets(labeling, 3)
+        assert abs(parts[2] - E[:, 0].sum()) <= 1e-9 * abs(parts[2])
+    assert (E[:, 0] >= 1e6 * 0.0075).any()  # the random labeling folds some control triangles
