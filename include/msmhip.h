@@ -225,6 +225,11 @@ int msm_mcmc_optimise(const double *unary, const double *tcosts, const int32_t *
 int msm_fusion_icm_step(const double *unary2 /* N x 2 or NULL */, const double *quads /* P x 4 */, const int32_t *pairs /* P x 2 */, int32_t P,
                         const double *octets /* T x 8 */, const int32_t *triplets /* T x 3 */, int32_t T, int32_t N, int32_t max_passes,
                         int32_t *x /* N, out */);
+/* [host] A STAND-IN for FPD::FastPD on the multi-label pairwise MRF of --regoption=1 (M/mesh_registration.cpp:182-188: computeUnaryCosts,
+ * computePairwiseCosts, FastPD): iterated conditional modes over unary[label * N + node] and paircosts[(pair * L + labelB) * L + labelA]
+ * (the layouts FastPD reads, I/FastPD/FastPD.h:126,213,224), nodes in ascending order, lowest label on ties, at most max_passes passes.
+ * labeling: the start (resetLabeling gives zeros) in, the result out.  Not FastPD's optimum: it lets the regoption-1 caller loop run. */
+int msm_pairwise_icm(const double *unary, const double *paircosts, const int32_t *pairs, int32_t N, int32_t L, int32_t P, int32_t max_passes, int32_t *labeling);
 
 /* ------------------------------------------------------------------------------------------------
  * discrete cost function.  Replaces NonLinearSRegDiscreteCostFunction and its five subclasses

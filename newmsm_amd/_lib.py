@@ -90,6 +90,7 @@ SIGNATURES = {
     "msm_variance_normalise": (C.c_int, [c_dp, C.c_int32, C.c_int32, c_dp]),
     "msm_mcmc_optimise": (C.c_int, [c_dp, c_dp, c_ip, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_int32, C.c_uint64, c_ip]),
     "msm_fusion_icm_step": (C.c_int, [c_dp, c_dp, c_ip, C.c_int32, c_dp, c_ip, C.c_int32, C.c_int32, C.c_int32, c_ip]),
+    "msm_pairwise_icm": (C.c_int, [c_dp, c_dp, c_ip, C.c_int32, C.c_int32, C.c_int32, C.c_int32, c_ip]),
     "msm_nearest_neighbour": (C.c_int, [_VP, c_dp, C.c_int32, c_dp, C.c_int32, c_dp, c_dp, c_dp]),
     "msm_cost_create": (_VP, [_VP, C.POINTER(CostParams)]),
     "msm_cost_destroy": (None, [_VP]),

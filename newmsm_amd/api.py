@@ -415,6 +415,19 @@ def fusion_icm_step(unary2, octets, triplets, passes=5, quads=None, pairs=None):
     return x
 
 
+def pairwise_icm(unary, paircosts, pairs, labeling=None, passes=100):
+    """msm_pairwise_icm: the stand-in solve of the multi-label pairwise MRF of --regoption=1 (iterated conditional modes; NOT FastPD).
+    unary L x N, paircosts P x L x L flat as computePairwiseCosts returns it, pairs P x 2; returns the labeling (N)."""
+    u = np.ascontiguousarray(unary, dtype=np.float64)
+    L, N = u.shape
+    pr = np.ascontiguousarray(pairs, dtype=np.int32).reshape(-1, 2)
+    pc = np.ascontiguousarray(paircosts, dtype=np.float64)
+    assert pc.size == pr.shape[0] * L * L
+    lab = np.zeros(N, dtype=np.int32) if labeling is None else np.array(labeling, dtype=np.int32)
+    check(lib().msm_pairwise_icm(u.ctypes.data_as(c_dp), pc.ctypes.data_as(c_dp), pr.ctypes.data_as(c_ip), N, L, pr.shape[0], int(passes), lab.ctypes.data_as(c_ip)))
+    return lab
+
+
 def nearest_neighbour_interpolation(orig_mesh, data, q, excl=None):
     d, pd = _d(np.atleast_2d(data))
     x, px = _soa(q)

@@ -244,4 +244,47 @@ int msm_fusion_icm_step(const double *unary2, const double *quads, const int32_t
     return MSM_OK;
 }
 
+// The multi-label pairwise MRF of --regoption=1 (unary table + pair tables: what FPD::FastPD reads, I/FastPD/FastPD.h:126,213,224) solved by
+// iterated conditional modes -- a STAND-IN for FastPD (licence-restricted, FSL-bound), the counterpart of msm_fusion_icm_step for the
+// regoption-1 caller loop (M/mesh_registration.cpp:182-188): nodes in ascending order, each takes the label of lowest cost given its
+// neighbours (the lowest label on ties), until a pass changes nothing or max_passes.  unary[label * N + node]; paircosts[(pair * L +
+// labelB) * L + labelA] with labelA the label of pairs[2 pair] (M/DiscreteCostFunction.cpp:228-234); labeling: start in, result out.
+int msm_pairwise_icm(const double *unary, const double *paircosts, const int32_t *pairs, int32_t N, int32_t L, int32_t P, int32_t max_passes, int32_t *labeling) {
+    if (!unary || !labeling || N <= 0 || L <= 0 || P < 0 || max_passes < 0 || (P > 0 && (!paircosts || !pairs))) return fail(MSM_ERR_INVALID, "msm_pairwise_icm: bad arguments");
+    for (int64_t i = 0; i < 2 * (int64_t)P; ++i)
+        if (pairs[i] < 0 || pairs[i] >= N) return fail(MSM_ERR_INVALID, "msm_pairwise_icm: pair node out of range");
+    for (int v = 0; v < N; ++v)
+        if (labeling[v] < 0 || labeling[v] >= L) return fail(MSM_ERR_INVALID, "msm_pairwise_icm: labeling[%d] out of range", v);
+    std::vector<int64_t> ptr((size_t)N + 1, 0);
+    for (int64_t i = 0; i < 2 * (int64_t)P; ++i) ++ptr[(size_t)pairs[i] + 1];
+    for (int v = 0; v < N; ++v) ptr[(size_t)v + 1] += ptr[(size_t)v];
+    std::vector<int64_t> inc(2 * (size_t)P), fill(ptr.begin(), ptr.end() - 1);
+    for (int64_t p = 0; p < P; ++p)
+        for (int j = 0; j < 2; ++j) inc[(size_t)fill[(size_t)pairs[2 * p + j]]++] = 2 * p + j;
+    std::vector<double> e((size_t)L);
+    for (int pass = 0; pass < max_passes; ++pass) {
+        bool changed = false;
+        for (int v = 0; v < N; ++v) {
+            for (int l = 0; l < L; ++l) e[(size_t)l] = unary[(size_t)l * N + v];
+            for (int64_t k = ptr[(size_t)v]; k < ptr[(size_t)v + 1]; ++k) {
+                const int64_t p = inc[(size_t)k] >> 1;
+                const int j = (int)(inc[(size_t)k] & 1);
+                const int other = labeling[pairs[2 * p + (1 - j)]];
+                const double *tab = paircosts + (size_t)p * L * L;
+                if (j == 0) for (int l = 0; l < L; ++l) e[(size_t)l] += tab[(size_t)other * L + l];  // v is node A: labelA = l, labelB = other
+                else for (int l = 0; l < L; ++l) e[(size_t)l] += tab[(size_t)l * L + other];
+            }
+            int best = labeling[v];
+            for (int l = 0; l < L; ++l)
+                if (e[(size_t)l] < e[(size_t)best] || (e[(size_t)l] == e[(size_t)best] && l < best)) best = l;
+            if (best != labeling[v]) {
+                labeling[v] = best;
+                changed = true;
+            }
+        }
+        if (!changed) break;
+    }
+    return MSM_OK;
+}
+
 }  // extern "C"

@@ -67,6 +67,9 @@ class ProductOps:
     def estimate_triplets(self, mesh, tri):
         return api.estimate_triplets(tri)
 
+    def estimate_pairs(self, mesh, tri, nodes):
+        return api.estimate_pairs(tri, nodes)
+
     def label_sampling_grid(self, sg_order, max_dist):
         return api.label_sampling_grid(sg_order, max_dist)
 
@@ -88,6 +91,9 @@ class ProductOps:
 
     def fusion_step(self, unary2, octets, triplets, passes, quads=None, pairs=None):
         return api.fusion_icm_step(unary2, octets, triplets, passes, quads=quads, pairs=pairs)
+
+    def pairwise_solve(self, unary, paircosts, pairs, passes):
+        return api.pairwise_icm(unary, paircosts, pairs, passes=passes)
 
 
 class _ProductCost:
@@ -112,11 +118,17 @@ class _ProductCost:
     def set_triplets(self, triplets):
         self.cf.setTriplets(triplets)
 
+    def set_pairs(self, pairs):
+        self.cf.setPairs(pairs)
+
     def get_source_data(self):
         self.cf.get_source_data()
 
     def unary_table(self):
         return self.cf.computeUnaryCosts()
+
+    def pairwise_table(self):
+        return self.cf.computePairwiseCosts()
 
     def triplet_table(self):
         return self.cf.computeTripletCosts(pinned=True)  # consumed by the optimiser before the next table is computed
@@ -130,13 +142,15 @@ class _ProductCost:
 
 
 def hcp_msmall_levels(iterations=(10, 15, 15)):
-    """The schedule of config/HCP_multimodal_alignment/MSMAllStrainFinalconf1to1_1to3_2 (BASELINE config 3) for run_multiresolution:
-    --CPgrid=2,3,4 --datagrid=4,5,6 --SGgrid=4,5,6 --it=10,15,15 --lambda=0.00001,0.0075,0.01 --regoption=3 --regexp=2 --k_exponent=2
-    --bulkmod=1.6 --shearmod=0.4 --sigma_in/ref=0 --simval=2, with --triclique (the HO classes), --rescaleL, --VN (pass varnorm=True) and
-    --dopt=HOCR (optimiser "fusion": the label loop of Fusion::optimize; its binary solve is a stand-in, see run_discrete_level)."""
-    hcp = dict(mu=0.4, kappa=1.6, k_exp=2.0, rexp=2.0)
-    return [dict(data_order=4 + k, cp_order=2 + k, sg_order=4 + k, iters=iterations[k], kind="ho_multivariate", rescale_labels=True, optimiser="fusion",
-                 cost_params=dict(lambda_=lam, **hcp)) for k, lam in enumerate((0.00001, 0.0075, 0.01))]
+    """The schedule of config/HCP_multimodal_alignment/MSMAllStrainFinalconf1to1_1to3_2 (BASELINE config 3) for run_multiresolution, read from
+    the configuration text itself (newmsm_amd/config.py: PRESETS["HCP_MSMAll"] through the reference's grammar, float options rounded to
+    float32 as the reference's option parser does): --CPgrid=2,3,4 --datagrid=4,5,6 --SGgrid=4,5,6 --it=10,15,15 --lambda=0.00001,0.0075,0.01
+    --regoption=3 --regexp=2 --k_exponent=2 --bulkmod=1.6 --shearmod=0.4 --sigma_in/ref=0 --simval=2, with --triclique (the HO classes over
+    the 32 feature rows of the MSMAll data), --rescaleL, --VN (pass varnorm=True) and --dopt=HOCR (optimiser "fusion": the label loop of
+    Fusion::optimize; its binary solve is a stand-in, see run_discrete_level)."""
+    from . import config
+
+    return config.preset_levels("HCP_MSMAll", 32, iterations)[0]
 
 
 def basic_levels(iterations=(3, 3, 3)):
@@ -165,13 +179,16 @@ def combine_costfunction_weighting(sourceweight, resampledtargetweight):
 def run_discrete_level(ops, target_xyz, target_tri, ref_feat, source_xyz, source_tri, src_feat, sph_reg, cp_order, *, sg_order=None,
                        iters=3, mciters=200, mcparam=0.8, seed=0, kind="univariate", simmeasure=2, rmode=3, labeldist=0.5,
                        rescale_labels=False, cost_params=None, timings=None, cp_start=None, in_weight=None, ref_weight=None,
-                       optimiser="mcmc", icm_passes=5):
+                       optimiser="mcmc", icm_passes=5, converge=False):
     """Runs `iters` iterations of run_discrete_opt for one level.  optimiser: "mcmc" -- the reference's Monte Carlo optimiser over the
     unary and T x L^3 triplet tables (M/mcmc_opt.h:31-134) -- or "fusion": the label loop of Fusion::optimize (I/Fusion/Fusion.h:136-229: two
     sweeps over the labels, per label step 2 N unary and 8 T triplet costs -- ONE fusion-move call on the MI355X path --, nodes that the
     binary solve gives 1 take the label), which is how every HCP configuration drives the hot path (--dopt=HOCR).  The binary solve itself
     (ELC + FastPD, licence-restricted) is replaced by a stand-in (ops.fusion_step: iterated conditional modes, icm_passes passes): such a run
-    exercises and times the path as HOCR would, its result is not the reference's optimum.
+    exercises and times the path as HOCR would, its result is not the reference's optimum.  "fastpd": --regoption=1 as --dopt=FastPD drives it
+    (M/mesh_registration.cpp:182-188): the unary table and the P x L x L pair tables (computePairwiseCosts), then a stand-in for FPD::FastPD
+    (ops.pairwise_solve: iterated conditional modes over all labels).  converge=True applies the reference's convergence test of a level
+    (:204-213; the stand-in solves make its energies differ from the reference's, so it is off unless asked for).
 
     target / source: the reference and the moving sphere at the data resolution of this level (source_xyz = the sphere the
     moving features live on, sph_reg = its current registered position).  Returns (sph_reg, cp_xyz, energies, labelings).
@@ -199,11 +216,16 @@ def run_discrete_level(ops, target_xyz, target_tri, ref_feat, source_xyz, source
     maxsep, mvdmax = ops.cp_spacings(cpgrid, cp_xyz, cp_tri)
     samples, barycentres = ops.label_sampling_grid(sg_order, labeldist * mvdmax)
     centre = samples[0]
-    triplets = ops.estimate_triplets(cpgrid, cp_tri)
+    pairwise = optimiser == "fastpd"  # --regoption=1: the model lists pairs instead of triplets (M/DiscreteModel.cpp:40,98-101,258-259)
+    if pairwise and rmode != 1:
+        raise ValueError("MeshREG ERROR:: you cannot run higher order clique regularisers with fastPD ")  # M/mesh_registration.cpp:759-760
+    triplets = None if pairwise else ops.estimate_triplets(cpgrid, cp_tri)
+    pairs = ops.estimate_pairs(cpgrid, cp_tri, len(cp_xyz)) if pairwise else None
     cost = ops.cost(kind, simmeasure, rmode, cost_params, target, source, cpgrid, src_feat)  # set_meshes: _ORIG, _oCPgrid
     cost.set_spacings(maxsep, mvdmax)
     m_iter, m_scale = 1, 1.0
     energies, labelings = [], []
+    energy = 0.0
     sph_reg = np.array(sph_reg, dtype=np.float64)
     if cp_start is not None:
         cp_xyz = np.array(cp_start, dtype=np.float64)
@@ -225,7 +247,10 @@ def run_discrete_level(ops, target_xyz, target_tri, ref_feat, source_xyz, source
             labels = barycentres
         cost.set_labels(labels, rot)
         timed("get_source_data", cost.get_source_data)
-        cost.set_triplets(triplets)
+        if pairwise:
+            cost.set_pairs(pairs)
+        else:
+            cost.set_triplets(triplets)
         m_iter += 1
         unary = timed("unary_table", cost.unary_table)
         labeling = np.zeros(len(cp_xyz), dtype=np.int32)  # resetLabeling
@@ -239,10 +264,19 @@ def run_discrete_level(ops, target_xyz, target_tri, ref_feat, source_xyz, source
                     unary2 = np.stack([unary[labeling, nodes], unary[label]], axis=1)
                     x = timed("optimiser", ops.fusion_step, unary2, octets, triplets, icm_passes)
                     labeling = np.where((x == 1) & (labeling != label), label, labeling).astype(np.int32)
+        elif pairwise:  # --- FastPD: computeUnaryCosts, computePairwiseCosts, FPD::FastPD(model, 100) (M/mesh_registration.cpp:182-188)
+            paircosts = timed("pairwise_table", cost.pairwise_table)
+            labeling = timed("optimiser", ops.pairwise_solve, unary, paircosts, pairs, 100)
         else:  # --- MCMC: computeUnaryCosts, computeTripletCosts, optimise
             tcosts = timed("triplet_table", cost.triplet_table)
             labeling = timed("optimiser", ops.mcmc, unary, tcosts, triplets, labeling, mcparam, mciters, seed + it)
-        energies.append(timed("total_cost", cost.total, labeling))
+        newenergy = timed("total_cost", cost.total, labeling)
+        # the level's convergence test (M/mesh_registration.cpp:204-213): from the fourth iteration on, every second one, not for MCMC; the
+        # iteration that triggers it is not applied
+        if converge and it > 2 and (it - 1) % 2 == 0 and energy - newenergy < 0.001 and optimiser != "mcmc":
+            break
+        energy = newenergy
+        energies.append(newenergy)
         labelings.append(labeling)
         # --- applyLabeling, warp the source through the control grid move, unfold both
         new_cp = apply_labeling(rot, labels, labeling)
@@ -308,7 +342,8 @@ def run_multiresolution(ops, in_xyz, in_tri, in_data, ref_xyz, ref_tri, ref_data
         timed("unfold", ops.unfold, moved)
         sph_in = ops.coords(moved)
         kw = dict(level_kw)
-        kw.update({k: lv[k] for k in ("sg_order", "iters", "mciters", "cost_params", "kind", "rescale_labels", "optimiser") if k in lv})
+        kw.update({k: lv[k] for k in ("sg_order", "iters", "mciters", "mcparam", "cost_params", "kind", "rescale_labels", "optimiser", "simmeasure", "rmode",
+                                      "converge") if k in lv})
         if in_cfweight is not None and ref_cfweight is not None:
             kw["in_weight"] = ops.nearest_neighbour(in_mesh, in_cfweight, ico_xyz)
             kw["ref_weight"] = ops.nearest_neighbour(ref_mesh, ref_cfweight, ico_xyz)

@@ -203,6 +203,7 @@ void   orc_cost_triplet_octets(orc_cost *c, const int *labeling, int label, doub
 /* computeTripletCosts (:245-253): out[(t - t0) x L x L x L] */
 void   orc_cost_triplet_table(orc_cost *c, int t0, int t1, double *out);
 double orc_cost_pairwise(orc_cost *c, int pair, int la, int lb);
+void   orc_cost_pairwise_table(orc_cost *c, double *out /* P x L x L, [(pair * L + labelB) * L + labelA], :228-234 */);
 double orc_cost_total(orc_cost *c, const int *labeling, double parts[3]);
 /* number of patch point samples evaluated so far (for throughput accounting) */
 long   orc_cost_samples(const orc_cost *c);

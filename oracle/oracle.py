@@ -468,6 +468,13 @@ class Cost:
     def pairwise(self, p, la, lb):
         return lib().orc_cost_pairwise(self.h, int(p), int(la), int(lb))
 
+    def pairwise_table(self):
+        """paircosts[(pair * L + labelB) * L + labelA], computePairwiseCosts M/DiscreteCostFunction.cpp:228-234"""
+        L, P = self.L, self.P
+        out = np.zeros(P * L * L)
+        lib().orc_cost_pairwise_table(self.h, out.ctypes.data_as(c_dp))
+        return out
+
     def total(self, labeling):
         lab, pl = _i(labeling)
         parts = np.zeros(3)

@@ -863,6 +863,17 @@ double orc_cost_total(orc_cost *c, const int *labeling, double parts[3]) {
     return u + pw + tc;
 }
 
+/* computePairwiseCosts, M/DiscreteCostFunction.cpp:228-234: paircosts[(pair * L + labelB) * L + labelA] = computePairwiseCost(pair, labelA, labelB).
+ * The reference runs this serially because its computePairwiseCost moves the control grid in place; the restatement is functional, so the
+ * pairs are spread over threads. */
+void orc_cost_pairwise_table(orc_cost *c, double *out) {
+    const int L = c->L;
+#pragma omp parallel for schedule(static)
+    for (int p = 0; p < c->P; ++p)
+        for (int j = 0; j < L; ++j)
+            for (int k = 0; k < L; ++k) out[((size_t)p * L + k) * L + j] = orc_cost_pairwise(c, p, j, k);
+}
+
 /* computeTripletCosts, M/DiscreteCostFunction.cpp:245-253: tcosts[t][a][b][c] for t0 <= t < t1 */
 void orc_cost_triplet_table(orc_cost *c, int t0, int t1, double *out) {
     const int L = c->L;

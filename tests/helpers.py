@@ -105,6 +105,9 @@ class OracleOps:
     def estimate_triplets(self, mesh, tri):
         return O.estimate_triplets(mesh)
 
+    def estimate_pairs(self, mesh, tri, nodes):
+        return O.estimate_pairs(mesh)
+
     def label_sampling_grid(self, sg_order, max_dist):
         _, s, b = O.label_sampling_grid(O.Mesh(*O.icosphere(sg_order)), max_dist)
         return s, b
@@ -129,6 +132,11 @@ class OracleOps:
         from newmsm_amd import api  # the caller's stand-in solver (not part of the path), the same for both runs
 
         return api.fusion_icm_step(unary2, octets, triplets, passes, quads=quads, pairs=pairs)
+
+    def pairwise_solve(self, unary, paircosts, pairs, passes):
+        from newmsm_amd import api  # the caller's stand-in solver (not part of the path), the same for both runs
+
+        return api.pairwise_icm(unary, paircosts, pairs, passes=passes)
 
     def group(self, S, simmeasure, lambda_, fixnan):
         return _OracleGroup(O.Group(S, simmeasure=simmeasure, lambda_=lambda_, fixnan=fixnan))
@@ -202,6 +210,14 @@ class _OracleCost:
 
     def set_triplets(self, triplets):
         self.c.set_triplets(triplets)
+        self.c.set_pairs(np.zeros((0, 2), dtype=np.int32))
+
+    def set_pairs(self, pairs):
+        self.c.set_pairs(pairs)
+        self.c.set_triplets(np.zeros((0, 3), dtype=np.int32))
+
+    def pairwise_table(self):
+        return self.c.pairwise_table()
 
     def get_source_data(self):
         self.c.get_source_data()

@@ -158,3 +158,49 @@ def test_full_size_msmall_schedule_matches_oracle(ctx):
     assert r["labelings"] == 6 and r["labelings_identical"], r
     assert r["max_angle_rad"] <= NORTH_STAR_TOL_RAD and r["moved_rad"] > 1e-3, r
     assert r["energies_rel_diff"] < 1e-9, r
+
+
+def test_pairwise_regoption1_level_matches_oracle(ctx):
+    """--regoption=1 as --dopt=FastPD drives it (M/mesh_registration.cpp:182-188; BASELINE config 1's shape): per iteration the unary table and
+    the P x L x L pair tables (computePairwiseCosts), then a stand-in for FPD::FastPD (iterated conditional modes, the same for both runs)"""
+    xyz, tri, ref, src = level_inputs(4, 1, seed=23)
+    kw = dict(cp_order=2, iters=3, seed=5, kind="univariate", rmode=1, cost_params=dict(lambda_=0.1, rexp=2.0), optimiser="fastpd")
+    t = {}
+    got = registration.run_discrete_level(registration.ProductOps(ctx), xyz, tri, ref, xyz, tri, src, xyz, timings=t, **kw)
+    want = registration.run_discrete_level(OracleOps(M.mcmc_optimise), xyz, tri, ref, xyz, tri, src, xyz, **kw)
+    assert len(got[3]) == 3 and "pairwise_table" in t and "triplet_table" not in t and "fusion_moves" not in t
+    for a, b in zip(got[3], want[3]):
+        assert np.array_equal(a, b)
+    assert np.allclose(got[2], want[2], rtol=1e-9)
+    assert angles(got[0], xyz).max() > 1e-3 and any(l.any() for l in got[3])
+    assert angles(got[0], want[0]).max() <= NORTH_STAR_TOL_RAD and np.abs(got[0] - want[0]).max() < 1e-9
+    with pytest.raises(ValueError, match="higher order clique regularisers with fastPD"):
+        registration.run_discrete_level(registration.ProductOps(ctx), xyz, tri, ref, xyz, tri, src, xyz, cp_order=2, rmode=3, optimiser="fastpd")
+
+
+def test_config_driven_registration_matches_oracle(ctx):
+    """a configuration in the reference's grammar (the keys of config/basic_configs/config_standard_MSMpair, smaller grids) -> levels ->
+    run_multiresolution over both paths; the AFFINE level is reported as skipped"""
+    from newmsm_amd import config
+
+    text = """
+--sigma_in=4,4,2
+--sigma_ref=4,4,2
+--lambda=0,0.1,0.2
+--it=50,2,2
+--opt=AFFINE,DISCRETE,DISCRETE
+--CPgrid=0,1,2
+--SGgrid=0,3,4
+--datagrid=3,3,4
+--regoption=1
+"""
+    levels, run_kw, skipped = config.levels_from_config(config.parse_config(text), D=1)
+    assert skipped == [(0, "AFFINE")] and len(levels) == 2
+    in_xyz, in_tri = M.make_mesh_from_icosa(4)
+    ref = synthetic.features(in_xyz, 1, 51)
+    src = synthetic.features(synthetic.known_warp(in_xyz, seed=53, rot_deg=4.0, amp=2.5), 1, 51)
+    lg, lw = [], []
+    got = registration.run_multiresolution(registration.ProductOps(ctx), in_xyz, in_tri, src, in_xyz, in_tri, ref, levels, labelings_out=lg, **run_kw)
+    want = registration.run_multiresolution(OracleOps(M.mcmc_optimise), in_xyz, in_tri, src, in_xyz, in_tri, ref, levels, labelings_out=lw, **run_kw)
+    assert len(lg) == 4 and all(np.array_equal(a, b) for a, b in zip(lg, lw))
+    assert angles(got[0], want[0]).max() <= NORTH_STAR_TOL_RAD and angles(got[0], in_xyz).max() > 1e-3
