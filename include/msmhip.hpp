@@ -288,6 +288,13 @@ inline std::vector<int32_t> fusion_icm_step(int num_nodes, const std::vector<dou
     return x;
 }
 
+// The stand-in for FPD::FastPD on the multi-label pairwise MRF of --regoption=1 (msm_pairwise_icm: iterated conditional modes): unary L x N,
+// paircosts P x L x L as computePairwiseCosts fills it, labeling in (the start) and out.
+inline void pairwise_icm(const Matrix &unary_costs, const Matrix &paircosts, const std::vector<int32_t> &pairs, int num_nodes, int num_labels,
+                         std::vector<int32_t> &labeling, int max_passes = 100) {
+    check(msm_pairwise_icm(unary_costs.data(), paircosts.data(), pairs.data(), num_nodes, num_labels, (int32_t)(pairs.size() / 2), max_passes, labeling.data()));
+}
+
 // ---------------------------------------------------------------- discrete cost function
 struct Parameters {  // what set_parameters reads from the myparam map, M/DiscreteCostFunction.cpp:119-133
     int kind = MSM_COST_UNIVARIATE;

@@ -28,6 +28,9 @@ struct LevelOptions {
     // licence-restricted binary solve (msm_fusion_icm_step, icm_passes passes): the path is exercised as HOCR would, the result is not HOCR's
     bool fusion = false;
     int icm_passes = 5;
+    // true: --regoption=1 as --dopt=FastPD drives it (M/mesh_registration.cpp:182-188): the model lists pairs instead of triplets, per iteration
+    // computeUnaryCosts + computePairwiseCosts, then a stand-in for FPD::FastPD(model, 100) (msm_pairwise_icm)
+    bool pairwise = false;
 };
 
 struct LevelResult {
@@ -59,7 +62,9 @@ inline LevelResult run_discrete_opt(Context &ctx, const Points &target_xyz, cons
     auto [MAXSEP, MVDmax] = cp_spacings(cp_xyz, cp_tri);
     auto [samples, barycentres] = label_sampling_grid(o.sg_order < 0 ? cp_order + 2 : o.sg_order, o.labeldist * MVDmax);
     const double centre[3] = {samples[0], samples[1], samples[2]};
-    const std::vector<int32_t> triplets = estimate_triplets(cp_tri);
+    if (o.pairwise && o.cost.regularisermode != 1) throw Error(MSM_ERR_INVALID, "MeshREG ERROR:: you cannot run higher order clique regularisers with fastPD ");
+    const std::vector<int32_t> triplets = o.pairwise ? std::vector<int32_t>() : estimate_triplets(cp_tri);
+    const std::vector<int32_t> pairs = o.pairwise ? estimate_pairs(cp_tri, (int)(cp_xyz.size() / 3)) : std::vector<int32_t>();
     DiscreteCostFunction costfct(ctx, o.cost);
     costfct.set_meshes(TARGET, SOURCE, CPGRID);  // _ORIG, _oCPgrid
     costfct.set_featurespace(src_feat, D);
@@ -82,7 +87,8 @@ inline LevelResult run_discrete_opt(Context &ctx, const Points &target_xyz, cons
         else labels = (m_iter % 2 == 0) ? samples : barycentres;
         costfct.set_labels(labels, ROT);
         costfct.get_source_data();
-        costfct.setTriplets(triplets);
+        if (o.pairwise) costfct.setPairs(pairs);
+        else costfct.setTriplets(triplets);
         ++m_iter;
         costfct.computeUnaryCosts();
         std::vector<int32_t> labeling((size_t)N, 0);  // resetLabeling
@@ -105,6 +111,9 @@ inline LevelResult run_discrete_opt(Context &ctx, const Points &target_xyz, cons
                     for (int i = 0; i < N; ++i)
                         if (x[(size_t)i] == 1 && labeling[(size_t)i] != label) labeling[(size_t)i] = label;
                 }
+        } else if (o.pairwise) {  // ---- FastPD: computeUnaryCosts, computePairwiseCosts, the solve
+            costfct.computePairwiseCosts();
+            pairwise_icm(costfct.unarycosts, costfct.paircosts, pairs, N, L, labeling, 100);
         } else {  // ---- MCMC: computeUnaryCosts, computeTripletCosts, optimise
             const std::vector<double> tcosts = costfct.computeTripletCosts();
             mcmc_optimise(costfct.unarycosts, tcosts, triplets, N, L, o.mcparam, o.mciters, o.seed + (uint64_t)it, labeling);

@@ -60,6 +60,10 @@ int main(int argc, char **argv) {
             o.cost.kind = D > 1 ? MSM_COST_HO_MULTIVARIATE : MSM_COST_HO_UNIVARIATE;
             o.cost.shearmodulus = 0.4, o.cost.bulkmodulus = 1.6, o.cost.kexponent = 2.0, o.cost.exponent = 2.0;
         }
+        if (I["orders"].size() > 8 && I["orders"][8] != 0) {  // --regoption=1 as --dopt=FastPD drives it: unary + pair tables, stand-in solve
+            o.pairwise = true;
+            o.cost.regularisermode = 1;
+        }
         const LevelResult r = run_discrete_opt(ctx, xyz, tri, F["ref_feat"], xyz, tri, F["src_feat"], D, xyz, cp_order, o);
         std::ofstream out(argv[2], std::ios::binary);
         put(out, "sph_reg", "f8", r.sph_reg);

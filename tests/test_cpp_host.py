@@ -111,6 +111,30 @@ def test_cpp_level_driver_fusion_loop_equals_python_loop(built, ctx, tmp_path, D
 
 
 @pytest.mark.gpu
+def test_cpp_level_driver_pairwise_loop_equals_python_loop(built, ctx, tmp_path):
+    """LevelOptions::pairwise (--regoption=1 as --dopt=FastPD drives it: computeUnaryCosts, computePairwiseCosts, the stand-in solve): identical
+    to registration.run_discrete_level(optimiser="fastpd")"""
+    import newmsm_amd as M
+    from newmsm_amd import registration, synthetic
+
+    build_cpp(LEVEL_SRC, LEVEL_EXE)
+    xyz, tri = M.make_mesh_from_icosa(4)
+    ref = synthetic.features(xyz, 1, 21)
+    src = synthetic.features(synthetic.known_warp(xyz, seed=23, rot_deg=4.0, amp=2.5), 1, 21)
+    fin, fout = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+    write_bag(fin, orders=np.array([4, 2, 1, 3, 0, 5, 0, 0, 1]), params=np.array([0.3, 0.1]), ref_feat=ref, src_feat=src)
+    run = subprocess.run([LEVEL_EXE, fin, fout], capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0, run.stderr + run.stdout
+    got = read_bag(fout)
+    want = registration.run_discrete_level(registration.ProductOps(ctx), xyz, tri, ref, xyz, tri, src, xyz, cp_order=2, iters=3, seed=5, kind="univariate",
+                                           rmode=1, optimiser="fastpd", cost_params=dict(lambda_=0.1))
+    assert np.array_equal(got["labelings"].reshape(3, -1), np.array(want[3]))
+    assert np.array_equal(got["energies"], np.array(want[2]))
+    assert np.array_equal(got["sph_reg"].reshape(-1, 3), want[0]) and np.array_equal(got["cpgrid"].reshape(-1, 3), want[1])
+    assert any(l.any() for l in want[3])
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("D", [1, 3])
 def test_cpp_host_mirror_against_oracle(built, tmp_path, D):
     build_host_mirror()
