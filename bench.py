@@ -258,7 +258,26 @@ GMSM_LEVELS = [(4, 2), (5, 3), (6, 4)]  # --datagrid / --CPgrid of the gMSM conf
 GMSM_ITERATIONS = 9                      # --it=9,9,9
 
 
-def gmsm_iteration(ctx, S, data_order, cp_order, comm, label_steps):
+GMSM_PMC_PROFILE = os.path.join("profiles", "r3_gstep_pmc.json")  # CHANGE=1 tools/collect_group_profile.sh r3_gstep 64: the bench's own label-step workload
+FP64_VALU_PEAK = 1024 * 2.4e9 / 4  # wave-instructions/s: 256 CUs x 4 SIMDs, a 64-lane FP64 (or any full-rate VALU) instruction every 4 cycles at 2.4 GHz
+                                   # (MI355X_MICROARCH.md: 78.6 TFLOP/s FP64 vector = this x 64 lanes x 2 flops)
+
+
+def gmsm_valu_profile(S, data_order, cp_order):
+    """VALU wave-instructions of k_group_pairwise per label step from the committed rocprofv3 PMC passes (SQ_INSTS_VALU per launch x launches
+    per step), valid for the profiled configuration only: 64 subjects, ico6 / ico4, the bench's label-change model."""
+    if (S, data_order, cp_order) != (64, 6, 4):
+        return None
+    try:
+        with open(os.path.join(ROOT, GMSM_PMC_PROFILE)) as f:
+            prof = json.load(f)
+        k = [v for name, v in prof["kernels"].items() if "k_group_pairwise" in name][0]
+        return {"per_launch": k["per_launch_mean"]["SQ_INSTS_VALU"], "launches_per_step": k["launches_per_step"], "kernel_avg_ns": k["kernel_avg_ns_from_kernel_stats"]}
+    except (OSError, KeyError, IndexError, ValueError):
+        return None
+
+
+def gmsm_iteration(ctx, S, data_order, cp_order, comm, label_steps, change=0.10):
     """One iteration of group registration at one level: setupCostFunction (M/DiscreteGroupModel.cpp:163-196) + the cost evaluations of
     Fusion::optimize (2 sweeps x L label steps, I/Fusion/Fusion.h:138-196).  Returns (set-up s, per-label-step s, steps in an iteration)."""
     import numpy as np
@@ -275,6 +294,7 @@ def gmsm_iteration(ctx, S, data_order, cp_order, comm, label_steps):
     comm.barrier()
     setup_s = time.perf_counter() - t0
     mover = D.ShardedMove(g, comm)
+    change_fraction = change
     rng = np.random.default_rng(3)
     lab = rng.integers(0, g.L, g.num_nodes).astype(np.int32)
     mover.move(lab, 1)
@@ -282,7 +302,7 @@ def gmsm_iteration(ctx, S, data_order, cp_order, comm, label_steps):
     # library keeps the (current, current) pair costs of the pairs whose two nodes did not change)
     labs = []
     for i in range(label_steps):
-        change = rng.random(g.num_nodes) < 0.10
+        change = rng.random(g.num_nodes) < change_fraction
         lab = np.where(change, rng.integers(0, g.L, g.num_nodes), lab).astype(np.int32)
         labs.append(lab)
     # an iteration is two sweeps over the labels (I/Fusion/Fusion.h:136-138): half of its steps propose a label for the second time, and
@@ -295,27 +315,54 @@ def gmsm_iteration(ctx, S, data_order, cp_order, comm, label_steps):
         q, o = mover.move(labs[i % len(labs)], proposed[i])
     comm.barrier()
     step_s = (time.perf_counter() - t0) / (2 * half)
-    sizes = dict(L=g.L, pairs=g.P, triplets=g.T, nodes=g.num_nodes)
+    # the same steps once more with HIP events around each step's kernels (on the context's stream): the GPU time of a label step
+    g.time_moves(True)
+    kms = []
+    for i in range(2 * half):
+        mover.move(labs[i % len(labs)], proposed[i])
+        kms.append(g.move_kernels_ms())
+    g.time_moves(False)
+    sizes = dict(L=g.L, pairs=g.P, triplets=g.T, nodes=g.num_nodes, step_kernels_s=float(np.mean(kms)) * 1e-3 if kms and min(kms) >= 0 else None)
+    mover.close()
     g.close()
     return setup_s, step_s, 2 * sizes["L"], sizes
 
 
-def bench_gmsm(ctx, S, comm, label_steps=6):
+def bench_gmsm(ctx, S, comm, label_steps=6, change=0.10):
     from newmsm_amd import dist as D
 
-    levels, total = [], 0.0
+    levels, total, roofline = [], 0.0, None
     for data_order, cp_order in GMSM_LEVELS:
-        setup_s, step_s, steps, sizes = gmsm_iteration(ctx, S, data_order, cp_order, comm, label_steps)
+        setup_s, step_s, steps, sizes = gmsm_iteration(ctx, S, data_order, cp_order, comm, label_steps, change)
         setup_s, step_s = D.max_over_ranks(setup_s, comm), D.max_over_ranks(step_s, comm)
         it_s = setup_s + steps * step_s
         total += GMSM_ITERATIONS * it_s
-        levels.append({"data_order": data_order, "cp_order": cp_order, "setup_s": setup_s, "label_step_s": step_s, "label_steps_per_iteration": steps,
-                       "iteration_s": it_s, "pair_evals_per_step": 4 * sizes["pairs"], "triplet_evals_per_step": 8 * sizes["triplets"]})
-    return {"subjects": S, "levels": levels, "iterations_per_level": GMSM_ITERATIONS, "path_s_per_group": total, "subjects_per_hour": S / total * 3600.0,
+        levels.append({"data_order": data_order, "cp_order": cp_order, "setup_s": setup_s, "label_step_s": step_s, "label_step_kernels_s": sizes["step_kernels_s"],
+                       "label_steps_per_iteration": steps, "iteration_s": it_s, "pair_evals_per_step": 4 * sizes["pairs"], "triplet_evals_per_step": 8 * sizes["triplets"]})
+        prof = gmsm_valu_profile(S, data_order, cp_order) if comm.world == 1 and change == 0.10 else None
+        if prof and sizes["step_kernels_s"]:
+            # the label step is bound by FP64 / integer vector issue, not by HBM (0.61 GB per launch = 0.06 of the HBM roofline): achieved =
+            # the pair kernel's VALU wave-instructions per step (counters of the committed profile) / this run's GPU time of a step
+            per_step = prof["per_launch"] * prof["launches_per_step"]
+            achieved = per_step / sizes["step_kernels_s"]
+            roofline = {"bound": "fp64_valu", "achieved": achieved / 1e9, "peak": FP64_VALU_PEAK / 1e9, "unit": "G wave-instructions/s", "frac": achieved / FP64_VALU_PEAK,
+                        "frac_per_step_delivered": per_step / step_s / FP64_VALU_PEAK, "kernel": "msm::k_group_pairwise",
+                        "valu_wave_instructions_per_label_step": per_step, "source": GMSM_PMC_PROFILE + ": SQ_INSTS_VALU per launch x launches per step",
+                        "step_kernels_ms_events": sizes["step_kernels_s"] * 1e3, "kernel_avg_ms_rocprof": prof["kernel_avg_ns"] * 1e-6,
+                        "level": "ico%d / ico%d" % (data_order, cp_order),
+                        "note": "a step's GPU time (HIP events around its kernels on the launch stream) also holds the strain triplets and the kept-cost copies"}
+    out = {"subjects": S, "levels": levels, "iterations_per_level": GMSM_ITERATIONS, "path_s_per_group": total, "subjects_per_hour": S / total * 3600.0,
+           "config": {"label_change_fraction": change, "label_steps_timed": label_steps,
+                      "model": "between label steps that fraction of the nodes changes its label (the library keeps the (current, current) costs of untouched pairs); half of the "
+                               "timed steps are second visits of their label, as in the two sweeps of an iteration (I/Fusion/Fusion.h:136-138)"}}
+    if roofline:
+        out["roofline"] = roofline
+    out.update({
             "definition": "cost-function side of a groupwise registration (docs/guide.md:390-407: 3 levels x 9 iterations): per iteration one "
                           "setupCostFunction (get_patch_data for every subject) + 2 x L label steps of 4 P pair + 8 T triplet costs delivered to the optimiser's "
-                          "rank; measured on one iteration per level (set-up: the second call, buffers allocated) and %d label steps (half of them second visits of their label, as in the two sweeps of an iteration) with 10 %% of the nodes changing their label between steps.  The MRF solve (ELC / FastPD, licence-restricted, serial) is not "
-                          "part of the path and not in this figure" % label_steps}
+                          "rank; measured on one iteration per level (set-up: the second call, buffers allocated) and %d label steps (half of them second visits of their label, as in the two sweeps of an iteration) with config.label_change_fraction of the nodes changing their label between steps.  The MRF solve (ELC / FastPD, licence-restricted, serial) is not "
+                          "part of the path and not in this figure" % label_steps})
+    return out
 
 
 def main():
@@ -328,6 +375,7 @@ def main():
     ap.add_argument("--cp-order", type=int, default=4)
     ap.add_argument("--dims", type=int, default=1)
     ap.add_argument("--subjects", type=int, default=64)
+    ap.add_argument("--label-change", type=float, default=0.10, help="gMSM: fraction of the nodes whose label changes between two label steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="headline line only (profiling runs)")
     args = ap.parse_args()
@@ -368,7 +416,7 @@ def main():
         # (ico6 / ico4); --warmup iterations untimed, --steps timed ones are folded into the per-level measurement (set-up once per level)
         sync_all()
         t0 = time.perf_counter()
-        res = bench_gmsm(ctx, args.subjects, comm, label_steps=max(2, min(args.steps, 8)))
+        res = bench_gmsm(ctx, args.subjects, comm, label_steps=max(2, min(args.steps, 8)), change=args.label_change)
         sync_all()
         if rank == 0:
             last = res["levels"][-1]
@@ -437,7 +485,7 @@ def main():
     gmsm_scaling = None
     if world > 1 and not args.no_extras and os.environ.get("MSM_BENCH_GMSM_SCALING", "1") != "0":
         try:
-            gmsm_scaling = bench_gmsm(ctx, args.subjects, comm)
+            gmsm_scaling = bench_gmsm(ctx, args.subjects, comm, change=args.label_change)
             gmsm_scaling["scaling"] = "strong"
         except Exception as e:  # reported, not fatal: the headline of this run stands
             gmsm_scaling = {"error": repr(e)}
@@ -492,7 +540,7 @@ def main():
                 out["registration"] = bench_registration(ctx, check=chk)
                 out["registration_fusion"] = bench_registration(ctx, "fusion", check=chk)
                 out["registration_msmall"] = bench_registration_msmall(ctx, check=chk)
-                out["gmsm"] = bench_gmsm(ctx, args.subjects, comm)
+                out["gmsm"] = bench_gmsm(ctx, args.subjects, comm, change=args.label_change)
         if world == 1 and not args.no_cpu_baseline:
             Uo, rate, dt, reps = cpu_baseline(inp, kind, threads)
             out["cpu_baseline"] = {

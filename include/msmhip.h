@@ -385,6 +385,11 @@ int msm_group_fusion_move(msm_group *g, const int32_t *labeling, int32_t label, 
  * the buffer order of msm_group_fusion_move. */
 int msm_group_fusion_move_dev(msm_group *g, const int32_t *labeling, int32_t label, int64_t pair0, int64_t pair1, int64_t trip0, int64_t trip1,
                               double *quads_dev, double *octets_dev);
+/* Optional HIP-event timing of a label step's kernels (everything msm_group_fusion_move / _dev queue on the context's stream for one
+ * step: the pair passes, the kept-cost copies, the triplets), for bench.py's gmsm roofline: msm_group_move_kernels_ms returns the most recent
+ * step's GPU time in milliseconds (-1 when none was timed). */
+int msm_group_time_moves(msm_group *g, int enable);
+int msm_group_move_kernels_ms(msm_group *g, double *ms);
 
 #ifdef __cplusplus
 }

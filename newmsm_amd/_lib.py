@@ -123,6 +123,8 @@ SIGNATURES = {
     "msm_group_create": (_VP, [_VP, C.POINTER(GroupParams), C.c_int32]),
     "msm_group_fusion_move": (C.c_int, [_VP, c_ip, C.c_int32, c_dp, c_dp]),
     "msm_group_destroy": (None, [_VP]),
+    "msm_group_time_moves": (C.c_int, [_VP, C.c_int]),
+    "msm_group_move_kernels_ms": (C.c_int, [_VP, c_dp]),
     "msm_group_set_template": (C.c_int, [_VP, _VP, c_dp]),
     "msm_group_set_controlgrid": (C.c_int, [_VP, c_dp, c_ip, C.c_int32, C.c_int32]),
     "msm_group_set_subject": (C.c_int, [_VP, C.c_int32, _VP, c_dp, C.c_int32]),

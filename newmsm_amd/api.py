@@ -729,6 +729,15 @@ class DiscreteGroupCostFunction:
         check(lib().msm_group_fusion_move_dev(self.h, pl, int(label), int(pair_range[0]), int(pair_range[1]), int(triplet_range[0]), int(triplet_range[1]),
                                               C.c_void_p(quads_ptr), C.c_void_p(octets_ptr)))
 
+    def time_moves(self, on=True):
+        """HIP events around the kernels of every label step (msm_group_time_moves)"""
+        check(lib().msm_group_time_moves(self.h, int(on)))
+
+    def move_kernels_ms(self):
+        ms = C.c_double(-1.0)
+        check(lib().msm_group_move_kernels_ms(self.h, C.byref(ms)))
+        return ms.value
+
     def finalize(self):
         check(lib().msm_group_finalize(self.h))
         n, p, t = C.c_int32(), C.c_int32(), C.c_int32()

@@ -114,6 +114,9 @@ struct msm_group {
         std::fill(e11_have.begin(), e11_have.end(), (unsigned char)0);
     }
     std::vector<int64_t> order_chunk;    // the slice's order is cut into pieces by OUTPUT range: piece k holds the pairs [order_chunk[k], order_chunk[k+1]) of the slice
+    // msm_group_time_moves: HIP events around the kernels of a label step on the context's stream
+    hipEvent_t t_ev0 = nullptr, t_ev1 = nullptr;
+    bool timing = false, timed = false;
     hipStream_t copy_stream = nullptr;   // the finished pieces of a label step leave for the host while the next ones are computed
     std::vector<hipEvent_t> copy_events;
     // scratch of subject_patches, kept between subjects
@@ -371,6 +374,8 @@ void msm_group_destroy(msm_group *g) {
         (void)hipStreamDestroy(g->copy_stream);
     }
     for (hipEvent_t e : g->copy_events) (void)hipEventDestroy(e);
+    if (g->t_ev0) (void)hipEventDestroy(g->t_ev0);
+    if (g->t_ev1) (void)hipEventDestroy(g->t_ev1);
     delete g;
 }
 
@@ -1342,7 +1347,7 @@ static int slice_pair_order(msm_group *g, int64_t pair0, int64_t pair1, const in
 
 // the evaluations of a (slice of a) label step, queued on the stream; results in device memory
 // after_piece(k, lo, hi): the kernels of piece k (pairs [pair0 + lo, pair0 + hi) of the output) have been queued; k = -1: the triplets
-static int group_move_compute(msm_group *g, const int32_t *labeling, int32_t label, int64_t pair0, int64_t pair1, int64_t trip0, int64_t trip1,
+static int group_move_compute_untimed(msm_group *g, const int32_t *labeling, int32_t label, int64_t pair0, int64_t pair1, int64_t trip0, int64_t trip1,
                               double *quads_dev, double *octets_dev, const char *who, const std::function<int(int, int64_t, int64_t)> *after_piece = nullptr) {
     GroupArgs a;
     int st = group_args(g, a);
@@ -1458,6 +1463,18 @@ static int group_move_compute(msm_group *g, const int32_t *labeling, int32_t lab
         a.move_e11 = nullptr;
     }
     return triplets_last ? triplets() : MSM_OK;
+}
+
+// the same between two events when the caller asked for the kernels' time (msm_group_time_moves; bench.py's gmsm roofline)
+static int group_move_compute(msm_group *g, const int32_t *labeling, int32_t label, int64_t pair0, int64_t pair1, int64_t trip0, int64_t trip1,
+                              double *quads_dev, double *octets_dev, const char *who, const std::function<int(int, int64_t, int64_t)> *after_piece = nullptr) {
+    if (!g->timing) return group_move_compute_untimed(g, labeling, label, pair0, pair1, trip0, trip1, quads_dev, octets_dev, who, after_piece);
+    MSM_HIP(hipEventRecord(g->t_ev0, g->ctx->stream));
+    const int st = group_move_compute_untimed(g, labeling, label, pair0, pair1, trip0, trip1, quads_dev, octets_dev, who, after_piece);
+    if (st) return st;
+    MSM_HIP(hipEventRecord(g->t_ev1, g->ctx->stream));
+    g->timed = true;
+    return MSM_OK;
 }
 
 // the copy stream and its events (one per piece + one for the triplets)
@@ -1594,6 +1611,29 @@ int msm_group_fusion_move_dev(msm_group *g, const int32_t *labeling, int32_t lab
     const int st = group_fusion_move_dev_impl(g, labeling, label, pair0, pair1, trip0, trip1, quads_dev, octets_dev);
     if (st && g) g->drop_kept();
     return st;
+}
+
+int msm_group_time_moves(msm_group *g, int enable) {
+    if (!g) return fail(MSM_ERR_INVALID, "null group");
+    (void)hipSetDevice(g->ctx->device);
+    if (enable && !g->t_ev0) {
+        MSM_HIP(hipEventCreate(&g->t_ev0));
+        MSM_HIP(hipEventCreate(&g->t_ev1));
+    }
+    g->timing = enable != 0;
+    g->timed = false;
+    return MSM_OK;
+}
+
+int msm_group_move_kernels_ms(msm_group *g, double *ms) {
+    if (!g || !ms) return fail(MSM_ERR_INVALID, "msm_group_move_kernels_ms: null argument");
+    *ms = -1.0;
+    if (!g->timed) return MSM_OK;
+    MSM_HIP(hipEventSynchronize(g->t_ev1));
+    float f = 0.f;
+    MSM_HIP(hipEventElapsedTime(&f, g->t_ev0, g->t_ev1));
+    *ms = f;
+    return MSM_OK;
 }
 
 int msm_group_triplet_batch(msm_group *g, const int32_t *t, const int32_t *la, const int32_t *lb, const int32_t *lc, int32_t n, double *out) {

@@ -12,4 +12,5 @@ run --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_${tag}
 run --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d gpurun_out/pmc_${tag}_4 || exit 1
 run --kernel-trace --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/pmc_${tag}_5 || exit 1
 cp "$(find gpurun_out/prof_$tag -name '*kernel_stats.csv' | head -1)" gpurun_out/${tag}_kernel_stats.csv
-python3 tools/summarise_pmc.py $tag msm::k_group "$B"
+# tools/time_group_step.py runs 4 delivery variants x (1 + 5 + 5) label steps
+MSM_PROFILE_STEPS=44 python3 tools/summarise_pmc.py $tag msm::k_group "${CHANGE:+CHANGE=$CHANGE }$B"

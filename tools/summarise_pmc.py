@@ -18,9 +18,13 @@ for d in sorted(glob.glob("gpurun_out/pmc_%s_*" % tag)):
             acc[(r["Kernel_Name"].split("(")[0], r["Counter_Name"])].append(float(r["Counter_Value"]))
         for (k, c), v in acc.items():
             per[k][c] = sum(v) / len(v)
-avg_ns = {}
+import os
+
+avg_ns, calls = {}, {}
 for r in csv.DictReader(open("gpurun_out/%s_kernel_stats.csv" % tag)):
     avg_ns[r["Name"].split("(")[0]] = float(r["AverageNs"])
+    calls[r["Name"].split("(")[0]] = int(r["Calls"])
+steps = int(os.environ.get("MSM_PROFILE_STEPS", "0"))  # label steps the profiled command ran (tools/collect_group_profile.sh): launches per step
 out = {
     "command": "rocprofv3 --kernel-trace --pmc <one counter set per pass> -- " + command,
     "traffic_formula": "(2 * FETCH_SIZE + WRITE_SIZE) * 1024: FETCH_SIZE/WRITE_SIZE are reported in KiB; gfx950 FETCH_SIZE counts "
@@ -30,7 +34,9 @@ out = {
 for k, v in per.items():
     if prefix not in k:
         continue
-    e = {"per_launch_mean": v, "kernel_avg_ns_from_kernel_stats": avg_ns.get(k)}
+    e = {"per_launch_mean": v, "kernel_avg_ns_from_kernel_stats": avg_ns.get(k), "calls_in_stats_pass": calls.get(k)}
+    if steps and calls.get(k):
+        e["launches_per_step"] = calls[k] / steps
     if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
         e["hbm_traffic_bytes_per_launch"] = (2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024
     out["kernels"][k] = e
