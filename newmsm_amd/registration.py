@@ -99,6 +99,7 @@ class ProductOps:
 class _ProductCost:
     def __init__(self, cf):
         self.cf = cf
+        self._octets = None
 
     def reset_source(self, mesh):
         self.cf.reset_source(mesh)
@@ -134,8 +135,11 @@ class _ProductCost:
         return self.cf.computeTripletCosts(pinned=True)  # consumed by the optimiser before the next table is computed
 
     def triplet_octets(self, labeling, label):
-        # the optimiser's per-step buffer: mapped pinned memory the kernel writes (one grow-only buffer per context, consumed before the next step)
-        return self.cf.tripletOctets(labeling, label, self.cf.ctx.scratch_host_array("octets", (self.cf.T, 8)))
+        # the optimiser's per-step buffer: mapped pinned memory the kernel writes (one grow-only buffer per context, consumed before the next
+        # step); the numpy view is made once per set of triplets, not once per label step
+        if self._octets is None or self._octets.shape[0] != self.cf.T:
+            self._octets = self.cf.ctx.scratch_host_array("octets", (self.cf.T, 8))
+        return self.cf.tripletOctets(labeling, label, self._octets)
 
     def total(self, labeling):
         return self.cf.evaluateTotalCostSum(labeling)[0]

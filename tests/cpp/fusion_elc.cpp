@@ -9,6 +9,7 @@
 //      three with the real PBF: identical labelings, step energies and change counts.
 // Prints one JSON line.
 #include <cstdio>
+#include <string>
 
 #include <ELC/ELC.h>
 
@@ -63,8 +64,62 @@ static int check_converted_models(int N, int L, int label, long &aux, long &edge
     return bad;
 }
 
+// What the reference's reduction costs per label step at the size of BASELINE configs 2 - 4 (ico4 control grid: 2 562 nodes, 5 120 control
+// triangles, no pairs): AddUnaryTerm / AddHigherTerm for every clique, toQuadratic (HOCR), convert into the array model, initialise.  The costs
+// are synthetic (hash), the sizes and the call sequence are those of I/Fusion/Fusion.h:157-217.  CPU only; the solve (FastPD) is not included.
+#include <chrono>
+static void time_reduction(int N, int T, int reps, double &assemble_ms, double &reduce_ms, double &convert_ms, long &aux, long &edges) {
+    using clk = std::chrono::steady_clock;
+    std::vector<int> trip((size_t)3 * T);
+    for (int t = 0; t < T; ++t) {  // ascending triples spread over the nodes, each node in about six of them (an icosphere's valence)
+        int a = (int)(((long long)t * 2654435761ll) % N), b = (a + 1 + t % 7) % N, c = (a + 9 + t % 11) % N;
+        int v[3] = {a, b, c};
+        std::sort(v, v + 3);
+        if (v[0] == v[1]) v[1] = (v[1] + 1) % N;
+        if (v[1] == v[2] || v[0] == v[2]) v[2] = (std::max(v[0], v[1]) + 1) % N;
+        std::sort(v, v + 3);
+        trip[3 * (size_t)t] = v[0], trip[3 * (size_t)t + 1] = v[1], trip[3 * (size_t)t + 2] = v[2];
+    }
+    FlatModel f;
+    assemble_ms = reduce_ms = convert_ms = 0;
+    for (int r = 0; r < reps; ++r) {
+        auto t0 = clk::now();
+        PBF pbf;
+        for (int i = 0; i < N; ++i) pbf.AddUnaryTerm(i, hash_cost(1, i, r, 0, 0), hash_cost(1, i, r, 1, 0));
+        for (int t = 0; t < T; ++t) {
+            if (trip[3 * (size_t)t] == trip[3 * (size_t)t + 1] || trip[3 * (size_t)t + 1] == trip[3 * (size_t)t + 2]) continue;
+            double E[8];
+            for (int k = 0; k < 8; ++k) E[k] = 0.5 * hash_cost(3, t, r, k, 0);
+            pbf.AddHigherTerm(3, &trip[3 * (size_t)t], E);
+        }
+        auto t1 = clk::now();
+        PBF q;
+        pbf.toQuadratic(q, pbf.maxID() + 1);
+        auto t2 = clk::now();
+        f.reset();
+        q.convert(f, q.maxID() + 1);
+        pbf.clear();
+        q.clear();
+        f.initialise();
+        auto t3 = clk::now();
+        assemble_ms += std::chrono::duration<double, std::milli>(t1 - t0).count();
+        reduce_ms += std::chrono::duration<double, std::milli>(t2 - t1).count();
+        convert_ms += std::chrono::duration<double, std::milli>(t3 - t2).count();
+        aux = f.getNumNodes() - N, edges = f.getNumPairs();
+    }
+    assemble_ms /= reps, reduce_ms /= reps, convert_ms /= reps;
+}
+
 int main(int argc, char **argv) {
     const int threads = argc > 1 ? std::atoi(argv[1]) : 4;
+    if (argc > 2 && std::string(argv[2]) == "time") {
+        double a, r, c;
+        long aux, edges;
+        time_reduction(2562, 5120, 20, a, r, c, aux, edges);
+        std::printf("{\"nodes\": 2562, \"triplets\": 5120, \"assemble_ms\": %.3f, \"toQuadratic_ms\": %.3f, \"convert_initialise_ms\": %.3f, \"aux_variables\": %ld, \"edges\": %ld}\n",
+                    a, r, c, aux, edges);
+        return 0;
+    }
     long aux = 0, edges = 0;
     int bad_models = 0;
     for (int label = 0; label < 3; ++label) bad_models += check_converted_models(120, 7, label, aux, edges);

@@ -40,3 +40,9 @@ def test_fusion_glue_with_the_references_own_elc():
     res = json.loads(out.stdout.strip().splitlines()[-1])
     assert res["bad_models"] == 0 and res["bad_drivers"] == 0
     assert res["aux_variables"] > 0 and res["edges"] > 0 and res["steps"] > 0 and res["nodes_moved"] > 0 and res["energy_end"] < res["energy_start"]
+    # what the reduction costs per label step at the size of BASELINE configs 2 - 4 (reported in DESIGN.md section 7; no threshold asserted)
+    out = subprocess.run([exe, "1", "time"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    t = json.loads(out.stdout.strip().splitlines()[-1])
+    assert t["nodes"] == 2562 and t["triplets"] == 5120 and t["aux_variables"] > 0 and t["toQuadratic_ms"] > 0
+    print("ELC per label step at ico4:", t)
