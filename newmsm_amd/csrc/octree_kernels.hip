@@ -32,7 +32,7 @@ namespace msm {
 namespace {
 
 constexpr int kWave = 64;
-enum { C_NNODES = 0, C_NOPEN, C_ARENA, C_NMASK, C_MAXDEPTH, C_OVERFLOW, C_REFS, C_MAXLEAF, C_NLEAVES, C_NCHUNK, C_NCHUNK_NEXT, C_COUNT };
+enum { C_NNODES = 0, C_NOPEN, C_ARENA, C_NMASK, C_MAXDEPTH, C_OVERFLOW, C_REFS, C_MAXLEAF, C_NLEAVES, C_NCHUNK, C_NCHUNK_NEXT, C_SCAN_DONE, C_SCAN_OVER, C_COUNT };
 
 __device__ __forceinline__ int wave_incl_scan(int v, int lane) {
 #pragma unroll
@@ -82,6 +82,7 @@ struct OctWork {
     int *cc;               // 8 per chunk: what each child receives from this chunk, then (after k_oct_chunk_scan) where the chunk's share starts
     int *ctot;             // 8 per open node: what each child of a splitting node receives in all
     int32_t *leaf_tri;     // the mesh's leaf array
+    int *agg;              // k_oct_scan: 8 ints per 1024 open nodes (7 sums + the level that published them), see there
     int cap_nodes, cap_refs, cap_arena, cap_open, cap_chunks;
     // a forest (gpu_build_forest): tree blockIdx.y of the launch uses the arrays `stride` elements further on; all zero for one tree
     size_t s_box, s_node, s_cnt, s_ints, s_leaf;  // s_ints: every int work array of a tree lies in one block, the blocks s_ints apart
@@ -109,6 +110,7 @@ __device__ __forceinline__ OctWork tree_view(OctWork w) {
     w.split += b * w.s_ints;
     w.ctot += b * w.s_ints;
     w.cc += b * w.s_ints;
+    w.agg += b * w.s_ints;
     w.leaf_tri += b * w.s_leaf;
     return w;
 }
@@ -180,7 +182,7 @@ template <int cur>  // which of the two open lists this level reads (a template 
 __global__ __launch_bounds__(256) void k_oct_count(OctWork w) {
     w = tree_view(w);
     __shared__ int s_cnt[4][8];
-    const int nchunks = w.counters[C_NCHUNK];
+    const int nchunks = w.counters[cur ? C_NCHUNK_NEXT : C_NCHUNK];  // one count per open list: the scan of a level writes the other one
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     for (int k = blockIdx.x; k < nchunks; k += gridDim.x) {  // uniform
         const int o = w.chunk_open[cur][k];
@@ -291,21 +293,32 @@ __device__ int block_excl_scan(int v, int *total) {
     return excl;
 }
 
-// One workgroup turns the level's decisions into node numbers, list offsets, chunk tables and leaf slots -- prefix sums in
-// open-node order, so the numbering of the tree does not depend on scheduling.
+// The level's decisions become node numbers, list offsets, chunk tables and leaf slots -- prefix sums in open-node order, so the numbering
+// of the tree does not depend on scheduling.  One workgroup did this for a whole level (up to 95 us at the deep levels of an ico6 mesh:
+// twelve rounds of 1024 nodes, each thread then writing its node's eight children and their chunk tables).  Now up to kScanBlocks
+// workgroups per tree share the level: logical block lb = 1024 consecutive open nodes; a workgroup scans its block, publishes the block's
+// seven sums (w.agg, tagged with the level), waits for the sums of the blocks before it (they are published before anything is waited for,
+// and a workgroup only ever waits for lower logical blocks, all of which belong to workgroups dispatched no later than itself), and writes
+// its nodes.  The last workgroup to finish adds everything up for the counters.
+constexpr int kScanBlocks = 16;
+constexpr int kBigNode = 24;  // a splitting node whose children hold more chunks than this has its chunk tables written by the whole workgroup
 template <int cur>
 __global__ __launch_bounds__(1024) void k_oct_scan(OctWork w, int depth) {
     w = tree_view(w);
     const int nopen = w.counters[C_NOPEN];
-    if (nopen == 0) return;
     const int nxt = cur ^ 1, tid = threadIdx.x;
+    if (nopen == 0) {  // the tree is complete: the levels still queued find no chunks either
+        if (blockIdx.x == 0 && tid == 0) w.counters[nxt ? C_NCHUNK_NEXT : C_NCHUNK] = 0;
+        return;
+    }
     const int nnodes0 = w.counters[C_NNODES], arena0 = w.counters[C_ARENA], nmask0 = w.counters[C_NMASK];
-    __shared__ int s_over, s_max;
-    if (tid == 0) s_over = 0, s_max = 0;
-    __syncthreads();
-    int carry_rank = 0, carry_arena = 0, carry_mask = 0, carry_list = 0, carry_chunk = 0, refs = 0, nleaves = 0;
-    for (int base = 0; base < nopen; base += 1024) {  // uniform
-        const int o = base + tid;
+    const int nlog = (nopen + 1023) / 1024, epoch = depth + 1;
+    __shared__ int s_over, s_max, s_last, s_nbig;
+    __shared__ int4 s_big[1024];
+    for (int lb = blockIdx.x; lb < nlog; lb += gridDim.x) {  // uniform
+        if (tid == 0) s_over = 0, s_max = 0, s_nbig = 0;
+        __syncthreads();
+        const int o = lb * 1024 + tid;
         const bool in = o < nopen;
         const int sp = in ? w.split[o] : 0;
         const int len = in ? w.open_len[cur][o] : 0;
@@ -321,8 +334,27 @@ __global__ __launch_bounds__(1024) void k_oct_scan(OctWork w, int depth) {
         const int hasmask = leaf && len >= 1 && len <= 64;
         int sc[7] = {sp, leaf ? ((len + 7) & ~7) : 0, hasmask, ctot, cchunks, leaf ? len : 0, leaf ? 1 : 0}, tot[7];
         block_excl_scan_n<7>(sc, tot);
-        const int rank = carry_rank + sc[0], aoff = carry_arena + sc[1], mblk = carry_mask + sc[2], loff = carry_list + sc[3], koff = carry_chunk + sc[4];
-        carry_rank += tot[0], carry_arena += tot[1], carry_mask += tot[2], carry_list += tot[3], carry_chunk += tot[4], refs += tot[5], nleaves += tot[6];
+        // publish this block's sums, then collect those of the blocks before it (a level of up to 1024 open nodes has neither)
+        int before[7] = {0, 0, 0, 0, 0, 0, 0}, carry[7] = {0, 0, 0, 0, 0, 0, 0};
+        if (nlog > 1) {
+            if (tid < 7) __hip_atomic_store(w.agg + 8 * (size_t)lb + tid, tot[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(w.agg + 8 * (size_t)lb + 7, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        for (int j = tid; j < lb; j += 1024) {
+            // (bounded: should a block before this one never report -- it cannot, see above -- the build gives up and the host builds the tree)
+            for (int spin = 0; __hip_atomic_load(w.agg + 8 * (size_t)j + 7, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != epoch; ++spin) {
+                if (spin > (1 << 22)) {
+                    atomicOr(&w.counters[C_SCAN_OVER], 1);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+#pragma unroll
+            for (int q = 0; q < 7; ++q) before[q] += __hip_atomic_load(w.agg + 8 * (size_t)j + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (lb > 0) block_excl_scan_n<7>(before, carry);  // carry: the sums over all blocks before this one
+        const int rank = carry[0] + sc[0], aoff = carry[1] + sc[1], mblk = carry[2] + sc[2], loff = carry[3] + sc[3], koff = carry[4] + sc[4];
         if (leaf) atomicMax(&s_max, len);
         if (in) {
             const int n = w.open_node[cur][o];
@@ -347,12 +379,18 @@ __global__ __launch_bounds__(1024) void k_oct_scan(OctWork w, int depth) {
                         w.open_off[nxt][oc] = lo;
                         w.open_len[nxt][oc] = ct[c];
                         w.open_chunk[nxt][oc] = kk;
-                        for (int j = 0; j * kChunk < ct[c]; ++j) {
-                            w.chunk_open[nxt][kk] = oc;
-                            w.chunk_beg[nxt][kk] = j * kChunk;
-                            ++kk;
-                        }
+                        const int nk = (ct[c] + kChunk - 1) / kChunk;
+                        if (cchunks <= kBigNode)
+                            for (int j = 0; j < nk; ++j) {
+                                w.chunk_open[nxt][kk + j] = oc;
+                                w.chunk_beg[nxt][kk + j] = j * kChunk;
+                            }
+                        kk += nk;
                         lo += ct[c];
+                    }
+                    if (cchunks > kBigNode) {  // the large nodes of the top levels (the root of an ico6 mesh: 400 chunks): the whole workgroup, below
+                        const int at = atomicAdd(&s_nbig, 1);
+                        s_big[at] = make_int4(o, 8 * rank, koff, 0);
                     }
                 }
             } else {
@@ -360,23 +398,54 @@ __global__ __launch_bounds__(1024) void k_oct_scan(OctWork w, int depth) {
                 else w.node[n] = make_int4(-len - 1, arena0 + aoff, hasmask ? nmask0 + mblk : -1, depth);  // k_oct_fill finds its slot here
             }
         }
-    }
-    __syncthreads();
-    if (tid == 0) {
-        if (s_over) {
-            w.counters[C_OVERFLOW] = 1;
-            w.counters[C_NOPEN] = 0;
-            w.counters[C_NCHUNK_NEXT] = 0;
-        } else {
-            w.counters[C_NNODES] = nnodes0 + 8 * carry_rank;
-            w.counters[C_NOPEN] = 8 * carry_rank;
-            w.counters[C_NCHUNK_NEXT] = carry_chunk;
-            w.counters[C_ARENA] = arena0 + carry_arena;
-            w.counters[C_NMASK] = nmask0 + carry_mask;
-            w.counters[C_MAXDEPTH] = depth;
-            w.counters[C_REFS] += refs;
-            w.counters[C_MAXLEAF] = max(w.counters[C_MAXLEAF], s_max);
-            w.counters[C_NLEAVES] += nleaves;
+        __syncthreads();
+        for (int b = 0; b < s_nbig; ++b) {  // uniform; at most 1024 / kBigNode... entries: a node with that many chunks holds that many triangles
+            const int4 big = s_big[b];
+            int kk = big.z;
+            for (int c = 0; c < 8; ++c) {
+                const int cnt = w.ctot[8 * (size_t)big.x + c], nk = (cnt + kChunk - 1) / kChunk;
+                for (int j = tid; j < nk; j += 1024) {
+                    w.chunk_open[nxt][kk + j] = big.y + c;
+                    w.chunk_beg[nxt][kk + j] = j * kChunk;
+                }
+                kk += nk;
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            if (s_over) atomicOr(&w.counters[C_SCAN_OVER], 1);
+            if (s_max) atomicMax(&w.counters[C_MAXLEAF], s_max);
+            s_last = atomicAdd(&w.counters[C_SCAN_DONE], 1) == nlog - 1;
+        }
+        __syncthreads();
+        if (s_last) {  // every block of the level has written its nodes: the level's totals
+            int all[7] = {0, 0, 0, 0, 0, 0, 0}, sum[7];
+            if (nlog > 1) {
+                for (int j = tid; j < nlog; j += 1024)
+#pragma unroll
+                    for (int q = 0; q < 7; ++q) all[q] += __hip_atomic_load(w.agg + 8 * (size_t)j + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                block_excl_scan_n<7>(all, sum);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 7; ++q) sum[q] = tot[q];
+            }
+            if (tid == 0) {
+                w.counters[C_SCAN_DONE] = 0;
+                if (__hip_atomic_load(&w.counters[C_SCAN_OVER], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                    w.counters[C_OVERFLOW] = 1;
+                    w.counters[C_NOPEN] = 0;
+                    w.counters[C_NCHUNK] = w.counters[C_NCHUNK_NEXT] = 0;
+                } else {
+                    w.counters[C_NNODES] = nnodes0 + 8 * sum[0];
+                    w.counters[C_NOPEN] = 8 * sum[0];
+                    w.counters[nxt ? C_NCHUNK_NEXT : C_NCHUNK] = sum[4];  // the chunk count of the list the next level reads
+                    w.counters[C_ARENA] = arena0 + sum[1];
+                    w.counters[C_NMASK] = nmask0 + sum[2];
+                    w.counters[C_MAXDEPTH] = depth;
+                    w.counters[C_REFS] += sum[5];
+                    w.counters[C_NLEAVES] += sum[6];
+                }
+            }
         }
     }
 }
@@ -388,7 +457,7 @@ __global__ __launch_bounds__(256) void k_oct_fill(OctWork w) {
     w = tree_view(w);
     __shared__ int s_cnt[4][8];
     if (w.counters[C_OVERFLOW]) return;
-    const int nchunks = w.counters[C_NCHUNK];
+    const int nchunks = w.counters[cur ? C_NCHUNK_NEXT : C_NCHUNK];
     const int nxt = cur ^ 1;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     for (int k = blockIdx.x; k < nchunks; k += gridDim.x) {  // uniform
@@ -426,11 +495,6 @@ __global__ __launch_bounds__(256) void k_oct_fill(OctWork w) {
     }
 }
 
-__global__ void k_oct_begin_level(int *counters, size_t stride) {
-    counters += blockIdx.y * stride;
-    counters[C_NCHUNK] = counters[C_NCHUNK_NEXT];
-}
-
 // the state before level 0: node 0 with the cube (-101, 101) and every triangle (k_oct_boxes wrote the list), in chunks
 __global__ __launch_bounds__(256) void k_oct_init(OctWork w, int T, int root_chunks) {
     w = tree_view(w);
@@ -439,7 +503,8 @@ __global__ __launch_bounds__(256) void k_oct_init(OctWork w, int T, int root_chu
         w.chunk_open[0][i] = 0;
         w.chunk_beg[0][i] = i * kChunk;
     }
-    if (i <= C_COUNT) w.counters[i] = i == C_NNODES || i == C_NOPEN ? 1 : i == C_NCHUNK_NEXT ? root_chunks : 0;
+    if (i <= C_COUNT) w.counters[i] = i == C_NNODES || i == C_NOPEN ? 1 : i == C_NCHUNK ? root_chunks : 0;
+    for (int j = i; j < 8 * (w.cap_open / 1024 + 2); j += gridDim.x * blockDim.x) w.agg[j] = 0;  // no level has published sums yet
     if (i == 0) {
         w.node[0] = make_int4(-1, 0, -1, 0);
         w.nodebox[0] = make_double4(-kBounds, -kBounds, -kBounds, 2 * kBounds);
@@ -497,26 +562,34 @@ struct OctJob {  // a build between gpu_build_octree_begin and _finish
     int trees = 1;
     int *h_counters = nullptr;  // pinned, trees x (C_COUNT + 1)
 };
-constexpr int kMaxLevels = 24, kFirstBatch = 8, kNextBatch = 4;
-// Levels are queued in batches without looking at the outcome in between: a level with nothing open costs six empty launches, a
-// look costs a round trip.  Ico-derived meshes finish at depth 6 or 7, i.e. within the first batch.
+constexpr int kMaxLevels = 24, kNextBatch = 2;
+// levels queued before the first look: an icosphere of T triangles finishes at depth log4(T) - 2 (ico6: 6, ico5: 5, ico4: 4) and the loop runs once
+// per depth including the last; a deeper (warped, irregular) tree gets the rest in batches of kNextBatch after a look at the counters
+static int first_batch(int T) {
+    int l4 = 0;
+    for (long long t = T; t >= 4; t >>= 2) ++l4;
+    return std::max(3, std::min(10, l4 - 1));
+}
+// Levels are queued in batches without looking at the outcome in between: a level with nothing open costs five empty launches, a
+// look costs a round trip (first_batch sizes the first one from the number of triangles).
 int queue_levels(msm_ctx *ctx, OctJob &j, int count) {
     const int upto = std::min(kMaxLevels, j.depth + count);
     const unsigned B = (unsigned)j.trees;
     const unsigned div = B > 1 ? 4 : 1;  // a forest's trees share the machine
+    // k_oct_scan's workgroups wait for one another: all of a launch must be resident at once (256 CUs, at least one 1024-thread workgroup each)
+    const unsigned scan_blocks = std::max(1u, std::min((unsigned)kScanBlocks, 256u / B));
     for (; j.depth < upto; ++j.depth) {
-        hipLaunchKernelGGL(k_oct_begin_level, dim3(1, B), dim3(1), 0, ctx->stream, j.w.counters, j.w.s_cnt);
         if (j.cur == 0) {
             hipLaunchKernelGGL(k_oct_decide<0>, dim3(512 / div, B), dim3(256), 0, ctx->stream, j.w);
             hipLaunchKernelGGL(k_oct_count<0>, dim3(1024 / div, B), dim3(256), 0, ctx->stream, j.w);
             hipLaunchKernelGGL(k_oct_chunk_scan<0>, dim3(256 / div, B), dim3(256), 0, ctx->stream, j.w);
-            hipLaunchKernelGGL(k_oct_scan<0>, dim3(1, B), dim3(1024), 0, ctx->stream, j.w, j.depth);
+            hipLaunchKernelGGL(k_oct_scan<0>, dim3(scan_blocks, B), dim3(1024), 0, ctx->stream, j.w, j.depth);
             hipLaunchKernelGGL(k_oct_fill<0>, dim3(1024 / div, B), dim3(256), 0, ctx->stream, j.w);
         } else {
             hipLaunchKernelGGL(k_oct_decide<1>, dim3(512 / div, B), dim3(256), 0, ctx->stream, j.w);
             hipLaunchKernelGGL(k_oct_count<1>, dim3(1024 / div, B), dim3(256), 0, ctx->stream, j.w);
             hipLaunchKernelGGL(k_oct_chunk_scan<1>, dim3(256 / div, B), dim3(256), 0, ctx->stream, j.w);
-            hipLaunchKernelGGL(k_oct_scan<1>, dim3(1, B), dim3(1024), 0, ctx->stream, j.w, j.depth);
+            hipLaunchKernelGGL(k_oct_scan<1>, dim3(scan_blocks, B), dim3(1024), 0, ctx->stream, j.w, j.depth);
             hipLaunchKernelGGL(k_oct_fill<1>, dim3(1024 / div, B), dim3(256), 0, ctx->stream, j.w);
         }
         j.cur ^= 1;
@@ -543,7 +616,8 @@ int gpu_build_octree_begin(msm_mesh *m) {
         ctx->oct_cap_box = (size_t)6 * T + 1024;
         MSM_HIP(msm::pool_malloc((void **)&ctx->oct_box, ctx->oct_cap_box * sizeof(double)));
     }
-    const size_t need_ints = (size_t)2 * cap_refs + (size_t)8 * cap_open + (size_t)cap_open + (size_t)8 * cap_open + (size_t)4 * cap_chunks + (size_t)8 * cap_chunks + 16;
+    const size_t need_ints = (size_t)2 * cap_refs + (size_t)8 * cap_open + (size_t)cap_open + (size_t)8 * cap_open + (size_t)4 * cap_chunks + (size_t)8 * cap_chunks + 16 +
+                             8 * ((size_t)cap_open / 1024 + 2);
     if (need_ints > ctx->oct_cap_ints) {
         if (ctx->oct_ints) (void)msm::pool_free(ctx->oct_ints);
         ctx->oct_ints = nullptr;
@@ -593,7 +667,8 @@ int gpu_build_octree_begin(msm_mesh *m) {
     w.split = p, p += cap_open;
     p += (4 - ((p - s.ints) & 3)) & 3;  // 16-byte alignment of the int4 accesses below
     w.ctot = p, p += (size_t)8 * cap_open;
-    w.cc = p;
+    w.cc = p, p += (size_t)8 * cap_chunks;
+    w.agg = p;
     w.leaf_tri = m->d_leaf_tri;
     w.cap_nodes = cap_nodes, w.cap_refs = cap_refs, w.cap_arena = cap_arena, w.cap_open = cap_open, w.cap_chunks = cap_chunks;
 
@@ -606,7 +681,7 @@ int gpu_build_octree_begin(msm_mesh *m) {
     job->w = w;
     job->h_counters = ctx->oct_hcounters;
     m->oct_job = job;
-    return queue_levels(ctx, *job, kFirstBatch);
+    return queue_levels(ctx, *job, first_batch(T));
 }
 
 int gpu_build_octree_finish(msm_mesh *m) {
@@ -650,7 +725,8 @@ int gpu_build_forest(msm_ctx *ctx, Forest &f, const double *d_xyz, size_t comp_s
     if (B <= 0 || T <= 0) return fail(MSM_ERR_INVALID, "gpu_build_forest: bad arguments");
     MSM_HIP(hipSetDevice(ctx->device));
     const int cap_nodes = T + 64, cap_refs = 6 * T + 256, cap_arena = 8 * T + 512, cap_open = cap_nodes, cap_chunks = cap_refs / kChunk + cap_open + 64;
-    const size_t per_ints = ((size_t)2 * cap_refs + (size_t)8 * cap_open + (size_t)cap_open + (size_t)8 * cap_open + (size_t)4 * cap_chunks + (size_t)8 * cap_chunks + 16 + 3) & ~(size_t)3;
+    const size_t per_ints = ((size_t)2 * cap_refs + (size_t)8 * cap_open + (size_t)cap_open + (size_t)8 * cap_open + (size_t)4 * cap_chunks + (size_t)8 * cap_chunks + 16 +
+                             8 * ((size_t)cap_open / 1024 + 2) + 3) & ~(size_t)3;
     f.B = B, f.T = T, f.V = V;
     f.s_node = (size_t)cap_nodes, f.s_leaf = (size_t)cap_arena, f.s_rec = (size_t)T, f.s_grid = (size_t)64 * 64 * 64;
     MSM_HIP(f.node.ensure(f.s_node * B));
@@ -692,7 +768,8 @@ int gpu_build_forest(msm_ctx *ctx, Forest &f, const double *d_xyz, size_t comp_s
     w.split = p, p += cap_open;
     p += (4 - ((p - f.ints.p) & 3)) & 3;
     w.ctot = p, p += (size_t)8 * cap_open;
-    w.cc = p;
+    w.cc = p, p += (size_t)8 * cap_chunks;
+    w.agg = p;
     w.leaf_tri = f.leaf_tri.p;
     w.cap_nodes = cap_nodes, w.cap_refs = cap_refs, w.cap_arena = cap_arena, w.cap_open = cap_open, w.cap_chunks = cap_chunks;
     w.s_box = (size_t)6 * T, w.s_node = f.s_node, w.s_cnt = (size_t)(C_COUNT + 1), w.s_ints = per_ints, w.s_leaf = f.s_leaf;
@@ -704,7 +781,7 @@ int gpu_build_forest(msm_ctx *ctx, Forest &f, const double *d_xyz, size_t comp_s
     job.w = w;
     job.trees = B;
     job.h_counters = f.h_counters;
-    int st = queue_levels(ctx, job, kFirstBatch);
+    int st = queue_levels(ctx, job, first_batch(T));
     if (st) return st;
     MSM_HIP(hipStreamSynchronize(ctx->stream));
     auto open_somewhere = [&] {
