@@ -132,8 +132,10 @@ int finish_tree(msm_mesh *m) {
     return MSM_OK;
 }
 
-// Meshes of this size and above get their tree built on the GPU (octree_kernels.hip): below it the host build takes less
-// than the dozen launches of the level loop.  MSMHIP_OCTREE=host|gpu forces one of them (tests compare the two).
+// Meshes of this size and above get their tree built on the GPU (octree_kernels.hip).  The level loop is some thirty launches for an ico4
+// mesh (170 us) against 400 us of single-threaded host build plus the upload of its arrays; below 2 048 triangles (ico3: 1 280) the host
+// build is the shorter one.  (Until round 3 the limit was 8 192: the level scan was one workgroup and a level six launches.)
+// MSMHIP_OCTREE=host|gpu forces one of them (tests compare the two).
 bool mesh_tree_on_gpu(const msm_mesh *m);
 static bool tree_on_gpu(const msm_mesh *m) { return mesh_tree_on_gpu(m); }
 bool mesh_tree_on_gpu(const msm_mesh *m) {
@@ -141,7 +143,7 @@ bool mesh_tree_on_gpu(const msm_mesh *m) {
         const char *e = std::getenv("MSMHIP_OCTREE");
         return !e ? 0 : (std::strcmp(e, "host") == 0 ? 1 : (std::strcmp(e, "gpu") == 0 ? 2 : 0));
     }();
-    return mode == 2 || (mode != 1 && m->gpu_tree_always) || (mode == 0 && m->T >= 8192);
+    return mode == 2 || (mode != 1 && m->gpu_tree_always) || (mode == 0 && m->T >= 2048);
 }
 
 int upload_staged(msm_ctx *ctx, void *dst, const void *src, size_t bytes) {

@@ -146,6 +146,11 @@ int patches_by_triangle(msm_cost *c) {
     st = query_host(c->cpgrid, c->source->xyz.data(), Ns, tri.data(), nullptr, nullptr, MSM_WEIGHTS_RAW, "get_source_data (HO)",
                     c->source->ctx == c->cpgrid->ctx ? c->source->d_xyz : nullptr);  // the source's vertices are in HBM already
     if (st) return st;
+    // both trees on the GPU (a control grid of 2 048 triangles or more): the source's build is queued now and runs while the host bins
+    if (mesh_tree_on_gpu(c->cpgrid)) {
+        st = ensure_tree_begin(c->source);
+        if (st) return st;
+    }
     c->pptr.assign(Tc + 1, 0);
     for (int i = 0; i < Ns; ++i) c->pptr[tri[i] + 1]++;
     for (int t = 0; t < Tc; ++t) c->pptr[t + 1] += c->pptr[t];
