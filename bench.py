@@ -48,7 +48,7 @@ def algorithmic_bytes(samples, evals, D):
 
 
 DOMINANT_KERNEL = "msm::k_unary_rays"  # the sampling kernel of a simple-surface target (newmsm_amd/csrc/unary_kernels.hip)
-PMC_PROFILE = os.path.join("profiles", "r2_z_unary_pmc.json")  # tools/collect_profile.sh on this workload
+PMC_PROFILE = os.path.join("profiles", "r3_z_unary_pmc.json")  # tools/collect_profile.sh on this workload (round 3; the kernel has not changed since round 1)
 
 
 def kernel_algorithmic_bytes(samples, evals, D):
@@ -519,7 +519,7 @@ def main():
                        "definition": "table kernels (incl. the rotation kernel) enqueued back to back, no copy of the table to the host, one synchronisation at the end"},
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": pmc_traffic(args), "traffic_source": PMC_PROFILE + " (rocprofv3 --pmc passes of tools/collect_profile.sh at the end of round 2)",
+                "traffic": pmc_traffic(args), "traffic_source": PMC_PROFILE + " (rocprofv3 --pmc passes of tools/collect_profile.sh, round 3)",
                 "kernel": DOMINANT_KERNEL, "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": kbytes,
                 "note": "nominal: the level's working set (tens of MB) lives in L2 / Infinity Cache, counter traffic is far below the algorithmic bytes; "
                         "the kernel is bound by the L1 lookup rate of its divergent gathers (DESIGN.md section 5.2)",

@@ -33,7 +33,8 @@
 extern "C" {
 #endif
 
-#define MSM_ABI_VERSION 5
+#define MSM_ABI_VERSION 6  /* 6 (round 3): msm_pairwise_icm, msm_ctx_time_queries / msm_ctx_query_kernel_ms, msm_group_time_moves / msm_group_move_kernels_ms,
+                             * msm_store_release_i64 / msm_load_acquire_i64 / msm_min_acquire_i64 added; nothing removed or changed */
 
 #define MSM_OK 0
 #define MSM_ERR_INVALID (-1)  /* bad argument / inconsistent sizes */
