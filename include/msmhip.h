@@ -34,7 +34,7 @@ extern "C" {
 #endif
 
 #define MSM_ABI_VERSION 6  /* 6 (round 3): msm_pairwise_icm, msm_ctx_time_queries / msm_ctx_query_kernel_ms, msm_group_time_moves / msm_group_move_kernels_ms,
-                             * msm_store_release_i64 / msm_load_acquire_i64 / msm_min_acquire_i64 added; nothing removed or changed */
+                             * msm_store_release_i64 / msm_load_acquire_i64 / msm_min_acquire_i64, msm_mesh_sphere_project_warp added; nothing removed or changed */
 
 #define MSM_OK 0
 #define MSM_ERR_INVALID (-1)  /* bad argument / inconsistent sizes */
@@ -180,6 +180,10 @@ int msm_adaptive_barycentric_weights(msm_mesh *in_mesh, msm_mesh *new_mesh, cons
 int msm_metric_resample(msm_mesh *in_mesh, const double *data, int32_t D, msm_mesh *new_mesh, const double *excl, double *out, double *excl_out);
 /* sphere_project_warp R/resampler.cpp:311-328: sphere (3 x N, in/out) is carried through from -> to_xyz (3 x V(from)) */
 int msm_sphere_project_warp(msm_mesh *from, const double *to_xyz, double *sphere_xyz, int32_t N);
+/* The same for the coordinates a mesh handle already holds: `sphere`'s vertices are located on `from` and moved through (from -> to_xyz) in place on
+ * the device, its host copy follows -- SPH_reg of Mesh_registration::run_discrete_opt (M/mesh_registration.cpp:224) without three host round trips.
+ * to_xyz: 3 x V(from) SoA.  Same context for both meshes.  Bit-identical to msm_sphere_project_warp on the same inputs. */
+int msm_mesh_sphere_project_warp(msm_mesh *sphere, msm_mesh *from, const double *to_xyz);
 /* surface_resample :284-302 / project_anatomical_mesh :260-282 core: out = sum_j w_j * coords[v_j] for the
  * barycentric weights of q against `from` (no renormalisation); coords 3 x V(from), out 3 x N */
 int msm_barycentric_coords_resample(msm_mesh *from, const double *coords_xyz, const double *q_xyz, int32_t N, double *out_xyz);

@@ -234,6 +234,10 @@ inline Points sphere_project_warp(const Points &sphere, Mesh &from, const Points
     check(msm_sphere_project_warp(from.handle(), to_soa(to).data(), s.data(), (int32_t)(sphere.size() / 3)));
     return to_aos(s);
 }
+// the same for the coordinates a mesh already holds, in place on the device (msm_mesh_sphere_project_warp): SPH_reg of run_discrete_opt
+inline void sphere_project_warp(Mesh &sphere, Mesh &from, const Points &to) {
+    check(msm_mesh_sphere_project_warp(sphere.handle(), from.handle(), to_soa(to).data()));
+}
 // smooth_data, R/resampler.cpp:168-230
 inline Matrix smooth_data(Mesh &orig, const Matrix &data, Mesh &sphLow, double sigma, std::vector<double> *EXCL = nullptr) {
     const int32_t D = (int32_t)(data.size() / orig.nvertices());

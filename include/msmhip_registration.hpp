@@ -122,11 +122,10 @@ inline LevelResult run_discrete_opt(Context &ctx, const Points &target_xyz, cons
         res.labelings.push_back(labeling);
         // ---- applyLabeling, warp the source through the control grid's move, unfold both (:219-230)
         const Points moved = apply_labeling(ROT, labels, labeling);
-        sph_reg = sphere_project_warp(sph_reg, CPGRID, moved);  // CPGRID still holds the previous grid
+        sphere_project_warp(SOURCE, CPGRID, moved);  // SOURCE holds sph_reg since the top of the iteration; CPGRID still holds the previous grid
         CPGRID.set_coords(moved);
         unfold(CPGRID);
         cp_xyz = CPGRID.get_coords();
-        SOURCE.set_coords(sph_reg);
         unfold(SOURCE);
         sph_reg = SOURCE.get_coords();
     }

@@ -83,6 +83,7 @@ SIGNATURES = {
     "msm_metric_resample": (C.c_int, [_VP, c_dp, C.c_int32, _VP, c_dp, c_dp, c_dp]),
     "msm_create_exclusion": (C.c_int, [c_dp, C.c_int32, C.c_int32, C.c_double, C.c_double, c_dp]),
     "msm_sphere_project_warp": (C.c_int, [_VP, c_dp, c_dp, C.c_int32]),
+    "msm_mesh_sphere_project_warp": (C.c_int, [_VP, _VP, c_dp]),
     "msm_barycentric_coords_resample": (C.c_int, [_VP, c_dp, c_dp, C.c_int32, c_dp]),
     "msm_smooth_data": (C.c_int, [_VP, c_dp, C.c_int32, _VP, C.c_double, c_dp, c_dp, c_dp]),
     "msm_mesh_unfold": (C.c_int, [_VP, C.c_double, c_ip, c_ip]),

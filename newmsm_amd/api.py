@@ -351,6 +351,11 @@ def sphere_project_warp(sphere, from_mesh, to_xyz):
     return np.ascontiguousarray(s.T)
 
 
+def sphere_project_warp_mesh(sphere_mesh, from_mesh, to_xyz):
+    """msm_mesh_sphere_project_warp: the coordinates `sphere_mesh` holds moved through (from_mesh -> to_xyz), in place on the device"""
+    check(lib().msm_mesh_sphere_project_warp(sphere_mesh.h, from_mesh.h, _soa(to_xyz)[1]))
+
+
 def barycentric_coords_resample(from_mesh, coords, q):
     x, px = _soa(q)
     out = np.zeros((3, x.shape[1]))

@@ -101,6 +101,7 @@ static int upload_tree(msm_mesh *m) {
     };
     size_t total = 0;
     for (const Part &pt : parts) total += (pt.bytes + 255) & ~(size_t)255;
+    std::unique_lock<std::mutex> lock(ctx->stage_mu);
     MSM_HIP(hipStreamSynchronize(ctx->stream));  // an earlier upload may still read the staging buffer
     if (total > ctx->stage_cap) {
         if (ctx->stage) (void)hipHostFree(ctx->stage);
@@ -148,6 +149,7 @@ bool mesh_tree_on_gpu(const msm_mesh *m) {
 
 int upload_staged(msm_ctx *ctx, void *dst, const void *src, size_t bytes) {
     if (bytes == 0) return MSM_OK;
+    std::lock_guard<std::mutex> lock(ctx->stage_mu);
     MSM_HIP(hipStreamSynchronize(ctx->stream));  // an earlier upload may still read the staging buffer
     if (bytes > ctx->stage_cap) {
         if (ctx->stage) (void)hipHostFree(ctx->stage);
@@ -593,8 +595,12 @@ int ensure_adjacency_dev(msm_mesh *m) {
     MSM_HIP(msm::pool_malloc((void **)&m->d_tid_ptr, sizeof(int32_t) * adj.tid_ptr.size()));
     MSM_HIP(msm::pool_malloc((void **)&m->d_tid, sizeof(int32_t) * std::max<size_t>(adj.tid.size(), 1)));
     MSM_HIP(msm::pool_malloc((void **)&m->d_fold, sizeof(int32_t) * (2 + (size_t)m->V)));
-    MSM_HIP(hipMemcpyAsync(m->d_tid_ptr, adj.tid_ptr.data(), sizeof(int32_t) * adj.tid_ptr.size(), hipMemcpyHostToDevice, ctx->stream));
-    if (!adj.tid.empty()) MSM_HIP(hipMemcpyAsync(m->d_tid, adj.tid.data(), sizeof(int32_t) * adj.tid.size(), hipMemcpyHostToDevice, ctx->stream));
+    int st = upload_staged(ctx, m->d_tid_ptr, adj.tid_ptr.data(), sizeof(int32_t) * adj.tid_ptr.size());
+    if (st) return st;
+    if (!adj.tid.empty()) {
+        st = upload_staged(ctx, m->d_tid, adj.tid.data(), sizeof(int32_t) * adj.tid.size());
+        if (st) return st;
+    }
     MSM_HIP(hipStreamSynchronize(ctx->stream));
     return MSM_OK;
 }
@@ -961,11 +967,14 @@ msm_mesh *msm_mesh_create(msm_ctx *ctx, const double *xyz, int32_t V, const int3
     m->xyz.assign(xyz, xyz + 3 * (size_t)V);
     m->tri.assign(tri, tri + 3 * (size_t)T);
     (void)hipSetDevice(ctx->device);
+    // uploads go through the context's pinned staging block: what the runtime does with an asynchronous copy from pageable memory depends on
+    // whether it has seen the pages before (a megabyte took anything from 40 us to 25 ms, paid by whichever call synchronised next)
     if (msm::pool_malloc((void **)&m->d_xyz, sizeof(double) * 3 * (size_t)V) != hipSuccess ||
-        hipMemcpyAsync(m->d_xyz, m->xyz.data(), sizeof(double) * 3 * (size_t)V, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+        upload_staged(ctx, m->d_xyz, m->xyz.data(), sizeof(double) * 3 * (size_t)V) != MSM_OK ||
         msm::pool_malloc((void **)&m->d_tri, sizeof(int32_t) * 3 * (size_t)T) != hipSuccess ||
-        hipMemcpyAsync(m->d_tri, m->tri.data(), sizeof(int32_t) * 3 * (size_t)T, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
-        msm::pool_malloc((void **)&m->d_tcone, sizeof(float4) * (size_t)T) != hipSuccess) {
+        upload_staged(ctx, m->d_tri, m->tri.data(), sizeof(int32_t) * 3 * (size_t)T) != MSM_OK ||
+        msm::pool_malloc((void **)&m->d_tcone, sizeof(float4) * (size_t)T) != hipSuccess ||
+        hipStreamSynchronize(ctx->stream) != hipSuccess) {  // the mesh is on the device when the call returns (other streams may use it: group.cpp)
         fail(MSM_ERR_HIP, "msm_mesh_create: device allocation failed");
         msm_mesh_destroy(m);
         return nullptr;
@@ -987,7 +996,9 @@ int msm_mesh_update_coords(msm_mesh *m, const double *xyz) {
     MSM_HIP(hipStreamSynchronize(m->ctx->stream));  // the host copy may still be the source of an async upload
     m->xyz.assign(xyz, xyz + 3 * (size_t)m->V);
     m->tree_valid = false;
-    MSM_HIP(hipMemcpyAsync(m->d_xyz, m->xyz.data(), sizeof(double) * 3 * (size_t)m->V, hipMemcpyHostToDevice, m->ctx->stream));
+    const int st = upload_staged(m->ctx, m->d_xyz, m->xyz.data(), sizeof(double) * 3 * (size_t)m->V);
+    if (st) return st;
+    MSM_HIP(hipStreamSynchronize(m->ctx->stream));  // as with the pageable copy this replaces: the coordinates have arrived when the call returns
     return MSM_OK;
 }
 
@@ -1023,7 +1034,10 @@ int msm_mesh_set_features(msm_mesh *m, const double *feat, int32_t D) {
     if (!m->d_feat) MSM_HIP(msm::pool_malloc((void **)&m->d_feat, sizeof(double) * (size_t)D * V));
     m->D = D;
     m->rayrec_valid = false;
-    MSM_HIP(hipMemcpyAsync(m->d_feat, vm.data(), sizeof(double) * (size_t)D * V, hipMemcpyHostToDevice, m->ctx->stream));
+    {
+        const int st = upload_staged(m->ctx, m->d_feat, vm.data(), sizeof(double) * (size_t)D * V);  // pinned staging: pageable copies of megabytes crawl
+        if (st) return st;
+    }
     MSM_HIP(hipStreamSynchronize(m->ctx->stream));
     return MSM_OK;
 }
@@ -1229,44 +1243,34 @@ int msm_create_exclusion(const double *data, int32_t D, int32_t V, double thrl, 
 
 // shared by the coordinate-resampling entry points: out = sum_j w_j * coords[v_j], ids in ascending order
 // (the reference iterates a std::map<int,double>)
+// The weights of every query in its triangle of `from` applied to `coords` (3 x V of `from`'s vertices), search and combination in one kernel
+// (kernels.hip: k_warp); host arrays travel through the context's pinned block: [queries | coords] in, [out] back.
 static int bary_coords(msm_mesh *from, const double *coords, const double *q, int N, double *out, bool to_sphere, const char *what) {
-    std::vector<int> vid(3 * (size_t)N);
-    std::vector<double> w(3 * (size_t)N);
-    int st = query_host(from, q, N, nullptr, vid.data(), w.data(), MSM_WEIGHTS_PROJECTED, what);
+    msm_ctx *ctx = from->ctx;
+    int st = ensure_tree(from);
     if (st) return st;
     const int V = from->V;
-    for (int i = 0; i < N; ++i) {
-        int id[3] = {vid[i], vid[N + i], vid[2 * N + i]};
-        double wt[3] = {w[i], w[N + i], w[2 * N + i]};
-        // std::map semantics: later duplicate keys overwrite, iteration ascending
-        int n = 0, kid[3];
-        double kw[3];
-        for (int j = 0; j < 3; ++j) {
-            int pos = 0;
-            while (pos < n && kid[pos] < id[j]) ++pos;
-            if (pos < n && kid[pos] == id[j]) {
-                kw[pos] = wt[j];
-                continue;
-            }
-            for (int s = n; s > pos; --s) {
-                kid[s] = kid[s - 1];
-                kw[s] = kw[s - 1];
-            }
-            kid[pos] = id[j];
-            kw[pos] = wt[j];
-            ++n;
-        }
-        V3 p = mk(0, 0, 0);
-        for (int j = 0; j < n; ++j) {
-            p.x += coords[kid[j]] * kw[j];
-            p.y += coords[V + kid[j]] * kw[j];
-            p.z += coords[2 * V + kid[j]] * kw[j];
-        }
-        if (to_sphere) p = scale(normalized(p), 100);  // R/resampler.cpp:324-325
-        out[i] = p.x;
-        out[N + i] = p.y;
-        out[2 * N + i] = p.z;
-    }
+    const size_t bq = sizeof(double) * 3 * (size_t)N, bc = sizeof(double) * 3 * (size_t)V;
+    auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    void *pin = nullptr;
+    st = ctx_io_pinned(ctx, pad(bq) + pad(bc) + pad(bq), &pin);
+    if (st) return st;
+    char *pq = (char *)pin, *pc = pq + pad(bq), *po = pc + pad(bc);
+    std::memcpy(pq, q, bq);
+    std::memcpy(pc, coords, bc);
+    double *dq = nullptr, *dc = nullptr, *dout = nullptr;
+    MSM_HIP(ctx_scratch(ctx, 0, bq, (void **)&dq));
+    MSM_HIP(ctx_scratch(ctx, 1, bc, (void **)&dc));
+    MSM_HIP(ctx_scratch(ctx, 3, bq, (void **)&dout));
+    MSM_HIP(hipMemcpyAsync(dq, pq, bq, hipMemcpyHostToDevice, ctx->stream));
+    MSM_HIP(hipMemcpyAsync(dc, pc, bc, hipMemcpyHostToDevice, ctx->stream));
+    MSM_HIP(hipMemcpyAsync(dout, dq, bq, hipMemcpyDeviceToDevice, ctx->stream));  // a failed query leaves its point where it was
+    st = launch_warp(ctx, dev_tree(from), dq, N, dc, V, to_sphere, dout);
+    if (st) return st;
+    MSM_HIP(hipMemcpyAsync(po, dout, bq, hipMemcpyDeviceToHost, ctx->stream));
+    st = check_status(ctx, what);  // synchronises
+    if (st) return st;
+    std::memcpy(out, po, bq);
     return MSM_OK;
 }
 
@@ -1275,6 +1279,36 @@ int msm_sphere_project_warp(msm_mesh *from, const double *to_xyz, double *sphere
     if (N == 0) return MSM_OK;
     std::vector<double> q(sphere, sphere + 3 * (size_t)N);
     return bary_coords(from, to_xyz, q.data(), N, sphere, true, "msm_sphere_project_warp");
+}
+
+// sphere_project_warp of a mesh's own coordinates, in place on the device: what run_discrete_opt does with SPH_reg every iteration
+// (M/mesh_registration.cpp:224) without the three host round trips of the array version (queries up, ids and weights down, result up again).
+int msm_mesh_sphere_project_warp(msm_mesh *sphere, msm_mesh *from, const double *to_xyz) {
+    if (!sphere || !from || !to_xyz) return fail(MSM_ERR_INVALID, "msm_mesh_sphere_project_warp: null argument");
+    if (sphere->ctx != from->ctx) return fail(MSM_ERR_INVALID, "msm_mesh_sphere_project_warp: the meshes belong to different contexts");
+    if (sphere == from) return fail(MSM_ERR_INVALID, "msm_mesh_sphere_project_warp: a mesh cannot be warped through itself");
+    msm_ctx *ctx = from->ctx;
+    int st = ensure_tree(from);
+    if (st) return st;
+    const int V = from->V, N = sphere->V;
+    const size_t bc = sizeof(double) * 3 * (size_t)V;
+    double *dc = nullptr;
+    MSM_HIP(ctx_scratch(ctx, 1, bc, (void **)&dc));
+    st = upload_staged(ctx, dc, to_xyz, bc);
+    if (st) return st;
+    st = launch_warp(ctx, dev_tree(from), sphere->d_xyz, N, dc, V, true, sphere->d_xyz);
+    if (st) return st;
+    // the host copy follows (unfold's repair, get_coords and the set-up code read it)
+    sphere->tree_valid = false;
+    const size_t bx = sizeof(double) * 3 * (size_t)N;
+    void *pin = nullptr;  // through the pinned block: a copy into the pageable vector itself is staged by the runtime at a fraction of the speed
+    st = ctx_io_pinned(ctx, bx, &pin);
+    if (st) return st;
+    MSM_HIP(hipMemcpyAsync(pin, sphere->d_xyz, bx, hipMemcpyDeviceToHost, ctx->stream));
+    st = check_status(ctx, "msm_mesh_sphere_project_warp");  // synchronises; on a failed search the unmoved points stay (the reference throws)
+    std::memcpy(sphere->xyz.data(), pin, bx);
+    sphere->host_xyz_stale = false;
+    return st;
 }
 
 int msm_barycentric_coords_resample(msm_mesh *from, const double *coords, const double *q, int32_t N, double *out) {
@@ -1297,7 +1331,9 @@ int msm_smooth_data(msm_mesh *orig, const double *data, int32_t D, msm_mesh *sph
     st = launch_closest_vertex(ctx, dev_tree(orig), sphlow->d_xyz, N, dcv.p);  // Octree(orig).get_closest_vertex_ID(ci), :182
     if (st) return st;
     MSM_HIP(dunit.ensure(smooth_scratch_doubles(N)));
-    MSM_HIP(ddata.upload(data, (size_t)D * orig->V, ctx->stream));
+    MSM_HIP(ddata.ensure((size_t)D * orig->V));
+    st = upload_staged(ctx, ddata.p, data, sizeof(double) * (size_t)D * orig->V);
+    if (st) return st;
     if (excl) MSM_HIP(dexcl.upload(excl, (size_t)orig->V, ctx->stream));
     MSM_HIP(dout.ensure((size_t)D * N));
     if (excl && excl_out) MSM_HIP(dexo.ensure(N));

@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <functional>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -131,6 +132,7 @@ struct msm_ctx {
     // pinned staging for the search-structure uploads (pageable copies of the 16 MB of an ico6 tree ran at < 1 GB/s)
     void *stage = nullptr;
     size_t stage_cap = 0;
+    std::mutex stage_mu;  // upload_staged / upload_tree: the gMSM set-up reaches one context's block from several host threads
     // small pinned buffers for the per-label-step calls (labeling in, fusion-move energies out)
     void *io_pin = nullptr;
     void *io_dev = nullptr;  // its device address (the block is mapped), or nullptr

@@ -278,6 +278,65 @@ __global__ __launch_bounds__(256) void k_query(DevTree T, const double *__restri
     }
 }
 
+// sphere_project_warp / surface_resample (R/resampler.cpp:284-302,311-328): the query's barycentric weights in its triangle of `from`
+// (get_barycentric_weights: a std::map per query -- ascending vertex id, a later duplicate overwrites) applied to the coordinates `to` of the
+// same vertices, summed in map order; to_sphere: renormalised to radius 100 (:324-325).  The lane that finds the triangle does all of it.
+struct WarpPayload {
+    const double *to;  // 3 x V SoA
+    int V, to_sphere;
+    double x, y, z;
+    __device__ __forceinline__ void compute(const TriRec &r, const V3 &, const V3 &mp) {
+        double wt[3];
+        area_weights(rec_v0(r), rec_v1(r), rec_v2(r), mp, wt[0], wt[1], wt[2]);
+        int n = 0, kid[3];
+        double kw[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int id = r.id[j];
+            int pos = 0;
+            while (pos < n && kid[pos] < id) ++pos;
+            if (pos < n && kid[pos] == id) {
+                kw[pos] = wt[j];
+                continue;
+            }
+            for (int s = n; s > pos; --s) kid[s] = kid[s - 1], kw[s] = kw[s - 1];
+            kid[pos] = id, kw[pos] = wt[j];
+            ++n;
+        }
+        V3 p = mk(0.0, 0.0, 0.0);
+        for (int j = 0; j < n; ++j) {
+            p.x += to[kid[j]] * kw[j];
+            p.y += to[(size_t)V + kid[j]] * kw[j];
+            p.z += to[2 * (size_t)V + kid[j]] * kw[j];
+        }
+        if (to_sphere) p = scale(normalized(p), 100);
+        x = p.x, y = p.y, z = p.z;
+    }
+};
+
+// q and out may be the same array (a mesh warped in place): a query's coordinates are read before its result is written, by its own group only
+template <int G>
+__global__ __launch_bounds__(256) void k_warp(DevTree T, const double *q, int N, const double *__restrict__ to, int V, int to_sphere, double *out, int *status) {
+    constexpr int per_block = 256 / G;
+    const int lane = threadIdx.x & 63;
+    for (int base = blockIdx.x * per_block; base < N; base += gridDim.x * per_block) {
+        const int i = base + threadIdx.x / G;
+        const bool valid = i < N;
+        const V3 p = valid ? mk(q[i], q[N + i], q[2 * (size_t)N + i]) : mk(0.0, 0.0, 0.0);
+        WarpPayload wp;
+        wp.to = to, wp.V = V, wp.to_sphere = to_sphere;
+        wp.x = wp.y = wp.z = 0.0;
+        bool owner;
+        const int t = group_search<G>(T, valid, p, lane, wp, owner);
+        if (!owner) continue;
+        if (t < 0) {
+            raise_status(status, t);
+            continue;  // the coordinates stay what they were; the call fails
+        }
+        out[i] = wp.x, out[N + i] = wp.y, out[2 * (size_t)N + i] = wp.z;
+    }
+}
+
 // Octree::get_closest_vertex_ID, R/octree.cpp:216-233
 struct ClosestVertexPayload {
     int best;
@@ -637,6 +696,16 @@ int launch_query(msm_ctx *ctx, const DevTree &T, const double *d_q, int N, int *
         hipLaunchKernelGGL(k_query<4>, dim3(grid_for(N, 64, 32768)), dim3(256), 0, ctx->stream, T, d_q, N, d_tri, d_vid, d_w, mode, ctx->d_status);
     else
         hipLaunchKernelGGL(k_query<8>, dim3(grid_for(N, 32, 32768)), dim3(256), 0, ctx->stream, T, d_q, N, d_tri, d_vid, d_w, mode, ctx->d_status);
+    MSM_HIP(hipGetLastError());
+    return MSM_OK;
+}
+
+int launch_warp(msm_ctx *ctx, const DevTree &T, const double *d_q, int N, const double *d_to, int V, bool to_sphere, double *d_out) {
+    if (N <= 0) return MSM_OK;
+    if (query_lanes(N) == 4)
+        hipLaunchKernelGGL(k_warp<4>, dim3(grid_for(N, 64, 32768)), dim3(256), 0, ctx->stream, T, d_q, N, d_to, V, to_sphere ? 1 : 0, d_out, ctx->d_status);
+    else
+        hipLaunchKernelGGL(k_warp<8>, dim3(grid_for(N, 32, 32768)), dim3(256), 0, ctx->stream, T, d_q, N, d_to, V, to_sphere ? 1 : 0, d_out, ctx->d_status);
     MSM_HIP(hipGetLastError());
     return MSM_OK;
 }

@@ -52,6 +52,8 @@ int launch_apply_rows(msm_ctx *ctx, int nNew, int nOld, int D, const int *row_pt
 int launch_copy_to_mapped(msm_ctx *ctx, const double *d_src, double *mapped_dst, size_t n, int *flags_mapped);
 int launch_query(msm_ctx *ctx, const DevTree &T, const double *d_q, int N, int *d_tri, int *d_vid, double *d_w, int mode);
 int launch_closest_vertex(msm_ctx *ctx, const DevTree &T, const double *d_q, int N, int *d_out);
+// sphere_project_warp / surface_resample on the device: out[i] = the weights of query i in its triangle applied to d_to (3 x V); d_out may be d_q
+int launch_warp(msm_ctx *ctx, const DevTree &T, const double *d_q, int N, const double *d_to, int V, bool to_sphere, double *d_out);
 int query_lanes(long long N);  // lanes per query of the search kernels for a launch of N queries (kernels.hip)
 // smooth_data: unit vectors of the N vertices (d_unit: 3 x N scratch), then one wavefront per output vertex
 // d_unit of launch_smooth holds smooth_scratch_doubles(N) doubles: the unit vectors and, from smooth_bounds_offset(N), a bounding ball per 64 of them

@@ -32,7 +32,8 @@ namespace msm {
 namespace {
 
 constexpr int kWave = 64;
-enum { C_NNODES = 0, C_NOPEN, C_ARENA, C_NMASK, C_MAXDEPTH, C_OVERFLOW, C_REFS, C_MAXLEAF, C_NLEAVES, C_NCHUNK, C_NCHUNK_NEXT, C_SCAN_DONE, C_SCAN_OVER, C_COUNT };
+enum { C_NNODES = 0, C_NOPEN, C_ARENA, C_NMASK, C_MAXDEPTH, C_OVERFLOW, C_REFS, C_MAXLEAF, C_NLEAVES, C_NCHUNK, C_NCHUNK_NEXT, C_SCAN_DONE, C_SCAN_OVER,
+       C_SNAP_NOPEN, C_SNAP_NNODES, C_SNAP_ARENA, C_SNAP_NMASK, C_COUNT };  // C_SNAP_*: the level's starting values, see k_oct_decide
 
 __device__ __forceinline__ int wave_incl_scan(int v, int lane) {
 #pragma unroll
@@ -145,6 +146,15 @@ template <int cur>  // which of the two open lists this level reads (a template 
 __global__ __launch_bounds__(256) void k_oct_decide(OctWork w) {
     w = tree_view(w);
     const int nopen = w.counters[C_NOPEN];
+    // The level's starting values for k_oct_scan.  That kernel's last workgroup overwrites C_NOPEN / C_NNODES / C_ARENA / C_NMASK with the
+    // next level's while others of its workgroups may not have started yet (two processes sharing the GPU: a workgroup scheduled late read the
+    // NEW open count and went to work on a block that did not exist) -- so its workgroups read this copy, which nothing touches while it runs.
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        w.counters[C_SNAP_NOPEN] = nopen;
+        w.counters[C_SNAP_NNODES] = w.counters[C_NNODES];
+        w.counters[C_SNAP_ARENA] = w.counters[C_ARENA];
+        w.counters[C_SNAP_NMASK] = w.counters[C_NMASK];
+    }
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
     for (int o = wave; o < nopen; o += nwaves) {
@@ -305,13 +315,13 @@ constexpr int kBigNode = 24;  // a splitting node whose children hold more chunk
 template <int cur>
 __global__ __launch_bounds__(1024) void k_oct_scan(OctWork w, int depth) {
     w = tree_view(w);
-    const int nopen = w.counters[C_NOPEN];
+    const int nopen = w.counters[C_SNAP_NOPEN];  // the copies k_oct_decide made for this level (see there)
     const int nxt = cur ^ 1, tid = threadIdx.x;
     if (nopen == 0) {  // the tree is complete: the levels still queued find no chunks either
         if (blockIdx.x == 0 && tid == 0) w.counters[nxt ? C_NCHUNK_NEXT : C_NCHUNK] = 0;
         return;
     }
-    const int nnodes0 = w.counters[C_NNODES], arena0 = w.counters[C_ARENA], nmask0 = w.counters[C_NMASK];
+    const int nnodes0 = w.counters[C_SNAP_NNODES], arena0 = w.counters[C_SNAP_ARENA], nmask0 = w.counters[C_SNAP_NMASK];
     const int nlog = (nopen + 1023) / 1024, epoch = depth + 1;
     __shared__ int s_over, s_max, s_last, s_nbig;
     __shared__ int4 s_big[1024];

@@ -47,6 +47,10 @@ class ProductOps:
     def sphere_project_warp(self, sphere_xyz, from_mesh, to_xyz):
         return api.sphere_project_warp(sphere_xyz, from_mesh, to_xyz)
 
+    def warp_mesh(self, mesh, from_mesh, to_xyz):
+        """sphere_project_warp of the coordinates `mesh` holds, in place (on the device: no host round trip of the 3 x V arrays)"""
+        api.sphere_project_warp_mesh(mesh, from_mesh, to_xyz)
+
     # --- featurespace::initialise
     def metric_resample(self, in_mesh, data, new_mesh):
         return api.metric_resample(in_mesh, data, new_mesh)
@@ -284,11 +288,11 @@ def run_discrete_level(ops, target_xyz, target_tri, ref_feat, source_xyz, source
         labelings.append(labeling)
         # --- applyLabeling, warp the source through the control grid move, unfold both
         new_cp = apply_labeling(rot, labels, labeling)
-        sph_reg = timed("sphere_project_warp", ops.sphere_project_warp, sph_reg, cpgrid, new_cp)  # cpgrid still holds the previous grid
+        # (the source mesh holds sph_reg since the top of the iteration: it is warped where it lies; cpgrid still holds the previous grid)
+        timed("sphere_project_warp", ops.warp_mesh, source, cpgrid, new_cp)
         ops.set_coords(cpgrid, new_cp)
         timed("unfold", ops.unfold, cpgrid)
         cp_xyz = ops.coords(cpgrid)
-        ops.set_coords(source, sph_reg)
         timed("unfold", ops.unfold, source)
         sph_reg = ops.coords(source)
     return sph_reg, cp_xyz, energies, labelings

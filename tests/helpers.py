@@ -87,6 +87,9 @@ class OracleOps:
     def sphere_project_warp(self, sphere_xyz, from_mesh, to_xyz):
         return O.sphere_project_warp(sphere_xyz, from_mesh, to_xyz)
 
+    def warp_mesh(self, mesh, from_mesh, to_xyz):
+        mesh.set_coords(O.sphere_project_warp(np.array(mesh.xyz), from_mesh, to_xyz))
+
     def metric_resample(self, in_mesh, data, new_mesh):
         return O.metric_resample(in_mesh, data, new_mesh)
 

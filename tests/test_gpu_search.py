@@ -169,6 +169,20 @@ def test_metric_resample_warp_and_nn(ctx):
     # sphere_project_warp: carry a fine sphere through a coarse deformation
     to = synthetic.known_warp(xnew, seed=5, rot_deg=6.0, amp=2.0)
     assert np.array_equal(M.sphere_project_warp(xin, mnew, to), O.sphere_project_warp(xin, onew, to))
+    # the same for the coordinates a mesh handle holds, in place on the device (msm_mesh_sphere_project_warp): identical bits, host copy follows,
+    # and the moved mesh can be searched and warped again
+    from newmsm_amd import api
+
+    moving = M.Mesh(ctx, xin, tin)
+    api.sphere_project_warp_mesh(moving, mnew, to)
+    once = O.sphere_project_warp(xin, onew, to)
+    assert np.array_equal(moving.get_coords(), once)
+    api.sphere_project_warp_mesh(moving, mnew, to)
+    assert np.array_equal(moving.get_coords(), O.sphere_project_warp(once, onew, to))
+    om = O.Mesh(O.sphere_project_warp(once, onew, to), tin)
+    assert np.array_equal(M.metric_resample(moving, data, mnew), O.metric_resample(om, data, onew))  # its tree follows the new coordinates
+    with pytest.raises(M.MsmError):
+        api.sphere_project_warp_mesh(M.Mesh(ctx, xin * 1.2, tin), mnew, to)  # points outside the octree's root: the reference throws, so does this
     q = queries(xin, 3000, seed=6)
     assert np.array_equal(M.nearest_neighbour_interpolation(min_, data, q), O.nearest_neighbour(oin, data, q))
 
