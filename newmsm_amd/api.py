@@ -579,11 +579,14 @@ class DiscreteCostFunction:
     def tripletOctets(self, labeling, label, out=None):
         """One label step of Fusion (Fusion.h:181-196).  `out` (optional, T x 8): the array to fill, e.g. Context.host_array((T, 8))
         -- mapped pinned memory the kernels write directly, as the optimiser's per-step buffer would be."""
-        lab, pl = _i(labeling)
+        lab = labeling if (type(labeling) is np.ndarray and labeling.dtype == np.int32 and labeling.flags.c_contiguous) else np.ascontiguousarray(labeling, dtype=np.int32)
+        assert lab.shape == (self.N,)
         if out is None:
             out = np.zeros((self.T, 8))
         assert out.shape == (self.T, 8) and out.dtype == np.float64 and out.flags.c_contiguous
-        check(lib().msm_cost_triplet_octets(self.h, pl, int(label), out.ctypes.data_as(c_dp)))
+        st = lib().msm_cost_triplet_octets(self.h, lab.ctypes.data, int(label), out.ctypes.data)
+        if st:
+            check(st)
         return out
 
     def computeTripletCosts(self, t0=0, t1=None, pinned=False):
