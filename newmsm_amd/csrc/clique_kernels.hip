@@ -25,7 +25,7 @@ __global__ __launch_bounds__(128) void k_triplet_batch(CliqueArgs a, const int *
 // Measured at ico6 / ico4 (bins of ~8): 1 lane 126 us, 4 lanes 111 us, 8 lanes 152 us, 16 lanes 215 us (univariate);
 // 395 / 294 / 298 / 323 us (32 features) -- the complete search behind the ray table costs 244 registers, two
 // wavefronts per SIMD, so wider groups only add idle lanes to the serial part.  Four lanes for bins up to 256 points,
-// sixteen for bins up to 1 024 (the LDS slices must fit).
+// sixteen for bins up to 1 024, 64 up to 4 096, the whole workgroup up to 16 384 (the LDS slices must fit).
 // ------------------------------------------------------------------------------------------------
 
 template <int kHoLanes>
@@ -300,7 +300,8 @@ __global__ __launch_bounds__(256) void k_pairwise_table(CliqueArgs a, double *__
 }
 
 static bool is_ho(const CliqueArgs &a) { return a.kind == MSM_COST_HO_UNIVARIATE || a.kind == MSM_COST_HO_MULTIVARIATE; }
-static int ho_lanes(const CliqueArgs &a) { return a.bin_cap <= 256 ? 4 : 16; }
+// lanes per evaluation by the largest bin: the 256 / lanes LDS slices of bin_cap values must fit 128 KB (host-checked: bin_cap <= kHoBinMax)
+static int ho_lanes(const CliqueArgs &a) { return a.bin_cap <= 256 ? 4 : (a.bin_cap <= 1024 ? 16 : (a.bin_cap <= 4096 ? 64 : 256)); }
 // grid and dynamic LDS of an HO launch of `evals` evaluations with `lanes` lanes each
 template <class K>
 static int ho_config(const CliqueArgs &a, K kernel, int lanes, size_t evals, dim3 &grid, size_t &lds) {
@@ -314,14 +315,23 @@ static int ho_config(const CliqueArgs &a, K kernel, int lanes, size_t evals, dim
     do {                                                                                                    \
         dim3 grid_;                                                                                         \
         size_t lds_;                                                                                        \
-        if (ho_lanes(a) == 4) {                                                                             \
+        const int lanes_ = ho_lanes(a);                                                                     \
+        if (lanes_ == 4) {                                                                                  \
             int st_ = ho_config(a, kernel<4>, 4, evals, grid_, lds_);                                       \
             if (st_) return st_;                                                                            \
             hipLaunchKernelGGL(kernel<4>, grid_, dim3(256), lds_, ctx->stream, __VA_ARGS__);                \
-        } else {                                                                                            \
+        } else if (lanes_ == 16) {                                                                          \
             int st_ = ho_config(a, kernel<16>, 16, evals, grid_, lds_);                                     \
             if (st_) return st_;                                                                            \
             hipLaunchKernelGGL(kernel<16>, grid_, dim3(256), lds_, ctx->stream, __VA_ARGS__);               \
+        } else if (lanes_ == 64) { /* bins beyond 1 024 points: control grids far coarser than the data */  \
+            int st_ = ho_config(a, kernel<64>, 64, evals, grid_, lds_);                                     \
+            if (st_) return st_;                                                                            \
+            hipLaunchKernelGGL(kernel<64>, grid_, dim3(256), lds_, ctx->stream, __VA_ARGS__);               \
+        } else {                                                                                            \
+            int st_ = ho_config(a, kernel<256>, 256, evals, grid_, lds_);                                   \
+            if (st_) return st_;                                                                            \
+            hipLaunchKernelGGL(kernel<256>, grid_, dim3(256), lds_, ctx->stream, __VA_ARGS__);              \
         }                                                                                                   \
     } while (0)
 

@@ -91,8 +91,8 @@ int clique_args(msm_cost *c, bool need_triplets, bool need_pairs, CliqueArgs &a)
             a.ho_pending = c->d_ho_pending.p;
             a.ho_count = c->d_ho_count.p;
         }
-        if (c->pmax > 1024)
-            return fail(MSM_ERR_CAPACITY, "msm_cost: %d source vertices under one control-grid triangle; the triclique kernels hold at most 1024 per evaluation", c->pmax);
+        if (c->pmax > kHoBinMax)
+            return fail(MSM_ERR_CAPACITY, "msm_cost: %d source vertices under one control-grid triangle; the triclique kernels hold at most %d per evaluation", c->pmax, kHoBinMax);
     }
     a.tree = dev_tree(c->target);
     a.rmode = c->p.rmode;
@@ -341,7 +341,7 @@ static int fused_move(msm_cost *c, const CliqueArgs &a, const int32_t *labeling,
     m.single = single ? 1 : 0;
 #ifdef MSM_MOVE_TRACE
     static DevBuf<unsigned long long> trace_buf;
-    const size_t trace_words = 8 * (size_t)(8 * ((c->move_nblk + 7) / 8));
+    const size_t trace_words = 8 * (size_t)(8 * ((c->move_nblk + 7) / 8)) + 8;  // 8 stamps per workgroup of the grid, then 4 counters (ray_open_reason)
     MSM_HIP(trace_buf.zero(trace_words, ctx->stream));
     m.trace = trace_buf.p;
 #endif

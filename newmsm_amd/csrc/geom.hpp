@@ -18,6 +18,7 @@ namespace msm {
 constexpr double kEps = 1e-8;        // EPSILON, R/point.h:31
 constexpr double kRad = 100.0;       // RAD, R/point.h:32
 constexpr double kBounds = 101.0;    // MESH_BOUNDS, R/octree.h:37
+constexpr double kRayFloatAllowance = 3e-6;  // direction table: what the float evaluation of an edge-plane product may be off by (octree.cpp: build_ray_table)
 constexpr int kMaxTriangles = 50;    // MAX_TRIANGLES, R/node.h:33
 
 struct V3 {

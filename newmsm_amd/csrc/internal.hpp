@@ -84,7 +84,7 @@ struct FlatOctree {
     std::vector<int4> ray_cell;      // 6 x G x G: up to four candidate triangles per direction cell, -1 padded
     std::vector<float4> ray_edge;    // 3 per triangle: inward unit normal of the plane (origin, edge k); .w: see octree.cpp
     std::vector<int4> ray_more;      // candidates 4..7 of the cells that have more than four
-    std::vector<int4> ray_excl;      // up to three leaf boxes a query must not lie in for its triangle to be vouched for (.w = count)
+    std::vector<int4> ray_excl;      // up to seven leaf boxes a query must not lie in for its triangle to be vouched for: {b0, b1, b2, count} and, for count > 3, {b3 .. b6} in the next record
     double ray_r2lo = 0, ray_r2hi = 0;  // squared radius range of the query points the table is valid for
     int64_t stats[5] = {0, 0, 0, 0, 0};
     // a tree built on the GPU (octree_kernels.hip) has no host arrays: `node` etc. stay empty and these describe it

@@ -169,6 +169,7 @@ struct CliqueArgs {
 };
 // ---- fused fusion move of the HO (triclique) classes on a direction-table target (move_kernels.hip) ----
 // The labeling travels in the kernel arguments, one byte per control point (no copy engine on the call's critical path).
+constexpr int kHoBinMax = 16384;  // source vertices under one control triangle the on-demand triclique kernels can hold (one workgroup's 128 KB LDS slice)
 constexpr int kMoveLabelWords = 704;  // N <= 2816 control points (ico4: 2562), L <= 256
 struct MoveLabels {
     uint32_t w[kMoveLabelWords];

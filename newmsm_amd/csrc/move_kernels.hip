@@ -72,8 +72,11 @@ __device__ __forceinline__ int ray_find_rec(const DevTree &T, const V3 &p, doubl
     d0 = dv[0], d1 = dv[1], d2 = dv[2], d3 = dv[3], d4 = dv[4], d5 = dv[5];
     int t = c.x;
     float4 ev = e1;
-    if (!ray_accepts(e0, e1, e2, fx, fy, fz)) {
+    float least_a = 0.f, least;
+    const int lvl0 = ray_accept_level(e0, e1, e2, fx, fy, fz, least_a);
+    if (lvl0 != 2) {
         t = -1;
+        int near_a = lvl0 == 1 ? c.x : -1, near_b = -1;  // the candidates the float test nearly accepted, likeliest first (see below)
         int4 mo = make_int4(c.w, -1, -1, -1);
         if (c.w < -1) mo = T.ray_more[-2 - c.w];
 #pragma unroll 1
@@ -82,19 +85,85 @@ __device__ __forceinline__ int ray_find_rec(const DevTree &T, const V3 &p, doubl
             if (ck < 0) break;
             const float4 *r2 = T.ray_tri + (size_t)kRayPieces * ck;
             const float4 g0 = r2[0], g1 = r2[1], g2 = r2[2];
-            if (ray_accepts(g0, g1, g2, fx, fy, fz)) {
+            const int lvl = ray_accept_level(g0, g1, g2, fx, fy, fz, least);
+            if (lvl == 2) {
                 t = ck;
                 ev = g1;
+            } else if (lvl == 1) {
+                if (near_a < 0 || least > least_a) {
+                    near_b = near_a;
+                    near_a = ck;
+                    least_a = least;
+                } else if (near_b < 0) {
+                    near_b = ck;
+                }
             }
         }
         if (t >= 0) {
             dv = reinterpret_cast<const double2 *>(T.ray_tri + (size_t)kRayPieces * t + 3);
             d0 = dv[0], d1 = dv[1], d2 = dv[2], d3 = dv[3], d4 = dv[4], d5 = dv[5];
         }
+#ifndef MSM_MOVE_NO_FP64_RETEST  // (diagnostics: the kernel without this step)
+        else if (near_a >= 0) {
+            // No candidate passed in float: 3e-6 of the stored threshold are the float evaluation's allowance, thirty times the margin the
+            // proof needs (octree.cpp: build_ray_table).  The (at most two) candidates the float test nearly accepted are looked at again
+            // with FP64 edge planes from the record's vertices, which leaves open one sample in 15 000 instead of one in 1 000 -- and with
+            // them the leaf search of the open samples that every third workgroup had to run.
+            const double pn = norm(p);
+#pragma unroll 1
+            for (int r = 0; r < 2 && t < 0; ++r) {
+                const int ck = r == 0 ? near_a : near_b;
+                if (ck < 0) break;
+                if (ck == c.x) {  // the first candidate's record is here already
+                    if (ray_accepts_fp64(mk(d0.x, d0.y, d1.x), mk(d1.y, d2.x, d2.y), mk(d3.x, d3.y, d4.x), p, pn, (double)e0.w - kRayFloatAllowance + 1e-12)) {
+                        t = ck;
+                        ev = e1;
+                    }
+                } else {
+                    const float4 *r2 = T.ray_tri + (size_t)kRayPieces * ck;
+                    const float thr = r2[0].w;
+                    const float4 g1 = r2[1];
+                    const double2 *dq = reinterpret_cast<const double2 *>(r2 + 3);
+                    const double2 q0 = dq[0], q1 = dq[1], q2 = dq[2], q3 = dq[3], q4 = dq[4];
+                    if (ray_accepts_fp64(mk(q0.x, q0.y, q1.x), mk(q1.y, q2.x, q2.y), mk(q3.x, q3.y, q4.x), p, pn, (double)thr - kRayFloatAllowance + 1e-12)) {
+                        t = ck;
+                        ev = g1;
+                        d0 = q0, d1 = q1, d2 = q2, d3 = q3, d4 = q4, d5 = dq[5];
+                    }
+                }
+            }
+        }
+#endif
     }
     if (t >= 0 && __float_as_int(ev.w) >= 0 && !ray_vouches(T, ev, p)) t = -1;  // its leaf may not list the triangle
     return t;
 }
+#ifdef MSM_MOVE_TRACE
+// diagnostics: why the table left a sample open -- 0 no cell, 1 no candidate near its threshold, 2 near but outside in FP64, 3 its leaf may not list it
+__device__ int ray_open_reason(const DevTree &T, const V3 &p) {
+    float fx, fy, fz;
+    const int4 c = ray_cell_of(T, p, fx, fy, fz);
+    if (c.x < 0) return 0;
+    int4 mo = make_int4(c.w, -1, -1, -1);
+    if (c.w < -1) mo = T.ray_more[-2 - c.w];
+    const double pn = norm(p);
+    int reason = 1;
+    for (int k = 0; k < 7; ++k) {
+        const int ck = k == 0 ? c.x : (k == 1 ? c.y : (k == 2 ? c.z : (k == 3 ? mo.x : (k == 4 ? mo.y : (k == 5 ? mo.z : mo.w)))));
+        if (ck < 0) break;
+        const float4 *r2 = T.ray_tri + (size_t)kRayPieces * ck;
+        const float4 g0 = r2[0], g1 = r2[1], g2 = r2[2];
+        float least;
+        const int lvl = ray_accept_level(g0, g1, g2, fx, fy, fz, least);
+        if (lvl == 0) continue;
+        reason = 2;
+        const double2 *dq = reinterpret_cast<const double2 *>(r2 + 3);
+        const double2 q0 = dq[0], q1 = dq[1], q2 = dq[2], q3 = dq[3], q4 = dq[4];
+        if (lvl == 2 || ray_accepts_fp64(mk(q0.x, q0.y, q1.x), mk(q1.y, q2.x, q2.y), mk(q3.x, q3.y, q4.x), p, pn, (double)g0.w - kRayFloatAllowance + 1e-12)) return 3;
+    }
+    return reason;
+}
+#endif
 
 // the eight proposed triangles of control triangle t: combination k (bits A,B,C; 0 = current label), I/Fusion/Fusion.h:188-195
 template <bool kPacked>
@@ -291,6 +360,9 @@ __global__ __launch_bounds__(kThreads) void k_ho_move(CliqueArgs a, MoveArgs m, 
                 }
             } else {
                 s_pend[atomicAdd(&s_npend, 1)] = s;
+#ifdef MSM_MOVE_TRACE
+                if (m.trace) atomicAdd(m.trace + 8 * (size_t)gridDim.x + ray_open_reason(a.tree, p), 1ull);
+#endif
             }
         }
         if (kMode == 2) {
@@ -327,7 +399,11 @@ __global__ __launch_bounds__(kThreads) void k_ho_move(CliqueArgs a, MoveArgs m, 
     // ---- the samples the direction table left open (0.2 %): the octree leaf's candidates, eight lanes per sample
     // (search_device.hpp: group8_find); what even that cannot decide (no candidate in the leaf: sibling leaves, nearest vertex)
     // is left to the tail kernel, which the host launches only when told to
+#ifdef MSM_MOVE_SKIP_OPEN  // diagnostics (WRONG results): what the leaf search of the open samples costs the launch -- 1: no workgroup runs it, 2: one in 32 does
+    const int npend = ((MSM_MOVE_SKIP_OPEN == 2 && (blockIdx.x & 31) == 0) || m.cap < 0) ? s_npend : 0;  // (cap < 0 never holds: keeps the code in)
+#else
     const int npend = s_npend;
+#endif
     // the strain of the 64 evaluations (a chain of some hundred dependent FP64 operations that only needs the proposed triangles) is
     // computed by the last wavefront here, while the first ones search for the open samples and then start on the similarities:
     // it used to follow the similarity in every evaluation's lane, 2 us of the 4.3 us last phase
@@ -339,6 +415,9 @@ __global__ __launch_bounds__(kThreads) void k_ho_move(CliqueArgs a, MoveArgs m, 
             s_strain[h] = s_flag[h] ? 0.0 : move_strain(a, s_frame + 5 * (h >> 3), rr);
         }
     }
+#ifdef MSM_MOVE_TRACE
+    if (m.trace && tid == 0) m.trace[8 * (size_t)blockIdx.x + 7] = (unsigned long long)npend;  // how many samples this workgroup had to search for
+#endif
     for (int q0 = 0; q0 < npend; q0 += kThreads / 8) {  // workgroup-uniform
         const int q = q0 + (tid >> 3);
         const bool valid = q < npend;
@@ -352,10 +431,30 @@ __global__ __launch_bounds__(kThreads) void k_ho_move(CliqueArgs a, MoveArgs m, 
             p = moved_point(s_geo + 9 * el, m.slot_w[3 * slot], m.slot_w[3 * slot + 1], m.slot_w[3 * slot + 2]);
         }
         if (!__any(valid)) continue;
-        const int found = group8_find(a.tree, valid, p, lane);
+        const int found = group8_find(a.tree, valid, p, lane);  // the same in the eight lanes of a group
+        double val = 0.0;
+        if (kMode == 2) {
+            // the similarity over the features like the sampling rounds above: eight lanes per sample (one lane through 32 dimensions was
+            // 14 of the kernel's 88 us at ico4: a third of the workgroups have an open sample and every one of them waited for that lane)
+            const bool go = valid && found >= 0;
+            const int D = a.D;
+            const double *f0 = a.tfeat, *f1 = a.tfeat, *f2 = a.tfeat, *sa = a.sfeat_vm, *cw = nullptr;
+            double wa = 0.0, wb = 0.0, wc = 0.0;
+            if (go) {
+                const TriRec &r = a.tree.rec[found];
+                area_weights(rec_v0(r), rec_v1(r), rec_v2(r), p, wa, wb, wc);  // every lane: same instructions, same values
+                const int sv = a.bin_idx[s0 + j];
+                f0 = a.tfeat + (size_t)r.id[0] * D, f1 = a.tfeat + (size_t)r.id[1] * D, f2 = a.tfeat + (size_t)r.id[2] * D;
+                sa = a.sfeat_vm + (size_t)sv * D;
+                cw = a.cfw_vm ? a.cfw_vm + (size_t)sv * a.cfw_rows : nullptr;
+            }
+            val = feature_vector_similarity8x2(a.simmeasure, go, lane & 7, D, sa, cw, a.cfw_rows, f0, f1, f2, wa, wb, wc);
+        } else if (valid && (lane & 7) == 0 && found >= 0) {
+            val = ho_value_on(a, a.bin_idx[s0 + j], p, found);
+        }
         if (valid && (lane & 7) == 0) {
             if (found >= 0) {
-                s_vals[kk * m.cap + j] = ho_value_on(a, a.bin_idx[s0 + j], p, found);
+                s_vals[kk * m.cap + j] = val;
             } else {
                 s_vals[kk * m.cap + j] = pending_value();
                 s_flag[64 + el] = 1;

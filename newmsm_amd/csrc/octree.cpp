@@ -313,17 +313,21 @@ bool lacking_leaves(const FlatOctree &o, int n, const double lo[3], const double
 //   edge planes  the inward unit normals n_k of the planes through the origin and edge k.  The in-plane distance of
 //                the projected point from edge k is at least |projection| * (p^ . n_k) >= rho * (p^ . n_k), rho = distance
 //                of the triangle's plane from the origin, so  p^ . n_k >= margin / rho  for k = 0,1,2  implies (2);
-//                the stored threshold adds 3e-6 for the float evaluation (direction 2e-7, normals 6e-8, dot 2e-7);
+//                the stored threshold adds kRayFloatAllowance = 3e-6 for the float evaluation (direction 2e-7, normals 6e-8, dot 2e-7);
+//                a kernel may settle what lies inside that allowance with FP64 edge planes (search_device.hpp: ray_accepts_fp64);
 //   robustness   every point of the shell kRayShell around radius 100 whose direction lies in t's spherical triangle
 //                is within `sag` of the flat triangle scaled to that radius; if every leaf meeting the AABB of that
 //                region lists t, (1) holds for every such p.  Up to three leaves that do not list t are recorded as
 //                exclusion boxes (ray_excl): (1) then holds for every p outside those leaves, and p's leaf at depth d
-//                is found arithmetically (child boxes are exact halvings).  More than three: a threshold nothing passes.
+//                is found arithmetically (child boxes are exact halvings).  More than kRayExclMax = 7 (two records): a threshold
+//                nothing passes.  (With three, 72 of the 81 920 triangles of an ico6 sphere were unusable -- the ones whose box ends
+//                on a leaf boundary with 2 x 2 leaves beyond it -- and every sample in them went to the complete search.)
 // Record layout (three float4 per triangle): {n0, thr} {n1, bits of the ray_excl index or -1} {n2, 0}.
 // The cube-map cells only propose candidates, likeliest first: {c0,c1,c2,c3}, or {c0,c1,c2,-2-k} with c3..c6 in
 // ray_more[k]; a miss just means the complete search.
 // ------------------------------------------------------------------------------------------------
 constexpr double kRayShell = 1e-4;
+constexpr int kRayExclMax = 7;
 
 }  // namespace
 
@@ -362,7 +366,7 @@ void build_ray_table(const double *xyz, const int32_t *tri, int V, int T, FlatOc
         plane_of(v[0], v[1], v[2], s3, pd);
         const double rho = std::fabs(pd);  // distance of the triangle's plane from the origin
         if (!(margin[t] < HUGE_VAL) || !(rho > 0)) continue;
-        const double thr = margin[t] / rho * (1 + 1e-6) + 3e-6;
+        const double thr = margin[t] / rho * (1 + 1e-6) + kRayFloatAllowance;
         if (!(thr < 0.1)) continue;
         // (1): the shell region above the triangle
         V3 u[3];
@@ -391,7 +395,7 @@ void build_ray_table(const double *xyz, const int32_t *tri, int V, int T, FlatOc
             hi[a] += sag;
         }
         lack.clear();
-        if (!lacking_leaves(out, 0, lo, hi, t, 3, lack)) continue;
+        if (!lacking_leaves(out, 0, lo, hi, t, kRayExclMax, lack)) continue;
         // (2): edge planes; edge k is opposite vertex k (same_side(p, v_k, v_k+1, v_k+2), R/point.cpp:41-44)
         float4 e[3];
         for (int k = 0; k < 3 && ok; ++k) {
@@ -409,8 +413,8 @@ void build_ray_table(const double *xyz, const int32_t *tri, int V, int T, FlatOc
         if (!ok) continue;
         int excl = -1;
         if (!lack.empty()) {  // leaf boxes as depth << 24 | ix << 16 | iy << 8 | iz (depth <= 8: coordinates fit 8 bits)
-            int4 boxes = make_int4(-1, -1, -1, (int)lack.size());
-            int32_t *bx = &boxes.x;
+            int32_t bx[kRayExclMax];
+            for (int j = 0; j < kRayExclMax; ++j) bx[j] = -1;
             for (size_t j = 0; j < lack.size() && ok; ++j) {
                 const double4 nb = out.nodebox[lack[j]];
                 const int d = out.node[lack[j]].w;
@@ -424,8 +428,12 @@ void build_ray_table(const double *xyz, const int32_t *tri, int V, int T, FlatOc
             }
             if (!ok) continue;
             excl = (int)mine.excl.size();  // chunk-local; renumbered below
-            mine.excl.push_back(boxes);
+            mine.excl.push_back(make_int4(bx[0], bx[1], bx[2], (int)lack.size()));
             mine.owner.push_back(t);
+            if (lack.size() > 3) {  // boxes 3..6 in the record that follows
+                mine.excl.push_back(make_int4(bx[3], bx[4], bx[5], bx[6]));
+                mine.owner.push_back(-1);
+            }
         }
         e[1].w = __builtin_bit_cast(float, (int32_t)excl);
         e[2].w = 0.f;
@@ -437,7 +445,7 @@ void build_ray_table(const double *xyz, const int32_t *tri, int V, int T, FlatOc
         const int base = (int)out.ray_excl.size();
         for (size_t k = 0; k < c.excl.size(); ++k) {
             out.ray_excl.push_back(c.excl[k]);
-            out.ray_edge[(size_t)3 * c.owner[k] + 1].w = __builtin_bit_cast(float, (int32_t)(base + (int)k));
+            if (c.owner[k] >= 0) out.ray_edge[(size_t)3 * c.owner[k] + 1].w = __builtin_bit_cast(float, (int32_t)(base + (int)k));
         }
     }
     TICK("edges+robust");

@@ -74,7 +74,35 @@ __device__ __forceinline__ bool ray_accepts(const float4 &e0, const float4 &e1, 
     return (int)(d0 >= e0.w) & (int)(d1 >= e0.w) & (int)(d2 >= e0.w);
 }
 
-// Is the accepted triangle listed in the octree leaf p descends to?  Yes unless p lies in one of the (at most three)
+// The float test's allowance inside the stored threshold (octree.cpp: build_ray_table adds it to margin / rho: direction 2e-7, normals 6e-8, dot
+// 2e-7 and slack), and the two tests that use it: level 1 of ray_accept_level ("no float evaluation of a point the FP64 test would accept lies below this") and the FP64
+// test itself -- the inward unit normals of the planes through the origin and each edge from the FP64 vertices, p^ . n_k >= thr for k = 0, 1, 2
+// with thr = (stored threshold) - allowance (+ 1e-12 for its own rounding), which is at least the margin / rho the proof asks for.
+// 2: accepted (as ray_accepts); 1: not accepted, but no product is further below the threshold than the allowance allows; 0: neither
+// (`least`: the smallest of the three products -- among nearly accepted candidates the one with the largest is the likeliest to hold the point)
+__device__ __forceinline__ int ray_accept_level(const float4 &e0, const float4 &e1, const float4 &e2, float fx, float fy, float fz, float &least) {
+    const float d0 = __builtin_fmaf(e0.z, fz, __builtin_fmaf(e0.y, fy, e0.x * fx));
+    const float d1 = __builtin_fmaf(e1.z, fz, __builtin_fmaf(e1.y, fy, e1.x * fx));
+    const float d2 = __builtin_fmaf(e2.z, fz, __builtin_fmaf(e2.y, fy, e2.x * fx));
+    least = fminf(d0, fminf(d1, d2));
+    const float lo = e0.w - 6.5e-6f;  // (comparisons, not the minimum: a NaN product must not pass)
+    if ((int)(d0 >= e0.w) & (int)(d1 >= e0.w) & (int)(d2 >= e0.w)) return 2;
+    return (int)(d0 >= lo) & (int)(d1 >= lo) & (int)(d2 >= lo);
+}
+__device__ __forceinline__ bool ray_accepts_fp64(const V3 &v0, const V3 &v1, const V3 &v2, const V3 &p, double pn, double thr) {
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const V3 &a = k == 0 ? v1 : (k == 1 ? v2 : v0), &b = k == 0 ? v2 : (k == 1 ? v0 : v1), &c = k == 0 ? v0 : (k == 1 ? v1 : v2);
+        const V3 n = cross(a, b);  // plane through the origin and the edge opposite vertex k; turned towards vertex k
+        double val = dot(n, p);
+        if (dot(n, c) < 0.0) val = -val;
+        ok = ok && val >= thr * norm(n) * pn;
+    }
+    return ok;
+}
+
+// Is the accepted triangle listed in the octree leaf p descends to?  Yes unless p lies in one of the (at most seven)
 // leaf boxes recorded for the triangle (octree.cpp: build_ray_table); e1.w carries the index of that record, or -1.
 __device__ __forceinline__ bool ray_vouches(const DevTree &T, const float4 &e1, const V3 &p);
 
@@ -185,16 +213,26 @@ __device__ __forceinline__ bool ray_vouches(const DevTree &T, const float4 &e1, 
     const int k = __float_as_int(e1.w);
     if (k < 0) return true;
     const int4 b = T.ray_excl[k];
-    const int box[3] = {b.x, b.y, b.z};
+    auto lies_in = [&](int box) {
+        const int d = box >> 24, G = 1 << d;
+        const double h = 2 * kBounds / G;
+        return grid_axis(p.x, G, h) == ((box >> 16) & 0xff) && grid_axis(p.y, G, h) == ((box >> 8) & 0xff) && grid_axis(p.z, G, h) == (box & 0xff);
+    };
+    const int first[3] = {b.x, b.y, b.z};
     bool clear = true;
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         if (j >= b.w) continue;
-        const int d = box[j] >> 24, G = 1 << d;
-        const double h = 2 * kBounds / G;
-        const bool inside = grid_axis(p.x, G, h) == ((box[j] >> 16) & 0xff) && grid_axis(p.y, G, h) == ((box[j] >> 8) & 0xff) &&
-                            grid_axis(p.z, G, h) == (box[j] & 0xff);
-        clear = clear && !inside;
+        clear = clear && !lies_in(first[j]);
+    }
+    if (b.w > 3) {  // boxes 3 .. 6 in the next record (a triangle in 1 000 of an icosphere)
+        const int4 b2 = T.ray_excl[k + 1];
+        const int rest[4] = {b2.x, b2.y, b2.z, b2.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (3 + j >= b.w) continue;
+            clear = clear && !lies_in(rest[j]);
+        }
     }
     return clear;
 }

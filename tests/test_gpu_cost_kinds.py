@@ -221,6 +221,33 @@ def test_triclique_large_bins(ctx, data_order, cp_order):
     assert np.allclose(got, want, rtol=RTOL, atol=ATOL), np.max(np.abs(got - want))
 
 
+@pytest.mark.parametrize("data_order,kind,D,least", [(5, "ho_multivariate", 9, 1024), (6, "ho_univariate", 1, 1500), (7, "ho_univariate", 1, 4096)])
+def test_triclique_bins_beyond_1024_points(ctx, data_order, kind, D, least):
+    # an ico0 control grid under fine data (tests/fuzz_parity.py found the first case: 1 052 source vertices under one control triangle was
+    # MSM_ERR_CAPACITY): 64 lanes per evaluation up to 4 096 points, the whole workgroup beyond; single evaluations and a whole label step
+    kw = dict(seed=86634, warp_amp=0.3482850938627505, warp_rot=3.350507727100841, labeldist=0.33807290039714544, rescale=False)
+    if data_order == 7:
+        kw.update(warp_amp=0.05, warp_rot=0.5)  # (the stronger warp puts 16 436 vertices under one triangle: beyond the 16 384 of a workgroup's LDS)
+    inp = problem.pairwise_inputs(data_order, 0, D=D, **kw)
+    cf, oc, _ = pair(ctx, inp, kind, simmeasure=1, rmode=3, lambda_=0.1)
+    ptr, _ = cf.patches()
+    assert least < np.diff(ptr).max() <= 16384
+    rng = np.random.default_rng(77)
+    n = 40 if data_order < 7 else 12
+    t, la, lb, lc = random_queries(rng, n, cf.T, cf.L, 3)
+    got = cf.computeTripletCost(t, la, lb, lc)
+    want = np.array([oc.triplet(*q) for q in zip(t, la, lb, lc)])
+    assert np.isfinite(want).any()
+    assert np.allclose(got, want, rtol=RTOL, atol=ATOL, equal_nan=True), np.nanmax(np.abs(got - want))
+    if data_order < 7:
+        lab = rng.integers(0, cf.L, cf.N).astype(np.int32)
+        E, Eo = cf.tripletOctets(lab, 5), oc.triplet_octets(lab, 5, threads=8)
+        assert np.allclose(E, Eo, rtol=RTOL, atol=ATOL, equal_nan=True), np.nanmax(np.abs(E - Eo))
+        oc.set_pairs(np.zeros((0, 2), dtype=np.int32))  # the model holds pairs or triplets, never both
+        tot, otot = cf.evaluateTotalCostSum(lab)[0], oc.total(lab)[0]
+        assert abs(tot - otot) <= 1e-9 * abs(otot) + 1e-11
+
+
 @pytest.mark.parametrize("kind,D", [("ho_univariate", 1), ("ho_multivariate", 3)])
 def test_triclique_with_many_labels(ctx, kind, D):
     """≈ 80 labels (finer sampling grid): on-demand triplet costs and the eight-combination fusion move against the oracle"""

@@ -138,6 +138,43 @@ def test_ray_table_and_general_kernel_agree(ctx, monkeypatch):
     assert np.allclose(U_ray, Uo, rtol=RTOL, atol=ATOL) and np.allclose(U_gen, Uo, rtol=RTOL, atol=ATOL)
 
 
+def test_target_moved_on_the_device_gets_a_new_direction_table(ctx):
+    # a target whose coordinates are rewritten on the device after its direction table was built (msm_mesh_sphere_project_warp, in place):
+    # the next cost function over the same handle must search the new surface -- tree, masks and table all follow the coordinates
+    from newmsm_amd import api
+
+    inp = problem.pairwise_inputs(5, 3, D=1)
+    cf, keep = problem.build_cost(ctx, inp, kind="univariate")
+    cf.get_source_data()
+    U_before = cf.computeUnaryCosts()  # builds the table of the unwarped target
+    cpx, cpt = M.make_mesh_from_icosa(3)
+    to = synthetic.known_warp(cpx, seed=21, rot_deg=4.0, amp=1.5)
+    target = keep["target"]
+    api.sphere_project_warp_mesh(target, M.Mesh(ctx, cpx, cpt), to)
+    moved = O.sphere_project_warp(inp["target_xyz"], O.Mesh(cpx, cpt), to)
+    assert np.array_equal(target.get_coords(), moved)
+    cf2 = api.DiscreteCostFunction(ctx, kind="univariate", simmeasure=2, rmode=3)
+    keep["source"].set_coords(inp["source_orig_xyz"])
+    keep["cpgrid"].set_coords(inp["cp_orig_xyz"])
+    cf2.set_meshes(target, keep["source"], keep["cpgrid"])
+    keep["source"].set_coords(inp["source_xyz"])
+    keep["cpgrid"].set_coords(inp["cp_xyz"])
+    cf2.reset_source(keep["source"])
+    cf2.reset_CPgrid(keep["cpgrid"])
+    cf2.set_featurespace(inp["src_feat"])
+    cf2.set_spacings(inp["maxsep"], inp["mvdmax"])
+    cf2.set_labels(inp["labels"], inp["rot"])
+    cf2.setTriplets(inp["triplets"])
+    cf2.get_source_data()
+    U_after = cf2.computeUnaryCosts()
+    inp2 = dict(inp, target_xyz=moved)
+    oc = oracle_cost(inp2, "univariate")
+    oc.get_source_data()
+    Uo = oc.unary_table()
+    assert np.allclose(U_after, Uo, rtol=RTOL, atol=ATOL), np.max(np.abs(U_after - Uo))
+    assert not np.allclose(U_after, U_before, rtol=1e-6, atol=1e-9)
+
+
 def test_ray_table_multivariate_weights_are_bit_exact_with_general_kernel(ctx, monkeypatch):
     # D > 1: the sampling kernels store (triangle, raw weights) per sample and one common kernel reduces them, so the
     # two search paths must give bit-identical tables
