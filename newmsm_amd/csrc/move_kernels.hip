@@ -278,8 +278,8 @@ __global__ __launch_bounds__(kThreads) void k_ho_move(CliqueArgs a, MoveArgs m, 
     // to do while lanes 0 .. 8 * ntrip set up the proposed triangles, so that the last phase starts without dependent global loads
     double *s_wda = s_vals + 8 * (size_t)m.cap, *s_cw = s_wda + m.cap, *s_sf = s_cw + m.cap;  // per bin slot
     double *s_stat = s_sf + m.cap, *s_frame = s_stat + 24, *s_strain = s_frame + 40;            // 8 x 3, 8 x 5, 64
-    double *s_w = s_strain + 64;                     // kMode 2: 3 weights per sample of a round
-    int *s_flag = reinterpret_cast<int *>(s_w + (kMode == 2 ? 3 * kThreads : 0));  // [0,64) folded, [64,128) deferred
+    double *s_w = s_strain + 64;                     // kMode 2: 3 weights per sample of a round, then its similarity's moments (4)
+    int *s_flag = reinterpret_cast<int *>(s_w + (kMode == 2 ? 4 * kThreads : 0));  // [0,64) folded, [64,128) deferred
     int *s_pend = s_flag + 128;                     // samples the direction table left open (at most all of a round... of the block: 8 * cap)
     int *s_tt = s_pend + 8 * m.cap;                 // kMode 2: triangle and its vertex ids per sample of a round (4 x kThreads)
     int *s_bin = s_tt + (kMode == 2 ? 4 * kThreads : 0);  // bin_ptr[t0 .. t0 + ntrip]
@@ -385,10 +385,13 @@ __global__ __launch_bounds__(kThreads) void k_ho_move(CliqueArgs a, MoveArgs m, 
                     sa = a.sfeat_vm + (size_t)sv * D;
                     cw = a.cfw_vm ? a.cfw_vm + (size_t)sv * a.cfw_rows : nullptr;
                 }
-                const double c = feature_vector_similarity8x2(a.simmeasure, go, jj, D, sa, cw, a.cfw_rows, f0, f1, f2, s_w[3 * q], s_w[3 * q + 1], s_w[3 * q + 2]);
-                if (go && jj == 0) s_vals[qk * m.cap + qj] = c;
+                const Moments mo = feature_vector_moments8x2(a.simmeasure, go, jj, D, sa, cw, a.cfw_rows, f0, f1, f2, s_w[3 * q], s_w[3 * q + 1], s_w[3 * q + 2]);
+                if (go && jj == 0) s_w[3 * q] = mo.pr, s_w[3 * q + 1] = mo.va, s_w[3 * q + 2] = mo.vb, s_w[3 * kThreads + q] = mo.sum;  // (the weights have been used)
             }
             __syncthreads();
+            // the divisions and square roots that end the measure: a lane per sample -- once per wavefront and round instead of once per pass
+            // (they were 13 of the kernel's 76 us at ico4 / 32 features)
+            if (tt >= 0) s_vals[kk * m.cap + j] = similarity_from_moments(a.simmeasure, D, Moments{s_w[3 * tid], s_w[3 * tid + 1], s_w[3 * tid + 2], s_w[3 * kThreads + tid]});
         }
     }
     MSM_STAMP(3);
@@ -564,7 +567,7 @@ int launch_move(msm_ctx *ctx, const CliqueArgs &a, const MoveArgs &m, const Move
     // (neighbouring lanes reading neighbouring 16-byte pieces) 33 / 142.
     static const int threads = [] { const char *e = std::getenv("MSMHIP_MOVE_THREADS"); return e && std::atoi(e) == 512 ? 512 : 256; }();
     const dim3 grid((unsigned)(8 * ((m.nblk + 7) / 8))), block(threads);
-    const size_t lds = sizeof(double) * (64 * 9 + 8 * (size_t)m.cap + 3 * (size_t)m.cap + 24 + 40 + 64 + (mode == 2 ? 3 * threads : 0)) +
+    const size_t lds = sizeof(double) * (64 * 9 + 8 * (size_t)m.cap + 3 * (size_t)m.cap + 24 + 40 + 64 + (mode == 2 ? 4 * threads : 0)) +
                        sizeof(int) * (128 + 8 * (size_t)m.cap + (mode == 2 ? 4 * threads : 0) + 16);
     if (lds > 64 * 1024) return fail(MSM_ERR_CAPACITY, "fusion move: %d bin slots per workgroup do not fit LDS", m.cap);
     const MoveLabels &lab = labels ? *labels : g_no_labels;

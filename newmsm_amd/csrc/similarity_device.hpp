@@ -152,9 +152,35 @@ __device__ __forceinline__ double feature_vector_similarity(int sim, double perc
 constexpr int kMvLanes = 8;
 constexpr int kMvKeep = 8;  // dimensions per lane: D <= 64
 
+// x / s -- as x * (1 / s) when s is a power of two with a normal reciprocal: the product is then the correctly rounded quotient, bit for bit, and an
+// FP64 division is some 35 instructions.  The weights of an unweighted similarity sum to the number of dimensions (32 in the HCP configurations).
+__device__ __forceinline__ double div_exact(double x, double s) {
+    const long long b = __double_as_longlong(s);
+    if ((b & 0x000fffffffffffffll) == 0 && b >= 0x0010000000000000ll && b <= 0x7fd0000000000000ll) return x * __longlong_as_double(0x7fe0000000000000ll - b);
+    return x / s;
+}
+
+// v of lane (lane ^ kXor) within each group of eight, by DPP moves (the shuffle of __shfl_xor goes through the LDS pipe: 36 per sample and pass of
+// the kernels below, which they wait for): lane ^ 1 and lane ^ 2 are quad permutations, lane ^ 4 two row shifts by four with complementary bank masks
+template <int kXor>
+__device__ __forceinline__ int dpp_xor_i(int x) {
+    static_assert(kXor == 1 || kXor == 2 || kXor == 4, "within a group of eight lanes");
+    if (kXor == 1) return __builtin_amdgcn_update_dpp(x, x, 0xB1, 0xf, 0xf, false);  // quad_perm [1,0,3,2]
+    if (kXor == 2) return __builtin_amdgcn_update_dpp(x, x, 0x4E, 0xf, 0xf, false);  // quad_perm [2,3,0,1]
+    const int t = __builtin_amdgcn_update_dpp(x, x, 0x104, 0xf, 0x5, false);         // row_shl:4 into lanes 0-3 and 8-11 of each row: lane <- lane + 4
+    return __builtin_amdgcn_update_dpp(t, x, 0x114, 0xf, 0xa, false);                // row_shr:4 into lanes 4-7 and 12-15: lane <- lane - 4
+}
+template <int kXor>
+__device__ __forceinline__ double dpp_xor(double v) {
+    const long long b = __double_as_longlong(v);
+    const unsigned lo = (unsigned)dpp_xor_i<kXor>((int)(unsigned)b), hi = (unsigned)dpp_xor_i<kXor>((int)(unsigned)((unsigned long long)b >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+// sum over the eight lanes of a group, in every lane; the order (lane ^ 4, then ^ 2, then ^ 1) is part of the result
 __device__ __forceinline__ double mv_group_sum(double v) {
-#pragma unroll
-    for (int off = kMvLanes / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, kMvLanes);
+    v += dpp_xor<4>(v);
+    v += dpp_xor<2>(v);
+    v += dpp_xor<1>(v);
     return v;
 }
 
@@ -182,8 +208,8 @@ __device__ __forceinline__ double feature_vector_similarity8(int sim, bool go, i
         ma = mv_group_sum(ma);
         mb = mv_group_sum(mb);
         if (sum > 0.0) {
-            ma /= sum;
-            mb /= sum;
+            ma = div_exact(ma, sum);
+            mb = div_exact(mb, sum);
         }
         double pr = 0, va = 0, vb = 0;
 #pragma unroll
@@ -197,9 +223,9 @@ __device__ __forceinline__ double feature_vector_similarity8(int sim, bool go, i
         va = mv_group_sum(va);
         vb = mv_group_sum(vb);
         if (sum > 0.0) {
-            pr /= sum;
-            va /= sum;
-            vb /= sum;
+            pr = div_exact(pr, sum);
+            va = div_exact(va, sum);
+            vb = div_exact(vb, sum);
         }
         const double rr = (va == 0.0 || vb == 0.0) ? 0.0 : pr / (sqrt(va) * sqrt(vb));
         return 1 - (1 + rr) * 0.5;
@@ -215,9 +241,27 @@ __device__ __forceinline__ double feature_vector_similarity8(int sim, bool go, i
 }
 
 // The same with 16-byte loads: lane j owns the dimension pairs (16 k + 2 j, 16 k + 2 j + 1), so one load instruction of the
-// group reads 128 contiguous bytes of a row.  D even (rows of vertex-major arrays are then 16-byte aligned), D <= 64.
-__device__ __forceinline__ double feature_vector_similarity8x2(int sim, bool go, int j, int D, const double *sa, const double *cw, int cfw_rows, const double *f0,
-                                                               const double *f1, const double *f2, double wa, double wb, double wc) {
+// group reads 128 contiguous bytes of a row.  D even (rows of vertex-major arrays are then 16-byte aligned), D <= 64.  In two halves:
+// what the eight lanes sum (Moments) and the scalar arithmetic that ends the measure (similarity_from_moments: 4 divisions + 2 square roots for the
+// correlation, one of each for SSD -- about 200 FP64 instructions that do not need eight lanes: a kernel with many samples per wavefront keeps the
+// moments and finishes 64 samples with one pass of these instructions instead of eight; same operations on the same values, same result).
+struct Moments {
+    double pr, va, vb, sum;
+};
+__device__ __forceinline__ double similarity_from_moments(int sim, int D, Moments m) {
+    if (sim == 2) {
+        if (m.sum > 0.0) {
+            m.pr = div_exact(m.pr, m.sum);
+            m.va = div_exact(m.va, m.sum);
+            m.vb = div_exact(m.vb, m.sum);
+        }
+        const double rr = (m.va == 0.0 || m.vb == 0.0) ? 0.0 : m.pr / (sqrt(m.va) * sqrt(m.vb));
+        return 1 - (1 + rr) * 0.5;
+    }
+    return sqrt(m.pr) / D;
+}
+__device__ __forceinline__ Moments feature_vector_moments8x2(int sim, bool go, int j, int D, const double *sa, const double *cw, int cfw_rows, const double *f0,
+                                                             const double *f1, const double *f2, double wa, double wb, double wc) {
     constexpr int kPairs = 4;
     double A[2 * kPairs], B[2 * kPairs], W[2 * kPairs];
 #pragma unroll
@@ -246,8 +290,8 @@ __device__ __forceinline__ double feature_vector_similarity8x2(int sim, bool go,
         ma = mv_group_sum(ma);
         mb = mv_group_sum(mb);
         if (sum > 0.0) {
-            ma /= sum;
-            mb /= sum;
+            ma = div_exact(ma, sum);
+            mb = div_exact(mb, sum);
         }
         double pr = 0, va = 0, vb = 0;
 #pragma unroll
@@ -260,13 +304,7 @@ __device__ __forceinline__ double feature_vector_similarity8x2(int sim, bool go,
         pr = mv_group_sum(pr);
         va = mv_group_sum(va);
         vb = mv_group_sum(vb);
-        if (sum > 0.0) {
-            pr /= sum;
-            va /= sum;
-            vb /= sum;
-        }
-        const double rr = (va == 0.0 || vb == 0.0) ? 0.0 : pr / (sqrt(va) * sqrt(vb));
-        return 1 - (1 + rr) * 0.5;
+        return Moments{pr, va, vb, sum};
     }
     double pr = 0;  // sparsesimkernel::SSD, :179-188
 #pragma unroll
@@ -275,7 +313,11 @@ __device__ __forceinline__ double feature_vector_similarity8x2(int sim, bool go,
         pr += W[k] * df * df;
     }
     pr = mv_group_sum(pr);
-    return sqrt(pr) / D;
+    return Moments{pr, 0.0, 0.0, 0.0};
+}
+__device__ __forceinline__ double feature_vector_similarity8x2(int sim, bool go, int j, int D, const double *sa, const double *cw, int cfw_rows, const double *f0,
+                                                               const double *f1, const double *f2, double wa, double wb, double wc) {
+    return similarity_from_moments(sim, D, feature_vector_moments8x2(sim, go, j, D, sa, cw, cfw_rows, f0, f1, f2, wa, wb, wc));
 }
 
 }  // namespace msm
