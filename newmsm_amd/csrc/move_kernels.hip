@@ -266,7 +266,7 @@ __global__ __launch_bounds__(256) void k_move_prepare(CliqueArgs a, int *__restr
     tri_stat[3 * (size_t)t] = sum, tri_stat[3 * (size_t)t + 1] = meanA, tri_stat[3 * (size_t)t + 2] = varA;
 }
 
-// kMode 0: HO univariate (value = interpolated target feature, from the table record)
+// kMode 0: HO univariate (value = interpolated target feature, from the table record); 3: as 2 with two dimension pairs per lane (D <= 32)
 //       1: HO multivariate, a lane per sample (any D, any measure): ho_value_on
 //       2: HO multivariate, 12 <= D <= 64 and even, SSD / correlation: eight lanes per sample split the dimensions
 template <bool kPacked, int kMode, int kThreads>
@@ -279,10 +279,10 @@ __global__ __launch_bounds__(kThreads) void k_ho_move(CliqueArgs a, MoveArgs m, 
     double *s_wda = s_vals + 8 * (size_t)m.cap, *s_cw = s_wda + m.cap, *s_sf = s_cw + m.cap;  // per bin slot
     double *s_stat = s_sf + m.cap, *s_frame = s_stat + 24, *s_strain = s_frame + 40;            // 8 x 3, 8 x 5, 64
     double *s_w = s_strain + 64;                     // kMode 2: 3 weights per sample of a round, then its similarity's moments (4)
-    int *s_flag = reinterpret_cast<int *>(s_w + (kMode == 2 ? 4 * kThreads : 0));  // [0,64) folded, [64,128) deferred
+    int *s_flag = reinterpret_cast<int *>(s_w + (kMode >= 2 ? 4 * kThreads : 0));  // [0,64) folded, [64,128) deferred
     int *s_pend = s_flag + 128;                     // samples the direction table left open (at most all of a round... of the block: 8 * cap)
     int *s_tt = s_pend + 8 * m.cap;                 // kMode 2: triangle and its vertex ids per sample of a round (4 x kThreads)
-    int *s_bin = s_tt + (kMode == 2 ? 4 * kThreads : 0);  // bin_ptr[t0 .. t0 + ntrip]
+    int *s_bin = s_tt + (kMode >= 2 ? 4 * kThreads : 0);  // bin_ptr[t0 .. t0 + ntrip]
     __shared__ int s_npend;
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -365,7 +365,7 @@ __global__ __launch_bounds__(kThreads) void k_ho_move(CliqueArgs a, MoveArgs m, 
 #endif
             }
         }
-        if (kMode == 2) {
+        if (kMode >= 2) {
             // eight lanes per sample: 32 groups x 8 passes cover the round's 256 samples (four lanes per sample and half the
             // passes took 112 instead of 95 us at D = 32: the passes are bound by the rows' way through L2, not by their number)
             s_tt[tid] = tt;
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(kThreads) void k_ho_move(CliqueArgs a, MoveArgs m, 
                     sa = a.sfeat_vm + (size_t)sv * D;
                     cw = a.cfw_vm ? a.cfw_vm + (size_t)sv * a.cfw_rows : nullptr;
                 }
-                const Moments mo = feature_vector_moments8x2(a.simmeasure, go, jj, D, sa, cw, a.cfw_rows, f0, f1, f2, s_w[3 * q], s_w[3 * q + 1], s_w[3 * q + 2]);
+                const Moments mo = feature_vector_moments8x2<kMode == 3 ? 2 : 4>(a.simmeasure, go, jj, D, sa, cw, a.cfw_rows, f0, f1, f2, s_w[3 * q], s_w[3 * q + 1], s_w[3 * q + 2]);
                 if (go && jj == 0) s_w[3 * q] = mo.pr, s_w[3 * q + 1] = mo.va, s_w[3 * q + 2] = mo.vb, s_w[3 * kThreads + q] = mo.sum;  // (the weights have been used)
             }
             __syncthreads();
@@ -436,7 +436,7 @@ __global__ __launch_bounds__(kThreads) void k_ho_move(CliqueArgs a, MoveArgs m, 
         if (!__any(valid)) continue;
         const int found = group8_find(a.tree, valid, p, lane);  // the same in the eight lanes of a group
         double val = 0.0;
-        if (kMode == 2) {
+        if (kMode >= 2) {
             // the similarity over the features like the sampling rounds above: eight lanes per sample (one lane through 32 dimensions was
             // 14 of the kernel's 88 us at ico4: a third of the workgroups have an open sample and every one of them waited for that lane)
             const bool go = valid && found >= 0;
@@ -554,7 +554,8 @@ static_assert(sizeof(CliqueArgs) + sizeof(MoveArgs) + sizeof(MoveLabels) <= 4096
 
 static int move_mode(const CliqueArgs &a) {
     if (a.kind != MSM_COST_HO_MULTIVARIATE) return 0;
-    return (a.sfeat_vm && a.D >= 12 && a.D <= 64 && a.D % 2 == 0 && (a.simmeasure == 1 || a.simmeasure == 2)) ? 2 : 1;
+    if (!(a.sfeat_vm && a.D >= 12 && a.D <= 64 && a.D % 2 == 0 && (a.simmeasure == 1 || a.simmeasure == 2))) return 1;
+    return a.D <= 32 ? 3 : 2;  // 3: two dimension pairs per lane instead of four
 }
 static MoveLabels g_no_labels;  // handed over (and never read) when the labeling comes as a device array
 
@@ -567,8 +568,8 @@ int launch_move(msm_ctx *ctx, const CliqueArgs &a, const MoveArgs &m, const Move
     // (neighbouring lanes reading neighbouring 16-byte pieces) 33 / 142.
     static const int threads = [] { const char *e = std::getenv("MSMHIP_MOVE_THREADS"); return e && std::atoi(e) == 512 ? 512 : 256; }();
     const dim3 grid((unsigned)(8 * ((m.nblk + 7) / 8))), block(threads);
-    const size_t lds = sizeof(double) * (64 * 9 + 8 * (size_t)m.cap + 3 * (size_t)m.cap + 24 + 40 + 64 + (mode == 2 ? 4 * threads : 0)) +
-                       sizeof(int) * (128 + 8 * (size_t)m.cap + (mode == 2 ? 4 * threads : 0) + 16);
+    const size_t lds = sizeof(double) * (64 * 9 + 8 * (size_t)m.cap + 3 * (size_t)m.cap + 24 + 40 + 64 + (mode >= 2 ? 4 * threads : 0)) +
+                       sizeof(int) * (128 + 8 * (size_t)m.cap + (mode >= 2 ? 4 * threads : 0) + 16);
     if (lds > 64 * 1024) return fail(MSM_ERR_CAPACITY, "fusion move: %d bin slots per workgroup do not fit LDS", m.cap);
     const MoveLabels &lab = labels ? *labels : g_no_labels;
     if (ev_start) MSM_HIP(hipEventRecord(ev_start, ctx->stream));
@@ -577,11 +578,13 @@ int launch_move(msm_ctx *ctx, const CliqueArgs &a, const MoveArgs &m, const Move
         if (threads == 512) {                                                                                       \
             if (mode == 0) hipLaunchKernelGGL((k_ho_move<PACKED, 0, 512>), grid, block, lds, ctx->stream, a, m, lab);     \
             else if (mode == 1) hipLaunchKernelGGL((k_ho_move<PACKED, 1, 512>), grid, block, lds, ctx->stream, a, m, lab); \
-            else hipLaunchKernelGGL((k_ho_move<PACKED, 2, 512>), grid, block, lds, ctx->stream, a, m, lab);                \
+            else if (mode == 2) hipLaunchKernelGGL((k_ho_move<PACKED, 2, 512>), grid, block, lds, ctx->stream, a, m, lab); \
+            else hipLaunchKernelGGL((k_ho_move<PACKED, 3, 512>), grid, block, lds, ctx->stream, a, m, lab);                \
         } else {                                                                                                    \
             if (mode == 0) hipLaunchKernelGGL((k_ho_move<PACKED, 0, 256>), grid, block, lds, ctx->stream, a, m, lab);     \
             else if (mode == 1) hipLaunchKernelGGL((k_ho_move<PACKED, 1, 256>), grid, block, lds, ctx->stream, a, m, lab); \
-            else hipLaunchKernelGGL((k_ho_move<PACKED, 2, 256>), grid, block, lds, ctx->stream, a, m, lab);                \
+            else if (mode == 2) hipLaunchKernelGGL((k_ho_move<PACKED, 2, 256>), grid, block, lds, ctx->stream, a, m, lab); \
+            else hipLaunchKernelGGL((k_ho_move<PACKED, 3, 256>), grid, block, lds, ctx->stream, a, m, lab);                \
         }                                                                                                           \
     } while (0)
     if (labels) MSM_MOVE_LAUNCH(true);

@@ -260,9 +260,9 @@ __device__ __forceinline__ double similarity_from_moments(int sim, int D, Moment
     }
     return sqrt(m.pr) / D;
 }
+template <int kPairs = 4>  // dimension pairs per lane: D <= 16 * kPairs (2 for the 32 features of the HCP configurations: half the arithmetic of 4)
 __device__ __forceinline__ Moments feature_vector_moments8x2(int sim, bool go, int j, int D, const double *sa, const double *cw, int cfw_rows, const double *f0,
                                                              const double *f1, const double *f2, double wa, double wb, double wc) {
-    constexpr int kPairs = 4;
     double A[2 * kPairs], B[2 * kPairs], W[2 * kPairs];
 #pragma unroll
     for (int k = 0; k < kPairs; ++k) {
