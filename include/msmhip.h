@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MSM_ABI_VERSION 6  /* 6 (round 3): msm_pairwise_icm, msm_ctx_time_queries / msm_ctx_query_kernel_ms, msm_group_time_moves / msm_group_move_kernels_ms,
+#define MSM_ABI_VERSION 7  /* 6 (round 3): msm_pairwise_icm, msm_ctx_time_queries / msm_ctx_query_kernel_ms, msm_group_time_moves / msm_group_move_kernels_ms,
                              * msm_store_release_i64 / msm_load_acquire_i64 / msm_min_acquire_i64, msm_mesh_sphere_project_warp added; nothing removed or changed */
 
 #define MSM_OK 0
@@ -97,6 +97,13 @@ int msm_estimate_pairs(const int32_t *tri, int32_t V, int32_t T, int32_t *pairs)
 /* testing hook: the search tree (newresampler::Octree, R/octree.cpp:31-141) of a mesh, built on the host without a GPU:
  * stats as msm_mesh_octree_stats, and a signature of the leaves (box + triangle list in stored order of every leaf) */
 int msm_octree_signature(const double *xyz, const int32_t *tri, int32_t V, int32_t T, int64_t stats[5], uint64_t *signature);
+/* testing hook, host only: the guarantee of the direction table that the cost kernels search simple-surface targets with (csrc/octree.cpp:
+ * build_ray_table), checked at nsamples points (random directions; points next to random edges and vertices) against the first pass of
+ * Octree::get_closest_triangle (R/octree.cpp:156-178) over the host-built tree: whatever a kernel may accept must be the one listed triangle
+ * that passes the inside test.  report: [0] points [1] accepted by the float test [2] only by the FP64 re-test [3] left to the complete search
+ * [4] violations (must be 0) [5] triangles the table cannot use [6] triangles with exclusion boxes [7] simple surface [8] exclusion boxes
+ * checked one by one (the centre of the leaf a box stands for must be refused) [9] sampled points refused by the boxes alone */
+int msm_ray_table_check(const double *xyz, const int32_t *tri, int32_t V, int32_t T, int32_t nsamples, uint64_t seed, int64_t report[10]);
 
 /* ------------------------------------------------------------------------------------------------
  * context: one per GPU

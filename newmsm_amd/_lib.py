@@ -55,6 +55,7 @@ SIGNATURES = {
     "msm_estimate_triplets": (C.c_int, [c_ip, C.c_int32, c_ip]),
     "msm_estimate_pairs": (C.c_int, [c_ip, C.c_int32, C.c_int32, c_ip]),
     "msm_octree_signature": (C.c_int, [c_dp, c_ip, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_uint64)]),
+    "msm_ray_table_check": (C.c_int, [c_dp, c_ip, C.c_int32, C.c_int32, C.c_int32, C.c_uint64, C.POINTER(C.c_int64)]),
     "msm_ctx_create": (_VP, [C.c_int]),
     "msm_ctx_create_on_stream": (_VP, [C.c_int, _VP]),
     "msm_ctx_destroy": (None, [_VP]),

@@ -133,6 +133,15 @@ def octree_signature(xyz, tri):
     return dict(nodes=stats[0], leaves=stats[1], depth=stats[2], refs=stats[3], max_leaf=stats[4]), sig.value
 
 
+def ray_table_check(xyz, tri, nsamples=20000, seed=1):
+    """[host] the direction table's guarantee checked point by point against the reference's leaf search (testing hook, msm_ray_table_check)."""
+    x, px = _soa(xyz)
+    t, pt = _tri_soa(tri)
+    rep = (C.c_int64 * 10)()
+    check(lib().msm_ray_table_check(px, pt, x.shape[1], t.shape[1], nsamples, seed, rep))
+    return dict(points=rep[0], by_float=rep[1], by_fp64=rep[2], open=rep[3], violations=rep[4], unusable=rep[5], with_exclusions=rep[6], simple=bool(rep[7]), boxes_checked=rep[8], refused_by_boxes=rep[9])
+
+
 def estimate_triplets(tri):
     t, pt = _tri_soa(tri)
     out = np.zeros((t.shape[1], 3), dtype=np.int32)

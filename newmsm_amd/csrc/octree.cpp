@@ -26,6 +26,7 @@
 
 #include "host_parallel.hpp"
 #include "internal.hpp"
+#include "search_device.hpp"  // the acceptance test of the direction table, which also compiles for the host (msm_ray_table_check)
 
 // set-up timing to stderr when MSMHIP_TIMING is set
 #define TICK(name) do { if (std::getenv("MSMHIP_TIMING")) { auto now_ = std::chrono::steady_clock::now(); fprintf(stderr, "  %s %.1f ms\n", name, std::chrono::duration<double, std::milli>(now_ - tick_).count()); tick_ = now_; } } while (0)
@@ -760,3 +761,133 @@ extern "C" int msm_octree_signature(const double *xyz, const int32_t *tri, int32
     return MSM_OK;
 }
 
+// Testing hook, host only: the guarantee of the direction table (build_ray_table), checked point by point against the reference's own search.
+// For each of `nsamples` points on the radius shell -- random directions, and points placed within 1e-10 .. 1e-3 (relative to the edge) of
+// random edges and vertices, on either side -- every candidate of the point's cell that a kernel may accept (the float test, or the FP64
+// re-test of a nearly accepted candidate, plus ray_vouches: the very functions the kernels call, search_device.hpp) must be THE answer of
+// Octree::get_closest_triangle's first pass (R/octree.cpp:156-178): listed in the leaf the point descends to, and the only listed triangle
+// that passes the -1e-8 inside test.  report: [0] points, [1] accepted by the float test, [2] accepted only by the FP64 re-test, [3] left to
+// the complete search, [4] VIOLATIONS (must be 0), [5] triangles the table cannot use, [6] triangles with exclusion boxes, [7] simple surface,
+// [8] exclusion boxes checked one by one (a point at the centre of the leaf a box stands for must be refused for that triangle, a violation otherwise),
+// [9] sampled points whose triangle passed the edge-plane test and was refused by ray_vouches alone.
+extern "C" int msm_ray_table_check(const double *xyz, const int32_t *tri, int32_t V, int32_t T, int32_t nsamples, uint64_t seed, int64_t report[10]) {
+    using namespace msm;
+    if (!xyz || !tri || !report || V <= 0 || T <= 0 || nsamples < 0) return fail(MSM_ERR_INVALID, "msm_ray_table_check: bad arguments");
+    for (int64_t i = 0; i < 3 * (int64_t)T; ++i)
+        if (tri[i] < 0 || tri[i] >= V) return fail(MSM_ERR_INVALID, "msm_ray_table_check: triangle vertex id %d out of range [0,%d)", tri[i], V);
+    FlatOctree o;
+    build_octree(xyz, tri, V, T, o);
+    build_ray_table(xyz, tri, V, T, o);
+    for (int k = 0; k < 10; ++k) report[k] = 0;
+    report[7] = o.simple ? 1 : 0;
+    if (o.ray_G <= 0) return MSM_OK;
+    std::vector<int> guarded;  // triangles with exclusion boxes: every fifth point is placed above one of them
+    for (int t = 0; t < T; ++t) {
+        if (o.ray_edge[3 * (size_t)t].w >= 2.f) ++report[5];
+        else if (__builtin_bit_cast(int32_t, o.ray_edge[3 * (size_t)t + 1].w) >= 0) guarded.push_back(t);
+    }
+    report[6] = (int64_t)guarded.size();
+    DevTree dt{};
+    dt.ray_G = o.ray_G;
+    dt.ray_cell = o.ray_cell.data();
+    dt.ray_more = o.ray_more.data();
+    dt.ray_excl = o.ray_excl.data();
+    dt.ray_r2lo = o.ray_r2lo, dt.ray_r2hi = o.ray_r2hi;
+    // the records themselves: every leaf that meets the shell region of a guarded triangle without listing it must be refused
+    for (int t : guarded) {
+        const V3 v[3] = {vtx(xyz, V, tri[t]), vtx(xyz, V, tri[T + t]), vtx(xyz, V, tri[2 * (size_t)T + t])};
+        double lo[3] = {HUGE_VAL, HUGE_VAL, HUGE_VAL}, hi[3] = {-HUGE_VAL, -HUGE_VAL, -HUGE_VAL};
+        for (int k = 0; k < 3; ++k) {
+            const V3 u = scale(v[k], 1.0 / norm(v[k]));
+            const double c[3] = {u.x, u.y, u.z};
+            for (int a = 0; a < 3; ++a) {
+                lo[a] = std::fmin(lo[a], std::fmin((kRad - kRayShell) * c[a], (kRad + kRayShell) * c[a]));
+                hi[a] = std::fmax(hi[a], std::fmax((kRad - kRayShell) * c[a], (kRad + kRayShell) * c[a]));
+            }
+        }
+        double cosmax = 1.0;  // the region's box grown by the sagitta, as build_ray_table does
+        for (int k = 0; k < 3; ++k) cosmax = std::fmin(cosmax, dot(scale(v[k], 1.0 / norm(v[k])), scale(v[(k + 1) % 3], 1.0 / norm(v[(k + 1) % 3]))));
+        const double sag = (kRad + kRayShell) * (1 - std::sqrt(cosmax)) * (1 + 1e-9) + 1e-9;
+        for (int a = 0; a < 3; ++a) lo[a] -= sag, hi[a] += sag;
+        std::vector<int> lack;
+        lacking_leaves(o, 0, lo, hi, t, 1 << 20, lack);
+        for (int leaf : lack) {
+            const double4 b = o.nodebox[leaf];
+            const V3 centre = mk(b.x + 0.5 * b.w, b.y + 0.5 * b.w, b.z + 0.5 * b.w);
+            ++report[8];
+            if (ray_vouches(dt, o.ray_edge[3 * (size_t)t + 1], centre)) ++report[4];
+        }
+    }
+    uint64_t rs = seed * 6364136223846793005ull + 1442695040888963407ull;
+    auto rnd = [&]() {  // uniform in [0, 1)
+        rs = rs * 6364136223846793005ull + 1442695040888963407ull;
+        return (double)(rs >> 11) * (1.0 / 9007199254740992.0);
+    };
+    auto vert = [&](int t, int k) { return vtx(xyz, V, tri[(size_t)k * T + t]); };
+    std::vector<int> hits;
+    for (int it = 0; it < nsamples; ++it) {
+        V3 p;
+        const int kind = (it % 5 == 4 && !guarded.empty()) ? 4 : it % 4;
+        if (kind == 4) {  // above a triangle with exclusion boxes, towards its rim (where the shell region leaves the triangle's own box)
+            const int t = guarded[(size_t)(rnd() * guarded.size()) % guarded.size()];
+            double w[3] = {rnd(), rnd() * 0.05, rnd() * 0.05};
+            const int k = (int)(rnd() * 3) % 3;
+            std::swap(w[0], w[k]);
+            const V3 a = vert(t, 0), b = vert(t, 1), c = vert(t, 2);
+            p = mk(w[0] * a.x + w[1] * b.x + w[2] * c.x, w[0] * a.y + w[1] * b.y + w[2] * c.y, w[0] * a.z + w[1] * b.z + w[2] * c.z);
+        } else if (kind == 0) {  // a random direction
+            do p = mk(2 * rnd() - 1, 2 * rnd() - 1, 2 * rnd() - 1);
+            while (!(norm(p) > 0.1 && norm(p) <= 1.0));
+        } else {  // next to an edge (kind 1, 2) or a vertex (kind 3) of a random triangle, on either side
+            const int t = (int)(rnd() * T) % T, k = (int)(rnd() * 3) % 3;
+            const V3 a = vert(t, k), b = vert(t, (k + 1) % 3), c = vert(t, (k + 2) % 3);
+            const double along = kind == 3 ? (rnd() < 0.5 ? 0.0 : 1e-9 * rnd()) : rnd();
+            const V3 on = mk(a.x + along * (b.x - a.x), a.y + along * (b.y - a.y), a.z + along * (b.z - a.z));
+            const double off = (rnd() < 0.5 ? -1.0 : 1.0) * std::pow(10.0, -10.0 + 7.0 * rnd()) * (rnd() < 0.1 ? 0.0 : 1.0);
+            p = mk(on.x + off * (c.x - on.x), on.y + off * (c.y - on.y), on.z + off * (c.z - on.z));
+        }
+        const double radius = kRad + (it % 7 == 0 ? (2 * rnd() - 1) * 0.9e-4 : 0.0);  // the shell the table vouches for: 1e-4 either side
+        p = scale(normalized(p), radius);
+        ++report[0];
+        // the reference's first pass: descend to the leaf, every listed triangle through the inside test
+        int n = 0;
+        while (o.node[n].x >= 0) {
+            const double4 b = o.nodebox[n];
+            const double mx = (b.x + (b.x + b.w)) / 2.0, my = (b.y + (b.y + b.w)) / 2.0, mz = (b.z + (b.z + b.w)) / 2.0;
+            n = o.node[n].x + 4 * (!(p.x < mx)) + 2 * (!(p.y < my)) + (!(p.z < mz));
+        }
+        hits.clear();
+        for (int e = 0; e < -o.node[n].x - 1; ++e) {
+            const int t = o.leaf_tri[o.node[n].y + e];
+            const V3 a = vert(t, 0), b = vert(t, 1), c = vert(t, 2);
+            if (point_in_triangle(project_point(p, a, b, c), a, b, c)) hits.push_back(t);
+        }
+        // what a kernel may accept
+        float fx, fy, fz;
+        const int4 cell = ray_cell_of(dt, p, fx, fy, fz);
+        int4 more = make_int4(cell.w, -1, -1, -1);
+        if (cell.x >= 0 && cell.w < -1) more = o.ray_more[-2 - cell.w];
+        const int cand[7] = {cell.x, cell.y, cell.z, more.x, more.y, more.z, more.w};
+        const double pn = norm(p);
+        bool by_float = false, by_fp64 = false, bad = false;
+        for (int k = 0; k < 7 && cell.x >= 0; ++k) {
+            const int t = cand[k];
+            if (t < 0) break;
+            const float4 e0 = o.ray_edge[3 * (size_t)t], e1 = o.ray_edge[3 * (size_t)t + 1], e2 = o.ray_edge[3 * (size_t)t + 2];
+            float least;
+            const int lvl = ray_accept_level(e0, e1, e2, fx, fy, fz, least);
+            bool ok = lvl == 2;
+            const bool fp64 = lvl == 1 && ray_accepts_fp64(vert(t, 0), vert(t, 1), vert(t, 2), p, pn, (double)e0.w - kRayFloatAllowance + 1e-12);
+            ok = ok || fp64;
+            if (ok && !ray_vouches(dt, e1, p)) ++report[9];
+            if (!ok || !ray_vouches(dt, e1, p)) continue;
+            (lvl == 2 ? by_float : by_fp64) = true;
+            if (!(hits.size() == 1 && hits[0] == t)) bad = true;
+        }
+        if (bad) ++report[4];
+        if (by_float) ++report[1];
+        else if (by_fp64) ++report[2];
+        else ++report[3];
+    }
+    return MSM_OK;
+}

@@ -42,12 +42,20 @@ __device__ __forceinline__ bool inside_test(const TriRec &r, const V3 &p, V3 &mp
 // Ray table (octree.cpp: build_ray_table): the direction cell of p, i.e. up to four candidate triangles, likeliest
 // first; all -1 when p is off the radius shell the table vouches for (or NaN).  Float arithmetic only proposes
 // candidates and accepts them with the margins built into the thresholds; it never decides between two candidates.
-__device__ __forceinline__ int4 ray_cell_of(const DevTree &T, const V3 &p, float &fx, float &fy, float &fz) {
+// (the functions of the table's acceptance test also compile for the host: octree.cpp checks the table's guarantee with them, msm_ray_table_check)
+MSM_HD float ray_rsqrt(float x) {
+#ifdef __HIP_DEVICE_COMPILE__
+    return rsqrtf(x);
+#else
+    return 1.0f / sqrtf(x);
+#endif
+}
+MSM_HD int4 ray_cell_of(const DevTree &T, const V3 &p, float &fx, float &fy, float &fz) {
     const double r2 = p.x * p.x + p.y * p.y + p.z * p.z;
     fx = fy = fz = 0.f;
     if (!(r2 >= T.ray_r2lo && r2 <= T.ray_r2hi)) return make_int4(-1, -1, -1, -1);
     const float qx = (float)p.x, qy = (float)p.y, qz = (float)p.z;
-    const float inv = rsqrtf(qx * qx + qy * qy + qz * qz);
+    const float inv = ray_rsqrt(qx * qx + qy * qy + qz * qz);
     fx = qx * inv, fy = qy * inv, fz = qz * inv;
     const float ax = fabsf(fx), ay = fabsf(fy), az = fabsf(fz);
     int face;
@@ -61,13 +69,14 @@ __device__ __forceinline__ int4 ray_cell_of(const DevTree &T, const V3 &p, float
     }
     const float iw = 1.0f / w, half = 0.5f * (float)T.ray_G;
     const int G = T.ray_G;
-    const int iu = max(0, min(G - 1, (int)((u * iw + 1.0f) * half)));
-    const int iv = max(0, min(G - 1, (int)((v * iw + 1.0f) * half)));
+    int iu = (int)((u * iw + 1.0f) * half), iv = (int)((v * iw + 1.0f) * half);
+    iu = iu < 0 ? 0 : (iu > G - 1 ? G - 1 : iu);
+    iv = iv < 0 ? 0 : (iv > G - 1 ? G - 1 : iv);
     return T.ray_cell[((size_t)face * G + iu) * G + iv];
 }
 
 // the acceptance test of one candidate: all three edge-plane products at or above the triangle's threshold (e0.w)
-__device__ __forceinline__ bool ray_accepts(const float4 &e0, const float4 &e1, const float4 &e2, float fx, float fy, float fz) {
+MSM_HD bool ray_accepts(const float4 &e0, const float4 &e1, const float4 &e2, float fx, float fy, float fz) {
     const float d0 = __builtin_fmaf(e0.z, fz, __builtin_fmaf(e0.y, fy, e0.x * fx));
     const float d1 = __builtin_fmaf(e1.z, fz, __builtin_fmaf(e1.y, fy, e1.x * fx));
     const float d2 = __builtin_fmaf(e2.z, fz, __builtin_fmaf(e2.y, fy, e2.x * fx));
@@ -80,7 +89,7 @@ __device__ __forceinline__ bool ray_accepts(const float4 &e0, const float4 &e1, 
 // with thr = (stored threshold) - allowance (+ 1e-12 for its own rounding), which is at least the margin / rho the proof asks for.
 // 2: accepted (as ray_accepts); 1: not accepted, but no product is further below the threshold than the allowance allows; 0: neither
 // (`least`: the smallest of the three products -- among nearly accepted candidates the one with the largest is the likeliest to hold the point)
-__device__ __forceinline__ int ray_accept_level(const float4 &e0, const float4 &e1, const float4 &e2, float fx, float fy, float fz, float &least) {
+MSM_HD int ray_accept_level(const float4 &e0, const float4 &e1, const float4 &e2, float fx, float fy, float fz, float &least) {
     const float d0 = __builtin_fmaf(e0.z, fz, __builtin_fmaf(e0.y, fy, e0.x * fx));
     const float d1 = __builtin_fmaf(e1.z, fz, __builtin_fmaf(e1.y, fy, e1.x * fx));
     const float d2 = __builtin_fmaf(e2.z, fz, __builtin_fmaf(e2.y, fy, e2.x * fx));
@@ -89,7 +98,7 @@ __device__ __forceinline__ int ray_accept_level(const float4 &e0, const float4 &
     if ((int)(d0 >= e0.w) & (int)(d1 >= e0.w) & (int)(d2 >= e0.w)) return 2;
     return (int)(d0 >= lo) & (int)(d1 >= lo) & (int)(d2 >= lo);
 }
-__device__ __forceinline__ bool ray_accepts_fp64(const V3 &v0, const V3 &v1, const V3 &v2, const V3 &p, double pn, double thr) {
+MSM_HD bool ray_accepts_fp64(const V3 &v0, const V3 &v1, const V3 &v2, const V3 &p, double pn, double thr) {
     bool ok = true;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -104,7 +113,7 @@ __device__ __forceinline__ bool ray_accepts_fp64(const V3 &v0, const V3 &v1, con
 
 // Is the accepted triangle listed in the octree leaf p descends to?  Yes unless p lies in one of the (at most seven)
 // leaf boxes recorded for the triangle (octree.cpp: build_ray_table); e1.w carries the index of that record, or -1.
-__device__ __forceinline__ bool ray_vouches(const DevTree &T, const float4 &e1, const V3 &p);
+MSM_HD bool ray_vouches(const DevTree &T, const float4 &e1, const V3 &p);
 
 __device__ __forceinline__ double candidate_distance(const DevTree &T, int t, const V3 &p) {
     const TriRec &r = T.rec[t];
@@ -201,16 +210,16 @@ __device__ __forceinline__ int fallback_search(const DevTree &T, int n, const V3
 // index of the grid cell along one axis: the number of cell boundaries b_j = -101 + j*h that are <= p,
 // i.e. exactly the upper/lower choices the reference's descent makes with its (lo+hi)/2.0 midpoints
 // (h = 202/G and all b_j are exact in FP64)
-__device__ __forceinline__ int grid_axis(double p, int G, double h) {
+MSM_HD int grid_axis(double p, int G, double h) {
     int i = (int)((p + kBounds) * (1.0 / h));  // estimate; the two comparisons below make it exact
-    i = max(0, min(G - 1, i));
+    i = i < 0 ? 0 : (i > G - 1 ? G - 1 : i);
     if (i + 1 < G && !(p < -kBounds + (i + 1) * h)) ++i;
     else if (i > 0 && p < -kBounds + i * h) --i;
     return (p == p) ? i : G - 1;  // NaN: every child "contains" it, the last one wins
 }
 
-__device__ __forceinline__ bool ray_vouches(const DevTree &T, const float4 &e1, const V3 &p) {
-    const int k = __float_as_int(e1.w);
+MSM_HD bool ray_vouches(const DevTree &T, const float4 &e1, const V3 &p) {
+    const int k = __builtin_bit_cast(int, e1.w);
     if (k < 0) return true;
     const int4 b = T.ray_excl[k];
     auto lies_in = [&](int box) {

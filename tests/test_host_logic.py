@@ -84,6 +84,37 @@ def test_top_down_octree_equals_incremental_insertion(built, monkeypatch, order,
         assert fast[0] == dict(nodes=14281, leaves=12496, depth=6, refs=176096, max_leaf=49)  # SURVEY.md section 8 [probe]
 
 
+@pytest.mark.parametrize("order,shape", [(3, "regular"), (4, "regular"), (5, "warped"), (5, "radial"), (6, "regular"), (4, "jittered")])
+def test_direction_table_accepts_only_the_reference_answer(built, order, shape):
+    # The table the cost kernels search simple-surface targets with (csrc/octree.cpp: build_ray_table), against the first pass of
+    # Octree::get_closest_triangle (R/octree.cpp:156-178) on the host: at random directions and at points placed 1e-10 .. 1e-3 of an edge
+    # away from random edges and vertices, whatever a kernel may accept -- the float edge-plane test, or the FP64 re-test of a nearly
+    # accepted candidate, and ray_vouches; the very functions the kernels call -- must be the one triangle listed in the point's leaf
+    # that passes the inside test.  Every exclusion box is checked too: a point in the leaf it stands for must be refused.
+    import newmsm_amd as M
+    from newmsm_amd import api, synthetic
+
+    xyz, tri = M.make_mesh_from_icosa(order)
+    if shape == "warped":
+        xyz = synthetic.known_warp(xyz, seed=3, rot_deg=5.0, amp=2.0)
+    elif shape == "radial":  # off the sphere by up to 1e-3: still one triangle per ray
+        rng = np.random.default_rng(6)
+        xyz = xyz * (1.0 + 1e-5 * rng.normal(size=(len(xyz), 1)))
+    elif shape == "jittered":  # folds: not a simple surface, no table
+        rng = np.random.default_rng(4)
+        xyz = xyz + rng.normal(scale=2.0, size=xyz.shape)
+    rep = api.ray_table_check(xyz, tri, 60000, seed=order)
+    if shape == "jittered":
+        assert not rep["simple"] and rep["points"] == 0
+        return
+    assert rep["simple"] and rep["points"] == 60000
+    assert rep["violations"] == 0, rep
+    assert rep["by_float"] > 20000 and rep["by_fp64"] > 500 and rep["open"] > 0   # all three outcomes occur
+    assert rep["boxes_checked"] >= rep["with_exclusions"] > 0
+    if shape == "regular":
+        assert rep["unusable"] == 0   # up to seven exclusion boxes per triangle: with three, 24 / 72 triangles of ico4 / ico6 were left out
+
+
 def test_variance_normalise_matches_oracle(built):
     """variance_normalise (M/reg_tools.cpp:804-843): the serial mean / variance recurrence, with and without exclusion"""
     rng = np.random.default_rng(5)
