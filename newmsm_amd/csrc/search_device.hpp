@@ -43,6 +43,13 @@ __device__ __forceinline__ bool inside_test(const TriRec &r, const V3 &p, V3 &mp
 // first; all -1 when p is off the radius shell the table vouches for (or NaN).  Float arithmetic only proposes
 // candidates and accepts them with the margins built into the thresholds; it never decides between two candidates.
 // (the functions of the table's acceptance test also compile for the host: octree.cpp checks the table's guarantee with them, msm_ray_table_check)
+MSM_HD int ray_clamp(int i, int hi) {  // max(0, min(hi, i))
+#ifdef __HIP_DEVICE_COMPILE__
+    return max(0, min(hi, i));
+#else
+    return i < 0 ? 0 : (i > hi ? hi : i);
+#endif
+}
 MSM_HD float ray_rsqrt(float x) {
 #ifdef __HIP_DEVICE_COMPILE__
     return rsqrtf(x);
@@ -69,9 +76,8 @@ MSM_HD int4 ray_cell_of(const DevTree &T, const V3 &p, float &fx, float &fy, flo
     }
     const float iw = 1.0f / w, half = 0.5f * (float)T.ray_G;
     const int G = T.ray_G;
-    int iu = (int)((u * iw + 1.0f) * half), iv = (int)((v * iw + 1.0f) * half);
-    iu = iu < 0 ? 0 : (iu > G - 1 ? G - 1 : iu);
-    iv = iv < 0 ? 0 : (iv > G - 1 ? G - 1 : iv);
+    const int iu = ray_clamp((int)((u * iw + 1.0f) * half), G - 1);
+    const int iv = ray_clamp((int)((v * iw + 1.0f) * half), G - 1);
     return T.ray_cell[((size_t)face * G + iu) * G + iv];
 }
 
@@ -212,7 +218,7 @@ __device__ __forceinline__ int fallback_search(const DevTree &T, int n, const V3
 // (h = 202/G and all b_j are exact in FP64)
 MSM_HD int grid_axis(double p, int G, double h) {
     int i = (int)((p + kBounds) * (1.0 / h));  // estimate; the two comparisons below make it exact
-    i = i < 0 ? 0 : (i > G - 1 ? G - 1 : i);
+    i = ray_clamp(i, G - 1);
     if (i + 1 < G && !(p < -kBounds + (i + 1) * h)) ++i;
     else if (i > 0 && p < -kBounds + i * h) --i;
     return (p == p) ? i : G - 1;  // NaN: every child "contains" it, the last one wins
