@@ -35,6 +35,7 @@ struct msm_group {
     msm_ctx *ctx = nullptr;
     int patch_cap_hint = 0;
     int patch_max = 0;  // largest patch of any subject (msm_group_finalize)
+    int pair_lanes = 32;  // lanes per query of k_group_pairwise: 16 when nearly all patches fit a quarter wavefront's registers (msm_group_finalize)
     msm_group_params p{};
     int S = 0;
     msm_mesh *tmpl = nullptr;
@@ -291,6 +292,7 @@ int group_args(msm_group *g, GroupArgs &a) {
     a.move_e00 = nullptr;
     a.move_e11 = nullptr;
     a.patch_cap = g->patch_max;
+    a.pair_lanes = g->pair_lanes;
     a.status = g->ctx->d_status;
     return MSM_OK;
 }
@@ -1207,8 +1209,18 @@ int msm_group_finalize(msm_group *g) {
     MSM_HIP(hipStreamSynchronize(ctx->stream));
     g->drop_kept();  // new patches: nothing kept from earlier label steps applies
     g->patch_max = 0;
+    int64_t npatch = 0, nsmall = 0;
     for (int s = 0; s < S; ++s)
-        for (size_t k = 0; k + 1 < g->h_pptr[s].size(); ++k) g->patch_max = std::max(g->patch_max, g->h_pptr[s][k + 1] - g->h_pptr[s][k]);
+        for (size_t k = 0; k + 1 < g->h_pptr[s].size(); ++k) {
+            const int n = g->h_pptr[s][k + 1] - g->h_pptr[s][k];
+            g->patch_max = std::max(g->patch_max, n);
+            ++npatch;
+            nsmall += n <= kPairSmallPatch;
+        }
+    // a quarter wavefront per pair cost when (nearly) all patches fit its registers: four queries share a wavefront's instruction stream and latency
+    // instead of two (label step 12.5 -> 9.5 ms at ico6 / ico4, patches of ~65 entries); the others take the general path, at half the lanes
+    g->pair_lanes = (npatch > 0 && 10 * nsmall >= 9 * npatch) ? 16 : 32;
+    if (const char *e = std::getenv("MSMHIP_GROUP_PAIR_LANES")) g->pair_lanes = std::atoi(e) == 16 ? 16 : 32;
     g->ready = true;
     return MSM_OK;
 }

@@ -35,35 +35,45 @@ __device__ __forceinline__ double lanes_sum(double v) {
 // half_reduce leaves value k, complete, in the lanes whose bits 16 / 8 / 4 are bits 0 / 1 / 2 of k (four lanes each); half_get
 // fetches one.  Keeping the sums where they land lets the per-query scalar arithmetic that follows (divisions by the sum of
 // weights, square roots) run ONCE with a different value in every lane group, instead of once per value in all lanes.
-template <int N>
+template <int N, int kLanes = 32>
 __device__ __forceinline__ double half_reduce(const double (&v)[N], int lane) {
     static_assert(N >= 1 && N <= 8, "at most eight values");
-    constexpr int N1 = (N + 1) / 2, N2 = (N1 + 1) / 2, N3 = (N2 + 1) / 2;
+    static_assert(kLanes == 32 || kLanes == 16, "half or quarter of a wavefront");
+    constexpr int N1 = (N + 1) / 2, N2 = (N1 + 1) / 2, N3 = (N2 + 1) / 2, T = kLanes / 2;
     static_assert(N3 == 1, "three halving steps");
     double w[N1], x[N2], y;
-    const bool u16 = lane & 16, u8 = lane & 8, u4 = lane & 4;
+    const bool u1 = lane & T, u2 = lane & (T / 2), u3 = lane & (T / 4);
 #pragma unroll
     for (int j = 0; j < N1; ++j) {
         const double e = v[2 * j], o = 2 * j + 1 < N ? v[2 * j + 1] : 0.0;
-        w[j] = (u16 ? o : e) + __shfl_xor(u16 ? e : o, 16, 64);
+        w[j] = (u1 ? o : e) + __shfl_xor(u1 ? e : o, T, 64);
     }
 #pragma unroll
     for (int j = 0; j < N2; ++j) {
         const double e = w[2 * j], o = 2 * j + 1 < N1 ? w[2 * j + 1] : 0.0;
-        x[j] = (u8 ? o : e) + __shfl_xor(u8 ? e : o, 8, 64);
+        x[j] = (u2 ? o : e) + __shfl_xor(u2 ? e : o, T / 2, 64);
     }
     {
         const double e = x[0], o = N2 > 1 ? x[N2 - 1] : 0.0;
-        y = (u4 ? o : e) + __shfl_xor(u4 ? e : o, 4, 64);
+        y = (u3 ? o : e) + __shfl_xor(u3 ? e : o, T / 4, 64);
     }
-    y += __shfl_xor(y, 2, 64);
-    y += __shfl_xor(y, 1, 64);
+#pragma unroll
+    for (int off = T / 8; off > 0; off >>= 1) y += __shfl_xor(y, off, 64);
     return y;
 }
-// which value a lane holds after half_reduce, and a lane that holds value k
-__device__ __forceinline__ int half_slot(int lane) { return ((lane >> 4) & 1) | (((lane >> 3) & 1) << 1) | (((lane >> 2) & 1) << 2); }
-__device__ __forceinline__ int half_lane_of(int k) { return ((k & 1) << 4) | (((k >> 1) & 1) << 3) | (((k >> 2) & 1) << 2); }
-__device__ __forceinline__ double half_get(double y, int k) { return __shfl(y, ((threadIdx.x & 63) & 32) | half_lane_of(k), 64); }
+// which value a lane holds after half_reduce, and a lane that holds value k (kLanes == 16: the same with the lane bits 8 / 4 / 2)
+template <int kLanes = 32>
+__device__ __forceinline__ int half_slot(int lane) {
+    constexpr int T = kLanes / 2;
+    return ((lane / T) & 1) | (((lane / (T / 2)) & 1) << 1) | (((lane / (T / 4)) & 1) << 2);
+}
+template <int kLanes = 32>
+__device__ __forceinline__ int half_lane_of(int k) {
+    constexpr int T = kLanes / 2;
+    return ((k & 1) * T) | (((k >> 1) & 1) * (T / 2)) | (((k >> 2) & 1) * (T / 4));
+}
+template <int kLanes = 32>
+__device__ __forceinline__ double half_get(double y, int k) { return __shfl(y, ((threadIdx.x & 63) & ~(kLanes - 1)) | half_lane_of<kLanes>(k), 64); }
 template <int N>
 __device__ __forceinline__ void half_sums(double (&v)[N], int lane) {
     const double y = half_reduce<N>(v, lane);
@@ -103,7 +113,7 @@ int launch_rotate_to_label(msm_ctx *ctx, const double *d_xyz, int V, const doubl
 template <bool kDice, int kLanes>
 __global__ __launch_bounds__(256) void k_group_pairwise(GroupArgs a, const int *__restrict__ qp, const int *__restrict__ qa,
                                                          const int *__restrict__ qb, int n, double *__restrict__ out) {
-    static_assert(kLanes == 64 || (kLanes == 32 && !kDice), "DICE uses whole wavefronts");
+    static_assert(kLanes == 64 || ((kLanes == 32 || kLanes == 16) && !kDice), "DICE uses whole wavefronts");
     constexpr int kPerBlock = 256 / kLanes;
     // workgroups are dealt to the 8 XCDs in turn: give each XCD (its own L2) a contiguous eighth of the launch's queries
     int blk = blockIdx.x;
@@ -163,7 +173,9 @@ __global__ __launch_bounds__(256) void k_group_pairwise(GroupArgs a, const int *
         // kernel is bound by exactly that latency (64 % of its wave cycles were waits; its L2 misses did not matter: changing
         // the order of the pairs to cut them left the time unchanged).  Same per-lane accumulation order, same shuffles: the
         // results are bit-identical to the general code's.
-        constexpr int kRounds = 4;
+        constexpr int kRounds = kLanes == 16 ? kPairSmallPatch / 16 : 4;  // entries per lane kept in registers: patches of up to 80 / 128 entries (6 and 8
+                                                                          // rounds of sixteen lanes: 89 / 109 registers, 10.2 / 12.1 ms per label step against 9.5)
+        constexpr int kQ = kLanes == 64 ? 32 : kLanes;  // (the fast path is compiled for 32 and 16 lanes per query)
         if (cntA <= kRounds * kLanes && a.D <= 2 && a.simmeasure != 4 && a.simmeasure != 5) {
             int id[kRounds];
             bool mem[kRounds];
@@ -195,7 +207,7 @@ __global__ __launch_bounds__(256) void k_group_pairwise(GroupArgs a, const int *
             // size of the intersection: the set bits of the rounds' ballots within this half wavefront
             int ncommon = 0;
             {
-                const unsigned long long halfmask = 0xffffffffull << ((threadIdx.x & 63) & 32);
+                const unsigned long long halfmask = (kQ == 32 ? 0xffffffffull : 0xffffull) << ((threadIdx.x & 63) & ~(kQ - 1));
 #pragma unroll
                 for (int r = 0; r < kRounds; ++r) ncommon += __popcll(__ballot(mem[r]) & halfmask);
             }
@@ -218,7 +230,7 @@ __global__ __launch_bounds__(256) void k_group_pairwise(GroupArgs a, const int *
                     if (mem[r] && a.mask) w[r] = fabs(a.mask[id[r]]);
                 }
                 const bool two = a.D == 2;
-                const int row = (lane >> 4) & 1;  // the tail of feature row 0 runs in the lower sixteen lanes, of row 1 in the upper
+                const int row = (lane / (kQ / 2)) & 1;  // the tail of feature row 0 runs in the lower half of the query's lanes, of row 1 in the upper
                 double c_row;                     // this lane's row's similarity
                 if (a.simmeasure == 2) {  // sparsesimkernel::corr, M/similarities.cpp:129-158, both feature rows side by side
                     double s1[5] = {0.0, 0.0, 0.0, 0.0, 0.0};  // sum of weights, then weighted sums of A and B per row
@@ -233,10 +245,10 @@ __global__ __launch_bounds__(256) void k_group_pairwise(GroupArgs a, const int *
                             }
                         }
                     // every lane group divides ITS sum by the sum of weights: one division for the four means
-                    double y = half_reduce<5>(s1, lane);
-                    const double sw = half_get(y, 0);
+                    double y = half_reduce<5, kQ>(s1, lane);
+                    const double sw = half_get<kQ>(y, 0);
                     if (sw > 0.0) y /= sw;
-                    const double ma[2] = {half_get(y, 1), half_get(y, 3)}, mb[2] = {half_get(y, 2), half_get(y, 4)};
+                    const double ma[2] = {half_get<kQ>(y, 1), half_get<kQ>(y, 3)}, mb[2] = {half_get<kQ>(y, 2), half_get<kQ>(y, 4)};
                     double s2[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};  // per row: products, variance of A, variance of B
 #pragma unroll
                     for (int r = 0; r < kRounds; ++r)
@@ -250,12 +262,12 @@ __global__ __launch_bounds__(256) void k_group_pairwise(GroupArgs a, const int *
                             }
                         }
                     // likewise one division for the six second moments and one square root for the four variances
-                    double z = half_reduce<6>(s2, lane);
+                    double z = half_reduce<6, kQ>(s2, lane);
                     if (sw > 0.0) z /= sw;
                     const double rt = sqrt(z);  // of a product sum in the lanes that hold one: not used
-                    const int src = (threadIdx.x & 63) & 32;
-                    const double pr = __shfl(z, src | half_lane_of(3 * row), 64);
-                    const double sa = __shfl(rt, src | half_lane_of(3 * row + 1), 64), sb = __shfl(rt, src | half_lane_of(3 * row + 2), 64);
+                    const int src = (threadIdx.x & 63) & ~(kQ - 1);
+                    const double pr = __shfl(z, src | half_lane_of<kQ>(3 * row), 64);
+                    const double sa = __shfl(rt, src | half_lane_of<kQ>(3 * row + 1), 64), sb = __shfl(rt, src | half_lane_of<kQ>(3 * row + 2), 64);
                     // sqrt(x) == 0 exactly when x == 0: the reference's test on the variances
                     const double rr = (sa == 0.0 || sb == 0.0) ? 0.0 : pr / (sa * sb);
                     c_row = 1 - (1 + rr) * 0.5;
@@ -270,11 +282,11 @@ __global__ __launch_bounds__(256) void k_group_pairwise(GroupArgs a, const int *
                                 s1[d] += w[r] * df * df;
                             }
                         }
-                    const double y = half_reduce<2>(s1, lane);  // row 0 in the lower sixteen lanes, row 1 in the upper
+                    const double y = half_reduce<2, kQ>(s1, lane);  // row 0 in the lower half of the query's lanes, row 1 in the upper
                     c_row = sqrt(y) / ncommon;
                 }
                 // cost = (row 0 [+ row 1]) / D, the rows added in the reference's order
-                const double c0 = __shfl(c_row, ((threadIdx.x & 63) & 32), 64), c1 = __shfl(c_row, ((threadIdx.x & 63) & 32) | 16, 64);
+                const double c0 = __shfl(c_row, ((threadIdx.x & 63) & ~(kQ - 1)), 64), c1 = __shfl(c_row, ((threadIdx.x & 63) & ~(kQ - 1)) | (kQ / 2), 64);
                 cost = two ? c0 + c1 : c0;
                 cost /= a.D;
             }
@@ -576,8 +588,9 @@ int launch_group_pairwise(msm_ctx *ctx, const GroupArgs &a, const int *qp, const
         if (lds > 64 * 1024) MSM_HIP(hipFuncSetAttribute((const void *)k_group_pairwise<true, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL((k_group_pairwise<true, 64>), dim3((n + 3) / 4), dim3(256), lds, ctx->stream, a, qp, qa, qb, n, out);
     } else {
-        // half a wavefront per query: patches hold ~65 entries, so two queries share a wavefront's latency
-        hipLaunchKernelGGL((k_group_pairwise<false, 32>), dim3((n + 7) / 8), dim3(256), 0, ctx->stream, a, qp, qa, qb, n, out);
+        // half a wavefront per query: two queries share a wavefront's latency; a quarter when the group's patches are small enough (a.pair_lanes)
+        if (a.pair_lanes == 16) hipLaunchKernelGGL((k_group_pairwise<false, 16>), dim3((n + 15) / 16), dim3(256), 0, ctx->stream, a, qp, qa, qb, n, out);
+        else hipLaunchKernelGGL((k_group_pairwise<false, 32>), dim3((n + 7) / 8), dim3(256), 0, ctx->stream, a, qp, qa, qb, n, out);
     }
     MSM_HIP(hipGetLastError());
     return MSM_OK;

@@ -169,6 +169,7 @@ struct CliqueArgs {
 };
 // ---- fused fusion move of the HO (triclique) classes on a direction-table target (move_kernels.hip) ----
 // The labeling travels in the kernel arguments, one byte per control point (no copy engine on the call's critical path).
+constexpr int kPairSmallPatch = 80;  // entries a 16-lane query of k_group_pairwise keeps in registers (5 per lane)
 constexpr int kHoBinMax = 16384;  // source vertices under one control triangle the on-demand triclique kernels can hold (one workgroup's 128 KB LDS slice)
 constexpr int kMoveLabelWords = 704;  // N <= 2816 control points (ico4: 2562), L <= 256
 struct MoveLabels {
@@ -250,6 +251,7 @@ struct GroupArgs {
     double *move_e00;
     double *move_e11;
     int patch_cap;               // largest patch of any subject (DICE: LDS staging of the common entries)
+    int pair_lanes;              // 32 or 16 lanes per pair cost (group.cpp: msm_group_finalize)
     int *status;
 };
 // out[i], out[stride + i], out[2 * stride + i] (stride 0: V)
