@@ -35,6 +35,12 @@ __device__ __forceinline__ double lanes_sum(double v) {
 // half_reduce leaves value k, complete, in the lanes whose bits 16 / 8 / 4 are bits 0 / 1 / 2 of k (four lanes each); half_get
 // fetches one.  Keeping the sums where they land lets the per-query scalar arithmetic that follows (divisions by the sum of
 // weights, square roots) run ONCE with a different value in every lane group, instead of once per value in all lanes.
+// v of lane (lane ^ kOff): a DPP move within a row of sixteen lanes (similarity_device.hpp), a shuffle through the LDS pipe across rows
+template <int kOff>
+__device__ __forceinline__ double xor_exchange(double v) {
+    if constexpr (kOff >= 16) return __shfl_xor(v, kOff, 64);
+    else return dpp_xor<kOff>(v);
+}
 template <int N, int kLanes = 32>
 __device__ __forceinline__ double half_reduce(const double (&v)[N], int lane) {
     static_assert(N >= 1 && N <= 8, "at most eight values");
@@ -46,19 +52,19 @@ __device__ __forceinline__ double half_reduce(const double (&v)[N], int lane) {
 #pragma unroll
     for (int j = 0; j < N1; ++j) {
         const double e = v[2 * j], o = 2 * j + 1 < N ? v[2 * j + 1] : 0.0;
-        w[j] = (u1 ? o : e) + __shfl_xor(u1 ? e : o, T, 64);
+        w[j] = (u1 ? o : e) + xor_exchange<T>(u1 ? e : o);
     }
 #pragma unroll
     for (int j = 0; j < N2; ++j) {
         const double e = w[2 * j], o = 2 * j + 1 < N1 ? w[2 * j + 1] : 0.0;
-        x[j] = (u2 ? o : e) + __shfl_xor(u2 ? e : o, T / 2, 64);
+        x[j] = (u2 ? o : e) + xor_exchange<T / 2>(u2 ? e : o);
     }
     {
         const double e = x[0], o = N2 > 1 ? x[N2 - 1] : 0.0;
-        y = (u3 ? o : e) + __shfl_xor(u3 ? e : o, T / 4, 64);
+        y = (u3 ? o : e) + xor_exchange<T / 4>(u3 ? e : o);
     }
-#pragma unroll
-    for (int off = T / 8; off > 0; off >>= 1) y += __shfl_xor(y, off, 64);
+    if constexpr (T / 8 >= 2) y += xor_exchange<2>(y);
+    if constexpr (T / 8 >= 1) y += xor_exchange<1>(y);
     return y;
 }
 // which value a lane holds after half_reduce, and a lane that holds value k (kLanes == 16: the same with the lane bits 8 / 4 / 2)

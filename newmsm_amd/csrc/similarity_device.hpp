@@ -160,13 +160,14 @@ __device__ __forceinline__ double div_exact(double x, double s) {
     return x / s;
 }
 
-// v of lane (lane ^ kXor) within each group of eight, by DPP moves (the shuffle of __shfl_xor goes through the LDS pipe: 36 per sample and pass of
+// v of lane (lane ^ kXor), kXor < 16, by DPP moves (the shuffle of __shfl_xor goes through the LDS pipe: 36 per sample and pass of
 // the kernels below, which they wait for): lane ^ 1 and lane ^ 2 are quad permutations, lane ^ 4 two row shifts by four with complementary bank masks
 template <int kXor>
 __device__ __forceinline__ int dpp_xor_i(int x) {
-    static_assert(kXor == 1 || kXor == 2 || kXor == 4, "within a group of eight lanes");
+    static_assert(kXor == 1 || kXor == 2 || kXor == 4 || kXor == 8, "within a row of sixteen lanes");
     if (kXor == 1) return __builtin_amdgcn_update_dpp(x, x, 0xB1, 0xf, 0xf, false);  // quad_perm [1,0,3,2]
     if (kXor == 2) return __builtin_amdgcn_update_dpp(x, x, 0x4E, 0xf, 0xf, false);  // quad_perm [2,3,0,1]
+    if (kXor == 8) return __builtin_amdgcn_update_dpp(x, x, 0x128, 0xf, 0xf, false); // row_ror:8: lane <- lane +- 8 within its row
     const int t = __builtin_amdgcn_update_dpp(x, x, 0x104, 0xf, 0x5, false);         // row_shl:4 into lanes 0-3 and 8-11 of each row: lane <- lane + 4
     return __builtin_amdgcn_update_dpp(t, x, 0x114, 0xf, 0xa, false);                // row_shr:4 into lanes 4-7 and 12-15: lane <- lane - 4
 }
