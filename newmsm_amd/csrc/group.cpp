@@ -1221,6 +1221,9 @@ int msm_group_finalize(msm_group *g) {
     // instead of two (label step 12.5 -> 9.5 ms at ico6 / ico4, patches of ~65 entries); the others take the general path, at half the lanes
     g->pair_lanes = (npatch > 0 && 10 * nsmall >= 9 * npatch) ? 16 : 32;
     if (const char *e = std::getenv("MSMHIP_GROUP_PAIR_LANES")) g->pair_lanes = std::atoi(e) == 16 ? 16 : 32;
+    if (std::getenv("MSMHIP_TIMING"))
+        fprintf(stderr, "  group patches: %lld, %.1f %% of them with at most %d entries, largest %d -> %d lanes per pair cost\n", (long long)npatch,
+                npatch ? 100.0 * (double)nsmall / (double)npatch : 0.0, kPairSmallPatch, g->patch_max, g->pair_lanes);
     g->ready = true;
     return MSM_OK;
 }
