@@ -341,7 +341,7 @@ def bench_gmsm(ctx, S, comm, label_steps=6, change=0.10):
                        "label_steps_per_iteration": steps, "iteration_s": it_s, "pair_evals_per_step": 4 * sizes["pairs"], "triplet_evals_per_step": 8 * sizes["triplets"]})
         prof = gmsm_valu_profile(S, data_order, cp_order) if comm.world == 1 and change == 0.10 else None
         if prof and sizes["step_kernels_s"]:
-            # the label step is bound by FP64 / integer vector issue, not by HBM (0.61 GB per launch = 0.06 of the HBM roofline): achieved =
+            # the label step is priced against FP64 / integer vector issue, not HBM (0.61 GB per launch = 0.06 of the HBM roofline): achieved =
             # the pair kernel's VALU wave-instructions per step (counters of the committed profile) / this run's GPU time of a step
             per_step = prof["per_launch"] * prof["launches_per_step"]
             achieved = per_step / sizes["step_kernels_s"]
@@ -350,7 +350,9 @@ def bench_gmsm(ctx, S, comm, label_steps=6, change=0.10):
                         "valu_wave_instructions_per_label_step": per_step, "source": GMSM_PMC_PROFILE + ": SQ_INSTS_VALU per launch x launches per step",
                         "step_kernels_ms_events": sizes["step_kernels_s"] * 1e3, "kernel_avg_ms_rocprof": prof["kernel_avg_ns"] * 1e-6,
                         "level": "ico%d / ico%d" % (data_order, cp_order),
-                        "note": "a step's GPU time (HIP events around its kernels on the launch stream) also holds the strain triplets and the kept-cost copies"}
+                        "note": "a step's GPU time (HIP events around its kernels on the launch stream) also holds the strain triplets and the kept-cost copies.  "
+                                "An upper bound on what instruction issue explains, not the binding limit: rewrites that cut the instructions by up to a third left the "
+                                "step where it was, a quarter wavefront per pair cost (more dependent chains in flight) took it from 12.5 to 9.3 ms (DESIGN.md 5.6)"}
     out = {"subjects": S, "levels": levels, "iterations_per_level": GMSM_ITERATIONS, "path_s_per_group": total, "subjects_per_hour": S / total * 3600.0,
            "config": {"label_change_fraction": change, "label_steps_timed": label_steps,
                       "model": "between label steps that fraction of the nodes changes its label (the library keeps the (current, current) costs of untouched pairs); half of the "
