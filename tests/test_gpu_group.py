@@ -85,8 +85,12 @@ def test_group_subjects_on_different_data_meshes(ctx):
     assert np.allclose(got[~both], want[~both], rtol=RTOL, atol=ATOL)
 
 
+@pytest.mark.parametrize("lanes", [None, 16, 32])
 @pytest.mark.parametrize("mask,sim", [(False, 2), (True, 2), (False, 1)])
-def test_group_pairwise_costs(ctx, mask, sim):
+def test_group_pairwise_costs(ctx, monkeypatch, mask, sim, lanes):
+    # lanes: a quarter or half a wavefront per pair cost (k_group_pairwise<false, 16 | 32>); None: chosen from the group's patch sizes
+    if lanes is not None:
+        monkeypatch.setenv("MSMHIP_GROUP_PAIR_LANES", str(lanes))  # read when the set-up is finalised
     g, og, _ = build(ctx, mask=mask, sim=sim)
     rng = np.random.default_rng(1)
     p = rng.integers(0, g.P, 400).astype(np.int32)
@@ -122,9 +126,12 @@ def test_group_rejects_bad_similarity(ctx):
         M.DiscreteGroupCostFunction(ctx, 2, simmeasure=4, percentile=1.0)
 
 
-def test_group_fusion_move(ctx):
+@pytest.mark.parametrize("lanes", [16, 32])
+def test_group_fusion_move(ctx, monkeypatch, lanes):
     """one label step of Fusion::optimize in one call: the four pair costs and eight triplet costs per clique, in the buffer
-    order of Fusion.h:170-173,188-195, equal to the explicit batches (same kernels) and to the oracle"""
+    order of Fusion.h:170-173,188-195, equal to the explicit batches (same kernels) and to the oracle; with a quarter and with
+    half a wavefront per pair cost"""
+    monkeypatch.setenv("MSMHIP_GROUP_PAIR_LANES", str(lanes))
     g, og, _ = build(ctx, mask=True)
     rng = np.random.default_rng(5)
     labeling = rng.integers(0, g.L, g.num_nodes).astype(np.int32)
