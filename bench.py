@@ -368,6 +368,76 @@ def bench_gmsm(ctx, S, comm, label_steps=6, change=0.10):
     return out
 
 
+def free_port():
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def self_launch(n, argv):
+    """`python bench.py --gpus N` with N > 1 outside a launcher: start the N ranks as `python -m torch.distributed.run` would be typed by hand --
+    one process per GPU, rendezvous on 127.0.0.1 -- as a CHILD process, pass its output through and exit with its code.  This process has not
+    imported torch or touched HIP and never does (a process that has initialised the GPU must not be replaced by or turned into another).
+    The reference's own scale-out launches independent processes the same way (gMSM_scripts/group_reg_dataset.sh:9-33: SLURM tasks)."""
+    import subprocess
+
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ, MSM_BENCH_SELF_LAUNCHED="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // n)))
+    sys.stdout.flush()
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def bench_template_allreduce(comm, S, V, Dfeat, reps=20):
+    """The collective north_star names: the group-mean template update of a groupwise run -- what gMSM_scripts/run_gMSM.sh:66-139 does with files,
+    `wb_command -surface-average` and `-metric-reduce MEAN / STDEV` -- as ONE all-reduce(sum) of [sum xyz | sum f | sum f^2 | n] over the ranks'
+    accumulators (newmsm_amd/dist.py: group_template_update; RCCL over xGMI with the nccl backend).  Every rank holds the registered spheres and
+    resampled features of ITS subjects (synthetic here: subject s contributes the constant s + 1, so the reduced sums are known)."""
+    import numpy as np
+    import torch
+
+    from newmsm_amd import dist as D
+
+    mine = list(D.shard(S, comm.rank, comm.world))
+    n = 3 * V + 2 * Dfeat * V + 1
+    out = {"bytes": 8 * n, "ranks": comm.world, "subjects": S, "layout": "[sum xyz 3V | sum f DV | sum f^2 DV | n] f64, V = %d, D = %d" % (V, Dfeat),
+           "collective": "none (one process, no communicator)" if comm.dist is None else "all_reduce(sum), backend %s, tensors on %s" % (comm.backend, comm.device)}
+    spheres = np.empty((len(mine), V, 3))
+    feats = np.empty((len(mine), Dfeat, V))
+    for k, s in enumerate(mine):
+        spheres[k], feats[k] = s + 1.0, s + 1.0
+    t0 = time.perf_counter()
+    res = D.group_template_update(spheres, feats, comm)
+    out["us_call_first"] = (time.perf_counter() - t0) * 1e6
+    ok = res["n_subjects"] == S and np.allclose(res["mean"], (S + 1) / 2.0)
+    if comm.dist is not None:
+        acc = torch.ones(n, dtype=torch.float64, device=comm.device)
+        ts = []
+        for _ in range(reps):
+            acc.fill_(1.0)
+            if comm.on_gpu:
+                torch.cuda.synchronize()
+            comm.barrier()
+            t0 = time.perf_counter()
+            comm.dist.all_reduce(acc, op=comm.dist.ReduceOp.SUM)
+            if comm.on_gpu:
+                torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        ok = ok and bool((acc == float(comm.world)).all().item())
+        out["us"] = D.max_over_ranks(float(np.median(ts)), comm) * 1e6
+        out["us_definition"] = "median of %d all-reduces of the accumulator tensor, issue to completion on the slowest rank" % reps
+    t0 = time.perf_counter()
+    D.group_template_update(spheres, feats, comm)
+    out["us_call"] = D.max_over_ranks(time.perf_counter() - t0, comm) * 1e6
+    out["us_call_definition"] = "group_template_update: local sums on the host, upload, the all-reduce, download, mean sphere / mean / stdev"
+    out["sums_correct"] = bool(ok)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -381,7 +451,13 @@ def main():
     ap.add_argument("--label-change", type=float, default=0.10, help="gMSM: fraction of the nodes whose label changes between two label steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="headline line only (profiling runs)")
+    ap.add_argument("--dry-launch", action="store_true", help="launch the ranks, create the communicator, count the ranks through it, print that and stop "
+                                                              "(no GPU work: the check that --gpus N really starts N ranks; gloo when no GPU is visible)")
     args = ap.parse_args()
+
+    # --gpus N outside a launcher: become the launcher's parent BEFORE torch or HIP are touched (the driver's N = 1 command shape with N > 1)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args.gpus, sys.argv[1:])
 
     import numpy as np
     import torch
@@ -389,6 +465,20 @@ def main():
     from newmsm_amd import dist as D
 
     rank, local_rank, world = D.env()
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE): the line would misreport n_gpus" % (args.gpus, world))
+    if args.dry_launch:
+        gpu = torch.cuda.is_available() and os.environ.get("MSM_BENCH_REHEARSAL") != "1"
+        comm = D.init("nccl" if gpu else "gloo", local_rank if gpu else None)
+        seen = D.count_ranks(comm)
+        ranks = D.all_reduce_sum(np.eye(world)[rank], comm)
+        tmpl = bench_template_allreduce(comm, 64, 2562, 2, reps=3)
+        if rank == 0:
+            print(json.dumps({"dry_launch": True, "n_gpus": seen, "world": world, "gpus_asked": args.gpus, "backend": comm.backend,
+                              "every_rank_reported": bool((ranks == 1.0).all()), "self_launched": os.environ.get("MSM_BENCH_SELF_LAUNCHED") == "1",
+                              "template_allreduce": tmpl}))
+        comm.close()
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     # rehearsal of the N > 1 path on a one-GPU box: all ranks share cuda:0 and talk over gloo
@@ -414,17 +504,37 @@ def main():
         comm.barrier()
         torch.cuda.synchronize()
 
+    n_gpus = D.count_ranks(comm)  # an all-reduce of ones over the communicator: the ranks RCCL saw
+    if n_gpus != args.gpus:
+        raise SystemExit("bench.py: the communicator has %d rank(s), --gpus says %d" % (n_gpus, args.gpus))
+
+    def template_allreduce():
+        """gmsm.template_allreduce: the group-mean template update at ico6, D = 2 over this run's communicator; a single process makes a
+        one-rank RCCL communicator for it, so that the N = 1 line shows the same call"""
+        try:
+            if comm.dist is not None:
+                return bench_template_allreduce(comm, args.subjects, 40962, 2)
+            os.environ["MASTER_PORT"] = str(free_port())
+            one = D.init("nccl", device_index)
+            try:
+                return bench_template_allreduce(one, args.subjects, 40962, 2)
+            finally:
+                one.close()
+        except Exception as e:  # reported, not fatal
+            return {"error": repr(e)}
+
     if args.mode == "gmsm":
         # strong scaling: the same 64-subject group whatever N.  One "step" = the cost-function side of one iteration at the last level
         # (ico6 / ico4); --warmup iterations untimed, --steps timed ones are folded into the per-level measurement (set-up once per level)
         sync_all()
         t0 = time.perf_counter()
         res = bench_gmsm(ctx, args.subjects, comm, label_steps=max(2, min(args.steps, 8)), change=args.label_change)
+        res["template_allreduce"] = template_allreduce()
         sync_all()
         if rank == 0:
             last = res["levels"][-1]
             print(json.dumps({
-                "metric": "gMSM subjects/hour", "value": res["subjects_per_hour"], "unit": "subjects/hour", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "metric": "gMSM subjects/hour", "value": res["subjects_per_hour"], "unit": "subjects/hour", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": last["iteration_s"] * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
                 "config": {"workload": "gMSM groupwise, %d synthetic subjects (D=2), levels data ico4/5/6 / control ico2/3/4, %d iterations per level, sharded over %d GPU(s) "
                                        "(BASELINE config 5); a step = one iteration at ico6 / ico4" % (args.subjects, GMSM_ITERATIONS, world),
@@ -490,6 +600,7 @@ def main():
         try:
             gmsm_scaling = bench_gmsm(ctx, args.subjects, comm, change=args.label_change)
             gmsm_scaling["scaling"] = "strong"
+            gmsm_scaling["template_allreduce"] = template_allreduce()
         except Exception as e:  # reported, not fatal: the headline of this run stands
             gmsm_scaling = {"error": repr(e)}
 
@@ -502,7 +613,7 @@ def main():
             "metric": "label-cost evals/sec",
             "value": value,
             "unit": "evals/s",
-            "n_gpus": world,
+            "n_gpus": n_gpus,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": wall / args.steps * 1e3,
@@ -544,6 +655,7 @@ def main():
                 out["registration_fusion"] = bench_registration(ctx, "fusion", check=chk)
                 out["registration_msmall"] = bench_registration_msmall(ctx, check=chk)
                 out["gmsm"] = bench_gmsm(ctx, args.subjects, comm, change=args.label_change)
+                out["gmsm"]["template_allreduce"] = template_allreduce()
         if world == 1 and not args.no_cpu_baseline:
             Uo, rate, dt, reps = cpu_baseline(inp, kind, threads)
             out["cpu_baseline"] = {

@@ -130,6 +130,11 @@ def all_reduce_sum(arr, comm=None):
     return t.cpu().numpy()
 
 
+def count_ranks(comm=None):
+    """how many ranks the communicator really has: an all-reduce(sum) of ones -- what RCCL saw, not what the environment says"""
+    return int(round(float(all_reduce_sum(np.ones(1), comm)[0])))
+
+
 def max_over_ranks(value, comm=None):
     c = _comm(comm)
     if c.dist is None:

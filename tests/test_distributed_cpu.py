@@ -162,3 +162,27 @@ def test_shared_step_buffer_two_ranks(tmp_path):
         so, se = p.communicate(timeout=240)
         assert p.returncode == 0, se[-2000:]
         assert json.loads(so.strip().splitlines()[-1])["ok"]
+
+
+def _bench(argv, env=None, timeout=600):
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout)
+    lines = [ln for ln in p.stdout.strip().splitlines() if ln.startswith("{")]
+    return p.returncode, (json.loads(lines[-1]) if lines else None), p.stderr
+
+
+def test_bench_gpus_2_starts_two_ranks():
+    """`python bench.py --gpus 2` -- the shape of the driver's N = 1 command with N > 1 -- launches its own ranks (torch.distributed.run as a child),
+    and n_gpus is what an all-reduce of ones over the communicator says.  --dry-launch stops after the communicator exists (no GPU here)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    rc, line, err = _bench(["--gpus", "2", "--dry-launch"], env)
+    assert rc == 0, err[-2000:]
+    assert line["dry_launch"] and line["self_launched"] and line["n_gpus"] == 2 and line["world"] == 2 and line["every_rank_reported"]
+    t = line["template_allreduce"]  # the north-star collective ran over the same communicator
+    assert t["ranks"] == 2 and t["sums_correct"] and t["bytes"] == 8 * (7 * 2562 + 1) and t["us"] > 0
+
+
+def test_bench_refuses_a_world_that_is_not_gpus():
+    """under a launcher that started another number of ranks than --gpus says the bench ends non-zero instead of misreporting n_gpus"""
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    rc, line, err = _bench(["--gpus", "2", "--dry-launch"], env)
+    assert rc != 0 and line is None and "--gpus 2" in err
