@@ -168,7 +168,7 @@ def bench_resample(ctx, calls, cpu):
            "queries_per_s_kernel": N / kern_s, "kernel_us": kern_s * 1e6, "queries_per_s_call": N / call_s, "us_per_call": call_s * 1e6, "calls": calls,
            "call": "msm_query_triangles with host arrays in and out: upload of the queries, kernel, three result arrays back, one synchronisation",
            "roofline": {"bound": "hbm", "achieved": nbytes / kern_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nbytes / kern_s / 1e9 / HBM_PEAK_GBS,
-                        "kernel": "msm::k_query<4>", "algorithmic_bytes_per_launch": nbytes,
+                        "kernel": "msm::k_query<%d>" % ctx.query_lanes(N), "algorithmic_bytes_per_launch": nbytes,
                         "note": "kernel time = HIP events around the launch on its stream; a launch of this size (2 561 wavefronts) is a dependent chain of "
                                 "six memory accesses per query (query, grid cell, node, cones, triangle id, record), not a stream: see DESIGN.md section 5.1"}}
     if cpu:

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MSM_ABI_VERSION 7  /* 6 (round 3): msm_pairwise_icm, msm_ctx_time_queries / msm_ctx_query_kernel_ms, msm_group_time_moves / msm_group_move_kernels_ms,
+#define MSM_ABI_VERSION 8  /* 8 (round 4): msm_query_lanes added.  6 (round 3): msm_pairwise_icm, msm_ctx_time_queries / msm_ctx_query_kernel_ms, msm_group_time_moves / msm_group_move_kernels_ms,
                              * msm_store_release_i64 / msm_load_acquire_i64 / msm_min_acquire_i64, msm_mesh_sphere_project_warp added; nothing removed or changed */
 
 #define MSM_OK 0
@@ -124,6 +124,7 @@ int64_t  msm_load_acquire_i64(const int64_t *addr);
 int64_t  msm_min_acquire_i64(const int64_t *addr, int32_t n);   /* the smallest of n counters, each read with acquire semantics */
 int      msm_ctx_time_queries(msm_ctx *ctx, int enable);
 int      msm_ctx_query_kernel_ms(msm_ctx *ctx, double *ms);
+int      msm_query_lanes(int64_t n_queries);                 /* [host] lanes per query (4 or 8) the search kernels use for a launch of n_queries: names the instantiation a profile shows */
 /* Pinned host memory mapped into the GPU's address space.  An output array that lies inside such a block is written by the
  * kernels directly (no staging copy, no copy-engine command): use it for the arrays of the optimisers' inner loop --
  * msm_cost_triplet_octets' E, msm_group_fusion_move's pair_quads / triplet_octets -- the counterpart of the buffers

@@ -76,7 +76,9 @@ inline int to_int(const std::string &key, const std::string &v) {
 }
 }  // namespace detail
 
-inline Config parse_config(const std::string &text) {
+// text: the contents of the configuration file; no_config: no --conf was given (the reference branches on the file NAME being empty,
+// M/mesh_registration.cpp:627 -- an empty file is not "no config": it yields zero levels)
+inline Config parse_config(const std::string &text, bool no_config = false) {
     Config c;
     std::set<std::string> seen;
     std::istringstream in(text);
@@ -131,7 +133,7 @@ inline Config parse_config(const std::string &text) {
         seen.insert(key);
     }
     auto set = [&](const char *k) { return seen.count(k) != 0; };
-    if (seen.empty()) {  // no config: the sulc configuration of September 2014 (M/mesh_registration.cpp:629-642)
+    if (no_config) {  // no config: the sulc configuration of September 2014 (M/mesh_registration.cpp:629-642)
         c.opt = {"RIGID", "DISCRETE", "DISCRETE", "DISCRETE"};
         c.lambda = {0.0, (double)0.1f, (double)0.2f, (double)0.3f};
         c.simval = {1, 2, 2, 2};

@@ -66,6 +66,7 @@ SIGNATURES = {
     "msm_min_acquire_i64": (C.c_int64, [_VP, C.c_int32]),
     "msm_ctx_time_queries": (C.c_int, [_VP, C.c_int]),
     "msm_ctx_query_kernel_ms": (C.c_int, [_VP, c_dp]),
+    "msm_query_lanes": (C.c_int, [C.c_int64]),
     "msm_host_alloc": (_VP, [_VP, C.c_size_t]),
     "msm_host_free": (None, [_VP, _VP]),
     "msm_host_register": (C.c_int, [_VP, _VP, C.c_size_t]),

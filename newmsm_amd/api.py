@@ -217,6 +217,11 @@ class Context:
         check(lib().msm_ctx_query_kernel_ms(self.h, C.byref(ms)))
         return ms.value
 
+    @staticmethod
+    def query_lanes(n_queries):
+        """lanes per query (4 or 8) of the search kernels for a launch of n_queries (msm_query_lanes): the k_query<G> instantiation that runs"""
+        return int(lib().msm_query_lanes(int(n_queries)))
+
     def forest_signatures(self, xyz_sets, tri):
         """leaf signatures (Mesh.octree_signature) of the trees of B coordinate sets over one triangle list, built together as a forest"""
         sets = [np.ascontiguousarray(np.asarray(x, dtype=np.float64).T) for x in xyz_sets]

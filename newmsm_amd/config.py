@@ -40,10 +40,16 @@ _DEFAULT = dict(regoption=1, dopt="FastPD", shearmod=_f32(0.4), bulkmod=_f32(1.6
 
 
 def parse_config(text):
-    """`text`: the contents of a configuration file.  Returns the options as parse_reg_options holds them after its defaults and checks
-    (per-level lists have one entry per resolution level); raises ConfigError with the reference's messages."""
+    """`text`: the contents of a configuration file, or None when no --conf was given.  Returns the options as parse_reg_options holds them
+    after its defaults and checks (per-level lists have one entry per resolution level); raises ConfigError -- the consistency checks with
+    the reference's messages, the grammar errors (which FSL's option parser reports in its own words) with the line number.
+    The reference branches on the file NAME being empty (M/mesh_registration.cpp:627): only `None` selects the built-in sulc schedule; a
+    file that is empty or holds comments only goes through the other branch and yields zero levels.  --regoption is passed through as
+    given (2 is documented as an alias of 3 in the help text but nothing in parse_reg_options maps it; the cost function treats 2 and 3
+    alike, M/DiscreteCostFunction.cpp:158-160)."""
     raw = {}
-    for lineno, line in enumerate(text.splitlines(), 1):
+    no_config = text is None
+    for lineno, line in enumerate((text or "").splitlines(), 1):
         line = line.split("#", 1)[0].strip()
         if not line:
             continue
@@ -79,7 +85,7 @@ def parse_config(text):
     cfg = dict(_DEFAULT)
     cfg.update({k: False for k in _FLAG})
     cfg.update(raw)
-    if not raw:  # no config: the sulc configuration of September 2014 (M/mesh_registration.cpp:629-642)
+    if no_config:  # no config: the sulc configuration of September 2014 (M/mesh_registration.cpp:629-642)
         cfg.update(opt=["RIGID", "DISCRETE", "DISCRETE", "DISCRETE"], **{"lambda": [0.0, _f32(0.1), _f32(0.2), _f32(0.3)]}, simval=[1, 2, 2, 2],
                    sigma_in=[2.0, 2.0, 3.0, 2.0], sigma_ref=[2.0, 2.0, 1.5, 1.0], it=[50, 3, 3, 3], CPgrid=[0, 2, 3, 4], anatgrid=[0, 4, 5, 6],
                    datagrid=[4, 4, 5, 6], SGgrid=[0, 4, 5, 6])

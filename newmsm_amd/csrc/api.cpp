@@ -200,7 +200,9 @@ static int ensure_tree_overlapped(msm_mesh *m, const std::function<void()> *over
         if (st != MSM_ERR_CAPACITY) return st;  // a tree that outgrew the preallocated arrays (a degenerate mesh): the host build below
     }
     if (m->host_xyz_stale) {
-        MSM_HIP(hipMemcpy(m->xyz.data(), m->d_xyz, sizeof(double) * 3 * (size_t)m->V, hipMemcpyDeviceToHost));
+        // on the context's stream (created non-blocking: the null stream does not wait for the kernels that wrote the coordinates there)
+        MSM_HIP(hipMemcpyAsync(m->xyz.data(), m->d_xyz, sizeof(double) * 3 * (size_t)m->V, hipMemcpyDeviceToHost, m->ctx->stream));
+        MSM_HIP(hipStreamSynchronize(m->ctx->stream));
         m->host_xyz_stale = false;
     }
     build_octree(m->xyz.data(), m->tri.data(), m->V, m->T, m->tree);
@@ -343,7 +345,9 @@ int ensure_rays(msm_mesh *m, bool wait) {
     int st = ensure_masks(m);  // what the ray table cannot settle goes through the masked search
     if (st) return st;
     if (m->host_xyz_stale) {  // coordinates written on the device (group.cpp: lane meshes): the table is keyed by and built from the host copy
-        MSM_HIP(hipMemcpy(m->xyz.data(), m->d_xyz, sizeof(double) * 3 * (size_t)m->V, hipMemcpyDeviceToHost));
+        // on the context's stream (created non-blocking: the null stream does not wait for the kernels that wrote the coordinates there)
+        MSM_HIP(hipMemcpyAsync(m->xyz.data(), m->d_xyz, sizeof(double) * 3 * (size_t)m->V, hipMemcpyDeviceToHost, m->ctx->stream));
+        MSM_HIP(hipStreamSynchronize(m->ctx->stream));
         m->host_xyz_stale = false;
     }
     if (m->rays_valid) return ensure_rayrec(m);
@@ -818,6 +822,10 @@ static msm_ctx *ctx_make(int device, hipStream_t stream, bool own) {
     }
     msm_ctx *ctx = new msm_ctx();
     ctx->device = device;
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) ctx->num_cus = cus;
+    }
     ctx->own_stream = own;
     ctx->stream = stream;
     if (own && hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
@@ -899,6 +907,8 @@ int msm_ctx_query_kernel_ms(msm_ctx *ctx, double *ms) {
     *ms = f;
     return MSM_OK;
 }
+
+int msm_query_lanes(int64_t n_queries) { return msm::query_lanes((long long)n_queries); }
 
 void *msm_host_alloc(msm_ctx *ctx, size_t bytes) {
     if (!ctx || bytes == 0) {

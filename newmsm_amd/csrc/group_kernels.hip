@@ -304,23 +304,27 @@ __global__ __launch_bounds__(256) void k_group_pairwise(GroupArgs a, const int *
             return;
         }
     }
-    // membership of A's entries in B, kept as a bit per (lane, round): patches hold at most 2048 entries
-    unsigned long long member = 0ull;
-    int common = 0;
-    for (int r = 0, i = lane; i < cntA; i += kLanes, ++r) {
-        const int id = ia[i];
+    // membership of A's entries in B (std::map::find, M/DiscreteGroupCostFunction.cpp:75-78), kept as a bit per (lane, round) for the first 64
+    // rounds (64 x kLanes entries: 1024 with a quarter wavefront per query); the entries of a larger patch are looked up again in every pass --
+    // the reference has no limit on a patch's size and neither has this path (DICE packs the common entries into LDS: 64 lanes, 4096 entries)
+    const auto in_b = [&](int id) {
         int lo = 0, hi = cntB;
         while (lo < hi) {
             const int mid = (lo + hi) >> 1;
             if (fb[mid] < id) lo = mid + 1;
             else hi = mid;
         }
-        if (lo < cntB && fb[lo] == id) {
-            member |= 1ull << r;
+        return lo < cntB && fb[lo] == id;
+    };
+    unsigned long long member = 0ull;
+    int common = 0;
+    for (int r = 0, i = lane; i < cntA; i += kLanes, ++r)
+        if (in_b(ia[i])) {
+            if (r < 64) member |= 1ull << r;
             ++common;
         }
-    }
-    if (cntA > 64 * 32) raise_status(a.status, MSM_ERR_CAPACITY);
+    const auto is_member = [&](int r, int i) { return r < 64 ? (member >> r & 1ull) != 0 : in_b(ia[i]); };
+    if (kDice && cntA > 64 * 64) raise_status(a.status, MSM_ERR_CAPACITY);
     const int ncommon = (int)lanes_sum<kLanes>((double)common);
     double cost = 0.0;
     if (ncommon == 0) {
@@ -351,7 +355,7 @@ __global__ __launch_bounds__(256) void k_group_pairwise(GroupArgs a, const int *
             } else if (a.simmeasure == 2) {  // sparsesimkernel::corr, M/similarities.cpp:129-158
                 double sw = 0, ma = 0, mb = 0;
                 for (int r = 0, i = lane; i < cntA; i += kLanes, ++r)
-                    if (member >> r & 1ull) {
+                    if (is_member(r, i)) {
                         const int id = ia[i];
                         const double w = a.mask ? fabs(a.mask[id]) : 1.0;
                         sw += w;
@@ -367,7 +371,7 @@ __global__ __launch_bounds__(256) void k_group_pairwise(GroupArgs a, const int *
                 }
                 double pr = 0, va = 0, vb = 0;
                 for (int r = 0, i = lane; i < cntA; i += kLanes, ++r)
-                    if (member >> r & 1ull) {
+                    if (is_member(r, i)) {
                         const int id = ia[i];
                         const double w = a.mask ? fabs(a.mask[id]) : 1.0, da = A[id] - ma, db = B[id] - mb;
                         pr += w * da * db;
@@ -387,7 +391,7 @@ __global__ __launch_bounds__(256) void k_group_pairwise(GroupArgs a, const int *
             } else {  // sparsesimkernel::SSD, :179-188
                 double pr = 0;
                 for (int r = 0, i = lane; i < cntA; i += kLanes, ++r)
-                    if (member >> r & 1ull) {
+                    if (is_member(r, i)) {
                         const int id = ia[i];
                         const double w = a.mask ? fabs(a.mask[id]) : 1.0, df = A[id] - B[id];
                         pr += w * df * df;

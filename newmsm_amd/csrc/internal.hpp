@@ -122,6 +122,7 @@ struct DevTree {
 // ---------------------------------------------------------------- handles
 struct msm_ctx {
     int device = 0;
+    int num_cus = 256;  // hipDeviceAttributeMultiprocessorCount (MI355X: 256; a partitioned or smaller device has fewer): sizes the launches whose workgroups wait for one another
     hipStream_t stream = nullptr;
     bool own_stream = false;
     int *d_status = nullptr;  // first error code raised by a kernel (atomicMin), 0 when clean

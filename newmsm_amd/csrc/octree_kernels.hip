@@ -355,7 +355,7 @@ __global__ __launch_bounds__(1024) void k_oct_scan(OctWork w, int depth) {
             // (bounded: should a block before this one never report -- it cannot, see above -- the build gives up and the host builds the tree)
             for (int spin = 0; __hip_atomic_load(w.agg + 8 * (size_t)j + 7, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != epoch; ++spin) {
                 if (spin > (1 << 22)) {
-                    atomicOr(&w.counters[C_SCAN_OVER], 1);
+                    atomicOr(&w.counters[C_SCAN_OVER], 2);  // 2: a wait that ran out (reported under MSMHIP_TIMING), 1: an array that is too small
                     break;
                 }
                 __builtin_amdgcn_s_sleep(2);
@@ -441,8 +441,8 @@ __global__ __launch_bounds__(1024) void k_oct_scan(OctWork w, int depth) {
             }
             if (tid == 0) {
                 w.counters[C_SCAN_DONE] = 0;
-                if (__hip_atomic_load(&w.counters[C_SCAN_OVER], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                    w.counters[C_OVERFLOW] = 1;
+                if (const int over = __hip_atomic_load(&w.counters[C_SCAN_OVER], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                    w.counters[C_OVERFLOW] = over;
                     w.counters[C_NOPEN] = 0;
                     w.counters[C_NCHUNK] = w.counters[C_NCHUNK_NEXT] = 0;
                 } else {
@@ -586,8 +586,9 @@ int queue_levels(msm_ctx *ctx, OctJob &j, int count) {
     const int upto = std::min(kMaxLevels, j.depth + count);
     const unsigned B = (unsigned)j.trees;
     const unsigned div = B > 1 ? 4 : 1;  // a forest's trees share the machine
-    // k_oct_scan's workgroups wait for one another: all of a launch must be resident at once (256 CUs, at least one 1024-thread workgroup each)
-    const unsigned scan_blocks = std::max(1u, std::min((unsigned)kScanBlocks, 256u / B));
+    // k_oct_scan's workgroups wait for one another: all of a launch must be resident at once (at least one 1024-thread workgroup per CU of THIS
+    // device: 256 on an MI355X, fewer on a partition)
+    const unsigned scan_blocks = std::max(1u, std::min((unsigned)kScanBlocks, (unsigned)std::max(1, ctx->num_cus) / B));
     for (; j.depth < upto; ++j.depth) {
         if (j.cur == 0) {
             hipLaunchKernelGGL(k_oct_decide<0>, dim3(512 / div, B), dim3(256), 0, ctx->stream, j.w);
@@ -712,6 +713,8 @@ int gpu_build_octree_finish(msm_mesh *m) {
         int *h_counters;
     } s{ctx->oct_hcounters};
     const int *hc = s.h_counters;
+    if ((hc[C_OVERFLOW] & 2) && std::getenv("MSMHIP_TIMING"))
+        fprintf(stderr, "  octree build: a k_oct_scan workgroup waited in vain for an earlier one (%d CUs, not all of the launch resident?): host build instead\n", ctx->num_cus);
     if (hc[C_OVERFLOW] || hc[C_NOPEN] != 0) return MSM_ERR_CAPACITY;
     FlatOctree &o = m->tree;
     o = FlatOctree{};  // no host arrays: the tree lives on the device (dev_nnodes etc. below describe it)
@@ -809,6 +812,8 @@ int gpu_build_forest(msm_ctx *ctx, Forest &f, const double *d_xyz, size_t comp_s
     f.info.assign(B, Forest::Info{});
     for (int b = 0; b < B; ++b) {
         const int *hc = f.h_counters + (size_t)b * (C_COUNT + 1);
+        if ((hc[C_OVERFLOW] & 2) && std::getenv("MSMHIP_TIMING"))
+            fprintf(stderr, "  forest build: a k_oct_scan workgroup of tree %d waited in vain for an earlier one (%d CUs): per-tree builds instead\n", b, ctx->num_cus);
         if (hc[C_OVERFLOW] || hc[C_NOPEN] != 0) return MSM_ERR_CAPACITY;
         f.info[b].nnodes = hc[C_NNODES];
         f.info[b].entries = hc[C_ARENA];

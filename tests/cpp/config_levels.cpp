@@ -12,7 +12,7 @@ int main(int argc, char **argv) {
     std::stringstream ss;
     ss << in.rdbuf();
     try {
-        const msmhip::Config c = msmhip::parse_config(ss.str());
+        const msmhip::Config c = msmhip::parse_config(ss.str(), std::string(argv[1]) == "NONE");  // NONE: no --conf given
         bool vn = false;
         std::vector<std::pair<int, std::string>> skipped;
         const auto levels = msmhip::levels_from_config(c, std::atoi(argv[2]), &vn, &skipped);

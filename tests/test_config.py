@@ -87,7 +87,9 @@ def test_defaults_and_the_affine_level():
 
 
 def test_no_config_is_the_sulc_configuration():
-    cfg = config.parse_config("")
+    empty = config.parse_config("# nothing but a comment\n")  # an empty FILE is not "no config" (the reference tests the file name): zero levels
+    assert empty["opt"] == [] and empty["levels"] == 0 and config.levels_from_config(empty, D=1)[0] == []
+    cfg = config.parse_config(None)
     assert cfg["opt"] == ["RIGID", "DISCRETE", "DISCRETE", "DISCRETE"] and cfg["it"] == [50, 3, 3, 3] and cfg["datagrid"] == [4, 4, 5, 6]
     assert cfg["regoption"] == 1 and cfg["dopt"] == "FastPD"
     levels, _, skipped = config.levels_from_config(cfg, D=1)

@@ -51,6 +51,15 @@ def test_cpp_parser_gives_the_python_schedule(exe, tmp_path, text, D):
         assert g == flat
 
 
+def test_cpp_parser_without_a_config_file(exe):
+    """no --conf: the built-in sulc schedule (M/mesh_registration.cpp:627-642); an empty file is something else (zero levels, EXTRA above)"""
+    out = subprocess.run([exe, "NONE", "1"], capture_output=True, text=True, timeout=60)
+    got = json.loads(out.stdout.strip().splitlines()[-1])
+    levels, run_kw, skipped = config.levels_from_config(config.parse_config(None), 1)
+    assert [tuple(s) for s in got["skipped"]] == skipped == [(0, "RIGID")]
+    assert [(g["data_order"], g["cp_order"], g["sg_order"], g["iters"]) for g in got["levels"]] == [(w["data_order"], w["cp_order"], w["sg_order"], w["iters"]) for w in levels]
+
+
 @pytest.mark.parametrize("text", ["--opt=DISCRETE,DISCRETE\n--lambda=0.1\n--dopt=HOCR\n--regoption=3\n", "--opt=DISCRETE\n--lambda=0.1\n--triclique\n--patchwise\n--dopt=HOCR\n--regoption=3\n",
                                   "--opt=DISCRETE\n--lambda=0.1\n--percentile=1.0\n", "--opt=DISCRETE\n--lambda=0.1\n--nosuchoption=1\n", "--opt=DISCRETE\n--lambda\n",
                                   "--opt=DISCRETE\n--lambda=0.1\n--VN=1\n", "--opt=DISCRETE\n--lambda=0.1\n--dopt=HOCR\n--regoption=5\n",

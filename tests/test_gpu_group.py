@@ -102,6 +102,25 @@ def test_group_pairwise_costs(ctx, monkeypatch, mask, sim, lanes):
     assert np.isfinite(want).sum() > 300
 
 
+@pytest.mark.parametrize("lanes", [16, 32])
+@pytest.mark.parametrize("sim", [2, 1])
+def test_group_pairwise_costs_of_patches_beyond_the_membership_bits(ctx, monkeypatch, lanes, sim):
+    """An ico5 template under an ico0 control grid: patches of several thousand template vertices -- beyond the 64 rounds x 16 | 32 lanes of
+    membership bits k_group_pairwise keeps per query (1025..2048 entries under 16 lanes used to alias bits silently, more than 2048
+    was MSM_ERR_CAPACITY).  The reference has no limit (M/DiscreteGroupCostFunction.cpp:54-98 walks a std::map)."""
+    monkeypatch.setenv("MSMHIP_GROUP_PAIR_LANES", str(lanes))
+    g, og, _ = build(ctx, S=2, data_order=5, cp_order=0, sim=sim)
+    sizes = [len(g.patch(s, v, l)[0]) for s in range(2) for v in range(12) for l in (0, 3)]
+    assert max(sizes) > 2048 and min(sizes) > 1024, (min(sizes), max(sizes))
+    rng = np.random.default_rng(11)
+    p = rng.integers(0, g.P, 60).astype(np.int32)
+    la, lb = rng.integers(0, g.L, 60).astype(np.int32), rng.integers(0, g.L, 60).astype(np.int32)
+    got = g.computePairwiseCost(p, la, lb)
+    want = np.array([og.pairwise(*q) for q in zip(p, la, lb)])
+    assert np.isfinite(want).all()
+    assert np.allclose(got, want, rtol=RTOL, atol=ATOL), np.abs(got - want).max()
+
+
 @pytest.mark.parametrize("sim,percentile", [(4, 0.75), (5, 0.75), (4, 0.3)])
 def test_group_pairwise_dice(ctx, sim, percentile):
     """DICE / genDICE over the common entries of the two patches (get_sim_for_min, similarities.h:53-56): the costs are
