@@ -254,6 +254,68 @@ def bench_registration_msmall(ctx, check=True):
     return out
 
 
+BASIC_FUSION_CONFIG = """# three DISCRETE levels shaped like config/basic_configs/config_standard_MSM_strain (its AFFINE level left out), driven as --dopt=HOCR drives BASELINE config 2
+--opt=DISCRETE,DISCRETE,DISCRETE
+--simval=2,2,2
+--sigma_in=4,2,1
+--sigma_ref=4,2,1
+--lambda=0.1,0.1,0.1
+--it=3,3,3
+--CPgrid=2,3,4
+--SGgrid=4,5,6
+--datagrid=4,5,6
+--dopt=HOCR
+--regoption=3
+--VN
+"""
+
+
+def bench_registration_cpp(ctx, config_text, D, what, check=True):
+    """The same registration with the host side in C++ (north_star: "host code stays C++ and calls HIP through a thin C-ABI"): tools/cpp/registration_bench
+    -- include/msmhip_registration.hpp: run_multiresolutions + include/msmhip_config.hpp over include/msmhip.hpp over the C ABI -- run as a child process
+    on the bench's synthetic subject with the schedule read from `config_text`; compared with the Python-driven loop (newmsm_amd/registration.py) over
+    the same schedule: identical labelings, registered spheres within 1e-4 rad.  Matches M/mesh_registration.cpp:30-50,164-232, I/Fusion/Fusion.h:136-229."""
+    import subprocess
+    import tempfile
+
+    import numpy as np
+
+    import __graft_entry__ as g
+    import newmsm_amd as M
+    from newmsm_amd import config, registration, synthetic
+    from newmsm_amd.bag import read_bag, write_bag
+
+    exe = g.build_cpp_host()
+    xyz, tri = M.make_mesh_from_icosa(6)
+    ref = synthetic.features(xyz, D, 7)
+    src = synthetic.features(synthetic.known_warp(xyz, seed=9, rot_deg=3.0, amp=2.0), D, 7)
+    with tempfile.TemporaryDirectory() as tmp:
+        bag, outbag, conf = os.path.join(tmp, "in.bag"), os.path.join(tmp, "out.bag"), os.path.join(tmp, "conf")
+        write_bag(bag, orders=np.array([6, D], dtype=np.int32), in_data=src, ref_data=ref)
+        with open(conf, "w") as f:
+            f.write(config_text)
+        p = subprocess.run([exe, bag, outbag, conf, "2"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+        if p.returncode != 0:
+            return {"error": p.stderr[-1000:]}
+        out = json.loads(p.stdout.strip().splitlines()[-1])
+        res = read_bag(outbag)
+    out["phases_s"] = {k: round(v, 4) for k, v in sorted(out["phases_s"].items())}
+    out["workload"] = what
+    out["host"] = "C++: tools/cpp/registration_bench (include/msmhip_registration.hpp + msmhip_config.hpp over the C ABI), a child process of bench.py; second of two runs"
+    out["move_call_minus_kernel_us"] = out["move_us_per_call"] - out["move_kernel_us"] if out["moves_timed"] else None
+    if check:  # the Python-driven loop over the same schedule and subject
+        levels, run_kw, _ = config.levels_from_config(config.parse_config(config_text), D)
+        labs = []
+        ops = registration.ProductOps(ctx)
+        sphere, _, _ = registration.run_multiresolution(ops, xyz, tri, src, xyz, tri, ref, levels, labelings_out=labs, **run_kw)
+        got = res["sphere_reg"].reshape(-1, 3)
+        cosang = np.clip(np.sum(got * sphere, axis=1) / (np.linalg.norm(got, axis=1) * np.linalg.norm(sphere, axis=1)), -1.0, 1.0)
+        flat = np.concatenate(labs) if labs else np.zeros(0, dtype=np.int32)
+        out["check"] = {"labelings_identical_to_the_python_run": bool(len(flat) == len(res["labelings"]) and np.array_equal(flat, res["labelings"])),
+                        "labelings_compared": len(labs), "max_angle_rad_vs_python_run": float(np.max(np.arccos(cosang))), "tolerance_rad": 1e-4}
+    return out
+
+
 GMSM_LEVELS = [(4, 2), (5, 3), (6, 4)]  # --datagrid / --CPgrid of the gMSM configuration of docs/guide.md:390-407
 GMSM_ITERATIONS = 9                      # --it=9,9,9
 
@@ -654,6 +716,12 @@ def main():
                 out["registration"] = bench_registration(ctx, check=chk)
                 out["registration_fusion"] = bench_registration(ctx, "fusion", check=chk)
                 out["registration_msmall"] = bench_registration_msmall(ctx, check=chk)
+                from newmsm_amd import config as _config
+
+                out["registration_fusion_cpp"] = bench_registration_cpp(ctx, BASIC_FUSION_CONFIG, 1, "run_multiresolutions, 3 DISCRETE levels (data ico4/5/6, control ico2/3/4, "
+                                                                        "sigma 4/2/1, --VN), 3 iterations each, sulc-like D=1, ico6 spheres, --dopt=HOCR --regoption=3 (stand-in solve)")
+                out["registration_msmall_cpp"] = bench_registration_cpp(ctx, _config.PRESETS["HCP_MSMAll"], 32, "run_multiresolutions, the HCP MSMAll schedule "
+                                                                        "(config text through the reference's grammar), ho_multivariate D=32, ico6 spheres: 40 set-ups + 1 520 fusion moves (stand-in solve)")
                 out["gmsm"] = bench_gmsm(ctx, args.subjects, comm, change=args.label_change)
                 out["gmsm"]["template_allreduce"] = template_allreduce()
         if world == 1 and not args.no_cpu_baseline:

@@ -42,11 +42,7 @@ struct ConfigError : std::runtime_error {
     using std::runtime_error::runtime_error;
 };
 
-struct LevelSpec {
-    int data_order = 5, cp_order = 2;
-    double sigma_in = 0.0, sigma_ref = 0.0;
-    LevelOptions options;
-};
+// (LevelSpec -- data grid, control grid, smoothing and the LevelOptions of one level -- lives in msmhip_registration.hpp, next to the loop that runs it)
 
 namespace detail {
 inline std::string trim(const std::string &s) {

@@ -10,9 +10,35 @@
 #ifndef MSMHIP_REGISTRATION_HPP
 #define MSMHIP_REGISTRATION_HPP
 
+#include <chrono>
+#include <map>
+#include <string>
+
 #include "msmhip.hpp"
 
 namespace msmhip {
+
+// wall-clock seconds and call counts per phase of the loops below, under the names newmsm_amd/registration.py uses ("get_source_data",
+// "unary_table", "fusion_moves", "optimiser", "total_cost", "sphere_project_warp", "unfold", "metric_resample", "smooth_data", ...)
+struct PhaseClock {
+    std::map<std::string, double> seconds;
+    std::map<std::string, long> calls;
+    template <class Fn>
+    static auto timed(PhaseClock *c, const char *name, Fn &&fn) {
+        if (!c) return fn();
+        const auto t0 = std::chrono::steady_clock::now();
+        struct Stop {
+            PhaseClock *c;
+            const char *name;
+            std::chrono::steady_clock::time_point t0;
+            ~Stop() {
+                c->seconds[name] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                ++c->calls[name];
+            }
+        } stop{c, name, t0};
+        return fn();
+    }
+};
 
 struct LevelOptions {
     int sg_order = -1;  // sampling grid resolution; cp_order + 2 when negative
@@ -31,6 +57,9 @@ struct LevelOptions {
     // true: --regoption=1 as --dopt=FastPD drives it (M/mesh_registration.cpp:182-188): the model lists pairs instead of triplets, per iteration
     // computeUnaryCosts + computePairwiseCosts, then a stand-in for FPD::FastPD(model, 100) (msm_pairwise_icm)
     bool pairwise = false;
+    // measurement only: when set, the cost function records HIP events around its kernels (msm_cost_enable_timing) and the duration of every fusion
+    // move's kernel (ms) is appended here -- one event query per move, so a run with this set is not the one whose wall clock is reported
+    std::vector<double> *move_kernel_ms = nullptr;
 };
 
 struct LevelResult {
@@ -54,7 +83,7 @@ inline Points apply_labeling(const std::vector<double> &ROT, const Points &label
 // sph_reg: the current registered position of the source sphere; cp_start: the control grid after warp_CPgrid, or null
 inline LevelResult run_discrete_opt(Context &ctx, const Points &target_xyz, const Triangles &target_tri, const Matrix &ref_feat,
                                     const Points &source_xyz, const Triangles &source_tri, const Matrix &src_feat, int D, Points sph_reg,
-                                    int cp_order, const LevelOptions &o, const Points *cp_start = nullptr) {
+                                    int cp_order, const LevelOptions &o, const Points *cp_start = nullptr, PhaseClock *clock = nullptr) {
     // ---- initialize_level / Initialize(CONTROL)
     auto [cp_xyz, cp_tri] = make_mesh_from_icosa(cp_order);
     Mesh TARGET(ctx, target_xyz, target_tri), SOURCE(ctx, source_xyz, source_tri), CPGRID(ctx, cp_xyz, cp_tri);
@@ -70,6 +99,7 @@ inline LevelResult run_discrete_opt(Context &ctx, const Points &target_xyz, cons
     costfct.set_featurespace(src_feat, D);
     costfct.set_spacings(MAXSEP, MVDmax);
     const int N = (int)(cp_xyz.size() / 3);
+    if (o.move_kernel_ms) check(msm_cost_enable_timing(costfct.handle(), 1));
     int m_iter = 1;
     double m_scale = 1.0;
     if (cp_start) cp_xyz = *cp_start;
@@ -86,11 +116,11 @@ inline LevelResult run_discrete_opt(Context &ctx, const Points &target_xyz, cons
         if (o.rescale_labels) labels = rescale_sampling_grid(samples, m_scale);
         else labels = (m_iter % 2 == 0) ? samples : barycentres;
         costfct.set_labels(labels, ROT);
-        costfct.get_source_data();
+        PhaseClock::timed(clock, "get_source_data", [&] { costfct.get_source_data(); });
         if (o.pairwise) costfct.setPairs(pairs);
         else costfct.setTriplets(triplets);
         ++m_iter;
-        costfct.computeUnaryCosts();
+        PhaseClock::timed(clock, "unary_table", [&] { costfct.computeUnaryCosts(); });
         std::vector<int32_t> labeling((size_t)N, 0);  // resetLabeling
         const int L = (int)(labels.size() / 3), T = (int)(triplets.size() / 3);
         if (o.fusion) {  // ---- Fusion::optimize: two sweeps over the labels, a fusion move per label step
@@ -102,35 +132,119 @@ inline LevelResult run_discrete_opt(Context &ctx, const Points &target_xyz, cons
                     bool any = false;
                     for (int i = 0; i < N; ++i) any = any || labeling[(size_t)i] != label;
                     if (!any) continue;
-                    check(msm_cost_triplet_octets(costfct.handle(), labeling.data(), label, E));
+                    PhaseClock::timed(clock, "fusion_moves", [&] { check(msm_cost_triplet_octets(costfct.handle(), labeling.data(), label, E)); });
+                    if (o.move_kernel_ms) {
+                        double ms = 0.0;
+                        int32_t got = 0;
+                        check(msm_cost_kernel_times(costfct.handle(), &ms, 1, &got));
+                        if (got == 1) o.move_kernel_ms->push_back(ms);
+                    }
                     for (int i = 0; i < N; ++i) {
                         unary2[2 * (size_t)i] = costfct.unarycosts[(size_t)labeling[(size_t)i] * N + i];
                         unary2[2 * (size_t)i + 1] = costfct.unarycosts[(size_t)label * N + i];
                     }
-                    const std::vector<int32_t> x = fusion_icm_step(N, unary2, nullptr, no_pairs, E, triplets, o.icm_passes);
+                    const std::vector<int32_t> x =
+                        PhaseClock::timed(clock, "optimiser", [&] { return fusion_icm_step(N, unary2, nullptr, no_pairs, E, triplets, o.icm_passes); });
                     for (int i = 0; i < N; ++i)
                         if (x[(size_t)i] == 1 && labeling[(size_t)i] != label) labeling[(size_t)i] = label;
                 }
         } else if (o.pairwise) {  // ---- FastPD: computeUnaryCosts, computePairwiseCosts, the solve
-            costfct.computePairwiseCosts();
-            pairwise_icm(costfct.unarycosts, costfct.paircosts, pairs, N, L, labeling, 100);
+            PhaseClock::timed(clock, "pairwise_table", [&] { costfct.computePairwiseCosts(); });
+            PhaseClock::timed(clock, "optimiser", [&] { pairwise_icm(costfct.unarycosts, costfct.paircosts, pairs, N, L, labeling, 100); });
         } else {  // ---- MCMC: computeUnaryCosts, computeTripletCosts, optimise
-            const std::vector<double> tcosts = costfct.computeTripletCosts();
-            mcmc_optimise(costfct.unarycosts, tcosts, triplets, N, L, o.mcparam, o.mciters, o.seed + (uint64_t)it, labeling);
+            const std::vector<double> tcosts = PhaseClock::timed(clock, "triplet_table", [&] { return costfct.computeTripletCosts(); });
+            PhaseClock::timed(clock, "optimiser", [&] { mcmc_optimise(costfct.unarycosts, tcosts, triplets, N, L, o.mcparam, o.mciters, o.seed + (uint64_t)it, labeling); });
         }
-        res.energies.push_back(costfct.evaluateTotalCostSum(labeling));
+        res.energies.push_back(PhaseClock::timed(clock, "total_cost", [&] { return costfct.evaluateTotalCostSum(labeling); }));
         res.labelings.push_back(labeling);
         // ---- applyLabeling, warp the source through the control grid's move, unfold both (:219-230)
         const Points moved = apply_labeling(ROT, labels, labeling);
-        sphere_project_warp(SOURCE, CPGRID, moved);  // SOURCE holds sph_reg since the top of the iteration; CPGRID still holds the previous grid
+        // SOURCE holds sph_reg since the top of the iteration; CPGRID still holds the previous grid
+        PhaseClock::timed(clock, "sphere_project_warp", [&] { sphere_project_warp(SOURCE, CPGRID, moved); });
         CPGRID.set_coords(moved);
-        unfold(CPGRID);
+        PhaseClock::timed(clock, "unfold", [&] { return unfold(CPGRID); });
         cp_xyz = CPGRID.get_coords();
-        unfold(SOURCE);
+        PhaseClock::timed(clock, "unfold", [&] { return unfold(SOURCE); });
         sph_reg = SOURCE.get_coords();
     }
     res.sph_reg = sph_reg;
     res.cpgrid = cp_xyz;
+    return res;
+}
+
+// one resolution level of a schedule (msmhip_config.hpp: levels_from_config fills these from a configuration file)
+struct LevelSpec {
+    int data_order = 5, cp_order = 2;
+    double sigma_in = 0.0, sigma_ref = 0.0;
+    LevelOptions options;
+};
+
+struct MultiresResult {
+    Points sphere_reg;                            // the input sphere moved through the final warp ("sphere.reg", M/mesh_registration.cpp:352-356)
+    std::vector<Points> level_reg;                // the registered data grid of every level
+    std::vector<std::vector<double>> energies;    // per level, per iteration
+    std::vector<std::vector<int32_t>> labelings;  // every iteration's labeling, level after level
+};
+
+// Mesh_registration::run_multiresolutions (M/mesh_registration.cpp:30-50) for DISCRETE levels without file I/O -- the C++ twin of
+// newmsm_amd/registration.py: run_multiresolution (same calls in the same order; tests/test_cpp_host.py compares the two):
+//   per level  featurespace::initialise (M/featurespace.cpp:39-86: metric_resample of both data sets onto the level's icosphere, smooth_data,
+//              variance_normalise), project_CPgrid (M/mesh_registration.cpp:131-162: the warp of the previous level carried to the new data
+//              grid and control grid, unfold) and run_discrete_opt;
+//   at the end transform (:352-356).
+// in_* / ref_*: the input and reference spheres (radius 100) with their D x V data.
+inline MultiresResult run_multiresolutions(Context &ctx, const Points &in_xyz, const Triangles &in_tri, const Matrix &in_data, const Points &ref_xyz,
+                                           const Triangles &ref_tri, const Matrix &ref_data, int D, const std::vector<LevelSpec> &levels, bool varnorm,
+                                           PhaseClock *clock = nullptr) {
+    if (levels.empty()) throw Error(MSM_ERR_INVALID, "run_multiresolutions: no DISCRETE level");
+    Mesh in_mesh(ctx, in_xyz, in_tri), ref_mesh(ctx, ref_xyz, ref_tri);
+    MultiresResult res;
+    Points sph_reg_prev;
+    int prev_order = -1;
+    for (const LevelSpec &lv : levels) {
+        auto [ico_xyz, ico_tri] = make_mesh_from_icosa(lv.data_order);
+        Mesh ico(ctx, ico_xyz, ico_tri);
+        Matrix feats[2];
+        for (int k = 0; k < 2; ++k) {
+            Mesh &mesh = k == 0 ? in_mesh : ref_mesh;
+            const Matrix &data = k == 0 ? in_data : ref_data;
+            const double sigma = k == 0 ? lv.sigma_in : lv.sigma_ref;
+            Matrix f = PhaseClock::timed(clock, "metric_resample", [&] { return metric_resample(mesh, data, ico); });
+            if (sigma > 0.0) f = PhaseClock::timed(clock, "smooth_data", [&] { return smooth_data(ico, f, ico, sigma); });
+            if (varnorm) variance_normalise(f, ico.nvertices());
+            feats[k] = std::move(f);
+        }
+        Points sph_in, cp_start;
+        bool have_cp_start = false;
+        if (sph_reg_prev.empty()) {
+            sph_in = ico_xyz;  // level 1, no transformed mesh: project_CPgrid only unfolds the (regular) data grid
+        } else {
+            auto [prev_xyz, prev_tri] = make_mesh_from_icosa(prev_order);
+            Mesh prev(ctx, prev_xyz, prev_tri);
+            const Points incurrent = PhaseClock::timed(clock, "sphere_project_warp", [&] { return sphere_project_warp(in_xyz, prev, sph_reg_prev); });
+            sph_in = PhaseClock::timed(clock, "sphere_project_warp", [&] { return sphere_project_warp(ico_xyz, in_mesh, incurrent); });
+            auto [cp_xyz, cp_tri] = make_mesh_from_icosa(lv.cp_order);
+            Mesh cpm(ctx, PhaseClock::timed(clock, "sphere_project_warp", [&] { return sphere_project_warp(cp_xyz, in_mesh, incurrent); }), cp_tri);  // warp_CPgrid
+            PhaseClock::timed(clock, "unfold", [&] { return unfold(cpm); });
+            cp_start = cpm.get_coords();
+            have_cp_start = true;
+        }
+        {
+            Mesh moved(ctx, sph_in, ico_tri);
+            PhaseClock::timed(clock, "unfold", [&] { return unfold(moved); });
+            sph_in = moved.get_coords();
+        }
+        LevelResult r = run_discrete_opt(ctx, ico_xyz, ico_tri, feats[1], ico_xyz, ico_tri, feats[0], D, sph_in, lv.cp_order, lv.options,
+                                         have_cp_start ? &cp_start : nullptr, clock);
+        res.labelings.insert(res.labelings.end(), r.labelings.begin(), r.labelings.end());
+        res.energies.push_back(r.energies);
+        res.level_reg.push_back(r.sph_reg);
+        sph_reg_prev = std::move(r.sph_reg);
+        prev_order = lv.data_order;
+    }
+    auto [last_xyz, last_tri] = make_mesh_from_icosa(levels.back().data_order);
+    Mesh last(ctx, last_xyz, last_tri);
+    res.sphere_reg = PhaseClock::timed(clock, "sphere_project_warp", [&] { return sphere_project_warp(in_xyz, last, sph_reg_prev); });
     return res;
 }
 

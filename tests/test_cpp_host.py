@@ -30,27 +30,7 @@ LEVEL_SRC = os.path.join(ROOT, "tests", "cpp", "level_driver.cpp")
 LEVEL_EXE = os.path.join(ROOT, "tests", "cpp", "level_driver")
 
 
-def write_bag(path, **arrays):
-    with open(path, "wb") as f:
-        for name, a in arrays.items():
-            a = np.ascontiguousarray(a)
-            dt = "f8" if a.dtype.kind == "f" else "i4"
-            a = a.astype(np.float64 if dt == "f8" else np.int32)
-            f.write(("%s %s %d\n" % (name, dt, a.size)).encode())
-            f.write(a.tobytes())
-
-
-def read_bag(path):
-    out = {}
-    with open(path, "rb") as f:
-        while True:
-            line = f.readline()
-            if not line:
-                break
-            name, dt, n = line.decode().split()
-            n = int(n)
-            out[name] = np.frombuffer(f.read(n * (8 if dt == "f8" else 4)), dtype=np.float64 if dt == "f8" else np.int32)
-    return out
+from newmsm_amd.bag import read_bag, write_bag  # noqa: E402  (the container of the compiled programs' arrays)
 
 
 def test_header_compiles_without_gpu(built):
@@ -335,3 +315,46 @@ def test_group_fusion_loops_through_the_adapter(built, tmp_path):
     lab = got["fused_labeling"]
     want = sum(og.pairwise(p, int(lab[pr[p, 0]]), int(lab[pr[p, 1]])) for p in range(P)) + sum(og.triplet(t, *(int(lab[v]) for v in tr[t])) for t in range(T))
     assert (np.isnan(want) and np.isnan(energy)) or abs(energy - want) <= 1e-9 * abs(want) + 1e-11
+
+
+MULTIRES_CONFIGS = {
+    # two DISCRETE levels driven as --dopt=HOCR drives them; smoothing and --VN on (the featurespace calls of a level), the second level starts from the first one's warp
+    "fusion": "--opt=DISCRETE,DISCRETE\n--simval=2,2\n--sigma_in=2,1\n--sigma_ref=2,1\n--lambda=0.1,0.1\n--it=2,2\n--CPgrid=1,2\n--SGgrid=3,4\n--datagrid=3,4\n--dopt=HOCR\n--regoption=3\n--VN\n",
+    "triclique": "--opt=DISCRETE,DISCRETE\n--simval=2,2\n--sigma_in=0,0\n--sigma_ref=0,0\n--lambda=0.01,0.02\n--it=2,2\n--CPgrid=1,2\n--SGgrid=3,4\n--datagrid=3,4\n--dopt=HOCR\n--regoption=3\n"
+                 "--triclique\n--rescaleL\n--shearmod=0.4\n--bulkmod=1.6\n--k_exponent=2\n--regexp=2\n",
+}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,D", [("fusion", 1), ("triclique", 4)])
+def test_cpp_run_multiresolutions_equals_python_loop(built, ctx, tmp_path, name, D):
+    """tools/cpp/registration_bench -- msmhip::run_multiresolutions with its schedule from msmhip_config.hpp, what bench.py's registration_*_cpp
+    objects run -- against newmsm_amd/registration.py: run_multiresolution over config.py's reading of the same text: identical labelings in
+    every iteration of every level, the same registered sphere (M/mesh_registration.cpp:30-50,131-232)."""
+    import __graft_entry__ as g
+    import newmsm_amd as M
+    from newmsm_amd import config, registration, synthetic
+
+    exe = g.build_cpp_host()
+    xyz, tri = M.make_mesh_from_icosa(4)
+    ref = synthetic.features(xyz, D, 7)
+    src = synthetic.features(synthetic.known_warp(xyz, seed=9, rot_deg=3.0, amp=2.0), D, 7)
+    fin, fout, conf = str(tmp_path / "in.bag"), str(tmp_path / "out.bag"), str(tmp_path / "conf")
+    write_bag(fin, orders=np.array([4, D], dtype=np.int32), in_data=src, ref_data=ref)
+    with open(conf, "w") as f:
+        f.write(MULTIRES_CONFIGS[name])
+    run = subprocess.run([exe, fin, fout, conf, "1"], capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0, run.stderr + run.stdout
+    import json
+
+    line = json.loads(run.stdout.strip().splitlines()[-1])
+    got = read_bag(fout)
+    levels, run_kw, skipped = config.levels_from_config(config.parse_config(MULTIRES_CONFIGS[name]), D)
+    labs = []
+    sphere, regs, energies = registration.run_multiresolution(registration.ProductOps(ctx), xyz, tri, src, xyz, tri, ref, levels, labelings_out=labs, **run_kw)
+    assert line["levels"] == 2 and len(labs) == 4 and list(got["nodes"]) == [len(l) for l in labs]
+    assert np.array_equal(got["labelings"], np.concatenate(labs))
+    assert np.allclose(got["energies"], np.concatenate(energies), rtol=1e-12, atol=0)
+    assert np.allclose(got["sphere_reg"].reshape(-1, 3), sphere, rtol=0, atol=1e-10)
+    assert any(np.any(l != 0) for l in labs)   # the registration moved something
+    assert line["moves"] == line["calls"]["fusion_moves"] > 0 and line["moves_timed"] == line["moves"] and line["move_kernel_us"] > 0

@@ -117,8 +117,8 @@ def test_group_pairwise_costs_of_patches_beyond_the_membership_bits(ctx, monkeyp
     la, lb = rng.integers(0, g.L, 60).astype(np.int32), rng.integers(0, g.L, 60).astype(np.int32)
     got = g.computePairwiseCost(p, la, lb)
     want = np.array([og.pairwise(*q) for q in zip(p, la, lb)])
-    assert np.isfinite(want).all()
-    assert np.allclose(got, want, rtol=RTOL, atol=ATOL), np.abs(got - want).max()
+    assert np.isfinite(want).sum() > 40  # (two patches without a common template vertex: NaN on both sides)
+    assert np.allclose(got, want, rtol=RTOL, atol=ATOL, equal_nan=True), np.nanmax(np.abs(got - want))
 
 
 @pytest.mark.parametrize("sim,percentile", [(4, 0.75), (5, 0.75), (4, 0.3)])
