@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MSM_ABI_VERSION 8  /* 8 (round 4): msm_query_lanes added.  6 (round 3): msm_pairwise_icm, msm_ctx_time_queries / msm_ctx_query_kernel_ms, msm_group_time_moves / msm_group_move_kernels_ms,
+#define MSM_ABI_VERSION 8  /* 8 (round 4): msm_query_lanes, msm_group_export_subjects_dev / msm_group_import_subjects_dev / msm_group_setup_more_subjects added.  6 (round 3): msm_pairwise_icm, msm_ctx_time_queries / msm_ctx_query_kernel_ms, msm_group_time_moves / msm_group_move_kernels_ms,
                              * msm_store_release_i64 / msm_load_acquire_i64 / msm_min_acquire_i64, msm_mesh_sphere_project_warp added; nothing removed or changed */
 
 #define MSM_OK 0
@@ -374,6 +374,16 @@ int msm_group_import_subject(msm_group *g, int32_t subject, const double *F, con
  * no host copy in between.  F_dev / pptr_dev / pidx_dev as above; any of them may be NULL on export. */
 int msm_group_export_subject_dev(msm_group *g, int32_t subject, double *F_dev, int32_t *pptr_dev, int32_t *pidx_dev, int64_t cap, int64_t *npidx);
 int msm_group_import_subject_dev(msm_group *g, int32_t subject, const double *F_dev, const int32_t *pptr_dev, const int32_t *pidx_dev, int64_t npidx);
+/* n subjects at once out of / into strided device buffers -- the send and receive buffers of ONE all-gather: subject subjects[k]'s arrays start at
+ * F_dev + k * F_stride (doubles), pptr_dev + k * pptr_stride, pidx_dev + k * pidx_stride (int32 entries); npidx[k] = its index count (written on
+ * export, read on import).  One range-check launch and one synchronisation per call; the imported row offsets stay on the device (the host copy is
+ * fetched if msm_group_patch asks).  msm_group_setup_more_subjects: further subjects of this rank after msm_group_setup_subjects, so that a rank can
+ * set up and exchange its shard in chunks (the exchange of one chunk overlapping the set-up of the next, newmsm_amd/dist.py). */
+int msm_group_export_subjects_dev(msm_group *g, const int32_t *subjects, int32_t n, double *F_dev, int64_t F_stride, int32_t *pptr_dev, int64_t pptr_stride,
+                                  int32_t *pidx_dev, int64_t pidx_stride, int64_t *npidx);
+int msm_group_import_subjects_dev(msm_group *g, const int32_t *subjects, int32_t n, const double *F_dev, int64_t F_stride, const int32_t *pptr_dev,
+                                  int64_t pptr_stride, const int32_t *pidx_dev, int64_t pidx_stride, const int64_t *npidx);
+int msm_group_setup_more_subjects(msm_group *g, const int32_t *subjects, int32_t n);
 int msm_group_finalize(msm_group *g);
 int msm_group_sizes(msm_group *g, int32_t *nodes, int32_t *pairs, int32_t *triplets);
 /* S subjects, N control points each, L labels, D feature rows, V(template): the sizes of the exchange buffers above (any pointer may be NULL) */

@@ -163,10 +163,18 @@ inline std::vector<int32_t> sharded_group_setup(msm_group *g, const Comm &c) {
             if (r == c.rank()) continue;
             int a, b;
             shard(S, r, c.world(), a, b);
+            if (b <= a) continue;
+            // rank r's shard in one call: its slots are consecutive in the gathered buffers (one range check launch, one synchronisation)
+            std::vector<int32_t> theirs;
+            std::vector<int64_t> np;
             for (int s = a; s < b; ++s) {
-                const size_t k = (size_t)r * nmax + (s - a);
-                check_msm(msm_group_import_subject_dev(g, s, aF.p + k * per_F, app.p + k * per_pp, api.p + k * imax, (int64_t)all_counts[k]), "msm_group_import_subject_dev");
+                theirs.push_back(s);
+                np.push_back((int64_t)all_counts[(size_t)r * nmax + (s - a)]);
             }
+            const size_t k = (size_t)r * nmax;
+            check_msm(msm_group_import_subjects_dev(g, theirs.data(), (int32_t)theirs.size(), aF.p + k * per_F, (int64_t)per_F, app.p + k * per_pp, (int64_t)per_pp,
+                                                    api.p + k * imax, (int64_t)imax, np.data()),
+                      "msm_group_import_subjects_dev");
         }
     }
     check_msm(msm_group_finalize(g), "msm_group_finalize");

@@ -139,6 +139,9 @@ SIGNATURES = {
     "msm_group_import_subject": (C.c_int, [_VP, C.c_int32, c_dp, c_ip, c_ip, C.c_int64]),
     "msm_group_export_subject_dev": (C.c_int, [_VP, C.c_int32, _VP, _VP, _VP, C.c_int64, c_lp]),
     "msm_group_import_subject_dev": (C.c_int, [_VP, C.c_int32, _VP, _VP, _VP, C.c_int64]),
+    "msm_group_export_subjects_dev": (C.c_int, [_VP, c_ip, C.c_int32, _VP, C.c_int64, _VP, C.c_int64, _VP, C.c_int64, C.POINTER(C.c_int64)]),
+    "msm_group_import_subjects_dev": (C.c_int, [_VP, c_ip, C.c_int32, _VP, C.c_int64, _VP, C.c_int64, _VP, C.c_int64, C.POINTER(C.c_int64)]),
+    "msm_group_setup_more_subjects": (C.c_int, [_VP, c_ip, C.c_int32]),
     "msm_group_fusion_move_dev": (C.c_int, [_VP, c_ip, C.c_int32, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _VP, _VP]),
     "msm_group_finalize": (C.c_int, [_VP]),
     "msm_group_sizes": (C.c_int, [_VP, c_ip, c_ip, c_ip]),

@@ -714,6 +714,11 @@ class DiscreteGroupCostFunction:
         s, ps = _i(np.asarray(list(subjects), dtype=np.int32))
         check(lib().msm_group_setup_subjects(self.h, ps, len(s)))
 
+    def setup_more_subjects(self, subjects):
+        """further subjects of this rank after setup_subjects (msm_group_setup_more_subjects): the set-up in chunks"""
+        s, ps = _i(np.asarray(list(subjects), dtype=np.int32))
+        check(lib().msm_group_setup_more_subjects(self.h, ps, len(s)))
+
     def export_subject(self, subject):
         n = C.c_int64()
         check(lib().msm_group_export_subject(self.h, int(subject), None, None, None, 0, C.byref(n)))
@@ -744,6 +749,23 @@ class DiscreteGroupCostFunction:
 
     def import_subject_dev(self, subject, F_ptr, pptr_ptr, pidx_ptr, npidx):
         check(lib().msm_group_import_subject_dev(self.h, int(subject), C.c_void_p(F_ptr), C.c_void_p(pptr_ptr), C.c_void_p(pidx_ptr), int(npidx)))
+
+    def export_subjects_dev(self, subjects, F_ptr, F_stride, pptr_ptr, pptr_stride, pidx_ptr, pidx_stride):
+        """subjects[k] into F_ptr + k * F_stride doubles, pptr_ptr + k * pptr_stride, pidx_ptr + k * pidx_stride int32 (device addresses): the send
+        buffers of one all-gather, one synchronisation (msm_group_export_subjects_dev); returns the index counts"""
+        s, ps = _i(np.asarray(list(subjects), dtype=np.int32))
+        n = np.zeros(max(len(s), 1), dtype=np.int64)
+        check(lib().msm_group_export_subjects_dev(self.h, ps, len(s), C.c_void_p(F_ptr), int(F_stride), C.c_void_p(pptr_ptr), int(pptr_stride),
+                                                  C.c_void_p(pidx_ptr), int(pidx_stride), n.ctypes.data_as(C.POINTER(C.c_int64))))
+        return n[: len(s)]
+
+    def import_subjects_dev(self, subjects, F_ptr, F_stride, pptr_ptr, pptr_stride, pidx_ptr, pidx_stride, npidx):
+        """the counterpart: subjects[k] out of the receive buffers of one all-gather, range-checked on the device (msm_group_import_subjects_dev)"""
+        s, ps = _i(np.asarray(list(subjects), dtype=np.int32))
+        n = np.ascontiguousarray(np.asarray(npidx, dtype=np.int64))
+        assert len(n) == len(s)
+        check(lib().msm_group_import_subjects_dev(self.h, ps, len(s), C.c_void_p(F_ptr), int(F_stride), C.c_void_p(pptr_ptr), int(pptr_stride),
+                                                  C.c_void_p(pidx_ptr), int(pidx_stride), n.ctypes.data_as(C.POINTER(C.c_int64))))
 
     def fusionMove_dev(self, labeling, label, pair_range, triplet_range, quads_ptr, octets_ptr):
         """a slice of a label step, results left in device memory (quads_ptr / octets_ptr: device addresses)"""

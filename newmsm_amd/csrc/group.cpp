@@ -64,6 +64,13 @@ struct msm_group {
                                                          // and set-up, and large pages under the label steps' gathers)
     std::vector<std::unique_ptr<DevBuf<int32_t>>> pptr, pidx;  // per subject
     std::vector<std::vector<int32_t>> h_pptr, h_pidx;
+    // subjects imported in a batch from device memory keep their row offsets on the device only (fetched when msm_group_patch asks): what
+    // msm_group_finalize needs of them -- index count, largest patch, patches of at most kPairSmallPatch entries -- comes from the check kernel
+    struct ImportStat {
+        int64_t npidx = 0;
+        int largest = 0, small = 0;
+    };
+    std::vector<ImportStat> imp_stat;
     DevBuf<const double *> d_Fp;
     DevBuf<const int *> d_pptrp, d_pidxp;
     DevBuf<int> d_query[4];   // index columns of a batch of evaluations (kept between calls)
@@ -349,6 +356,7 @@ msm_group *msm_group_create(msm_ctx *ctx, const msm_group_params *params, int32_
     g->spacing.resize(S);
     g->h_pptr.resize(S);
     g->h_pidx.resize(S);
+    g->imp_stat.resize(S);
     for (int s = 0; s < S; ++s) {
         g->pptr.emplace_back(new DevBuf<int32_t>());
         g->pidx.emplace_back(new DevBuf<int32_t>());
@@ -885,6 +893,8 @@ static int group_setup_pipeline(msm_group *g, const int32_t *subjects, int n) {
     auto t0 = std::chrono::steady_clock::now();
     st = stage_prepare(g, subjects[0], g->stage[0]);
     if (st) return st;
+    if (timing) fprintf(stderr, "  group set-up, first subject's rotations + forest (nothing beside them): %.1f ms\n",
+                        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     for (int i = 0; i < n; ++i) {
         const int s = subjects[i];
         msm_group::Stage &cur = g->stage[i & 1];
@@ -895,16 +905,22 @@ static int group_setup_pipeline(msm_group *g, const int32_t *subjects, int n) {
         // the subject's patch lists (0.65 ms, of which the range kernel 0.5) follow its per-label work on that thread and stream when there is
         // one (stage_batch: 1.5 ms) -- the main stream's preparation of the next subject (1.95 ms) was the longer side with the lists on it
         const bool batch = cur.forest_ok && !no_batch;
+        double ms_lanes = 0.0, ms_main = 0.0;
         std::thread lanes([&] {
+            const auto l0 = std::chrono::steady_clock::now();
             (void)hipSetDevice(ctx->device);
             st_lanes = batch ? stage_batch(g, s, cur, which) : stage_lanes(g, s, cur);
             if (!st_lanes && batch) st_lanes = subject_patches(g, s, g->batch.ctx);
             if (st_lanes) msg_lanes = msm_last_error();
+            ms_lanes = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - l0).count();
         });
         int st_main = MSM_OK;
+        const auto m0 = std::chrono::steady_clock::now();
         if (i + 1 < n) st_main = stage_prepare(g, subjects[i + 1], g->stage[(i + 1) & 1]);
         if (!st_main && !batch) st_main = subject_patches(g, s);
+        ms_main = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - m0).count();
         lanes.join();
+        if (timing && i < 2) fprintf(stderr, "  group set-up, subject %d: per-label work + patches %.1f ms beside the next subject's rotations + forest %.1f ms\n", s, ms_lanes, ms_main);
         if (st_lanes) return fail(st_lanes, "%s", msg_lanes.c_str());
         if (st_main) return st_main;
         g->have_subject[s] = 1;
@@ -1073,6 +1089,32 @@ int msm_group_setup_subjects(msm_group *g, const int32_t *subjects, int32_t n) {
     return MSM_OK;
 }
 
+// further subjects of this rank after msm_group_setup_subjects (same control grids, labels and data): the set-up in chunks, so that the exchange of
+// one chunk (an all-gather on another stream) runs while the next is set up
+int msm_group_setup_more_subjects(msm_group *g, const int32_t *subjects, int32_t n) {
+    if (!g || (n > 0 && !subjects) || n < 0) return fail(MSM_ERR_INVALID, "msm_group_setup_more_subjects: bad arguments");
+    if (!g->common_ready) return fail(MSM_ERR_STATE, "msm_group: msm_group_setup_subjects() must be called first (an empty list is fine)");
+    g->ready = false;
+    for (int i = 0; i < n; ++i)
+        if (subjects[i] < 0 || subjects[i] >= g->S) return fail(MSM_ERR_INVALID, "subject %d out of range", subjects[i]);
+    if (group_device_path()) return group_setup_pipeline(g, subjects, n);
+    for (int i = 0; i < n; ++i) {
+        int st = group_subject_setup(g, subjects[i]);
+        if (st) return st;
+    }
+    return MSM_OK;
+}
+
+// the host copy of a subject's row offsets: there after a set-up on this rank or a single import, fetched when first asked for after a batched import
+static int fetch_host_pptr(msm_group *g, int s) {
+    if (!g->h_pptr[s].empty()) return MSM_OK;
+    if (!g->have_subject[s]) return fail(MSM_ERR_STATE, "msm_group: subject %d is neither set up nor imported", s);
+    g->h_pptr[s].resize((size_t)g->N * g->L + 1);
+    MSM_HIP(g->pptr[s]->download(g->h_pptr[s].data(), g->h_pptr[s].size(), g->ctx->stream));
+    MSM_HIP(hipStreamSynchronize(g->ctx->stream));
+    return MSM_OK;
+}
+
 // the host copy of a subject's index list is fetched when first asked for (set up or imported on the device)
 static int fetch_host_pidx(msm_group *g, int s) {
     if (!g->h_pidx[s].empty() || g->h_pptr[s].empty() || g->h_pptr[s].back() <= 0) return MSM_OK;
@@ -1086,6 +1128,10 @@ int msm_group_export_subject(msm_group *g, int32_t s, double *F, int32_t *pptr, 
     if (!g || s < 0 || s >= g->S) return fail(MSM_ERR_INVALID, "msm_group_export_subject: bad arguments");
     if (!g->common_ready || !g->have_subject[s]) return fail(MSM_ERR_STATE, "msm_group: subject %d has not been set up on this rank", s);
     const size_t per = (size_t)g->D * g->tmpl->V;
+    {
+        int st = fetch_host_pptr(g, s);
+        if (st) return st;
+    }
     if (npidx) *npidx = (int64_t)g->h_pptr[s].back();
     if (pidx) {
         int st = fetch_host_pidx(g, s);
@@ -1137,6 +1183,10 @@ int msm_group_export_subject_dev(msm_group *g, int32_t s, double *F_dev, int32_t
     if (!g->common_ready || !g->have_subject[s]) return fail(MSM_ERR_STATE, "msm_group: subject %d has not been set up on this rank", s);
     msm_ctx *ctx = g->ctx;
     const size_t per = (size_t)g->D * g->tmpl->V, M = (size_t)g->N * g->L;
+    {
+        int st = fetch_host_pptr(g, s);
+        if (st) return st;
+    }
     const int64_t n = (int64_t)g->h_pptr[s][M];
     if (npidx) *npidx = n;
     if (F_dev)
@@ -1193,6 +1243,105 @@ int msm_group_import_subject_dev(msm_group *g, int32_t s, const double *F_dev, c
     return MSM_OK;
 }
 
+namespace {
+// the range checks of msm_group_import_subject_dev for n subjects at once (blockIdx.y), and what msm_group_finalize wants to know of their patches
+__global__ void k_check_patch_csr_batch(const int32_t *__restrict__ pptr, int64_t pptr_stride, size_t M, const int32_t *__restrict__ pidx, int64_t pidx_stride,
+                                        const int64_t *__restrict__ npidx, int32_t Vt, int small_len, int *__restrict__ out /* n x 4: bad, largest, small, - */) {
+    const int k = blockIdx.y;
+    const int32_t *pp = pptr + (size_t)k * pptr_stride, *pi = pidx + (size_t)k * pidx_stride;
+    const int64_t np = npidx[k];
+    int bad = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < M || (int64_t)i < np; i += (size_t)gridDim.x * blockDim.x) {
+        if (i == 0 && (pp[0] != 0 || pp[M] != np)) bad |= 1;
+        if (i < M) {
+            const int len = pp[i + 1] - pp[i];
+            if (len < 0) bad |= 2;
+            if (len > out[4 * k + 1]) atomicMax(&out[4 * k + 1], len);
+            const unsigned long long sm = __ballot(len >= 0 && len <= small_len);
+            if ((threadIdx.x & 63) == (unsigned)(__ffsll((long long)__ballot(1)) - 1)) atomicAdd(&out[4 * k + 2], (int)__popcll(sm));
+        }
+        if ((int64_t)i < np && (pi[i] < 0 || pi[i] >= Vt)) bad |= 4;
+    }
+    if (bad) atomicOr(&out[4 * k], bad);
+}
+}  // namespace
+
+// n subjects at once into / out of strided device buffers -- the send and receive buffers of ONE all-gather: subject subjects[k]'s arrays start at
+// F_dev + k * F_stride (doubles), pptr_dev + k * pptr_stride and pidx_dev + k * pidx_stride (int32).  One synchronisation per call instead of two per
+// subject (56 imports of an 8-rank, 64-subject group: 9.2 -> under 1 ms, tools/time_group_rank.py).
+int msm_group_export_subjects_dev(msm_group *g, const int32_t *subjects, int32_t n, double *F_dev, int64_t F_stride, int32_t *pptr_dev, int64_t pptr_stride,
+                                  int32_t *pidx_dev, int64_t pidx_stride, int64_t *npidx) {
+    if (!g || (n > 0 && (!subjects || !F_dev || !pptr_dev || !pidx_dev)) || n < 0) return fail(MSM_ERR_INVALID, "msm_group_export_subjects_dev: bad arguments");
+    msm_ctx *ctx = g->ctx;
+    const size_t per = (size_t)g->D * g->tmpl->V, M = (size_t)g->N * g->L;
+    if ((int64_t)(per * g->L) > F_stride || (int64_t)(M + 1) > pptr_stride) return fail(MSM_ERR_CAPACITY, "msm_group_export_subjects_dev: strides too small");
+    for (int k = 0; k < n; ++k) {
+        const int s = subjects[k];
+        if (s < 0 || s >= g->S) return fail(MSM_ERR_INVALID, "subject %d out of range", s);
+        if (!g->common_ready || !g->have_subject[s]) return fail(MSM_ERR_STATE, "msm_group: subject %d has not been set up on this rank", s);
+        int st = fetch_host_pptr(g, s);
+        if (st) return st;
+        const int64_t cnt = (int64_t)g->h_pptr[s][M];
+        if (npidx) npidx[k] = cnt;
+        if (cnt > pidx_stride) return fail(MSM_ERR_CAPACITY, "patch index buffer too small");
+        MSM_HIP(hipMemcpyAsync(F_dev + (size_t)k * F_stride, g->Fslab[s]->p, sizeof(double) * per * g->L, hipMemcpyDeviceToDevice, ctx->stream));
+        MSM_HIP(hipMemcpyAsync(pptr_dev + (size_t)k * pptr_stride, g->pptr[s]->p, sizeof(int32_t) * (M + 1), hipMemcpyDeviceToDevice, ctx->stream));
+        if (cnt > 0) MSM_HIP(hipMemcpyAsync(pidx_dev + (size_t)k * pidx_stride, g->pidx[s]->p, sizeof(int32_t) * (size_t)cnt, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    MSM_HIP(hipStreamSynchronize(ctx->stream));  // the buffers may go straight into a collective on another stream
+    return MSM_OK;
+}
+
+int msm_group_import_subjects_dev(msm_group *g, const int32_t *subjects, int32_t n, const double *F_dev, int64_t F_stride, const int32_t *pptr_dev,
+                                  int64_t pptr_stride, const int32_t *pidx_dev, int64_t pidx_stride, const int64_t *npidx) {
+    if (!g || n < 0 || (n > 0 && (!subjects || !F_dev || !pptr_dev || !pidx_dev || !npidx))) return fail(MSM_ERR_INVALID, "msm_group_import_subjects_dev: bad arguments");
+    if (!g->common_ready) return fail(MSM_ERR_STATE, "msm_group: msm_group_setup_subjects() must be called first (an empty list is fine)");
+    if (n == 0) return MSM_OK;
+    msm_ctx *ctx = g->ctx;
+    const size_t per = (size_t)g->D * g->tmpl->V, M = (size_t)g->N * g->L;
+    if ((int64_t)(per * g->L) > F_stride || (int64_t)(M + 1) > pptr_stride) return fail(MSM_ERR_INVALID, "msm_group_import_subjects_dev: strides too small");
+    int64_t most = (int64_t)M + 1;
+    for (int k = 0; k < n; ++k) {
+        if (subjects[k] < 0 || subjects[k] >= g->S) return fail(MSM_ERR_INVALID, "subject %d out of range", subjects[k]);
+        if (npidx[k] < 0 || npidx[k] > pidx_stride) return fail(MSM_ERR_INVALID, "patch CSR of subject %d: %lld entries do not fit the buffer", subjects[k], (long long)npidx[k]);
+        most = std::max(most, npidx[k]);
+    }
+    // the arrays come from other ranks: checked (on the device, where they are) before any kernel indexes with them
+    DevBuf<int64_t> d_np;
+    DevBuf<int> d_out;
+    MSM_HIP(d_np.upload(npidx, (size_t)n, ctx->stream));
+    MSM_HIP(d_out.zero(4 * (size_t)n, ctx->stream));
+    const unsigned gx = (unsigned)std::min<int64_t>((most + 255) / 256, 4096);
+    hipLaunchKernelGGL(k_check_patch_csr_batch, dim3(gx, (unsigned)n), dim3(256), 0, ctx->stream, pptr_dev, pptr_stride, M, pidx_dev, pidx_stride, d_np.p, g->tmpl->V,
+                       kPairSmallPatch, d_out.p);
+    MSM_HIP(hipGetLastError());
+    std::vector<int> out(4 * (size_t)n);
+    MSM_HIP(d_out.download(out.data(), out.size(), ctx->stream));
+    MSM_HIP(hipStreamSynchronize(ctx->stream));
+    for (int k = 0; k < n; ++k)
+        if (out[4 * (size_t)k])
+            return fail(MSM_ERR_INVALID, "patch CSR of subject %d is inconsistent (code %d: 1 ends, 2 row lengths, 4 vertex ids)", subjects[k], out[4 * (size_t)k]);
+    for (int k = 0; k < n; ++k) {
+        const int s = subjects[k];
+        int st = subject_feature_slab(g, s, per);
+        if (st) return st;
+        MSM_HIP(hipMemcpyAsync(g->Fslab[s]->p, F_dev + (size_t)k * F_stride, sizeof(double) * per * g->L, hipMemcpyDeviceToDevice, ctx->stream));
+        MSM_HIP(g->pptr[s]->ensure(M + 1));
+        MSM_HIP(hipMemcpyAsync(g->pptr[s]->p, pptr_dev + (size_t)k * pptr_stride, sizeof(int32_t) * (M + 1), hipMemcpyDeviceToDevice, ctx->stream));
+        MSM_HIP(g->pidx[s]->ensure(std::max<size_t>((size_t)npidx[k], 1)));
+        if (npidx[k] > 0)
+            MSM_HIP(hipMemcpyAsync(g->pidx[s]->p, pidx_dev + (size_t)k * pidx_stride, sizeof(int32_t) * (size_t)npidx[k], hipMemcpyDeviceToDevice, ctx->stream));
+        g->h_pptr[s].clear();  // fetched on demand (msm_group_patch, a re-export)
+        g->h_pidx[s].clear();
+        g->imp_stat[s].npidx = npidx[k];
+        g->imp_stat[s].largest = out[4 * (size_t)k + 1];
+        g->imp_stat[s].small = out[4 * (size_t)k + 2];
+    }
+    MSM_HIP(hipStreamSynchronize(ctx->stream));  // the caller may reuse its buffers
+    for (int k = 0; k < n; ++k) g->have_subject[subjects[k]] = 1;
+    return MSM_OK;
+}
+
 int msm_group_finalize(msm_group *g) {
     if (!g) return fail(MSM_ERR_INVALID, "null group");
     if (!g->common_ready) return fail(MSM_ERR_STATE, "msm_group: nothing has been set up");
@@ -1214,13 +1363,20 @@ int msm_group_finalize(msm_group *g) {
     g->drop_kept();  // new patches: nothing kept from earlier label steps applies
     g->patch_max = 0;
     int64_t npatch = 0, nsmall = 0;
-    for (int s = 0; s < S; ++s)
+    for (int s = 0; s < S; ++s) {
+        if (g->h_pptr[s].empty()) {  // imported in a batch: the check kernel counted
+            g->patch_max = std::max(g->patch_max, g->imp_stat[s].largest);
+            npatch += (int64_t)g->N * L;
+            nsmall += g->imp_stat[s].small;
+            continue;
+        }
         for (size_t k = 0; k + 1 < g->h_pptr[s].size(); ++k) {
             const int n = g->h_pptr[s][k + 1] - g->h_pptr[s][k];
             g->patch_max = std::max(g->patch_max, n);
             ++npatch;
             nsmall += n <= kPairSmallPatch;
         }
+    }
     // a quarter wavefront per pair cost when (nearly) all patches fit its registers: four queries share a wavefront's instruction stream and latency
     // instead of two (label step 12.5 -> 9.5 ms at ico6 / ico4, patches of ~65 entries); the others take the general path, at half the lanes
     g->pair_lanes = (npatch > 0 && 10 * nsmall >= 9 * npatch) ? 16 : 32;
@@ -1281,6 +1437,10 @@ int msm_group_patch(msm_group *g, int32_t s, int32_t v, int32_t l, int32_t *ids,
     if (!g || !n) return fail(MSM_ERR_INVALID, "msm_group_patch: null argument");
     if (!g->ready) return fail(MSM_ERR_STATE, "msm_group: msm_group_setup() must be called first");
     if (s < 0 || s >= g->S || v < 0 || v >= g->N || l < 0 || l >= g->L) return fail(MSM_ERR_INVALID, "msm_group_patch: index out of range");
+    {
+        int st = fetch_host_pptr(g, s);
+        if (st) return st;
+    }
     const int beg = g->h_pptr[s][v * g->L + l], cnt = g->h_pptr[s][v * g->L + l + 1] - beg;
     *n = cnt;
     if (g->h_pidx[s].empty() && g->h_pptr[s].back() > 0) {  // a subject imported from device memory: its index list is fetched when first asked for

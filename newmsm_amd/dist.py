@@ -176,61 +176,110 @@ def group_template_update(local_spheres, local_features=None, comm=None, radius=
     return out
 
 
-def sharded_group_setup(group, n_subjects, comm=None):
+def _chunk_bounds(nmax, chunks):
+    """local index ranges [k0, k1) of the chunks a shard of up to nmax subjects is set up and exchanged in (the same on every rank)"""
+    chunks = max(1, min(int(chunks), nmax)) if nmax > 0 else 1
+    edges = [(i * nmax) // chunks for i in range(chunks + 1)]
+    return [(edges[i], edges[i + 1]) for i in range(chunks) if edges[i + 1] > edges[i]]
+
+
+def sharded_group_setup(group, n_subjects, comm=None, chunks=None):
     """Groupwise set-up with the subjects sharded over the ranks.
 
-    `group` is a newmsm_amd.DiscreteGroupCostFunction.  Every rank runs the expensive per-subject work for ITS subjects only,
-    then three all-gathers move every subject's resampled feature maps F (L x D x V doubles, 12.5 MB per subject at ico6 /
-    19 labels / D = 2), patch row pointers and patch index lists to every rank: shards are padded to the largest one, so
-    each collective is one call for the whole group.  With the nccl backend the buffers are torch tensors on the GPU that
-    libmsmhip fills and reads with device-to-device copies (msm_group_export_subject_dev / _import_subject_dev): nothing
-    goes through the host.  With gloo (CPU rehearsal) the same code runs on host tensors through the host entry points."""
+    `group` is a newmsm_amd.DiscreteGroupCostFunction.  Every rank runs the expensive per-subject work (get_patch_data,
+    M/DiscreteGroupModel.cpp:88-121) for ITS subjects only; all-gathers then move every subject's resampled feature maps F (L x D x V
+    doubles, 12.5 MB per subject at ico6 / 19 labels / D = 2), patch row pointers and patch index lists to every rank.
+
+    nccl backend: the buffers are torch tensors on the GPU that libmsmhip fills and reads with device-to-device copies, a chunk of subjects
+    per call (msm_group_export_subjects_dev / msm_group_import_subjects_dev: one synchronisation per call, range checks on the device), and
+    the shard is set up and exchanged in `chunks` pieces (default 2 from four subjects per rank on; MSMHIP_GROUP_CHUNKS): the all-gathers of
+    one piece are issued asynchronously (RCCL's own stream) and run over xGMI while the next piece is set up; everything is waited for once,
+    before the imports.  gloo (CPU rehearsal): one piece, host tensors through the host entry points."""
     c = _comm(comm)
     mine = list(shard(n_subjects, c.rank, c.world))
-    group.setup_subjects(mine)
-    if c.dist is not None:  # also with ONE rank in a process group: the same collectives run (the one-GPU test of the nccl path)
-        import torch
+    if c.dist is None:
+        group.setup_subjects(mine)
+        group.finalize()
+        return mine
+    import torch
 
-        L, D, V, M = group.L, group.D, group._keep["template"].V, group.N * group.L + 1
-        nmax = max(len(shard(n_subjects, r, c.world)) for r in range(c.world))
-        counts = torch.zeros(nmax, dtype=torch.int64, device=c.device)
-        local_counts = [group.subject_index_count(s) for s in mine]
+    L, D, V, M = group.L, group.D, group._keep["template"].V, group.N * group.L + 1
+    nmax = max(len(shard(n_subjects, r, c.world)) for r in range(c.world))
+    if not c.on_gpu:  # also with ONE rank in a process group: the same collectives run
+        group.setup_subjects(mine)
+        counts = torch.zeros(nmax, dtype=torch.int64)
         if mine:
-            counts[: len(mine)] = torch.tensor(local_counts, dtype=torch.int64, device=c.device)
-        all_counts = torch.zeros((c.world, nmax), dtype=torch.int64, device=c.device)
+            counts[: len(mine)] = torch.tensor([group.subject_index_count(s) for s in mine], dtype=torch.int64)
+        all_counts = torch.zeros((c.world, nmax), dtype=torch.int64)
         c.all_gather(all_counts, counts)
-        all_counts = all_counts.cpu().numpy()
+        all_counts = all_counts.numpy()
         imax = int(all_counts.max())
-        F = torch.zeros((nmax, L, D, V), dtype=torch.float64, device=c.device)
-        pp = torch.zeros((nmax, M), dtype=torch.int32, device=c.device)
-        pi = torch.zeros((nmax, max(imax, 1)), dtype=torch.int32, device=c.device)
+        F = torch.zeros((nmax, L, D, V), dtype=torch.float64)
+        pp = torch.zeros((nmax, M), dtype=torch.int32)
+        pi = torch.zeros((nmax, max(imax, 1)), dtype=torch.int32)
         for k, s in enumerate(mine):
-            if c.on_gpu:
-                group.export_subject_dev(s, F[k].data_ptr(), pp[k].data_ptr(), pi[k].data_ptr(), imax)
-            else:
-                f, p, i = group.export_subject(s)
-                F[k] = torch.from_numpy(f)
-                pp[k] = torch.from_numpy(p)
-                pi[k, : len(i)] = torch.from_numpy(i)
-        if c.on_gpu:
-            torch.cuda.synchronize()
-        aF = torch.empty((c.world,) + tuple(F.shape), dtype=F.dtype, device=c.device)
-        app = torch.empty((c.world,) + tuple(pp.shape), dtype=pp.dtype, device=c.device)
-        api = torch.empty((c.world,) + tuple(pi.shape), dtype=pi.dtype, device=c.device)
+            f, p, i = group.export_subject(s)
+            F[k] = torch.from_numpy(f)
+            pp[k] = torch.from_numpy(p)
+            pi[k, : len(i)] = torch.from_numpy(i)
+        aF = torch.empty((c.world,) + tuple(F.shape), dtype=F.dtype)
+        app = torch.empty((c.world,) + tuple(pp.shape), dtype=pp.dtype)
+        api = torch.empty((c.world,) + tuple(pi.shape), dtype=pi.dtype)
         c.all_gather(aF, F)
         c.all_gather(app, pp)
         c.all_gather(api, pi)
-        if c.on_gpu:
-            torch.cuda.synchronize()
         for r in range(c.world):
             if r == c.rank:
                 continue
             for k, s in enumerate(shard(n_subjects, r, c.world)):
                 n = int(all_counts[r, k])
-                if c.on_gpu:
-                    group.import_subject_dev(s, aF[r, k].data_ptr(), app[r, k].data_ptr(), api[r, k].data_ptr(), n)
-                else:
-                    group.import_subject(s, aF[r, k].numpy(), app[r, k].numpy(), api[r, k, :n].numpy())
+                group.import_subject(s, aF[r, k].numpy(), app[r, k].numpy(), api[r, k, :n].numpy())
+        group.finalize()
+        return mine
+
+    if chunks is None:
+        chunks = int(os.environ.get("MSMHIP_GROUP_CHUNKS", "2" if nmax >= 4 else "1"))
+    pending = []  # per piece: (k0, k1, all_counts, aF, app, api, [work handles], send buffers kept alive)
+    first = True
+    for k0, k1 in _chunk_bounds(nmax, chunks):
+        part = mine[k0:k1]
+        if first:
+            group.setup_subjects(part)  # includes the part every rank repeats (estimate_pairs, spacings, rotations)
+            first = False
+        elif part:
+            group.setup_more_subjects(part)
+        n = k1 - k0
+        counts = torch.zeros(n, dtype=torch.int64)
+        if part:
+            counts[: len(part)] = torch.tensor([group.subject_index_count(s) for s in part], dtype=torch.int64)
+        counts = counts.to(c.device)
+        all_counts = torch.zeros((c.world, n), dtype=torch.int64, device=c.device)
+        c.all_gather(all_counts, counts)  # small and blocking: sizes the index buffers of this piece
+        all_counts = all_counts.cpu().numpy()
+        imax = max(int(all_counts.max()), 1)
+        F = torch.empty((n, L, D, V), dtype=torch.float64, device=c.device)
+        pp = torch.zeros((n, M), dtype=torch.int32, device=c.device)
+        pi = torch.zeros((n, imax), dtype=torch.int32, device=c.device)
+        if part:
+            group.export_subjects_dev(part, F.data_ptr(), L * D * V, pp.data_ptr(), M, pi.data_ptr(), imax)  # synchronises libmsmhip's stream
+        torch.cuda.current_stream().synchronize()  # the zero fills above: complete before RCCL's stream reads the buffers
+        aF = torch.empty((c.world,) + tuple(F.shape), dtype=F.dtype, device=c.device)
+        app = torch.empty((c.world,) + tuple(pp.shape), dtype=pp.dtype, device=c.device)
+        api = torch.empty((c.world,) + tuple(pi.shape), dtype=pi.dtype, device=c.device)
+        works = [c.dist.all_gather_into_tensor(o, i, async_op=True) for o, i in ((aF, F), (app, pp), (api, pi))]
+        pending.append((k0, k1, all_counts, aF, app, api, works, (F, pp, pi)))
+    for _, _, _, _, _, _, works, _ in pending:
+        for w in works:
+            w.wait()
+    torch.cuda.synchronize()  # libmsmhip's stream is not one torch orders against: the gathered buffers are complete for any stream from here on
+    for k0, k1, all_counts, aF, app, api, _, _ in pending:
+        imax = api.shape[2]
+        for r in range(c.world):
+            if r == c.rank:
+                continue
+            theirs = list(shard(n_subjects, r, c.world))[k0:k1]
+            if theirs:
+                group.import_subjects_dev(theirs, aF[r].data_ptr(), L * D * V, app[r].data_ptr(), M, api[r].data_ptr(), imax, all_counts[r, : len(theirs)])
     group.finalize()
     return mine
 

@@ -180,6 +180,52 @@ def save_ascii(path, xyz, tri, values=None):
     _write_ascii(path, xyz, tri, values)
 
 
+def _g(x):
+    """a float as std::ostream writes it by default (6 significant digits, %g)"""
+    return "%g" % float(np.float32(x))
+
+
+def save_dpv(path, xyz, values):
+    """Mesh::save_dpv, R/mesh.cpp:707-741: `index x y z value` per vertex (indices below 100 zero-padded to three digits), first data row only"""
+    xyz = np.asarray(xyz, dtype=np.float64).reshape(-1, 3)
+    val = np.atleast_2d(np.asarray(values, dtype=np.float64))[0]
+    if len(val) != len(xyz):
+        raise MeshIOError("Mesh::save_dpv, data and mesh dimensions do not agree")
+    with open(path, "w") as f:
+        for i, (p, v) in enumerate(zip(xyz, val)):
+            f.write("%s %s %s %s %s\n" % ("%03d" % i if i < 100 else str(i), _g(p[0]), _g(p[1]), _g(p[2]), _g(v)))
+
+
+def load_dpv(path):
+    """(xyz, values 1 x V) of a .dpv file (Mesh::load_ascii_file, R/mesh.cpp:517-549: five columns)"""
+    a = np.loadtxt(path, dtype=np.float64, ndmin=2)
+    if a.shape[1] != 5:
+        raise MeshIOError("Mesh::load_dpv:error opening file (wrong format) : %s" % path)
+    return a[:, 1:4].copy(), a[:, 4][None, :].copy()
+
+
+def save_matrix(path, data):
+    """Mesh::save_matrix, R/mesh.cpp:743-766: one line per data row, values separated (and followed) by a blank"""
+    with open(path, "w") as f:
+        for row in np.atleast_2d(np.asarray(data, dtype=np.float64)):
+            f.write("".join(_g(v) + " " for v in row) + "\n")
+
+
+def load_matrix(path):
+    return np.atleast_2d(np.loadtxt(path, dtype=np.float64, ndmin=2))
+
+
+def load_data(path, nvertices=None):
+    """the data of a --indata / --refdata file by its extension, D x V (set_data, M/reg_tools.cpp:846-867 / Mesh::load, R/mesh.cpp:296-348)"""
+    p = str(path)
+    if p.endswith(".dpv"):
+        return load_dpv(p)[1]
+    if p.endswith(".txt"):
+        m = load_matrix(p)
+        return m if nvertices is None or m.shape[1] == nvertices else m.T
+    return load_metric(p, nvertices)
+
+
 if __name__ == "__main__":  # python -m newmsm_amd.meshio file.gii: list the arrays
     for intent, a in read_gifti(sys.argv[1]):
         print(intent, a.dtype, a.shape)

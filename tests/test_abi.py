@@ -42,9 +42,12 @@ def test_product_never_touches_the_oracle():
             if f.endswith((".py", ".cpp", ".hpp", ".hip", ".h")) or f == "Makefile":
                 src = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "msm_oracle" not in src and "orc_" not in src and "from oracle" not in src and "import oracle" not in src, f
-    for f in os.listdir(os.path.join(ROOT, "tools")):  # measurement scripts of the product: no oracle either
-        src = open(os.path.join(ROOT, "tools", f), errors="replace").read()
-        assert "from oracle" not in src and "import oracle" not in src and "tests.helpers" not in src and "libmsm_oracle" not in src, f
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "tools")):  # measurement scripts and compiled host programs of the product: no oracle either
+        for f in files:
+            if not f.endswith((".py", ".sh", ".cpp", ".hpp")):
+                continue
+            src = open(os.path.join(dirpath, f), errors="replace").read()
+            assert "from oracle" not in src and "import oracle" not in src and "tests.helpers" not in src and "libmsm_oracle" not in src and "orc_" not in src, f
 
 
 def test_argument_validation(built):

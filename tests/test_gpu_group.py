@@ -356,12 +356,31 @@ for (g, _), mine in zip(ranks, shards):
         g.export_subject_dev(s, F.data_ptr(), pp.data_ptr(), pi.data_ptr(), n + 7)
         wire[s] = (F, pp, pi, n)
 torch.cuda.synchronize()
-for (g, _), mine in zip(ranks, shards):
-    for s in range(S):
-        if s not in mine:
-            F, pp, pi, n = wire[s]
-            g.import_subject_dev(s, F.data_ptr(), pp.data_ptr(), pi.data_ptr(), n)
-    g.finalize()
+if BATCHED:  # the strided send / receive buffers of one all-gather: a shard per call (msm_group_export_subjects_dev / msm_group_import_subjects_dev)
+    for (g, _), mine in zip(ranks, shards):
+        other = [s for s in range(S) if s not in mine]
+        src = ranks[0][0] if other[0] in shards[0] else ranks[1][0]
+        imax = max(src.subject_index_count(s) for s in other) + 5
+        F = torch.zeros((len(other), g.L, g.D, V), dtype=torch.float64, device="cuda:0")
+        pp = torch.zeros((len(other), M_ + 3), dtype=torch.int32, device="cuda:0")    # strides larger than the rows: padded slots
+        pi = torch.full((len(other), imax), -1, dtype=torch.int32, device="cuda:0")
+        counts = src.export_subjects_dev(other, F.data_ptr(), g.L * g.D * V, pp.data_ptr(), M_ + 3, pi.data_ptr(), imax)
+        assert [int(c) for c in counts] == [src.subject_index_count(s) for s in other]
+        g.import_subjects_dev(other, F.data_ptr(), g.L * g.D * V, pp.data_ptr(), M_ + 3, pi.data_ptr(), imax, counts)
+        bad = pi.clone(); bad[0, 0] = V + 5                                             # a vertex id out of range must be refused, not indexed with
+        try:
+            g.import_subjects_dev(other, F.data_ptr(), g.L * g.D * V, pp.data_ptr(), M_ + 3, bad.data_ptr(), imax, counts)
+            raise SystemExit("an out-of-range template vertex id was imported")
+        except M.MsmError as e:
+            assert "inconsistent" in str(e), str(e)
+        g.finalize()
+else:
+    for (g, _), mine in zip(ranks, shards):
+        for s in range(S):
+            if s not in mine:
+                F, pp, pi, n = wire[s]
+                g.import_subject_dev(s, F.data_ptr(), pp.data_ptr(), pi.data_ptr(), n)
+        g.finalize()
 g1, keep1 = make(); g1.setupCostFunction()
 rng = np.random.default_rng(3)
 p = rng.integers(0, g1.P, 400).astype(np.int32); la = rng.integers(0, g1.L, 400).astype(np.int32); lb = rng.integers(0, g1.L, 400).astype(np.int32)
@@ -379,16 +398,19 @@ print(json.dumps({"ok": ok, "finite": int(np.isfinite(single).sum())}))
 '''
 
 
-def test_device_resident_exchange_between_two_shards(tmp_path):
+@pytest.mark.parametrize("batched", [False, True])
+def test_device_resident_exchange_between_two_shards(tmp_path, batched):
     """msm_group_export_subject_dev -> device buffers -> msm_group_import_subject_dev, the path an RCCL all-gather takes between two GPUs,
-    driven between two shards of one process on the one GPU of the test box: both shards end up equal to the unsharded set-up."""
+    driven between two shards of one process on the one GPU of the test box: both shards end up equal to the unsharded set-up.
+    batched: a whole shard per call through strided buffers (msm_group_export_subjects_dev / msm_group_import_subjects_dev), the row offsets of
+    the imported subjects left on the device until msm_group_export_subject asks for them; a corrupted index list is refused."""
     import os
     import subprocess
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / "exchange.py"
-    script.write_text(EXCHANGE_WORKER % root)
+    script.write_text("BATCHED = %s\n" % batched + EXCHANGE_WORKER % root)
     pr = subprocess.run([sys.executable, str(script)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=500)
     assert pr.returncode == 0, pr.stderr[-3000:]
     o = eval(pr.stdout.strip().splitlines()[-1].replace("true", "True").replace("false", "False"))

@@ -85,29 +85,64 @@ def test_two_levels_match_oracle(ctx):
     assert angles(got[0], in_xyz).max() > 1e-3
 
 
-def test_files_in_files_out(ctx, tmp_path):
-    """GIFTI in, sphere.reg + transformed data out (tools/register_files.py), a small case"""
+@pytest.mark.parametrize("fmt", ["GIFTI", "ASCII"])
+def test_files_in_files_out(ctx, tmp_path, fmt):
+    """tools/register_files.py under newmsm's flag names (CLI/msmOptions.h:59-157: --inmesh --refmesh --indata --refdata --conf --out -f) with the
+    shipped standard_MSM_strain configuration (config/basic_configs/config_standard_MSM_strain; its AFFINE level is reported as skipped, fewer
+    iterations for the test's sake): the three outputs of run_multiresolutions (M/mesh_registration.cpp:47-49) appear under the reference's names --
+    <out>sphere.reg, <out>sphere.LR.reg (M/mesh_registration.h:170), <out>transformed_and_reprojected -- and hold what the same schedule gives when
+    run_multiresolution is called directly (to the float32 of the files)."""
+    import os
     import subprocess
     import sys
 
-    from newmsm_amd import meshio
+    from newmsm_amd import config, meshio
 
-    xyz, tri = M.make_mesh_from_icosa(4)
+    xyz, tri = M.make_mesh_from_icosa(5)
     ref = synthetic.features(xyz, 1, 5)
     src = synthetic.features(synthetic.known_warp(xyz, seed=8, rot_deg=3.0, amp=2.0), 1, 5)
     d = str(tmp_path) + "/"
-    meshio.save_surface(d + "in.surf.gii", xyz, tri)
-    meshio.save_metric(d + "in.func.gii", src)
-    meshio.save_metric(d + "ref.func.gii", ref)
-    import os
-
+    text = config.PRESETS["standard_MSM_strain"].replace("--it=50,20,25,25", "--it=50,2,2,2").replace("--datagrid=5,5,5,6", "--datagrid=5,4,5,5").replace("--SGgrid=0,4,5,6", "--SGgrid=0,4,5,5").replace("--CPgrid=0,2,3,4", "--CPgrid=0,2,3,3")
+    assert "--opt=AFFINE,DISCRETE,DISCRETE,DISCRETE" in text and "--it=50,2,2,2" in text
+    with open(d + "conf", "w") as f:
+        f.write(text)
+    if fmt == "GIFTI":
+        files = dict(mesh=d + "in.surf.gii", indata=d + "in.func.gii", refdata=d + "ref.func.gii")
+        meshio.save_surface(files["mesh"], xyz, tri)
+        meshio.save_metric(files["indata"], src)
+        meshio.save_metric(files["refdata"], ref)
+        surf, data = ".surf.gii", ".func.gii"
+    else:
+        files = dict(mesh=d + "in.asc", indata=d + "in_data.asc", refdata=d + "ref_data.asc")
+        meshio.save_ascii(files["mesh"], xyz, tri)
+        meshio.save_ascii(files["indata"], xyz, tri, src[0])
+        meshio.save_ascii(files["refdata"], xyz, tri, ref[0])
+        surf, data = ".asc", ".dpv"
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    run = subprocess.run([sys.executable, "tools/register_files.py", d + "in.surf.gii", d + "in.surf.gii", d + "in.func.gii", d + "ref.func.gii", d + "out.", "1", "20"],
+    run = subprocess.run([sys.executable, "tools/register_files.py", "--inmesh=" + files["mesh"], "--refmesh=" + files["mesh"], "--indata=" + files["indata"],
+                          "--refdata=" + files["refdata"], "--conf=" + d + "conf", "--out=" + d + "out.", "-f", fmt, "--verbose"],
                          cwd=root, capture_output=True, text=True, timeout=600)
     assert run.returncode == 0, run.stderr
-    reg, rtri = meshio.load_surface(d + "out.sphere.reg.surf.gii")
+    assert "level 1 (--opt=AFFINE)" in run.stderr and "skipped" in run.stderr
+    reg, rtri = meshio.load_surface(d + "out.sphere.reg" + surf)
+    lr, lrtri = meshio.load_surface(d + "out.sphere.LR.reg" + surf)
     assert np.array_equal(rtri, tri) and np.allclose(np.linalg.norm(reg, axis=1), 100.0, atol=1e-3) and angles(reg, xyz).max() > 1e-4
-    assert meshio.load_metric(d + "out.transformed_and_reprojected.func.gii").shape == (1, len(xyz))
+    assert np.array_equal(lrtri, tri) and np.allclose(np.linalg.norm(lr, axis=1), 100.0, atol=1e-3)   # the last level's data grid is ico5 as well
+    moved = meshio.load_data(d + "out.transformed_and_reprojected" + data, len(xyz))
+    assert moved.shape == (1, len(xyz))
+    # the same schedule run directly on what the files hold (float32 data, the surface's coordinates through a float32 / a text file)
+    in_xyz, _ = meshio.load_surface(files["mesh"])
+    in_xyz = in_xyz - in_xyz.mean(axis=0)
+    in_xyz = in_xyz * (100.0 / np.linalg.norm(in_xyz, axis=1, keepdims=True))
+    src_f, ref_f = meshio.load_data(files["indata"], len(xyz)), meshio.load_data(files["refdata"], len(xyz))
+    levels, run_kw, skipped = config.levels_from_config(config.parse_config(text), 1)
+    want, regs, _ = registration.run_multiresolution(registration.ProductOps(ctx), in_xyz, tri, src_f, in_xyz, tri, ref_f, levels, **run_kw)
+    assert skipped == [(0, "AFFINE")]
+    assert np.abs(reg - want).max() < (2e-5 if fmt == "GIFTI" else 1e-3) and np.abs(lr - regs[-1]).max() < (2e-5 if fmt == "GIFTI" else 1e-3)
+    direct = M.metric_resample(M.Mesh(ctx, want, tri), src_f, M.Mesh(ctx, in_xyz, tri))
+    assert np.abs(moved - direct).max() < 1e-3 * max(1.0, np.abs(direct).max())
+    # the closer the better: the moved data correlate with the reference better than the unmoved ones
+    assert np.corrcoef(moved[0], ref[0])[0, 1] > np.corrcoef(src[0], ref[0])[0, 1]
 
 
 @pytest.mark.parametrize("kind,D", [("ho_univariate", 1), ("ho_multivariate", 16), ("univariate", 1)])

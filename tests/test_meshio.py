@@ -89,3 +89,23 @@ def test_freesurfer_ascii(tmp_path):
     p.write_text("no header\n")
     with pytest.raises(meshio.MeshIOError, match="error in the header"):
         meshio.load_surface(str(p))
+
+
+def test_dpv_and_matrix_text_files(tmp_path):
+    """the ASCII / ASCII_MAT data formats of set_output_format (M/mesh_registration.cpp:827-842): Mesh::save_dpv (R/mesh.cpp:707-741: `index x y z value`,
+    indices below 100 padded to three digits, six significant digits as std::ostream writes floats) and Mesh::save_matrix (:743-766: a line per data row)"""
+    rng = np.random.default_rng(0)
+    xyz, val = rng.normal(size=(130, 3)) * 100.0, rng.normal(size=(2, 130))
+    p = str(tmp_path / "a.dpv")
+    meshio.save_dpv(p, xyz, val)
+    lines = open(p).read().splitlines()
+    assert len(lines) == 130 and lines[7].split()[0] == "007" and lines[99].split()[0] == "099" and lines[100].split()[0] == "100"
+    assert lines[3] == "003 " + " ".join("%g" % float(np.float32(v)) for v in (*xyz[3], val[0, 3]))
+    x2, v2 = meshio.load_dpv(p)
+    assert np.allclose(x2, xyz, rtol=1e-5, atol=1e-4) and np.allclose(v2[0], val[0], rtol=1e-5, atol=1e-6)
+    q = str(tmp_path / "m.txt")
+    meshio.save_matrix(q, val)
+    rows = open(q).read().splitlines()
+    assert len(rows) == 2 and rows[0].endswith(" ") and len(rows[0].split()) == 130
+    assert np.allclose(meshio.load_data(q, 130), val, rtol=1e-5, atol=1e-6)
+    assert meshio.load_data(p, 130).shape == (1, 130)
