@@ -438,6 +438,21 @@ def free_port():
         return sk.getsockname()[1]
 
 
+class stdout_to_stderr:
+    """file descriptor 1 points at stderr inside the block: RCCL prints a version banner on stdout when its first communicator comes up, and the
+    contract is ONE JSON line there"""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
 def self_launch(n, argv):
     """`python bench.py --gpus N` with N > 1 outside a launcher: start the N ranks as `python -m torch.distributed.run` would be typed by hand --
     one process per GPU, rendezvous on 127.0.0.1 -- as a CHILD process, pass its output through and exit with its code.  This process has not
@@ -531,8 +546,9 @@ def main():
         raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE): the line would misreport n_gpus" % (args.gpus, world))
     if args.dry_launch:
         gpu = torch.cuda.is_available() and os.environ.get("MSM_BENCH_REHEARSAL") != "1"
-        comm = D.init("nccl" if gpu else "gloo", local_rank if gpu else None)
-        seen = D.count_ranks(comm)
+        with stdout_to_stderr():
+            comm = D.init("nccl" if gpu else "gloo", local_rank if gpu else None)
+            seen = D.count_ranks(comm)
         ranks = D.all_reduce_sum(np.eye(world)[rank], comm)
         tmpl = bench_template_allreduce(comm, 64, 2562, 2, reps=3)
         if rank == 0:
@@ -549,7 +565,9 @@ def main():
     torch.cuda.set_device(device_index)
     # MSM_BENCH_FORCE_DIST=1: a one-rank process group, so that a one-GPU box runs the RCCL collectives of the N > 1 path
     force = os.environ.get("MSM_BENCH_FORCE_DIST") == "1"
-    comm = D.init("gloo" if rehearse else "nccl", device_index) if (world > 1 or force) else D.Comm()
+    with stdout_to_stderr():
+        comm = D.init("gloo" if rehearse else "nccl", device_index) if (world > 1 or force) else D.Comm()
+        n_gpus = D.count_ranks(comm)  # an all-reduce of ones over the communicator: the ranks RCCL saw (also brings the communicator up)
 
     import __graft_entry__ as g
 
@@ -566,7 +584,6 @@ def main():
         comm.barrier()
         torch.cuda.synchronize()
 
-    n_gpus = D.count_ranks(comm)  # an all-reduce of ones over the communicator: the ranks RCCL saw
     if n_gpus != args.gpus:
         raise SystemExit("bench.py: the communicator has %d rank(s), --gpus says %d" % (n_gpus, args.gpus))
 
@@ -577,11 +594,12 @@ def main():
             if comm.dist is not None:
                 return bench_template_allreduce(comm, args.subjects, 40962, 2)
             os.environ["MASTER_PORT"] = str(free_port())
-            one = D.init("nccl", device_index)
-            try:
-                return bench_template_allreduce(one, args.subjects, 40962, 2)
-            finally:
-                one.close()
+            with stdout_to_stderr():
+                one = D.init("nccl", device_index)
+                try:
+                    return bench_template_allreduce(one, args.subjects, 40962, 2)
+                finally:
+                    one.close()
         except Exception as e:  # reported, not fatal
             return {"error": repr(e)}
 

@@ -32,50 +32,64 @@ template <int kHoLanes>
 __device__ void ho_group_eval(const CliqueArgs &a, bool valid, int t, int la, int lb, int lc, double *out) {
     extern __shared__ __align__(16) double s_vals[];  // (256 / kHoLanes) slices of a.bin_cap values
     const int grp = threadIdx.x / kHoLanes, sub = threadIdx.x % kHoLanes;
-    double *vals = s_vals + (size_t)grp * a.bin_cap;
+    // bins beyond kHoBinMax points (kHoLanes = 256: the workgroup works on one evaluation) keep their values in the workgroup's slice in HBM
+    double *vals = (kHoLanes == 256 && a.ho_big) ? a.ho_big + (size_t)blockIdx.x * a.bin_cap : s_vals + (size_t)grp * a.bin_cap;
     if (valid) {
         const int id[3] = {a.triplets[3 * t], a.triplets[3 * t + 1], a.triplets[3 * t + 2]};
         const V3 r0 = aos(a.moved, (size_t)id[0] * a.L + la), r1 = aos(a.moved, (size_t)id[1] * a.L + lb), r2 = aos(a.moved, (size_t)id[2] * a.L + lc);
         const V3 cp0 = soa(a.cp, a.N, id[0]), cp1 = soa(a.cp, a.N, id[1]), cp2 = soa(a.cp, a.N, id[2]);
         // a folded proposal never looks at the data (computeTripletCost, :151-152)
         if (!(dot(tri_normal(r0, r1, r2), tri_normal(cp0, cp1, cp2)) < 0.0)) {
-            const int beg = a.bin_ptr[t], n = a.bin_ptr[t + 1] - beg;  // n <= a.bin_cap (host-checked)
+            const int beg = a.bin_ptr[t], n = a.bin_ptr[t + 1] - beg;  // n <= a.bin_cap
             V3 s3;
             double pd;
             plane_of(cp0, cp1, cp2, s3, pd);
             for (int i = sub; i < n; i += kHoLanes) vals[i] = ho_point_value(a, a.bin_idx[beg + i], cp0, cp1, cp2, s3, pd, r0, r1, r2);
         }
     }
-    __syncthreads();
+    __syncthreads();  // (also makes the slice in HBM visible to the lane that reduces it)
     if (valid && sub == 0) *out = triplet_cost<true>(a, t, la, lb, lc, vals);
+    __syncthreads();  // the slice is reused by the workgroup's next evaluation
 }
 
+// the three kernels walk their evaluations with a workgroup-uniform stride (gridDim.x workgroups of 256 / kHoLanes evaluations each; one round
+// unless the launch was capped for the HBM slices of very large bins)
 template <int kHoLanes>
 __global__ __launch_bounds__(256) void k_triplet_batch_ho(CliqueArgs a, const int *__restrict__ qt, const int *__restrict__ qa,
                                                            const int *__restrict__ qb, const int *__restrict__ qc, int n, double *__restrict__ out) {
-    const int i = blockIdx.x * (256 / kHoLanes) + threadIdx.x / kHoLanes;
-    const bool valid = i < n;
-    ho_group_eval<kHoLanes>(a, valid, valid ? qt[i] : 0, valid ? qa[i] : 0, valid ? qb[i] : 0, valid ? qc[i] : 0, out + (valid ? i : 0));
+    constexpr int per = 256 / kHoLanes;
+    for (size_t base = (size_t)blockIdx.x * per; base < (size_t)n; base += (size_t)gridDim.x * per) {
+        const size_t i = base + threadIdx.x / kHoLanes;
+        const bool valid = i < (size_t)n;
+        ho_group_eval<kHoLanes>(a, valid, valid ? qt[i] : 0, valid ? qa[i] : 0, valid ? qb[i] : 0, valid ? qc[i] : 0, out + (valid ? i : 0));
+    }
 }
 
 template <int kHoLanes>
 __global__ __launch_bounds__(256) void k_triplet_octets_ho(CliqueArgs a, const int *__restrict__ labeling, int label, double *__restrict__ out) {
-    const int i = blockIdx.x * (256 / kHoLanes) + threadIdx.x / kHoLanes;
-    const bool valid = i < 8 * a.T;
-    const int t = valid ? i >> 3 : 0, k = i & 7;
-    const int la = (k & 4) ? label : labeling[a.triplets[3 * t]];
-    const int lb = (k & 2) ? label : labeling[a.triplets[3 * t + 1]];
-    const int lc = (k & 1) ? label : labeling[a.triplets[3 * t + 2]];
-    ho_group_eval<kHoLanes>(a, valid, t, la, lb, lc, out + (valid ? i : 0));
+    constexpr int per = 256 / kHoLanes;
+    const size_t total = (size_t)8 * a.T;
+    for (size_t base = (size_t)blockIdx.x * per; base < total; base += (size_t)gridDim.x * per) {
+        const size_t i = base + threadIdx.x / kHoLanes;
+        const bool valid = i < total;
+        const int t = valid ? (int)(i >> 3) : 0, k = (int)(i & 7);
+        const int la = (k & 4) ? label : labeling[a.triplets[3 * t]];
+        const int lb = (k & 2) ? label : labeling[a.triplets[3 * t + 1]];
+        const int lc = (k & 1) ? label : labeling[a.triplets[3 * t + 2]];
+        ho_group_eval<kHoLanes>(a, valid, t, la, lb, lc, out + (valid ? i : 0));
+    }
 }
 
 template <int kHoLanes>
 __global__ __launch_bounds__(256) void k_triplet_table_ho(CliqueArgs a, int t0, int t1, double *__restrict__ out) {
-    const size_t i = (size_t)blockIdx.x * (256 / kHoLanes) + threadIdx.x / kHoLanes;
-    const size_t L = (size_t)a.L, per = L * L * L;
-    const bool valid = i < (size_t)(t1 - t0) * per;
-    const size_t r = valid ? i % per : 0;
-    ho_group_eval<kHoLanes>(a, valid, valid ? t0 + (int)(i / per) : 0, (int)(r / (L * L)), (int)((r / L) % L), (int)(r % L), out + (valid ? i : 0));
+    constexpr int per = 256 / kHoLanes;
+    const size_t L = (size_t)a.L, cube = L * L * L, total = (size_t)(t1 - t0) * cube;
+    for (size_t base = (size_t)blockIdx.x * per; base < total; base += (size_t)gridDim.x * per) {
+        const size_t i = base + threadIdx.x / kHoLanes;
+        const bool valid = i < total;
+        const size_t r = valid ? i % cube : 0;
+        ho_group_eval<kHoLanes>(a, valid, valid ? t0 + (int)(i / cube) : 0, (int)(r / (L * L)), (int)((r / L) % L), (int)(r % L), out + (valid ? i : 0));
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -300,14 +314,16 @@ __global__ __launch_bounds__(256) void k_pairwise_table(CliqueArgs a, double *__
 }
 
 static bool is_ho(const CliqueArgs &a) { return a.kind == MSM_COST_HO_UNIVARIATE || a.kind == MSM_COST_HO_MULTIVARIATE; }
-// lanes per evaluation by the largest bin: the 256 / lanes LDS slices of bin_cap values must fit 128 KB (host-checked: bin_cap <= kHoBinMax)
+// lanes per evaluation by the largest bin: the 256 / lanes LDS slices of bin_cap values must fit 128 KB; beyond kHoBinMax points the whole
+// workgroup works on one evaluation with its values in HBM (CliqueArgs::ho_big)
 static int ho_lanes(const CliqueArgs &a) { return a.bin_cap <= 256 ? 4 : (a.bin_cap <= 1024 ? 16 : (a.bin_cap <= 4096 ? 64 : 256)); }
 // grid and dynamic LDS of an HO launch of `evals` evaluations with `lanes` lanes each
 template <class K>
 static int ho_config(const CliqueArgs &a, K kernel, int lanes, size_t evals, dim3 &grid, size_t &lds) {
     const int per = 256 / lanes;
-    lds = sizeof(double) * per * (size_t)a.bin_cap;
-    grid = dim3((unsigned)((evals + per - 1) / per));
+    const bool big = lanes == 256 && a.ho_big;
+    lds = big ? 0 : sizeof(double) * per * (size_t)a.bin_cap;
+    grid = dim3((unsigned)std::min<size_t>((evals + per - 1) / per, big ? (size_t)kHoBigBlocks : ((size_t)1 << 30)));
     if (lds > 64 * 1024) MSM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     return MSM_OK;
 }

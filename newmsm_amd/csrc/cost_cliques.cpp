@@ -65,6 +65,7 @@ int clique_args(msm_cost *c, bool need_triplets, bool need_pairs, CliqueArgs &a)
     a.bin_idx = c->d_pidx.p;
     a.bin_cap = std::max(c->pmax, 1);
     a.ho_vals = nullptr;
+    a.ho_big = nullptr;
     a.ho_pending = nullptr;
     a.ho_count = nullptr;
     a.absw = c->d_absw.p;
@@ -91,8 +92,12 @@ int clique_args(msm_cost *c, bool need_triplets, bool need_pairs, CliqueArgs &a)
             a.ho_pending = c->d_ho_pending.p;
             a.ho_count = c->d_ho_count.p;
         }
-        if (c->pmax > kHoBinMax)
-            return fail(MSM_ERR_CAPACITY, "msm_cost: %d source vertices under one control-grid triangle; the triclique kernels hold at most %d per evaluation", c->pmax, kHoBinMax);
+        if (c->pmax > kHoBinMax) {
+            // a bin that outgrows a workgroup's LDS (an ico7 data mesh under an ico0 control grid; the reference pushes into a std::vector,
+            // M/DiscreteCostFunction.cpp:468-485, and has no limit): the sampled values of an evaluation live in HBM, a slice per workgroup
+            MSM_HIP(c->d_ho_big.ensure((size_t)kHoBigBlocks * (size_t)c->pmax));
+            a.ho_big = c->d_ho_big.p;
+        }
     }
     a.tree = dev_tree(c->target);
     a.rmode = c->p.rmode;
@@ -414,8 +419,17 @@ int msm_cost_triplet_octets(msm_cost *c, const int32_t *labeling, int32_t label,
             MoveLabels lab;
             std::memset(lab.w, 0, sizeof(uint32_t) * (size_t)((a.N + 3) / 4));
             for (int i = 0; i < a.N; ++i) lab.w[i >> 2] |= (uint32_t)labeling[i] << ((i & 3) * 8);
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            if (c->timing) {  // msm_cost_enable_timing: events around this move's kernel, like the triclique move's
+                e0 = c->ev0[c->ev_next];
+                e1 = c->ev1[c->ev_next];
+                c->ev_next = (c->ev_next + 1) % (int)c->ev0.size();
+                c->ev_count = std::min(c->ev_count + 1, (int)c->ev0.size());
+                MSM_HIP(hipEventRecord(e0, ctx->stream));
+            }
             st = launch_triplet_octets_packed(ctx, a, lab, label, out_dev, ctx->d_flag_map);
             if (st) return st;
+            if (e1) MSM_HIP(hipEventRecord(e1, ctx->stream));
             c->counters[2] += (int64_t)8 * a.T;
             MSM_HIP(hipStreamSynchronize(ctx->stream));
             volatile int *flags = ctx->h_flag;

@@ -37,7 +37,7 @@ struct msm_cost {
     bool cp_conn_valid = false;
     DevBuf<int32_t> d_labeling;
     DevBuf<double> d_clique_out;
-    DevBuf<double> d_ho_vals;
+    DevBuf<double> d_ho_vals, d_ho_big;
     DevBuf<unsigned> d_ho_pending, d_ho_count;
     // fused fusion move of the HO classes (move_kernels.hip): per bin slot data prepared once per get_source_data()
     DevBuf<int32_t> d_slot_tri;

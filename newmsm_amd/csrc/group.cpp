@@ -630,10 +630,20 @@ int group_common_setup(msm_group *g) {
         int st = upload_staged(ctx, g->d_rot.p, g->rot.data(), sizeof(double) * g->rot.size());
         if (st) return st;
     }
-    MSM_HIP(g->d_labels3.upload(g->labels.data(), 3 * (size_t)L, ctx->stream));
-    MSM_HIP(g->d_spacing.upload(spacing_all.data(), spacing_all.size(), ctx->stream));
-    MSM_HIP(g->d_cp.upload(cp_all.data(), cp_all.size(), ctx->stream));
-    MSM_HIP(g->d_orig.upload(orig_all.data(), orig_all.size(), ctx->stream));
+    // through the pinned staging block: asynchronous copies out of freshly allocated pageable vectors (these are locals) left a stall of 10-30 ms
+    // behind them that the NEXT work on the stream paid for -- the first subject's rotations (tools/time_group_rank.py; DESIGN 5.4b has the same
+    // finding for the mesh uploads)
+    MSM_HIP(g->d_labels3.ensure(3 * (size_t)L));
+    MSM_HIP(g->d_spacing.ensure(spacing_all.size()));
+    MSM_HIP(g->d_cp.ensure(cp_all.size()));
+    MSM_HIP(g->d_orig.ensure(orig_all.size()));
+    {
+        int st = upload_staged(ctx, g->d_labels3.p, g->labels.data(), sizeof(double) * 3 * (size_t)L);
+        if (!st) st = upload_staged(ctx, g->d_spacing.p, spacing_all.data(), sizeof(double) * spacing_all.size());
+        if (!st) st = upload_staged(ctx, g->d_cp.p, cp_all.data(), sizeof(double) * cp_all.size());
+        if (!st) st = upload_staged(ctx, g->d_orig.p, orig_all.data(), sizeof(double) * orig_all.size());
+        if (st) return st;
+    }
     {
         int st = launch_group_moved(ctx, g->d_rot.p, S * N, g->d_labels3.p, L, g->d_moved.p);
         if (st) return st;
@@ -707,6 +717,15 @@ static int stage_prepare(msm_group *g, int s, msm_group::Stage &b) {
     msm_mesh *dm = g->data[s];
     const int V = dm->V, T = dm->T;
     const size_t LV = (size_t)L * V;
+    static const bool timing = std::getenv("MSMHIP_TIMING") != nullptr && std::getenv("MSMHIP_TIMING")[0] == '2';
+    auto tick = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        (void)hipStreamSynchronize(ctx->stream);
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "      prepare subject %d: %s %.2f ms\n", s, what, std::chrono::duration<double, std::milli>(now - tick).count());
+        tick = now;
+    };
     MSM_HIP(b.d_rot.ensure(3 * LV));
     for (int a = 0; a < 3; ++a)  // label 0 is the centre of the sampling grid: no rotation
         MSM_HIP(hipMemcpyAsync(b.d_rot.p + a * LV, dm->d_xyz + (size_t)a * V, sizeof(double) * (size_t)V, hipMemcpyDeviceToDevice, ctx->stream));
@@ -715,11 +734,14 @@ static int stage_prepare(msm_group *g, int s, msm_group::Stage &b) {
         int st = launch_rotate_to_label(ctx, dm->d_xyz, V, centre, lab, b.d_rot.p + (size_t)l * V, LV);
         if (st) return st;
     }
+    lap("rotations");
     MSM_HIP(b.d_feat.ensure((size_t)D * V));
     int st = upload_staged(ctx, b.d_feat.p, g->feat[s].data(), sizeof(double) * (size_t)D * V);
     if (st) return st;
+    lap("feature upload");
     st = subject_feature_slab(g, s, (size_t)D * Vt);
     if (st) return st;
+    lap("slab");
     // the L trees, built together (one chain of launches per subject instead of one per label); a tree that outgrows its arrays
     // (a degenerate mesh) sends the subject down the per-label builds of the lanes
     static const bool no_forest = [] { const char *e = std::getenv("MSMHIP_GROUP_FOREST"); return e && std::strcmp(e, "off") == 0; }();
@@ -729,6 +751,7 @@ static int stage_prepare(msm_group *g, int s, msm_group::Stage &b) {
         if (st == MSM_ERR_CAPACITY) b.forest_ok = false;
         else if (st) return st;
     }
+    lap("forest");
     st = check_status(ctx, "get_patch_data (rotation)");  // synchronises: rotations, features and trees are where the lanes will read them
     return st;
 }

@@ -149,6 +149,7 @@ struct CliqueArgs {
     const int *bin_ptr, *bin_idx;  // source vertices per control-grid triangle
     int bin_cap;                   // largest bin (LDS slice per evaluation in the HO kernels)
     // scratch of the three-kernel fusion-move path (ray-table targets): one value per (octet evaluation, bin point)
+    double *ho_big;                // bins beyond kHoBinMax: a slice of bin_cap doubles per WORKGROUP in HBM instead of LDS (or nullptr)
     double *ho_vals;               // 8 x (all bin points) doubles, or nullptr
     unsigned *ho_pending;          // same count: evaluation << 10 | point, for the complete search
     unsigned *ho_count;            // 1 word, zero between calls
@@ -170,7 +171,8 @@ struct CliqueArgs {
 // ---- fused fusion move of the HO (triclique) classes on a direction-table target (move_kernels.hip) ----
 // The labeling travels in the kernel arguments, one byte per control point (no copy engine on the call's critical path).
 constexpr int kPairSmallPatch = 80;  // entries a 16-lane query of k_group_pairwise keeps in registers (5 per lane)
-constexpr int kHoBinMax = 16384;  // source vertices under one control triangle the on-demand triclique kernels can hold (one workgroup's 128 KB LDS slice)
+constexpr int kHoBinMax = 16384;  // source vertices under one control triangle whose sampled values fit one workgroup's 128 KB LDS slice; larger bins keep them in HBM
+constexpr int kHoBigBlocks = 512;  // ... a slice per workgroup of at most this many workgroups, which loop over the evaluations
 constexpr int kMoveLabelWords = 704;  // N <= 2816 control points (ico4: 2562), L <= 256
 struct MoveLabels {
     uint32_t w[kMoveLabelWords];

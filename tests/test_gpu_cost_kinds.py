@@ -221,20 +221,28 @@ def test_triclique_large_bins(ctx, data_order, cp_order):
     assert np.allclose(got, want, rtol=RTOL, atol=ATOL), np.max(np.abs(got - want))
 
 
-@pytest.mark.parametrize("data_order,kind,D,least", [(5, "ho_multivariate", 9, 1024), (6, "ho_univariate", 1, 1500), (7, "ho_univariate", 1, 4096)])
-def test_triclique_bins_beyond_1024_points(ctx, data_order, kind, D, least):
-    # an ico0 control grid under fine data (tests/fuzz_parity.py found the first case: 1 052 source vertices under one control triangle was
-    # MSM_ERR_CAPACITY): 64 lanes per evaluation up to 4 096 points, the whole workgroup beyond; single evaluations and a whole label step
+@pytest.mark.parametrize("data_order,kind,D,least,squeeze", [(5, "ho_multivariate", 9, 1024, 0.0), (6, "ho_univariate", 1, 1500, 0.0), (7, "ho_univariate", 1, 16384, 0.0),
+                                                             (7, "ho_univariate", 1, 32768, 0.55), (6, "ho_multivariate", 3, 16384, 0.75)])
+def test_triclique_bins_beyond_1024_points(ctx, data_order, kind, D, least, squeeze):
+    """An ico0 control grid under fine data (tests/fuzz_parity.py found the first case: 1 052 source vertices under one control triangle was
+    MSM_ERR_CAPACITY): 64 lanes per evaluation up to 4 096 points, the whole workgroup with an LDS slice up to 16 384, and beyond that (round 4:
+    the order-7 case puts 16 436 vertices under one triangle, and a source sphere whose vertices crowd towards one pole more than 32 768) the
+    values of an evaluation live in HBM: the reference pushes a bin into a std::vector and has no limit (M/DiscreteCostFunction.cpp:468-485).
+    Single evaluations and a whole label step."""
     kw = dict(seed=86634, warp_amp=0.3482850938627505, warp_rot=3.350507727100841, labeldist=0.33807290039714544, rescale=False)
-    if data_order == 7:
-        kw.update(warp_amp=0.05, warp_rot=0.5)  # (the stronger warp puts 16 436 vertices under one triangle: beyond the 16 384 of a workgroup's LDS)
     inp = problem.pairwise_inputs(data_order, 0, D=D, **kw)
-    cf, oc, _ = pair(ctx, inp, kind, simmeasure=1, rmode=3, lambda_=0.1)
+    if squeeze > 0.0:  # x -> R (x + squeeze R e) / |x + squeeze R e|: a bijection of the sphere (squeeze < 1) that crowds the vertices towards e
+        e = inp["cp_xyz"][0] / np.linalg.norm(inp["cp_xyz"][0])
+        sx = inp["source_xyz"] + squeeze * 100.0 * e
+        inp["source_xyz"] = sx / np.linalg.norm(sx, axis=1, keepdims=True) * 100.0
+    cf, oc, _ = pair(ctx, inp, kind, simmeasure=1 if D == 1 else 2, rmode=3, lambda_=0.1)
     ptr, _ = cf.patches()
-    assert least < np.diff(ptr).max() <= 16384
+    assert np.diff(ptr).max() > least, np.diff(ptr).max()
     rng = np.random.default_rng(77)
-    n = 40 if data_order < 7 else 12
+    big = int(np.argmax(np.diff(ptr)))  # the triangle with the largest bin is among the queries
+    n = 40 if data_order < 7 and squeeze == 0.0 else 10
     t, la, lb, lc = random_queries(rng, n, cf.T, cf.L, 3)
+    t[0] = big
     got = cf.computeTripletCost(t, la, lb, lc)
     want = np.array([oc.triplet(*q) for q in zip(t, la, lb, lc)])
     assert np.isfinite(want).any()
