@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MSM_ABI_VERSION 8  /* 8 (round 4): msm_query_lanes, msm_group_export_subjects_dev / msm_group_import_subjects_dev / msm_group_setup_more_subjects added.  6 (round 3): msm_pairwise_icm, msm_ctx_time_queries / msm_ctx_query_kernel_ms, msm_group_time_moves / msm_group_move_kernels_ms,
+#define MSM_ABI_VERSION 8  /* 8 (round 4): msm_query_lanes, msm_resample_anatomy_grid, msm_group_export_subjects_dev / msm_group_import_subjects_dev / msm_group_setup_more_subjects added.  6 (round 3): msm_pairwise_icm, msm_ctx_time_queries / msm_ctx_query_kernel_ms, msm_group_time_moves / msm_group_move_kernels_ms,
                              * msm_store_release_i64 / msm_load_acquire_i64 / msm_min_acquire_i64, msm_mesh_sphere_project_warp added; nothing removed or changed */
 
 #define MSM_OK 0
@@ -76,6 +76,16 @@ int msm_mesh_adjacency(const int32_t *tri, int32_t V, int32_t T, int32_t *nbr_pt
 /* per-vertex mean adjacent triangle area: compute_vertex_area R/mesh.cpp:1275-1283 with the
  * triangle areas taken from the given coordinates (Triangle::calc_area R/triangle.cpp:52-55) */
 int msm_vertex_areas(const double *xyz, const int32_t *tri, int32_t V, int32_t T, double *area);
+/* Mesh_registration::resample_anatomy, M/mesh_registration.cpp:250-332, without its surface_resample call (msm_barycentric_coords_resample does that):
+ * what a --regoption=5 (aMSM) level prepares for msm_cost_set_anatomical.  The control grid (3 x N SoA, 3 x Tc SoA) is retessellated `levels` (=
+ * --anatgrid minus --CPgrid, >= 0) times as retessellate(mesh, old_tr_nbours) does it (R/mesh.cpp:1007-1109: children of triangle t numbered 4t .. 4t+3,
+ * every vertex re-normalised) and rescaled to `rad` (true_rescale) -> ANAT_ico (axyz 3 x Va SoA, atri 3 x Ta SoA); face_ptr (Tc + 1) / face_idx (Ta):
+ * NEARESTFACES, the faces of ANAT_ico under every control triangle IN THE REFERENCE'S ORDER (each pass after the first puts an entry's children in
+ * front of the list, :268-283; the order is the summation order of the mean anatomical strain); w_ptr (Va + 1) / w_cp / w_val (3 Va each):
+ * _ANATbaryweights, calc_barycentric_weights (R/triangle.cpp:124-143) of every ANAT_ico vertex in the control triangle that names it LAST in the loop
+ * :303-321, control point ids ascending within a row (std::map order).  With every output pointer NULL the call only returns the sizes *Va, *Ta. */
+int msm_resample_anatomy_grid(const double *cp_xyz, int32_t N, const int32_t *cp_tri, int32_t Tc, int32_t levels, double rad, int32_t *Va, int32_t *Ta,
+                              double *axyz, int32_t *atri, int32_t *w_ptr, int32_t *w_cp, double *w_val, int32_t *face_ptr, int32_t *face_idx);
 /* NonLinearSRegDiscreteModel::Initialize M/DiscreteModel.cpp:72-89: per control point the largest
  * geodesic distance to a neighbour, and Mesh::calculate_MaxVD R/mesh.cpp:263-277 */
 int msm_cp_spacings(const double *xyz, const int32_t *tri, int32_t V, int32_t T, double *maxsep, double *mvdmax);

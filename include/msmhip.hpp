@@ -228,6 +228,42 @@ inline Matrix metric_resample(Mesh &in_mesh, const Matrix &data, Mesh &ref, std:
     if (EXCL) *EXCL = eo;  // the reference writes the resampled mask back (:66)
     return out;
 }
+// surface_resample (R/resampler.cpp:284-302) / project_anatomical_mesh (:260-282): the coordinates `coords` given on the vertices of `from`, carried to
+// the points q by barycentric weights
+inline Points barycentric_coords_resample(Mesh &from, const Points &coords, const Points &q) {
+    std::vector<double> out(q.size());
+    check(msm_barycentric_coords_resample(from.handle(), to_soa(coords).data(), to_soa(q).data(), (int32_t)(q.size() / 3), out.data()));
+    return to_aos(out);
+}
+// Mesh_registration::resample_anatomy (M/mesh_registration.cpp:250-332) without its surface_resample call [host]: see msm_resample_anatomy_grid
+struct AnatomyGrid {
+    Points sphere_xyz;       // ANAT_ico, radius rad
+    Triangles sphere_tri;
+    SparseWeights weights;   // _ANATbaryweights
+    std::vector<int32_t> face_ptr, face_idx;  // NEARESTFACES
+};
+inline AnatomyGrid resample_anatomy_grid(const Points &cp_xyz, const Triangles &cp_tri, int levels, double rad = 100.0) {
+    const int32_t N = (int32_t)(cp_xyz.size() / 3), Tc = (int32_t)(cp_tri.size() / 3);
+    const std::vector<double> x = to_soa(cp_xyz);
+    const std::vector<int32_t> t = tri_to_soa(cp_tri);
+    int32_t Va = 0, Ta = 0;
+    check(msm_resample_anatomy_grid(x.data(), N, t.data(), Tc, levels, rad, &Va, &Ta, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr));
+    std::vector<double> ax(3 * (size_t)Va), wv(3 * (size_t)Va);
+    std::vector<int32_t> at(3 * (size_t)Ta), wp((size_t)Va + 1), wc(3 * (size_t)Va);
+    AnatomyGrid g;
+    g.face_ptr.resize((size_t)Tc + 1);
+    g.face_idx.resize((size_t)Ta);
+    check(msm_resample_anatomy_grid(x.data(), N, t.data(), Tc, levels, rad, &Va, &Ta, ax.data(), at.data(), wp.data(), wc.data(), wv.data(), g.face_ptr.data(),
+                                    g.face_idx.data()));
+    g.sphere_xyz = to_aos(ax);
+    g.sphere_tri.resize(3 * (size_t)Ta);
+    for (int32_t k = 0; k < Ta; ++k)
+        for (int c = 0; c < 3; ++c) g.sphere_tri[3 * (size_t)k + c] = at[(size_t)c * Ta + k];
+    wc.resize((size_t)wp.back());
+    wv.resize((size_t)wp.back());
+    g.weights.row_ptr = wp, g.weights.col = wc, g.weights.val = wv;
+    return g;
+}
 // sphere_project_warp, R/resampler.cpp:311-328: `sphere` is carried through the deformation from -> to
 inline Points sphere_project_warp(const Points &sphere, Mesh &from, const Points &to) {
     std::vector<double> s = to_soa(sphere);

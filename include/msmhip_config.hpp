@@ -11,7 +11,8 @@
 // parser in Python; tests/test_cpp_config.py checks that the two agree.
 //
 // Reported instead of silently dropped: AFFINE / RIGID levels (the affine stage is outside the path: listed in `skipped`), --IN / --INc (FSL's
-// histogram matching is not in the reference tree), --excl, --regoption=5 (the anatomical meshes come from the command line).
+// histogram matching is not in the reference tree), --excl.  --regoption=5 (aMSM) needs the anatomical surfaces (command line: --inanat / --refanat):
+// levels_from_config(..., anat = true) says the caller has them.
 #ifndef MSMHIP_CONFIG_HPP
 #define MSMHIP_CONFIG_HPP
 
@@ -178,10 +179,15 @@ inline Config parse_config(const std::string &text, bool no_config = false) {
 }
 
 // the DISCRETE levels of `c` for data with D feature rows; skipped (optional): index and method of the levels that are not DISCRETE
-inline std::vector<LevelSpec> levels_from_config(const Config &c, int D, bool *varnorm = nullptr, std::vector<std::pair<int, std::string>> *skipped = nullptr) {
+// anat: the caller has the anatomical surfaces a --regoption=5 (aMSM) run needs (they come from the command line: --inanat / --refanat)
+inline std::vector<LevelSpec> levels_from_config(const Config &c, int D, bool *varnorm = nullptr, std::vector<std::pair<int, std::string>> *skipped = nullptr,
+                                                 bool anat = false) {
     if (c.IN || c.INc) throw ConfigError("--IN / --INc (histogram matching through FSL's MISCMATHS::Histogram, M/reg_tools.cpp:745-802) is not available");
     if (c.excl) throw ConfigError("--excl (exclusion masks from the cut thresholds) is not wired into the level loop");
-    if (c.regoption == 4 || c.regoption == 5)
+    if (c.regoption == 4)  // M/mesh_registration.cpp:101-102
+        throw ConfigError("--regoption 4 has been removed from newMSM. Use --regoption 3 for spherical mesh regularisation or --regoption 5 for anatomical mesh "
+                          "regularisation.");
+    if (c.regoption == 5 && !anat)  // :103-104
         throw ConfigError("--regoption 5 requires anatomical meshes. Use --regoption 3 for spherical mesh regularisation or provide anatomical meshes.");
     int kind;
     if (D > 1) kind = c.patchwise ? MSM_COST_PATCHWISE : (c.triclique ? MSM_COST_HO_MULTIVARIATE : MSM_COST_MULTIVARIATE);  // M/DiscreteModel.cpp:44-58
@@ -201,6 +207,7 @@ inline std::vector<LevelSpec> levels_from_config(const Config &c, int D, bool *v
         LevelOptions &o = lv.options;
         o.sg_order = c.SGgrid[i], o.iters = c.it[i], o.mciters = c.mciters[i], o.mcparam = c.mcparam, o.rescale_labels = c.rescaleL;
         o.fusion = c.dopt == "HOCR", o.pairwise = c.dopt == "FastPD";
+        o.anat_order = i < c.anatgrid.size() ? c.anatgrid[i] : c.CPgrid[i] + 2;
         o.cost.kind = kind, o.cost.simmeasure = c.simval[i], o.cost.regularisermode = c.regoption, o.cost.lambda = c.lambda[i];
         o.cost.shearmodulus = c.shearmod, o.cost.bulkmodulus = c.bulkmod, o.cost.kexponent = c.k_exponent, o.cost.exponent = c.regexp;
         o.cost.range = c.cprange, o.cost.percentile = c.percentile;

@@ -12,6 +12,7 @@
 
 #include <chrono>
 #include <map>
+#include <memory>
 #include <string>
 
 #include "msmhip.hpp"
@@ -57,9 +58,17 @@ struct LevelOptions {
     // true: --regoption=1 as --dopt=FastPD drives it (M/mesh_registration.cpp:182-188): the model lists pairs instead of triplets, per iteration
     // computeUnaryCosts + computePairwiseCosts, then a stand-in for FPD::FastPD(model, 100) (msm_pairwise_icm)
     bool pairwise = false;
+    int anat_order = -1;  // --anatgrid of this level (regularisermode 4 / 5, aMSM); cp_order + 2 when negative
     // measurement only: when set, the cost function records HIP events around its kernels (msm_cost_enable_timing) and the duration of every fusion
     // move's kernel (ms) is appended here -- one event query per move, so a run with this set is not the one whose wall clock is reported
     std::vector<double> *move_kernel_ms = nullptr;
+};
+
+// the anatomical surfaces of a --regoption=5 (aMSM) run: V x 3 on the vertices of the input / reference SPHERE (MESHES[0] / MESHES[1]), whose handles
+// the level loop searches (set_anatomical, M/mesh_registration.cpp:437-441)
+struct Anatomy {
+    Mesh *in_sphere = nullptr, *ref_sphere = nullptr;
+    const Points *in_anat = nullptr, *ref_anat = nullptr;
 };
 
 struct LevelResult {
@@ -83,7 +92,8 @@ inline Points apply_labeling(const std::vector<double> &ROT, const Points &label
 // sph_reg: the current registered position of the source sphere; cp_start: the control grid after warp_CPgrid, or null
 inline LevelResult run_discrete_opt(Context &ctx, const Points &target_xyz, const Triangles &target_tri, const Matrix &ref_feat,
                                     const Points &source_xyz, const Triangles &source_tri, const Matrix &src_feat, int D, Points sph_reg,
-                                    int cp_order, const LevelOptions &o, const Points *cp_start = nullptr, PhaseClock *clock = nullptr) {
+                                    int cp_order, const LevelOptions &o, const Points *cp_start = nullptr, PhaseClock *clock = nullptr,
+                                    const Anatomy *anat = nullptr) {
     // ---- initialize_level / Initialize(CONTROL)
     auto [cp_xyz, cp_tri] = make_mesh_from_icosa(cp_order);
     Mesh TARGET(ctx, target_xyz, target_tri), SOURCE(ctx, source_xyz, source_tri), CPGRID(ctx, cp_xyz, cp_tri);
@@ -98,6 +108,22 @@ inline LevelResult run_discrete_opt(Context &ctx, const Points &target_xyz, cons
     costfct.set_meshes(TARGET, SOURCE, CPGRID);  // _ORIG, _oCPgrid
     costfct.set_featurespace(src_feat, D);
     costfct.set_spacings(MAXSEP, MVDmax);
+    std::unique_ptr<Mesh> anat_sphere;
+    if (o.cost.regularisermode == 4 || o.cost.regularisermode == 5) {  // initialize_level, M/mesh_registration.cpp:91-104
+        if (o.cost.regularisermode == 4)
+            throw Error(MSM_ERR_INVALID, "--regoption 4 has been removed from newMSM. Use --regoption 3 for spherical mesh regularisation or --regoption 5 for "
+                                         "anatomical mesh regularisation.");
+        if (!anat || !anat->in_sphere || !anat->ref_sphere || !anat->in_anat || !anat->ref_anat)
+            throw Error(MSM_ERR_INVALID, "--regoption 5 requires anatomical meshes. Use --regoption 3 for spherical mesh regularisation or provide anatomical meshes.");
+        if (o.pairwise) throw Error(MSM_ERR_INVALID, "MeshREG ERROR:: you cannot run higher order clique regularisers with fastPD ");
+        // resample_anatomy (:250-332): ANAT_ico with NEARESTFACES and _ANATbaryweights, both anatomies resampled onto it
+        const AnatomyGrid grid = resample_anatomy_grid(cp_xyz, cp_tri, std::max(0, (o.anat_order < 0 ? cp_order + 2 : o.anat_order) - cp_order));
+        const Points anat_orig = PhaseClock::timed(clock, "surface_resample", [&] { return barycentric_coords_resample(*anat->in_sphere, *anat->in_anat, grid.sphere_xyz); });
+        const Points anat_target = PhaseClock::timed(clock, "surface_resample", [&] { return barycentric_coords_resample(*anat->ref_sphere, *anat->ref_anat, grid.sphere_xyz); });
+        anat_sphere.reset(new Mesh(ctx, grid.sphere_xyz, grid.sphere_tri));
+        costfct.setTriplets(triplets);  // NEARESTFACES is indexed by triplet = control triangle
+        costfct.set_anatomical(*anat_sphere, anat_target, anat_orig, grid.sphere_tri, grid.weights, grid.face_ptr, grid.face_idx);
+    }
     const int N = (int)(cp_xyz.size() / 3);
     if (o.move_kernel_ms) check(msm_cost_enable_timing(costfct.handle(), 1));
     int m_iter = 1;
@@ -195,9 +221,14 @@ struct MultiresResult {
 // in_* / ref_*: the input and reference spheres (radius 100) with their D x V data.
 inline MultiresResult run_multiresolutions(Context &ctx, const Points &in_xyz, const Triangles &in_tri, const Matrix &in_data, const Points &ref_xyz,
                                            const Triangles &ref_tri, const Matrix &ref_data, int D, const std::vector<LevelSpec> &levels, bool varnorm,
-                                           PhaseClock *clock = nullptr) {
+                                           PhaseClock *clock = nullptr, const Points *in_anat = nullptr, const Points *ref_anat = nullptr) {
     if (levels.empty()) throw Error(MSM_ERR_INVALID, "run_multiresolutions: no DISCRETE level");
+    if ((in_anat != nullptr) != (ref_anat != nullptr)) throw Error(MSM_ERR_INVALID, "Error: must supply both anatomical meshes or none");  // CLI/newmsm.cpp:41-43
+    if (in_anat && (in_anat->size() != in_xyz.size() || ref_anat->size() != ref_xyz.size()))
+        throw Error(MSM_ERR_INVALID, "MeshREG ERROR:: input/reference anatomical mesh resolution is inconsistent with input/reference spherical mesh resolution.");
     Mesh in_mesh(ctx, in_xyz, in_tri), ref_mesh(ctx, ref_xyz, ref_tri);
+    Anatomy anatomy;
+    if (in_anat) anatomy.in_sphere = &in_mesh, anatomy.ref_sphere = &ref_mesh, anatomy.in_anat = in_anat, anatomy.ref_anat = ref_anat;
     MultiresResult res;
     Points sph_reg_prev;
     int prev_order = -1;
@@ -235,7 +266,7 @@ inline MultiresResult run_multiresolutions(Context &ctx, const Points &in_xyz, c
             sph_in = moved.get_coords();
         }
         LevelResult r = run_discrete_opt(ctx, ico_xyz, ico_tri, feats[1], ico_xyz, ico_tri, feats[0], D, sph_in, lv.cp_order, lv.options,
-                                         have_cp_start ? &cp_start : nullptr, clock);
+                                         have_cp_start ? &cp_start : nullptr, clock, in_anat ? &anatomy : nullptr);
         res.labelings.insert(res.labelings.end(), r.labelings.begin(), r.labelings.end());
         res.energies.push_back(r.energies);
         res.level_reg.push_back(r.sph_reg);

@@ -47,6 +47,7 @@ SIGNATURES = {
     "msm_icosphere": (C.c_int, [C.c_int, C.c_double, c_dp, c_ip]),
     "msm_mesh_adjacency": (C.c_int, [c_ip, C.c_int32, C.c_int32, c_ip, c_ip, c_ip, c_ip]),
     "msm_vertex_areas": (C.c_int, [c_dp, c_ip, C.c_int32, C.c_int32, c_dp]),
+    "msm_resample_anatomy_grid": (C.c_int, [c_dp, C.c_int32, c_ip, C.c_int32, C.c_int32, C.c_double, c_ip, c_ip, c_dp, c_ip, c_ip, c_ip, c_dp, c_ip, c_ip]),
     "msm_cp_spacings": (C.c_int, [c_dp, c_ip, C.c_int32, C.c_int32, c_dp, c_dp]),
     "msm_label_sampling_grid": (C.c_int, [C.c_int, C.c_double, C.c_int, C.c_int32, c_dp, c_ip, c_dp, c_ip]),
     "msm_rescale_sampling_grid": (C.c_int, [c_dp, C.c_int32, c_dp, c_dp]),

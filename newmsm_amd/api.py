@@ -370,6 +370,27 @@ def sphere_project_warp_mesh(sphere_mesh, from_mesh, to_xyz):
     check(lib().msm_mesh_sphere_project_warp(sphere_mesh.h, from_mesh.h, _soa(to_xyz)[1]))
 
 
+def resample_anatomy_grid(cp_xyz, cp_tri, levels, rad=100.0):
+    """Mesh_registration::resample_anatomy (M/mesh_registration.cpp:250-332) without its surface_resample call [host]: the control grid retessellated
+    `levels` (= anatgrid - CPgrid) times and rescaled to `rad` -> dict(sphere_xyz, sphere_tri, w_ptr, w_cp, w_val (_ANATbaryweights as CSR),
+    face_ptr, face_idx (NEARESTFACES as CSR, the reference's order)): the arguments of DiscreteCostFunction.set_anatomical besides the two anatomies."""
+    x, px = _soa(cp_xyz)
+    t, pt = _tri_soa(cp_tri)
+    N, Tc = x.shape[1], t.shape[1]
+    va, ta = C.c_int32(), C.c_int32()
+    check(lib().msm_resample_anatomy_grid(px, N, pt, Tc, int(levels), float(rad), C.byref(va), C.byref(ta), None, None, None, None, None, None, None))
+    Va, Ta = va.value, ta.value
+    axyz, atri = np.zeros((3, Va)), np.zeros((3, Ta), dtype=np.int32)
+    w_ptr, w_cp, w_val = np.zeros(Va + 1, dtype=np.int32), np.zeros(3 * Va, dtype=np.int32), np.zeros(3 * Va)
+    face_ptr, face_idx = np.zeros(Tc + 1, dtype=np.int32), np.zeros(Ta, dtype=np.int32)
+    check(lib().msm_resample_anatomy_grid(px, N, pt, Tc, int(levels), float(rad), C.byref(va), C.byref(ta), axyz.ctypes.data_as(c_dp), atri.ctypes.data_as(c_ip),
+                                          w_ptr.ctypes.data_as(c_ip), w_cp.ctypes.data_as(c_ip), w_val.ctypes.data_as(c_dp), face_ptr.ctypes.data_as(c_ip),
+                                          face_idx.ctypes.data_as(c_ip)))
+    n = int(w_ptr[-1])
+    return dict(sphere_xyz=np.ascontiguousarray(axyz.T), sphere_tri=np.ascontiguousarray(atri.T), w_ptr=w_ptr, w_cp=w_cp[:n].copy(), w_val=w_val[:n].copy(),
+                face_ptr=face_ptr, face_idx=face_idx)
+
+
 def barycentric_coords_resample(from_mesh, coords, q):
     x, px = _soa(q)
     out = np.zeros((3, x.shape[1]))

@@ -11,8 +11,8 @@ they become doubles, as `Utilities::Option<float>` / `std::vector<float>` do the
 0.007499999832361937, --shearmod=0.4 as 0.4000000059604645.
 
 Out of scope here, reported instead of silently dropped: AFFINE / RIGID levels (`--opt=AFFINE,...`: the affine stage is not part of the path;
-`levels_from_config` lists them in `skipped`), --IN / --INc (FSL's histogram matching is not in the reference tree), --excl, --anatgrid with
---regoption=5 (the anatomical meshes come from the command line, not from the config).
+`levels_from_config` lists them in `skipped`), --IN / --INc (FSL's histogram matching is not in the reference tree), --excl.  --regoption=5 (aMSM)
+needs the anatomical surfaces, which come from the command line (--inanat / --refanat): `levels_from_config(cfg, D, anat=True)` says the caller has them.
 """
 import numpy as np
 
@@ -121,7 +121,7 @@ def parse_config(text):
     return cfg
 
 
-def levels_from_config(cfg, D):
+def levels_from_config(cfg, D, anat=False):
     """The DISCRETE levels of `cfg` (parse_config's result) for data with D feature rows, as keyword sets of run_multiresolution, plus what
     applies to the whole run: returns (levels, run_kw, skipped) -- run_multiresolution(ops, ..., levels, **run_kw).  skipped: the (index,
     method) of levels that are not DISCRETE (the affine stage is outside the path).  fix_parameters_for_level + NonLinearSRegDiscreteModel::
@@ -130,7 +130,10 @@ def levels_from_config(cfg, D):
         raise ConfigError("--IN / --INc (histogram matching through FSL's MISCMATHS::Histogram, M/reg_tools.cpp:745-802) is not available")
     if cfg["excl"]:
         raise ConfigError("--excl (exclusion masks from the cut thresholds) is not wired into run_multiresolution")
-    if cfg["regoption"] in (4, 5):
+    if cfg["regoption"] == 4:  # M/mesh_registration.cpp:101-102
+        raise ConfigError("--regoption 4 has been removed from newMSM. Use --regoption 3 for spherical mesh regularisation or --regoption 5 for anatomical mesh "
+                          "regularisation.")
+    if cfg["regoption"] == 5 and not anat:  # :103-104: the anatomical meshes come from the command line (--inanat / --refanat), `anat` says they are there
         raise ConfigError("--regoption 5 requires anatomical meshes. Use --regoption 3 for spherical mesh regularisation or provide anatomical meshes.")
     multivariate = D > 1
     if multivariate:  # initialize_cost_function, M/DiscreteModel.cpp:44-58
@@ -153,13 +156,15 @@ def levels_from_config(cfg, D):
             params["percentile"] = cfg["percentile"]
         levels.append(dict(data_order=cfg["datagrid"][i], cp_order=cfg["CPgrid"][i], sg_order=cfg["SGgrid"][i], sigma_in=cfg["sigma_in"][i],
                            sigma_ref=cfg["sigma_ref"][i], iters=cfg["it"][i], mciters=cfg["mciters"][i], mcparam=cfg["mcparam"], kind=kind,
-                           simmeasure=cfg["simval"][i], rmode=rmode, rescale_labels=cfg["rescaleL"], optimiser=optimiser, cost_params=params))
+                           simmeasure=cfg["simval"][i], rmode=rmode, rescale_labels=cfg["rescaleL"], optimiser=optimiser, cost_params=params,
+                           anat_order=cfg["anatgrid"][i] if i < len(cfg["anatgrid"]) else cfg["CPgrid"][i] + 2))
     return levels, dict(varnorm=cfg["VN"]), skipped
 
 
 # The shipped configurations the BASELINE configs name, as text (the files themselves live in the reference tree, which is not available at run
 # time): same keys and values as config/HCP_multimodal_alignment/MSMAllStrainFinalconf1to1_1to3_2, config/NeuroImage2017_configs/
-# sMSM_STR_longitudinal_alignment, config/NeuroImage2017_configs/sMSM_PAIR_longitudinal_alignment (whose --regoption line is commented out: FastPD,
+# sMSM_STR_longitudinal_alignment, config/NeuroImage2017_configs/aMSM_STR_longitudinal_alignment (--regoption=5: needs the anatomical surfaces),
+# config/NeuroImage2017_configs/sMSM_PAIR_longitudinal_alignment (whose --regoption line is commented out: FastPD,
 # regoption 1) and config/basic_configs/config_standard_MSM_strain / config_standard_MSMpair.
 PRESETS = {
     "HCP_MSMAll": """
@@ -217,6 +222,27 @@ PRESETS = {
 
 #--regoption=1
 """,
+    "aMSM_STR": """
+--simval=2,2,2
+--sigma_in=6,4,2
+--sigma_ref=6,4,2
+--lambda=0.025,0.025,0.025
+--it=40,40,40
+--opt=DISCRETE,DISCRETE,DISCRETE
+--CPgrid=2,3,4
+--SGgrid=4,5,6
+--datagrid=4,5,6
+--anatgrid=4,5,6
+--regoption=5
+--regexp=2
+--dopt=HOCR
+--VN
+--rescaleL
+--triclique
+--k_exponent=2
+--bulkmod=1.6
+--shearmod=0.4
+""",
     "standard_MSM_strain": """
 --simval=2,2,2,2
 --sigma_in=2,4,2,1
@@ -250,9 +276,10 @@ PRESETS = {
 }
 
 
-def preset_levels(name, D, iterations=None):
-    """(levels, run_kw, skipped) of a shipped configuration; iterations (optional): overrides --it of the DISCRETE levels, in order"""
-    levels, run_kw, skipped = levels_from_config(parse_config(PRESETS[name]), D)
+def preset_levels(name, D, iterations=None, anat=False):
+    """(levels, run_kw, skipped) of a shipped configuration; iterations (optional): overrides --it of the DISCRETE levels, in order; anat: the caller
+    has the anatomical surfaces a --regoption=5 preset needs"""
+    levels, run_kw, skipped = levels_from_config(parse_config(PRESETS[name]), D, anat=anat)
     if iterations is not None:
         for lv, it in zip(levels, iterations):
             lv["iters"] = it

@@ -446,8 +446,17 @@ int msm_cost_triplet_octets(msm_cost *c, const int32_t *labeling, int32_t label,
     MSM_HIP(c->d_labeling.ensure(a.N));
     MSM_HIP(hipMemcpyAsync(c->d_labeling.p, pin, in_bytes, hipMemcpyHostToDevice, ctx->stream));
     MSM_HIP(c->d_clique_out.ensure((size_t)8 * a.T));
+    hipEvent_t g0 = nullptr, g1 = nullptr;
+    if (c->timing) {  // msm_cost_enable_timing: events around this move's kernels (the on-demand kernels: anatomical strain, large bins, general targets)
+        g0 = c->ev0[c->ev_next];
+        g1 = c->ev1[c->ev_next];
+        c->ev_next = (c->ev_next + 1) % (int)c->ev0.size();
+        c->ev_count = std::min(c->ev_count + 1, (int)c->ev0.size());
+        MSM_HIP(hipEventRecord(g0, ctx->stream));
+    }
     st = launch_triplet_octets(ctx, a, c->d_labeling.p, label, c->d_clique_out.p);
     if (st) return st;
+    if (g1) MSM_HIP(hipEventRecord(g1, ctx->stream));
     MSM_HIP(hipMemcpyAsync((char *)pin + in_pad, c->d_clique_out.p, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
     c->counters[2] += (int64_t)8 * a.T;
     st = check_status(ctx, "computeTripletCost");  // synchronises

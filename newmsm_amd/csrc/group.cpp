@@ -1522,7 +1522,8 @@ static int slice_pair_order(msm_group *g, int64_t pair0, int64_t pair1, const in
         msm_ctx *ctx = g->ctx;
         MSM_HIP(hipStreamSynchronize(ctx->stream));
         const int64_t n = pair1 - pair0;
-        const int pieces = n >= (1 << 18) ? 4 : 1;
+        static const int pieces_env = [] { const char *e = std::getenv("MSMHIP_GROUP_PIECES"); return e ? std::max(1, std::min(16, std::atoi(e))) : 0; }();
+        const int pieces = pieces_env ? pieces_env : (n >= (1 << 18) ? 4 : 1);
         g->order_chunk.assign(pieces + 1, 0);
         for (int k = 0; k <= pieces; ++k) g->order_chunk[k] = n * k / pieces;
         std::vector<std::vector<int32_t>> part(pieces);

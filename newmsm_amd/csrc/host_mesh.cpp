@@ -216,6 +216,100 @@ int msm_icosphere(int order, double radius, double *xyz, int32_t *tri) {
     return MSM_OK;
 }
 
+// Mesh_registration::resample_anatomy, M/mesh_registration.cpp:250-332, without its surface_resample call.
+//   ANAT_ico   the control grid retessellated `levels` times: retessellate(mesh, old_tr_nbours) R/mesh.cpp:1007-1109 numbers the children of triangle t
+//              4t .. 4t+3 and re-normalises EVERY vertex to the unit sphere; true_rescale to `rad` afterwards (:299)
+//   NEARESTFACES[i]  the faces of ANAT_ico under control triangle i: after the first pass [4i, 4i+1, 4i+2, 4i+3]; every further pass replaces each
+//              entry by its four children, inserting each entry's children at the FRONT of the new list (:268-283) -- so the order of a list
+//              reverses block-wise with every pass.  It is the summation order of the mean strain (computeTripletCost, M/DiscreteCostFunction.cpp:169-182)
+//   _ANATbaryweights[v]  calc_barycentric_weights (R/triangle.cpp:124-143) of ANAT_ico vertex v in the control triangle of the LAST (i, face, corner) that
+//              names it in the loop :303-321 (std::map assignment replaces the row); keys ascending (std::map order)
+int msm_resample_anatomy_grid(const double *cp_xyz, int32_t N, const int32_t *cp_tri, int32_t Tc, int32_t levels, double rad, int32_t *Va_out, int32_t *Ta_out,
+                              double *axyz, int32_t *atri, int32_t *w_ptr, int32_t *w_cp, double *w_val, int32_t *face_ptr, int32_t *face_idx) {
+    if (!cp_xyz || !cp_tri || N <= 0 || Tc <= 0 || levels < 0 || levels > 8) return fail(MSM_ERR_INVALID, "msm_resample_anatomy_grid: bad arguments");
+    if (int st = check_triangles("msm_resample_anatomy_grid", cp_tri, N, Tc)) return st;
+    std::vector<double> xyz(3 * (size_t)N);
+    std::vector<int32_t> tri(3 * (size_t)Tc);
+    for (int i = 0; i < N; ++i)
+        for (int k = 0; k < 3; ++k) xyz[3 * (size_t)i + k] = cp_xyz[(size_t)k * N + i];
+    for (int t = 0; t < Tc; ++t)
+        for (int k = 0; k < 3; ++k) tri[3 * (size_t)t + k] = cp_tri[(size_t)k * Tc + t];
+    std::vector<std::vector<int32_t>> faces((size_t)Tc);
+    for (int i = 0; i < Tc; ++i) faces[(size_t)i].push_back(i);  // levels == 0: each control triangle is its own face (:287-293)
+    for (int pass = 0; pass < levels; ++pass) {
+        subdivide(xyz, tri);  // children of triangle t: 4t .. 4t+3 (tot_triangles counts up through the loop over the old triangles)
+        for (auto &list : faces) {
+            std::vector<int32_t> next;
+            next.reserve(list.size() * 4);
+            if (pass == 0) {  // FACE_neighbours = FACE_neighbours_tmp: in order
+                for (int32_t f : list)
+                    for (int c = 0; c < 4; ++c) next.push_back(4 * f + c);
+            } else {          // insert(begin, children of list[k]) for k = 0, 1, ...: the last entry's children come first
+                for (size_t k = list.size(); k-- > 0;)
+                    for (int c = 0; c < 4; ++c) next.push_back(4 * list[k] + c);
+            }
+            list.swap(next);
+        }
+    }
+    const int32_t Va = (int32_t)(xyz.size() / 3), Ta = (int32_t)(tri.size() / 3);
+    if (Va_out) *Va_out = Va;
+    if (Ta_out) *Ta_out = Ta;
+    if (!axyz && !atri && !w_ptr && !w_cp && !w_val && !face_ptr && !face_idx) return MSM_OK;  // the sizing call
+    if (!axyz || !atri || !w_ptr || !w_cp || !w_val || !face_ptr || !face_idx) return fail(MSM_ERR_INVALID, "msm_resample_anatomy_grid: all outputs or none");
+    for (int32_t i = 0; i < Va; ++i) {  // true_rescale(ANAT_ico, RAD)
+        const V3 c = scale(normalized(mk(xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2])), rad);
+        xyz[3 * (size_t)i] = c.x, xyz[3 * (size_t)i + 1] = c.y, xyz[3 * (size_t)i + 2] = c.z;
+    }
+    struct Row {
+        int n = 0;
+        int32_t id[3];
+        double w[3];
+    };
+    std::vector<Row> rows((size_t)Va);
+    for (int i = 0; i < Tc; ++i) {
+        const int32_t id[3] = {cp_tri[i], cp_tri[(size_t)Tc + i], cp_tri[2 * (size_t)Tc + i]};
+        V3 v[3];
+        for (int k = 0; k < 3; ++k) v[k] = mk(cp_xyz[id[k]], cp_xyz[(size_t)N + id[k]], cp_xyz[2 * (size_t)N + id[k]]);
+        for (int32_t j : faces[(size_t)i])
+            for (int k = 0; k < 3; ++k) {
+                const int32_t a = tri[3 * (size_t)j + k];
+                const V3 ci = mk(xyz[3 * (size_t)a], xyz[3 * (size_t)a + 1], xyz[3 * (size_t)a + 2]);
+                const V3 pp = project_point(ci, v[0], v[1], v[2]);
+                const double Aa = compute_area(pp, v[1], v[2]), Ab = compute_area(pp, v[0], v[2]), Ac = compute_area(pp, v[0], v[1]);
+                const double A = Aa + Ab + Ac;
+                const double w[3] = {Aa / A, Ab / A, Ac / A};
+                std::map<int32_t, double> m;  // weights[n1] = ..; weights[n2] = ..; weights[n3] = ..: a repeated id keeps the later value
+                for (int q = 0; q < 3; ++q) m[id[q]] = w[q];
+                Row &r = rows[(size_t)a];
+                r.n = 0;
+                for (const auto &kv : m) {
+                    r.id[r.n] = kv.first;
+                    r.w[r.n] = kv.second;
+                    ++r.n;
+                }
+            }
+    }
+    w_ptr[0] = 0;
+    for (int32_t a = 0; a < Va; ++a) {
+        const Row &r = rows[(size_t)a];
+        for (int q = 0; q < r.n; ++q) {
+            w_cp[w_ptr[a] + q] = r.id[q];
+            w_val[w_ptr[a] + q] = r.w[q];
+        }
+        w_ptr[a + 1] = w_ptr[a] + r.n;
+    }
+    face_ptr[0] = 0;
+    for (int i = 0; i < Tc; ++i) {
+        std::copy(faces[(size_t)i].begin(), faces[(size_t)i].end(), face_idx + face_ptr[i]);
+        face_ptr[i + 1] = face_ptr[i] + (int32_t)faces[(size_t)i].size();
+    }
+    for (int32_t i = 0; i < Va; ++i)
+        for (int k = 0; k < 3; ++k) axyz[(size_t)k * Va + i] = xyz[3 * (size_t)i + k];
+    for (int32_t t = 0; t < Ta; ++t)
+        for (int k = 0; k < 3; ++k) atri[(size_t)k * Ta + t] = tri[3 * (size_t)t + k];
+    return MSM_OK;
+}
+
 int msm_mesh_adjacency(const int32_t *tri, int32_t V, int32_t T, int32_t *nbr_ptr, int32_t *nbr, int32_t *tid_ptr, int32_t *tid) {
     if (int st = check_triangles("msm_mesh_adjacency", tri, V, T)) return st;
     Adjacency a;

@@ -68,36 +68,19 @@ def build_cost(ctx, inp, kind="univariate", simmeasure=2, rmode=3, **params):
 
 
 def anatomical_inputs(ctx, inp, anat_order=None, seed=99):
-    """Synthetic inputs of the anatomical regulariser (regoption 5), shaped like Mesh_registration::resample_anatomy
-    (M/mesh_registration.cpp:250-332) prepares them: the anatomical-resolution sphere aICO (the control grid
-    retessellated, so the control points keep their vertex ids), a source and a target anatomy on its vertices,
-    the barycentric weights of every aICO vertex in its control-grid triangle and, per control-grid triangle, the
-    aICO faces lying in it."""
+    """Inputs of the anatomical regulariser (regoption 5) as Mesh_registration::resample_anatomy (M/mesh_registration.cpp:250-332) prepares them --
+    api.resample_anatomy_grid: the control grid retessellated to anatomical resolution with the reference's face-neighbourhood bookkeeping
+    (NEARESTFACES in its order, _ANATbaryweights in its overwrite order) -- with a synthetic source and target anatomy on the vertices of that
+    sphere (what surface_resample of the two anatomical surfaces would deliver)."""
     if anat_order is None:
         anat_order = inp["cp_order"] + 2
-    axyz, atri = api.make_mesh_from_icosa(anat_order)
-    cp = api.Mesh(ctx, inp["cp_orig_xyz"], inp["cp_tri"])
-    # NEARESTFACES: the control triangle under each aICO face centroid; _ANATbaryweights: weights of each aICO vertex in
-    # the control triangle of (the last of) its faces, keyed by control point id (std::map order)
-    cen = axyz[atri].mean(axis=1)
-    cen = cen / np.linalg.norm(cen, axis=1, keepdims=True) * synthetic.RAD
-    _, ftri, _, _ = cp.query_triangles(cen)
-    order = np.argsort(ftri, kind="stable")
-    face_ptr = np.zeros(len(inp["cp_tri"]) + 1, dtype=np.int32)
-    np.add.at(face_ptr, ftri + 1, 1)
-    face_ptr = np.cumsum(face_ptr).astype(np.int32)
-    face_idx = order.astype(np.int32)
-    _, _, vid, w = cp.query_triangles(axyz)
-    key = np.argsort(vid, axis=1, kind="stable")
-    w_cp = np.take_along_axis(vid, key, axis=1).astype(np.int32).ravel()
-    w_val = np.take_along_axis(w, key, axis=1).ravel()
-    w_ptr = (3 * np.arange(len(axyz) + 1)).astype(np.int32)
+    grid = api.resample_anatomy_grid(inp["cp_orig_xyz"], inp["cp_tri"], anat_order - inp["cp_order"], synthetic.RAD)
+    axyz = grid["sphere_xyz"]
     # two smooth "cortical" surfaces on the aICO vertices
     d = axyz / synthetic.RAD
     rs = 60.0 + 6.0 * synthetic.smooth_feature(axyz, 0, seed) + 3.0 * synthetic.smooth_feature(axyz, 1, seed)
     rt = 62.0 + 5.0 * synthetic.smooth_feature(axyz, 2, seed + 1) + 4.0 * synthetic.smooth_feature(axyz, 0, seed + 2)
-    return dict(anat_order=anat_order, sphere_xyz=axyz, sphere_tri=atri, asource_xyz=d * rs[:, None], atarget_xyz=d * rt[:, None],
-                w_ptr=w_ptr, w_cp=w_cp, w_val=w_val, face_ptr=face_ptr, face_idx=face_idx)
+    return dict(grid, anat_order=anat_order, asource_xyz=d * rs[:, None], atarget_xyz=d * rt[:, None])
 
 
 def build_group(ctx, S, data_order=6, cp_order=4, D=2, subjects=None, lambda_=0.2, simmeasure=2, seed=40, template_order=None):

@@ -64,6 +64,14 @@ class ProductOps:
     def nearest_neighbour(self, mesh, data, q_xyz):
         return api.nearest_neighbour_interpolation(mesh, data, q_xyz)
 
+    # --- aMSM (--regoption=5): Mesh_registration::resample_anatomy, M/mesh_registration.cpp:250-332
+    def resample_anatomy_grid(self, cp_xyz, cp_tri, levels):
+        return api.resample_anatomy_grid(cp_xyz, cp_tri, levels, RAD)
+
+    def surface_resample(self, anat_xyz, sphere_mesh, q_xyz):
+        """newresampler::surface_resample / project_anatomical_mesh (R/resampler.cpp:284-302, :260-282): the anatomy given on the vertices of sphere_mesh at q"""
+        return api.barycentric_coords_resample(sphere_mesh, anat_xyz, q_xyz)
+
     # --- model host logic
     def cp_spacings(self, mesh, xyz, tri):
         return api.cp_spacings(xyz, tri)
@@ -126,6 +134,10 @@ class _ProductCost:
     def set_pairs(self, pairs):
         self.cf.setPairs(pairs)
 
+    def set_anatomical(self, sphere_mesh, atarget_xyz, asource_xyz, grid):
+        self.cf.set_anatomical(sphere_mesh, atarget_xyz, asource_xyz, grid["sphere_tri"], grid["w_ptr"], grid["w_cp"], grid["w_val"], grid["face_ptr"],
+                               grid["face_idx"])
+
     def get_source_data(self):
         self.cf.get_source_data()
 
@@ -187,7 +199,7 @@ def combine_costfunction_weighting(sourceweight, resampledtargetweight):
 def run_discrete_level(ops, target_xyz, target_tri, ref_feat, source_xyz, source_tri, src_feat, sph_reg, cp_order, *, sg_order=None,
                        iters=3, mciters=200, mcparam=0.8, seed=0, kind="univariate", simmeasure=2, rmode=3, labeldist=0.5,
                        rescale_labels=False, cost_params=None, timings=None, cp_start=None, in_weight=None, ref_weight=None,
-                       optimiser="mcmc", icm_passes=5, converge=False):
+                       optimiser="mcmc", icm_passes=5, converge=False, anat=None):
     """Runs `iters` iterations of run_discrete_opt for one level.  optimiser: "mcmc" -- the reference's Monte Carlo optimiser over the
     unary and T x L^3 triplet tables (M/mcmc_opt.h:31-134) -- or "fusion": the label loop of Fusion::optimize (I/Fusion/Fusion.h:136-229: two
     sweeps over the labels, per label step 2 N unary and 8 T triplet costs -- ONE fusion-move call on the MI355X path --, nodes that the
@@ -204,7 +216,13 @@ def run_discrete_level(ops, target_xyz, target_tri, ref_feat, source_xyz, source
     warp of the previous level applied to it); the regular grid when None.  in_weight / ref_weight (rows x V, optional): the
     cost-function weightings of the moving and the reference data at this resolution (SPHin_CFWEIGHTING / SPHref_CFWEIGHTING);
     with both given every iteration resamples the reference weighting onto the moving sphere and averages the two
-    (combine_weighting, M/mesh_registration.cpp:234-248), otherwise the weighting is all ones."""
+    (combine_weighting, M/mesh_registration.cpp:234-248), otherwise the weighting is all ones.
+    anat (rmode 4 / 5, aMSM): dict(order, in_anat, in_mesh, ref_anat, ref_mesh) -- --anatgrid of this level and the input / reference anatomical
+    surfaces (V x 3) with the spheres (ops meshes) whose vertices they share (MESHES[0] / MESHES[1]).  initialize_level (M/mesh_registration.cpp:
+    91-99) then prepares the anatomical regulariser: resample_anatomy (:250-332: the control grid retessellated to anatomical resolution with the
+    face neighbourhoods -> NEARESTFACES, _ANATbaryweights, the input anatomy resampled onto it), the reference anatomy resampled the same way,
+    set_anatomical_meshspace / set_anatomical_neighbourhood.  (setupCostFunction's reset_anatomical, M/DiscreteCostFunction.cpp:85-100, computes
+    _aSOURCEtrans and MAXstrain, which nothing reads: not evaluated.)"""
     if sg_order is None:
         sg_order = cp_order + 2
     cost_params = dict(cost_params or {})
@@ -231,6 +249,18 @@ def run_discrete_level(ops, target_xyz, target_tri, ref_feat, source_xyz, source
     pairs = ops.estimate_pairs(cpgrid, cp_tri, len(cp_xyz)) if pairwise else None
     cost = ops.cost(kind, simmeasure, rmode, cost_params, target, source, cpgrid, src_feat)  # set_meshes: _ORIG, _oCPgrid
     cost.set_spacings(maxsep, mvdmax)
+    if rmode in (4, 5):
+        if anat is None:  # M/mesh_registration.cpp:100-104
+            raise ValueError("--regoption 4 has been removed from newMSM. Use --regoption 3 for spherical mesh regularisation or --regoption 5 for anatomical mesh "
+                             "regularisation." if rmode == 4 else
+                             "--regoption 5 requires anatomical meshes. Use --regoption 3 for spherical mesh regularisation or provide anatomical meshes.")
+        if pairwise:
+            raise ValueError("MeshREG ERROR:: you cannot run higher order clique regularisers with fastPD ")
+        grid = ops.resample_anatomy_grid(cp_xyz, cp_tri, max(0, anat["order"] - cp_order))     # ANAT_ico, _ANATbaryweights, NEARESTFACES
+        anat_orig = timed("surface_resample", ops.surface_resample, anat["in_anat"], anat["in_mesh"], grid["sphere_xyz"])    # ANAT_orig (:323)
+        anat_target = timed("surface_resample", ops.surface_resample, anat["ref_anat"], anat["ref_mesh"], grid["sphere_xyz"])  # ANAT_target (:93)
+        cost.set_triplets(triplets)  # NEARESTFACES is indexed by triplet = control triangle
+        cost.set_anatomical(ops.mesh(grid["sphere_xyz"], grid["sphere_tri"]), anat_target, anat_orig, grid)
     m_iter, m_scale = 1, 1.0
     energies, labelings = [], []
     energy = 0.0
@@ -299,7 +329,7 @@ def run_discrete_level(ops, target_xyz, target_tri, ref_feat, source_xyz, source
 
 
 def run_multiresolution(ops, in_xyz, in_tri, in_data, ref_xyz, ref_tri, ref_data, levels, *, varnorm=False, timings=None, in_cfweight=None,
-                        ref_cfweight=None, labelings_out=None, **level_kw):
+                        ref_cfweight=None, labelings_out=None, in_anat=None, ref_anat=None, **level_kw):
     """Mesh_registration::run_multiresolutions (M/mesh_registration.cpp:30-50) for DISCRETE levels without file I/O:
 
     per level  featurespace::initialise (M/featurespace.cpp:39-86: metric_resample of both data sets onto the level's
@@ -311,7 +341,9 @@ def run_multiresolution(ops, in_xyz, in_tri, in_data, ref_xyz, ref_tri, ref_data
     and optionally sg_order, sigma_in, sigma_ref, iters, mciters, cost_params.  in_cfweight / ref_cfweight (rows x V on the
     input / reference sphere, optional): cost-function weightings, brought to each level's grid by nearest-neighbour
     interpolation (downsample_cfweighting, M/mesh_registration.cpp:334-350).  labelings_out (optional list): receives every iteration's labeling, level
-    after level (the parity tests compare the optimiser's decisions of two runs).  recentre() of the regular spheres
+    after level (the parity tests compare the optimiser's decisions of two runs).  in_anat / ref_anat (V x 3 on the vertices of the input /
+    reference sphere; both or none, CLI/newmsm.cpp:40-45): the anatomical surfaces of a --regoption=5 (aMSM) run; a level's "anat_order" is its
+    --anatgrid.  recentre() of the regular spheres
     (a shift of ~1e-15) is not applied.  Returns (sphere_reg, per-level registered data grids, per-level energies)."""
     clock = timings if timings is not None else {}
 
@@ -352,6 +384,13 @@ def run_multiresolution(ops, in_xyz, in_tri, in_data, ref_xyz, ref_tri, ref_data
         kw = dict(level_kw)
         kw.update({k: lv[k] for k in ("sg_order", "iters", "mciters", "mcparam", "cost_params", "kind", "rescale_labels", "optimiser", "simmeasure", "rmode",
                                       "converge") if k in lv})
+        if in_anat is not None or ref_anat is not None:
+            if in_anat is None or ref_anat is None:
+                raise ValueError("Error: must supply both anatomical meshes or none")  # CLI/newmsm.cpp:41-43
+            if len(in_anat) != len(in_xyz) or len(ref_anat) != len(np.asarray(ref_xyz)):
+                raise ValueError("MeshREG ERROR:: input/reference anatomical mesh resolution is inconsistent with input/reference spherical mesh resolution.")
+            kw["anat"] = dict(order=lv.get("anat_order", lv["cp_order"] + 2), in_anat=np.asarray(in_anat, dtype=np.float64), in_mesh=in_mesh,
+                              ref_anat=np.asarray(ref_anat, dtype=np.float64), ref_mesh=ref_mesh)
         if in_cfweight is not None and ref_cfweight is not None:
             kw["in_weight"] = ops.nearest_neighbour(in_mesh, in_cfweight, ico_xyz)
             kw["ref_weight"] = ops.nearest_neighbour(ref_mesh, ref_cfweight, ico_xyz)

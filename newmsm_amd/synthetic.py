@@ -53,3 +53,12 @@ def random_sphere_points(n, seed=0, radius=RAD):
     rng = np.random.default_rng(seed)
     p = rng.normal(size=(n, 3))
     return p / np.linalg.norm(p, axis=1, keepdims=True) * radius
+
+
+def anatomy(sphere_xyz, seed=0, base=60.0):
+    """a smooth star-shaped "cortical" surface on the vertices of a sphere (V x 3): radius base + a few mm of smooth relief -- the anatomical
+    surface (--inanat / --refanat) of a synthetic subject"""
+    d = np.asarray(sphere_xyz, dtype=np.float64)
+    d = d / np.linalg.norm(d, axis=1, keepdims=True)
+    r = base + 6.0 * smooth_feature(d * RAD, 0, seed) + 3.0 * smooth_feature(d * RAD, 1, seed + 1) + 1.5 * smooth_feature(d * RAD, 2, seed + 2)
+    return d * r[:, None]

@@ -60,6 +60,12 @@ void orc_icosphere_counts(int order, int *V, int *T);
 int  orc_icosphere(int order, int literal_search, double *xyz, int *tri);
 /* true_rescale (R/mesh.cpp:1210) */
 void orc_true_rescale(double *xyz, int V, double rad);
+/* Mesh_registration::resample_anatomy (M/mesh_registration.cpp:250-332) without its surface_resample call: the control grid (AoS) retessellated `levels`
+ * times with the face neighbourhoods kept and merged as the reference merges them, rescaled to rad; _ANATbaryweights and NEARESTFACES as CSR.
+ * axyz 3 x Va (AoS), atri 3 x Ta, w_ptr Va + 1, w_cp / w_val 3 x Va, face_ptr Tc + 1, face_idx Ta (sizes: orc_resample_anatomy_sizes). */
+void orc_resample_anatomy_sizes(int N, int Tc, int levels, int *Va, int *Ta);
+int  orc_resample_anatomy_grid(const double *cp_xyz, int N, const int *cp_tri, int Tc, int levels, double rad, int literal_search, double *axyz, int *atri,
+                               int *w_ptr, int *w_cp, double *w_val, int *face_ptr, int *face_idx);
 
 typedef struct orc_mesh orc_mesh;
 /* builds adjacency in Mesh::push_triangle order and caches triangle areas from the given coords */

@@ -111,6 +111,41 @@ def icosphere(order, radius=100.0, literal=False):
     return xyz, tri
 
 
+def resample_anatomy_grid(cp_xyz, cp_tri, levels, rad=100.0, literal=False):
+    """Mesh_registration::resample_anatomy (M/mesh_registration.cpp:250-332) without its surface_resample call: dict(sphere_xyz, sphere_tri, w_ptr, w_cp,
+    w_val, face_ptr, face_idx) -- ANAT_ico, _ANATbaryweights and NEARESTFACES (CSR) as the reference builds them."""
+    x, px = _d(cp_xyz)
+    t, pt = _i(cp_tri)
+    va, ta = C.c_int(), C.c_int()
+    lib().orc_resample_anatomy_sizes(len(x), len(t), int(levels), C.byref(va), C.byref(ta))
+    Va, Ta = va.value, ta.value
+    axyz, atri = np.zeros((Va, 3)), np.zeros((Ta, 3), dtype=np.int32)
+    w_ptr, w_cp, w_val = np.zeros(Va + 1, dtype=np.int32), np.zeros(3 * Va, dtype=np.int32), np.zeros(3 * Va)
+    face_ptr, face_idx = np.zeros(len(t) + 1, dtype=np.int32), np.zeros(Ta, dtype=np.int32)
+    st = lib().orc_resample_anatomy_grid(px, len(x), pt, len(t), int(levels), C.c_double(rad), int(literal), axyz.ctypes.data_as(c_dp), atri.ctypes.data_as(c_ip),
+                                         w_ptr.ctypes.data_as(c_ip), w_cp.ctypes.data_as(c_ip), w_val.ctypes.data_as(c_dp), face_ptr.ctypes.data_as(c_ip),
+                                         face_idx.ctypes.data_as(c_ip))
+    if st:
+        raise RuntimeError("orc_resample_anatomy_grid failed")
+    n = int(w_ptr[-1])
+    return dict(sphere_xyz=axyz, sphere_tri=atri, w_ptr=w_ptr, w_cp=w_cp[:n].copy(), w_val=w_val[:n].copy(), face_ptr=face_ptr, face_idx=face_idx)
+
+
+def surface_resample(anat_xyz, sph_tree, q_xyz):
+    """newresampler::surface_resample / project_anatomical_mesh (R/resampler.cpp:284-302, :260-282): get_barycentric_weights of the points q in the sphere
+    the anatomy lives on (its octree: sph_tree), then newPt += anat(id) * w in std::map order (ascending vertex id) from Point() = 0."""
+    st, _, vid, w = sph_tree.barycentric_weights(q_xyz)
+    if np.any(st != 0):
+        raise RuntimeError("octree query failed")
+    anat = np.asarray(anat_xyz, dtype=np.float64)
+    key = np.argsort(vid, axis=1, kind="stable")
+    vid, w = np.take_along_axis(vid, key, axis=1), np.take_along_axis(w, key, axis=1)
+    out = np.zeros((len(vid), 3))
+    for k in range(3):
+        out = out + anat[vid[:, k]] * w[:, k][:, None]
+    return out
+
+
 class Mesh:
     def __init__(self, xyz, tri):
         self.xyz, px = _d(xyz)

@@ -131,6 +131,154 @@ void orc_true_rescale(double *xyz, int V, double rad) {
     }
 }
 
+/* ------------------------------------------------------------------ resample_anatomy (aMSM, --regoption=5) */
+
+/* a growing list of ints with std::vector's insert-at-the-front, as M/mesh_registration.cpp:277-279 uses it */
+typedef struct {
+    int *v;
+    int n, cap;
+} int_list;
+static void list_reserve(int_list *l, int want) {
+    if (want <= l->cap) return;
+    while (l->cap < want) l->cap = l->cap ? 2 * l->cap : 8;
+    l->v = (int *)realloc(l->v, sizeof(int) * (size_t)l->cap);
+}
+static void list_push_back(int_list *l, int x) {
+    list_reserve(l, l->n + 1);
+    l->v[l->n++] = x;
+}
+static void list_insert_front(int_list *l, const int *src, int count) { /* vector::insert(begin(), first, last) */
+    list_reserve(l, l->n + count);
+    memmove(l->v + count, l->v, sizeof(int) * (size_t)l->n);
+    memcpy(l->v, src, sizeof(int) * (size_t)count);
+    l->n += count;
+}
+static void list_assign(int_list *dst, const int_list *src) {
+    dst->n = 0;
+    list_reserve(dst, src->n);
+    memcpy(dst->v, src->v, sizeof(int) * (size_t)src->n);
+    dst->n = src->n;
+}
+
+/*
+ * Mesh_registration::resample_anatomy, M/mesh_registration.cpp:250-332 (without its surface_resample call :323), statement by statement:
+ * ANAT_ico = control_grid; `levels` x retessellate(ANAT_ico, FACE_neighbours_tmp) -- R/mesh.cpp:1007-1109: old_tr_nbours[t] = the four children of t in
+ * the order they are numbered --; from the second pass on the lists are merged by inserting the children of every entry at the FRONT (:268-283);
+ * true_rescale (:299); baryweights[id] = calc_barycentric_weights(...) in the loop order of :303-321 (a later assignment replaces the map).
+ * Sizes: Va = N + (vertices added), Ta = Tc * 4^levels; the caller allocates from orc_resample_anatomy_sizes.  literal: the O(V^2) duplicate search.
+ */
+void orc_resample_anatomy_sizes(int N, int Tc, int levels, int *Va, int *Ta) {
+    long v = N, t = Tc;
+    for (int i = 0; i < levels; ++i) {
+        v += 3 * t / 2;
+        t *= 4;
+    }
+    *Va = (int)v;
+    *Ta = (int)t;
+}
+int orc_resample_anatomy_grid(const double *cp_xyz, int N, const int *cp_tri, int Tc, int levels, double rad, int literal, double *axyz, int *atri, int *w_ptr,
+                              int *w_cp, double *w_val, int *face_ptr, int *face_idx) {
+    int V = N, T = Tc;
+    memcpy(axyz, cp_xyz, sizeof(double) * 3 * (size_t)N);
+    memcpy(atri, cp_tri, sizeof(int) * 3 * (size_t)Tc);
+    int_list *nb = (int_list *)calloc((size_t)Tc, sizeof(int_list));   /* ANAT_to_CPgrid_neighbours */
+    int_list *fn = (int_list *)calloc((size_t)Tc, sizeof(int_list));   /* FACE_neighbours */
+    if (levels > 0) {
+        for (int i = 0; i < levels; ++i) {
+            const int oldT = T;
+            retessellate(axyz, &V, atri, &T, literal);
+            /* FACE_neighbours_tmp[t] = {4t, 4t+1, 4t+2, 4t+3}: tot_triangles counts up through the old triangles in order (R/mesh.cpp:1083-1094) */
+            if (i > 0) {
+                for (int j = 0; j < Tc; ++j) {
+                    nb[j].n = 0; /* ANAT_to_CPgrid_neighbours.clear(); push_back(tmp) */
+                    for (int k = 0; k < fn[j].n; ++k) {
+                        const int f = fn[j].v[k];
+                        if (f < 0 || f >= oldT) return -1;
+                        const int kids[4] = {4 * f, 4 * f + 1, 4 * f + 2, 4 * f + 3};
+                        list_insert_front(&nb[j], kids, 4);
+                    }
+                }
+                for (int j = 0; j < Tc; ++j) list_assign(&fn[j], &nb[j]);
+            } else {
+                for (int j = 0; j < Tc; ++j) {
+                    fn[j].n = 0;
+                    for (int c = 0; c < 4; ++c) list_push_back(&fn[j], 4 * j + c);
+                }
+            }
+        }
+        for (int j = 0; j < Tc; ++j)
+            if (nb[j].n == 0) list_assign(&nb[j], &fn[j]); /* one increase in resolution: the result of the retessellation directly (:284-286) */
+    } else {
+        for (int i = 0; i < Tc; ++i) list_push_back(&nb[i], i);
+    }
+    orc_true_rescale(axyz, V, rad);
+    /* baryweights: std::map<int,double> per vertex, here three (id, weight) slots kept sorted by id */
+    int *cnt = (int *)calloc((size_t)V, sizeof(int));
+    int *ids = (int *)malloc(sizeof(int) * 3 * (size_t)V);
+    double *ws = (double *)malloc(sizeof(double) * 3 * (size_t)V);
+    for (int i = 0; i < Tc; ++i) {
+        const int id[3] = {cp_tri[3 * i], cp_tri[3 * i + 1], cp_tri[3 * i + 2]};
+        const double *v0 = &cp_xyz[3 * id[0]], *v1 = &cp_xyz[3 * id[1]], *v2 = &cp_xyz[3 * id[2]];
+        for (int jj = 0; jj < nb[i].n; ++jj) {
+            const int j = nb[i].v[jj];
+            for (int k = 0; k < 3; ++k) {
+                const int a = atri[3 * j + k];
+                double w[3];
+                orc_calc_barycentric_weights(v0, v1, v2, &axyz[3 * a], w);
+                /* weights[n1] = ..; weights[n2] = ..; weights[n3] = ..  into a fresh map */
+                int n = 0, mid[3];
+                double mw[3];
+                for (int q = 0; q < 3; ++q) {
+                    int at = -1;
+                    for (int r = 0; r < n; ++r)
+                        if (mid[r] == id[q]) at = r;
+                    if (at >= 0) {
+                        mw[at] = w[q];
+                        continue;
+                    }
+                    int pos = n;
+                    while (pos > 0 && mid[pos - 1] > id[q]) {
+                        mid[pos] = mid[pos - 1];
+                        mw[pos] = mw[pos - 1];
+                        --pos;
+                    }
+                    mid[pos] = id[q];
+                    mw[pos] = w[q];
+                    ++n;
+                }
+                cnt[a] = n;
+                for (int r = 0; r < n; ++r) {
+                    ids[3 * a + r] = mid[r];
+                    ws[3 * a + r] = mw[r];
+                }
+            }
+        }
+    }
+    w_ptr[0] = 0;
+    for (int a = 0; a < V; ++a) {
+        for (int r = 0; r < cnt[a]; ++r) {
+            w_cp[w_ptr[a] + r] = ids[3 * a + r];
+            w_val[w_ptr[a] + r] = ws[3 * a + r];
+        }
+        w_ptr[a + 1] = w_ptr[a] + cnt[a];
+    }
+    face_ptr[0] = 0;
+    for (int i = 0; i < Tc; ++i) {
+        memcpy(face_idx + face_ptr[i], nb[i].v, sizeof(int) * (size_t)nb[i].n);
+        face_ptr[i + 1] = face_ptr[i] + nb[i].n;
+    }
+    for (int j = 0; j < Tc; ++j) {
+        free(nb[j].v);
+        free(fn[j].v);
+    }
+    free(nb);
+    free(fn);
+    free(cnt);
+    free(ids);
+    free(ws);
+    return 0;
+}
+
 /* ------------------------------------------------------------------ mesh */
 
 static int has_nbr(const int *list, int n, int v) {

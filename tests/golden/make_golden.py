@@ -61,9 +61,9 @@ def main():
 
 def anatomy_case():
     """Inputs of the anatomical-strain vectors (shared with tests/test_golden.py)."""
-    from tests.helpers import oracle_anatomy
+    from tests.helpers import oracle_anatomy_by_queries
 
-    cxyz, ctri, axyz, atri, w_ptr, w_cp, w_val, face_ptr, face_idx = oracle_anatomy(2, 4)
+    cxyz, ctri, axyz, atri, w_ptr, w_cp, w_val, face_ptr, face_idx = oracle_anatomy_by_queries(2, 4)
     rs = 60.0 + 6.0 * synthetic.smooth_feature(axyz, 0, 99) + 3.0 * synthetic.smooth_feature(axyz, 1, 99)
     rt = 62.0 + 5.0 * synthetic.smooth_feature(axyz, 2, 100) + 4.0 * synthetic.smooth_feature(axyz, 0, 101)
     d = axyz / synthetic.RAD

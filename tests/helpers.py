@@ -33,8 +33,16 @@ def ulp_close(a, b, rtol=1e-11, atol=1e-12):
 
 
 def oracle_anatomy(cp_order=2, anat_order=4):
-    """Anatomical-regulariser inputs (control grid, anatomical sphere, _ANATbaryweights, NEARESTFACES) built with the oracle
-    only, shaped like Mesh_registration::resample_anatomy (M/mesh_registration.cpp:250-332) prepares them."""
+    """Anatomical-regulariser inputs (control grid, anatomical sphere, _ANATbaryweights, NEARESTFACES) built with the oracle only, as
+    Mesh_registration::resample_anatomy (M/mesh_registration.cpp:250-332) prepares them (O.resample_anatomy_grid)."""
+    cxyz, ctri = O.icosphere(cp_order)
+    g = O.resample_anatomy_grid(cxyz, ctri, anat_order - cp_order)
+    return cxyz, ctri, g["sphere_xyz"], g["sphere_tri"], g["w_ptr"], g["w_cp"], g["w_val"], g["face_ptr"], g["face_idx"]
+
+
+def oracle_anatomy_by_queries(cp_order=2, anat_order=4):
+    """The shape of the same inputs from octree queries instead of the retessellation bookkeeping (NEARESTFACES by face centroid, weights by a search of
+    every vertex): what the committed golden vectors of the anatomical strain (tests/golden/oracle_more.npz, g8_*) were generated from in round 1."""
     cxyz, ctri = O.icosphere(cp_order)
     axyz, atri = O.icosphere(anat_order)
     cp = O.Mesh(cxyz, ctri)
@@ -52,8 +60,6 @@ def oracle_anatomy(cp_order=2, anat_order=4):
     w_val = np.take_along_axis(w, key, axis=1).ravel()
     w_ptr = (3 * np.arange(len(axyz) + 1)).astype(np.int32)
     return cxyz, ctri, axyz, atri, w_ptr, w_cp, w_val, face_ptr, face_idx
-
-
 
 
 ORACLE_THREADS = int(os.environ.get("MSM_ORACLE_THREADS", "8"))  # OpenMP threads of the oracle's table / octet evaluations
@@ -101,6 +107,12 @@ class OracleOps:
 
     def nearest_neighbour(self, mesh, data, q_xyz):
         return O.nearest_neighbour(mesh, data, q_xyz)
+
+    def resample_anatomy_grid(self, cp_xyz, cp_tri, levels):
+        return O.resample_anatomy_grid(cp_xyz, cp_tri, levels, 100.0)
+
+    def surface_resample(self, anat_xyz, sphere_mesh, q_xyz):
+        return O.surface_resample(anat_xyz, O.Octree(sphere_mesh), q_xyz)
 
     def cp_spacings(self, mesh, xyz, tri):
         return O.cp_spacings(mesh)
@@ -218,6 +230,10 @@ class _OracleCost:
     def set_pairs(self, pairs):
         self.c.set_pairs(pairs)
         self.c.set_triplets(np.zeros((0, 3), dtype=np.int32))
+
+    def set_anatomical(self, sphere_mesh, atarget_xyz, asource_xyz, grid):
+        self.keep = (sphere_mesh, O.Octree(sphere_mesh), O.Mesh(asource_xyz, grid["sphere_tri"]))
+        self.c.set_anatomical(self.keep[0], self.keep[1], atarget_xyz, self.keep[2], grid["w_ptr"], grid["w_cp"], grid["w_val"], grid["face_ptr"], grid["face_idx"])
 
     def pairwise_table(self):
         return self.c.pairwise_table()

@@ -125,5 +125,12 @@ def test_what_the_path_does_not_cover_is_reported():
 
 def test_every_shipped_preset_parses():
     for name in config.PRESETS:
-        levels, run_kw, skipped = config.preset_levels(name, 1)
+        levels, run_kw, skipped = config.preset_levels(name, 1, anat=name.startswith("aMSM"))
         assert len(levels) == 3 and len(skipped) == (1 if name.startswith("standard") else 0)
+    # the aMSM preset (config/NeuroImage2017_configs/aMSM_STR_longitudinal_alignment): --regoption=5 with --anatgrid=4,5,6, refused without the surfaces
+    levels, _, _ = config.preset_levels("aMSM_STR", 1, anat=True)
+    assert [lv["rmode"] for lv in levels] == [5, 5, 5] and [lv["anat_order"] for lv in levels] == [4, 5, 6] and levels[0]["kind"] == "ho_univariate"
+    with pytest.raises(config.ConfigError, match="requires anatomical meshes"):
+        config.preset_levels("aMSM_STR", 1)
+    with pytest.raises(config.ConfigError, match="regoption 4 has been removed"):
+        config.levels_from_config(config.parse_config("--opt=DISCRETE\n--lambda=0.1\n--dopt=HOCR\n--regoption=4\n"), 1, anat=True)

@@ -24,10 +24,10 @@ def exe():
     return EXE
 
 
-def run(exe, tmp_path, text, D):
+def run(exe, tmp_path, text, D, anat=False):
     path = tmp_path / "conf"
     path.write_text(text)
-    out = subprocess.run([exe, str(path), str(D)], capture_output=True, text=True, timeout=60)
+    out = subprocess.run([exe, str(path), str(D)] + (["anat"] if anat else []), capture_output=True, text=True, timeout=60)
     assert out.returncode == 0, out.stderr
     return json.loads(out.stdout.strip().splitlines()[-1])
 
@@ -40,8 +40,9 @@ EXTRA = ["--opt=DISCRETE,DISCRETE\n--lambda=0.1,0.2\n--regoption=3\n--sigma_in=3
 @pytest.mark.parametrize("text", list(config.PRESETS.values()) + EXTRA)
 @pytest.mark.parametrize("D", [1, 32])
 def test_cpp_parser_gives_the_python_schedule(exe, tmp_path, text, D):
-    got = run(exe, tmp_path, text, D)
-    levels, run_kw, skipped = config.levels_from_config(config.parse_config(text), D)
+    anat = "--regoption=5" in text   # the aMSM preset: the caller says it has the anatomical surfaces
+    got = run(exe, tmp_path, text, D, anat)
+    levels, run_kw, skipped = config.levels_from_config(config.parse_config(text), D, anat=anat)
     assert got["varnorm"] == run_kw["varnorm"] and [tuple(s) for s in got["skipped"]] == skipped and len(got["levels"]) == len(levels)
     for g, w in zip(got["levels"], levels):
         flat = dict(w, **w["cost_params"])

@@ -322,11 +322,14 @@ MULTIRES_CONFIGS = {
     "fusion": "--opt=DISCRETE,DISCRETE\n--simval=2,2\n--sigma_in=2,1\n--sigma_ref=2,1\n--lambda=0.1,0.1\n--it=2,2\n--CPgrid=1,2\n--SGgrid=3,4\n--datagrid=3,4\n--dopt=HOCR\n--regoption=3\n--VN\n",
     "triclique": "--opt=DISCRETE,DISCRETE\n--simval=2,2\n--sigma_in=0,0\n--sigma_ref=0,0\n--lambda=0.01,0.02\n--it=2,2\n--CPgrid=1,2\n--SGgrid=3,4\n--datagrid=3,4\n--dopt=HOCR\n--regoption=3\n"
                  "--triclique\n--rescaleL\n--shearmod=0.4\n--bulkmod=1.6\n--k_exponent=2\n--regexp=2\n",
+    # --regoption=5 (aMSM): resample_anatomy per level (M/mesh_registration.cpp:250-332), the anatomical strain in every fusion move
+    "amsm": "--opt=DISCRETE,DISCRETE\n--simval=2,2\n--sigma_in=2,1\n--sigma_ref=2,1\n--lambda=0.025,0.025\n--it=2,1\n--CPgrid=1,2\n--SGgrid=3,4\n--datagrid=3,4\n--anatgrid=3,4\n"
+            "--dopt=HOCR\n--regoption=5\n--regexp=2\n--VN\n--rescaleL\n--triclique\n--k_exponent=2\n--bulkmod=1.6\n--shearmod=0.4\n",
 }
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name,D", [("fusion", 1), ("triclique", 4)])
+@pytest.mark.parametrize("name,D", [("fusion", 1), ("triclique", 4), ("amsm", 1)])
 def test_cpp_run_multiresolutions_equals_python_loop(built, ctx, tmp_path, name, D):
     """tools/cpp/registration_bench -- msmhip::run_multiresolutions with its schedule from msmhip_config.hpp, what bench.py's registration_*_cpp
     objects run -- against newmsm_amd/registration.py: run_multiresolution over config.py's reading of the same text: identical labelings in
@@ -340,7 +343,10 @@ def test_cpp_run_multiresolutions_equals_python_loop(built, ctx, tmp_path, name,
     ref = synthetic.features(xyz, D, 7)
     src = synthetic.features(synthetic.known_warp(xyz, seed=9, rot_deg=3.0, amp=2.0), D, 7)
     fin, fout, conf = str(tmp_path / "in.bag"), str(tmp_path / "out.bag"), str(tmp_path / "conf")
-    write_bag(fin, orders=np.array([4, D], dtype=np.int32), in_data=src, ref_data=ref)
+    anat = {}
+    if name == "amsm":
+        anat = dict(in_anat=synthetic.anatomy(xyz, seed=61, base=60.0), ref_anat=synthetic.anatomy(xyz, seed=71, base=62.0))
+    write_bag(fin, orders=np.array([4, D], dtype=np.int32), in_data=src, ref_data=ref, **anat)
     with open(conf, "w") as f:
         f.write(MULTIRES_CONFIGS[name])
     run = subprocess.run([exe, fin, fout, conf, "1"], capture_output=True, text=True, timeout=600)
@@ -349,10 +355,10 @@ def test_cpp_run_multiresolutions_equals_python_loop(built, ctx, tmp_path, name,
 
     line = json.loads(run.stdout.strip().splitlines()[-1])
     got = read_bag(fout)
-    levels, run_kw, skipped = config.levels_from_config(config.parse_config(MULTIRES_CONFIGS[name]), D)
+    levels, run_kw, skipped = config.levels_from_config(config.parse_config(MULTIRES_CONFIGS[name]), D, anat=bool(anat))
     labs = []
-    sphere, regs, energies = registration.run_multiresolution(registration.ProductOps(ctx), xyz, tri, src, xyz, tri, ref, levels, labelings_out=labs, **run_kw)
-    assert line["levels"] == 2 and len(labs) == 4 and list(got["nodes"]) == [len(l) for l in labs]
+    sphere, regs, energies = registration.run_multiresolution(registration.ProductOps(ctx), xyz, tri, src, xyz, tri, ref, levels, labelings_out=labs, **run_kw, **anat)
+    assert line["levels"] == 2 and len(labs) == (3 if name == "amsm" else 4) and list(got["nodes"]) == [len(l) for l in labs]
     assert np.array_equal(got["labelings"], np.concatenate(labs))
     assert np.allclose(got["energies"], np.concatenate(energies), rtol=1e-12, atol=0)
     assert np.allclose(got["sphere_reg"].reshape(-1, 3), sphere, rtol=0, atol=1e-10)

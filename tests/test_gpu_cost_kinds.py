@@ -222,7 +222,7 @@ def test_triclique_large_bins(ctx, data_order, cp_order):
 
 
 @pytest.mark.parametrize("data_order,kind,D,least,squeeze", [(5, "ho_multivariate", 9, 1024, 0.0), (6, "ho_univariate", 1, 1500, 0.0), (7, "ho_univariate", 1, 16384, 0.0),
-                                                             (7, "ho_univariate", 1, 32768, 0.55), (6, "ho_multivariate", 3, 16384, 0.75)])
+                                                             (7, "ho_univariate", 1, 32768, 3.0), (6, "ho_multivariate", 3, 16384, 6.0)])
 def test_triclique_bins_beyond_1024_points(ctx, data_order, kind, D, least, squeeze):
     """An ico0 control grid under fine data (tests/fuzz_parity.py found the first case: 1 052 source vertices under one control triangle was
     MSM_ERR_CAPACITY): 64 lanes per evaluation up to 4 096 points, the whole workgroup with an LDS slice up to 16 384, and beyond that (round 4:
@@ -231,10 +231,16 @@ def test_triclique_bins_beyond_1024_points(ctx, data_order, kind, D, least, sque
     Single evaluations and a whole label step."""
     kw = dict(seed=86634, warp_amp=0.3482850938627505, warp_rot=3.350507727100841, labeldist=0.33807290039714544, rescale=False)
     inp = problem.pairwise_inputs(data_order, 0, D=D, **kw)
-    if squeeze > 0.0:  # x -> R (x + squeeze R e) / |x + squeeze R e|: a bijection of the sphere (squeeze < 1) that crowds the vertices towards e
-        e = inp["cp_xyz"][0] / np.linalg.norm(inp["cp_xyz"][0])
-        sx = inp["source_xyz"] + squeeze * 100.0 * e
-        inp["source_xyz"] = sx / np.linalg.norm(sx, axis=1, keepdims=True) * 100.0
+    if squeeze > 0.0:  # the polar angle about the middle of a control triangle shrinks, theta -> pi (theta / pi)^squeeze: a bijection of the sphere
+        e = inp["cp_xyz"][inp["cp_tri"][0]].mean(axis=0)   # that crowds most source vertices under that triangle
+        e = e / np.linalg.norm(e)
+        u = inp["source_xyz"] / 100.0
+        c = np.clip(u @ e, -1.0, 1.0)
+        theta = np.arccos(c)
+        tang = u - c[:, None] * e
+        tang = tang / np.maximum(np.linalg.norm(tang, axis=1, keepdims=True), 1e-300)
+        th2 = np.pi * (theta / np.pi) ** squeeze
+        inp["source_xyz"] = 100.0 * (np.cos(th2)[:, None] * e + np.sin(th2)[:, None] * tang)
     cf, oc, _ = pair(ctx, inp, kind, simmeasure=1 if D == 1 else 2, rmode=3, lambda_=0.1)
     ptr, _ = cf.patches()
     assert np.diff(ptr).max() > least, np.diff(ptr).max()

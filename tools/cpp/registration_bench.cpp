@@ -5,7 +5,8 @@
 //
 //   registration_bench <in.bag> <out.bag> <config file> [runs]
 //
-// in.bag  (tests/test_cpp_host.py: write_bag):  orders i4 [sphere order, D], in_data f8 D x V, ref_data f8 D x V, [iters i4: iterations per level]
+// in.bag  (newmsm_amd/bag.py):  orders i4 [sphere order, D], in_data f8 D x V, ref_data f8 D x V, [iters i4: iterations per level],
+//          [in_anat, ref_anat f8 V x 3: the anatomical surfaces of a --regoption=5 (aMSM) configuration]
 // out.bag: sphere_reg f8 3 x V (AoS), labelings i4 (all iterations, level after level), nodes i4 (control points per labeling), energies f8,
 //          move_kernel_ms f8 (one per fusion move of the extra timed run)
 // stdout: one JSON line -- wall_s, path_s (everything but the stand-in solve), phases_s, calls per phase -- of the LAST of `runs` runs (default 2:
@@ -64,7 +65,9 @@ int main(int argc, char **argv) {
         ss << cf.rdbuf();
         bool varnorm = false;
         std::vector<std::pair<int, std::string>> skipped;
-        std::vector<LevelSpec> levels = levels_from_config(parse_config(ss.str()), D, &varnorm, &skipped);
+        const bool anat = F.count("in_anat") && F.count("ref_anat");
+        const Points *in_anat = anat ? &F["in_anat"] : nullptr, *ref_anat = anat ? &F["ref_anat"] : nullptr;
+        std::vector<LevelSpec> levels = levels_from_config(parse_config(ss.str()), D, &varnorm, &skipped, anat);
         if (I.count("iters"))
             for (size_t k = 0; k < levels.size() && k < I["iters"].size(); ++k) levels[k].options.iters = I["iters"][k];
         auto [xyz, tri] = make_mesh_from_icosa(order);
@@ -75,7 +78,7 @@ int main(int argc, char **argv) {
         for (int r = 0; r < runs; ++r) {
             clock = PhaseClock();
             const auto t0 = std::chrono::steady_clock::now();
-            res = run_multiresolutions(ctx, xyz, tri, F.at("in_data"), xyz, tri, F.at("ref_data"), D, levels, varnorm, &clock);
+            res = run_multiresolutions(ctx, xyz, tri, F.at("in_data"), xyz, tri, F.at("ref_data"), D, levels, varnorm, &clock, in_anat, ref_anat);
             wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         }
         // once more with HIP events around every fusion move's kernel (not the run that is reported: an event query per move)
@@ -83,7 +86,7 @@ int main(int argc, char **argv) {
         if (levels[0].options.fusion) {
             std::vector<LevelSpec> timed = levels;
             for (LevelSpec &lv : timed) lv.options.move_kernel_ms = &kernel_ms;
-            const MultiresResult again = run_multiresolutions(ctx, xyz, tri, F.at("in_data"), xyz, tri, F.at("ref_data"), D, timed, varnorm);
+            const MultiresResult again = run_multiresolutions(ctx, xyz, tri, F.at("in_data"), xyz, tri, F.at("ref_data"), D, timed, varnorm, nullptr, in_anat, ref_anat);
             if (again.labelings != res.labelings) throw std::runtime_error("the timed run took different decisions");
         }
         std::ofstream out(argv[2], std::ios::binary);
