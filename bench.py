@@ -152,25 +152,41 @@ def bench_resample(ctx, calls, cpu):
     xyz, tri = M.make_mesh_from_icosa(6)
     warped = synthetic.known_warp(xyz, seed=3, rot_deg=2.0, amp=0.6)
     mesh = M.Mesh(ctx, warped, tri)
-    mesh.query_triangles(xyz)
+    N = len(xyz)
+    st, t_id, vid, w = mesh.query_triangles(xyz)
+    # the call as a C / C++ host makes it: the ABI's own layout (3 x N), arrays in pinned memory of the context (msm_host_alloc) -- the copy engine reads
+    # the queries and writes the three result arrays where they lie: upload, kernel, three downloads, one synchronisation
+    q_soa = ctx.host_array((3, N))
+    q_soa[:] = xyz.T
+    o_tri, o_vid, o_w = ctx.host_array((N,), np.int32), ctx.host_array((3, N), np.int32), ctx.host_array((3, N))
     ctx.time_queries(True)
-    kt, ct = [], []
+    kt, ct, pt = [], [], []
     for _ in range(calls):
         t0 = time.perf_counter()
-        st, t_id, vid, w = mesh.query_triangles(xyz)
+        rc = mesh.query_triangles_soa(q_soa, o_tri, o_vid, o_w)
         ct.append(time.perf_counter() - t0)
         kt.append(ctx.query_kernel_ms() * 1e-3)
+        if rc:
+            raise SystemExit("msm_query_triangles failed: %d" % rc)
+    for _ in range(max(10, calls // 5)):  # the Python wrapper over pageable numpy arrays (transposes, allocations, a staging memcpy each way)
+        t0 = time.perf_counter()
+        mesh.query_triangles(xyz)
+        pt.append(time.perf_counter() - t0)
     ctx.time_queries(False)
-    N = len(xyz)
+    if not (np.array_equal(o_tri, t_id) and np.array_equal(o_vid.T, vid) and np.array_equal(o_w.T, w)):
+        raise SystemExit("the pinned-array call and the wrapper disagree")
     kern_s, call_s = float(np.median(kt)), float(np.median(ct))
     nbytes = 144 * N
     out = {"workload": "get_barycentric_weights: %d queries (regular ico6 vertices) on a warped ico6 mesh (81 920 triangles, fresh octree)" % N,
            "queries_per_s_kernel": N / kern_s, "kernel_us": kern_s * 1e6, "queries_per_s_call": N / call_s, "us_per_call": call_s * 1e6, "calls": calls,
-           "call": "msm_query_triangles with host arrays in and out: upload of the queries, kernel, three result arrays back, one synchronisation",
+           "call": "msm_query_triangles with the four arrays in pinned memory of the context (msm_host_alloc), ABI layout: upload of the queries, kernel, three "
+                   "result arrays back, one synchronisation -- no staging memcpy",
+           "us_per_call_python_wrapper": float(np.median(pt)) * 1e6,
+           "python_wrapper": "Mesh.query_triangles on pageable numpy arrays: (N,3) <-> 3 x N transposes, three allocations and a staging memcpy each way on top",
            "roofline": {"bound": "hbm", "achieved": nbytes / kern_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nbytes / kern_s / 1e9 / HBM_PEAK_GBS,
                         "kernel": "msm::k_query<%d>" % ctx.query_lanes(N), "algorithmic_bytes_per_launch": nbytes,
                         "note": "kernel time = HIP events around the launch on its stream; a launch of this size (2 561 wavefronts) is a dependent chain of "
-                                "six memory accesses per query (query, grid cell, node, cones, triangle id, record), not a stream: see DESIGN.md section 5.1"}}
+                                "memory accesses per query (query, grid cell, node, cones, triangle id, record), not a stream: see DESIGN.md section 5.1"}}
     if cpu:
         from oracle import oracle as O
 

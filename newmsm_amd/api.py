@@ -307,6 +307,15 @@ class Mesh:
         return dict(nodes=s[0], leaves=s[1], depth=s[2], refs=s[3], max_leaf=s[4]), sig.value
 
     # Octree::get_closest_triangle + get_barycentric_weights
+    def query_triangles_soa(self, q_soa, tri, vid, w, mode=WEIGHTS_PROJECTED):
+        """msm_query_triangles on the ABI's own layout, no transposes and no allocation: q_soa 3 x N float64, tri N int32, vid 3 x N int32, w 3 x N
+        float64 (C-contiguous).  Arrays from Context.host_array (pinned, mapped) are read and written by the copy engine directly -- the call is the
+        upload, the kernel, three downloads and one synchronisation.  Returns the status."""
+        N = q_soa.shape[1]
+        assert q_soa.flags.c_contiguous and tri.flags.c_contiguous and vid.flags.c_contiguous and w.flags.c_contiguous and q_soa.dtype == np.float64
+        assert tri.shape == (N,) and vid.shape == (3, N) and w.shape == (3, N) and tri.dtype == np.int32 and vid.dtype == np.int32 and w.dtype == np.float64
+        return lib().msm_query_triangles(self.h, q_soa.ctypes.data_as(c_dp), N, tri.ctypes.data_as(c_ip), vid.ctypes.data_as(c_ip), w.ctypes.data_as(c_dp), mode)
+
     def query_triangles(self, q, mode=WEIGHTS_PROJECTED, check_status=True):
         x, px = _soa(q)
         N = x.shape[1]
@@ -338,10 +347,13 @@ def get_adaptive_barycentric_weights(in_mesh, new_mesh, excl=None):
     return rp, col, val
 
 
-def metric_resample(in_mesh, data, new_mesh, excl=None):
-    """metric_resample (R/resampler.cpp:304-309); with excl (the EXCL mesh's values on in_mesh) returns (data, resampled mask)."""
+def metric_resample(in_mesh, data, new_mesh, excl=None, out=None):
+    """metric_resample (R/resampler.cpp:304-309); with excl (the EXCL mesh's values on in_mesh) returns (data, resampled mask).  out (optional): the
+    D x V(new) result array -- one from Context.host_array is written by the copy engine directly (no staging memcpy)."""
     d, pd = _d(np.atleast_2d(data))
-    out = np.zeros((d.shape[0], new_mesh.V))
+    if out is None:
+        out = np.zeros((d.shape[0], new_mesh.V))
+    assert out.shape == (d.shape[0], new_mesh.V) and out.flags.c_contiguous and out.dtype == np.float64
     if excl is None:
         check(lib().msm_metric_resample(in_mesh.h, pd, d.shape[0], new_mesh.h, None, out.ctypes.data_as(c_dp), None))
         return out

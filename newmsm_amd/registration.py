@@ -52,8 +52,29 @@ class ProductOps:
         api.sphere_project_warp_mesh(mesh, from_mesh, to_xyz)
 
     # --- featurespace::initialise
-    def metric_resample(self, in_mesh, data, new_mesh):
-        return api.metric_resample(in_mesh, data, new_mesh)
+    def metric_resample(self, in_mesh, data, new_mesh, slot=None):
+        """slot (optional): a name under which the result may live in a pinned buffer of the context that the NEXT call with the same name reuses
+        (the copy engine writes it directly: no staging memcpy of the D x V matrix); None: a fresh numpy array"""
+        if slot is None:
+            return api.metric_resample(in_mesh, data, new_mesh)
+        out = self.ctx.scratch_host_array("metric_resample:" + slot, (np.atleast_2d(data).shape[0], new_mesh.V))
+        return api.metric_resample(in_mesh, data, new_mesh, out=out)
+
+    def pin(self, array):
+        """page-lock a large input matrix for the length of a run (msm_host_register): its uploads then skip the staging block.  Returns a token for
+        unpin, or None when the array cannot be pinned (not C-contiguous float64, or the driver refuses)."""
+        a = np.asarray(array)
+        if a.dtype != np.float64 or not a.flags.c_contiguous or a.nbytes < (1 << 20):
+            return None
+        try:
+            self.ctx.register_host(a.ctypes.data, a.nbytes)
+        except api.MsmError:
+            return None
+        return (a.ctypes.data, a)  # the array stays alive with the token
+
+    def unpin(self, token):
+        if token is not None:
+            self.ctx.unregister_host(token[0])
 
     def smooth_data(self, mesh, data, sigma):
         return api.smooth_data(mesh, data, mesh, sigma)
@@ -356,12 +377,27 @@ def run_multiresolution(ops, in_xyz, in_tri, in_data, ref_xyz, ref_tri, ref_data
     in_xyz = np.asarray(in_xyz, dtype=np.float64)
     in_mesh, ref_mesh = ops.mesh(in_xyz, in_tri), ops.mesh(ref_xyz, ref_tri)
     sph_reg_prev, prev_order, regs, all_energies = None, None, [], []
+    # the two data matrices go up once per level: page-locked for the run, their uploads skip the staging block (ProductOps.pin; a no-op elsewhere)
+    pins = [ops.pin(d) for d in (in_data, ref_data)] if hasattr(ops, "pin") else []
+    try:
+        return _run_levels(ops, clock, timed, in_xyz, in_mesh, ref_mesh, in_data, ref_data, levels, varnorm, in_cfweight, ref_cfweight, labelings_out, in_anat,
+                           ref_anat, ref_xyz, level_kw, sph_reg_prev, prev_order, regs, all_energies)
+    finally:
+        for t in pins:
+            ops.unpin(t)
+
+
+def _run_levels(ops, clock, timed, in_xyz, in_mesh, ref_mesh, in_data, ref_data, levels, varnorm, in_cfweight, ref_cfweight, labelings_out, in_anat, ref_anat,
+                ref_xyz, level_kw, sph_reg_prev, prev_order, regs, all_energies):
+    """the level loop of run_multiresolution (see there)"""
     for lv in levels:
         ico_xyz, ico_tri = ops.icosphere(lv["data_order"])
         ico = ops.mesh(ico_xyz, ico_tri)
         feats = []
-        for mesh, data, sigma in ((in_mesh, in_data, lv.get("sigma_in", 0.0)), (ref_mesh, ref_data, lv.get("sigma_ref", 0.0))):
-            f = timed("metric_resample", ops.metric_resample, mesh, data, ico)
+        for mesh, data, sigma, slot in ((in_mesh, in_data, lv.get("sigma_in", 0.0), "in"), (ref_mesh, ref_data, lv.get("sigma_ref", 0.0), "ref")):
+            # (a level's matrices are consumed -- uploaded by the cost function and the target mesh -- before the next level asks for its own: the
+            # result slots are reused from level to level)
+            f = timed("metric_resample", ops.metric_resample, mesh, data, ico, slot)
             if sigma > 0.0:
                 f = timed("smooth_data", ops.smooth_data, ico, f, sigma)
             if varnorm:

@@ -96,7 +96,7 @@ class OracleOps:
     def warp_mesh(self, mesh, from_mesh, to_xyz):
         mesh.set_coords(O.sphere_project_warp(np.array(mesh.xyz), from_mesh, to_xyz))
 
-    def metric_resample(self, in_mesh, data, new_mesh):
+    def metric_resample(self, in_mesh, data, new_mesh, slot=None):
         return O.metric_resample(in_mesh, data, new_mesh)
 
     def smooth_data(self, mesh, data, sigma):

@@ -60,6 +60,40 @@ def test_query_bit_exact_warped_sphere(ctx):
     assert np.array_equal(t, ot) and np.array_equal(vid, ovid) and np.array_equal(w, ow)
 
 
+def test_query_into_pinned_arrays_of_the_caller(ctx):
+    """msm_query_triangles with its four arrays in pinned blocks of the context (msm_host_alloc): read and written by the copy engine where they lie
+    (no staging memcpy) -- the same bits as through the staging block, also when only some of the arrays are pinned, and the resampled matrix of
+    msm_metric_resample written into a pinned array of the caller"""
+    xyz, tri = M.make_mesh_from_icosa(5)
+    wxyz = synthetic.known_warp(xyz, seed=11, rot_deg=4.0, amp=1.5)
+    mesh = M.Mesh(ctx, wxyz, tri)
+    q = queries(xyz, 20000, seed=9)
+    st, t, vid, w = mesh.query_triangles(q)
+    N = len(q)
+    q_soa = ctx.host_array((3, N))
+    q_soa[:] = q.T
+    o_t, o_v, o_w = ctx.host_array((N,), np.int32), ctx.host_array((3, N), np.int32), ctx.host_array((3, N))
+    o_t[:], o_v[:], o_w[:] = -5, -5, -5.0
+    assert mesh.query_triangles_soa(q_soa, o_t, o_v, o_w) == 0
+    assert np.array_equal(o_t, t) and np.array_equal(o_v.T, vid) and np.array_equal(o_w.T, w)
+    # mixed: pageable queries and weights, pinned ids
+    p_w = np.full((3, N), -5.0)
+    o_t[:], o_v[:] = -5, -5
+    assert mesh.query_triangles_soa(np.ascontiguousarray(q.T), o_t, o_v, p_w) == 0
+    assert np.array_equal(o_t, t) and np.array_equal(o_v.T, vid) and np.array_equal(p_w.T, w)
+    # metric_resample: pinned data in, pinned result out
+    coarse = M.Mesh(ctx, *M.make_mesh_from_icosa(4))
+    data = synthetic.features(xyz, 3, 4)
+    want = M.metric_resample(mesh, data, coarse)
+    pin_in, pin_out = ctx.host_array(data.shape), ctx.host_array((3, coarse.V))
+    pin_in[:] = data
+    pin_out[:] = -7.0
+    got = M.metric_resample(mesh, pin_in, coarse, out=pin_out)
+    assert got is pin_out and np.array_equal(got, want)
+    for arr in (q_soa, o_t, o_v, o_w, pin_in, pin_out):
+        ctx.release_host_array(arr)
+
+
 def test_query_folded_mesh_uses_reference_tie_breaks(ctx):
     # strong high-frequency warp: folds and slivers -> several triangles pass the inside test, fallbacks fire
     xyz, tri = M.make_mesh_from_icosa(4)
