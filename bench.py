@@ -432,7 +432,19 @@ def bench_gmsm(ctx, S, comm, label_steps=6, change=0.10):
                         "note": "a step's GPU time (HIP events around its kernels on the launch stream) also holds the strain triplets and the kept-cost copies.  "
                                 "An upper bound on what instruction issue explains, not the binding limit: rewrites that cut the instructions by up to a third left the "
                                 "step where it was, a quarter wavefront per pair cost (more dependent chains in flight) took it from 12.5 to 9.3 ms (DESIGN.md 5.6)"}
+    # the set-up against the HBM roofline in SURVEY 8(d)'s units: get_patch_data is L adaptive-barycentric resamples per subject = (V + Vt) nearest-triangle
+    # queries of 144 B each (forward and reverse weights) + the D x Vt resampled values written, per (subject, label)
+    last = levels[-1]
+    V6 = 10 * 4 ** last["data_order"] + 2
+    setup_bytes = S * 19 * ((V6 + V6) * 144 + 2 * V6 * 8)
+    setup_roofline = {"bound": "hbm", "achieved": setup_bytes / last["setup_s"] / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": setup_bytes / last["setup_s"] / 1e9 / HBM_PEAK_GBS,
+                      "algorithmic_bytes": setup_bytes, "level": "ico%d / ico%d" % (last["data_order"], last["cp_order"]),
+                      "definition": "S x L x ((V + Vt) queries x 144 B + D x Vt x 8 B of resampled features): the resampling a subject's set-up is made of, SURVEY 8(d) units; "
+                                    "the 19 search trees per subject (the larger half of the GPU time, DESIGN 5.6), the weight-list surgery and the patch lists have no unit there",
+                      "note": "nominal and small by construction: a subject's set-up is ~100 dependent launches over tens of MB that live in L2; the GPU is busy (two set-up "
+                              "pipelines side by side gain 8 %), not the memory system"}
     out = {"subjects": S, "levels": levels, "iterations_per_level": GMSM_ITERATIONS, "path_s_per_group": total, "subjects_per_hour": S / total * 3600.0,
+           "setup_roofline": setup_roofline,
            "config": {"label_change_fraction": change, "label_steps_timed": label_steps,
                       "model": "between label steps that fraction of the nodes changes its label (the library keeps the (current, current) costs of untouched pairs); half of the "
                                "timed steps are second visits of their label, as in the two sweeps of an iteration (I/Fusion/Fusion.h:136-138)"}}
