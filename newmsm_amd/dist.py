@@ -205,7 +205,8 @@ def sharded_group_setup(group, n_subjects, comm=None, chunks=None):
 
     L, D, V, M = group.L, group.D, group._keep["template"].V, group.N * group.L + 1
     nmax = max(len(shard(n_subjects, r, c.world)) for r in range(c.world))
-    if not c.on_gpu:  # also with ONE rank in a process group: the same collectives run
+    device_path = hasattr(group, "export_subjects_dev") and torch.cuda.is_available()
+    if not device_path:  # host tensors through the host entry points (CPU tests with a stand-in group)
         group.setup_subjects(mine)
         counts = torch.zeros(nmax, dtype=torch.int64)
         if mine:
@@ -237,6 +238,9 @@ def sharded_group_setup(group, n_subjects, comm=None, chunks=None):
         group.finalize()
         return mine
 
+    # device buffers that libmsmhip fills and reads; with gloo (the rehearsal of the N > 1 path on a one-GPU box) the collectives themselves go
+    # through host copies of them, everything else -- pieces, batched export / import, range checks -- is the nccl path
+    dev = c.device if c.on_gpu else "cuda:%d" % torch.cuda.current_device()
     if chunks is None:
         chunks = int(os.environ.get("MSMHIP_GROUP_CHUNKS", "2" if nmax >= 4 else "1"))
     pending = []  # per piece: (k0, k1, all_counts, aF, app, api, [work handles], send buffers kept alive)
@@ -257,16 +261,25 @@ def sharded_group_setup(group, n_subjects, comm=None, chunks=None):
         c.all_gather(all_counts, counts)  # small and blocking: sizes the index buffers of this piece
         all_counts = all_counts.cpu().numpy()
         imax = max(int(all_counts.max()), 1)
-        F = torch.empty((n, L, D, V), dtype=torch.float64, device=c.device)
-        pp = torch.zeros((n, M), dtype=torch.int32, device=c.device)
-        pi = torch.zeros((n, imax), dtype=torch.int32, device=c.device)
+        F = torch.empty((n, L, D, V), dtype=torch.float64, device=dev)
+        pp = torch.zeros((n, M), dtype=torch.int32, device=dev)
+        pi = torch.zeros((n, imax), dtype=torch.int32, device=dev)
+        if len(part) < n:
+            F[len(part):].zero_()  # a rank with fewer subjects than the largest shard sends defined padding
         if part:
             group.export_subjects_dev(part, F.data_ptr(), L * D * V, pp.data_ptr(), M, pi.data_ptr(), imax)  # synchronises libmsmhip's stream
-        torch.cuda.current_stream().synchronize()  # the zero fills above: complete before RCCL's stream reads the buffers
-        aF = torch.empty((c.world,) + tuple(F.shape), dtype=F.dtype, device=c.device)
-        app = torch.empty((c.world,) + tuple(pp.shape), dtype=pp.dtype, device=c.device)
-        api = torch.empty((c.world,) + tuple(pi.shape), dtype=pi.dtype, device=c.device)
-        works = [c.dist.all_gather_into_tensor(o, i, async_op=True) for o, i in ((aF, F), (app, pp), (api, pi))]
+        torch.cuda.current_stream().synchronize()  # the fills above: complete before RCCL's stream (or the host copy) reads the buffers
+        aF = torch.empty((c.world,) + tuple(F.shape), dtype=F.dtype, device=dev)
+        app = torch.empty((c.world,) + tuple(pp.shape), dtype=pp.dtype, device=dev)
+        api = torch.empty((c.world,) + tuple(pi.shape), dtype=pi.dtype, device=dev)
+        works = []
+        for o, i in ((aF, F), (app, pp), (api, pi)):
+            if c.on_gpu:
+                works.append(c.dist.all_gather_into_tensor(o, i, async_op=True))
+            else:
+                host = torch.empty(o.shape, dtype=o.dtype)
+                c.all_gather(host, i.cpu())
+                o.copy_(host)
         pending.append((k0, k1, all_counts, aF, app, api, works, (F, pp, pi)))
     for _, _, _, _, _, _, works, _ in pending:
         for w in works:

@@ -281,7 +281,9 @@ def test_sharded_group_two_ranks_match_single_rank(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / "sharded.py"
     script.write_text(SHARDED_WORKER % root)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29561", WORLD_SIZE="2")
+    # MSMHIP_GROUP_CHUNKS=2: each rank sets up and exchanges its two subjects in two pieces (msm_group_setup_more_subjects, a gather per piece, the
+    # batched device export / import of dist.sharded_group_setup) -- with gloo the gathers go through host copies, the rest is the nccl path
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29561", WORLD_SIZE="2", MSMHIP_GROUP_CHUNKS="2")
     procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE,
                               stderr=subprocess.PIPE, text=True) for r in range(2)]
     outs = []
