@@ -58,6 +58,26 @@ def kernel_algorithmic_bytes(samples, evals, D):
     return samples * (108 + (24 if D == 1 else 0)) + evals * 72
 
 
+def kernel_source_stamp():
+    """sha256 over newmsm_amd/csrc/*.hip, *.hpp, as tools/summarise_pmc.py stamps a profile: counters of a committed profile are reported only while
+    the kernel sources are the ones that were profiled"""
+    import hashlib
+
+    h = hashlib.sha256()
+    root = os.path.join(ROOT, "newmsm_amd", "csrc")
+    for name in sorted(os.listdir(root)):
+        if name.endswith((".hip", ".hpp")):
+            h.update(name.encode())
+            h.update(open(os.path.join(root, name), "rb").read())
+    return h.hexdigest()
+
+
+def profile_is_current(prof):
+    """a profile without a stamp (rounds 1-3) is taken as it is; a stamped one must match the sources"""
+    stamp = prof.get("kernel_source_sha256")
+    return stamp is None or stamp == kernel_source_stamp()
+
+
 def pmc_traffic(args):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (separate --pmc runs,
     (2 * FETCH_SIZE + WRITE_SIZE) * 1024 as MI355X_MICROARCH.md prescribes for gfx950).  Only valid for the default workload."""
@@ -65,7 +85,10 @@ def pmc_traffic(args):
         return None
     try:
         with open(os.path.join(ROOT, PMC_PROFILE)) as f:
-            return json.load(f)["kernels"][DOMINANT_KERNEL]["hbm_traffic_bytes_per_launch"]
+            prof = json.load(f)
+        if not profile_is_current(prof):
+            return None
+        return prof["kernels"][DOMINANT_KERNEL]["hbm_traffic_bytes_per_launch"]
     except (OSError, KeyError, ValueError):
         return None
 
@@ -349,6 +372,8 @@ def gmsm_valu_profile(S, data_order, cp_order):
     try:
         with open(os.path.join(ROOT, GMSM_PMC_PROFILE)) as f:
             prof = json.load(f)
+        if not profile_is_current(prof):
+            return None
         k = [v for name, v in prof["kernels"].items() if "k_group_pairwise" in name][0]
         return {"per_launch": k["per_launch_mean"]["SQ_INSTS_VALU"], "launches_per_step": k["launches_per_step"], "kernel_avg_ns": k["kernel_avg_ns_from_kernel_stats"]}
     except (OSError, KeyError, IndexError, ValueError):

@@ -25,8 +25,24 @@ for r in csv.DictReader(open("gpurun_out/%s_kernel_stats.csv" % tag)):
     avg_ns[r["Name"].split("(")[0]] = float(r["AverageNs"])
     calls[r["Name"].split("(")[0]] = int(r["Calls"])
 steps = int(os.environ.get("MSM_PROFILE_STEPS", "0"))  # label steps the profiled command ran (tools/collect_group_profile.sh): launches per step
+import hashlib
+
+
+def source_stamp():
+    """sha256 over the kernel sources the profiled library was built from (newmsm_amd/csrc/*.hip, *.hpp): bench.py reports counters of a profile only
+    while the sources still hash to this (a committed profile must not be priced against a different kernel binary)"""
+    h = hashlib.sha256()
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "newmsm_amd", "csrc")
+    for name in sorted(os.listdir(root)):
+        if name.endswith((".hip", ".hpp")):
+            h.update(name.encode())
+            h.update(open(os.path.join(root, name), "rb").read())
+    return h.hexdigest()
+
+
 out = {
     "command": "rocprofv3 --kernel-trace --pmc <one counter set per pass> -- " + command,
+    "kernel_source_sha256": source_stamp(),
     "traffic_formula": "(2 * FETCH_SIZE + WRITE_SIZE) * 1024: FETCH_SIZE/WRITE_SIZE are reported in KiB; gfx950 FETCH_SIZE counts "
                        "half of the bytes of wide reads (MI355X_MICROARCH.md, HBM section)",
     "kernels": {},
