@@ -20,8 +20,15 @@ for k in range(n):
     S = int(rng.integers(2, 5))
     data_order = int(rng.choice([3, 4]))
     cp_order = int(rng.integers(1, data_order - 1))
+    big = rng.integers(0, 5) == 0
+    if big:  # round 4: a control grid far coarser than the template -- patches of hundreds to thousands of entries (beyond the register
+        cp_order, data_order = int(rng.integers(0, 2)), int(rng.choice([4, 5]))  # rounds and the membership bits of k_group_pairwise), DICE left to LDS-sized patches
+        S = 2
+    os.environ["MSMHIP_GROUP_PAIR_LANES"] = str(rng.choice([16, 32]))  # read when the set-up is finalised
     D = int(rng.integers(1, 4))
     sim = int(rng.choice([1, 2, 4, 5]))
+    if big:
+        sim = int(rng.choice([1, 2]))  # (DICE packs a patch's common entries into LDS: at most 2 560 entries, a loud MSM_ERR_CAPACITY beyond)
     mask = bool(rng.integers(0, 2))
     pct = float(rng.uniform(0.2, 0.9))
     amp, rot = float(rng.uniform(0.0, 1.0)), float(rng.uniform(0.0, 4.0))

@@ -34,8 +34,19 @@ for k in range(n):
               optimiser=optimiser)
     if kind.startswith("ho_"):
         kw["cost_params"].update(lambda_=float(rng.uniform(0.001, 0.05)), mu=0.4, kappa=1.6, k_exp=2.0, rexp=2.0)
-    got = registration.run_discrete_level(registration.ProductOps(ctx), xyz, tri, ref, xyz, tri, src, xyz, **kw)
-    want = registration.run_discrete_level(OracleOps(M.mcmc_optimise), xyz, tri, ref, xyz, tri, src, xyz, **kw)
+    pops, oops = registration.ProductOps(ctx), OracleOps(M.mcmc_optimise)
+    akw_p, akw_o = {}, {}
+    if optimiser == "fusion" and kind in ("univariate", "ho_univariate", "ho_multivariate") and rng.integers(0, 3) == 0:
+        # round 4: --regoption=5 (aMSM): the level prepares the anatomical regulariser (resample_anatomy) from two synthetic anatomical surfaces
+        kw.update(rmode=5, iters=min(kw["iters"], 2))
+        kw["cost_params"].update(lambda_=float(rng.uniform(0.005, 0.05)), mu=0.4, kappa=1.6, k_exp=2.0, rexp=2.0)
+        order = int(rng.integers(cp_order, min(cp_order + 3, data_order + 1)))
+        ian, ran = synthetic.anatomy(xyz, seed=seed + 5, base=60.0), synthetic.anatomy(xyz, seed=seed + 6, base=62.0)
+        akw_p = dict(anat=dict(order=order, in_anat=ian, ref_anat=ran, in_mesh=pops.mesh(xyz, tri), ref_mesh=pops.mesh(xyz, tri)))
+        akw_o = dict(anat=dict(order=order, in_anat=ian, ref_anat=ran, in_mesh=oops.mesh(xyz, tri), ref_mesh=oops.mesh(xyz, tri)))
+        kind = kind + " aMSM(anat ico%d)" % order
+    got = registration.run_discrete_level(pops, xyz, tri, ref, xyz, tri, src, xyz, **kw, **akw_p)
+    want = registration.run_discrete_level(oops, xyz, tri, ref, xyz, tri, src, xyz, **kw, **akw_o)
     same = all(np.array_equal(a, b) for a, b in zip(got[3], want[3]))
     ua, ub = got[0] / 100.0, want[0] / 100.0
     ang = float(np.max(2 * np.arcsin(np.minimum(1.0, 0.5 * np.linalg.norm(ua - ub, axis=1)))))
