@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MSM_ABI_VERSION 8  /* 8 (round 4): msm_query_lanes, msm_resample_anatomy_grid, msm_group_export_subjects_dev / msm_group_import_subjects_dev / msm_group_setup_more_subjects added.  6 (round 3): msm_pairwise_icm, msm_ctx_time_queries / msm_ctx_query_kernel_ms, msm_group_time_moves / msm_group_move_kernels_ms,
+#define MSM_ABI_VERSION 8  /* 8 (round 4): msm_query_lanes, msm_resample_anatomy_grid, msm_cost_triplet_octets_prefetch / msm_cost_prefetch_stats, msm_group_export_subjects_dev / msm_group_import_subjects_dev / msm_group_setup_more_subjects added.  6 (round 3): msm_pairwise_icm, msm_ctx_time_queries / msm_ctx_query_kernel_ms, msm_group_time_moves / msm_group_move_kernels_ms,
                              * msm_store_release_i64 / msm_load_acquire_i64 / msm_min_acquire_i64, msm_mesh_sphere_project_warp added; nothing removed or changed */
 
 #define MSM_OK 0
@@ -325,6 +325,15 @@ int msm_cost_triplet_batch(msm_cost *c, const int32_t *triplet, const int32_t *l
 /* the 8 costs per triplet of one fusion move, I/Fusion/Fusion.h:181-196: E[8*t + k], k = 000..111 with bit
  * order (A,B,C) and 0 = current labeling, 1 = `label` */
 int msm_cost_triplet_octets(msm_cost *c, const int32_t *labeling, int32_t label, double *E);
+/* A hint that costs nothing to ignore: queue the label step (labeling, label) into E and return without waiting.  Between two label steps of
+ * Fusion::optimize the host solves a binary problem (ELC + FastPD, I/Fusion/Fusion.h:204-221) while the GPU idles, and most steps of a converging level
+ * change no label (three of four in the HCP MSMAll schedule): the next step's evaluations can run meanwhile.  The next msm_cost_triplet_octets on this
+ * cost function with the same labeling, label and E only waits for the queued kernel; any other call drops the queued step (its evaluations were never
+ * asked for: a status they raised is discarded).  Honoured when E lies in msm_host_alloc memory and the step has its one-kernel form (the fused triclique
+ * move, or the strain-only move with the labeling in the kernel arguments); silently ignored otherwise.  Results do not depend on it.
+ * msm_cost_prefetch_stats: steps taken from a prefetch / prefetches dropped, since creation. */
+int msm_cost_triplet_octets_prefetch(msm_cost *c, const int32_t *labeling, int32_t label, double *E);
+int msm_cost_prefetch_stats(msm_cost *c, int64_t *taken, int64_t *dropped);
 /* computePairwiseCost :190-226 for n (pair, labelA, labelB) queries, and the full table of
  * computePairwiseCosts :228-234: paircosts[(pair*L + labelB)*L + labelA] */
 int msm_cost_pairwise_batch(msm_cost *c, const int32_t *pair, const int32_t *la, const int32_t *lb, int32_t n, double *out);

@@ -651,8 +651,7 @@ public:
         if (fits) {  // a new label step: all 8 T costs with one call, into the buffer the kernel writes directly
             step_lab_ = labeling_;
             step_label_ = label;
-            double *E = octets_.ensure(ctx_, 8 * triplets_.size() / 3);
-            check(msm_cost_triplet_octets(cf_.handle(), step_lab_.data(), label, E));
+            evaluate_step(label);
             step_valid_ = true;
             counters.step_calls.fetch_add(1, std::memory_order_relaxed);
             if (lookup(triplet, n, labelA, labelB, labelC, v)) return v;
@@ -692,17 +691,32 @@ public:
             out.pair_quads = step_quads_.data();
         }
         if (T > 0) {
-            double *E = octets_.ensure(ctx_, 8 * (size_t)T);
-            check(msm_cost_triplet_octets(cf_.handle(), step_lab_.data(), label, E));
+            out.triplet_octets = evaluate_step(label);
             step_valid_ = true;
-            out.triplet_octets = E;
         }
         counters.step_calls.fetch_add(1, std::memory_order_relaxed);
         return out;
     }
     FusionCounters counters;
+    bool speculate = true;  // queue the next label step's evaluations while the optimiser solves the current one (msm_cost_triplet_octets_prefetch)
 
 private:
+    // The 8 T costs of the step (step_lab_, label) into one of two buffers used in turn, then -- a hint -- the NEXT step of Fusion's sweep over the labels
+    // (I/Fusion/Fusion.h:136-140: label + 1, wrapping into the second sweep) queued into the other for the labeling as it stands: while ELC + FastPD solve this
+    // step the GPU would idle, and a step that accepts no proposal (most of a converging level) leaves the next step's evaluations exactly these.  A step
+    // whose labeling did change is evaluated afresh; the buffer a solve is reading is never the one being written.
+    double *evaluate_step(int label) {
+        const size_t n = 8 * triplets_.size() / 3;
+        double *E = octets_[turn_].ensure(ctx_, n);
+        check(msm_cost_triplet_octets(cf_.handle(), step_lab_.data(), label, E));
+        cur_ = E;
+        turn_ ^= 1;
+        if (speculate && getNumLabels() > 1) {
+            double *next = octets_[turn_].ensure(ctx_, n);
+            check(msm_cost_triplet_octets_prefetch(cf_.handle(), step_lab_.data(), (label + 1) % getNumLabels(), next));
+        }
+        return E;
+    }
     bool lookup(int t, const int32_t *n, int la, int lb, int lc, double &v) {
         if (!step_valid_) return false;
         int k = 0;
@@ -713,7 +727,7 @@ private:
             else if (arg[j] == step_label_) k = 2 * k + 1;
             else return false;
         }
-        v = octets_.data()[8 * (size_t)t + k];
+        v = cur_[8 * (size_t)t + k];
         counters.served.fetch_add(1, std::memory_order_relaxed);
         return true;
     }
@@ -726,7 +740,9 @@ private:
     std::vector<int32_t> step_lab_;
     std::vector<double> step_quads_;
     int step_label_ = -1;
-    detail::HostBuffer octets_;
+    detail::HostBuffer octets_[2];
+    double *cur_ = nullptr;
+    int turn_ = 0;
 };
 
 // Groupwise registration: DiscreteGroupModel (M/DiscreteGroupModel.h:37-108) as Fusion::optimize calls it.  computeUnaryCost is 0

@@ -59,6 +59,9 @@ struct LevelOptions {
     // computeUnaryCosts + computePairwiseCosts, then a stand-in for FPD::FastPD(model, 100) (msm_pairwise_icm)
     bool pairwise = false;
     int anat_order = -1;  // --anatgrid of this level (regularisermode 4 / 5, aMSM); cp_order + 2 when negative
+    // the fusion loop queues the next label step's evaluations while the host solves the current one (msm_cost_triplet_octets_prefetch: a hint, the
+    // results do not depend on it)
+    bool speculate = true;
     // measurement only: when set, the cost function records HIP events around its kernels (msm_cost_enable_timing) and the duration of every fusion
     // move's kernel (ms) is appended here -- one event query per move, so a run with this set is not the one whose wall clock is reported
     std::vector<double> *move_kernel_ms = nullptr;
@@ -130,7 +133,7 @@ inline LevelResult run_discrete_opt(Context &ctx, const Points &target_xyz, cons
     double m_scale = 1.0;
     if (cp_start) cp_xyz = *cp_start;
     LevelResult res;
-    detail::HostBuffer octets;
+    detail::HostBuffer octets[2];  // used in turn: a step's costs are read by its solve while the next step may already be written into the other
     for (int it = 0; it < o.iters; ++it) {
         // ---- reset_meshspace + setupCostFunction
         SOURCE.set_coords(sph_reg);
@@ -150,30 +153,43 @@ inline LevelResult run_discrete_opt(Context &ctx, const Points &target_xyz, cons
         std::vector<int32_t> labeling((size_t)N, 0);  // resetLabeling
         const int L = (int)(labels.size() / 3), T = (int)(triplets.size() / 3);
         if (o.fusion) {  // ---- Fusion::optimize: two sweeps over the labels, a fusion move per label step
-            double *E = octets.ensure(ctx.handle(), 8 * (size_t)T);  // pinned, GPU-mapped: the kernel writes the costs where the solve reads them
+            double *Ebuf[2] = {octets[0].ensure(ctx.handle(), 8 * (size_t)T), octets[1].ensure(ctx.handle(), 8 * (size_t)T)};  // pinned, GPU-mapped
+            int turn = 0;
             std::vector<double> unary2(2 * (size_t)N);
             const std::vector<int32_t> no_pairs;
-            for (int sweep = 0; sweep < 2; ++sweep)
-                for (int label = 0; label < L; ++label) {
-                    bool any = false;
-                    for (int i = 0; i < N; ++i) any = any || labeling[(size_t)i] != label;
-                    if (!any) continue;
-                    PhaseClock::timed(clock, "fusion_moves", [&] { check(msm_cost_triplet_octets(costfct.handle(), labeling.data(), label, E)); });
-                    if (o.move_kernel_ms) {
-                        double ms = 0.0;
-                        int32_t got = 0;
-                        check(msm_cost_kernel_times(costfct.handle(), &ms, 1, &got));
-                        if (got == 1) o.move_kernel_ms->push_back(ms);
-                    }
-                    for (int i = 0; i < N; ++i) {
-                        unary2[2 * (size_t)i] = costfct.unarycosts[(size_t)labeling[(size_t)i] * N + i];
-                        unary2[2 * (size_t)i + 1] = costfct.unarycosts[(size_t)label * N + i];
-                    }
-                    const std::vector<int32_t> x =
-                        PhaseClock::timed(clock, "optimiser", [&] { return fusion_icm_step(N, unary2, nullptr, no_pairs, E, triplets, o.icm_passes); });
-                    for (int i = 0; i < N; ++i)
-                        if (x[(size_t)i] == 1 && labeling[(size_t)i] != label) labeling[(size_t)i] = label;
+            auto differs = [&](int label) {
+                for (int i = 0; i < N; ++i)
+                    if (labeling[(size_t)i] != label) return true;
+                return false;
+            };
+            for (int step = 0; step < 2 * L; ++step) {
+                const int label = step % L;
+                if (!differs(label)) continue;
+                double *E = Ebuf[turn];
+                turn ^= 1;
+                PhaseClock::timed(clock, "fusion_moves", [&] { check(msm_cost_triplet_octets(costfct.handle(), labeling.data(), label, E)); });
+                if (o.move_kernel_ms) {
+                    double ms = 0.0;
+                    int32_t got = 0;
+                    check(msm_cost_kernel_times(costfct.handle(), &ms, 1, &got));
+                    if (got == 1) o.move_kernel_ms->push_back(ms);
                 }
+                if (o.speculate && !o.move_kernel_ms) {  // the next step that will be evaluated if this solve changes nothing: queued while the host solves
+                    for (int nxt = step + 1; nxt < 2 * L; ++nxt)
+                        if (differs(nxt % L)) {
+                            PhaseClock::timed(clock, "fusion_prefetch", [&] { check(msm_cost_triplet_octets_prefetch(costfct.handle(), labeling.data(), nxt % L, Ebuf[turn])); });
+                            break;
+                        }
+                }
+                for (int i = 0; i < N; ++i) {
+                    unary2[2 * (size_t)i] = costfct.unarycosts[(size_t)labeling[(size_t)i] * N + i];
+                    unary2[2 * (size_t)i + 1] = costfct.unarycosts[(size_t)label * N + i];
+                }
+                const std::vector<int32_t> x =
+                    PhaseClock::timed(clock, "optimiser", [&] { return fusion_icm_step(N, unary2, nullptr, no_pairs, E, triplets, o.icm_passes); });
+                for (int i = 0; i < N; ++i)
+                    if (x[(size_t)i] == 1 && labeling[(size_t)i] != label) labeling[(size_t)i] = label;
+            }
         } else if (o.pairwise) {  // ---- FastPD: computeUnaryCosts, computePairwiseCosts, the solve
             PhaseClock::timed(clock, "pairwise_table", [&] { costfct.computePairwiseCosts(); });
             PhaseClock::timed(clock, "optimiser", [&] { pairwise_icm(costfct.unarycosts, costfct.paircosts, pairs, N, L, labeling, 100); });

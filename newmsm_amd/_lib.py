@@ -116,6 +116,8 @@ SIGNATURES = {
     "msm_cost_unary_table_fetch": (C.c_int, [_VP, c_dp]),
     "msm_cost_unary_batch": (C.c_int, [_VP, c_ip, c_ip, C.c_int32, c_dp]),
     "msm_cost_triplet_batch": (C.c_int, [_VP, c_ip, c_ip, c_ip, c_ip, C.c_int32, c_dp]),
+    "msm_cost_triplet_octets_prefetch": (C.c_int, [_VP, _VP, C.c_int32, _VP]),
+    "msm_cost_prefetch_stats": (C.c_int, [_VP, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "msm_cost_triplet_octets": (C.c_int, [_VP, _VP, C.c_int32, _VP]),  # addresses as integers: called once per label step (ctypes casts cost microseconds)
     "msm_cost_pairwise_batch": (C.c_int, [_VP, c_ip, c_ip, c_ip, C.c_int32, c_dp]),
     "msm_cost_pairwise_table": (C.c_int, [_VP, c_dp]),

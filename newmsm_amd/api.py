@@ -636,6 +636,20 @@ class DiscreteCostFunction:
             check(st)
         return out
 
+    def prefetchTripletOctets(self, labeling, label, out):
+        """msm_cost_triplet_octets_prefetch: queue the label step (labeling, label) into `out` (a Context.host_array, T x 8) without waiting -- a hint;
+        the next tripletOctets with the same labeling, label and out only waits for it, any other call on this cost function drops it"""
+        lab = labeling if (type(labeling) is np.ndarray and labeling.dtype == np.int32 and labeling.flags.c_contiguous) else np.ascontiguousarray(labeling, dtype=np.int32)
+        st = lib().msm_cost_triplet_octets_prefetch(self.h, lab.ctypes.data, int(label), out.ctypes.data)
+        if st:
+            check(st)
+
+    def prefetch_stats(self):
+        """(label steps taken from a prefetch, prefetches dropped) since creation"""
+        a, b = C.c_int64(), C.c_int64()
+        check(lib().msm_cost_prefetch_stats(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def computeTripletCosts(self, t0=0, t1=None, pinned=False):
         """tcosts[t][a][b][c] (M/DiscreteCostFunction.cpp:245-253) for the triplets t0 <= t < t1.  Like the reference's
         tcosts member the table lives in the object: the returned array is reused by the next call of the same shape (a fresh

@@ -61,6 +61,7 @@ int ensure_label_rotations(msm_cost *c) {
 namespace {
 
 void invalidate_table(msm_cost *c) {
+    (void)drop_pending_move(c);  // a label step queued ahead reads what the caller is about to change
     c->move_valid = false;
     c->table_valid = false;
     c->rotations_valid = false;
@@ -339,6 +340,7 @@ msm_cost *msm_cost_create(msm_ctx *ctx, const msm_cost_params *params) {
 void msm_cost_destroy(msm_cost *c) {
     if (!c) return;
     (void)hipSetDevice(c->ctx->device);
+    (void)drop_pending_move(c);
     (void)hipStreamSynchronize(c->ctx->stream);
     for (hipEvent_t e : c->ev0) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->ev1) (void)hipEventDestroy(e);
@@ -484,6 +486,7 @@ int msm_cost_set_pairs(msm_cost *c, const int32_t *pairs, int32_t P) {
 
 int msm_cost_get_source_data(msm_cost *c) {
     if (!c) return fail(MSM_ERR_INVALID, "null cost");
+    (void)drop_pending_move(c);
     int st = need(c, c->target && c->source && c->cpgrid, "meshes");
     if (st) return st;
     st = need(c, c->D > 0, "source features");

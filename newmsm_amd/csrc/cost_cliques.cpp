@@ -9,10 +9,33 @@
 
 using namespace msm;
 
+namespace msm {
+// A label step queued by msm_cost_triplet_octets_prefetch that nobody took: wait for its kernel and discard what it may have raised (its evaluations
+// were never asked for).  Called by every entry point of a cost function except the msm_cost_triplet_octets call that matches the prefetch.
+int drop_pending_move(msm_cost *c) {
+    if (!c->pending.valid) return MSM_OK;
+    c->pending.valid = false;
+    ++c->prefetch_drops;
+    msm_ctx *ctx = c->ctx;
+    MSM_HIP(hipStreamSynchronize(ctx->stream));
+    volatile int *flags = ctx->h_flag;
+    if (flags) {
+        flags[1] = 0;
+        if (flags[0] != 0) {
+            flags[0] = 0;
+            (void)check_status(ctx, "a dropped prefetch");  // clears the device status word
+        }
+    }
+    return MSM_OK;
+}
+
+}  // namespace msm
+
 namespace {
 
 // everything the clique kernels read; uploads the control grid's connectivity on first use
 int clique_args(msm_cost *c, bool need_triplets, bool need_pairs, CliqueArgs &a) {
+    if (int st = drop_pending_move(c)) return st;
     if (!c->cpgrid || !c->source || !c->target) return fail(MSM_ERR_STATE, "msm_cost: meshes must be set first");
     if (need_triplets && c->triplets.empty()) return fail(MSM_ERR_STATE, "msm_cost: triplets must be set first");
     if (need_pairs && c->pairs.empty()) return fail(MSM_ERR_STATE, "msm_cost: pairs must be set first");
@@ -279,9 +302,15 @@ int msm_cost_triplet_batch(msm_cost *c, const int32_t *triplet, const int32_t *l
 // The fused fusion move of the triclique classes (move_kernels.hip) for one labeling: all eight combinations of every control triangle
 // (E: 8 x T, a label step of Fusion) or, single, combination 000 only (E: T values -- the triplet part of evaluateTotalCostSum,
 // M/DiscreteCostFunction.cpp:55-77, which used to go through the general on-demand kernel at 143 us per call at ico4 / 32 features).
-static int fused_move(msm_cost *c, const CliqueArgs &a, const int32_t *labeling, int32_t label, double *E, bool single) {
+static int fused_move_finish(msm_cost *c, const CliqueArgs &a, const MoveArgs &m, const MoveLabels *lab, bool staged_copy, bool direct, void *pin, size_t in_pad,
+                             size_t out_bytes, double *out_dev, double *E);
+
+// prefetch != nullptr: queue the move and return without waiting (requires the fast form of the call: labeling in the kernel arguments, costs written into
+// the caller's mapped array); *prefetch tells whether it was queued
+static int fused_move(msm_cost *c, const CliqueArgs &a, const int32_t *labeling, int32_t label, double *E, bool single, bool *prefetch = nullptr) {
     msm_ctx *ctx = c->ctx;
     int st;
+    if (prefetch) *prefetch = false;
     const size_t in_bytes = sizeof(int32_t) * (size_t)a.N, out_bytes = sizeof(double) * (single ? 1 : 8) * (size_t)a.T, in_pad = (in_bytes + 255) & ~(size_t)255;
     // The call of the optimisers' inner loop (once per label step).  Two launches and one synchronisation: the labeling
     // rides in the kernel arguments, the costs are written into mapped pinned memory (the caller's own array when it
@@ -303,6 +332,7 @@ static int fused_move(msm_cost *c, const CliqueArgs &a, const int32_t *labeling,
     void *pin = nullptr;
     double *out_dev = out_by_copy ? nullptr : (double *)ctx_mapped(ctx, E, out_bytes);
     const bool direct = out_dev != nullptr;
+    if (prefetch && (!direct || !packed || single)) return MSM_OK;  // not the fast form: the hint is ignored, the call itself will do everything
     if (!direct || !packed) {
         st = ctx_io_pinned(ctx, in_pad + out_bytes, &pin);
         if (st) return st;
@@ -361,6 +391,18 @@ static int fused_move(msm_cost *c, const CliqueArgs &a, const int32_t *labeling,
     if (st) return st;
     if (staged_copy) MSM_HIP(hipMemcpyAsync((char *)pin + in_pad, out_dev, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
     c->counters[2] += (int64_t)(single ? 1 : 8) * a.T;
+    if (prefetch) {  // queued: msm_cost_triplet_octets(labeling, label, E) will wait for it
+        c->pending.kind = 1;
+        c->pending.label = label;
+        c->pending.E = E;
+        c->pending.labeling.assign(labeling, labeling + a.N);
+        c->pending.a = a;
+        c->pending.m = m;
+        c->pending.lab = lab;
+        c->pending.valid = true;
+        *prefetch = true;
+        return MSM_OK;
+    }
     MSM_HIP(hipStreamSynchronize(ctx->stream));
 #ifdef MSM_MOVE_TRACE
     if (const char *path = std::getenv("MSMHIP_MOVE_TRACE")) {
@@ -372,10 +414,18 @@ static int fused_move(msm_cost *c, const CliqueArgs &a, const int32_t *labeling,
         }
     }
 #endif
+    return fused_move_finish(c, a, m, packed ? &lab : nullptr, staged_copy, direct, pin, in_pad, out_bytes, out_dev, E);
+}
+
+// after the move's kernel has completed (the stream is synchronised): the tail kernel when the main one asked for it, a raised status, the staged copy
+static int fused_move_finish(msm_cost *c, const CliqueArgs &a, const MoveArgs &m, const MoveLabels *lab, bool staged_copy, bool direct, void *pin, size_t in_pad,
+                             size_t out_bytes, double *out_dev, double *E) {
+    msm_ctx *ctx = c->ctx;
+    int st;
     volatile int *flags = ctx->h_flag;
     if (flags[1] != 0) {  // rare: some evaluations need the complete search (sibling leaves, nearest vertex)
         flags[1] = 0;
-        st = launch_move_tail(ctx, a, m, packed ? &lab : nullptr);
+        st = launch_move_tail(ctx, a, m, lab);
         if (st) return st;
         if (staged_copy) MSM_HIP(hipMemcpyAsync((char *)pin + in_pad, out_dev, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
         MSM_HIP(hipStreamSynchronize(ctx->stream));
@@ -390,17 +440,97 @@ static int fused_move(msm_cost *c, const CliqueArgs &a, const int32_t *labeling,
     return st;
 }
 
+// the strain-only label step in its fast form (labeling in the kernel arguments, costs into mapped memory): launch, and unless queued ahead, wait
+static int packed_strain_move(msm_cost *c, const CliqueArgs &a, const int32_t *labeling, int32_t label, double *E, double *out_dev, bool direct, void *pin, size_t in_pad,
+                              size_t out_bytes, bool queue_only) {
+    msm_ctx *ctx = c->ctx;
+    MoveLabels lab;
+    std::memset(lab.w, 0, sizeof(uint32_t) * (size_t)((a.N + 3) / 4));
+    for (int i = 0; i < a.N; ++i) lab.w[i >> 2] |= (uint32_t)labeling[i] << ((i & 3) * 8);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (c->timing) {  // msm_cost_enable_timing: events around this move's kernel, like the triclique move's
+        e0 = c->ev0[c->ev_next];
+        e1 = c->ev1[c->ev_next];
+        c->ev_next = (c->ev_next + 1) % (int)c->ev0.size();
+        c->ev_count = std::min(c->ev_count + 1, (int)c->ev0.size());
+        MSM_HIP(hipEventRecord(e0, ctx->stream));
+    }
+    int st = launch_triplet_octets_packed(ctx, a, lab, label, out_dev, ctx->d_flag_map);
+    if (st) return st;
+    if (e1) MSM_HIP(hipEventRecord(e1, ctx->stream));
+    c->counters[2] += (int64_t)8 * a.T;
+    if (queue_only) {
+        c->pending.kind = 2;
+        c->pending.label = label;
+        c->pending.E = E;
+        c->pending.labeling.assign(labeling, labeling + a.N);
+        c->pending.valid = true;
+        return MSM_OK;
+    }
+    MSM_HIP(hipStreamSynchronize(ctx->stream));
+    volatile int *flags = ctx->h_flag;
+    st = MSM_OK;
+    if (flags[0] != 0) {
+        flags[0] = 0;
+        st = check_status(ctx, "computeTripletCost");
+    }
+    if (!direct) std::memcpy(E, static_cast<char *>(pin) + in_pad, out_bytes);
+    return st;
+}
+
+// the msm_cost_triplet_octets call a prefetch was queued for: wait for the kernel, then what follows a move's kernel in the synchronous call
+static int take_pending_move(msm_cost *c, double *E) {
+    msm_ctx *ctx = c->ctx;
+    msm_cost::PendingMove &p = c->pending;
+    p.valid = false;
+    ++c->prefetch_hits;
+    MSM_HIP(hipStreamSynchronize(ctx->stream));
+    if (p.kind == 1) return fused_move_finish(c, p.a, p.m, &p.lab, false, true, nullptr, 0, 0, nullptr, E);
+    volatile int *flags = ctx->h_flag;
+    if (flags[0] != 0) {
+        flags[0] = 0;
+        return check_status(ctx, "computeTripletCost");
+    }
+    return MSM_OK;
+}
+
+static int triplet_octets_impl(msm_cost *c, const int32_t *labeling, int32_t label, double *E, bool *prefetch);
+
 int msm_cost_triplet_octets(msm_cost *c, const int32_t *labeling, int32_t label, double *E) {
     if (!c || !labeling || !E) return fail(MSM_ERR_INVALID, "msm_cost_triplet_octets: null argument");
+    if (c->pending.valid && c->pending.label == label && c->pending.E == E && c->cpgrid && (int)c->pending.labeling.size() == c->cpgrid->V &&
+        std::memcmp(c->pending.labeling.data(), labeling, sizeof(int32_t) * c->pending.labeling.size()) == 0)
+        return take_pending_move(c, E);  // queued ahead by msm_cost_triplet_octets_prefetch: the kernel ran while the host solved
+    return triplet_octets_impl(c, labeling, label, E, nullptr);
+}
+
+// A hint: queue the label step (labeling, label) into E without waiting -- the optimiser's host-side solve of the step before runs meanwhile, and most
+// steps of a converging level leave the labeling as it was (three of four in the MSMAll schedule).  Honoured when E lies in msm_host_alloc memory and the
+// step takes the one-kernel form (triclique fused move or strain-only packed move); silently ignored otherwise.  The results do not depend on it.
+int msm_cost_triplet_octets_prefetch(msm_cost *c, const int32_t *labeling, int32_t label, double *E) {
+    if (!c || !labeling || !E) return fail(MSM_ERR_INVALID, "msm_cost_triplet_octets_prefetch: null argument");
+    bool queued = false;
+    return triplet_octets_impl(c, labeling, label, E, &queued);
+}
+
+int msm_cost_prefetch_stats(msm_cost *c, int64_t *taken, int64_t *dropped) {
+    if (!c) return fail(MSM_ERR_INVALID, "null cost");
+    if (taken) *taken = c->prefetch_hits;
+    if (dropped) *dropped = c->prefetch_drops;
+    return MSM_OK;
+}
+
+static int triplet_octets_impl(msm_cost *c, const int32_t *labeling, int32_t label, double *E, bool *prefetch) {
     CliqueArgs a;
-    int st = clique_args(c, true, false, a);
+    int st = clique_args(c, true, false, a);  // (drops a queued step nobody took)
     if (st) return st;
     if (label < 0 || label >= a.L) return fail(MSM_ERR_INVALID, "label %d out of range", label);
     msm_ctx *ctx = c->ctx;
     const size_t in_bytes = sizeof(int32_t) * (size_t)a.N, out_bytes = sizeof(double) * 8 * (size_t)a.T, in_pad = (in_bytes + 255) & ~(size_t)255;
-    if (fused_move_applies(c, a)) return fused_move(c, a, labeling, label, E, false);  // the call of the optimisers' inner loop (once per label step)
+    if (fused_move_applies(c, a)) return fused_move(c, a, labeling, label, E, false, prefetch);  // the call of the optimisers' inner loop (once per label step)
     for (int i = 0; i < a.N; ++i)
         if (labeling[i] < 0 || labeling[i] >= a.L) return fail(MSM_ERR_INVALID, "labeling[%d] out of range", i);
+    if (prefetch && !ctx_mapped(ctx, E, out_bytes)) return MSM_OK;  // the hint needs the caller's mapped array
     // labeling and energies travel through pinned memory (pageable copies of these sizes cost more than the kernels)
     void *pin = nullptr;
     st = ctx_io_pinned(ctx, in_pad + out_bytes, &pin);
@@ -416,32 +546,13 @@ int msm_cost_triplet_octets(msm_cost *c, const int32_t *labeling, int32_t label,
         const bool direct = out_dev != nullptr;
         if (!direct && ctx->io_dev) out_dev = reinterpret_cast<double *>(static_cast<char *>(ctx->io_dev) + in_pad);
         if (out_dev) {
-            MoveLabels lab;
-            std::memset(lab.w, 0, sizeof(uint32_t) * (size_t)((a.N + 3) / 4));
-            for (int i = 0; i < a.N; ++i) lab.w[i >> 2] |= (uint32_t)labeling[i] << ((i & 3) * 8);
-            hipEvent_t e0 = nullptr, e1 = nullptr;
-            if (c->timing) {  // msm_cost_enable_timing: events around this move's kernel, like the triclique move's
-                e0 = c->ev0[c->ev_next];
-                e1 = c->ev1[c->ev_next];
-                c->ev_next = (c->ev_next + 1) % (int)c->ev0.size();
-                c->ev_count = std::min(c->ev_count + 1, (int)c->ev0.size());
-                MSM_HIP(hipEventRecord(e0, ctx->stream));
-            }
-            st = launch_triplet_octets_packed(ctx, a, lab, label, out_dev, ctx->d_flag_map);
-            if (st) return st;
-            if (e1) MSM_HIP(hipEventRecord(e1, ctx->stream));
-            c->counters[2] += (int64_t)8 * a.T;
-            MSM_HIP(hipStreamSynchronize(ctx->stream));
-            volatile int *flags = ctx->h_flag;
-            st = MSM_OK;
-            if (flags[0] != 0) {
-                flags[0] = 0;
-                st = check_status(ctx, "computeTripletCost");
-            }
-            if (!direct) std::memcpy(E, static_cast<char *>(pin) + in_pad, out_bytes);
+            st = packed_strain_move(c, a, labeling, label, E, out_dev, direct, pin, in_pad, out_bytes, prefetch != nullptr && direct);
+            if (!st && prefetch && direct) *prefetch = true;
+            if (prefetch && !direct) return MSM_OK;
             return st;
         }
     }
+    if (prefetch) return MSM_OK;  // the general path is not queued ahead
     std::memcpy(pin, labeling, in_bytes);
     MSM_HIP(c->d_labeling.ensure(a.N));
     MSM_HIP(hipMemcpyAsync(c->d_labeling.p, pin, in_bytes, hipMemcpyHostToDevice, ctx->stream));

@@ -44,6 +44,19 @@ struct msm_cost {
     DevBuf<int4> d_blk;
     DevBuf<double> d_slot_w, d_slot_sf, d_slot_cw, d_slot_wda, d_tri_frame, d_tri_stat;
     int64_t move_tails = 0;  // moves that needed the tail kernel
+    // msm_cost_triplet_octets_prefetch: a label step queued ahead of its msm_cost_triplet_octets call (the optimiser's host-side solve of the previous
+    // step runs meanwhile); taken by the call that asks for exactly this (labeling, label, E), dropped by any other entry point of this cost function
+    struct PendingMove {
+        bool valid = false;
+        int kind = 0;  // 1: fused triclique move (k_ho_move), 2: strain-only packed move
+        int label = 0;
+        double *E = nullptr;
+        std::vector<int32_t> labeling;
+        msm::CliqueArgs a;
+        msm::MoveArgs m;
+        msm::MoveLabels lab;
+    } pending;
+    int64_t prefetch_hits = 0, prefetch_drops = 0;
     DevBuf<unsigned> d_defer_list, d_defer_cnt;
     int move_nblk = 0, move_cap = 0, move_parity = 0;
     bool move_valid = false;
@@ -101,6 +114,7 @@ int query_host(msm_mesh *target, const double *q, int N, int *tri_id, int *vid, 
 const Adjacency &mesh_adjacency(msm_mesh *m);
 // (re)computes the per (control point, label) rotation matrices and moved control points if stale
 int ensure_label_rotations(msm_cost *c);
+int drop_pending_move(msm_cost *c);  // cost_cliques.cpp: waits for and discards a label step queued by msm_cost_triplet_octets_prefetch that nobody took
 int ensure_vertex_major(msm_cost *c);  // d_sfeat_vm / d_cfw_vm
 inline bool cost_is_ho(const msm_cost *c) { return c->p.kind == MSM_COST_HO_UNIVARIATE || c->p.kind == MSM_COST_HO_MULTIVARIATE; }
 }  // namespace msm

@@ -171,12 +171,24 @@ class _ProductCost:
     def triplet_table(self):
         return self.cf.computeTripletCosts(pinned=True)  # consumed by the optimiser before the next table is computed
 
+    def _octet_buffers(self):
+        # the optimiser's per-step buffers: mapped pinned memory the kernel writes (two grow-only buffers per context, used in turn: a step's costs are
+        # consumed by its solve while the next step may already be written into the other); the numpy views are made once per set of triplets
+        if self._octets is None or self._octets[0].shape[0] != self.cf.T:
+            self._octets = [self.cf.ctx.scratch_host_array("octets%d" % k, (self.cf.T, 8)) for k in range(2)]
+            self._turn = 0
+        return self._octets
+
     def triplet_octets(self, labeling, label):
-        # the optimiser's per-step buffer: mapped pinned memory the kernel writes (one grow-only buffer per context, consumed before the next
-        # step); the numpy view is made once per set of triplets, not once per label step
-        if self._octets is None or self._octets.shape[0] != self.cf.T:
-            self._octets = self.cf.ctx.scratch_host_array("octets", (self.cf.T, 8))
-        return self.cf.tripletOctets(labeling, label, self._octets)
+        bufs = self._octet_buffers()
+        out = bufs[self._turn]
+        self._turn ^= 1
+        return self.cf.tripletOctets(labeling, label, out)
+
+    def prefetch_octets(self, labeling, label):
+        """the NEXT triplet_octets call will ask for (labeling, label) unless the solve in between changes a label: let its kernel run meanwhile
+        (msm_cost_triplet_octets_prefetch into the buffer that call will use)"""
+        self.cf.prefetchTripletOctets(labeling, label, self._octet_buffers()[self._turn])
 
     def total(self, labeling):
         return self.cf.evaluateTotalCostSum(labeling)[0]
@@ -220,7 +232,7 @@ def combine_costfunction_weighting(sourceweight, resampledtargetweight):
 def run_discrete_level(ops, target_xyz, target_tri, ref_feat, source_xyz, source_tri, src_feat, sph_reg, cp_order, *, sg_order=None,
                        iters=3, mciters=200, mcparam=0.8, seed=0, kind="univariate", simmeasure=2, rmode=3, labeldist=0.5,
                        rescale_labels=False, cost_params=None, timings=None, cp_start=None, in_weight=None, ref_weight=None,
-                       optimiser="mcmc", icm_passes=5, converge=False, anat=None):
+                       optimiser="mcmc", icm_passes=5, converge=False, anat=None, speculate=True):
     """Runs `iters` iterations of run_discrete_opt for one level.  optimiser: "mcmc" -- the reference's Monte Carlo optimiser over the
     unary and T x L^3 triplet tables (M/mcmc_opt.h:31-134) -- or "fusion": the label loop of Fusion::optimize (I/Fusion/Fusion.h:136-229: two
     sweeps over the labels, per label step 2 N unary and 8 T triplet costs -- ONE fusion-move call on the MI355X path --, nodes that the
@@ -238,6 +250,7 @@ def run_discrete_level(ops, target_xyz, target_tri, ref_feat, source_xyz, source
     cost-function weightings of the moving and the reference data at this resolution (SPHin_CFWEIGHTING / SPHref_CFWEIGHTING);
     with both given every iteration resamples the reference weighting onto the moving sphere and averages the two
     (combine_weighting, M/mesh_registration.cpp:234-248), otherwise the weighting is all ones.
+    speculate (fusion loop): queue the next label step's evaluations while the host solves the current one (ops' cost.prefetch_octets, if it has one).
     anat (rmode 4 / 5, aMSM): dict(order, in_anat, in_mesh, ref_anat, ref_mesh) -- --anatgrid of this level and the input / reference anatomical
     surfaces (V x 3) with the spheres (ops meshes) whose vertices they share (MESHES[0] / MESHES[1]).  initialize_level (M/mesh_registration.cpp:
     91-99) then prepares the anatomical regulariser: resample_anatomy (:250-332: the control grid retessellated to anatomical resolution with the
@@ -315,14 +328,23 @@ def run_discrete_level(ops, target_xyz, target_tri, ref_feat, source_xyz, source
         labeling = np.zeros(len(cp_xyz), dtype=np.int32)  # resetLabeling
         if optimiser == "fusion":  # --- Fusion::optimize: computeUnaryCosts, then per label step the 8 T combinations
             nodes = np.arange(len(cp_xyz))
-            for sweep in range(2):
-                for label in range(len(labels)):
-                    if not np.any(labeling != label):
-                        continue
-                    octets = timed("fusion_moves", cost.triplet_octets, labeling, label)
-                    unary2 = np.stack([unary[labeling, nodes], unary[label]], axis=1)
-                    x = timed("optimiser", ops.fusion_step, unary2, octets, triplets, icm_passes)
-                    labeling = np.where((x == 1) & (labeling != label), label, labeling).astype(np.int32)
+            L = len(labels)
+            steps = [(sweep, label) for sweep in range(2) for label in range(L)]
+            prefetch = getattr(cost, "prefetch_octets", None) if speculate else None
+            for k, (sweep, label) in enumerate(steps):
+                if not np.any(labeling != label):
+                    continue
+                octets = timed("fusion_moves", cost.triplet_octets, labeling, label)
+                if prefetch is not None:
+                    # While the host solves this step the GPU would idle; most steps of a converging level change no label, and then the next step's
+                    # evaluations are a function of what is known now: queue them (a hint: the results do not depend on it, a step whose labeling did
+                    # change is evaluated afresh)
+                    nxt = next((lb for _, lb in steps[k + 1:] if np.any(labeling != lb)), None)
+                    if nxt is not None:
+                        timed("fusion_prefetch", prefetch, labeling, nxt)
+                unary2 = np.stack([unary[labeling, nodes], unary[label]], axis=1)
+                x = timed("optimiser", ops.fusion_step, unary2, octets, triplets, icm_passes)
+                labeling = np.where((x == 1) & (labeling != label), label, labeling).astype(np.int32)
         elif pairwise:  # --- FastPD: computeUnaryCosts, computePairwiseCosts, FPD::FastPD(model, 100) (M/mesh_registration.cpp:182-188)
             paircosts = timed("pairwise_table", cost.pairwise_table)
             labeling = timed("optimiser", ops.pairwise_solve, unary, paircosts, pairs, 100)
