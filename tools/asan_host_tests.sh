@@ -15,4 +15,4 @@ done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -fsanitize=address -shared-libsan -o $OUT/libmsmhip.so $OUT/*.o kernels.o octree_kernels.o resample_kernels.o unary_kernels.o clique_kernels.o move_kernels.o group_kernels.o
 RT=$(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so | head -1)
 cd $ROOT
-LD_PRELOAD=$RT ASAN_OPTIONS=detect_leaks=0:verify_asan_link_order=0 MSM_LIB_PATH=$OUT/libmsmhip.so python -m pytest tests/test_host_logic.py tests/test_abi.py tests/test_meshio.py tests/test_golden.py -x -q -m "not gpu"
+LD_PRELOAD=$RT ASAN_OPTIONS=detect_leaks=0:verify_asan_link_order=0 MSM_LIB_PATH=$OUT/libmsmhip.so python -m pytest tests/test_host_logic.py tests/test_abi.py tests/test_meshio.py tests/test_golden.py tests/test_anatomy_grid.py tests/test_config.py -x -q -m "not gpu"
