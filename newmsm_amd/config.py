@@ -121,19 +121,23 @@ def parse_config(text):
     return cfg
 
 
-def levels_from_config(cfg, D, anat=False):
+def levels_from_config(cfg, D, anat=False, groupwise=False):
     """The DISCRETE levels of `cfg` (parse_config's result) for data with D feature rows, as keyword sets of run_multiresolution, plus what
     applies to the whole run: returns (levels, run_kw, skipped) -- run_multiresolution(ops, ..., levels, **run_kw).  skipped: the (index,
     method) of levels that are not DISCRETE (the affine stage is outside the path).  fix_parameters_for_level + NonLinearSRegDiscreteModel::
-    set_parameters / initialize_cost_function (M/mesh_registration.cpp:786-817, M/DiscreteModel.cpp:26-60)."""
+    set_parameters / initialize_cost_function (M/mesh_registration.cpp:786-817, M/DiscreteModel.cpp:26-60).  groupwise: the levels of a --groupwise
+    run (group_registration.run_group_multiresolution), whose model has its own regulariser (strain triplets per subject, M/DiscreteGroupCostFunction.cpp:
+    26-52) whatever --regoption says: the checks on --regoption do not apply (Group_Mesh_registration::initialize_level has none)."""
     if cfg["IN"] or cfg["INc"]:
         raise ConfigError("--IN / --INc (histogram matching through FSL's MISCMATHS::Histogram, M/reg_tools.cpp:745-802) is not available")
     if cfg["excl"]:
         raise ConfigError("--excl (exclusion masks from the cut thresholds) is not wired into run_multiresolution")
-    if cfg["regoption"] == 4:  # M/mesh_registration.cpp:101-102
+    if groupwise:
+        pass
+    elif cfg["regoption"] == 4:  # M/mesh_registration.cpp:101-102
         raise ConfigError("--regoption 4 has been removed from newMSM. Use --regoption 3 for spherical mesh regularisation or --regoption 5 for anatomical mesh "
                           "regularisation.")
-    if cfg["regoption"] == 5 and not anat:  # :103-104: the anatomical meshes come from the command line (--inanat / --refanat), `anat` says they are there
+    elif cfg["regoption"] == 5 and not anat:  # :103-104: the anatomical meshes come from the command line (--inanat / --refanat), `anat` says they are there
         raise ConfigError("--regoption 5 requires anatomical meshes. Use --regoption 3 for spherical mesh regularisation or provide anatomical meshes.")
     multivariate = D > 1
     if multivariate:  # initialize_cost_function, M/DiscreteModel.cpp:44-58
@@ -144,7 +148,7 @@ def levels_from_config(cfg, D, anat=False):
     if optimiser is None:
         raise ConfigError("Unrecognized optimiser")  # M/mesh_registration.cpp:202
     rmode = cfg["regoption"]
-    if optimiser != "fastpd" and rmode == 1:
+    if optimiser != "fastpd" and rmode == 1 and not groupwise:
         raise ConfigError("--regoption=1 (pairwise regulariser) is driven by FastPD only in the reference; Fusion / MCMC read triplets")
     levels, skipped = [], []
     for i, method in enumerate(cfg["opt"]):

@@ -19,16 +19,18 @@ from .registration import ProductOps, apply_labeling
 
 
 class ProductGroupOps(ProductOps):
-    def group(self, S, simmeasure, lambda_, fixnan):
-        return _ProductGroup(api.DiscreteGroupCostFunction(self.ctx, S, simmeasure=simmeasure, lambda_=lambda_, fixnan=fixnan))
+    def group(self, S, simmeasure, lambda_, fixnan, **params):
+        """params: mu, kappa, k_exp, rexp, range_, percentile (--shearmod --bulkmod --k_exponent --regexp --cprange --percentile) where they differ from the
+        reference's defaults"""
+        return _ProductGroup(api.DiscreteGroupCostFunction(self.ctx, S, simmeasure=simmeasure, lambda_=lambda_, fixnan=fixnan, **params))
 
 
 class _ProductGroup:
     def __init__(self, g):
         self.g = g
 
-    def set_template(self, mesh):
-        self.g.set_template(mesh, None)
+    def set_template(self, mesh, mask=None):
+        self.g.set_template(mesh, mask)
 
     def initialize(self, cp_mesh, cp_xyz, cp_tri):
         self.g.Initialize(cp_xyz, cp_tri)
@@ -56,9 +58,12 @@ class _ProductGroup:
 
 
 def run_group_level(ops, template_xyz, template_tri, data_xyz, data_tri, feats, sph_regs, cp_order, *, iters=2, simmeasure=2, lambda_=0.1,
-                    labeldist=0.5, icm_passes=5, timings=None, fixnan=True):
+                    labeldist=0.5, icm_passes=5, timings=None, fixnan=True, sg_order=None, cps_start=None, mask=None, cost_params=None):
     """feats: S x D x V data on the subjects' data grid (data_xyz, data_tri: the regular sphere the features live on); sph_regs: S x V x 3,
-    every subject's registered sphere so far.  fixnan (--fixnan, M/DiscreteGroupCostFunction.cpp:50,96): the cost of two patches without a
+    every subject's registered sphere so far.  sg_order: the sampling grid's resolution (--SGgrid, m_SGres; two above the control grid when not
+    given); cps_start (S x N x 3, optional): the control grids the level starts from (warp_CPgrid of the previous level's warp,
+    M/DiscreteGroupModel.h:69-72; the regular grid when not given); mask (V(template), optional): --mask, the weights of the common template
+    vertices in a pair cost (M/DiscreteGroupCostFunction.cpp:77); cost_params: the strain and similarity parameters of ops.group.  fixnan (--fixnan, M/DiscreteGroupCostFunction.cpp:50,96): the cost of two patches without a
     common template vertex is 1e7 instead of NaN -- with NaN costs the stand-in solve never moves a node of such a pair.  Returns (sph_regs, control grids S x N x 3, energies per iteration, labelings)."""
     import time
 
@@ -75,17 +80,20 @@ def run_group_level(ops, template_xyz, template_tri, data_xyz, data_tri, feats, 
     N = len(cp_xyz0)
     cp_mesh0 = ops.mesh(cp_xyz0, cp_tri)
     _, mvdmax = ops.cp_spacings(cp_mesh0, cp_xyz0, cp_tri)
-    samples, _ = ops.label_sampling_grid(cp_order + 2, labeldist * mvdmax)  # m_labels = m_samples in every iteration, :176
-    g = ops.group(S, simmeasure, lambda_, fixnan)
+    samples, _ = ops.label_sampling_grid(cp_order + 2 if sg_order is None else sg_order, labeldist * mvdmax)  # m_labels = m_samples in every iteration, :176
+    g = ops.group(S, simmeasure, lambda_, fixnan, **(cost_params or {}))
     template = ops.mesh(template_xyz, template_tri)
-    g.set_template(template)
+    if mask is None:
+        g.set_template(template)
+    else:
+        g.set_template(template, np.ascontiguousarray(mask, dtype=np.float64))
     g.initialize(cp_mesh0, cp_xyz0, cp_tri)
     meshes = [ops.mesh(data_xyz, data_tri) for _ in range(S)]
     for s in range(S):
         g.set_subject(s, meshes[s], feats[s])  # set_meshspace: the original data meshes
     sph_regs = [np.array(x, dtype=np.float64) for x in sph_regs]
-    cps = [np.array(cp_xyz0) for _ in range(S)]
-    prev = [np.array(cp_xyz0) for _ in range(S)]
+    cps = [np.array(cp_xyz0 if cps_start is None else cps_start[s], dtype=np.float64) for s in range(S)]
+    prev = [np.array(c) for c in cps]  # previous_controlgrids = model->get_CPgrid(subject), :75-78
     energies, labelings, energy = [], [], 0.0
     for it in range(iters):
         for s in range(S):
@@ -121,3 +129,81 @@ def run_group_level(ops, template_xyz, template_tri, data_xyz, data_tri, feats, 
             prev[s], cps[s] = new_cp, new_cp
         energy = newenergy
     return np.stack(sph_regs), np.stack(cps), energies, labelings
+
+
+def run_group_multiresolution(ops, meshes, datas, template_xyz, template_tri, levels, *, mask=None, varnorm=False, fixnan=False, timings=None,
+                              labelings_out=None, **level_kw):
+    """Group_Mesh_registration::run_multiresolutions (M/mesh_registration.cpp:30-50 over the overrides of M/group_mesh_registration.cpp) without
+    file I/O:
+
+    per level  initialize_level (:26-57): featurespace::initialise over all subjects (M/featurespace.cpp:39-86: every subject's data onto the
+               level's icosphere by metric_resample, smooth_data with the level's --sigma_in, variance_normalise), the control grid, the
+               model over (template, data grid, S);
+               evaluate (:59-68): level 1 starts every subject on the data grid; later levels carry each subject's warp to the new data grid
+               and control grid (project_CPgrid with the subject's index, M/mesh_registration.cpp:131-162), then run_discrete_opt (:70-118);
+    at the end transform (:120-125): every subject's input sphere moved through its final warp ("sphere-<i>.reg").
+
+    meshes: per subject (xyz, tri), spheres of radius 100; datas: per subject D x V(mesh); template_*: the sphere the patches are compared on
+    (--template); levels: dicts as config.levels_from_config builds them (data_order, cp_order, sg_order, sigma_in, iters, simmeasure,
+    cost_params["lambda_"]); mask: V(template) weights (--mask).  Returns (registered input spheres, per-level S x V x 3 registered data grids,
+    per-level energies)."""
+    import time
+
+    clock = timings if timings is not None else {}
+
+    def timed(name, fn, *a):
+        t0 = time.perf_counter()
+        out = fn(*a)
+        clock[name] = clock.get(name, 0.0) + time.perf_counter() - t0
+        return out
+
+    S = len(meshes)
+    if len(datas) != S:
+        raise ValueError("featurespace::Initialize do not have the same number of datasets and surface meshes")  # M/featurespace.cpp:43-44
+    in_xyz = [np.asarray(m[0], dtype=np.float64) for m in meshes]
+    in_mesh = [ops.mesh(in_xyz[s], meshes[s][1]) for s in range(S)]
+    prev_regs, prev_order, regs, all_energies = None, None, [], []
+    for lv in levels:
+        ico_xyz, ico_tri = ops.icosphere(lv["data_order"])
+        ico = ops.mesh(ico_xyz, ico_tri)
+        feats = []
+        for s in range(S):
+            f = timed("metric_resample", ops.metric_resample, in_mesh[s], datas[s], ico)
+            if lv.get("sigma_in", 0.0) > 0.0:
+                f = timed("smooth_data", ops.smooth_data, ico, f, lv["sigma_in"])
+            if varnorm:
+                f = ops.variance_normalise(f)
+            feats.append(f)
+        cps_start = None
+        if prev_regs is None:
+            sph = [ico_xyz for _ in range(S)]  # ALL_SPH_REG.resize(num_subjects, SPH_orig), :60-61
+        else:
+            prev_xyz, prev_tri = ops.icosphere(prev_order)
+            prev_ico = ops.mesh(prev_xyz, prev_tri)
+            cp_xyz, cp_tri = ops.icosphere(lv["cp_order"])
+            sph, cps_start = [], []
+            for s in range(S):
+                incurrent = timed("sphere_project_warp", ops.sphere_project_warp, in_xyz[s], prev_ico, prev_regs[s])
+                moved = ops.mesh(timed("sphere_project_warp", ops.sphere_project_warp, ico_xyz, in_mesh[s], incurrent), ico_tri)
+                cpm = ops.mesh(timed("sphere_project_warp", ops.sphere_project_warp, cp_xyz, in_mesh[s], incurrent), cp_tri)  # warp_CPgrid
+                timed("unfold", ops.unfold, cpm)
+                timed("unfold", ops.unfold, moved)
+                cps_start.append(ops.coords(cpm))
+                sph.append(ops.coords(moved))
+        kw = dict(level_kw)
+        kw.update({k: lv[k] for k in ("sg_order", "iters", "simmeasure") if k in lv})
+        if "cost_params" in lv:
+            kw["cost_params"] = {k: v for k, v in lv["cost_params"].items() if k != "lambda_"}
+            if "lambda_" in lv["cost_params"]:
+                kw["lambda_"] = lv["cost_params"]["lambda_"]
+        out, _, energies, labelings = run_group_level(ops, template_xyz, template_tri, ico_xyz, ico_tri, np.stack(feats), sph, lv["cp_order"], cps_start=cps_start,
+                                                      mask=mask, fixnan=fixnan, timings=clock, **kw)
+        if labelings_out is not None:
+            labelings_out.extend(labelings)
+        regs.append(out)
+        all_energies.append(energies)
+        prev_regs, prev_order = out, lv["data_order"]
+    last_xyz, last_tri = ops.icosphere(levels[-1]["data_order"])
+    last = ops.mesh(last_xyz, last_tri)
+    sphere_regs = [timed("sphere_project_warp", ops.sphere_project_warp, in_xyz[s], last, prev_regs[s]) for s in range(S)]
+    return sphere_regs, regs, all_energies

@@ -153,8 +153,8 @@ class OracleOps:
 
         return api.pairwise_icm(unary, paircosts, pairs, passes=passes)
 
-    def group(self, S, simmeasure, lambda_, fixnan):
-        return _OracleGroup(O.Group(S, simmeasure=simmeasure, lambda_=lambda_, fixnan=fixnan))
+    def group(self, S, simmeasure, lambda_, fixnan, **params):
+        return _OracleGroup(O.Group(S, simmeasure=simmeasure, lambda_=lambda_, fixnan=fixnan, **params))
 
 
 class _OracleGroup:
@@ -163,9 +163,9 @@ class _OracleGroup:
     def __init__(self, g):
         self.g, self.keep = g, []
 
-    def set_template(self, mesh):
+    def set_template(self, mesh, mask=None):
         self.keep.append(mesh)
-        self.g.set_template(mesh, None)
+        self.g.set_template(mesh, mask)
 
     def initialize(self, cp_mesh, cp_xyz, cp_tri):
         self.keep.append(cp_mesh)

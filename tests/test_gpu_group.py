@@ -563,3 +563,44 @@ def test_group_level_loop_matches_oracle(ctx):
     ang = 2.0 * np.arcsin(np.minimum(1.0, 0.5 * np.linalg.norm(ua - ub, axis=2)))
     assert ang.max() <= 1e-4 and np.abs(got[0] - want[0]).max() < 1e-9 and np.abs(got[1] - want[1]).max() < 1e-9
     assert np.abs(got[0] - sph).max() > 1e-3
+
+
+def test_group_multiresolution_matches_oracle(ctx):
+    """Group_Mesh_registration::run_multiresolutions (M/mesh_registration.cpp:30-50 over M/group_mesh_registration.cpp:26-133) without the files: two
+    levels over three subjects with a --mask on the template -- per level featurespace::initialise over all subjects (metric_resample, smooth_data,
+    variance_normalise), from level 2 on project_CPgrid per subject (the previous level's warp carried to the new data grid and control grid), the
+    level's iterations, at the end every subject's input sphere through its final warp.  The same caller loop over the oracle: same labelings in every
+    iteration of both levels, energies to 1e-9, registered spheres within the north star's 1e-4 rad.
+
+    The template and the subjects' spheres are irregular (smoothly warped icospheres).  With a REGULAR template under regular data grids a label of the
+    sampling grid carries data vertices exactly onto template vertices; which of the five or six triangles around such a vertex "contains" it -- and with
+    it the adaptive weight lists -- is then decided by the last bits of the rotation (libm's acos / sincos against the device's: 7e-14 apart), in the
+    reference as much as here: the oracle itself answers differently for two inputs that close."""
+    from helpers import OracleOps, angles
+    from newmsm_amd import group_registration as GR
+
+    S, D = 3, 2
+    xyz, tri = M.make_mesh_from_icosa(4)
+    txyz = synthetic.known_warp(xyz, seed=33, rot_deg=7.0, amp=1.5)
+    meshes = [(synthetic.known_warp(xyz, seed=40 + s, rot_deg=0.0, amp=1.0), tri) for s in range(S)]
+    datas = [synthetic.features(synthetic.known_warp(meshes[s][0], seed=90 + s, rot_deg=3.0, amp=2.0), D, seed=5) for s in range(S)]
+    levels = [dict(data_order=3, cp_order=1, sg_order=3, iters=2, simmeasure=2, cost_params=dict(lambda_=1e-3), sigma_in=2.0),
+              dict(data_order=4, cp_order=2, sg_order=4, iters=2, simmeasure=2, cost_params=dict(lambda_=1e-3), sigma_in=0.0)]
+    mask = (np.random.default_rng(1).random(len(xyz)) > 0.2).astype(np.float64)
+    lg, lw, t = [], [], {}
+    kw = dict(mask=mask, varnorm=True, fixnan=True)
+    got = GR.run_group_multiresolution(GR.ProductGroupOps(ctx), meshes, datas, txyz, tri, levels, labelings_out=lg, timings=t, **kw)
+    want = GR.run_group_multiresolution(OracleOps(M.mcmc_optimise), meshes, datas, txyz, tri, levels, labelings_out=lw, **kw)
+    assert len(lg) == len(lw) == 4
+    for a, b in zip(lg, lw):
+        assert np.array_equal(a, b)
+    assert any(l.any() for l in lg[:2]) and any(l.any() for l in lg[2:])  # labels were taken at both levels
+    for a, b in zip(got[2], want[2]):
+        assert np.allclose(a, b, rtol=1e-9)
+    for s in range(S):
+        assert angles(got[0][s], want[0][s]).max() <= 1e-4 and np.abs(got[0][s] - want[0][s]).max() < 1e-8
+        assert angles(got[0][s], meshes[s][0]).max() > 1e-3
+    for a, b in zip(got[1], want[1]):
+        assert np.abs(a - b).max() < 1e-8
+    assert got[1][0].shape == (S, 642, 3) and got[1][1].shape == (S, 2562, 3)
+    assert {"metric_resample", "smooth_data", "sphere_project_warp", "unfold", "setup", "fusion_moves"} <= set(t)

@@ -145,6 +145,117 @@ def test_files_in_files_out(ctx, tmp_path, fmt):
     assert np.corrcoef(moved[0], ref[0])[0, 1] > np.corrcoef(src[0], ref[0])[0, 1]
 
 
+def test_groupwise_files_in_files_out(ctx, tmp_path):
+    """tools/register_files.py --groupwise under newmsm's flag names (CLI/msmOptions.h:73-87: -g --meshes --template --data --mask): mesh and data lists
+    as text files (read_ascii_list), two levels, three subjects; the outputs of Group_Mesh_registration (M/group_mesh_registration.cpp:120-133,
+    .h:79-82) appear per subject -- <out>sphere-<i>.reg, <out>sphere-<i>.LR.reg, <out>transformed_and_reprojected-<i> -- and hold what
+    run_group_multiresolution gives on what the files hold."""
+    import os
+    import subprocess
+    import sys
+
+    from newmsm_amd import config, group_registration, meshio
+
+    S = 3
+    xyz, tri = M.make_mesh_from_icosa(4)
+    d = str(tmp_path) + "/"
+    text = "--simval=2,2\n--sigma_in=2,0\n--lambda=0.001,0.001\n--it=2,2\n--opt=DISCRETE,DISCRETE\n--CPgrid=1,2\n--SGgrid=3,4\n--datagrid=3,4\n--dopt=HOCR\n--VN\n--fixnan\n"
+    with open(d + "conf", "w") as f:
+        f.write(text)
+    # irregular spheres: a subject's own sphere each, a template that is no regular icosphere (see test_group_multiresolution_matches_oracle)
+    meshio.save_surface(d + "template.surf.gii", synthetic.known_warp(xyz, seed=33, rot_deg=7.0, amp=1.5), tri)
+    subj = [synthetic.known_warp(xyz, seed=40 + s, rot_deg=0.0, amp=1.0) for s in range(S)]
+    for s in range(S):
+        meshio.save_surface(d + "sphere%d.surf.gii" % s, subj[s], tri)
+    mask = (np.random.default_rng(1).random(len(xyz)) > 0.2).astype(np.float64)
+    meshio.save_metric(d + "mask.func.gii", mask[None])
+    datas = [synthetic.features(synthetic.known_warp(subj[s], seed=90 + s, rot_deg=3.0, amp=2.0), 2, seed=5) for s in range(S)]
+    for s in range(S):
+        meshio.save_metric(d + "data%d.func.gii" % s, datas[s])
+    with open(d + "meshes.txt", "w") as f:
+        f.write("".join(d + "sphere%d.surf.gii\n" % s for s in range(S)))
+    with open(d + "data.txt", "w") as f:
+        f.write("".join(d + "data%d.func.gii\n" % s for s in range(S)))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    run = subprocess.run([sys.executable, "tools/register_files.py", "--groupwise", "--meshes=" + d + "meshes.txt", "--data=" + d + "data.txt",
+                          "--template=" + d + "template.surf.gii", "--mask=" + d + "mask.func.gii", "--conf=" + d + "conf", "--out=" + d + "gw.", "--verbose"],
+                         cwd=root, capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0, run.stderr
+    assert "Mesh #2 is" in run.stdout and "Template is" in run.stdout
+    def sphere(path):
+        p, _ = meshio.load_surface(path)
+        p = p - p.mean(axis=0)
+        return p * (100.0 / np.linalg.norm(p, axis=1, keepdims=True))
+
+    in_xyz, t_xyz = [sphere(d + "sphere%d.surf.gii" % s) for s in range(S)], sphere(d + "template.surf.gii")
+    fdatas = [meshio.load_data(d + "data%d.func.gii" % s, len(xyz)) for s in range(S)]
+    cfg = config.parse_config(text)
+    levels, run_kw, _ = config.levels_from_config(cfg, 2, groupwise=True)
+    want, regs, _ = group_registration.run_group_multiresolution(group_registration.ProductGroupOps(ctx), [(p, tri) for p in in_xyz], fdatas, t_xyz, tri, levels,
+                                                                 mask=meshio.load_data(d + "mask.func.gii", len(xyz))[0], fixnan=cfg["fixnan"], **run_kw)
+    target = M.Mesh(ctx, t_xyz, tri)
+    for s in range(S):
+        reg, rtri = meshio.load_surface(d + "gw.sphere-%d.reg.surf.gii" % s)
+        lr, lrtri = meshio.load_surface(d + "gw.sphere-%d.LR.reg.surf.gii" % s)
+        assert np.array_equal(rtri, tri) and np.array_equal(lrtri, tri)
+        assert np.abs(reg - want[s]).max() < 2e-5 and np.abs(lr - regs[-1][s]).max() < 2e-5 and angles(reg, in_xyz[s]).max() > 1e-4
+        moved = meshio.load_data(d + "gw.transformed_and_reprojected-%d.func.gii" % s, len(xyz))
+        direct = M.metric_resample(M.Mesh(ctx, want[s], tri), fdatas[s], target)
+        assert moved.shape == (2, len(xyz)) and np.abs(moved - direct).max() < 1e-3 * max(1.0, np.abs(direct).max())
+    # the run refuses what the reference refuses in this mode
+    with open(d + "conf_affine", "w") as f:
+        f.write(text.replace("--opt=DISCRETE,DISCRETE", "--opt=AFFINE,DISCRETE"))
+    bad = subprocess.run([sys.executable, "tools/register_files.py", "--groupwise", "--meshes=" + d + "meshes.txt", "--data=" + d + "data.txt",
+                          "--template=" + d + "template.surf.gii", "--conf=" + d + "conf_affine", "--out=" + d + "bad."], cwd=root, capture_output=True, text=True, timeout=600)
+    assert bad.returncode != 0 and "not supported in groupwise mode" in bad.stderr
+
+
+def test_amsm_files_in_files_out(ctx, tmp_path):
+    """tools/register_files.py with --inanat / --refanat and a --regoption=5 configuration (CLI/newmsm.cpp:40-47, set_anatomical M/mesh_registration.cpp:
+    434-438): the outputs hold what run_multiresolution gives with the same anatomical surfaces; one anatomical mesh alone is refused."""
+    import os
+    import subprocess
+    import sys
+
+    from newmsm_amd import config, meshio
+
+    xyz, tri = M.make_mesh_from_icosa(4)
+    ref = synthetic.features(xyz, 1, 5)
+    src = synthetic.features(synthetic.known_warp(xyz, seed=8, rot_deg=3.0, amp=2.0), 1, 5)
+    ian, ran = synthetic.anatomy(xyz, seed=61, base=60.0), synthetic.anatomy(xyz, seed=71, base=62.0)
+    d = str(tmp_path) + "/"
+    text = ("--simval=2,2\n--sigma_in=2,0\n--sigma_ref=2,0\n--lambda=0.025,0.025\n--it=2,2\n--opt=DISCRETE,DISCRETE\n--CPgrid=1,2\n--SGgrid=3,4\n--datagrid=3,4\n"
+            "--anatgrid=3,4\n--regoption=5\n--dopt=HOCR\n--triclique\n--rescaleL\n--shearmod=0.4\n--bulkmod=1.6\n--k_exponent=2\n")
+    with open(d + "conf", "w") as f:
+        f.write(text)
+    meshio.save_surface(d + "sphere.surf.gii", xyz, tri)
+    meshio.save_surface(d + "in.anat.surf.gii", ian, tri)
+    meshio.save_surface(d + "ref.anat.surf.gii", ran, tri)
+    meshio.save_metric(d + "in.func.gii", src)
+    meshio.save_metric(d + "ref.func.gii", ref)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = [sys.executable, "tools/register_files.py", "--inmesh=" + d + "sphere.surf.gii", "--indata=" + d + "in.func.gii", "--refdata=" + d + "ref.func.gii",
+            "--conf=" + d + "conf", "--out=" + d + "a."]
+    run = subprocess.run(base + ["--inanat=" + d + "in.anat.surf.gii", "--refanat=" + d + "ref.anat.surf.gii"], cwd=root, capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0, run.stderr
+    in_xyz, _ = meshio.load_surface(d + "sphere.surf.gii")
+    in_xyz = in_xyz - in_xyz.mean(axis=0)
+    in_xyz = in_xyz * (100.0 / np.linalg.norm(in_xyz, axis=1, keepdims=True))
+    levels, run_kw, _ = config.levels_from_config(config.parse_config(text), 1, anat=True)
+    want, _, _ = registration.run_multiresolution(registration.ProductOps(ctx), in_xyz, tri, meshio.load_data(d + "in.func.gii", len(xyz)), in_xyz, tri,
+                                                  meshio.load_data(d + "ref.func.gii", len(xyz)), levels, in_anat=meshio.load_surface(d + "in.anat.surf.gii")[0],
+                                                  ref_anat=meshio.load_surface(d + "ref.anat.surf.gii")[0], **run_kw)
+    reg, _ = meshio.load_surface(d + "a.sphere.reg.surf.gii")
+    assert np.abs(reg - want).max() < 2e-5 and angles(reg, xyz).max() > 1e-4
+    plain, _, _ = registration.run_multiresolution(registration.ProductOps(ctx), in_xyz, tri, meshio.load_data(d + "in.func.gii", len(xyz)), in_xyz, tri,
+                                                   meshio.load_data(d + "ref.func.gii", len(xyz)), [dict(lv, rmode=3) for lv in levels], **run_kw)
+    assert np.abs(plain - want).max() > 1e-3  # the anatomical surfaces were used: the spherical regulariser ends elsewhere
+    one = subprocess.run(base + ["--inanat=" + d + "in.anat.surf.gii"], cwd=root, capture_output=True, text=True, timeout=600)
+    assert one.returncode != 0 and "must supply both anatomical meshes or none" in one.stderr
+    none = subprocess.run(base, cwd=root, capture_output=True, text=True, timeout=600)
+    assert none.returncode != 0 and "--regoption 5 requires anatomical meshes" in none.stderr
+
+
 @pytest.mark.parametrize("kind,D", [("ho_univariate", 1), ("ho_multivariate", 16), ("univariate", 1)])
 def test_fusion_driven_level_matches_oracle(ctx, kind, D):
     """The label loop of Fusion::optimize (I/Fusion/Fusion.h:136-229) over the triclique classes -- what every HCP configuration runs: per
