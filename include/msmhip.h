@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MSM_ABI_VERSION 8  /* 8 (round 4): msm_query_lanes, msm_resample_anatomy_grid, msm_cost_triplet_octets_prefetch / msm_cost_prefetch_stats, msm_group_export_subjects_dev / msm_group_import_subjects_dev / msm_group_setup_more_subjects added.  6 (round 3): msm_pairwise_icm, msm_ctx_time_queries / msm_ctx_query_kernel_ms, msm_group_time_moves / msm_group_move_kernels_ms,
+#define MSM_ABI_VERSION 9  /* 9 (round 4): msm_group_set_pair_layout.  8 (round 4): msm_query_lanes, msm_resample_anatomy_grid, msm_cost_triplet_octets_prefetch / msm_cost_prefetch_stats, msm_group_export_subjects_dev / msm_group_import_subjects_dev / msm_group_setup_more_subjects added.  6 (round 3): msm_pairwise_icm, msm_ctx_time_queries / msm_ctx_query_kernel_ms, msm_group_time_moves / msm_group_move_kernels_ms,
                              * msm_store_release_i64 / msm_load_acquire_i64 / msm_min_acquire_i64, msm_mesh_sphere_project_warp added; nothing removed or changed */
 
 #define MSM_OK 0
@@ -378,6 +378,12 @@ int msm_group_set_subject(msm_group *g, int32_t subject, msm_mesh *data_mesh, co
 int msm_group_reset_cpgrid(msm_group *g, int32_t subject, const double *xyz);
 /* m_labels = m_samples (M/DiscreteGroupModel.cpp:177); labels[0] is the sampling-grid centre */
 int msm_group_set_labels(msm_group *g, const double *labels, int32_t L);
+/* The order of the pair list -- of msm_group_get_pairs and of every pair index and pair range of this interface.  0 (default): estimate_pairs' own
+ * (subject A, control point, subject B: M/DiscreteGroupModel.cpp:37-55).  1: control point by control point along a space-filling curve, so that a
+ * contiguous range of the list is a region of the sphere: the layout for runs that shard the list over ranks (msm_group_fusion_move_dev), whose
+ * slices then read a part of every resampled map instead of whole maps.  Same set of pairs; the optimiser reads pairs[i] beside the i-th costs
+ * (I/Fusion/Fusion.h:157-196).  Takes effect at the next set-up. */
+int msm_group_set_pair_layout(msm_group *g, int32_t layout);
 /* setupCostFunction M/DiscreteGroupModel.cpp:163-196: estimate_pairs :37-55, get_spacings :123-139, get_rotations :77-86,
  * get_patch_data :88-121 */
 int msm_group_setup(msm_group *g);

@@ -485,6 +485,8 @@ public:
     void reset_meshspace(Mesh &source, const Matrix &features, int D, int num) { check(msm_group_set_subject(h_, num, source.handle(), features.data(), D)); }
     void reset_CPgrid(const Points &grid, int num) { check(msm_group_reset_cpgrid(h_, num, to_soa(grid).data())); }
     void set_labels(const Points &labels) { check(msm_group_set_labels(h_, to_soa(labels).data(), (int32_t)(labels.size() / 3))); }
+    // 0: the reference's list order; 1: control point by control point (the layout for lists sharded over ranks), msm_group_set_pair_layout
+    void set_pair_layout(int layout) { check(msm_group_set_pair_layout(h_, layout)); }
     void setupCostFunction() { check(msm_group_setup(h_)); }  // :163-196
     int getNumNodes() {
         int32_t n, p, t;

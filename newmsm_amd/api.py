@@ -750,6 +750,14 @@ class DiscreteGroupCostFunction:
         self.L = l.shape[1]
         check(lib().msm_group_set_labels(self.h, pl, self.L))
 
+    REFERENCE_ORDER, CP_MAJOR = 0, 1
+
+    def set_pair_layout(self, layout):
+        """the order of the pair list (getPairs and every pair index / range): REFERENCE_ORDER = estimate_pairs' own (subject A, control point, subject
+        B), CP_MAJOR = control point by control point along a space-filling curve -- a contiguous slice is then a region of the sphere (the layout
+        dist.sharded_group_setup chooses for more than one rank).  Takes effect at the next set-up (msm_group_set_pair_layout)."""
+        check(lib().msm_group_set_pair_layout(self.h, int(layout)))
+
     def setupCostFunction(self):
         check(lib().msm_group_setup(self.h))
         n, p, t = C.c_int32(), C.c_int32(), C.c_int32()

@@ -620,6 +620,20 @@ int launch_group_kept(msm_ctx *ctx, const int *order, int base, const double *ke
     return MSM_OK;
 }
 
+// the pair list in another order: out[i] = in[order[i]] (msm_group_set_pair_layout)
+__global__ __launch_bounds__(256) void k_group_permute_pairs(const int2 *__restrict__ in, const int *__restrict__ order, int n, int2 *__restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = in[order[i]];
+}
+
+int launch_group_permute_pairs(msm_ctx *ctx, const int *d_in, const int *d_order, int n, int *d_out) {
+    if (n <= 0) return MSM_OK;
+    hipLaunchKernelGGL(k_group_permute_pairs, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, reinterpret_cast<const int2 *>(d_in), d_order, n,
+                       reinterpret_cast<int2 *>(d_out));
+    MSM_HIP(hipGetLastError());
+    return MSM_OK;
+}
+
 int launch_group_triplet(msm_ctx *ctx, const GroupArgs &a, const int *qt, const int *qa, const int *qb, const int *qc, int n, double *out) {
     if (n <= 0) return MSM_OK;
     hipLaunchKernelGGL(k_group_triplet, dim3((n + 127) / 128), dim3(128), 0, ctx->stream, a, qt, qa, qb, qc, n, out);

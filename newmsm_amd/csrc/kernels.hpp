@@ -278,6 +278,7 @@ int launch_query_forest(msm_ctx *ctx, const ForestDev &f, int B, const double *d
 // subject b closest to control point v of subject a, Octree::get_closest_vertex_ID), in the reference's list order.  cp: component
 // c of control point v of subject s at cp[c * S * N + s * N + v].
 int launch_group_pairs(msm_ctx *ctx, const ForestDev &f, const double *d_cp, int S, int N, int *d_pairs);
+int launch_group_permute_pairs(msm_ctx *ctx, const int *d_in, const int *d_order, int n, int *d_out);
 // moved[((s * N + v) * L + l) * 3 ..] = rot[s * N + v] (row-major 3 x 3) * label l: the control points' candidate positions
 int launch_group_moved(msm_ctx *ctx, const double *d_rot, int nodes, const double *d_labels /* 3 x L SoA */, int L, double *d_moved);
 // the patch centres of one subject as k_range takes them: centres 3 x (N * L) SoA and the per-centre spacing

@@ -183,7 +183,7 @@ def _chunk_bounds(nmax, chunks):
     return [(edges[i], edges[i + 1]) for i in range(chunks) if edges[i + 1] > edges[i]]
 
 
-def sharded_group_setup(group, n_subjects, comm=None, chunks=None):
+def sharded_group_setup(group, n_subjects, comm=None, chunks=None, pair_layout=None):
     """Groupwise set-up with the subjects sharded over the ranks.
 
     `group` is a newmsm_amd.DiscreteGroupCostFunction.  Every rank runs the expensive per-subject work (get_patch_data,
@@ -194,8 +194,16 @@ def sharded_group_setup(group, n_subjects, comm=None, chunks=None):
     per call (msm_group_export_subjects_dev / msm_group_import_subjects_dev: one synchronisation per call, range checks on the device), and
     the shard is set up and exchanged in `chunks` pieces (default 2 from four subjects per rank on; MSMHIP_GROUP_CHUNKS): the all-gathers of
     one piece are issued asynchronously (RCCL's own stream) and run over xGMI while the next piece is set up; everything is waited for once,
-    before the imports.  gloo (CPU rehearsal): one piece, host tensors through the host entry points."""
+    before the imports.  gloo (CPU rehearsal): one piece, host tensors through the host entry points.
+
+    pair_layout: the order of the group's pair list (DiscreteGroupCostFunction.set_pair_layout).  None: control-point major when there is more than
+    one rank -- ShardedMove gives every rank a contiguous slice of the list, which is then a region of the sphere (an eighth of every resampled map)
+    instead of eight subjects' rows of it (all of their maps and most of everyone else's) -- and the group's current layout otherwise."""
     c = _comm(comm)
+    if pair_layout is None and c.world > 1 and hasattr(group, "set_pair_layout"):
+        pair_layout = group.CP_MAJOR
+    if pair_layout is not None:
+        group.set_pair_layout(pair_layout)
     mine = list(shard(n_subjects, c.rank, c.world))
     if c.dist is None:
         group.setup_subjects(mine)

@@ -245,9 +245,15 @@ g, keep = make()
 mine = D.sharded_group_setup(g, S, dist)
 rng = np.random.default_rng(3)
 p = rng.integers(0, g.P, 300).astype(np.int32); la = rng.integers(0, g.L, 300).astype(np.int32); lb = rng.integers(0, g.L, 300).astype(np.int32)
-sharded = g.computePairwiseCost(p, la, lb)
 g1, keep1 = make(); g1.setupCostFunction()
-single = g1.computePairwiseCost(p, la, lb)
+# with more than one rank the sharded group's pair list is control-point major (a contiguous slice = a region of the sphere): the same pairs as the
+# reference's list in another order -- `pos`: where pair i of the sharded group's list sits in the single-rank group's
+pairs_s, pairs_1 = g.getPairs(), g1.getPairs()
+where = {(int(a), int(b)): i for i, (a, b) in enumerate(pairs_1)}
+pos = np.array([where[(int(a), int(b))] for a, b in pairs_s], dtype=np.int64)
+layout_ok = bool((world == 1) == np.array_equal(pos, np.arange(g.P))) and len(set(pos.tolist())) == g.P
+sharded = g.computePairwiseCost(p, la, lb)
+single = g1.computePairwiseCost(pos[p].astype(np.int32), la, lb)
 # a label step with the pair and triplet lists sharded over the two ranks, gathered on rank 0 (M/DiscreteGroupCostFunction.cpp:54-98)
 lab = rng.integers(0, g.L, g.num_nodes).astype(np.int32)
 move_ok, transports = True, []
@@ -259,7 +265,7 @@ for transport in (None, "gather"):   # None: the ranks share a node -> every ran
         q, o = sm.move(lab_s, label)
         q1, o1 = g1.fusionMove(lab_s, label)
         if rank == 0:
-            move_ok = move_ok and bool(np.array_equal(q, q1, equal_nan=True) and np.array_equal(o, o1))
+            move_ok = move_ok and bool(np.array_equal(q, q1[pos], equal_nan=True) and np.array_equal(o, o1))
     sm.close()
 # the single-process transport: pinned arrays of this process
 q, o = D.ShardedMove(g1, None).move(lab, 4)
@@ -267,7 +273,7 @@ q1, o1 = g1.fusionMove(lab, 4)
 move_ok = move_ok and bool(np.array_equal(q, q1, equal_nan=True) and np.array_equal(o, o1)) and transports == ["shm", "gather"]
 tmpl = D.group_template_update(np.stack([keep[1 + s].get_coords() for s in mine]), None, dist)
 dist.barrier()
-print(json.dumps({"rank": rank, "mine": mine, "equal": bool(np.array_equal(sharded, single, equal_nan=True)), "finite": int(np.isfinite(single).sum()), "move_ok": move_ok,
+print(json.dumps({"rank": rank, "mine": mine, "equal": bool(np.array_equal(sharded, single, equal_nan=True)) and layout_ok, "finite": int(np.isfinite(single).sum()), "move_ok": move_ok,
                   "template_radius_ok": bool(np.allclose(np.linalg.norm(tmpl["template"], axis=1), 100.0)), "n": tmpl["n_subjects"]}))
 dist.destroy_process_group()
 '''
@@ -604,3 +610,47 @@ def test_group_multiresolution_matches_oracle(ctx):
         assert np.abs(a - b).max() < 1e-8
     assert got[1][0].shape == (S, 642, 3) and got[1][1].shape == (S, 2562, 3)
     assert {"metric_resample", "smooth_data", "sphere_project_warp", "unfold", "setup", "fusion_moves"} <= set(t)
+
+
+def test_pair_layout_control_point_major(ctx):
+    """msm_group_set_pair_layout: the pair list control point by control point (the layout of runs that shard the list over ranks) holds the pairs of
+    estimate_pairs (M/DiscreteGroupModel.cpp:37-55) in another order -- every control point's S (S - 1) / 2 subject pairs together --, and every
+    evaluator addressed through it gives bit for bit what the reference's order gives for the same pair: single costs, whole label steps (first
+    visit, a changed labeling, second visit: the kept-cost caches follow the layout), slices of a step; back to the reference's order on request."""
+    g, og, keep = build(ctx, S=4, data_order=4, cp_order=2)
+    ref_pairs = g.getPairs().copy()
+    assert np.array_equal(ref_pairs, og.pairs())
+    rng = np.random.default_rng(11)
+    labs = [rng.integers(0, g.L, g.num_nodes).astype(np.int32)]
+    labs.append(np.where(rng.random(g.num_nodes) < 0.2, rng.integers(0, g.L, g.num_nodes), labs[0]).astype(np.int32))
+    steps = [(labs[0], 3), (labs[1], 5), (labs[1], 3)]
+    want = [tuple(np.array(x) for x in g.fusionMove(l, k)) for l, k in steps]
+    g.set_pair_layout(g.CP_MAJOR)
+    g.setupCostFunction()
+    pairs = g.getPairs()
+    where = {(int(a), int(b)): i for i, (a, b) in enumerate(ref_pairs)}
+    pos = np.array([where[(int(a), int(b))] for a, b in pairs])
+    assert sorted(pos.tolist()) == list(range(g.P)) and not np.array_equal(pos, np.arange(g.P))
+    per_cp = 4 * 3 // 2  # the subject pairs of one control point are neighbours in the list
+    first = pairs[:, 0] % g.N
+    assert all(len(set(first[i:i + per_cp].tolist())) == 1 for i in range(0, g.P, per_cp)) and len(set(first[::per_cp].tolist())) == g.N
+    for (l, k), (q0, o0) in zip(steps, want):
+        q, o = g.fusionMove(l, k)
+        assert np.array_equal(q, q0[pos], equal_nan=True) and np.array_equal(o, o0)
+    p = rng.integers(0, g.P, 200).astype(np.int32)
+    la, lb = rng.integers(0, g.L, 200).astype(np.int32), rng.integers(0, g.L, 200).astype(np.int32)
+    got = g.computePairwiseCost(p, la, lb)
+    assert np.allclose(got, [og.pairwise(int(pos[i]), int(a), int(b)) for i, a, b in zip(p, la, lb)], rtol=RTOL, atol=ATOL, equal_nan=True)
+    # a slice of the list = a range of control points: the second half of a step, delivered into pinned host memory at the slice's position
+    half = (g.P // 2, g.P)
+    out_q, out_t = ctx.host_array((g.P, 4)), ctx.host_array((g.T, 8))
+    out_q[:] = -1.0
+    g.fusionMove_dev(labs[1], 5, half, (0, g.T), out_q.ctypes.data + 32 * half[0], out_t.ctypes.data)
+    assert np.array_equal(out_q[half[0]:], want[1][0][pos][half[0]:], equal_nan=True) and (out_q[: half[0]] == -1.0).all() and np.array_equal(out_t, want[1][1])
+    g.set_pair_layout(g.REFERENCE_ORDER)
+    g.setupCostFunction()
+    assert np.array_equal(g.getPairs(), ref_pairs)
+    q, o = g.fusionMove(*steps[0])
+    assert np.array_equal(q, want[0][0], equal_nan=True) and np.array_equal(o, want[0][1])
+    with pytest.raises(M.MsmError):
+        g.set_pair_layout(2)

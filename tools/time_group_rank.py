@@ -8,7 +8,8 @@ except the wire time of the collectives.  Rank `r` of `W` at S subjects, ico<dat
   finalize    pointer tables, patch statistics                                                           msm_group_finalize
   step        a label step on the rank's slice of the pair / triplet lists into pinned host memory       msm_group_fusion_move_dev
 
-usage: time_group_rank.py [S] [W] [r] [data_order cp_order]     (MSMHIP_TIMING=1 prints the library's own phase timings)"""
+usage: time_group_rank.py [S] [W] [r] [data_order cp_order]     (MSMHIP_TIMING=1 prints the library's own phase timings; LAYOUT=0: the pair list in the
+reference's order instead of control-point major, the layout dist.sharded_group_setup chooses for W > 1)"""
 import os
 import sys
 import time
@@ -30,7 +31,9 @@ mine = list(D.shard(S, r, W))
 others = [s for s in range(S) if s not in mine]
 
 # the whole group once (stands in for the other ranks): its subjects exported into device tensors = what the all-gathers deliver
+LAYOUT = int(os.environ.get("LAYOUT", "1"))
 full, keep_full = problem.build_group(ctx, S, do, co, D=2)
+full.set_pair_layout(LAYOUT)
 full.setupCostFunction()
 L, Dm, V, Mrows = full.L, full.D, full._keep["template"].V, full.N * full.L + 1
 counts = [full.subject_index_count(s) for s in range(S)]
@@ -43,6 +46,7 @@ for s in range(S):
 torch.cuda.synchronize()
 
 g, keep = problem.build_group(ctx, S, do, co, D=2, subjects=mine)
+g.set_pair_layout(LAYOUT)
 sendF = torch.zeros((len(mine), L, Dm, V), dtype=torch.float64, device="cuda:0")
 sendpp = torch.zeros((len(mine), Mrows), dtype=torch.int32, device="cuda:0")
 sendpi = torch.zeros((len(mine), imax), dtype=torch.int32, device="cuda:0")
@@ -77,7 +81,7 @@ def iteration(report):
     g.finalize()
     t["finalize"] = time.perf_counter() - t0
     if report:
-        print("rank %d of %d, S = %d, ico%d / ico%d: %d subjects of its own, set up and exchanged in %d piece(s)" % (r, W, S, do, co, len(mine), len(bounds)))
+        print("rank %d of %d, S = %d, ico%d / ico%d: %d subjects of its own, set up and exchanged in %d piece(s); pair list %s" % (r, W, S, do, co, len(mine), len(bounds), "control-point major" if LAYOUT else "in the reference's order"))
         for k, v in t.items():
             print("  %-28s %7.2f ms" % (k, v * 1e3))
         print("  %-28s %7.2f ms   (all-gather payload of the group: %.2f GB)" % ("set-up, this rank", sum(t.values()) * 1e3, (F.numel() * 8 + pp.numel() * 4 + pi.numel() * 4) / 1e9), flush=True)
