@@ -125,6 +125,9 @@ inline std::vector<int32_t> sharded_group_setup(msm_group *g, const Comm &c) {
     shard(S, c.rank(), c.world(), lo, hi);
     std::vector<int32_t> mine;
     for (int s = lo; s < hi; ++s) mine.push_back(s);
+    // more than one rank: the pair list control point by control point, so that the contiguous slice of it a rank evaluates in every label step is a
+    // region of the sphere (msmhip.h: msm_group_set_pair_layout; newmsm_amd/dist.py does the same)
+    if (c.world() > 1) check_msm(msm_group_set_pair_layout(g, 1), "msm_group_set_pair_layout");
     check_msm(msm_group_setup_subjects(g, mine.data(), (int32_t)mine.size()), "msm_group_setup_subjects");
     if (c.world() > 1) {
         int nmax = 0;
