@@ -33,9 +33,14 @@ LEVEL_EXE = os.path.join(ROOT, "tests", "cpp", "level_driver")
 from newmsm_amd.bag import read_bag, write_bag  # noqa: E402  (the container of the compiled programs' arrays)
 
 
+GROUP_SRC = os.path.join(ROOT, "tests", "cpp", "group_driver.cpp")
+GROUP_EXE = os.path.join(ROOT, "tests", "cpp", "group_driver")
+
+
 def test_header_compiles_without_gpu(built):
     build_host_mirror()  # -Wall -Wextra -Werror: the header is clean C++17 and needs no HIP headers
     build_cpp(LEVEL_SRC, LEVEL_EXE)
+    build_cpp(GROUP_SRC, GROUP_EXE)  # include/msmhip_group_registration.hpp
 
 
 @pytest.mark.gpu
@@ -364,3 +369,41 @@ def test_cpp_run_multiresolutions_equals_python_loop(built, ctx, tmp_path, name,
     assert np.allclose(got["sphere_reg"].reshape(-1, 3), sphere, rtol=0, atol=1e-10)
     assert any(np.any(l != 0) for l in labs)   # the registration moved something
     assert line["moves"] == line["calls"]["fusion_moves"] > 0 and line["moves_timed"] == line["moves"] and line["move_kernel_us"] > 0
+
+
+@pytest.mark.gpu
+def test_cpp_group_multiresolutions_equals_python_loop(built, ctx, tmp_path):
+    """run_group_multiresolutions of include/msmhip_group_registration.hpp (compiled, no Python: tests/cpp/group_driver.cpp) against
+    newmsm_amd/group_registration.py: run_group_multiresolution -- Group_Mesh_registration's level loop (M/group_mesh_registration.cpp:26-133) with the
+    host side in C++: two levels, three subjects on irregular spheres, a --mask, variance normalisation; the same library calls in the same order, so
+    the labelings of all four iterations are identical and the registered spheres agree to rounding of the energy sums (which decide nothing here)."""
+    import newmsm_amd as M
+    from newmsm_amd import group_registration as GR, synthetic
+
+    build_cpp(GROUP_SRC, GROUP_EXE)
+    S, D = 3, 2
+    xyz, tri = M.make_mesh_from_icosa(4)
+    txyz = synthetic.known_warp(xyz, seed=33, rot_deg=7.0, amp=1.5)
+    meshes = [(synthetic.known_warp(xyz, seed=40 + s, rot_deg=0.0, amp=1.0), tri) for s in range(S)]
+    datas = [synthetic.features(synthetic.known_warp(meshes[s][0], seed=90 + s, rot_deg=3.0, amp=2.0), D, seed=5) for s in range(S)]
+    levels = [dict(data_order=3, cp_order=1, sg_order=3, iters=2, simmeasure=2, cost_params=dict(lambda_=1e-3), sigma_in=2.0),
+              dict(data_order=4, cp_order=2, sg_order=4, iters=2, simmeasure=2, cost_params=dict(lambda_=1e-3), sigma_in=0.0)]
+    mask = (np.random.default_rng(1).random(len(xyz)) > 0.2).astype(np.float64)
+    fin, fout = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+    arrays = dict(sizes=np.array([S, D, len(levels), 1, 1, 1], dtype=np.int32), template_xyz=txyz, template_tri=tri.astype(np.int32), mask=mask,
+                  level_orders=np.array([[lv["data_order"], lv["cp_order"], lv["sg_order"], lv["iters"], lv["simmeasure"]] for lv in levels], dtype=np.int32),
+                  level_params=np.array([[lv["sigma_in"], lv["cost_params"]["lambda_"]] for lv in levels]))
+    for s in range(S):
+        arrays.update({"mesh%d_xyz" % s: meshes[s][0], "mesh%d_tri" % s: tri.astype(np.int32), "data%d" % s: datas[s]})
+    write_bag(fin, **arrays)
+    run = subprocess.run([GROUP_EXE, fin, fout], capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0, run.stderr + run.stdout
+    got = read_bag(fout)
+    labs = []
+    want = GR.run_group_multiresolution(GR.ProductGroupOps(ctx), meshes, datas, txyz, tri, levels, mask=mask, varnorm=True, fixnan=True, labelings_out=labs)
+    assert len(labs) == 4 and np.array_equal(got["labelings"], np.concatenate(labs)) and any(l.any() for l in labs[2:])
+    assert np.allclose(got["energies"], np.concatenate(want[2]), rtol=1e-12, atol=0)
+    for s in range(S):
+        assert np.allclose(got["sphere_reg%d" % s].reshape(-1, 3), want[0][s], rtol=0, atol=1e-10)
+        assert np.allclose(got["level_reg%d" % s].reshape(-1, 3), want[1][-1][s], rtol=0, atol=1e-10)
+        assert np.abs(want[0][s] - meshes[s][0]).max() > 1e-3
