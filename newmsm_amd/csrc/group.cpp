@@ -111,7 +111,8 @@ struct msm_group {
         DevBuf<uint32_t> d_slots;
         DevBuf<int> d_counts;
     };
-    Pipe pipe[2];
+    static constexpr int kMaxPipes = 4;
+    Pipe pipe[kMaxPipes];
     std::mutex lanes_mu;  // the per-label lanes (the path of a subject whose forest could not be built) are shared by the pipelines
     DevBuf<double> d_move_out;           // msm_group_fusion_move: the step's 4 P + 8 T results before they go to the host
     std::vector<int32_t> pair_order;     // the pair list in processing order (control points along a space-filling curve)
@@ -1028,33 +1029,36 @@ static int group_setup_pipeline(msm_group *g, const int32_t *subjects, int n) {
         if (st) return st;
     }
     MSM_HIP(hipStreamSynchronize(ctx->stream));
-    static const int pipes_env = [] { const char *e = std::getenv("MSMHIP_GROUP_PIPES"); return e ? std::max(1, std::min(2, std::atoi(e))) : 2; }();
-    const int npipes = n >= 4 ? pipes_env : 1;
+    static const int pipes_env = [] { const char *e = std::getenv("MSMHIP_GROUP_PIPES"); return e ? std::max(1, std::min(msm_group::kMaxPipes, std::atoi(e))) : 2; }();
+    const int npipes = std::max(1, std::min(pipes_env, n / 2));
     g->pipe[0].main = ctx;
-    if (npipes > 1 && !g->pipe[1].main) {
-        g->pipe[1].main = msm_ctx_create(ctx->device);
-        if (!g->pipe[1].main) return MSM_ERR_HIP;
-        g->pipe[1].own_main = true;
-    }
+    for (int k = 1; k < npipes; ++k)
+        if (!g->pipe[k].main) {
+            g->pipe[k].main = msm_ctx_create(ctx->device);
+            if (!g->pipe[k].main) return MSM_ERR_HIP;
+            g->pipe[k].own_main = true;
+        }
     for (int k = 0; k < npipes; ++k)
         if (!g->pipe[k].batch.ctx) {
             g->pipe[k].batch.ctx = msm_ctx_create(ctx->device);
             if (!g->pipe[k].batch.ctx) return MSM_ERR_HIP;
         }
-    std::vector<int> share[2];
+    std::vector<int> share[msm_group::kMaxPipes];
     for (int i = 0; i < n; ++i) share[i % npipes].push_back(subjects[i]);
     if (npipes == 1) return run_setup_pipe(g, g->pipe[0], 0, share[0]);
-    int st1 = MSM_OK;
-    std::string msg1;
-    std::thread second([&] {
-        st1 = run_setup_pipe(g, g->pipe[1], 1, share[1]);
-        if (st1) msg1 = msm_last_error();
-    });
-    const int st0 = run_setup_pipe(g, g->pipe[0], 0, share[0]);
-    const std::string msg0 = st0 ? std::string(msm_last_error()) : std::string();
-    second.join();
-    if (st0) return fail(st0, "%s", msg0.c_str());
-    if (st1) return fail(st1, "%s", msg1.c_str());
+    int stk[msm_group::kMaxPipes] = {MSM_OK, MSM_OK, MSM_OK, MSM_OK};
+    std::string msgk[msm_group::kMaxPipes];
+    std::vector<std::thread> others;
+    for (int k = 1; k < npipes; ++k)
+        others.emplace_back([&, k] {
+            stk[k] = run_setup_pipe(g, g->pipe[k], k, share[k]);
+            if (stk[k]) msgk[k] = msm_last_error();
+        });
+    stk[0] = run_setup_pipe(g, g->pipe[0], 0, share[0]);
+    if (stk[0]) msgk[0] = msm_last_error();
+    for (auto &t : others) t.join();
+    for (int k = 0; k < npipes; ++k)
+        if (stk[k]) return fail(stk[k], "%s", msgk[k].c_str());
     return MSM_OK;
 }
 
