@@ -117,6 +117,29 @@ for k in range(n):
             why.append("label step %d against the batch evaluation" % label)
         ok = ok and step_ok
         lab = np.where(rng.random(g.num_nodes) < 0.2, label, lab).astype(np.int32)
+    if rng.integers(0, 3) == 0:
+        # round 4: the pair list control point by control point (msm_group_set_pair_layout, the layout of sharded runs): the same pairs, and label steps
+        # -- first visits, a changed labeling, second visits with the kept costs -- equal to the reference order's under the permutation, bit for bit
+        ref_pairs = pr.copy()
+        steps, lab2 = [], lab.copy()
+        for label in (l1, l2, l1):
+            steps.append((lab2.copy(), label))
+            lab2 = np.where(rng.random(g.num_nodes) < 0.2, label, lab2).astype(np.int32)
+        want_q = [np.array(g.fusionMove(*st)[0]) for st in steps]
+        g.set_pair_layout(g.CP_MAJOR)
+        g.setupCostFunction()
+        where = {(int(a), int(b)): i for i, (a, b) in enumerate(ref_pairs)}
+        try:
+            pos = np.array([where[(int(a), int(b))] for a, b in g.getPairs()])
+            lay_ok = sorted(pos.tolist()) == list(range(g.P))
+        except KeyError:
+            lay_ok = False
+        if lay_ok:
+            for st, wq in zip(steps, want_q):
+                lay_ok = lay_ok and np.array_equal(g.fusionMove(*st)[0], wq[pos], equal_nan=True)
+        if not lay_ok:
+            why.append("control-point-major pair list")
+        ok = ok and lay_ok
     if not ok:
         bad += 1
     print("ok" if ok else "MISMATCH", k, "S=%d data=%d cp=%d D=%d sim=%d mask=%s pct=%.2f lanes=%s" % (S, data_order, cp_order, D, sim, mask, pct, os.environ["MSMHIP_GROUP_PAIR_LANES"]),
