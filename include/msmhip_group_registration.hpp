@@ -9,6 +9,7 @@
 #ifndef MSMHIP_GROUP_REGISTRATION_HPP
 #define MSMHIP_GROUP_REGISTRATION_HPP
 
+#include "msmhip_config.hpp"
 #include "msmhip_registration.hpp"
 
 namespace msmhip {
@@ -184,6 +185,31 @@ inline GroupMultiresResult run_group_multiresolutions(Context &ctx, const std::v
     for (int s = 0; s < S; ++s)
         res.sphere_regs.push_back(PhaseClock::timed(clock, "sphere_project_warp", [&] { return sphere_project_warp(meshes[(size_t)s].first, last, prev_regs[(size_t)s]); }));
     return res;
+}
+
+// The levels of a --groupwise run from a configuration (msmhip_config.hpp: parse_config), as Group_Mesh_registration reads it: every level DISCRETE
+// ("AFFINE/RIGID registration is not supported in groupwise mode.", M/group_mesh_registration.cpp:29-30), the optimiser HOCR (:87); the model has its own
+// regulariser, so --regoption is not looked at (the twin of newmsm_amd/config.py: levels_from_config(..., groupwise=True)).
+inline std::vector<GroupLevelSpec> group_levels_from_config(const Config &c, bool *varnorm = nullptr) {
+    if (c.IN || c.INc) throw ConfigError("--IN / --INc (histogram matching through FSL's MISCMATHS::Histogram, M/reg_tools.cpp:745-802) is not available");
+    if (c.excl) throw ConfigError("--excl (exclusion masks from the cut thresholds) is not wired into the level loop");
+    for (const std::string &m : c.opt)
+        if (m == "RIGID" || m == "AFFINE") throw ConfigError("AFFINE/RIGID registration is not supported in groupwise mode.");
+    if (c.dopt != "HOCR") throw ConfigError("Groupwise mode is only supported in the HOCR version of MSM.");
+    if (varnorm) *varnorm = c.VN;
+    std::vector<GroupLevelSpec> levels;
+    for (size_t i = 0; i < c.opt.size(); ++i) {
+        if (c.opt[i] != "DISCRETE") continue;
+        GroupLevelSpec lv;
+        lv.data_order = c.datagrid[i], lv.cp_order = c.CPgrid[i], lv.sigma_in = c.sigma_in[i];
+        GroupLevelOptions &o = lv.options;
+        o.sg_order = c.SGgrid[i], o.iters = c.it[i];
+        o.cost.simmeasure = c.simval[i], o.cost.fixnan = c.fixnan, o.cost.lambda = c.lambda[i];
+        o.cost.shearmodulus = c.shearmod, o.cost.bulkmodulus = c.bulkmod, o.cost.kexponent = c.k_exponent, o.cost.exponent = c.regexp;
+        o.cost.range = c.cprange, o.cost.percentile = c.percentile;
+        levels.push_back(lv);
+    }
+    return levels;
 }
 
 }  // namespace msmhip

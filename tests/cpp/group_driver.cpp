@@ -1,7 +1,8 @@
 // group_driver.cpp -- run_group_multiresolutions of include/msmhip_group_registration.hpp as a compiled program (g++ + libmsmhip.so, no Python in
 // the loop), for comparison with newmsm_amd/group_registration.py on the same inputs (tests/test_cpp_host.py).
 //
-//   group_driver <in.bin> <out.bin>      file format: host_mirror.cpp
+//   group_driver <in.bin> <out.bin> [config]     file format: host_mirror.cpp; config: a newmsm configuration file -- the levels then come from it
+//                                                (group_levels_from_config) instead of from level_orders / level_params
 // in:  sizes [S, D, levels, varnorm, fixnan, masked], per subject mesh<i>_xyz / mesh<i>_tri / data<i>, template_xyz / template_tri, mask,
 //      level_orders [data_order, cp_order, sg_order, iters, simval] per level, level_params [sigma_in, lambda] per level
 #include <cstdio>
@@ -43,7 +44,7 @@ static void put(std::ofstream &out, const std::string &name, const char *dtype, 
 }
 
 int main(int argc, char **argv) {
-    if (argc != 3) return 2;
+    if (argc != 3 && argc != 4) return 2;
     try {
         read_bag(argv[1]);
         const int S = I["sizes"][0], D = I["sizes"][1], nlevels = I["sizes"][2];
@@ -65,9 +66,17 @@ int main(int argc, char **argv) {
             lv.options.cost.lambda = F["level_params"][2 * l + 1];
             lv.options.cost.fixnan = fixnan;
         }
+        bool vn = varnorm;
+        if (argc == 4) {
+            std::ifstream cf(argv[3]);
+            if (!cf) throw std::runtime_error(std::string("cannot open ") + argv[3]);
+            std::stringstream text;
+            text << cf.rdbuf();
+            levels = group_levels_from_config(parse_config(text.str()), &vn);
+        }
         Context ctx(0);
         PhaseClock clock;
-        const GroupMultiresResult r = run_group_multiresolutions(ctx, meshes, datas, D, F["template_xyz"], I["template_tri"], levels, varnorm, masked ? &F["mask"] : nullptr, &clock);
+        const GroupMultiresResult r = run_group_multiresolutions(ctx, meshes, datas, D, F["template_xyz"], I["template_tri"], levels, vn, masked ? &F["mask"] : nullptr, &clock);
         std::ofstream out(argv[2], std::ios::binary);
         for (int s = 0; s < S; ++s) {
             put(out, "sphere_reg" + std::to_string(s), "f8", r.sphere_regs[(size_t)s]);

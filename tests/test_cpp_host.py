@@ -372,11 +372,13 @@ def test_cpp_run_multiresolutions_equals_python_loop(built, ctx, tmp_path, name,
 
 
 @pytest.mark.gpu
-def test_cpp_group_multiresolutions_equals_python_loop(built, ctx, tmp_path):
+@pytest.mark.parametrize("levels_from", ["arrays", "config"])
+def test_cpp_group_multiresolutions_equals_python_loop(built, ctx, tmp_path, levels_from):
     """run_group_multiresolutions of include/msmhip_group_registration.hpp (compiled, no Python: tests/cpp/group_driver.cpp) against
     newmsm_amd/group_registration.py: run_group_multiresolution -- Group_Mesh_registration's level loop (M/group_mesh_registration.cpp:26-133) with the
     host side in C++: two levels, three subjects on irregular spheres, a --mask, variance normalisation; the same library calls in the same order, so
-    the labelings of all four iterations are identical and the registered spheres agree to rounding of the energy sums (which decide nothing here)."""
+    the labelings of all four iterations are identical and the registered spheres agree to rounding of the energy sums (which decide nothing here).
+    "config": the levels of both runs come from a configuration text -- group_levels_from_config in C++, config.levels_from_config(groupwise=True) here."""
     import newmsm_amd as M
     from newmsm_amd import group_registration as GR, synthetic
 
@@ -396,11 +398,24 @@ def test_cpp_group_multiresolutions_equals_python_loop(built, ctx, tmp_path):
     for s in range(S):
         arrays.update({"mesh%d_xyz" % s: meshes[s][0], "mesh%d_tri" % s: tri.astype(np.int32), "data%d" % s: datas[s]})
     write_bag(fin, **arrays)
-    run = subprocess.run([GROUP_EXE, fin, fout], capture_output=True, text=True, timeout=600)
+    cmd, kw = [GROUP_EXE, fin, fout], dict(varnorm=True, fixnan=True)
+    if levels_from == "config":
+        from newmsm_amd import config
+
+        text = ("--simval=2,2\n--sigma_in=2,0\n--lambda=0.001,0.001\n--it=2,2\n--opt=DISCRETE,DISCRETE\n--CPgrid=1,2\n--SGgrid=3,4\n--datagrid=3,4\n--dopt=HOCR\n--VN\n--fixnan\n"
+                "--shearmod=0.4\n--bulkmod=1.6\n")
+        conf = str(tmp_path / "conf")
+        with open(conf, "w") as f:
+            f.write(text)
+        cmd.append(conf)
+        cfg = config.parse_config(text)
+        levels, run_kw, _ = config.levels_from_config(cfg, D, groupwise=True)
+        kw = dict(fixnan=cfg["fixnan"], **run_kw)
+    run = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert run.returncode == 0, run.stderr + run.stdout
     got = read_bag(fout)
     labs = []
-    want = GR.run_group_multiresolution(GR.ProductGroupOps(ctx), meshes, datas, txyz, tri, levels, mask=mask, varnorm=True, fixnan=True, labelings_out=labs)
+    want = GR.run_group_multiresolution(GR.ProductGroupOps(ctx), meshes, datas, txyz, tri, levels, mask=mask, labelings_out=labs, **kw)
     assert len(labs) == 4 and np.array_equal(got["labelings"], np.concatenate(labs)) and any(l.any() for l in labs[2:])
     assert np.allclose(got["energies"], np.concatenate(want[2]), rtol=1e-12, atol=0)
     for s in range(S):
