@@ -293,6 +293,38 @@ def bench_registration_msmall(ctx, check=True):
     return out
 
 
+def bench_registration_gmsm(ctx, S=8, iters=2):
+    """A groupwise registration as its caller loop runs it (BASELINE config 5's shape at a size a default bench run affords): Group_Mesh_registration::
+    run_multiresolutions (M/group_mesh_registration.cpp:26-133) over newmsm_amd/group_registration.py -- per level the featurespace of all S subjects,
+    from level 2 on project_CPgrid per subject, per iteration setupCostFunction, 2 x L label steps (4 P pair + 8 T triplet costs each), applyLabeling,
+    unfold / warp / unfold per subject.  The `gmsm` object times the cost-function side at S = 64; this one is the whole loop at S = 8."""
+    import numpy as np
+
+    import newmsm_amd as M
+    from newmsm_amd import group_registration as GR
+    from newmsm_amd import synthetic
+
+    xyz, tri = M.make_mesh_from_icosa(6)
+    txyz = synthetic.known_warp(xyz, seed=33, rot_deg=7.0, amp=1.5)  # (an irregular template: DESIGN.md section 3)
+    meshes = [(synthetic.known_warp(xyz, seed=40 + s, rot_deg=0.0, amp=1.0), tri) for s in range(S)]
+    datas = [synthetic.features(synthetic.known_warp(meshes[s][0], seed=90 + s, rot_deg=3.0, amp=2.0), 2, seed=5) for s in range(S)]
+    levels = [dict(data_order=d, cp_order=c, sg_order=c + 2, iters=iters, simmeasure=2, sigma_in=sg, cost_params=dict(lambda_=1.0, mu=0.4, kappa=1.6))
+              for d, c, sg in ((4, 2, 4.0), (5, 3, 2.0), (6, 4, 1.0))]
+    ops = GR.ProductGroupOps(ctx)
+    for _ in range(2):  # the first run pays for allocations
+        clock, labs = {}, []
+        t0 = time.perf_counter()
+        regs, _, energies = GR.run_group_multiresolution(ops, meshes, datas, txyz, tri, levels, varnorm=True, fixnan=True, timings=clock, labelings_out=labs)
+        wall = time.perf_counter() - t0
+    moved = max(float(np.abs(regs[s] - meshes[s][0]).max()) for s in range(S))
+    return {"wall_s": wall, "path_s": sum(v for k, v in clock.items() if k != "optimiser"), "phases_s": {k: round(v, 4) for k, v in sorted(clock.items())},
+            "subjects": S, "label_steps": int(sum(2 * 19 for _ in labs)), "nodes_that_took_a_label": int(sum(int(np.count_nonzero(l)) for l in labs)),
+            "largest_move_mm": moved, "energies": [[round(e, 6) for e in lv] for lv in energies],
+            "workload": "run_multiresolutions of a groupwise registration: %d synthetic subjects (D=2) on ico6 spheres of their own, an irregular ico6 template, levels data ico4/5/6 / "
+                        "control ico2/3/4 (sigma 4/2/1, --VN --fixnan, lambda 1.0: with the stand-in solve a weaker regulariser folds the meshes, and unfold's up to 1 000 repair passes per mesh -- M/reg_tools.cpp:59-178 -- take over the run), %d iteration(s) per level" % (S, iters),
+            "optimiser": "the label loop of Fusion::optimize with the stand-in binary solve (msm_fusion_icm_step), as in registration_msmall; its time is wall_s - path_s"}
+
+
 BASIC_FUSION_CONFIG = """# three DISCRETE levels shaped like config/basic_configs/config_standard_MSM_strain (its AFFINE level left out), driven as --dopt=HOCR drives BASELINE config 2
 --opt=DISCRETE,DISCRETE,DISCRETE
 --simval=2,2,2
@@ -793,6 +825,10 @@ def main():
                                                                         "sigma 4/2/1, --VN), 3 iterations each, sulc-like D=1, ico6 spheres, --dopt=HOCR --regoption=3 (stand-in solve)")
                 out["registration_msmall_cpp"] = bench_registration_cpp(ctx, _config.PRESETS["HCP_MSMAll"], 32, "run_multiresolutions, the HCP MSMAll schedule "
                                                                         "(config text through the reference's grammar), ho_multivariate D=32, ico6 spheres: 40 set-ups + 1 520 fusion moves (stand-in solve)")
+                try:
+                    out["registration_gmsm"] = bench_registration_gmsm(ctx)
+                except Exception as e:  # reported, not fatal
+                    out["registration_gmsm"] = {"error": repr(e)}
                 out["gmsm"] = bench_gmsm(ctx, args.subjects, comm, change=args.label_change)
                 out["gmsm"]["template_allreduce"] = template_allreduce()
         if world == 1 and not args.no_cpu_baseline:
