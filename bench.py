@@ -445,20 +445,22 @@ def gmsm_iteration(ctx, S, data_order, cp_order, comm, label_steps, change=0.10)
     # the library then has the (label, label) pair costs of the first visit.  The timed steps keep that ratio: label_steps / 2 labels, twice.
     half = max(1, label_steps // 2)
     proposed = [(2 + i % half) % g.L for i in range(2 * half)]
+    # HIP events around each step's kernels (on the context's stream; two event records per step) in the SAME steps: the GPU time of the mix of first and
+    # second visits that the delivered time is measured on
+    g.time_moves(True)
     comm.barrier()
     t0 = time.perf_counter()
+    each, kms = [], []
     for i in range(2 * half):
+        t1 = time.perf_counter()
         q, o = mover.move(labs[i % len(labs)], proposed[i])
+        each.append(time.perf_counter() - t1)
+        kms.append(g.move_kernels_ms())
     comm.barrier()
     step_s = (time.perf_counter() - t0) / (2 * half)
-    # the same steps once more with HIP events around each step's kernels (on the context's stream): the GPU time of a label step
-    g.time_moves(True)
-    kms = []
-    for i in range(2 * half):
-        mover.move(labs[i % len(labs)], proposed[i])
-        kms.append(g.move_kernels_ms())
     g.time_moves(False)
-    sizes = dict(L=g.L, pairs=g.P, triplets=g.T, nodes=g.num_nodes, step_kernels_s=float(np.mean(kms)) * 1e-3 if kms and min(kms) >= 0 else None)
+    sizes = dict(L=g.L, pairs=g.P, triplets=g.T, nodes=g.num_nodes, step_kernels_s=float(np.mean(kms)) * 1e-3 if kms and min(kms) >= 0 else None,
+                 step_ms_each=[round(t * 1e3, 3) for t in each], step_kernels_ms_each=[round(float(k), 3) for k in kms])
     mover.close()
     g.close()
     return setup_s, step_s, 2 * sizes["L"], sizes
@@ -474,7 +476,8 @@ def bench_gmsm(ctx, S, comm, label_steps=6, change=0.10):
         it_s = setup_s + steps * step_s
         total += GMSM_ITERATIONS * it_s
         levels.append({"data_order": data_order, "cp_order": cp_order, "setup_s": setup_s, "label_step_s": step_s, "label_step_kernels_s": sizes["step_kernels_s"],
-                       "label_steps_per_iteration": steps, "iteration_s": it_s, "pair_evals_per_step": 4 * sizes["pairs"], "triplet_evals_per_step": 8 * sizes["triplets"]})
+                       "label_steps_per_iteration": steps, "iteration_s": it_s, "pair_evals_per_step": 4 * sizes["pairs"], "triplet_evals_per_step": 8 * sizes["triplets"],
+                       "label_step_ms_each": sizes["step_ms_each"], "label_step_kernels_ms_each": sizes["step_kernels_ms_each"]})
         prof = gmsm_valu_profile(S, data_order, cp_order) if comm.world == 1 and change == 0.10 else None
         if prof and sizes["step_kernels_s"]:
             # the label step is priced against FP64 / integer vector issue, not HBM (0.61 GB per launch = 0.06 of the HBM roofline): achieved =
