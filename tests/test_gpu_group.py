@@ -279,26 +279,39 @@ dist.destroy_process_group()
 '''
 
 
-def test_sharded_group_two_ranks_match_single_rank(tmp_path):
+def run_sharded_workers(tmp_path, world, S, port):
     import os
     import subprocess
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / "sharded.py"
-    script.write_text(SHARDED_WORKER % root)
-    # MSMHIP_GROUP_CHUNKS=2: each rank sets up and exchanges its two subjects in two pieces (msm_group_setup_more_subjects, a gather per piece, the
+    script.write_text((SHARDED_WORKER % root).replace("S, Dm = 4, 2", "S, Dm = %d, 2" % S))
+    # MSMHIP_GROUP_CHUNKS=2: each rank sets up and exchanges its subjects in two pieces (msm_group_setup_more_subjects, a gather per piece, the
     # batched device export / import of dist.sharded_group_setup) -- with gloo the gathers go through host copies, the rest is the nccl path
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29561", WORLD_SIZE="2", MSMHIP_GROUP_CHUNKS="2")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), MSMHIP_GROUP_CHUNKS="2")
     procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE,
-                              stderr=subprocess.PIPE, text=True) for r in range(2)]
+                              stderr=subprocess.PIPE, text=True) for r in range(world)]
     outs = []
     for pr in procs:
         so, se = pr.communicate(timeout=500)
         assert pr.returncode == 0, se[-3000:]
         outs.append(eval(so.strip().splitlines()[-1].replace("true", "True").replace("false", "False")))
-    assert all(o["equal"] and o["move_ok"] and o["template_radius_ok"] and o["n"] == 4 and o["finite"] > 200 for o in outs), outs
+    assert all(o["equal"] and o["move_ok"] and o["template_radius_ok"] and o["n"] == S and o["finite"] > 200 for o in outs), outs
+    return outs
+
+
+def test_sharded_group_two_ranks_match_single_rank(tmp_path):
+    outs = run_sharded_workers(tmp_path, 2, 4, 29561)
     assert sorted(outs[0]["mine"] + outs[1]["mine"]) == [0, 1, 2, 3]
+
+
+def test_sharded_group_four_ranks_uneven_shards(tmp_path):
+    """four ranks (processes sharing the test box's GPU, gloo between them) over six subjects: shards of 2, 2, 1, 1 -- ranks with fewer subjects than
+    the largest shard send padding, the second piece of the short shards is empty --, the pair list control point by control point and cut in four,
+    both transports of a label step: every rank's group equals a single rank's, every delivered step bit for bit"""
+    outs = run_sharded_workers(tmp_path, 4, 6, 29567)
+    assert [o["mine"] for o in sorted(outs, key=lambda o: o["rank"])] == [[0, 1], [2, 3], [4], [5]]
 
 
 NCCL_WORKER = SHARDED_WORKER.replace('dist = D.init("gloo")', 'dist = D.init("nccl", 0)').replace('for transport in (None, "gather"):', 'for transport in ("gather", "gather"):') \
