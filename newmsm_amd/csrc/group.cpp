@@ -658,7 +658,10 @@ int group_common_setup(msm_group *g) {
             std::swap(g->d_pairs.owned, g->d_pairs_tmp.owned);
             int st = launch_group_permute_pairs(ctx, g->d_pairs_tmp.p, g->d_pair_perm.p, (int)g->npairs, g->d_pairs.p);
             if (st) return st;
-            g->pairs.clear();  // the host copy (if the fallback above filled it) is in the other order: fetched again when asked for
+            if (!g->pairs.empty()) {  // the fallback above filled the host copy and queued its upload: in the other order now -- fetched again when asked for
+                MSM_HIP(hipStreamSynchronize(ctx->stream));  // (the upload reads the vector)
+                g->pairs.clear();
+            }
         }
     }
     lap("pair order");
