@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MSM_ABI_VERSION 9  /* 9 (round 4): msm_group_set_pair_layout.  8 (round 4): msm_query_lanes, msm_resample_anatomy_grid, msm_cost_triplet_octets_prefetch / msm_cost_prefetch_stats, msm_group_export_subjects_dev / msm_group_import_subjects_dev / msm_group_setup_more_subjects added.  6 (round 3): msm_pairwise_icm, msm_ctx_time_queries / msm_ctx_query_kernel_ms, msm_group_time_moves / msm_group_move_kernels_ms,
+#define MSM_ABI_VERSION 10  /* 10 (round 4): msm_group_set_rotation_mode.  9 (round 4): msm_group_set_pair_layout.  8 (round 4): msm_query_lanes, msm_resample_anatomy_grid, msm_cost_triplet_octets_prefetch / msm_cost_prefetch_stats, msm_group_export_subjects_dev / msm_group_import_subjects_dev / msm_group_setup_more_subjects added.  6 (round 3): msm_pairwise_icm, msm_ctx_time_queries / msm_ctx_query_kernel_ms, msm_group_time_moves / msm_group_move_kernels_ms,
                              * msm_store_release_i64 / msm_load_acquire_i64 / msm_min_acquire_i64, msm_mesh_sphere_project_warp added; nothing removed or changed */
 
 #define MSM_OK 0
@@ -384,6 +384,12 @@ int msm_group_set_labels(msm_group *g, const double *labels, int32_t L);
  * slices then read a part of every resampled map instead of whole maps.  Same set of pairs; the optimiser reads pairs[i] beside the i-th costs
  * (I/Fusion/Fusion.h:157-196).  Takes effect at the next set-up. */
 int msm_group_set_pair_layout(msm_group *g, int32_t layout);
+/* Who computes estimate_rotation_matrix(centre, vertex) (R/point.cpp:97-152) for the data meshes' vertices in get_patch_data (M/DiscreteGroupModel.cpp:97-105):
+ * 1 (default) the host's libm as the reference calls it (the matrices are applied on the device in the reference's operation order): the rotated meshes are then
+ * the reference's to the bit -- which decides the resampled values where a label carries data vertices exactly onto template vertices (a regular icosphere as the
+ * template under regular data grids: the last bits of the rotation pick the triangle that "contains" such a vertex); V x 0.15 us of host time per subject and
+ * set-up, beside the GPU's work.  0: the device (its own acos / sincos: the rotated meshes agree with the reference's to 1e-13). */
+int msm_group_set_rotation_mode(msm_group *g, int32_t mode);
 /* setupCostFunction M/DiscreteGroupModel.cpp:163-196: estimate_pairs :37-55, get_spacings :123-139, get_rotations :77-86,
  * get_patch_data :88-121 */
 int msm_group_setup(msm_group *g);

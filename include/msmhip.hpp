@@ -487,6 +487,8 @@ public:
     void set_labels(const Points &labels) { check(msm_group_set_labels(h_, to_soa(labels).data(), (int32_t)(labels.size() / 3))); }
     // 0: the reference's list order; 1: control point by control point (the layout for lists sharded over ranks), msm_group_set_pair_layout
     void set_pair_layout(int layout) { check(msm_group_set_pair_layout(h_, layout)); }
+    // 1 (default): the data vertices' rotation matrices from the host's libm, as the reference; 0: the device computes them (msm_group_set_rotation_mode)
+    void set_rotation_mode(int mode) { check(msm_group_set_rotation_mode(h_, mode)); }
     void setupCostFunction() { check(msm_group_setup(h_)); }  // :163-196
     int getNumNodes() {
         int32_t n, p, t;

@@ -137,6 +137,7 @@ SIGNATURES = {
     "msm_group_reset_cpgrid": (C.c_int, [_VP, C.c_int32, c_dp]),
     "msm_group_set_labels": (C.c_int, [_VP, c_dp, C.c_int32]),
     "msm_group_set_pair_layout": (C.c_int, [_VP, C.c_int32]),
+    "msm_group_set_rotation_mode": (C.c_int, [_VP, C.c_int32]),
     "msm_group_setup": (C.c_int, [_VP]),
     "msm_group_setup_subjects": (C.c_int, [_VP, c_ip, C.c_int32]),
     "msm_group_export_subject": (C.c_int, [_VP, C.c_int32, c_dp, c_ip, c_ip, C.c_int64, c_lp]),

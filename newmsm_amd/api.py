@@ -751,6 +751,13 @@ class DiscreteGroupCostFunction:
         check(lib().msm_group_set_labels(self.h, pl, self.L))
 
     REFERENCE_ORDER, CP_MAJOR = 0, 1
+    DEVICE_ROTATIONS, HOST_ROTATIONS = 0, 1
+
+    def set_rotation_mode(self, mode):
+        """who computes the rotation matrices of the data meshes' vertices in get_patch_data: HOST_ROTATIONS (default) -- the host's libm, as the reference
+        calls it: the rotated meshes are then the reference's to the bit, which decides the resampled values where a label carries data vertices exactly onto
+        template vertices (regular icospheres on both sides) -- or DEVICE_ROTATIONS (msm_group_set_rotation_mode).  Takes effect at the next set-up."""
+        check(lib().msm_group_set_rotation_mode(self.h, int(mode)))
 
     def set_pair_layout(self, layout):
         """the order of the pair list (getPairs and every pair index / range): REFERENCE_ORDER = estimate_pairs' own (subject A, control point, subject

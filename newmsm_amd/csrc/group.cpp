@@ -86,7 +86,8 @@ struct msm_group {
     // what the set-up of ONE subject needs before its per-label work can start: the L rotated copies of its data mesh, their trees
     // (a forest), its features.  Two of them: while the lanes work through subject i the main stream prepares subject i + 1.
     struct Stage {
-        DevBuf<double> d_rot, d_feat;
+        DevBuf<double> d_rot, d_feat, d_rot9;  // d_rot9: the vertices' rotation matrices when they come from the host (rotation_mode 1)
+        std::vector<double> rot9;
         Forest forest;
         bool forest_ok = false;
     };
@@ -122,6 +123,9 @@ struct msm_group {
     // msm_group_set_pair_layout: 0 = the reference's list order (subject A, control point, subject B); 1 = control point by control point along the
     // curve -- the list itself in what is otherwise only the processing order, so that a contiguous slice of it is a REGION of the sphere
     int pair_layout = 0;
+    // msm_group_set_rotation_mode: who computes estimate_rotation_matrix(centre, vertex) for the data meshes' vertices in get_patch_data.  1 (default): the
+    // host's libm, as the reference does -- the rotated meshes are then the reference's to the bit; 0: the device (acos / sincos of the GPU's math library)
+    int rotation_mode = 1;
     DevBuf<int> d_pair_perm, d_pairs_tmp;  // layout 1: reference position of every list position (kept with pair_order), and the list as the search wrote it
     Forest cp_forest;                    // the search trees of the S control grids, built together (estimate_pairs)
     DevBuf<double> d_cp_soa, d_rot, d_spacing, d_labels3;  // control points by component; ROT per node; spacing per node; labels 3 x L
@@ -521,6 +525,22 @@ int msm_group_set_pair_layout(msm_group *g, int32_t layout) {
     return MSM_OK;
 }
 
+// Who computes estimate_rotation_matrix(centre, vertex) (R/point.cpp:97-152) for the vertices of the data meshes in get_patch_data (M/DiscreteGroupModel.cpp:
+// 97-105).  1 (default): the host's libm -- acos / sincos as the reference calls them -- with the matrices applied on the device in the reference's operation
+// order: the rotated meshes are then the reference's to the bit.  That matters when a label carries data vertices EXACTLY onto template vertices (a regular
+// icosphere as the template under regular data grids, as gMSM's own scripts set a run up): which triangle around such a vertex "contains" it is decided by the
+// last bits of the rotation.  V x 0.15 us of host time per subject and set-up, on the host workers beside the GPU's work on other subjects
+// (S = 64 at ico6: 145 against 144 ms per set-up).  0: the device computes them (its own acos / sincos).  Takes effect at the next set-up.
+int msm_group_set_rotation_mode(msm_group *g, int32_t mode) {
+    if (!g || (mode != 0 && mode != 1)) return fail(MSM_ERR_INVALID, "msm_group_set_rotation_mode: mode must be 0 (device) or 1 (the host's libm)");
+    if (g->rotation_mode != mode) {
+        g->rotation_mode = mode;
+        g->ready = false;
+        g->drop_kept();
+    }
+    return MSM_OK;
+}
+
 }  // extern "C" (re-opened below)
 
 namespace {
@@ -772,10 +792,42 @@ static bool group_device_path() {
 //             (up to where a tree build's outcome is looked at), then the second half of each, so that it never waits for work it
 //             has only just submitted.
 //   patches   main stream: subject_patches
+// the L rotated copies of subject s's data mesh into d_out (3 x (L * V)), on ctx's stream: one launch; with rotation_mode 1 the V rotation matrices are
+// computed here on the host workers first (libm's acos / sincos: 0.15 us each) and uploaded (72 V bytes)
+static int rotate_subject(msm_group *g, msm_mesh *dm, msm_ctx *ctx, std::vector<double> &rot9, DevBuf<double> &d_rot9, double *d_out) {
+    const int L = g->L, V = dm->V;
+    const double centre[3] = {g->labels[0], g->labels[L], g->labels[2 * (size_t)L]};
+    static const int env_mode = [] {
+        const char *e = std::getenv("MSMHIP_GROUP_ROTATIONS");
+        return !e ? -1 : (std::strcmp(e, "host") == 0 ? 1 : (std::strcmp(e, "device") == 0 ? 0 : -1));
+    }();
+    const int mode = env_mode >= 0 ? env_mode : g->rotation_mode;
+    const double *d_mats = nullptr;
+    if (mode == 1) {
+        if (dm->host_xyz_stale) {
+            MSM_HIP(hipMemcpyAsync(dm->xyz.data(), dm->d_xyz, sizeof(double) * 3 * (size_t)V, hipMemcpyDeviceToHost, ctx->stream));
+            MSM_HIP(hipStreamSynchronize(ctx->stream));
+            dm->host_xyz_stale = false;
+        }
+        rot9.resize(9 * (size_t)V);
+        std::atomic<int> bad{0};
+        const double *xyz = dm->xyz.data();
+        parallel_chunks(V, host_workers(), [&](int, int v0, int v1) {
+            for (int v = v0; v < v1; ++v)
+                if (!rotation_matrix(mk(centre[0], centre[1], centre[2]), pt(xyz, V, v), rot9.data() + 9 * (size_t)v)) bad.store(1);
+        });
+        if (bad.load()) return fail(MSM_ERR_ROTATION, "rotation angle is greater than 90 degrees");
+        MSM_HIP(d_rot9.ensure(rot9.size()));
+        int st = upload_staged(ctx, d_rot9.p, rot9.data(), sizeof(double) * rot9.size());
+        if (st) return st;
+        d_mats = d_rot9.p;
+    }
+    return launch_rotate_to_labels(ctx, dm->d_xyz, V, centre, g->d_labels3.p, L, d_mats, d_out, (size_t)L * V);
+}
+
 static int stage_prepare(msm_group *g, int s, msm_group::Stage &b, msm_ctx *ctx) {
     if (!g->data[s]) return fail(MSM_ERR_STATE, "msm_group: subject %d has no data", s);
     const int L = g->L, D = g->D, Vt = g->tmpl->V;
-    const double centre[3] = {g->labels[0], g->labels[L], g->labels[2 * (size_t)L]};
     msm_mesh *dm = g->data[s];
     const int V = dm->V, T = dm->T;
     const size_t LV = (size_t)L * V;
@@ -789,16 +841,11 @@ static int stage_prepare(msm_group *g, int s, msm_group::Stage &b, msm_ctx *ctx)
         tick = now;
     };
     MSM_HIP(b.d_rot.ensure(3 * LV));
-    for (int a = 0; a < 3; ++a)  // label 0 is the centre of the sampling grid: no rotation
-        MSM_HIP(hipMemcpyAsync(b.d_rot.p + a * LV, dm->d_xyz + (size_t)a * V, sizeof(double) * (size_t)V, hipMemcpyDeviceToDevice, ctx->stream));
-    for (int l = 1; l < L; ++l) {
-        const double lab[3] = {g->labels[l], g->labels[L + l], g->labels[2 * (size_t)L + l]};
-        int st = launch_rotate_to_label(ctx, dm->d_xyz, V, centre, lab, b.d_rot.p + (size_t)l * V, LV);
-        if (st) return st;
-    }
+    int st = rotate_subject(g, dm, ctx, b.rot9, b.d_rot9, b.d_rot.p);  // one launch for the L labels (round 4: L - 1 launches that each computed the matrices again, and 3 copies)
+    if (st) return st;
     lap("rotations");
     MSM_HIP(b.d_feat.ensure((size_t)D * V));
-    int st = upload_staged(ctx, b.d_feat.p, g->feat[s].data(), sizeof(double) * (size_t)D * V);
+    st = upload_staged(ctx, b.d_feat.p, g->feat[s].data(), sizeof(double) * (size_t)D * V);
     if (st) return st;
     lap("feature upload");
     st = subject_feature_slab(g, s, (size_t)D * Vt);
@@ -1074,7 +1121,6 @@ int group_subject_setup(msm_group *g, int s) {
     if (!g->data[s]) return fail(MSM_ERR_STATE, "msm_group: subject %d has no data", s);
     msm_ctx *ctx = g->ctx;
     const int L = g->L, D = g->D, Vt = g->tmpl->V;
-    const double centre[3] = {g->labels[0], g->labels[L], g->labels[2 * (size_t)L]};
     msm_mesh *dm = g->data[s], *sm = g->scratch[s];
     const int V = dm->V, T = dm->T;
     const int workers = host_workers();
@@ -1093,15 +1139,10 @@ int group_subject_setup(msm_group *g, int s) {
     DevBuf<double> &d_rot = g->d_rotated;
     {
         MSM_HIP(d_rot.ensure(3 * LV));
-        for (int a = 0; a < 3; ++a)  // label 0 is the centre of the sampling grid: no rotation
-            MSM_HIP(hipMemcpyAsync(d_rot.p + a * LV, dm->d_xyz + (size_t)a * V, sizeof(double) * (size_t)V, hipMemcpyDeviceToDevice, ctx->stream));
-        for (int l = 1; l < L; ++l) {
-            const double lab[3] = {g->labels[l], g->labels[L + l], g->labels[2 * (size_t)L + l]};
-            int st = launch_rotate_to_label(ctx, dm->d_xyz, V, centre, lab, d_rot.p + (size_t)l * V, LV);
-            if (st) return st;
-        }
+        int st = rotate_subject(g, dm, ctx, g->pipe[0].stage[0].rot9, g->pipe[0].stage[0].d_rot9, d_rot.p);
+        if (st) return st;
         void *pin = nullptr;
-        int st = ctx_io_pinned(ctx, sizeof(double) * 3 * LV, &pin);
+        st = ctx_io_pinned(ctx, sizeof(double) * 3 * LV, &pin);
         if (st) return st;
         MSM_HIP(hipMemcpyAsync(pin, d_rot.p, sizeof(double) * 3 * LV, hipMemcpyDeviceToHost, ctx->stream));
         st = check_status(ctx, "get_patch_data (rotation)");

@@ -104,6 +104,39 @@ __global__ __launch_bounds__(256) void k_rotate_to_label(const double *__restric
     out[2 * stride + i] = p.z;
 }
 
+// The same for ALL labels of a set-up in one launch: the rotation of a vertex does not depend on the label (estimate_rotation_matrix(centre, vertex)), only the
+// vector it is applied to does -- k_rotate_to_label per label computed it L - 1 times.  out: 3 x (L * V), x of label 0, x of label 1, ..., y of label 0, ...
+// (stride = L * V); label 0 is the centre of the sampling grid: the coordinates as they are (M/DiscreteGroupModel.cpp:100: "if (label > 0)").
+// rot9 != nullptr: the V matrices come from the host (msm_group_set_rotation_mode: the host's libm, as the reference computes them) and are only applied here.
+__global__ __launch_bounds__(256) void k_rotate_to_labels(const double *__restrict__ xyz, int V, V3 centre, const double *__restrict__ labels, int L,
+                                                           const double *__restrict__ rot9, double *__restrict__ out, size_t stride, int *status) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= V) return;
+    const V3 p = mk(xyz[i], xyz[V + i], xyz[2 * (size_t)V + i]);
+    double R[9];
+    if (rot9) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) R[k] = rot9[9 * (size_t)i + k];
+    } else if (!rotation_matrix(centre, p, R)) {
+        raise_status(status, MSM_ERR_ROTATION);
+    }
+    out[i] = p.x, out[stride + i] = p.y, out[2 * stride + i] = p.z;
+    for (int l = 1; l < L; ++l) {
+        const V3 q = rotate(R, mk(labels[l], labels[L + l], labels[2 * (size_t)L + l]));
+        const size_t at = (size_t)l * V + i;
+        out[at] = q.x, out[stride + at] = q.y, out[2 * stride + at] = q.z;
+    }
+}
+
+int launch_rotate_to_labels(msm_ctx *ctx, const double *d_xyz, int V, const double centre[3], const double *d_labels3, int L, const double *d_rot9, double *d_out,
+                            size_t stride) {
+    if (V <= 0 || L <= 0) return MSM_OK;
+    hipLaunchKernelGGL(k_rotate_to_labels, dim3((V + 255) / 256), dim3(256), 0, ctx->stream, d_xyz, V, mk(centre[0], centre[1], centre[2]), d_labels3, L, d_rot9, d_out,
+                       stride, ctx->d_status);
+    MSM_HIP(hipGetLastError());
+    return MSM_OK;
+}
+
 int launch_rotate_to_label(msm_ctx *ctx, const double *d_xyz, int V, const double centre[3], const double label[3], double *d_out, size_t stride) {
     hipLaunchKernelGGL(k_rotate_to_label, dim3((V + 255) / 256), dim3(256), 0, ctx->stream, d_xyz, V, mk(centre[0], centre[1], centre[2]),
                        mk(label[0], label[1], label[2]), d_out, stride ? stride : (size_t)V, ctx->d_status);

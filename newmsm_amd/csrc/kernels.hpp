@@ -258,6 +258,9 @@ struct GroupArgs {
 };
 // out[i], out[stride + i], out[2 * stride + i] (stride 0: V)
 int launch_rotate_to_label(msm_ctx *ctx, const double *d_xyz, int V, const double centre[3], const double label[3], double *d_out, size_t stride = 0);
+// all L labels in one launch (out 3 x (L * V), stride = L * V); d_rot9 (optional, V x 9 on the device): the vertices' rotation matrices from the host
+int launch_rotate_to_labels(msm_ctx *ctx, const double *d_xyz, int V, const double centre[3], const double *d_labels3, int L, const double *d_rot9, double *d_out,
+                            size_t stride);
 int launch_group_pairwise(msm_ctx *ctx, const GroupArgs &a, const int *qp, const int *qa, const int *qb, int n, double *out);
 // out[4 * (pair - base) + 3] = kept[pair - base] for the n pairs order[0 .. n)
 int launch_group_kept(msm_ctx *ctx, const int *order, int base, const double *kept, int n, double *out);

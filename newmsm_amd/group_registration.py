@@ -19,10 +19,19 @@ from .registration import ProductOps, apply_labeling
 
 
 class ProductGroupOps(ProductOps):
+    def __init__(self, ctx, host_rotations=True):
+        """host_rotations (the library's default): the rotation matrices of the data meshes' vertices from the host's libm, as the reference computes them
+        (DiscreteGroupCostFunction.set_rotation_mode) -- on regular icospheres (template and subjects' spheres alike, as gMSM's scripts set them up) a label
+        carries data vertices exactly onto template vertices and the last bits of the rotation decide the resampled values there; False: the device computes them"""
+        super().__init__(ctx)
+        self.host_rotations = host_rotations
+
     def group(self, S, simmeasure, lambda_, fixnan, **params):
         """params: mu, kappa, k_exp, rexp, range_, percentile (--shearmod --bulkmod --k_exponent --regexp --cprange --percentile) where they differ from the
         reference's defaults"""
-        return _ProductGroup(api.DiscreteGroupCostFunction(self.ctx, S, simmeasure=simmeasure, lambda_=lambda_, fixnan=fixnan, **params))
+        g = api.DiscreteGroupCostFunction(self.ctx, S, simmeasure=simmeasure, lambda_=lambda_, fixnan=fixnan, **params)
+        g.set_rotation_mode(g.HOST_ROTATIONS if self.host_rotations else g.DEVICE_ROTATIONS)
+        return _ProductGroup(g)
 
 
 class _ProductGroup:

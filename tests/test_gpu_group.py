@@ -591,10 +591,9 @@ def test_group_multiresolution_matches_oracle(ctx):
     level's iterations, at the end every subject's input sphere through its final warp.  The same caller loop over the oracle: same labelings in every
     iteration of both levels, energies to 1e-9, registered spheres within the north star's 1e-4 rad.
 
-    The template and the subjects' spheres are irregular (smoothly warped icospheres).  With a REGULAR template under regular data grids a label of the
-    sampling grid carries data vertices exactly onto template vertices; which of the five or six triangles around such a vertex "contains" it -- and with
-    it the adaptive weight lists -- is then decided by the last bits of the rotation (libm's acos / sincos against the device's: 7e-14 apart), in the
-    reference as much as here: the oracle itself answers differently for two inputs that close."""
+    The template and the subjects' spheres are irregular (smoothly warped icospheres), a subject's own sphere each; the regular case -- where a label
+    carries data vertices exactly onto template vertices and the last bits of the rotation decide the resampled values -- is
+    test_host_rotations_on_regular_spheres."""
     from helpers import OracleOps, angles
     from newmsm_amd import group_registration as GR
 
@@ -667,3 +666,50 @@ def test_pair_layout_control_point_major(ctx):
     assert np.array_equal(q, want[0][0], equal_nan=True) and np.array_equal(o, want[0][1])
     with pytest.raises(M.MsmError):
         g.set_pair_layout(2)
+
+
+def test_host_rotations_on_regular_spheres(ctx):
+    """msm_group_set_rotation_mode(1), the default: the data vertices' rotation matrices from the host's libm, as the reference computes them (R/point.cpp:97-152 called from
+    M/DiscreteGroupModel.cpp:97-105), applied on the device.  On REGULAR icospheres -- the template and every subject's sphere, as gMSM's own scripts set a run up --
+    a label carries data vertices exactly onto template vertices, and the last bits of the rotation decide which triangle around such a vertex "contains" it (the
+    device's acos / sincos: a few resampled values differ from the reference's by up to 1e-2).  With the host's matrices every resampled
+    value of every (subject, control point, label) patch is the oracle's, and the two-level registration of test_group_multiresolution_matches_oracle on regular
+    spheres takes the oracle's decisions in every label step."""
+    from helpers import OracleOps, angles
+    from newmsm_amd import group_registration as GR
+
+    g, og, keep = build(ctx, S=2, data_order=3, cp_order=1)
+    worst_device = 0.0
+    for mode in (g.DEVICE_ROTATIONS, g.HOST_ROTATIONS):
+        g.set_rotation_mode(mode)
+        g.setupCostFunction()
+        worst = 0.0
+        for s in range(2):
+            for v in range(g.N):
+                for l in range(g.L):
+                    ids, data = g.patch(s, v, l)
+                    oids, odata = og.patch(s, v, l)
+                    assert np.array_equal(ids, oids)
+                    if len(ids):
+                        worst = max(worst, float(np.abs(data - odata).max()))
+        if mode == g.DEVICE_ROTATIONS:
+            worst_device = worst
+        else:
+            assert worst < 1e-12, worst
+    # (build() warps the subjects' spheres: the device's rotations agree to 1e-9 there; the regular case follows)
+    assert worst_device < 1e-9
+    S, D = 3, 2
+    xyz, tri = M.make_mesh_from_icosa(4)
+    datas = [synthetic.features(synthetic.known_warp(xyz, seed=90 + s, rot_deg=3.0, amp=2.0), D, seed=5) for s in range(S)]
+    levels = [dict(data_order=3, cp_order=1, sg_order=3, iters=2, simmeasure=2, cost_params=dict(lambda_=1e-3), sigma_in=2.0),
+              dict(data_order=4, cp_order=2, sg_order=4, iters=2, simmeasure=2, cost_params=dict(lambda_=1e-3), sigma_in=0.0)]
+    mask = (np.random.default_rng(1).random(len(xyz)) > 0.2).astype(np.float64)
+    lg, lw = [], []
+    kw = dict(mask=mask, varnorm=True, fixnan=True)
+    got = GR.run_group_multiresolution(GR.ProductGroupOps(ctx), [(xyz, tri)] * S, datas, xyz, tri, levels, labelings_out=lg, **kw)
+    want = GR.run_group_multiresolution(OracleOps(M.mcmc_optimise), [(xyz, tri)] * S, datas, xyz, tri, levels, labelings_out=lw, **kw)
+    assert len(lg) == len(lw) == 4 and all(np.array_equal(a, b) for a, b in zip(lg, lw)) and any(l.any() for l in lg[2:])
+    for a, b in zip(got[2], want[2]):
+        assert np.allclose(a, b, rtol=1e-9)
+    for s in range(S):
+        assert angles(got[0][s], want[0][s]).max() <= 1e-4 and np.abs(got[0][s] - want[0][s]).max() < 1e-8
