@@ -629,6 +629,7 @@ def main():
 
     from newmsm_amd import dist as D
 
+    t_start = time.perf_counter()
     rank, local_rank, world = D.env()
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE): the line would misreport n_gpus" % (args.gpus, world))
@@ -813,26 +814,39 @@ def main():
         if gmsm_scaling is not None:
             out["gmsm"] = gmsm_scaling
         threads = D.host_cores()  # cgroup / affinity aware: the GPU box gives one GPU's share of the host
+        def stage(name):  # MSM_BENCH_TRACE=1: the object being measured, on stderr as it starts (which one was running when a run ended early)
+            if os.environ.get("MSM_BENCH_TRACE"):
+                print("[bench %.1f s] %s" % (time.perf_counter() - t_start, name), file=sys.stderr, flush=True)
+
         if world == 1 and not args.no_extras:
             with torch.cuda.stream(stream):
+                stage("triclique_move")
                 out["triclique_move"] = {"d1": bench_triclique_move(ctx, 1, 200, 0 if args.no_cpu_baseline else threads),
                                          "d32": bench_triclique_move(ctx, 32, 200, 0 if args.no_cpu_baseline else threads)}
+                stage("resample")
                 out["resample"] = bench_resample(ctx, 100, not args.no_cpu_baseline)
                 chk = not args.no_cpu_baseline  # the checks run the CPU port (a few seconds each)
+                stage("registration")
                 out["registration"] = bench_registration(ctx, check=chk)
+                stage("registration_fusion")
                 out["registration_fusion"] = bench_registration(ctx, "fusion", check=chk)
+                stage("registration_msmall")
                 out["registration_msmall"] = bench_registration_msmall(ctx, check=chk)
                 from newmsm_amd import config as _config
 
+                stage("registration_*_cpp")
                 out["registration_fusion_cpp"] = bench_registration_cpp(ctx, BASIC_FUSION_CONFIG, 1, "run_multiresolutions, 3 DISCRETE levels (data ico4/5/6, control ico2/3/4, "
                                                                         "sigma 4/2/1, --VN), 3 iterations each, sulc-like D=1, ico6 spheres, --dopt=HOCR --regoption=3 (stand-in solve)")
                 out["registration_msmall_cpp"] = bench_registration_cpp(ctx, _config.PRESETS["HCP_MSMAll"], 32, "run_multiresolutions, the HCP MSMAll schedule "
                                                                         "(config text through the reference's grammar), ho_multivariate D=32, ico6 spheres: 40 set-ups + 1 520 fusion moves (stand-in solve)")
+                stage("registration_gmsm")
                 try:
                     out["registration_gmsm"] = bench_registration_gmsm(ctx)
                 except Exception as e:  # reported, not fatal
                     out["registration_gmsm"] = {"error": repr(e)}
+                stage("gmsm")
                 out["gmsm"] = bench_gmsm(ctx, args.subjects, comm, change=args.label_change)
+                stage("gmsm.template_allreduce")
                 out["gmsm"]["template_allreduce"] = template_allreduce()
         if world == 1 and not args.no_cpu_baseline:
             Uo, rate, dt, reps = cpu_baseline(inp, kind, threads)

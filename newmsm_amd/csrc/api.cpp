@@ -221,7 +221,10 @@ int install_coords_and_tree(msm_mesh *m, const double *xyz, FlatOctree &&tree) {
     msm_ctx *ctx = m->ctx;
     MSM_HIP(hipStreamSynchronize(ctx->stream));
     m->xyz.assign(xyz, xyz + 3 * (size_t)m->V);
-    MSM_HIP(hipMemcpyAsync(m->d_xyz, m->xyz.data(), sizeof(double) * 3 * (size_t)m->V, hipMemcpyHostToDevice, ctx->stream));
+    {
+        const int st = upload_staged(ctx, m->d_xyz, m->xyz.data(), sizeof(double) * 3 * (size_t)m->V);
+        if (st) return st;
+    }
     m->tree = std::move(tree);
     m->rayrec_valid = false;
     return upload_tree(m);
@@ -421,14 +424,19 @@ int ensure_rays(msm_mesh *m, bool wait) {
         };
         MSM_HIP(grow((void **)&m->d_ray_cell, m->cap_ray_cell, m->tree.ray_cell.size(), sizeof(int4)));
         MSM_HIP(grow((void **)&m->d_ray_edge, m->cap_ray_edge, m->tree.ray_edge.size(), sizeof(float4)));
-        MSM_HIP(hipMemcpyAsync(m->d_ray_cell, m->tree.ray_cell.data(), m->tree.ray_cell.size() * sizeof(int4), hipMemcpyHostToDevice, ctx->stream));
-        MSM_HIP(hipMemcpyAsync(m->d_ray_edge, m->tree.ray_edge.data(), m->tree.ray_edge.size() * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
+        {
+            int st = upload_staged(ctx, m->d_ray_cell, m->tree.ray_cell.data(), m->tree.ray_cell.size() * sizeof(int4));
+            if (!st) st = upload_staged(ctx, m->d_ray_edge, m->tree.ray_edge.data(), m->tree.ray_edge.size() * sizeof(float4));
+            if (st) return st;
+        }
         MSM_HIP(grow((void **)&m->d_ray_more, m->cap_ray_more, m->tree.ray_more.size() + 1, sizeof(int4)));
         MSM_HIP(grow((void **)&m->d_ray_excl, m->cap_ray_excl, m->tree.ray_excl.size() + 1, sizeof(int4)));
-        if (!m->tree.ray_more.empty())
-            MSM_HIP(hipMemcpyAsync(m->d_ray_more, m->tree.ray_more.data(), m->tree.ray_more.size() * sizeof(int4), hipMemcpyHostToDevice, ctx->stream));
-        if (!m->tree.ray_excl.empty())
-            MSM_HIP(hipMemcpyAsync(m->d_ray_excl, m->tree.ray_excl.data(), m->tree.ray_excl.size() * sizeof(int4), hipMemcpyHostToDevice, ctx->stream));
+        {
+            int st = MSM_OK;
+            if (!m->tree.ray_more.empty()) st = upload_staged(ctx, m->d_ray_more, m->tree.ray_more.data(), m->tree.ray_more.size() * sizeof(int4));
+            if (!st && !m->tree.ray_excl.empty()) st = upload_staged(ctx, m->d_ray_excl, m->tree.ray_excl.data(), m->tree.ray_excl.size() * sizeof(int4));
+            if (st) return st;
+        }
         MSM_HIP(hipStreamSynchronize(ctx->stream));
         m->rayrec_valid = false;
     }

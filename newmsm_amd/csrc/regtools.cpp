@@ -82,8 +82,11 @@ int msm_mesh_unfold(msm_mesh *m, double radius, int32_t *passes, int32_t *first_
         MSM_HIP(msm::pool_malloc((void **)&m->d_tid_ptr, sizeof(int32_t) * adj.tid_ptr.size()));
         MSM_HIP(msm::pool_malloc((void **)&m->d_tid, sizeof(int32_t) * std::max<size_t>(adj.tid.size(), 1)));
         MSM_HIP(msm::pool_malloc((void **)&m->d_fold, sizeof(int32_t) * (2 + (size_t)V)));
-        MSM_HIP(hipMemcpyAsync(m->d_tid_ptr, adj.tid_ptr.data(), sizeof(int32_t) * adj.tid_ptr.size(), hipMemcpyHostToDevice, ctx->stream));
-        if (!adj.tid.empty()) MSM_HIP(hipMemcpyAsync(m->d_tid, adj.tid.data(), sizeof(int32_t) * adj.tid.size(), hipMemcpyHostToDevice, ctx->stream));
+        // (through the context's pinned staging block, like every upload of the library: the GPU never reads the caller's pageable pages, whose pinning by the
+        // runtime for an asynchronous copy outlives nothing the library controls)
+        int st = upload_staged(ctx, m->d_tid_ptr, adj.tid_ptr.data(), sizeof(int32_t) * adj.tid_ptr.size());
+        if (!st && !adj.tid.empty()) st = upload_staged(ctx, m->d_tid, adj.tid.data(), sizeof(int32_t) * adj.tid.size());
+        if (st) return st;
     }
     if (passes) *passes = 0;
     if (first_folded) *first_folded = 0;
@@ -121,7 +124,8 @@ int msm_mesh_unfold(msm_mesh *m, double radius, int32_t *passes, int32_t *first_
             fm.set(folded[k], scale(pp, radius));
         }
         m->tree_valid = false;
-        MSM_HIP(hipMemcpyAsync(m->d_xyz, m->xyz.data(), sizeof(double) * 3 * (size_t)V, hipMemcpyHostToDevice, ctx->stream));
+        st = upload_staged(ctx, m->d_xyz, m->xyz.data(), sizeof(double) * 3 * (size_t)V);
+        if (st) return st;
         if (passes) *passes = it + 1;
         if (it + 1 == 1000) break;
     }

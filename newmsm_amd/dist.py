@@ -274,9 +274,12 @@ def sharded_group_setup(group, n_subjects, comm=None, chunks=None, pair_layout=N
         pi = torch.zeros((n, imax), dtype=torch.int32, device=dev)
         if len(part) < n:
             F[len(part):].zero_()  # a rank with fewer subjects than the largest shard sends defined padding
+        # torch's fills above run on torch's current stream, which libmsmhip's streams (created non-blocking) do not order against: they are complete BEFORE
+        # the library writes into the same tensors -- a fill that lands after the export wipes exported rows (seen with four ranks sharing one GPU: one run in
+        # seven delivered zeroed patch lists to every rank)
+        torch.cuda.current_stream().synchronize()
         if part:
             group.export_subjects_dev(part, F.data_ptr(), L * D * V, pp.data_ptr(), M, pi.data_ptr(), imax)  # synchronises libmsmhip's stream
-        torch.cuda.current_stream().synchronize()  # the fills above: complete before RCCL's stream (or the host copy) reads the buffers
         aF = torch.empty((c.world,) + tuple(F.shape), dtype=F.dtype, device=dev)
         app = torch.empty((c.world,) + tuple(pp.shape), dtype=pp.dtype, device=dev)
         api = torch.empty((c.world,) + tuple(pi.shape), dtype=pi.dtype, device=dev)
@@ -471,6 +474,10 @@ class ShardedMove:
         if not c.on_gpu:  # rehearsal: the kernels still need device buffers; results are staged through the host
             self.gpu_scratch = (torch.zeros(4 * self.pmax + 8 * self.tmax, dtype=torch.float64, device="cuda:%d" % torch.cuda.current_device())
                                 if torch.cuda.is_available() else None)
+        if torch.cuda.is_available():
+            # the zero fills of the tensors above run on torch's current stream; libmsmhip's kernels write into them from streams that do not order against
+            # it: complete before the first move (a late fill wiped the first results written -- the kept (label, label) costs of a rank's slice)
+            torch.cuda.synchronize()
 
     def close(self):
         if self.transport == "shm" and self.shared is not None:

@@ -256,7 +256,7 @@ sharded = g.computePairwiseCost(p, la, lb)
 single = g1.computePairwiseCost(pos[p].astype(np.int32), la, lb)
 # a label step with the pair and triplet lists sharded over the two ranks, gathered on rank 0 (M/DiscreteGroupCostFunction.cpp:54-98)
 lab = rng.integers(0, g.L, g.num_nodes).astype(np.int32)
-move_ok, transports = True, []
+move_ok, transports, move_bad = True, [], []
 for transport in (None, "gather"):   # None: the ranks share a node -> every rank's GPU writes its slice into shared host memory
     sm = D.ShardedMove(g, dist, transport=transport)
     transports.append(sm.transport)
@@ -265,7 +265,11 @@ for transport in (None, "gather"):   # None: the ranks share a node -> every ran
         q, o = sm.move(lab_s, label)
         q1, o1 = g1.fusionMove(lab_s, label)
         if rank == 0:
-            move_ok = move_ok and bool(np.array_equal(q, q1[pos], equal_nan=True) and np.array_equal(o, o1))
+            same = bool(np.array_equal(q, q1[pos], equal_nan=True) and np.array_equal(o, o1))
+            if not same:   # what differs, for the assertion message
+                dq = ~((q == q1[pos]) | (np.isnan(q) & np.isnan(q1[pos])))
+                move_bad.append((sm.transport, step, int(dq.sum()), np.argwhere(dq)[:4].tolist(), int((o != o1).sum()), float(np.nanmax(np.abs(np.where(dq, q - q1[pos], 0.0))))))
+            move_ok = move_ok and same
     sm.close()
 # the single-process transport: pinned arrays of this process
 q, o = D.ShardedMove(g1, None).move(lab, 4)
@@ -273,7 +277,7 @@ q1, o1 = g1.fusionMove(lab, 4)
 move_ok = move_ok and bool(np.array_equal(q, q1, equal_nan=True) and np.array_equal(o, o1)) and transports == ["shm", "gather"]
 tmpl = D.group_template_update(np.stack([keep[1 + s].get_coords() for s in mine]), None, dist)
 dist.barrier()
-print(json.dumps({"rank": rank, "mine": mine, "equal": bool(np.array_equal(sharded, single, equal_nan=True)) and layout_ok, "finite": int(np.isfinite(single).sum()), "move_ok": move_ok,
+print(json.dumps({"rank": rank, "mine": mine, "equal": bool(np.array_equal(sharded, single, equal_nan=True)) and layout_ok, "finite": int(np.isfinite(single).sum()), "move_ok": move_ok, "move_bad": move_bad,
                   "template_radius_ok": bool(np.allclose(np.linalg.norm(tmpl["template"], axis=1), 100.0)), "n": tmpl["n_subjects"]}))
 dist.destroy_process_group()
 '''
@@ -374,6 +378,7 @@ for (g, _), mine in zip(ranks, shards):
         F = torch.zeros((g.L, g.D, V), dtype=torch.float64, device="cuda:0")
         pp = torch.zeros(M_, dtype=torch.int32, device="cuda:0")
         pi = torch.zeros(n + 7, dtype=torch.int32, device="cuda:0")   # a padded slot, as in the padded all-gather
+        torch.cuda.synchronize()   # torch's fills are complete before the library writes into the tensors from its own (non-blocking) streams
         g.export_subject_dev(s, F.data_ptr(), pp.data_ptr(), pi.data_ptr(), n + 7)
         wire[s] = (F, pp, pi, n)
 torch.cuda.synchronize()
@@ -385,10 +390,12 @@ if BATCHED:  # the strided send / receive buffers of one all-gather: a shard per
         F = torch.zeros((len(other), g.L, g.D, V), dtype=torch.float64, device="cuda:0")
         pp = torch.zeros((len(other), M_ + 3), dtype=torch.int32, device="cuda:0")    # strides larger than the rows: padded slots
         pi = torch.full((len(other), imax), -1, dtype=torch.int32, device="cuda:0")
+        torch.cuda.synchronize()
         counts = src.export_subjects_dev(other, F.data_ptr(), g.L * g.D * V, pp.data_ptr(), M_ + 3, pi.data_ptr(), imax)
         assert [int(c) for c in counts] == [src.subject_index_count(s) for s in other]
         g.import_subjects_dev(other, F.data_ptr(), g.L * g.D * V, pp.data_ptr(), M_ + 3, pi.data_ptr(), imax, counts)
         bad = pi.clone(); bad[0, 0] = V + 5                                             # a vertex id out of range must be refused, not indexed with
+        torch.cuda.synchronize()
         try:
             g.import_subjects_dev(other, F.data_ptr(), g.L * g.D * V, pp.data_ptr(), M_ + 3, bad.data_ptr(), imax, counts)
             raise SystemExit("an out-of-range template vertex id was imported")

@@ -41,6 +41,7 @@ imax = max(counts)
 F = torch.zeros((S, L, Dm, V), dtype=torch.float64, device="cuda:0")
 pp = torch.zeros((S, Mrows), dtype=torch.int32, device="cuda:0")
 pi = torch.zeros((S, imax), dtype=torch.int32, device="cuda:0")
+torch.cuda.synchronize()  # torch's fills are complete before the library writes into the tensors from its own streams
 for s in range(S):
     full.export_subject_dev(s, F[s].data_ptr(), pp[s].data_ptr(), pi[s].data_ptr(), imax)
 torch.cuda.synchronize()
@@ -50,6 +51,7 @@ g.set_pair_layout(LAYOUT)
 sendF = torch.zeros((len(mine), L, Dm, V), dtype=torch.float64, device="cuda:0")
 sendpp = torch.zeros((len(mine), Mrows), dtype=torch.int32, device="cuda:0")
 sendpi = torch.zeros((len(mine), imax), dtype=torch.int32, device="cuda:0")
+torch.cuda.synchronize()  # torch's fills are complete before the library writes into the tensors from its own streams
 
 
 CHUNKS = int(os.environ.get("CHUNKS", "2"))

@@ -19,6 +19,7 @@ t0 = time.perf_counter(); g.setupCostFunction(); print("set-up %.3f s (%.1f ms p
 rng = np.random.default_rng(3)
 lab = rng.integers(0, g.L, g.num_nodes).astype(np.int32)
 buf = torch.zeros(4 * g.P + 8 * g.T, dtype=torch.float64, device="cuda:0")
+torch.cuda.synchronize()  # the fill is complete before the library writes into the tensor from its own stream
 def dev_step(label):
     g.fusionMove_dev(lab, label, (0, g.P), (0, g.T), buf.data_ptr(), buf.data_ptr() + 8 * 4 * g.P)
     torch.cuda.synchronize()
