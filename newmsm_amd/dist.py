@@ -53,6 +53,10 @@ class Comm:
     def close(self):
         if self.dist is not None:
             self.dist.barrier()
+            if self.on_gpu:  # nothing of this communicator is still queued or running on the device when its buffers go
+                import torch
+
+                torch.cuda.synchronize()
             self.dist.destroy_process_group()
             self.dist = None
 
