@@ -1,6 +1,6 @@
 """tests/fuzz_group_multires.py [seed] [count] -- random multi-level groupwise registrations (Group_Mesh_registration::run_multiresolutions,
 M/group_mesh_registration.cpp:26-133) through newmsm_amd/group_registration.py over the MI355X path and over the oracle: subjects on irregular spheres of
-their own, an irregular template, two levels of random resolutions, smoothing, variance normalisation, masks, similarity measures.  The labelings of every
+their own and an irregular template (every third run: the regular icosphere for all of them), two levels of random resolutions, smoothing, variance normalisation, masks, similarity measures.  The labelings of every
 iteration must be identical and the registered spheres within 1e-4 rad (north_star).  A script, run by hand on a GPU box."""
 import os
 import sys
@@ -23,8 +23,12 @@ for k in range(n):
     S, D = int(rng.integers(2, 4)), int(rng.integers(1, 3))
     mesh_order = int(rng.choice([3, 4]))
     xyz, tri = M.make_mesh_from_icosa(mesh_order)
-    txyz = synthetic.known_warp(xyz, seed=int(rng.integers(1, 10**6)), rot_deg=float(rng.uniform(2, 9)), amp=float(rng.uniform(0.5, 2.0)))
-    meshes = [(synthetic.known_warp(xyz, seed=int(rng.integers(1, 10**6)), rot_deg=float(rng.uniform(0, 2)), amp=float(rng.uniform(0.3, 1.5))), tri) for _ in range(S)]
+    regular = bool(rng.integers(0, 3) == 0)  # every third: the regular icosphere as the template and as every subject's sphere, as gMSM's scripts set a run up --
+    if regular:                               # labels then carry data vertices exactly onto template vertices (exact with the host's rotation matrices, the default)
+        txyz, meshes = xyz, [(xyz, tri) for _ in range(S)]
+    else:
+        txyz = synthetic.known_warp(xyz, seed=int(rng.integers(1, 10**6)), rot_deg=float(rng.uniform(2, 9)), amp=float(rng.uniform(0.5, 2.0)))
+        meshes = [(synthetic.known_warp(xyz, seed=int(rng.integers(1, 10**6)), rot_deg=float(rng.uniform(0, 2)), amp=float(rng.uniform(0.3, 1.5))), tri) for _ in range(S)]
     datas = [synthetic.features(synthetic.known_warp(meshes[s][0], seed=int(rng.integers(1, 10**6)), rot_deg=3.0, amp=2.0), D, seed=5) for s in range(S)]
     sim = int(rng.choice([1, 2]))
     lam = float(rng.choice([1e-3, 1e-2, 0.1]))
@@ -43,7 +47,7 @@ for k in range(n):
     ang = max(float(angles(got[0][s], want[0][s]).max()) for s in range(S))
     ok = same and ang <= 1e-4
     bad += 0 if ok else 1
-    print("ok" if ok else "MISMATCH", k, "S=%d D=%d mesh=ico%d levels=%s sim=%d lambda=%g mask=%s vn=%s: labelings %s, %.1e rad, %d labels taken" % (
+    print("ok" if ok else "MISMATCH", k, "regular" if regular else "irregular", "S=%d D=%d mesh=ico%d levels=%s sim=%d lambda=%g mask=%s vn=%s: labelings %s, %.1e rad, %d labels taken" % (
         S, D, mesh_order, [(l["data_order"], l["cp_order"], l["sg_order"], l["iters"], l["sigma_in"]) for l in levels], sim, lam, mask is not None, kw["varnorm"],
         "identical" if same else "DIFFER", ang, sum(int(np.count_nonzero(l)) for l in lg)), flush=True)
 print("fuzz_group_multires: %d configs, %d mismatches, %.0f s" % (n, bad, time.time() - t0))
