@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MSM_ABI_VERSION 10  /* 10 (round 4): msm_group_set_rotation_mode.  9 (round 4): msm_group_set_pair_layout.  8 (round 4): msm_query_lanes, msm_resample_anatomy_grid, msm_cost_triplet_octets_prefetch / msm_cost_prefetch_stats, msm_group_export_subjects_dev / msm_group_import_subjects_dev / msm_group_setup_more_subjects added.  6 (round 3): msm_pairwise_icm, msm_ctx_time_queries / msm_ctx_query_kernel_ms, msm_group_time_moves / msm_group_move_kernels_ms,
+#define MSM_ABI_VERSION 11  /* 11 (round 5): msm_ctx_wait_stream, msm_ctx_staging_stats, msm_group_context; msm_host_register takes whole pages only.  10 (round 4): msm_group_set_rotation_mode.  9 (round 4): msm_group_set_pair_layout.  8 (round 4): msm_query_lanes, msm_resample_anatomy_grid, msm_cost_triplet_octets_prefetch / msm_cost_prefetch_stats, msm_group_export_subjects_dev / msm_group_import_subjects_dev / msm_group_setup_more_subjects added.  6 (round 3): msm_pairwise_icm, msm_ctx_time_queries / msm_ctx_query_kernel_ms, msm_group_time_moves / msm_group_move_kernels_ms,
                              * msm_store_release_i64 / msm_load_acquire_i64 / msm_min_acquire_i64, msm_mesh_sphere_project_warp added; nothing removed or changed */
 
 #define MSM_OK 0
@@ -132,6 +132,21 @@ void    *msm_ctx_stream(msm_ctx *ctx);                        /* hipStream_t, fo
 void     msm_store_release_i64(int64_t *addr, int64_t value);
 int64_t  msm_load_acquire_i64(const int64_t *addr);
 int64_t  msm_min_acquire_i64(const int64_t *addr, int32_t n);   /* the smallest of n counters, each read with acquire semantics */
+/* Stream contract.  A context from msm_ctx_create owns a NON-BLOCKING stream: nothing it runs orders against the caller's streams (not even the
+ * default stream), and every entry point that takes HOST arrays is complete when it returns.  The entry points that take DEVICE pointers of the
+ * caller (msm_group_export_subject(s)_dev, msm_group_import_subject(s)_dev, msm_group_fusion_move_dev, ...) read and write them on the context's
+ * stream, therefore:
+ *   before the call   the caller's pending work on those buffers (a memset, a collective that fills them, a kernel) must be complete -- or ordered
+ *                     by msm_ctx_wait_stream(ctx, your_stream): everything the library queues after it waits for what your_stream held when it
+ *                     was called (one event, no host wait; your_stream = NULL names the default stream).  Without either, a late fill of yours
+ *                     lands on top of what the library wrote (the race DESIGN.md section 6 describes).
+ *   after the call    the library's work on the buffers is complete: every such entry point synchronises the context's stream before it returns,
+ *                     so any stream may use them.
+ * A context from msm_ctx_create_on_stream runs on the caller's stream and orders with the rest of that stream as usual. */
+int      msm_ctx_wait_stream(msm_ctx *ctx, void *hip_stream);
+/* [diagnostics] the pinned staging blocks of the context's host <-> device copies (csrc/stager.cpp): out[0] blocks, out[1] their bytes, out[2] blocks ever
+ * allocated, out[3] times a copy waited for a busy block.  Blocks are never moved or freed before the context goes. */
+int      msm_ctx_staging_stats(msm_ctx *ctx, int64_t out[4]);
 int      msm_ctx_time_queries(msm_ctx *ctx, int enable);
 int      msm_ctx_query_kernel_ms(msm_ctx *ctx, double *ms);
 int      msm_query_lanes(int64_t n_queries);                 /* [host] lanes per query (4 or 8) the search kernels use for a launch of n_queries: names the instantiation a profile shows */
@@ -144,7 +159,10 @@ void    *msm_host_alloc(msm_ctx *ctx, size_t bytes);
 void     msm_host_free(msm_ctx *ctx, void *p);
 /* The same for memory the caller owns -- e.g. a POSIX shared-memory segment that the processes of one node (one per GPU) map, so
  * that every rank's kernels deliver their slice of a label step into the optimiser rank's address space without a collective.
- * msm_host_free(ctx, p) undoes the registration (the memory stays the caller's). */
+ * msm_host_free(ctx, p) undoes the registration (the memory stays the caller's).  p must be page aligned and bytes a multiple of the page
+ * size (4096; MSM_ERR_INVALID otherwise): page-locking works on whole pages and the device address of the block is its host address, so a
+ * range that shares a page with other data would share that page's GPU mapping with whatever else gets locked there -- the HIP runtime
+ * page-locks pageable buffers of asynchronous copies on its own -- and the first of the two to be released unmaps it under the other. */
 int      msm_host_register(msm_ctx *ctx, void *p, size_t bytes);
 
 /* ------------------------------------------------------------------------------------------------
@@ -366,6 +384,7 @@ typedef struct msm_group_params { /* set_parameters M/DiscreteCostFunction.cpp:1
     double  percentile;  /* "percentile" (M/DiscreteCostFunction.cpp:129): DICE threshold rank; 0 means the default 0.75 */
 } msm_group_params;
 msm_group *msm_group_create(msm_ctx *ctx, const msm_group_params *params, int32_t num_subjects);
+msm_ctx   *msm_group_context(msm_group *g);   /* [host] the context the group was created on (its stream: msm_ctx_stream / msm_ctx_wait_stream) */
 void       msm_group_destroy(msm_group *g);
 /* DiscreteGroupModel::set_meshspace target_space M/DiscreteGroupModel.h:56-61, set_masks :54 (mask: V(template) or NULL) */
 int msm_group_set_template(msm_group *g, msm_mesh *template_mesh, const double *mask);

@@ -61,8 +61,13 @@ inline GroupLevelResult run_group_discrete_opt(Context &ctx, const Points &templ
     std::vector<double> quads, octets;
     for (int it = 0; it < o.iters; ++it) {
         for (int s = 0; s < S; ++s) {
-            meshes[(size_t)s]->set_coords(sph_regs[(size_t)s]);
-            g.reset_meshspace(*meshes[(size_t)s], feats[(size_t)s], D, s);
+            // iteration 0 runs on the level's ORIGINAL data grid for every subject (set_meshspace(target_space, SPH_orig, S), M/group_mesh_registration.cpp:54),
+            // also at later levels: project_CPgrid carries the previous warp to ALL_SPH_REG and the control grids (warp_CPgrid), not to m_datameshes;
+            // reset_meshspace(ALL_SPH_REG[subject]) comes at the end of an iteration (:114)
+            if (it > 0) {
+                meshes[(size_t)s]->set_coords(sph_regs[(size_t)s]);
+                g.reset_meshspace(*meshes[(size_t)s], feats[(size_t)s], D, s);
+            }
             g.reset_CPgrid(cps[(size_t)s], s);
         }
         g.set_labels(samples);

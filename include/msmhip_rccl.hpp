@@ -114,6 +114,24 @@ struct DeviceArray {
     DeviceArray(const DeviceArray &) = delete;
     DeviceArray &operator=(const DeviceArray &) = delete;
 };
+// small host buffers the copy engine reads and writes: page-locked memory of their own (an asynchronous copy into a pageable std::vector makes the HIP
+// runtime page-lock whole pages of the heap behind the caller's back -- shared with whatever else lives there; csrc/stager.cpp has the story)
+template <typename T>
+struct PinnedArray {
+    T *p = nullptr;
+    size_t n = 0;
+    explicit PinnedArray(size_t count) : n(count) {
+        check_hip(hipHostMalloc((void **)&p, std::max<size_t>(count, 1) * sizeof(T)), "hipHostMalloc");
+        std::fill(p, p + count, T(0));
+    }
+    ~PinnedArray() {
+        if (p) (void)hipHostFree(p);
+    }
+    T &operator[](size_t i) { return p[i]; }
+    const T &operator[](size_t i) const { return p[i]; }
+    PinnedArray(const PinnedArray &) = delete;
+    PinnedArray &operator=(const PinnedArray &) = delete;
+};
 }  // namespace detail
 
 // Groupwise set-up with the subjects sharded over the ranks.  Every rank has created the group with ALL control grids and labels
@@ -125,9 +143,10 @@ inline std::vector<int32_t> sharded_group_setup(msm_group *g, const Comm &c) {
     shard(S, c.rank(), c.world(), lo, hi);
     std::vector<int32_t> mine;
     for (int s = lo; s < hi; ++s) mine.push_back(s);
-    // more than one rank: the pair list control point by control point, so that the contiguous slice of it a rank evaluates in every label step is a
-    // region of the sphere (msmhip.h: msm_group_set_pair_layout; newmsm_amd/dist.py does the same)
-    if (c.world() > 1) check_msm(msm_group_set_pair_layout(g, 1), "msm_group_set_pair_layout");
+    // the pair list control point by control point, so that the contiguous slice of it a rank evaluates in every label step is a region of the sphere
+    // (msmhip.h: msm_group_set_pair_layout; newmsm_amd/dist.py does the same) -- for ANY number of ranks, one included: the optimiser consumes pairs and
+    // costs in list order, and a launched run must not depend on how many ranks it was given
+    check_msm(msm_group_set_pair_layout(g, 1), "msm_group_set_pair_layout");
     check_msm(msm_group_setup_subjects(g, mine.data(), (int32_t)mine.size()), "msm_group_setup_subjects");
     if (c.world() > 1) {
         int nmax = 0;
@@ -137,7 +156,7 @@ inline std::vector<int32_t> sharded_group_setup(msm_group *g, const Comm &c) {
             nmax = std::max(nmax, b - a);
         }
         // 1. how long every subject's index list is
-        std::vector<long long> counts(nmax, 0), all_counts((size_t)c.world() * nmax, 0);
+        detail::PinnedArray<long long> counts(nmax), all_counts((size_t)c.world() * nmax);
         for (size_t k = 0; k < mine.size(); ++k) {
             int64_t n = 0;
             check_msm(msm_group_export_subject_dev(g, mine[k], nullptr, nullptr, nullptr, 0, &n), "msm_group_export_subject_dev (count)");
@@ -145,23 +164,27 @@ inline std::vector<int32_t> sharded_group_setup(msm_group *g, const Comm &c) {
         }
         {
             detail::DeviceArray<long long> d_counts(nmax), d_all((size_t)c.world() * nmax);
-            check_hip(hipMemcpyAsync(d_counts.p, counts.data(), sizeof(long long) * nmax, hipMemcpyHostToDevice, c.stream()), "copy counts");
+            check_hip(hipMemcpyAsync(d_counts.p, counts.p, sizeof(long long) * nmax, hipMemcpyHostToDevice, c.stream()), "copy counts");
             c.all_gather(d_counts.p, d_all.p, (size_t)nmax);
-            check_hip(hipMemcpyAsync(all_counts.data(), d_all.p, sizeof(long long) * all_counts.size(), hipMemcpyDeviceToHost, c.stream()), "copy counts back");
+            check_hip(hipMemcpyAsync(all_counts.p, d_all.p, sizeof(long long) * all_counts.n, hipMemcpyDeviceToHost, c.stream()), "copy counts back");
             c.synchronize();
         }
-        const size_t imax = (size_t)std::max<long long>(1, *std::max_element(all_counts.begin(), all_counts.end()));
+        const size_t imax = (size_t)std::max<long long>(1, *std::max_element(all_counts.p, all_counts.p + all_counts.n));
         const size_t per_F = (size_t)L * D * Vt, per_pp = (size_t)N * L + 1;
         // 2. this rank's shard in device buffers libmsmhip fills, 3. three all-gathers, 4. the other ranks' subjects read back from them
         detail::DeviceArray<double> F(nmax * per_F), aF((size_t)c.world() * nmax * per_F);
         detail::DeviceArray<int32_t> pp(nmax * per_pp), app((size_t)c.world() * nmax * per_pp), pi(nmax * imax), api((size_t)c.world() * nmax * imax);
         check_hip(hipMemsetAsync(pi.p, 0, sizeof(int32_t) * nmax * imax, c.stream()), "hipMemsetAsync");
+        // the stream contract of the ..._dev entry points (msmhip.h): the library writes these buffers on ITS stream, which does not order against ours --
+        // it waits for the fill above (an event, no host wait); a fill landing after the export would wipe exported rows
+        msm_ctx *lib = msm_group_context(g);
+        check_msm(msm_ctx_wait_stream(lib, c.stream()), "msm_ctx_wait_stream");
         for (size_t k = 0; k < mine.size(); ++k)
             check_msm(msm_group_export_subject_dev(g, mine[k], F.p + k * per_F, pp.p + k * per_pp, pi.p + k * imax, (int64_t)imax, nullptr), "msm_group_export_subject_dev");
         c.all_gather(F.p, aF.p, nmax * per_F);
         c.all_gather(pp.p, app.p, nmax * per_pp);
         c.all_gather(pi.p, api.p, nmax * imax);
-        c.synchronize();
+        check_msm(msm_ctx_wait_stream(lib, c.stream()), "msm_ctx_wait_stream");  // the imports below read what the collectives are still writing
         for (int r = 0; r < c.world(); ++r) {
             if (r == c.rank()) continue;
             int a, b;
@@ -203,10 +226,13 @@ inline TemplateUpdate group_template_update(const double *local_xyz, int n_local
     }
     acc[total - 1] = (double)n_local;
     detail::DeviceArray<double> d(total);
-    check_hip(hipMemcpyAsync(d.p, acc.data(), sizeof(double) * total, hipMemcpyHostToDevice, c.stream()), "upload accumulators");
+    detail::PinnedArray<double> pinned(total);  // the copy engine's side of the two transfers (see PinnedArray)
+    std::copy(acc.begin(), acc.end(), pinned.p);
+    check_hip(hipMemcpyAsync(d.p, pinned.p, sizeof(double) * total, hipMemcpyHostToDevice, c.stream()), "upload accumulators");
     c.all_reduce_sum(d.p, total);
-    check_hip(hipMemcpyAsync(acc.data(), d.p, sizeof(double) * total, hipMemcpyDeviceToHost, c.stream()), "download accumulators");
+    check_hip(hipMemcpyAsync(pinned.p, d.p, sizeof(double) * total, hipMemcpyDeviceToHost, c.stream()), "download accumulators");
     c.synchronize();
+    std::copy(pinned.p, pinned.p + total, acc.begin());
     TemplateUpdate out;
     out.n_subjects = (long long)std::llround(acc[total - 1]);
     const double n = std::max(1.0, acc[total - 1]);

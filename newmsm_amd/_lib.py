@@ -68,6 +68,9 @@ SIGNATURES = {
     "msm_ctx_time_queries": (C.c_int, [_VP, C.c_int]),
     "msm_ctx_query_kernel_ms": (C.c_int, [_VP, c_dp]),
     "msm_query_lanes": (C.c_int, [C.c_int64]),
+    "msm_group_context": (_VP, [_VP]),
+    "msm_ctx_wait_stream": (C.c_int, [_VP, _VP]),
+    "msm_ctx_staging_stats": (C.c_int, [_VP, C.POINTER(C.c_int64)]),
     "msm_host_alloc": (_VP, [_VP, C.c_size_t]),
     "msm_host_free": (None, [_VP, _VP]),
     "msm_host_register": (C.c_int, [_VP, _VP, C.c_size_t]),

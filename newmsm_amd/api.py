@@ -177,6 +177,17 @@ class Context:
     def stream(self):
         return lib().msm_ctx_stream(self.h)
 
+    def wait_stream(self, hip_stream=None):
+        """everything the library queues on this context from now on waits for what `hip_stream` (a hipStream_t value; None = the default stream)
+        holds now (msm_ctx_wait_stream): the ordering a caller owes the ..._dev entry points for buffers its own stream is still filling"""
+        check(lib().msm_ctx_wait_stream(self.h, C.c_void_p(hip_stream or 0)))
+
+    def staging_stats(self):
+        """pinned staging blocks of this context: dict(blocks, bytes, allocated, waits) (msm_ctx_staging_stats)"""
+        out = (C.c_int64 * 4)()
+        check(lib().msm_ctx_staging_stats(self.h, out))
+        return dict(blocks=int(out[0]), bytes=int(out[1]), allocated=int(out[2]), waits=int(out[3]))
+
     def host_array(self, shape, dtype=np.float64):
         """A numpy array in pinned host memory mapped into the GPU's address space (msm_host_alloc): passed as an output array
         the kernels write it directly.  Lives as long as the context."""

@@ -18,8 +18,12 @@ namespace msm {
 
 int ctx_io_pinned(msm_ctx *ctx, size_t bytes, void **out) {
     if (bytes > ctx->io_cap || !ctx->io_pin) {
-        MSM_HIP(hipStreamSynchronize(ctx->stream));
-        if (ctx->io_pin) (void)hipHostFree(ctx->io_pin);
+        // the old block is mapped into the device's address space: nothing queued anywhere (this stream, a copy stream, a queued label step) may still
+        // reach it when it goes -- rare (the block grows a handful of times per process), so the whole device is waited for
+        if (ctx->io_pin) {
+            MSM_HIP(hipDeviceSynchronize());
+            (void)hipHostFree(ctx->io_pin);
+        }
         ctx->io_pin = nullptr;
         ctx->io_cap = bytes + bytes / 4 + 4096;
         if (hipHostMalloc(&ctx->io_pin, ctx->io_cap, hipHostMallocMapped) != hipSuccess) {
@@ -53,7 +57,7 @@ int ctx_flag(msm_ctx *ctx) {
 
 int check_status(msm_ctx *ctx, const char *what) {
     MSM_HIP(hipMemcpyAsync(ctx->h_status, ctx->d_status, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    MSM_HIP(hipStreamSynchronize(ctx->stream));
+    MSM_TRY(ctx_sync(ctx));  // (+ the deliveries of stage_d2h)
     const int st = *ctx->h_status;
     if (st != 0) {
         MSM_HIP(hipMemsetAsync(ctx->d_status, 0, sizeof(int), ctx->stream));
@@ -86,7 +90,6 @@ static int upload_tree(msm_mesh *m) {
     MSM_HIP(grow((void **)&m->d_rec, m->cap_rec, (size_t)m->T, sizeof(TriRec)));
     MSM_HIP(grow((void **)&m->d_grid, m->cap_grid, m->tree.grid.size(), sizeof(int32_t)));
     MSM_HIP(grow((void **)&m->d_nodebox, m->cap_box, m->tree.node.size(), sizeof(double4)));
-    // all arrays go through one pinned staging buffer: a host memcpy each, then DMA at link speed
     struct Part {
         void *dst;
         const void *src;
@@ -99,28 +102,12 @@ static int upload_tree(msm_mesh *m) {
         {m->d_grid, m->tree.grid.data(), m->tree.grid.size() * sizeof(int32_t)},
         {m->d_nodebox, m->tree.nodebox.data(), m->tree.nodebox.size() * sizeof(double4)},
     };
-    size_t total = 0;
-    for (const Part &pt : parts) total += (pt.bytes + 255) & ~(size_t)255;
-    std::unique_lock<std::mutex> lock(ctx->stage_mu);
-    MSM_HIP(hipStreamSynchronize(ctx->stream));  // an earlier upload may still read the staging buffer
-    if (total > ctx->stage_cap) {
-        if (ctx->stage) (void)hipHostFree(ctx->stage);
-        ctx->stage = nullptr;
-        ctx->stage_cap = total + total / 4;
-        MSM_HIP(hipHostMalloc(&ctx->stage, ctx->stage_cap));
-    }
-    size_t off = 0;
-    for (const Part &pt : parts) {
-        if (pt.bytes == 0) continue;
-        std::memcpy((char *)ctx->stage + off, pt.src, pt.bytes);
-        MSM_HIP(hipMemcpyAsync(pt.dst, (char *)ctx->stage + off, pt.bytes, hipMemcpyHostToDevice, ctx->stream));
-        off += (pt.bytes + 255) & ~(size_t)255;
-    }
+    for (const Part &pt : parts) MSM_TRY(stage_h2d(ctx, pt.dst, pt.src, pt.bytes));  // pinned staging blocks (stager.cpp): a host memcpy each, then DMA at link speed
     {
         int st = launch_build_recs(ctx, m->d_xyz, m->V, m->d_tri, m->T, m->d_rec, m->d_tcone, m->d_leaf_tri, (int)m->tree.leaf_tri.size(), m->d_cone);
         if (st) return st;
     }
-    MSM_HIP(hipStreamSynchronize(ctx->stream));
+    MSM_TRY(ctx_sync(ctx));
     return finish_tree(m);
 }
 
@@ -153,20 +140,10 @@ int upload_staged(msm_ctx *ctx, void *dst, const void *src, size_t bytes) {
         // the caller's array lies in a pinned block of this context (msm_host_alloc / msm_host_register): the copy engine reads it where it is -- no
         // pass through the staging block (a 10 MB feature matrix: 1 ms of memcpy).  Complete on return: the caller may write the array again
         MSM_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
-        MSM_HIP(hipStreamSynchronize(ctx->stream));
+        MSM_TRY(ctx_sync(ctx));
         return MSM_OK;
     }
-    std::lock_guard<std::mutex> lock(ctx->stage_mu);
-    MSM_HIP(hipStreamSynchronize(ctx->stream));  // an earlier upload may still read the staging buffer
-    if (bytes > ctx->stage_cap) {
-        if (ctx->stage) (void)hipHostFree(ctx->stage);
-        ctx->stage = nullptr;
-        ctx->stage_cap = bytes + bytes / 4;
-        MSM_HIP(hipHostMalloc(&ctx->stage, ctx->stage_cap));
-    }
-    std::memcpy(ctx->stage, src, bytes);
-    MSM_HIP(hipMemcpyAsync(dst, ctx->stage, bytes, hipMemcpyHostToDevice, ctx->stream));
-    return MSM_OK;
+    return stage_h2d(ctx, dst, src, bytes);
 }
 
 static int ensure_tree_overlapped(msm_mesh *m, const std::function<void()> *overlap);
@@ -208,8 +185,8 @@ static int ensure_tree_overlapped(msm_mesh *m, const std::function<void()> *over
     }
     if (m->host_xyz_stale) {
         // on the context's stream (created non-blocking: the null stream does not wait for the kernels that wrote the coordinates there)
-        MSM_HIP(hipMemcpyAsync(m->xyz.data(), m->d_xyz, sizeof(double) * 3 * (size_t)m->V, hipMemcpyDeviceToHost, m->ctx->stream));
-        MSM_HIP(hipStreamSynchronize(m->ctx->stream));
+        MSM_TRY(stage_d2h(m->ctx, m->xyz.data(), m->d_xyz, sizeof(double) * 3 * (size_t)m->V));
+        MSM_TRY(ctx_sync(m->ctx));
         m->host_xyz_stale = false;
     }
     build_octree(m->xyz.data(), m->tri.data(), m->V, m->T, m->tree);
@@ -219,7 +196,7 @@ static int ensure_tree_overlapped(msm_mesh *m, const std::function<void()> *over
 // new coordinates together with the search structure built for them elsewhere (e.g. on a worker thread)
 int install_coords_and_tree(msm_mesh *m, const double *xyz, FlatOctree &&tree) {
     msm_ctx *ctx = m->ctx;
-    MSM_HIP(hipStreamSynchronize(ctx->stream));
+    MSM_TRY(ctx_sync(ctx));
     m->xyz.assign(xyz, xyz + 3 * (size_t)m->V);
     {
         const int st = upload_staged(ctx, m->d_xyz, m->xyz.data(), sizeof(double) * 3 * (size_t)m->V);
@@ -356,8 +333,8 @@ int ensure_rays(msm_mesh *m, bool wait) {
     if (st) return st;
     if (m->host_xyz_stale) {  // coordinates written on the device (group.cpp: lane meshes): the table is keyed by and built from the host copy
         // on the context's stream (created non-blocking: the null stream does not wait for the kernels that wrote the coordinates there)
-        MSM_HIP(hipMemcpyAsync(m->xyz.data(), m->d_xyz, sizeof(double) * 3 * (size_t)m->V, hipMemcpyDeviceToHost, m->ctx->stream));
-        MSM_HIP(hipStreamSynchronize(m->ctx->stream));
+        MSM_TRY(stage_d2h(m->ctx, m->xyz.data(), m->d_xyz, sizeof(double) * 3 * (size_t)m->V));
+        MSM_TRY(ctx_sync(m->ctx));
         m->host_xyz_stale = false;
     }
     if (m->rays_valid) return ensure_rayrec(m);
@@ -437,7 +414,7 @@ int ensure_rays(msm_mesh *m, bool wait) {
             if (!st && !m->tree.ray_excl.empty()) st = upload_staged(ctx, m->d_ray_excl, m->tree.ray_excl.data(), m->tree.ray_excl.size() * sizeof(int4));
             if (st) return st;
         }
-        MSM_HIP(hipStreamSynchronize(ctx->stream));
+        MSM_TRY(ctx_sync(ctx));
         m->rayrec_valid = false;
     }
     m->rays_valid = true;
@@ -602,11 +579,11 @@ int adaptive_queries(msm_mesh *in_mesh, msm_mesh *new_mesh, bool with_closest, A
         msm_ctx *ctx = in_mesh->ctx;
         DevBuf<double> dq;
         DevBuf<int> dout;
-        MSM_HIP(dq.upload(new_mesh->xyz.data(), 3 * (size_t)nNew, ctx->stream));
+        MSM_TRY(dq.upload(new_mesh->xyz.data(), 3 * (size_t)nNew, ctx));
         MSM_HIP(dout.ensure(nNew));
         st = launch_closest_vertex(ctx, dev_tree(in_mesh), dq.p, nNew, dout.p);
         if (st) return st;
-        MSM_HIP(dout.download(q.closest.data(), nNew, ctx->stream));
+        MSM_TRY(dout.download(q.closest.data(), nNew, ctx));
         st = check_status(ctx, "adaptive weights (exclusion)");
         if (st) return st;
     }
@@ -626,7 +603,7 @@ int ensure_adjacency_dev(msm_mesh *m) {
         st = upload_staged(ctx, m->d_tid, adj.tid.data(), sizeof(int32_t) * adj.tid.size());
         if (st) return st;
     }
-    MSM_HIP(hipStreamSynchronize(ctx->stream));
+    MSM_TRY(ctx_sync(ctx));
     return MSM_OK;
 }
 
@@ -711,15 +688,15 @@ static int adaptive_weights_via_device(msm_mesh *in_mesh, msm_mesh *new_mesh, st
     if (st) return st;
     msm_ctx *ctx = in_mesh->ctx;
     row_ptr.resize((size_t)w.nNew + 1);
-    MSM_HIP(hipMemcpyAsync(row_ptr.data(), w.row_ptr, sizeof(int32_t) * row_ptr.size(), hipMemcpyDeviceToHost, ctx->stream));
-    MSM_HIP(hipStreamSynchronize(ctx->stream));
+    MSM_TRY(stage_d2h(ctx, row_ptr.data(), w.row_ptr, sizeof(int32_t) * row_ptr.size()));
+    MSM_TRY(ctx_sync(ctx));
     const size_t nnz = (size_t)row_ptr.back();
     col.resize(nnz);
     val.resize(nnz);
     if (nnz) {
-        MSM_HIP(hipMemcpyAsync(col.data(), w.col, sizeof(int32_t) * nnz, hipMemcpyDeviceToHost, ctx->stream));
-        MSM_HIP(hipMemcpyAsync(val.data(), w.val, sizeof(double) * nnz, hipMemcpyDeviceToHost, ctx->stream));
-        MSM_HIP(hipStreamSynchronize(ctx->stream));
+        MSM_TRY(stage_d2h(ctx, col.data(), w.col, sizeof(int32_t) * nnz));
+        MSM_TRY(stage_d2h(ctx, val.data(), w.val, sizeof(double) * nnz));
+        MSM_TRY(ctx_sync(ctx));
     }
     return MSM_OK;
 }
@@ -849,6 +826,7 @@ static msm_ctx *ctx_make(int device, hipStream_t stream, bool own) {
     }
     ctx->own_stream = own;
     ctx->stream = stream;
+    stager_create(ctx);
     if (own && hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
         delete ctx;
         fail(MSM_ERR_HIP, "hipStreamCreate failed");
@@ -870,12 +848,15 @@ msm_ctx *msm_ctx_create_on_stream(int device, void *hip_stream) { return ctx_mak
 void msm_ctx_destroy(msm_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    // pinned blocks below are mapped into the device's address space (the device address of pinned host memory is the host address): the whole device
+    // is idle before any of them goes -- other streams of the family (a group's copy stream and lanes) may have been given their addresses
+    (void)hipDeviceSynchronize();
+    stager_destroy(ctx);
     for (void *b : ctx->q_buf)
         if (b) (void)msm::pool_free(b);
-    if (ctx->stage) (void)hipHostFree(ctx->stage);
     if (ctx->io_pin) (void)hipHostFree(ctx->io_pin);
     if (ctx->h_flag) (void)hipHostFree(ctx->h_flag);
+    if (ctx->wait_ev) (void)hipEventDestroy(ctx->wait_ev);
     if (ctx->q_ev0) (void)hipEventDestroy(ctx->q_ev0);
     if (ctx->q_ev1) (void)hipEventDestroy(ctx->q_ev1);
     if (ctx->oct_box) (void)msm::pool_free(ctx->oct_box);
@@ -892,11 +873,28 @@ void msm_ctx_destroy(msm_ctx *ctx) {
 
 int msm_ctx_synchronize(msm_ctx *ctx) {
     if (!ctx) return fail(MSM_ERR_INVALID, "null context");
-    MSM_HIP(hipStreamSynchronize(ctx->stream));
+    MSM_TRY(ctx_sync(ctx));
     return MSM_OK;
 }
 
 void *msm_ctx_stream(msm_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+int msm_ctx_wait_stream(msm_ctx *ctx, void *hip_stream) {
+    if (!ctx) return fail(MSM_ERR_INVALID, "null context");
+    hipStream_t other = static_cast<hipStream_t>(hip_stream);
+    if (other == ctx->stream) return MSM_OK;
+    MSM_HIP(hipSetDevice(ctx->device));
+    if (!ctx->wait_ev) MSM_HIP(hipEventCreateWithFlags(&ctx->wait_ev, hipEventDisableTiming));
+    MSM_HIP(hipEventRecord(ctx->wait_ev, other));
+    MSM_HIP(hipStreamWaitEvent(ctx->stream, ctx->wait_ev, 0));
+    return MSM_OK;
+}
+
+int msm_ctx_staging_stats(msm_ctx *ctx, int64_t out[4]) {
+    if (!ctx || !out) return fail(MSM_ERR_INVALID, "msm_ctx_staging_stats: null argument");
+    stager_stats(ctx, out);
+    return MSM_OK;
+}
 
 void msm_store_release_i64(int64_t *addr, int64_t value) { __atomic_store_n(addr, value, __ATOMIC_RELEASE); }
 int64_t msm_load_acquire_i64(const int64_t *addr) { return __atomic_load_n(addr, __ATOMIC_ACQUIRE); }
@@ -956,7 +954,9 @@ void msm_host_free(msm_ctx *ctx, void *p) {
     for (size_t i = 0; i < ctx->host_blocks.size(); ++i)
         if (ctx->host_blocks[i].host == (char *)p) {
             (void)hipSetDevice(ctx->device);
-            (void)hipStreamSynchronize(ctx->stream);
+            (void)drop_ctx_pending(ctx);   // a label step queued into the block is waited for and forgotten ...
+            ++ctx->epoch;                  // ... and none queued from now on is matched through an address the next block may be given again
+            (void)hipDeviceSynchronize();  // a group's copy stream, another context of the family: nothing may still write the block
             (void)(ctx->host_blocks[i].registered ? hipHostUnregister(p) : hipHostFree(p));
             ctx->host_blocks.erase(ctx->host_blocks.begin() + i);
             return;
@@ -965,6 +965,12 @@ void msm_host_free(msm_ctx *ctx, void *p) {
 
 int msm_host_register(msm_ctx *ctx, void *p, size_t bytes) {
     if (!ctx || !p || bytes == 0) return fail(MSM_ERR_INVALID, "msm_host_register: bad arguments");
+    // Page-locking works on whole pages and the device address of the block is its host address: a range that shares its first or last page with
+    // other data shares the GPU mapping of that page with whatever else gets page-locked there (the HIP runtime locks pageable buffers of asynchronous
+    // copies on its own), and the first of the two to be released unmaps it under the other (stager.cpp).  Only whole pages are taken.
+    if (reinterpret_cast<uintptr_t>(p) % 4096 != 0 || bytes % 4096 != 0)
+        return fail(MSM_ERR_INVALID, "msm_host_register: the block must start on a page boundary and cover whole pages (4096 bytes): %p + %zu does not -- "
+                                     "use msm_host_alloc, or register a page-aligned mapping (mmap, shared memory, posix_memalign)", p, bytes);
     MSM_HIP(hipSetDevice(ctx->device));
     msm_ctx::HostBlock b{static_cast<char *>(p), nullptr, bytes, true};
     if (hipHostRegister(p, bytes, hipHostRegisterMapped | hipHostRegisterPortable) != hipSuccess) {
@@ -1024,12 +1030,13 @@ void msm_mesh_destroy(msm_mesh *m) {
 
 int msm_mesh_update_coords(msm_mesh *m, const double *xyz) {
     if (!m || !xyz) return fail(MSM_ERR_INVALID, "msm_mesh_update_coords: null argument");
-    MSM_HIP(hipStreamSynchronize(m->ctx->stream));  // the host copy may still be the source of an async upload
+    ++m->ctx->epoch;  // a label step queued ahead was evaluated on the old coordinates: not to be taken (msm_ctx::epoch)
+    MSM_TRY(ctx_sync(m->ctx));  // the host copy may still be the source of an async upload
     m->xyz.assign(xyz, xyz + 3 * (size_t)m->V);
     m->tree_valid = false;
     const int st = upload_staged(m->ctx, m->d_xyz, m->xyz.data(), sizeof(double) * 3 * (size_t)m->V);
     if (st) return st;
-    MSM_HIP(hipStreamSynchronize(m->ctx->stream));  // as with the pageable copy this replaces: the coordinates have arrived when the call returns
+    MSM_TRY(ctx_sync(m->ctx));  // as with the pageable copy this replaces: the coordinates have arrived when the call returns
     return MSM_OK;
 }
 
@@ -1038,7 +1045,7 @@ int msm_mesh_prepare_search(msm_mesh *m, int wait, int32_t *ready) {
     MSM_HIP(hipSetDevice(m->ctx->device));
     int st = ensure_rays(m, wait != 0);
     if (st) return st;
-    MSM_HIP(hipStreamSynchronize(m->ctx->stream));
+    MSM_TRY(ctx_sync(m->ctx));
     const char *mode = std::getenv("MSMHIP_RAYTABLE");
     if (ready) *ready = (m->rays_valid || (mode && std::strcmp(mode, "off") == 0)) ? 1 : 0;
     return MSM_OK;
@@ -1052,8 +1059,9 @@ int msm_mesh_get_coords(msm_mesh *m, double *xyz) {
 
 int msm_mesh_set_features(msm_mesh *m, const double *feat, int32_t D) {
     if (!m || !feat || D <= 0) return fail(MSM_ERR_INVALID, "msm_mesh_set_features: bad arguments");
+    ++m->ctx->epoch;
     const int V = m->V;
-    MSM_HIP(hipStreamSynchronize(m->ctx->stream));
+    MSM_TRY(ctx_sync(m->ctx));
     m->feat.assign(feat, feat + (size_t)D * V);
     std::vector<double> vm((size_t)D * V);  // vertex-major rows so that a gather by vertex id reads D contiguous values
     for (int d = 0; d < D; ++d)
@@ -1069,7 +1077,7 @@ int msm_mesh_set_features(msm_mesh *m, const double *feat, int32_t D) {
         const int st = upload_staged(m->ctx, m->d_feat, vm.data(), sizeof(double) * (size_t)D * V);  // pinned staging: pageable copies of megabytes crawl
         if (st) return st;
     }
-    MSM_HIP(hipStreamSynchronize(m->ctx->stream));
+    MSM_TRY(ctx_sync(m->ctx));
     return MSM_OK;
 }
 
@@ -1099,9 +1107,11 @@ int msm_mesh_octree_signature(msm_mesh *m, int64_t stats[5], uint64_t *signature
     std::vector<int4> node(n);
     std::vector<double4> box(n);
     std::vector<int32_t> leaf((size_t)std::max(ne, 1));
-    MSM_HIP(hipMemcpy(node.data(), m->d_node, sizeof(int4) * (size_t)n, hipMemcpyDeviceToHost));
-    MSM_HIP(hipMemcpy(box.data(), m->d_nodebox, sizeof(double4) * (size_t)n, hipMemcpyDeviceToHost));
-    if (ne > 0) MSM_HIP(hipMemcpy(leaf.data(), m->d_leaf_tri, sizeof(int32_t) * (size_t)ne, hipMemcpyDeviceToHost));
+    msm_ctx *ctx = m->ctx;
+    MSM_TRY(stage_d2h(ctx, node.data(), m->d_node, sizeof(int4) * (size_t)n));
+    MSM_TRY(stage_d2h(ctx, box.data(), m->d_nodebox, sizeof(double4) * (size_t)n));
+    if (ne > 0) MSM_TRY(stage_d2h(ctx, leaf.data(), m->d_leaf_tri, sizeof(int32_t) * (size_t)ne));
+    MSM_TRY(ctx_sync(ctx));
     uint64_t sum = 0;
     for (int i = 0; i < n; ++i) {
         if (node[i].x >= 0) continue;
@@ -1129,20 +1139,21 @@ int msm_octree_forest_signatures(msm_ctx *ctx, const double *xyz, int32_t V, con
     MSM_HIP(hipSetDevice(ctx->device));
     DevBuf<double> d_xyz;
     DevBuf<int32_t> d_tri;
-    MSM_HIP(d_xyz.upload(xyz, (size_t)3 * V * B, ctx->stream));
-    MSM_HIP(d_tri.upload(tri, (size_t)3 * T, ctx->stream));
+    MSM_TRY(d_xyz.upload(xyz, (size_t)3 * V * B, ctx));
+    MSM_TRY(d_tri.upload(tri, (size_t)3 * T, ctx));
     Forest f;
     int st = gpu_build_forest(ctx, f, d_xyz.p, (size_t)V, (size_t)3 * V, V, d_tri.p, T, B);
     if (st) return st == MSM_ERR_CAPACITY ? fail(st, "msm_octree_forest_signatures: a tree outgrew the preallocated arrays") : st;
-    MSM_HIP(hipStreamSynchronize(ctx->stream));
+    MSM_TRY(ctx_sync(ctx));
     for (int b = 0; b < B; ++b) {
         const int n = f.info[b].nnodes, ne = f.info[b].entries;
         std::vector<int4> node(n);
         std::vector<double4> box(n);
         std::vector<int32_t> leaf((size_t)std::max(ne, 1));
-        MSM_HIP(hipMemcpy(node.data(), f.node.p + (size_t)b * f.s_node, sizeof(int4) * (size_t)n, hipMemcpyDeviceToHost));
-        MSM_HIP(hipMemcpy(box.data(), f.nodebox.p + (size_t)b * f.s_node, sizeof(double4) * (size_t)n, hipMemcpyDeviceToHost));
-        if (ne > 0) MSM_HIP(hipMemcpy(leaf.data(), f.leaf_tri.p + (size_t)b * f.s_leaf, sizeof(int32_t) * (size_t)ne, hipMemcpyDeviceToHost));
+            MSM_TRY(stage_d2h(ctx, node.data(), f.node.p + (size_t)b * f.s_node, sizeof(int4) * (size_t)n));
+        MSM_TRY(stage_d2h(ctx, box.data(), f.nodebox.p + (size_t)b * f.s_node, sizeof(double4) * (size_t)n));
+        if (ne > 0) MSM_TRY(stage_d2h(ctx, leaf.data(), f.leaf_tri.p + (size_t)b * f.s_leaf, sizeof(int32_t) * (size_t)ne));
+        MSM_TRY(ctx_sync(ctx));
         uint64_t sum = 0;
         for (int i = 0; i < n; ++i) {
             if (node[i].x >= 0) continue;
@@ -1229,14 +1240,14 @@ int msm_metric_resample(msm_mesh *in_mesh, const double *data, int32_t D, msm_me
         if (st) return st;
         if (ctx_mapped(ctx, out, sizeof(double) * nout)) {  // the caller's array is pinned for this context: one copy command, no memcpy
             MSM_HIP(hipMemcpyAsync(out, s.out.p, sizeof(double) * nout, hipMemcpyDeviceToHost, ctx->stream));
-            MSM_HIP(hipStreamSynchronize(ctx->stream));
+            MSM_TRY(ctx_sync(ctx));
             return MSM_OK;
         }
         void *pin = nullptr;
         st = ctx_io_pinned(ctx, sizeof(double) * nout, &pin);
         if (st) return st;
         MSM_HIP(hipMemcpyAsync(pin, s.out.p, sizeof(double) * nout, hipMemcpyDeviceToHost, ctx->stream));
-        MSM_HIP(hipStreamSynchronize(ctx->stream));
+        MSM_TRY(ctx_sync(ctx));
         std::memcpy(out, pin, sizeof(double) * nout);
         return MSM_OK;
     }
@@ -1321,6 +1332,7 @@ int msm_sphere_project_warp(msm_mesh *from, const double *to_xyz, double *sphere
 // (M/mesh_registration.cpp:224) without the three host round trips of the array version (queries up, ids and weights down, result up again).
 int msm_mesh_sphere_project_warp(msm_mesh *sphere, msm_mesh *from, const double *to_xyz) {
     if (!sphere || !from || !to_xyz) return fail(MSM_ERR_INVALID, "msm_mesh_sphere_project_warp: null argument");
+    ++sphere->ctx->epoch;
     if (sphere->ctx != from->ctx) return fail(MSM_ERR_INVALID, "msm_mesh_sphere_project_warp: the meshes belong to different contexts");
     if (sphere == from) return fail(MSM_ERR_INVALID, "msm_mesh_sphere_project_warp: a mesh cannot be warped through itself");
     msm_ctx *ctx = from->ctx;
@@ -1370,15 +1382,15 @@ int msm_smooth_data(msm_mesh *orig, const double *data, int32_t D, msm_mesh *sph
     MSM_HIP(ddata.ensure((size_t)D * orig->V));
     st = upload_staged(ctx, ddata.p, data, sizeof(double) * (size_t)D * orig->V);
     if (st) return st;
-    if (excl) MSM_HIP(dexcl.upload(excl, (size_t)orig->V, ctx->stream));
+    if (excl) MSM_TRY(dexcl.upload(excl, (size_t)orig->V, ctx));
     MSM_HIP(dout.ensure((size_t)D * N));
     if (excl && excl_out) MSM_HIP(dexo.ensure(N));
     const double ang = 4 * asin(sigma / (2 * kRad));  // :175, with the host's libm like the reference
     st = launch_smooth(ctx, sphlow->d_xyz, N, dunit.p, dcv.p, ddata.p, orig->V, D, sigma, cos(ang), excl ? dexcl.p : nullptr, dout.p,
                        (excl && excl_out) ? dexo.p : nullptr);
     if (st) return st;
-    MSM_HIP(dout.download(out, (size_t)D * N, ctx->stream));
-    if (excl && excl_out) MSM_HIP(dexo.download(excl_out, N, ctx->stream));
+    MSM_TRY(dout.download(out, (size_t)D * N, ctx));
+    if (excl && excl_out) MSM_TRY(dexo.download(excl_out, N, ctx));
     return check_status(ctx, "msm_smooth_data");
 }
 

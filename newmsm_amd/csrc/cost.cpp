@@ -40,7 +40,7 @@ int ensure_vertex_major(msm_cost *c) {
         const int st = upload_staged(ctx, c->d_cfw_vm.p, wm.data(), sizeof(double) * wm.size());
         if (st) return st;
     }
-    MSM_HIP(hipStreamSynchronize(ctx->stream));
+    MSM_TRY(ctx_sync(ctx));
     c->vm_valid = true;
     return MSM_OK;
 }
@@ -83,7 +83,7 @@ inline int cfw_nrows(const msm_cost *c) { return c->cfw.empty() ? 1 : c->cfw_row
 int patches_by_range(msm_cost *c) {
     msm_ctx *ctx = c->ctx;
     const int N = c->cpgrid->V, Ns = c->source->V;
-    MSM_HIP(c->d_maxsep.upload(c->maxsep.data(), N, ctx->stream));
+    MSM_TRY(c->d_maxsep.upload(c->maxsep.data(), N, ctx));
     MSM_HIP(c->d_counts.ensure((size_t)N + 1));  // + the number of undecided entries
     MSM_HIP(c->d_chunkb.ensure((size_t)(Ns + 63) / 64 + 1));
     int cap = std::max(128, c->patch_cap_hint);  // the previous call's largest patch: one k_range pass instead of two
@@ -95,8 +95,8 @@ int patches_by_range(msm_cost *c) {
         int st = launch_range(ctx, c->cpgrid->d_xyz, N, c->source->d_xyz, Ns, c->d_maxsep.p, c->p.range, cap, c->d_slots.p, c->d_counts.p, c->d_chunkb.p,
                               c->d_counts.p + N);
         if (st) return st;
-        MSM_HIP(c->d_counts.download(counts.data(), (size_t)N + 1, ctx->stream));
-        MSM_HIP(hipStreamSynchronize(ctx->stream));
+        MSM_TRY(c->d_counts.download(counts.data(), (size_t)N + 1, ctx));
+        MSM_TRY(ctx_sync(ctx));
         const int mx = *std::max_element(counts.begin(), counts.begin() + N);
         c->patch_cap_hint = std::max(c->patch_cap_hint, mx + 16);
         if (mx <= cap) break;
@@ -109,20 +109,20 @@ int patches_by_range(msm_cost *c) {
         c->pptr.assign((size_t)N + 1, 0);
         for (int k = 0; k < N; ++k) c->pptr[k + 1] = c->pptr[k] + counts[k];
         const size_t total = (size_t)c->pptr[N];
-        MSM_HIP(c->d_pptr.upload(c->pptr.data(), c->pptr.size(), ctx->stream));
+        MSM_TRY(c->d_pptr.upload(c->pptr.data(), c->pptr.size(), ctx));
         MSM_HIP(c->d_pidx_asc.ensure(std::max<size_t>(total, 1)));
         int st = launch_patch_compact(ctx, c->d_slots.p, cap, c->d_pptr.p, N, c->d_pidx_asc.p);
         if (st) return st;
         c->pidx.resize(total);
-        if (total) MSM_HIP(c->d_pidx_asc.download(c->pidx.data(), total, ctx->stream));
-        MSM_HIP(hipStreamSynchronize(ctx->stream));
+        if (total) MSM_TRY(c->d_pidx_asc.download(c->pidx.data(), total, ctx));
+        MSM_TRY(ctx_sync(ctx));
         c->pidx_asc_on_device = true;
         c->ngroups = N;
         return MSM_OK;
     }
     slots.resize((size_t)N * cap);
-    MSM_HIP(c->d_slots.download(slots.data(), slots.size(), ctx->stream));
-    MSM_HIP(hipStreamSynchronize(ctx->stream));
+    MSM_TRY(c->d_slots.download(slots.data(), slots.size(), ctx));
+    MSM_TRY(ctx_sync(ctx));
     const double *cp = c->cpgrid->xyz.data(), *src = c->source->xyz.data();
     c->pptr.assign(N + 1, 0);
     c->pidx.clear();
@@ -194,8 +194,8 @@ int resample_weights(msm_cost *c) {
         st = apply_weights_dev(ctx, w, c->d_maxw.p, 1, c->d_absw.p);
         if (st) return st;
         c->absw.resize(N);
-        MSM_HIP(hipMemcpyAsync(c->absw.data(), c->d_absw.p, sizeof(double) * (size_t)N, hipMemcpyDeviceToHost, ctx->stream));
-        MSM_HIP(hipStreamSynchronize(ctx->stream));
+        MSM_TRY(stage_d2h(ctx, c->absw.data(), c->d_absw.p, sizeof(double) * (size_t)N));
+        MSM_TRY(ctx_sync(ctx));
         return MSM_OK;
     }
     std::vector<int32_t> rp, col;
@@ -261,8 +261,8 @@ int ensure_unary_table(msm_cost *c) {
     if (!c->fix_off_valid) {
         std::vector<uint32_t> off;
         unary_fix_offsets(N, c->L, c->pmax, c->pptr.data(), c->order.data(), off);
-        MSM_HIP(c->d_fix_off.upload(off.data(), off.size(), ctx->stream));
-        MSM_HIP(hipStreamSynchronize(ctx->stream));
+        MSM_TRY(c->d_fix_off.upload(off.data(), off.size(), ctx));
+        MSM_TRY(ctx_sync(ctx));
         c->fix_off_valid = true;
     }
     MSM_HIP(c->d_queues.ensure(N));
@@ -357,9 +357,9 @@ int msm_cost_set_meshes(msm_cost *c, msm_mesh *target, msm_mesh *source, msm_mes
     c->cp_conn_valid = false;
     c->orig_xyz = source->xyz;
     c->ocp_xyz = cpgrid->xyz;
-    MSM_HIP(c->d_orig.upload(c->orig_xyz.data(), c->orig_xyz.size(), c->ctx->stream));
-    MSM_HIP(c->d_ocp.upload(c->ocp_xyz.data(), c->ocp_xyz.size(), c->ctx->stream));
-    MSM_HIP(hipStreamSynchronize(c->ctx->stream));
+    MSM_TRY(c->d_orig.upload(c->orig_xyz.data(), c->orig_xyz.size(), c->ctx));
+    MSM_TRY(c->d_ocp.upload(c->ocp_xyz.data(), c->ocp_xyz.size(), c->ctx));
+    MSM_TRY(ctx_sync(c->ctx));
     c->have_source = false;
     invalidate_table(c);
     return MSM_OK;
@@ -393,14 +393,14 @@ int msm_cost_set_source_features(msm_cost *c, const double *feat, int32_t D) {
     // the univariate classes read feature row 1 only (M/DiscreteCostFunction.cpp:343-347, :371, :477-481): with D > 1 their
     // kernels index row 0 of this D x V array and column 0 of the target's vertex-major features
     c->D = D;
-    MSM_HIP(hipStreamSynchronize(c->ctx->stream));
+    MSM_TRY(ctx_sync(c->ctx));
     c->sfeat.assign(feat, feat + (size_t)D * c->source->V);
     c->vm_valid = false;
     MSM_HIP(c->d_sfeat.ensure(c->sfeat.size()));
     {
         const int st = upload_staged(c->ctx, c->d_sfeat.p, c->sfeat.data(), sizeof(double) * c->sfeat.size());  // D x V: megabytes
         if (st) return st;
-        MSM_HIP(hipStreamSynchronize(c->ctx->stream));
+        MSM_TRY(ctx_sync(c->ctx));
     }
     invalidate_table(c);
     return MSM_OK;
@@ -410,7 +410,7 @@ int msm_cost_set_cfweight(msm_cost *c, const double *w, int32_t rows) {
     if (!c) return fail(MSM_ERR_INVALID, "null cost");
     int st = need(c, c->source != nullptr, "meshes");
     if (st) return st;
-    MSM_HIP(hipStreamSynchronize(c->ctx->stream));
+    MSM_TRY(ctx_sync(c->ctx));
     if (!w) {
         c->cfw.clear();
         c->cfw_rows = 0;
@@ -426,7 +426,7 @@ int msm_cost_set_cfweight(msm_cost *c, const double *w, int32_t rows) {
         MSM_HIP(c->d_cfw.ensure(c->cfw.size()));
         st = upload_staged(c->ctx, c->d_cfw.p, c->cfw.data(), sizeof(double) * c->cfw.size());
         if (st) return st;
-        MSM_HIP(hipStreamSynchronize(c->ctx->stream));
+        MSM_TRY(ctx_sync(c->ctx));
     }
     c->have_source = false;
     invalidate_table(c);
@@ -448,13 +448,13 @@ int msm_cost_set_labels(msm_cost *c, const double *labels, int32_t L, const doub
     if (!c || !labels || !rot || L <= 0) return fail(MSM_ERR_INVALID, "msm_cost_set_labels: bad arguments");
     int st = need(c, c->cpgrid != nullptr, "meshes");
     if (st) return st;
-    MSM_HIP(hipStreamSynchronize(c->ctx->stream));
+    MSM_TRY(ctx_sync(c->ctx));
     c->L = L;
     c->fix_off_valid = false;
     c->labels.assign(labels, labels + 3 * (size_t)L);
     c->rot.assign(rot, rot + 9 * (size_t)c->cpgrid->V);
-    MSM_HIP(c->d_labels.upload(c->labels.data(), c->labels.size(), c->ctx->stream));
-    MSM_HIP(c->d_rot.upload(c->rot.data(), c->rot.size(), c->ctx->stream));
+    MSM_TRY(c->d_labels.upload(c->labels.data(), c->labels.size(), c->ctx));
+    MSM_TRY(c->d_rot.upload(c->rot.data(), c->rot.size(), c->ctx));
     invalidate_table(c);
     return MSM_OK;
 }
@@ -465,10 +465,10 @@ int msm_cost_set_triplets(msm_cost *c, const int32_t *triplets, int32_t T) {
     if (st) return st;
     for (int64_t i = 0; i < 3 * (int64_t)T; ++i)
         if (triplets[i] < 0 || triplets[i] >= c->cpgrid->V) return fail(MSM_ERR_INVALID, "triplet node id out of range");
-    MSM_HIP(hipStreamSynchronize(c->ctx->stream));
+    MSM_TRY(ctx_sync(c->ctx));
     c->triplets.assign(triplets, triplets + 3 * (size_t)T);
     c->move_valid = false;
-    if (T > 0) MSM_HIP(c->d_triplets.upload(c->triplets.data(), c->triplets.size(), c->ctx->stream));
+    if (T > 0) MSM_TRY(c->d_triplets.upload(c->triplets.data(), c->triplets.size(), c->ctx));
     return MSM_OK;
 }
 
@@ -478,9 +478,9 @@ int msm_cost_set_pairs(msm_cost *c, const int32_t *pairs, int32_t P) {
     if (st) return st;
     for (int64_t i = 0; i < 2 * (int64_t)P; ++i)
         if (pairs[i] < 0 || pairs[i] >= c->cpgrid->V) return fail(MSM_ERR_INVALID, "pair node id out of range");
-    MSM_HIP(hipStreamSynchronize(c->ctx->stream));
+    MSM_TRY(ctx_sync(c->ctx));
     c->pairs.assign(pairs, pairs + 2 * (size_t)P);
-    if (P > 0) MSM_HIP(c->d_pairs.upload(c->pairs.data(), c->pairs.size(), c->ctx->stream));
+    if (P > 0) MSM_TRY(c->d_pairs.upload(c->pairs.data(), c->pairs.size(), c->ctx));
     return MSM_OK;
 }
 
@@ -512,21 +512,21 @@ int msm_cost_get_source_data(msm_cost *c) {
     if (st) return st;
     lap("resample_weights");
     msm_ctx *ctx = c->ctx;
-    MSM_HIP(c->d_pptr.upload(c->pptr.data(), c->pptr.size(), ctx->stream));
+    MSM_TRY(c->d_pptr.upload(c->pptr.data(), c->pptr.size(), ctx));
     if (is_ho(c) || std::getenv("MSMHIP_NO_PATCH_SORT")) {
-        MSM_HIP(c->d_pidx.upload_vec(c->pidx, ctx->stream));
+        MSM_TRY(c->d_pidx.upload_vec(c->pidx, ctx));
     } else {
         // Device-side order of the points of each patch: Morton order of their positions (launch_sort_patches), so that the
         // lanes of a wavefront sample neighbouring places of the target (neighbouring direction cells and triangle records
         // share cache lines).  The similarity does not depend on the order of the patch points; the API keeps reporting
         // ascending ids.
-        if (!c->pidx_asc_on_device) MSM_HIP(c->d_pidx_asc.upload_vec(c->pidx, ctx->stream));
+        if (!c->pidx_asc_on_device) MSM_TRY(c->d_pidx_asc.upload_vec(c->pidx, ctx));
         MSM_HIP(c->d_pidx.ensure(std::max<size_t>(c->pidx.size(), 1)));
         MSM_HIP(c->d_code.ensure(c->source->V));
         st = launch_sort_patches(ctx, c->source->d_xyz, c->source->V, c->d_pptr.p, c->ngroups, c->d_pidx_asc.p, c->d_code.p, c->d_pidx.p);
         if (st) return st;
     }
-    MSM_HIP(c->d_absw.upload(c->absw.data(), c->absw.size(), ctx->stream));
+    MSM_TRY(c->d_absw.upload(c->absw.data(), c->absw.size(), ctx));
     {
         // Launch order of the control points in the unary kernels: Morton order of their positions, so that the
         // contiguous share of each XCD (kernels map blockIdx % 8 to a range of this list) is one region of the sphere
@@ -553,10 +553,10 @@ int msm_cost_get_source_data(msm_cost *c) {
         std::sort(key.begin(), key.end());
         c->order.resize(N);
         for (int i = 0; i < N; ++i) c->order[i] = key[i].second;
-        MSM_HIP(c->d_order.upload(c->order.data(), c->order.size(), ctx->stream));
+        MSM_TRY(c->d_order.upload(c->order.data(), c->order.size(), ctx));
         c->fix_off_valid = false;
     }
-    MSM_HIP(hipStreamSynchronize(ctx->stream));
+    MSM_TRY(ctx_sync(ctx));
     lap("orders + uploads");
     c->have_source = true;
     invalidate_table(c);
@@ -586,6 +586,7 @@ int msm_cost_absolute_weights(msm_cost *c, double *absw) {
 
 int msm_cost_unary_table_async(msm_cost *c) {
     if (!c) return fail(MSM_ERR_INVALID, "null cost");
+    MSM_TRY(drop_ctx_pending(c->ctx));  // a label step queued ahead on this context shares the stream, the status word and the flags with this call
     // every call is a fresh computeUnaryCosts(): the per (control point, label) rotations are recomputed too, as they are in
     // every iteration of a registration (new labels / a moved control grid each time)
     c->table_valid = false;
@@ -596,6 +597,7 @@ int msm_cost_unary_table_async(msm_cost *c) {
 
 int msm_cost_unary_table_fetch(msm_cost *c, double *U) {
     if (!c || !U) return fail(MSM_ERR_INVALID, "msm_cost_unary_table_fetch: null argument");
+    MSM_TRY(drop_ctx_pending(c->ctx));
     int st = need(c, c->table_valid, "msm_cost_unary_table_async()");
     if (st) return st;
     msm_ctx *ctx = c->ctx;
@@ -608,7 +610,7 @@ int msm_cost_unary_table_fetch(msm_cost *c, double *U) {
         if (st) return st;
         st = launch_copy_to_mapped(ctx, c->d_U.p, static_cast<double *>(mapped), n, ctx->d_flag_map);
         if (st) return st;
-        MSM_HIP(hipStreamSynchronize(ctx->stream));
+        MSM_TRY(ctx_sync(ctx));
         volatile int *flags = ctx->h_flag;
         if (flags[0] != 0) {
             flags[0] = 0;
@@ -616,7 +618,7 @@ int msm_cost_unary_table_fetch(msm_cost *c, double *U) {
         }
         return MSM_OK;
     }
-    MSM_HIP(c->d_U.download(U, n, ctx->stream));
+    MSM_TRY(c->d_U.download(U, n, ctx));
     return check_status(ctx, "computeUnaryCosts");
 }
 
@@ -628,6 +630,7 @@ int msm_cost_unary_table(msm_cost *c, double *U) {
 
 int msm_cost_unary_batch(msm_cost *c, const int32_t *nodes, const int32_t *labels, int32_t n, double *out) {
     if (!c || !nodes || !labels || !out || n < 0) return fail(MSM_ERR_INVALID, "msm_cost_unary_batch: bad arguments");
+    MSM_TRY(drop_ctx_pending(c->ctx));
     // computeUnaryCost(node,label) is a pure function between two get_source_data()/set_labels() calls,
     // so the batch is served from the table (computed once)
     if (!c->table_valid || c->h_U.size() != (size_t)c->L * c->cpgrid->V) {
@@ -663,7 +666,8 @@ int msm_cost_enable_timing(msm_cost *c, int enable) {
 
 int msm_cost_kernel_times(msm_cost *c, double *ms, int32_t cap, int32_t *n) {
     if (!c || !ms || !n) return fail(MSM_ERR_INVALID, "msm_cost_kernel_times: null argument");
-    MSM_HIP(hipStreamSynchronize(c->ctx->stream));
+    MSM_TRY(drop_ctx_pending(c->ctx));
+    MSM_TRY(ctx_sync(c->ctx));
     const int total = (int)c->ev0.size(), cnt = std::min(c->ev_count, (int)cap);
     for (int k = 0; k < cnt; ++k) {
         const int slot = ((c->ev_next - cnt + k) % total + total) % total;

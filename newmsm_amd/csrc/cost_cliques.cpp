@@ -17,7 +17,8 @@ int drop_pending_move(msm_cost *c) {
     c->pending.valid = false;
     ++c->prefetch_drops;
     msm_ctx *ctx = c->ctx;
-    MSM_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->pending_cost == c) ctx->pending_cost = nullptr;
+    MSM_TRY(ctx_sync(ctx));
     volatile int *flags = ctx->h_flag;
     if (flags) {
         flags[1] = 0;
@@ -29,6 +30,16 @@ int drop_pending_move(msm_cost *c) {
     return MSM_OK;
 }
 
+// The same from the context's side: whichever cost function holds the context's queued step.  Every entry point that synchronises the stream and reads the
+// status word or the mapped flags calls this first (or drop_pending_move on its own object) -- a status raised by a speculative kernel must not be reported
+// against another call, a tail request in flags[1] not be consumed by another cost function's move.
+int drop_ctx_pending(msm_ctx *ctx) {
+    msm_cost *c = ctx->pending_cost;
+    if (!c) return MSM_OK;
+    ctx->pending_cost = nullptr;
+    return drop_pending_move(c);
+}
+
 }  // namespace msm
 
 namespace {
@@ -36,6 +47,7 @@ namespace {
 // everything the clique kernels read; uploads the control grid's connectivity on first use
 int clique_args(msm_cost *c, bool need_triplets, bool need_pairs, CliqueArgs &a) {
     if (int st = drop_pending_move(c)) return st;
+    if (int st = drop_ctx_pending(c->ctx)) return st;  // (another cost function's, on the same context)
     if (!c->cpgrid || !c->source || !c->target) return fail(MSM_ERR_STATE, "msm_cost: meshes must be set first");
     if (need_triplets && c->triplets.empty()) return fail(MSM_ERR_STATE, "msm_cost: triplets must be set first");
     if (need_pairs && c->pairs.empty()) return fail(MSM_ERR_STATE, "msm_cost: pairs must be set first");
@@ -45,10 +57,10 @@ int clique_args(msm_cost *c, bool need_triplets, bool need_pairs, CliqueArgs &a)
     msm_mesh *g = c->cpgrid;
     if (!c->cp_conn_valid) {
         const Adjacency &adj = mesh_adjacency(g);
-        MSM_HIP(c->d_cp_tri.upload(g->tri.data(), g->tri.size(), ctx->stream));
-        MSM_HIP(c->d_cp_tid_ptr.upload(adj.tid_ptr.data(), adj.tid_ptr.size(), ctx->stream));
-        MSM_HIP(c->d_cp_tid.upload(adj.tid.data(), adj.tid.size(), ctx->stream));
-        MSM_HIP(hipStreamSynchronize(ctx->stream));
+        MSM_TRY(c->d_cp_tri.upload(g->tri.data(), g->tri.size(), ctx));
+        MSM_TRY(c->d_cp_tid_ptr.upload(adj.tid_ptr.data(), adj.tid_ptr.size(), ctx));
+        MSM_TRY(c->d_cp_tid.upload(adj.tid.data(), adj.tid.size(), ctx));
+        MSM_TRY(ctx_sync(ctx));
         c->cp_conn_valid = true;
     }
     a.kind = c->p.kind;
@@ -207,7 +219,7 @@ int ensure_move(msm_cost *c, const CliqueArgs &a) {
     }
     close(T);
     const size_t ns = std::max<size_t>(c->pidx.size(), 1);
-    MSM_HIP(c->d_blk.upload(blk.data(), blk.size(), ctx->stream));
+    MSM_TRY(c->d_blk.upload(blk.data(), blk.size(), ctx));
     MSM_HIP(c->d_tri_frame.ensure(5 * (size_t)T));
     MSM_HIP(c->d_tri_stat.ensure(3 * (size_t)T));
     MSM_HIP(c->d_slot_wda.ensure(ns));
@@ -220,7 +232,7 @@ int ensure_move(msm_cost *c, const CliqueArgs &a) {
     int st = launch_move_prepare(ctx, a, (int)c->pidx.size(), c->d_slot_tri.p, c->d_slot_w.p, c->d_slot_sf.p, a.cfw ? c->d_slot_cw.p : nullptr, c->d_slot_wda.p,
                                  c->d_tri_frame.p, c->d_tri_stat.p);
     if (st) return st;
-    MSM_HIP(hipStreamSynchronize(ctx->stream));  // blk is a local
+    MSM_TRY(ctx_sync(ctx));  // blk is a local
     c->move_nblk = (int)blk.size();
     c->move_cap = cap;
     c->move_valid = true;
@@ -228,7 +240,7 @@ int ensure_move(msm_cost *c, const CliqueArgs &a) {
 }
 
 int upload_ints(msm_ctx *ctx, DevBuf<int> &buf, const int32_t *host, size_t n) {
-    MSM_HIP(buf.upload(host, n, ctx->stream));
+    MSM_TRY(buf.upload(host, n, ctx));
     return MSM_OK;
 }
 
@@ -260,15 +272,15 @@ int msm_cost_set_anatomical(msm_cost *c, msm_mesh *sphere, const double *atarget
         if (asource_tri[j] < 0 || asource_tri[j] >= Vs) return fail(MSM_ERR_INVALID, "msm_cost_set_anatomical: vertex id %d out of range", asource_tri[j]);
     msm_ctx *ctx = c->ctx;
     MSM_HIP(hipSetDevice(ctx->device));
-    MSM_HIP(c->d_atarget.upload(atarget_xyz, 3 * (size_t)sphere->V, ctx->stream));
-    MSM_HIP(c->d_asrc.upload(asource_xyz, 3 * (size_t)Vs, ctx->stream));
-    MSM_HIP(c->d_asrc_tri.upload(asource_tri, 3 * (size_t)Ts, ctx->stream));
-    MSM_HIP(c->d_aw_ptr.upload(w_ptr, (size_t)Vs + 1, ctx->stream));
-    MSM_HIP(c->d_aw_cp.upload(w_cp, std::max<size_t>(w_ptr[Vs], 1), ctx->stream));
-    MSM_HIP(c->d_aw_val.upload(w_val, std::max<size_t>(w_ptr[Vs], 1), ctx->stream));
-    MSM_HIP(c->d_af_ptr.upload(face_ptr, (size_t)T + 1, ctx->stream));
-    MSM_HIP(c->d_af_idx.upload(face_idx, std::max<size_t>(face_ptr[T], 1), ctx->stream));
-    MSM_HIP(hipStreamSynchronize(ctx->stream));  // the caller's arrays may go away
+    MSM_TRY(c->d_atarget.upload(atarget_xyz, 3 * (size_t)sphere->V, ctx));
+    MSM_TRY(c->d_asrc.upload(asource_xyz, 3 * (size_t)Vs, ctx));
+    MSM_TRY(c->d_asrc_tri.upload(asource_tri, 3 * (size_t)Ts, ctx));
+    MSM_TRY(c->d_aw_ptr.upload(w_ptr, (size_t)Vs + 1, ctx));
+    MSM_TRY(c->d_aw_cp.upload(w_cp, std::max<size_t>(w_ptr[Vs], 1), ctx));
+    MSM_TRY(c->d_aw_val.upload(w_val, std::max<size_t>(w_ptr[Vs], 1), ctx));
+    MSM_TRY(c->d_af_ptr.upload(face_ptr, (size_t)T + 1, ctx));
+    MSM_TRY(c->d_af_idx.upload(face_idx, std::max<size_t>(face_ptr[T], 1), ctx));
+    MSM_TRY(ctx_sync(ctx));  // the caller's arrays may go away
     c->asphere = sphere;
     c->aVs = Vs;
     c->aTs = Ts;
@@ -294,7 +306,7 @@ int msm_cost_triplet_batch(msm_cost *c, const int32_t *triplet, const int32_t *l
     MSM_HIP(dout.ensure(n));
     st = launch_triplet_batch(ctx, a, qt.p, qa.p, qb.p, qc.p, n, dout.p);
     if (st) return st;
-    MSM_HIP(dout.download(out, n, ctx->stream));
+    MSM_TRY(dout.download(out, n, ctx));
     c->counters[2] += n;
     return check_status(ctx, "computeTripletCost");
 }
@@ -395,6 +407,8 @@ static int fused_move(msm_cost *c, const CliqueArgs &a, const int32_t *labeling,
         c->pending.kind = 1;
         c->pending.label = label;
         c->pending.E = E;
+        c->pending.epoch = ctx->epoch;
+        ctx->pending_cost = c;
         c->pending.labeling.assign(labeling, labeling + a.N);
         c->pending.a = a;
         c->pending.m = m;
@@ -403,7 +417,7 @@ static int fused_move(msm_cost *c, const CliqueArgs &a, const int32_t *labeling,
         *prefetch = true;
         return MSM_OK;
     }
-    MSM_HIP(hipStreamSynchronize(ctx->stream));
+    MSM_TRY(ctx_sync(ctx));
 #ifdef MSM_MOVE_TRACE
     if (const char *path = std::getenv("MSMHIP_MOVE_TRACE")) {
         std::vector<unsigned long long> h(trace_words);
@@ -428,7 +442,7 @@ static int fused_move_finish(msm_cost *c, const CliqueArgs &a, const MoveArgs &m
         st = launch_move_tail(ctx, a, m, lab);
         if (st) return st;
         if (staged_copy) MSM_HIP(hipMemcpyAsync((char *)pin + in_pad, out_dev, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
-        MSM_HIP(hipStreamSynchronize(ctx->stream));
+        MSM_TRY(ctx_sync(ctx));
         c->move_tails++;
     }
     st = MSM_OK;
@@ -463,11 +477,13 @@ static int packed_strain_move(msm_cost *c, const CliqueArgs &a, const int32_t *l
         c->pending.kind = 2;
         c->pending.label = label;
         c->pending.E = E;
+        c->pending.epoch = ctx->epoch;
+        ctx->pending_cost = c;
         c->pending.labeling.assign(labeling, labeling + a.N);
         c->pending.valid = true;
         return MSM_OK;
     }
-    MSM_HIP(hipStreamSynchronize(ctx->stream));
+    MSM_TRY(ctx_sync(ctx));
     volatile int *flags = ctx->h_flag;
     st = MSM_OK;
     if (flags[0] != 0) {
@@ -483,8 +499,9 @@ static int take_pending_move(msm_cost *c, double *E) {
     msm_ctx *ctx = c->ctx;
     msm_cost::PendingMove &p = c->pending;
     p.valid = false;
+    if (ctx->pending_cost == c) ctx->pending_cost = nullptr;
     ++c->prefetch_hits;
-    MSM_HIP(hipStreamSynchronize(ctx->stream));
+    MSM_TRY(ctx_sync(ctx));
     if (p.kind == 1) return fused_move_finish(c, p.a, p.m, &p.lab, false, true, nullptr, 0, 0, nullptr, E);
     volatile int *flags = ctx->h_flag;
     if (flags[0] != 0) {
@@ -498,7 +515,7 @@ static int triplet_octets_impl(msm_cost *c, const int32_t *labeling, int32_t lab
 
 int msm_cost_triplet_octets(msm_cost *c, const int32_t *labeling, int32_t label, double *E) {
     if (!c || !labeling || !E) return fail(MSM_ERR_INVALID, "msm_cost_triplet_octets: null argument");
-    if (c->pending.valid && c->pending.label == label && c->pending.E == E && c->cpgrid && (int)c->pending.labeling.size() == c->cpgrid->V &&
+    if (c->pending.valid && c->pending.label == label && c->pending.E == E && c->pending.epoch == c->ctx->epoch && c->ctx->pending_cost == c && c->cpgrid && (int)c->pending.labeling.size() == c->cpgrid->V &&
         std::memcmp(c->pending.labeling.data(), labeling, sizeof(int32_t) * c->pending.labeling.size()) == 0)
         return take_pending_move(c, E);  // queued ahead by msm_cost_triplet_octets_prefetch: the kernel ran while the host solved
     return triplet_octets_impl(c, labeling, label, E, nullptr);
@@ -590,7 +607,7 @@ int msm_cost_pairwise_batch(msm_cost *c, const int32_t *pair, const int32_t *la,
     MSM_HIP(dout.ensure(n));
     st = launch_pairwise_batch(ctx, a, qp.p, qa.p, qb.p, n, dout.p);
     if (st) return st;
-    MSM_HIP(dout.download(out, n, ctx->stream));
+    MSM_TRY(dout.download(out, n, ctx));
     c->counters[3] += n;
     return check_status(ctx, "computePairwiseCost");
 }
@@ -605,7 +622,7 @@ int msm_cost_pairwise_table(msm_cost *c, double *paircosts) {
     MSM_HIP(c->d_clique_out.ensure(total));
     st = launch_pairwise_table(ctx, a, c->d_clique_out.p);
     if (st) return st;
-    MSM_HIP(c->d_clique_out.download(paircosts, total, ctx->stream));
+    MSM_TRY(c->d_clique_out.download(paircosts, total, ctx));
     c->counters[3] += (int64_t)total;
     return check_status(ctx, "computePairwiseCosts");
 }
@@ -623,7 +640,7 @@ int msm_cost_triplet_table(msm_cost *c, int32_t t0, int32_t t1, double *tcosts) 
     MSM_HIP(c->d_clique_out.ensure(total));
     st = launch_triplet_table(ctx, a, t0, t1, c->d_clique_out.p);
     if (st) return st;
-    MSM_HIP(c->d_clique_out.download(tcosts, total, ctx->stream));
+    MSM_TRY(c->d_clique_out.download(tcosts, total, ctx));
     c->counters[2] += (int64_t)total;
     return check_status(ctx, "computeTripletCosts");
 }

@@ -51,6 +51,7 @@ struct msm_cost {
         int kind = 0;  // 1: fused triclique move (k_ho_move), 2: strain-only packed move
         int label = 0;
         double *E = nullptr;
+        uint64_t epoch = 0;  // msm_ctx::epoch when it was queued
         std::vector<int32_t> labeling;
         msm::CliqueArgs a;
         msm::MoveArgs m;

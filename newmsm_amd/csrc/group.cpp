@@ -204,8 +204,8 @@ int subject_patches(msm_group *g, int s, msm_ctx *ctx = nullptr, msm_group::Pipe
         MSM_HIP(d_slots.ensure((size_t)M * cap));
         int st = launch_range(ctx, d_c.p, M, g->tmpl->d_xyz, Vt, d_sep.p, g->p.range, cap, d_slots.p, d_counts.p, pipe->d_chunkb.p, d_counts.p + M);
         if (st) return st;
-        MSM_HIP(d_counts.download(counts.data(), (size_t)M + 1, ctx->stream));
-        MSM_HIP(hipStreamSynchronize(ctx->stream));
+        MSM_TRY(d_counts.download(counts.data(), (size_t)M + 1, ctx));
+        MSM_TRY(ctx_sync(ctx));
         const int mx = *std::max_element(counts.begin(), counts.begin() + M);
         if (mx + 16 > g->patch_cap_hint.load()) g->patch_cap_hint.store(mx + 16);
         if (mx <= cap) break;
@@ -220,11 +220,11 @@ int subject_patches(msm_group *g, int s, msm_ctx *ctx = nullptr, msm_group::Pipe
         pp.assign((size_t)M + 1, 0);
         for (int k = 0; k < M; ++k) pp[k + 1] = pp[k] + counts[k];
         g->h_pidx[s].clear();
-        MSM_HIP(g->pptr[s]->upload(pp.data(), pp.size(), ctx->stream));
+        MSM_TRY(g->pptr[s]->upload(pp.data(), pp.size(), ctx));
         MSM_HIP(g->pidx[s]->ensure(std::max<size_t>((size_t)pp[M], 1)));
         int st = launch_patch_compact(ctx, d_slots.p, cap, g->pptr[s]->p, M, g->pidx[s]->p);
         if (st) return st;
-        MSM_HIP(hipStreamSynchronize(ctx->stream));
+        MSM_TRY(ctx_sync(ctx));
         lap("lists (device)");
         return MSM_OK;
     }
@@ -236,7 +236,7 @@ int subject_patches(msm_group *g, int s, msm_ctx *ctx = nullptr, msm_group::Pipe
     }
     const uint32_t *slots = static_cast<const uint32_t *>(pin);
     MSM_HIP(hipMemcpyAsync(pin, d_slots.p, sizeof(uint32_t) * (size_t)M * cap, hipMemcpyDeviceToHost, ctx->stream));
-    MSM_HIP(hipStreamSynchronize(ctx->stream));
+    MSM_TRY(ctx_sync(ctx));
     lap("slots to the host");
     auto &pp = g->h_pptr[s];
     auto &pi = g->h_pidx[s];
@@ -244,9 +244,9 @@ int subject_patches(msm_group *g, int s, msm_ctx *ctx = nullptr, msm_group::Pipe
     const double *tx = g->tmpl->xyz.data();
     // the centres and spacings the kernel used, for the host's decisions (this branch is rare: exact ties)
     std::vector<double> centres(3 * (size_t)M), sep(M);
-    MSM_HIP(d_c.download(centres.data(), centres.size(), ctx->stream));
-    MSM_HIP(d_sep.download(sep.data(), sep.size(), ctx->stream));
-    MSM_HIP(hipStreamSynchronize(ctx->stream));
+    MSM_TRY(d_c.download(centres.data(), centres.size(), ctx));
+    MSM_TRY(d_sep.download(sep.data(), sep.size(), ctx));
+    MSM_TRY(ctx_sync(ctx));
     // an entry flagged by the kernel sits within 1e-11 of the threshold: decided with the host libm, as the reference does
     auto keeps = [&](int k, uint32_t e) {
         if (!(e & 0x80000000u)) return true;
@@ -274,13 +274,13 @@ int subject_patches(msm_group *g, int s, msm_ctx *ctx = nullptr, msm_group::Pipe
         }
     });
     lap("lists");
-    MSM_HIP(g->pptr[s]->upload(pp.data(), pp.size(), ctx->stream));
+    MSM_TRY(g->pptr[s]->upload(pp.data(), pp.size(), ctx));
     MSM_HIP(g->pidx[s]->ensure(std::max<size_t>(pi.size(), 1)));
     {
         int st = upload_staged(ctx, g->pidx[s]->p, pi.data(), pi.size() * sizeof(int32_t));  // 12.7 MB at ico6 / 19 labels
         if (st) return st;
     }
-    MSM_HIP(hipStreamSynchronize(ctx->stream));
+    MSM_TRY(ctx_sync(ctx));
     lap("uploads");
     return MSM_OK;
 }
@@ -423,8 +423,8 @@ int msm_group_set_template(msm_group *g, msm_mesh *t, const double *mask) {
     g->mask.clear();
     if (mask) {
         g->mask.assign(mask, mask + t->V);
-        MSM_HIP(g->d_mask.upload(g->mask.data(), g->mask.size(), g->ctx->stream));
-        MSM_HIP(hipStreamSynchronize(g->ctx->stream));
+        MSM_TRY(g->d_mask.upload(g->mask.data(), g->mask.size(), g->ctx));
+        MSM_TRY(ctx_sync(g->ctx));
     }
     g->ready = false;
     g->common_ready = false;
@@ -450,8 +450,8 @@ int msm_group_set_controlgrid(msm_group *g, const double *xyz, const int32_t *tr
             std::sort(v, v + 3);
             std::copy(v, v + 3, &g->triplets[3 * ((size_t)s * Tc + t)]);
         }
-    MSM_HIP(g->d_triplets.upload(g->triplets.data(), g->triplets.size(), g->ctx->stream));
-    MSM_HIP(hipStreamSynchronize(g->ctx->stream));
+    MSM_TRY(g->d_triplets.upload(g->triplets.data(), g->triplets.size(), g->ctx));
+    MSM_TRY(ctx_sync(g->ctx));
     g->ready = false;
     g->common_ready = false;
     g->drop_kept();
@@ -511,6 +511,8 @@ int msm_group_set_labels(msm_group *g, const double *labels, int32_t L) {
 // an eighth of it touches an eighth of every resampled map instead of all of eight subjects' and most of everyone else's (an eighth of a label
 // step at S = 64, ico6 / ico4: 1.59 -> 1.42 ms of kernels).  The optimiser takes the list as it comes (I/Fusion/Fusion.h:157-196 reads pairs[i]
 // beside the i-th costs); the same set of pairs either way.  Takes effect at the next msm_group_setup / msm_group_setup_subjects.
+msm_ctx *msm_group_context(msm_group *g) { return g ? g->ctx : nullptr; }
+
 int msm_group_set_pair_layout(msm_group *g, int32_t layout) {
     if (!g || (layout != 0 && layout != 1)) return fail(MSM_ERR_INVALID, "msm_group_set_pair_layout: layout must be 0 (reference order) or 1 (control-point major)");
     if (g->pair_layout == layout) return MSM_OK;
@@ -581,7 +583,7 @@ int group_common_setup(msm_group *g) {
         if (st == MSM_OK) {
             std::vector<int2> info(S);
             for (int b = 0; b < S; ++b) info[b] = make_int2(g->cp_forest.info[b].nnodes, g->cp_forest.info[b].grid_depth);
-            MSM_HIP(g->d_forest_info.upload(info.data(), info.size(), ctx->stream));
+            MSM_TRY(g->d_forest_info.upload(info.data(), info.size(), ctx));
             ForestDev fd;
             fd.node = g->cp_forest.node.p, fd.parent = g->cp_forest.parent.p, fd.leaf_tri = g->cp_forest.leaf_tri.p, fd.grid = g->cp_forest.grid.p;
             fd.cone = g->cp_forest.cone.p, fd.rec = g->cp_forest.rec.p;
@@ -620,7 +622,7 @@ int group_common_setup(msm_group *g) {
                     g->pairs[2 * pair + 1] = b * N + closest[(size_t)a * S + b][v];
                     ++pair;
                 }
-        MSM_HIP(g->d_pairs.upload_vec(g->pairs, ctx->stream));
+        MSM_TRY(g->d_pairs.upload_vec(g->pairs, ctx));
     }
     lap("estimate_pairs");
     {
@@ -667,7 +669,7 @@ int group_common_setup(msm_group *g) {
                 MSM_HIP(g->d_pair_perm.ensure(std::max<size_t>(g->pair_order.size(), 1)));
                 int st = upload_staged(ctx, g->d_pair_perm.p, g->pair_order.data(), sizeof(int32_t) * g->pair_order.size());
                 if (st) return st;
-                MSM_HIP(hipStreamSynchronize(ctx->stream));
+                MSM_TRY(ctx_sync(ctx));
                 std::iota(g->pair_order.begin(), g->pair_order.end(), 0);
             }
         }
@@ -679,7 +681,7 @@ int group_common_setup(msm_group *g) {
             int st = launch_group_permute_pairs(ctx, g->d_pairs_tmp.p, g->d_pair_perm.p, (int)g->npairs, g->d_pairs.p);
             if (st) return st;
             if (!g->pairs.empty()) {  // the fallback above filled the host copy and queued its upload: in the other order now -- fetched again when asked for
-                MSM_HIP(hipStreamSynchronize(ctx->stream));  // (the upload reads the vector)
+                MSM_TRY(ctx_sync(ctx));  // (the upload reads the vector)
                 g->pairs.clear();
             }
         }
@@ -731,7 +733,7 @@ int group_common_setup(msm_group *g) {
         int st = launch_group_moved(ctx, g->d_rot.p, S * N, g->d_labels3.p, L, g->d_moved.p);
         if (st) return st;
     }
-    MSM_HIP(hipStreamSynchronize(ctx->stream));
+    MSM_TRY(ctx_sync(ctx));
     g->F.resize((size_t)S * L);
     g->Fslab.resize(S);
     g->have_subject.assign(S, 0);
@@ -760,7 +762,7 @@ int ensure_lanes(msm_group *g, const msm_mesh *dm) {
             if (!lane.ctx) return MSM_ERR_HIP;
         }
         if (lane.mesh && (lane.mesh->V != dm->V || lane.mesh->T != dm->T || lane.mesh->tri != dm->tri)) {
-            MSM_HIP(hipStreamSynchronize(lane.ctx->stream));
+            MSM_TRY(ctx_sync(lane.ctx));
             msm_mesh_destroy(lane.mesh);
             lane.mesh = nullptr;
         }
@@ -805,8 +807,8 @@ static int rotate_subject(msm_group *g, msm_mesh *dm, msm_ctx *ctx, std::vector<
     const double *d_mats = nullptr;
     if (mode == 1) {
         if (dm->host_xyz_stale) {
-            MSM_HIP(hipMemcpyAsync(dm->xyz.data(), dm->d_xyz, sizeof(double) * 3 * (size_t)V, hipMemcpyDeviceToHost, ctx->stream));
-            MSM_HIP(hipStreamSynchronize(ctx->stream));
+            MSM_TRY(stage_d2h(ctx, dm->xyz.data(), dm->d_xyz, sizeof(double) * 3 * (size_t)V));
+            MSM_TRY(ctx_sync(ctx));
             dm->host_xyz_stale = false;
         }
         rot9.resize(9 * (size_t)V);
@@ -907,8 +909,8 @@ static int stage_batch(msm_group *g, int s, msm_group::Stage &b, int which, msm_
     std::vector<int2> info(L);
     for (int l = 0; l < L; ++l) info[l] = make_int2(b.forest.info[l].nnodes, b.forest.info[l].grid_depth);
     MSM_HIP(w.info[which].ensure(L));
-    MSM_HIP(hipMemcpyAsync(w.info[which].p, info.data(), sizeof(int2) * (size_t)L, hipMemcpyHostToDevice, ctx->stream));
-    MSM_HIP(hipStreamSynchronize(ctx->stream));  // info is a local (and the previous subject's batch has finished with the scratch)
+    MSM_TRY(stage_h2d(ctx, w.info[which].p, info.data(), sizeof(int2) * (size_t)L));
+    MSM_TRY(ctx_sync(ctx));  // the previous subject's batch has finished with the scratch
     ForestDev fd;
     fd.node = b.forest.node.p, fd.parent = b.forest.parent.p, fd.leaf_tri = b.forest.leaf_tri.p, fd.grid = b.forest.grid.p;
     fd.cone = b.forest.cone.p, fd.rec = b.forest.rec.p;
@@ -1078,7 +1080,7 @@ static int group_setup_pipeline(msm_group *g, const int32_t *subjects, int n) {
         st = ensure_adjacency_dev(g->data[subjects[i]]);
         if (st) return st;
     }
-    MSM_HIP(hipStreamSynchronize(ctx->stream));
+    MSM_TRY(ctx_sync(ctx));
     static const int pipes_env = [] { const char *e = std::getenv("MSMHIP_GROUP_PIPES"); return e ? std::max(1, std::min(msm_group::kMaxPipes, std::atoi(e))) : 2; }();
     const int npipes = std::max(1, std::min(pipes_env, n / 2));
     g->pipe[0].main = ctx;
@@ -1231,7 +1233,7 @@ int group_subject_setup(msm_group *g, int s) {
         int st = upload_staged(ctx, g->F[(size_t)s * L + l]->p, resampled[l].data(), resampled[l].size() * sizeof(double));
         if (st) return st;
     }
-    MSM_HIP(hipStreamSynchronize(ctx->stream));
+    MSM_TRY(ctx_sync(ctx));
     lap("weights + resample");
     int st = subject_patches(g, s);
     if (st) return st;
@@ -1282,8 +1284,8 @@ static int fetch_host_pptr(msm_group *g, int s) {
     if (!g->h_pptr[s].empty()) return MSM_OK;
     if (!g->have_subject[s]) return fail(MSM_ERR_STATE, "msm_group: subject %d is neither set up nor imported", s);
     g->h_pptr[s].resize((size_t)g->N * g->L + 1);
-    MSM_HIP(g->pptr[s]->download(g->h_pptr[s].data(), g->h_pptr[s].size(), g->ctx->stream));
-    MSM_HIP(hipStreamSynchronize(g->ctx->stream));
+    MSM_TRY(g->pptr[s]->download(g->h_pptr[s].data(), g->h_pptr[s].size(), g->ctx));
+    MSM_TRY(ctx_sync(g->ctx));
     return MSM_OK;
 }
 
@@ -1291,8 +1293,8 @@ static int fetch_host_pptr(msm_group *g, int s) {
 static int fetch_host_pidx(msm_group *g, int s) {
     if (!g->h_pidx[s].empty() || g->h_pptr[s].empty() || g->h_pptr[s].back() <= 0) return MSM_OK;
     g->h_pidx[s].resize((size_t)g->h_pptr[s].back());
-    MSM_HIP(g->pidx[s]->download(g->h_pidx[s].data(), g->h_pidx[s].size(), g->ctx->stream));
-    MSM_HIP(hipStreamSynchronize(g->ctx->stream));
+    MSM_TRY(g->pidx[s]->download(g->h_pidx[s].data(), g->h_pidx[s].size(), g->ctx));
+    MSM_TRY(ctx_sync(g->ctx));
     return MSM_OK;
 }
 
@@ -1310,8 +1312,8 @@ int msm_group_export_subject(msm_group *g, int32_t s, double *F, int32_t *pptr, 
         if (st) return st;
     }
     if (F) {
-        for (int l = 0; l < g->L; ++l) MSM_HIP(g->F[(size_t)s * g->L + l]->download(F + per * l, per, g->ctx->stream));
-        MSM_HIP(hipStreamSynchronize(g->ctx->stream));
+        for (int l = 0; l < g->L; ++l) MSM_TRY(g->F[(size_t)s * g->L + l]->download(F + per * l, per, g->ctx));
+        MSM_TRY(ctx_sync(g->ctx));
     }
     if (pptr) std::copy(g->h_pptr[s].begin(), g->h_pptr[s].end(), pptr);
     if (pidx) {
@@ -1338,12 +1340,12 @@ int msm_group_import_subject(msm_group *g, int32_t s, const double *F, const int
         int st = subject_feature_slab(g, s, per);
         if (st) return st;
     }
-    for (int l = 0; l < g->L; ++l) MSM_HIP(hipMemcpyAsync(g->F[(size_t)s * g->L + l]->p, F + per * l, sizeof(double) * per, hipMemcpyHostToDevice, ctx->stream));
+    for (int l = 0; l < g->L; ++l) MSM_TRY(upload_staged(ctx, g->F[(size_t)s * g->L + l]->p, F + per * l, sizeof(double) * per));
     g->h_pptr[s].assign(pptr, pptr + M + 1);
     g->h_pidx[s].assign(pidx, pidx + npidx);
-    MSM_HIP(g->pptr[s]->upload(g->h_pptr[s].data(), M + 1, ctx->stream));
-    MSM_HIP(g->pidx[s]->upload_vec(g->h_pidx[s], ctx->stream));
-    MSM_HIP(hipStreamSynchronize(ctx->stream));
+    MSM_TRY(g->pptr[s]->upload(g->h_pptr[s].data(), M + 1, ctx));
+    MSM_TRY(g->pidx[s]->upload_vec(g->h_pidx[s], ctx));
+    MSM_TRY(ctx_sync(ctx));
     g->have_subject[s] = 1;
     return MSM_OK;
 }
@@ -1369,7 +1371,7 @@ int msm_group_export_subject_dev(msm_group *g, int32_t s, double *F_dev, int32_t
         if (n > cap) return fail(MSM_ERR_CAPACITY, "patch index buffer too small");
         if (n > 0) MSM_HIP(hipMemcpyAsync(pidx_dev, g->pidx[s]->p, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToDevice, ctx->stream));
     }
-    MSM_HIP(hipStreamSynchronize(ctx->stream));  // the buffers may go straight into a collective on another stream
+    MSM_TRY(ctx_sync(ctx));  // the buffers may go straight into a collective on another stream
     return MSM_OK;
 }
 
@@ -1394,8 +1396,8 @@ int msm_group_import_subject_dev(msm_group *g, int32_t s, const double *F_dev, c
     hipLaunchKernelGGL(k_check_patch_csr, dim3((unsigned)((span + 255) / 256)), dim3(256), 0, ctx->stream, pptr_dev, M, pidx_dev, npidx, g->tmpl->V, bad.p);
     MSM_HIP(hipGetLastError());
     int hbad = 0;
-    MSM_HIP(hipMemcpyAsync(&hbad, bad.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    MSM_HIP(hipStreamSynchronize(ctx->stream));
+    MSM_TRY(stage_d2h(ctx, &hbad, bad.p, sizeof(int)));
+    MSM_TRY(ctx_sync(ctx));
     if (hbad) return fail(MSM_ERR_INVALID, "patch CSR of subject %d is inconsistent (code %d: 1 ends, 2 row lengths, 4 vertex ids)", s, hbad);
     {
         int st = subject_feature_slab(g, s, per);
@@ -1408,9 +1410,9 @@ int msm_group_import_subject_dev(msm_group *g, int32_t s, const double *F_dev, c
     MSM_HIP(g->pidx[s]->ensure(std::max<size_t>((size_t)npidx, 1)));
     if (npidx > 0) MSM_HIP(hipMemcpyAsync(g->pidx[s]->p, pidx_dev, sizeof(int32_t) * (size_t)npidx, hipMemcpyDeviceToDevice, ctx->stream));
     g->h_pptr[s].resize(M + 1);  // the row lengths are host knowledge too (largest patch, msm_group_patch)
-    MSM_HIP(hipMemcpyAsync(g->h_pptr[s].data(), pptr_dev, sizeof(int32_t) * (M + 1), hipMemcpyDeviceToHost, ctx->stream));
+    MSM_TRY(stage_d2h(ctx, g->h_pptr[s].data(), pptr_dev, sizeof(int32_t) * (M + 1)));
     g->h_pidx[s].clear();        // fetched on demand by msm_group_patch
-    MSM_HIP(hipStreamSynchronize(ctx->stream));
+    MSM_TRY(ctx_sync(ctx));
     g->have_subject[s] = 1;
     return MSM_OK;
 }
@@ -1460,7 +1462,7 @@ int msm_group_export_subjects_dev(msm_group *g, const int32_t *subjects, int32_t
         MSM_HIP(hipMemcpyAsync(pptr_dev + (size_t)k * pptr_stride, g->pptr[s]->p, sizeof(int32_t) * (M + 1), hipMemcpyDeviceToDevice, ctx->stream));
         if (cnt > 0) MSM_HIP(hipMemcpyAsync(pidx_dev + (size_t)k * pidx_stride, g->pidx[s]->p, sizeof(int32_t) * (size_t)cnt, hipMemcpyDeviceToDevice, ctx->stream));
     }
-    MSM_HIP(hipStreamSynchronize(ctx->stream));  // the buffers may go straight into a collective on another stream
+    MSM_TRY(ctx_sync(ctx));  // the buffers may go straight into a collective on another stream
     return MSM_OK;
 }
 
@@ -1481,15 +1483,15 @@ int msm_group_import_subjects_dev(msm_group *g, const int32_t *subjects, int32_t
     // the arrays come from other ranks: checked (on the device, where they are) before any kernel indexes with them
     DevBuf<int64_t> d_np;
     DevBuf<int> d_out;
-    MSM_HIP(d_np.upload(npidx, (size_t)n, ctx->stream));
+    MSM_TRY(d_np.upload(npidx, (size_t)n, ctx));
     MSM_HIP(d_out.zero(4 * (size_t)n, ctx->stream));
     const unsigned gx = (unsigned)std::min<int64_t>((most + 255) / 256, 4096);
     hipLaunchKernelGGL(k_check_patch_csr_batch, dim3(gx, (unsigned)n), dim3(256), 0, ctx->stream, pptr_dev, pptr_stride, M, pidx_dev, pidx_stride, d_np.p, g->tmpl->V,
                        kPairSmallPatch, d_out.p);
     MSM_HIP(hipGetLastError());
     std::vector<int> out(4 * (size_t)n);
-    MSM_HIP(d_out.download(out.data(), out.size(), ctx->stream));
-    MSM_HIP(hipStreamSynchronize(ctx->stream));
+    MSM_TRY(d_out.download(out.data(), out.size(), ctx));
+    MSM_TRY(ctx_sync(ctx));
     for (int k = 0; k < n; ++k)
         if (out[4 * (size_t)k])
             return fail(MSM_ERR_INVALID, "patch CSR of subject %d is inconsistent (code %d: 1 ends, 2 row lengths, 4 vertex ids)", subjects[k], out[4 * (size_t)k]);
@@ -1509,7 +1511,7 @@ int msm_group_import_subjects_dev(msm_group *g, const int32_t *subjects, int32_t
         g->imp_stat[s].largest = out[4 * (size_t)k + 1];
         g->imp_stat[s].small = out[4 * (size_t)k + 2];
     }
-    MSM_HIP(hipStreamSynchronize(ctx->stream));  // the caller may reuse its buffers
+    MSM_TRY(ctx_sync(ctx));  // the caller may reuse its buffers
     for (int k = 0; k < n; ++k) g->have_subject[subjects[k]] = 1;
     return MSM_OK;
 }
@@ -1528,10 +1530,10 @@ int msm_group_finalize(msm_group *g) {
         pp[s] = g->pptr[s]->p;
         pi[s] = g->pidx[s]->p;
     }
-    MSM_HIP(g->d_Fp.upload(Fp.data(), Fp.size(), ctx->stream));
-    MSM_HIP(g->d_pptrp.upload(pp.data(), pp.size(), ctx->stream));
-    MSM_HIP(g->d_pidxp.upload(pi.data(), pi.size(), ctx->stream));
-    MSM_HIP(hipStreamSynchronize(ctx->stream));
+    MSM_TRY(g->d_Fp.upload(Fp.data(), Fp.size(), ctx));
+    MSM_TRY(g->d_pptrp.upload(pp.data(), pp.size(), ctx));
+    MSM_TRY(g->d_pidxp.upload(pi.data(), pi.size(), ctx));
+    MSM_TRY(ctx_sync(ctx));
     g->drop_kept();  // new patches: nothing kept from earlier label steps applies
     g->patch_max = 0;
     int64_t npatch = 0, nsmall = 0;
@@ -1592,8 +1594,8 @@ int msm_group_get_pairs(msm_group *g, int32_t *pairs) {
     if (!g->ready) return fail(MSM_ERR_STATE, "msm_group: msm_group_setup() must be called first");
     if (g->pairs.size() != 2 * (size_t)g->npairs) {  // the list was written on the device: fetched when first asked for
         g->pairs.resize(2 * (size_t)g->npairs);
-        if (g->npairs > 0) MSM_HIP(g->d_pairs.download(g->pairs.data(), g->pairs.size(), g->ctx->stream));
-        MSM_HIP(hipStreamSynchronize(g->ctx->stream));
+        if (g->npairs > 0) MSM_TRY(g->d_pairs.download(g->pairs.data(), g->pairs.size(), g->ctx));
+        MSM_TRY(ctx_sync(g->ctx));
     }
     std::copy(g->pairs.begin(), g->pairs.end(), pairs);
     return MSM_OK;
@@ -1617,16 +1619,16 @@ int msm_group_patch(msm_group *g, int32_t s, int32_t v, int32_t l, int32_t *ids,
     *n = cnt;
     if (g->h_pidx[s].empty() && g->h_pptr[s].back() > 0) {  // a subject imported from device memory: its index list is fetched when first asked for
         g->h_pidx[s].resize((size_t)g->h_pptr[s].back());
-        MSM_HIP(g->pidx[s]->download(g->h_pidx[s].data(), g->h_pidx[s].size(), g->ctx->stream));
-        MSM_HIP(hipStreamSynchronize(g->ctx->stream));
+        MSM_TRY(g->pidx[s]->download(g->h_pidx[s].data(), g->h_pidx[s].size(), g->ctx));
+        MSM_TRY(ctx_sync(g->ctx));
     }
     if (!ids && !data) return MSM_OK;
     const int Vt = g->tmpl->V;
     std::vector<double> F;
     if (data) {
         F.resize((size_t)g->D * Vt);
-        MSM_HIP(g->F[(size_t)s * g->L + l]->download(F.data(), F.size(), g->ctx->stream));
-        MSM_HIP(hipStreamSynchronize(g->ctx->stream));
+        MSM_TRY(g->F[(size_t)s * g->L + l]->download(F.data(), F.size(), g->ctx));
+        MSM_TRY(ctx_sync(g->ctx));
     }
     for (int i = 0; i < cnt && i < cap; ++i) {
         const int id = g->h_pidx[s][beg + i];
@@ -1669,7 +1671,7 @@ int msm_group_pairwise_batch(msm_group *g, const int32_t *pair, const int32_t *l
 static int slice_pair_order(msm_group *g, int64_t pair0, int64_t pair1, const int **d_order) {
     if (g->order_p0 != pair0 || g->order_p1 != pair1) {
         msm_ctx *ctx = g->ctx;
-        MSM_HIP(hipStreamSynchronize(ctx->stream));
+        MSM_TRY(ctx_sync(ctx));
         const int64_t n = pair1 - pair0;
         static const int pieces_env = [] { const char *e = std::getenv("MSMHIP_GROUP_PIECES"); return e ? std::max(1, std::min(16, std::atoi(e))) : 0; }();
         const int pieces = pieces_env ? pieces_env : (n >= (1 << 18) ? 4 : 1);
@@ -1700,10 +1702,10 @@ static int slice_pair_order(msm_group *g, int64_t pair0, int64_t pair1, const in
         MSM_HIP(g->d_pair_order.ensure(std::max<size_t>((size_t)n, 1)));
         size_t at = 0;
         for (auto &v : part) {
-            if (!v.empty()) MSM_HIP(hipMemcpyAsync(g->d_pair_order.p + at, v.data(), sizeof(int32_t) * v.size(), hipMemcpyHostToDevice, ctx->stream));
+            if (!v.empty()) MSM_TRY(stage_h2d(ctx, g->d_pair_order.p + at, v.data(), sizeof(int32_t) * v.size()));
             at += v.size();
         }
-        MSM_HIP(hipStreamSynchronize(ctx->stream));
+        MSM_TRY(ctx_sync(ctx));
         g->order_p0 = pair0, g->order_p1 = pair1;
     }
     *d_order = g->d_pair_order.p;
@@ -1725,7 +1727,7 @@ static int group_move_compute_untimed(msm_group *g, const int32_t *labeling, int
     void *pin = nullptr;
     st = ctx_io_pinned(ctx, sizeof(int32_t) * (size_t)nodes, &pin);
     if (st) return st;
-    MSM_HIP(hipStreamSynchronize(ctx->stream));  // the staging buffer may still be the source of an earlier copy
+    MSM_TRY(ctx_sync(ctx));  // the staging buffer may still be the source of an earlier copy
     std::memcpy(pin, labeling, sizeof(int32_t) * (size_t)nodes);
     MSM_HIP(g->d_query[0].ensure(nodes));
     MSM_HIP(hipMemcpyAsync(g->d_query[0].p, pin, sizeof(int32_t) * (size_t)nodes, hipMemcpyHostToDevice, ctx->stream));
@@ -1913,7 +1915,7 @@ static int group_fusion_move_impl(msm_group *g, const int32_t *labeling, int32_t
             st = ctx_io_pinned(ctx, sizeof(double) * m, &pin);
             if (st) return st;
             MSM_HIP(hipMemcpyAsync(pin, src + off, sizeof(double) * m, hipMemcpyDeviceToHost, ctx->stream));
-            MSM_HIP(hipStreamSynchronize(ctx->stream));
+            MSM_TRY(ctx_sync(ctx));
             std::memcpy(out + off, pin, sizeof(double) * m);
         }
     }

@@ -32,6 +32,7 @@ int fail(int code, const char *fmt, ...) {
     vsnprintf(buf, sizeof(buf), fmt, ap);
     va_end(ap);
     g_error = buf;
+    stage_on_failure();  // stager.cpp: what this thread fetched and has not delivered yet is dropped (its destination may not outlive the failed call)
     return code;
 }
 

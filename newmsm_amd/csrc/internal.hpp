@@ -33,6 +33,12 @@ size_t pool_idle_bytes();
         if (e_ != hipSuccess) return msm::fail(MSM_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
     } while (0)
 
+#define MSM_TRY(call)               \
+    do {                            \
+        const int st_ = (call);     \
+        if (st_) return st_;        \
+    } while (0)
+
 // ---------------------------------------------------------------- host mesh helpers (host_mesh.cpp)
 struct Adjacency {
     std::vector<int32_t> nbr_ptr, nbr, tid_ptr, tid;
@@ -119,6 +125,10 @@ struct DevTree {
 
 }  // namespace msm
 
+namespace msm {
+struct Stager;
+}
+
 // ---------------------------------------------------------------- handles
 struct msm_ctx {
     int device = 0;
@@ -130,10 +140,17 @@ struct msm_ctx {
     // grow-only scratch of the host-array query entry points (hipMalloc / hipFree per call cost more than the queries)
     void *q_buf[4] = {nullptr, nullptr, nullptr, nullptr};
     size_t q_cap[4] = {0, 0, 0, 0};
-    // pinned staging for the search-structure uploads (pageable copies of the 16 MB of an ico6 tree ran at < 1 GB/s)
-    void *stage = nullptr;
-    size_t stage_cap = 0;
-    std::mutex stage_mu;  // upload_staged / upload_tree: the gMSM set-up reaches one context's block from several host threads
+    // pinned staging blocks of every host <-> device copy whose host side is not pinned memory of this library (stager.cpp): grow only, event fenced,
+    // never moved; created and destroyed with the context
+    msm::Stager *stager = nullptr;
+    hipEvent_t wait_ev = nullptr;  // msm_ctx_wait_stream
+    // A label step queued ahead (msm_cost_triplet_octets_prefetch) shares the stream, the status word and the mapped flags with every other call on the context:
+    // the cost function that holds one (at most one per context), resolved -- taken by its matching call, or waited for and discarded -- before any other
+    // entry point synchronises the stream or reads the flags (cost_cliques.cpp: drop_ctx_pending)
+    struct msm_cost *pending_cost = nullptr;
+    // bumped by everything a queued label step's inputs or destination depend on and that the cost function cannot see: a mesh's coordinates or features
+    // changed, a pinned block released (a new block may get the old one's address).  A queued step is only taken when the epoch is the one it was queued under.
+    uint64_t epoch = 0;
     // small pinned buffers for the per-label-step calls (labeling in, fusion-move energies out)
     void *io_pin = nullptr;
     void *io_dev = nullptr;  // its device address (the block is mapped), or nullptr
@@ -271,7 +288,19 @@ int ctx_io_pinned(msm_ctx *ctx, size_t bytes, void **out);  // grow-only pinned 
 // device address of [p, p + bytes) when it lies in a msm_host_alloc block of this context, else nullptr
 void *ctx_mapped(msm_ctx *ctx, const void *p, size_t bytes);
 int ctx_flag(msm_ctx *ctx);  // makes ctx->h_flag / d_flag_map available
-// host -> device through the context's pinned staging buffer (pageable copies of tens of MB ran at < 1 GB/s); waits for
-// earlier work on the stream first, returns with the copy queued
+int drop_ctx_pending(msm_ctx *ctx);  // cost_cliques.cpp: the label step queued ahead on this context, if any, is waited for and discarded (see msm_ctx::pending_cost)
+// host -> device on the context's stream: from where it lies when src is pinned memory of this context (msm_host_alloc / msm_host_register; complete on
+// return, the caller may write the array again), through the staging blocks otherwise (src consumed on return, the copy queued; nothing waits)
 int upload_staged(msm_ctx *ctx, void *dst, const void *src, size_t bytes);
+// stager.cpp (stage_h2d / stage_d2h are declared in devbuf.hpp)
+void stager_create(msm_ctx *ctx);
+void stager_destroy(msm_ctx *ctx);  // the device is idle
+void stager_stats(msm_ctx *ctx, int64_t out[4]);  // blocks, bytes, blocks ever allocated, waits for a busy block
+int ctx_sync(msm_ctx *ctx);         // hipStreamSynchronize(ctx->stream) + what stage_d2h fetched goes to its destinations
+void stage_deliver(msm_ctx *ctx);   // the second half alone (the stream has been synchronised by other means)
+void stage_forget(msm_ctx *ctx);     // drops them instead
+// An entry point that fails between a device -> host copy and its synchronisation must not leave the delivery behind: a later synchronisation would write
+// into a local that is gone, or into an array the caller freed after the failed call.  Every error return starts at fail() on the thread that queued the
+// copy, which calls this: the deliveries still pending on the context this thread last fetched through are dropped.
+void stage_on_failure();
 }  // namespace msm

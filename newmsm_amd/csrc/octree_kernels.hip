@@ -33,7 +33,7 @@ namespace {
 
 constexpr int kWave = 64;
 enum { C_NNODES = 0, C_NOPEN, C_ARENA, C_NMASK, C_MAXDEPTH, C_OVERFLOW, C_REFS, C_MAXLEAF, C_NLEAVES, C_NCHUNK, C_NCHUNK_NEXT, C_SCAN_DONE, C_SCAN_OVER,
-       C_SNAP_NOPEN, C_SNAP_NNODES, C_SNAP_ARENA, C_SNAP_NMASK, C_COUNT };  // C_SNAP_*: the level's starting values, see k_oct_decide
+       C_SNAP_NOPEN, C_SNAP_NNODES, C_SNAP_ARENA, C_SNAP_NMASK, C_SCAN_TICKET, C_COUNT };  // C_SNAP_*: the level's starting values, see k_oct_decide; C_SCAN_TICKET: k_oct_scan
 
 __device__ __forceinline__ int wave_incl_scan(int v, int lane) {
 #pragma unroll
@@ -154,6 +154,7 @@ __global__ __launch_bounds__(256) void k_oct_decide(OctWork w) {
         w.counters[C_SNAP_NNODES] = w.counters[C_NNODES];
         w.counters[C_SNAP_ARENA] = w.counters[C_ARENA];
         w.counters[C_SNAP_NMASK] = w.counters[C_NMASK];
+        w.counters[C_SCAN_TICKET] = 0;  // k_oct_scan's workgroups draw their logical blocks of this level from here
     }
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
@@ -307,9 +308,13 @@ __device__ int block_excl_scan(int v, int *total) {
 // of the tree does not depend on scheduling.  One workgroup did this for a whole level (up to 95 us at the deep levels of an ico6 mesh:
 // twelve rounds of 1024 nodes, each thread then writing its node's eight children and their chunk tables).  Now up to kScanBlocks
 // workgroups per tree share the level: logical block lb = 1024 consecutive open nodes; a workgroup scans its block, publishes the block's
-// seven sums (w.agg, tagged with the level), waits for the sums of the blocks before it (they are published before anything is waited for,
-// and a workgroup only ever waits for lower logical blocks, all of which belong to workgroups dispatched no later than itself), and writes
+// seven sums (w.agg, tagged with the level), waits for the sums of the blocks before it (published before anything is waited for) and writes
 // its nodes.  The last workgroup to finish adds everything up for the counters.
+// A workgroup DRAWS its logical blocks from a ticket counter (round 5; until then block lb belonged to workgroup lb % gridDim.x, and a workgroup in its
+// second round waited for first-round blocks of workgroups that might not have been dispatched yet -- with two to four set-up pipelines building forests
+// side by side the launches are no longer resident as a whole, and a wait that ran out sent the subject down the slow per-label path, silently: ADVICE r4).
+// A ticket is only ever lower than one's own if its holder drew it earlier, i.e. is running and publishes its sums before it waits for anything: the
+// waits end whatever part of the launch is resident, and the numbering (prefix sums in open-node order) does not depend on who scans which block.
 constexpr int kScanBlocks = 16;
 constexpr int kBigNode = 24;  // a splitting node whose children hold more chunks than this has its chunk tables written by the whole workgroup
 template <int cur>
@@ -323,11 +328,13 @@ __global__ __launch_bounds__(1024) void k_oct_scan(OctWork w, int depth) {
     }
     const int nnodes0 = w.counters[C_SNAP_NNODES], arena0 = w.counters[C_SNAP_ARENA], nmask0 = w.counters[C_SNAP_NMASK];
     const int nlog = (nopen + 1023) / 1024, epoch = depth + 1;
-    __shared__ int s_over, s_max, s_last, s_nbig;
+    __shared__ int s_over, s_max, s_last, s_nbig, s_lb;
     __shared__ int4 s_big[1024];
-    for (int lb = blockIdx.x; lb < nlog; lb += gridDim.x) {  // uniform
-        if (tid == 0) s_over = 0, s_max = 0, s_nbig = 0;
+    for (;;) {
+        if (tid == 0) s_over = 0, s_max = 0, s_nbig = 0, s_lb = atomicAdd(&w.counters[C_SCAN_TICKET], 1);
         __syncthreads();
+        const int lb = s_lb;  // uniform
+        if (lb >= nlog) break;
         const int o = lb * 1024 + tid;
         const bool in = o < nopen;
         const int sp = in ? w.split[o] : 0;
@@ -586,8 +593,8 @@ int queue_levels(msm_ctx *ctx, OctJob &j, int count) {
     const int upto = std::min(kMaxLevels, j.depth + count);
     const unsigned B = (unsigned)j.trees;
     const unsigned div = B > 1 ? 4 : 1;  // a forest's trees share the machine
-    // k_oct_scan's workgroups wait for one another: all of a launch must be resident at once (at least one 1024-thread workgroup per CU of THIS
-    // device: 256 on an MI355X, fewer on a partition)
+    // k_oct_scan's workgroups wait for one another's sums; they draw their blocks from a ticket counter, so the waits end whatever part of a launch is
+    // resident (see there) -- the grid is sized for one 1024-thread workgroup per CU of this device and tree, more would only queue
     const unsigned scan_blocks = std::max(1u, std::min((unsigned)kScanBlocks, (unsigned)std::max(1, ctx->num_cus) / B));
     for (; j.depth < upto; ++j.depth) {
         if (j.cur == 0) {
@@ -703,11 +710,11 @@ int gpu_build_octree_finish(msm_mesh *m) {
     m->oct_job.reset();
     const int T = m->T, V = m->V;
     MSM_HIP(hipSetDevice(ctx->device));
-    MSM_HIP(hipStreamSynchronize(ctx->stream));
+    MSM_TRY(ctx_sync(ctx));
     while (ctx->oct_hcounters[C_NOPEN] != 0 && !ctx->oct_hcounters[C_OVERFLOW] && job.depth < kMaxLevels) {
         int st = queue_levels(ctx, job, kNextBatch);
         if (st) return st;
-        MSM_HIP(hipStreamSynchronize(ctx->stream));
+        MSM_TRY(ctx_sync(ctx));
     }
     struct {
         int *h_counters;
@@ -796,7 +803,7 @@ int gpu_build_forest(msm_ctx *ctx, Forest &f, const double *d_xyz, size_t comp_s
     job.h_counters = f.h_counters;
     int st = queue_levels(ctx, job, first_batch(T));
     if (st) return st;
-    MSM_HIP(hipStreamSynchronize(ctx->stream));
+    MSM_TRY(ctx_sync(ctx));
     auto open_somewhere = [&] {
         for (int b = 0; b < B; ++b) {
             const int *hc = f.h_counters + (size_t)b * (C_COUNT + 1);
@@ -807,7 +814,7 @@ int gpu_build_forest(msm_ctx *ctx, Forest &f, const double *d_xyz, size_t comp_s
     while (open_somewhere() && job.depth < kMaxLevels) {
         st = queue_levels(ctx, job, kNextBatch);
         if (st) return st;
-        MSM_HIP(hipStreamSynchronize(ctx->stream));
+        MSM_TRY(ctx_sync(ctx));
     }
     f.info.assign(B, Forest::Info{});
     for (int b = 0; b < B; ++b) {

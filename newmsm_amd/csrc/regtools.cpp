@@ -74,6 +74,7 @@ extern "C" {
 
 int msm_mesh_unfold(msm_mesh *m, double radius, int32_t *passes, int32_t *first_folded) {
     if (!m) return fail(MSM_ERR_INVALID, "msm_mesh_unfold: null mesh");
+    ++m->ctx->epoch;  // (the coordinates may change: a label step queued ahead is not taken, msm_ctx::epoch)
     msm_ctx *ctx = m->ctx;
     MSM_HIP(hipSetDevice(ctx->device));
     const int V = m->V, T = m->T;
@@ -98,14 +99,14 @@ int msm_mesh_unfold(msm_mesh *m, double radius, int32_t *passes, int32_t *first_
         int st = launch_fold_detect(ctx, m->d_xyz, V, m->d_tri, T, m->d_tid_ptr, m->d_tid, m->d_fold);
         if (st) return st;
         int32_t head[2];
-        MSM_HIP(hipMemcpyAsync(head, m->d_fold, sizeof(head), hipMemcpyDeviceToHost, ctx->stream));
-        MSM_HIP(hipStreamSynchronize(ctx->stream));
+        MSM_TRY(stage_d2h(ctx, head, m->d_fold, sizeof(head)));
+        MSM_TRY(ctx_sync(ctx));
         if (head[1] > 0) return fail(MSM_ERR_INVALID, "get_triangle: index exceeds face dimensions");  // a vertex without triangles, R/mesh.h:82-86
         if (it == 0 && first_folded) *first_folded = head[0];
         if (head[0] == 0) break;  // the usual case: nothing is folded and nothing leaves the GPU but two counters
         flags.resize(V);
-        MSM_HIP(hipMemcpyAsync(flags.data(), m->d_fold + 2, sizeof(int32_t) * (size_t)V, hipMemcpyDeviceToHost, ctx->stream));
-        MSM_HIP(hipStreamSynchronize(ctx->stream));
+        MSM_TRY(stage_d2h(ctx, flags.data(), m->d_fold + 2, sizeof(int32_t) * (size_t)V));
+        MSM_TRY(ctx_sync(ctx));
         folded.clear();
         for (int v = 0; v < V; ++v)
             if (flags[v]) folded.push_back(v);
@@ -129,7 +130,7 @@ int msm_mesh_unfold(msm_mesh *m, double radius, int32_t *passes, int32_t *first_
         if (passes) *passes = it + 1;
         if (it + 1 == 1000) break;
     }
-    MSM_HIP(hipStreamSynchronize(ctx->stream));
+    MSM_TRY(ctx_sync(ctx));
     return MSM_OK;
 }
 

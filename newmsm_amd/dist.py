@@ -200,11 +200,14 @@ def sharded_group_setup(group, n_subjects, comm=None, chunks=None, pair_layout=N
     one piece are issued asynchronously (RCCL's own stream) and run over xGMI while the next piece is set up; everything is waited for once,
     before the imports.  gloo (CPU rehearsal): one piece, host tensors through the host entry points.
 
-    pair_layout: the order of the group's pair list (DiscreteGroupCostFunction.set_pair_layout).  None: control-point major when there is more than
-    one rank -- ShardedMove gives every rank a contiguous slice of the list, which is then a region of the sphere (an eighth of every resampled map)
-    instead of eight subjects' rows of it (all of their maps and most of everyone else's) -- and the group's current layout otherwise."""
+    pair_layout: the order of the group's pair list (DiscreteGroupCostFunction.set_pair_layout).  None: control-point major whenever the run has a
+    process group -- ShardedMove gives every rank a contiguous slice of the list, which is then a region of the sphere (an eighth of every resampled map)
+    instead of eight subjects' rows of it (all of their maps and most of everyone else's) -- WHATEVER the number of ranks, one included: the optimiser
+    consumes pairs and their costs in list order (the order of its sums, and with near-ties its decisions), so a launched run must not depend on how many
+    ranks it was given (until round 5 one rank kept the reference's order and N > 1 did not).  A plain process without a process group keeps
+    the group's current layout (the reference's order by default)."""
     c = _comm(comm)
-    if pair_layout is None and c.world > 1 and hasattr(group, "set_pair_layout"):
+    if pair_layout is None and c.dist is not None and hasattr(group, "set_pair_layout"):
         pair_layout = group.CP_MAJOR
     if pair_layout is not None:
         group.set_pair_layout(pair_layout)
@@ -278,10 +281,10 @@ def sharded_group_setup(group, n_subjects, comm=None, chunks=None, pair_layout=N
         pi = torch.zeros((n, imax), dtype=torch.int32, device=dev)
         if len(part) < n:
             F[len(part):].zero_()  # a rank with fewer subjects than the largest shard sends defined padding
-        # torch's fills above run on torch's current stream, which libmsmhip's streams (created non-blocking) do not order against: they are complete BEFORE
-        # the library writes into the same tensors -- a fill that lands after the export wipes exported rows (seen with four ranks sharing one GPU: one run in
-        # seven delivered zeroed patch lists to every rank)
-        torch.cuda.current_stream().synchronize()
+        # torch's fills above run on torch's current stream, which libmsmhip's streams (created non-blocking) do not order against: the library's stream waits
+        # for them (msm_ctx_wait_stream: an event, no host wait) BEFORE it writes into the same tensors -- a fill that lands after the export wipes exported
+        # rows (seen with four ranks sharing one GPU: one run in seven delivered zeroed patch lists to every rank).  include/msmhip.h: "Stream contract".
+        _order_after_torch(group.ctx, torch)
         if part:
             group.export_subjects_dev(part, F.data_ptr(), L * D * V, pp.data_ptr(), M, pi.data_ptr(), imax)  # synchronises libmsmhip's stream
         aF = torch.empty((c.world,) + tuple(F.shape), dtype=F.dtype, device=dev)
@@ -299,7 +302,9 @@ def sharded_group_setup(group, n_subjects, comm=None, chunks=None, pair_layout=N
     for _, _, _, _, _, _, works, _ in pending:
         for w in works:
             w.wait()
-    torch.cuda.synchronize()  # libmsmhip's stream is not one torch orders against: the gathered buffers are complete for any stream from here on
+    # work.wait() has made torch's current stream wait for the collectives; libmsmhip's stream is not one torch orders against: it waits for that stream in turn
+    # before the imports read the gathered buffers
+    _order_after_torch(group.ctx, torch)
     for k0, k1, all_counts, aF, app, api, _, _ in pending:
         imax = api.shape[2]
         for r in range(c.world):
@@ -326,6 +331,13 @@ def same_node(comm):
     names = [None] * c.world
     c.dist.all_gather_object(names, os.uname().nodename)
     return len(set(names)) == 1
+
+
+def _order_after_torch(ctx, torch):
+    """libmsmhip's stream of `ctx` waits for everything torch's current stream holds now (msm_ctx_wait_stream; the caller's side of the stream contract of
+    the ..._dev entry points, include/msmhip.h).  No-op without a GPU (gloo rehearsals on the CPU never reach device buffers)."""
+    if torch.cuda.is_available():
+        ctx.wait_stream(torch.cuda.current_stream().cuda_stream)
 
 
 class SharedStepBuffer:
@@ -479,9 +491,9 @@ class ShardedMove:
             self.gpu_scratch = (torch.zeros(4 * self.pmax + 8 * self.tmax, dtype=torch.float64, device="cuda:%d" % torch.cuda.current_device())
                                 if torch.cuda.is_available() else None)
         if torch.cuda.is_available():
-            # the zero fills of the tensors above run on torch's current stream; libmsmhip's kernels write into them from streams that do not order against
-            # it: complete before the first move (a late fill wiped the first results written -- the kept (label, label) costs of a rank's slice)
-            torch.cuda.synchronize()
+            # the zero fills of the tensors above run on torch's current stream; libmsmhip's kernels write into them from a stream that does not order against
+            # it: that stream waits for them before the first move (a late fill wiped the first results written -- the kept (label, label) costs of a rank's slice)
+            _order_after_torch(group.ctx, torch)
 
     def close(self):
         if self.transport == "shm" and self.shared is not None:

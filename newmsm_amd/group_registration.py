@@ -106,8 +106,14 @@ def run_group_level(ops, template_xyz, template_tri, data_xyz, data_tri, feats, 
     energies, labelings, energy = [], [], 0.0
     for it in range(iters):
         for s in range(S):
-            ops.set_coords(meshes[s], sph_regs[s])
-            g.set_subject(s, meshes[s], feats[s])  # reset_meshspace
+            # The model's data meshes at iteration 0 are the level's ORIGINAL data grid for every subject (set_meshspace(target_space, SPH_orig, S) in
+            # initialize_level, M/group_mesh_registration.cpp:54) -- also at levels after the first, where project_CPgrid has carried the previous level's warp
+            # to ALL_SPH_REG and to the model's control grids (warp_CPgrid) but NOT to m_datameshes; reset_meshspace(ALL_SPH_REG[subject]) only comes at the
+            # end of an iteration (:114).  So the first get_patch_data of a later level rotates and resamples the unwarped data grid against warped control
+            # grids: what newmsm does, reproduced here (until round 5 iteration 0 started from the projected spheres).
+            if it > 0:
+                ops.set_coords(meshes[s], sph_regs[s])
+                g.set_subject(s, meshes[s], feats[s])  # reset_meshspace at the end of the previous iteration, :114
             g.reset_cpgrid(s, cps[s])
         g.set_labels(samples)
         timed("setup", g.setup)

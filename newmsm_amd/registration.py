@@ -61,20 +61,25 @@ class ProductOps:
         return api.metric_resample(in_mesh, data, new_mesh, out=out)
 
     def pin(self, array):
-        """page-lock a large input matrix for the length of a run (msm_host_register): its uploads then skip the staging block.  Returns a token for
-        unpin, or None when the array cannot be pinned (not C-contiguous float64, or the driver refuses)."""
+        """a large input matrix in page-locked memory of the context for the length of a run (msm_host_alloc: one copy here, and every level's upload of
+        it then skips the staging blocks).  Returns (token for unpin, the array to use); (None, array) when the array is small or not float64.
+        (Until round 5 the caller's own numpy array was page-locked in place (msm_host_register).  Page-locking works on whole pages and the device address
+        of such memory is its host address: the first and last page of an array in the heap are shared with its heap neighbours, and the HIP runtime
+        page-locks and releases pageable buffers of asynchronous copies on its own -- whichever of two sharers is released first unmaps the page under the
+        other.  msm_host_register now refuses ranges that are not whole pages)"""
         a = np.asarray(array)
-        if a.dtype != np.float64 or not a.flags.c_contiguous or a.nbytes < (1 << 20):
-            return None
+        if a.dtype != np.float64 or a.nbytes < (1 << 20):
+            return None, array
         try:
-            self.ctx.register_host(a.ctypes.data, a.nbytes)
+            pinned = self.ctx.host_array(a.shape)
         except api.MsmError:
-            return None
-        return (a.ctypes.data, a)  # the array stays alive with the token
+            return None, array
+        pinned[...] = a
+        return pinned, pinned
 
     def unpin(self, token):
         if token is not None:
-            self.ctx.unregister_host(token[0])
+            self.ctx.release_host_array(token)
 
     def smooth_data(self, mesh, data, sigma):
         return api.smooth_data(mesh, data, mesh, sigma)
@@ -399,9 +404,17 @@ def run_multiresolution(ops, in_xyz, in_tri, in_data, ref_xyz, ref_tri, ref_data
     in_xyz = np.asarray(in_xyz, dtype=np.float64)
     in_mesh, ref_mesh = ops.mesh(in_xyz, in_tri), ops.mesh(ref_xyz, ref_tri)
     sph_reg_prev, prev_order, regs, all_energies = None, None, [], []
-    # the two data matrices go up once per level: page-locked for the run, their uploads skip the staging block (ProductOps.pin; a no-op elsewhere)
-    pins = [ops.pin(d) for d in (in_data, ref_data)] if hasattr(ops, "pin") else []
+    # the two data matrices go up once per level: in page-locked memory for the run, their uploads skip the staging blocks (ProductOps.pin; absent elsewhere)
+    pins = []
     try:
+        if hasattr(ops, "pin"):
+            for which in (0, 1):
+                token, arr = ops.pin(in_data if which == 0 else ref_data)
+                pins.append(token)
+                if which == 0:
+                    in_data = arr
+                else:
+                    ref_data = arr
         return _run_levels(ops, clock, timed, in_xyz, in_mesh, ref_mesh, in_data, ref_data, levels, varnorm, in_cfweight, ref_cfweight, labelings_out, in_anat,
                            ref_anat, ref_xyz, level_kw, sph_reg_prev, prev_order, regs, all_energies)
     finally:

@@ -241,6 +241,10 @@ const int *orc_group_triplets(const orc_group *g);
 int  orc_group_patch(const orc_group *g, int s, int v, int l, int *ids, double *data, int cap);
 double orc_group_pairwise(orc_group *g, int pair, int la, int lb);   /* DiscreteGroupCostFunction.cpp:54-98 */
 double orc_group_triplet(orc_group *g, int t, int la, int lb, int lc); /* :26-52 */
+void orc_group_set_threads(orc_group *g, int nthreads); /* get_patch_data's OpenMP loop over the subjects, M/DiscreteGroupModel.cpp:92 */
+/* n evaluations each over OpenMP threads, as Fusion::optimize's pair and triplet loops run them (I/Fusion/Fusion.h:164,181) */
+void orc_group_pairwise_batch(orc_group *g, const int *pair, const int *la, const int *lb, int n, double *out, int nthreads);
+void orc_group_triplet_batch(orc_group *g, const int *t, const int *la, const int *lb, const int *lc, int n, double *out, int nthreads);
 
 #ifdef __cplusplus
 }

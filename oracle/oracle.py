@@ -582,6 +582,28 @@ class Group:
         lib().orc_group_sizes(self.h, C.byref(n), C.byref(p), C.byref(t))
         self.num_nodes, self.P, self.T = n.value, p.value, t.value
 
+    def set_threads(self, n):
+        """OpenMP threads of get_patch_data's loop over the subjects (the reference: num_threads(_nthreads), M/DiscreteGroupModel.cpp:92)"""
+        lib().orc_group_set_threads(self.h, int(n))
+
+    def pairwise_batch(self, pair, la, lb, threads=1):
+        """computePairwiseCost for n (pair, labelA, labelB) over OpenMP threads, as Fusion::optimize's pair loop runs them (I/Fusion/Fusion.h:164)"""
+        p, pp = _i(pair)
+        a, pa = _i(la)
+        b, pb = _i(lb)
+        out = np.empty(len(p))
+        lib().orc_group_pairwise_batch(self.h, pp, pa, pb, len(p), out.ctypes.data_as(c_dp), int(threads))
+        return out
+
+    def triplet_batch(self, t, la, lb, lc, threads=1):
+        tt, pt = _i(t)
+        a, pa = _i(la)
+        b, pb = _i(lb)
+        c, pc = _i(lc)
+        out = np.empty(len(tt))
+        lib().orc_group_triplet_batch(self.h, pt, pa, pb, pc, len(tt), out.ctypes.data_as(c_dp), int(threads))
+        return out
+
     def pairs(self):
         return np.ctypeslib.as_array(lib().orc_group_pairs(self.h), (self.P, 2)).copy()
 

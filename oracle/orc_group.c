@@ -27,6 +27,7 @@ struct orc_group {
     double **spacing;     /* per subject N */
     double **F;           /* per (s,l): D x V_tmpl resampled features */
     int **pptr, **pidx;   /* per subject: CSR over (v*L + l) of template vertex ids */
+    int nthreads;         /* OpenMP threads of get_patch_data's loop over the subjects (0 / 1: serial) */
 };
 
 orc_group *orc_group_create(const orc_group_params *p, int S) {
@@ -161,8 +162,10 @@ int orc_group_setup(orc_group *g) {
         orc_cp_spacings(g->cpmesh[s], g->spacing[s], &mvd);
         orc_cp_rotations(centre, g->cpmesh[s]->xyz, N, &g->rot[9 * (size_t)s * N]);
     }
-    /* get_patch_data :88-121 */
+    /* get_patch_data :88-121; the reference's loop over the subjects is an OpenMP loop (:92, num_threads(_nthreads)): orc_group_set_threads */
     g->F = (double **)calloc((size_t)S * L, sizeof(double *));
+    int failed = 0;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(g->nthreads > 0 ? g->nthreads : 1)
     for (int s = 0; s < S; ++s) {
         const orc_mesh *dm = g->data[s];
         long cap = 256L * N * L, n = 0;
@@ -183,7 +186,10 @@ int orc_group_setup(orc_group *g) {
             int st = orc_metric_resample(rot_mesh, g->feat[s], D, g->tmpl, F);
             orc_mesh_destroy(rot_mesh);
             g->F[(size_t)s * L + l] = F;
-            if (st) return st;
+            if (st) {
+#pragma omp critical
+                if (!failed) failed = st;
+            }
         }
         /* patch membership: template vertices in range of the rotated control point, ascending id */
         for (int v = 0; v < N; ++v)
@@ -205,7 +211,20 @@ int orc_group_setup(orc_group *g) {
             }
         g->pptr[s][N * L] = (int)n;
     }
-    return 0;
+    return failed;
+}
+
+void orc_group_set_threads(orc_group *g, int nthreads) { g->nthreads = nthreads; }
+
+/* n evaluations each, spread over threads as Fusion::optimize spreads its pair and triplet loops (I/Fusion/Fusion.h:164, :181): the CPU leg of bench.py's
+ * gMSM object */
+void orc_group_pairwise_batch(orc_group *g, const int *pair, const int *la, const int *lb, int n, double *out, int nthreads) {
+#pragma omp parallel for schedule(static) num_threads(nthreads > 0 ? nthreads : 1)
+    for (int i = 0; i < n; ++i) out[i] = orc_group_pairwise(g, pair[i], la[i], lb[i]);
+}
+void orc_group_triplet_batch(orc_group *g, const int *t, const int *la, const int *lb, const int *lc, int n, double *out, int nthreads) {
+#pragma omp parallel for schedule(static) num_threads(nthreads > 0 ? nthreads : 1)
+    for (int i = 0; i < n; ++i) out[i] = orc_group_triplet(g, t[i], la[i], lb[i], lc[i]);
 }
 
 void orc_group_sizes(const orc_group *g, int *nodes, int *pairs, int *triplets) {

@@ -94,7 +94,8 @@ int main() {
         msm_ctx *ctx = msm_ctx_create(0);
         if (!ctx) throw msmhip::rccl::Error(msm_last_error());
         Problem a = make_problem(ctx), b = make_problem(ctx);
-        // the unsharded reference: plain ABI calls
+        // the unsharded reference: plain ABI calls (the pair list in the layout sharded_group_setup gives every launched run, whatever its rank count)
+        check_msm(msm_group_set_pair_layout(a.g, 1), "msm_group_set_pair_layout");
         check_msm(msm_group_setup(a.g), "msm_group_setup");
         int32_t nodes = 0, P = 0, T = 0;
         check_msm(msm_group_sizes(a.g, &nodes, &P, &T), "sizes");

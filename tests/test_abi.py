@@ -24,7 +24,7 @@ def test_every_declared_symbol_is_exported_and_bound(built):
         assert hasattr(L, n), "libmsmhip.so does not export %s" % n
         assert n in _lib.SIGNATURES, "python binding lacks %s" % n
     assert sorted(_lib.SIGNATURES) == names
-    assert L.msm_abi_version() == 10
+    assert L.msm_abi_version() == 11
 
 
 def test_no_cpu_fallback(built):

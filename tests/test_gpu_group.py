@@ -246,12 +246,12 @@ mine = D.sharded_group_setup(g, S, dist)
 rng = np.random.default_rng(3)
 p = rng.integers(0, g.P, 300).astype(np.int32); la = rng.integers(0, g.L, 300).astype(np.int32); lb = rng.integers(0, g.L, 300).astype(np.int32)
 g1, keep1 = make(); g1.setupCostFunction()
-# with more than one rank the sharded group's pair list is control-point major (a contiguous slice = a region of the sphere): the same pairs as the
-# reference's list in another order -- `pos`: where pair i of the sharded group's list sits in the single-rank group's
+# a launched run's pair list is control-point major whatever the number of ranks (a contiguous slice = a region of the sphere; the optimiser's sums must not
+# depend on the rank count): the same pairs as the reference's list in another order -- `pos`: where pair i of the sharded group's list sits in the plain group's
 pairs_s, pairs_1 = g.getPairs(), g1.getPairs()
 where = {(int(a), int(b)): i for i, (a, b) in enumerate(pairs_1)}
 pos = np.array([where[(int(a), int(b))] for a, b in pairs_s], dtype=np.int64)
-layout_ok = bool((world == 1) == np.array_equal(pos, np.arange(g.P))) and len(set(pos.tolist())) == g.P
+layout_ok = (not np.array_equal(pos, np.arange(g.P))) and len(set(pos.tolist())) == g.P
 sharded = g.computePairwiseCost(p, la, lb)
 single = g1.computePairwiseCost(pos[p].astype(np.int32), la, lb)
 # a label step with the pair and triplet lists sharded over the two ranks, gathered on rank 0 (M/DiscreteGroupCostFunction.cpp:54-98)

@@ -181,7 +181,7 @@ def main(argv):
     if a.inanat:  # set_anatomical: loaded as they are
         cfw.update(in_anat=meshio.load_surface(a.inanat)[0], ref_anat=meshio.load_surface(a.refanat)[0])
     if a.inweight and a.refweight:
-        cfw = dict(in_cfweight=meshio.load_data(a.inweight, len(ixyz)), ref_cfweight=meshio.load_data(a.refweight, len(rxyz)))
+        cfw.update(in_cfweight=meshio.load_data(a.inweight, len(ixyz)), ref_cfweight=meshio.load_data(a.refweight, len(rxyz)))
     ctx = M.Context(a.device)
     if a.verbose:
         print("This is newMSM's DISCRETE path on an MI355X (msm-mi355x).\nStarting multiresolution with %d levels." % len(levels))
