@@ -89,6 +89,14 @@ __device__ __forceinline__ void half_sums(double (&v)[N], int lane) {
 
 constexpr int kGroupStage = 256;  // ids of patch B staged in LDS per wavefront
 
+// a pointer the compiler knows to point into device memory (address space 1)
+template <class T>
+using GlobalPtr = const T __attribute__((address_space(1))) *;
+template <class T>
+__device__ __forceinline__ GlobalPtr<T> as_global(const T *p) {
+    return (GlobalPtr<T>)p;
+}
+
 }  // namespace
 
 // every data vertex v is moved to estimate_rotation_matrix(centre, v) * label: "rigid rotation" of the mesh by the label
@@ -189,22 +197,27 @@ __global__ __launch_bounds__(256) void k_group_pairwise(GroupArgs a, const int *
     }
     const int ga = a.pairs[2 * pair], gb = a.pairs[2 * pair + 1];
     const int sa = ga / a.N, sb = gb / a.N, na = ga - sa * a.N, nb = gb - sb * a.N;
-    const int *pa = a.pptr[sa], *pb = a.pptr[sb];
+    // The per-subject arrays are reached through pointer tables in device memory.  A pointer LOADED from memory is a generic one to the compiler, and every
+    // access through it a FLAT instruction (the vector-memory path plus the LDS path's wait counter: the 20 feature gathers and 10 list loads of a query);
+    // they are device memory, and say so (round 5: global_load instead of flat_load).
+    const GlobalPtr<int> pa = as_global(a.pptr[sa]), pb = as_global(a.pptr[sb]);
     const int ba = pa[na * a.L + la], ea = pa[na * a.L + la + 1], bb = pb[nb * a.L + lb], eb = pb[nb * a.L + lb + 1];
-    const int *ia = a.pidx[sa] + ba, *ib = a.pidx[sb] + bb;
+    const GlobalPtr<int> ia = as_global(a.pidx[sa]) + ba, ib = as_global(a.pidx[sb]) + bb;
     const int cntA = ea - ba, cntB = eb - bb;
-    const double *FA = a.F[(size_t)sa * a.L + la], *FB = a.F[(size_t)sb * a.L + lb];
+    const GlobalPtr<double> FA = as_global(a.F[(size_t)sa * a.L + la]), FB = as_global(a.F[(size_t)sb * a.L + lb]);
     const double nan = __longlong_as_double(0x7ff8000000000000ll);
     // B's ids go to LDS first when they fit (patches hold ~65 entries at ico6 / ico4): the binary search below is a chain
     // of dependent loads, and seven round trips to memory per query were most of this kernel's time
-    __shared__ int s_ids[kPerBlock][kGroupStage];
+    // (+ 8 words per slot: the slots of a wavefront's queries start 8 banks apart -- their lanes walk lists of similar length in lockstep and would otherwise
+    // read the same index of four lists, i.e. four addresses in one bank, at every step of the search)
+    __shared__ int s_ids[kPerBlock][kGroupStage + 8];
     int *stage = s_ids[slot];
     const bool staged = cntB <= kGroupStage;
     if (staged)
         for (int i = lane; i < cntB; i += kLanes) stage[i] = ib[i];
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    const int *fb = staged ? stage : ib;
+    const int *fb = staged ? (const int *)stage : (const int *)ib;  // (generic: the general path below reads it either way)
     if constexpr (!kDice) {
         // The usual case -- patches of up to 4 entries per lane, one or two feature rows -- keeps everything in registers: ids
         // loaded once, all gathers of both passes and both rows issued together.  The general code below reads ids and values
@@ -215,7 +228,9 @@ __global__ __launch_bounds__(256) void k_group_pairwise(GroupArgs a, const int *
         constexpr int kRounds = kLanes == 16 ? kPairSmallPatch / 16 : 4;  // entries per lane kept in registers: patches of up to 80 / 128 entries (6 and 8
                                                                           // rounds of sixteen lanes: 89 / 109 registers, 10.2 / 12.1 ms per label step against 9.5)
         constexpr int kQ = kLanes == 64 ? 32 : kLanes;  // (the fast path is compiled for 32 and 16 lanes per query)
-        if (cntA <= kRounds * kLanes && a.D <= 2 && a.simmeasure != 4 && a.simmeasure != 5) {
+        // (staged: B's ids are read through `stage`, a pointer the compiler knows to be LDS -- through `fb`, which may point either way, every step of
+        // the search was a FLAT load: the vector-memory path's issue rate and both wait counters for what is a 4-byte LDS read; round 5)
+        if (staged && cntA <= kRounds * kLanes && a.D <= 2 && a.simmeasure != 4 && a.simmeasure != 5) {
             int id[kRounds];
             bool mem[kRounds];
 #pragma unroll
@@ -232,15 +247,15 @@ __global__ __launch_bounds__(256) void k_group_pairwise(GroupArgs a, const int *
                 const int half = n >> 1;
 #pragma unroll
                 for (int r = 0; r < kRounds; ++r)
-                    if (r * kLanes < cntA) base[r] += fb[base[r] + half - 1] < id[r] ? half : 0;
+                    if (r * kLanes < cntA) base[r] += stage[base[r] + half - 1] < id[r] ? half : 0;
                 n -= half;
             }
 #pragma unroll
             for (int r = 0; r < kRounds; ++r) {
                 mem[r] = false;
                 if (r * kLanes < cntA && cntB > 0 && id[r] >= 0) {
-                    const int pos = base[r] + (fb[base[r]] < id[r] ? 1 : 0);
-                    mem[r] = pos < cntB && fb[pos] == id[r];
+                    const int pos = base[r] + (stage[base[r]] < id[r] ? 1 : 0);
+                    mem[r] = pos < cntB && stage[pos] == id[r];
                 }
             }
             // size of the intersection: the set bits of the rounds' ballots within this half wavefront
@@ -364,7 +379,7 @@ __global__ __launch_bounds__(256) void k_group_pairwise(GroupArgs a, const int *
         cost = nan;  // the reference indexes an empty vector here (undefined behaviour)
     } else {
         for (int d = 0; d < a.D; ++d) {
-            const double *A = FA + (size_t)d * a.Vt, *B = FB + (size_t)d * a.Vt;
+            const GlobalPtr<double> A = FA + (size_t)d * a.Vt, B = FB + (size_t)d * a.Vt;
             double c;
             if constexpr (kDice) {  // sparsesimkernel::DICE / genDICE, M/similarities.cpp:201-253 (weights unused)
                 double *SA = s_common + (size_t)slot * 2 * a.patch_cap, *SB = SA + a.patch_cap;
