@@ -315,10 +315,12 @@ __device__ int block_excl_scan(int v, int *total) {
 // side by side the launches are no longer resident as a whole, and a wait that ran out sent the subject down the slow per-label path, silently: ADVICE r4).
 // A ticket is only ever lower than one's own if its holder drew it earlier, i.e. is running and publishes its sums before it waits for anything: the
 // waits end whatever part of the launch is resident, and the numbering (prefix sums in open-node order) does not depend on who scans which block.
-constexpr int kScanBlocks = 16;
+constexpr int kScanThreads = 256;  // threads of a k_oct_scan workgroup = open nodes of a logical block (round 5: 1024 -- sixteen wavefronts that need a whole CU's
+                                   // worth of slots at once waited long for one while two set-up pipelines and their batch streams kept the CUs busy)
+constexpr int kScanBlocks = 64;
 constexpr int kBigNode = 24;  // a splitting node whose children hold more chunks than this has its chunk tables written by the whole workgroup
 template <int cur>
-__global__ __launch_bounds__(1024) void k_oct_scan(OctWork w, int depth) {
+__global__ __launch_bounds__(kScanThreads) void k_oct_scan(OctWork w, int depth) {
     w = tree_view(w);
     const int nopen = w.counters[C_SNAP_NOPEN];  // the copies k_oct_decide made for this level (see there)
     const int nxt = cur ^ 1, tid = threadIdx.x;
@@ -327,15 +329,15 @@ __global__ __launch_bounds__(1024) void k_oct_scan(OctWork w, int depth) {
         return;
     }
     const int nnodes0 = w.counters[C_SNAP_NNODES], arena0 = w.counters[C_SNAP_ARENA], nmask0 = w.counters[C_SNAP_NMASK];
-    const int nlog = (nopen + 1023) / 1024, epoch = depth + 1;
+    const int nlog = (nopen + kScanThreads - 1) / kScanThreads, epoch = depth + 1;
     __shared__ int s_over, s_max, s_last, s_nbig, s_lb;
-    __shared__ int4 s_big[1024];
+    __shared__ int4 s_big[kScanThreads];
     for (;;) {
         if (tid == 0) s_over = 0, s_max = 0, s_nbig = 0, s_lb = atomicAdd(&w.counters[C_SCAN_TICKET], 1);
         __syncthreads();
         const int lb = s_lb;  // uniform
         if (lb >= nlog) break;
-        const int o = lb * 1024 + tid;
+        const int o = lb * kScanThreads + tid;
         const bool in = o < nopen;
         const int sp = in ? w.split[o] : 0;
         const int len = in ? w.open_len[cur][o] : 0;
@@ -358,7 +360,7 @@ __global__ __launch_bounds__(1024) void k_oct_scan(OctWork w, int depth) {
             __syncthreads();
             if (tid == 0) __hip_atomic_store(w.agg + 8 * (size_t)lb + 7, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         }
-        for (int j = tid; j < lb; j += 1024) {
+        for (int j = tid; j < lb; j += kScanThreads) {
             // (bounded: should a block before this one never report -- it cannot, see above -- the build gives up and the host builds the tree)
             for (int spin = 0; __hip_atomic_load(w.agg + 8 * (size_t)j + 7, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != epoch; ++spin) {
                 if (spin > (1 << 22)) {
@@ -421,7 +423,7 @@ __global__ __launch_bounds__(1024) void k_oct_scan(OctWork w, int depth) {
             int kk = big.z;
             for (int c = 0; c < 8; ++c) {
                 const int cnt = w.ctot[8 * (size_t)big.x + c], nk = (cnt + kChunk - 1) / kChunk;
-                for (int j = tid; j < nk; j += 1024) {
+                for (int j = tid; j < nk; j += kScanThreads) {
                     w.chunk_open[nxt][kk + j] = big.y + c;
                     w.chunk_beg[nxt][kk + j] = j * kChunk;
                 }
@@ -438,7 +440,7 @@ __global__ __launch_bounds__(1024) void k_oct_scan(OctWork w, int depth) {
         if (s_last) {  // every block of the level has written its nodes: the level's totals
             int all[7] = {0, 0, 0, 0, 0, 0, 0}, sum[7];
             if (nlog > 1) {
-                for (int j = tid; j < nlog; j += 1024)
+                for (int j = tid; j < nlog; j += kScanThreads)
 #pragma unroll
                     for (int q = 0; q < 7; ++q) all[q] += __hip_atomic_load(w.agg + 8 * (size_t)j + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 block_excl_scan_n<7>(all, sum);
@@ -521,7 +523,7 @@ __global__ __launch_bounds__(256) void k_oct_init(OctWork w, int T, int root_chu
         w.chunk_beg[0][i] = i * kChunk;
     }
     if (i <= C_COUNT) w.counters[i] = i == C_NNODES || i == C_NOPEN ? 1 : i == C_NCHUNK ? root_chunks : 0;
-    for (int j = i; j < 8 * (w.cap_open / 1024 + 2); j += gridDim.x * blockDim.x) w.agg[j] = 0;  // no level has published sums yet
+    for (int j = i; j < 8 * (w.cap_open / kScanThreads + 2); j += gridDim.x * blockDim.x) w.agg[j] = 0;  // no level has published sums yet
     if (i == 0) {
         w.node[0] = make_int4(-1, 0, -1, 0);
         w.nodebox[0] = make_double4(-kBounds, -kBounds, -kBounds, 2 * kBounds);
@@ -595,19 +597,19 @@ int queue_levels(msm_ctx *ctx, OctJob &j, int count) {
     const unsigned div = B > 1 ? 4 : 1;  // a forest's trees share the machine
     // k_oct_scan's workgroups wait for one another's sums; they draw their blocks from a ticket counter, so the waits end whatever part of a launch is
     // resident (see there) -- the grid is sized for one 1024-thread workgroup per CU of this device and tree, more would only queue
-    const unsigned scan_blocks = std::max(1u, std::min((unsigned)kScanBlocks, (unsigned)std::max(1, ctx->num_cus) / B));
+    const unsigned scan_blocks = std::max(1u, std::min((unsigned)kScanBlocks, 4u * (unsigned)std::max(1, ctx->num_cus) / B));
     for (; j.depth < upto; ++j.depth) {
         if (j.cur == 0) {
             hipLaunchKernelGGL(k_oct_decide<0>, dim3(512 / div, B), dim3(256), 0, ctx->stream, j.w);
             hipLaunchKernelGGL(k_oct_count<0>, dim3(1024 / div, B), dim3(256), 0, ctx->stream, j.w);
             hipLaunchKernelGGL(k_oct_chunk_scan<0>, dim3(256 / div, B), dim3(256), 0, ctx->stream, j.w);
-            hipLaunchKernelGGL(k_oct_scan<0>, dim3(scan_blocks, B), dim3(1024), 0, ctx->stream, j.w, j.depth);
+            hipLaunchKernelGGL(k_oct_scan<0>, dim3(scan_blocks, B), dim3(kScanThreads), 0, ctx->stream, j.w, j.depth);
             hipLaunchKernelGGL(k_oct_fill<0>, dim3(1024 / div, B), dim3(256), 0, ctx->stream, j.w);
         } else {
             hipLaunchKernelGGL(k_oct_decide<1>, dim3(512 / div, B), dim3(256), 0, ctx->stream, j.w);
             hipLaunchKernelGGL(k_oct_count<1>, dim3(1024 / div, B), dim3(256), 0, ctx->stream, j.w);
             hipLaunchKernelGGL(k_oct_chunk_scan<1>, dim3(256 / div, B), dim3(256), 0, ctx->stream, j.w);
-            hipLaunchKernelGGL(k_oct_scan<1>, dim3(scan_blocks, B), dim3(1024), 0, ctx->stream, j.w, j.depth);
+            hipLaunchKernelGGL(k_oct_scan<1>, dim3(scan_blocks, B), dim3(kScanThreads), 0, ctx->stream, j.w, j.depth);
             hipLaunchKernelGGL(k_oct_fill<1>, dim3(1024 / div, B), dim3(256), 0, ctx->stream, j.w);
         }
         j.cur ^= 1;
@@ -635,7 +637,7 @@ int gpu_build_octree_begin(msm_mesh *m) {
         MSM_HIP(msm::pool_malloc((void **)&ctx->oct_box, ctx->oct_cap_box * sizeof(double)));
     }
     const size_t need_ints = (size_t)2 * cap_refs + (size_t)8 * cap_open + (size_t)cap_open + (size_t)8 * cap_open + (size_t)4 * cap_chunks + (size_t)8 * cap_chunks + 16 +
-                             8 * ((size_t)cap_open / 1024 + 2);
+                             8 * ((size_t)cap_open / kScanThreads + 2);
     if (need_ints > ctx->oct_cap_ints) {
         if (ctx->oct_ints) (void)msm::pool_free(ctx->oct_ints);
         ctx->oct_ints = nullptr;
@@ -746,7 +748,7 @@ int gpu_build_forest(msm_ctx *ctx, Forest &f, const double *d_xyz, size_t comp_s
     MSM_HIP(hipSetDevice(ctx->device));
     const int cap_nodes = T + 64, cap_refs = 6 * T + 256, cap_arena = 8 * T + 512, cap_open = cap_nodes, cap_chunks = cap_refs / kChunk + cap_open + 64;
     const size_t per_ints = ((size_t)2 * cap_refs + (size_t)8 * cap_open + (size_t)cap_open + (size_t)8 * cap_open + (size_t)4 * cap_chunks + (size_t)8 * cap_chunks + 16 +
-                             8 * ((size_t)cap_open / 1024 + 2) + 3) & ~(size_t)3;
+                             8 * ((size_t)cap_open / kScanThreads + 2) + 3) & ~(size_t)3;
     f.B = B, f.T = T, f.V = V;
     f.s_node = (size_t)cap_nodes, f.s_leaf = (size_t)cap_arena, f.s_rec = (size_t)T, f.s_grid = (size_t)64 * 64 * 64;
     MSM_HIP(f.node.ensure(f.s_node * B));
