@@ -385,6 +385,91 @@ inline void save_metric(const std::string &path, const std::vector<double> &data
     detail::write_gifti(path, arrays);
 }
 
+// ---- the text formats of -f ASCII / ASCII_MAT (set_output_format, M/mesh_registration.cpp:827-842)
+namespace detail {
+// a float as std::ostream writes it by default: the value rounded to float, six significant digits (%g)
+inline std::string g(double x) {
+    char buf[64];
+    std::snprintf(buf, sizeof(buf), "%g", (double)(float)x);
+    return buf;
+}
+// the numbers of a text file, row by row (lines starting with '#' and empty lines skipped)
+inline std::vector<std::vector<double>> read_rows(const std::string &path) {
+    std::ifstream in(path);
+    if (!in) throw Error("cannot open " + path);
+    std::vector<std::vector<double>> rows;
+    std::string line;
+    while (std::getline(in, line)) {
+        std::istringstream ls(line);
+        std::vector<double> r;
+        std::string tok;
+        while (ls >> tok) {
+            if (tok[0] == '#') break;
+            char *end = nullptr;
+            const double v = std::strtod(tok.c_str(), &end);
+            if (end == tok.c_str()) throw Error(path + ": not a number: " + tok);
+            r.push_back(v);
+        }
+        if (!r.empty()) rows.push_back(std::move(r));
+    }
+    return rows;
+}
+}  // namespace detail
+
+// Mesh::save_dpv, R/mesh.cpp:707-741: `index x y z value` per vertex (indices below 100 zero-padded to three digits), first data row only
+inline void save_dpv(const std::string &path, const std::vector<double> &xyz, const std::vector<double> &data) {
+    const size_t V = xyz.size() / 3;
+    if (data.size() < V) throw Error("Mesh::save_dpv, data and mesh dimensions do not agree");
+    FILE *f = std::fopen(path.c_str(), "w");
+    if (!f) throw Error("cannot write " + path);
+    for (size_t i = 0; i < V; ++i) {
+        if (i < 100) std::fprintf(f, "%03zu", i);
+        else std::fprintf(f, "%zu", i);
+        std::fprintf(f, " %s %s %s %s\n", detail::g(xyz[3 * i]).c_str(), detail::g(xyz[3 * i + 1]).c_str(), detail::g(xyz[3 * i + 2]).c_str(), detail::g(data[i]).c_str());
+    }
+    std::fclose(f);
+}
+// Mesh::save_matrix, R/mesh.cpp:743-766: one line per data row, values separated (and followed) by a blank
+inline void save_matrix(const std::string &path, const std::vector<double> &data, int D) {
+    const size_t V = D > 0 ? data.size() / (size_t)D : 0;
+    FILE *f = std::fopen(path.c_str(), "w");
+    if (!f) throw Error("cannot write " + path);
+    for (int d = 0; d < D; ++d) {
+        for (size_t i = 0; i < V; ++i) std::fprintf(f, "%s ", detail::g(data[(size_t)d * V + i]).c_str());
+        std::fprintf(f, "\n");
+    }
+    std::fclose(f);
+}
+// the data of a --indata / --refdata file by its extension, D x V row-major (set_data, M/reg_tools.cpp:846-867 / Mesh::load, R/mesh.cpp:296-348):
+// .dpv: the value column of `index x y z value` lines; .txt: a matrix, one row per feature (or per vertex: transposed when the rows are as long as
+// nvertices says they should not be); anything else: load_metric
+inline std::vector<double> load_data(const std::string &path, int *D, long nvertices = -1) {
+    if (detail::ends_with(path, ".dpv")) {
+        const auto rows = detail::read_rows(path);
+        std::vector<double> out;
+        for (const auto &r : rows) {
+            if (r.size() != 5) throw Error("Mesh::load_dpv:error opening file (wrong format) : " + path);
+            out.push_back(r[4]);
+        }
+        if (D) *D = 1;
+        return out;
+    }
+    if (detail::ends_with(path, ".txt")) {
+        const auto rows = detail::read_rows(path);
+        if (rows.empty()) throw Error(path + " holds no data");
+        const size_t R = rows.size(), C = rows[0].size();
+        for (const auto &r : rows)
+            if (r.size() != C) throw Error(path + ": rows of different lengths");
+        const bool transpose = nvertices >= 0 && (long)C != nvertices;
+        std::vector<double> out(R * C);
+        for (size_t i = 0; i < R; ++i)
+            for (size_t j = 0; j < C; ++j) out[transpose ? j * R + i : i * C + j] = rows[i][j];
+        if (D) *D = (int)(transpose ? C : R);
+        return out;
+    }
+    return load_metric(path, D, nvertices);
+}
+
 }  // namespace io
 }  // namespace msmhip
 

@@ -74,6 +74,22 @@ struct Anatomy {
     const Points *in_anat = nullptr, *ref_anat = nullptr;
 };
 
+// --inweight / --refweight brought to a level's data grid (downsample_cfweighting, M/mesh_registration.cpp:334-350: nearest neighbour): rows x V(data grid)
+struct Weighting {
+    const Matrix *in_weight = nullptr, *ref_weight = nullptr;
+    int in_rows = 0, ref_rows = 0;
+};
+
+// Mesh_registration::combine_costfunction_weighting, M/mesh_registration.cpp:849-869: the mean of the two weightings over the rows both have; the rows
+// only the larger one has are kept.  a: ra x V, b: rb x V.
+inline Matrix combine_costfunction_weighting(const Matrix &a, int ra, const Matrix &b, int rb, int *rows) {
+    Matrix out = ra >= rb ? a : b;
+    const size_t V = ra > 0 ? a.size() / (size_t)ra : 0, n = (size_t)std::min(ra, rb) * V;
+    for (size_t i = 0; i < n; ++i) out[i] = (a[i] + b[i]) / 2.0;
+    *rows = std::max(ra, rb);
+    return out;
+}
+
 struct LevelResult {
     Points sph_reg, cpgrid;
     std::vector<double> energies;
@@ -96,7 +112,7 @@ inline Points apply_labeling(const std::vector<double> &ROT, const Points &label
 inline LevelResult run_discrete_opt(Context &ctx, const Points &target_xyz, const Triangles &target_tri, const Matrix &ref_feat,
                                     const Points &source_xyz, const Triangles &source_tri, const Matrix &src_feat, int D, Points sph_reg,
                                     int cp_order, const LevelOptions &o, const Points *cp_start = nullptr, PhaseClock *clock = nullptr,
-                                    const Anatomy *anat = nullptr) {
+                                    const Anatomy *anat = nullptr, const Weighting *weights = nullptr) {
     // ---- initialize_level / Initialize(CONTROL)
     auto [cp_xyz, cp_tri] = make_mesh_from_icosa(cp_order);
     Mesh TARGET(ctx, target_xyz, target_tri), SOURCE(ctx, source_xyz, source_tri), CPGRID(ctx, cp_xyz, cp_tri);
@@ -137,6 +153,12 @@ inline LevelResult run_discrete_opt(Context &ctx, const Points &target_xyz, cons
     for (int it = 0; it < o.iters; ++it) {
         // ---- reset_meshspace + setupCostFunction
         SOURCE.set_coords(sph_reg);
+        if (weights && weights->in_weight && weights->ref_weight) {  // setupCostFunctionWeighting(combine_weighting()), M/mesh_registration.cpp:171,334-350
+            const Matrix resampled = PhaseClock::timed(clock, "metric_resample", [&] { return metric_resample(TARGET, *weights->ref_weight, SOURCE); });
+            int rows = 0;
+            const Matrix W = combine_costfunction_weighting(*weights->in_weight, weights->in_rows, resampled, weights->ref_rows, &rows);
+            costfct.set_dataaffintyweighting(W, rows);
+        }
         costfct.reset_source(SOURCE);
         CPGRID.set_coords(cp_xyz);
         costfct.reset_CPgrid(CPGRID);
@@ -237,7 +259,8 @@ struct MultiresResult {
 // in_* / ref_*: the input and reference spheres (radius 100) with their D x V data.
 inline MultiresResult run_multiresolutions(Context &ctx, const Points &in_xyz, const Triangles &in_tri, const Matrix &in_data, const Points &ref_xyz,
                                            const Triangles &ref_tri, const Matrix &ref_data, int D, const std::vector<LevelSpec> &levels, bool varnorm,
-                                           PhaseClock *clock = nullptr, const Points *in_anat = nullptr, const Points *ref_anat = nullptr) {
+                                           PhaseClock *clock = nullptr, const Points *in_anat = nullptr, const Points *ref_anat = nullptr,
+                                           const Matrix *in_cfweight = nullptr, int in_cfrows = 0, const Matrix *ref_cfweight = nullptr, int ref_cfrows = 0) {
     if (levels.empty()) throw Error(MSM_ERR_INVALID, "run_multiresolutions: no DISCRETE level");
     if ((in_anat != nullptr) != (ref_anat != nullptr)) throw Error(MSM_ERR_INVALID, "Error: must supply both anatomical meshes or none");  // CLI/newmsm.cpp:41-43
     if (in_anat && (in_anat->size() != in_xyz.size() || ref_anat->size() != ref_xyz.size()))
@@ -281,8 +304,15 @@ inline MultiresResult run_multiresolutions(Context &ctx, const Points &in_xyz, c
             PhaseClock::timed(clock, "unfold", [&] { return unfold(moved); });
             sph_in = moved.get_coords();
         }
+        Matrix w_in, w_ref;
+        Weighting weights;
+        if (in_cfweight && ref_cfweight) {  // downsample_cfweighting: both weightings onto the level's data grid by nearest neighbour
+            w_in = nearest_neighbour_interpolation(in_mesh, *in_cfweight, ico_xyz);
+            w_ref = nearest_neighbour_interpolation(ref_mesh, *ref_cfweight, ico_xyz);
+            weights.in_weight = &w_in, weights.ref_weight = &w_ref, weights.in_rows = in_cfrows, weights.ref_rows = ref_cfrows;
+        }
         LevelResult r = run_discrete_opt(ctx, ico_xyz, ico_tri, feats[1], ico_xyz, ico_tri, feats[0], D, sph_in, lv.cp_order, lv.options,
-                                         have_cp_start ? &cp_start : nullptr, clock, in_anat ? &anatomy : nullptr);
+                                         have_cp_start ? &cp_start : nullptr, clock, in_anat ? &anatomy : nullptr, in_cfweight && ref_cfweight ? &weights : nullptr);
         res.labelings.insert(res.labelings.end(), r.labelings.begin(), r.labelings.end());
         res.energies.push_back(r.energies);
         res.level_reg.push_back(r.sph_reg);

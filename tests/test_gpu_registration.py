@@ -410,3 +410,103 @@ def test_amsm_preset_end_to_end_matches_oracle(ctx):
     want = registration.run_multiresolution(OracleOps(M.mcmc_optimise), xyz, tri, src, xyz, tri, ref, levels, labelings_out=lw, in_anat=ian, ref_anat=ran, **run_kw)
     assert len(lg) == 2 and all(np.array_equal(a, b) for a, b in zip(lg, lw))
     assert angles(got[0], want[0]).max() <= NORTH_STAR_TOL_RAD and angles(got[0], xyz).max() > 1e-3
+
+
+def _cpp_newmsm():
+    """tools/cpp/newmsm, built on demand (g++ over the headers of include/ and libmsmhip.so)"""
+    import __graft_entry__ as g
+
+    return g.build_cpp_newmsm()
+
+
+def _same_files(a_prefix, b_prefix, names):
+    for n in names:
+        with open(a_prefix + n, "rb") as fa, open(b_prefix + n, "rb") as fb:
+            assert fa.read() == fb.read(), "%s differs between the two programs" % n
+
+
+@pytest.mark.parametrize("fmt", ["GIFTI", "ASCII", "ASCII_MAT"])
+def test_cpp_newmsm_writes_the_same_files_as_the_python_tool(ctx, tmp_path, fmt):
+    """tools/cpp/newmsm -- the `newmsm` executable with the host side in C++ (flags of src/msmOptions.h:59-157, CLI/newmsm.cpp:29-58) -- against
+    tools/register_files.py on the same inputs: pairwise mode with cost-function weightings and the shipped standard_MSM_strain schedule (its AFFINE level
+    skipped with a note), short and long flags, every output format: the three outputs byte for byte."""
+    import os
+    import subprocess
+    import sys
+
+    from newmsm_amd import config, meshio
+
+    exe = _cpp_newmsm()
+    xyz, tri = M.make_mesh_from_icosa(5)
+    ref = synthetic.features(xyz, 2, 5)
+    src = synthetic.features(synthetic.known_warp(xyz, seed=8, rot_deg=3.0, amp=2.0), 2, 5)
+    d = str(tmp_path) + "/"
+    text = config.PRESETS["standard_MSM_strain"].replace("--it=50,20,25,25", "--it=50,2,2,2").replace("--datagrid=5,5,5,6", "--datagrid=5,4,5,5").replace("--SGgrid=0,4,5,6", "--SGgrid=0,4,5,5").replace("--CPgrid=0,2,3,4", "--CPgrid=0,2,3,3")
+    with open(d + "conf", "w") as f:
+        f.write(text)
+    meshio.save_surface(d + "in.surf.gii", synthetic.known_warp(xyz, seed=3, rot_deg=0.0, amp=0.7) + 0.25, tri)  # off-centre and irregular: recentre / rescale matter
+    meshio.save_surface(d + "ref.surf.gii", xyz, tri)
+    meshio.save_metric(d + "in.func.gii", src)
+    meshio.save_metric(d + "ref.func.gii", ref)
+    w = 0.5 + np.random.default_rng(2).random((1, len(xyz)))
+    meshio.save_metric(d + "inw.func.gii", w)
+    meshio.save_metric(d + "refw.func.gii", w[:, ::-1].copy())
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--inmesh=" + d + "in.surf.gii", "--refmesh=" + d + "ref.surf.gii", "--indata=" + d + "in.func.gii", "--refdata=" + d + "ref.func.gii",
+              "--inweight=" + d + "inw.func.gii", "--refweight=" + d + "refw.func.gii", "--conf=" + d + "conf", "-f", fmt]
+    py = subprocess.run([sys.executable, "tools/register_files.py"] + common + ["--out=" + d + "py."], cwd=root, capture_output=True, text=True, timeout=600)
+    assert py.returncode == 0, py.stderr
+    cpp = subprocess.run([exe] + common + ["-o", d + "cpp.", "-v"], cwd=root, capture_output=True, text=True, timeout=600)
+    assert cpp.returncode == 0, cpp.stderr
+    assert "level 1 (--opt=AFFINE)" in cpp.stderr and "skipped" in cpp.stderr and "This is newMSM" in cpp.stdout
+    surf, data = {"GIFTI": (".surf.gii", ".func.gii"), "ASCII": (".asc", ".dpv"), "ASCII_MAT": (".asc", ".txt")}[fmt]
+    _same_files(d + "py.", d + "cpp.", ["sphere.reg" + surf, "sphere.LR.reg" + surf, "transformed_and_reprojected" + data])
+    reg, _ = meshio.load_surface(d + "cpp.sphere.reg" + surf)
+    assert angles(reg, meshio.load_surface(d + "in.surf.gii")[0]).max() > 1e-4  # something was registered
+    # the error behaviour of CLI/newmsm.cpp:41-43,62-68: the message, exit status 1
+    bad = subprocess.run([exe] + common + ["-o", d + "bad.", "--inanat=" + d + "in.surf.gii"], cwd=root, capture_output=True, text=True, timeout=600)
+    assert bad.returncode == 1 and "must supply both anatomical meshes or none" in bad.stderr
+    bad = subprocess.run([exe, "--nonsense"], cwd=root, capture_output=True, text=True, timeout=600)
+    assert bad.returncode == 1 and "is not an option" in bad.stderr
+
+
+def test_cpp_newmsm_groupwise_writes_the_same_files_as_the_python_tool(ctx, tmp_path):
+    """the same for -g / --groupwise (CLI/newmsm.cpp:13-27): three subjects on spheres of their own, an irregular template, a mask, two levels: the three
+    outputs per subject byte for byte; AFFINE levels refused with the reference's message"""
+    import os
+    import subprocess
+    import sys
+
+    from newmsm_amd import meshio
+
+    exe = _cpp_newmsm()
+    S = 3
+    xyz, tri = M.make_mesh_from_icosa(4)
+    d = str(tmp_path) + "/"
+    text = "--simval=2,2\n--sigma_in=2,0\n--lambda=0.001,0.001\n--it=2,2\n--opt=DISCRETE,DISCRETE\n--CPgrid=1,2\n--SGgrid=3,4\n--datagrid=3,4\n--dopt=HOCR\n--VN\n--fixnan\n"
+    with open(d + "conf", "w") as f:
+        f.write(text)
+    meshio.save_surface(d + "template.surf.gii", synthetic.known_warp(xyz, seed=33, rot_deg=7.0, amp=1.5), tri)
+    subj = [synthetic.known_warp(xyz, seed=40 + s, rot_deg=0.0, amp=1.0) for s in range(S)]
+    for s in range(S):
+        meshio.save_surface(d + "sphere%d.surf.gii" % s, subj[s], tri)
+        meshio.save_metric(d + "data%d.func.gii" % s, synthetic.features(synthetic.known_warp(subj[s], seed=90 + s, rot_deg=3.0, amp=2.0), 2, seed=5))
+    meshio.save_metric(d + "mask.func.gii", (np.random.default_rng(1).random(len(xyz)) > 0.2).astype(np.float64)[None])
+    with open(d + "meshes.txt", "w") as f:
+        f.write("".join(d + "sphere%d.surf.gii\n" % s for s in range(S)))
+    with open(d + "data.txt", "w") as f:
+        f.write("".join(d + "data%d.func.gii\n" % s for s in range(S)))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--groupwise", "--meshes=" + d + "meshes.txt", "--data=" + d + "data.txt", "--template=" + d + "template.surf.gii", "--mask=" + d + "mask.func.gii", "--conf=" + d + "conf"]
+    py = subprocess.run([sys.executable, "tools/register_files.py"] + common + ["--out=" + d + "py."], cwd=root, capture_output=True, text=True, timeout=600)
+    assert py.returncode == 0, py.stderr
+    cpp = subprocess.run([exe] + common + ["--out=" + d + "cpp."], cwd=root, capture_output=True, text=True, timeout=600)
+    assert cpp.returncode == 0, cpp.stderr
+    names = []
+    for s in range(S):
+        names += ["sphere-%d.reg.surf.gii" % s, "sphere-%d.LR.reg.surf.gii" % s, "transformed_and_reprojected-%d.func.gii" % s]
+    _same_files(d + "py.", d + "cpp.", names)
+    with open(d + "conf_affine", "w") as f:
+        f.write(text.replace("--opt=DISCRETE,DISCRETE", "--opt=AFFINE,DISCRETE"))
+    bad = subprocess.run([exe] + common[:-1] + ["--conf=" + d + "conf_affine", "--out=" + d + "bad."], cwd=root, capture_output=True, text=True, timeout=600)
+    assert bad.returncode == 1 and "not supported in groupwise mode" in bad.stderr
