@@ -482,6 +482,7 @@ static hipError_t ctx_scratch(msm_ctx *ctx, int slot, size_t bytes, void **out) 
     return hipSuccess;
 }
 
+constexpr int kRayQueryMin = 4096;  // queries from which a target's direction table is used by the plain search entry points (kernels.hip: launch_query_rays)
 int query_host(msm_mesh *target, const double *q, int N, int *tri_id, int *vid, double *w, int mode, const char *what, const double *q_on_device = nullptr);
 
 // q_on_device (optional): the same 3 x N points already in HBM (the vertices of a mesh handle of this context); the host copy
@@ -510,7 +511,9 @@ int query_host(msm_mesh *target, const double *q, int N, int *tri_id, int *vid, 
         int *t_dev = tri_id ? static_cast<int *>(ctx_mapped(ctx, tri_id, bt)) : nullptr, *v_dev = vid ? static_cast<int *>(ctx_mapped(ctx, vid, bv)) : nullptr;
         double *w_dev = w ? static_cast<double *>(ctx_mapped(ctx, w, bw)) : nullptr;
         if (ctx->q_timing) MSM_HIP(hipEventRecord(ctx->q_ev0, ctx->stream));
-        st = launch_query(ctx, dev_tree(target), sq_dev, N, t_dev, v_dev, w_dev, mode);
+        int *d_open = nullptr;  // a target with a direction table (a cost function's target, msm_mesh_prepare_search) and enough queries to pay for two launches
+        if (target->rays_valid && N >= kRayQueryMin) MSM_HIP(ctx_scratch(ctx, 4, sizeof(int) * ((size_t)N + 1), (void **)&d_open));
+        st = launch_query_rays(ctx, dev_tree(target), sq_dev, N, t_dev, v_dev, w_dev, mode, d_open);
         if (st) return st;
         if (ctx->q_timing) {
             MSM_HIP(hipEventRecord(ctx->q_ev1, ctx->stream));
@@ -545,7 +548,9 @@ int query_host(msm_mesh *target, const double *q, int N, int *tri_id, int *vid, 
     if (vid) MSM_HIP(ctx_scratch(ctx, 2, bv, (void **)&dv));
     if (w) MSM_HIP(ctx_scratch(ctx, 3, bw, (void **)&dw));
     if (ctx->q_timing) MSM_HIP(hipEventRecord(ctx->q_ev0, ctx->stream));
-    st = launch_query(ctx, dev_tree(target), dq, N, dt, dv, dw, mode);
+    int *d_open = nullptr;
+    if (target->rays_valid && N >= kRayQueryMin) MSM_HIP(ctx_scratch(ctx, 4, sizeof(int) * ((size_t)N + 1), (void **)&d_open));
+    st = launch_query_rays(ctx, dev_tree(target), dq, N, dt, dv, dw, mode, d_open);
     if (st) return st;
     if (ctx->q_timing) {
         MSM_HIP(hipEventRecord(ctx->q_ev1, ctx->stream));

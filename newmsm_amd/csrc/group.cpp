@@ -94,7 +94,7 @@ struct msm_group {
     // the per-label remainder of a subject's set-up with the label as the second grid dimension of every launch (stage_batch)
     struct Batch {
         msm_ctx *ctx = nullptr;  // a stream of its own: runs beside the main stream's preparation of the next subject
-        DevBuf<int> fvid, rvid, roff, rfill, rkey, coff, cfill, ckey, row_ptr, col, tkey, scan_tmp, long_flag;
+        DevBuf<int> fvid, rvid, roff, rfill, rkey, coff, cfill, ckey, row_ptr, col, tkey, scan_tmp, long_flag, open;
         DevBuf<double> fw, rw, oldA, newA, ta, rwt, cval, correction, val, tval;
         DevBuf<int2> info[2];
     };
@@ -565,6 +565,33 @@ int group_common_setup(msm_group *g) {
     // control grids share their triangle list, so their search trees are built together as a forest and one kernel writes the
     // whole list (N S (S - 1) / 2 pairs: 5.2 M at S = 64) where the cost kernels read it.  Round 1 / the first half of round 2:
     // S - 1 search calls with host trees and host loops, 67 ms at S = 64 on every rank.
+    // get_spacings :123-139 and get_rotations :77-86 on the host (their asin / acos decide patch membership to the last bit, so they use the host's libm as
+    // the reference does), subjects spread over the host threads -- started here, beside the GPU's estimate_pairs below (round 5: they used to follow it,
+    // 2 ms that every rank of a sharded run repeats)
+    g->rot.resize(9 * (size_t)S * N);
+    g->moved.clear();
+    g->moved_on_host = false;
+    std::vector<double> cp_all(3 * (size_t)S * N), orig_all(3 * (size_t)S * N, 0.0), spacing_all((size_t)S * N);
+    std::vector<int> sub_status(S, MSM_OK);
+    std::thread host_side([&] {
+        parallel_for(S, host_workers(), [&](int s) {
+            msm_mesh *cm = g->cpmesh[s];
+            g->spacing[s].resize(N);
+            double mvd;
+            int st = msm_cp_spacings(cm->xyz.data(), cm->tri.data(), N, g->Tc, g->spacing[s].data(), &mvd);
+            if (!st) st = msm_cp_rotations(centre, cm->xyz.data(), N, &g->rot[9 * (size_t)s * N]);
+            sub_status[s] = st;
+            std::copy(g->spacing[s].begin(), g->spacing[s].end(), spacing_all.begin() + (size_t)s * N);
+            std::copy(cm->xyz.begin(), cm->xyz.end(), cp_all.begin() + 3 * (size_t)s * N);
+            if (g->have_orig[s]) std::copy(g->orig[s].begin(), g->orig[s].end(), orig_all.begin() + 3 * (size_t)s * N);
+        });
+    });
+    struct Joiner {  // every return below leaves with the thread joined
+        std::thread &t;
+        ~Joiner() {
+            if (t.joinable()) t.join();
+        }
+    } joiner{host_side};
     g->npairs = (int64_t)N * S * (S - 1) / 2;
     g->pairs.clear();
     std::vector<double> cp_soa(3 * (size_t)S * N);
@@ -687,26 +714,9 @@ int group_common_setup(msm_group *g) {
         }
     }
     lap("pair order");
-    // get_spacings :123-139 and get_rotations :77-86 on the host (their asin / acos decide patch membership to the last bit, so
-    // they use the host's libm as the reference does), subjects spread over the host threads; ROT * label for every (node, label)
-    // -- 3.1 M products at S = 64, 75 MB -- on the device from the uploaded rotations (multiplications and additions only, in
-    // the host's order: the same bits)
-    g->rot.resize(9 * (size_t)S * N);
-    g->moved.clear();
-    g->moved_on_host = false;
-    std::vector<double> cp_all(3 * (size_t)S * N), orig_all(3 * (size_t)S * N, 0.0), spacing_all((size_t)S * N);
-    std::vector<int> sub_status(S, MSM_OK);
-    parallel_for(S, host_workers(), [&](int s) {
-        msm_mesh *cm = g->cpmesh[s];
-        g->spacing[s].resize(N);
-        double mvd;
-        int st = msm_cp_spacings(cm->xyz.data(), cm->tri.data(), N, g->Tc, g->spacing[s].data(), &mvd);
-        if (!st) st = msm_cp_rotations(centre, cm->xyz.data(), N, &g->rot[9 * (size_t)s * N]);
-        sub_status[s] = st;
-        std::copy(g->spacing[s].begin(), g->spacing[s].end(), spacing_all.begin() + (size_t)s * N);
-        std::copy(cm->xyz.begin(), cm->xyz.end(), cp_all.begin() + 3 * (size_t)s * N);
-        if (g->have_orig[s]) std::copy(g->orig[s].begin(), g->orig[s].end(), orig_all.begin() + 3 * (size_t)s * N);
-    });
+    // ROT * label for every (node, label) -- 3.1 M products at S = 64, 75 MB -- on the device from the uploaded rotations (multiplications and additions
+    // only, in the host's order: the same bits)
+    host_side.join();
     for (int s = 0; s < S; ++s)
         if (sub_status[s]) return fail(sub_status[s], "msm_group: spacings / rotations of subject %d's control grid failed", s);
     MSM_HIP(g->d_rot.ensure(g->rot.size()));
@@ -919,7 +929,8 @@ static int stage_batch(msm_group *g, int s, msm_group::Stage &b, int which, msm_
     // forward: the template's vertices in every label's tree; reverse: every label's vertices in the template's tree (:74-78)
     st = launch_query_forest(ctx, fd, L, tm->d_xyz, Vt, w.fvid.p, w.fw.p, LVt);
     if (st) return st;
-    st = launch_query(ctx, dev_tree(tm), b.d_rot.p, (int)LV, nullptr, w.rvid.p, w.rw.p, MSM_WEIGHTS_PROJECTED);
+    MSM_HIP(w.open.ensure(LV + 1));
+    st = launch_query_rays(ctx, dev_tree(tm), b.d_rot.p, (int)LV, nullptr, w.rvid.p, w.rw.p, MSM_WEIGHTS_PROJECTED, w.open.p);  // (the template's direction table: group_setup_pipeline)
     if (st) return st;
     st = launch_vertex_areas_batch(ctx, b.d_rot.p, LV, (size_t)V, V, dm->d_tri, T, dm->d_tid_ptr, dm->d_tid, L, w.ta.p, w.oldA.p);
     if (st) return st;
@@ -1072,6 +1083,10 @@ static int group_setup_pipeline(msm_group *g, const int32_t *subjects, int n) {
     msm_ctx *ctx = g->ctx;
     // the template's search structure and adjacency, and the data meshes' adjacency lists, are read by every pipeline: complete before they start
     int st = ensure_tree(g->tmpl);
+    if (st) return st;
+    // the template's direction table (a simple surface has one; built once per template content and kept, api.cpp: ensure_rays): the reverse queries of every
+    // subject and label run through it (stage_batch)
+    st = ensure_rays(g->tmpl, true);
     if (st) return st;
     st = ensure_adjacency_dev(g->tmpl);
     if (st) return st;

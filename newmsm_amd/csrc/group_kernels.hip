@@ -212,9 +212,17 @@ __global__ __launch_bounds__(256) void k_group_pairwise(GroupArgs a, const int *
     // read the same index of four lists, i.e. four addresses in one bank, at every step of the search)
     __shared__ int s_ids[kPerBlock][kGroupStage + 8];
     int *stage = s_ids[slot];
+    // Staged up to the next of 64 / 128 / 256 entries, the tail filled with INT_MAX: the fast path's search then walks a power of two with no bounds to check.
     const bool staged = cntB <= kGroupStage;
-    if (staged)
-        for (int i = lane; i < cntB; i += kLanes) stage[i] = ib[i];
+    const int padded = cntB <= 64 ? 64 : (cntB <= 128 ? 128 : 256);
+    if (staged) {
+#pragma unroll
+        for (int r = 0; r < 64 / kLanes; ++r) {  // (the first 64 without a loop: most patches end there or in the next 64)
+            const int i = lane + r * kLanes;
+            stage[i] = i < cntB ? ib[i] : 0x7fffffff;
+        }
+        for (int i = lane + 64; i < padded; i += kLanes) stage[i] = i < cntB ? ib[i] : 0x7fffffff;
+    }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     const int *fb = staged ? (const int *)stage : (const int *)ib;  // (generic: the general path below reads it either way)
@@ -238,26 +246,22 @@ __global__ __launch_bounds__(256) void k_group_pairwise(GroupArgs a, const int *
                 const int i = lane + r * kLanes;
                 id[r] = i < cntA ? ia[i] : -1;
             }
-            // lower_bound of every round's id in B, all rounds in lockstep (independent LDS reads per step instead of one
-            // dependent chain per round), rounds beyond the end of A skipped
+            // The last entry of B that is <= the round's id, all rounds in lockstep (independent LDS reads per step instead of one dependent chain per
+            // round): steps of padded / 2 ... 1 over the padded list, no bounds and no per-round branches (an unused round carries id -1 and stays at
+            // entry 0) -- round 5: the lower_bound it replaces cost two more look-ups per round and a scalar branch per round and step, a quarter of the
+            // kernel's vector and nearly all of its scalar instructions.  Membership is an equality either way: the same common set.
             int base[kRounds];
 #pragma unroll
             for (int r = 0; r < kRounds; ++r) base[r] = 0;
-            for (int n = cntB; n > 1;) {  // the same trip count for every lane of the half wavefront
-                const int half = n >> 1;
+            for (int step = padded >> 1; step > 0; step >>= 1) {  // the same trip count for the lanes of a query
 #pragma unroll
-                for (int r = 0; r < kRounds; ++r)
-                    if (r * kLanes < cntA) base[r] += stage[base[r] + half - 1] < id[r] ? half : 0;
-                n -= half;
-            }
-#pragma unroll
-            for (int r = 0; r < kRounds; ++r) {
-                mem[r] = false;
-                if (r * kLanes < cntA && cntB > 0 && id[r] >= 0) {
-                    const int pos = base[r] + (stage[base[r]] < id[r] ? 1 : 0);
-                    mem[r] = pos < cntB && stage[pos] == id[r];
+                for (int r = 0; r < kRounds; ++r) {
+                    const int t = base[r] + step;
+                    base[r] = stage[t] <= id[r] ? t : base[r];
                 }
             }
+#pragma unroll
+            for (int r = 0; r < kRounds; ++r) mem[r] = id[r] >= 0 && stage[base[r]] == id[r];
             // size of the intersection: the set bits of the rounds' ballots within this half wavefront
             int ncommon = 0;
             {

@@ -138,8 +138,8 @@ struct msm_ctx {
     int *d_status = nullptr;  // first error code raised by a kernel (atomicMin), 0 when clean
     int *h_status = nullptr;  // pinned
     // grow-only scratch of the host-array query entry points (hipMalloc / hipFree per call cost more than the queries)
-    void *q_buf[4] = {nullptr, nullptr, nullptr, nullptr};
-    size_t q_cap[4] = {0, 0, 0, 0};
+    void *q_buf[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // queries, triangle ids, vertex ids, weights, the list of queries the direction table left open
+    size_t q_cap[5] = {0, 0, 0, 0, 0};
     // pinned staging blocks of every host <-> device copy whose host side is not pinned memory of this library (stager.cpp): grow only, event fenced,
     // never moved; created and destroyed with the context
     msm::Stager *stager = nullptr;

@@ -3,6 +3,7 @@
 // All arithmetic that decides an index (which triangle, which patch) is FP64 in the reference's own
 // operation order (this file is compiled with -ffp-contract=off).  No MFMA: the path is gather /
 // compare / short reductions.  Wavefront = 64 lanes throughout.
+#include <cstring>
 #include <algorithm>
 
 #include "kernels.hpp"
@@ -681,6 +682,62 @@ static inline int grid_for(int n, int block, int cap) {
 // (4 per SIMD at the kernels' 124 registers: 32 768 queries) -- the launch is then one dependent chain, which eight lanes keep shortest
 // (2 562 queries: 7.4 us against 9.2 with four) --, four beyond that, where instruction issue counts as well (40 962 queries on an ico6
 // tree: 13.3 us against 17.2).  MSMHIP_QUERY_LANES=4|8 forces one.
+// The same queries against a target that has a direction table (a simple surface: every regular icosphere, a group's template): a lane per query looks its
+// direction's cell up, tests the (at most seven) candidate triangles' edge planes in float and, when the table vouches for the accepted one (ray_find: the
+// triangle the reference's search returns, provably), computes the weights from the triangle's record exactly as the searching lane of k_query does -- a
+// chain of two dependent loads instead of six.  What the table cannot settle (a point within the float test's allowance of an edge, a triangle with
+// exclusion boxes: a fraction of a percent) is listed and searched by k_query_open, eight lanes per query.  Same triangles, same weights, bit for bit
+// (tests/test_gpu_search.py: test_query_through_the_direction_table).  Used where one target serves very many queries: the reverse queries of gMSM's
+// get_patch_data (L x V rotated vertices against the template per subject, M/DiscreteGroupModel.cpp:105 -> R/resampler.cpp:77).
+__global__ __launch_bounds__(256) void k_query_rays(DevTree T, const double *__restrict__ q, int N, int *__restrict__ tri_id, int *__restrict__ vid,
+                                                     double *__restrict__ w, int mode, int *__restrict__ open_list, int *__restrict__ open_count) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const V3 p = mk(q[i], q[N + i], q[2 * (size_t)N + i]);
+    const int t = ray_find(T, p);
+    if (t < 0) {
+        open_list[atomicAdd(open_count, 1)] = i;
+        return;
+    }
+    const TriRec &r = T.rec[t];
+    V3 mp;
+    (void)inside_test(r, p, mp);  // the projection onto the triangle's plane (the table has vouched for the test's outcome)
+    QueryPayload out;
+    out.mode = mode;
+    out.compute(r, p, mp);
+    if (tri_id) tri_id[i] = t;
+    if (vid) vid[i] = out.id0, vid[N + i] = out.id1, vid[2 * (size_t)N + i] = out.id2;
+    if (w) w[i] = out.wa, w[N + i] = out.wb, w[2 * (size_t)N + i] = out.wc;
+}
+
+// the listed queries through the complete search (k_query's body at the listed indices; the list's order does not matter: a query's result is its own)
+template <int G>
+__global__ __launch_bounds__(256) void k_query_open(DevTree T, const double *__restrict__ q, int N, const int *__restrict__ open_list, const int *__restrict__ open_count,
+                                                     int *__restrict__ tri_id, int *__restrict__ vid, double *__restrict__ w, int mode, int *status) {
+    constexpr int per_block = 256 / G;
+    const int lane = threadIdx.x & 63, n = *open_count;
+    for (int base = blockIdx.x * per_block; base < n; base += gridDim.x * per_block) {  // block-uniform
+        const int j = base + threadIdx.x / G;
+        const bool valid = j < n;
+        const int i = valid ? open_list[j] : 0;
+        const V3 p = valid ? mk(q[i], q[N + i], q[2 * (size_t)N + i]) : mk(0.0, 0.0, 0.0);
+        QueryPayload out;
+        out.mode = mode;
+        bool owner;
+        const int t = group_search<G>(T, valid, p, lane, out, owner);
+        if (!owner) continue;
+        if (tri_id) tri_id[i] = t;
+        if (t < 0) {
+            raise_status(status, t);
+            if (vid) vid[i] = vid[N + i] = vid[2 * (size_t)N + i] = -1;
+            if (w) w[i] = w[N + i] = w[2 * (size_t)N + i] = 0.0;
+            continue;
+        }
+        if (vid) vid[i] = out.id0, vid[N + i] = out.id1, vid[2 * (size_t)N + i] = out.id2;
+        if (w) w[i] = out.wa, w[N + i] = out.wb, w[2 * (size_t)N + i] = out.wc;
+    }
+}
+
 int query_lanes(long long N) {
     static const int forced = [] {
         const char *e = std::getenv("MSMHIP_QUERY_LANES");
@@ -696,6 +753,18 @@ int launch_query(msm_ctx *ctx, const DevTree &T, const double *d_q, int N, int *
         hipLaunchKernelGGL(k_query<4>, dim3(grid_for(N, 64, 32768)), dim3(256), 0, ctx->stream, T, d_q, N, d_tri, d_vid, d_w, mode, ctx->d_status);
     else
         hipLaunchKernelGGL(k_query<8>, dim3(grid_for(N, 32, 32768)), dim3(256), 0, ctx->stream, T, d_q, N, d_tri, d_vid, d_w, mode, ctx->d_status);
+    MSM_HIP(hipGetLastError());
+    return MSM_OK;
+}
+
+// d_open: N + 1 ints of scratch (the list of unsettled queries and, at d_open[N], their count); a target without a table: the complete search
+int launch_query_rays(msm_ctx *ctx, const DevTree &T, const double *d_q, int N, int *d_tri, int *d_vid, double *d_w, int mode, int *d_open) {
+    if (N <= 0) return MSM_OK;
+    static const bool off = [] { const char *e = std::getenv("MSMHIP_QUERY_RAYS"); return e && std::strcmp(e, "off") == 0; }();
+    if (T.ray_G <= 0 || !d_open || off) return launch_query(ctx, T, d_q, N, d_tri, d_vid, d_w, mode);
+    MSM_HIP(hipMemsetAsync(d_open + N, 0, sizeof(int), ctx->stream));
+    hipLaunchKernelGGL(k_query_rays, dim3((N + 255) / 256), dim3(256), 0, ctx->stream, T, d_q, N, d_tri, d_vid, d_w, mode, d_open, d_open + N);
+    hipLaunchKernelGGL(k_query_open<8>, dim3(256), dim3(256), 0, ctx->stream, T, d_q, N, d_open, d_open + N, d_tri, d_vid, d_w, mode, ctx->d_status);
     MSM_HIP(hipGetLastError());
     return MSM_OK;
 }

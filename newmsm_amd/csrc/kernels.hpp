@@ -51,6 +51,8 @@ int launch_apply_rows(msm_ctx *ctx, int nNew, int nOld, int D, const int *row_pt
 // n doubles from device memory into mapped pinned host memory, and the context's status word into flags_mapped[0] when it is set
 int launch_copy_to_mapped(msm_ctx *ctx, const double *d_src, double *mapped_dst, size_t n, int *flags_mapped);
 int launch_query(msm_ctx *ctx, const DevTree &T, const double *d_q, int N, int *d_tri, int *d_vid, double *d_w, int mode);
+// the same through the target's direction table where it has one (kernels.hip: k_query_rays + k_query_open); d_open: N + 1 ints of scratch
+int launch_query_rays(msm_ctx *ctx, const DevTree &T, const double *d_q, int N, int *d_tri, int *d_vid, double *d_w, int mode, int *d_open);
 int launch_closest_vertex(msm_ctx *ctx, const DevTree &T, const double *d_q, int N, int *d_out);
 // sphere_project_warp / surface_resample on the device: out[i] = the weights of query i in its triangle applied to d_to (3 x V); d_out may be d_q
 int launch_warp(msm_ctx *ctx, const DevTree &T, const double *d_q, int N, const double *d_to, int V, bool to_sphere, double *d_out);

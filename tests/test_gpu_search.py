@@ -353,3 +353,27 @@ def test_forest_build_gives_every_tree_of_the_single_builds(ctx):
             m = M.Mesh(ctx, x, tri)
             want.append(m.octree_signature()[1])
         assert got == want
+
+
+@pytest.mark.parametrize("order,n", [(4, 6000), (6, 60000)])
+@pytest.mark.parametrize("mode", [M.WEIGHTS_PROJECTED, M.WEIGHTS_RAW])
+def test_query_through_the_direction_table(ctx, order, n, mode):
+    """A target with a direction table (msm_mesh_prepare_search; a cost function's target, a group's template) answers plain queries through it from 4 096
+    queries on (kernels.hip: k_query_rays, what the table cannot vouch for through k_query_open): the reference's triangles and weights bit for bit --
+    random points, points on and a hair off edges and vertices, points off the radius (outside the table's shell: the complete search)."""
+    xyz, tri = M.make_mesh_from_icosa(order)
+    rng = np.random.default_rng(order)
+    q = queries(xyz, n, seed=order + 20)
+    edge = 0.5 * (xyz[tri[:2000, 0]] + xyz[tri[:2000, 1]])
+    edge = edge * (100.0 / np.linalg.norm(edge, axis=1, keepdims=True))
+    q[:2000] = edge + rng.normal(scale=1e-9, size=edge.shape)      # on the edges, to rounding
+    q[2000:3000] = xyz[:1000] + rng.normal(scale=1e-7, size=(1000, 3))  # at the vertices
+    q[3000:3200] *= 1.01                                            # off the radius
+    mesh = M.Mesh(ctx, xyz, tri)
+    plain = mesh.query_triangles(q, mode=mode)
+    mesh.prepare_search(wait=True)
+    table = mesh.query_triangles(q, mode=mode)
+    for a, b in zip(plain, table):
+        assert np.array_equal(a, b)
+    ost, ot, ovid, ow = O.Octree(O.Mesh(xyz, tri)).barycentric_weights(q, raw=(mode == M.WEIGHTS_RAW))
+    assert table[0] == 0 and np.array_equal(table[1], ot) and np.array_equal(table[2], ovid) and np.array_equal(table[3], ow)
