@@ -48,7 +48,7 @@ def algorithmic_bytes(samples, evals, D):
 
 
 DOMINANT_KERNEL = "msm::k_unary_rays"  # the sampling kernel of a simple-surface target (newmsm_amd/csrc/unary_kernels.hip)
-PMC_PROFILE = os.path.join("profiles", "r4_z_unary_pmc.json")  # tools/collect_profile.sh r4_z on this workload (stamped with a hash of the kernel sources)
+PMC_PROFILE = os.path.join("profiles", "r5_z_unary_pmc.json")  # tools/collect_profile.sh r5_z on this workload (stamped with a hash of the kernel sources)
 
 
 def kernel_algorithmic_bytes(samples, evals, D):
@@ -438,7 +438,7 @@ GMSM_LEVELS = [(4, 2), (5, 3), (6, 4)]  # --datagrid / --CPgrid of the gMSM conf
 GMSM_ITERATIONS = 9                      # --it=9,9,9
 
 
-GMSM_PMC_PROFILE = os.path.join("profiles", "r4_gstep_pmc.json")
+GMSM_PMC_PROFILE = os.path.join("profiles", "r5_gstep_pmc.json")
 FP64_VALU_PEAK = 1024 * 2.4e9 / 4  # wave-instructions/s: 256 CUs x 4 SIMDs, a 64-lane FP64 (or any full-rate VALU) instruction every 4 cycles at 2.4 GHz
                                    # (MI355X_MICROARCH.md: 78.6 TFLOP/s FP64 vector = this x 64 lanes x 2 flops)
 
@@ -923,7 +923,7 @@ def main():
                        "definition": "table kernels (incl. the rotation kernel) enqueued back to back, no copy of the table to the host, one synchronisation at the end"},
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": pmc_traffic(args), "traffic_source": PMC_PROFILE + " (rocprofv3 --pmc passes of tools/collect_profile.sh, round 4)",
+                "traffic": pmc_traffic(args), "traffic_source": PMC_PROFILE + " (rocprofv3 --pmc passes of tools/collect_profile.sh, round 5)",
                 "kernel": DOMINANT_KERNEL, "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": kbytes,
                 "binding": pmc_binding_limits(args, kernel_ms),
                 "note": "nominal: the level's working set (tens of MB) lives in L2 / Infinity Cache, counter traffic is far below the algorithmic bytes; "
