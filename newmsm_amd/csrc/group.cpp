@@ -64,6 +64,11 @@ struct msm_group {
     std::vector<std::unique_ptr<DevBuf<double>>> Fslab;  // per subject: its L resampled feature maps in one allocation (one hipMalloc instead of nineteen per subject
                                                          // and set-up, and large pages under the label steps' gathers)
     std::vector<std::unique_ptr<DevBuf<int32_t>>> pptr, pidx;  // per subject
+    // per subject: the D values of every patch entry beside its id (GroupArgs::pval; built by msm_group_finalize, 50 MB per subject at ico6 / ico4, D = 2)
+    std::vector<std::unique_ptr<DevBuf<double>>> pval;
+    DevBuf<double *> d_pvalp;
+    DevBuf<GroupPatchRef> d_patch_dir;  // GroupArgs::dir
+    bool pval_ready = false;
     std::vector<std::vector<int32_t>> h_pptr, h_pidx;
     // subjects imported in a batch from device memory keep their row offsets on the device only (fetched when msm_group_patch asks): what
     // msm_group_finalize needs of them -- index count, largest patch, patches of at most kPairSmallPatch entries -- comes from the check kernel
@@ -118,6 +123,8 @@ struct msm_group {
     DevBuf<double> d_move_out;           // msm_group_fusion_move: the step's 4 P + 8 T results before they go to the host
     std::vector<int32_t> pair_order;     // the pair list in processing order (control points along a space-filling curve)
     DevBuf<int> d_pair_order;            // ... restricted to the slice [order_p0, order_p1) last asked for
+    DevBuf<int4> d_pair_order4;          // the slice's positions with their pairs' nodes (GroupArgs::move_order4): rebuilt when the slice or the pair list changed
+    uint64_t pairs_gen = 0, order4_gen = ~0ull;  // pairs_gen: counts estimate_pairs runs (the list's second nodes move with the control grids)
     int64_t order_p0 = -1, order_p1 = -1;
     int order_S = 0, order_N = 0;        // the sizes pair_order was built for
     // msm_group_set_pair_layout: 0 = the reference's list order (subject A, control point, subject B); 1 = control point by control point along the
@@ -300,6 +307,8 @@ int group_args(msm_group *g, GroupArgs &a) {
     a.pptr = g->d_pptrp.p;
     a.pidx = g->d_pidxp.p;
     a.F = g->d_Fp.p;
+    a.pval = g->pval_ready ? const_cast<const double *const *>(g->d_pvalp.p) : nullptr;
+    a.dir = g->pval_ready ? g->d_patch_dir.p : nullptr;
     a.mask = g->mask.empty() ? nullptr : g->d_mask.p;
     a.moved = g->d_moved.p;
     a.cp = g->d_cp.p;
@@ -314,6 +323,7 @@ int group_args(msm_group *g, GroupArgs &a) {
     a.move_labeling = nullptr;
     a.move_label = a.move_offset = 0;
     a.move_order = nullptr;
+    a.move_order4 = nullptr;
     a.move_base = 0;
     a.move_combos = 0;
     a.move_prev = nullptr;
@@ -594,6 +604,7 @@ int group_common_setup(msm_group *g) {
     } joiner{host_side};
     g->npairs = (int64_t)N * S * (S - 1) / 2;
     g->pairs.clear();
+    ++g->pairs_gen;
     std::vector<double> cp_soa(3 * (size_t)S * N);
     for (int s = 0; s < S; ++s)
         for (int ax = 0; ax < 3; ++ax)
@@ -1570,6 +1581,34 @@ int msm_group_finalize(msm_group *g) {
     // instead of two (label step 12.5 -> 9.5 ms at ico6 / ico4, patches of ~65 entries); the others take the general path, at half the lanes
     g->pair_lanes = (npatch > 0 && 10 * nsmall >= 9 * npatch) ? 16 : 32;
     if (const char *e = std::getenv("MSMHIP_GROUP_PAIR_LANES")) g->pair_lanes = std::atoi(e) == 16 ? 16 : 32;
+    // The patch entries' values beside their ids (GroupArgs::pval), for the register path of k_group_pairwise (D <= 2): one launch over all subjects, whether
+    // they were set up here or imported -- 3.2 GB written at S = 64, ico6 / ico4 (0.5 ms), and the label steps' value gathers by vertex id become a coalesced
+    // read of patch A and reads of one 1 KB window of patch B.  MSMHIP_GROUP_PVAL=off: the maps are gathered from, as until round 5.
+    static const bool pval_off = [] { const char *e = std::getenv("MSMHIP_GROUP_PVAL"); return e && std::strcmp(e, "off") == 0; }();
+    g->pval_ready = false;
+    if (!pval_off && g->D <= 2) {
+        g->pval.resize(S);
+        std::vector<double *> pv(S);
+        for (int s = 0; s < S; ++s) {
+            const size_t n = g->h_pptr[s].empty() ? (size_t)g->imp_stat[s].npidx : (size_t)g->h_pptr[s].back();
+            if (!g->pval[s]) g->pval[s].reset(new DevBuf<double>());
+            MSM_HIP(g->pval[s]->ensure(std::max<size_t>((size_t)g->D * n, 2)));
+            pv[s] = g->pval[s]->p;
+        }
+        MSM_TRY(g->d_pvalp.upload(pv.data(), pv.size(), ctx));
+        g->ready = true;  // (group_args checks it)
+        GroupArgs a;
+        int st = group_args(g, a);
+        if (!st) st = launch_group_patch_values(ctx, a, g->d_pvalp.p);
+        if (!st && g->d_patch_dir.ensure((size_t)S * g->N * L) != hipSuccess) st = fail(MSM_ERR_HIP, "device allocation of the patch directory failed");
+        if (!st) st = launch_group_patch_dir(ctx, a, g->d_pvalp.p, g->d_patch_dir.p);
+        if (!st) st = ctx_sync(ctx);
+        if (st) {
+            g->ready = false;
+            return st;
+        }
+        g->pval_ready = true;
+    }
     if (std::getenv("MSMHIP_TIMING"))
         fprintf(stderr, "  group patches: %lld, %.1f %% of them with at most %d entries, largest %d -> %d lanes per pair cost\n", (long long)npatch,
                 npatch ? 100.0 * (double)nsmall / (double)npatch : 0.0, kPairSmallPatch, g->patch_max, g->pair_lanes);
@@ -1722,6 +1761,13 @@ static int slice_pair_order(msm_group *g, int64_t pair0, int64_t pair1, const in
         }
         MSM_TRY(ctx_sync(ctx));
         g->order_p0 = pair0, g->order_p1 = pair1;
+        g->order4_gen = ~0ull;
+    }
+    if (g->order4_gen != g->pairs_gen) {  // the positions with their pairs' nodes, for this slice and this set-up's pair list
+        const int64_t n = pair1 - pair0;
+        MSM_HIP(g->d_pair_order4.ensure(std::max<size_t>((size_t)n, 1)));
+        MSM_TRY(launch_group_expand_order(g->ctx, g->d_pair_order.p, g->d_pairs.p, (int)n, g->d_pair_order4.p));
+        g->order4_gen = g->pairs_gen;
     }
     *d_order = g->d_pair_order.p;
     return MSM_OK;
@@ -1779,6 +1825,7 @@ static int group_move_compute_untimed(msm_group *g, const int32_t *labeling, int
     if (pair1 > pair0) {
         st = slice_pair_order(g, pair0, pair1, &a.move_order);
         if (st) return st;
+        a.move_order4 = g->d_pair_order4.p;
         a.move_base = (int)pair0;
         // The (current, current) combination of a pair does not depend on the proposed label: it is evaluated in a pass of its own
         // (whole wavefronts of pairs whose two nodes kept their labels since the last step leave at once with the kept cost), the

@@ -92,6 +92,7 @@ constexpr int kGroupStage = 256;  // ids of patch B staged in LDS per wavefront
 // a pointer the compiler knows to point into device memory (address space 1)
 template <class T>
 using GlobalPtr = const T __attribute__((address_space(1))) *;
+typedef double Dbl2 __attribute__((ext_vector_type(2)));  // (a builtin vector: loadable through an address-space pointer, which HIP's double2 class is not)
 template <class T>
 __device__ __forceinline__ GlobalPtr<T> as_global(const T *p) {
     return (GlobalPtr<T>)p;
@@ -171,16 +172,23 @@ __global__ __launch_bounds__(256) void k_group_pairwise(GroupArgs a, const int *
     const int slot = threadIdx.x / kLanes, q = blk * kPerBlock + slot, lane = threadIdx.x & (kLanes - 1);
     if (q >= n) return;
     extern __shared__ double s_common[];
-    int pair, la, lb;
+    int pair, la, lb, ga_known = -1, gb_known = -1;
     size_t at = (size_t)q;
     double *keep = nullptr;  // where this query's cost is kept for the next label step
     if (a.move_labeling) {  // Fusion's pair_data[pair].buffer[k], I/Fusion/Fusion.h:170-173: k = 2 * (A takes the label) + (B takes it)
         const int e = q + a.move_offset;
         const int idx = a.move_combos == 0 ? e >> 2 : (a.move_combos == 1 ? e : (a.move_combos == 2 ? e / 3 : e >> 1));
         const int k = a.move_combos == 0 ? (e & 3) : (a.move_combos == 1 ? 0 : (a.move_combos == 2 ? 1 + (e - 3 * idx) : 1 + (e & 1)));
-        pair = a.move_order ? a.move_order[idx] : idx;
+        int nodeA, nodeB;
+        if (a.move_order4) {  // (round 5: one 16-byte load for the position's pair and its nodes)
+            const int4 o = a.move_order4[idx];
+            pair = o.x, nodeA = o.y, nodeB = o.z;
+        } else {
+            pair = a.move_order ? a.move_order[idx] : idx;
+            nodeA = a.pairs[2 * pair], nodeB = a.pairs[2 * pair + 1];
+        }
         if (a.move_order) at = 4 * (size_t)(pair - a.move_base) + k;
-        const int nodeA = a.pairs[2 * pair], nodeB = a.pairs[2 * pair + 1];
+        ga_known = nodeA, gb_known = nodeB;
         const int curA = a.move_labeling[nodeA], curB = a.move_labeling[nodeB];
         if (k == 0 && a.move_e00) {
             if (a.move_prev && a.move_prev[nodeA] == curA && a.move_prev[nodeB] == curB) {  // same patches as in the previous step
@@ -195,15 +203,27 @@ __global__ __launch_bounds__(256) void k_group_pairwise(GroupArgs a, const int *
     } else {
         pair = qp[q], la = qa[q], lb = qb[q];
     }
-    const int ga = a.pairs[2 * pair], gb = a.pairs[2 * pair + 1];
+    const int ga = ga_known >= 0 ? ga_known : a.pairs[2 * pair], gb = gb_known >= 0 ? gb_known : a.pairs[2 * pair + 1];
     const int sa = ga / a.N, sb = gb / a.N, na = ga - sa * a.N, nb = gb - sb * a.N;
     // The per-subject arrays are reached through pointer tables in device memory.  A pointer LOADED from memory is a generic one to the compiler, and every
     // access through it a FLAT instruction (the vector-memory path plus the LDS path's wait counter: the 20 feature gathers and 10 list loads of a query);
     // they are device memory, and say so (round 5: global_load instead of flat_load).
-    const GlobalPtr<int> pa = as_global(a.pptr[sa]), pb = as_global(a.pptr[sb]);
-    const int ba = pa[na * a.L + la], ea = pa[na * a.L + la + 1], bb = pb[nb * a.L + lb], eb = pb[nb * a.L + lb + 1];
-    const GlobalPtr<int> ia = as_global(a.pidx[sa]) + ba, ib = as_global(a.pidx[sb]) + bb;
-    const int cntA = ea - ba, cntB = eb - bb;
+    // Round 5: with the patch directory (GroupArgs::dir, built with the value copies) one 32-byte record per side says where the patch's ids and values lie and
+    // how long it is -- the pointer tables and the row offsets were two more dependent round trips in front of every query's data.
+    int ba, bb, cntA, cntB;
+    GlobalPtr<int> ia, ib;
+    GlobalPtr<double> dirA = nullptr, dirB = nullptr;
+    if (a.dir) {
+        const GroupPatchRef ra = a.dir[(size_t)ga * a.L + la], rb = a.dir[(size_t)gb * a.L + lb];
+        ia = as_global(ra.ids), ib = as_global(rb.ids);
+        dirA = as_global(ra.vals), dirB = as_global(rb.vals);
+        ba = ra.begin, bb = rb.begin, cntA = ra.count, cntB = rb.count;
+    } else {
+        const GlobalPtr<int> pa = as_global(a.pptr[sa]), pb = as_global(a.pptr[sb]);
+        ba = pa[na * a.L + la], bb = pb[nb * a.L + lb];
+        cntA = pa[na * a.L + la + 1] - ba, cntB = pb[nb * a.L + lb + 1] - bb;
+        ia = as_global(a.pidx[sa]) + ba, ib = as_global(a.pidx[sb]) + bb;
+    }
     const GlobalPtr<double> FA = as_global(a.F[(size_t)sa * a.L + la]), FB = as_global(a.F[(size_t)sb * a.L + lb]);
     const double nan = __longlong_as_double(0x7ff8000000000000ll);
     // B's ids go to LDS first when they fit (patches hold ~65 entries at ico6 / ico4): the binary search below is a chain
@@ -215,11 +235,47 @@ __global__ __launch_bounds__(256) void k_group_pairwise(GroupArgs a, const int *
     // Staged up to the next of 64 / 128 / 256 entries, the tail filled with INT_MAX: the fast path's search then walks a power of two with no bounds to check.
     const bool staged = cntB <= kGroupStage;
     const int padded = cntB <= 64 ? 64 : (cntB <= 128 ? 128 : 256);
-    if (staged) {
+    // The usual case -- patches of up to 5 (4) entries per lane, one or two feature rows, correlation or SSD -- keeps everything in registers (below).  Its
+    // loads are requested HERE, all at once and unconditionally (indices clamped into the patch instead of branched around): patch A's ids, patch A's
+    // values from the entry-major copy beside them (GroupArgs::pval) and the first 64 ids of patch B.  Round 5: B's ids used to be fetched and written to
+    // LDS one round after the other (load, wait, write, four times), and A's ids only after that -- five dependent memory phases in front of the search
+    // where one does; A's values were ten gathers by vertex id behind the search.
+    constexpr int kRounds = kLanes == 16 ? kPairSmallPatch / 16 : 4;  // entries per lane kept in registers: patches of up to 80 / 128 entries (6 and 8
+                                                                      // rounds of sixteen lanes: 89 / 109 registers, 10.2 / 12.1 ms per label step against 9.5)
+    constexpr int kQ = kLanes == 64 ? 32 : kLanes;                    // (the fast path is compiled for 32 and 16 lanes per query)
+    const bool fast = !kDice && staged && cntA <= kRounds * kLanes && a.D <= 2 && a.simmeasure != 4 && a.simmeasure != 5;
+    const bool compact = fast && a.pval != nullptr;
+    const GlobalPtr<double> PA = !compact ? GlobalPtr<double>(nullptr) : (a.dir ? dirA : as_global(a.pval[sa]) + (size_t)a.D * ba);
+    const GlobalPtr<double> PB = !compact ? GlobalPtr<double>(nullptr) : (a.dir ? dirB : as_global(a.pval[sb]) + (size_t)a.D * bb);
+    int id[kRounds];
+    double pa_[kRounds][2];
+    if (fast) {
+        const int lastA = max(cntA, 1) - 1;
 #pragma unroll
-        for (int r = 0; r < 64 / kLanes; ++r) {  // (the first 64 without a loop: most patches end there or in the next 64)
+        for (int r = 0; r < kRounds; ++r) {
+            const int i = lane + r * kLanes, ic = min(i, lastA);
+            const int v = ia[ic];
+            id[r] = i < cntA ? v : -1;
+            pa_[r][0] = pa_[r][1] = 0.0;
+            if (compact) {
+                if (a.D == 2) {
+                    const Dbl2 pv = *reinterpret_cast<const __attribute__((address_space(1))) Dbl2 *>(PA + 2 * (size_t)ic);
+                    pa_[r][0] = pv.x, pa_[r][1] = pv.y;
+                } else {
+                    pa_[r][0] = PA[ic];
+                }
+            }
+        }
+    }
+    if (staged) {
+        const int lastB = max(cntB, 1) - 1;
+        int bid[64 / kLanes];
+#pragma unroll
+        for (int r = 0; r < 64 / kLanes; ++r) bid[r] = ib[min(lane + r * kLanes, lastB)];  // (the first 64 without a loop: most patches end there or in the next 64)
+#pragma unroll
+        for (int r = 0; r < 64 / kLanes; ++r) {
             const int i = lane + r * kLanes;
-            stage[i] = i < cntB ? ib[i] : 0x7fffffff;
+            stage[i] = i < cntB ? bid[r] : 0x7fffffff;
         }
         for (int i = lane + 64; i < padded; i += kLanes) stage[i] = i < cntB ? ib[i] : 0x7fffffff;
     }
@@ -227,25 +283,13 @@ __global__ __launch_bounds__(256) void k_group_pairwise(GroupArgs a, const int *
     __builtin_amdgcn_wave_barrier();
     const int *fb = staged ? (const int *)stage : (const int *)ib;  // (generic: the general path below reads it either way)
     if constexpr (!kDice) {
-        // The usual case -- patches of up to 4 entries per lane, one or two feature rows -- keeps everything in registers: ids
-        // loaded once, all gathers of both passes and both rows issued together.  The general code below reads ids and values
-        // again in every pass of every row: thirteen dependent round trips to memory per query against five here, and this
-        // kernel is bound by exactly that latency (64 % of its wave cycles were waits; its L2 misses did not matter: changing
-        // the order of the pairs to cut them left the time unchanged).  Same per-lane accumulation order, same shuffles: the
-        // results are bit-identical to the general code's.
-        constexpr int kRounds = kLanes == 16 ? kPairSmallPatch / 16 : 4;  // entries per lane kept in registers: patches of up to 80 / 128 entries (6 and 8
-                                                                          // rounds of sixteen lanes: 89 / 109 registers, 10.2 / 12.1 ms per label step against 9.5)
-        constexpr int kQ = kLanes == 64 ? 32 : kLanes;  // (the fast path is compiled for 32 and 16 lanes per query)
-        // (staged: B's ids are read through `stage`, a pointer the compiler knows to be LDS -- through `fb`, which may point either way, every step of
-        // the search was a FLAT load: the vector-memory path's issue rate and both wait counters for what is a 4-byte LDS read; round 5)
-        if (staged && cntA <= kRounds * kLanes && a.D <= 2 && a.simmeasure != 4 && a.simmeasure != 5) {
-            int id[kRounds];
+        // Everything of a query in registers: ids loaded once, the values of both rows for both passes at hand.  The general code below reads ids and values
+        // again in every pass of every row: thirteen dependent round trips to memory per query, and this kernel is bound by exactly that latency (64 % of its
+        // wave cycles were waits; its L2 misses did not matter).  Same per-lane accumulation order, same shuffles: the results are bit-identical to the
+        // general code's.  B's ids are read through `stage`, a pointer the compiler knows to be LDS (through `fb`, which may point either way, every step
+        // of the search was a FLAT load).
+        if (fast) {
             bool mem[kRounds];
-#pragma unroll
-            for (int r = 0; r < kRounds; ++r) {
-                const int i = lane + r * kLanes;
-                id[r] = i < cntA ? ia[i] : -1;
-            }
             // The last entry of B that is <= the round's id, all rounds in lockstep (independent LDS reads per step instead of one dependent chain per
             // round): steps of padded / 2 ... 1 over the padded list, no bounds and no per-round branches (an unused round carries id -1 and stays at
             // entry 0) -- round 5: the lower_bound it replaces cost two more look-ups per round and a scalar branch per round and step, a quarter of the
@@ -277,12 +321,23 @@ __global__ __launch_bounds__(256) void k_group_pairwise(GroupArgs a, const int *
 #pragma unroll
                 for (int r = 0; r < kRounds; ++r) {
                     w[r] = mem[r] ? 1.0 : 0.0;  // an entry outside the intersection takes part with weight 0 and values 0: sums unchanged, no branches
+                    va[r][0] = va[r][1] = vb[r][0] = vb[r][1] = 0.0;
+                    if (mem[r]) {
+                        if (compact) {  // A's values are in registers; B's at the position the search ended on (one 16-byte load for two rows)
+                            va[r][0] = pa_[r][0], va[r][1] = pa_[r][1];
+                            if (a.D == 2) {
+                                const Dbl2 v = *reinterpret_cast<const __attribute__((address_space(1))) Dbl2 *>(PB + 2 * (size_t)base[r]);
+                                vb[r][0] = v.x, vb[r][1] = v.y;
+                            } else {
+                                vb[r][0] = PB[base[r]];
+                            }
+                        } else {
 #pragma unroll
-                    for (int d = 0; d < 2; ++d) {
-                        va[r][d] = vb[r][d] = 0.0;
-                        if (mem[r] && d < a.D) {
-                            va[r][d] = FA[(size_t)d * a.Vt + id[r]];
-                            vb[r][d] = FB[(size_t)d * a.Vt + id[r]];
+                            for (int d = 0; d < 2; ++d)
+                                if (d < a.D) {
+                                    va[r][d] = FA[(size_t)d * a.Vt + id[r]];
+                                    vb[r][d] = FB[(size_t)d * a.Vt + id[r]];
+                                }
                         }
                     }
                     if (mem[r] && a.mask) w[r] = fabs(a.mask[id[r]]);
@@ -663,6 +718,66 @@ __global__ __launch_bounds__(256) void k_group_kept(const int *__restrict__ orde
     if (i >= n) return;
     const int at = order[i] - base;
     out[4 * (size_t)at + 3] = kept[at];
+}
+
+// The values of every patch entry beside its id (GroupArgs::pval): a wavefront per (control point, label) row of a subject, blockIdx.y = subject
+__global__ __launch_bounds__(256) void k_group_patch_values(GroupArgs a, double *const *__restrict__ pval) {
+    const int s = blockIdx.y, rows = a.N * a.L;
+    const GlobalPtr<int> pp = as_global(a.pptr[s]), pi = as_global(a.pidx[s]);
+    double *__restrict__ out = pval[s];
+    const int lane = threadIdx.x & 63;
+    for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += gridDim.x * 4) {
+        const int beg = pp[row], end = pp[row + 1], l = row % a.L;
+        const GlobalPtr<double> F = as_global(a.F[(size_t)s * a.L + l]);
+        for (int e = beg + lane; e < end; e += 64) {
+            const int id = pi[e];
+            for (int d = 0; d < a.D; ++d) out[(size_t)a.D * e + d] = F[(size_t)d * a.Vt + id];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_group_patch_dir(GroupArgs a, double *const *__restrict__ pval, GroupPatchRef *__restrict__ dir) {
+    const size_t rows = (size_t)a.N * a.L, i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * a.S) return;
+    const int s = (int)(i / rows), row = (int)(i - (size_t)s * rows);
+    const int beg = a.pptr[s][row], end = a.pptr[s][row + 1];
+    GroupPatchRef r;
+    r.ids = a.pidx[s] + beg;
+    r.vals = pval ? pval[s] + (size_t)a.D * beg : nullptr;
+    r.begin = beg, r.count = end - beg;
+    r.pad[0] = r.pad[1] = 0;
+    dir[i] = r;
+}
+
+int launch_group_patch_dir(msm_ctx *ctx, const GroupArgs &a, double *const *pval, GroupPatchRef *dir) {
+    const size_t n = (size_t)a.S * a.N * a.L;
+    if (n == 0) return MSM_OK;
+    hipLaunchKernelGGL(k_group_patch_dir, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, a, pval, dir);
+    MSM_HIP(hipGetLastError());
+    return MSM_OK;
+}
+
+__global__ __launch_bounds__(256) void k_group_expand_order(const int *__restrict__ order, const int2 *__restrict__ pairs, int n, int4 *__restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int p = order[i];
+    const int2 ab = pairs[p];
+    out[i] = make_int4(p, ab.x, ab.y, 0);
+}
+
+int launch_group_expand_order(msm_ctx *ctx, const int *order, const int *pairs, int n, int4 *out) {
+    if (n <= 0) return MSM_OK;
+    hipLaunchKernelGGL(k_group_expand_order, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, order, reinterpret_cast<const int2 *>(pairs), n, out);
+    MSM_HIP(hipGetLastError());
+    return MSM_OK;
+}
+
+int launch_group_patch_values(msm_ctx *ctx, const GroupArgs &a, double *const *pval) {
+    const int rows = a.N * a.L;
+    if (rows <= 0 || a.S <= 0) return MSM_OK;
+    hipLaunchKernelGGL(k_group_patch_values, dim3((unsigned)std::min((rows + 3) / 4, 4096), (unsigned)a.S), dim3(256), 0, ctx->stream, a, pval);
+    MSM_HIP(hipGetLastError());
+    return MSM_OK;
 }
 
 int launch_group_kept(msm_ctx *ctx, const int *order, int base, const double *kept, int n, double *out) {

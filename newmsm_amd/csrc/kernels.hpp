@@ -219,6 +219,15 @@ int launch_triplet_table(msm_ctx *ctx, const CliqueArgs &a, int t0, int t1, doub
 
 
 // groupwise (gMSM)
+// one patch (subject, control point, label) as the pair kernel wants it: where its ids and values lie, its position in the subject's lists, its length --
+// one 32-byte record instead of four dependent look-ups (pointer tables, row offsets) per side of a query
+struct alignas(32) GroupPatchRef {
+    const int *ids;
+    const double *vals;  // entry-major values (GroupArgs::pval), or nullptr
+    int begin, count;
+    int pad[2];
+};
+
 struct GroupArgs {
     int S, N, L, D, Tc, Vt;
     int simmeasure, fixnan;
@@ -227,6 +236,11 @@ struct GroupArgs {
     const int *const *pptr;      // per subject: CSR over (control point * L + label)
     const int *const *pidx;      // per subject: template vertex ids, ascending per patch
     const double *const *F;      // per (subject * L + label): D x Vt resampled features
+    // per subject (or nullptr): the D values of every patch entry, entry-major beside pidx -- pval[s][D * e + d] = F[s][label of e's patch][d][pidx[s][e]] --
+    // so that a pair cost reads patch A's values as it reads its ids (coalesced) and patch B's at the matched POSITIONS (one 1 KB window) instead of gathering
+    // both from the Vt-sized maps by vertex id (msm_group_finalize builds them: launch_group_patch_values)
+    const double *const *pval;
+    const GroupPatchRef *dir;    // per (global node * L + label), or nullptr (built with pval)
     const double *mask;          // Vt or nullptr
     const double *moved;         // (S * N) x L x 3: ROT * label
     const double *cp;            // S x (3 x N) current control grids
@@ -241,6 +255,7 @@ struct GroupArgs {
     // pair move_order[(move_offset + i) / 4] and writes out[4 * (pair - move_base) + combination] -- the results keep the list's
     // order, the work runs control-point tile by tile (group.cpp: pair_order)
     const int *move_order;
+    const int4 *move_order4;     // beside move_order (or nullptr): {pair, its two global nodes, 0} per position -- one load instead of order -> pair -> nodes
     int move_base;
     // which combinations of a pair a launch evaluates: 0 all four (query i -> pair i / 4, combination i % 4), 1 only (current,
     // current) (query i -> pair i), 2 the three with the proposed label (query i -> pair i / 3, combination 1 + i % 3).  The
@@ -264,6 +279,11 @@ int launch_rotate_to_label(msm_ctx *ctx, const double *d_xyz, int V, const doubl
 int launch_rotate_to_labels(msm_ctx *ctx, const double *d_xyz, int V, const double centre[3], const double *d_labels3, int L, const double *d_rot9, double *d_out,
                             size_t stride);
 int launch_group_pairwise(msm_ctx *ctx, const GroupArgs &a, const int *qp, const int *qa, const int *qb, int n, double *out);
+// pval[s][D * e + d] for every entry e of every patch of the S subjects (one launch; pval: device table of S device pointers, written through)
+int launch_group_patch_values(msm_ctx *ctx, const GroupArgs &a, double *const *pval);
+// out[i] = {order[i], pairs[2 * order[i]], pairs[2 * order[i] + 1], 0}
+int launch_group_expand_order(msm_ctx *ctx, const int *order, const int *pairs, int n, int4 *out);
+int launch_group_patch_dir(msm_ctx *ctx, const GroupArgs &a, double *const *pval, GroupPatchRef *dir);
 // out[4 * (pair - base) + 3] = kept[pair - base] for the n pairs order[0 .. n)
 int launch_group_kept(msm_ctx *ctx, const int *order, int base, const double *kept, int n, double *out);
 int launch_group_triplet(msm_ctx *ctx, const GroupArgs &a, const int *qt, const int *qa, const int *qb, const int *qc, int n, double *out);

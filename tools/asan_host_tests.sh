@@ -9,7 +9,7 @@ OUT=/tmp/msmhip_asan
 mkdir -p $OUT
 cd $ROOT/newmsm_amd/csrc
 make >/dev/null
-for f in pool.cpp host_mesh.cpp octree.cpp api.cpp cost.cpp cost_cliques.cpp group.cpp regtools.cpp; do
+for f in pool.cpp stager.cpp host_mesh.cpp octree.cpp api.cpp cost.cpp cost_cliques.cpp group.cpp regtools.cpp; do
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -x hip -O1 -g -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fsanitize=address -fno-omit-frame-pointer -c $f -o $OUT/${f%.cpp}.o
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -fsanitize=address -shared-libsan -o $OUT/libmsmhip.so $OUT/*.o kernels.o octree_kernels.o resample_kernels.o unary_kernels.o clique_kernels.o move_kernels.o group_kernels.o
