@@ -198,6 +198,17 @@ __global__ __launch_bounds__(256) void k_group_pairwise(GroupArgs a, const int *
             keep = a.move_e00 + pair;
         }
         if (k == 3 && a.move_e11) keep = a.move_e11 + (pair - a.move_base);
+        // A combination whose proposed label IS the node's current one repeats (current, current): taken from the pass that has just evaluated or kept it
+        // (same kernel, same inputs: the same bits).  A nineteenth of the evaluations with uniformly random labels; most of them in a registration that is
+        // converging, where the proposed label is the current one of most nodes.
+        if (k != 0 && a.move_e00 && (a.move_combos == 2 || a.move_combos == 3) && (!(k & 2) || curA == a.move_label) && (!(k & 1) || curB == a.move_label)) {
+            if (lane == 0) {
+                const double c = a.move_e00[pair];
+                out[at] = c;
+                if (keep) *keep = c;
+            }
+            return;
+        }
         la = (k & 2) ? a.move_label : curA;
         lb = (k & 1) ? a.move_label : curB;
     } else {
