@@ -69,6 +69,12 @@ struct msm_group {
     DevBuf<double *> d_pvalp;
     DevBuf<GroupPatchRef> d_patch_dir;  // GroupArgs::dir
     bool pval_ready = false;
+    // A group with imported subjects (a rank of a sharded run) evaluates a SLICE of the pair list, which touches a fraction of the patches (an eighth of the
+    // control points with eight ranks): the value copies are then written for the nodes of the slice only, when the slice is first asked for
+    // (ensure_patch_values); pval_p0 / pval_p1: the slice they cover (the whole list after a set-up without imports)
+    bool pval_deferred = false;
+    int64_t pval_p0 = -1, pval_p1 = -1;
+    DevBuf<int> d_node_flags;
     std::vector<std::vector<int32_t>> h_pptr, h_pidx;
     // subjects imported in a batch from device memory keep their row offsets on the device only (fetched when msm_group_patch asks): what
     // msm_group_finalize needs of them -- index count, largest patch, patches of at most kPairSmallPatch entries -- comes from the check kernel
@@ -307,8 +313,9 @@ int group_args(msm_group *g, GroupArgs &a) {
     a.pptr = g->d_pptrp.p;
     a.pidx = g->d_pidxp.p;
     a.F = g->d_Fp.p;
-    a.pval = g->pval_ready ? const_cast<const double *const *>(g->d_pvalp.p) : nullptr;
-    a.dir = g->pval_ready ? g->d_patch_dir.p : nullptr;
+    const bool pval_all = g->pval_ready && g->pval_p0 == 0 && g->pval_p1 == g->npairs;  // (a slice's copies serve that slice's label steps only: group_move_compute)
+    a.pval = pval_all ? const_cast<const double *const *>(g->d_pvalp.p) : nullptr;
+    a.dir = pval_all ? g->d_patch_dir.p : nullptr;
     a.mask = g->mask.empty() ? nullptr : g->d_mask.p;
     a.moved = g->d_moved.p;
     a.cp = g->d_cp.p;
@@ -1372,7 +1379,7 @@ int msm_group_import_subject(msm_group *g, int32_t s, const double *F, const int
     MSM_TRY(g->pptr[s]->upload(g->h_pptr[s].data(), M + 1, ctx));
     MSM_TRY(g->pidx[s]->upload_vec(g->h_pidx[s], ctx));
     MSM_TRY(ctx_sync(ctx));
-    g->have_subject[s] = 1;
+    g->have_subject[s] = 2;  // (2: imported)
     return MSM_OK;
 }
 
@@ -1439,7 +1446,7 @@ int msm_group_import_subject_dev(msm_group *g, int32_t s, const double *F_dev, c
     MSM_TRY(stage_d2h(ctx, g->h_pptr[s].data(), pptr_dev, sizeof(int32_t) * (M + 1)));
     g->h_pidx[s].clear();        // fetched on demand by msm_group_patch
     MSM_TRY(ctx_sync(ctx));
-    g->have_subject[s] = 1;
+    g->have_subject[s] = 2;
     return MSM_OK;
 }
 
@@ -1538,9 +1545,40 @@ int msm_group_import_subjects_dev(msm_group *g, const int32_t *subjects, int32_t
         g->imp_stat[s].small = out[4 * (size_t)k + 2];
     }
     MSM_TRY(ctx_sync(ctx));  // the caller may reuse its buffers
-    for (int k = 0; k < n; ++k) g->have_subject[subjects[k]] = 1;
+    for (int k = 0; k < n; ++k) g->have_subject[subjects[k]] = 2;
     return MSM_OK;
 }
+
+}  // extern "C"
+
+namespace {
+// The patch entries' values beside their ids and the patch directory (GroupArgs::pval / dir) for the label steps of the pairs [pair0, pair1): the whole list
+// writes every patch (3.2 GB at S = 64, ico6 / ico4: 2.3 ms), a rank's slice only the patches of the nodes its pairs touch.
+int ensure_patch_values(msm_group *g, int64_t pair0, int64_t pair1) {
+    if (g->pval_ready && g->pval_p0 <= pair0 && g->pval_p1 >= pair1) return MSM_OK;
+    msm_ctx *ctx = g->ctx;
+    const bool ready_before = g->pval_ready;
+    g->pval_ready = false;
+    GroupArgs a;
+    int st = group_args(g, a);
+    if (st) return st;
+    const bool all = pair0 == 0 && pair1 == g->npairs;
+    if (!all) {
+        MSM_HIP(g->d_node_flags.zero((size_t)g->S * g->N, ctx->stream));
+        st = launch_group_mark_nodes(ctx, g->d_pairs.p, pair0, pair1, g->d_node_flags.p);
+        if (st) return st;
+    }
+    st = launch_group_patch_values(ctx, a, g->d_pvalp.p, all ? nullptr : g->d_node_flags.p);
+    if (!st && !ready_before) st = launch_group_patch_dir(ctx, a, g->d_pvalp.p, g->d_patch_dir.p);  // (every patch's record: it does not depend on the slice)
+    if (!st) st = ctx_sync(ctx);
+    if (st) return st;
+    g->pval_ready = true;
+    g->pval_p0 = pair0, g->pval_p1 = pair1;
+    return MSM_OK;
+}
+}  // namespace
+
+extern "C" {
 
 int msm_group_finalize(msm_group *g) {
     if (!g) return fail(MSM_ERR_INVALID, "null group");
@@ -1585,29 +1623,32 @@ int msm_group_finalize(msm_group *g) {
     // they were set up here or imported -- 3.2 GB written at S = 64, ico6 / ico4 (0.5 ms), and the label steps' value gathers by vertex id become a coalesced
     // read of patch A and reads of one 1 KB window of patch B.  MSMHIP_GROUP_PVAL=off: the maps are gathered from, as until round 5.
     static const bool pval_off = [] { const char *e = std::getenv("MSMHIP_GROUP_PVAL"); return e && std::strcmp(e, "off") == 0; }();
-    g->pval_ready = false;
+    g->pval_ready = g->pval_deferred = false;
+    g->pval_p0 = g->pval_p1 = -1;
     if (!pval_off && g->D <= 2) {
         g->pval.resize(S);
         std::vector<double *> pv(S);
+        bool imported = false;
         for (int s = 0; s < S; ++s) {
             const size_t n = g->h_pptr[s].empty() ? (size_t)g->imp_stat[s].npidx : (size_t)g->h_pptr[s].back();
             if (!g->pval[s]) g->pval[s].reset(new DevBuf<double>());
             MSM_HIP(g->pval[s]->ensure(std::max<size_t>((size_t)g->D * n, 2)));
             pv[s] = g->pval[s]->p;
+            imported = imported || g->have_subject[s] == 2;
         }
         MSM_TRY(g->d_pvalp.upload(pv.data(), pv.size(), ctx));
+        if (g->d_patch_dir.ensure((size_t)S * g->N * L) != hipSuccess) return fail(MSM_ERR_HIP, "device allocation of the patch directory failed");
         g->ready = true;  // (group_args checks it)
-        GroupArgs a;
-        int st = group_args(g, a);
-        if (!st) st = launch_group_patch_values(ctx, a, g->d_pvalp.p);
-        if (!st && g->d_patch_dir.ensure((size_t)S * g->N * L) != hipSuccess) st = fail(MSM_ERR_HIP, "device allocation of the patch directory failed");
-        if (!st) st = launch_group_patch_dir(ctx, a, g->d_pvalp.p, g->d_patch_dir.p);
-        if (!st) st = ctx_sync(ctx);
-        if (st) {
-            g->ready = false;
-            return st;
+        if (imported) {
+            g->pval_deferred = true;  // a rank of a sharded run: written for the nodes of its slice when the slice is first evaluated
+            MSM_TRY(ctx_sync(ctx));
+        } else {
+            const int st = ensure_patch_values(g, 0, g->npairs);
+            if (st) {
+                g->ready = false;
+                return st;
+            }
         }
-        g->pval_ready = true;
     }
     if (std::getenv("MSMHIP_TIMING"))
         fprintf(stderr, "  group patches: %lld, %.1f %% of them with at most %d entries, largest %d -> %d lanes per pair cost\n", (long long)npatch,
@@ -1826,6 +1867,12 @@ static int group_move_compute_untimed(msm_group *g, const int32_t *labeling, int
         st = slice_pair_order(g, pair0, pair1, &a.move_order);
         if (st) return st;
         a.move_order4 = g->d_pair_order4.p;
+        if (g->pval_deferred || g->pval_ready) {  // the value copies of this slice's patches (a rank of a sharded run builds them here, once per set-up and slice)
+            st = ensure_patch_values(g, pair0, pair1);
+            if (st) return st;
+            a.pval = const_cast<const double *const *>(g->d_pvalp.p);
+            a.dir = g->d_patch_dir.p;
+        }
         a.move_base = (int)pair0;
         // The (current, current) combination of a pair does not depend on the proposed label: it is evaluated in a pass of its own
         // (whole wavefronts of pairs whose two nodes kept their labels since the last step leave at once with the kept cost), the

@@ -732,12 +732,13 @@ __global__ __launch_bounds__(256) void k_group_kept(const int *__restrict__ orde
 }
 
 // The values of every patch entry beside its id (GroupArgs::pval): a wavefront per (control point, label) row of a subject, blockIdx.y = subject
-__global__ __launch_bounds__(256) void k_group_patch_values(GroupArgs a, double *const *__restrict__ pval) {
+__global__ __launch_bounds__(256) void k_group_patch_values(GroupArgs a, double *const *__restrict__ pval, const int *__restrict__ node_flags) {
     const int s = blockIdx.y, rows = a.N * a.L;
     const GlobalPtr<int> pp = as_global(a.pptr[s]), pi = as_global(a.pidx[s]);
     double *__restrict__ out = pval[s];
     const int lane = threadIdx.x & 63;
     for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += gridDim.x * 4) {
+        if (node_flags && !node_flags[(size_t)s * a.N + row / a.L]) continue;  // (wavefront-uniform: a row per wavefront)
         const int beg = pp[row], end = pp[row + 1], l = row % a.L;
         const GlobalPtr<double> F = as_global(a.F[(size_t)s * a.L + l]);
         for (int e = beg + lane; e < end; e += 64) {
@@ -783,10 +784,26 @@ int launch_group_expand_order(msm_ctx *ctx, const int *order, const int *pairs, 
     return MSM_OK;
 }
 
-int launch_group_patch_values(msm_ctx *ctx, const GroupArgs &a, double *const *pval) {
+__global__ __launch_bounds__(256) void k_group_mark_nodes(const int2 *__restrict__ pairs, long long n, int *__restrict__ node_flags) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int2 ab = pairs[i];
+    node_flags[ab.x] = 1;
+    node_flags[ab.y] = 1;
+}
+
+int launch_group_mark_nodes(msm_ctx *ctx, const int *pairs, long long pair0, long long pair1, int *node_flags) {
+    const long long n = pair1 - pair0;
+    if (n <= 0) return MSM_OK;
+    hipLaunchKernelGGL(k_group_mark_nodes, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, reinterpret_cast<const int2 *>(pairs) + pair0, n, node_flags);
+    MSM_HIP(hipGetLastError());
+    return MSM_OK;
+}
+
+int launch_group_patch_values(msm_ctx *ctx, const GroupArgs &a, double *const *pval, const int *node_flags) {
     const int rows = a.N * a.L;
     if (rows <= 0 || a.S <= 0) return MSM_OK;
-    hipLaunchKernelGGL(k_group_patch_values, dim3((unsigned)std::min((rows + 3) / 4, 4096), (unsigned)a.S), dim3(256), 0, ctx->stream, a, pval);
+    hipLaunchKernelGGL(k_group_patch_values, dim3((unsigned)std::min((rows + 3) / 4, 4096), (unsigned)a.S), dim3(256), 0, ctx->stream, a, pval, node_flags);
     MSM_HIP(hipGetLastError());
     return MSM_OK;
 }

@@ -280,7 +280,10 @@ int launch_rotate_to_labels(msm_ctx *ctx, const double *d_xyz, int V, const doub
                             size_t stride);
 int launch_group_pairwise(msm_ctx *ctx, const GroupArgs &a, const int *qp, const int *qa, const int *qb, int n, double *out);
 // pval[s][D * e + d] for every entry e of every patch of the S subjects (one launch; pval: device table of S device pointers, written through)
-int launch_group_patch_values(msm_ctx *ctx, const GroupArgs &a, double *const *pval);
+// node_flags (optional, S * N ints): only the patches of flagged nodes are written (a rank's slice of the pair list touches an eighth of them)
+int launch_group_patch_values(msm_ctx *ctx, const GroupArgs &a, double *const *pval, const int *node_flags = nullptr);
+// node_flags[node] = 1 for both nodes of the pairs [pair0, pair1)
+int launch_group_mark_nodes(msm_ctx *ctx, const int *pairs, long long pair0, long long pair1, int *node_flags);
 // out[i] = {order[i], pairs[2 * order[i]], pairs[2 * order[i] + 1], 0}
 int launch_group_expand_order(msm_ctx *ctx, const int *order, const int *pairs, int n, int4 *out);
 int launch_group_patch_dir(msm_ctx *ctx, const GroupArgs &a, double *const *pval, GroupPatchRef *dir);
