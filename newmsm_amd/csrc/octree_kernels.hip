@@ -64,7 +64,8 @@ __global__ __launch_bounds__(256) void k_oct_boxes(const double *__restrict__ xy
     list[t] = t;  // the root's list
 }
 
-constexpr int kChunk = 256;  // list entries a workgroup of k_oct_count / k_oct_fill takes
+constexpr int kChunk = 64;  // list entries a WAVEFRONT of k_oct_count / k_oct_fill takes (round 5: 256 per workgroup -- at the deep levels nearly every node's list is shorter than a
+                            // wavefront, three of a workgroup's four wavefronts idled through two barriers per chunk, and a workgroup had one chunk's dependent loads in flight)
 
 struct OctWork {
     const double *box;     // 6 per triangle
@@ -192,26 +193,25 @@ __global__ __launch_bounds__(256) void k_oct_decide(OctWork w) {
 template <int cur>  // which of the two open lists this level reads (a template parameter: a run-time index into the views' pointer pairs sent the kernels to scratch)
 __global__ __launch_bounds__(256) void k_oct_count(OctWork w) {
     w = tree_view(w);
-    __shared__ int s_cnt[4][8];
     const int nchunks = w.counters[cur ? C_NCHUNK_NEXT : C_NCHUNK];  // one count per open list: the scan of a level writes the other one
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    for (int k = blockIdx.x; k < nchunks; k += gridDim.x) {  // uniform
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+    for (int k = wave; k < nchunks; k += nwaves) {  // wavefront-uniform
         const int o = w.chunk_open[cur][k];
         if (!w.split[o]) continue;
         const int n = w.open_node[cur][o], beg = w.chunk_beg[cur][k], len = w.open_len[cur][o];
         const int *list = w.list[cur] + w.open_off[cur][o];
         double lo[3], mid[3], hi[3];
         node_box(w.nodebox[n], lo, mid, hi);
-        const int i = beg + threadIdx.x;
+        const int i = beg + lane;
         const unsigned f = i < len ? child_flags(w.box + (size_t)6 * list[i], lo, mid, hi) : 0u;
+        int mine = 0;
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             const int pc = __popcll(__ballot((f >> c) & 1u));
-            if (lane == 0) s_cnt[wv][c] = pc;
+            if (lane == c) mine = pc;
         }
-        __syncthreads();
-        if (threadIdx.x < 8) w.cc[8 * (size_t)k + threadIdx.x] = s_cnt[0][threadIdx.x] + s_cnt[1][threadIdx.x] + s_cnt[2][threadIdx.x] + s_cnt[3][threadIdx.x];
-        __syncthreads();
+        if (lane < 8) w.cc[8 * (size_t)k + lane] = mine;
     }
 }
 
@@ -474,17 +474,17 @@ __global__ __launch_bounds__(kScanThreads) void k_oct_scan(OctWork w, int depth)
 template <int cur>  // which of the two open lists this level reads (a template parameter: a run-time index into the views' pointer pairs sent the kernels to scratch)
 __global__ __launch_bounds__(256) void k_oct_fill(OctWork w) {
     w = tree_view(w);
-    __shared__ int s_cnt[4][8];
     if (w.counters[C_OVERFLOW]) return;
     const int nchunks = w.counters[cur ? C_NCHUNK_NEXT : C_NCHUNK];
     const int nxt = cur ^ 1;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    for (int k = blockIdx.x; k < nchunks; k += gridDim.x) {  // uniform
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+    for (int k = wave; k < nchunks; k += nwaves) {  // wavefront-uniform
         const int o = w.chunk_open[cur][k];
         const int n = w.open_node[cur][o], beg = w.chunk_beg[cur][k], len = w.open_len[cur][o];
         const int *list = w.list[cur] + w.open_off[cur][o];
         const int4 nd = w.node[n];
-        const int i = beg + threadIdx.x;
+        const int i = beg + lane;
         if (nd.x < 0) {
             const int cnt = -nd.x - 1, padded = (cnt + 7) & ~7;
             if (i < padded) w.leaf_tri[nd.y + i] = i < cnt ? list[i] : -1;
@@ -494,23 +494,15 @@ __global__ __launch_bounds__(256) void k_oct_fill(OctWork w) {
         node_box(w.nodebox[n], lo, mid, hi);
         const int t = i < len ? list[i] : 0;
         const unsigned f = i < len ? child_flags(w.box + (size_t)6 * t, lo, mid, hi) : 0u;
-        unsigned long long bal[8];
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            bal[c] = __ballot((f >> c) & 1u);
-            if (lane == 0) s_cnt[wv][c] = __popcll(bal[c]);
-        }
-        __syncthreads();
         const int oc0 = nd.x - w.open_node[nxt][0];  // the children's places in the next open list (consecutive)
         int *out = w.list[nxt];
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
+            const unsigned long long bal = __ballot((f >> c) & 1u);
             if (!((f >> c) & 1u)) continue;
-            int at = w.open_off[nxt][oc0 + c] + w.cc[8 * (size_t)k + c];
-            for (int q = 0; q < wv; ++q) at += s_cnt[q][c];
-            out[at + __popcll(bal[c] & ((1ull << lane) - 1ull))] = t;
+            const int at = w.open_off[nxt][oc0 + c] + w.cc[8 * (size_t)k + c];
+            out[at + __popcll(bal & ((1ull << lane) - 1ull))] = t;
         }
-        __syncthreads();
     }
 }
 
