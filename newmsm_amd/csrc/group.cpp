@@ -215,7 +215,7 @@ int subject_patches(msm_group *g, int s, msm_ctx *ctx = nullptr, msm_group::Pipe
     std::vector<int> counts((size_t)M + 1);
     for (int attempt = 0; attempt < 3; ++attempt) {
         MSM_HIP(d_slots.ensure((size_t)M * cap));
-        int st = launch_range(ctx, d_c.p, M, g->tmpl->d_xyz, Vt, d_sep.p, g->p.range, cap, d_slots.p, d_counts.p, pipe->d_chunkb.p, d_counts.p + M);
+        int st = launch_range(ctx, d_c.p, M, g->tmpl->d_xyz, Vt, d_sep.p, g->p.range, cap, d_slots.p, d_counts.p, pipe->d_chunkb.p, d_counts.p + M, L);
         if (st) return st;
         MSM_TRY(d_counts.download(counts.data(), (size_t)M + 1, ctx));
         MSM_TRY(ctx_sync(ctx));

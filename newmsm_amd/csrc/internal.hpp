@@ -268,6 +268,7 @@ struct Forest {
         int nnodes = 0, entries = 0, grid_depth = 0;
     };
     std::vector<Info> info;
+    int last_levels = 0;  // the levels the deepest tree of the previous build needed: queued up front by the next one (no look in between)
     ~Forest() {
         if (h_counters) (void)hipHostFree(h_counters);
     }

@@ -597,6 +597,114 @@ __global__ __launch_bounds__(256) void k_range(const double *__restrict__ cp, in
     if (threadIdx.x == 0) counts[k] = running;
 }
 
+// The same test for centres that come in clusters (gMSM: the L candidate positions of a control point, consecutive in the list and within a label
+// radius of one another).  k_range spends most of its time on what the cluster has in common: every centre's workgroup tests all the chunks' balls
+// (641 of them on an ico6 template, for a patch that touches ten) and takes three block barriers per four chunks.  Here a workgroup takes a cluster of
+// up to 64 consecutive centres: the balls are tested ONCE against the cluster's own bounding ball, the survivors (ascending) are kept in LDS, and each
+// wavefront then owns centres -- for a centre it tests the listed balls 64 at a time (a lane each) and sweeps the chunks that pass, its running count in
+// a register: no barrier after the list is made.  Pruning is conservative at both stages (a chunk is dropped only if no point of its ball can be in
+// range), so rows, order and flags are k_range's.
+__global__ __launch_bounds__(256) void k_range_cluster(const double *__restrict__ cp, int Ncp, int cluster, const double *__restrict__ src, int Nsrc,
+                                                        const double4 *__restrict__ cb, const double *__restrict__ maxsep, double range, int cap,
+                                                        uint32_t *__restrict__ slots, int *__restrict__ counts, int *__restrict__ nflag) {
+    const int k0 = blockIdx.x * cluster, n = min(cluster, Ncp - k0);  // cluster <= 64
+    if (n <= 0) return;
+    constexpr int kTile = 1024;
+    __shared__ int cand[kTile];
+    __shared__ int wave_count[4];
+    __shared__ int ncand;
+    __shared__ int s_run[64];
+    __shared__ double s_ball[4];  // the cluster's bounding ball: centre, radius + the largest reach of its centres
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (wave == 0) {
+        const bool in = lane < n;
+        const V3 c = in ? mk(cp[k0 + lane], cp[Ncp + k0 + lane], cp[2 * (size_t)Ncp + k0 + lane]) : mk(0, 0, 0);
+        const double thr0 = in ? range * maxsep[k0 + lane] : 0.0, hi0 = thr0 + fabs(thr0) * 1e-11;  // as below, per centre
+        const double inv = 1.0 / (double)n;
+        const V3 m = mk(wave_sum(c.x) * inv, wave_sum(c.y) * inv, wave_sum(c.z) * inv);
+        double r = in ? norm(sub(c, m)) : 0.0, reach = in ? hi0 * (1 + 1e-12) + 1e-12 : -1.0;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const double o = __shfl_xor(r, off, 64), q = __shfl_xor(reach, off, 64);
+            r = (o > r || o != o) ? o : r;  // a NaN centre makes every chunk a candidate (the comparisons below are all false)
+            reach = (q > reach || q != q) ? q : reach;
+        }
+        if (lane == 0) s_ball[0] = m.x, s_ball[1] = m.y, s_ball[2] = m.z, s_ball[3] = (r + reach) * (1 + 1e-12) + 1e-12;
+        s_run[lane] = 0;
+    }
+    __syncthreads();
+    const V3 bc = mk(s_ball[0], s_ball[1], s_ball[2]);
+    const double breach = s_ball[3];
+    const int nchunks = (Nsrc + 63) >> 6;
+    for (int tile = 0; tile < nchunks; tile += kTile) {
+        __syncthreads();  // the previous tile's list is no longer read
+        if (threadIdx.x == 0) ncand = 0;
+        __syncthreads();
+        for (int part = 0; part < kTile && tile + part < nchunks; part += 256) {  // uniform
+            const int ch = tile + part + threadIdx.x;
+            bool keep = false;
+            if (ch < nchunks) {
+                const double4 b = cb[ch];
+                keep = !(norm(sub(bc, mk(b.x, b.y, b.z))) - b.w > breach);
+            }
+            const unsigned long long ball = __ballot(keep);
+            if (lane == 0) wave_count[wave] = __popcll(ball);
+            __syncthreads();
+            if (keep) {
+                int pos = ncand + __popcll(ball & ((1ull << lane) - 1));
+                for (int wv = 0; wv < wave; ++wv) pos += wave_count[wv];
+                cand[pos] = ch;
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) ncand += wave_count[0] + wave_count[1] + wave_count[2] + wave_count[3];
+            __syncthreads();
+        }
+        const int nc = ncand;
+        for (int t = wave; t < n; t += 4) {  // wavefront-uniform: this wavefront's centres
+            const int k = k0 + t;
+            const V3 c = mk(cp[k], cp[Ncp + k], cp[2 * (size_t)Ncp + k]);
+            const double thr = range * maxsep[k];
+            const double slack = fabs(thr) * 1e-11;
+            const double lo = thr - slack, hi = thr + slack;
+            const double reach = hi * (1 + 1e-12) + 1e-12;
+            int run = s_run[t];
+            for (int base = 0; base < nc; base += 64) {  // uniform
+                const int ci = base + lane;
+                bool keep = false;
+                int mych = 0;
+                if (ci < nc) {
+                    mych = cand[ci];
+                    const double4 b = cb[mych];
+                    keep = !(norm(sub(c, mk(b.x, b.y, b.z))) - b.w > reach);
+                }
+                unsigned long long todo = __ballot(keep);
+                while (todo) {  // uniform: the chunks that pass, ascending
+                    const int j = __ffsll((long long)todo) - 1;
+                    todo &= todo - 1;
+                    const int i = __shfl(mych, j, 64) * 64 + lane;
+                    int state = 0;  // 0 out, 1 in, 2 undecided
+                    if (i < Nsrc) {
+                        const double d = norm(sub(c, mk(src[i], src[Nsrc + i], src[2 * (size_t)Nsrc + i])));
+                        if (!(d > hi)) {  // arc >= chord, so chord > hi is certainly out of range
+                            const double arc = chord_to_arc(d);
+                            state = (arc < lo) ? 1 : ((arc > hi) ? 0 : 2);
+                        }
+                    }
+                    const unsigned long long hit = __ballot(state != 0);
+                    if (state != 0) {
+                        const int pos = run + __popcll(hit & ((1ull << lane) - 1));
+                        if (pos < cap) slots[(size_t)k * cap + pos] = (uint32_t)i | (state == 2 ? 0x80000000u : 0u);
+                        if (state == 2) atomicAdd(nflag, 1);
+                    }
+                    run += __popcll(hit);
+                }
+            }
+            if (lane == 0) s_run[t] = run;  // only this wavefront reads it again (next tile)
+            if (tile + kTile >= nchunks && lane == 0) counts[k] = run;
+        }
+    }
+}
+
 // slot rows -> one contiguous list (CSR offsets pptr already scanned from the counts); only used when no entry was flagged
 __global__ __launch_bounds__(256) void k_patch_compact(const uint32_t *__restrict__ slots, int cap, const int32_t *__restrict__ pptr, int M,
                                                         int32_t *__restrict__ pidx) {
@@ -840,12 +948,18 @@ int launch_sort_patches(msm_ctx *ctx, const double *d_xyz, int n, const int32_t 
 }
 
 int launch_range(msm_ctx *ctx, const double *d_cp, int Ncp, const double *d_src, int Nsrc, const double *d_maxsep, double range,
-                 int cap, uint32_t *d_slots, int *d_counts, double4 *d_chunk_bounds, int *d_nflag) {
+                 int cap, uint32_t *d_slots, int *d_counts, double4 *d_chunk_bounds, int *d_nflag, int cluster) {
     if (Ncp <= 0) return MSM_OK;
     const int nchunks = (Nsrc + 63) / 64;
     MSM_HIP(hipMemsetAsync(d_nflag, 0, sizeof(int), ctx->stream));
     if (nchunks > 0) hipLaunchKernelGGL(k_chunk_bounds, dim3((nchunks + 3) / 4), dim3(256), 0, ctx->stream, d_src, Nsrc, d_chunk_bounds);
-    hipLaunchKernelGGL(k_range, dim3(Ncp), dim3(256), 0, ctx->stream, d_cp, Ncp, d_src, Nsrc, d_chunk_bounds, d_maxsep, range, cap, d_slots, d_counts, d_nflag);
+    static const bool cluster_off = [] { const char *e = std::getenv("MSMHIP_RANGE_CLUSTER"); return e && std::strcmp(e, "off") == 0; }();
+    if (cluster > 1 && nchunks > 0 && !cluster_off) {
+        const int per = cluster <= 64 ? cluster : 32;  // centres that are consecutive in the list are neighbours either way
+        hipLaunchKernelGGL(k_range_cluster, dim3((Ncp + per - 1) / per), dim3(256), 0, ctx->stream, d_cp, Ncp, per, d_src, Nsrc, d_chunk_bounds, d_maxsep, range, cap, d_slots,
+                           d_counts, d_nflag);
+    } else
+        hipLaunchKernelGGL(k_range, dim3(Ncp), dim3(256), 0, ctx->stream, d_cp, Ncp, d_src, Nsrc, d_chunk_bounds, d_maxsep, range, cap, d_slots, d_counts, d_nflag);
     MSM_HIP(hipGetLastError());
     return MSM_OK;
 }

@@ -68,9 +68,10 @@ int launch_fold_detect(msm_ctx *ctx, const double *d_xyz, int V, const int32_t *
 // d_sorted = each patch's members (d_pidx, CSR d_pptr) in Morton order of their positions d_xyz (3 x n SoA); d_code: n scratch words
 int launch_sort_patches(msm_ctx *ctx, const double *d_xyz, int n, const int32_t *d_pptr, int ngroups, const int32_t *d_pidx, uint32_t *d_code,
                         int32_t *d_sorted);
-// d_chunk_bounds: scratch, one double4 per 64 source vertices; *d_nflag (device int) = entries flagged as undecided (bit 31)
+// d_chunk_bounds: scratch, one double4 per 64 source vertices; *d_nflag (device int) = entries flagged as undecided (bit 31);
+// cluster > 1: every `cluster` consecutive centres lie close together (gMSM: a control point's L candidate positions) and share the pruning
 int launch_range(msm_ctx *ctx, const double *d_cp, int Ncp, const double *d_src, int Nsrc, const double *d_maxsep, double range, int cap,
-                 uint32_t *d_slots, int *d_counts, double4 *d_chunk_bounds, int *d_nflag);
+                 uint32_t *d_slots, int *d_counts, double4 *d_chunk_bounds, int *d_nflag, int cluster = 1);
 // rows of slots -> the contiguous list d_pidx at the offsets d_pptr (M + 1, already summed); valid when nothing was flagged
 int launch_patch_compact(msm_ctx *ctx, const uint32_t *d_slots, int cap, const int32_t *d_pptr, int M, int32_t *d_pidx);
 

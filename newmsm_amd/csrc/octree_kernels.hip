@@ -161,6 +161,12 @@ __global__ __launch_bounds__(256) void k_oct_decide(OctWork w) {
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
     for (int o = wave; o < nopen; o += nwaves) {
         const int n = w.open_node[cur][o], off = w.open_off[cur][o], len = w.open_len[cur][o];
+        // the level's chunk tables (round 5: k_oct_scan wrote them for the next level, a thread walking its node's children chunk by chunk -- with
+        // 64-entry chunks the nodes of levels 2 and 3 have hundreds, and the scan took 200 us there)
+        for (int j = lane, k0 = w.open_chunk[cur][o], nk = (len + kChunk - 1) / kChunk; j < nk; j += kWave) {
+            w.chunk_open[cur][k0 + j] = o;
+            w.chunk_beg[cur][k0 + j] = j * kChunk;
+        }
         const int *list = w.list[cur] + off;
         double lo[3], mid[3], hi[3];
         node_box(w.nodebox[n], lo, mid, hi);
@@ -318,7 +324,6 @@ __device__ int block_excl_scan(int v, int *total) {
 constexpr int kScanThreads = 256;  // threads of a k_oct_scan workgroup = open nodes of a logical block (round 5: 1024 -- sixteen wavefronts that need a whole CU's
                                    // worth of slots at once waited long for one while two set-up pipelines and their batch streams kept the CUs busy)
 constexpr int kScanBlocks = 64;
-constexpr int kBigNode = 24;  // a splitting node whose children hold more chunks than this has its chunk tables written by the whole workgroup
 template <int cur>
 __global__ __launch_bounds__(kScanThreads) void k_oct_scan(OctWork w, int depth) {
     w = tree_view(w);
@@ -330,10 +335,9 @@ __global__ __launch_bounds__(kScanThreads) void k_oct_scan(OctWork w, int depth)
     }
     const int nnodes0 = w.counters[C_SNAP_NNODES], arena0 = w.counters[C_SNAP_ARENA], nmask0 = w.counters[C_SNAP_NMASK];
     const int nlog = (nopen + kScanThreads - 1) / kScanThreads, epoch = depth + 1;
-    __shared__ int s_over, s_max, s_last, s_nbig, s_lb;
-    __shared__ int4 s_big[kScanThreads];
+    __shared__ int s_over, s_max, s_last, s_lb;
     for (;;) {
-        if (tid == 0) s_over = 0, s_max = 0, s_nbig = 0, s_lb = atomicAdd(&w.counters[C_SCAN_TICKET], 1);
+        if (tid == 0) s_over = 0, s_max = 0, s_lb = atomicAdd(&w.counters[C_SCAN_TICKET], 1);
         __syncthreads();
         const int lb = s_lb;  // uniform
         if (lb >= nlog) break;
@@ -362,13 +366,16 @@ __global__ __launch_bounds__(kScanThreads) void k_oct_scan(OctWork w, int depth)
         }
         for (int j = tid; j < lb; j += kScanThreads) {
             // (bounded: should a block before this one never report -- it cannot, see above -- the build gives up and the host builds the tree)
-            for (int spin = 0; __hip_atomic_load(w.agg + 8 * (size_t)j + 7, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != epoch; ++spin) {
+            // (polled relaxed, one acquire fence behind the wait: an acquire load per round invalidated the vector L1 of a CU this kernel shares with the
+            // other streams' kernels on every round)
+            for (int spin = 0; __hip_atomic_load(w.agg + 8 * (size_t)j + 7, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch; ++spin) {
                 if (spin > (1 << 22)) {
                     atomicOr(&w.counters[C_SCAN_OVER], 2);  // 2: a wait that ran out (reported under MSMHIP_TIMING), 1: an array that is too small
                     break;
                 }
                 __builtin_amdgcn_s_sleep(2);
             }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // pairs with the release store of the sums' tag
 #pragma unroll
             for (int q = 0; q < 7; ++q) before[q] += __hip_atomic_load(w.agg + 8 * (size_t)j + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -397,37 +404,14 @@ __global__ __launch_bounds__(kScanThreads) void k_oct_scan(OctWork w, int depth)
                         w.open_node[nxt][oc] = id;
                         w.open_off[nxt][oc] = lo;
                         w.open_len[nxt][oc] = ct[c];
-                        w.open_chunk[nxt][oc] = kk;
-                        const int nk = (ct[c] + kChunk - 1) / kChunk;
-                        if (cchunks <= kBigNode)
-                            for (int j = 0; j < nk; ++j) {
-                                w.chunk_open[nxt][kk + j] = oc;
-                                w.chunk_beg[nxt][kk + j] = j * kChunk;
-                            }
-                        kk += nk;
+                        w.open_chunk[nxt][oc] = kk;  // (the chunk tables themselves: the next level's k_oct_decide)
+                        kk += (ct[c] + kChunk - 1) / kChunk;
                         lo += ct[c];
-                    }
-                    if (cchunks > kBigNode) {  // the large nodes of the top levels (the root of an ico6 mesh: 400 chunks): the whole workgroup, below
-                        const int at = atomicAdd(&s_nbig, 1);
-                        s_big[at] = make_int4(o, 8 * rank, koff, 0);
                     }
                 }
             } else {
                 if (arena0 + aoff + ((len + 7) & ~7) > w.cap_arena) s_over = 1;
                 else w.node[n] = make_int4(-len - 1, arena0 + aoff, hasmask ? nmask0 + mblk : -1, depth);  // k_oct_fill finds its slot here
-            }
-        }
-        __syncthreads();
-        for (int b = 0; b < s_nbig; ++b) {  // uniform; at most 1024 / kBigNode... entries: a node with that many chunks holds that many triangles
-            const int4 big = s_big[b];
-            int kk = big.z;
-            for (int c = 0; c < 8; ++c) {
-                const int cnt = w.ctot[8 * (size_t)big.x + c], nk = (cnt + kChunk - 1) / kChunk;
-                for (int j = tid; j < nk; j += kScanThreads) {
-                    w.chunk_open[nxt][kk + j] = big.y + c;
-                    w.chunk_beg[nxt][kk + j] = j * kChunk;
-                }
-                kk += nk;
             }
         }
         __syncthreads();
@@ -795,7 +779,9 @@ int gpu_build_forest(msm_ctx *ctx, Forest &f, const double *d_xyz, size_t comp_s
     job.w = w;
     job.trees = B;
     job.h_counters = f.h_counters;
-    int st = queue_levels(ctx, job, first_batch(T));
+    // a forest that is rebuilt (gMSM: one per set-up pipeline, subject after subject, iteration after iteration) queues what its last build needed:
+    // warped ico6 meshes go two levels deeper than the regular one, and a second batch costs a round trip plus launches the GPU waits for
+    int st = queue_levels(ctx, job, std::min(kMaxLevels, std::max(first_batch(T), f.last_levels)));
     if (st) return st;
     MSM_TRY(ctx_sync(ctx));
     auto open_somewhere = [&] {
@@ -811,6 +797,8 @@ int gpu_build_forest(msm_ctx *ctx, Forest &f, const double *d_xyz, size_t comp_s
         MSM_TRY(ctx_sync(ctx));
     }
     f.info.assign(B, Forest::Info{});
+    f.last_levels = 0;
+    for (int b = 0; b < B; ++b) f.last_levels = std::max(f.last_levels, f.h_counters[(size_t)b * (C_COUNT + 1) + C_MAXDEPTH] + 1);
     for (int b = 0; b < B; ++b) {
         const int *hc = f.h_counters + (size_t)b * (C_COUNT + 1);
         if ((hc[C_OVERFLOW] & 2) && std::getenv("MSMHIP_TIMING"))
