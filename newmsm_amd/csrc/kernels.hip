@@ -393,6 +393,38 @@ __global__ __launch_bounds__(256) void k_unit_vectors(const double *__restrict__
 
 constexpr int kSmoothList = 512;  // neighbours per LDS pass of one wavefront
 
+// A centre's thresholds.  lo / hi: the band around range * MAXSEP inside which the host decides (see above).  dlo2 / dhi2: squared chords that settle a point
+// without the square root and the asin() of the reference's test (round 5: those two were most of the kernel -- some 25 chunks of 64 points survive the
+// pruning per centre, ten of them with a point in range): arc(d) = 2 R asin(d / 2R) is increasing, so a chord below 2 R sin(lo / 2R) (1 - 1e-9) has its arc below
+// lo and one above 2 R sin(hi / 2R) (1 + 1e-9) has it above hi, with nine orders of magnitude between the margin and the rounding of either libm; the points
+// in between -- ties, in practice none -- take the reference's arithmetic as before.
+struct RangeBand {
+    double lo, hi, dlo2, dhi2;
+};
+__device__ __forceinline__ RangeBand range_band(double thr) {
+    RangeBand b;
+    const double slack = fabs(thr) * 1e-11;
+    b.lo = thr - slack, b.hi = thr + slack;
+    b.dlo2 = -1.0, b.dhi2 = INFINITY;  // nothing settled early (a NaN or non-positive threshold, a range beyond a quarter of the sphere's girth)
+    const double a = b.lo / (2 * kRad), e = b.hi / (2 * kRad);
+    if (a > 0.0 && e < 1.5) {
+        const double s = 2 * kRad * sin(a) * (1 - 1e-9), t = 2 * kRad * sin(e) * (1 + 1e-9);
+        b.dlo2 = s * s, b.dhi2 = t * t;
+    }
+    return b;
+}
+// 0 out, 1 in, 2 undecided (within_controlpt_range, M/DiscreteCostFunction.cpp:102-107)
+__device__ __forceinline__ int range_state(const V3 c, const V3 p, const RangeBand &b) {
+    const V3 v = sub(c, p);
+    const double d2 = v.x * v.x + v.y * v.y + v.z * v.z;
+    if (d2 < b.dlo2) return 1;
+    if (d2 > b.dhi2) return 0;
+    const double d = norm(v);
+    if (d > b.hi) return 0;  // arc >= chord, so chord > hi is certainly out of range
+    const double arc = chord_to_arc(d);
+    return (arc < b.lo) ? 1 : ((arc > b.hi) ? 0 : 2);
+}
+
 __global__ __launch_bounds__(256) void k_chunk_bounds(const double *__restrict__ src, int Nsrc, double4 *__restrict__ cb);
 
 __global__ __launch_bounds__(256) void k_smooth(const double *__restrict__ unit, int N, const int *__restrict__ cv, const double *__restrict__ data,
@@ -533,10 +565,8 @@ __global__ __launch_bounds__(256) void k_range(const double *__restrict__ cp, in
     const int k = blockIdx.x;
     if (k >= Ncp) return;
     const V3 c = mk(cp[k], cp[Ncp + k], cp[2 * Ncp + k]);
-    const double thr = range * maxsep[k];
-    const double slack = fabs(thr) * 1e-11;
-    const double lo = thr - slack, hi = thr + slack;
-    const double reach = hi * (1 + 1e-12) + 1e-12;  // a chunk is skipped only if even its ball's nearest point is beyond hi
+    const RangeBand band = range_band(range * maxsep[k]);
+    const double reach = band.hi * (1 + 1e-12) + 1e-12;  // a chunk is skipped only if even its ball's nearest point is beyond hi
     const int nchunks = (Nsrc + 63) >> 6;
     constexpr int kTile = 1024;
     __shared__ int cand[kTile];
@@ -571,14 +601,7 @@ __global__ __launch_bounds__(256) void k_range(const double *__restrict__ cp, in
         for (int it = 0; it < nc; it += 4) {  // uniform
             const int ci = it + wave;
             const int i = ci < nc ? cand[ci] * 64 + lane : Nsrc;
-            int state = 0;  // 0 out, 1 in, 2 undecided
-            if (i < Nsrc) {
-                const double d = norm(sub(c, mk(src[i], src[Nsrc + i], src[2 * Nsrc + i])));
-                if (!(d > hi)) {  // arc >= chord, so chord > hi is certainly out of range
-                    const double arc = chord_to_arc(d);
-                    state = (arc < lo) ? 1 : ((arc > hi) ? 0 : 2);
-                }
-            }
+            const int state = i < Nsrc ? range_state(c, mk(src[i], src[Nsrc + i], src[2 * (size_t)Nsrc + i]), band) : 0;
             const unsigned long long ball = __ballot(state != 0);
             if (lane == 0) wave_count[wave] = __popcll(ball);
             __syncthreads();
@@ -663,10 +686,8 @@ __global__ __launch_bounds__(256) void k_range_cluster(const double *__restrict_
         for (int t = wave; t < n; t += 4) {  // wavefront-uniform: this wavefront's centres
             const int k = k0 + t;
             const V3 c = mk(cp[k], cp[Ncp + k], cp[2 * (size_t)Ncp + k]);
-            const double thr = range * maxsep[k];
-            const double slack = fabs(thr) * 1e-11;
-            const double lo = thr - slack, hi = thr + slack;
-            const double reach = hi * (1 + 1e-12) + 1e-12;
+            const RangeBand band = range_band(range * maxsep[k]);
+            const double reach = band.hi * (1 + 1e-12) + 1e-12;
             int run = s_run[t];
             for (int base = 0; base < nc; base += 64) {  // uniform
                 const int ci = base + lane;
@@ -682,14 +703,7 @@ __global__ __launch_bounds__(256) void k_range_cluster(const double *__restrict_
                     const int j = __ffsll((long long)todo) - 1;
                     todo &= todo - 1;
                     const int i = __shfl(mych, j, 64) * 64 + lane;
-                    int state = 0;  // 0 out, 1 in, 2 undecided
-                    if (i < Nsrc) {
-                        const double d = norm(sub(c, mk(src[i], src[Nsrc + i], src[2 * (size_t)Nsrc + i])));
-                        if (!(d > hi)) {  // arc >= chord, so chord > hi is certainly out of range
-                            const double arc = chord_to_arc(d);
-                            state = (arc < lo) ? 1 : ((arc > hi) ? 0 : 2);
-                        }
-                    }
+                    const int state = i < Nsrc ? range_state(c, mk(src[i], src[Nsrc + i], src[2 * (size_t)Nsrc + i]), band) : 0;
                     const unsigned long long hit = __ballot(state != 0);
                     if (state != 0) {
                         const int pos = run + __popcll(hit & ((1ull << lane) - 1));
