@@ -14,7 +14,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cmath>
+#include <condition_variable>
 #include <memory>
+#include <mutex>
 #include <numeric>
 #include <thread>
 
@@ -35,6 +37,7 @@ bool mesh_tree_on_gpu(const msm_mesh *m);
 struct msm_group {
     msm_ctx *ctx = nullptr;
     std::atomic<int> patch_cap_hint{0};
+    std::atomic<size_t> pidx_hint{0};  // the longest patch index list of a subject so far: the next one's is compacted before the look at its counts
     int patch_max = 0;  // largest patch of any subject (msm_group_finalize)
     int pair_lanes = 32;  // lanes per query of k_group_pairwise: 16 when nearly all patches fit a quarter wavefront's registers (msm_group_finalize)
     msm_group_params p{};
@@ -96,6 +99,7 @@ struct msm_group {
     std::vector<Lane> lanes;
     // what the set-up of ONE subject needs before its per-label work can start: the L rotated copies of its data mesh, their trees
     // (a forest), its features.  Two of them: while the lanes work through subject i the main stream prepares subject i + 1.
+    static constexpr int kStages = 3;  // of a pipeline: the preparing loop runs this many subjects ahead of the consuming one (run_setup_pipe)
     struct Stage {
         DevBuf<double> d_rot, d_feat, d_rot9;  // d_rot9: the vertices' rotation matrices when they come from the host (rotation_mode 1)
         std::vector<double> rot9;
@@ -115,11 +119,12 @@ struct msm_group {
     struct Pipe {
         msm_ctx *main = nullptr;  // pipe 0: the group's context; pipe 1: a context (stream) of its own
         bool own_main = false;
-        Stage stage[2];
+        Stage stage[kStages];
         Batch batch;
         // scratch of subject_patches
         DevBuf<double> d_centres, d_sep;
         DevBuf<double4> d_chunkb;       // k_range: bounding balls of the template's vertices, 64 ids at a time
+        DevBuf<int> d_scan_tmp;         // subject_patches: block sums of the row-offset scan
         DevBuf<uint32_t> d_slots;
         DevBuf<int> d_counts;
     };
@@ -188,7 +193,9 @@ int subject_feature_slab(msm_group *g, int s, size_t per) {
     return MSM_OK;
 }
 
-int subject_patches(msm_group *g, int s, msm_ctx *ctx = nullptr, msm_group::Pipe *pipe = nullptr) {  // ctx: the context (stream) to work on, pipe: whose scratch
+// deferred: work queued on the stream before this call whose status has not been looked at yet (stage_batch) -- named in the error should it have failed;
+// the first synchronisation here covers it
+int subject_patches(msm_group *g, int s, msm_ctx *ctx = nullptr, msm_group::Pipe *pipe = nullptr, const char *deferred = nullptr) {  // ctx: the context (stream) to work on, pipe: whose scratch
     if (!pipe) pipe = &g->pipe[0];
     if (!ctx) ctx = g->ctx;
     const int N = g->N, L = g->L, M = N * L, Vt = g->tmpl->V;
@@ -213,17 +220,40 @@ int subject_patches(msm_group *g, int s, msm_ctx *ctx = nullptr, msm_group::Pipe
     MSM_HIP(pipe->d_chunkb.ensure((size_t)(Vt + 63) / 64 + 1));
     int cap = std::max(256, g->patch_cap_hint.load());  // the previous call's largest patch: one k_range pass instead of two
     std::vector<int> counts((size_t)M + 1);
+    auto first_sync = [&]() -> int {
+        if (!deferred) return ctx_sync(ctx);
+        const char *what = deferred;
+        deferred = nullptr;
+        return check_status(ctx, what);
+    };
+    // Round 5: from a set-up's second subject on the row offsets are summed and the list compacted on the device BEFORE the host has seen the counts (the list
+    // sized from the longest one so far, the kernel guarded), so that a subject's batch stream synchronises once -- it was three round trips (after the
+    // resampling, after the counts, after the compaction), each followed by launches onto an idle stream: a quarter of the stream's time was gaps.
+    const size_t list_hint = g->pidx_hint.load();
+    bool early = false;
     for (int attempt = 0; attempt < 3; ++attempt) {
         MSM_HIP(d_slots.ensure((size_t)M * cap));
         int st = launch_range(ctx, d_c.p, M, g->tmpl->d_xyz, Vt, d_sep.p, g->p.range, cap, d_slots.p, d_counts.p, pipe->d_chunkb.p, d_counts.p + M, L);
         if (st) return st;
+        early = attempt == 0 && list_hint > 0;
+        if (early) {
+            MSM_HIP(g->pptr[s]->ensure((size_t)M + 1));
+            MSM_HIP(pipe->d_scan_tmp.ensure((size_t)M / 4096 + 2));
+            MSM_HIP(g->pidx[s]->ensure(list_hint + list_hint / 8 + 1024));
+            MSM_HIP(hipMemcpyAsync(g->pptr[s]->p, d_counts.p, sizeof(int) * (size_t)M, hipMemcpyDeviceToDevice, ctx->stream));
+            st = launch_scan_exclusive(ctx, g->pptr[s]->p, M, pipe->d_scan_tmp.p);
+            if (st) return st;
+            st = launch_patch_compact(ctx, d_slots.p, cap, g->pptr[s]->p, M, g->pidx[s]->p, g->pidx[s]->cap);
+            if (st) return st;
+        }
         MSM_TRY(d_counts.download(counts.data(), (size_t)M + 1, ctx));
-        MSM_TRY(ctx_sync(ctx));
+        MSM_TRY(first_sync());
         const int mx = *std::max_element(counts.begin(), counts.begin() + M);
         if (mx + 16 > g->patch_cap_hint.load()) g->patch_cap_hint.store(mx + 16);
         if (mx <= cap) break;
         if (attempt == 2) return fail(MSM_ERR_CAPACITY, "group patch capacity");
         cap = mx + 16;
+        early = false;
     }
     lap("range kernel");
     if (counts[M] == 0) {
@@ -233,6 +263,11 @@ int subject_patches(msm_group *g, int s, msm_ctx *ctx = nullptr, msm_group::Pipe
         pp.assign((size_t)M + 1, 0);
         for (int k = 0; k < M; ++k) pp[k + 1] = pp[k] + counts[k];
         g->h_pidx[s].clear();
+        if ((size_t)pp[M] > g->pidx_hint.load()) g->pidx_hint.store((size_t)pp[M]);
+        if (early && (size_t)pp[M] <= g->pidx[s]->cap) {
+            lap("lists (device, no second look)");
+            return MSM_OK;
+        }
         MSM_TRY(g->pptr[s]->upload(pp.data(), pp.size(), ctx));
         MSM_HIP(g->pidx[s]->ensure(std::max<size_t>((size_t)pp[M], 1)));
         int st = launch_patch_compact(ctx, d_slots.p, cap, g->pptr[s]->p, M, g->pidx[s]->p);
@@ -871,13 +906,13 @@ static int stage_prepare(msm_group *g, int s, msm_group::Stage &b, msm_ctx *ctx)
         tick = now;
     };
     MSM_HIP(b.d_rot.ensure(3 * LV));
-    int st = rotate_subject(g, dm, ctx, b.rot9, b.d_rot9, b.d_rot.p);  // one launch for the L labels (round 4: L - 1 launches that each computed the matrices again, and 3 copies)
-    if (st) return st;
-    lap("rotations");
     MSM_HIP(b.d_feat.ensure((size_t)D * V));
-    st = upload_staged(ctx, b.d_feat.p, g->feat[s].data(), sizeof(double) * (size_t)D * V);
+    int st = upload_staged(ctx, b.d_feat.p, g->feat[s].data(), sizeof(double) * (size_t)D * V);  // (first: the host's copy into the staging block is not between two launches then)
     if (st) return st;
     lap("feature upload");
+    st = rotate_subject(g, dm, ctx, b.rot9, b.d_rot9, b.d_rot.p);  // one launch for the L labels (round 4: L - 1 launches that each computed the matrices again, and 3 copies)
+    if (st) return st;
+    lap("rotations");
     st = subject_feature_slab(g, s, (size_t)D * Vt);
     if (st) return st;
     lap("slab");
@@ -899,7 +934,7 @@ static int stage_prepare(msm_group *g, int s, msm_group::Stage &b, msm_ctx *ctx)
 // vertices in every tree, reverse queries of all rotated vertices in the template's tree (one launch over the L * V points of
 // d_rot), vertex areas, weight-list surgery and the weighted sums into the subject's slab -- some forty launches per SUBJECT
 // where the lanes made thirty per label.  On a stream of its own (batch.ctx), beside the main stream's work on the next subject.
-static int stage_batch(msm_group *g, int s, msm_group::Stage &b, int which, msm_group::Batch &w) {
+static int stage_batch(msm_group *g, int s, msm_group::Stage &b, int which, msm_group::Batch &w, bool defer_status = false) {
     if (!w.ctx) {
         w.ctx = msm_ctx_create(g->ctx->device);
         if (!w.ctx) return MSM_ERR_HIP;
@@ -970,6 +1005,7 @@ static int stage_batch(msm_group *g, int s, msm_group::Stage &b, int which, msm_
     if (st) return st;
     st = launch_apply_rows_batch(ctx, a, D, b.d_feat.p, g->Fslab[s]->p, (size_t)D * Vt);
     if (st) return st;
+    if (defer_status) return MSM_OK;  // the caller queues the subject's patch lists behind this and looks once (subject_patches)
     return check_status(ctx, "get_patch_data (resampling)");  // synchronises the batch stream
 }
 
@@ -1049,48 +1085,65 @@ static int run_setup_pipe(msm_group *g, msm_group::Pipe &P, int pipe_no, const s
     msm_ctx *ctx = P.main;
     (void)hipSetDevice(ctx->device);
     const bool timing = std::getenv("MSMHIP_TIMING") != nullptr;
-    auto t0 = std::chrono::steady_clock::now();
-    int st = stage_prepare(g, subjects[0], P.stage[0], ctx);
-    if (st) return st;
-    if (timing) fprintf(stderr, "  group set-up, pipeline %d: first subject's rotations + forest (nothing of this pipeline beside them): %.1f ms\n", pipe_no,
-                        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
-    for (int i = 0; i < n; ++i) {
-        const int s = subjects[i];
-        msm_group::Stage &cur = P.stage[i & 1];
-        int st_lanes = MSM_OK;
-        std::string msg_lanes;
-        static const bool no_batch = [] { const char *e = std::getenv("MSMHIP_GROUP_BATCH"); return e && std::strcmp(e, "off") == 0; }();
-        const int which = i & 1;
-        // the subject's patch lists (0.65 ms, of which the range kernel 0.5) follow its per-label work on that thread and stream when there is
-        // one (stage_batch: 1.5 ms) -- the main stream's preparation of the next subject (1.95 ms) was the longer side with the lists on it
-        const bool batch = cur.forest_ok && !no_batch;
-        double ms_lanes = 0.0, ms_main = 0.0;
-        std::thread lanes([&] {
+    static const bool no_batch = [] { const char *e = std::getenv("MSMHIP_GROUP_BATCH"); return e && std::strcmp(e, "off") == 0; }();
+    // Two loops over a ring of kStages stages (round 5; until then one iteration = a thread for subject i's per-label work beside the preparation of subject
+    // i + 1, joined: either stream idled 0.4 - 0.55 ms per subject for the other one, thread start and join included).  The preparing loop (this thread,
+    // the main stream) runs up to kStages subjects ahead of the consuming one (a thread of its own for the whole pipeline, the batch stream).
+    constexpr int K = msm_group::kStages;
+    std::mutex mu;
+    std::condition_variable cv;
+    int prepared = 0, consumed = 0;  // subjects whose stage is ready / whose stage is free again
+    bool stop = false;
+    int st_batch = MSM_OK, st_main = MSM_OK;
+    std::string msg_batch;
+    std::thread consumer([&] {
+        (void)hipSetDevice(ctx->device);
+        for (int i = 0; i < n; ++i) {
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return prepared > i || stop; });
+                if (prepared <= i) return;  // the preparing side failed
+            }
+            const int s = subjects[i];
+            msm_group::Stage &cur = P.stage[i % K];
             const auto l0 = std::chrono::steady_clock::now();
-            (void)hipSetDevice(ctx->device);
-            st_lanes = batch ? stage_batch(g, s, cur, which, P.batch) : stage_lanes(g, s, cur);
-            if (!st_lanes && batch) st_lanes = subject_patches(g, s, P.batch.ctx, &P);
-            if (st_lanes) msg_lanes = msm_last_error();
-            ms_lanes = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - l0).count();
-        });
-        int st_main = MSM_OK;
-        const auto m0 = std::chrono::steady_clock::now();
-        if (i + 1 < n) st_main = stage_prepare(g, subjects[i + 1], P.stage[(i + 1) & 1], ctx);
-        if (!st_main && !batch) st_main = subject_patches(g, s, ctx, &P);
-        ms_main = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - m0).count();
-        lanes.join();
-        if (timing && i < 2) fprintf(stderr, "  group set-up, subject %d: per-label work + patches %.1f ms beside the next subject's rotations + forest %.1f ms\n", s, ms_lanes, ms_main);
-        if (st_lanes) return fail(st_lanes, "%s", msg_lanes.c_str());
-        if (st_main) return st_main;
-        g->have_subject[s] = 1;
-        if (timing) {
-            const auto now = std::chrono::steady_clock::now();
-            fprintf(stderr, "  group set-up, subject %d (pipeline %d): %.1f ms (per-label work || next subject's rotations + forest, this subject's patches)\n", s, pipe_no,
-                    std::chrono::duration<double, std::milli>(now - t0).count());
-            t0 = now;
+            // the subject's patch lists (the range kernel) follow its per-label work on the batch stream, one look at the outcome of both
+            const bool batch = cur.forest_ok && !no_batch;
+            int st = batch ? stage_batch(g, s, cur, i & 1, P.batch, true) : stage_lanes(g, s, cur);
+            if (!st) st = subject_patches(g, s, P.batch.ctx, &P, batch ? "get_patch_data (resampling)" : nullptr);
+            if (timing && i < 4)
+                fprintf(stderr, "  group set-up, pipeline %d, subject %d: per-label work + patches %.2f ms\n", pipe_no, s,
+                        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - l0).count());
+            std::lock_guard<std::mutex> lk(mu);
+            if (st) {
+                st_batch = st, msg_batch = msm_last_error(), stop = true;
+                cv.notify_all();
+                return;
+            }
+            g->have_subject[s] = 1;
+            consumed = i + 1;
+            cv.notify_all();
         }
+    });
+    for (int i = 0; i < n && !st_main; ++i) {
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return i - consumed < K || stop; });
+            if (stop) break;
+        }
+        const auto m0 = std::chrono::steady_clock::now();
+        st_main = stage_prepare(g, subjects[i], P.stage[i % K], ctx);
+        if (timing && i < 4)
+            fprintf(stderr, "  group set-up, pipeline %d, subject %d: rotations + forest %.2f ms\n", pipe_no, subjects[i],
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - m0).count());
+        std::lock_guard<std::mutex> lk(mu);
+        if (st_main) stop = true;
+        else prepared = i + 1;
+        cv.notify_all();
     }
-    return MSM_OK;
+    consumer.join();
+    if (st_batch) return fail(st_batch, "%s", msg_batch.c_str());
+    return st_main;
 }
 
 // The subjects of this rank, pipelined.  Within a pipeline the batch stream works through subject i while the main stream prepares subject i + 1

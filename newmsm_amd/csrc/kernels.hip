@@ -720,12 +720,15 @@ __global__ __launch_bounds__(256) void k_range_cluster(const double *__restrict_
 }
 
 // slot rows -> one contiguous list (CSR offsets pptr already scanned from the counts); only used when no entry was flagged
+// (pidx_cap: the list's capacity -- a caller that compacts before it has looked at the counts sizes the list from the previous subject's and
+// checks afterwards; rows beyond `cap` entries were not written by k_range either)
 __global__ __launch_bounds__(256) void k_patch_compact(const uint32_t *__restrict__ slots, int cap, const int32_t *__restrict__ pptr, int M,
-                                                        int32_t *__restrict__ pidx) {
+                                                        int32_t *__restrict__ pidx, size_t pidx_cap) {
     const int lane = threadIdx.x & 63, k = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (k >= M) return;
-    const int b = pptr[k], n = pptr[k + 1] - b;
-    for (int j = lane; j < n; j += 64) pidx[b + j] = (int32_t)(slots[(size_t)k * cap + j] & 0x7fffffffu);
+    const int b = pptr[k], n = min(pptr[k + 1] - b, cap);
+    for (int j = lane; j < n; j += 64)
+        if ((size_t)(b + j) < pidx_cap) pidx[b + j] = (int32_t)(slots[(size_t)k * cap + j] & 0x7fffffffu);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -978,9 +981,9 @@ int launch_range(msm_ctx *ctx, const double *d_cp, int Ncp, const double *d_src,
     return MSM_OK;
 }
 
-int launch_patch_compact(msm_ctx *ctx, const uint32_t *d_slots, int cap, const int32_t *d_pptr, int M, int32_t *d_pidx) {
+int launch_patch_compact(msm_ctx *ctx, const uint32_t *d_slots, int cap, const int32_t *d_pptr, int M, int32_t *d_pidx, size_t pidx_cap) {
     if (M <= 0) return MSM_OK;
-    hipLaunchKernelGGL(k_patch_compact, dim3((M + 3) / 4), dim3(256), 0, ctx->stream, d_slots, cap, d_pptr, M, d_pidx);
+    hipLaunchKernelGGL(k_patch_compact, dim3((M + 3) / 4), dim3(256), 0, ctx->stream, d_slots, cap, d_pptr, M, d_pidx, pidx_cap);
     MSM_HIP(hipGetLastError());
     return MSM_OK;
 }

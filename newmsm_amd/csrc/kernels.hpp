@@ -73,7 +73,9 @@ int launch_sort_patches(msm_ctx *ctx, const double *d_xyz, int n, const int32_t 
 int launch_range(msm_ctx *ctx, const double *d_cp, int Ncp, const double *d_src, int Nsrc, const double *d_maxsep, double range, int cap,
                  uint32_t *d_slots, int *d_counts, double4 *d_chunk_bounds, int *d_nflag, int cluster = 1);
 // rows of slots -> the contiguous list d_pidx at the offsets d_pptr (M + 1, already summed); valid when nothing was flagged
-int launch_patch_compact(msm_ctx *ctx, const uint32_t *d_slots, int cap, const int32_t *d_pptr, int M, int32_t *d_pidx);
+int launch_patch_compact(msm_ctx *ctx, const uint32_t *d_slots, int cap, const int32_t *d_pptr, int M, int32_t *d_pidx, size_t pidx_cap = (size_t)-1);
+// data[0 .. n) -> its exclusive prefix sums in place, data[n] = the total; tmp: n / 4096 + 2 ints
+int launch_scan_exclusive(msm_ctx *ctx, int *d_data, int n, int *d_tmp);
 
 // rnl[(node*L + l)*9..] = estimate_rotation_matrix(cp[node], rot[node]*labels[l]); moved (optional, N x L x 3 AoS) = rot[node]*labels[l]
 int launch_label_rotations(msm_ctx *ctx, const double *d_cp, int N, const double *d_rot, const double *d_labels, int L, double *d_rnl,

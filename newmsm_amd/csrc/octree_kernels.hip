@@ -783,7 +783,19 @@ int gpu_build_forest(msm_ctx *ctx, Forest &f, const double *d_xyz, size_t comp_s
     // warped ico6 meshes go two levels deeper than the regular one, and a second batch costs a round trip plus launches the GPU waits for
     int st = queue_levels(ctx, job, std::min(kMaxLevels, std::max(first_batch(T), f.last_levels)));
     if (st) return st;
+    // grid, records and cones read the counters on the device: queued behind the levels without a look at the outcome (round 5: the look was a round trip
+    // on the critical path of every subject of a gMSM set-up); should a tree turn out to need more levels they run again
+    auto finish = [&]() -> int {
+        hipLaunchKernelGGL(k_oct_grid_forest, dim3((unsigned)((f.s_grid + 255) / 256), UB), dim3(256), 0, ctx->stream, f.node.p, f.s_node, f.counters.p, (size_t)(C_COUNT + 1),
+                           f.grid.p, f.s_grid);
+        MSM_HIP(hipGetLastError());
+        return launch_build_recs_forest(ctx, d_xyz, comp_stride, tree_stride, d_tri, T, B, f.rec.p, f.tcone.p, f.s_rec, f.leaf_tri.p, f.cone.p, f.s_leaf, f.counters.p + C_ARENA,
+                                        (size_t)(C_COUNT + 1));
+    };
+    st = finish();
+    if (st) return st;
     MSM_TRY(ctx_sync(ctx));
+    bool again = false;
     auto open_somewhere = [&] {
         for (int b = 0; b < B; ++b) {
             const int *hc = f.h_counters + (size_t)b * (C_COUNT + 1);
@@ -795,6 +807,7 @@ int gpu_build_forest(msm_ctx *ctx, Forest &f, const double *d_xyz, size_t comp_s
         st = queue_levels(ctx, job, kNextBatch);
         if (st) return st;
         MSM_TRY(ctx_sync(ctx));
+        again = true;
     }
     f.info.assign(B, Forest::Info{});
     f.last_levels = 0;
@@ -808,11 +821,7 @@ int gpu_build_forest(msm_ctx *ctx, Forest &f, const double *d_xyz, size_t comp_s
         f.info[b].entries = hc[C_ARENA];
         f.info[b].grid_depth = std::min(hc[C_MAXDEPTH], 6);
     }
-    hipLaunchKernelGGL(k_oct_grid_forest, dim3((unsigned)((f.s_grid + 255) / 256), UB), dim3(256), 0, ctx->stream, f.node.p, f.s_node, f.counters.p, (size_t)(C_COUNT + 1),
-                       f.grid.p, f.s_grid);
-    MSM_HIP(hipGetLastError());
-    return launch_build_recs_forest(ctx, d_xyz, comp_stride, tree_stride, d_tri, T, B, f.rec.p, f.tcone.p, f.s_rec, f.leaf_tri.p, f.cone.p, f.s_leaf, f.counters.p + C_ARENA,
-                                    (size_t)(C_COUNT + 1));
+    return again ? finish() : MSM_OK;
 }
 
 DevTree forest_tree(const Forest &f, int b) {

@@ -372,6 +372,12 @@ static void scan_excl(msm_ctx *ctx, int *data, int n, int *tmp, int B, size_t s_
         hipLaunchKernelGGL(k_scan_block_sums, dim3(nb, (unsigned)B), dim3(256), 0, ctx->stream, data, n, tmp, s_data, s_tmp);
     hipLaunchKernelGGL(k_scan_apply, dim3(nb, (unsigned)B), dim3(256), 0, ctx->stream, data, n, tmp, s_data, s_tmp);
 }
+int launch_scan_exclusive(msm_ctx *ctx, int *d_data, int n, int *d_tmp) {
+    if (n <= 0) return MSM_OK;
+    scan_excl(ctx, d_data, n, d_tmp, 1, 0, 0);
+    MSM_HIP(hipGetLastError());
+    return MSM_OK;
+}
 int launch_vertex_areas_batch(msm_ctx *ctx, const double *d_xyz, size_t comp, size_t set, int V, const int32_t *d_tri, int T, const int32_t *d_tid_ptr, const int32_t *d_tid,
                               int B, double *d_ta, double *d_area) {
     MSM_LAUNCH2D(k_tri_areas, T, B, d_xyz, comp, set, d_tri, T, d_ta);
