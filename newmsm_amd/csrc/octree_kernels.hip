@@ -80,6 +80,7 @@ struct OctWork {
     int *chunk_open[2];    // per chunk: its open node (index into open_*), and where it starts in that node's list
     int *chunk_beg[2];
     int *list[2];          // the lists themselves
+    unsigned char *flags;  // per entry of list[cur]: which children of its (splitting) node it goes to -- k_oct_count works them out from the 48-byte box, k_oct_fill reads the byte
     int *split;            // per open node
     int *cc;               // 8 per chunk: what each child receives from this chunk, then (after k_oct_chunk_scan) where the chunk's share starts
     int *ctot;             // 8 per open node: what each child of a splitting node receives in all
@@ -110,6 +111,7 @@ __device__ __forceinline__ OctWork tree_view(OctWork w) {
         w.list[k] += b * w.s_ints;
     }
     w.split += b * w.s_ints;
+    w.flags += b * w.s_ints * sizeof(int);
     w.ctot += b * w.s_ints;
     w.cc += b * w.s_ints;
     w.agg += b * w.s_ints;
@@ -211,6 +213,7 @@ __global__ __launch_bounds__(256) void k_oct_count(OctWork w) {
         node_box(w.nodebox[n], lo, mid, hi);
         const int i = beg + lane;
         const unsigned f = i < len ? child_flags(w.box + (size_t)6 * list[i], lo, mid, hi) : 0u;
+        if (i < len) w.flags[w.open_off[cur][o] + i] = (unsigned char)f;
         int mine = 0;
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
@@ -474,10 +477,8 @@ __global__ __launch_bounds__(256) void k_oct_fill(OctWork w) {
             if (i < padded) w.leaf_tri[nd.y + i] = i < cnt ? list[i] : -1;
             continue;
         }
-        double lo[3], mid[3], hi[3];
-        node_box(w.nodebox[n], lo, mid, hi);
         const int t = i < len ? list[i] : 0;
-        const unsigned f = i < len ? child_flags(w.box + (size_t)6 * t, lo, mid, hi) : 0u;
+        const unsigned f = i < len ? (unsigned)w.flags[w.open_off[cur][o] + i] : 0u;  // k_oct_count's (round 5: both kernels read the entry's box, 48 bytes gathered, to get these eight bits)
         const int oc0 = nd.x - w.open_node[nxt][0];  // the children's places in the next open list (consecutive)
         int *out = w.list[nxt];
 #pragma unroll
@@ -613,7 +614,7 @@ int gpu_build_octree_begin(msm_mesh *m) {
         MSM_HIP(msm::pool_malloc((void **)&ctx->oct_box, ctx->oct_cap_box * sizeof(double)));
     }
     const size_t need_ints = (size_t)2 * cap_refs + (size_t)8 * cap_open + (size_t)cap_open + (size_t)8 * cap_open + (size_t)4 * cap_chunks + (size_t)8 * cap_chunks + 16 +
-                             8 * ((size_t)cap_open / kScanThreads + 2);
+                             8 * ((size_t)cap_open / kScanThreads + 2) + ((size_t)cap_refs + 3) / 4;
     if (need_ints > ctx->oct_cap_ints) {
         if (ctx->oct_ints) (void)msm::pool_free(ctx->oct_ints);
         ctx->oct_ints = nullptr;
@@ -664,7 +665,8 @@ int gpu_build_octree_begin(msm_mesh *m) {
     p += (4 - ((p - s.ints) & 3)) & 3;  // 16-byte alignment of the int4 accesses below
     w.ctot = p, p += (size_t)8 * cap_open;
     w.cc = p, p += (size_t)8 * cap_chunks;
-    w.agg = p;
+    w.agg = p, p += 8 * ((size_t)cap_open / kScanThreads + 2);
+    w.flags = reinterpret_cast<unsigned char *>(p);
     w.leaf_tri = m->d_leaf_tri;
     w.cap_nodes = cap_nodes, w.cap_refs = cap_refs, w.cap_arena = cap_arena, w.cap_open = cap_open, w.cap_chunks = cap_chunks;
 
@@ -724,7 +726,7 @@ int gpu_build_forest(msm_ctx *ctx, Forest &f, const double *d_xyz, size_t comp_s
     MSM_HIP(hipSetDevice(ctx->device));
     const int cap_nodes = T + 64, cap_refs = 6 * T + 256, cap_arena = 8 * T + 512, cap_open = cap_nodes, cap_chunks = cap_refs / kChunk + cap_open + 64;
     const size_t per_ints = ((size_t)2 * cap_refs + (size_t)8 * cap_open + (size_t)cap_open + (size_t)8 * cap_open + (size_t)4 * cap_chunks + (size_t)8 * cap_chunks + 16 +
-                             8 * ((size_t)cap_open / kScanThreads + 2) + 3) & ~(size_t)3;
+                             8 * ((size_t)cap_open / kScanThreads + 2) + ((size_t)cap_refs + 3) / 4 + 3) & ~(size_t)3;
     f.B = B, f.T = T, f.V = V;
     f.s_node = (size_t)cap_nodes, f.s_leaf = (size_t)cap_arena, f.s_rec = (size_t)T, f.s_grid = (size_t)64 * 64 * 64;
     MSM_HIP(f.node.ensure(f.s_node * B));
@@ -767,7 +769,8 @@ int gpu_build_forest(msm_ctx *ctx, Forest &f, const double *d_xyz, size_t comp_s
     p += (4 - ((p - f.ints.p) & 3)) & 3;
     w.ctot = p, p += (size_t)8 * cap_open;
     w.cc = p, p += (size_t)8 * cap_chunks;
-    w.agg = p;
+    w.agg = p, p += 8 * ((size_t)cap_open / kScanThreads + 2);
+    w.flags = reinterpret_cast<unsigned char *>(p);
     w.leaf_tri = f.leaf_tri.p;
     w.cap_nodes = cap_nodes, w.cap_refs = cap_refs, w.cap_arena = cap_arena, w.cap_open = cap_open, w.cap_chunks = cap_chunks;
     w.s_box = (size_t)6 * T, w.s_node = f.s_node, w.s_cnt = (size_t)(C_COUNT + 1), w.s_ints = per_ints, w.s_leaf = f.s_leaf;
