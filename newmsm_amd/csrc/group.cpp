@@ -37,7 +37,11 @@ bool mesh_tree_on_gpu(const msm_mesh *m);
 struct msm_group {
     msm_ctx *ctx = nullptr;
     std::atomic<int> patch_cap_hint{0};
-    std::atomic<size_t> pidx_hint{0};  // the longest patch index list of a subject so far: the next one's is compacted before the look at its counts
+    std::atomic<size_t> pidx_hint{0};
+    // a uniform grid over the template's vertices for the range test of a set-up's patch lists (built by group_setup_pipeline, valid while it runs)
+    DevBuf<int> d_rg_start, d_rg_cursor, d_rg_ids, d_rg_bad, d_rg_tmp;
+    RangeGrid rgrid;
+    bool rgrid_valid = false;  // the longest patch index list of a subject so far: the next one's is compacted before the look at its counts
     int patch_max = 0;  // largest patch of any subject (msm_group_finalize)
     int pair_lanes = 32;  // lanes per query of k_group_pairwise: 16 when nearly all patches fit a quarter wavefront's registers (msm_group_finalize)
     msm_group_params p{};
@@ -233,7 +237,8 @@ int subject_patches(msm_group *g, int s, msm_ctx *ctx = nullptr, msm_group::Pipe
     bool early = false;
     for (int attempt = 0; attempt < 3; ++attempt) {
         MSM_HIP(d_slots.ensure((size_t)M * cap));
-        int st = launch_range(ctx, d_c.p, M, g->tmpl->d_xyz, Vt, d_sep.p, g->p.range, cap, d_slots.p, d_counts.p, pipe->d_chunkb.p, d_counts.p + M, L);
+        int st = launch_range(ctx, d_c.p, M, g->tmpl->d_xyz, Vt, d_sep.p, g->p.range, cap, d_slots.p, d_counts.p, pipe->d_chunkb.p, d_counts.p + M, L,
+                              g->rgrid_valid ? &g->rgrid : nullptr);
         if (st) return st;
         early = attempt == 0 && list_hint > 0;
         if (early) {
@@ -1161,6 +1166,24 @@ static int group_setup_pipeline(msm_group *g, const int32_t *subjects, int n) {
     if (st) return st;
     st = ensure_adjacency_dev(g->tmpl);
     if (st) return st;
+    {   // the grid the subjects' range tests take their candidates from (subject_patches): cells of about a sixteenth of the sphere's diameter
+        const int G = g->tmpl->V > 60000 ? 64 : 32;
+        const size_t cells = (size_t)G * G * G;
+        MSM_HIP(g->d_rg_start.ensure(cells + 1));
+        MSM_HIP(g->d_rg_cursor.ensure(cells));
+        MSM_HIP(g->d_rg_ids.ensure((size_t)g->tmpl->V));
+        MSM_HIP(g->d_rg_bad.ensure(1));
+        MSM_HIP(g->d_rg_tmp.ensure(cells / 4096 + 2));
+        const double origin = -1.01 * kRad, inv_h = (double)G / (2.02 * kRad);
+        st = launch_range_grid_build(ctx, g->tmpl->d_xyz, g->tmpl->V, G, origin, inv_h, g->d_rg_start.p, g->d_rg_cursor.p, g->d_rg_ids.p, g->d_rg_bad.p, g->d_rg_tmp.p);
+        if (st) return st;
+        g->rgrid.start = g->d_rg_start.p, g->rgrid.ids = g->d_rg_ids.p, g->rgrid.bad = g->d_rg_bad.p, g->rgrid.G = G, g->rgrid.origin = origin, g->rgrid.inv_h = inv_h;
+        g->rgrid_valid = true;
+    }
+    struct GridScope {  // the template may move before anybody else asks for patch lists
+        msm_group *g;
+        ~GridScope() { g->rgrid_valid = false; }
+    } grid_scope{g};
     for (int i = 0; i < n; ++i) {
         if (!g->data[subjects[i]]) return fail(MSM_ERR_STATE, "msm_group: subject %d has no data", subjects[i]);
         st = ensure_adjacency_dev(g->data[subjects[i]]);

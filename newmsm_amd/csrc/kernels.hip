@@ -3,6 +3,7 @@
 // All arithmetic that decides an index (which triangle, which patch) is FP64 in the reference's own
 // operation order (this file is compiled with -ffp-contract=off).  No MFMA: the path is gather /
 // compare / short reductions.  Wavefront = 64 lanes throughout.
+#include <climits>
 #include <cstring>
 #include <algorithm>
 
@@ -620,6 +621,27 @@ __global__ __launch_bounds__(256) void k_range(const double *__restrict__ cp, in
     if (threadIdx.x == 0) counts[k] = running;
 }
 
+__device__ __forceinline__ int grid_cell(double x, const RangeGrid &g) {
+    const double f = floor((x - g.origin) * g.inv_h);  // monotone in x: a point within R of m lies in a cell between those of m - R and m + R
+    return f < 0.0 ? 0 : (f >= (double)g.G ? g.G - 1 : (int)f);
+}
+__global__ __launch_bounds__(256) void k_range_grid_count(const double *__restrict__ src, int Nsrc, RangeGrid g, int *__restrict__ count, int *__restrict__ bad) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Nsrc) return;
+    const double x = src[i], y = src[Nsrc + i], z = src[2 * (size_t)Nsrc + i];
+    if (!(fabs(x) <= 1e300 && fabs(y) <= 1e300 && fabs(z) <= 1e300)) {  // NaN or infinite: such a vertex is a candidate of every centre (k_range flags it)
+        *bad = 1;
+        return;
+    }
+    atomicAdd(&count[(grid_cell(x, g) * g.G + grid_cell(y, g)) * g.G + grid_cell(z, g)], 1);
+}
+__global__ __launch_bounds__(256) void k_range_grid_fill(const double *__restrict__ src, int Nsrc, RangeGrid g, int *__restrict__ cursor, int *__restrict__ ids) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Nsrc || *g.bad) return;
+    const int cell = (grid_cell(src[i], g) * g.G + grid_cell(src[Nsrc + i], g)) * g.G + grid_cell(src[2 * (size_t)Nsrc + i], g);
+    ids[g.start[cell] + atomicAdd(&cursor[cell], 1)] = i;
+}
+
 // The same test for centres that come in clusters (gMSM: the L candidate positions of a control point, consecutive in the list and within a label
 // radius of one another).  k_range spends most of its time on what the cluster has in common: every centre's workgroup tests all the chunks' balls
 // (641 of them on an ico6 template, for a patch that touches ten) and takes three block barriers per four chunks.  Here a workgroup takes a cluster of
@@ -629,11 +651,13 @@ __global__ __launch_bounds__(256) void k_range(const double *__restrict__ cp, in
 // range), so rows, order and flags are k_range's.
 __global__ __launch_bounds__(256) void k_range_cluster(const double *__restrict__ cp, int Ncp, int cluster, const double *__restrict__ src, int Nsrc,
                                                         const double4 *__restrict__ cb, const double *__restrict__ maxsep, double range, int cap,
-                                                        uint32_t *__restrict__ slots, int *__restrict__ counts, int *__restrict__ nflag) {
+                                                        uint32_t *__restrict__ slots, int *__restrict__ counts, int *__restrict__ nflag, RangeGrid grid) {
     const int k0 = blockIdx.x * cluster, n = min(cluster, Ncp - k0);  // cluster <= 64
     if (n <= 0) return;
     constexpr int kTile = 1024;
     __shared__ int cand[kTile];
+    __shared__ double s_px[kTile], s_py[kTile], s_pz[kTile];  // the grid path: the candidates' coordinates
+    __shared__ int s_n;
     __shared__ int wave_count[4];
     __shared__ int ncand;
     __shared__ int s_run[64];
@@ -658,6 +682,71 @@ __global__ __launch_bounds__(256) void k_range_cluster(const double *__restrict_
     __syncthreads();
     const V3 bc = mk(s_ball[0], s_ball[1], s_ball[2]);
     const double breach = s_ball[3];
+    // With a grid over the source vertices (round 5): consecutive ids are NOT neighbours on an icosphere -- the ball of 64 consecutive vertices of an ico6
+    // mesh has a radius of 30 on a sphere of radius 100, 66 of 641 chunks pass a centre's test and 4 200 points are looked at for a patch of 60 -- so the
+    // candidates come from the cells the cluster's ball touches (some 350 vertices), are sorted by id once for the cluster and tested by every centre
+    // from LDS.  Same tests on the same points in the same order: rows, order and flags are the sweep's, which stays for what does not fit (more than
+    // kTile candidates, a grid with a non-finite vertex, a NaN centre).
+    if (grid.start && !*grid.bad && fabs(bc.x) <= 1e300 && fabs(bc.y) <= 1e300 && fabs(bc.z) <= 1e300 && breach >= 0.0 && breach <= 1e300) {  // uniform
+        const int G = grid.G;
+        const int x0 = grid_cell(bc.x - breach, grid), x1 = grid_cell(bc.x + breach, grid), y0 = grid_cell(bc.y - breach, grid), y1 = grid_cell(bc.y + breach, grid);
+        const int z0 = grid_cell(bc.z - breach, grid), z1 = grid_cell(bc.z + breach, grid);
+        const int ny = y1 - y0 + 1, nz = z1 - z0 + 1, ncell = (x1 - x0 + 1) * ny * nz;
+        if (ncell <= 4096) {
+            if (threadIdx.x == 0) s_n = 0;
+            __syncthreads();
+            for (int t = threadIdx.x; t < ncell; t += 256) {
+                const int cell = ((x0 + t / (ny * nz)) * G + y0 + (t / nz) % ny) * G + z0 + t % nz;
+                const int b = grid.start[cell], len = grid.start[cell + 1] - b;
+                if (len > 0) {
+                    const int at = atomicAdd(&s_n, len);
+                    for (int j = 0; j < len && at + j < kTile; ++j) cand[at + j] = grid.ids[b + j];
+                }
+            }
+            __syncthreads();
+            const int nc = s_n;
+            if (nc <= kTile) {  // uniform
+                int P = 64;
+                while (P < nc) P <<= 1;
+                for (int t = nc + threadIdx.x; t < P; t += 256) cand[t] = INT_MAX;
+                __syncthreads();
+                for (int kk = 2; kk <= P; kk <<= 1)  // ascending ids (bitonic: the cells come in no order)
+                    for (int j = kk >> 1; j > 0; j >>= 1) {
+                        for (int t = threadIdx.x; t < (P >> 1); t += 256) {
+                            const int i = 2 * t - (t & (j - 1)), l = i + j;
+                            const int a = cand[i], b = cand[l];
+                            if ((a > b) == ((i & kk) == 0)) cand[i] = b, cand[l] = a;
+                        }
+                        __syncthreads();
+                    }
+                for (int t = threadIdx.x; t < nc; t += 256) {
+                    const int i = cand[t];
+                    s_px[t] = src[i], s_py[t] = src[Nsrc + i], s_pz[t] = src[2 * (size_t)Nsrc + i];
+                }
+                __syncthreads();
+                for (int t = wave; t < n; t += 4) {  // wavefront-uniform: this wavefront's centres
+                    const int k = k0 + t;
+                    const V3 c = mk(cp[k], cp[Ncp + k], cp[2 * (size_t)Ncp + k]);
+                    const RangeBand band = range_band(range * maxsep[k]);
+                    int run = 0;
+                    for (int base = 0; base < nc; base += 64) {  // uniform
+                        const int ci = base + lane;
+                        const int i = ci < nc ? cand[ci] : 0;
+                        const int state = ci < nc ? range_state(c, mk(s_px[ci], s_py[ci], s_pz[ci]), band) : 0;
+                        const unsigned long long hit = __ballot(state != 0);
+                        if (state != 0) {
+                            const int pos = run + __popcll(hit & ((1ull << lane) - 1));
+                            if (pos < cap) slots[(size_t)k * cap + pos] = (uint32_t)i | (state == 2 ? 0x80000000u : 0u);
+                            if (state == 2) atomicAdd(nflag, 1);
+                        }
+                        run += __popcll(hit);
+                    }
+                    if (lane == 0) counts[k] = run;
+                }
+                return;
+            }
+        }
+    }
     const int nchunks = (Nsrc + 63) >> 6;
     for (int tile = 0; tile < nchunks; tile += kTile) {
         __syncthreads();  // the previous tile's list is no longer read
@@ -699,18 +788,30 @@ __global__ __launch_bounds__(256) void k_range_cluster(const double *__restrict_
                     keep = !(norm(sub(c, mk(b.x, b.y, b.z))) - b.w > reach);
                 }
                 unsigned long long todo = __ballot(keep);
-                while (todo) {  // uniform: the chunks that pass, ascending
-                    const int j = __ffsll((long long)todo) - 1;
-                    todo &= todo - 1;
-                    const int i = __shfl(mych, j, 64) * 64 + lane;
-                    const int state = i < Nsrc ? range_state(c, mk(src[i], src[Nsrc + i], src[2 * (size_t)Nsrc + i]), band) : 0;
-                    const unsigned long long hit = __ballot(state != 0);
-                    if (state != 0) {
-                        const int pos = run + __popcll(hit & ((1ull << lane) - 1));
-                        if (pos < cap) slots[(size_t)k * cap + pos] = (uint32_t)i | (state == 2 ? 0x80000000u : 0u);
-                        if (state == 2) atomicAdd(nflag, 1);
+                while (todo) {  // uniform: the chunks that pass, ascending, four at a time (their twelve loads in flight together: one chunk per round was a chain
+                                // of dependent loads, 25 rounds per centre)
+                    constexpr int kU = 4;
+                    int i[kU];
+                    V3 q[kU];
+#pragma unroll
+                    for (int u = 0; u < kU; ++u) {
+                        const bool any = todo != 0;
+                        const int j = any ? __ffsll((long long)todo) - 1 : 0;
+                        if (any) todo &= todo - 1;
+                        i[u] = any ? __shfl(mych, j, 64) * 64 + lane : Nsrc;
+                        q[u] = i[u] < Nsrc ? mk(src[i[u]], src[Nsrc + i[u]], src[2 * (size_t)Nsrc + i[u]]) : mk(0, 0, 0);
                     }
-                    run += __popcll(hit);
+#pragma unroll
+                    for (int u = 0; u < kU; ++u) {
+                        const int state = i[u] < Nsrc ? range_state(c, q[u], band) : 0;
+                        const unsigned long long hit = __ballot(state != 0);
+                        if (state != 0) {
+                            const int pos = run + __popcll(hit & ((1ull << lane) - 1));
+                            if (pos < cap) slots[(size_t)k * cap + pos] = (uint32_t)i[u] | (state == 2 ? 0x80000000u : 0u);
+                            if (state == 2) atomicAdd(nflag, 1);
+                        }
+                        run += __popcll(hit);
+                    }
                 }
             }
             if (lane == 0) s_run[t] = run;  // only this wavefront reads it again (next tile)
@@ -964,8 +1065,25 @@ int launch_sort_patches(msm_ctx *ctx, const double *d_xyz, int n, const int32_t 
     return MSM_OK;
 }
 
+int launch_range_grid_build(msm_ctx *ctx, const double *d_src, int Nsrc, int G, double origin, double inv_h, int *d_start, int *d_cursor, int *d_ids, int *d_bad, int *d_tmp) {
+    if (Nsrc <= 0 || G <= 0) return MSM_OK;
+    const size_t cells = (size_t)G * G * G;
+    MSM_HIP(hipMemsetAsync(d_start, 0, sizeof(int) * (cells + 1), ctx->stream));
+    MSM_HIP(hipMemsetAsync(d_cursor, 0, sizeof(int) * cells, ctx->stream));
+    MSM_HIP(hipMemsetAsync(d_bad, 0, sizeof(int), ctx->stream));
+    RangeGrid g;
+    g.start = d_start, g.ids = d_ids, g.bad = d_bad, g.G = G, g.origin = origin, g.inv_h = inv_h;
+    hipLaunchKernelGGL(k_range_grid_count, dim3((Nsrc + 255) / 256), dim3(256), 0, ctx->stream, d_src, Nsrc, g, d_start, d_bad);
+    MSM_HIP(hipGetLastError());
+    int st = launch_scan_exclusive(ctx, d_start, (int)cells, d_tmp);
+    if (st) return st;
+    hipLaunchKernelGGL(k_range_grid_fill, dim3((Nsrc + 255) / 256), dim3(256), 0, ctx->stream, d_src, Nsrc, g, d_cursor, d_ids);
+    MSM_HIP(hipGetLastError());
+    return MSM_OK;
+}
+
 int launch_range(msm_ctx *ctx, const double *d_cp, int Ncp, const double *d_src, int Nsrc, const double *d_maxsep, double range,
-                 int cap, uint32_t *d_slots, int *d_counts, double4 *d_chunk_bounds, int *d_nflag, int cluster) {
+                 int cap, uint32_t *d_slots, int *d_counts, double4 *d_chunk_bounds, int *d_nflag, int cluster, const RangeGrid *grid) {
     if (Ncp <= 0) return MSM_OK;
     const int nchunks = (Nsrc + 63) / 64;
     MSM_HIP(hipMemsetAsync(d_nflag, 0, sizeof(int), ctx->stream));
@@ -973,8 +1091,9 @@ int launch_range(msm_ctx *ctx, const double *d_cp, int Ncp, const double *d_src,
     static const bool cluster_off = [] { const char *e = std::getenv("MSMHIP_RANGE_CLUSTER"); return e && std::strcmp(e, "off") == 0; }();
     if (cluster > 1 && nchunks > 0 && !cluster_off) {
         const int per = cluster <= 64 ? cluster : 32;  // centres that are consecutive in the list are neighbours either way
+        static const bool grid_off = [] { const char *e = std::getenv("MSMHIP_RANGE_GRID"); return e && std::strcmp(e, "off") == 0; }();
         hipLaunchKernelGGL(k_range_cluster, dim3((Ncp + per - 1) / per), dim3(256), 0, ctx->stream, d_cp, Ncp, per, d_src, Nsrc, d_chunk_bounds, d_maxsep, range, cap, d_slots,
-                           d_counts, d_nflag);
+                           d_counts, d_nflag, grid && !grid_off ? *grid : RangeGrid{});
     } else
         hipLaunchKernelGGL(k_range, dim3(Ncp), dim3(256), 0, ctx->stream, d_cp, Ncp, d_src, Nsrc, d_chunk_bounds, d_maxsep, range, cap, d_slots, d_counts, d_nflag);
     MSM_HIP(hipGetLastError());

@@ -68,10 +68,19 @@ int launch_fold_detect(msm_ctx *ctx, const double *d_xyz, int V, const int32_t *
 // d_sorted = each patch's members (d_pidx, CSR d_pptr) in Morton order of their positions d_xyz (3 x n SoA); d_code: n scratch words
 int launch_sort_patches(msm_ctx *ctx, const double *d_xyz, int n, const int32_t *d_pptr, int ngroups, const int32_t *d_pidx, uint32_t *d_code,
                         int32_t *d_sorted);
+// A uniform grid over the source vertices for launch_range's clustered form: cell (ix, iy, iz) = G * (G * ix + iy) + iz holds ids[start[cell] .. start[cell + 1]) in no
+// particular order; *bad != 0: a vertex is not finite and the grid is not used.  Cell of a coordinate x: floor((x - origin) * inv_h) clamped to [0, G).
+struct RangeGrid {
+    const int *start = nullptr, *ids = nullptr, *bad = nullptr;
+    int G = 0;
+    double origin = 0.0, inv_h = 0.0;
+};
+// start: G^3 + 1 ints, cursor: G^3 ints, ids: Nsrc ints, bad: 1 int, tmp: G^3 / 4096 + 2 ints
+int launch_range_grid_build(msm_ctx *ctx, const double *d_src, int Nsrc, int G, double origin, double inv_h, int *d_start, int *d_cursor, int *d_ids, int *d_bad, int *d_tmp);
 // d_chunk_bounds: scratch, one double4 per 64 source vertices; *d_nflag (device int) = entries flagged as undecided (bit 31);
 // cluster > 1: every `cluster` consecutive centres lie close together (gMSM: a control point's L candidate positions) and share the pruning
 int launch_range(msm_ctx *ctx, const double *d_cp, int Ncp, const double *d_src, int Nsrc, const double *d_maxsep, double range, int cap,
-                 uint32_t *d_slots, int *d_counts, double4 *d_chunk_bounds, int *d_nflag, int cluster = 1);
+                 uint32_t *d_slots, int *d_counts, double4 *d_chunk_bounds, int *d_nflag, int cluster = 1, const RangeGrid *grid = nullptr);
 // rows of slots -> the contiguous list d_pidx at the offsets d_pptr (M + 1, already summed); valid when nothing was flagged
 int launch_patch_compact(msm_ctx *ctx, const uint32_t *d_slots, int cap, const int32_t *d_pptr, int M, int32_t *d_pidx, size_t pidx_cap = (size_t)-1);
 // data[0 .. n) -> its exclusive prefix sums in place, data[n] = the total; tmp: n / 4096 + 2 ints

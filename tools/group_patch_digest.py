@@ -1,0 +1,23 @@
+"""tools/group_patch_digest.py [S] -- sha256 over the exported set-up products (resampled maps, patch row offsets, patch index lists) of S subjects at ico6 / ico4:
+two builds or two settings of the library (MSMHIP_RANGE_GRID=off, MSMHIP_RANGE_CLUSTER=off, ...) must print the same digest."""
+import hashlib
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import newmsm_amd as M
+from newmsm_amd import problem
+
+S = int(sys.argv[1]) if len(sys.argv) > 1 else 6
+ctx = M.Context(0)
+g, keep = problem.build_group(ctx, S, 6, 4, D=2)
+g.setupCostFunction()
+h = hashlib.sha256()
+n = 0
+for s in range(S):
+    F, pptr, pidx = g.export_subject(s)
+    for a in (F, pptr, pidx):
+        h.update(np.ascontiguousarray(a).tobytes())
+    n += len(pidx)
+print("digest %s  (%d subjects, %d patch entries)" % (h.hexdigest()[:32], S, n))
