@@ -371,6 +371,7 @@ int group_args(msm_group *g, GroupArgs &a) {
     a.move_label = a.move_offset = 0;
     a.move_order = nullptr;
     a.move_order4 = nullptr;
+    a.move_first = a.move_count = 0;
     a.move_base = 0;
     a.move_combos = 0;
     a.move_prev = nullptr;
@@ -1987,6 +1988,8 @@ static int group_move_compute_untimed(msm_group *g, const int32_t *labeling, int
                 st = launch_group_kept(ctx, a.move_order + n0, (int)pair0, a.move_e11, (int)(n1 - n0), quads_dev);
                 if (st) return st;
             }
+            static const bool by_four = [] { const char *e = std::getenv("MSMHIP_GROUP_BY_FOUR"); return !(e && std::strcmp(e, "off") == 0); }();
+            a.move_first = (int)n0, a.move_count = by_four ? (int)(n1 - n0) : 0;
             for (int pass = two_pass ? 1 : 0; pass <= (two_pass ? 2 : 0); ++pass) {
                 const int64_t mult = pass == 0 ? 4 : (pass == 1 ? 1 : (have11 ? 2 : 3)), q0 = mult * n0, q1 = mult * n1;
                 a.move_combos = pass == 2 && have11 ? 3 : pass;
@@ -2010,6 +2013,7 @@ static int group_move_compute_untimed(msm_group *g, const int32_t *labeling, int
         }
         if (a.move_e11) g->e11_have[(size_t)label] = 1;
         a.move_combos = 0;
+        a.move_first = a.move_count = 0;
         a.move_prev = nullptr;
         a.move_e00 = nullptr;
         a.move_e11 = nullptr;

@@ -177,8 +177,21 @@ __global__ __launch_bounds__(256) void k_group_pairwise(GroupArgs a, const int *
     double *keep = nullptr;  // where this query's cost is kept for the next label step
     if (a.move_labeling) {  // Fusion's pair_data[pair].buffer[k], I/Fusion/Fusion.h:170-173: k = 2 * (A takes the label) + (B takes it)
         const int e = q + a.move_offset;
-        const int idx = a.move_combos == 0 ? e >> 2 : (a.move_combos == 1 ? e : (a.move_combos == 2 ? e / 3 : e >> 1));
-        const int k = a.move_combos == 0 ? (e & 3) : (a.move_combos == 1 ? 0 : (a.move_combos == 2 ? 1 + (e - 3 * idx) : 1 + (e & 1)));
+        int idx = a.move_combos == 0 ? e >> 2 : (a.move_combos == 1 ? e : (a.move_combos == 2 ? e / 3 : e >> 1));
+        int k = a.move_combos == 0 ? (e & 3) : (a.move_combos == 1 ? 0 : (a.move_combos == 2 ? 1 + (e - 3 * idx) : 1 + (e & 1)));
+        if (a.move_order4 && a.move_count > 0 && a.move_combos != 1) {  // four positions at a time, combination by combination (GroupArgs::move_first)
+            const int m = a.move_combos == 0 ? 4 : (a.move_combos == 2 ? 3 : 2);
+            const int r = e - m * a.move_first, full = a.move_count & ~3;
+            int ks;
+            if (r < m * full) {
+                const int c = r / (4 * m), j = r - c * 4 * m;
+                idx = a.move_first + 4 * c + (j & 3), ks = j >> 2;
+            } else {
+                const int r2 = r - m * full, p = r2 / m;
+                idx = a.move_first + full + p, ks = r2 - p * m;
+            }
+            k = a.move_combos == 0 ? ks : 1 + ks;
+        }
         int nodeA, nodeB;
         if (a.move_order4) {  // (round 5: one 16-byte load for the position's pair and its nodes)
             const int4 o = a.move_order4[idx];

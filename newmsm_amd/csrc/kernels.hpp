@@ -278,6 +278,12 @@ struct GroupArgs {
     // from the first sweep of Fusion to the second (set with combination 3 evaluated: written; with move_combos 3: the launch evaluates
     // only combinations 1 and 2, query i -> pair i / 2, combination 1 + i % 2, and launch_group_kept copies the kept costs).
     int move_combos;
+    // Round 5: with move_order4 and more than one combination per pair the evaluations of a launch's piece (positions [move_first, move_first + move_count) of the
+    // order) are enumerated FOUR POSITIONS AT A TIME, combination by combination: evaluation r of the piece = chunk r / (4 m), within it combination (r % (4 m)) / 4 of
+    // position 4 chunk + r % 4 (m combinations per pair; the last move_count % 4 positions pair by pair as before).  The four lane groups of a wavefront then hold
+    // the same combination of four consecutive pairs -- in the control-point-major order these share their first node, so patch A is the same memory for all
+    // four and the wavefront's loads of it touch a quarter of the cache lines.  move_count 0: pair by pair (evaluation i -> pair i / m, combination i % m).
+    int move_first, move_count;
     const int *move_prev;
     double *move_e00;
     double *move_e11;
