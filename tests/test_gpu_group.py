@@ -720,3 +720,25 @@ def test_host_rotations_on_regular_spheres(ctx):
         assert np.allclose(a, b, rtol=1e-9)
     for s in range(S):
         assert angles(got[0][s], want[0][s]).max() <= 1e-4 and np.abs(got[0][s] - want[0][s]).max() < 1e-8
+
+
+@pytest.mark.gpu
+def test_patch_lists_do_not_depend_on_how_the_range_test_finds_its_candidates():
+    """The range test of gMSM's patch lists (get_patch_data, M/DiscreteGroupModel.cpp:109-117) draws its candidates from a grid over the template, sorted by id per
+    control point (round 5); what does not fit takes the sweep over 64-id chunks, and MSMHIP_RANGE_CLUSTER=off the kernel that takes every centre on its own.  The
+    three must give the same rows in the same order: one digest over the exported maps, row offsets and index lists (ico5 / ico3: 12 k centres per subject; ico5 / ico1:
+    patches of a thousand entries, beyond the grid path's candidate list)."""
+    import os
+    import subprocess
+    import sys as _sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for sizes in (("4", "5", "3"), ("2", "5", "1")):
+        seen = set()
+        for env in ({}, {"MSMHIP_RANGE_GRID": "off"}, {"MSMHIP_RANGE_CLUSTER": "off"}):
+            r = subprocess.run([_sys.executable, os.path.join(root, "tools", "group_patch_digest.py"), *sizes], env={**os.environ, **env}, capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, r.stderr[-2000:]
+            line = [x for x in r.stdout.splitlines() if x.startswith("digest ")]
+            assert line, r.stdout
+            seen.add(line[0])
+        assert len(seen) == 1, seen

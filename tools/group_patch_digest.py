@@ -1,4 +1,4 @@
-"""tools/group_patch_digest.py [S] -- sha256 over the exported set-up products (resampled maps, patch row offsets, patch index lists) of S subjects at ico6 / ico4:
+"""tools/group_patch_digest.py [S] [data_order cp_order] -- sha256 over the exported set-up products (resampled maps, patch row offsets, patch index lists) of S subjects (default: ico6 / ico4):
 two builds or two settings of the library (MSMHIP_RANGE_GRID=off, MSMHIP_RANGE_CLUSTER=off, ...) must print the same digest."""
 import hashlib
 import os
@@ -10,8 +10,9 @@ import newmsm_amd as M
 from newmsm_amd import problem
 
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 6
+do, co = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (6, 4)
 ctx = M.Context(0)
-g, keep = problem.build_group(ctx, S, 6, 4, D=2)
+g, keep = problem.build_group(ctx, S, do, co, D=2)
 g.setupCostFunction()
 h = hashlib.sha256()
 n = 0
