@@ -371,9 +371,9 @@ __global__ __launch_bounds__(256) void k_group_pairwise(GroupArgs a, const int *
                 double c_row;                     // this lane's row's similarity
                 if (a.simmeasure == 2) {  // sparsesimkernel::corr, M/similarities.cpp:129-158, both feature rows side by side
                     double s1[5] = {0.0, 0.0, 0.0, 0.0, 0.0};  // sum of weights, then weighted sums of A and B per row
+                    if (a.mask) {
 #pragma unroll
-                    for (int r = 0; r < kRounds; ++r)
-                        {
+                        for (int r = 0; r < kRounds; ++r) {
                             s1[0] += w[r];
 #pragma unroll
                             for (int d = 0; d < 2; ++d) {
@@ -381,6 +381,17 @@ __global__ __launch_bounds__(256) void k_group_pairwise(GroupArgs a, const int *
                                 s1[2 + 2 * d] += w[r] * vb[r][d];
                             }
                         }
+                    } else {  // weights 1 (in the intersection) or 0 with values 0 (outside): w * v IS v, bit for bit -- twenty multiplications less per lane
+#pragma unroll
+                        for (int r = 0; r < kRounds; ++r) {
+                            s1[0] += w[r];
+#pragma unroll
+                            for (int d = 0; d < 2; ++d) {
+                                s1[1 + 2 * d] += va[r][d];
+                                s1[2 + 2 * d] += vb[r][d];
+                            }
+                        }
+                    }
                     // every lane group divides ITS sum by the sum of weights: one division for the four means
                     double y = half_reduce<5, kQ>(s1, lane);
                     const double sw = half_get<kQ>(y, 0);
@@ -425,7 +436,7 @@ __global__ __launch_bounds__(256) void k_group_pairwise(GroupArgs a, const int *
                 // cost = (row 0 [+ row 1]) / D, the rows added in the reference's order
                 const double c0 = __shfl(c_row, ((threadIdx.x & 63) & ~(kQ - 1)), 64), c1 = __shfl(c_row, ((threadIdx.x & 63) & ~(kQ - 1)) | (kQ / 2), 64);
                 cost = two ? c0 + c1 : c0;
-                cost /= a.D;
+                if (two) cost *= 0.5;  // x / 2 exactly (the division is a dozen instructions)
             }
             if (a.fixnan && cost != cost) cost = 1e7;  // FIX_NAN, M/reg_tools.h:31
             if (lane == 0) {
