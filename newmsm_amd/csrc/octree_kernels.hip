@@ -119,6 +119,19 @@ __device__ __forceinline__ OctWork tree_view(OctWork w) {
     return w;
 }
 
+// a triangle's box (lower corner, upper corner) as three 16-byte loads: the six 8-byte loads the compiler makes of `bx[a]` (it only knows the array to be 8-byte
+// aligned) are six L1 look-ups per lane of a divergent gather -- the boxes start on 16-byte boundaries (48-byte records in a pool block)
+struct Box6 {
+    double v[6];
+};
+__device__ __forceinline__ Box6 load_box(const double *box, int t) {
+    const double2 *q = reinterpret_cast<const double2 *>(box + (size_t)6 * t);
+    const double2 a = q[0], b = q[1], c = q[2];
+    Box6 r;
+    r.v[0] = a.x, r.v[1] = a.y, r.v[2] = b.x, r.v[3] = b.y, r.v[4] = c.x, r.v[5] = c.y;
+    return r;
+}
+
 // the 8 overlap flags of a triangle box against the children of a node (Node::can_contain on each child, R/node.cpp:108-116):
 // per axis the child box is the parent's [lower, middle] or [middle, upper]
 __device__ __forceinline__ unsigned child_flags(const double *bx, const double lo[3], const double mid[3], const double hi[3]) {
@@ -179,7 +192,8 @@ __global__ __launch_bounds__(256) void k_oct_decide(OctWork w) {
                 const int i = base + lane;
                 int s = 0, q = 0;
                 if (i < len) {
-                    const double *bx = w.box + (size_t)6 * list[i];
+                    const Box6 b6 = load_box(w.box, list[i]);
+                    const double *bx = b6.v;
                     s = 8;
 #pragma unroll
                     for (int d = 0; d < 3; ++d)
@@ -212,7 +226,11 @@ __global__ __launch_bounds__(256) void k_oct_count(OctWork w) {
         double lo[3], mid[3], hi[3];
         node_box(w.nodebox[n], lo, mid, hi);
         const int i = beg + lane;
-        const unsigned f = i < len ? child_flags(w.box + (size_t)6 * list[i], lo, mid, hi) : 0u;
+        unsigned f = 0u;
+        if (i < len) {
+            const Box6 b6 = load_box(w.box, list[i]);
+            f = child_flags(b6.v, lo, mid, hi);
+        }
         if (i < len) w.flags[w.open_off[cur][o] + i] = (unsigned char)f;
         int mine = 0;
 #pragma unroll
