@@ -474,8 +474,7 @@ def gmsm_iteration(ctx, S, data_order, cp_order, comm, label_steps, change=0.10)
     for _ in range(3):  # iterations 2 - 4 of a level's nine: the median (the second still sizes a few hints -- list capacities, the forests' depth -- from the first)
         comm.barrier()
         t0 = time.perf_counter()
-        D.sharded_group_setup(g, S, comm)
-        comm.barrier()
+        D.sharded_group_setup(g, S, comm)  # complete on return (its collectives waited for, the library's stream synchronised); the slowest rank's time counts (max_over_ranks)
         setups.append(time.perf_counter() - t0)
     setup_s = sorted(setups)[1]
     mover = D.ShardedMove(g, comm)

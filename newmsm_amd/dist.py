@@ -212,7 +212,10 @@ def sharded_group_setup(group, n_subjects, comm=None, chunks=None, pair_layout=N
     if pair_layout is not None:
         group.set_pair_layout(pair_layout)
     mine = list(shard(n_subjects, c.rank, c.world))
-    if c.dist is None:
+    # one rank has nobody to exchange with (as include/msmhip_rccl.hpp: `if (c.world() > 1)`): until round 5 a launched one-rank run exported its 64 subjects into
+    # torch tensors and all-gathered them to itself, 1.65 GB twice and the set-up in two pieces -- 11 ms of bench.py's 104.5.  MSMHIP_DIST_EXCHANGE=always keeps
+    # that path (tests/test_gpu_group.py drives the device-resident exchange over RCCL with the one rank a one-GPU box allows).
+    if c.dist is None or (c.world == 1 and os.environ.get("MSMHIP_DIST_EXCHANGE") != "always"):
         group.setup_subjects(mine)
         group.finalize()
         return mine

@@ -333,7 +333,8 @@ def test_sharded_group_one_rank_over_rccl(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / "sharded_nccl.py"
     script.write_text(NCCL_WORKER % root)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29563", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29563", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0",
+               MSMHIP_DIST_EXCHANGE="always")  # (a one-rank run skips the exchange by default: nobody to exchange with)
     pr = subprocess.run([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=500)
     assert pr.returncode == 0, pr.stderr[-3000:]
     o = eval(pr.stdout.strip().splitlines()[-1].replace("true", "True").replace("false", "False"))
