@@ -83,7 +83,7 @@ def anatomical_inputs(ctx, inp, anat_order=None, seed=99):
     return dict(grid, anat_order=anat_order, asource_xyz=d * rs[:, None], atarget_xyz=d * rt[:, None])
 
 
-def build_group(ctx, S, data_order=6, cp_order=4, D=2, subjects=None, lambda_=0.2, simmeasure=2, seed=40, template_order=None):
+def build_group(ctx, S, data_order=6, cp_order=4, D=2, subjects=None, lambda_=0.2, simmeasure=2, seed=40, template_order=None, label_order_offset=2):
     """A synthetic groupwise (gMSM) problem part-way through a registration, BASELINE config 5 shape: S subjects on the data grid
     ico<data_order>, each with its own smooth warp so far and D feature rows, the template = the regular sphere at data
     resolution, control grid ico<cp_order>, the unrescaled sampling-grid labels (DiscreteGroupModel::setupCostFunction
@@ -92,7 +92,7 @@ def build_group(ctx, S, data_order=6, cp_order=4, D=2, subjects=None, lambda_=0.
     dxyz, dtri = api.make_mesh_from_icosa(data_order)
     cxyz, ctri = api.make_mesh_from_icosa(cp_order)
     _, mvd = api.cp_spacings(cxyz, ctri)
-    samples, _ = api.label_sampling_grid(cp_order + 2, 0.5 * mvd)
+    samples, _ = api.label_sampling_grid(cp_order + label_order_offset, 0.5 * mvd)  # (offset 2: the 19 labels of the reference's sampling grid; 3, 4: 61, 217 -- tests)
     g = api.DiscreteGroupCostFunction(ctx, S, simmeasure=simmeasure, lambda_=lambda_)
     txyz, ttri = dxyz, dtri
     if template_order == "morton":  # the same template with its vertices renumbered along a space-filling curve

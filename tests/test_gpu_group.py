@@ -734,7 +734,8 @@ def test_patch_lists_do_not_depend_on_how_the_range_test_finds_its_candidates():
     import sys as _sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for sizes in (("4", "5", "3"), ("2", "5", "1")):
+    # (the last two: 61 and 217 labels per control point -- clusters of up to 64 centres, and a control point's centres in clusters of 32)
+    for sizes in (("4", "5", "3"), ("2", "5", "1"), ("2", "4", "2", "3"), ("2", "3", "1", "4")):
         seen = set()
         for env in ({}, {"MSMHIP_RANGE_GRID": "off"}, {"MSMHIP_RANGE_CLUSTER": "off"}):
             r = subprocess.run([_sys.executable, os.path.join(root, "tools", "group_patch_digest.py"), *sizes], env={**os.environ, **env}, capture_output=True, text=True, timeout=600)
