@@ -14,12 +14,12 @@ pytestmark = pytest.mark.gpu
 RTOL, ATOL = 1e-9, 1e-11
 
 
-def build(ctx, S=3, data_order=4, cp_order=2, D=2, mask=False, sim=2, percentile=0.75, subject_orders=None):
+def build(ctx, S=3, data_order=4, cp_order=2, D=2, mask=False, sim=2, percentile=0.75, subject_orders=None, label_order_offset=2):
     dxyz, dtri = M.make_mesh_from_icosa(data_order)
     cxyz, ctri = M.make_mesh_from_icosa(cp_order)
     txyz, ttri = dxyz, dtri  # template space = a regular sphere at data resolution
     _, mvd = M.cp_spacings(cxyz, ctri)
-    samples, _ = M.label_sampling_grid(cp_order + 2, 0.5 * mvd)
+    samples, _ = M.label_sampling_grid(cp_order + label_order_offset, 0.5 * mvd)
     mk = (np.cos(txyz[:, 0] / 30.0) if mask else None)
     g = M.DiscreteGroupCostFunction(ctx, S, simmeasure=sim, lambda_=0.2, percentile=percentile)
     og = O.Group(S, simmeasure=sim, lambda_=0.2, percentile=percentile)
@@ -66,6 +66,22 @@ def test_group_structure_and_patches(ctx):
         oids, odata = og.patch(s, v, l)
         assert np.array_equal(ids, oids)
         assert np.allclose(data, odata, rtol=1e-10, atol=1e-11)
+
+
+def test_group_with_68_labels(ctx):
+    """A finer sampling grid than the reference's 19 labels (68 per control point): the set-up's label-batched launches, the range test's clusters of 32 centres
+    (a control point's labels no longer fit one cluster of 64), patches, pair costs and a label step against the oracle."""
+    g, og, _ = build(ctx, S=2, data_order=4, cp_order=2, label_order_offset=3)
+    assert g.L == og.L == 68
+    rng = np.random.default_rng(5)
+    for s, v, l in zip(rng.integers(0, 2, 30), rng.integers(0, 162, 30), rng.integers(0, g.L, 30)):
+        ids, data = g.patch(s, v, l)
+        oids, odata = og.patch(s, v, l)
+        assert np.array_equal(ids, oids)
+        assert np.allclose(data, odata, rtol=1e-10, atol=1e-11)
+    n = 400
+    p, la, lb = rng.integers(0, g.P, n).astype(np.int32), rng.integers(0, g.L, n).astype(np.int32), rng.integers(0, g.L, n).astype(np.int32)
+    assert np.allclose(g.computePairwiseCost(p, la, lb), og.pairwise_batch(p, la, lb), rtol=RTOL, atol=ATOL, equal_nan=True)
 
 
 def test_group_subjects_on_different_data_meshes(ctx):
